@@ -1,0 +1,367 @@
+"""ORACLE - test infrastructure, never part of the product path.
+
+CPU restatement (torch CPU ops, fp32) of the reference's pocket-conditioned
+denoising path: noise schedule, EGNN denoiser, DDPM ancestral sampler.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this file.  The product (``cmd-gen_amd/``) never does: it fails
+loudly when the HIP library is missing.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function
+here against fixtures under ``tests/golden/`` that were produced by importing
+the real reference (``/root/reference/DiffPhar``) in the build container with
+``tests/golden/make_golden.py`` (script committed next to the vectors).
+
+Op order follows the reference's eager sequence on purpose (same ``cat`` then
+``addmm`` shapes, same association in the posterior mean, the N_total x N_total
+edge build, the per-step host-visible checks) so that (a) results agree with the
+reference to fp32 round-off and (b) its wall-clock is a fair stand-in for the
+reference's CPU path (``cpu_baseline.kind = "port"``).
+
+Each function cites the reference lines it restates (paths relative to
+``/root/reference/DiffPhar``).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+FLOAT = torch.float32   # constants.py:8
+INT = torch.int64       # constants.py:9
+
+
+# --------------------------------------------------------------------------
+# parameters
+# --------------------------------------------------------------------------
+def to_torch_params(state_dict: Dict[str, np.ndarray], prefix: str = 'ddpm.') -> Dict[str, torch.Tensor]:
+    """numpy state dict (checkpoint names) -> torch tensors keyed without prefix."""
+    out = {}
+    for k, v in state_dict.items():
+        kk = k[len(prefix):] if k.startswith(prefix) else k
+        out[kk] = torch.as_tensor(np.asarray(v)).to(FLOAT) if not torch.is_tensor(v) else v.detach().to(FLOAT).cpu()
+    return out
+
+
+def _lin(p, name, x):
+    """nn.Linear: y = x W^T + b  (weight layout [out, in])."""
+    return F.linear(x, p[name + '.weight'], p.get(name + '.bias'))
+
+
+# --------------------------------------------------------------------------
+# scatter helpers (torch_scatter==2.0.9 semantics along dim 0)
+# --------------------------------------------------------------------------
+def scatter_add(src: torch.Tensor, index: torch.Tensor, dim_size: Optional[int] = None) -> torch.Tensor:
+    n = int(index.max()) + 1 if dim_size is None else dim_size
+    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+    return out.index_add_(0, index, src)
+
+
+def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim_size: Optional[int] = None) -> torch.Tensor:
+    n = int(index.max()) + 1 if dim_size is None else dim_size
+    tot = scatter_add(src, index, n)
+    cnt = torch.zeros(n, dtype=src.dtype).index_add_(0, index, torch.ones(len(index), dtype=src.dtype))
+    cnt = cnt.clamp(min=1)
+    return tot / cnt.view((-1,) + (1,) * (src.dim() - 1))
+
+
+# --------------------------------------------------------------------------
+# noise schedule  (en_diffusion.py:1119-1188)
+# --------------------------------------------------------------------------
+def gamma_table(noise_schedule: str, timesteps: int, precision: float) -> torch.Tensor:
+    """polynomial_schedule :1135-1149 + clip_noise_schedule :1119-1132 +
+    PredefinedNoiseSchedule.__init__ :1157-1184 (float64 numpy -> fp32)."""
+    splits = noise_schedule.split('_')
+    assert len(splits) == 2 and splits[0] == 'polynomial'
+    power = float(splits[1])
+    steps = timesteps + 1
+    x = np.linspace(0, steps, steps)
+    alphas2 = (1 - np.power(x / steps, power)) ** 2
+    alphas2 = np.concatenate([np.ones(1), alphas2], axis=0)
+    step = np.clip(alphas2[1:] / alphas2[:-1], a_min=0.001, a_max=1.)
+    alphas2 = np.cumprod(step, axis=0)
+    alphas2 = (1 - 2 * precision) * alphas2 + precision
+    sigmas2 = 1 - alphas2
+    gamma = -(np.log(alphas2) - np.log(sigmas2))
+    return torch.from_numpy(gamma).float()
+
+
+def gamma_lookup(table: torch.Tensor, t: torch.Tensor, T: int) -> torch.Tensor:
+    """PredefinedNoiseSchedule.forward :1186-1188."""
+    return table[torch.round(t * T).long()]
+
+
+def sigma_and_alpha_t_given_s(gamma_t, gamma_s):
+    """en_diffusion.py:79-103 (inflate_batch_array is a no-op for [B,1] vs 2-D targets)."""
+    sigma2_t_given_s = -torch.expm1(F.softplus(gamma_s) - F.softplus(gamma_t))
+    log_alpha2_t = F.logsigmoid(-gamma_t)
+    log_alpha2_s = F.logsigmoid(-gamma_s)
+    alpha_t_given_s = torch.exp(0.5 * (log_alpha2_t - log_alpha2_s))
+    sigma_t_given_s = torch.sqrt(sigma2_t_given_s)
+    return sigma2_t_given_s, sigma_t_given_s, alpha_t_given_s
+
+
+def sigma_of(gamma):   # en_diffusion.py:859-862
+    return torch.sqrt(torch.sigmoid(gamma))
+
+
+def alpha_of(gamma):   # en_diffusion.py:864-867
+    return torch.sqrt(torch.sigmoid(-gamma))
+
+
+# --------------------------------------------------------------------------
+# EGNN  (egnn_new.py)
+# --------------------------------------------------------------------------
+def coord2diff(x, row, col, norm_constant=1.0):
+    """egnn_new.py:265-271."""
+    coord_diff = x[row] - x[col]
+    radial = torch.sum(coord_diff ** 2, 1).unsqueeze(1)
+    norm = torch.sqrt(radial + 1e-8)
+    coord_diff = coord_diff / (norm + norm_constant)
+    return radial, coord_diff
+
+
+def segment_sum(data, segment_ids, num_segments, normalization_factor, aggregation_method):
+    """unsorted_segment_sum, egnn_new.py:276-292 (scatter_add_ in edge order)."""
+    result = data.new_full((num_segments, data.size(1)), 0)
+    idx = segment_ids.unsqueeze(-1).expand(-1, data.size(1))
+    result.scatter_add_(0, idx, data)
+    if aggregation_method == 'sum':
+        result = result / normalization_factor
+    if aggregation_method == 'mean':
+        norm = data.new_zeros(result.shape)
+        norm.scatter_add_(0, idx, data.new_ones(data.shape))
+        norm[norm == 0] = 1
+        result = result / norm
+    return result
+
+
+def get_edges(batch_mask, x, edge_cutoff):
+    """EGNNDynamics.get_edges, dynamics.py:141-147: same sample AND cdist<=cutoff,
+    N_total x N_total, row-major order, self loops kept (quirks Q1, Q2)."""
+    adj = batch_mask[:, None] == batch_mask[None, :]
+    if edge_cutoff is not None:
+        adj = adj & (torch.cdist(x, x) <= edge_cutoff)
+    row, col = torch.where(adj)
+    return row, col
+
+
+def egnn_forward(p, cfg, h, x, row, col, update_coords_mask, trace: Optional[dict] = None):
+    """EGNN.forward egnn_new.py:193-208 with EquivariantBlock :141-156,
+    GCL :31-66 and EquivariantUpdate :87-112 inlined per block."""
+    pre = 'dynamics.egnn.'
+    nf, agg_m = cfg['normalization_factor'], cfg['aggregation_method']
+    d0, _ = coord2diff(x, row, col)                       # :195, default norm_constant (Q4)
+    h = _lin(p, pre + 'embedding', h)                     # :198
+    for b in range(cfg['n_layers']):
+        bp = f'{pre}e_block_{b}.'
+        radial, coord_diff = coord2diff(x, row, col, cfg['norm_constant'])   # :143
+        edge_attr = torch.cat([radial, d0], dim=1)                           # :146
+        for g in range(cfg['inv_sublayers']):
+            gp = f'{bp}gcl_{g}.'
+            inp = torch.cat([h[row], h[col], edge_attr], dim=1)              # :35
+            mij = F.silu(_lin(p, gp + 'edge_mlp.2', F.silu(_lin(p, gp + 'edge_mlp.0', inp))))
+            if cfg['attention']:
+                att = torch.sigmoid(_lin(p, gp + 'att_mlp.0', mij))          # :26-29, :38-40
+                edge_feat = mij * att
+            else:
+                edge_feat = mij
+            agg = segment_sum(edge_feat, row, h.size(0), nf, agg_m)           # :50-52
+            node_in = torch.cat([h, agg], dim=1)                              # :56
+            h = h + _lin(p, gp + 'node_mlp.2', F.silu(_lin(p, gp + 'node_mlp.0', node_in)))  # :57
+            if trace is not None:
+                trace.setdefault('mij', []).append(mij)
+                trace.setdefault('edge_feat', []).append(edge_feat)
+                trace.setdefault('agg', []).append(agg)
+        cp = bp + 'gcl_equiv.'
+        inp = torch.cat([h[row], h[col], edge_attr], dim=1)                   # :89
+        phi = _lin(p, cp + 'coord_mlp.4', F.silu(_lin(p, cp + 'coord_mlp.2',
+                   F.silu(_lin(p, cp + 'coord_mlp.0', inp)))))
+        if cfg['tanh']:
+            trans = coord_diff * torch.tanh(phi) * cfg['coords_range']       # :91 (Q3: undivided 15)
+        else:
+            trans = coord_diff * phi
+        cagg = segment_sum(trans, row, x.size(0), nf, agg_m)                  # :96-98
+        if update_coords_mask is not None:
+            cagg = update_coords_mask * cagg                                  # :100-101
+        x = x + cagg                                                          # :103
+        if trace is not None:
+            trace.setdefault('trans', []).append(trans)
+            trace.setdefault('h_block', []).append(h)
+            trace.setdefault('x_block', []).append(x)
+    h = _lin(p, pre + 'embedding_out', h)                                     # :205
+    return h, x
+
+
+def dynamics_forward(p, cfg, xh_phars, xh_residues, t, mask_phars, mask_residues,
+                     trace: Optional[dict] = None):
+    """EGNNDynamics.forward, dynamics.py:75-139 (mode 'egnn_dynamics')."""
+    nd = cfg['n_dims']
+    x_phars = xh_phars[:, :nd].clone()
+    h_phars = xh_phars[:, nd:].clone()
+    x_res = xh_residues[:, :nd].clone()
+    h_res = xh_residues[:, nd:].clone()
+    d = 'dynamics.'
+    h_phars = _lin(p, d + 'phar_encoder.2', F.silu(_lin(p, d + 'phar_encoder.0', h_phars)))
+    h_res = _lin(p, d + 'residue_encoder.2', F.silu(_lin(p, d + 'residue_encoder.0', h_res)))
+    x = torch.cat((x_phars, x_res), dim=0)                    # phar rows first, :88
+    h = torch.cat((h_phars, h_res), dim=0)
+    mask = torch.cat([mask_phars, mask_residues])
+    if cfg['condition_time']:
+        if int(np.prod(t.size())) == 1:                       # Q5: scalar-time branch :93-95
+            h_time = torch.empty_like(h[:, 0:1]).fill_(t.item())
+        else:
+            h_time = t[mask]                                  # :98
+        h = torch.cat([h, h_time], dim=1)
+    row, col = get_edges(mask, x, cfg['edge_cutoff'])         # :102
+    if trace is not None:
+        trace['row'], trace['col'] = row, col
+    ucm = None if cfg['update_pocket_coords'] else torch.cat(
+        (torch.ones_like(mask_phars), torch.zeros_like(mask_residues))).unsqueeze(1)   # :105-107
+    h_final, x_final = egnn_forward(p, cfg, h, x, row, col, ucm, trace)
+    vel = x_final - x                                         # :110
+    if cfg['condition_time']:
+        h_final = h_final[:, :-1]                             # :121-123
+    nl = len(mask_phars)
+    h_fp = _lin(p, d + 'phar_decoder.2', F.silu(_lin(p, d + 'phar_decoder.0', h_final[:nl])))
+    h_fr = _lin(p, d + 'residue_decoder.2', F.silu(_lin(p, d + 'residue_decoder.0', h_final[nl:])))
+    if torch.any(torch.isnan(vel)):                           # Q6: batch-global reset :129-131
+        vel = torch.zeros_like(vel)
+    if cfg['update_pocket_coords']:                           # joint mode only :133-136
+        vel = vel - scatter_mean(vel, mask)[mask]
+    return torch.cat([vel[:nl], h_fp], dim=-1), torch.cat([vel[nl:], h_fr], dim=-1)
+
+
+# --------------------------------------------------------------------------
+# ConditionalDDPM sampler  (conditional_model.py)
+# --------------------------------------------------------------------------
+def remove_mean_batch(x_phar, x_pocket, phar_idx, pocket_idx):
+    """conditional_model.py:467-475: subtract the PHAR centre of mass from both (Q7)."""
+    mean = scatter_mean(x_phar, phar_idx)
+    return x_phar - mean[phar_idx], x_pocket - mean[pocket_idx]
+
+
+def sample_normal_zero_com(mu_phar, xh0_pocket, sigma, phar_mask, pocket_mask, eps, nd):
+    """conditional_model.py:136-156 with the Gaussian draw ``eps`` supplied by the caller."""
+    out_phar = mu_phar + sigma[phar_mask] * eps
+    xh_pocket = xh0_pocket.detach().clone()
+    a, b = remove_mean_batch(out_phar[:, :nd], xh0_pocket[:, :nd], phar_mask, pocket_mask)
+    out_phar[:, :nd], xh_pocket[:, :nd] = a, b
+    return out_phar, xh_pocket
+
+
+def assert_mean_zero_with_mask(x, node_mask, eps=1e-10):
+    """en_diffusion.py:919-924."""
+    largest = x.abs().max().item()
+    err = scatter_add(x, node_mask).abs().max().item()
+    rel = err / (largest + eps)
+    assert rel < 1e-2, f'Mean is not zero, relative_error {rel}'
+
+
+def step_coefficients(table: torch.Tensor, T: int, timesteps: int):
+    """Per-step scalars of sample_p_zs_given_zt (conditional_model.py:342-374) for
+    s = timesteps-1 .. 0, evaluated exactly as the reference does on a [1,1] batch:
+    columns (inv-free) alpha_ts, c_eps = sigma2_ts/alpha_ts/sigma_t, sigma = sigma_ts*sigma_s/sigma_t, t."""
+    rows = []
+    for s in reversed(range(timesteps)):
+        s_arr = torch.full((1, 1), fill_value=s) / timesteps        # int64 -> true divide, :429-433
+        t_arr = (torch.full((1, 1), fill_value=s) + 1) / timesteps
+        g_s, g_t = gamma_lookup(table, s_arr, T), gamma_lookup(table, t_arr, T)
+        s2, s_ts, a_ts = sigma_and_alpha_t_given_s(g_t, g_s)
+        sig_s, sig_t = sigma_of(g_s), sigma_of(g_t)
+        rows.append([a_ts.item(), (s2 / a_ts / sig_t).item(), (s_ts * sig_s / sig_t).item(), t_arr.item()])
+    return torch.tensor(rows, dtype=FLOAT)
+
+
+def sample_given_pocket(p, cfg, pocket, num_nodes_phar, timesteps=None,
+                        noise: Optional[Callable[[Tuple[int, int]], torch.Tensor]] = None,
+                        return_chain: bool = False, checks: bool = True):
+    """ConditionalDDPM.sample_given_pocket, conditional_model.py:388-465 (return_frames=1).
+
+    ``pocket`` = dict(x[Np,3], one_hot[Np,R], size[B], mask[Np]); ``noise(shape)``
+    supplies each of the T+2 Gaussian draws (default torch.randn).
+    Returns (xh_phar, xh_pocket, phar_mask, pocket_mask[, chain]).
+    """
+    T = cfg['timesteps']
+    nd, pnf = cfg['n_dims'], cfg['phar_nf']
+    nv, nb = cfg['norm_values'], cfg['norm_biases']
+    table = p['gamma.gamma']
+    timesteps = T if timesteps is None else timesteps
+    draw = noise if noise is not None else (lambda shape: torch.randn(shape))
+    n_samples = len(pocket['size'])
+    # normalize, en_diffusion.py:874-889
+    px = pocket['x'].to(FLOAT) / nv[0]
+    ph = (pocket['one_hot'].float() - nb[1]) / nv[1]
+    pmask = pocket['mask'].to(INT)
+    xh0_pocket = torch.cat([px, ph], dim=1)
+    nnp = torch.as_tensor(num_nodes_phar).to(INT)
+    phar_mask = torch.repeat_interleave(torch.arange(n_samples), nnp)      # utils.py:137-145
+    mu_x = scatter_mean(px, pmask)
+    mu_h = torch.zeros((n_samples, pnf))
+    mu_phar = torch.cat((mu_x, mu_h), dim=1)[phar_mask]
+    sigma = torch.ones_like(pocket['size']).unsqueeze(1)                   # int64 ones (Q8)
+    shape = (len(phar_mask), nd + pnf)
+    z_phar, xh_pocket = sample_normal_zero_com(mu_phar, xh0_pocket, sigma, phar_mask, pmask,
+                                               draw(shape), nd)
+    if checks:
+        assert_mean_zero_with_mask(z_phar[:, :nd], phar_mask)
+    chain = [z_phar.clone()] if return_chain else None
+    for s in reversed(range(0, timesteps)):
+        s_array = torch.full((n_samples, 1), fill_value=s)
+        t_array = s_array + 1
+        s_array = s_array / timesteps
+        t_array = t_array / timesteps
+        # sample_p_zs_given_zt :342-374
+        gamma_s = gamma_lookup(table, s_array, T)
+        gamma_t = gamma_lookup(table, t_array, T)
+        sigma2_ts, sigma_ts, alpha_ts = sigma_and_alpha_t_given_s(gamma_t, gamma_s)
+        sigma_s, sigma_t = sigma_of(gamma_s), sigma_of(gamma_t)
+        eps_t, _ = dynamics_forward(p, cfg, z_phar, xh_pocket, t_array, phar_mask, pmask)
+        mu = z_phar / alpha_ts[phar_mask] - (sigma2_ts / alpha_ts / sigma_t)[phar_mask] * eps_t
+        sig = sigma_ts * sigma_s / sigma_t
+        zt_old = z_phar
+        z_phar, xh_pocket = sample_normal_zero_com(mu, xh_pocket, sig, phar_mask, pmask, draw(shape), nd)
+        if checks:
+            assert_mean_zero_with_mask(zt_old[:, :nd], phar_mask)
+        if return_chain:
+            chain.append(z_phar.clone())
+    # sample_p_xh_given_z0 :108-131
+    t_zeros = torch.zeros((n_samples, 1))
+    gamma_0 = gamma_lookup(table, t_zeros, T)
+    sigma_x = torch.exp(-(-0.5 * gamma_0))                                 # SNR(-0.5*gamma_0)
+    net_out, _ = dynamics_forward(p, cfg, z_phar, xh_pocket, t_zeros, phar_mask, pmask)
+    sigma_0, alpha_0 = sigma_of(gamma_0), alpha_of(gamma_0)                # compute_x_pred en_diffusion.py:153-165
+    mu_x_phar = 1. / alpha_0[phar_mask] * (z_phar - sigma_0[phar_mask] * net_out)
+    xh_phar, xh_pocket = sample_normal_zero_com(mu_x_phar, xh_pocket, sigma_x, phar_mask, pmask,
+                                                draw(shape), nd)
+    x_phar = xh_phar[:, :nd] * nv[0]
+    h_phar = z_phar[:, nd:] * nv[1] + nb[1]                                # types come from z0, not xh
+    x_pocket = xh_pocket[:, :nd] * nv[0]
+    h_pocket = xh_pocket[:, nd:] * nv[1] + nb[1]
+    h_phar = F.one_hot(torch.argmax(h_phar, dim=1), pnf)
+    if checks:
+        assert_mean_zero_with_mask(x_phar, phar_mask)
+    max_cog = scatter_add(x_phar, phar_mask).abs().max().item()            # :451-457
+    if max_cog > 5e-2:
+        x_phar, x_pocket = remove_mean_batch(x_phar, x_pocket, phar_mask, pmask)
+    out_phar = torch.cat([x_phar, h_phar.to(FLOAT)], dim=1)   # written into a float frame buffer :460
+    out_pocket = torch.cat([x_pocket, h_pocket], dim=1)
+    if return_chain:
+        return out_phar, out_pocket, phar_mask, pmask, chain
+    return out_phar, out_pocket, phar_mask, pmask
+
+
+# --------------------------------------------------------------------------
+# node-count prior  (en_diffusion.py:952-1022)
+# --------------------------------------------------------------------------
+def n1_given_n2_log_prob(histogram: np.ndarray, n1: Sequence[int], n2: Sequence[int]) -> torch.Tensor:
+    """DistributionNodes.log_prob_n1_given_n2 :1010-1015 (+1e-3 smoothing :956)."""
+    hist = torch.tensor(histogram).float() + 1e-3
+    prob = hist / hist.sum()
+    out = []
+    for a, c in zip(n1, n2):
+        col = prob[:, int(c)]
+        col = col / col.sum()
+        out.append(torch.log(col[int(a)]))
+    return torch.stack(out)

@@ -1,0 +1,70 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import os
+
+import numpy as np
+import torch
+
+import cmdgen_amd  # noqa: F401  (alias shim)
+from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name)) as f:
+        return {k: f[k] for k in f.files}
+
+
+def cases_of(g):
+    return sorted({k.split('/')[0] for k in g if '/' in k})
+
+
+def cfg_from_meta(H, L, R, timesteps=500):
+    return ModelConfig(hidden_nf=int(H), n_layers=int(L), residue_nf=int(R), timesteps=timesteps)
+
+
+def masks_from_sizes(pocket_size, num_nodes_phar):
+    B = len(pocket_size)
+    return (np.repeat(np.arange(B, dtype=np.int64), num_nodes_phar),
+            np.repeat(np.arange(B, dtype=np.int64), pocket_size))
+
+
+def dynamics_case(g, name):
+    """-> cfg, numpy state dict, inputs dict for one G2 case."""
+    H, L, B, R, seed, gain1, first = [int(v) for v in g[name + '/meta']]
+    cfg = cfg_from_meta(H, L, R)
+    sd = make_state_dict(cfg, seed=seed, coord_gain=1.0 if gain1 else 1e-3)
+    pm, qm = masks_from_sizes(g[name + '/pocket_size'], g[name + '/num_nodes_phar'])
+    inp = dict(xh_phar=g[name + '/xh_phar'], xh_pocket=g[name + '/xh_pocket'], t=g[name + '/t'],
+               mask_phar=pm, mask_pocket=qm)
+    return cfg, sd, inp
+
+
+def chain_case(g, name):
+    H, L, B, R, seed, K, gain1, first = [int(v) for v in g[name + '/meta']]
+    cfg = cfg_from_meta(H, L, R)
+    sd = make_state_dict(cfg, seed=seed, coord_gain=1.0 if gain1 else 1e-3)
+    rep = 'CA' if R == 20 else 'full-atom'
+    ragged = bool(int(g[name + '/ragged']))
+    if rep == 'full-atom':
+        pb = make_pockets(B, rep, n_pocket_nodes=90, n_phar=9, first_index=first)
+    else:
+        pb = make_pockets(B, rep, ragged=ragged, n_phar=8, first_index=first)
+    return cfg, sd, pb, K
+
+
+class NoiseTape:
+    """Replays recorded Gaussian draws in order (noise-injection interface)."""
+    def __init__(self, arr):
+        self.arr, self.i = arr, 0
+
+    def __call__(self, shape):
+        out = torch.from_numpy(self.arr[self.i].copy())
+        assert tuple(out.shape) == tuple(shape)
+        self.i += 1
+        return out
+
+
+def rms(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)))

@@ -1,0 +1,103 @@
+"""CPU suite: the oracle (oracle/ref_cpu.py) against the golden vectors captured
+from the real reference (tests/golden/make_golden.py).  This is what pins the
+oracle; the GPU parity tests then compare the HIP path with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (load_golden, cases_of, dynamics_case, chain_case, NoiseTape, rms)
+from oracle import ref_cpu
+from cmdgen_amd.synthetic import gamma_table
+
+
+def test_g1_gamma_tables_bit_exact():
+    g = load_golden('g1_schedule.npz')
+    for T in (100, 500, 1000):
+        want = g[f'gamma_T{T}']
+        got = ref_cpu.gamma_table('polynomial_2', T, 1e-5).numpy()
+        assert got.dtype == np.float32 and np.array_equal(got, want)
+        # the product's own table builder must agree bit for bit too
+        assert np.array_equal(gamma_table('polynomial_2', T, 1e-5), want)
+    # spot values quoted in SURVEY.md App. A.2
+    t500 = g['gamma_T500']
+    assert abs(t500[0] + 11.5129) < 1e-3 and abs(t500[500] - 11.5113) < 1e-3
+
+
+def test_g1_step_coefficients_bit_exact():
+    g = load_golden('g1_schedule.npz')
+    table = torch.from_numpy(g['gamma_T500'])
+    for K in (5, 50, 500):
+        got = ref_cpu.step_coefficients(table, 500, K).numpy()
+        assert np.array_equal(got, g[f'coef_T500_K{K}'])
+
+
+def test_g3_edges_order_selfloops_cutoff():
+    g = load_golden('g3_edges.npz')
+    row, col = ref_cpu.get_edges(torch.from_numpy(g['mask']), torch.from_numpy(g['x']), 6.0)
+    e = np.stack([row.numpy(), col.numpy()])
+    assert np.array_equal(e, g['edges'])
+    pairs = set(map(tuple, e.T))
+    assert (0, 1) in pairs and (1, 0) in pairs          # distance exactly 6.0 is kept (<=)
+    assert (0, 2) not in pairs                          # 6.5 is not
+    assert all((i, i) in pairs for i in range(40))      # self loops (Q1)
+    assert all(g['mask'][i] == g['mask'][j] for i, j in pairs)
+    # row-major sorted
+    key = e[0].astype(np.int64) * 1000 + e[1]
+    assert np.all(np.diff(key) > 0)
+
+
+@pytest.mark.parametrize('name', cases_of(load_golden('g2_dynamics.npz')))
+def test_g2_dynamics_forward(name):
+    g = load_golden('g2_dynamics.npz')
+    cfg, sd, inp = dynamics_case(g, name)
+    p = ref_cpu.to_torch_params(sd)
+    trace = {}
+    with torch.no_grad():
+        eps_phar, eps_pocket = ref_cpu.dynamics_forward(
+            p, cfg.as_dict(), torch.from_numpy(inp['xh_phar']), torch.from_numpy(inp['xh_pocket']),
+            torch.from_numpy(inp['t']), torch.from_numpy(inp['mask_phar']),
+            torch.from_numpy(inp['mask_pocket']), trace=trace)
+    e = np.stack([trace['row'].numpy(), trace['col'].numpy()])
+    assert np.array_equal(e, g[name + '/edges'])
+    want = g[name + '/eps_phar']
+    # same aten kernels in the same order: expect (near) bit equality
+    assert np.abs(eps_phar.numpy() - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    if name + '/eps_pocket' in g:
+        assert np.abs(eps_pocket.numpy() - g[name + '/eps_pocket']).max() <= 2e-6 * max(1.0, np.abs(g[name + '/eps_pocket']).max())
+        nl = len(inp['mask_phar'])
+        for b in range(cfg.n_layers):
+            hb, xb = trace['h_block'][b].numpy(), trace['x_block'][b].numpy()
+            assert np.abs(hb[:nl] - g[name + f'/block{b}_h_phar']).max() < 2e-5
+            assert np.abs(hb[nl:nl + 16] - g[name + f'/block{b}_h_pocket_head']).max() < 2e-5
+            assert np.abs(xb[:nl] - g[name + f'/block{b}_x_phar']).max() < 2e-5
+            # pocket rows never move in conditional mode
+            assert np.array_equal(xb[nl:], inp['xh_pocket'][:, :3])
+
+
+@pytest.mark.parametrize('name', cases_of(load_golden('g4_chains.npz')))
+def test_g4_chain_with_injected_noise(name):
+    g = load_golden('g4_chains.npz')
+    cfg, sd, pb, K = chain_case(g, name)
+    p = ref_cpu.to_torch_params(sd)
+    pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot),
+              'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
+    tape = NoiseTape(g[name + '/noise'])
+    with torch.no_grad():
+        xh_phar, xh_pocket, phar_mask, _, chain = ref_cpu.sample_given_pocket(
+            p, cfg.as_dict(), pocket, pb.num_nodes_phar, timesteps=K, noise=tape, return_chain=True)
+    assert tape.i == K + 2                       # T+2 Gaussian draws per chain
+    assert np.array_equal(phar_mask.numpy(), g[name + '/phar_mask'])
+    want = g[name + '/xh_phar']
+    assert rms(xh_phar[:, :3].numpy(), want[:, :3]) < 1e-4 * max(1.0, np.abs(want[:, :3]).max())
+    assert np.array_equal(xh_phar[:, 3:].numpy(), want[:, 3:])          # one-hot types exact
+    assert rms(xh_pocket.numpy(), g[name + '/xh_pocket']) < 1e-4 * max(1.0, np.abs(g[name + '/xh_pocket']).max())
+    if name + '/z_steps' in g:
+        zs = g[name + '/z_steps']
+        for k in range(K):
+            assert np.abs(chain[k + 1].numpy() - zs[k]).max() < 1e-4 * max(1.0, np.abs(zs[k]).max())
+
+
+def test_g8_node_count_prior():
+    g = load_golden('g8_nodes.npz')
+    got = ref_cpu.n1_given_n2_log_prob(g['hist'], g['n1'], g['n2']).numpy()
+    assert np.allclose(got, g['logp'], rtol=1e-5, atol=1e-6)
