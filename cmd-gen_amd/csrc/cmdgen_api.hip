@@ -1,0 +1,612 @@
+// cmdgen_api.hip - the C ABI of libcmdgen_hip.so (include/cmdgen_hip.h): handle, weight
+// packing, workspaces, the launch sequence of one evaluation and the denoising loop
+// (eager or replayed as a hipGraph).
+#include "cmdgen_dev.h"
+#include "../../include/cmdgen_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+// launchers implemented next to the kernels
+void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket,
+                        const float* t_arr, const float4* coef, ChainState* chain, float* eps_phar,
+                        float* eps_pocket, hipStream_t s, hipEvent_t* ev);
+void cmdgen_launch_nan_fix(const EvalLaunch& a, float* eps_phar, hipStream_t s);
+void cmdgen_launch_edge_msg_only(const EvalLaunch& a, int layer, hipStream_t s);
+void cmdgen_launch_chain_init(const Layout& lay, const Dims& d, const ChainBuf& c, const float* px,
+                              const float* poh, hipStream_t s);
+void cmdgen_launch_ddpm_step(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
+                             const float* eps, hipStream_t s);
+void cmdgen_launch_chain_final(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
+                               const float* eps, float* xo, float* po, unsigned int* cog, hipStream_t s);
+
+static std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+};
+
+struct cmdgen_handle {
+    cmdgen_config cfg{};
+    int device = 0;
+    std::string err;
+    Dims dims{};
+    // weights
+    std::map<std::string, std::vector<float>> staged;
+    bool finalized = false;
+    std::vector<void*> weight_allocs;
+    std::vector<LayerW> layers;
+    SmallW small{};
+    std::vector<float> gamma;              // host copy of the table [T+1]
+    // layout + workspace
+    bool have_layout = false;
+    std::vector<int64_t> cur_nphar, cur_npocket;
+    std::vector<void*> layout_allocs;
+    Layout lay{};
+    Work work{};
+    int64_t ecap = 0, eccap = 0;
+    int edge_grid = 512;
+    int64_t* d_gid = nullptr;
+    // chain
+    std::vector<void*> chain_allocs;
+    ChainBuf chain{};
+    int chain_K = -1;
+    bool chain_steps_out = false;
+    unsigned int* d_cog = nullptr;
+    std::vector<float> user_coef;          // optional host-supplied step table
+    int user_coef_K = -1;
+    hipGraphExec_t step_graph = nullptr;
+    hipStream_t own_stream = nullptr;      // used when the caller's stream is the legacy default stream (not capturable)
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    const float* graph_noise = nullptr; float* graph_zsteps = nullptr; hipStream_t graph_stream = nullptr;
+    unsigned long long graph_seed = 0;
+};
+
+static int fail(cmdgen_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+#define HIPCHK(h, call) do { hipError_t _e = (call); if (_e != hipSuccess) \
+    return fail(h, CMDGEN_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+
+static int dev_alloc(cmdgen_handle* h, std::vector<void*>& pool, void** out, size_t bytes, bool zero) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) return fail(h, CMDGEN_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    pool.push_back(*out);
+    if (zero) { e = hipMemset(*out, 0, bytes); if (e != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemset failed"); }
+    return 0;
+}
+static void free_pool(std::vector<void*>& pool) { for (void* p : pool) hipFree(p); pool.clear(); }
+
+extern "C" const char* cmdgen_version(void) { return "cmdgen_hip 0.1 (gfx950)"; }
+
+extern "C" const char* cmdgen_last_error(const cmdgen_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle** out) {
+    if (!cfg || !out) return fail(nullptr, CMDGEN_EINVAL, "null argument");
+    const int H = cfg->hidden_nf;
+    if (!(H == 64 || H == 128 || H == 256))
+        return fail(nullptr, CMDGEN_EINVAL, "hidden_nf=%d unsupported: the gfx950 kernels tile 64 columns per wave (64, 128 or 256)", H);
+    if (cfg->inv_sublayers != 1) return fail(nullptr, CMDGEN_EINVAL, "inv_sublayers=%d unsupported (shipped configs use 1)", cfg->inv_sublayers);
+    if (cfg->n_layers < 1 || cfg->n_layers > CMDGEN_MAX_LAYERS) return fail(nullptr, CMDGEN_EINVAL, "n_layers out of range");
+    if (cfg->phar_nf < 1 || 2 * cfg->phar_nf > CMDGEN_MAX_SMALL || cfg->residue_nf < 1 ||
+        2 * cfg->residue_nf > CMDGEN_MAX_SMALL || cfg->joint_nf < 1 || cfg->joint_nf + 1 > CMDGEN_MAX_SMALL)
+        return fail(nullptr, CMDGEN_EINVAL, "feature sizes exceed the small-MLP bound %d", CMDGEN_MAX_SMALL);
+    if (cfg->timesteps < 1) return fail(nullptr, CMDGEN_EINVAL, "timesteps < 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(nullptr, CMDGEN_EHIP, "no usable HIP device %d (found %d)", device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, CMDGEN_EHIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, CMDGEN_EINVAL, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, CMDGEN_EHIP, "hipSetDevice failed");
+    cmdgen_handle* h = new cmdgen_handle();
+    h->cfg = *cfg; h->device = device;
+    Dims& d = h->dims;
+    d.P = cfg->phar_nf; d.R = cfg->residue_nf; d.J = cfg->joint_nf; d.H = H; d.L = cfg->n_layers;
+    d.condition_time = cfg->condition_time ? 1 : 0; d.dyn = d.J + d.condition_time;
+    d.attention = cfg->attention ? 1 : 0; d.use_tanh = cfg->tanh ? 1 : 0;
+    d.cutoff2 = cfg->edge_cutoff < 0.f ? -1.f : cfg->edge_cutoff * cfg->edge_cutoff;
+    d.norm_constant = cfg->norm_constant; d.norm_factor = cfg->normalization_factor; d.coords_range = cfg->coords_range;
+    d.norm_x = cfg->norm_x; d.norm_h = cfg->norm_h; d.bias_h = cfg->bias_h;
+    h->edge_grid = 2 * prop.multiProcessorCount;      // two 66 KB-LDS workgroups per CU
+    *out = h;
+    return CMDGEN_OK;
+}
+
+extern "C" void cmdgen_destroy(cmdgen_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->step_graph) hipGraphExecDestroy(h->step_graph);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    if (h->ev_in) hipEventDestroy(h->ev_in);
+    if (h->ev_out) hipEventDestroy(h->ev_out);
+    free_pool(h->weight_allocs); free_pool(h->layout_allocs); free_pool(h->chain_allocs);
+    delete h;
+}
+
+// ---------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------
+extern "C" int cmdgen_load_weights(cmdgen_handle* h, const char* name, const float* host, size_t n) {
+    if (!h || !name || !host) return fail(h, CMDGEN_EINVAL, "null argument");
+    h->staged[name].assign(host, host + n);
+    h->finalized = false;
+    return CMDGEN_OK;
+}
+
+static int get_w(cmdgen_handle* h, const std::string& name, size_t n, const std::vector<float>** out) {
+    auto it = h->staged.find(name);
+    if (it == h->staged.end()) return fail(h, CMDGEN_ESTATE, "missing tensor '%s'", name.c_str());
+    if (it->second.size() != n) return fail(h, CMDGEN_EINVAL, "tensor '%s' has %zu values, expected %zu", name.c_str(), it->second.size(), n);
+    *out = &it->second;
+    return 0;
+}
+
+static int upload(cmdgen_handle* h, const std::vector<float>& v, const float** dev) {
+    void* p; int rc = dev_alloc(h, h->weight_allocs, &p, v.size() * sizeof(float), false);
+    if (rc) return rc;
+    if (hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemcpy H2D failed");
+    *dev = (const float*)p;
+    return 0;
+}
+
+// W[out][ld] rows, columns [c0, c0+in) -> MFMA fragment order (see cmdgen_dev.h)
+static std::vector<float> pack_frag(const float* W, int out, int ld, int c0, int in) {
+    const int NT = out / 32, KB = in / 8;
+    std::vector<float> p((size_t)NT * KB * 64 * 4);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j)
+                    p[(((size_t)nt * KB + kb) * 64 + lane) * 4 + j] =
+                        W[(size_t)(32 * nt + (lane & 31)) * ld + c0 + 8 * kb + 4 * (lane >> 5) + j];
+    return p;
+}
+
+extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
+    if (!h) return CMDGEN_EINVAL;
+    hipSetDevice(h->device);
+    if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+    free_pool(h->weight_allocs);
+    h->layers.clear();
+    const Dims& d = h->dims;
+    const int H = d.H, T = h->cfg.timesteps;
+    const std::vector<float>* v; int rc;
+#define GET(name, n) do { rc = get_w(h, name, (size_t)(n), &v); if (rc) return rc; } while (0)
+#define UP(dst) do { rc = upload(h, *v, &(dst)); if (rc) return rc; } while (0)
+    GET("gamma.gamma", T + 1); h->gamma = *v;
+    const std::string dy = "dynamics.";
+    SmallW& s = h->small;
+    GET(dy + "phar_encoder.0.weight", 2 * d.P * d.P); UP(s.pe0_w); GET(dy + "phar_encoder.0.bias", 2 * d.P); UP(s.pe0_b);
+    GET(dy + "phar_encoder.2.weight", d.J * 2 * d.P); UP(s.pe2_w); GET(dy + "phar_encoder.2.bias", d.J); UP(s.pe2_b);
+    GET(dy + "phar_decoder.0.weight", 2 * d.P * d.J); UP(s.pd0_w); GET(dy + "phar_decoder.0.bias", 2 * d.P); UP(s.pd0_b);
+    GET(dy + "phar_decoder.2.weight", d.P * 2 * d.P); UP(s.pd2_w); GET(dy + "phar_decoder.2.bias", d.P); UP(s.pd2_b);
+    GET(dy + "residue_encoder.0.weight", 2 * d.R * d.R); UP(s.re0_w); GET(dy + "residue_encoder.0.bias", 2 * d.R); UP(s.re0_b);
+    GET(dy + "residue_encoder.2.weight", d.J * 2 * d.R); UP(s.re2_w); GET(dy + "residue_encoder.2.bias", d.J); UP(s.re2_b);
+    GET(dy + "residue_decoder.0.weight", 2 * d.R * d.J); UP(s.rd0_w); GET(dy + "residue_decoder.0.bias", 2 * d.R); UP(s.rd0_b);
+    GET(dy + "residue_decoder.2.weight", d.R * 2 * d.R); UP(s.rd2_w); GET(dy + "residue_decoder.2.bias", d.R); UP(s.rd2_b);
+    GET(dy + "egnn.embedding.weight", H * d.dyn); UP(s.emb_w); GET(dy + "egnn.embedding.bias", H); UP(s.emb_b);
+    {   // embedding_out [dyn][H] -> transposed [H][dyn]
+        GET(dy + "egnn.embedding_out.weight", d.dyn * H);
+        std::vector<float> t((size_t)H * d.dyn);
+        for (int j = 0; j < d.dyn; ++j) for (int k = 0; k < H; ++k) t[(size_t)k * d.dyn + j] = (*v)[(size_t)j * H + k];
+        rc = upload(h, t, &s.embo_wT); if (rc) return rc;
+        GET(dy + "egnn.embedding_out.bias", d.dyn); UP(s.embo_b);
+    }
+    const int ld1 = 2 * H + 2;
+    for (int b = 0; b < d.L; ++b) {
+        LayerW lw{};
+        const std::string g = dy + "egnn.e_block_" + std::to_string(b) + ".gcl_0.";
+        const std::string c = dy + "egnn.e_block_" + std::to_string(b) + ".gcl_equiv.";
+        auto split_first = [&](const std::string& wname, const std::string& bname, const float4** Wpq,
+                               const float** bias, const float** wr, const float** wd) -> int {
+            const std::vector<float>* w; int r = get_w(h, wname, (size_t)H * ld1, &w); if (r) return r;
+            // stack [A ; B] as a [2H][H] matrix: rows 0..H-1 = columns 0..H-1 (h_row), rows H.. = columns H..2H-1 (h_col)
+            std::vector<float> AB((size_t)2 * H * H);
+            std::vector<float> vr(H), vd(H);
+            for (int o = 0; o < H; ++o) {
+                for (int k = 0; k < H; ++k) {
+                    AB[(size_t)o * H + k] = (*w)[(size_t)o * ld1 + k];
+                    AB[(size_t)(H + o) * H + k] = (*w)[(size_t)o * ld1 + H + k];
+                }
+                vr[o] = (*w)[(size_t)o * ld1 + 2 * H]; vd[o] = (*w)[(size_t)o * ld1 + 2 * H + 1];
+            }
+            std::vector<float> p = pack_frag(AB.data(), 2 * H, H, 0, H);
+            const float* dp; r = upload(h, p, &dp); if (r) return r; *Wpq = (const float4*)dp;
+            r = upload(h, vr, wr); if (r) return r; r = upload(h, vd, wd); if (r) return r;
+            const std::vector<float>* bb; r = get_w(h, bname, H, &bb); if (r) return r;
+            return upload(h, *bb, bias);
+        };
+        auto square = [&](const std::string& wname, int in, const float4** Wp) -> int {
+            const std::vector<float>* w; int r = get_w(h, wname, (size_t)H * in, &w); if (r) return r;
+            std::vector<float> p = pack_frag(w->data(), H, in, 0, in);
+            const float* dp; r = upload(h, p, &dp); if (r) return r; *Wp = (const float4*)dp; return 0;
+        };
+        rc = split_first(g + "edge_mlp.0.weight", g + "edge_mlp.0.bias", &lw.Wpq_e, &lw.b1, &lw.wr_e, &lw.wd_e); if (rc) return rc;
+        rc = square(g + "edge_mlp.2.weight", H, &lw.W2); if (rc) return rc;
+        GET(g + "edge_mlp.2.bias", H); UP(lw.b2);
+        if (d.attention) {
+            GET(g + "att_mlp.0.weight", H); UP(lw.wa);
+            GET(g + "att_mlp.0.bias", 1); lw.ba = (*v)[0];
+        } else { lw.wa = lw.b2; lw.ba = 0.f; }
+        rc = square(g + "node_mlp.0.weight", 2 * H, &lw.W3); if (rc) return rc;
+        GET(g + "node_mlp.0.bias", H); UP(lw.b3);
+        rc = square(g + "node_mlp.2.weight", H, &lw.W4); if (rc) return rc;
+        GET(g + "node_mlp.2.bias", H); UP(lw.b4);
+        rc = split_first(c + "coord_mlp.0.weight", c + "coord_mlp.0.bias", &lw.Wpq_c, &lw.b6, &lw.wr_c, &lw.wd_c); if (rc) return rc;
+        rc = square(c + "coord_mlp.2.weight", H, &lw.W7); if (rc) return rc;
+        GET(c + "coord_mlp.2.bias", H); UP(lw.b7);
+        GET(c + "coord_mlp.4.weight", H); UP(lw.w5);
+        h->layers.push_back(lw);
+    }
+#undef GET
+#undef UP
+    h->finalized = true;
+    return CMDGEN_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// layout
+// ---------------------------------------------------------------------------------
+extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t* nph, const int64_t* npk) {
+    if (!h || batch < 1 || !nph || !npk) return fail(h, CMDGEN_EINVAL, "bad layout arguments");
+    if (h->have_layout && (int64_t)h->cur_nphar.size() == batch &&
+        memcmp(h->cur_nphar.data(), nph, batch * sizeof(int64_t)) == 0 &&
+        memcmp(h->cur_npocket.data(), npk, batch * sizeof(int64_t)) == 0)
+        return CMDGEN_OK;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+    free_pool(h->layout_allocs); free_pool(h->chain_allocs); h->chain_K = -1;
+    h->have_layout = false;
+    const Dims& d = h->dims;
+    const int B = (int)batch;
+    std::vector<int> vph(B), vpk(B), bph(B), bpk(B);
+    int64_t Nl = 0, Np = 0, ecap = 0, eccap = 0; int max_n = 0;
+    for (int b = 0; b < B; ++b) {
+        if (nph[b] < 0 || npk[b] < 0) return fail(h, CMDGEN_EINVAL, "negative node count");
+        vph[b] = (int)nph[b]; vpk[b] = (int)npk[b]; bph[b] = (int)Nl; bpk[b] = (int)Np;
+        Nl += nph[b]; Np += npk[b];
+        const int64_t n = nph[b] + npk[b];
+        ecap += n * n; eccap += nph[b] * n;           // dense bound per sample: never overflows
+        if (n > max_n) max_n = (int)n;
+    }
+    const int64_t N = Nl + Np;
+    if (N < 1 || ecap > (int64_t)2000000000) return fail(h, CMDGEN_EINVAL, "batch too large for int32 edge indexing (dense bound %lld)", (long long)ecap);
+    if ((size_t)max_n * 20 > 150 * 1024) return fail(h, CMDGEN_EINVAL, "a sample has %d nodes; the per-sample neighbour search keeps positions in LDS (max ~7600)", max_n);
+    std::vector<int> ns(N);
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < vph[b]; ++i) ns[bph[b] + i] = b;
+        for (int i = 0; i < vpk[b]; ++i) ns[Nl + bpk[b] + i] = b;
+    }
+    int rc; void* p;
+    Layout& L = h->lay; Work& w = h->work;
+    L.B = B; L.Nl = (int)Nl; L.Np = (int)Np; L.N = (int)N; L.max_n = max_n;
+#define ALLOC_I(dst, vec) do { rc = dev_alloc(h, h->layout_allocs, &p, (vec).size() * sizeof(int), false); if (rc) return rc; \
+        HIPCHK(h, hipMemcpy(p, (vec).data(), (vec).size() * sizeof(int), hipMemcpyHostToDevice)); dst = (const int*)p; } while (0)
+    ALLOC_I(L.num_phar, vph); ALLOC_I(L.num_pocket, vpk); ALLOC_I(L.phar_base, bph); ALLOC_I(L.pocket_base, bpk);
+    ALLOC_I(L.node_sample, ns);
+#undef ALLOC_I
+    std::vector<int64_t> gid(B); for (int b = 0; b < B; ++b) gid[b] = b;
+    rc = dev_alloc(h, h->layout_allocs, &p, B * sizeof(int64_t), false); if (rc) return rc;
+    HIPCHK(h, hipMemcpy(p, gid.data(), B * sizeof(int64_t), hipMemcpyHostToDevice));
+    h->d_gid = (int64_t*)p; L.pocket_gid = h->d_gid;
+    const size_t H = d.H;
+#define ALLOC(dst, type, count, zero) do { rc = dev_alloc(h, h->layout_allocs, &p, (size_t)(count) * sizeof(type), zero); if (rc) return rc; dst = (type*)p; } while (0)
+    ALLOC(w.X0, float4, Nl, true); ALLOC(w.XP, float4, Np, true);
+    ALLOC(w.XL, float4, (size_t)d.L * Nl, true); ALLOC(w.ACC, float4, (size_t)d.L * Nl, true);
+    ALLOC(w.h, float, N * H, true); ALLOC(w.P, float, N * H, true); ALLOC(w.Q, float, N * H, true);
+    ALLOC(w.Pc, float, N * H, true); ALLOC(w.Qc, float, N * H, true); ALLOC(w.agg, float, N * H, true);
+    ALLOC(w.degL, int, N, true); ALLOC(w.pocketE, int, B, true); ALLOC(w.pocketEph, int, B, true);
+    ALLOC(w.erow, int, ecap, false); ALLOC(w.ecol, int, ecap, false); ALLOC(w.ed0, float, ecap, false);
+    ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true);
+    ALLOC(w.eps_tmp, float, (size_t)Nl * (3 + d.P), true);
+#undef ALLOC
+    h->ecap = ecap; h->eccap = eccap;
+    h->cur_nphar.assign(nph, nph + B); h->cur_npocket.assign(npk, npk + B);
+    h->have_layout = true;
+    return CMDGEN_OK;
+}
+
+static int check_ready(cmdgen_handle* h) {
+    if (!h) return CMDGEN_EINVAL;
+    if (!h->finalized) return fail(h, CMDGEN_ESTATE, "weights not finalised (cmdgen_finalize_weights)");
+    if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
+    return 0;
+}
+
+static EvalLaunch make_launch(cmdgen_handle* h) {
+    EvalLaunch a; a.lay = h->lay; a.w = h->work; a.d = h->dims; a.sw = h->small; a.layers = h->layers.data();
+    a.edge_grid = h->edge_grid;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------
+// one evaluation
+// ---------------------------------------------------------------------------------
+extern "C" int cmdgen_dynamics_forward(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket,
+                                       const float* t, float* eps_phar, float* eps_pocket, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!xh_phar || !xh_pocket || !t || !eps_phar) return fail(h, CMDGEN_EINVAL, "null device pointer");
+    hipSetDevice(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    EvalLaunch a = make_launch(h);
+    cmdgen_launch_eval(a, xh_phar, xh_pocket, t, nullptr, nullptr, eps_phar, eps_pocket, s, nullptr);
+    cmdgen_launch_nan_fix(a, eps_phar, s);
+    HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_get_edges(cmdgen_handle* h, int32_t* row, int32_t* col, int64_t cap, int64_t* n_edges, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    hipSetDevice(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipStreamSynchronize(s));
+    int tot[2];
+    HIPCHK(h, hipMemcpy(tot, h->work.totals, sizeof tot, hipMemcpyDeviceToHost));
+    if (n_edges) *n_edges = tot[0];
+    const int64_t n = tot[0] < cap ? tot[0] : cap;
+    if (n > 0 && row) HIPCHK(h, hipMemcpy(row, h->work.erow, n * sizeof(int), hipMemcpyDeviceToHost));
+    if (n > 0 && col) HIPCHK(h, hipMemcpy(col, h->work.ecol, n * sizeof(int), hipMemcpyDeviceToHost));
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_debug_read(cmdgen_handle* h, const char* what, float* host, size_t n, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    const void* src = nullptr; size_t have = 0;
+    const std::string k = what ? what : "";
+    const Dims& d = h->dims;
+    if (k == "h") { src = h->work.h; have = (size_t)h->lay.N * d.H; }
+    else if (k == "agg") { src = h->work.agg; have = (size_t)h->lay.N * d.H; }
+    else if (k == "P") { src = h->work.P; have = (size_t)h->lay.N * d.H; }
+    else if (k == "Q") { src = h->work.Q; have = (size_t)h->lay.N * d.H; }
+    else if (k == "x0") { src = h->work.X0; have = (size_t)h->lay.Nl * 4; }
+    else if (k == "xl") { src = h->work.XL; have = (size_t)d.L * h->lay.Nl * 4; }
+    else if (k == "acc") { src = h->work.ACC; have = (size_t)d.L * h->lay.Nl * 4; }
+    else return fail(h, CMDGEN_EINVAL, "unknown debug buffer '%s'", k.c_str());
+    if (n > have) n = have;
+    HIPCHK(h, hipMemcpy(host, src, n * sizeof(float), hipMemcpyDeviceToHost));
+    return CMDGEN_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// schedule: per-step scalars of sample_p_zs_given_zt, fp32 in the reference's op order
+// (en_diffusion.py:79-103, :859-867; conditional_model.py:345-366, :429-433)
+// ---------------------------------------------------------------------------------
+static inline float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }          // F.softplus, threshold 20
+static inline float logsigmoid_f(float x) { return -softplus_f(-x); }
+static inline float sigmoid_h(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+static void build_step_table(const std::vector<float>& gamma, int T, int K, std::vector<float>& coef) {
+    coef.assign((size_t)(K + 1) * 4, 0.f);
+    for (int i = 0; i < K; ++i) {
+        const int s = K - 1 - i;
+        const float s_arr = (float)s / (float)K, t_arr = (float)(s + 1) / (float)K;
+        const float g_s = gamma[(size_t)lrintf(s_arr * (float)T)], g_t = gamma[(size_t)lrintf(t_arr * (float)T)];
+        const float sigma2_ts = -expm1f(softplus_f(g_s) - softplus_f(g_t));
+        const float alpha_ts = expf(0.5f * (logsigmoid_f(-g_t) - logsigmoid_f(-g_s)));
+        const float sigma_ts = sqrtf(sigma2_ts);
+        const float sigma_s = sqrtf(sigmoid_h(g_s)), sigma_t = sqrtf(sigmoid_h(g_t));
+        coef[i * 4 + 0] = alpha_ts;
+        coef[i * 4 + 1] = sigma2_ts / alpha_ts / sigma_t;
+        coef[i * 4 + 2] = sigma_ts * sigma_s / sigma_t;
+        coef[i * 4 + 3] = t_arr;
+    }
+    const float g0 = gamma[0];
+    coef[K * 4 + 0] = sqrtf(sigmoid_h(g0));          // sigma_0
+    coef[K * 4 + 1] = sqrtf(sigmoid_h(-g0));         // alpha_0
+    coef[K * 4 + 2] = expf(0.5f * g0);               // SNR(-gamma_0/2)
+    coef[K * 4 + 3] = 0.f;                           // t of the final evaluation
+}
+
+// Optional: the host supplies the table ([K+1][4], same meaning) computed with its own fp32
+// math so that it matches the reference's torch ops bit for bit.
+extern "C" int cmdgen_set_step_table(cmdgen_handle* h, int32_t K, const float* coef_host) {
+    if (!h || K < 1 || !coef_host) return fail(h, CMDGEN_EINVAL, "bad step table");
+    h->user_coef.assign(coef_host, coef_host + (size_t)(K + 1) * 4);
+    h->user_coef_K = K;
+    h->chain_K = -1;
+    return CMDGEN_OK;
+}
+
+static int prepare_chain(cmdgen_handle* h, int K, bool want_steps) {
+    if (h->chain_K == K) return 0;
+    hipDeviceSynchronize();
+    if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+    free_pool(h->chain_allocs);
+    const Dims& d = h->dims;
+    void* p; int rc;
+    std::vector<float> coef;
+    if (h->user_coef_K == K) coef = h->user_coef; else build_step_table(h->gamma, h->cfg.timesteps, K, coef);
+    rc = dev_alloc(h, h->chain_allocs, &p, coef.size() * sizeof(float), false); if (rc) return rc;
+    HIPCHK(h, hipMemcpy(p, coef.data(), coef.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->chain.coef = (const float4*)p;
+    rc = dev_alloc(h, h->chain_allocs, &p, (size_t)h->lay.Nl * (3 + d.P) * sizeof(float), true); if (rc) return rc; h->chain.z_phar = (float*)p;
+    rc = dev_alloc(h, h->chain_allocs, &p, (size_t)h->lay.Np * (3 + d.R) * sizeof(float), true); if (rc) return rc; h->chain.xh_pocket = (float*)p;
+    rc = dev_alloc(h, h->chain_allocs, &p, (size_t)(K + 3) * 2 * sizeof(unsigned int), true); if (rc) return rc; h->chain.check = (unsigned int*)p;
+    rc = dev_alloc(h, h->chain_allocs, &p, sizeof(ChainState), true); if (rc) return rc; h->chain.state = (ChainState*)p;
+    rc = dev_alloc(h, h->chain_allocs, &p, 4 * sizeof(unsigned int), true); if (rc) return rc; h->d_cog = (unsigned int*)p;
+    h->chain_K = K;
+    (void)want_steps;
+    return 0;
+}
+
+extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, const float* pocket_onehot,
+                                   int32_t timesteps, const float* noise, uint64_t seed,
+                                   const int64_t* pocket_ids_host, float* xh_phar_out, float* xh_pocket_out,
+                                   float* z_steps_out, int32_t use_graph, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!pocket_x || !pocket_onehot || !xh_phar_out || !xh_pocket_out) return fail(h, CMDGEN_EINVAL, "null device pointer");
+    const int K = timesteps;
+    if (K < 1 || K > h->cfg.timesteps) return fail(h, CMDGEN_EINVAL, "timesteps=%d must be in [1, %d]", K, h->cfg.timesteps);
+    hipSetDevice(h->device);
+    hipStream_t caller = (hipStream_t)stream;
+    hipStream_t s = caller;
+    if (use_graph && caller == nullptr) {
+        // the legacy default stream cannot be captured: run the chain on a stream of our own,
+        // ordered after the caller's pending work and before its later work by events
+        if (!h->own_stream) {
+            HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+        }
+        HIPCHK(h, hipEventRecord(h->ev_in, caller));
+        HIPCHK(h, hipStreamWaitEvent(h->own_stream, h->ev_in, 0));
+        s = h->own_stream;
+    }
+    rc = prepare_chain(h, K, z_steps_out != nullptr); if (rc) return rc;
+    const Dims& d = h->dims;
+    // global pocket ids for the Philox key
+    {
+        std::vector<int64_t> gid(h->lay.B);
+        for (int b = 0; b < h->lay.B; ++b) gid[b] = pocket_ids_host ? pocket_ids_host[b] : b;
+        HIPCHK(h, hipMemcpyAsync(h->d_gid, gid.data(), gid.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipStreamSynchronize(s));          // gid is a stack vector
+    }
+    ChainBuf c = h->chain;
+    c.noise = noise; c.seed = seed; c.z_steps = z_steps_out;
+    const ChainState st0{-1, K, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(c.state, &st0, sizeof st0, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemsetAsync(c.check, 0, (size_t)(K + 3) * 2 * sizeof(unsigned int), s));
+    HIPCHK(h, hipMemsetAsync(h->d_cog, 0, 4 * sizeof(unsigned int), s));
+    HIPCHK(h, hipStreamSynchronize(s));              // st0 is on the stack
+    EvalLaunch a = make_launch(h);
+    cmdgen_launch_chain_init(h->lay, d, c, pocket_x, pocket_onehot, s);
+    auto one_step = [&](hipStream_t ss) {
+        cmdgen_launch_eval(a, c.z_phar, c.xh_pocket, nullptr, c.coef, c.state, h->work.eps_tmp, nullptr, ss, nullptr);
+        cmdgen_launch_ddpm_step(h->lay, d, c, h->work, h->work.eps_tmp, ss);
+    };
+    if (use_graph) {
+        // The step is identical every iteration (the step index lives on the device), so it is
+        // captured once per (layout, K, noise/z_steps pointers, stream) and replayed K times.
+        if (h->step_graph && (h->graph_noise != noise || h->graph_zsteps != z_steps_out || h->graph_stream != s || h->graph_seed != seed)) {
+            hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr;
+        }
+        if (!h->step_graph) {
+            hipGraph_t g = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            one_step(s);
+            HIPCHK(h, hipStreamEndCapture(s, &g));
+            HIPCHK(h, hipGraphInstantiate(&h->step_graph, g, nullptr, nullptr, 0));
+            hipGraphDestroy(g);
+            h->graph_noise = noise; h->graph_zsteps = z_steps_out; h->graph_stream = s; h->graph_seed = seed;
+        }
+        for (int i = 0; i < K; ++i) HIPCHK(h, hipGraphLaunch(h->step_graph, s));
+    } else {
+        for (int i = 0; i < K; ++i) one_step(s);
+    }
+    // final p(x, h | z0): one more evaluation at t = 0 (coef[K].w), then decode
+    cmdgen_launch_eval(a, c.z_phar, c.xh_pocket, nullptr, c.coef, c.state, h->work.eps_tmp, nullptr, s, nullptr);
+    cmdgen_launch_chain_final(h->lay, d, c, h->work, h->work.eps_tmp, xh_phar_out, xh_pocket_out, h->d_cog, s);
+    HIPCHK(h, hipGetLastError());
+    if (s != caller) {
+        HIPCHK(h, hipEventRecord(h->ev_out, s));
+        HIPCHK(h, hipStreamWaitEvent(caller, h->ev_out, 0));
+    }
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_chain_status(cmdgen_handle* h, float* max_rel, float* max_cog, int64_t* nan_resets, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (h->chain_K < 0) return fail(h, CMDGEN_ESTATE, "no chain has run");
+    hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    const int K = h->chain_K;
+    std::vector<unsigned int> chk((size_t)(K + 3) * 2);
+    HIPCHK(h, hipMemcpy(chk.data(), h->chain.check, chk.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    float worst = 0.f;
+    for (int i = 0; i < K + 2; ++i) {
+        float largest, err;
+        memcpy(&largest, &chk[2 * i], 4); memcpy(&err, &chk[2 * i + 1], 4);
+        const float rel = err / (largest + 1e-10f);
+        if (rel > worst) worst = rel;
+    }
+    if (max_rel) *max_rel = worst;
+    unsigned int cog; HIPCHK(h, hipMemcpy(&cog, h->d_cog, 4, hipMemcpyDeviceToHost));
+    if (max_cog) memcpy(max_cog, &cog, 4);
+    unsigned long long cnt[8];
+    HIPCHK(h, hipMemcpy(cnt, h->work.counters, sizeof cnt, hipMemcpyDeviceToHost));
+    if (nan_resets) *nan_resets = (int64_t)cnt[4];
+    return CMDGEN_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------------
+extern "C" int cmdgen_get_counters(cmdgen_handle* h, cmdgen_counters* out, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long cnt[8];
+    HIPCHK(h, hipMemcpy(cnt, h->work.counters, sizeof cnt, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->evaluations = cnt[0]; out->edges = cnt[1]; out->edges_phar = cnt[2]; out->nodes = cnt[3]; out->nan_resets = cnt[4];
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_reset_counters(cmdgen_handle* h, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    hipSetDevice(h->device);
+    HIPCHK(h, hipMemsetAsync(h->work.counters, 0, 8 * sizeof(unsigned long long), (hipStream_t)stream));
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket, const float* t,
+                                         float* eps_phar, cmdgen_kernel_times* out, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!out) return fail(h, CMDGEN_EINVAL, "null output");
+    hipSetDevice(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int L = h->dims.L;
+    const int nev = 2 * (3 + 3 * L);
+    std::vector<hipEvent_t> ev(nev);
+    for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
+    EvalLaunch a = make_launch(h);
+    cmdgen_launch_eval(a, xh_phar, xh_pocket, t, nullptr, nullptr, eps_phar, nullptr, s, ev.data());
+    cmdgen_launch_nan_fix(a, eps_phar, s);
+    HIPCHK(h, hipStreamSynchronize(s));
+    memset(out, 0, sizeof *out);
+    auto ms = [&](int i) { float m = 0.f; hipEventElapsedTime(&m, ev[2 * i], ev[2 * i + 1]); return m; };
+    int i = 0;
+    out->edge_build_ms = ms(i++); out->embed_ms = ms(i++);
+    for (int l = 0; l < L; ++l) {
+        out->edge_msg_ms += ms(i++); out->node_ms += ms(i++); out->edge_coord_ms += ms(i++);
+    }
+    out->readout_ms = ms(i++);
+    out->edge_msg_launches = L; out->node_launches = L; out->edge_coord_launches = L;
+    for (auto& e : ev) hipEventDestroy(e);
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_time_edge_kernel(cmdgen_handle* h, int32_t layer, int32_t reps, float* mean_ms, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (layer < 0 || layer >= h->dims.L || reps < 1 || !mean_ms) return fail(h, CMDGEN_EINVAL, "bad arguments");
+    hipSetDevice(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    EvalLaunch a = make_launch(h);
+    cmdgen_launch_edge_msg_only(a, layer, s);                       // warm
+    HIPCHK(h, hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) cmdgen_launch_edge_msg_only(a, layer, s);
+    HIPCHK(h, hipEventRecord(e1, s));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    *mean_ms = ms / (float)reps;
+    // the replays accumulated into agg; restore the invariant "agg is zero between blocks"
+    HIPCHK(h, hipMemsetAsync(h->work.agg, 0, (size_t)h->lay.N * h->dims.H * sizeof(float), s));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return CMDGEN_OK;
+}

@@ -1,0 +1,202 @@
+// kernels_ddpm.hip - the ancestral-sampling arithmetic around the network evaluation:
+// ConditionalDDPM.sample_given_pocket (conditional_model.py:388-465).  One wave per sample;
+// sums that the reference forms with scatter_add/scatter_mean in index order are formed in
+// the same order here (a lane walks the sample's nodes) so results agree to the last bit
+// given the same inputs.
+#include "cmdgen_dev.h"
+
+__device__ __forceinline__ float draw(const ChainBuf& c, const Layout& lay, int draw_idx, int b,
+                                      int local, int node, int comp, int ld) {
+    if (c.noise) return c.noise[((size_t)draw_idx * lay.Nl + node) * ld + comp];
+    float z[4];
+    philox_normal4(c.seed, (uint32_t)lay.pocket_gid[b], (uint32_t)(lay.pocket_gid[b] >> 32),
+                   (uint32_t)draw_idx, (uint32_t)(local * 4 + (comp >> 2)), z);
+    return z[comp & 3];
+}
+
+// subtract the phar centre of mass from phar and pocket coordinates of sample b
+// (remove_mean_batch, conditional_model.py:467-475); returns nothing, works in place.
+__device__ __forceinline__ void remove_com(float* zx, int ld, int pb, int nl, float* px, int ldq,
+                                           int qb, int np, int lane) {
+    float mean = 0.f;
+    if (lane < 3) {
+        float s = 0.f;
+        for (int i = 0; i < nl; ++i) s += zx[(size_t)(pb + i) * ld + lane];   // index order, as index_add_
+        mean = s / fmaxf((float)nl, 1.0f);
+    }
+    const float m0 = __shfl(mean, 0), m1 = __shfl(mean, 1), m2 = __shfl(mean, 2);
+    for (int i = lane; i < nl; i += 64) {
+        float* p = zx + (size_t)(pb + i) * ld;
+        p[0] -= m0; p[1] -= m1; p[2] -= m2;
+    }
+    for (int i = lane; i < np; i += 64) {
+        float* p = px + (size_t)(qb + i) * ldq;
+        p[0] -= m0; p[1] -= m1; p[2] -= m2;
+    }
+}
+
+__device__ __forceinline__ void atomic_max_pos(unsigned int* slot, float v) {
+    atomicMax(slot, __float_as_uint(fabsf(v)));     // non-negative floats order like their bits
+}
+
+// records the two maxima assert_mean_zero_with_mask compares (en_diffusion.py:919-924)
+__device__ __forceinline__ void record_com_check(unsigned int* slot2, const float* zx, int ld, int pb,
+                                                 int nl, float scale, int lane) {
+    float mx = 0.f;
+    for (int i = lane; i < nl; i += 64) {
+        const float* p = zx + (size_t)(pb + i) * ld;
+        mx = fmaxf(mx, fmaxf(fabsf(p[0] * scale), fmaxf(fabsf(p[1] * scale), fabsf(p[2] * scale))));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float s = 0.f;
+    if (lane < 3) for (int i = 0; i < nl; ++i) s += zx[(size_t)(pb + i) * ld + lane] * scale;
+    s = fabsf(s);
+    s = fmaxf(s, fmaxf(__shfl(s, 1), __shfl(s, 2)));
+    if (lane == 0) { atomic_max_pos(slot2, mx); atomic_max_pos(slot2 + 1, s); }
+}
+
+// z_T = [pocket COM, 0] + noise, then COM projection (conditional_model.py:402-420)
+__global__ __launch_bounds__(64) void k_chain_init(Layout lay, Dims d, ChainBuf c,
+                                                   const float* __restrict__ pocket_x,
+                                                   const float* __restrict__ pocket_onehot) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int nl = lay.num_phar[b], np = lay.num_pocket[b];
+    const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
+    const int ld = 3 + d.P, ldq = 3 + d.R;
+    // normalize (en_diffusion.py:874-889)
+    for (int i = lane; i < np; i += 64) {
+        float* o = c.xh_pocket + (size_t)(qb + i) * ldq;
+        for (int k = 0; k < 3; ++k) o[k] = pocket_x[(size_t)(qb + i) * 3 + k] / d.norm_x;
+        for (int k = 0; k < d.R; ++k) o[3 + k] = (pocket_onehot[(size_t)(qb + i) * d.R + k] - d.bias_h) / d.norm_h;
+    }
+    __syncthreads();
+    float mu = 0.f;
+    if (lane < 3) {
+        float s = 0.f;
+        for (int i = 0; i < np; ++i) s += c.xh_pocket[(size_t)(qb + i) * ldq + lane];
+        mu = s / fmaxf((float)np, 1.0f);
+    }
+    const float m0 = __shfl(mu, 0), m1 = __shfl(mu, 1), m2 = __shfl(mu, 2);
+    for (int idx = lane; idx < nl * ld; idx += 64) {
+        const int i = idx / ld, k = idx % ld;
+        const float m = k == 0 ? m0 : k == 1 ? m1 : k == 2 ? m2 : 0.f;
+        c.z_phar[(size_t)(pb + i) * ld + k] = m + 1.0f * draw(c, lay, 0, b, i, pb + i, k, ld);
+    }
+    __syncthreads();
+    remove_com(c.z_phar, ld, pb, nl, c.xh_pocket, ldq, qb, np, lane);
+    __syncthreads();
+    record_com_check(c.check, c.z_phar, ld, pb, nl, 1.0f, lane);
+}
+
+// one posterior step z_t -> z_s (sample_p_zs_given_zt, conditional_model.py:342-374)
+__global__ __launch_bounds__(64) void k_ddpm_step(Layout lay, Dims d, ChainBuf c, Work w,
+                                                  const float* __restrict__ eps) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int nl = lay.num_phar[b], np = lay.num_pocket[b];
+    const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
+    const int ld = 3 + d.P, ldq = 3 + d.R;
+    const int step = c.state->step;                 // 0-based index of this posterior step
+    const float4 cf = c.coef[step];
+    const bool nan_reset = *w.nan_flag != 0;
+    // the reference checks z_t (the step's input) after the update; same numbers, recorded first
+    record_com_check(c.check + 2 * (1 + step), c.z_phar, ld, pb, nl, 1.0f, lane);
+    __syncthreads();
+    for (int idx = lane; idx < nl * ld; idx += 64) {
+        const int i = idx / ld, k = idx % ld;
+        const size_t o = (size_t)(pb + i) * ld + k;
+        float e = eps[o];
+        if (nan_reset && k < 3) e = 0.f;
+        const float mu = c.z_phar[o] / cf.x - cf.y * e;
+        c.z_phar[o] = mu + cf.z * draw(c, lay, 1 + step, b, i, pb + i, k, ld);
+    }
+    __syncthreads();
+    remove_com(c.z_phar, ld, pb, nl, c.xh_pocket, ldq, qb, np, lane);
+    __syncthreads();
+    if (c.z_steps)
+        for (int idx = lane; idx < nl * ld; idx += 64) {
+            const size_t o = (size_t)pb * ld + idx;
+            c.z_steps[(size_t)step * lay.Nl * ld + o] = c.z_phar[o];
+        }
+    if (b == 0 && lane == 0 && nan_reset) atomicAdd(&w.counters[4], 1ull);
+}
+
+// p(x, h | z_0): sample_p_xh_given_z0 (conditional_model.py:108-131) + unnormalize + one-hot
+__global__ __launch_bounds__(64) void k_chain_final(Layout lay, Dims d, ChainBuf c, Work w,
+                                                    const float* __restrict__ eps,
+                                                    float* __restrict__ xh_phar_out,
+                                                    float* __restrict__ xh_pocket_out,
+                                                    unsigned int* cog_slot) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int nl = lay.num_phar[b], np = lay.num_pocket[b];
+    const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
+    const int ld = 3 + d.P, ldq = 3 + d.R;
+    const int K = c.state->K;
+    const float4 cf = c.coef[K];                    // (sigma_0, alpha_0, sigma_x = exp(gamma_0/2), 0)
+    const bool nan_reset = *w.nan_flag != 0;
+    // types come from z_0 itself (not from the sampled xh): argmax of the un-normalised h
+    for (int i = lane; i < nl; i += 64) {
+        const float* z = c.z_phar + (size_t)(pb + i) * ld;
+        int best = 0; float bv = z[3] * d.norm_h + d.bias_h;
+        for (int k = 1; k < d.P; ++k) { const float v = z[3 + k] * d.norm_h + d.bias_h; if (v > bv) { bv = v; best = k; } }
+        float* o = xh_phar_out + (size_t)(pb + i) * ld;
+        for (int k = 0; k < d.P; ++k) o[3 + k] = (k == best) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    // mu_x = 1/alpha_0 * (z_0 - sigma_0 * eps)  (compute_x_pred, en_diffusion.py:153-165); + sigma_x * noise
+    for (int idx = lane; idx < nl * ld; idx += 64) {
+        const int i = idx / ld, k = idx % ld;
+        const size_t o = (size_t)(pb + i) * ld + k;
+        float e = eps[o];
+        if (nan_reset && k < 3) e = 0.f;
+        const float mu = (1.0f / cf.y) * (c.z_phar[o] - cf.x * e);
+        c.z_phar[o] = mu + cf.z * draw(c, lay, 1 + K, b, i, pb + i, k, ld);
+    }
+    __syncthreads();
+    remove_com(c.z_phar, ld, pb, nl, c.xh_pocket, ldq, qb, np, lane);
+    __syncthreads();
+    // unnormalize (en_diffusion.py:891-895)
+    for (int i = lane; i < nl; i += 64) {
+        const float* z = c.z_phar + (size_t)(pb + i) * ld;
+        float* o = xh_phar_out + (size_t)(pb + i) * ld;
+        o[0] = z[0] * d.norm_x; o[1] = z[1] * d.norm_x; o[2] = z[2] * d.norm_x;
+    }
+    for (int i = lane; i < np; i += 64) {
+        const float* q = c.xh_pocket + (size_t)(qb + i) * ldq;
+        float* o = xh_pocket_out + (size_t)(qb + i) * ldq;
+        o[0] = q[0] * d.norm_x; o[1] = q[1] * d.norm_x; o[2] = q[2] * d.norm_x;
+        for (int k = 0; k < d.R; ++k) o[3 + k] = q[3 + k] * d.norm_h + d.bias_h;
+    }
+    __syncthreads();
+    record_com_check(c.check + 2 * (1 + K), xh_phar_out, ld, pb, nl, 1.0f, lane);
+    // CoG drift of the un-normalised coordinates (conditional_model.py:451-452)
+    float s = 0.f;
+    if (lane < 3) for (int i = 0; i < nl; ++i) s += xh_phar_out[(size_t)(pb + i) * ld + lane];
+    s = fabsf(s);
+    s = fmaxf(s, fmaxf(__shfl(s, 1), __shfl(s, 2)));
+    if (lane == 0) atomic_max_pos(cog_slot, s);
+    if (b == 0 && lane == 0 && nan_reset) atomicAdd(&w.counters[4], 1ull);
+}
+
+// if the batch-wide max drift exceeds 5e-2 every sample is re-centred (conditional_model.py:453-457)
+__global__ __launch_bounds__(64) void k_chain_drift_fix(Layout lay, Dims d, float* __restrict__ xh_phar_out,
+                                                        float* __restrict__ xh_pocket_out,
+                                                        const unsigned int* cog_slot) {
+    if (__uint_as_float(*cog_slot) <= 5e-2f) return;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    remove_com(xh_phar_out, 3 + d.P, lay.phar_base[b], lay.num_phar[b], xh_pocket_out, 3 + d.R,
+               lay.pocket_base[b], lay.num_pocket[b], lane);
+}
+
+void cmdgen_launch_chain_init(const Layout& lay, const Dims& d, const ChainBuf& c, const float* px,
+                              const float* poh, hipStream_t s) {
+    hipLaunchKernelGGL(k_chain_init, dim3(lay.B), dim3(64), 0, s, lay, d, c, px, poh);
+}
+void cmdgen_launch_ddpm_step(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
+                             const float* eps, hipStream_t s) {
+    hipLaunchKernelGGL(k_ddpm_step, dim3(lay.B), dim3(64), 0, s, lay, d, c, w, eps);
+}
+void cmdgen_launch_chain_final(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
+                               const float* eps, float* xo, float* po, unsigned int* cog, hipStream_t s) {
+    hipLaunchKernelGGL(k_chain_final, dim3(lay.B), dim3(64), 0, s, lay, d, c, w, eps, xo, po, cog);
+    hipLaunchKernelGGL(k_chain_drift_fix, dim3(lay.B), dim3(64), 0, s, lay, d, xo, po, (const unsigned int*)cog);
+}

@@ -1,0 +1,652 @@
+// kernels_egnn.hip - one EGNNDynamics.forward (dynamics.py:75-139) as gfx950 kernels.
+//
+// Launch sequence of one evaluation (host side: cmdgen_api.hip, launch_evaluation):
+//   k_edge_count   radius graph, pass 1: degrees per receiver      (dynamics.py:141-147)
+//   k_edge_write   pass 2: compact (row, col, d0) lists sorted like torch.where
+//   k_embed        encoders + time column + embedding + P/Q of block 0
+//   per block l:   k_edge_msg   GCL.edge_model + segment sum          (egnn_new.py:31-52)
+//                  k_node       GCL.node_model, then P/Q for the coord MLP and block l+1
+//                  k_edge_coord EquivariantUpdate.coord_model          (egnn_new.py:87-104)
+//   k_readout      embedding_out, decoders, velocity, NaN flag       (dynamics.py:110-139)
+//
+// Tiling: a workgroup owns 64 rows (edges or nodes) and all H output columns; wave w owns
+// columns [64w, 64w+64) as 2x2 MFMA 32x32 tiles, so the block has H/64 waves.  The A
+// operand (rows x H) lives in LDS with a 4-float row pad (conflict-free ds_read_b128);
+// the B operand (weights) streams from L2 in MFMA fragment order (cmdgen_dev.h).
+#include "cmdgen_dev.h"
+
+#define LDA(H) ((H) + 4)
+
+// ------------------------------------------------------------------------------------
+// Radius graph.  One workgroup per sample; a wave scans the candidate senders of one
+// receiver at a time, so neighbours come out in ascending sender order and ballots give
+// both the degree and the compaction offsets.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int flat_node(int i, int nl, int pb, int qb, int Nl) {
+    return i < nl ? pb + i : Nl + qb + (i - nl);
+}
+
+__global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict__ xh_phar,
+                             const float* __restrict__ xh_pocket, ChainState* chain) {
+    extern __shared__ float4 spos[];            // [max_n] positions, then int sdeg[max_n]
+    int* sdeg = reinterpret_cast<int*>(spos + lay.max_n);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nl = lay.num_phar[b], np = lay.num_pocket[b], n = nl + np;
+    const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
+    const int ldp = 3 + d.P, ldq = 3 + d.R;
+    for (int i = tid; i < n; i += blockDim.x) {
+        float4 p;
+        if (i < nl) {
+            const float* s = xh_phar + (size_t)(pb + i) * ldp;
+            p = make_float4(s[0], s[1], s[2], 0.f);
+            w.X0[pb + i] = p;
+            for (int l = 0; l < d.L; ++l) w.ACC[(size_t)l * lay.Nl + pb + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const float* s = xh_pocket + (size_t)(qb + i - nl) * ldq;
+            p = make_float4(s[0], s[1], s[2], 0.f);
+            w.XP[qb + i - nl] = p;
+        }
+        spos[i] = p;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    for (int i = wave; i < n; i += nwaves) {
+        const float4 pi = spos[i];
+        int cnt = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            bool ok = false;
+            if (j < n) {
+                const float r2 = dist2(pi, spos[j]);
+                ok = (d.cutoff2 < 0.f) || (r2 <= d.cutoff2);
+            }
+            cnt += __popcll(__ballot(ok));
+        }
+        if (lane == 0) { sdeg[i] = cnt; w.degL[pb + qb + i] = cnt; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int e = 0, eph = 0;
+        for (int i = lane; i < n; i += 64) { const int dg = sdeg[i]; e += dg; if (i < nl) eph += dg; }
+        for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o); eph += __shfl_xor(eph, o); }
+        if (lane == 0) { w.pocketE[b] = e; w.pocketEph[b] = eph; }
+    }
+    if (b == 0 && tid == 0) {
+        if (chain) chain->step += 1;
+        *w.nan_flag = 0;
+        atomicAdd(&w.counters[0], 1ull);                       // evaluations
+        atomicAdd(&w.counters[3], (unsigned long long)lay.N);  // nodes
+    }
+}
+
+__global__ void k_edge_write(Layout lay, Work w, Dims d) {
+    extern __shared__ float4 spos[];
+    int* soff = reinterpret_cast<int*>(spos + lay.max_n);
+    __shared__ int s_base[3];
+    __shared__ int s_red[3][16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nl = lay.num_phar[b], np = lay.num_pocket[b], n = nl + np;
+    const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
+    const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    for (int i = tid; i < n; i += blockDim.x) spos[i] = i < nl ? w.X0[pb + i] : w.XP[qb + i - nl];
+    // The compact list is ordered like torch.where on the N x N adjacency of the flat node
+    // numbering (dynamics.py:146): all phar receivers first (sample by sample), then all pocket
+    // receivers.  So the phar-receiver edges - the only ones the coordinate update needs - are
+    // the first Ec entries of the same list.
+    int e = 0, eph = 0, ephall = 0;
+    for (int k = tid; k < lay.B; k += blockDim.x) {
+        const int pe = w.pocketE[k], pp = w.pocketEph[k];
+        ephall += pp;
+        if (k < b) { e += pe; eph += pp; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o); eph += __shfl_xor(eph, o); ephall += __shfl_xor(ephall, o); }
+    if (lane == 0) { s_red[0][wave] = e; s_red[1][wave] = eph; s_red[2][wave] = ephall; }
+    __syncthreads();
+    if (tid == 0) {
+        int te = 0, tp = 0, ta = 0;
+        for (int k = 0; k < nwaves; ++k) { te += s_red[0][k]; tp += s_red[1][k]; ta += s_red[2][k]; }
+        s_base[0] = tp;                     // phar-receiver section: edges of earlier samples' phar rows
+        s_base[1] = ta + (te - tp);         // pocket-receiver section starts after ALL phar-receiver edges
+        s_base[2] = ta;
+    }
+    // exclusive scan of the degrees inside the sample (wave 0, 64 at a time)
+    if (wave == 0) {
+        int carry = 0;
+        for (int c = 0; c < n; c += 64) {
+            const int i = c + lane;
+            const int v = i < n ? w.degL[pb + qb + i] : 0;
+            int s = v;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(s, o); if (lane >= o) s += t; }
+            if (i < n) soff[i] = carry + s - v;
+            carry += __shfl(s, 63);
+        }
+    }
+    __syncthreads();
+    const int eph_b = w.pocketEph[b];
+    for (int i = wave; i < n; i += nwaves) {
+        const float4 pi = spos[i];
+        const int gi = flat_node(i, nl, pb, qb, lay.Nl);
+        int off = i < nl ? s_base[0] + soff[i] : s_base[1] + (soff[i] - eph_b);
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            bool ok = false; float r2 = 0.f;
+            if (j < n) {
+                r2 = dist2(pi, spos[j]);
+                ok = (d.cutoff2 < 0.f) || (r2 <= d.cutoff2);
+            }
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+                w.erow[pos] = gi; w.ecol[pos] = flat_node(j, nl, pb, qb, lay.Nl); w.ed0[pos] = r2;
+            }
+            off += __popcll(m);
+        }
+    }
+    if (b == lay.B - 1 && tid == 0) {
+        const int E = s_base[1] + (w.pocketE[b] - eph_b), Ec = s_base[2];
+        w.totals[0] = E; w.totals[1] = Ec;
+        atomicAdd(&w.counters[1], (unsigned long long)E);
+        atomicAdd(&w.counters[2], (unsigned long long)Ec);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// shared pieces of the tile kernels
+// ------------------------------------------------------------------------------------
+// out[row][col] = acc + bias (bias may be null) for rows < nvalid; two 128-byte segments
+// per store instruction (lanes 0-31 one row, 32-63 another).
+template <int H>
+__device__ __forceinline__ void store_acc_rows(f32x16 (&acc)[2][2], int wave, float* __restrict__ out,
+                                               int row0, int nvalid, const float* __restrict__ bias) {
+    CMDGEN_ACC_FOREACH(wave, {
+        if (row < nvalid) out[(size_t)(row0 + row) * H + col] = v + (bias ? bias[col] : 0.f);
+    })
+}
+
+// P|Q = BUF x Wpq^T for a 64-row tile already resident in LDS: two passes of H columns.
+template <int H>
+__device__ __forceinline__ void tile_project_pq(const float* buf, const float4* __restrict__ Wpq,
+                                                const float* __restrict__ bias_p, float* __restrict__ Pout,
+                                                float* __restrict__ Qout, int row0, int nvalid,
+                                                bool want_p) {
+    const int wave = threadIdx.x >> 6;
+    f32x16 acc[2][2];
+    if (want_p) {
+        acc_zero(acc);
+        mfma_tile_64x64<H / 8>(buf, LDA(H), Wpq, H / 8, 0, 2 * wave, acc);
+        store_acc_rows<H>(acc, wave, Pout, row0, nvalid, bias_p);
+    }
+    acc_zero(acc);
+    mfma_tile_64x64<H / 8>(buf, LDA(H), Wpq, H / 8, 0, H / 32 + 2 * wave, acc);
+    store_acc_rows<H>(acc, wave, Qout, row0, nvalid, nullptr);
+}
+
+// ------------------------------------------------------------------------------------
+// k_embed: h0 = embedding([encoder(features) | t]) for a 64-node tile, then P/Q of block 0.
+// Encoders are tiny (8->16->32, R->2R->32): plain FMA loops through LDS.
+// ------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW sw, LayerW lw0,
+                                             const float* __restrict__ xh_phar,
+                                             const float* __restrict__ xh_pocket,
+                                             const float* __restrict__ t_arr,
+                                             const float4* __restrict__ coef, const ChainState* chain) {
+    __shared__ __attribute__((aligned(16))) float buf[CMDGEN_TILE * LDA(H)];
+    __shared__ float s_in[CMDGEN_TILE][CMDGEN_MAX_SMALL];
+    __shared__ float s_h1[CMDGEN_TILE][CMDGEN_MAX_SMALL];
+    __shared__ float s_h2[CMDGEN_TILE][CMDGEN_MAX_SMALL + 1];
+    const int tid = threadIdx.x, nthr = H;
+    const int row0 = blockIdx.x * CMDGEN_TILE;
+    const int nvalid = min(CMDGEN_TILE, lay.N - row0);
+    const int ldp = 3 + d.P, ldq = 3 + d.R;
+    const int Fmax = max(d.P, d.R), F1max = 2 * Fmax;
+    // stage input features
+    for (int idx = tid; idx < CMDGEN_TILE * Fmax; idx += nthr) {
+        const int r = idx / Fmax, k = idx % Fmax;
+        const int n = row0 + r;
+        float v = 0.f;
+        if (r < nvalid) {
+            if (n < lay.Nl) { if (k < d.P) v = xh_phar[(size_t)n * ldp + 3 + k]; }
+            else if (k < d.R) v = xh_pocket[(size_t)(n - lay.Nl) * ldq + 3 + k];
+        }
+        s_in[r][k] = v;
+    }
+    __syncthreads();
+    // encoder layer 0 + SiLU
+    for (int idx = tid; idx < CMDGEN_TILE * F1max; idx += nthr) {
+        const int r = idx / F1max, o = idx % F1max;
+        const int n = row0 + r;
+        if (r >= nvalid) continue;
+        const bool ph = n < lay.Nl;
+        const int F = ph ? d.P : d.R;
+        if (o >= 2 * F) continue;
+        const float* W = (ph ? sw.pe0_w : sw.re0_w) + (size_t)o * F;
+        float s = (ph ? sw.pe0_b : sw.re0_b)[o];
+        for (int k = 0; k < F; ++k) s = fmaf(s_in[r][k], W[k], s);
+        s_h1[r][o] = silu_f(s);
+    }
+    __syncthreads();
+    // encoder layer 2 -> joint space, then the time column (dynamics.py:92-99)
+    for (int idx = tid; idx < CMDGEN_TILE * d.dyn; idx += nthr) {
+        const int r = idx / d.dyn, j = idx % d.dyn;
+        const int n = row0 + r;
+        float s = 0.f;
+        if (r < nvalid) {
+            if (j < d.J) {
+                const bool ph = n < lay.Nl;
+                const int F2 = 2 * (ph ? d.P : d.R);
+                const float* W = (ph ? sw.pe2_w : sw.re2_w) + (size_t)j * F2;
+                s = (ph ? sw.pe2_b : sw.re2_b)[j];
+                for (int k = 0; k < F2; ++k) s = fmaf(s_h1[r][k], W[k], s);
+            } else {
+                s = t_arr ? t_arr[lay.node_sample[n]] : coef[chain->step].w;
+            }
+        }
+        s_h2[r][j] = s;
+    }
+    __syncthreads();
+    // embedding dyn -> H: one output column per thread
+    {
+        const int c = tid;
+        float wreg[CMDGEN_MAX_SMALL + 1];
+#pragma unroll
+        for (int k = 0; k < CMDGEN_MAX_SMALL + 1; ++k) wreg[k] = (k < d.dyn) ? sw.emb_w[(size_t)c * d.dyn + k] : 0.f;
+        const float bc = sw.emb_b[c];
+        for (int r = 0; r < CMDGEN_TILE; ++r) {
+            float s = bc;
+#pragma unroll
+            for (int k = 0; k < CMDGEN_MAX_SMALL + 1; ++k) if (k < d.dyn) s = fmaf(s_h2[r][k], wreg[k], s);
+            if (r >= nvalid) s = 0.f;
+            buf[r * LDA(H) + c] = s;
+            if (r < nvalid) w.h[(size_t)(row0 + r) * H + c] = s;
+        }
+    }
+    __syncthreads();
+    tile_project_pq<H>(buf, lw0.Wpq_e, lw0.b1, w.P, w.Q, row0, nvalid, true);
+}
+
+// ------------------------------------------------------------------------------------
+// positions: pocket rows never move (conditional mode); phar rows of block l are
+// X[l] = X[l-1] + ACC[l-1] / normalization_factor, materialised by k_node(l) and formed on
+// the fly (same expression, same bits) by k_edge_msg(l), which runs before it.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 node_pos(const Layout& lay, const Work& w, const Dims& d, int n,
+                                           int layer, bool lazy) {
+    if (n >= lay.Nl) return w.XP[n - lay.Nl];
+    if (layer == 0) return w.X0[n];
+    if (!lazy) return w.XL[(size_t)layer * lay.Nl + n];
+    const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nl + n];
+    const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nl + n];
+    return make_float4(p.x + a.x / d.norm_factor, p.y + a.y / d.norm_factor, p.z + a.z / d.norm_factor, 0.f);
+}
+
+// A-tile generation shared by the two edge kernels:
+//   a1[e][:] = SiLU(P[row_e] + Q[col_e] + w_r * radial_e + w_d * d0_e)     (b folded into P)
+// which equals SiLU(W1 [h_row | h_col | radial | d0] + b1) of egnn_new.py:33-36 / :89-93.
+template <int H>
+__device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, const int* s_col,
+                                                const float* s_r, const float* s_d0, int ne,
+                                                const float* __restrict__ P, const float* __restrict__ Q,
+                                                const float* __restrict__ wr, const float* __restrict__ wd) {
+    constexpr int LPR = H / 4;                  // lanes per row (float4 each)
+    const int c4 = threadIdx.x % LPR, rsub = threadIdx.x / LPR;   // 4 rows per pass
+    const float4 wr4 = reinterpret_cast<const float4*>(wr)[c4];
+    const float4 wd4 = reinterpret_cast<const float4*>(wd)[c4];
+#pragma unroll 4
+    for (int pass = 0; pass < CMDGEN_TILE / 4; ++pass) {
+        const int e = pass * 4 + rsub;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < ne) {
+            const float4 p = reinterpret_cast<const float4*>(P + (size_t)s_row[e] * H)[c4];
+            const float4 q = reinterpret_cast<const float4*>(Q + (size_t)s_col[e] * H)[c4];
+            const float r = s_r[e], d0 = s_d0[e];
+            a.x = silu_f(p.x + q.x + wr4.x * r + wd4.x * d0);
+            a.y = silu_f(p.y + q.y + wr4.y * r + wd4.y * d0);
+            a.z = silu_f(p.z + q.z + wr4.z * r + wd4.z * d0);
+            a.w = silu_f(p.w + q.w + wr4.w * r + wd4.w * d0);
+        }
+        *reinterpret_cast<float4*>(buf + e * LDA(H) + 4 * c4) = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_edge_msg: GCL.edge_model + attention gate + segment sum by receiver for 64-edge tiles
+// of the compact list.  Persistent-style grid: tiles are taken round-robin until the
+// device-side edge count is exhausted, so the launch geometry is static (graph-capturable).
+// ------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(H) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer) {
+    __shared__ __attribute__((aligned(16))) float buf[CMDGEN_TILE * LDA(H)];
+    __shared__ int s_row[CMDGEN_TILE], s_col[CMDGEN_TILE];
+    __shared__ float s_r[CMDGEN_TILE], s_d0[CMDGEN_TILE], s_att[CMDGEN_TILE];
+    constexpr int NW = H / 64;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int E = w.totals[0];
+    const int ntiles = (E + CMDGEN_TILE - 1) / CMDGEN_TILE;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int e0 = tile * CMDGEN_TILE;
+        const int ne = min(CMDGEN_TILE, E - e0);
+        if (tid < CMDGEN_TILE) {
+            int row = -1, col = -1; float r = 0.f, d0 = 0.f;
+            if (tid < ne) {
+                row = w.erow[e0 + tid]; col = w.ecol[e0 + tid]; d0 = w.ed0[e0 + tid];
+                r = dist2(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
+            }
+            s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
+        }
+        __syncthreads();
+        build_edge_tile<H>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, lw.wr_e, lw.wd_e);
+        __syncthreads();
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        mfma_tile_64x64<H / 8>(buf, LDA(H), lw.W2, H / 8, 0, 2 * wave, acc);
+        __syncthreads();                         // every wave is done reading the A tile
+        CMDGEN_ACC_FOREACH(wave, { buf[row * LDA(H) + col] = silu_f(v + lw.b2[col]); })   // m_ij
+        __syncthreads();
+        {   // attention gate: sigmoid(w_a . m_ij + b_a), NW threads per edge row
+            const int r = tid / NW, q = tid % NW;
+            float s = 0.f;
+            const float4* mrow = reinterpret_cast<const float4*>(buf + r * LDA(H) + q * 64);
+            const float4* wa4 = reinterpret_cast<const float4*>(lw.wa + q * 64);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float4 m = mrow[k], a = wa4[k];
+                s += m.x * a.x + m.y * a.y + m.z * a.z + m.w * a.w;
+            }
+            for (int o = 1; o < NW; o <<= 1) s += __shfl_xor(s, o);
+            if (q == 0) s_att[r] = d.attention ? sigmoid_f(s + lw.ba) : 1.0f;
+        }
+        __syncthreads();
+        {   // segment sum over the tile's rows, one column per thread, edge order preserved
+            const int c = tid;
+            int cur = s_row[0];
+            float sum = 0.f;
+            bool first = true;
+            for (int e = 0; e < ne; ++e) {
+                const int rr = s_row[e];
+                if (rr != cur) {
+                    float* dst = w.agg + (size_t)cur * H + c;
+                    if (first) atomicAdd(dst, sum); else *dst = sum;     // a segment may continue from the previous tile
+                    first = false; cur = rr; sum = 0.f;
+                }
+                sum += buf[e * LDA(H) + c] * s_att[e];
+            }
+            atomicAdd(w.agg + (size_t)cur * H + c, sum);                 // ... or into the next one
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_node: GCL.node_model for a 64-node tile (egnn_new.py:48-58)
+//   h <- h + W4 SiLU(W3 [h | agg/nf] + b3) + b4
+// then, while the new h tile is still in LDS, the projections every later kernel of this
+// evaluation gathers: P_c|Q_c for this block's coord MLP and P|Q for block l+1's edge MLP.
+// ------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(H) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
+                                            int layer, int has_next) {
+    __shared__ __attribute__((aligned(16))) float buf[CMDGEN_TILE * LDA(H)];
+    constexpr int LPR = H / 4;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int row0 = blockIdx.x * CMDGEN_TILE;
+    const int nvalid = min(CMDGEN_TILE, lay.N - row0);
+    const int c4 = tid % LPR, rsub = tid / LPR;
+    // materialise the phar coordinates entering this block (see node_pos)
+    if (layer >= 1 && tid < CMDGEN_TILE) {
+        const int n = row0 + tid;
+        if (tid < nvalid && n < lay.Nl) w.XL[(size_t)layer * lay.Nl + n] = node_pos(lay, w, d, n, layer, true);
+    }
+    for (int pass = 0; pass < CMDGEN_TILE / 4; ++pass) {
+        const int r = pass * 4 + rsub;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nvalid) v = reinterpret_cast<const float4*>(w.h + (size_t)(row0 + r) * H)[c4];
+        *reinterpret_cast<float4*>(buf + r * LDA(H) + 4 * c4) = v;
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+    acc_zero(acc);
+    mfma_tile_64x64<H / 8>(buf, LDA(H), lw.W3, 2 * H / 8, 0, 2 * wave, acc);            // h part of [h | agg]
+    __syncthreads();
+    for (int pass = 0; pass < CMDGEN_TILE / 4; ++pass) {
+        const int r = pass * 4 + rsub;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nvalid) {
+            float4* g = reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H) + c4;
+            v = *g;
+            *g = make_float4(0.f, 0.f, 0.f, 0.f);                                         // agg is zero between blocks
+            v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
+        }
+        *reinterpret_cast<float4*>(buf + r * LDA(H) + 4 * c4) = v;
+    }
+    __syncthreads();
+    mfma_tile_64x64<H / 8>(buf, LDA(H), lw.W3, 2 * H / 8, H / 8, 2 * wave, acc);        // agg part
+    __syncthreads();
+    CMDGEN_ACC_FOREACH(wave, { buf[row * LDA(H) + col] = silu_f(v + lw.b3[col]); })
+    __syncthreads();
+    acc_zero(acc);
+    mfma_tile_64x64<H / 8>(buf, LDA(H), lw.W4, H / 8, 0, 2 * wave, acc);
+    __syncthreads();
+    CMDGEN_ACC_FOREACH(wave, {
+        float hn = 0.f;
+        if (row < nvalid) {
+            float* hp = w.h + (size_t)(row0 + row) * H + col;
+            hn = *hp + (v + lw.b4[col]);                                                  // residual (egnn_new.py:57)
+            *hp = hn;
+        }
+        buf[row * LDA(H) + col] = hn;
+    })
+    __syncthreads();
+    // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
+    tile_project_pq<H>(buf, lw.Wpq_c, lw.b6, w.Pc, w.Qc, row0, nvalid, row0 < lay.Nl);
+    if (has_next) tile_project_pq<H>(buf, lw_next.Wpq_e, lw_next.b1, w.P, w.Q, row0, nvalid, true);
+}
+
+// ------------------------------------------------------------------------------------
+// k_edge_coord: EquivariantUpdate.coord_model on the edges whose receiver is a phar node
+// (pocket rows are multiplied by update_coords_mask = 0 in the reference, egnn_new.py:100-101):
+//   phi = w5 . SiLU(W7 SiLU(W6 [h_i, h_j, r, d0] + b6) + b7)
+//   ACC[l][i] += (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant) * tanh(phi) * coords_range
+// ------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(H) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer) {
+    __shared__ __attribute__((aligned(16))) float buf[CMDGEN_TILE * LDA(H)];
+    __shared__ int s_row[CMDGEN_TILE], s_col[CMDGEN_TILE];
+    __shared__ float s_r[CMDGEN_TILE], s_d0[CMDGEN_TILE];
+    __shared__ float s_cd[CMDGEN_TILE][3], s_tr[CMDGEN_TILE][3];
+    constexpr int NW = H / 64;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int E = w.totals[1];
+    const int ntiles = (E + CMDGEN_TILE - 1) / CMDGEN_TILE;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int e0 = tile * CMDGEN_TILE;
+        const int ne = min(CMDGEN_TILE, E - e0);
+        if (tid < CMDGEN_TILE) {
+            int row = -1, col = -1; float r = 0.f, d0 = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+            if (tid < ne) {
+                row = w.erow[e0 + tid]; col = w.ecol[e0 + tid]; d0 = w.ed0[e0 + tid];   // phar-receiver prefix
+                const float4 pi = node_pos(lay, w, d, row, layer, false);
+                const float4 pj = node_pos(lay, w, d, col, layer, false);
+                cx = pi.x - pj.x; cy = pi.y - pj.y; cz = pi.z - pj.z;
+                r = cx * cx + cy * cy + cz * cz;
+                const float den = sqrtf(r + 1e-8f) + d.norm_constant;      // coord2diff, egnn_new.py:265-271
+                cx /= den; cy /= den; cz /= den;
+            }
+            s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
+            s_cd[tid][0] = cx; s_cd[tid][1] = cy; s_cd[tid][2] = cz;
+        }
+        __syncthreads();
+        build_edge_tile<H>(buf, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, lw.wr_c, lw.wd_c);
+        __syncthreads();
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        mfma_tile_64x64<H / 8>(buf, LDA(H), lw.W7, H / 8, 0, 2 * wave, acc);
+        __syncthreads();
+        CMDGEN_ACC_FOREACH(wave, { buf[row * LDA(H) + col] = silu_f(v + lw.b7[col]); })
+        __syncthreads();
+        {
+            const int r = tid / NW, q = tid % NW;
+            float s = 0.f;
+            const float4* mrow = reinterpret_cast<const float4*>(buf + r * LDA(H) + q * 64);
+            const float4* w54 = reinterpret_cast<const float4*>(lw.w5 + q * 64);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float4 m = mrow[k], a = w54[k];
+                s += m.x * a.x + m.y * a.y + m.z * a.z + m.w * a.w;
+            }
+            for (int o = 1; o < NW; o <<= 1) s += __shfl_xor(s, o);
+            if (q == 0) {
+                const float g = d.use_tanh ? tanhf(s) * d.coords_range : s;
+                s_tr[r][0] = s_cd[r][0] * g; s_tr[r][1] = s_cd[r][1] * g; s_tr[r][2] = s_cd[r][2] * g;
+            }
+        }
+        __syncthreads();
+        if (tid < 3) {   // segment sum of the three components in edge order
+            int cur = s_row[0];
+            float sum = 0.f;
+            for (int e = 0; e < ne; ++e) {
+                const int rr = s_row[e];
+                if (rr != cur) {
+                    atomicAdd(reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nl + cur) + tid, sum);
+                    cur = rr; sum = 0.f;
+                }
+                sum += s_tr[e][tid];
+            }
+            atomicAdd(reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nl + cur) + tid, sum);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_readout: embedding_out (drop the time column), decoders, velocity, NaN flag
+// (egnn_new.py:205, dynamics.py:110-131).  32 threads per node, 8 nodes per workgroup.
+// eps rows: [vel(3) | decoded features].  The batch-global NaN reset is applied by the
+// consumer (k_nan_fix or the DDPM kernels) once the flag is complete.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, SmallW sw,
+                                                 float* __restrict__ eps_phar, float* __restrict__ eps_pocket) {
+    __shared__ float s_j[8][CMDGEN_MAX_SMALL + 1];
+    __shared__ float s_h1[8][CMDGEN_MAX_SMALL];
+    const int tid = threadIdx.x, g = tid >> 5, l32 = tid & 31;
+    const int nnodes = eps_pocket ? lay.N : lay.Nl;
+    const int n = blockIdx.x * 8 + g;
+    const bool live = n < nnodes;
+    const bool ph = n < lay.Nl;
+    const int H = d.H;
+    if (live) {
+        for (int j = l32; j < d.J; j += 32) {
+            float s = sw.embo_b[j];
+            const float* hrow = w.h + (size_t)n * H;
+            for (int k = 0; k < H; ++k) s = fmaf(hrow[k], sw.embo_wT[(size_t)k * d.dyn + j], s);
+            s_j[g][j] = s;
+        }
+    }
+    __syncthreads();
+    if (live) {
+        const int F = ph ? d.P : d.R;
+        const float* W0 = ph ? sw.pd0_w : sw.rd0_w; const float* B0 = ph ? sw.pd0_b : sw.rd0_b;
+        for (int o = l32; o < 2 * F; o += 32) {
+            float s = B0[o];
+            for (int k = 0; k < d.J; ++k) s = fmaf(s_j[g][k], W0[(size_t)o * d.J + k], s);
+            s_h1[g][o] = silu_f(s);
+        }
+    }
+    __syncthreads();
+    if (live) {
+        const int F = ph ? d.P : d.R;
+        const float* W2 = ph ? sw.pd2_w : sw.rd2_w; const float* B2 = ph ? sw.pd2_b : sw.rd2_b;
+        float* out = ph ? eps_phar + (size_t)n * (3 + d.P) : eps_pocket + (size_t)(n - lay.Nl) * (3 + d.R);
+        for (int o = l32; o < F; o += 32) {
+            float s = B2[o];
+            for (int k = 0; k < 2 * F; ++k) s = fmaf(s_h1[g][k], W2[(size_t)o * 2 * F + k], s);
+            out[3 + o] = s;
+        }
+        if (l32 == 0) {
+            float vx = 0.f, vy = 0.f, vz = 0.f;
+            if (ph) {
+                // x_final = X[L-1] + ACC[L-1]/nf ; vel = x_final - x_input
+                const float4 p = (d.L == 1) ? w.X0[n] : w.XL[(size_t)(d.L - 1) * lay.Nl + n];
+                const float4 a = w.ACC[(size_t)(d.L - 1) * lay.Nl + n];
+                const float4 x0 = w.X0[n];
+                vx = (p.x + a.x / d.norm_factor) - x0.x;
+                vy = (p.y + a.y / d.norm_factor) - x0.y;
+                vz = (p.z + a.z / d.norm_factor) - x0.z;
+                if (isnan(vx) || isnan(vy) || isnan(vz)) atomicOr(w.nan_flag, 1);
+            }
+            out[0] = vx; out[1] = vy; out[2] = vz;
+        }
+    }
+}
+
+// applies the reference's batch-global NaN reset to an evaluation's output (dynamics.py:129-131)
+__global__ void k_nan_fix(Layout lay, Work w, Dims d, float* __restrict__ eps_phar) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0 && *w.nan_flag) atomicAdd(&w.counters[4], 1ull);
+    if (n < lay.Nl && *w.nan_flag) {
+        float* o = eps_phar + (size_t)n * (3 + d.P);
+        o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host-callable launchers (C++ linkage, used by cmdgen_api.hip)
+// ------------------------------------------------------------------------------------
+template <int H>
+static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket,
+                          const float* t_arr, const float4* coef, ChainState* chain,
+                          float* eps_phar, float* eps_pocket, hipStream_t s,
+                          hipEvent_t* ev /* null or 2*(4+3L) events */) {
+    const int B = a.lay.B, N = a.lay.N;
+    const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + sizeof(int));
+    const int ntile_nodes = (N + CMDGEN_TILE - 1) / CMDGEN_TILE;
+    int e = 0;
+#define REC() do { if (ev) hipEventRecord(ev[e++], s); } while (0)
+    REC();
+    hipLaunchKernelGGL(k_edge_count, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket, chain);
+    hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d);
+    REC(); REC();
+    hipLaunchKernelGGL(k_embed<H>, dim3(ntile_nodes), dim3(H), 0, s, a.lay, a.w, a.d, a.sw, a.layers[0],
+                       xh_phar, xh_pocket, t_arr, coef, (const ChainState*)chain);
+    REC();
+    for (int l = 0; l < a.d.L; ++l) {
+        const int has_next = l + 1 < a.d.L;
+        REC();
+        hipLaunchKernelGGL(k_edge_msg<H>, dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);
+        REC(); REC();
+        hipLaunchKernelGGL(k_node<H>, dim3(ntile_nodes), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
+                           a.layers[has_next ? l + 1 : l], l, has_next);
+        REC(); REC();
+        hipLaunchKernelGGL(k_edge_coord<H>, dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);
+        REC();
+    }
+    REC();
+    const int nn = eps_pocket ? N : a.lay.Nl;
+    hipLaunchKernelGGL(k_readout, dim3((nn + 7) / 8), dim3(256), 0, s, a.lay, a.w, a.d, a.sw, eps_phar, eps_pocket);
+    REC();
+#undef REC
+}
+
+void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket,
+                        const float* t_arr, const float4* coef, ChainState* chain,
+                        float* eps_phar, float* eps_pocket, hipStream_t s, hipEvent_t* ev) {
+    switch (a.d.H) {
+        case 256: launch_eval_H<256>(a, xh_phar, xh_pocket, t_arr, coef, chain, eps_phar, eps_pocket, s, ev); break;
+        case 128: launch_eval_H<128>(a, xh_phar, xh_pocket, t_arr, coef, chain, eps_phar, eps_pocket, s, ev); break;
+        case 64:  launch_eval_H<64>(a, xh_phar, xh_pocket, t_arr, coef, chain, eps_phar, eps_pocket, s, ev); break;
+        default: break;   // rejected in cmdgen_create
+    }
+}
+
+void cmdgen_launch_nan_fix(const EvalLaunch& a, float* eps_phar, hipStream_t s) {
+    hipLaunchKernelGGL(k_nan_fix, dim3((a.lay.Nl + 255) / 256), dim3(256), 0, s, a.lay, a.w, a.d, eps_phar);
+}
+
+void cmdgen_launch_edge_msg_only(const EvalLaunch& a, int layer, hipStream_t s) {
+    switch (a.d.H) {
+        case 256: hipLaunchKernelGGL(k_edge_msg<256>, dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[layer], layer); break;
+        case 128: hipLaunchKernelGGL(k_edge_msg<128>, dim3(a.edge_grid), dim3(128), 0, s, a.lay, a.w, a.d, a.layers[layer], layer); break;
+        case 64:  hipLaunchKernelGGL(k_edge_msg<64>, dim3(a.edge_grid), dim3(64), 0, s, a.lay, a.w, a.d, a.layers[layer], layer); break;
+        default: break;
+    }
+}

@@ -1,0 +1,87 @@
+"""Parameter containers of the E(n)-equivariant GNN (names/shapes of egnn_new.py:6-208).
+
+The arithmetic of these modules is NOT here: one whole ``EGNNDynamics.forward`` runs as
+gfx950 kernels (csrc/kernels_egnn.hip).  The classes exist so that ``state_dict`` keys,
+``load_state_dict`` and optimizers see exactly the tensors of the reference
+(``egnn.e_block_{b}.gcl_0.edge_mlp.0.weight`` ...).
+"""
+import torch
+from torch import nn
+
+
+def _no_forward(self, *a, **k):
+    raise RuntimeError(f'{type(self).__name__} holds parameters only; the fused HIP evaluation is '
+                       'entered through EGNNDynamics.forward')
+
+
+class GCL(nn.Module):
+    """egnn_new.py:6-29: edge_mlp (2H+edges_in_d -> H -> H), node_mlp (2H -> H -> H), att_mlp (H -> 1)."""
+    def __init__(self, input_nf, output_nf, hidden_nf, normalization_factor, aggregation_method,
+                 edges_in_d=0, nodes_att_dim=0, act_fn=nn.SiLU(), attention=False):
+        super().__init__()
+        self.normalization_factor, self.aggregation_method, self.attention = \
+            normalization_factor, aggregation_method, attention
+        self.edge_mlp = nn.Sequential(nn.Linear(2 * input_nf + edges_in_d, hidden_nf), act_fn,
+                                      nn.Linear(hidden_nf, hidden_nf), act_fn)
+        self.node_mlp = nn.Sequential(nn.Linear(hidden_nf + input_nf + nodes_att_dim, hidden_nf), act_fn,
+                                      nn.Linear(hidden_nf, output_nf))
+        if attention:
+            self.att_mlp = nn.Sequential(nn.Linear(hidden_nf, 1), nn.Sigmoid())
+    forward = _no_forward
+
+
+class EquivariantUpdate(nn.Module):
+    """egnn_new.py:69-85: coord_mlp (2H+edges_in_d -> H -> H -> 1, last layer bias-free, xavier gain 1e-3)."""
+    def __init__(self, hidden_nf, normalization_factor, aggregation_method, edges_in_d=1,
+                 act_fn=nn.SiLU(), tanh=False, coords_range=10.0):
+        super().__init__()
+        self.tanh, self.coords_range = tanh, coords_range
+        last = nn.Linear(hidden_nf, 1, bias=False)
+        torch.nn.init.xavier_uniform_(last.weight, gain=0.001)
+        self.coord_mlp = nn.Sequential(nn.Linear(2 * hidden_nf + edges_in_d, hidden_nf), act_fn,
+                                       nn.Linear(hidden_nf, hidden_nf), act_fn, last)
+        self.normalization_factor, self.aggregation_method = normalization_factor, aggregation_method
+    forward = _no_forward
+
+
+class EquivariantBlock(nn.Module):
+    """egnn_new.py:115-139."""
+    def __init__(self, hidden_nf, edge_feat_nf=2, device='cpu', act_fn=nn.SiLU(), n_layers=2, attention=True,
+                 norm_diff=True, tanh=False, coords_range=15, norm_constant=1, sin_embedding=None,
+                 normalization_factor=100, aggregation_method='sum'):
+        super().__init__()
+        self.hidden_nf, self.n_layers = hidden_nf, n_layers
+        self.coords_range_layer = float(coords_range)
+        self.norm_constant = norm_constant
+        for i in range(n_layers):
+            self.add_module('gcl_%d' % i, GCL(hidden_nf, hidden_nf, hidden_nf, edges_in_d=edge_feat_nf,
+                                              act_fn=act_fn, attention=attention,
+                                              normalization_factor=normalization_factor,
+                                              aggregation_method=aggregation_method))
+        self.add_module('gcl_equiv', EquivariantUpdate(hidden_nf, edges_in_d=edge_feat_nf, act_fn=nn.SiLU(),
+                                                       tanh=tanh, coords_range=self.coords_range_layer,
+                                                       normalization_factor=normalization_factor,
+                                                       aggregation_method=aggregation_method))
+    forward = _no_forward
+
+
+class EGNN(nn.Module):
+    """egnn_new.py:159-191.  Quirk Q3 kept: every block receives the undivided coords_range."""
+    def __init__(self, in_node_nf, in_edge_nf, hidden_nf, device='cpu', act_fn=nn.SiLU(), n_layers=3,
+                 attention=False, norm_diff=True, out_node_nf=None, tanh=False, coords_range=15,
+                 norm_constant=1, inv_sublayers=2, sin_embedding=False, normalization_factor=100,
+                 aggregation_method='sum'):
+        super().__init__()
+        if sin_embedding:
+            raise NotImplementedError('sin_embedding=True: not used by the shipped configs, not built')
+        out_node_nf = in_node_nf if out_node_nf is None else out_node_nf
+        self.hidden_nf, self.n_layers = hidden_nf, n_layers
+        self.coords_range = float(coords_range)
+        self.embedding = nn.Linear(in_node_nf, hidden_nf)
+        self.embedding_out = nn.Linear(hidden_nf, out_node_nf)
+        for i in range(n_layers):
+            self.add_module('e_block_%d' % i, EquivariantBlock(
+                hidden_nf, edge_feat_nf=2, act_fn=act_fn, n_layers=inv_sublayers, attention=attention,
+                norm_diff=norm_diff, tanh=tanh, coords_range=coords_range, norm_constant=norm_constant,
+                normalization_factor=normalization_factor, aggregation_method=aggregation_method))
+    forward = _no_forward

@@ -1,0 +1,185 @@
+"""Noise schedule, alpha/sigma algebra and node-count prior
+(counterparts in en_diffusion.py: PredefinedNoiseSchedule :1152-1188, polynomial_schedule :1135-1149,
+clip_noise_schedule :1119-1132, EnVariationalDiffusion helpers :79-103, :849-949,
+DistributionNodes :952-1022).
+
+These are scalar, per-chain quantities: they are evaluated on the host with the same torch
+fp32 ops as the reference (so the per-step table handed to the HIP library is bit-identical)
+and never sit on the per-step critical path.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..synthetic import gamma_table
+
+
+class PredefinedNoiseSchedule(nn.Module):
+    """Lookup table gamma[0..T] for the 'polynomial_<p>' schedules (built in float64, stored fp32)."""
+    def __init__(self, noise_schedule, timesteps, precision):
+        super().__init__()
+        self.timesteps = timesteps
+        if 'polynomial' not in noise_schedule:
+            raise ValueError(noise_schedule)       # 'cosine' / 'learned' are not used by the shipped configs
+        self.gamma = nn.Parameter(torch.from_numpy(gamma_table(noise_schedule, timesteps, precision)),
+                                  requires_grad=False)
+
+    def forward(self, t):
+        return self.gamma[torch.round(t * self.timesteps).long()]
+
+
+class DistributionNodes:
+    """Joint histogram over (n_phar, n_pocket) node counts with +1e-3 smoothing (en_diffusion.py:952-1022)."""
+    def __init__(self, histogram):
+        hist = torch.tensor(np.asarray(histogram)).float() + 1e-3
+        prob = hist / hist.sum()
+        self.prob = prob
+        n1, n2 = prob.shape
+        self.idx_to_n_nodes = torch.stack(torch.meshgrid(torch.arange(n1), torch.arange(n2), indexing='ij'),
+                                          dim=-1).view(-1, 2)
+        self.n_nodes_to_idx = {tuple(x.tolist()): i for i, x in enumerate(self.idx_to_n_nodes)}
+        self.m = torch.distributions.Categorical(prob.view(-1), validate_args=True)
+        self.n1_given_n2 = [torch.distributions.Categorical(prob[:, j], validate_args=True) for j in range(n2)]
+        self.n2_given_n1 = [torch.distributions.Categorical(prob[i, :], validate_args=True) for i in range(n1)]
+
+    def sample(self, n_samples=1):
+        idx = self.m.sample((n_samples,))
+        a, b = self.idx_to_n_nodes[idx].T
+        return a, b
+
+    def sample_conditional(self, n1=None, n2=None):
+        assert (n1 is None) ^ (n2 is None), 'Exactly one input argument must be None'
+        m = self.n1_given_n2 if n2 is not None else self.n2_given_n1
+        c = n2 if n2 is not None else n1
+        return torch.tensor([m[int(i)].sample() for i in c], device=c.device)
+
+    def log_prob(self, batch_n_nodes_1, batch_n_nodes_2):
+        assert batch_n_nodes_1.dim() == 1 and batch_n_nodes_2.dim() == 1
+        idx = torch.tensor([self.n_nodes_to_idx[(a, b)]
+                            for a, b in zip(batch_n_nodes_1.tolist(), batch_n_nodes_2.tolist())])
+        return self.m.log_prob(idx).to(batch_n_nodes_1.device)
+
+    def log_prob_n1_given_n2(self, n1, n2):
+        assert n1.dim() == 1 and n2.dim() == 1
+        lp = torch.stack([self.n1_given_n2[int(c)].log_prob(i.cpu()) for i, c in zip(n1, n2)])
+        return lp.to(n1.device)
+
+    def log_prob_n2_given_n1(self, n2, n1):
+        assert n1.dim() == 1 and n2.dim() == 1
+        lp = torch.stack([self.n2_given_n1[int(c)].log_prob(i.cpu()) for i, c in zip(n2, n1)])
+        return lp.to(n2.device)
+
+
+class EnVariationalDiffusion(nn.Module):
+    """Schedule algebra shared by the diffusion variants (en_diffusion.py:13-103, :849-906).
+
+    The joint sampler / RePaint inpainting of the reference's base class
+    (en_diffusion.py:576-831) is a later scope row; every shipped
+    config uses the conditional subclass."""
+
+    def __init__(self, dynamics: nn.Module, phar_nf: int, residue_nf: int, n_dims: int,
+                 size_histogram: Dict, timesteps: int = 1000, parametrization='eps',
+                 noise_schedule='learned', noise_precision=1e-4, loss_type='vlb',
+                 norm_values=(1., 1.), norm_biases=(None, 0.)):
+        super().__init__()
+        assert loss_type in {'vlb', 'l2'}
+        assert parametrization == 'eps'
+        if noise_schedule == 'learned':
+            raise NotImplementedError("noise_schedule='learned' is not used by the shipped configs and not built")
+        self.loss_type = loss_type
+        self.gamma = PredefinedNoiseSchedule(noise_schedule, timesteps=timesteps, precision=noise_precision)
+        self.dynamics = dynamics
+        self.phar_nf, self.residue_nf, self.n_dims = phar_nf, residue_nf, n_dims
+        self.num_classes = phar_nf
+        self.T = timesteps
+        self.parametrization = parametrization
+        self.norm_values, self.norm_biases = norm_values, norm_biases
+        self.register_buffer('buffer', torch.zeros(1))
+        self.size_distribution = DistributionNodes(size_histogram)
+        self.check_issues_norm_values()
+        if hasattr(dynamics, 'attach_diffusion'):
+            dynamics.attach_diffusion(timesteps, self.gamma.gamma.detach().cpu().numpy(), norm_values, norm_biases)
+
+    def check_issues_norm_values(self, num_stdevs=8):
+        zeros = torch.zeros((1, 1))
+        gamma_0 = self.gamma(zeros)
+        sigma_0 = self.sigma(gamma_0, target_tensor=zeros).item()
+        norm_value = self.norm_values[1]
+        if sigma_0 * num_stdevs > 1. / norm_value:
+            raise ValueError(f'Value for normalization value {norm_value} probably too large with sigma_0 '
+                             f'{sigma_0:.5f} and 1 / norm_value = {1. / norm_value}')
+
+    # ---- alpha / sigma algebra (all on [B,1]-shaped gammas)
+    @staticmethod
+    def inflate_batch_array(array, target):
+        return array.view((array.size(0),) + (1,) * (len(target.size()) - 1))
+
+    def sigma(self, gamma, target_tensor):
+        return self.inflate_batch_array(torch.sqrt(torch.sigmoid(gamma)), target_tensor)
+
+    def alpha(self, gamma, target_tensor):
+        return self.inflate_batch_array(torch.sqrt(torch.sigmoid(-gamma)), target_tensor)
+
+    @staticmethod
+    def SNR(gamma):
+        return torch.exp(-gamma)
+
+    def sigma_and_alpha_t_given_s(self, gamma_t, gamma_s, target_tensor):
+        sigma2_t_given_s = self.inflate_batch_array(
+            -torch.expm1(F.softplus(gamma_s) - F.softplus(gamma_t)), target_tensor)
+        log_alpha2_t_given_s = F.logsigmoid(-gamma_t) - F.logsigmoid(-gamma_s)
+        alpha_t_given_s = self.inflate_batch_array(torch.exp(0.5 * log_alpha2_t_given_s), target_tensor)
+        return sigma2_t_given_s, torch.sqrt(sigma2_t_given_s), alpha_t_given_s
+
+    def step_table(self, timesteps: int) -> np.ndarray:
+        """[K+1, 4] per-step scalars of the ancestral sampler, evaluated with the reference's
+        own op sequence on a single-sample batch (conditional_model.py:345-366, :429-433;
+        final row: sigma_0, alpha_0, SNR(-gamma_0/2), t=0 from :108-131)."""
+        table = self.gamma.gamma.detach().cpu()
+        T, K = self.T, timesteps
+        z = torch.zeros(1, 1)
+        rows = []
+        look = lambda t: table[torch.round(t * T).long()]
+        for s in reversed(range(K)):
+            s_arr = torch.full((1, 1), fill_value=s) / K
+            t_arr = (torch.full((1, 1), fill_value=s) + 1) / K
+            g_s, g_t = look(s_arr), look(t_arr)
+            s2, s_ts, a_ts = self.sigma_and_alpha_t_given_s(g_t, g_s, z)
+            sig_s, sig_t = self.sigma(g_s, z), self.sigma(g_t, z)
+            rows.append([a_ts.item(), (s2 / a_ts / sig_t).item(), (s_ts * sig_s / sig_t).item(), t_arr.item()])
+        g0 = look(torch.zeros(1, 1))
+        rows.append([self.sigma(g0, z).item(), self.alpha(g0, z).item(), self.SNR(-0.5 * g0).item(), 0.0])
+        return np.asarray(rows, dtype=np.float32)
+
+    # ---- normalisation (en_diffusion.py:874-906)
+    def normalize(self, phar=None, pocket=None):
+        if phar is not None:
+            phar['x'] = phar['x'] / self.norm_values[0]
+            phar['one_hot'] = (phar['one_hot'].float() - self.norm_biases[1]) / self.norm_values[1]
+        if pocket is not None:
+            pocket['x'] = pocket['x'] / self.norm_values[0]
+            pocket['one_hot'] = (pocket['one_hot'].float() - self.norm_biases[1]) / self.norm_values[1]
+        return phar, pocket
+
+    def unnormalize(self, x, h_cat):
+        return x * self.norm_values[0], h_cat * self.norm_values[1] + self.norm_biases[1]
+
+    def unnormalize_z(self, z_phar, z_pocket):
+        nd = self.n_dims
+        xl, hl = self.unnormalize(z_phar[:, :nd], z_phar[:, nd:])
+        xp, hp = self.unnormalize(z_pocket[:, :nd], z_pocket[:, nd:])
+        return torch.cat([xl, hl], dim=1), torch.cat([xp, hp], dim=1)
+
+    def subspace_dimensionality(self, input_size):
+        return (input_size - 1) * self.n_dims
+
+    def sample(self, *args, **kwargs):
+        raise NotImplementedError('joint sampling (en_diffusion.py:576-647) is not built yet (SURVEY 8f #2)')
+
+    def inpaint(self, *args, **kwargs):
+        raise NotImplementedError('RePaint inpainting (en_diffusion.py:672-831) is not built yet (SURVEY 8f #2)')

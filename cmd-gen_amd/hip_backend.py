@@ -1,0 +1,271 @@
+"""ctypes binding of libcmdgen_hip.so (include/cmdgen_hip.h).
+
+There is no CPU fallback: if the library has not been built
+(``python __graft_entry__.py``) or no MI355X is visible, using the model raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libcmdgen_hip.so')
+_lib = None
+
+
+class CmdgenError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'phar_nf', 'residue_nf', 'joint_nf', 'hidden_nf', 'n_layers', 'inv_sublayers',
+        'attention', 'tanh', 'condition_time', 'timesteps')] + \
+        [(n, C.c_float) for n in ('edge_cutoff', 'norm_constant', 'normalization_factor',
+                                  'coords_range', 'norm_x', 'norm_h', 'bias_h')]
+
+
+class Counters(C.Structure):
+    _fields_ = [('evaluations', C.c_uint64), ('edges', C.c_uint64), ('edges_phar', C.c_uint64),
+                ('nodes', C.c_uint64), ('nan_resets', C.c_uint64), ('reserved', C.c_uint64 * 3)]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ('edge_build_ms', 'embed_ms', 'edge_msg_ms', 'node_ms',
+                                         'edge_coord_ms', 'readout_ms', 'ddpm_ms')] + \
+               [(n, C.c_int32) for n in ('edge_msg_launches', 'node_launches', 'edge_coord_launches')]
+
+
+# every symbol include/cmdgen_hip.h declares: (name, restype, argtypes)
+_vp, _fp, _i64p = C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)
+SYMBOLS = [
+    ('cmdgen_create', C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(_vp)]),
+    ('cmdgen_destroy', None, [_vp]),
+    ('cmdgen_last_error', C.c_char_p, [_vp]),
+    ('cmdgen_version', C.c_char_p, []),
+    ('cmdgen_load_weights', C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t]),
+    ('cmdgen_finalize_weights', C.c_int, [_vp]),
+    ('cmdgen_set_layout', C.c_int, [_vp, C.c_int64, _i64p, _i64p]),
+    ('cmdgen_dynamics_forward', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _vp]),
+    ('cmdgen_get_edges', C.c_int, [_vp, _vp, _vp, C.c_int64, _i64p, _vp]),
+    ('cmdgen_debug_read', C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t, _vp]),
+    ('cmdgen_sample_chain', C.c_int, [_vp, _fp, _fp, C.c_int32, _fp, C.c_uint64, _i64p, _fp, _fp, _fp,
+                                      C.c_int32, _vp]),
+    ('cmdgen_set_step_table', C.c_int, [_vp, C.c_int32, _vp]),
+    ('cmdgen_chain_status', C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i64p, _vp]),
+    ('cmdgen_get_counters', C.c_int, [_vp, C.POINTER(Counters), _vp]),
+    ('cmdgen_reset_counters', C.c_int, [_vp, _vp]),
+    ('cmdgen_profile_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.POINTER(KernelTimes), _vp]),
+    ('cmdgen_time_edge_kernel', C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
+]
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the in-tree library and bind every declared symbol (no device needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise CmdgenError(
+            f'{_LIB_PATH} is missing: build it with `python __graft_entry__.py` '
+            '(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.')
+    import torch  # noqa: F401  - loads the process's HIP runtime first so both share it
+    lib = C.CDLL(_LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Handle:
+    """One cmdgen_handle: bound to one device, not thread-safe (as the reference's modules)."""
+
+    def __init__(self, cfg: Dict, device_index: int = 0):
+        import torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise CmdgenError('no GPU visible: the DiffPhar denoising path runs on MI355X (gfx950) only; '
+                              'there is no CPU fallback')
+        c = Config()
+        c.phar_nf, c.residue_nf = int(cfg['phar_nf']), int(cfg['residue_nf'])
+        c.joint_nf, c.hidden_nf, c.n_layers = int(cfg['joint_nf']), int(cfg['hidden_nf']), int(cfg['n_layers'])
+        c.inv_sublayers = int(cfg.get('inv_sublayers', 1))
+        c.attention, c.tanh = int(bool(cfg['attention'])), int(bool(cfg['tanh']))
+        c.condition_time = int(bool(cfg.get('condition_time', True)))
+        c.timesteps = int(cfg['timesteps'])
+        ec = cfg.get('edge_cutoff')
+        c.edge_cutoff = -1.0 if ec is None else float(ec)
+        c.norm_constant = float(cfg['norm_constant'])
+        c.normalization_factor = float(cfg['normalization_factor'])
+        c.coords_range = float(cfg.get('coords_range', 15.0))
+        nv, nb = cfg['norm_values'], cfg['norm_biases']
+        c.norm_x, c.norm_h = float(nv[0]), float(nv[1])
+        c.bias_h = float(nb[1] if nb[1] is not None else 0.0)
+        if cfg.get('aggregation_method', 'sum') != 'sum':
+            raise CmdgenError("aggregation_method must be 'sum' (the only one the shipped configs use)")
+        if cfg.get('sin_embedding', False):
+            raise CmdgenError('sin_embedding=True is not supported (shipped configs use False)')
+        h = C.c_void_p()
+        rc = self.lib.cmdgen_create(C.byref(c), int(device_index), C.byref(h))
+        if rc != 0:
+            raise CmdgenError('cmdgen_create: ' + self.lib.cmdgen_last_error(None).decode())
+        self.h = h
+        self.device_index = device_index
+        self.cfg = dict(cfg)
+        self._layout_key = None
+        self.n_phar = self.n_pocket = self.batch = 0
+
+    # ---- helpers
+    def _check(self, rc, what):
+        if rc != 0:
+            raise CmdgenError(f'{what}: ' + self.lib.cmdgen_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.cmdgen_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---- parameters
+    def load_state_dict(self, state: Dict[str, 'np.ndarray'], prefix: str = 'ddpm.'):
+        """state: reference checkpoint names -> arrays/tensors (only the 'ddpm.' sub-tree is used)."""
+        for k, v in state.items():
+            if not k.startswith(prefix):
+                continue
+            name = k[len(prefix):]
+            if name == 'buffer':
+                continue
+            a = v.detach().cpu().numpy() if hasattr(v, 'detach') else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            self._check(self.lib.cmdgen_load_weights(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size),
+                        'cmdgen_load_weights')
+        self._check(self.lib.cmdgen_finalize_weights(self.h), 'cmdgen_finalize_weights')
+
+    # ---- layout
+    def set_layout(self, num_phar: Sequence[int], num_pocket: Sequence[int]):
+        a = np.ascontiguousarray(np.asarray(num_phar, dtype=np.int64))
+        b = np.ascontiguousarray(np.asarray(num_pocket, dtype=np.int64))
+        assert a.shape == b.shape and a.ndim == 1
+        key = (a.tobytes(), b.tobytes())
+        if key != self._layout_key:
+            self._check(self.lib.cmdgen_set_layout(self.h, len(a), a.ctypes.data_as(_i64p), b.ctypes.data_as(_i64p)),
+                        'cmdgen_set_layout')
+            self._layout_key = key
+        self.batch, self.n_phar, self.n_pocket = len(a), int(a.sum()), int(b.sum())
+
+    # ---- one evaluation
+    def dynamics_forward(self, xh_phar, xh_pocket, t, want_pocket: bool = True):
+        import torch
+        P, R = self.cfg['phar_nf'], self.cfg['residue_nf']
+        assert xh_phar.is_cuda and xh_phar.dtype == torch.float32 and xh_phar.is_contiguous()
+        assert xh_pocket.is_cuda and xh_pocket.dtype == torch.float32 and xh_pocket.is_contiguous()
+        assert tuple(xh_phar.shape) == (self.n_phar, 3 + P), (xh_phar.shape, self.n_phar)
+        assert tuple(xh_pocket.shape) == (self.n_pocket, 3 + R)
+        t = t.reshape(-1).to(torch.float32).contiguous()
+        if t.numel() == 1 and self.batch > 1:
+            t = t.expand(self.batch).contiguous()
+        assert t.numel() == self.batch
+        eps_phar = torch.empty_like(xh_phar)
+        eps_pocket = torch.empty_like(xh_pocket) if want_pocket else None
+        self._check(self.lib.cmdgen_dynamics_forward(self.h, _ptr(xh_phar), _ptr(xh_pocket), _ptr(t),
+                                                     _ptr(eps_phar), _ptr(eps_pocket), self._stream()),
+                    'cmdgen_dynamics_forward')
+        return eps_phar, eps_pocket
+
+    def get_edges(self):
+        cap = int(np.sum((np.frombuffer(self._layout_key[0], dtype=np.int64) +
+                          np.frombuffer(self._layout_key[1], dtype=np.int64)) ** 2))
+        row = np.empty(cap, dtype=np.int32)
+        col = np.empty(cap, dtype=np.int32)
+        n = C.c_int64(0)
+        self._check(self.lib.cmdgen_get_edges(self.h, row.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
+                                              cap, C.byref(n), self._stream()), 'cmdgen_get_edges')
+        return np.stack([row[:n.value], col[:n.value]])
+
+    def debug_read(self, what: str, n: int):
+        out = np.empty(n, dtype=np.float32)
+        self._check(self.lib.cmdgen_debug_read(self.h, what.encode(), out.ctypes.data_as(C.c_void_p), n, self._stream()),
+                    'cmdgen_debug_read')
+        return out
+
+    # ---- the chain
+    def set_step_table(self, K: int, coef: 'np.ndarray'):
+        a = np.ascontiguousarray(coef, dtype=np.float32)
+        assert a.shape == (K + 1, 4)
+        self._check(self.lib.cmdgen_set_step_table(self.h, K, a.ctypes.data_as(C.c_void_p)), 'cmdgen_set_step_table')
+
+    def sample_chain(self, pocket_x, pocket_onehot, timesteps: int, noise=None, seed: int = 0,
+                     pocket_ids: Optional[Sequence[int]] = None, want_steps: bool = False,
+                     use_graph: bool = True):
+        import torch
+        P, R = self.cfg['phar_nf'], self.cfg['residue_nf']
+        dev = pocket_x.device
+        assert pocket_x.is_cuda and pocket_x.dtype == torch.float32 and pocket_x.is_contiguous()
+        assert pocket_onehot.dtype == torch.float32 and pocket_onehot.is_contiguous()
+        assert tuple(pocket_x.shape) == (self.n_pocket, 3) and tuple(pocket_onehot.shape) == (self.n_pocket, R)
+        if noise is not None:
+            assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
+            assert tuple(noise.shape) == (timesteps + 2, self.n_phar, 3 + P), noise.shape
+        xh_phar = torch.empty((self.n_phar, 3 + P), dtype=torch.float32, device=dev)
+        xh_pocket = torch.empty((self.n_pocket, 3 + R), dtype=torch.float32, device=dev)
+        z_steps = torch.empty((timesteps, self.n_phar, 3 + P), dtype=torch.float32, device=dev) if want_steps else None
+        ids = None
+        if pocket_ids is not None:
+            ids = np.ascontiguousarray(np.asarray(pocket_ids, dtype=np.int64))
+            assert len(ids) == self.batch
+        self._check(self.lib.cmdgen_sample_chain(
+            self.h, _ptr(pocket_x), _ptr(pocket_onehot), int(timesteps), _ptr(noise), C.c_uint64(seed & (2 ** 64 - 1)),
+            ids.ctypes.data_as(_i64p) if ids is not None else None, _ptr(xh_phar), _ptr(xh_pocket),
+            _ptr(z_steps), int(bool(use_graph)), self._stream()), 'cmdgen_sample_chain')
+        return xh_phar, xh_pocket, z_steps
+
+    def chain_status(self):
+        a, b, n = C.c_float(0), C.c_float(0), C.c_int64(0)
+        self._check(self.lib.cmdgen_chain_status(self.h, C.byref(a), C.byref(b), C.byref(n), self._stream()),
+                    'cmdgen_chain_status')
+        return {'max_rel_com_error': a.value, 'max_cog': b.value, 'nan_resets': n.value}
+
+    # ---- measurement
+    def counters(self) -> Dict[str, int]:
+        c = Counters()
+        self._check(self.lib.cmdgen_get_counters(self.h, C.byref(c), self._stream()), 'cmdgen_get_counters')
+        return {k: int(getattr(c, k)) for k in ('evaluations', 'edges', 'edges_phar', 'nodes', 'nan_resets')}
+
+    def reset_counters(self):
+        self._check(self.lib.cmdgen_reset_counters(self.h, self._stream()), 'cmdgen_reset_counters')
+
+    def profile_evaluation(self, xh_phar, xh_pocket, t):
+        import torch
+        t = t.reshape(-1).to(torch.float32).contiguous()
+        eps = torch.empty_like(xh_phar)
+        kt = KernelTimes()
+        self._check(self.lib.cmdgen_profile_evaluation(self.h, _ptr(xh_phar), _ptr(xh_pocket), _ptr(t), _ptr(eps),
+                                                       C.byref(kt), self._stream()), 'cmdgen_profile_evaluation')
+        return {n: getattr(kt, n) for n, _ in KernelTimes._fields_}
+
+    def time_edge_kernel(self, layer: int, reps: int) -> float:
+        ms = C.c_float(0)
+        self._check(self.lib.cmdgen_time_edge_kernel(self.h, layer, reps, C.byref(ms), self._stream()),
+                    'cmdgen_time_edge_kernel')
+        return ms.value

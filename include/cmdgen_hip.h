@@ -1,0 +1,190 @@
+/*
+ * cmdgen_hip.h - C ABI of libcmdgen_hip.so: the MI355X (gfx950) implementation of
+ * DiffPhar's pocket-conditioned denoising path.
+ *
+ * The reference (zyrlia1018/CMD-GEN, DiffPhar/) is pure Python and has no FFI of its
+ * own; the entry points below are what a binding for this path replaces, cited as
+ * file:line relative to /root/reference/DiffPhar.  INTEGRATION.md shows the ctypes
+ * stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  "dev" pointers are device memory
+ *     owned by the CALLER (e.g. torch tensors' data_ptr()); "host" pointers are host
+ *     memory.  The handle owns packed weights, the schedule table, workspaces and
+ *     hipGraph executables, nothing else.
+ *   - Every launch goes to the caller-supplied stream; no hidden device synchronise
+ *     except where a function is documented to return host-visible results.
+ *   - Return 0 on success, a negative CMDGEN_E* code otherwise; cmdgen_last_error()
+ *     gives the message.  Nothing throws across the ABI.
+ *   - A handle is bound to one device and is not thread-safe (one handle per GPU /
+ *     host thread), like the reference's module objects.
+ *   - Flat, un-padded node lists (PyG style): all samples' nodes concatenated along
+ *     dim 0, sample membership given by per-sample counts; masks must be ascending
+ *     and contiguous, as every mask the reference builds is (utils.py:137-145,
+ *     dataset.py:59-60, lightning_modules.py:445-448).
+ *   - All floating point is fp32 (constants.py:8).
+ */
+#ifndef CMDGEN_HIP_H
+#define CMDGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMDGEN_OK            0
+#define CMDGEN_EINVAL       -1   /* bad argument / unsupported configuration */
+#define CMDGEN_ESTATE       -2   /* call order (weights not finalised, no layout, ...) */
+#define CMDGEN_EHIP         -3   /* a HIP runtime call failed */
+#define CMDGEN_ENOMEM       -4
+
+typedef struct cmdgen_handle cmdgen_handle;
+typedef void* cmdgen_stream;     /* hipStream_t */
+
+/* Hyper-parameters that fix every shape on the path
+ * (EGNNDynamics.__init__ dynamics.py:10-73, EGNN.__init__ egnn_new.py:160-191,
+ *  EnVariationalDiffusion.__init__ en_diffusion.py:18-62; values of
+ *  configs/crossdocked_ca_cond.yml:22-41 in comments). */
+typedef struct cmdgen_config {
+    int32_t phar_nf;               /* 8  */
+    int32_t residue_nf;            /* 20 (CA) or 11 (full-atom) */
+    int32_t joint_nf;              /* 32 */
+    int32_t hidden_nf;             /* 256; must be a multiple of 64, <= 256 */
+    int32_t n_layers;              /* 5  */
+    int32_t inv_sublayers;         /* 1 (only value supported) */
+    int32_t attention;             /* 1  */
+    int32_t tanh;                  /* 1  */
+    int32_t condition_time;        /* 1  */
+    int32_t timesteps;             /* T of the gamma table (500) */
+    float   edge_cutoff;           /* 6.0; < 0 means no cutoff (complete graph per sample) */
+    float   norm_constant;         /* 1  */
+    float   normalization_factor;  /* 100 ('sum' aggregation only) */
+    float   coords_range;          /* 15 (egnn_new.py:161; quirk: never divided by n_layers) */
+    float   norm_x;                /* norm_values[0] = 1 */
+    float   norm_h;                /* norm_values[1] = 4 */
+    float   bias_h;                /* norm_biases[1] = 0 */
+} cmdgen_config;
+
+/* Work counters accumulated on the device since the last reset (for the
+ * algorithmic-FLOP roofline). */
+typedef struct cmdgen_counters {
+    uint64_t evaluations;          /* network evaluations (EGNNDynamics.forward calls) */
+    uint64_t edges;                /* sum over evaluations of directed edges incl. self loops */
+    uint64_t edges_phar;           /* ... of those whose receiver is a pharmacophore node */
+    uint64_t nodes;                /* sum over evaluations of nodes */
+    uint64_t nan_resets;           /* evaluations whose velocity was reset (dynamics.py:129-131) */
+    uint64_t reserved[3];
+} cmdgen_counters;
+
+/* Per-kernel timing of one profiled evaluation (hipEvent pairs on the launch stream). */
+typedef struct cmdgen_kernel_times {
+    float edge_build_ms, embed_ms, edge_msg_ms, node_ms, edge_coord_ms, readout_ms, ddpm_ms;
+    int32_t edge_msg_launches, node_launches, edge_coord_launches;
+} cmdgen_kernel_times;
+
+/* ---- lifetime --------------------------------------------------------------------- */
+/* Replaces constructing EGNNDynamics + ConditionalDDPM (lightning_modules.py:110-139). */
+int  cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle** out);
+void cmdgen_destroy(cmdgen_handle* h);
+const char* cmdgen_last_error(const cmdgen_handle* h);   /* h may be NULL: last create error */
+const char* cmdgen_version(void);
+
+/* ---- parameters ------------------------------------------------------------------- */
+/* Replaces nn.Module.load_state_dict for the 'ddpm.' sub-tree of a Lightning checkpoint
+ * (generate_phars.py:32).  `name` is the reference key below 'ddpm.', e.g.
+ * "dynamics.egnn.e_block_0.gcl_0.edge_mlp.0.weight" or "gamma.gamma"; `host` holds `n`
+ * fp32 values in nn.Linear layout [out, in] row-major. */
+int cmdgen_load_weights(cmdgen_handle* h, const char* name, const float* host, size_t n);
+/* Checks that every tensor arrived, packs them into MFMA fragment order on the device. */
+int cmdgen_finalize_weights(cmdgen_handle* h);
+
+/* ---- batch layout ----------------------------------------------------------------- */
+/* Per-sample node counts of the flat batch (host arrays of length `batch`):
+ * num_phar = num_nodes_phar, num_pocket = pocket['size'] (conditional_model.py:388-408).
+ * Sizes workspaces; cheap when the layout is unchanged. */
+int cmdgen_set_layout(cmdgen_handle* h, int64_t batch,
+                      const int64_t* num_phar_host, const int64_t* num_pocket_host);
+
+/* ---- one network evaluation ------------------------------------------------------- */
+/* EGNNDynamics.forward (dynamics.py:75-139), conditional mode.
+ *   xh_phar   dev [Nl, 3+phar_nf]      xh_pocket dev [Np, 3+residue_nf]
+ *   t         dev [batch]              (the reference's [B,1]; a single-sample batch uses t[0])
+ *   eps_phar  dev [Nl, 3+phar_nf]  out
+ *   eps_pocket dev [Np, 3+residue_nf] out, may be NULL (every conditional caller discards it:
+ *              conditional_model.py:115, :246, :355) */
+int cmdgen_dynamics_forward(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket,
+                            const float* t, float* eps_phar, float* eps_pocket,
+                            cmdgen_stream stream);
+
+/* Radius graph of the last evaluation, EGNNDynamics.get_edges (dynamics.py:141-147):
+ * copies up to `cap` edges as (row, col) int32 pairs in the reference's flat node
+ * numbering (phar nodes first) to HOST arrays; returns the edge count in *n_edges.
+ * Synchronises the stream.  Debug / parity aid. */
+int cmdgen_get_edges(cmdgen_handle* h, int32_t* row_host, int32_t* col_host, int64_t cap,
+                     int64_t* n_edges, cmdgen_stream stream);
+
+/* Copy an internal activation of the last evaluation to host (parity aid):
+ * what = "h" [N, hidden] after the last block, "x" [Nl, 4] final phar coordinates. */
+int cmdgen_debug_read(cmdgen_handle* h, const char* what, float* host, size_t n, cmdgen_stream stream);
+
+/* ---- the denoising loop ----------------------------------------------------------- */
+/* ConditionalDDPM.sample_given_pocket (conditional_model.py:388-465) with return_frames=1:
+ * init noise around the pocket COM, `timesteps` posterior steps (sample_p_zs_given_zt
+ * :342-374), final p(x,h|z0) decode (:108-131), CoG drift fix (:451-457).
+ *   pocket_x      dev [Np, 3]           un-normalised coordinates
+ *   pocket_onehot dev [Np, residue_nf]  one-hot (un-normalised; scaled by 1/norm_h inside)
+ *   timesteps     K <= T, strided schedule t=(s+1)/K as the reference
+ *   noise         dev [K+2, Nl, 3+phar_nf] Gaussian draws in the reference's draw order, or
+ *                 NULL to draw on the device (Philox4x32-10 keyed by seed, global pocket id,
+ *                 draw index, node) - the reference draws with torch.randn on the compute
+ *                 device (en_diffusion.py:946-949), which no other device can reproduce.
+ *   pocket_ids_host  host [batch] global pocket indices for the Philox key (NULL: 0..batch-1);
+ *                 makes results independent of how pockets are sharded over GPUs.
+ *   xh_phar_out   dev [Nl, 3+phar_nf]    x in Angstrom, h one-hot (as floats)
+ *   xh_pocket_out dev [Np, 3+residue_nf] translated pocket, h = one_hot
+ *   z_steps_out   dev [K, Nl, 3+phar_nf] z after each posterior step, or NULL
+ *   use_graph     1: replay the step as a hipGraph, 0: eager launches
+ * Asynchronous on `stream`; call cmdgen_chain_status afterwards for the deferred checks. */
+int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, const float* pocket_onehot,
+                        int32_t timesteps, const float* noise, uint64_t seed,
+                        const int64_t* pocket_ids_host,
+                        float* xh_phar_out, float* xh_pocket_out, float* z_steps_out,
+                        int32_t use_graph, cmdgen_stream stream);
+
+/* Optional: supply the per-step scalars of sample_p_zs_given_zt computed by the host
+ * (e.g. with the same torch fp32 ops as the reference, bit for bit) instead of the
+ * library's own libm evaluation.  coef_host is [K+1][4]:
+ *   rows 0..K-1 (s = K-1 .. 0): alpha_ts, sigma2_ts/alpha_ts/sigma_t, sigma_ts*sigma_s/sigma_t, t
+ *   row  K     (final decode) : sigma_0, alpha_0, exp(gamma_0/2), 0
+ * (conditional_model.py:345-366, :108-131; en_diffusion.py:79-103).  Used by the next
+ * cmdgen_sample_chain whose `timesteps` equals K. */
+int cmdgen_set_step_table(cmdgen_handle* h, int32_t K, const float* coef_host);
+
+/* Deferred, non-syncing versions of the reference's in-loop checks, read back after the
+ * chain (synchronises the stream):
+ *   max_rel_com_error : max over steps of assert_mean_zero_with_mask's relative error
+ *                       (en_diffusion.py:919-924; the reference asserts < 1e-2)
+ *   max_cog           : the final CoG drift (conditional_model.py:451-457)
+ *   nan_resets        : evaluations whose output was reset by the NaN guard */
+int cmdgen_chain_status(cmdgen_handle* h, float* max_rel_com_error, float* max_cog,
+                        int64_t* nan_resets, cmdgen_stream stream);
+
+/* ---- measurement ------------------------------------------------------------------ */
+int cmdgen_get_counters(cmdgen_handle* h, cmdgen_counters* out, cmdgen_stream stream); /* syncs */
+int cmdgen_reset_counters(cmdgen_handle* h, cmdgen_stream stream);
+/* Runs ONE evaluation on the current inputs with a hipEvent pair around every launch and
+ * returns the per-kernel sums (synchronises). */
+int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket,
+                              const float* t, float* eps_phar, cmdgen_kernel_times* out,
+                              cmdgen_stream stream);
+/* Replays the edge-message kernel of block `layer` `reps` times on the state left by the
+ * last evaluation and returns the mean launch duration in ms (hipEvents on `stream`). */
+int cmdgen_time_edge_kernel(cmdgen_handle* h, int32_t layer, int32_t reps, float* mean_ms,
+                            cmdgen_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMDGEN_HIP_H */

@@ -1,0 +1,268 @@
+"""GPU parity tests: the HIP path (through the C ABI, via cmdgen_amd.hip_backend) against
+(a) the golden vectors captured from the reference and (b) the oracle on seeded inputs.
+
+Tolerances (fp32, stated per test):
+  * one network evaluation: max |eps - eps_ref| <= 2e-5 * max(1, max|eps_ref|)
+    (fp32 re-association: first-layer factorisation P_i + Q_j, MFMA k-order, v_exp/v_rcp SiLU)
+  * chains with injected noise: coordinate RMS <= 1e-4 * max(1, max|x|) (north-star bound),
+    one-hot types exact; fixtures keep every pair >= 2e-3 A away from the 6 A cutoff because
+    the radius graph is a hard threshold (hard part 2).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (load_golden, cases_of, dynamics_case, chain_case, rms)
+from cmdgen_amd import hip_backend
+from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets, min_cutoff_margin
+
+pytestmark = pytest.mark.gpu
+
+EVAL_TOL = 2e-5
+_handles = {}
+
+
+def handle_for(cfg, sd_key, sd):
+    """One handle per (config, weight set); reused across tests."""
+    key = (tuple(sorted((k, str(v)) for k, v in cfg.as_dict().items())), sd_key)
+    if key not in _handles:
+        h = hip_backend.Handle(cfg.as_dict(), 0)
+        h.load_state_dict(sd)
+        _handles[key] = h
+    return _handles[key]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def supported(name):
+    return '_h32_' not in name          # hidden_nf 32 is below the 64-column wave tile
+
+
+G2 = load_golden('g2_dynamics.npz')
+G4 = load_golden('g4_chains.npz')
+
+
+def run_eval(name):
+    cfg, sd, inp = dynamics_case(G2, name)
+    h = handle_for(cfg, name, sd)
+    h.set_layout(G2[name + '/num_nodes_phar'], G2[name + '/pocket_size'])
+    eps_phar, eps_pocket = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']))
+    torch.cuda.synchronize()
+    return cfg, h, inp, eps_phar.cpu().numpy(), eps_pocket.cpu().numpy()
+
+
+@pytest.mark.parametrize('name', [n for n in cases_of(G2) if supported(n)])
+def test_radius_graph_matches_reference(name):
+    cfg, h, inp, _, _ = run_eval(name)
+    edges = h.get_edges()
+    want = G2[name + '/edges']
+    assert edges.shape == want.shape, (edges.shape, want.shape)
+    assert np.array_equal(edges, want)          # same set, same (row, col) order, self loops kept
+
+
+def test_radius_graph_boundary_cases():
+    """G3: a pair at exactly 6.0 A is kept (<=), 6.5 is not, self loops, no cross-sample edges."""
+    g = load_golden('g3_edges.npz')
+    cfg = ModelConfig(hidden_nf=64, n_layers=1)
+    sd = make_state_dict(cfg, seed=3)
+    h = handle_for(cfg, 'g3', sd)
+    # sample 0 = 30 phar nodes and no pocket nodes, sample 1 = 10 pocket nodes and no phar nodes:
+    # the flat order [phar..., pocket...] is then exactly the fixture's node order.
+    h.set_layout([30, 0], [0, 10])
+    xh_phar = np.zeros((30, 3 + cfg.phar_nf), np.float32); xh_phar[:, :3] = g['x'][:30]
+    xh_pocket = np.zeros((10, 3 + cfg.residue_nf), np.float32); xh_pocket[:, :3] = g['x'][30:]
+    h.dynamics_forward(dev(xh_phar), dev(xh_pocket), dev(np.array([0.5, 0.5], np.float32)))
+    assert np.array_equal(h.get_edges(), g['edges'])
+
+
+@pytest.mark.parametrize('name', [n for n in cases_of(G2) if supported(n)])
+def test_dynamics_forward_matches_reference(name):
+    cfg, h, inp, eps_phar, eps_pocket = run_eval(name)
+    want = G2[name + '/eps_phar']
+    tol = EVAL_TOL * max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(eps_phar - want).max())
+    assert err <= tol, f'{name}: max abs err {err:.3e} > {tol:.3e}'
+    # conditional mode: the pocket never moves
+    assert np.all(eps_pocket[:, :3] == 0)
+    if name + '/eps_pocket' in G2:
+        wp = G2[name + '/eps_pocket']
+        assert float(np.abs(eps_pocket - wp).max()) <= EVAL_TOL * max(1.0, float(np.abs(wp).max()))
+    if name + '/block0_h_phar' in G2:          # last block's h of the phar rows and final x
+        nl = len(inp['mask_phar'])
+        L = cfg.n_layers
+        hfin = h.debug_read('h', (nl + 16) * cfg.hidden_nf).reshape(-1, cfg.hidden_nf)
+        wh = G2[name + f'/block{L - 1}_h_phar']
+        assert float(np.abs(hfin[:nl] - wh).max()) <= 5e-5 * max(1.0, float(np.abs(wh).max()))
+        assert float(np.abs(hfin[nl:nl + 16] - G2[name + f'/block{L - 1}_h_pocket_head']).max()) <= 5e-5 * max(1.0, float(np.abs(wh).max()))
+
+
+@pytest.mark.parametrize('H,L,rep', [(64, 2, 'CA'), (128, 3, 'CA'), (128, 2, 'full-atom')])
+def test_dynamics_forward_matches_oracle_other_widths(H, L, rep):
+    """Oracle-checked cases for the other supported hidden sizes (seeded inputs, ragged sizes)."""
+    from oracle import ref_cpu
+    cfg = ModelConfig(hidden_nf=H, n_layers=L, residue_nf=20 if rep == 'CA' else 11)
+    sd = make_state_dict(cfg, seed=100 + H + L, coord_gain=1.0)
+    first = 5000 + H
+    while True:
+        pb = make_pockets(5, rep, ragged=(rep == 'CA'), n_pocket_nodes=70 if rep != 'CA' else None,
+                          n_phar=7, first_index=first)
+        rng = np.random.Generator(np.random.PCG64(first))
+        B = len(pb.size)
+        phar_mask = np.repeat(np.arange(B), pb.num_nodes_phar)
+        com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(B)])
+        xp = (com[phar_mask] + rng.normal(size=(len(phar_mask), 3)) * 2.5).astype(np.float32)
+        allx = np.concatenate([xp, pb.x]); allm = np.concatenate([phar_mask, pb.mask])
+        if min_cutoff_margin(allx, allm, 6.0) > 2e-3:
+            break
+        first += 1000
+    xh_phar = np.concatenate([xp, rng.normal(size=(len(phar_mask), cfg.phar_nf)).astype(np.float32)], 1)
+    xh_pocket = np.concatenate([pb.x, pb.one_hot / 4.0], 1).astype(np.float32)
+    t = rng.uniform(0.1, 0.9, size=(B, 1)).astype(np.float32)
+    p = ref_cpu.to_torch_params(sd)
+    with torch.no_grad():
+        want, _ = ref_cpu.dynamics_forward(p, cfg.as_dict(), torch.from_numpy(xh_phar), torch.from_numpy(xh_pocket),
+                                           torch.from_numpy(t), torch.from_numpy(phar_mask), torch.from_numpy(pb.mask))
+    want = want.numpy()
+    h = handle_for(cfg, f'oracle{H}{L}{rep}', sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    got, _ = h.dynamics_forward(dev(xh_phar), dev(xh_pocket), dev(t))
+    err = float(np.abs(got.cpu().numpy() - want).max())
+    assert err <= EVAL_TOL * max(1.0, float(np.abs(want).max())), err
+
+
+def run_chain(name, use_graph):
+    cfg, sd, pb, K = chain_case(G4, name)
+    h = handle_for(cfg, name, sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    # per-step scalars evaluated by the host exactly as the reference does (bit-identical table)
+    from cmdgen_amd.equivariant_diffusion.en_diffusion import PredefinedNoiseSchedule  # noqa: F401
+    from oracle import ref_cpu
+    table = ref_cpu.gamma_table(cfg.noise_schedule, cfg.timesteps, cfg.noise_precision)
+    coef = ref_cpu.step_coefficients(table, cfg.timesteps, K).numpy()
+    g0 = table[0]
+    final = np.array([[float(torch.sqrt(torch.sigmoid(g0))), float(torch.sqrt(torch.sigmoid(-g0))),
+                       float(torch.exp(0.5 * g0)), 0.0]], np.float32)
+    h.set_step_table(K, np.concatenate([coef, final]))
+    xh_phar, xh_pocket, z_steps = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=dev(G4[name + '/noise']),
+                                                 want_steps=True, use_graph=use_graph)
+    st = h.chain_status()
+    return cfg, K, xh_phar.cpu().numpy(), xh_pocket.cpu().numpy(), z_steps.cpu().numpy(), st
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+@pytest.mark.parametrize('name', [n for n in cases_of(G4) if supported(n)])
+def test_chain_with_injected_noise_matches_reference(name, use_graph):
+    cfg, K, xh_phar, xh_pocket, z_steps, st = run_chain(name, use_graph)
+    want = G4[name + '/xh_phar']
+    scale = max(1.0, float(np.abs(want[:, :3]).max()))
+    if name + '/z_steps' in G4:
+        zs = G4[name + '/z_steps']
+        for k in range(K):
+            e = float(np.abs(z_steps[k] - zs[k]).max())
+            assert e <= 1e-4 * max(1.0, float(np.abs(zs[k]).max())), f'step {k}: {e:.3e}'
+    assert rms(xh_phar[:, :3], want[:, :3]) <= 1e-4 * scale
+    assert np.array_equal(xh_phar[:, 3:], want[:, 3:])
+    wp = G4[name + '/xh_pocket']
+    assert rms(xh_pocket, wp) <= 1e-4 * max(1.0, float(np.abs(wp).max()))
+    assert st['max_rel_com_error'] < 1e-2 and st['nan_resets'] == 0
+
+
+def _philox_chain(h, pb, K, ids=None, seed=1234, use_graph=True):
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    out = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=None, seed=seed, pocket_ids=ids, use_graph=use_graph)
+    st = h.chain_status()
+    return out[0].cpu().numpy(), out[1].cpu().numpy(), st
+
+
+def test_full_size_batch_properties():
+    """BASELINE config shape (64 C-alpha pockets, H=256, L=5), on-device Philox noise, 25 steps:
+    size-independent properties - zero phar COM per sample, valid one-hot rows, pocket rigidly
+    translated, counters consistent, graph replay == eager launches."""
+    cfg = ModelConfig(timesteps=500)
+    sd = make_state_dict(cfg, seed=0)
+    h = handle_for(cfg, 'seed0', sd)
+    pb = make_pockets(64, 'CA', n_phar=15)
+    K = 25
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    h.reset_counters()
+    xg, pg, st = _philox_chain(h, pb, K, use_graph=True)
+    c = h.counters()
+    assert c['evaluations'] == K + 1 and c['nodes'] == (K + 1) * (64 * 59)
+    assert c['edges'] >= c['edges_phar'] >= (K + 1) * 64 * 15       # at least the self loops
+    assert st['max_rel_com_error'] < 1e-2 and st['nan_resets'] == 0
+    assert np.isfinite(xg).all()
+    oh = xg[:, 3:]
+    assert np.all((oh == 0) | (oh == 1)) and np.all(oh.sum(1) == 1)
+    pm = np.repeat(np.arange(64), 15)
+    for b in range(64):
+        assert np.abs(xg[pm == b, :3].sum(0)).max() < 5e-2           # CoG drift bound the reference enforces
+        shift = pg[pb.mask == b, :3] - pb.x[pb.mask == b]
+        assert np.abs(shift - shift[0]).max() < 1e-3 * max(1.0, np.abs(shift).max())   # rigid translation
+        assert np.array_equal(pg[pb.mask == b, 3:], pb.one_hot[pb.mask == b])
+    xe, pe, _ = _philox_chain(h, pb, K, use_graph=False)
+    assert np.abs(xe[:, :3] - xg[:, :3]).max() <= 1e-4 * max(1.0, np.abs(xg[:, :3]).max())
+    assert np.array_equal(xe[:, 3:], xg[:, 3:])
+
+
+def test_sharding_independence():
+    """Pockets shard embarrassingly: two shards keyed by global pocket ids reproduce the full batch."""
+    cfg = ModelConfig(timesteps=500)
+    sd = make_state_dict(cfg, seed=0)
+    h = handle_for(cfg, 'seed0', sd)
+    K = 6
+    full = make_pockets(8, 'CA', ragged=True)
+    xf, pf, _ = _philox_chain(h, full, K, ids=full.pocket_index)
+    a = make_pockets(4, 'CA', ragged=True, first_index=0)
+    b = make_pockets(4, 'CA', ragged=True, first_index=4)
+    xa, _, _ = _philox_chain(h, a, K, ids=a.pocket_index)
+    xb, _, _ = _philox_chain(h, b, K, ids=b.pocket_index)
+    xs = np.concatenate([xa, xb])
+    assert xs.shape == xf.shape
+    assert np.abs(xs[:, :3] - xf[:, :3]).max() <= 1e-4 * max(1.0, np.abs(xf[:, :3]).max())
+    assert np.array_equal(xs[:, 3:], xf[:, 3:])
+
+
+def test_python_interface_matches_reference_chain():
+    """The reference-shaped Python API (ConditionalDDPM.sample_given_pocket) on a golden chain."""
+    from cmdgen_amd.equivariant_diffusion.dynamics import EGNNDynamics
+    from cmdgen_amd.equivariant_diffusion.conditional_model import ConditionalDDPM
+    name = 'ca_h256_K5'
+    cfg, sd, pb, K = chain_case(G4, name)
+    hist = np.ones((30, 70))
+    dyn = EGNNDynamics(phar_nf=cfg.phar_nf, residue_nf=cfg.residue_nf, n_dims=3, joint_nf=cfg.joint_nf,
+                       hidden_nf=cfg.hidden_nf, n_layers=cfg.n_layers, attention=True, tanh=True,
+                       norm_constant=1, inv_sublayers=1, sin_embedding=False, normalization_factor=100,
+                       aggregation_method='sum', edge_cutoff=6.0, update_pocket_coords=False)
+    ddpm = ConditionalDDPM(dynamics=dyn, phar_nf=cfg.phar_nf, residue_nf=cfg.residue_nf, n_dims=3,
+                           timesteps=cfg.timesteps, noise_schedule='polynomial_2', noise_precision=1e-5,
+                           loss_type='l2', norm_values=[1, 4], size_histogram=hist)
+    ddpm.load_state_dict({k[len('ddpm.'):]: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    ddpm = ddpm.cuda()
+    pocket = {'x': dev(pb.x), 'one_hot': dev(pb.one_hot), 'size': dev(pb.size), 'mask': dev(pb.mask)}
+    xh_phar, xh_pocket, phar_mask, pocket_mask = ddpm.sample_given_pocket(
+        pocket, torch.from_numpy(pb.num_nodes_phar), timesteps=K, noise=dev(G4[name + '/noise']))
+    want = G4[name + '/xh_phar']
+    assert np.array_equal(phar_mask.cpu().numpy(), G4[name + '/phar_mask'])
+    assert rms(xh_phar[:, :3].cpu().numpy(), want[:, :3]) <= 1e-4 * max(1.0, float(np.abs(want[:, :3]).max()))
+    assert np.array_equal(xh_phar[:, 3:].cpu().numpy(), want[:, 3:])
+    # EGNNDynamics.forward through the module interface on the chain's last state is covered by
+    # test_dynamics_forward_*; here check the module-level forward agrees with the handle-level one.
+    g = G2
+    c2, sd2, inp = dynamics_case(g, 'ca_h256_b3')
+    dyn.load_state_dict({k[len('ddpm.dynamics.'):]: torch.from_numpy(v) for k, v in sd2.items()
+                         if k.startswith('ddpm.dynamics.')})
+    e1, e2 = dyn(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']), dev(inp['mask_phar']), dev(inp['mask_pocket']))
+    wantp = g['ca_h256_b3/eps_phar']
+    assert float(np.abs(e1.cpu().numpy() - wantp).max()) <= EVAL_TOL * max(1.0, float(np.abs(wantp).max()))
+    assert np.array_equal(dyn.get_edges().numpy(), g['ca_h256_b3/edges'].astype(np.int64))
+
+
+def test_errors_are_loud():
+    with pytest.raises(hip_backend.CmdgenError):
+        hip_backend.Handle(ModelConfig(hidden_nf=32).as_dict(), 0)      # unsupported width
+    h = hip_backend.Handle(ModelConfig(hidden_nf=64, n_layers=1).as_dict(), 0)
+    with pytest.raises(hip_backend.CmdgenError):
+        h.set_layout([3], [10])
+        h.dynamics_forward(torch.zeros(3, 11).cuda(), torch.zeros(10, 23).cuda(), torch.zeros(1).cuda())  # no weights
