@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -123,6 +124,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     Layout lay; Work w; Dims d; SmallW sw;
     const LayerW* layers;       // host array [L]
     int edge_grid;              // workgroups of the persistent-style edge kernels
+    std::vector<hipEvent_t>* msg_events;   // when non-null: event pair around every edge-message launch
 };
 
 // ---------------------------------------------------------------------------------

@@ -612,7 +612,9 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     for (int l = 0; l < a.d.L; ++l) {
         const int has_next = l + 1 < a.d.L;
         REC();
+        if (a.msg_events) { hipEvent_t e0; hipEventCreate(&e0); hipEventRecord(e0, s); a.msg_events->push_back(e0); }
         hipLaunchKernelGGL(k_edge_msg<H>, dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);
+        if (a.msg_events) { hipEvent_t e1; hipEventCreate(&e1); hipEventRecord(e1, s); a.msg_events->push_back(e1); }
         REC(); REC();
         hipLaunchKernelGGL(k_node<H>, dim3(ntile_nodes), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
                            a.layers[has_next ? l + 1 : l], l, has_next);

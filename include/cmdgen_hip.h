@@ -184,6 +184,13 @@ int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar, const floa
 int cmdgen_time_edge_kernel(cmdgen_handle* h, int32_t layer, int32_t reps, float* mean_ms,
                             cmdgen_stream stream);
 
+/* Per-launch timing of the dominant kernel (edge message) inside a real chain: while enabled,
+ * every eager (use_graph = 0) launch of that kernel is bracketed by a hipEvent pair on the
+ * launch stream.  cmdgen_get_edge_profile synchronises, returns the summed duration and the
+ * number of launches since the last call, and clears the record. */
+int cmdgen_set_edge_profiling(cmdgen_handle* h, int32_t on);
+int cmdgen_get_edge_profile(cmdgen_handle* h, float* total_ms, int64_t* launches, cmdgen_stream stream);
+
 #ifdef __cplusplus
 }
 #endif
