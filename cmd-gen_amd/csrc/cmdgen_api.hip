@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -51,6 +52,8 @@ struct cmdgen_handle {
     Work work{};
     int64_t ecap = 0, eccap = 0;
     int edge_grid = 512;
+    int n_cus = 256;
+    int node_mt = 64, edge_mt = 64, coord_mt = 64;   // rows per tile, chosen in cmdgen_set_layout
     int64_t* d_gid = nullptr;
     // chain
     std::vector<void*> chain_allocs;
@@ -120,7 +123,8 @@ extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle
     d.cutoff2 = cfg->edge_cutoff < 0.f ? -1.f : cfg->edge_cutoff * cfg->edge_cutoff;
     d.norm_constant = cfg->norm_constant; d.norm_factor = cfg->normalization_factor; d.coords_range = cfg->coords_range;
     d.norm_x = cfg->norm_x; d.norm_h = cfg->norm_h; d.bias_h = cfg->bias_h;
-    h->edge_grid = 2 * prop.multiProcessorCount;      // two 66 KB-LDS workgroups per CU
+    h->n_cus = prop.multiProcessorCount;
+    h->edge_grid = 2 * prop.multiProcessorCount;      // two 66 KB-LDS workgroups per CU at 64-row tiles
     *out = h;
     return CMDGEN_OK;
 }
@@ -175,6 +179,28 @@ static std::vector<float> pack_frag(const float* W, int out, int ld, int c0, int
     return p;
 }
 
+// same matrix in v_mfma_f32_16x16x4_f32 fragment order (16-row tiles)
+static std::vector<float> pack_frag16(const float* W, int out, int ld, int c0, int in) {
+    const int NT = out / 16, KB = in / 16;
+    std::vector<float> p((size_t)NT * KB * 64 * 4);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j)
+                    p[(((size_t)nt * KB + kb) * 64 + lane) * 4 + j] =
+                        W[(size_t)(16 * nt + (lane & 15)) * ld + c0 + 16 * kb + 4 * (lane >> 4) + j];
+    return p;
+}
+
+static int upload_pack(cmdgen_handle* h, const float* W, int out, int in, WPack* wp) {
+    const float* dp;
+    std::vector<float> p = pack_frag(W, out, in, 0, in);
+    int r = upload(h, p, &dp); if (r) return r; wp->w32 = (const float4*)dp;
+    p = pack_frag16(W, out, in, 0, in);
+    r = upload(h, p, &dp); if (r) return r; wp->w16 = (const float4*)dp;
+    return 0;
+}
+
 extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
     if (!h) return CMDGEN_EINVAL;
     hipSetDevice(h->device);
@@ -197,7 +223,13 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
     GET(dy + "residue_encoder.2.weight", d.J * 2 * d.R); UP(s.re2_w); GET(dy + "residue_encoder.2.bias", d.J); UP(s.re2_b);
     GET(dy + "residue_decoder.0.weight", 2 * d.R * d.J); UP(s.rd0_w); GET(dy + "residue_decoder.0.bias", 2 * d.R); UP(s.rd0_b);
     GET(dy + "residue_decoder.2.weight", d.R * 2 * d.R); UP(s.rd2_w); GET(dy + "residue_decoder.2.bias", d.R); UP(s.rd2_b);
-    GET(dy + "egnn.embedding.weight", H * d.dyn); UP(s.emb_w); GET(dy + "egnn.embedding.bias", H); UP(s.emb_b);
+    {   // embedding [H][dyn] -> transposed [dyn][H]
+        GET(dy + "egnn.embedding.weight", H * d.dyn);
+        std::vector<float> t((size_t)H * d.dyn);
+        for (int c = 0; c < H; ++c) for (int k = 0; k < d.dyn; ++k) t[(size_t)k * H + c] = (*v)[(size_t)c * d.dyn + k];
+        rc = upload(h, t, &s.emb_wT); if (rc) return rc;
+        GET(dy + "egnn.embedding.bias", H); UP(s.emb_b);
+    }
     {   // embedding_out [dyn][H] -> transposed [H][dyn]
         GET(dy + "egnn.embedding_out.weight", d.dyn * H);
         std::vector<float> t((size_t)H * d.dyn);
@@ -210,7 +242,7 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
         LayerW lw{};
         const std::string g = dy + "egnn.e_block_" + std::to_string(b) + ".gcl_0.";
         const std::string c = dy + "egnn.e_block_" + std::to_string(b) + ".gcl_equiv.";
-        auto split_first = [&](const std::string& wname, const std::string& bname, const float4** Wpq,
+        auto split_first = [&](const std::string& wname, const std::string& bname, WPack* Wpq,
                                const float** bias, const float** wr, const float** wd) -> int {
             const std::vector<float>* w; int r = get_w(h, wname, (size_t)H * ld1, &w); if (r) return r;
             // stack [A ; B] as a [2H][H] matrix: rows 0..H-1 = columns 0..H-1 (h_row), rows H.. = columns H..2H-1 (h_col)
@@ -223,16 +255,14 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
                 }
                 vr[o] = (*w)[(size_t)o * ld1 + 2 * H]; vd[o] = (*w)[(size_t)o * ld1 + 2 * H + 1];
             }
-            std::vector<float> p = pack_frag(AB.data(), 2 * H, H, 0, H);
-            const float* dp; r = upload(h, p, &dp); if (r) return r; *Wpq = (const float4*)dp;
+            r = upload_pack(h, AB.data(), 2 * H, H, Wpq); if (r) return r;
             r = upload(h, vr, wr); if (r) return r; r = upload(h, vd, wd); if (r) return r;
             const std::vector<float>* bb; r = get_w(h, bname, H, &bb); if (r) return r;
             return upload(h, *bb, bias);
         };
-        auto square = [&](const std::string& wname, int in, const float4** Wp) -> int {
+        auto square = [&](const std::string& wname, int in, WPack* Wp) -> int {
             const std::vector<float>* w; int r = get_w(h, wname, (size_t)H * in, &w); if (r) return r;
-            std::vector<float> p = pack_frag(w->data(), H, in, 0, in);
-            const float* dp; r = upload(h, p, &dp); if (r) return r; *Wp = (const float4*)dp; return 0;
+            return upload_pack(h, w->data(), H, in, Wp);
         };
         rc = split_first(g + "edge_mlp.0.weight", g + "edge_mlp.0.bias", &lw.Wpq_e, &lw.b1, &lw.wr_e, &lw.wd_e); if (rc) return rc;
         rc = square(g + "edge_mlp.2.weight", H, &lw.W2); if (rc) return rc;
@@ -315,6 +345,24 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
     ALLOC(w.eps_tmp, float, (size_t)Nl * (3 + d.P), true);
 #undef ALLOC
     h->ecap = ecap; h->eccap = eccap;
+    {   // Rows per tile: the largest tile that still gives every CU a few workgroups.  Edge counts
+        // are only known on the device, so they are estimated from the layout (C-alpha pockets
+        // have ~6 neighbours within 6 A, full-atom ones ~36; a phar node keeps >= its self loop).
+        double e_est = 0.0, ec_est = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const double n = (double)(nph[b] + npk[b]);
+            const double deg = h->cfg.edge_cutoff < 0.f ? n : (n <= 128.0 ? 6.0 : 36.0);
+            e_est += n * (deg < n ? deg : n);
+            ec_est += (double)nph[b] * (deg < n ? deg : n) * 0.5;
+        }
+        auto pick = [&](double rows) { return rows / 64.0 >= 3.0 * h->n_cus ? 64 : (rows / 32.0 >= 2.0 * h->n_cus ? 32 : 16); };
+        h->node_mt = pick((double)N); h->edge_mt = pick(e_est); h->coord_mt = pick(ec_est);
+        const char* ev;
+        if ((ev = getenv("CMDGEN_NODE_MT"))) h->node_mt = atoi(ev);
+        if ((ev = getenv("CMDGEN_EDGE_MT"))) h->edge_mt = atoi(ev);
+        if ((ev = getenv("CMDGEN_COORD_MT"))) h->coord_mt = atoi(ev);
+        for (int* m : {&h->node_mt, &h->edge_mt, &h->coord_mt}) if (*m != 64 && *m != 32 && *m != 16) *m = 64;
+    }
     h->cur_nphar.assign(nph, nph + B); h->cur_npocket.assign(npk, npk + B);
     h->have_layout = true;
     return CMDGEN_OK;
@@ -331,6 +379,7 @@ static EvalLaunch make_launch(cmdgen_handle* h) {
     EvalLaunch a; a.lay = h->lay; a.w = h->work; a.d = h->dims; a.sw = h->small; a.layers = h->layers.data();
     a.edge_grid = h->edge_grid;
     a.msg_events = nullptr;
+    a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     return a;
 }
 

@@ -9,7 +9,6 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define CMDGEN_TILE 64          // rows (edges or nodes) per workgroup tile
 #define CMDGEN_MAX_LAYERS 16
 #define CMDGEN_MAX_SMALL 64     // upper bound for phar_nf*2, residue_nf*2, joint_nf+1
 
@@ -26,27 +25,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // (0,4),(1,5),(2,6),(3,7): a fixed re-association of the fp32 dot product.
 // ---------------------------------------------------------------------------------
 
+struct WPack {                  // one Linear weight in both MFMA fragment orders (see above / below)
+    const float4* w32;          // v_mfma_f32_32x32x2_f32 order  (64- and 32-row tiles)
+    const float4* w16;          // v_mfma_f32_16x16x4_f32 order  (16-row tiles)
+};
+
 struct LayerW {                 // device pointers to one EquivariantBlock's packed weights
     // GCL.edge_mlp (egnn_new.py:15-19): layer 0 split by input columns [h_row | h_col | radial | d0]
-    const float4* Wpq_e;        // [2H out][H in]: rows 0..H-1 act on h_row (-> P), H..2H-1 on h_col (-> Q)
+    WPack Wpq_e;                // [2H out][H in]: rows 0..H-1 act on h_row (-> P), H..2H-1 on h_col (-> Q)
     const float*  b1;           // folded into P
     const float*  wr_e;         // column 2H   (radial)
     const float*  wd_e;         // column 2H+1 (d0)
-    const float4* W2;           // edge_mlp.2 [H][H]
+    WPack W2;                   // edge_mlp.2 [H][H]
     const float*  b2;
     const float*  wa;           // att_mlp.0 weight [H]
     float         ba;
     // GCL.node_mlp (egnn_new.py:21-24)
-    const float4* W3;           // node_mlp.0 [H][2H]  (in = [h | agg])
+    WPack W3;                   // node_mlp.0 [H][2H]  (in = [h | agg])
     const float*  b3;
-    const float4* W4;           // node_mlp.2 [H][H]
+    WPack W4;                   // node_mlp.2 [H][H]
     const float*  b4;
     // EquivariantUpdate.coord_mlp (egnn_new.py:78-83)
-    const float4* Wpq_c;        // coord_mlp.0 split like Wpq_e
+    WPack Wpq_c;                // coord_mlp.0 split like Wpq_e
     const float*  b6;
     const float*  wr_c;
     const float*  wd_c;
-    const float4* W7;           // coord_mlp.2 [H][H]
+    WPack W7;                   // coord_mlp.2 [H][H]
     const float*  b7;
     const float*  w5;           // coord_mlp.4 weight [H], no bias
 };
@@ -56,7 +60,7 @@ struct SmallW {                 // encoders / decoders / embeddings, plain [out]
     const float *pd0_w, *pd0_b, *pd2_w, *pd2_b;     // phar_decoder   (:27-31)
     const float *re0_w, *re0_b, *re2_w, *re2_b;     // residue_encoder (:33-37)
     const float *rd0_w, *rd0_b, *rd2_w, *rd2_b;     // residue_decoder (:39-43)
-    const float *emb_w, *emb_b;                     // egnn.embedding      [H][J+1]
+    const float *emb_wT, *emb_b;                    // egnn.embedding, stored transposed [J+1][H]
     const float *embo_wT, *embo_b;                  // egnn.embedding_out, stored transposed [H][J+1]
 };
 
@@ -124,6 +128,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     Layout lay; Work w; Dims d; SmallW sw;
     const LayerW* layers;       // host array [L]
     int edge_grid;              // workgroups of the persistent-style edge kernels
+    int node_mt, edge_mt, coord_mt;   // rows per tile (64, 32 or 16) chosen per launch from the row counts
     std::vector<hipEvent_t>* msg_events;   // when non-null: event pair around every edge-message launch
 };
 
@@ -140,92 +145,146 @@ __device__ __forceinline__ float dist2(const float4& a, const float4& b) {
     return dx * dx + dy * dy + dz * dz;
 }
 
-// 64x64 output block per wave: acc[mt][nt] are 32x32 tiles; rows of A come from LDS
-// (row stride lda floats, 16-byte aligned rows), columns from the packed weight Wp.
-// KB k-blocks of 8 starting at kb0 of a matrix with kb_total k-blocks; n-tiles nt0, nt0+1.
-// Weight fragments are fetched two k-blocks ahead straight from L2 into registers.
-template <int KB>
-__device__ __forceinline__ void mfma_tile_64x64(const float* __restrict__ ldsA, int lda,
-                                                const float4* __restrict__ Wp, int kb_total,
-                                                int kb0, int nt0, f32x16 (&acc)[2][2]) {
+// ---------------------------------------------------------------------------------
+// Tile GEMM: a workgroup owns MT rows (MT = 64, 32 or 16) and wave w owns 64 output columns.
+//   MT = 64 / 32: v_mfma_f32_32x32x2_f32, MT/32 x 2 tiles of 32x32 per wave (64 cycles each)
+//   MT = 16     : v_mfma_f32_16x16x4_f32, 1 x 4 tiles of 16x16 per wave (32 cycles each) - used
+//                 when a launch has too few rows to fill 256 CUs with bigger tiles.
+// Rows of A come from LDS (row stride lda floats, 16-byte aligned), weights stream from L2 in
+// fragment order two k-blocks ahead of their use (pinned with sched_barrier so hipcc cannot
+// sink the prefetches back down to their uses; it still places the counted s_waitcnt).
+//
+// 16x16x4 fragment order: Wp16[(nt*KB16 + kb)*64 + lane] = { W[o][k..k+3] },
+//   o = 16*nt + (lane & 15), k = 16*kb + 4*(lane >> 4): step j pairs k-slot g = lane>>4 with
+//   k = 16kb + 4g + j, and the A row is read with one ds_read_b128 at the same k.
+// ---------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int MT> struct TileAcc;
+template <> struct TileAcc<64> { f32x16 a[2][2]; };
+template <> struct TileAcc<32> { f32x16 a[1][2]; };
+template <> struct TileAcc<16> { f32x4v a[4]; };
+
+template <int MT>
+__device__ __forceinline__ void acc_zero(TileAcc<MT>& acc) {
+    if constexpr (MT == 16) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.a[n][r] = 0.0f;
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT / 32; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.a[m][n][r] = 0.0f;
+    }
+}
+
+// C/D layouts (cdna guide section 3):
+//   32x32: lane l, reg r -> row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31
+//   16x16: lane l, reg r -> row = 4 * (l >> 4) + r,                      col = l & 15
+template <int MT, class F>
+__device__ __forceinline__ void acc_foreach(const TileAcc<MT>& acc, int wave, F f) {
     const int lane = threadIdx.x & 63;
-    const float* a0p = ldsA + (lane & 31) * lda + (lane >> 5) * 4;
-    const float* a1p = a0p + 32 * lda;
-    const float4* b0p = Wp + ((size_t)nt0 * kb_total + kb0) * 64 + lane;
-    const float4* b1p = Wp + ((size_t)(nt0 + 1) * kb_total + kb0) * 64 + lane;
+    if constexpr (MT == 16) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f(4 * (lane >> 4) + r, wave * 64 + n * 16 + (lane & 15), acc.a[n][r]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT / 32; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    f(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), wave * 64 + n * 32 + (lane & 31), acc.a[m][n][r]);
+    }
+}
 
-    float4 bA0 = b0p[0], bA1 = b1p[0];
-    float4 bB0 = b0p[64], bB1 = b1p[64];
-    float4 aA0 = *reinterpret_cast<const float4*>(a0p);
-    float4 aA1 = *reinterpret_cast<const float4*>(a1p);
+#define CMDGEN_MFMA32(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, ACC, 0, 0, 0)
+#define CMDGEN_MFMA16(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, ACC, 0, 0, 0)
 
-#define CMDGEN_MFMA4(A0, A1, B0, B1)                                                         \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x, B0.x, acc[0][0], 0, 0, 0);        \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x, B1.x, acc[0][1], 0, 0, 0);        \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x, B0.x, acc[1][0], 0, 0, 0);        \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x, B1.x, acc[1][1], 0, 0, 0);        \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.y, B0.y, acc[0][0], 0, 0, 0);        \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.y, B1.y, acc[0][1], 0, 0, 0);        \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.y, B0.y, acc[1][0], 0, 0, 0);        \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.y, B1.y, acc[1][1], 0, 0, 0);        \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.z, B0.z, acc[0][0], 0, 0, 0);        \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.z, B1.z, acc[0][1], 0, 0, 0);        \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.z, B0.z, acc[1][0], 0, 0, 0);        \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.z, B1.z, acc[1][1], 0, 0, 0);        \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.w, B0.w, acc[0][0], 0, 0, 0);        \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.w, B1.w, acc[0][1], 0, 0, 0);        \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.w, B0.w, acc[1][0], 0, 0, 0);        \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.w, B1.w, acc[1][1], 0, 0, 0);
-
-    static_assert(KB % 2 == 0, "KB must be even");
-    // Software pipeline, pinned with sched_barrier so hipcc cannot sink the prefetches back
-    // down to their uses: while the 16 MFMAs (1024 cycles) of block kb run, the weight
-    // fragments of block kb+2 (L2, ~500-900 cycles) and the A rows of block kb+1 (LDS) are
-    // in flight.  The compiler still places the counted s_waitcnt at the first use.
+// KB8 = k extent in blocks of 8; cg = index of this wave's 64-column group in the weight matrix.
+template <int MT, int KB8>
+__device__ __forceinline__ void tile_gemm(const float* __restrict__ ldsA, int lda, const WPack& W,
+                                          int kb_total8, int kb0_8, int cg, TileAcc<MT>& acc) {
+    const int lane = threadIdx.x & 63;
+    if constexpr (MT == 16) {
+        constexpr int KB = KB8 / 2;                      // k-blocks of 16
+        static_assert(KB >= 2 && KB % 2 == 0, "K must be a multiple of 32");
+        const int kbt = kb_total8 / 2, kb0 = kb0_8 / 2;
+        const float* ap = ldsA + (lane & 15) * lda + (lane >> 4) * 4;
+        const float4* bp = W.w16 + ((size_t)(4 * cg) * kbt + kb0) * 64 + lane;
+        const size_t ns = (size_t)kbt * 64;              // stride between n-tiles
+        float4 bA[4], bB[4], bC[4], bD[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { bA[n] = bp[n * ns]; bB[n] = bp[n * ns + 64]; }
+        float4 aA = *reinterpret_cast<const float4*>(ap), aB;
+#define STEP16(AV, BV)                                                                        \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.x, BV[n].x);  \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.y, BV[n].y);  \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.z, BV[n].z);  \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.w, BV[n].w);
 #pragma unroll 1
-    for (int kb = 0; kb < KB; kb += 2) {
-        const int k2 = (kb + 2 < KB) ? kb + 2 : KB - 1;     // clamped: the tail re-reads valid memory
-        const int k3 = (kb + 3 < KB) ? kb + 3 : KB - 1;
-        float4 bC0 = b0p[k2 * 64], bC1 = b1p[k2 * 64];
-        float4 aB0 = *reinterpret_cast<const float4*>(a0p + (kb + 1) * 8);
-        float4 aB1 = *reinterpret_cast<const float4*>(a1p + (kb + 1) * 8);
-        __builtin_amdgcn_sched_barrier(0);
-        CMDGEN_MFMA4(aA0, aA1, bA0, bA1)
-        __builtin_amdgcn_sched_barrier(0);
-        float4 bD0 = b0p[k3 * 64], bD1 = b1p[k3 * 64];
-        aA0 = *reinterpret_cast<const float4*>(a0p + k2 * 8);
-        aA1 = *reinterpret_cast<const float4*>(a1p + k2 * 8);
-        __builtin_amdgcn_sched_barrier(0);
-        CMDGEN_MFMA4(aB0, aB1, bB0, bB1)
-        __builtin_amdgcn_sched_barrier(0);
-        bA0 = bC0; bA1 = bC1; bB0 = bD0; bB1 = bD1;
+        for (int kb = 0; kb < KB; kb += 2) {
+            const int k2 = (kb + 2 < KB) ? kb + 2 : KB - 1;   // clamped: the tail re-reads valid memory
+            const int k3 = (kb + 3 < KB) ? kb + 3 : KB - 1;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bC[n] = bp[n * ns + k2 * 64];
+            aB = *reinterpret_cast<const float4*>(ap + (kb + 1) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            STEP16(aA, bA)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bD[n] = bp[n * ns + k3 * 64];
+            aA = *reinterpret_cast<const float4*>(ap + k2 * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            STEP16(aB, bB)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { bA[n] = bC[n]; bB[n] = bD[n]; }
+        }
+#undef STEP16
+    } else {
+        constexpr int NMT = MT / 32;
+        constexpr int KB = KB8;
+        static_assert(KB % 2 == 0, "KB must be even");
+        const float* a0p = ldsA + (lane & 31) * lda + (lane >> 5) * 4;
+        const float4* b0p = W.w32 + ((size_t)(2 * cg) * kb_total8 + kb0_8) * 64 + lane;
+        const float4* b1p = b0p + (size_t)kb_total8 * 64;
+        float4 bA0 = b0p[0], bA1 = b1p[0], bB0 = b0p[64], bB1 = b1p[64];
+        float4 aA[NMT], aB[NMT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) aA[m] = *reinterpret_cast<const float4*>(a0p + m * 32 * lda);
+#define STEP32(AV, B0, B1)                                                                    \
+        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].x, B0.x); CMDGEN_MFMA32(acc.a[m][1], AV[m].x, B1.x); } \
+        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].y, B0.y); CMDGEN_MFMA32(acc.a[m][1], AV[m].y, B1.y); } \
+        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].z, B0.z); CMDGEN_MFMA32(acc.a[m][1], AV[m].z, B1.z); } \
+        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].w, B0.w); CMDGEN_MFMA32(acc.a[m][1], AV[m].w, B1.w); }
+#pragma unroll 1
+        for (int kb = 0; kb < KB; kb += 2) {
+            const int k2 = (kb + 2 < KB) ? kb + 2 : KB - 1;
+            const int k3 = (kb + 3 < KB) ? kb + 3 : KB - 1;
+            float4 bC0 = b0p[k2 * 64], bC1 = b1p[k2 * 64];
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) aB[m] = *reinterpret_cast<const float4*>(a0p + m * 32 * lda + (kb + 1) * 8);
+            __builtin_amdgcn_sched_barrier(0);
+            STEP32(aA, bA0, bA1)
+            __builtin_amdgcn_sched_barrier(0);
+            float4 bD0 = b0p[k3 * 64], bD1 = b1p[k3 * 64];
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) aA[m] = *reinterpret_cast<const float4*>(a0p + m * 32 * lda + k2 * 8);
+            __builtin_amdgcn_sched_barrier(0);
+            STEP32(aB, bB0, bB1)
+            __builtin_amdgcn_sched_barrier(0);
+            bA0 = bC0; bA1 = bC1; bB0 = bD0; bB1 = bD1;
+        }
+#undef STEP32
     }
-#undef CMDGEN_MFMA4
 }
-
-__device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][2]) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-}
-
-// C/D layout of the 32x32 MFMA: lane l, register r hold
-//   row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),  col = l & 31   (cdna guide section 3)
-#define CMDGEN_ACC_FOREACH(wave, BODY)                                                      \
-    {                                                                                        \
-        const int _lane = threadIdx.x & 63;                                                  \
-        _Pragma("unroll") for (int _m = 0; _m < 2; ++_m)                                     \
-        _Pragma("unroll") for (int _n = 0; _n < 2; ++_n)                                     \
-        _Pragma("unroll") for (int _r = 0; _r < 16; ++_r) {                                  \
-            const int row = _m * 32 + (_r & 3) + 8 * (_r >> 2) + 4 * (_lane >> 5);           \
-            const int col = (wave) * 64 + _n * 32 + (_lane & 31);                            \
-            const float v = acc[_m][_n][_r];                                                    \
-            BODY                                                                             \
-        }                                                                                    \
-    }
 
 // Philox4x32-10 (Salmon et al. 2011), counter-based: results depend only on (key, counter).
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

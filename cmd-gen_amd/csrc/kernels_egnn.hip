@@ -9,10 +9,11 @@
 //                  k_edge_coord EquivariantUpdate.coord_model          (egnn_new.py:87-104)
 //   k_readout      embedding_out, decoders, velocity, NaN flag       (dynamics.py:110-139)
 //
-// Tiling: a workgroup owns 64 rows (edges or nodes) and all H output columns; wave w owns
-// columns [64w, 64w+64) as 2x2 MFMA 32x32 tiles, so the block has H/64 waves.  The A
-// operand (rows x H) lives in LDS with a 4-float row pad (conflict-free ds_read_b128);
-// the B operand (weights) streams from L2 in MFMA fragment order (cmdgen_dev.h).
+// Tiling: a workgroup owns MT rows (edges or nodes; MT = 64, 32 or 16, chosen per launch so
+// that even a 64-pocket batch spreads over all 256 CUs) and all H output columns; wave w owns
+// columns [64w, 64w+64), so the block has H/64 waves.  The A operand (rows x H) lives in LDS
+// with a 4-float row pad (conflict-free ds_read_b128); the B operand (weights) streams from
+// L2 in MFMA fragment order (cmdgen_dev.h).
 #include "cmdgen_dev.h"
 
 #define LDA(H) ((H) + 4)
@@ -153,68 +154,66 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
 // ------------------------------------------------------------------------------------
 // shared pieces of the tile kernels
 // ------------------------------------------------------------------------------------
-// out[row][col] = acc + bias (bias may be null) for rows < nvalid; two 128-byte segments
-// per store instruction (lanes 0-31 one row, 32-63 another).
-template <int H>
-__device__ __forceinline__ void store_acc_rows(f32x16 (&acc)[2][2], int wave, float* __restrict__ out,
+// out[row][col] = acc + bias (bias may be null) for rows < nvalid
+template <int H, int MT>
+__device__ __forceinline__ void store_acc_rows(const TileAcc<MT>& acc, int wave, float* __restrict__ out,
                                                int row0, int nvalid, const float* __restrict__ bias) {
-    CMDGEN_ACC_FOREACH(wave, {
+    acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
         if (row < nvalid) out[(size_t)(row0 + row) * H + col] = v + (bias ? bias[col] : 0.f);
-    })
+    });
 }
 
-// P|Q = BUF x Wpq^T for a 64-row tile already resident in LDS: two passes of H columns.
-template <int H>
-__device__ __forceinline__ void tile_project_pq(const float* buf, const float4* __restrict__ Wpq,
+// P|Q = BUF x Wpq^T for an MT-row tile already resident in LDS: two passes of H columns.
+template <int H, int MT>
+__device__ __forceinline__ void tile_project_pq(const float* buf, const WPack& Wpq,
                                                 const float* __restrict__ bias_p, float* __restrict__ Pout,
                                                 float* __restrict__ Qout, int row0, int nvalid,
                                                 bool want_p) {
     const int wave = threadIdx.x >> 6;
-    f32x16 acc[2][2];
+    TileAcc<MT> acc;
     if (want_p) {
-        acc_zero(acc);
-        mfma_tile_64x64<H / 8>(buf, LDA(H), Wpq, H / 8, 0, 2 * wave, acc);
-        store_acc_rows<H>(acc, wave, Pout, row0, nvalid, bias_p);
+        acc_zero<MT>(acc);
+        tile_gemm<MT, H / 8>(buf, LDA(H), Wpq, H / 8, 0, wave, acc);
+        store_acc_rows<H, MT>(acc, wave, Pout, row0, nvalid, bias_p);
     }
-    acc_zero(acc);
-    mfma_tile_64x64<H / 8>(buf, LDA(H), Wpq, H / 8, 0, H / 32 + 2 * wave, acc);
-    store_acc_rows<H>(acc, wave, Qout, row0, nvalid, nullptr);
+    acc_zero<MT>(acc);
+    tile_gemm<MT, H / 8>(buf, LDA(H), Wpq, H / 8, 0, H / 64 + wave, acc);
+    store_acc_rows<H, MT>(acc, wave, Qout, row0, nvalid, nullptr);
 }
 
 // ------------------------------------------------------------------------------------
-// k_embed: h0 = embedding([encoder(features) | t]) for a 64-node tile, then P/Q of block 0.
+// k_embed: h0 = embedding([encoder(features) | t]) for an MT-node tile, then P/Q of block 0.
 // Encoders are tiny (8->16->32, R->2R->32): plain FMA loops through LDS.
 // ------------------------------------------------------------------------------------
-template <int H>
+template <int H, int MT>
 __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW sw, LayerW lw0,
                                              const float* __restrict__ xh_phar,
                                              const float* __restrict__ xh_pocket,
                                              const float* __restrict__ t_arr,
                                              const float4* __restrict__ coef, const ChainState* chain) {
-    __shared__ __attribute__((aligned(16))) float buf[CMDGEN_TILE * LDA(H)];
-    __shared__ float s_in[CMDGEN_TILE][CMDGEN_MAX_SMALL];
-    __shared__ float s_h1[CMDGEN_TILE][CMDGEN_MAX_SMALL];
-    __shared__ float s_h2[CMDGEN_TILE][CMDGEN_MAX_SMALL + 1];
+    __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
+    __shared__ float s_in[MT][CMDGEN_MAX_SMALL];
+    __shared__ float s_h1[MT][CMDGEN_MAX_SMALL];
+    __shared__ float s_h2[MT][CMDGEN_MAX_SMALL + 1];
     const int tid = threadIdx.x, nthr = H;
-    const int row0 = blockIdx.x * CMDGEN_TILE;
-    const int nvalid = min(CMDGEN_TILE, lay.N - row0);
+    const int row0 = blockIdx.x * MT;
+    const int nvalid = min(MT, lay.N - row0);
     const int ldp = 3 + d.P, ldq = 3 + d.R;
     const int Fmax = max(d.P, d.R), F1max = 2 * Fmax;
-    // stage input features
-    for (int idx = tid; idx < CMDGEN_TILE * Fmax; idx += nthr) {
-        const int r = idx / Fmax, k = idx % Fmax;
-        const int n = row0 + r;
-        float v = 0.f;
-        if (r < nvalid) {
-            if (n < lay.Nl) { if (k < d.P) v = xh_phar[(size_t)n * ldp + 3 + k]; }
-            else if (k < d.R) v = xh_pocket[(size_t)(n - lay.Nl) * ldq + 3 + k];
+    for (int r = 0; r < MT; ++r)                       // stage input features (row-major, coalesced)
+        for (int k = tid; k < Fmax; k += nthr) {
+            const int n = row0 + r;
+            float v = 0.f;
+            if (r < nvalid) {
+                if (n < lay.Nl) { if (k < d.P) v = xh_phar[(size_t)n * ldp + 3 + k]; }
+                else if (k < d.R) v = xh_pocket[(size_t)(n - lay.Nl) * ldq + 3 + k];
+            }
+            s_in[r][k] = v;
         }
-        s_in[r][k] = v;
-    }
     __syncthreads();
-    // encoder layer 0 + SiLU
-    for (int idx = tid; idx < CMDGEN_TILE * F1max; idx += nthr) {
-        const int r = idx / F1max, o = idx % F1max;
+    // encoder layer 0 + SiLU: thread -> (row r, output o)
+    for (int idx = tid; idx < MT * F1max; idx += nthr) {
+        const int r = idx / F1max, o = idx - r * F1max;
         const int n = row0 + r;
         if (r >= nvalid) continue;
         const bool ph = n < lay.Nl;
@@ -227,8 +226,8 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
     }
     __syncthreads();
     // encoder layer 2 -> joint space, then the time column (dynamics.py:92-99)
-    for (int idx = tid; idx < CMDGEN_TILE * d.dyn; idx += nthr) {
-        const int r = idx / d.dyn, j = idx % d.dyn;
+    for (int idx = tid; idx < MT * d.dyn; idx += nthr) {
+        const int r = idx / d.dyn, j = idx - r * d.dyn;
         const int n = row0 + r;
         float s = 0.f;
         if (r < nvalid) {
@@ -245,24 +244,26 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         s_h2[r][j] = s;
     }
     __syncthreads();
-    // embedding dyn -> H: one output column per thread
-    {
+    {   // embedding dyn -> H: one output column per thread, weights transposed [dyn][H] (coalesced)
         const int c = tid;
-        float wreg[CMDGEN_MAX_SMALL + 1];
-#pragma unroll
-        for (int k = 0; k < CMDGEN_MAX_SMALL + 1; ++k) wreg[k] = (k < d.dyn) ? sw.emb_w[(size_t)c * d.dyn + k] : 0.f;
         const float bc = sw.emb_b[c];
-        for (int r = 0; r < CMDGEN_TILE; ++r) {
-            float s = bc;
+        float accr[MT];
 #pragma unroll
-            for (int k = 0; k < CMDGEN_MAX_SMALL + 1; ++k) if (k < d.dyn) s = fmaf(s_h2[r][k], wreg[k], s);
-            if (r >= nvalid) s = 0.f;
+        for (int r = 0; r < MT; ++r) accr[r] = bc;
+        for (int k = 0; k < d.dyn; ++k) {
+            const float wk = sw.emb_wT[(size_t)k * H + c];
+#pragma unroll
+            for (int r = 0; r < MT; ++r) accr[r] = fmaf(s_h2[r][k], wk, accr[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < MT; ++r) {
+            const float s = r < nvalid ? accr[r] : 0.f;
             buf[r * LDA(H) + c] = s;
             if (r < nvalid) w.h[(size_t)(row0 + r) * H + c] = s;
         }
     }
     __syncthreads();
-    tile_project_pq<H>(buf, lw0.Wpq_e, lw0.b1, w.P, w.Q, row0, nvalid, true);
+    tile_project_pq<H, MT>(buf, lw0.Wpq_e, lw0.b1, w.P, w.Q, row0, nvalid, true);
 }
 
 // ------------------------------------------------------------------------------------
@@ -283,17 +284,17 @@ __device__ __forceinline__ float4 node_pos(const Layout& lay, const Work& w, con
 // A-tile generation shared by the two edge kernels:
 //   a1[e][:] = SiLU(P[row_e] + Q[col_e] + w_r * radial_e + w_d * d0_e)     (b folded into P)
 // which equals SiLU(W1 [h_row | h_col | radial | d0] + b1) of egnn_new.py:33-36 / :89-93.
-template <int H>
+template <int H, int MT>
 __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, const int* s_col,
                                                 const float* s_r, const float* s_d0, int ne,
                                                 const float* __restrict__ P, const float* __restrict__ Q,
                                                 const float* __restrict__ wr, const float* __restrict__ wd) {
-    constexpr int LPR = H / 4;                  // lanes per row (float4 each)
-    const int c4 = threadIdx.x % LPR, rsub = threadIdx.x / LPR;   // 4 rows per pass
+    constexpr int LPR = H / 4;                  // lanes per row (float4 each) -> 4 rows per pass
+    const int c4 = threadIdx.x % LPR, rsub = threadIdx.x / LPR;
     const float4 wr4 = reinterpret_cast<const float4*>(wr)[c4];
     const float4 wd4 = reinterpret_cast<const float4*>(wd)[c4];
 #pragma unroll 4
-    for (int pass = 0; pass < CMDGEN_TILE / 4; ++pass) {
+    for (int pass = 0; pass < MT / 4; ++pass) {
         const int e = pass * 4 + rsub;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < ne) {
@@ -309,24 +310,43 @@ __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, co
     }
 }
 
+// per-row dot product of the LDS tile with a weight vector: H/MT threads per row
+template <int H, int MT>
+__device__ __forceinline__ float tile_row_dot(const float* buf, const float* __restrict__ wv, int& r_out, bool& lead) {
+    constexpr int TPR = H / MT;                 // threads per row (4, 8 or 16 at H=256)
+    constexpr int CPT = H / TPR;                // columns per thread (= MT)
+    const int r = threadIdx.x / TPR, q = threadIdx.x % TPR;
+    float s = 0.f;
+    const float4* mrow = reinterpret_cast<const float4*>(buf + r * LDA(H) + q * CPT);
+    const float4* w4 = reinterpret_cast<const float4*>(wv + q * CPT);
+#pragma unroll
+    for (int k = 0; k < CPT / 4; ++k) {
+        const float4 m = mrow[k], a = w4[k];
+        s += m.x * a.x + m.y * a.y + m.z * a.z + m.w * a.w;
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o);
+    r_out = r; lead = (q == 0);
+    return s;
+}
+
 // ------------------------------------------------------------------------------------
-// k_edge_msg: GCL.edge_model + attention gate + segment sum by receiver for 64-edge tiles
+// k_edge_msg: GCL.edge_model + attention gate + segment sum by receiver for MT-edge tiles
 // of the compact list.  Persistent-style grid: tiles are taken round-robin until the
 // device-side edge count is exhausted, so the launch geometry is static (graph-capturable).
 // ------------------------------------------------------------------------------------
-template <int H>
+template <int H, int MT>
 __global__ __launch_bounds__(H) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer) {
-    __shared__ __attribute__((aligned(16))) float buf[CMDGEN_TILE * LDA(H)];
-    __shared__ int s_row[CMDGEN_TILE], s_col[CMDGEN_TILE];
-    __shared__ float s_r[CMDGEN_TILE], s_d0[CMDGEN_TILE], s_att[CMDGEN_TILE];
-    constexpr int NW = H / 64;
+    __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
+    __shared__ int s_row[MT], s_col[MT];
+    __shared__ float s_r[MT], s_d0[MT], s_att[MT];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int E = w.totals[0];
-    const int ntiles = (E + CMDGEN_TILE - 1) / CMDGEN_TILE;
+    const int ntiles = (E + MT - 1) / MT;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int e0 = tile * CMDGEN_TILE;
-        const int ne = min(CMDGEN_TILE, E - e0);
-        if (tid < CMDGEN_TILE) {
+        const int e0 = tile * MT;
+        const int ne = min(MT, E - e0);
+        if (tid < MT) {
             int row = -1, col = -1; float r = 0.f, d0 = 0.f;
             if (tid < ne) {
                 row = w.erow[e0 + tid]; col = w.ecol[e0 + tid]; d0 = w.ed0[e0 + tid];
@@ -335,26 +355,18 @@ __global__ __launch_bounds__(H) void k_edge_msg(Layout lay, Work w, Dims d, Laye
             s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
         }
         __syncthreads();
-        build_edge_tile<H>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, lw.wr_e, lw.wd_e);
+        build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, lw.wr_e, lw.wd_e);
         __syncthreads();
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        mfma_tile_64x64<H / 8>(buf, LDA(H), lw.W2, H / 8, 0, 2 * wave, acc);
+        TileAcc<MT> acc;
+        acc_zero<MT>(acc);
+        tile_gemm<MT, H / 8>(buf, LDA(H), lw.W2, H / 8, 0, wave, acc);
         __syncthreads();                         // every wave is done reading the A tile
-        CMDGEN_ACC_FOREACH(wave, { buf[row * LDA(H) + col] = silu_f(v + lw.b2[col]); })   // m_ij
+        acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b2[col]); });   // m_ij
         __syncthreads();
-        {   // attention gate: sigmoid(w_a . m_ij + b_a), NW threads per edge row
-            const int r = tid / NW, q = tid % NW;
-            float s = 0.f;
-            const float4* mrow = reinterpret_cast<const float4*>(buf + r * LDA(H) + q * 64);
-            const float4* wa4 = reinterpret_cast<const float4*>(lw.wa + q * 64);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float4 m = mrow[k], a = wa4[k];
-                s += m.x * a.x + m.y * a.y + m.z * a.z + m.w * a.w;
-            }
-            for (int o = 1; o < NW; o <<= 1) s += __shfl_xor(s, o);
-            if (q == 0) s_att[r] = d.attention ? sigmoid_f(s + lw.ba) : 1.0f;
+        {   // attention gate: sigmoid(w_a . m_ij + b_a)
+            int r; bool lead;
+            const float s = tile_row_dot<H, MT>(buf, lw.wa, r, lead);
+            if (lead) s_att[r] = d.attention ? sigmoid_f(s + lw.ba) : 1.0f;
         }
         __syncthreads();
         {   // segment sum over the tile's rows, one column per thread, edge order preserved
@@ -378,37 +390,39 @@ __global__ __launch_bounds__(H) void k_edge_msg(Layout lay, Work w, Dims d, Laye
 }
 
 // ------------------------------------------------------------------------------------
-// k_node: GCL.node_model for a 64-node tile (egnn_new.py:48-58)
+// k_node: GCL.node_model for an MT-node tile (egnn_new.py:48-58)
 //   h <- h + W4 SiLU(W3 [h | agg/nf] + b3) + b4
 // then, while the new h tile is still in LDS, the projections every later kernel of this
 // evaluation gathers: P_c|Q_c for this block's coord MLP and P|Q for block l+1's edge MLP.
 // ------------------------------------------------------------------------------------
-template <int H>
+template <int H, int MT>
 __global__ __launch_bounds__(H) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
                                             int layer, int has_next) {
-    __shared__ __attribute__((aligned(16))) float buf[CMDGEN_TILE * LDA(H)];
+    __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     constexpr int LPR = H / 4;
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int row0 = blockIdx.x * CMDGEN_TILE;
-    const int nvalid = min(CMDGEN_TILE, lay.N - row0);
+    const int row0 = blockIdx.x * MT;
+    const int nvalid = min(MT, lay.N - row0);
     const int c4 = tid % LPR, rsub = tid / LPR;
     // materialise the phar coordinates entering this block (see node_pos)
-    if (layer >= 1 && tid < CMDGEN_TILE) {
+    if (layer >= 1 && tid < MT) {
         const int n = row0 + tid;
         if (tid < nvalid && n < lay.Nl) w.XL[(size_t)layer * lay.Nl + n] = node_pos(lay, w, d, n, layer, true);
     }
-    for (int pass = 0; pass < CMDGEN_TILE / 4; ++pass) {
+#pragma unroll 4
+    for (int pass = 0; pass < MT / 4; ++pass) {
         const int r = pass * 4 + rsub;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < nvalid) v = reinterpret_cast<const float4*>(w.h + (size_t)(row0 + r) * H)[c4];
         *reinterpret_cast<float4*>(buf + r * LDA(H) + 4 * c4) = v;
     }
     __syncthreads();
-    f32x16 acc[2][2];
-    acc_zero(acc);
-    mfma_tile_64x64<H / 8>(buf, LDA(H), lw.W3, 2 * H / 8, 0, 2 * wave, acc);            // h part of [h | agg]
+    TileAcc<MT> acc;
+    acc_zero<MT>(acc);
+    tile_gemm<MT, H / 8>(buf, LDA(H), lw.W3, 2 * H / 8, 0, wave, acc);                  // h part of [h | agg]
     __syncthreads();
-    for (int pass = 0; pass < CMDGEN_TILE / 4; ++pass) {
+#pragma unroll 4
+    for (int pass = 0; pass < MT / 4; ++pass) {
         const int r = pass * 4 + rsub;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < nvalid) {
@@ -420,14 +434,14 @@ __global__ __launch_bounds__(H) void k_node(Layout lay, Work w, Dims d, LayerW l
         *reinterpret_cast<float4*>(buf + r * LDA(H) + 4 * c4) = v;
     }
     __syncthreads();
-    mfma_tile_64x64<H / 8>(buf, LDA(H), lw.W3, 2 * H / 8, H / 8, 2 * wave, acc);        // agg part
+    tile_gemm<MT, H / 8>(buf, LDA(H), lw.W3, 2 * H / 8, H / 8, wave, acc);              // agg part
     __syncthreads();
-    CMDGEN_ACC_FOREACH(wave, { buf[row * LDA(H) + col] = silu_f(v + lw.b3[col]); })
+    acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b3[col]); });
     __syncthreads();
-    acc_zero(acc);
-    mfma_tile_64x64<H / 8>(buf, LDA(H), lw.W4, H / 8, 0, 2 * wave, acc);
+    acc_zero<MT>(acc);
+    tile_gemm<MT, H / 8>(buf, LDA(H), lw.W4, H / 8, 0, wave, acc);
     __syncthreads();
-    CMDGEN_ACC_FOREACH(wave, {
+    acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
         float hn = 0.f;
         if (row < nvalid) {
             float* hp = w.h + (size_t)(row0 + row) * H + col;
@@ -435,11 +449,11 @@ __global__ __launch_bounds__(H) void k_node(Layout lay, Work w, Dims d, LayerW l
             *hp = hn;
         }
         buf[row * LDA(H) + col] = hn;
-    })
+    });
     __syncthreads();
     // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
-    tile_project_pq<H>(buf, lw.Wpq_c, lw.b6, w.Pc, w.Qc, row0, nvalid, row0 < lay.Nl);
-    if (has_next) tile_project_pq<H>(buf, lw_next.Wpq_e, lw_next.b1, w.P, w.Q, row0, nvalid, true);
+    tile_project_pq<H, MT>(buf, lw.Wpq_c, lw.b6, w.Pc, w.Qc, row0, nvalid, row0 < lay.Nl);
+    if (has_next) tile_project_pq<H, MT>(buf, lw_next.Wpq_e, lw_next.b1, w.P, w.Q, row0, nvalid, true);
 }
 
 // ------------------------------------------------------------------------------------
@@ -448,20 +462,19 @@ __global__ __launch_bounds__(H) void k_node(Layout lay, Work w, Dims d, LayerW l
 //   phi = w5 . SiLU(W7 SiLU(W6 [h_i, h_j, r, d0] + b6) + b7)
 //   ACC[l][i] += (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant) * tanh(phi) * coords_range
 // ------------------------------------------------------------------------------------
-template <int H>
+template <int H, int MT>
 __global__ __launch_bounds__(H) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer) {
-    __shared__ __attribute__((aligned(16))) float buf[CMDGEN_TILE * LDA(H)];
-    __shared__ int s_row[CMDGEN_TILE], s_col[CMDGEN_TILE];
-    __shared__ float s_r[CMDGEN_TILE], s_d0[CMDGEN_TILE];
-    __shared__ float s_cd[CMDGEN_TILE][3], s_tr[CMDGEN_TILE][3];
-    constexpr int NW = H / 64;
+    __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
+    __shared__ int s_row[MT], s_col[MT];
+    __shared__ float s_r[MT], s_d0[MT];
+    __shared__ float s_cd[MT][3], s_tr[MT][3];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int E = w.totals[1];
-    const int ntiles = (E + CMDGEN_TILE - 1) / CMDGEN_TILE;
+    const int ntiles = (E + MT - 1) / MT;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int e0 = tile * CMDGEN_TILE;
-        const int ne = min(CMDGEN_TILE, E - e0);
-        if (tid < CMDGEN_TILE) {
+        const int e0 = tile * MT;
+        const int ne = min(MT, E - e0);
+        if (tid < MT) {
             int row = -1, col = -1; float r = 0.f, d0 = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
             if (tid < ne) {
                 row = w.erow[e0 + tid]; col = w.ecol[e0 + tid]; d0 = w.ed0[e0 + tid];   // phar-receiver prefix
@@ -476,26 +489,18 @@ __global__ __launch_bounds__(H) void k_edge_coord(Layout lay, Work w, Dims d, La
             s_cd[tid][0] = cx; s_cd[tid][1] = cy; s_cd[tid][2] = cz;
         }
         __syncthreads();
-        build_edge_tile<H>(buf, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, lw.wr_c, lw.wd_c);
+        build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, lw.wr_c, lw.wd_c);
         __syncthreads();
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        mfma_tile_64x64<H / 8>(buf, LDA(H), lw.W7, H / 8, 0, 2 * wave, acc);
+        TileAcc<MT> acc;
+        acc_zero<MT>(acc);
+        tile_gemm<MT, H / 8>(buf, LDA(H), lw.W7, H / 8, 0, wave, acc);
         __syncthreads();
-        CMDGEN_ACC_FOREACH(wave, { buf[row * LDA(H) + col] = silu_f(v + lw.b7[col]); })
+        acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b7[col]); });
         __syncthreads();
         {
-            const int r = tid / NW, q = tid % NW;
-            float s = 0.f;
-            const float4* mrow = reinterpret_cast<const float4*>(buf + r * LDA(H) + q * 64);
-            const float4* w54 = reinterpret_cast<const float4*>(lw.w5 + q * 64);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float4 m = mrow[k], a = w54[k];
-                s += m.x * a.x + m.y * a.y + m.z * a.z + m.w * a.w;
-            }
-            for (int o = 1; o < NW; o <<= 1) s += __shfl_xor(s, o);
-            if (q == 0) {
+            int r; bool lead;
+            const float s = tile_row_dot<H, MT>(buf, lw.w5, r, lead);
+            if (lead) {
                 const float g = d.use_tanh ? tanhf(s) * d.coords_range : s;
                 s_tr[r][0] = s_cd[r][0] * g; s_tr[r][1] = s_cd[r][1] * g; s_tr[r][2] = s_cd[r][2] * g;
             }
@@ -520,12 +525,14 @@ __global__ __launch_bounds__(H) void k_edge_coord(Layout lay, Work w, Dims d, La
 
 // ------------------------------------------------------------------------------------
 // k_readout: embedding_out (drop the time column), decoders, velocity, NaN flag
-// (egnn_new.py:205, dynamics.py:110-131).  32 threads per node, 8 nodes per workgroup.
+// (egnn_new.py:205, dynamics.py:110-131).  8 nodes per workgroup, 32 threads per node; the
+// node's h row is staged in LDS and the transposed weight is read coalesced.
 // eps rows: [vel(3) | decoded features].  The batch-global NaN reset is applied by the
 // consumer (k_nan_fix or the DDPM kernels) once the flag is complete.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, SmallW sw,
                                                  float* __restrict__ eps_phar, float* __restrict__ eps_pocket) {
+    extern __shared__ float s_hrow[];            // [8][H]
     __shared__ float s_j[8][CMDGEN_MAX_SMALL + 1];
     __shared__ float s_h1[8][CMDGEN_MAX_SMALL];
     const int tid = threadIdx.x, g = tid >> 5, l32 = tid & 31;
@@ -534,12 +541,20 @@ __global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, Sma
     const bool live = n < nnodes;
     const bool ph = n < lay.Nl;
     const int H = d.H;
+    if (live) for (int k = l32; k < H; k += 32) s_hrow[g * H + k] = w.h[(size_t)n * H + k];
+    __syncthreads();
     if (live) {
         for (int j = l32; j < d.J; j += 32) {
-            float s = sw.embo_b[j];
-            const float* hrow = w.h + (size_t)n * H;
-            for (int k = 0; k < H; ++k) s = fmaf(hrow[k], sw.embo_wT[(size_t)k * d.dyn + j], s);
-            s_j[g][j] = s;
+            float s0 = sw.embo_b[j], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            const float* hr = s_hrow + g * H;
+            const float* wt = sw.embo_wT + j;
+            for (int k = 0; k < H; k += 4) {
+                s0 = fmaf(hr[k], wt[(size_t)k * d.dyn], s0);
+                s1 = fmaf(hr[k + 1], wt[(size_t)(k + 1) * d.dyn], s1);
+                s2 = fmaf(hr[k + 2], wt[(size_t)(k + 2) * d.dyn], s2);
+                s3 = fmaf(hr[k + 3], wt[(size_t)(k + 3) * d.dyn], s3);
+            }
+            s_j[g][j] = (s0 + s1) + (s2 + s3);
         }
     }
     __syncthreads();
@@ -592,39 +607,57 @@ __global__ void k_nan_fix(Layout lay, Work w, Dims d, float* __restrict__ eps_ph
 // ------------------------------------------------------------------------------------
 // host-callable launchers (C++ linkage, used by cmdgen_api.hip)
 // ------------------------------------------------------------------------------------
+template <int H, int MT> static void launch_embed(const EvalLaunch& a, const float* xp, const float* xq, const float* t,
+                                                  const float4* coef, ChainState* chain, hipStream_t s) {
+    const int nt = (a.lay.N + MT - 1) / MT;
+    hipLaunchKernelGGL((k_embed<H, MT>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
+                       (const ChainState*)chain);
+}
+template <int H, int MT> static void launch_node(const EvalLaunch& a, int l, hipStream_t s) {
+    const int nt = (a.lay.N + MT - 1) / MT;
+    const int has_next = l + 1 < a.d.L;
+    hipLaunchKernelGGL((k_node<H, MT>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[has_next ? l + 1 : l],
+                       l, has_next);
+}
+template <int H, int MT> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
+    hipLaunchKernelGGL((k_edge_msg<H, MT>), dim3(a.edge_grid * (64 / MT)), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);
+}
+template <int H, int MT> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
+    hipLaunchKernelGGL((k_edge_coord<H, MT>), dim3(a.edge_grid * (64 / MT)), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);
+}
+#define MT_DISPATCH(mt, FN, ...) do { if ((mt) == 64) FN<H, 64>(__VA_ARGS__); else if ((mt) == 32) FN<H, 32>(__VA_ARGS__); \
+                                      else FN<H, 16>(__VA_ARGS__); } while (0)
+
 template <int H>
 static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket,
                           const float* t_arr, const float4* coef, ChainState* chain,
                           float* eps_phar, float* eps_pocket, hipStream_t s,
-                          hipEvent_t* ev /* null or 2*(4+3L) events */) {
+                          hipEvent_t* ev /* null or 2*(3+3L) events */) {
     const int B = a.lay.B, N = a.lay.N;
     const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + sizeof(int));
-    const int ntile_nodes = (N + CMDGEN_TILE - 1) / CMDGEN_TILE;
     int e = 0;
 #define REC() do { if (ev) hipEventRecord(ev[e++], s); } while (0)
     REC();
     hipLaunchKernelGGL(k_edge_count, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket, chain);
     hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d);
     REC(); REC();
-    hipLaunchKernelGGL(k_embed<H>, dim3(ntile_nodes), dim3(H), 0, s, a.lay, a.w, a.d, a.sw, a.layers[0],
-                       xh_phar, xh_pocket, t_arr, coef, (const ChainState*)chain);
+    MT_DISPATCH(a.node_mt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
     REC();
     for (int l = 0; l < a.d.L; ++l) {
-        const int has_next = l + 1 < a.d.L;
         REC();
         if (a.msg_events) { hipEvent_t e0; hipEventCreate(&e0); hipEventRecord(e0, s); a.msg_events->push_back(e0); }
-        hipLaunchKernelGGL(k_edge_msg<H>, dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);
+        MT_DISPATCH(a.edge_mt, launch_msg, a, l, s);
         if (a.msg_events) { hipEvent_t e1; hipEventCreate(&e1); hipEventRecord(e1, s); a.msg_events->push_back(e1); }
         REC(); REC();
-        hipLaunchKernelGGL(k_node<H>, dim3(ntile_nodes), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
-                           a.layers[has_next ? l + 1 : l], l, has_next);
+        MT_DISPATCH(a.node_mt, launch_node, a, l, s);
         REC(); REC();
-        hipLaunchKernelGGL(k_edge_coord<H>, dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);
+        MT_DISPATCH(a.coord_mt, launch_coord, a, l, s);
         REC();
     }
     REC();
     const int nn = eps_pocket ? N : a.lay.Nl;
-    hipLaunchKernelGGL(k_readout, dim3((nn + 7) / 8), dim3(256), 0, s, a.lay, a.w, a.d, a.sw, eps_phar, eps_pocket);
+    hipLaunchKernelGGL(k_readout, dim3((nn + 7) / 8), dim3(256), 8 * a.d.H * sizeof(float), s, a.lay, a.w, a.d, a.sw,
+                       eps_phar, eps_pocket);
     REC();
 #undef REC
 }
@@ -644,11 +677,14 @@ void cmdgen_launch_nan_fix(const EvalLaunch& a, float* eps_phar, hipStream_t s) 
     hipLaunchKernelGGL(k_nan_fix, dim3((a.lay.Nl + 255) / 256), dim3(256), 0, s, a.lay, a.w, a.d, eps_phar);
 }
 
+template <int H> static void launch_msg_only_H(const EvalLaunch& a, int layer, hipStream_t s) {
+    MT_DISPATCH(a.edge_mt, launch_msg, a, layer, s);
+}
 void cmdgen_launch_edge_msg_only(const EvalLaunch& a, int layer, hipStream_t s) {
     switch (a.d.H) {
-        case 256: hipLaunchKernelGGL(k_edge_msg<256>, dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[layer], layer); break;
-        case 128: hipLaunchKernelGGL(k_edge_msg<128>, dim3(a.edge_grid), dim3(128), 0, s, a.lay, a.w, a.d, a.layers[layer], layer); break;
-        case 64:  hipLaunchKernelGGL(k_edge_msg<64>, dim3(a.edge_grid), dim3(64), 0, s, a.lay, a.w, a.d, a.layers[layer], layer); break;
+        case 256: launch_msg_only_H<256>(a, layer, s); break;
+        case 128: launch_msg_only_H<128>(a, layer, s); break;
+        case 64:  launch_msg_only_H<64>(a, layer, s); break;
         default: break;
     }
 }
