@@ -355,7 +355,8 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
             e_est += n * (deg < n ? deg : n);
             ec_est += (double)nph[b] * (deg < n ? deg : n) * 0.5;
         }
-        auto pick = [&](double rows) { return rows / 64.0 >= 3.0 * h->n_cus ? 64 : (rows / 32.0 >= 2.0 * h->n_cus ? 32 : 16); };
+        // thresholds from sweeps on MI355X (profiles/r01_tile_sweep.txt)
+        auto pick = [&](double rows) { return rows / 64.0 >= 3.0 * h->n_cus ? 64 : (rows / 32.0 >= 1.5 * h->n_cus ? 32 : 16); };
         h->node_mt = pick((double)N); h->edge_mt = pick(e_est); h->coord_mt = pick(ec_est);
         const char* ev;
         if ((ev = getenv("CMDGEN_NODE_MT"))) h->node_mt = atoi(ev);

@@ -1,0 +1,91 @@
+"""world_size-2 gloo test of the multi-GPU path (CPU): pockets shard with no data-path
+collective and the gathered result equals the single-process result.  The per-pocket sampler
+is the oracle here (test infrastructure standing in for the GPU), with noise keyed by the
+GLOBAL pocket index exactly as the device Philox stream is."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import cmdgen_amd  # noqa: E402,F401
+from cmdgen_amd import sharding  # noqa: E402
+from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets  # noqa: E402
+
+
+def oracle_sampler(cfg, sd, K):
+    from oracle import ref_cpu
+    p = ref_cpu.to_torch_params(sd)
+
+    def fn(pocket, num_nodes_phar, pocket_ids=None, **kw):
+        nph = torch.as_tensor(num_nodes_phar)
+        # per-pocket noise streams keyed by global id -> independent of the sharding
+        draws = []
+        for d in range(K + 2):
+            parts = [torch.randn((int(n), 11), generator=torch.Generator().manual_seed(1000 * int(g) + d))
+                     for g, n in zip(pocket_ids, nph)]
+            draws.append(torch.cat(parts))
+        it = iter(draws)
+        with torch.no_grad():
+            return ref_cpu.sample_given_pocket(p, cfg.as_dict(), pocket, nph, timesteps=K,
+                                               noise=lambda shape: next(it))
+    return fn
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = ModelConfig(hidden_nf=64, n_layers=2)
+    sd = make_state_dict(cfg, seed=5)
+    pb = make_pockets(5, 'CA', ragged=True)
+    pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot),
+              'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
+    out = sharding.sample_sharded(oracle_sampler(cfg, sd, 3), pocket, pb.num_nodes_phar, rank, world)
+    if rank == 0:
+        q.put([o.numpy() for o in out])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_sampling_equals_single_process():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = ModelConfig(hidden_nf=64, n_layers=2)
+    sd = make_state_dict(cfg, seed=5)
+    pb = make_pockets(5, 'CA', ragged=True)
+    pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot),
+              'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
+    want = sharding.sample_sharded(oracle_sampler(cfg, sd, 3), pocket, pb.num_nodes_phar, 0, 1)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b.numpy())          # bit-identical: shards are independent
+
+
+def test_shard_bounds():
+    assert sharding.shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert sharding.shard_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    b = sharding.balanced_shard_bounds([1, 1, 1, 1, 4, 4], 2)
+    assert b[0][0] == 0 and b[-1][1] == 6 and b[0][1] == b[1][0]
+    cost = np.array([1, 1, 1, 1, 4, 4], float)
+    assert abs(cost[b[0][0]:b[0][1]].sum() - cost[b[1][0]:b[1][1]].sum()) <= 4
+    pb = make_pockets(4, 'CA', ragged=True)
+    pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot),
+              'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
+    sub, nph = sharding.slice_pocket(pocket, pb.num_nodes_phar, 1, 3)
+    assert sub['size'].tolist() == pb.size[1:3].tolist() and sub['mask'].min() == 0 and sub['mask'].max() == 1
+    assert len(sub['x']) == int(pb.size[1:3].sum()) and nph.tolist() == pb.num_nodes_phar[1:3].tolist()
