@@ -362,6 +362,7 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
         if ((ev = getenv("CMDGEN_NODE_MT"))) h->node_mt = atoi(ev);
         if ((ev = getenv("CMDGEN_EDGE_MT"))) h->edge_mt = atoi(ev);
         if ((ev = getenv("CMDGEN_COORD_MT"))) h->coord_mt = atoi(ev);
+        if ((ev = getenv("CMDGEN_EDGE_WGS_PER_CU"))) h->edge_grid = atoi(ev) * h->n_cus;
         for (int* m : {&h->node_mt, &h->edge_mt, &h->coord_mt}) if (*m != 64 && *m != 32 && *m != 16) *m = 64;
     }
     h->cur_nphar.assign(nph, nph + B); h->cur_npocket.assign(npk, npk + B);
@@ -379,7 +380,7 @@ static int check_ready(cmdgen_handle* h) {
 static EvalLaunch make_launch(cmdgen_handle* h) {
     EvalLaunch a; a.lay = h->lay; a.w = h->work; a.d = h->dims; a.sw = h->small; a.layers = h->layers.data();
     a.edge_grid = h->edge_grid;
-    a.msg_events = nullptr;
+    a.msg_events = nullptr; a.ablate = 0;
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     return a;
 }
@@ -646,12 +647,14 @@ extern "C" int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar,
 
 extern "C" int cmdgen_time_edge_kernel(cmdgen_handle* h, int32_t layer, int32_t reps, float* mean_ms, cmdgen_stream stream) {
     int rc = check_ready(h); if (rc) return rc;
-    if (layer < 0 || layer >= h->dims.L || reps < 1 || !mean_ms) return fail(h, CMDGEN_EINVAL, "bad arguments");
+    if (layer < 0 || (layer & 0xff) >= h->dims.L || reps < 1 || !mean_ms) return fail(h, CMDGEN_EINVAL, "bad arguments");
     hipSetDevice(h->device);
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     EvalLaunch a = make_launch(h);
+    a.ablate = (layer >> 8) & 0xff;                                 // bits 8.. of `layer`: phase-ablation mask (timing only)
+    layer &= 0xff;
     cmdgen_launch_edge_msg_only(a, layer, s);                       // warm
     HIPCHK(h, hipEventRecord(e0, s));
     for (int i = 0; i < reps; ++i) cmdgen_launch_edge_msg_only(a, layer, s);

@@ -130,15 +130,19 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int edge_grid;              // workgroups of the persistent-style edge kernels
     int node_mt, edge_mt, coord_mt;   // rows per tile (64, 32 or 16) chosen per launch from the row counts
     std::vector<hipEvent_t>* msg_events;   // when non-null: event pair around every edge-message launch
+    int ablate;                 // timing-only builds of the edge kernel (cmdgen_time_edge_kernel); 0 in production
 };
 
 // ---------------------------------------------------------------------------------
+// SiLU / sigmoid on the fast hardware path: v_exp_f32 (base 2) + v_rcp_f32, 5 VALU instructions.
+// (__frcp_rn / a plain division expand to the 10-instruction IEEE sequence; fp32 MFMA does not
+// co-execute with VALU on gfx950 - profiles/r01_c_mfma_valu_coexec.txt - so every VALU instruction
+// in the tile kernels is paid in full.)  Error ~2 ulp, far inside the 2e-5 evaluation tolerance.
 __device__ __forceinline__ float silu_f(float v) {
-    // v * sigmoid(v); v_exp_f32 + v_rcp_f32 path (about 2 ulp)
-    return v * __frcp_rn(1.0f + __expf(-v));
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 __device__ __forceinline__ float sigmoid_f(float v) {
-    return __frcp_rn(1.0f + __expf(-v));
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 __device__ __forceinline__ float dist2(const float4& a, const float4& b) {
     float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
@@ -208,81 +212,94 @@ __device__ __forceinline__ void acc_foreach(const TileAcc<MT>& acc, int wave, F 
 #define CMDGEN_MFMA16(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, ACC, 0, 0, 0)
 
 // KB8 = k extent in blocks of 8; cg = index of this wave's 64-column group in the weight matrix.
+// Four register sets (A..D) hold the fragments of k-blocks kb..kb+3 and are refilled in place two
+// blocks ahead of their use, so the pipeline needs no register-rotation moves (VALU work is paid
+// in full next to fp32 MFMA on gfx950).
 template <int MT, int KB8>
 __device__ __forceinline__ void tile_gemm(const float* __restrict__ ldsA, int lda, const WPack& W,
                                           int kb_total8, int kb0_8, int cg, TileAcc<MT>& acc) {
     const int lane = threadIdx.x & 63;
     if constexpr (MT == 16) {
         constexpr int KB = KB8 / 2;                      // k-blocks of 16
-        static_assert(KB >= 2 && KB % 2 == 0, "K must be a multiple of 32");
+        static_assert(KB >= 4 && KB % 4 == 0, "K must be a multiple of 64");
         const int kbt = kb_total8 / 2, kb0 = kb0_8 / 2;
         const float* ap = ldsA + (lane & 15) * lda + (lane >> 4) * 4;
         const float4* bp = W.w16 + ((size_t)(4 * cg) * kbt + kb0) * 64 + lane;
-        const size_t ns = (size_t)kbt * 64;              // stride between n-tiles
-        float4 bA[4], bB[4], bC[4], bD[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) { bA[n] = bp[n * ns]; bB[n] = bp[n * ns + 64]; }
-        float4 aA = *reinterpret_cast<const float4*>(ap), aB;
+        const unsigned ns = (unsigned)kbt * 64;          // stride between n-tiles (float4 units)
+        float4 bA[4], bB[4], bC[4], bD[4], aA, aB, aC, aD;
+#define LOADB16(DST, KBI) _Pragma("unroll") for (int n = 0; n < 4; ++n) DST[n] = bp[n * ns + (unsigned)(KBI) * 64u];
+#define LOADA16(DST, KBI) DST = *reinterpret_cast<const float4*>(ap + (KBI) * 16);
 #define STEP16(AV, BV)                                                                        \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.x, BV[n].x);  \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.y, BV[n].y);  \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.z, BV[n].z);  \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.w, BV[n].w);
+        LOADB16(bA, 0) LOADB16(bB, 1) LOADA16(aA, 0) LOADA16(aB, 1)
 #pragma unroll 1
-        for (int kb = 0; kb < KB; kb += 2) {
-            const int k2 = (kb + 2 < KB) ? kb + 2 : KB - 1;   // clamped: the tail re-reads valid memory
-            const int k3 = (kb + 3 < KB) ? kb + 3 : KB - 1;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) bC[n] = bp[n * ns + k2 * 64];
-            aB = *reinterpret_cast<const float4*>(ap + (kb + 1) * 16);
+        for (int kb = 0; kb < KB; kb += 4) {
+            const int k4 = (kb + 4 < KB) ? kb + 4 : KB - 1;   // clamped: the tail re-reads valid memory
+            const int k5 = (kb + 5 < KB) ? kb + 5 : KB - 1;
+            LOADB16(bC, kb + 2) LOADA16(aC, kb + 2)
             __builtin_amdgcn_sched_barrier(0);
             STEP16(aA, bA)
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) bD[n] = bp[n * ns + k3 * 64];
-            aA = *reinterpret_cast<const float4*>(ap + k2 * 16);
+            LOADB16(bD, kb + 3) LOADA16(aD, kb + 3)
             __builtin_amdgcn_sched_barrier(0);
             STEP16(aB, bB)
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) { bA[n] = bC[n]; bB[n] = bD[n]; }
+            LOADB16(bA, k4) LOADA16(aA, k4)
+            __builtin_amdgcn_sched_barrier(0);
+            STEP16(aC, bC)
+            __builtin_amdgcn_sched_barrier(0);
+            LOADB16(bB, k5) LOADA16(aB, k5)
+            __builtin_amdgcn_sched_barrier(0);
+            STEP16(aD, bD)
+            __builtin_amdgcn_sched_barrier(0);
         }
 #undef STEP16
+#undef LOADB16
+#undef LOADA16
     } else {
         constexpr int NMT = MT / 32;
         constexpr int KB = KB8;
-        static_assert(KB % 2 == 0, "KB must be even");
+        static_assert(KB >= 4 && KB % 4 == 0, "K must be a multiple of 32");
         const float* a0p = ldsA + (lane & 31) * lda + (lane >> 5) * 4;
         const float4* b0p = W.w32 + ((size_t)(2 * cg) * kb_total8 + kb0_8) * 64 + lane;
         const float4* b1p = b0p + (size_t)kb_total8 * 64;
-        float4 bA0 = b0p[0], bA1 = b1p[0], bB0 = b0p[64], bB1 = b1p[64];
-        float4 aA[NMT], aB[NMT];
-#pragma unroll
-        for (int m = 0; m < NMT; ++m) aA[m] = *reinterpret_cast<const float4*>(a0p + m * 32 * lda);
+        float4 bA0, bA1, bB0, bB1, bC0, bC1, bD0, bD1;
+        float4 aA[NMT], aB[NMT], aC[NMT], aD[NMT];
+#define LOADB32(D0, D1, KBI) D0 = b0p[(unsigned)(KBI) * 64u]; D1 = b1p[(unsigned)(KBI) * 64u];
+#define LOADA32(DST, KBI) _Pragma("unroll") for (int m = 0; m < NMT; ++m) DST[m] = *reinterpret_cast<const float4*>(a0p + m * 32 * lda + (KBI) * 8);
 #define STEP32(AV, B0, B1)                                                                    \
         _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].x, B0.x); CMDGEN_MFMA32(acc.a[m][1], AV[m].x, B1.x); } \
         _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].y, B0.y); CMDGEN_MFMA32(acc.a[m][1], AV[m].y, B1.y); } \
         _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].z, B0.z); CMDGEN_MFMA32(acc.a[m][1], AV[m].z, B1.z); } \
         _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].w, B0.w); CMDGEN_MFMA32(acc.a[m][1], AV[m].w, B1.w); }
+        LOADB32(bA0, bA1, 0) LOADB32(bB0, bB1, 1) LOADA32(aA, 0) LOADA32(aB, 1)
 #pragma unroll 1
-        for (int kb = 0; kb < KB; kb += 2) {
-            const int k2 = (kb + 2 < KB) ? kb + 2 : KB - 1;
-            const int k3 = (kb + 3 < KB) ? kb + 3 : KB - 1;
-            float4 bC0 = b0p[k2 * 64], bC1 = b1p[k2 * 64];
-#pragma unroll
-            for (int m = 0; m < NMT; ++m) aB[m] = *reinterpret_cast<const float4*>(a0p + m * 32 * lda + (kb + 1) * 8);
+        for (int kb = 0; kb < KB; kb += 4) {
+            const int k4 = (kb + 4 < KB) ? kb + 4 : KB - 1;
+            const int k5 = (kb + 5 < KB) ? kb + 5 : KB - 1;
+            LOADB32(bC0, bC1, kb + 2) LOADA32(aC, kb + 2)
             __builtin_amdgcn_sched_barrier(0);
             STEP32(aA, bA0, bA1)
             __builtin_amdgcn_sched_barrier(0);
-            float4 bD0 = b0p[k3 * 64], bD1 = b1p[k3 * 64];
-#pragma unroll
-            for (int m = 0; m < NMT; ++m) aA[m] = *reinterpret_cast<const float4*>(a0p + m * 32 * lda + k2 * 8);
+            LOADB32(bD0, bD1, kb + 3) LOADA32(aD, kb + 3)
             __builtin_amdgcn_sched_barrier(0);
             STEP32(aB, bB0, bB1)
             __builtin_amdgcn_sched_barrier(0);
-            bA0 = bC0; bA1 = bC1; bB0 = bD0; bB1 = bD1;
+            LOADB32(bA0, bA1, k4) LOADA32(aA, k4)
+            __builtin_amdgcn_sched_barrier(0);
+            STEP32(aC, bC0, bC1)
+            __builtin_amdgcn_sched_barrier(0);
+            LOADB32(bB0, bB1, k5) LOADA32(aB, k5)
+            __builtin_amdgcn_sched_barrier(0);
+            STEP32(aD, bD0, bD1)
+            __builtin_amdgcn_sched_barrier(0);
         }
 #undef STEP32
+#undef LOADB32
+#undef LOADA32
     }
 }
 

@@ -290,10 +290,11 @@ __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, co
                                                 const float* __restrict__ P, const float* __restrict__ Q,
                                                 const float* __restrict__ wr, const float* __restrict__ wd) {
     constexpr int LPR = H / 4;                  // lanes per row (float4 each) -> 4 rows per pass
-    const int c4 = threadIdx.x % LPR, rsub = threadIdx.x / LPR;
+    const int ltid = threadIdx.x % H;           // (dual-group kernels run two groups of H threads)
+    const int c4 = ltid % LPR, rsub = ltid / LPR;
     const float4 wr4 = reinterpret_cast<const float4*>(wr)[c4];
     const float4 wd4 = reinterpret_cast<const float4*>(wd)[c4];
-#pragma unroll 4
+#pragma unroll 8
     for (int pass = 0; pass < MT / 4; ++pass) {
         const int e = pass * 4 + rsub;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -315,7 +316,8 @@ template <int H, int MT>
 __device__ __forceinline__ float tile_row_dot(const float* buf, const float* __restrict__ wv, int& r_out, bool& lead) {
     constexpr int TPR = H / MT;                 // threads per row (4, 8 or 16 at H=256)
     constexpr int CPT = H / TPR;                // columns per thread (= MT)
-    const int r = threadIdx.x / TPR, q = threadIdx.x % TPR;
+    const int ltid = threadIdx.x % H;
+    const int r = ltid / TPR, q = ltid % TPR;
     float s = 0.f;
     const float4* mrow = reinterpret_cast<const float4*>(buf + r * LDA(H) + q * CPT);
     const float4* w4 = reinterpret_cast<const float4*>(wv + q * CPT);
@@ -336,7 +338,7 @@ __device__ __forceinline__ float tile_row_dot(const float* buf, const float* __r
 // device-side edge count is exhausted, so the launch geometry is static (graph-capturable).
 // ------------------------------------------------------------------------------------
 template <int H, int MT>
-__global__ __launch_bounds__(H) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer) {
+__global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer, int ablate) {
     __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     __shared__ int s_row[MT], s_col[MT];
     __shared__ float s_r[MT], s_d0[MT], s_att[MT];
@@ -350,40 +352,51 @@ __global__ __launch_bounds__(H) void k_edge_msg(Layout lay, Work w, Dims d, Laye
             int row = -1, col = -1; float r = 0.f, d0 = 0.f;
             if (tid < ne) {
                 row = w.erow[e0 + tid]; col = w.ecol[e0 + tid]; d0 = w.ed0[e0 + tid];
-                r = dist2(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
+                r = (ablate & 1) ? d0 : dist2(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
             }
             s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
         }
         __syncthreads();
-        build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, lw.wr_e, lw.wd_e);
+        if (!(ablate & 2)) build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, lw.wr_e, lw.wd_e);
         __syncthreads();
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
-        tile_gemm<MT, H / 8>(buf, LDA(H), lw.W2, H / 8, 0, wave, acc);
+        if (!(ablate & 4)) tile_gemm<MT, H / 8>(buf, LDA(H), lw.W2, H / 8, 0, wave, acc);
         __syncthreads();                         // every wave is done reading the A tile
         acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b2[col]); });   // m_ij
         __syncthreads();
-        {   // attention gate: sigmoid(w_a . m_ij + b_a)
+        if (!(ablate & 16)) {   // attention gate: sigmoid(w_a . m_ij + b_a)
             int r; bool lead;
             const float s = tile_row_dot<H, MT>(buf, lw.wa, r, lead);
             if (lead) s_att[r] = d.attention ? sigmoid_f(s + lw.ba) : 1.0f;
         }
         __syncthreads();
-        {   // segment sum over the tile's rows, one column per thread, edge order preserved
+        if (!(ablate & 8)) {
+            // Segment sum over the tile's rows, one column per thread, edge order preserved
+            // (= the reference's sequential scatter_add_).  All LDS reads are issued up front
+            // (independent, pipelined); the scan itself runs on registers under scalar control
+            // flow driven by a ballot of the segment starts.
             const int c = tid;
-            int cur = s_row[0];
+            float v[MT];
+#pragma unroll
+            for (int e = 0; e < MT; ++e) v[e] = buf[e * LDA(H) + c] * s_att[e];
+            const int lane = tid & 63;
+            const bool st = lane < ne && (lane == 0 || s_row[lane] != s_row[lane > 0 ? lane - 1 : 0]);
+            const unsigned long long starts = __ballot(st);          // bit e: row e begins a receiver segment
             float sum = 0.f;
-            bool first = true;
-            for (int e = 0; e < ne; ++e) {
-                const int rr = s_row[e];
-                if (rr != cur) {
-                    float* dst = w.agg + (size_t)cur * H + c;
-                    if (first) atomicAdd(dst, sum); else *dst = sum;     // a segment may continue from the previous tile
-                    first = false; cur = rr; sum = 0.f;
+            int seg0 = 0;
+#pragma unroll
+            for (int e = 0; e < MT; ++e) {
+                if (e < ne) {
+                    if (e > 0 && ((starts >> e) & 1ull)) {            // wave-uniform: flush the finished segment
+                        float* dst = w.agg + (size_t)s_row[seg0] * H + c;
+                        if (seg0 == 0) atomicAdd(dst, sum); else *dst = sum;   // a segment may continue from the previous tile
+                        seg0 = e; sum = 0.f;
+                    }
+                    sum += v[e];
                 }
-                sum += buf[e * LDA(H) + c] * s_att[e];
             }
-            atomicAdd(w.agg + (size_t)cur * H + c, sum);                 // ... or into the next one
+            atomicAdd(w.agg + (size_t)s_row[seg0] * H + c, sum);     // ... or into the next one
         }
         __syncthreads();
     }
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(H) void k_edge_msg(Layout lay, Work w, Dims d, Laye
 // evaluation gathers: P_c|Q_c for this block's coord MLP and P|Q for block l+1's edge MLP.
 // ------------------------------------------------------------------------------------
 template <int H, int MT>
-__global__ __launch_bounds__(H) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
+__global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
                                             int layer, int has_next) {
     __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     constexpr int LPR = H / 4;
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(H) void k_node(Layout lay, Work w, Dims d, LayerW l
 //   ACC[l][i] += (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant) * tanh(phi) * coords_range
 // ------------------------------------------------------------------------------------
 template <int H, int MT>
-__global__ __launch_bounds__(H) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer) {
+__global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer) {
     __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     __shared__ int s_row[MT], s_col[MT];
     __shared__ float s_r[MT], s_d0[MT];
@@ -620,7 +633,7 @@ template <int H, int MT> static void launch_node(const EvalLaunch& a, int l, hip
                        l, has_next);
 }
 template <int H, int MT> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
-    hipLaunchKernelGGL((k_edge_msg<H, MT>), dim3(a.edge_grid * (64 / MT)), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);
+    hipLaunchKernelGGL((k_edge_msg<H, MT>), dim3(a.edge_grid * (64 / MT)), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate);
 }
 template <int H, int MT> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
     hipLaunchKernelGGL((k_edge_coord<H, MT>), dim3(a.edge_grid * (64 / MT)), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);

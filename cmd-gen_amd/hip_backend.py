@@ -281,3 +281,4 @@ class Handle:
         self._check(self.lib.cmdgen_get_edge_profile(self.h, C.byref(ms), C.byref(n), self._stream()),
                     'cmdgen_get_edge_profile')
         return ms.value, n.value
+
