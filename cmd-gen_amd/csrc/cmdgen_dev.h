@@ -211,51 +211,79 @@ __device__ __forceinline__ void acc_foreach(const TileAcc<MT>& acc, int wave, F 
 #define CMDGEN_MFMA32(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, ACC, 0, 0, 0)
 #define CMDGEN_MFMA16(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, ACC, 0, 0, 0)
 
-// KB8 = k extent in blocks of 8; cg = index of this wave's 64-column group in the weight matrix.
-// Four register sets (A..D) hold the fragments of k-blocks kb..kb+3 and are refilled in place two
-// blocks ahead of their use, so the pipeline needs no register-rotation moves (VALU work is paid
-// in full next to fp32 MFMA on gfx950).
+// A wave's view of one packed weight matrix: base of its fragment stream and the stride between
+// its n-tiles (float4 units).  kb0_8 / kb_total8 are in blocks of 8 k; cg = the wave's 64-column group.
+struct FragPtr { const float4* p; unsigned ns; };
+template <int MT>
+__device__ __forceinline__ FragPtr frag_ptr(const WPack& W, int kb_total8, int kb0_8, int cg) {
+    const int lane = threadIdx.x & 63;
+    FragPtr f;
+    if constexpr (MT == 16) {
+        const int kbt = kb_total8 / 2;
+        f.p = W.w16 + ((size_t)(4 * cg) * kbt + kb0_8 / 2) * 64 + lane;
+        f.ns = (unsigned)kbt * 64u;
+    } else {
+        f.p = W.w32 + ((size_t)(2 * cg) * kb_total8 + kb0_8) * 64 + lane;
+        f.ns = (unsigned)kb_total8 * 64u;
+    }
+    return f;
+}
+// First two k-blocks of B fragments of a GEMM, fetched ahead of it (by the previous GEMM's last
+// iteration, or at kernel start) so that a GEMM never starts with an empty pipeline.
+template <int MT> struct BCarry { float4 a[MT == 16 ? 4 : 2], b[MT == 16 ? 4 : 2]; };
+
+template <int MT>
+__device__ __forceinline__ void gemm_prefetch(const FragPtr& f, BCarry<MT>& c) {
+    constexpr int NT = MT == 16 ? 4 : 2;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { c.a[n] = f.p[n * f.ns]; c.b[n] = f.p[n * f.ns + 64u]; }
+}
+
+// acc += A(lds) x W^T over KB8*8 k values.  Four register sets (A..D) hold the fragments of
+// k-blocks kb..kb+3 and are refilled in place two blocks ahead of their use, so the pipeline needs
+// no register-rotation moves (VALU work is paid in full next to fp32 MFMA on gfx950).  `carry`
+// brings this GEMM's first two blocks and leaves with the first two blocks of `next`.
 template <int MT, int KB8>
-__device__ __forceinline__ void tile_gemm(const float* __restrict__ ldsA, int lda, const WPack& W,
-                                          int kb_total8, int kb0_8, int cg, TileAcc<MT>& acc) {
+__device__ __forceinline__ void tile_gemm(const float* __restrict__ ldsA, int lda, const FragPtr cur,
+                                          const FragPtr next, TileAcc<MT>& acc, BCarry<MT>& carry) {
     const int lane = threadIdx.x & 63;
     if constexpr (MT == 16) {
         constexpr int KB = KB8 / 2;                      // k-blocks of 16
         static_assert(KB >= 4 && KB % 4 == 0, "K must be a multiple of 64");
-        const int kbt = kb_total8 / 2, kb0 = kb0_8 / 2;
         const float* ap = ldsA + (lane & 15) * lda + (lane >> 4) * 4;
-        const float4* bp = W.w16 + ((size_t)(4 * cg) * kbt + kb0) * 64 + lane;
-        const unsigned ns = (unsigned)kbt * 64;          // stride between n-tiles (float4 units)
-        float4 bA[4], bB[4], bC[4], bD[4], aA, aB, aC, aD;
-#define LOADB16(DST, KBI) _Pragma("unroll") for (int n = 0; n < 4; ++n) DST[n] = bp[n * ns + (unsigned)(KBI) * 64u];
+        float4 bC[4], bD[4], aA, aB, aC, aD;
+#define LOADB16(DST, F, KBI) _Pragma("unroll") for (int n = 0; n < 4; ++n) DST[n] = F.p[n * F.ns + (unsigned)(KBI) * 64u];
 #define LOADA16(DST, KBI) DST = *reinterpret_cast<const float4*>(ap + (KBI) * 16);
 #define STEP16(AV, BV)                                                                        \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.x, BV[n].x);  \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.y, BV[n].y);  \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.z, BV[n].z);  \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) CMDGEN_MFMA16(acc.a[n], AV.w, BV[n].w);
-        LOADB16(bA, 0) LOADB16(bB, 1) LOADA16(aA, 0) LOADA16(aB, 1)
+#define QUAD16(KB_, FN, KN4, KN5)                                                             \
+            LOADB16(bC, cur, KB_ + 2) LOADA16(aC, KB_ + 2)                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            STEP16(aA, carry.a)                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            LOADB16(bD, cur, KB_ + 3) LOADA16(aD, KB_ + 3)                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            STEP16(aB, carry.b)                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            LOADB16(carry.a, FN, KN4)                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            STEP16(aC, bC)                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            LOADB16(carry.b, FN, KN5)                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            STEP16(aD, bD)                                                                    \
+            __builtin_amdgcn_sched_barrier(0);
+        LOADA16(aA, 0) LOADA16(aB, 1)
 #pragma unroll 1
-        for (int kb = 0; kb < KB; kb += 4) {
-            const int k4 = (kb + 4 < KB) ? kb + 4 : KB - 1;   // clamped: the tail re-reads valid memory
-            const int k5 = (kb + 5 < KB) ? kb + 5 : KB - 1;
-            LOADB16(bC, kb + 2) LOADA16(aC, kb + 2)
-            __builtin_amdgcn_sched_barrier(0);
-            STEP16(aA, bA)
-            __builtin_amdgcn_sched_barrier(0);
-            LOADB16(bD, kb + 3) LOADA16(aD, kb + 3)
-            __builtin_amdgcn_sched_barrier(0);
-            STEP16(aB, bB)
-            __builtin_amdgcn_sched_barrier(0);
-            LOADB16(bA, k4) LOADA16(aA, k4)
-            __builtin_amdgcn_sched_barrier(0);
-            STEP16(aC, bC)
-            __builtin_amdgcn_sched_barrier(0);
-            LOADB16(bB, k5) LOADA16(aB, k5)
-            __builtin_amdgcn_sched_barrier(0);
-            STEP16(aD, bD)
-            __builtin_amdgcn_sched_barrier(0);
+        for (int kb = 0; kb < KB - 4; kb += 4) {
+            QUAD16(kb, cur, kb + 4, kb + 5)
+            LOADA16(aA, kb + 4) LOADA16(aB, kb + 5)
         }
+        QUAD16(KB - 4, next, 0, 1)
+#undef QUAD16
 #undef STEP16
 #undef LOADB16
 #undef LOADA16
@@ -264,39 +292,40 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ ldsA, int ld
         constexpr int KB = KB8;
         static_assert(KB >= 4 && KB % 4 == 0, "K must be a multiple of 32");
         const float* a0p = ldsA + (lane & 31) * lda + (lane >> 5) * 4;
-        const float4* b0p = W.w32 + ((size_t)(2 * cg) * kb_total8 + kb0_8) * 64 + lane;
-        const float4* b1p = b0p + (size_t)kb_total8 * 64;
-        float4 bA0, bA1, bB0, bB1, bC0, bC1, bD0, bD1;
+        float4 bC[2], bD[2];
         float4 aA[NMT], aB[NMT], aC[NMT], aD[NMT];
-#define LOADB32(D0, D1, KBI) D0 = b0p[(unsigned)(KBI) * 64u]; D1 = b1p[(unsigned)(KBI) * 64u];
+#define LOADB32(DST, F, KBI) DST[0] = F.p[(unsigned)(KBI) * 64u]; DST[1] = F.p[F.ns + (unsigned)(KBI) * 64u];
 #define LOADA32(DST, KBI) _Pragma("unroll") for (int m = 0; m < NMT; ++m) DST[m] = *reinterpret_cast<const float4*>(a0p + m * 32 * lda + (KBI) * 8);
-#define STEP32(AV, B0, B1)                                                                    \
-        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].x, B0.x); CMDGEN_MFMA32(acc.a[m][1], AV[m].x, B1.x); } \
-        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].y, B0.y); CMDGEN_MFMA32(acc.a[m][1], AV[m].y, B1.y); } \
-        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].z, B0.z); CMDGEN_MFMA32(acc.a[m][1], AV[m].z, B1.z); } \
-        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].w, B0.w); CMDGEN_MFMA32(acc.a[m][1], AV[m].w, B1.w); }
-        LOADB32(bA0, bA1, 0) LOADB32(bB0, bB1, 1) LOADA32(aA, 0) LOADA32(aB, 1)
+#define STEP32(AV, BV)                                                                        \
+        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].x, BV[0].x); CMDGEN_MFMA32(acc.a[m][1], AV[m].x, BV[1].x); } \
+        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].y, BV[0].y); CMDGEN_MFMA32(acc.a[m][1], AV[m].y, BV[1].y); } \
+        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].z, BV[0].z); CMDGEN_MFMA32(acc.a[m][1], AV[m].z, BV[1].z); } \
+        _Pragma("unroll") for (int m = 0; m < NMT; ++m) { CMDGEN_MFMA32(acc.a[m][0], AV[m].w, BV[0].w); CMDGEN_MFMA32(acc.a[m][1], AV[m].w, BV[1].w); }
+#define QUAD32(KB_, FN, KN4, KN5)                                                             \
+            LOADB32(bC, cur, KB_ + 2) LOADA32(aC, KB_ + 2)                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            STEP32(aA, carry.a)                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            LOADB32(bD, cur, KB_ + 3) LOADA32(aD, KB_ + 3)                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            STEP32(aB, carry.b)                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            LOADB32(carry.a, FN, KN4)                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            STEP32(aC, bC)                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            LOADB32(carry.b, FN, KN5)                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            STEP32(aD, bD)                                                                    \
+            __builtin_amdgcn_sched_barrier(0);
+        LOADA32(aA, 0) LOADA32(aB, 1)
 #pragma unroll 1
-        for (int kb = 0; kb < KB; kb += 4) {
-            const int k4 = (kb + 4 < KB) ? kb + 4 : KB - 1;
-            const int k5 = (kb + 5 < KB) ? kb + 5 : KB - 1;
-            LOADB32(bC0, bC1, kb + 2) LOADA32(aC, kb + 2)
-            __builtin_amdgcn_sched_barrier(0);
-            STEP32(aA, bA0, bA1)
-            __builtin_amdgcn_sched_barrier(0);
-            LOADB32(bD0, bD1, kb + 3) LOADA32(aD, kb + 3)
-            __builtin_amdgcn_sched_barrier(0);
-            STEP32(aB, bB0, bB1)
-            __builtin_amdgcn_sched_barrier(0);
-            LOADB32(bA0, bA1, k4) LOADA32(aA, k4)
-            __builtin_amdgcn_sched_barrier(0);
-            STEP32(aC, bC0, bC1)
-            __builtin_amdgcn_sched_barrier(0);
-            LOADB32(bB0, bB1, k5) LOADA32(aB, k5)
-            __builtin_amdgcn_sched_barrier(0);
-            STEP32(aD, bD0, bD1)
-            __builtin_amdgcn_sched_barrier(0);
+        for (int kb = 0; kb < KB - 4; kb += 4) {
+            QUAD32(kb, cur, kb + 4, kb + 5)
+            LOADA32(aA, kb + 4) LOADA32(aB, kb + 5)
         }
+        QUAD32(KB - 4, next, 0, 1)
+#undef QUAD32
 #undef STEP32
 #undef LOADB32
 #undef LOADA32

@@ -164,20 +164,23 @@ __device__ __forceinline__ void store_acc_rows(const TileAcc<MT>& acc, int wave,
 }
 
 // P|Q = BUF x Wpq^T for an MT-row tile already resident in LDS: two passes of H columns.
+// `carry` holds the first fragments of the first pass; `after` is the GEMM that follows this call
+// (its first fragments are fetched by the last iteration here).
 template <int H, int MT>
 __device__ __forceinline__ void tile_project_pq(const float* buf, const WPack& Wpq,
                                                 const float* __restrict__ bias_p, float* __restrict__ Pout,
                                                 float* __restrict__ Qout, int row0, int nvalid,
-                                                bool want_p) {
+                                                bool want_p, BCarry<MT>& carry, const FragPtr after) {
     const int wave = threadIdx.x >> 6;
+    const FragPtr fp = frag_ptr<MT>(Wpq, H / 8, 0, wave), fq = frag_ptr<MT>(Wpq, H / 8, 0, H / 64 + wave);
     TileAcc<MT> acc;
     if (want_p) {
         acc_zero<MT>(acc);
-        tile_gemm<MT, H / 8>(buf, LDA(H), Wpq, H / 8, 0, wave, acc);
+        tile_gemm<MT, H / 8>(buf, LDA(H), fp, fq, acc, carry);
         store_acc_rows<H, MT>(acc, wave, Pout, row0, nvalid, bias_p);
     }
     acc_zero<MT>(acc);
-    tile_gemm<MT, H / 8>(buf, LDA(H), Wpq, H / 8, 0, H / 64 + wave, acc);
+    tile_gemm<MT, H / 8>(buf, LDA(H), fq, after, acc, carry);
     store_acc_rows<H, MT>(acc, wave, Qout, row0, nvalid, nullptr);
 }
 
@@ -200,6 +203,9 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
     const int nvalid = min(MT, lay.N - row0);
     const int ldp = 3 + d.P, ldq = 3 + d.R;
     const int Fmax = max(d.P, d.R), F1max = 2 * Fmax;
+    BCarry<MT> carry;                                  // weight fragments of the projection, in flight during the encoders
+    const FragPtr f0 = frag_ptr<MT>(lw0.Wpq_e, H / 8, 0, tid >> 6);
+    gemm_prefetch<MT>(f0, carry);
     for (int r = 0; r < MT; ++r)                       // stage input features (row-major, coalesced)
         for (int k = tid; k < Fmax; k += nthr) {
             const int n = row0 + r;
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         }
     }
     __syncthreads();
-    tile_project_pq<H, MT>(buf, lw0.Wpq_e, lw0.b1, w.P, w.Q, row0, nvalid, true);
+    tile_project_pq<H, MT>(buf, lw0.Wpq_e, lw0.b1, w.P, w.Q, row0, nvalid, true, carry, f0);
 }
 
 // ------------------------------------------------------------------------------------
@@ -345,6 +351,9 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
     const int tid = threadIdx.x, wave = tid >> 6;
     const int E = w.totals[0];
     const int ntiles = (E + MT - 1) / MT;
+    const FragPtr fw = frag_ptr<MT>(lw.W2, H / 8, 0, wave);
+    BCarry<MT> carry;
+    if (blockIdx.x < ntiles) gemm_prefetch<MT>(fw, carry);   // refilled for the next tile by each GEMM's last iteration
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
         __syncthreads();
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
-        if (!(ablate & 4)) tile_gemm<MT, H / 8>(buf, LDA(H), lw.W2, H / 8, 0, wave, acc);
+        if (!(ablate & 4)) tile_gemm<MT, H / 8>(buf, LDA(H), fw, fw, acc, carry);
         __syncthreads();                         // every wave is done reading the A tile
         acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b2[col]); });   // m_ij
         __syncthreads();
@@ -417,6 +426,14 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     const int row0 = blockIdx.x * MT;
     const int nvalid = min(MT, lay.N - row0);
     const int c4 = tid % LPR, rsub = tid / LPR;
+    // the chain of GEMMs of this tile; each one's last iteration fetches the next one's first fragments
+    const bool want_pc = row0 < lay.Nl;
+    const FragPtr f3a = frag_ptr<MT>(lw.W3, 2 * H / 8, 0, wave), f3b = frag_ptr<MT>(lw.W3, 2 * H / 8, H / 8, wave);
+    const FragPtr f4 = frag_ptr<MT>(lw.W4, H / 8, 0, wave);
+    const FragPtr fc = frag_ptr<MT>(lw.Wpq_c, H / 8, 0, want_pc ? wave : H / 64 + wave);
+    const FragPtr fn = frag_ptr<MT>(lw_next.Wpq_e, H / 8, 0, wave);
+    BCarry<MT> carry;
+    gemm_prefetch<MT>(f3a, carry);
     // materialise the phar coordinates entering this block (see node_pos)
     if (layer >= 1 && tid < MT) {
         const int n = row0 + tid;
@@ -432,7 +449,7 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     __syncthreads();
     TileAcc<MT> acc;
     acc_zero<MT>(acc);
-    tile_gemm<MT, H / 8>(buf, LDA(H), lw.W3, 2 * H / 8, 0, wave, acc);                  // h part of [h | agg]
+    tile_gemm<MT, H / 8>(buf, LDA(H), f3a, f3b, acc, carry);                              // h part of [h | agg]
     __syncthreads();
 #pragma unroll 4
     for (int pass = 0; pass < MT / 4; ++pass) {
@@ -447,12 +464,12 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
         *reinterpret_cast<float4*>(buf + r * LDA(H) + 4 * c4) = v;
     }
     __syncthreads();
-    tile_gemm<MT, H / 8>(buf, LDA(H), lw.W3, 2 * H / 8, H / 8, wave, acc);              // agg part
+    tile_gemm<MT, H / 8>(buf, LDA(H), f3b, f4, acc, carry);                               // agg part
     __syncthreads();
     acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b3[col]); });
     __syncthreads();
     acc_zero<MT>(acc);
-    tile_gemm<MT, H / 8>(buf, LDA(H), lw.W4, H / 8, 0, wave, acc);
+    tile_gemm<MT, H / 8>(buf, LDA(H), f4, fc, acc, carry);
     __syncthreads();
     acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
         float hn = 0.f;
@@ -465,8 +482,8 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     });
     __syncthreads();
     // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
-    tile_project_pq<H, MT>(buf, lw.Wpq_c, lw.b6, w.Pc, w.Qc, row0, nvalid, row0 < lay.Nl);
-    if (has_next) tile_project_pq<H, MT>(buf, lw_next.Wpq_e, lw_next.b1, w.P, w.Q, row0, nvalid, true);
+    tile_project_pq<H, MT>(buf, lw.Wpq_c, lw.b6, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
+    if (has_next) tile_project_pq<H, MT>(buf, lw_next.Wpq_e, lw_next.b1, w.P, w.Q, row0, nvalid, true, carry, fn);
 }
 
 // ------------------------------------------------------------------------------------
@@ -484,6 +501,9 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
     const int tid = threadIdx.x, wave = tid >> 6;
     const int E = w.totals[1];
     const int ntiles = (E + MT - 1) / MT;
+    const FragPtr fw = frag_ptr<MT>(lw.W7, H / 8, 0, wave);
+    BCarry<MT> carry;
+    if (blockIdx.x < ntiles) gemm_prefetch<MT>(fw, carry);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
@@ -506,7 +526,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
         __syncthreads();
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
-        tile_gemm<MT, H / 8>(buf, LDA(H), lw.W7, H / 8, 0, wave, acc);
+        tile_gemm<MT, H / 8>(buf, LDA(H), fw, fw, acc, carry);
         __syncthreads();
         acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b7[col]); });
         __syncthreads();
