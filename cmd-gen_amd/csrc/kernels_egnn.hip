@@ -227,6 +227,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         if (o >= 2 * F) continue;
         const float* W = (ph ? sw.pe0_w : sw.re0_w) + (size_t)o * F;
         float s = (ph ? sw.pe0_b : sw.re0_b)[o];
+#pragma unroll 4
         for (int k = 0; k < F; ++k) s = fmaf(s_in[r][k], W[k], s);
         s_h1[r][o] = silu_f(s);
     }
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
                 const int F2 = 2 * (ph ? d.P : d.R);
                 const float* W = (ph ? sw.pe2_w : sw.re2_w) + (size_t)j * F2;
                 s = (ph ? sw.pe2_b : sw.re2_b)[j];
+#pragma unroll 4
                 for (int k = 0; k < F2; ++k) s = fmaf(s_h1[r][k], W[k], s);
             } else {
                 s = t_arr ? t_arr[lay.node_sample[n]] : coef[chain->step].w;
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         float accr[MT];
 #pragma unroll
         for (int r = 0; r < MT; ++r) accr[r] = bc;
+#pragma unroll 4
         for (int k = 0; k < d.dyn; ++k) {
             const float wk = sw.emb_wT[(size_t)k * H + c];
 #pragma unroll
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, SmallW sw,
                                                  float* __restrict__ eps_phar, float* __restrict__ eps_pocket) {
-    extern __shared__ float s_hrow[];            // [8][H]
+    extern __shared__ float s_hrow[];            // [8][H] node rows, then [H][dyn] embedding_out^T
     __shared__ float s_j[8][CMDGEN_MAX_SMALL + 1];
     __shared__ float s_h1[8][CMDGEN_MAX_SMALL];
     const int tid = threadIdx.x, g = tid >> 5, l32 = tid & 31;
@@ -574,18 +577,20 @@ __global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, Sma
     const bool live = n < nnodes;
     const bool ph = n < lay.Nl;
     const int H = d.H;
+    float* s_wT = s_hrow + 8 * H;
+    for (int i = tid; i < H * d.dyn; i += 256) s_wT[i] = sw.embo_wT[i];        // coalesced, all loads in flight
     if (live) for (int k = l32; k < H; k += 32) s_hrow[g * H + k] = w.h[(size_t)n * H + k];
     __syncthreads();
     if (live) {
         for (int j = l32; j < d.J; j += 32) {
             float s0 = sw.embo_b[j], s1 = 0.f, s2 = 0.f, s3 = 0.f;
             const float* hr = s_hrow + g * H;
-            const float* wt = sw.embo_wT + j;
+            const float* wt = s_wT + j;
             for (int k = 0; k < H; k += 4) {
-                s0 = fmaf(hr[k], wt[(size_t)k * d.dyn], s0);
-                s1 = fmaf(hr[k + 1], wt[(size_t)(k + 1) * d.dyn], s1);
-                s2 = fmaf(hr[k + 2], wt[(size_t)(k + 2) * d.dyn], s2);
-                s3 = fmaf(hr[k + 3], wt[(size_t)(k + 3) * d.dyn], s3);
+                s0 = fmaf(hr[k], wt[k * d.dyn], s0);
+                s1 = fmaf(hr[k + 1], wt[(k + 1) * d.dyn], s1);
+                s2 = fmaf(hr[k + 2], wt[(k + 2) * d.dyn], s2);
+                s3 = fmaf(hr[k + 3], wt[(k + 3) * d.dyn], s3);
             }
             s_j[g][j] = (s0 + s1) + (s2 + s3);
         }
@@ -689,7 +694,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     }
     REC();
     const int nn = eps_pocket ? N : a.lay.Nl;
-    hipLaunchKernelGGL(k_readout, dim3((nn + 7) / 8), dim3(256), 8 * a.d.H * sizeof(float), s, a.lay, a.w, a.d, a.sw,
+    hipLaunchKernelGGL(k_readout, dim3((nn + 7) / 8), dim3(256), (8 + a.d.dyn) * a.d.H * sizeof(float), s, a.lay, a.w, a.d, a.sw,
                        eps_phar, eps_pocket);
     REC();
 #undef REC
