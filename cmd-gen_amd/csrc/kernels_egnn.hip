@@ -422,8 +422,14 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
 // ------------------------------------------------------------------------------------
 template <int H, int MT>
 __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
-                                            int layer, int has_next) {
-    __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
+                                               int layer, int has_next) {
+    // Tiles of <= 32 rows keep two LDS images: buf0 = h (kept for the residual), buf1 = agg -> T -> h_new,
+    // so h and agg are fetched together and the residual needs no second global read.  64-row tiles
+    // (66 KB each) use one image so that two workgroups still fit a CU.
+    constexpr bool TWO = MT <= 32;
+    __shared__ __attribute__((aligned(16))) float bufs[(TWO ? 2 : 1) * MT * LDA(H)];
+    float* buf0 = bufs;
+    float* buf1 = TWO ? bufs + MT * LDA(H) : bufs;
     constexpr int LPR = H / 4;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int row0 = blockIdx.x * MT;
@@ -442,51 +448,84 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
         const int n = row0 + tid;
         if (tid < nvalid && n < lay.Nl) w.XL[(size_t)layer * lay.Nl + n] = node_pos(lay, w, d, n, layer, true);
     }
+    auto load_h = [&]() {
 #pragma unroll 4
-    for (int pass = 0; pass < MT / 4; ++pass) {
-        const int r = pass * 4 + rsub;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nvalid) v = reinterpret_cast<const float4*>(w.h + (size_t)(row0 + r) * H)[c4];
-        *reinterpret_cast<float4*>(buf + r * LDA(H) + 4 * c4) = v;
-    }
-    __syncthreads();
+        for (int pass = 0; pass < MT / 4; ++pass) {
+            const int r = pass * 4 + rsub;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nvalid) v = reinterpret_cast<const float4*>(w.h + (size_t)(row0 + r) * H)[c4];
+            *reinterpret_cast<float4*>(buf0 + r * LDA(H) + 4 * c4) = v;
+        }
+    };
+    auto load_agg = [&]() {
+#pragma unroll 4
+        for (int pass = 0; pass < MT / 4; ++pass) {
+            const int r = pass * 4 + rsub;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nvalid) {
+                float4* g = reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H) + c4;
+                v = *g;
+                *g = make_float4(0.f, 0.f, 0.f, 0.f);                                     // agg is zero between blocks
+                v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
+            }
+            *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
+        }
+    };
     TileAcc<MT> acc;
     acc_zero<MT>(acc);
-    tile_gemm<MT, H / 8>(buf, LDA(H), f3a, f3b, acc, carry);                              // h part of [h | agg]
-    __syncthreads();
-#pragma unroll 4
-    for (int pass = 0; pass < MT / 4; ++pass) {
-        const int r = pass * 4 + rsub;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nvalid) {
-            float4* g = reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H) + c4;
-            v = *g;
-            *g = make_float4(0.f, 0.f, 0.f, 0.f);                                         // agg is zero between blocks
-            v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
+    if constexpr (TWO) {
+        // all global loads of both images in flight together, then the LDS writes
+        float4 hv[MT / 4], av[MT / 4];
+#pragma unroll
+        for (int pass = 0; pass < MT / 4; ++pass) {
+            const int r = pass * 4 + rsub;
+            hv[pass] = make_float4(0.f, 0.f, 0.f, 0.f); av[pass] = hv[pass];
+            if (r < nvalid) {
+                hv[pass] = reinterpret_cast<const float4*>(w.h + (size_t)(row0 + r) * H)[c4];
+                av[pass] = reinterpret_cast<const float4*>(w.agg + (size_t)(row0 + r) * H)[c4];
+            }
         }
-        *reinterpret_cast<float4*>(buf + r * LDA(H) + 4 * c4) = v;
+#pragma unroll
+        for (int pass = 0; pass < MT / 4; ++pass) {
+            const int r = pass * 4 + rsub;
+            if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
+            float4 v = av[pass];
+            v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
+            *reinterpret_cast<float4*>(buf0 + r * LDA(H) + 4 * c4) = hv[pass];
+            *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
+        }
+        __syncthreads();
+        tile_gemm<MT, H / 8>(buf0, LDA(H), f3a, f3b, acc, carry);                         // h part of [h | agg]
+        tile_gemm<MT, H / 8>(buf1, LDA(H), f3b, f4, acc, carry);                          // agg part
+    } else {
+        load_h();
+        __syncthreads();
+        tile_gemm<MT, H / 8>(buf0, LDA(H), f3a, f3b, acc, carry);
+        __syncthreads();
+        load_agg();
+        __syncthreads();
+        tile_gemm<MT, H / 8>(buf1, LDA(H), f3b, f4, acc, carry);
     }
     __syncthreads();
-    tile_gemm<MT, H / 8>(buf, LDA(H), f3b, f4, acc, carry);                               // agg part
-    __syncthreads();
-    acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b3[col]); });
+    acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf1[row * LDA(H) + col] = silu_f(v + lw.b3[col]); });
     __syncthreads();
     acc_zero<MT>(acc);
-    tile_gemm<MT, H / 8>(buf, LDA(H), f4, fc, acc, carry);
+    tile_gemm<MT, H / 8>(buf1, LDA(H), f4, fc, acc, carry);
     __syncthreads();
     acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
         float hn = 0.f;
         if (row < nvalid) {
             float* hp = w.h + (size_t)(row0 + row) * H + col;
-            hn = *hp + (v + lw.b4[col]);                                                  // residual (egnn_new.py:57)
+            const float hold = TWO ? buf0[row * LDA(H) + col] : *hp;
+            hn = hold + (v + lw.b4[col]);                                                 // residual (egnn_new.py:57)
             *hp = hn;
         }
-        buf[row * LDA(H) + col] = hn;
+        buf1[row * LDA(H) + col] = hn;
     });
     __syncthreads();
     // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
-    tile_project_pq<H, MT>(buf, lw.Wpq_c, lw.b6, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
-    if (has_next) tile_project_pq<H, MT>(buf, lw_next.Wpq_e, lw_next.b1, w.P, w.Q, row0, nvalid, true, carry, fn);
+    tile_project_pq<H, MT>(buf1, lw.Wpq_c, lw.b6, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
+    if (has_next) tile_project_pq<H, MT>(buf1, lw_next.Wpq_e, lw_next.b1, w.P, w.Q, row0, nvalid, true, carry, fn);
 }
 
 // ------------------------------------------------------------------------------------
