@@ -212,7 +212,7 @@ def main():
                 'whole_job_frac': f_alg / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and n_gpus == 1:      # timed on rank 0 at N=1 only
             result['cpu_baseline'] = cpu_baseline(cfg, sd, B, rep, args.n_phar, args.cpu_seconds)
             result['config']['gpu_over_cpu'] = value / result['cpu_baseline']['value']
         else:

@@ -51,7 +51,7 @@ struct cmdgen_handle {
     Layout lay{};
     Work work{};
     int64_t ecap = 0, eccap = 0;
-    int edge_grid = 512;
+    int edge_grid = 512, coord_grid = 256;
     int n_cus = 256;
     int node_mt = 64, edge_mt = 64, coord_mt = 64;   // rows per tile, chosen in cmdgen_set_layout
     int64_t* d_gid = nullptr;
@@ -362,7 +362,18 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
         if ((ev = getenv("CMDGEN_NODE_MT"))) h->node_mt = atoi(ev);
         if ((ev = getenv("CMDGEN_EDGE_MT"))) h->edge_mt = atoi(ev);
         if ((ev = getenv("CMDGEN_COORD_MT"))) h->coord_mt = atoi(ev);
+        // grids of the persistent-style edge kernels: enough workgroups for the estimated tile count, capped at
+        // what is co-resident per CU (2 at 64-row tiles, 4 below); surplus tiles are picked up by the loop
+        auto grid_for = [&](double rows, int mt) {
+            const double tiles = rows / mt + 1.0;
+            const int cap = (mt == 64 ? 2 : 4) * h->n_cus;
+            int g = (int)(tiles * 1.25) + 8;
+            return g < h->n_cus / 4 ? h->n_cus / 4 : (g > cap ? cap : g);
+        };
+        h->edge_grid = grid_for(e_est, h->edge_mt);
+        h->coord_grid = grid_for(ec_est, h->coord_mt);
         if ((ev = getenv("CMDGEN_EDGE_WGS_PER_CU"))) h->edge_grid = atoi(ev) * h->n_cus;
+        if ((ev = getenv("CMDGEN_COORD_WGS_PER_CU"))) h->coord_grid = atoi(ev) * h->n_cus;
         for (int* m : {&h->node_mt, &h->edge_mt, &h->coord_mt}) if (*m != 64 && *m != 32 && *m != 16) *m = 64;
     }
     h->cur_nphar.assign(nph, nph + B); h->cur_npocket.assign(npk, npk + B);
@@ -379,7 +390,7 @@ static int check_ready(cmdgen_handle* h) {
 
 static EvalLaunch make_launch(cmdgen_handle* h) {
     EvalLaunch a; a.lay = h->lay; a.w = h->work; a.d = h->dims; a.sw = h->small; a.layers = h->layers.data();
-    a.edge_grid = h->edge_grid;
+    a.edge_grid = h->edge_grid; a.coord_grid = h->coord_grid;
     a.msg_events = nullptr; a.ablate = 0;
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     return a;

@@ -127,7 +127,7 @@ struct ChainBuf {               // device pointers owned by the handle for one c
 struct EvalLaunch {             // everything one evaluation's launches need (host side)
     Layout lay; Work w; Dims d; SmallW sw;
     const LayerW* layers;       // host array [L]
-    int edge_grid;              // workgroups of the persistent-style edge kernels
+    int edge_grid, coord_grid;  // workgroups of the persistent-style edge kernels (tiles are taken round-robin)
     int node_mt, edge_mt, coord_mt;   // rows per tile (64, 32 or 16) chosen per launch from the row counts
     std::vector<hipEvent_t>* msg_events;   // when non-null: event pair around every edge-message launch
     int ablate;                 // timing-only builds of the edge kernel (cmdgen_time_edge_kernel); 0 in production

@@ -18,6 +18,14 @@
 
 #define LDA(H) ((H) + 4)
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e.
+// drains every outstanding global store / atomic of the wave (1-3 us each time); the barriers of
+// the tile kernels only hand LDS tiles between phases, so stores and atomics stay in flight.
+// Loads whose values are needed are still waited for by the compiler's own counted s_waitcnt.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------
 // Radius graph.  One workgroup per sample; a wave scans the candidate senders of one
 // receiver at a time, so neighbours come out in ascending sender order and ballots give
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
             }
             s_in[r][k] = v;
         }
-    __syncthreads();
+    lds_barrier();
     // encoder layer 0 + SiLU: thread -> (row r, output o)
     for (int idx = tid; idx < MT * F1max; idx += nthr) {
         const int r = idx / F1max, o = idx - r * F1max;
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         for (int k = 0; k < F; ++k) s = fmaf(s_in[r][k], W[k], s);
         s_h1[r][o] = silu_f(s);
     }
-    __syncthreads();
+    lds_barrier();
     // encoder layer 2 -> joint space, then the time column (dynamics.py:92-99)
     for (int idx = tid; idx < MT * d.dyn; idx += nthr) {
         const int r = idx / d.dyn, j = idx - r * d.dyn;
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         }
         s_h2[r][j] = s;
     }
-    __syncthreads();
+    lds_barrier();
     {   // embedding dyn -> H: one output column per thread, weights transposed [dyn][H] (coalesced)
         const int c = tid;
         const float bc = sw.emb_b[c];
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
             if (r < nvalid) w.h[(size_t)(row0 + r) * H + c] = s;
         }
     }
-    __syncthreads();
+    lds_barrier();
     tile_project_pq<H, MT>(buf, lw0.Wpq_e, lw0.b1, w.P, w.Q, row0, nvalid, true, carry, f0);
 }
 
@@ -368,21 +376,21 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
             }
             s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
         }
-        __syncthreads();
+        lds_barrier();
         if (!(ablate & 2)) build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, lw.wr_e, lw.wd_e);
-        __syncthreads();
+        lds_barrier();
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
         if (!(ablate & 4)) tile_gemm<MT, H / 8>(buf, LDA(H), fw, fw, acc, carry);
-        __syncthreads();                         // every wave is done reading the A tile
+        lds_barrier();                         // every wave is done reading the A tile
         acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b2[col]); });   // m_ij
-        __syncthreads();
+        lds_barrier();
         if (!(ablate & 16)) {   // attention gate: sigmoid(w_a . m_ij + b_a)
             int r; bool lead;
             const float s = tile_row_dot<H, MT>(buf, lw.wa, r, lead);
             if (lead) s_att[r] = d.attention ? sigmoid_f(s + lw.ba) : 1.0f;
         }
-        __syncthreads();
+        lds_barrier();
         if (!(ablate & 8)) {
             // Segment sum over the tile's rows, one column per thread, edge order preserved
             // (= the reference's sequential scatter_add_).  All LDS reads are issued up front
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
             }
             atomicAdd(w.agg + (size_t)s_row[seg0] * H + c, sum);     // ... or into the next one
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -494,24 +502,24 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
             *reinterpret_cast<float4*>(buf0 + r * LDA(H) + 4 * c4) = hv[pass];
             *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
         }
-        __syncthreads();
+        lds_barrier();
         tile_gemm<MT, H / 8>(buf0, LDA(H), f3a, f3b, acc, carry);                         // h part of [h | agg]
         tile_gemm<MT, H / 8>(buf1, LDA(H), f3b, f4, acc, carry);                          // agg part
     } else {
         load_h();
-        __syncthreads();
+        lds_barrier();
         tile_gemm<MT, H / 8>(buf0, LDA(H), f3a, f3b, acc, carry);
-        __syncthreads();
+        lds_barrier();
         load_agg();
-        __syncthreads();
+        lds_barrier();
         tile_gemm<MT, H / 8>(buf1, LDA(H), f3b, f4, acc, carry);
     }
-    __syncthreads();
+    lds_barrier();
     acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf1[row * LDA(H) + col] = silu_f(v + lw.b3[col]); });
-    __syncthreads();
+    lds_barrier();
     acc_zero<MT>(acc);
     tile_gemm<MT, H / 8>(buf1, LDA(H), f4, fc, acc, carry);
-    __syncthreads();
+    lds_barrier();
     acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
         float hn = 0.f;
         if (row < nvalid) {
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
         }
         buf1[row * LDA(H) + col] = hn;
     });
-    __syncthreads();
+    lds_barrier();
     // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
     tile_project_pq<H, MT>(buf1, lw.Wpq_c, lw.b6, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
     if (has_next) tile_project_pq<H, MT>(buf1, lw_next.Wpq_e, lw_next.b1, w.P, w.Q, row0, nvalid, true, carry, fn);
@@ -563,15 +571,15 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
             s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
             s_cd[tid][0] = cx; s_cd[tid][1] = cy; s_cd[tid][2] = cz;
         }
-        __syncthreads();
+        lds_barrier();
         build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, lw.wr_c, lw.wd_c);
-        __syncthreads();
+        lds_barrier();
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
         tile_gemm<MT, H / 8>(buf, LDA(H), fw, fw, acc, carry);
-        __syncthreads();
+        lds_barrier();
         acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b7[col]); });
-        __syncthreads();
+        lds_barrier();
         {
             int r; bool lead;
             const float s = tile_row_dot<H, MT>(buf, lw.w5, r, lead);
@@ -580,7 +588,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
                 s_tr[r][0] = s_cd[r][0] * g; s_tr[r][1] = s_cd[r][1] * g; s_tr[r][2] = s_cd[r][2] * g;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < 3) {   // segment sum of the three components in edge order
             int cur = s_row[0];
             float sum = 0.f;
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
             }
             atomicAdd(reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nl + cur) + tid, sum);
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -697,10 +705,10 @@ template <int H, int MT> static void launch_node(const EvalLaunch& a, int l, hip
                        l, has_next);
 }
 template <int H, int MT> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
-    hipLaunchKernelGGL((k_edge_msg<H, MT>), dim3(a.edge_grid * (64 / MT)), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate);
+    hipLaunchKernelGGL((k_edge_msg<H, MT>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate);
 }
 template <int H, int MT> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
-    hipLaunchKernelGGL((k_edge_coord<H, MT>), dim3(a.edge_grid * (64 / MT)), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);
+    hipLaunchKernelGGL((k_edge_coord<H, MT>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);
 }
 #define MT_DISPATCH(mt, FN, ...) do { if ((mt) == 64) FN<H, 64>(__VA_ARGS__); else if ((mt) == 32) FN<H, 32>(__VA_ARGS__); \
                                       else FN<H, 16>(__VA_ARGS__); } while (0)

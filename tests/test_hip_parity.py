@@ -266,3 +266,88 @@ def test_errors_are_loud():
     with pytest.raises(hip_backend.CmdgenError):
         h.set_layout([3], [10])
         h.dynamics_forward(torch.zeros(3, 11).cuda(), torch.zeros(10, 23).cuda(), torch.zeros(1).cuda())  # no weights
+
+
+PDB_TEXT = """\
+ATOM      1  CA  ALA A   1      11.639   6.071  -5.147  1.00  0.00           C
+ATOM      2  CA  GLY A   2      14.000   7.500  -3.000  1.00  0.00           C
+ATOM      3  CA  TRP A   3      16.500   9.000  -1.000  1.00  0.00           C
+ATOM      4  CA  LEU A   4      12.500   9.500  -2.000  1.00  0.00           C
+ATOM      5  CA  SER A   5      10.000   8.000   0.500  1.00  0.00           C
+ATOM      6  CA  ASP A   6      13.500   4.000  -1.500  1.00  0.00           C
+END
+"""
+
+
+def test_generate_phars_end_to_end(tmp_path):
+    """BASELINE config[0] plumbing on the GPU: PDB -> pocket tensors -> 50 strided steps of a T=500
+    model -> per-'Molecule_k' dict, through PharPocketDDPM.generate_phars and the CLI."""
+    import json
+    from argparse import Namespace
+    from cmdgen_amd.lightning_modules import PharPocketDDPM
+    from cmdgen_amd import generate_phars as cli
+    hp = dict(outdir='out', dataset='crossdock', datadir='data', batch_size=4, lr=1e-4,
+              egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=256, n_layers=5,
+                                    attention=True, tanh=True, norm_constant=1, inv_sublayers=1, sin_embedding=False,
+                                    aggregation_method='sum', normalization_factor=100),
+              diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
+                                         diffusion_noise_precision=1e-5, diffusion_loss_type='l2',
+                                         normalize_factors=[1, 4]),
+              num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
+              eval_params=Namespace(n_eval_samples=100, eval_batch_size=100), mode='pocket_conditioning',
+              node_histogram=np.ones((30, 70)), pocket_representation='CA')
+    model = PharPocketDDPM(**hp)
+    sd = make_state_dict(ModelConfig(), seed=0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    ck = tmp_path / 'm.ckpt'
+    model.save_checkpoint(str(ck))
+    pdb = tmp_path / 'p.pdb'
+    pdb.write_text(PDB_TEXT)
+    model = PharPocketDDPM.load_from_checkpoint(str(ck), map_location='cuda').cuda()
+    out = model.generate_phars(str(pdb), 1, pocket_ids=[f'A:{i}' for i in range(1, 7)],
+                               num_nodes_phar=torch.tensor([8]), timesteps=50, seed=3)
+    assert sorted(out) == [f'Molecule_{k}' for k in range(1, 9)]           # 8 points of the one sample
+    pts = [c for feats in out.values() for cs in feats.values() for c in cs]
+    assert len(pts) == 8 and all(torch.isfinite(c).all() for c in pts)
+    names = {t for feats in out.values() for t in feats}
+    assert names <= set(model.dataset_info['phar_decoder'])
+    # same seed -> same sample; the CLI writes the JSON the next pipeline stage reads
+    out2 = model.generate_phars(str(pdb), 1, pocket_ids=[f'A:{i}' for i in range(1, 7)],
+                                num_nodes_phar=torch.tensor([8]), timesteps=50, seed=3)
+    a = torch.stack([c for k in sorted(out) for t in sorted(out[k]) for c in out[k][t]])
+    b = torch.stack([c for k in sorted(out2) for t in sorted(out2[k]) for c in out2[k][t]])
+    assert torch.allclose(a, b, atol=1e-3 * max(1.0, float(a.abs().max())))
+    plain = cli.main([str(ck), '--pdbfile', str(pdb), '--resi_list'] + [f'A:{i}' for i in range(1, 7)] +
+                     ['--n_samples', '3', '--num_nodes_phar', '4', '--timesteps', '20', '--outdir', str(tmp_path)])
+    written = json.load(open(tmp_path / cli.DEFAULT_JSON))
+    assert written == plain and sorted(written) == ['Molecule_1', 'Molecule_2', 'Molecule_3', 'Molecule_4']
+    assert sum(len(cs) for cs in written['Molecule_1'].values()) == 3       # k-th point of ALL 3 samples (quirk Q9)
+
+
+@pytest.mark.parametrize('nph,npk', [([1], [1]), ([1, 25, 3], [60, 30, 44]), ([5, 0, 7], [20, 33, 0])])
+def test_edge_case_layouts_match_oracle(nph, npk):
+    """Single-node samples, ragged extremes and samples with no phar / no pocket nodes."""
+    from oracle import ref_cpu
+    cfg = ModelConfig(hidden_nf=128, n_layers=2)
+    sd = make_state_dict(cfg, seed=77, coord_gain=1.0)
+    rng = np.random.Generator(np.random.PCG64(sum(nph) * 131 + sum(npk)))
+    B = len(nph)
+    pm, qm = np.repeat(np.arange(B), nph), np.repeat(np.arange(B), npk)
+    while True:
+        xp = rng.normal(size=(len(pm), 3)).astype(np.float32) * 3.0
+        xq = rng.normal(size=(len(qm), 3)).astype(np.float32) * 5.0
+        if min_cutoff_margin(np.concatenate([xp, xq]), np.concatenate([pm, qm]), 6.0) > 2e-3:
+            break
+    xh_phar = np.concatenate([xp, rng.normal(size=(len(pm), 8)).astype(np.float32)], 1)
+    oh = np.eye(20, dtype=np.float32)[rng.integers(0, 20, size=len(qm))] / 4.0
+    xh_pocket = np.concatenate([xq, oh], 1).astype(np.float32)
+    t = rng.uniform(0.1, 0.9, size=(B, 1)).astype(np.float32)
+    p = ref_cpu.to_torch_params(sd)
+    with torch.no_grad():
+        want, _ = ref_cpu.dynamics_forward(p, cfg.as_dict(), torch.from_numpy(xh_phar), torch.from_numpy(xh_pocket),
+                                           torch.from_numpy(t), torch.from_numpy(pm), torch.from_numpy(qm))
+    h = handle_for(cfg, 'edgecases', sd)
+    h.set_layout(nph, npk)
+    got, _ = h.dynamics_forward(dev(xh_phar), dev(xh_pocket), dev(t))
+    want = want.numpy()
+    assert float(np.abs(got.cpu().numpy() - want).max()) <= EVAL_TOL * max(1.0, float(np.abs(want).max()))

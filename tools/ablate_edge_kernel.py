@@ -1,6 +1,6 @@
 """Phase ablation of the edge-message kernel (timing-only; outputs are wrong while a phase is off)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import cmdgen_amd
 from cmdgen_amd import hip_backend
