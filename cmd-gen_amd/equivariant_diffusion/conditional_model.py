@@ -8,6 +8,8 @@ scalar table and reads the deferred checks afterwards.
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 import torch
 
@@ -32,9 +34,130 @@ class ConditionalDDPM(EnVariationalDiffusion):
     def sample(self, *args):
         raise NotImplementedError('Conditional model does not support sampling without given pocket.')
 
-    def forward(self, phar, pocket, return_info=False):
-        raise NotImplementedError('training loss (conditional_model.py:198-320) is the next scope row '
-                                  '(SURVEY.md section 8f #1); round 1 builds the sampling path')
+    # ---- loss terms (conditional_model.py:20-106, :158-320).  VALUES only: the network evaluation runs in
+    # the HIP library, which has no backward pass yet, so nothing here carries gradients (training is the
+    # next scope row).  The scalar algebra around the evaluation is host torch.
+    @staticmethod
+    def _seg_sum(x, idx, n):
+        return torch.zeros((n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device).index_add_(0, idx, x)
+
+    def sum_except_batch(self, x, indices, n):
+        return self._seg_sum(x.sum(-1), indices, n)
+
+    @staticmethod
+    def cdf_standard_gaussian(x):
+        return 0.5 * (1. + torch.erf(x / math.sqrt(2)))
+
+    @staticmethod
+    def gaussian_KL(q_mu_minus_p_mu_squared, q_sigma, p_sigma, d):
+        return d * torch.log(p_sigma / q_sigma) + 0.5 * (d * q_sigma ** 2 + q_mu_minus_p_mu_squared) / \
+            (p_sigma ** 2) - 0.5 * d
+
+    @staticmethod
+    def sample_gaussian(size, device):
+        return torch.randn(size, device=device)
+
+    def noised_representation(self, xh_phar, xh0_pocket, phar_mask, pocket_mask, gamma_t, eps=None):
+        alpha_t, sigma_t = self.alpha(gamma_t, xh_phar), self.sigma(gamma_t, xh_phar)
+        eps_phar = self.sample_gaussian((len(phar_mask), self.n_dims + self.phar_nf), phar_mask.device) \
+            if eps is None else eps
+        z_t = alpha_t[phar_mask] * xh_phar + sigma_t[phar_mask] * eps_phar
+        nd = self.n_dims
+        zx, px = self.remove_mean_batch(z_t[:, :nd], xh0_pocket[:, :nd], phar_mask, pocket_mask)
+        return torch.cat([zx, z_t[:, nd:]], 1), torch.cat([px, xh0_pocket[:, nd:]], 1), eps_phar
+
+    def kl_prior(self, xh_phar, mask_phar, num_nodes):
+        B, nd = len(num_nodes), self.n_dims
+        ones = torch.ones((B, 1), device=xh_phar.device)
+        gamma_T = self.gamma(ones)
+        mu_T = self.alpha(gamma_T, xh_phar)[mask_phar] * xh_phar
+        sigma_T = self.sigma(gamma_T, mu_T).squeeze()
+        one = torch.ones_like(sigma_T)
+        kl_h = self.gaussian_KL(self.sum_except_batch(mu_T[:, nd:] ** 2, mask_phar, B), sigma_T, one, d=1)
+        kl_x = self.gaussian_KL(self.sum_except_batch(mu_T[:, :nd] ** 2, mask_phar, B), sigma_T, one,
+                                self.subspace_dimensionality(num_nodes))
+        return kl_x + kl_h
+
+    def log_constants_p_x_given_z0(self, n_nodes, device):
+        B = len(n_nodes)
+        gamma_0 = self.gamma(torch.zeros((B, 1), device=device))
+        log_sigma_x = 0.5 * gamma_0.view(B)
+        return self.subspace_dimensionality(n_nodes) * (-log_sigma_x - 0.5 * np.log(2 * np.pi))
+
+    def log_pxh_given_z0_without_constants(self, phar, z_0_phar, eps_phar, net_out_phar, gamma_0, epsilon=1e-10):
+        nd, B = self.n_dims, len(phar['size'])
+        sigma_0_cat = self.sigma(gamma_0, target_tensor=z_0_phar) * self.norm_values[1]
+        log_px = -0.5 * self.sum_except_batch((eps_phar[:, :nd] - net_out_phar[:, :nd]) ** 2, phar['mask'], B)
+        phar_onehot = phar['one_hot'] * self.norm_values[1] + self.norm_biases[1]
+        centered = z_0_phar[:, nd:] * self.norm_values[1] + self.norm_biases[1] - 1
+        log_ph = torch.log(self.cdf_standard_gaussian((centered + 0.5) / sigma_0_cat[phar['mask']])
+                           - self.cdf_standard_gaussian((centered - 0.5) / sigma_0_cat[phar['mask']]) + epsilon)
+        log_ph = log_ph - torch.logsumexp(log_ph, dim=1, keepdim=True)
+        return log_px, self.sum_except_batch(log_ph * phar_onehot, phar['mask'], B)
+
+    def log_pN(self, N_phar, N_pocket):
+        return self.size_distribution.log_prob_n1_given_n2(N_phar, N_pocket)
+
+    def delta_log_px(self, num_nodes):
+        return -self.subspace_dimensionality(num_nodes) * np.log(self.norm_values[0])
+
+    def xh_given_zt_and_epsilon(self, z_t, epsilon, gamma_t, batch_mask):
+        alpha_t, sigma_t = self.alpha(gamma_t, z_t), self.sigma(gamma_t, z_t)
+        return z_t / alpha_t[batch_mask] - epsilon * sigma_t[batch_mask] / alpha_t[batch_mask]
+
+    @torch.no_grad()
+    def forward(self, phar, pocket, return_info=False, t_int=None, eps=None):
+        """The 12 loss terms (+ info) of conditional_model.py:198-320 as VALUES (no autograd graph).
+
+        t_int [B,1] and eps (list of the Gaussian draws, one per noised_representation call) may be
+        supplied for reproducibility; otherwise they are drawn like the reference does."""
+        phar, pocket = dict(phar), dict(pocket)
+        phar, pocket = self.normalize(phar, pocket)
+        B, nd, dev = len(phar['size']), self.n_dims, phar['x'].device
+        delta_log_px = self.delta_log_px(phar['size'])
+        if t_int is None:
+            t_int = torch.randint(0 if self.training else 1, self.T + 1, size=(B, 1), device=dev).float()
+        t_int = t_int.to(dev).float()
+        s_int = t_int - 1
+        t_is_zero = (t_int == 0).float()
+        s, t = s_int / self.T, t_int / self.T
+        gamma_s = self.inflate_batch_array(self.gamma(s), phar['x'])
+        gamma_t = self.inflate_batch_array(self.gamma(t), phar['x'])
+        xh0_phar = torch.cat([phar['x'], phar['one_hot']], dim=1)
+        xh0_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
+        cx, cp = self.remove_mean_batch(xh0_phar[:, :nd], xh0_pocket[:, :nd], phar['mask'], pocket['mask'])
+        xh0_phar = torch.cat([cx, xh0_phar[:, nd:]], 1)
+        xh0_pocket = torch.cat([cp, xh0_pocket[:, nd:]], 1)
+        draws = iter(eps) if eps is not None else None
+        nxt = (lambda: next(draws).to(dev)) if draws is not None else (lambda: None)
+        z_t, xh_pocket, eps_t = self.noised_representation(xh0_phar, xh0_pocket, phar['mask'], pocket['mask'],
+                                                           gamma_t, nxt())
+        net_out, _ = self.dynamics(z_t, xh_pocket, t, phar['mask'], pocket['mask'])
+        xh_phar_hat = self.xh_given_zt_and_epsilon(z_t, net_out, gamma_t, phar['mask'])
+        error_t = self.sum_except_batch((eps_t - net_out) ** 2, phar['mask'], B)
+        SNR_weight = (1 - self.SNR(gamma_s - gamma_t)).squeeze(1)
+        assert error_t.size() == SNR_weight.size()
+        neg_log_constants = -self.log_constants_p_x_given_z0(n_nodes=phar['size'], device=dev)
+        kl_prior = self.kl_prior(xh0_phar, phar['mask'], phar['size'])
+        if self.training:
+            lpx, lph = self.log_pxh_given_z0_without_constants(phar, z_t, eps_t, net_out, gamma_t)
+            loss_0_x, loss_0_h = -lpx * t_is_zero.squeeze(), -lph * t_is_zero.squeeze()
+            error_t = error_t * (1 - t_is_zero).squeeze()
+        else:
+            t_zeros = torch.zeros_like(s)
+            gamma_0 = self.inflate_batch_array(self.gamma(t_zeros), phar['x'])
+            z_0, xh_pocket0, eps_0 = self.noised_representation(xh0_phar, xh0_pocket, phar['mask'], pocket['mask'],
+                                                                gamma_0, nxt())
+            net_out_0, _ = self.dynamics(z_0, xh_pocket0, t_zeros, phar['mask'], pocket['mask'])
+            lpx, lph = self.log_pxh_given_z0_without_constants(phar, z_0, eps_0, net_out_0, gamma_0)
+            loss_0_x, loss_0_h = -lpx, -lph
+        log_pN = self.log_pN(phar['size'], pocket['size'])
+        cnt = self._seg_sum(torch.ones(len(phar['mask']), device=dev), phar['mask'], B).clamp(min=1)
+        info = {'eps_hat_phar_x': (self._seg_sum(net_out[:, :nd].abs().mean(1), phar['mask'], B) / cnt).mean(),
+                'eps_hat_phar_h': (self._seg_sum(net_out[:, nd:].abs().mean(1), phar['mask'], B) / cnt).mean()}
+        terms = (delta_log_px, error_t, torch.tensor(0.0), SNR_weight, loss_0_x, torch.tensor(0.0), loss_0_h,
+                 neg_log_constants, kl_prior, log_pN, t_int.squeeze(), xh_phar_hat)
+        return (*terms, info) if return_info else terms
 
     @classmethod
     def remove_mean_batch(cls, x_phar, x_pocket, phar_indices, pocket_indices):

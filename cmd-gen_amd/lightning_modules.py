@@ -131,9 +131,36 @@ class PharPocketDDPM(nn.Module):
                   'mask': data['pocket_mask'].to(self.device, INT_TYPE)}
         return phar, pocket
 
-    def forward(self, data):
-        raise NotImplementedError('training/evaluation NLL (lightning_modules.py:188-239) is the next scope '
-                                  'row (SURVEY.md section 8f #1)')
+    def forward(self, data, t_int=None, eps=None):
+        """-> (nll [B], info) as lightning_modules.py:188-239.  Loss VALUES (evaluation / monitoring): the HIP
+        evaluation has no backward pass yet, so this cannot drive an optimizer (SURVEY.md section 8f #1)."""
+        phar, pocket = self.get_phar_and_pocket(data)
+        delta_log_px, error_t_phar, error_t_pocket, SNR_weight, loss_0_x_phar, loss_0_x_pocket, loss_0_h, \
+            neg_log_const_0, kl_prior, log_pN, t_int_, xh_phar_hat, info = \
+            self.ddpm(phar, pocket, return_info=True, t_int=t_int, eps=eps)
+        dev = error_t_phar.device
+        error_t_pocket, loss_0_x_pocket = error_t_pocket.to(dev), loss_0_x_pocket.to(dev)
+        if self.loss_type == 'l2' and self.training:
+            error_t_phar = error_t_phar / ((self.x_dims + self.ddpm.phar_nf) * phar['size'])
+            error_t_pocket = error_t_pocket / ((self.x_dims + self.ddpm.residue_nf) * pocket['size'])
+            loss_t = 0.5 * (error_t_phar + error_t_pocket)
+            loss_0 = loss_0_x_phar / (self.x_dims * phar['size']) + loss_0_x_pocket / (self.x_dims * pocket['size']) \
+                + loss_0_h
+        else:
+            loss_t = -self.T * 0.5 * SNR_weight * (error_t_phar + error_t_pocket)
+            loss_0 = loss_0_x_phar + loss_0_x_pocket + loss_0_h + neg_log_const_0
+        nll = loss_t + loss_0 + kl_prior
+        if not (self.loss_type == 'l2' and self.training):
+            nll = nll - delta_log_px - log_pN        # normalisation on x; conditional -> joint nll
+        info['error_t_phar'] = error_t_phar.mean(0)
+        info['error_t_pocket'] = error_t_pocket.mean(0)
+        info['SNR_weight'] = SNR_weight.mean(0)
+        info['loss_0'] = loss_0.mean(0)
+        info['kl_prior'] = kl_prior.mean(0)
+        info['delta_log_px'] = delta_log_px.mean(0)
+        info['neg_log_const_0'] = neg_log_const_0.mean(0)
+        info['log_pN'] = log_pN.mean(0)
+        return nll, info
 
     # ------------------------------------------------------------------ sampling entry points
     @torch.no_grad()

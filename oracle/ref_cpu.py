@@ -22,6 +22,7 @@ Each function cites the reference lines it restates (paths relative to
 """
 from __future__ import annotations
 
+import math
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -365,3 +366,107 @@ def n1_given_n2_log_prob(histogram: np.ndarray, n1: Sequence[int], n2: Sequence[
         col = col / col.sum()
         out.append(torch.log(col[int(a)]))
     return torch.stack(out)
+
+
+# --------------------------------------------------------------------------
+# loss terms  (ConditionalDDPM.forward, conditional_model.py:198-320; no gradients here)
+# --------------------------------------------------------------------------
+def _sum_except_batch(x, idx, n):
+    return scatter_add(x.sum(-1), idx, n)                                   # en_diffusion.py:939-940
+
+
+def _cdf_std_gauss(x):
+    return 0.5 * (1. + torch.erf(x / math.sqrt(2)))                         # :943-944
+
+
+def _gaussian_KL(q_mu2, q_sigma, p_sigma, d):
+    return d * torch.log(p_sigma / q_sigma) + 0.5 * (d * q_sigma ** 2 + q_mu2) / (p_sigma ** 2) - 0.5 * d   # :834-847
+
+
+def ddpm_forward(p, cfg, phar, pocket, t_int, eps_draws, training, histogram):
+    """-> the 12 loss terms + info of ConditionalDDPM.forward with t_int [B,1] and the Gaussian draws given."""
+    T, nd, nv, nb = cfg['timesteps'], cfg['n_dims'], cfg['norm_values'], cfg['norm_biases']
+    table = p['gamma.gamma']
+    draws = iter(eps_draws)
+    B = len(phar['size'])
+    pm, qm = phar['mask'].to(INT), pocket['mask'].to(INT)
+    x_l = phar['x'].to(FLOAT) / nv[0]
+    h_l = (phar['one_hot'].float() - nb[1]) / nv[1]
+    x_p = pocket['x'].to(FLOAT) / nv[0]
+    h_p = (pocket['one_hot'].float() - nb[1]) / nv[1]
+    n_l = phar['size']
+    sub_d = (n_l - 1) * nd                                                   # subspace_dimensionality :908-911
+    delta_log_px = -sub_d * np.log(nv[0])                                    # :193-195
+    t_int = t_int.float()
+    s_int = t_int - 1
+    t_is_zero = (t_int == 0).float()
+    t_is_not_zero = 1 - t_is_zero
+    s, t = s_int / T, t_int / T
+    gamma_s, gamma_t = gamma_lookup(table, s, T), gamma_lookup(table, t, T)
+    xh0_l = torch.cat([x_l, h_l], dim=1)
+    xh0_p = torch.cat([x_p, h_p], dim=1)
+    a, b = remove_mean_batch(xh0_l[:, :nd], xh0_p[:, :nd], pm, qm)           # centre on the phar COM :235-238
+    xh0_l = torch.cat([a, xh0_l[:, nd:]], dim=1)
+    xh0_p = torch.cat([b, xh0_p[:, nd:]], dim=1)
+
+    def noised(gamma):
+        eps = next(draws)
+        z = alpha_of(gamma)[pm] * xh0_l + sigma_of(gamma)[pm] * eps        # :158-179
+        zx, px = remove_mean_batch(z[:, :nd], xh0_p[:, :nd], pm, qm)
+        return torch.cat([zx, z[:, nd:]], dim=1), torch.cat([px, xh0_p[:, nd:]], dim=1), eps
+
+    def l0_terms(z0, eps, net, gamma0, epsilon=1e-10):                       # :58-106
+        sigma_0_cat = sigma_of(gamma0) * nv[1]
+        lpx = -0.5 * _sum_except_batch((eps[:, :nd] - net[:, :nd]) ** 2, pm, B)
+        onehot = phar['one_hot'].float() * nv[1] + nb[1]                     # quirk: un-normalises the RAW one-hot
+        est = z0[:, nd:] * nv[1] + nb[1]
+        c = est - 1
+        logp = torch.log(_cdf_std_gauss((c + 0.5) / sigma_0_cat[pm]) - _cdf_std_gauss((c - 0.5) / sigma_0_cat[pm]) + epsilon)
+        logp = logp - torch.logsumexp(logp, dim=1, keepdim=True)
+        return lpx, _sum_except_batch(logp * onehot, pm, B)
+
+    z_t, xp_t, eps_t = noised(gamma_t)
+    net, _ = dynamics_forward(p, cfg, z_t, xp_t, t, pm, qm)
+    xh_hat = z_t / alpha_of(gamma_t)[pm] - net * sigma_of(gamma_t)[pm] / alpha_of(gamma_t)[pm]    # :322-329
+    error_t = _sum_except_batch((eps_t - net) ** 2, pm, B)
+    snr_w = (1 - torch.exp(-(gamma_s - gamma_t))).squeeze(1)
+    gamma_0 = gamma_lookup(table, torch.zeros((B, 1)), T)
+    neg_log_const = -(sub_d * (-(0.5 * gamma_0.view(B)) - 0.5 * np.log(2 * np.pi)))             # en_diffusion.py:167-180
+    gamma_T = gamma_lookup(table, torch.ones((B, 1)), T)                     # kl_prior :20-56
+    mu_T = alpha_of(gamma_T)[pm] * xh0_l
+    sig_T = sigma_of(gamma_T).squeeze()
+    kl_h = _gaussian_KL(_sum_except_batch(mu_T[:, nd:] ** 2, pm, B), sig_T, torch.ones_like(sig_T), d=1)
+    kl_x = _gaussian_KL(_sum_except_batch(mu_T[:, :nd] ** 2, pm, B), sig_T, torch.ones_like(sig_T), sub_d)
+    kl_prior = kl_x + kl_h
+    if training:
+        lpx, lph = l0_terms(z_t, eps_t, net, gamma_t)
+        loss_0_x, loss_0_h = -lpx * t_is_zero.squeeze(), -lph * t_is_zero.squeeze()
+        error_t = error_t * t_is_not_zero.squeeze()
+    else:
+        z_0, xp_0, eps_0 = noised(gamma_0)
+        net0, _ = dynamics_forward(p, cfg, z_0, xp_0, torch.zeros_like(s), pm, qm)
+        lpx, lph = l0_terms(z_0, eps_0, net0, gamma_0)
+        loss_0_x, loss_0_h = -lpx, -lph
+    log_pN = n1_given_n2_log_prob(histogram, n_l.tolist(), pocket['size'].tolist())
+    info = {'eps_hat_phar_x': scatter_mean(net[:, :nd].abs().mean(1), pm, B).mean(),
+            'eps_hat_phar_h': scatter_mean(net[:, nd:].abs().mean(1), pm, B).mean()}
+    return (delta_log_px, error_t, torch.tensor(0.0), snr_w, loss_0_x, torch.tensor(0.0), loss_0_h, neg_log_const,
+            kl_prior, log_pN, t_int.squeeze(), xh_hat, info)
+
+
+def nll_from_terms(terms, cfg, phar_size, pocket_size, training, loss_type='l2'):
+    """PharPocketDDPM.forward's assembly, lightning_modules.py:188-239."""
+    (delta_log_px, error_t, error_t_pocket, snr_w, l0x, l0x_pocket, l0h, neg_log_const, kl_prior, log_pN, _, _, _) = terms
+    nd, T = cfg['n_dims'], cfg['timesteps']
+    if loss_type == 'l2' and training:
+        error_t = error_t / ((nd + cfg['phar_nf']) * phar_size)
+        error_t_pocket = error_t_pocket / ((nd + cfg['residue_nf']) * pocket_size)
+        loss_t = 0.5 * (error_t + error_t_pocket)
+        loss_0 = l0x / (nd * phar_size) + l0x_pocket / (nd * pocket_size) + l0h
+    else:
+        loss_t = -T * 0.5 * snr_w * (error_t + error_t_pocket)
+        loss_0 = l0x + l0x_pocket + l0h + neg_log_const
+    nll = loss_t + loss_0 + kl_prior
+    if not (loss_type == 'l2' and training):
+        nll = nll - delta_log_px - log_pN
+    return nll

@@ -339,6 +339,55 @@ def main():
         print(name, 'noise draws', len(noises), 'min cutoff margin', min(margins))
     np.savez_compressed(os.path.join(HERE, 'g4_chains.npz'), **g4)
 
+    # ---------------- G6: loss terms of ConditionalDDPM.forward (+ PharPocketDDPM.forward nll), t_int and eps pinned
+    for g6_first in range(3100, 99999, 1000):
+        g6 = {}
+        cfg = ModelConfig(hidden_nf=64, n_layers=2, timesteps=500)
+        ddpm, _ = build_reference_ddpm(mods, cfg, 31, 1.0, HIST)
+        pb = make_pockets(4, 'CA', ragged=True, first_index=g6_first)
+        rng = np.random.Generator(np.random.PCG64(g6_first))
+        B = 4
+        nl = np.asarray([6, 9, 5, 12], dtype=np.int64)
+        phar_mask = np.repeat(np.arange(B), nl)
+        com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(B)])
+        phar_x = (com[phar_mask] + rng.normal(size=(len(phar_mask), 3)) * 2.0).astype(np.float32)
+        phar_oh = np.eye(8, dtype=np.float32)[rng.integers(0, 8, size=len(phar_mask))]
+        t_pin = np.asarray([[0.], [137.], [500.], [42.]], dtype=np.float32)       # includes t = 0 and t = T
+        eps_pin = [rng.normal(size=(len(phar_mask), 11)).astype(np.float32) for _ in range(2)]
+        real_randint = torch.randint
+        for mode in ('train', 'eval'):
+            ddpm.train() if mode == 'train' else ddpm.eval()
+            draws = iter(eps_pin)
+            ddpm.sample_gaussian = lambda size, device: torch.from_numpy(next(draws).copy())
+            torch.randint = lambda lo, hi, size, device=None: torch.from_numpy(t_pin.copy())
+            margins = []
+            orig_edges = type(ddpm.dynamics).get_edges.__get__(ddpm.dynamics)
+
+            def rec_edges(mask, x):
+                margins.append(min_cutoff_margin(x.numpy(), mask.numpy(), 6.0))
+                return orig_edges(mask, x)
+            ddpm.dynamics.get_edges = rec_edges
+            phar = {'x': torch.from_numpy(phar_x.copy()), 'one_hot': torch.from_numpy(phar_oh.copy()),
+                    'size': torch.from_numpy(nl.copy()), 'mask': torch.from_numpy(phar_mask.copy())}
+            pocket = pockets_to_torch(pb)
+            with torch.no_grad():
+                terms = ddpm(phar, pocket, return_info=True)
+            torch.randint = real_randint
+            names = ['delta_log_px', 'error_t_phar', 'error_t_pocket', 'SNR_weight', 'loss_0_x_phar', 'loss_0_x_pocket',
+                     'loss_0_h', 'neg_log_constants', 'kl_prior', 'log_pN', 't_int', 'xh_phar_hat']
+            for n, v in zip(names, terms[:-1]):
+                g6[f'{mode}/{n}'] = np.asarray(v.numpy() if torch.is_tensor(v) else v, dtype=np.float32)
+            g6[f'{mode}/info_eps_hat_phar_x'] = terms[-1]['eps_hat_phar_x'].numpy()
+            g6[f'{mode}/info_eps_hat_phar_h'] = terms[-1]['eps_hat_phar_h'].numpy()
+            g6[f'{mode}/min_margin'] = np.asarray(min(margins))
+            print('G6', mode, 'evaluations', len(margins), 'min margin', min(margins))
+        g6['phar_x'], g6['phar_one_hot'], g6['num_nodes_phar'] = phar_x, phar_oh, nl
+        g6['t_int'], g6['eps0'], g6['eps1'] = t_pin, eps_pin[0], eps_pin[1]
+        g6['meta'] = np.asarray([64, 2, 4, 20, 31, g6_first], dtype=np.int64)
+        if min(float(g6['train/min_margin']), float(g6['eval/min_margin'])) > 2e-3:
+            np.savez_compressed(os.path.join(HERE, 'g6_loss.npz'), **g6)
+            break
+
     # ---------------- G8: node-count prior
     dn = None
     with contextlib.redirect_stdout(io.StringIO()):

@@ -68,3 +68,22 @@ class NoiseTape:
 def rms(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+HIST = np.zeros((30, 70), dtype=np.float64)
+for _i in range(3, 26):
+    for _j in range(20, 66):
+        HIST[_i, _j] = 1 + ((_i * 7 + _j * 3) % 11)       # the histogram make_golden.py uses
+
+
+def loss_case(g):
+    H, L, B, R, seed, first = [int(v) for v in g['meta']]
+    cfg = cfg_from_meta(H, L, R)
+    sd = make_state_dict(cfg, seed=seed, coord_gain=1.0)
+    pb = make_pockets(B, 'CA', ragged=True, first_index=first)
+    nl = g['num_nodes_phar']
+    phar = {'x': torch.from_numpy(g['phar_x'].copy()), 'one_hot': torch.from_numpy(g['phar_one_hot'].copy()),
+            'size': torch.from_numpy(nl.copy()), 'mask': torch.from_numpy(np.repeat(np.arange(B), nl))}
+    pocket = {'x': torch.from_numpy(pb.x.copy()), 'one_hot': torch.from_numpy(pb.one_hot.copy()),
+              'size': torch.from_numpy(pb.size.copy()), 'mask': torch.from_numpy(pb.mask.copy())}
+    return cfg, sd, phar, pocket, HIST

@@ -101,3 +101,24 @@ def test_g8_node_count_prior():
     g = load_golden('g8_nodes.npz')
     got = ref_cpu.n1_given_n2_log_prob(g['hist'], g['n1'], g['n2']).numpy()
     assert np.allclose(got, g['logp'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_g6_loss_terms(mode):
+    """ConditionalDDPM.forward's 12 loss terms with t_int and the Gaussian draws pinned (t = 0 and t = T included)."""
+    from helpers import loss_case
+    g = load_golden('g6_loss.npz')
+    cfg, sd, phar, pocket, hist = loss_case(g)
+    p = ref_cpu.to_torch_params(sd)
+    with torch.no_grad():
+        terms = ref_cpu.ddpm_forward(p, cfg.as_dict(), phar, pocket, torch.from_numpy(g['t_int']),
+                                     [torch.from_numpy(g['eps0']), torch.from_numpy(g['eps1'])], mode == 'train', hist)
+    names = ['delta_log_px', 'error_t_phar', 'error_t_pocket', 'SNR_weight', 'loss_0_x_phar', 'loss_0_x_pocket',
+             'loss_0_h', 'neg_log_constants', 'kl_prior', 'log_pN', 't_int', 'xh_phar_hat']
+    for n, v in zip(names, terms[:-1]):
+        want = g[f'{mode}/{n}']
+        got = np.asarray(v.numpy() if torch.is_tensor(v) else v, dtype=np.float32)
+        assert np.allclose(got, want, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(want).max()))), n
+    assert abs(float(terms[-1]['eps_hat_phar_x']) - float(g[f'{mode}/info_eps_hat_phar_x'])) < 1e-6
+    nll = ref_cpu.nll_from_terms(terms, cfg.as_dict(), phar['size'], pocket['size'], mode == 'train')
+    assert nll.shape == (4,) and bool(torch.isfinite(nll).all())
