@@ -150,36 +150,49 @@ def main():
 
     result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: per-launch HIP events around every edge-message
-        # launch of one more (eager) chain on the same stream; algorithmic FLOP = 2(H^2+H) per edge.
+        # ---- roofline of the dominant kernel: per-launch HIP events around every launch of the three MFMA
+        # kernels during one more (eager) chain on the same stream; the kernel with the largest summed time is
+        # the dominant one.  Algorithmic FLOP per launch: edge message 2(H^2+H) per edge,
+        # node 14 H^2 per node, coord 2(H^2+H) per phar-receiver edge.
         H = cfg.hidden_nf
+        L = cfg.n_layers
         with torch.cuda.stream(stream):
             h.reset_counters()
-            h.set_edge_profiling(True)
+            h.set_kernel_profiling(True)
             Kp = min(T, 200)
             h.sample_chain(px, poh, Kp, noise=None, seed=7, pocket_ids=pb.pocket_index, use_graph=False)
-            ms, launches = h.edge_profile()
-            h.set_edge_profiling(False)
+            prof = h.kernel_profile()
+            h.set_kernel_profiling(False)
             pc = h.counters()
             # whole-evaluation kernel breakdown on the final chain state
             z = out[0].clone(); z[:, 3:] = 0
             kt = h.profile_evaluation(z.contiguous(), torch.cat([out[1][:, :3], out[1][:, 3:] / cfg.norm_values[1]], 1).contiguous(),
                                       torch.full((B,), 0.5, device=dev))
-        edges_per_launch = pc['edges'] / max(pc['evaluations'], 1)
-        flop_per_launch = 2.0 * (H * H + H) * edges_per_launch
-        avg_ms = ms / max(launches, 1)
-        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+        ev = max(pc['evaluations'], 1)
+        units = {'edge_msg': pc['edges'] / ev, 'node': pc['nodes'] / ev, 'edge_coord': pc['edges_phar'] / ev}
+        flop_unit = {'edge_msg': 2.0 * (H * H + H), 'node': 14.0 * H * H, 'edge_coord': 2.0 * (H * H + H)}
+        kname = {'edge_msg': 'k_edge_msg (GCL.edge_model + attention + segment sum)',
+                 'node': 'k_node (GCL.node_model + P/Q projections for the coord MLP and the next block)',
+                 'edge_coord': 'k_edge_coord (EquivariantUpdate.coord_model)'}
+        per_kernel = {}
+        for k, (ms_k, n_k) in prof.items():
+            avg = ms_k / max(n_k, 1)
+            fl = flop_unit[k] * units[k]
+            per_kernel[k] = {'total_ms': ms_k, 'launches': n_k, 'avg_launch_ms': avg, 'flop_per_launch': fl,
+                             'tflops': (fl / (avg * 1e-3) / 1e12) if avg > 0 else 0.0}
+        dom = max(per_kernel, key=lambda k: per_kernel[k]['total_ms'])
+        achieved = per_kernel[dom]['tflops']
+        avg_ms, launches, flop_per_launch = per_kernel[dom]['avg_launch_ms'], per_kernel[dom]['launches'], per_kernel[dom]['flop_per_launch']
         # whole-job algorithmic FLOP (SURVEY 8d F_alg) for the timed region
-        L = cfg.n_layers
         f_alg = L * (2.0 * (H * H + H) * (cnt['edges'] + cnt['edges_phar']) + 917504.0 * (H / 256.0) ** 2 * cnt['nodes']) \
             + 33792.0 * (H / 256.0) * cnt['nodes']
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'edge_msg_traffic.json')
+        tpath = os.path.join(ROOT, 'profiles', 'kernel_traffic.json')
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get('workload_batch') == B and tj.get('representation') == rep:
-                    traffic = tj.get('hbm_bytes_per_launch')
+                    traffic = tj.get('hbm_bytes_per_launch', {}).get(dom) if isinstance(tj.get('hbm_bytes_per_launch'), dict) else None
             except Exception:
                 traffic = None
         result = {
@@ -204,12 +217,14 @@ def main():
                 'kernel_ms_one_evaluation': kt,
             },
             'roofline': {
-                'bound': 'mfma', 'kernel': 'k_edge_msg<256> (GCL.edge_model + attention + segment sum)',
+                'bound': 'mfma', 'kernel': kname[dom],
                 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                 'flop_per_launch': flop_per_launch, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
-                'edges_per_launch': edges_per_launch,
+                'units_per_launch': units[dom],
                 'whole_job_frac': f_alg / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                'per_kernel': {k: {kk: v[kk] for kk in ('total_ms', 'avg_launch_ms', 'tflops')} | {'frac': v['tflops'] / PEAK_FP32_MFMA_TFLOPS}
+                               for k, v in per_kernel.items()},
             },
         }
         if not args.no_cpu_baseline and n_gpus == 1:      # timed on rank 0 at N=1 only

@@ -68,8 +68,8 @@ struct cmdgen_handle {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     const float* graph_noise = nullptr; float* graph_zsteps = nullptr; hipStream_t graph_stream = nullptr;
     unsigned long long graph_seed = 0;
-    bool edge_profiling = false;
-    std::vector<hipEvent_t> msg_events;
+    bool kernel_profiling = false;
+    std::vector<hipEvent_t> prof_events[3];
 };
 
 static int fail(cmdgen_handle* h, int code, const char* fmt, ...) {
@@ -391,7 +391,7 @@ static int check_ready(cmdgen_handle* h) {
 static EvalLaunch make_launch(cmdgen_handle* h) {
     EvalLaunch a; a.lay = h->lay; a.w = h->work; a.d = h->dims; a.sw = h->small; a.layers = h->layers.data();
     a.edge_grid = h->edge_grid; a.coord_grid = h->coord_grid;
-    a.msg_events = nullptr; a.ablate = 0;
+    a.prof_events = nullptr; a.ablate = 0;
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     return a;
 }
@@ -548,7 +548,7 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
     HIPCHK(h, hipMemsetAsync(h->d_cog, 0, 4 * sizeof(unsigned int), s));
     HIPCHK(h, hipStreamSynchronize(s));              // st0 is on the stack
     EvalLaunch a = make_launch(h);
-    if (h->edge_profiling && !use_graph) a.msg_events = &h->msg_events;
+    if (h->kernel_profiling && !use_graph) a.prof_events = h->prof_events;
     cmdgen_launch_chain_init(h->lay, d, c, pocket_x, pocket_onehot, s);
     auto one_step = [&](hipStream_t ss) {
         cmdgen_launch_eval(a, c.z_phar, c.xh_pocket, nullptr, c.coef, c.state, h->work.eps_tmp, nullptr, ss, nullptr);
@@ -679,28 +679,31 @@ extern "C" int cmdgen_time_edge_kernel(cmdgen_handle* h, int32_t layer, int32_t 
     return CMDGEN_OK;
 }
 
-extern "C" int cmdgen_set_edge_profiling(cmdgen_handle* h, int32_t on) {
+extern "C" int cmdgen_set_kernel_profiling(cmdgen_handle* h, int32_t on) {
     if (!h) return CMDGEN_EINVAL;
-    h->edge_profiling = on != 0;
+    h->kernel_profiling = on != 0;
     return CMDGEN_OK;
 }
 
-extern "C" int cmdgen_get_edge_profile(cmdgen_handle* h, float* total_ms, int64_t* launches, cmdgen_stream stream) {
+extern "C" int cmdgen_get_kernel_profile(cmdgen_handle* h, float total_ms[3], int64_t launches[3], cmdgen_stream stream) {
     int rc = check_ready(h); if (rc) return rc;
     hipSetDevice(h->device);
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
     if (h->own_stream) HIPCHK(h, hipStreamSynchronize(h->own_stream));
-    double tot = 0.0;
-    const size_t n = h->msg_events.size() / 2;
-    for (size_t i = 0; i < n; ++i) {
-        float ms = 0.f;
-        HIPCHK(h, hipEventSynchronize(h->msg_events[2 * i + 1]));
-        hipEventElapsedTime(&ms, h->msg_events[2 * i], h->msg_events[2 * i + 1]);
-        tot += ms;
+    for (int k = 0; k < 3; ++k) {
+        std::vector<hipEvent_t>& ev = h->prof_events[k];
+        double tot = 0.0;
+        const size_t n = ev.size() / 2;
+        for (size_t i = 0; i < n; ++i) {
+            float ms = 0.f;
+            HIPCHK(h, hipEventSynchronize(ev[2 * i + 1]));
+            hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+            tot += ms;
+        }
+        for (hipEvent_t e : ev) hipEventDestroy(e);
+        ev.clear();
+        if (total_ms) total_ms[k] = (float)tot;
+        if (launches) launches[k] = (int64_t)n;
     }
-    for (hipEvent_t e : h->msg_events) hipEventDestroy(e);
-    h->msg_events.clear();
-    if (total_ms) *total_ms = (float)tot;
-    if (launches) *launches = (int64_t)n;
     return CMDGEN_OK;
 }

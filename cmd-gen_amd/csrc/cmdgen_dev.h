@@ -129,7 +129,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     const LayerW* layers;       // host array [L]
     int edge_grid, coord_grid;  // workgroups of the persistent-style edge kernels (tiles are taken round-robin)
     int node_mt, edge_mt, coord_mt;   // rows per tile (64, 32 or 16) chosen per launch from the row counts
-    std::vector<hipEvent_t>* msg_events;   // when non-null: event pair around every edge-message launch
+    std::vector<hipEvent_t>* prof_events;  // when non-null: [3] vectors, event pairs around every msg / node / coord launch
     int ablate;                 // timing-only builds of the edge kernel (cmdgen_time_edge_kernel); 0 in production
 };
 

@@ -722,6 +722,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + sizeof(int));
     int e = 0;
 #define REC() do { if (ev) hipEventRecord(ev[e++], s); } while (0)
+#define PROF(k) do { if (a.prof_events) { hipEvent_t pe; hipEventCreate(&pe); hipEventRecord(pe, s); a.prof_events[k].push_back(pe); } } while (0)
     REC();
     hipLaunchKernelGGL(k_edge_count, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket, chain);
     hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d);
@@ -730,13 +731,12 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     REC();
     for (int l = 0; l < a.d.L; ++l) {
         REC();
-        if (a.msg_events) { hipEvent_t e0; hipEventCreate(&e0); hipEventRecord(e0, s); a.msg_events->push_back(e0); }
-        MT_DISPATCH(a.edge_mt, launch_msg, a, l, s);
-        if (a.msg_events) { hipEvent_t e1; hipEventCreate(&e1); hipEventRecord(e1, s); a.msg_events->push_back(e1); }
+        PROF(0); MT_DISPATCH(a.edge_mt, launch_msg, a, l, s); PROF(0);
         REC(); REC();
-        MT_DISPATCH(a.node_mt, launch_node, a, l, s);
+        PROF(1); MT_DISPATCH(a.node_mt, launch_node, a, l, s); PROF(1);
         REC(); REC();
-        MT_DISPATCH(a.coord_mt, launch_coord, a, l, s);
+        PROF(2);
+        MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF(2);
         REC();
     }
     REC();
@@ -745,6 +745,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
                        eps_phar, eps_pocket);
     REC();
 #undef REC
+#undef PROF
 }
 
 void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket,

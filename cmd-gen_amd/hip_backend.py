@@ -59,8 +59,8 @@ SYMBOLS = [
     ('cmdgen_reset_counters', C.c_int, [_vp, _vp]),
     ('cmdgen_profile_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.POINTER(KernelTimes), _vp]),
     ('cmdgen_time_edge_kernel', C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
-    ('cmdgen_set_edge_profiling', C.c_int, [_vp, C.c_int32]),
-    ('cmdgen_get_edge_profile', C.c_int, [_vp, C.POINTER(C.c_float), _i64p, _vp]),
+    ('cmdgen_set_kernel_profiling', C.c_int, [_vp, C.c_int32]),
+    ('cmdgen_get_kernel_profile', C.c_int, [_vp, C.POINTER(C.c_float), _i64p, _vp]),
 ]
 
 
@@ -272,13 +272,12 @@ class Handle:
                     'cmdgen_time_edge_kernel')
         return ms.value
 
-    def set_edge_profiling(self, on: bool):
-        self._check(self.lib.cmdgen_set_edge_profiling(self.h, int(bool(on))), 'cmdgen_set_edge_profiling')
+    def set_kernel_profiling(self, on: bool):
+        self._check(self.lib.cmdgen_set_kernel_profiling(self.h, int(bool(on))), 'cmdgen_set_kernel_profiling')
 
-    def edge_profile(self):
-        """-> (summed ms, launches) of the edge-message kernel since the last call (eager chains only)."""
-        ms, n = C.c_float(0), C.c_int64(0)
-        self._check(self.lib.cmdgen_get_edge_profile(self.h, C.byref(ms), C.byref(n), self._stream()),
-                    'cmdgen_get_edge_profile')
-        return ms.value, n.value
-
+    def kernel_profile(self):
+        """-> {'edge_msg'|'node'|'edge_coord': (summed ms, launches)} since the last call (eager chains only)."""
+        ms = (C.c_float * 3)()
+        n = (C.c_int64 * 3)()
+        self._check(self.lib.cmdgen_get_kernel_profile(self.h, ms, n, self._stream()), 'cmdgen_get_kernel_profile')
+        return {k: (ms[i], n[i]) for i, k in enumerate(('edge_msg', 'node', 'edge_coord'))}

@@ -184,12 +184,16 @@ int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar, const floa
 int cmdgen_time_edge_kernel(cmdgen_handle* h, int32_t layer, int32_t reps, float* mean_ms,
                             cmdgen_stream stream);
 
-/* Per-launch timing of the dominant kernel (edge message) inside a real chain: while enabled,
- * every eager (use_graph = 0) launch of that kernel is bracketed by a hipEvent pair on the
- * launch stream.  cmdgen_get_edge_profile synchronises, returns the summed duration and the
- * number of launches since the last call, and clears the record. */
-int cmdgen_set_edge_profiling(cmdgen_handle* h, int32_t on);
-int cmdgen_get_edge_profile(cmdgen_handle* h, float* total_ms, int64_t* launches, cmdgen_stream stream);
+/* Per-launch timing of the three MFMA kernels inside a real chain: while enabled, every eager
+ * (use_graph = 0) launch of k_edge_msg / k_node / k_edge_coord is bracketed by a hipEvent pair on
+ * the launch stream.  cmdgen_get_kernel_profile synchronises and returns, per kernel class
+ * (CMDGEN_K_EDGE_MSG, CMDGEN_K_NODE, CMDGEN_K_EDGE_COORD), the summed duration and the number of
+ * launches since the last call; it clears the record. */
+#define CMDGEN_K_EDGE_MSG   0
+#define CMDGEN_K_NODE       1
+#define CMDGEN_K_EDGE_COORD 2
+int cmdgen_set_kernel_profiling(cmdgen_handle* h, int32_t on);
+int cmdgen_get_kernel_profile(cmdgen_handle* h, float total_ms[3], int64_t launches[3], cmdgen_stream stream);
 
 #ifdef __cplusplus
 }
