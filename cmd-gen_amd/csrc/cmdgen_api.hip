@@ -66,7 +66,7 @@ struct cmdgen_handle {
     hipGraphExec_t step_graph = nullptr;
     hipStream_t own_stream = nullptr;      // used when the caller's stream is the legacy default stream (not capturable)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    const float* graph_noise = nullptr; float* graph_zsteps = nullptr; hipStream_t graph_stream = nullptr;
+    const float* graph_noise = nullptr; float* graph_zsteps = nullptr; float* graph_psteps = nullptr; hipStream_t graph_stream = nullptr;
     unsigned long long graph_seed = 0;
     bool kernel_profiling = false;
     std::vector<hipEvent_t> prof_events[3];
@@ -511,7 +511,7 @@ static int prepare_chain(cmdgen_handle* h, int K, bool want_steps) {
 extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, const float* pocket_onehot,
                                    int32_t timesteps, const float* noise, uint64_t seed,
                                    const int64_t* pocket_ids_host, float* xh_phar_out, float* xh_pocket_out,
-                                   float* z_steps_out, int32_t use_graph, cmdgen_stream stream) {
+                                   float* z_steps_out, float* pocket_steps_out, int32_t use_graph, cmdgen_stream stream) {
     int rc = check_ready(h); if (rc) return rc;
     if (!pocket_x || !pocket_onehot || !xh_phar_out || !xh_pocket_out) return fail(h, CMDGEN_EINVAL, "null device pointer");
     const int K = timesteps;
@@ -541,7 +541,7 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
         HIPCHK(h, hipStreamSynchronize(s));          // gid is a stack vector
     }
     ChainBuf c = h->chain;
-    c.noise = noise; c.seed = seed; c.z_steps = z_steps_out;
+    c.noise = noise; c.seed = seed; c.z_steps = z_steps_out; c.pocket_steps = pocket_steps_out;
     const ChainState st0{-1, K, 0, 0};
     HIPCHK(h, hipMemcpyAsync(c.state, &st0, sizeof st0, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemsetAsync(c.check, 0, (size_t)(K + 3) * 2 * sizeof(unsigned int), s));
@@ -557,7 +557,7 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
     if (use_graph) {
         // The step is identical every iteration (the step index lives on the device), so it is
         // captured once per (layout, K, noise/z_steps pointers, stream) and replayed K times.
-        if (h->step_graph && (h->graph_noise != noise || h->graph_zsteps != z_steps_out || h->graph_stream != s || h->graph_seed != seed)) {
+        if (h->step_graph && (h->graph_noise != noise || h->graph_zsteps != z_steps_out || h->graph_psteps != pocket_steps_out || h->graph_stream != s || h->graph_seed != seed)) {
             hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr;
         }
         if (!h->step_graph) {
@@ -567,7 +567,7 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
             HIPCHK(h, hipStreamEndCapture(s, &g));
             HIPCHK(h, hipGraphInstantiate(&h->step_graph, g, nullptr, nullptr, 0));
             hipGraphDestroy(g);
-            h->graph_noise = noise; h->graph_zsteps = z_steps_out; h->graph_stream = s; h->graph_seed = seed;
+            h->graph_noise = noise; h->graph_zsteps = z_steps_out; h->graph_psteps = pocket_steps_out; h->graph_stream = s; h->graph_seed = seed;
         }
         for (int i = 0; i < K; ++i) HIPCHK(h, hipGraphLaunch(h->step_graph, s));
     } else {

@@ -120,6 +120,7 @@ struct ChainBuf {               // device pointers owned by the handle for one c
     const float* noise;         // [K+2][Nl][3+P] or null (Philox on device)
     unsigned long long seed;
     float* z_steps;             // [K][Nl][3+P] or null
+    float* pocket_steps;        // [K][Np][3] or null
     unsigned int* check;        // [K+3][2] float bits: max|x|, max|sum x| per check point
     ChainState* state;
 };

@@ -117,6 +117,11 @@ __global__ __launch_bounds__(64) void k_ddpm_step(Layout lay, Dims d, ChainBuf c
             const size_t o = (size_t)pb * ld + idx;
             c.z_steps[(size_t)step * lay.Nl * ld + o] = c.z_phar[o];
         }
+    if (c.pocket_steps)
+        for (int idx = lane; idx < np * 3; idx += 64) {
+            const int i = idx / 3, k = idx - 3 * i;
+            c.pocket_steps[((size_t)step * lay.Np + qb + i) * 3 + k] = c.xh_pocket[(size_t)(qb + i) * ldq + k];
+        }
     if (b == 0 && lane == 0 && nan_reset) atomicAdd(&w.counters[4], 1ull);
 }
 

@@ -221,13 +221,15 @@ class ConditionalDDPM(EnVariationalDiffusion):
         # (conditional_model.py:439-442); frame 0 is overwritten by the final sample (:460-461).
         out_phar = torch.zeros((return_frames,) + tuple(xh_phar.shape), device=device)
         out_pocket = torch.zeros((return_frames,) + tuple(xh_pocket.shape), device=device)
+        p_steps = h.last_pocket_steps
+        nd = self.n_dims
         for s in range(timesteps):
             if (s * return_frames) % timesteps == 0:
                 idx = (s * return_frames) // timesteps
-                zs = z_steps[timesteps - 1 - s]
-                nd = self.n_dims
+                zs, ps = z_steps[timesteps - 1 - s], p_steps[timesteps - 1 - s]          # state after the step with index s
                 out_phar[idx] = torch.cat([zs[:, :nd] * self.norm_values[0],
                                            zs[:, nd:] * self.norm_values[1] + self.norm_biases[1]], dim=1)
+                out_pocket[idx] = torch.cat([ps * self.norm_values[0], xh_pocket[:, nd:]], dim=1)   # unnormalize_z :897-906
         out_phar[0], out_pocket[0] = xh_phar, xh_pocket
         return out_phar, out_pocket, phar_mask, pocket['mask']
 

@@ -51,7 +51,7 @@ SYMBOLS = [
     ('cmdgen_dynamics_forward', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _vp]),
     ('cmdgen_get_edges', C.c_int, [_vp, _vp, _vp, C.c_int64, _i64p, _vp]),
     ('cmdgen_debug_read', C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t, _vp]),
-    ('cmdgen_sample_chain', C.c_int, [_vp, _fp, _fp, C.c_int32, _fp, C.c_uint64, _i64p, _fp, _fp, _fp,
+    ('cmdgen_sample_chain', C.c_int, [_vp, _fp, _fp, C.c_int32, _fp, C.c_uint64, _i64p, _fp, _fp, _fp, _fp,
                                       C.c_int32, _vp]),
     ('cmdgen_set_step_table', C.c_int, [_vp, C.c_int32, _vp]),
     ('cmdgen_chain_status', C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i64p, _vp]),
@@ -232,6 +232,8 @@ class Handle:
         xh_phar = torch.empty((self.n_phar, 3 + P), dtype=torch.float32, device=dev)
         xh_pocket = torch.empty((self.n_pocket, 3 + R), dtype=torch.float32, device=dev)
         z_steps = torch.empty((timesteps, self.n_phar, 3 + P), dtype=torch.float32, device=dev) if want_steps else None
+        p_steps = torch.empty((timesteps, self.n_pocket, 3), dtype=torch.float32, device=dev) if want_steps else None
+        self.last_pocket_steps = p_steps
         ids = None
         if pocket_ids is not None:
             ids = np.ascontiguousarray(np.asarray(pocket_ids, dtype=np.int64))
@@ -239,7 +241,7 @@ class Handle:
         self._check(self.lib.cmdgen_sample_chain(
             self.h, _ptr(pocket_x), _ptr(pocket_onehot), int(timesteps), _ptr(noise), C.c_uint64(seed & (2 ** 64 - 1)),
             ids.ctypes.data_as(_i64p) if ids is not None else None, _ptr(xh_phar), _ptr(xh_pocket),
-            _ptr(z_steps), int(bool(use_graph)), self._stream()), 'cmdgen_sample_chain')
+            _ptr(z_steps), _ptr(p_steps), int(bool(use_graph)), self._stream()), 'cmdgen_sample_chain')
         return xh_phar, xh_pocket, z_steps
 
     def chain_status(self):

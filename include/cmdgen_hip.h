@@ -145,13 +145,15 @@ int cmdgen_debug_read(cmdgen_handle* h, const char* what, float* host, size_t n,
  *   xh_phar_out   dev [Nl, 3+phar_nf]    x in Angstrom, h one-hot (as floats)
  *   xh_pocket_out dev [Np, 3+residue_nf] translated pocket, h = one_hot
  *   z_steps_out   dev [K, Nl, 3+phar_nf] z after each posterior step, or NULL
+ *   pocket_steps_out dev [K, Np, 3] translated pocket coordinates after each step (normalised space), or NULL
+ *                 (both feed return_frames > 1, conditional_model.py:439-442)
  *   use_graph     1: replay the step as a hipGraph, 0: eager launches
  * Asynchronous on `stream`; call cmdgen_chain_status afterwards for the deferred checks. */
 int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, const float* pocket_onehot,
                         int32_t timesteps, const float* noise, uint64_t seed,
                         const int64_t* pocket_ids_host,
                         float* xh_phar_out, float* xh_pocket_out, float* z_steps_out,
-                        int32_t use_graph, cmdgen_stream stream);
+                        float* pocket_steps_out, int32_t use_graph, cmdgen_stream stream);
 
 /* Optional: supply the per-step scalars of sample_p_zs_given_zt computed by the host
  * (e.g. with the same torch fp32 ops as the reference, bit for bit) instead of the
