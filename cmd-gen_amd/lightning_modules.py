@@ -162,6 +162,41 @@ class PharPocketDDPM(nn.Module):
         info['log_pN'] = log_pN.mean(0)
         return nll, info
 
+    def setup(self, stage=None):
+        """Datasets from <datadir>/{train,val,test}.npz (lightning_modules.py:145-155)."""
+        from pathlib import Path
+        from .dataset import ProcessedLigandPharPocketDataset
+        if stage == 'fit':
+            self.train_dataset = ProcessedLigandPharPocketDataset(Path(self.datadir, 'train.npz'))
+            self.val_dataset = ProcessedLigandPharPocketDataset(Path(self.datadir, 'val.npz'))
+        elif stage == 'test':
+            self.test_dataset = ProcessedLigandPharPocketDataset(Path(self.datadir, 'test.npz'))
+        else:
+            raise NotImplementedError
+
+    @torch.no_grad()
+    def sample_given_pocket_dataset(self, n_samples, dataset, batch_size=None, timesteps=None, **kw):
+        """Sampling loop of sample_and_analyze_given_pocket (lightning_modules.py:337-373): cycles through the
+        dataset in batches, draws the phar-node counts from the size prior and samples; returns per-sample
+        (coords, types, reference phar coords).  The RDKit / KL analysis that follows in the reference
+        (analysis/metrics.py) is out of scope."""
+        batch_size = self.batch_size if batch_size is None else batch_size
+        batch_size = min(batch_size, n_samples)
+        phars = []
+        for i in range(math.ceil(n_samples / batch_size)):
+            n_b = min(batch_size, n_samples - len(phars))
+            batch = dataset.collate_fn([dataset[(i * batch_size + j) % len(dataset)] for j in range(n_b)])
+            phar, pocket = self.get_phar_and_pocket(batch)
+            num_nodes_phar = self.ddpm.size_distribution.sample_conditional(n1=None, n2=pocket['size'])
+            xh_phar, xh_pocket, phar_mask, _ = self.ddpm.sample_given_pocket(pocket, num_nodes_phar,
+                                                                            timesteps=timesteps, **kw)
+            x = xh_phar[:, :self.x_dims].detach().cpu()
+            t = xh_phar[:, self.x_dims:].argmax(1).detach().cpu()
+            pm = phar_mask.cpu()
+            phars.extend(zip(utils.batch_to_list(x, pm), utils.batch_to_list(t, pm),
+                             utils.batch_to_list(phar['x'].cpu(), phar['mask'].cpu())))
+        return phars
+
     # ------------------------------------------------------------------ sampling entry points
     @torch.no_grad()
     def sample_given_batch(self, batch, timesteps=None, **kw):

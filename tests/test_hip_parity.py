@@ -452,3 +452,29 @@ def test_return_frames_api():
             sb = shift[pb.mask == b]
             assert np.abs(sb - sb[0]).max() < 1e-3 * max(1.0, np.abs(sb).max())           # rigid translation per sample
         assert torch.equal(f_pocket[k][:, 3:], one_p[:, 3:])
+
+
+def test_sampling_from_processed_dataset(tmp_path):
+    """Dataset path (NPZ schema -> collate -> size prior -> sample_given_pocket), as validation sampling uses it."""
+    from argparse import Namespace
+    from cmdgen_amd.dataset import ProcessedLigandPharPocketDataset, write_synthetic_npz
+    from cmdgen_amd.lightning_modules import PharPocketDDPM
+    from helpers import HIST
+    write_synthetic_npz(str(tmp_path / 'test.npz'), n_complexes=5, seed=4)
+    hp = dict(outdir='o', dataset='crossdock', datadir=str(tmp_path), batch_size=3, lr=1e-4,
+              egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=64, n_layers=2, attention=True,
+                                    tanh=True, norm_constant=1, inv_sublayers=1, sin_embedding=False,
+                                    aggregation_method='sum', normalization_factor=100),
+              diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
+                                         diffusion_noise_precision=1e-5, diffusion_loss_type='l2', normalize_factors=[1, 4]),
+              num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
+              eval_params=Namespace(n_eval_samples=7, eval_batch_size=3), mode='pocket_conditioning',
+              node_histogram=HIST, pocket_representation='CA')
+    model = PharPocketDDPM(**hp).cuda()
+    model.setup('test')
+    torch.manual_seed(0)
+    out = model.sample_given_pocket_dataset(7, model.test_dataset, batch_size=3, timesteps=10)
+    assert len(out) == 7                                                     # 3 + 3 + 1, cycling through 5 complexes
+    for x, t, ref in out:
+        assert x.shape[1] == 3 and len(x) == len(t) and 3 <= len(x) <= 25 and torch.isfinite(x).all()
+        assert int(t.min()) >= 0 and int(t.max()) < 8 and ref.shape[1] == 3

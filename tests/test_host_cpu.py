@@ -213,3 +213,24 @@ def test_linear_specs_cover_all_weights():
     """2 987 314 trainable parameters + the frozen 501-entry gamma table."""
     n = sum(o * i + (o if b else 0) for o, i, b in linear_specs(ModelConfig()).values())
     assert n == 2987314 and n + 501 == 2987815
+
+
+def test_dataset_npz_schema_centering_and_collate(tmp_path):
+    """dataset.py:7-64: split by mask, per-complex joint centring, collate to a flat batch with float masks (Q13)."""
+    from cmdgen_amd.dataset import ProcessedLigandPharPocketDataset, write_synthetic_npz
+    f = tmp_path / 'val.npz'
+    pb = write_synthetic_npz(str(f), n_complexes=5, seed=2)
+    ds = ProcessedLigandPharPocketDataset(str(f))
+    assert len(ds) == 5 and ds.data['num_pocket_nodes'].tolist() == pb.size.tolist()
+    for i in range(5):
+        it = ds[i]
+        allx = torch.cat([it['phar_coords'], it['pocket_c_alpha']])
+        assert float(allx.mean(0).abs().max()) < 1e-4                      # centred on the joint COG
+        assert it['phar_one_hot'].shape[1] == 8 and it['pocket_one_hot'].shape[1] == 20
+    batch = ds.collate_fn([ds[3], ds[1]])
+    assert batch['names'] == ['complex_3', 'complex_1']
+    assert batch['phar_mask'].dtype == torch.float32 and batch['phar_mask'].unique().tolist() == [0.0, 1.0]
+    assert batch['num_pocket_nodes'].tolist() == [int(pb.size[3]), int(pb.size[1])]
+    assert len(batch['pocket_c_alpha']) == int(pb.size[3] + pb.size[1])
+    raw = ProcessedLigandPharPocketDataset(str(f), center=False)
+    assert float(torch.cat([raw[0]['phar_coords'], raw[0]['pocket_c_alpha']]).mean(0).abs().max()) > 1.0
