@@ -339,8 +339,9 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
     ALLOC(w.XL, float4, (size_t)d.L * Nl, true); ALLOC(w.ACC, float4, (size_t)d.L * Nl, true);
     ALLOC(w.h, float, N * H, true); ALLOC(w.P, float, N * H, true); ALLOC(w.Q, float, N * H, true);
     ALLOC(w.Pc, float, N * H, true); ALLOC(w.Qc, float, N * H, true); ALLOC(w.agg, float, N * H, true);
-    ALLOC(w.degL, int, N, true); ALLOC(w.pocketE, int, B, true); ALLOC(w.pocketEph, int, B, true);
+    ALLOC(w.degL, int, N, true); ALLOC(w.pocketE, int, B, true); ALLOC(w.pocketEph, int, B, true); ALLOC(w.pocketEns, int, B, true);
     ALLOC(w.erow, int, ecap, false); ALLOC(w.ecol, int, ecap, false); ALLOC(w.ed0, float, ecap, false);
+    ALLOC(w.crow, int, eccap, false); ALLOC(w.ccol, int, eccap, false); ALLOC(w.cd0, float, eccap, false);
     ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true);
     ALLOC(w.eps_tmp, float, (size_t)Nl * (3 + d.P), true);
 #undef ALLOC

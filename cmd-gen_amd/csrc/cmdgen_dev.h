@@ -98,9 +98,11 @@ struct Work {                   // per-layout workspace; all pointers device
     int*    degL;               // [N] degree in sample-local order
     int*    pocketE;            // [B] edges per sample
     int*    pocketEph;          // [B] edges with phar receiver per sample
+    int*    pocketEns;          // [B] ... of those that are not self loops
     int*    erow; int* ecol; float* ed0;        // [Ecap] compact edge list sorted by flat (row, col); the first
-                                                //        totals[1] entries are the phar-receiver edges
-    int*    totals;             // [0]=E, [1]=Ec of the current evaluation
+                                                //        pocketEph-sum entries are the phar-receiver edges
+    int*    crow; int* ccol; float* cd0;        // [Eccap] phar-receiver edges without self loops (coordinate update)
+    int*    totals;             // [0]=E, [1]=Ec (coordinate list) of the current evaluation
     unsigned long long* counters;   // cmdgen_counters
     int*    nan_flag;           // [1] set by readout when any velocity is NaN
     float*  eps_tmp;            // [Nl][3+P] evaluation output used by the chain

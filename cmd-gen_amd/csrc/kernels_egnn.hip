@@ -61,7 +61,7 @@ __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict
     const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     for (int i = wave; i < n; i += nwaves) {
         const float4 pi = spos[i];
-        int cnt = 0;
+        int cnt = 0, self = 0;
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
             bool ok = false;
@@ -69,16 +69,21 @@ __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict
                 const float r2 = dist2(pi, spos[j]);
                 ok = (d.cutoff2 < 0.f) || (r2 <= d.cutoff2);
             }
-            cnt += __popcll(__ballot(ok));
+            const unsigned long long m = __ballot(ok);
+            cnt += __popcll(m);
+            if (i >= j0 && i < j0 + 64) self = (int)((m >> (i - j0)) & 1ull);
         }
-        if (lane == 0) { sdeg[i] = cnt; w.degL[pb + qb + i] = cnt; }
+        if (lane == 0) { sdeg[i] = cnt | (self << 30); w.degL[pb + qb + i] = cnt | (self << 30); }   // bit 30: the self loop exists
     }
     __syncthreads();
     if (wave == 0) {
-        int e = 0, eph = 0;
-        for (int i = lane; i < n; i += 64) { const int dg = sdeg[i]; e += dg; if (i < nl) eph += dg; }
-        for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o); eph += __shfl_xor(eph, o); }
-        if (lane == 0) { w.pocketE[b] = e; w.pocketEph[b] = eph; }
+        int e = 0, eph = 0, ens = 0;
+        for (int i = lane; i < n; i += 64) {
+            const int dg = sdeg[i] & 0x3fffffff; e += dg;
+            if (i < nl) { eph += dg; ens += dg - ((sdeg[i] >> 30) & 1); }
+        }
+        for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o); eph += __shfl_xor(eph, o); ens += __shfl_xor(ens, o); }
+        if (lane == 0) { w.pocketE[b] = e; w.pocketEph[b] = eph; w.pocketEns[b] = ens; }
     }
     if (b == 0 && tid == 0) {
         if (chain) chain->step += 1;
@@ -91,8 +96,8 @@ __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict
 __global__ void k_edge_write(Layout lay, Work w, Dims d) {
     extern __shared__ float4 spos[];
     int* soff = reinterpret_cast<int*>(spos + lay.max_n);
-    __shared__ int s_base[3];
-    __shared__ int s_red[3][16];
+    __shared__ int s_base[4];
+    __shared__ int s_red[4][16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nl = lay.num_phar[b], np = lay.num_pocket[b], n = nl + np;
     const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
@@ -102,28 +107,31 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
     // numbering (dynamics.py:146): all phar receivers first (sample by sample), then all pocket
     // receivers.  So the phar-receiver edges - the only ones the coordinate update needs - are
     // the first Ec entries of the same list.
-    int e = 0, eph = 0, ephall = 0;
+    int e = 0, eph = 0, ephall = 0, ens = 0;
     for (int k = tid; k < lay.B; k += blockDim.x) {
         const int pe = w.pocketE[k], pp = w.pocketEph[k];
         ephall += pp;
-        if (k < b) { e += pe; eph += pp; }
+        if (k < b) { e += pe; eph += pp; ens += w.pocketEns[k]; }
     }
-    for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o); eph += __shfl_xor(eph, o); ephall += __shfl_xor(ephall, o); }
-    if (lane == 0) { s_red[0][wave] = e; s_red[1][wave] = eph; s_red[2][wave] = ephall; }
+    for (int o = 32; o > 0; o >>= 1) {
+        e += __shfl_xor(e, o); eph += __shfl_xor(eph, o); ephall += __shfl_xor(ephall, o); ens += __shfl_xor(ens, o);
+    }
+    if (lane == 0) { s_red[0][wave] = e; s_red[1][wave] = eph; s_red[2][wave] = ephall; s_red[3][wave] = ens; }
     __syncthreads();
     if (tid == 0) {
-        int te = 0, tp = 0, ta = 0;
-        for (int k = 0; k < nwaves; ++k) { te += s_red[0][k]; tp += s_red[1][k]; ta += s_red[2][k]; }
+        int te = 0, tp = 0, ta = 0, tn = 0;
+        for (int k = 0; k < nwaves; ++k) { te += s_red[0][k]; tp += s_red[1][k]; ta += s_red[2][k]; tn += s_red[3][k]; }
         s_base[0] = tp;                     // phar-receiver section: edges of earlier samples' phar rows
         s_base[1] = ta + (te - tp);         // pocket-receiver section starts after ALL phar-receiver edges
         s_base[2] = ta;
+        s_base[3] = tn;                     // coordinate list (phar receivers, self loops dropped)
     }
     // exclusive scan of the degrees inside the sample (wave 0, 64 at a time)
     if (wave == 0) {
         int carry = 0;
         for (int c = 0; c < n; c += 64) {
             const int i = c + lane;
-            const int v = i < n ? w.degL[pb + qb + i] : 0;
+            const int v = i < n ? (w.degL[pb + qb + i] & 0x3fffffff) : 0;
             int s = v;
             for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(s, o); if (lane >= o) s += t; }
             if (i < n) soff[i] = carry + s - v;
@@ -132,10 +140,21 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
     }
     __syncthreads();
     const int eph_b = w.pocketEph[b];
+    // The coordinate update needs the phar-receiver edges WITHOUT the self loops: their coord_diff is
+    // exactly (x_i - x_i)/(...) = 0, so they add exactly 0 to the sum (egnn_new.py:91, :265-271).
+    // Offset of receiver i in that list = (edges before it) - (self loops before it); inside a sample the
+    // phar rows come first, so the number of earlier rows is i.
     for (int i = wave; i < n; i += nwaves) {
         const float4 pi = spos[i];
         const int gi = flat_node(i, nl, pb, qb, lay.Nl);
         int off = i < nl ? s_base[0] + soff[i] : s_base[1] + (soff[i] - eph_b);
+        int coff = 0;
+        if (i < nl) {
+            int selfs = 0;
+            for (int k = lane; k < i; k += 64) selfs += (w.degL[pb + qb + k] >> 30) & 1;
+            for (int o = 32; o > 0; o >>= 1) selfs += __shfl_xor(selfs, o);
+            coff = s_base[3] + soff[i] - selfs;
+        }
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
             bool ok = false; float r2 = 0.f;
@@ -146,13 +165,22 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
             const unsigned long long m = __ballot(ok);
             if (ok) {
                 const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-                w.erow[pos] = gi; w.ecol[pos] = flat_node(j, nl, pb, qb, lay.Nl); w.ed0[pos] = r2;
+                const int gj = flat_node(j, nl, pb, qb, lay.Nl);
+                w.erow[pos] = gi; w.ecol[pos] = gj; w.ed0[pos] = r2;
             }
             off += __popcll(m);
+            if (i < nl) {
+                const unsigned long long mc = __ballot(ok && j != i);
+                if (ok && j != i) {
+                    const int cpos = coff + __popcll(mc & ((1ull << lane) - 1ull));
+                    w.crow[cpos] = gi; w.ccol[cpos] = flat_node(j, nl, pb, qb, lay.Nl); w.cd0[cpos] = r2;
+                }
+                coff += __popcll(mc);
+            }
         }
     }
     if (b == lay.B - 1 && tid == 0) {
-        const int E = s_base[1] + (w.pocketE[b] - eph_b), Ec = s_base[2];
+        const int E = s_base[1] + (w.pocketE[b] - eph_b), Ec = s_base[3] + w.pocketEns[b];
         w.totals[0] = E; w.totals[1] = Ec;
         atomicAdd(&w.counters[1], (unsigned long long)E);
         atomicAdd(&w.counters[2], (unsigned long long)Ec);
@@ -560,7 +588,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
         if (tid < MT) {
             int row = -1, col = -1; float r = 0.f, d0 = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
             if (tid < ne) {
-                row = w.erow[e0 + tid]; col = w.ecol[e0 + tid]; d0 = w.ed0[e0 + tid];   // phar-receiver prefix
+                row = w.crow[e0 + tid]; col = w.ccol[e0 + tid]; d0 = w.cd0[e0 + tid];   // phar receivers, self loops dropped
                 const float4 pi = node_pos(lay, w, d, row, layer, false);
                 const float4 pj = node_pos(lay, w, d, col, layer, false);
                 cx = pi.x - pj.x; cy = pi.y - pj.y; cz = pi.z - pj.z;

@@ -72,7 +72,8 @@ typedef struct cmdgen_config {
 typedef struct cmdgen_counters {
     uint64_t evaluations;          /* network evaluations (EGNNDynamics.forward calls) */
     uint64_t edges;                /* sum over evaluations of directed edges incl. self loops */
-    uint64_t edges_phar;           /* ... of those whose receiver is a pharmacophore node */
+    uint64_t edges_phar;           /* ... of those the coordinate update runs on: receiver is a pharmacophore node and
+                                      the edge is not a self loop (a self loop's coord_diff is exactly 0) */
     uint64_t nodes;                /* sum over evaluations of nodes */
     uint64_t nan_resets;           /* evaluations whose velocity was reset (dynamics.py:129-131) */
     uint64_t reserved[3];

@@ -190,7 +190,7 @@ def test_full_size_batch_properties():
     xg, pg, st = _philox_chain(h, pb, K, use_graph=True)
     c = h.counters()
     assert c['evaluations'] == K + 1 and c['nodes'] == (K + 1) * (64 * 59)
-    assert c['edges'] >= c['edges_phar'] >= (K + 1) * 64 * 15       # at least the self loops
+    assert c['edges'] >= (K + 1) * 64 * 59 and 0 <= c['edges_phar'] <= c['edges']   # every node keeps its self loop; edges_phar = phar receivers minus self loops
     assert st['max_rel_com_error'] < 1e-2 and st['nan_resets'] == 0
     assert np.isfinite(xg).all()
     oh = xg[:, 3:]
