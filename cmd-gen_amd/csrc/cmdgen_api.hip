@@ -68,6 +68,7 @@ struct cmdgen_handle {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     const float* graph_noise = nullptr; float* graph_zsteps = nullptr; float* graph_psteps = nullptr; hipStream_t graph_stream = nullptr;
     unsigned long long graph_seed = 0;
+    int graph_steps = 0;
     bool kernel_profiling = false;
     std::vector<hipEvent_t> prof_events[3];
 };
@@ -561,16 +562,25 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
         if (h->step_graph && (h->graph_noise != noise || h->graph_zsteps != z_steps_out || h->graph_psteps != pocket_steps_out || h->graph_stream != s || h->graph_seed != seed)) {
             hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr;
         }
+        // G identical steps per graph launch amortise the per-replay floor (~10-16 us host side, a few us of
+        // device idle): the step index lives on the device, so a G-step graph is just G copies of the step.
+        const char* gs = getenv("CMDGEN_GRAPH_STEPS");
+        int G = gs ? atoi(gs) : 8;
+        if (G < 1) G = 1;
+        if (G > K) G = K;
+        if (h->step_graph && h->graph_steps != G) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
         if (!h->step_graph) {
             hipGraph_t g = nullptr;
             HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            one_step(s);
+            for (int i = 0; i < G; ++i) one_step(s);
             HIPCHK(h, hipStreamEndCapture(s, &g));
             HIPCHK(h, hipGraphInstantiate(&h->step_graph, g, nullptr, nullptr, 0));
             hipGraphDestroy(g);
             h->graph_noise = noise; h->graph_zsteps = z_steps_out; h->graph_psteps = pocket_steps_out; h->graph_stream = s; h->graph_seed = seed;
+            h->graph_steps = G;
         }
-        for (int i = 0; i < K; ++i) HIPCHK(h, hipGraphLaunch(h->step_graph, s));
+        for (int i = 0; i < K / G; ++i) HIPCHK(h, hipGraphLaunch(h->step_graph, s));
+        for (int i = 0; i < K % G; ++i) one_step(s);
     } else {
         for (int i = 0; i < K; ++i) one_step(s);
     }
