@@ -23,6 +23,8 @@ void cmdgen_launch_chain_init(const Layout& lay, const Dims& d, const ChainBuf& 
                               const float* poh, hipStream_t s);
 void cmdgen_launch_ddpm_step(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
                              const float* eps, hipStream_t s);
+void cmdgen_launch_debug_noise(unsigned long long seed, long long pocket_id, int draw, int n_nodes, int width,
+                               float* out, hipStream_t s);
 void cmdgen_launch_chain_final(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
                                const float* eps, float* xo, float* po, unsigned int* cog, hipStream_t s);
 
@@ -285,6 +287,7 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
 #undef GET
 #undef UP
     h->finalized = true;
+    h->user_coef_K = -1; h->chain_K = -1;      // a new gamma table invalidates any step table
     return CMDGEN_OK;
 }
 
@@ -716,5 +719,14 @@ extern "C" int cmdgen_get_kernel_profile(cmdgen_handle* h, float total_ms[3], in
         if (total_ms) total_ms[k] = (float)tot;
         if (launches) launches[k] = (int64_t)n;
     }
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_debug_noise(cmdgen_handle* h, uint64_t seed, int64_t pocket_id, int32_t draw, int32_t n_nodes,
+                                  int32_t width, float* out_dev, cmdgen_stream stream) {
+    if (!h || !out_dev || n_nodes < 1 || width < 1 || width > 16) return fail(h, CMDGEN_EINVAL, "bad arguments");
+    hipSetDevice(h->device);
+    cmdgen_launch_debug_noise(seed, pocket_id, draw, n_nodes, width, out_dev, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;
 }

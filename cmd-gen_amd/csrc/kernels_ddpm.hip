@@ -205,3 +205,20 @@ void cmdgen_launch_chain_final(const Layout& lay, const Dims& d, const ChainBuf&
     hipLaunchKernelGGL(k_chain_final, dim3(lay.B), dim3(64), 0, s, lay, d, c, w, eps, xo, po, cog);
     hipLaunchKernelGGL(k_chain_drift_fix, dim3(lay.B), dim3(64), 0, s, lay, d, xo, po, (const unsigned int*)cog);
 }
+
+// same generator as draw() above, exposed for statistical tests
+__global__ void k_debug_noise(unsigned long long seed, long long pocket_id, int draw_idx, int n_nodes, int width,
+                              float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_nodes * width) return;
+    const int local = idx / width, comp = idx - local * width;
+    float z[4];
+    philox_normal4(seed, (uint32_t)pocket_id, (uint32_t)((unsigned long long)pocket_id >> 32), (uint32_t)draw_idx,
+                   (uint32_t)(local * 4 + (comp >> 2)), z);
+    out[idx] = z[comp & 3];
+}
+void cmdgen_launch_debug_noise(unsigned long long seed, long long pocket_id, int draw, int n_nodes, int width,
+                               float* out, hipStream_t s) {
+    const int n = n_nodes * width;
+    hipLaunchKernelGGL(k_debug_noise, dim3((n + 255) / 256), dim3(256), 0, s, seed, pocket_id, draw, n_nodes, width, out);
+}

@@ -51,6 +51,7 @@ SYMBOLS = [
     ('cmdgen_dynamics_forward', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _vp]),
     ('cmdgen_get_edges', C.c_int, [_vp, _vp, _vp, C.c_int64, _i64p, _vp]),
     ('cmdgen_debug_read', C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t, _vp]),
+    ('cmdgen_debug_noise', C.c_int, [_vp, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _fp, _vp]),
     ('cmdgen_sample_chain', C.c_int, [_vp, _fp, _fp, C.c_int32, _fp, C.c_uint64, _i64p, _fp, _fp, _fp, _fp,
                                       C.c_int32, _vp]),
     ('cmdgen_set_step_table', C.c_int, [_vp, C.c_int32, _vp]),
@@ -283,3 +284,10 @@ class Handle:
         n = (C.c_int64 * 3)()
         self._check(self.lib.cmdgen_get_kernel_profile(self.h, ms, n, self._stream()), 'cmdgen_get_kernel_profile')
         return {k: (ms[i], n[i]) for i, k in enumerate(('edge_msg', 'node', 'edge_coord'))}
+
+    def debug_noise(self, seed: int, pocket_id: int, draw: int, n_nodes: int, width: int = 11):
+        import torch
+        out = torch.empty((n_nodes, width), dtype=torch.float32, device=f'cuda:{self.device_index}')
+        self._check(self.lib.cmdgen_debug_noise(self.h, C.c_uint64(seed), C.c_int64(pocket_id), draw, n_nodes, width,
+                                                _ptr(out), self._stream()), 'cmdgen_debug_noise')
+        return out

@@ -130,6 +130,12 @@ int cmdgen_get_edges(cmdgen_handle* h, int32_t* row_host, int32_t* col_host, int
  * what = "h" [N, hidden] after the last block, "x" [Nl, 4] final phar coordinates. */
 int cmdgen_debug_read(cmdgen_handle* h, const char* what, float* host, size_t n, cmdgen_stream stream);
 
+/* Fills out_dev[n_nodes * width] with the standard normals the sampler would draw for draw index
+ * `draw`, global pocket id `pocket_id` (Philox4x32-10 + Box-Muller; the production noise source of
+ * cmdgen_sample_chain when `noise` is NULL).  Test aid for the statistical checks. */
+int cmdgen_debug_noise(cmdgen_handle* h, uint64_t seed, int64_t pocket_id, int32_t draw, int32_t n_nodes,
+                       int32_t width, float* out_dev, cmdgen_stream stream);
+
 /* ---- the denoising loop ----------------------------------------------------------- */
 /* ConditionalDDPM.sample_given_pocket (conditional_model.py:388-465) with return_frames=1:
  * init noise around the pocket COM, `timesteps` posterior steps (sample_p_zs_given_zt

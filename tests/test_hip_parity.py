@@ -478,3 +478,39 @@ def test_sampling_from_processed_dataset(tmp_path):
     for x, t, ref in out:
         assert x.shape[1] == 3 and len(x) == len(t) and 3 <= len(x) <= 25 and torch.isfinite(x).all()
         assert int(t.min()) >= 0 and int(t.max()) < 8 and ref.shape[1] == 3
+
+
+def test_device_noise_is_standard_normal_and_keyed():
+    """The production noise source (Philox4x32-10 + Box-Muller): moments of N(0,1), no correlation between
+    neighbouring components, reproducible, and distinct per (seed, pocket id, draw)."""
+    h = hip_backend.Handle(ModelConfig(hidden_nf=64, n_layers=1).as_dict(), 0)
+    z = h.debug_noise(seed=123, pocket_id=7, draw=3, n_nodes=200000, width=11).cpu().numpy().astype(np.float64)
+    n = z.size
+    assert abs(z.mean()) < 4 / np.sqrt(n) and abs(z.var() - 1) < 4 * np.sqrt(2 / n)
+    assert abs((z ** 3).mean()) < 0.02 and abs((z ** 4).mean() - 3) < 0.05
+    assert np.abs(z).max() < 6.5 and np.isfinite(z).all()
+    flat = z.ravel()
+    assert abs(np.corrcoef(flat[:-1], flat[1:])[0, 1]) < 5 / np.sqrt(n)
+    assert abs(np.corrcoef(z[:-1, 0], z[1:, 0])[0, 1]) < 5 / np.sqrt(len(z))
+    frac = (np.abs(flat) < 1).mean()
+    assert abs(frac - 0.682689) < 0.002
+    again = h.debug_noise(123, 7, 3, 1000).cpu().numpy()
+    assert np.array_equal(again, z[:1000].astype(np.float32))
+    for kw in (dict(seed=124, pocket_id=7, draw=3), dict(seed=123, pocket_id=8, draw=3), dict(seed=123, pocket_id=7, draw=4)):
+        other = h.debug_noise(n_nodes=1000, **kw).cpu().numpy()
+        assert abs(np.corrcoef(other.ravel(), z[:1000].ravel())[0, 1]) < 0.05
+
+
+def test_library_schedule_fallback_matches_host_table():
+    """Without cmdgen_set_step_table the library evaluates the per-step scalars itself (libm, fp32); a chain run
+    with it agrees with the host-table chain to fp32 round-off."""
+    name = 'ca_h256_K5'
+    cfg, sd, pb, K = chain_case(G4, name)
+    h = hip_backend.Handle(cfg.as_dict(), 0)
+    h.load_state_dict(sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    noise = dev(G4[name + '/noise'])
+    a, _, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=noise, use_graph=False)      # library table
+    want = G4[name + '/xh_phar']
+    assert rms(a[:, :3].cpu().numpy(), want[:, :3]) <= 1e-4 * max(1.0, float(np.abs(want[:, :3]).max()))
+    assert np.array_equal(a[:, 3:].cpu().numpy(), want[:, 3:])
