@@ -514,3 +514,19 @@ def test_library_schedule_fallback_matches_host_table():
     want = G4[name + '/xh_phar']
     assert rms(a[:, :3].cpu().numpy(), want[:, :3]) <= 1e-4 * max(1.0, float(np.abs(want[:, :3]).max()))
     assert np.array_equal(a[:, 3:].cpu().numpy(), want[:, 3:])
+
+
+def test_c_api_demo_runs_without_python_or_torch(tmp_path):
+    """examples/c_api_demo.cpp: a plain C++ host program against include/cmdgen_hip.h + libcmdgen_hip.so."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'c_api_demo')
+    libdir = os.path.join(root, 'cmd-gen_amd')
+    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O2', '-I' + os.path.join(root, 'include'),
+           os.path.join(root, 'examples', 'c_api_demo.cpp'), '-L' + libdir, '-lcmdgen_hip', '-Wl,-rpath,' + libdir, '-o', exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert 'evaluations 51' in r.stdout and 'one-hot rows valid 1' in r.stdout
