@@ -223,6 +223,8 @@ def main():
                 'flop_per_launch': flop_per_launch, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
                 'units_per_launch': units[dom],
                 'whole_job_frac': f_alg / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                # the north-star also asks for the HBM view: PMC bytes per launch / launch time / 8 TB/s (not the binding roofline)
+                'hbm_frac_from_pmc': (traffic / (avg_ms * 1e-3) / (PEAK_HBM_TBS * 1e12)) if traffic else None,
                 'per_kernel': {k: {kk: v[kk] for kk in ('total_ms', 'avg_launch_ms', 'tflops')} | {'frac': v['tflops'] / PEAK_FP32_MFMA_TFLOPS}
                                for k, v in per_kernel.items()},
             },

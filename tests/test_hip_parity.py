@@ -585,3 +585,47 @@ def test_long_chain_matches_oracle(K):
         assert rms(got_p.cpu().numpy(), want_p.numpy()) <= 1e-4 * max(1.0, float(np.abs(want_p.numpy()).max()))
         return
     pytest.skip('every candidate seed came within 1e-4 A of the cutoff')
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_fuzz_hyperparameters_and_layouts(seed):
+    """Randomised configurations outside the shipped ones: flags off, complete graph (no cutoff), no time
+    conditioning, other vocabulary / joint sizes, norm constants, 1-5 blocks, ragged batches - HIP vs oracle."""
+    from oracle import ref_cpu
+    rng = np.random.Generator(np.random.PCG64(4242 + seed))
+    cfg = ModelConfig(
+        phar_nf=int(rng.integers(3, 13)), residue_nf=int(rng.integers(4, 25)), joint_nf=int(rng.choice([8, 16, 32, 48])),
+        hidden_nf=int(rng.choice([64, 128, 256])), n_layers=int(rng.integers(1, 6)),
+        attention=bool(rng.integers(0, 2)), tanh=bool(rng.integers(0, 2)),
+        norm_constant=float(rng.choice([0.0, 1.0, 2.5])), normalization_factor=float(rng.choice([1.0, 100.0])),
+        edge_cutoff=None if rng.random() < 0.25 else float(rng.choice([4.0, 6.0, 9.0])),
+        condition_time=bool(rng.random() < 0.8))
+    sd = make_state_dict(cfg, seed=1000 + seed, coord_gain=float(rng.choice([1e-3, 0.3])))
+    B = int(rng.integers(1, 9))
+    nph = rng.integers(1, 14, size=B)
+    npk = rng.integers(1, 50, size=B)
+    pm, qm = np.repeat(np.arange(B), nph), np.repeat(np.arange(B), npk)
+    for _ in range(50):
+        xq = (rng.normal(size=(len(qm), 3)) * 5.0).astype(np.float32)
+        xp = (rng.normal(size=(len(pm), 3)) * 3.0).astype(np.float32)
+        if cfg.edge_cutoff is None or min_cutoff_margin(np.concatenate([xp, xq]), np.concatenate([pm, qm]), cfg.edge_cutoff) > 2e-3:
+            break
+    else:
+        pytest.skip('no layout with a safe cutoff margin found')
+    xh_phar = np.concatenate([xp, rng.normal(size=(len(pm), cfg.phar_nf)).astype(np.float32)], 1)
+    oh = np.eye(cfg.residue_nf, dtype=np.float32)[rng.integers(0, cfg.residue_nf, size=len(qm))] / 4.0
+    xh_pocket = np.concatenate([xq, oh], 1).astype(np.float32)
+    t = rng.uniform(0.0, 1.0, size=(B, 1)).astype(np.float32)
+    p = ref_cpu.to_torch_params(sd)
+    with torch.no_grad():
+        want, want_q = ref_cpu.dynamics_forward(p, cfg.as_dict(), torch.from_numpy(xh_phar), torch.from_numpy(xh_pocket),
+                                                torch.from_numpy(t), torch.from_numpy(pm), torch.from_numpy(qm))
+    h = hip_backend.Handle(cfg.as_dict(), 0)
+    h.load_state_dict(sd)
+    h.set_layout(nph, npk)
+    got, got_q = h.dynamics_forward(dev(xh_phar), dev(xh_pocket), dev(t))
+    want, want_q = want.numpy(), want_q.numpy()
+    tol = 5e-5 * max(1.0, float(np.abs(want).max()))       # complete graphs at normalization_factor 1 sum hundreds of terms
+    assert float(np.abs(got.cpu().numpy() - want).max()) <= tol, (cfg, B)
+    assert float(np.abs(got_q.cpu().numpy() - want_q).max()) <= 5e-5 * max(1.0, float(np.abs(want_q).max()))
+    h.close()
