@@ -122,7 +122,7 @@ extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle
     Dims& d = h->dims;
     d.P = cfg->phar_nf; d.R = cfg->residue_nf; d.J = cfg->joint_nf; d.H = H; d.L = cfg->n_layers;
     d.condition_time = cfg->condition_time ? 1 : 0; d.dyn = d.J + d.condition_time;
-    d.attention = cfg->attention ? 1 : 0; d.use_tanh = cfg->tanh ? 1 : 0;
+    d.attention = cfg->attention ? 1 : 0; d.use_tanh = cfg->tanh ? 1 : 0; d.no_com = cfg->no_com_projection ? 1 : 0;
     d.cutoff2 = cfg->edge_cutoff < 0.f ? -1.f : cfg->edge_cutoff * cfg->edge_cutoff;
     d.norm_constant = cfg->norm_constant; d.norm_factor = cfg->normalization_factor; d.coords_range = cfg->coords_range;
     d.norm_x = cfg->norm_x; d.norm_h = cfg->norm_h; d.bias_h = cfg->bias_h;

@@ -68,6 +68,7 @@ struct Dims {
     int P, R, J, H, L;          // phar_nf, residue_nf, joint_nf, hidden_nf, n_layers
     int dyn;                    // J + condition_time
     int attention, use_tanh, condition_time;
+    int no_com;                 // SimpleConditionalDDPM: no centre-of-mass projection in the sampler
     float cutoff2;              // cutoff^2, < 0: no cutoff
     float norm_constant, norm_factor, coords_range;
     float norm_x, norm_h, bias_h;

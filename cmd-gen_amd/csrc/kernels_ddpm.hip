@@ -70,6 +70,22 @@ __global__ __launch_bounds__(64) void k_chain_init(Layout lay, Dims d, ChainBuf 
         for (int k = 0; k < d.R; ++k) o[3 + k] = (pocket_onehot[(size_t)(qb + i) * d.R + k] - d.bias_h) / d.norm_h;
     }
     __syncthreads();
+    if (d.no_com) {      // SimpleConditionalDDPM.sample_given_pocket :512-521: subtract the pocket COM once (un-normalised x; norm_x divides both)
+        float pm = 0.f;
+        if (lane < 3) {
+            float s = 0.f;
+            for (int i = 0; i < np; ++i) s += pocket_x[(size_t)(qb + i) * 3 + lane];
+            pm = s / fmaxf((float)np, 1.0f);
+        }
+        const float p0 = __shfl(pm, 0), p1 = __shfl(pm, 1), p2 = __shfl(pm, 2);
+        for (int i = lane; i < np; i += 64) {
+            float* o = c.xh_pocket + (size_t)(qb + i) * ldq;
+            o[0] = (pocket_x[(size_t)(qb + i) * 3 + 0] - p0) / d.norm_x;
+            o[1] = (pocket_x[(size_t)(qb + i) * 3 + 1] - p1) / d.norm_x;
+            o[2] = (pocket_x[(size_t)(qb + i) * 3 + 2] - p2) / d.norm_x;
+        }
+        __syncthreads();
+    }
     float mu = 0.f;
     if (lane < 3) {
         float s = 0.f;
@@ -83,6 +99,7 @@ __global__ __launch_bounds__(64) void k_chain_init(Layout lay, Dims d, ChainBuf 
         c.z_phar[(size_t)(pb + i) * ld + k] = m + 1.0f * draw(c, lay, 0, b, i, pb + i, k, ld);
     }
     __syncthreads();
+    if (d.no_com) return;                       // no projection, and the mean-zero assertion is a no-op (:503-505)
     remove_com(c.z_phar, ld, pb, nl, c.xh_pocket, ldq, qb, np, lane);
     __syncthreads();
     record_com_check(c.check, c.z_phar, ld, pb, nl, 1.0f, lane);
@@ -99,7 +116,7 @@ __global__ __launch_bounds__(64) void k_ddpm_step(Layout lay, Dims d, ChainBuf c
     const float4 cf = c.coef[step];
     const bool nan_reset = *w.nan_flag != 0;
     // the reference checks z_t (the step's input) after the update; same numbers, recorded first
-    record_com_check(c.check + 2 * (1 + step), c.z_phar, ld, pb, nl, 1.0f, lane);
+    if (!d.no_com) record_com_check(c.check + 2 * (1 + step), c.z_phar, ld, pb, nl, 1.0f, lane);
     __syncthreads();
     for (int idx = lane; idx < nl * ld; idx += 64) {
         const int i = idx / ld, k = idx % ld;
@@ -110,7 +127,7 @@ __global__ __launch_bounds__(64) void k_ddpm_step(Layout lay, Dims d, ChainBuf c
         c.z_phar[o] = mu + cf.z * draw(c, lay, 1 + step, b, i, pb + i, k, ld);
     }
     __syncthreads();
-    remove_com(c.z_phar, ld, pb, nl, c.xh_pocket, ldq, qb, np, lane);
+    if (!d.no_com) remove_com(c.z_phar, ld, pb, nl, c.xh_pocket, ldq, qb, np, lane);
     __syncthreads();
     if (c.z_steps)
         for (int idx = lane; idx < nl * ld; idx += 64) {
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(64) void k_chain_final(Layout lay, Dims d, ChainBuf
         c.z_phar[o] = mu + cf.z * draw(c, lay, 1 + K, b, i, pb + i, k, ld);
     }
     __syncthreads();
-    remove_com(c.z_phar, ld, pb, nl, c.xh_pocket, ldq, qb, np, lane);
+    if (!d.no_com) remove_com(c.z_phar, ld, pb, nl, c.xh_pocket, ldq, qb, np, lane);
     __syncthreads();
     // unnormalize (en_diffusion.py:891-895)
     for (int i = lane; i < nl; i += 64) {
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(64) void k_chain_final(Layout lay, Dims d, ChainBuf
         for (int k = 0; k < d.R; ++k) o[3 + k] = q[3 + k] * d.norm_h + d.bias_h;
     }
     __syncthreads();
-    record_com_check(c.check + 2 * (1 + K), xh_phar_out, ld, pb, nl, 1.0f, lane);
+    if (!d.no_com) record_com_check(c.check + 2 * (1 + K), xh_phar_out, ld, pb, nl, 1.0f, lane);
     // CoG drift of the un-normalised coordinates (conditional_model.py:451-452)
     float s = 0.f;
     if (lane < 3) for (int i = 0; i < nl; ++i) s += xh_phar_out[(size_t)(pb + i) * ld + lane];
@@ -186,7 +203,7 @@ __global__ __launch_bounds__(64) void k_chain_final(Layout lay, Dims d, ChainBuf
 __global__ __launch_bounds__(64) void k_chain_drift_fix(Layout lay, Dims d, float* __restrict__ xh_phar_out,
                                                         float* __restrict__ xh_pocket_out,
                                                         const unsigned int* cog_slot) {
-    if (__uint_as_float(*cog_slot) <= 5e-2f) return;
+    if (d.no_com || __uint_as_float(*cog_slot) <= 5e-2f) return;       // the simple variant's re-centring is the identity (:500-501)
     const int b = blockIdx.x, lane = threadIdx.x;
     remove_com(xh_phar_out, 3 + d.P, lay.phar_base[b], lay.num_phar[b], xh_pocket_out, 3 + d.R,
                lay.pocket_base[b], lay.num_pocket[b], lane);

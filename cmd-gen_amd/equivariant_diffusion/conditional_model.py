@@ -235,7 +235,37 @@ class ConditionalDDPM(EnVariationalDiffusion):
 
 
 class SimpleConditionalDDPM(ConditionalDDPM):
-    """Variant without the COM subspace trick (conditional_model.py:481-525): not used by the
-    shipped configs; the HIP sampler implements the subspace version only."""
+    """The same model without the subspace trick (conditional_model.py:481-525): the context (pocket) is
+    centred once and samples are not projected to the COM-free subspace; translation equivariance comes from
+    evaluating everything in the pocket-centred frame."""
+
     def __init__(self, *args, **kwargs):
-        raise NotImplementedError("mode 'pocket_conditioning_simple' is not built (no shipped config uses it)")
+        super().__init__(*args, **kwargs)
+        self.dynamics.attach_diffusion(self.T, self.gamma.gamma.detach().cpu().numpy(), self.norm_values,
+                                       self.norm_biases, no_com_projection=True)
+
+    def subspace_dimensionality(self, input_size):
+        return input_size * self.n_dims
+
+    @classmethod
+    def remove_mean_batch(cls, x_phar, x_pocket, phar_indices, pocket_indices):
+        return x_phar, x_pocket
+
+    @staticmethod
+    def _pocket_com(pocket):
+        n = len(pocket['size'])
+        x, m = pocket['x'], pocket['mask']
+        tot = torch.zeros((n, x.size(1)), dtype=x.dtype, device=x.device).index_add_(0, m, x)
+        cnt = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(
+            0, m, torch.ones(len(m), dtype=x.dtype, device=x.device)).clamp(min=1)
+        return tot / cnt[:, None]
+
+    @torch.no_grad()
+    def forward(self, phar, pocket, return_info=False, t_int=None, eps=None):
+        phar, pocket = dict(phar), dict(pocket)
+        com = self._pocket_com(pocket)
+        phar['x'] = phar['x'] - com[phar['mask']]
+        pocket['x'] = pocket['x'] - com[pocket['mask']]
+        return super().forward(phar, pocket, return_info, t_int=t_int, eps=eps)
+
+    # sample_given_pocket: the library centres the pocket itself when no_com_projection is set

@@ -53,8 +53,9 @@ class EGNNDynamics(nn.Module):
         self._mask_cache = None
 
     # -- wiring from the diffusion module (schedule table and normalisation live in the same handle)
-    def attach_diffusion(self, timesteps, gamma_table, norm_values, norm_biases):
-        self._cfg.update(timesteps=int(timesteps), norm_values=tuple(norm_values), norm_biases=tuple(norm_biases))
+    def attach_diffusion(self, timesteps, gamma_table, norm_values, norm_biases, no_com_projection=False):
+        self._cfg.update(timesteps=int(timesteps), norm_values=tuple(norm_values), norm_biases=tuple(norm_biases),
+                         no_com_projection=bool(no_com_projection))
         self._gamma = np.asarray(gamma_table, dtype=np.float32)
         self._handle, self._weights_sig = None, None
 

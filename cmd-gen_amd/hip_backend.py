@@ -22,7 +22,7 @@ class CmdgenError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'phar_nf', 'residue_nf', 'joint_nf', 'hidden_nf', 'n_layers', 'inv_sublayers',
-        'attention', 'tanh', 'condition_time', 'timesteps')] + \
+        'attention', 'tanh', 'condition_time', 'timesteps', 'no_com_projection')] + \
         [(n, C.c_float) for n in ('edge_cutoff', 'norm_constant', 'normalization_factor',
                                   'coords_range', 'norm_x', 'norm_h', 'bias_h')]
 
@@ -107,6 +107,7 @@ class Handle:
         c.attention, c.tanh = int(bool(cfg['attention'])), int(bool(cfg['tanh']))
         c.condition_time = int(bool(cfg.get('condition_time', True)))
         c.timesteps = int(cfg['timesteps'])
+        c.no_com_projection = int(bool(cfg.get('no_com_projection', False)))
         ec = cfg.get('edge_cutoff')
         c.edge_cutoff = -1.0 if ec is None else float(ec)
         c.norm_constant = float(cfg['norm_constant'])

@@ -45,8 +45,9 @@ class PharPocketDDPM(nn.Module):
         ddpm_models = {'joint': EnVariationalDiffusion, 'pocket_conditioning': ConditionalDDPM,
                        'pocket_conditioning_simple': SimpleConditionalDDPM}
         assert mode in ddpm_models
-        if mode != 'pocket_conditioning':
-            raise NotImplementedError(f"mode '{mode}' is not built yet; all shipped configs use 'pocket_conditioning'")
+        if mode == 'joint':
+            raise NotImplementedError("mode 'joint' (EnVariationalDiffusion sample/inpaint) is not built yet; all shipped "
+                                      "configs use 'pocket_conditioning'")
         self.mode = mode
         assert pocket_representation in {'CA', 'full-atom'}
         self.pocket_representation = pocket_representation
@@ -245,7 +246,7 @@ class PharPocketDDPM(nn.Module):
         pocket_com_before = _scatter_mean(pocket['x'], pocket['mask'], n_samples)
         if num_nodes_phar is None:
             num_nodes_phar = self.ddpm.size_distribution.sample_conditional(n1=None, n2=pocket['size'])
-        if type(self.ddpm) == ConditionalDDPM:
+        if isinstance(self.ddpm, ConditionalDDPM):
             xh_phar, xh_pocket, phar_mask, pocket_mask = self.ddpm.sample_given_pocket(
                 pocket, num_nodes_phar, timesteps=timesteps, **sampler_kw)
         else:

@@ -51,6 +51,7 @@ class ModelConfig:
     coords_range: float = 15.0     # egnn_new.py:161 default; quirk Q3: never divided by n_layers
     condition_time: bool = True
     update_pocket_coords: bool = False   # conditional mode (lightning_modules.py:125)
+    no_com_projection: bool = False      # True: SimpleConditionalDDPM (conditional_model.py:481-525)
     # diffusion
     timesteps: int = 500
     noise_schedule: str = 'polynomial_2'

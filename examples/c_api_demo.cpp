@@ -19,7 +19,7 @@
 int main() {
     cmdgen_config cfg{};
     cfg.phar_nf = 8; cfg.residue_nf = 20; cfg.joint_nf = 32; cfg.hidden_nf = 256; cfg.n_layers = 5; cfg.inv_sublayers = 1;
-    cfg.attention = 1; cfg.tanh = 1; cfg.condition_time = 1; cfg.timesteps = 500; cfg.edge_cutoff = 6.0f;
+    cfg.attention = 1; cfg.tanh = 1; cfg.condition_time = 1; cfg.timesteps = 500; cfg.no_com_projection = 0; cfg.edge_cutoff = 6.0f;
     cfg.norm_constant = 1.0f; cfg.normalization_factor = 100.0f; cfg.coords_range = 15.0f;
     cfg.norm_x = 1.0f; cfg.norm_h = 4.0f; cfg.bias_h = 0.0f;
     cmdgen_handle* h = nullptr;

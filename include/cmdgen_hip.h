@@ -58,6 +58,8 @@ typedef struct cmdgen_config {
     int32_t tanh;                  /* 1  */
     int32_t condition_time;        /* 1  */
     int32_t timesteps;             /* T of the gamma table (500) */
+    int32_t no_com_projection;     /* 0; 1 = SimpleConditionalDDPM (conditional_model.py:481-525): pocket centred once,
+                                      no centre-of-mass projection of the samples */
     float   edge_cutoff;           /* 6.0; < 0 means no cutoff (complete graph per sample) */
     float   norm_constant;         /* 1  */
     float   normalization_factor;  /* 100 ('sum' aggregation only) */

@@ -237,8 +237,14 @@ def dynamics_forward(p, cfg, xh_phars, xh_residues, t, mask_phars, mask_residues
 # --------------------------------------------------------------------------
 # ConditionalDDPM sampler  (conditional_model.py)
 # --------------------------------------------------------------------------
+_SIMPLE = [False]      # SimpleConditionalDDPM (conditional_model.py:481-525): remove_mean_batch is the identity
+
+
 def remove_mean_batch(x_phar, x_pocket, phar_idx, pocket_idx):
-    """conditional_model.py:467-475: subtract the PHAR centre of mass from both (Q7)."""
+    """conditional_model.py:467-475: subtract the PHAR centre of mass from both (Q7); identity in the
+    simple variant (:499-502)."""
+    if _SIMPLE[0]:
+        return x_phar, x_pocket
     mean = scatter_mean(x_phar, phar_idx)
     return x_phar - mean[phar_idx], x_pocket - mean[pocket_idx]
 
@@ -291,6 +297,12 @@ def sample_given_pocket(p, cfg, pocket, num_nodes_phar, timesteps=None,
     timesteps = T if timesteps is None else timesteps
     draw = noise if noise is not None else (lambda shape: torch.randn(shape))
     n_samples = len(pocket['size'])
+    simple = bool(cfg.get('no_com_projection', False))
+    _SIMPLE[0] = simple
+    checks = checks and not simple                                         # assert_mean_zero_with_mask is a no-op (:503-505)
+    if simple:                                                             # subtract the pocket COM first (:512-521)
+        pocket = dict(pocket)
+        pocket['x'] = pocket['x'].to(FLOAT) - scatter_mean(pocket['x'].to(FLOAT), pocket['mask'].to(INT))[pocket['mask'].to(INT)]
     # normalize, en_diffusion.py:874-889
     px = pocket['x'].to(FLOAT) / nv[0]
     ph = (pocket['one_hot'].float() - nb[1]) / nv[1]
@@ -346,6 +358,7 @@ def sample_given_pocket(p, cfg, pocket, num_nodes_phar, timesteps=None,
     max_cog = scatter_add(x_phar, phar_mask).abs().max().item()            # :451-457
     if max_cog > 5e-2:
         x_phar, x_pocket = remove_mean_batch(x_phar, x_pocket, phar_mask, pmask)
+    _SIMPLE[0] = False
     out_phar = torch.cat([x_phar, h_phar.to(FLOAT)], dim=1)   # written into a float frame buffer :460
     out_pocket = torch.cat([x_pocket, h_pocket], dim=1)
     if return_chain:
@@ -390,12 +403,19 @@ def ddpm_forward(p, cfg, phar, pocket, t_int, eps_draws, training, histogram):
     draws = iter(eps_draws)
     B = len(phar['size'])
     pm, qm = phar['mask'].to(INT), pocket['mask'].to(INT)
+    simple = bool(cfg.get('no_com_projection', False))
+    _SIMPLE[0] = simple
+    if simple:                                                             # SimpleConditionalDDPM.forward :507-516
+        com = scatter_mean(pocket['x'].to(FLOAT), qm)
+        phar, pocket = dict(phar), dict(pocket)
+        phar['x'] = phar['x'].to(FLOAT) - com[pm]
+        pocket['x'] = pocket['x'].to(FLOAT) - com[qm]
     x_l = phar['x'].to(FLOAT) / nv[0]
     h_l = (phar['one_hot'].float() - nb[1]) / nv[1]
     x_p = pocket['x'].to(FLOAT) / nv[0]
     h_p = (pocket['one_hot'].float() - nb[1]) / nv[1]
     n_l = phar['size']
-    sub_d = (n_l - 1) * nd                                                   # subspace_dimensionality :908-911
+    sub_d = n_l * nd if simple else (n_l - 1) * nd                           # subspace_dimensionality :908-911 / :492-494
     delta_log_px = -sub_d * np.log(nv[0])                                    # :193-195
     t_int = t_int.float()
     s_int = t_int - 1
@@ -448,6 +468,7 @@ def ddpm_forward(p, cfg, phar, pocket, t_int, eps_draws, training, histogram):
         lpx, lph = l0_terms(z_0, eps_0, net0, gamma_0)
         loss_0_x, loss_0_h = -lpx, -lph
     log_pN = n1_given_n2_log_prob(histogram, n_l.tolist(), pocket['size'].tolist())
+    _SIMPLE[0] = False
     info = {'eps_hat_phar_x': scatter_mean(net[:, :nd].abs().mean(1), pm, B).mean(),
             'eps_hat_phar_h': scatter_mean(net[:, nd:].abs().mean(1), pm, B).mean()}
     return (delta_log_px, error_t, torch.tensor(0.0), snr_w, loss_0_x, torch.tensor(0.0), loss_0_h, neg_log_const,

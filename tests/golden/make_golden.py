@@ -110,7 +110,7 @@ def import_reference():
 
 
 # ------------------------------------------------------------------ builders
-def build_reference_ddpm(mods, cfg: ModelConfig, seed, coord_gain, histogram):
+def build_reference_ddpm(mods, cfg: ModelConfig, seed, coord_gain, histogram, simple=False):
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):      # reference prints the tables
         dyn = mods['dynamics'].EGNNDynamics(
@@ -121,7 +121,8 @@ def build_reference_ddpm(mods, cfg: ModelConfig, seed, coord_gain, histogram):
             normalization_factor=cfg.normalization_factor,
             aggregation_method=cfg.aggregation_method, edge_cutoff=cfg.edge_cutoff,
             update_pocket_coords=False)
-        ddpm = mods['conditional_model'].ConditionalDDPM(
+        cls = mods['conditional_model'].SimpleConditionalDDPM if simple else mods['conditional_model'].ConditionalDDPM
+        ddpm = cls(
             dynamics=dyn, phar_nf=cfg.phar_nf, residue_nf=cfg.residue_nf, n_dims=3,
             timesteps=cfg.timesteps, noise_schedule=cfg.noise_schedule,
             noise_precision=cfg.noise_precision, loss_type='l2',
@@ -287,10 +288,11 @@ def main():
         ('ca_h256_K50', 'CA', 256, 5, 2, 50, 1e-3, 23, False),
         ('ca_h256_K5_gain1', 'CA', 256, 5, 3, 5, 1.0, 24, True),
         ('fa_h256_K5', 'full-atom', 256, 5, 2, 5, 1e-3, 25, False),
+        ('simple_h64_K5', 'CA', 64, 2, 3, 5, 1.0, 26, True),      # SimpleConditionalDDPM (no COM projection)
     ]
     for name, rep, H, L, B, K, gain, seed, ragged in chain_cases:
         cfg = ModelConfig(hidden_nf=H, n_layers=L, residue_nf=20 if rep == 'CA' else 11, timesteps=500)
-        ddpm, _ = build_reference_ddpm(mods, cfg, seed, gain, HIST)
+        ddpm, _ = build_reference_ddpm(mods, cfg, seed, gain, HIST, simple=name.startswith('simple'))
         first, nseed = 100 * seed, seed
         while True:
             if rep == 'full-atom':

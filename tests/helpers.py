@@ -19,8 +19,8 @@ def cases_of(g):
     return sorted({k.split('/')[0] for k in g if '/' in k})
 
 
-def cfg_from_meta(H, L, R, timesteps=500):
-    return ModelConfig(hidden_nf=int(H), n_layers=int(L), residue_nf=int(R), timesteps=timesteps)
+def cfg_from_meta(H, L, R, timesteps=500, simple=False):
+    return ModelConfig(hidden_nf=int(H), n_layers=int(L), residue_nf=int(R), timesteps=timesteps, no_com_projection=simple)
 
 
 def masks_from_sizes(pocket_size, num_nodes_phar):
@@ -42,7 +42,7 @@ def dynamics_case(g, name):
 
 def chain_case(g, name):
     H, L, B, R, seed, K, gain1, first = [int(v) for v in g[name + '/meta']]
-    cfg = cfg_from_meta(H, L, R)
+    cfg = cfg_from_meta(H, L, R, simple=name.startswith('simple'))
     sd = make_state_dict(cfg, seed=seed, coord_gain=1.0 if gain1 else 1e-3)
     rep = 'CA' if R == 20 else 'full-atom'
     ragged = bool(int(g[name + '/ragged']))

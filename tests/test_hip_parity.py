@@ -629,3 +629,31 @@ def test_fuzz_hyperparameters_and_layouts(seed):
     assert float(np.abs(got.cpu().numpy() - want).max()) <= tol, (cfg, B)
     assert float(np.abs(got_q.cpu().numpy() - want_q).max()) <= 5e-5 * max(1.0, float(np.abs(want_q).max()))
     h.close()
+
+
+def test_simple_conditional_mode_python_api():
+    """mode 'pocket_conditioning_simple' (SimpleConditionalDDPM, conditional_model.py:481-525) through the Python
+    mirror, against the reference's golden chain: no COM projection, pocket centred once."""
+    from cmdgen_amd.equivariant_diffusion.dynamics import EGNNDynamics
+    from cmdgen_amd.equivariant_diffusion.conditional_model import SimpleConditionalDDPM
+    name = 'simple_h64_K5'
+    cfg, sd, pb, K = chain_case(G4, name)
+    dyn = EGNNDynamics(phar_nf=8, residue_nf=20, n_dims=3, joint_nf=32, hidden_nf=cfg.hidden_nf, n_layers=cfg.n_layers,
+                       attention=True, tanh=True, norm_constant=1, inv_sublayers=1, normalization_factor=100,
+                       aggregation_method='sum', edge_cutoff=6.0, update_pocket_coords=False)
+    ddpm = SimpleConditionalDDPM(dynamics=dyn, phar_nf=8, residue_nf=20, n_dims=3, timesteps=500,
+                                 noise_schedule='polynomial_2', noise_precision=1e-5, loss_type='l2', norm_values=[1, 4],
+                                 size_histogram=np.ones((30, 70)))
+    ddpm.load_state_dict({k[len('ddpm.'):]: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    ddpm = ddpm.cuda()
+    pocket = {'x': dev(pb.x), 'one_hot': dev(pb.one_hot), 'size': dev(pb.size), 'mask': dev(pb.mask)}
+    xh_phar, xh_pocket, pm, _ = ddpm.sample_given_pocket(pocket, torch.from_numpy(pb.num_nodes_phar), timesteps=K,
+                                                         noise=dev(G4[name + '/noise']))
+    want, wp = G4[name + '/xh_phar'], G4[name + '/xh_pocket']
+    assert rms(xh_phar[:, :3].cpu().numpy(), want[:, :3]) <= 1e-4 * max(1.0, float(np.abs(want[:, :3]).max()))
+    assert np.array_equal(xh_phar[:, 3:].cpu().numpy(), want[:, 3:])
+    assert rms(xh_pocket.cpu().numpy(), wp) <= 1e-4 * max(1.0, float(np.abs(wp).max()))
+    # the pocket is only centred, never translated by the samples
+    for b in range(len(pb.size)):
+        assert np.abs(xh_pocket[:, :3].cpu().numpy()[pb.mask == b].mean(0)).max() < 1e-3
+    assert ddpm.subspace_dimensionality(torch.tensor([5])).item() == 15
