@@ -657,3 +657,56 @@ def test_simple_conditional_mode_python_api():
     for b in range(len(pb.size)):
         assert np.abs(xh_pocket[:, :3].cpu().numpy()[pb.mask == b].mean(0)).max() < 1e-3
     assert ddpm.subspace_dimensionality(torch.tensor([5])).item() == 15
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_fuzz_chains(seed):
+    """Randomised sampler settings (normalisation factors, strided step counts, T, ragged layouts, with and
+    without the COM projection) on injected noise: HIP chain vs oracle chain, per-step states included."""
+    from oracle import ref_cpu
+    rng = np.random.Generator(np.random.PCG64(777 + seed))
+    T = int(rng.choice([100, 500, 1000]))
+    cfg = ModelConfig(hidden_nf=int(rng.choice([64, 128])), n_layers=int(rng.integers(1, 4)), timesteps=T,
+                      norm_values=(float(rng.choice([1.0, 2.0])), float(rng.choice([1.0, 4.0, 8.0]))),
+                      no_com_projection=bool(rng.integers(0, 2)), phar_nf=int(rng.integers(4, 10)))
+    sd = make_state_dict(cfg, seed=300 + seed, coord_gain=float(rng.choice([1e-3, 1.0])))
+    K = int(rng.choice([1, 3, 7]))
+    p = ref_cpu.to_torch_params(sd)
+    for attempt in range(6):
+        pb = make_pockets(int(rng.integers(1, 6)), 'CA', ragged=True, first_index=20000 + 100 * seed + attempt)
+        nph = rng.integers(1, 12, size=len(pb.size))
+        nl = int(nph.sum())
+        noise = torch.randn((K + 2, nl, 3 + cfg.phar_nf), generator=torch.Generator().manual_seed(seed * 10 + attempt))
+        margins = []
+        orig = ref_cpu.get_edges
+
+        def watched(mask, x, cutoff):
+            margins.append(min_cutoff_margin(x.numpy(), mask.numpy(), cutoff))
+            return orig(mask, x, cutoff)
+        ref_cpu.get_edges = watched
+        try:
+            tape = iter(noise)
+            pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot),
+                      'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
+            with torch.no_grad():
+                want, want_p, _, _, chain = ref_cpu.sample_given_pocket(p, cfg.as_dict(), pocket, nph, timesteps=K,
+                                                                       noise=lambda shape: next(tape), return_chain=True)
+        finally:
+            ref_cpu.get_edges = orig
+        if min(margins) > 2e-3:
+            break
+    else:
+        pytest.skip('no seed with a safe cutoff margin')
+    h = hip_backend.Handle(cfg.as_dict(), 0)
+    h.load_state_dict(sd)
+    h.set_layout(nph, pb.size)
+    got, got_p, z_steps = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=noise.cuda(), want_steps=True,
+                                         use_graph=bool(seed & 1))          # library-side schedule table
+    want = want.numpy()
+    for k in range(K):
+        zs = chain[k + 1].numpy()
+        assert float(np.abs(z_steps[k].cpu().numpy() - zs).max()) <= 1e-4 * max(1.0, float(np.abs(zs).max())), k
+    assert rms(got[:, :3].cpu().numpy(), want[:, :3]) <= 1e-4 * max(1.0, float(np.abs(want[:, :3]).max()))
+    assert np.array_equal(got[:, 3:].cpu().numpy(), want[:, 3:])
+    assert rms(got_p.cpu().numpy(), want_p.numpy()) <= 1e-4 * max(1.0, float(np.abs(want_p.numpy()).max()))
+    h.close()
