@@ -168,6 +168,35 @@ def main():
             z = out[0].clone(); z[:, 3:] = 0
             kt = h.profile_evaluation(z.contiguous(), torch.cat([out[1][:, :3], out[1][:, 3:] / cfg.norm_values[1]], 1).contiguous(),
                                       torch.full((B,), 0.5, device=dev))
+        # ---- steady-state micro-benchmark: one evaluation at the geometry a TRAINED model holds -
+        # phar points uniform in a 5 A ball at the pocket centre (random-init weights let the chain drift away,
+        # which roughly halves the edge count).  Eager launches, 30 repetitions.
+        with torch.cuda.stream(stream):
+            rng = np.random.Generator(np.random.PCG64(12345 + rank))
+            nl_tot = int(pb.num_nodes_phar.sum())
+            pm_np = np.repeat(np.arange(B), pb.num_nodes_phar)
+            com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(B)])
+            v = rng.normal(size=(nl_tot, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+            xin = (com[pm_np] + v * 5.0 * np.cbrt(rng.uniform(size=(nl_tot, 1)))).astype(np.float32)
+            xh_in = torch.from_numpy(np.concatenate([xin, rng.normal(size=(nl_tot, cfg.phar_nf)).astype(np.float32)], 1)).to(dev)
+            xq_in = torch.from_numpy(np.concatenate([pb.x, pb.one_hot / cfg.norm_values[1]], 1).astype(np.float32)).to(dev)
+            t_in = torch.full((B,), 0.5, device=dev)
+            for _ in range(3):
+                h.dynamics_forward(xh_in, xq_in, t_in, want_pocket=False)
+            torch.cuda.synchronize(dev)
+            h.reset_counters()
+            t1 = time.perf_counter()
+            reps = 30
+            for _ in range(reps):
+                h.dynamics_forward(xh_in, xq_in, t_in, want_pocket=False)
+            torch.cuda.synchronize(dev)
+            dt_micro = (time.perf_counter() - t1) / reps
+            mc = h.counters()
+        steady = {'us_per_evaluation': 1e6 * dt_micro, 'pocket_evaluations_per_s': B / dt_micro,
+                  'edges_per_pocket': mc['edges'] / max(mc['evaluations'], 1) / B,
+                  'coord_edges_per_pocket': mc['edges_phar'] / max(mc['evaluations'], 1) / B,
+                  'alg_tflops': (L * (2.0 * (H * H + H) * (mc['edges'] + mc['edges_phar']) + 917504.0 * (H / 256.0) ** 2 * mc['nodes'])
+                                 + 33792.0 * (H / 256.0) * mc['nodes']) / max(mc['evaluations'], 1) / dt_micro / 1e12}
         ev = max(pc['evaluations'], 1)
         units = {'edge_msg': pc['edges'] / ev, 'node': pc['nodes'] / ev, 'edge_coord': pc['edges_phar'] / ev}
         flop_unit = {'edge_msg': 2.0 * (H * H + H), 'node': 14.0 * H * H, 'edge_coord': 2.0 * (H * H + H)}
@@ -215,6 +244,7 @@ def main():
                 'whole_step_alg_tflops': f_alg / elapsed / 1e12,
                 'chain_status': st,
                 'kernel_ms_one_evaluation': kt,
+                'steady_state_evaluation': steady,
             },
             'roofline': {
                 'bound': 'mfma', 'kernel': kname[dom],
