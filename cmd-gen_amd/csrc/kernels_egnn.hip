@@ -377,6 +377,22 @@ __device__ __forceinline__ float tile_row_dot(const float* buf, const float* __r
     return s;
 }
 
+// XCD-aware tile walk for the persistent-style edge kernels (cdna guide T1): workgroups are dealt
+// round-robin over the 8 XCDs (blockIdx % 8 names the XCD group), each XCD has its own 4 MB L2.
+// Giving every XCD group one contiguous range of tiles keeps the P/Q rows it gathers (edges are sorted
+// by sample and receiver) inside that L2 instead of spreading every sample over all eight.
+// Placement only affects speed, never results.  Returns the k-th tile of this workgroup or -1.
+__device__ __forceinline__ int xcd_tile(int k, int ntiles) {
+    const int g = blockIdx.x & 7, nb = gridDim.x;
+    const int wg_in_g = blockIdx.x >> 3;
+    const int wgs_in_g = (nb - g + 7) >> 3;                 // workgroups whose blockIdx % 8 == g
+    const int per_g = (ntiles + 7) >> 3;                    // tiles per XCD group (last group may be short)
+    const int t = wg_in_g + k * wgs_in_g;
+    if (wgs_in_g == 0 || t >= per_g) return -1;
+    const int tile = g * per_g + t;
+    return tile < ntiles ? tile : -1;
+}
+
 // ------------------------------------------------------------------------------------
 // k_edge_msg: GCL.edge_model + attention gate + segment sum by receiver for MT-edge tiles
 // of the compact list.  Persistent-style grid: tiles are taken round-robin until the
@@ -392,8 +408,8 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
     const int ntiles = (E + MT - 1) / MT;
     const FragPtr fw = frag_ptr<MT>(lw.W2, H / 8, 0, wave);
     BCarry<MT> carry;
-    if (blockIdx.x < ntiles) gemm_prefetch<MT>(fw, carry);   // refilled for the next tile by each GEMM's last iteration
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (xcd_tile(0, ntiles) >= 0) gemm_prefetch<MT>(fw, carry);   // refilled for the next tile by each GEMM's last iteration
+    for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
         if (tid < MT) {
@@ -581,8 +597,8 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
     const int ntiles = (E + MT - 1) / MT;
     const FragPtr fw = frag_ptr<MT>(lw.W7, H / 8, 0, wave);
     BCarry<MT> carry;
-    if (blockIdx.x < ntiles) gemm_prefetch<MT>(fw, carry);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (xcd_tile(0, ntiles) >= 0) gemm_prefetch<MT>(fw, carry);
+    for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
         if (tid < MT) {
