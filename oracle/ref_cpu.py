@@ -367,6 +367,219 @@ def sample_given_pocket(p, cfg, pocket, num_nodes_phar, timesteps=None,
 
 
 # --------------------------------------------------------------------------
+# EnVariationalDiffusion: joint sampler and RePaint inpainting  (en_diffusion.py)
+# (mode 'joint': pocket nodes are noised and denoised too; COM over ALL nodes of a sample;
+#  the denoiser runs with update_pocket_coords=True)
+# --------------------------------------------------------------------------
+def combined_noise(draw, phar_mask, pocket_mask, nd, pnf, rnf):
+    """sample_combined_position_feature_noise, en_diffusion.py:555-574: three draws in this order -
+    x for all nodes [Nl+Np, 3] (then COM-projected, :927-937), h_phar [Nl, P], h_pocket [Np, R]."""
+    nl = len(phar_mask)
+    comb = torch.cat((phar_mask, pocket_mask))
+    zx = draw((nl + len(pocket_mask), nd))
+    zx = zx - scatter_mean(zx, comb)[comb]
+    zh_phar = draw((nl, pnf))
+    zh_pocket = draw((len(pocket_mask), rnf))
+    return torch.cat([zx[:nl], zh_phar], dim=1), torch.cat([zx[nl:], zh_pocket], dim=1)
+
+
+def _remove_mean_all(z_phar, z_pocket, phar_mask, pocket_mask, nd):
+    """the cat / remove_mean_batch / split idiom of en_diffusion.py:486-495, :542-551."""
+    comb = torch.cat((phar_mask, pocket_mask))
+    zx = torch.cat((z_phar[:, :nd], z_pocket[:, :nd]), dim=0)
+    zx = zx - scatter_mean(zx, comb)[comb]
+    nl = len(phar_mask)
+    return torch.cat((zx[:nl], z_phar[:, nd:]), dim=1), torch.cat((zx[nl:], z_pocket[:, nd:]), dim=1)
+
+
+def joint_sample_p_zs_given_zt(p, cfg, s, t, zt_phar, zt_pocket, phar_mask, pocket_mask, draw, checks=True):
+    """EnVariationalDiffusion.sample_p_zs_given_zt, en_diffusion.py:499-553."""
+    T, nd = cfg['timesteps'], cfg['n_dims']
+    table = p['gamma.gamma']
+    gamma_s, gamma_t = gamma_lookup(table, s, T), gamma_lookup(table, t, T)
+    sigma2_ts, sigma_ts, alpha_ts = sigma_and_alpha_t_given_s(gamma_t, gamma_s)
+    sigma_s, sigma_t = sigma_of(gamma_s), sigma_of(gamma_t)
+    eps_phar, eps_pocket = dynamics_forward(p, cfg, zt_phar, zt_pocket, t, phar_mask, pocket_mask)
+    comb = torch.cat((phar_mask, pocket_mask))
+    if checks:
+        assert_mean_zero_with_mask(torch.cat((zt_phar[:, :nd], zt_pocket[:, :nd]), dim=0), comb)
+        assert_mean_zero_with_mask(torch.cat((eps_phar[:, :nd], eps_pocket[:, :nd]), dim=0), comb)
+    mu_phar = zt_phar / alpha_ts[phar_mask] - (sigma2_ts / alpha_ts / sigma_t)[phar_mask] * eps_phar
+    mu_pocket = zt_pocket / alpha_ts[pocket_mask] - (sigma2_ts / alpha_ts / sigma_t)[pocket_mask] * eps_pocket
+    sigma = sigma_ts * sigma_s / sigma_t
+    e_phar, e_pocket = combined_noise(draw, phar_mask, pocket_mask, nd, cfg['phar_nf'], cfg['residue_nf'])
+    zs_phar = mu_phar + sigma[phar_mask] * e_phar                          # sample_normal :286-296
+    zs_pocket = mu_pocket + sigma[pocket_mask] * e_pocket
+    return _remove_mean_all(zs_phar, zs_pocket, phar_mask, pocket_mask, nd)
+
+
+def joint_sample_p_zt_given_zs(cfg, zs_phar, zs_pocket, phar_mask, pocket_mask, gamma_t, gamma_s, draw):
+    """EnVariationalDiffusion.sample_p_zt_given_zs (the RePaint re-noising step), en_diffusion.py:475-497."""
+    nd = cfg['n_dims']
+    _, sigma_ts, alpha_ts = sigma_and_alpha_t_given_s(gamma_t, gamma_s)
+    mu_phar = alpha_ts[phar_mask] * zs_phar
+    mu_pocket = alpha_ts[pocket_mask] * zs_pocket
+    e_phar, e_pocket = combined_noise(draw, phar_mask, pocket_mask, nd, cfg['phar_nf'], cfg['residue_nf'])
+    zt_phar = mu_phar + sigma_ts[phar_mask] * e_phar
+    zt_pocket = mu_pocket + sigma_ts[pocket_mask] * e_pocket
+    return _remove_mean_all(zt_phar, zt_pocket, phar_mask, pocket_mask, nd)
+
+
+def joint_sample_p_xh_given_z0(p, cfg, z0_phar, z0_pocket, phar_mask, pocket_mask, n_samples, draw):
+    """EnVariationalDiffusion.sample_p_xh_given_z0, en_diffusion.py:259-284 (no COM projection here)."""
+    T, nd = cfg['timesteps'], cfg['n_dims']
+    nv, nb = cfg['norm_values'], cfg['norm_biases']
+    t_zeros = torch.zeros((n_samples, 1))
+    gamma_0 = gamma_lookup(p['gamma.gamma'], t_zeros, T)
+    sigma_x = torch.exp(-(-0.5 * gamma_0))
+    net_phar, net_pocket = dynamics_forward(p, cfg, z0_phar, z0_pocket, t_zeros, phar_mask, pocket_mask)
+    sigma_0, alpha_0 = sigma_of(gamma_0), alpha_of(gamma_0)
+    mu_phar = 1. / alpha_0[phar_mask] * (z0_phar - sigma_0[phar_mask] * net_phar)
+    mu_pocket = 1. / alpha_0[pocket_mask] * (z0_pocket - sigma_0[pocket_mask] * net_pocket)
+    e_phar, e_pocket = combined_noise(draw, phar_mask, pocket_mask, nd, cfg['phar_nf'], cfg['residue_nf'])
+    xh_phar = mu_phar + sigma_x[phar_mask] * e_phar
+    xh_pocket = mu_pocket + sigma_x[pocket_mask] * e_pocket
+    x_phar, h_phar = xh_phar[:, :nd] * nv[0], z0_phar[:, nd:] * nv[1] + nb[1]
+    x_pocket, h_pocket = xh_pocket[:, :nd] * nv[0], z0_pocket[:, nd:] * nv[1] + nb[1]
+    h_phar = F.one_hot(torch.argmax(h_phar, dim=1), cfg['phar_nf'])
+    h_pocket = F.one_hot(torch.argmax(h_pocket, dim=1), cfg['residue_nf'])
+    return x_phar, h_phar, x_pocket, h_pocket
+
+
+def _joint_finish(x_phar, h_phar, x_pocket, h_pocket, phar_mask, pocket_mask, checks):
+    """tail shared by sample / inpaint, en_diffusion.py:626-647 / :808-831 (return_frames=1)."""
+    comb = torch.cat((phar_mask, pocket_mask))
+    if checks:
+        assert_mean_zero_with_mask(torch.cat((x_phar, x_pocket), dim=0), comb)
+    x = torch.cat((x_phar, x_pocket))
+    max_cog = scatter_add(x, comb).abs().max().item()
+    if max_cog > 5e-2:
+        x = x - scatter_mean(x, comb)[comb]
+        x_phar, x_pocket = x[:len(x_phar)], x[len(x_phar):]
+    return (torch.cat([x_phar, h_phar.to(FLOAT)], dim=1), torch.cat([x_pocket, h_pocket.to(FLOAT)], dim=1),
+            phar_mask, pocket_mask)
+
+
+def joint_sample(p, cfg, n_samples, num_nodes_phar, num_nodes_pocket, timesteps=None, noise=None,
+                 return_chain=False, checks=True):
+    """EnVariationalDiffusion.sample, en_diffusion.py:576-647 (return_frames=1)."""
+    T, nd = cfg['timesteps'], cfg['n_dims']
+    assert cfg['update_pocket_coords']
+    timesteps = T if timesteps is None else timesteps
+    draw = noise if noise is not None else (lambda shape: torch.randn(shape))
+    phar_mask = torch.repeat_interleave(torch.arange(n_samples), torch.as_tensor(num_nodes_phar).to(INT))
+    pocket_mask = torch.repeat_interleave(torch.arange(n_samples), torch.as_tensor(num_nodes_pocket).to(INT))
+    z_phar, z_pocket = combined_noise(draw, phar_mask, pocket_mask, nd, cfg['phar_nf'], cfg['residue_nf'])
+    chain = []
+    for s in reversed(range(0, timesteps)):
+        s_array = torch.full((n_samples, 1), fill_value=s)
+        t_array = s_array + 1
+        s_array = s_array / timesteps
+        t_array = t_array / timesteps
+        z_phar, z_pocket = joint_sample_p_zs_given_zt(p, cfg, s_array, t_array, z_phar, z_pocket, phar_mask,
+                                                      pocket_mask, draw, checks)
+        if return_chain:
+            chain.append((z_phar.clone(), z_pocket.clone()))
+    out = joint_sample_p_xh_given_z0(p, cfg, z_phar, z_pocket, phar_mask, pocket_mask, n_samples, draw)
+    res = _joint_finish(*out, phar_mask, pocket_mask, checks)
+    return res + (chain,) if return_chain else res
+
+
+def get_repaint_schedule(resamplings, jump_length, timesteps):
+    """en_diffusion.py:649-670: how many denoising steps to run before each jump back."""
+    sched, curr_t = [], 0
+    while curr_t < timesteps:
+        if curr_t + jump_length < timesteps:
+            if len(sched) > 0:
+                sched[-1] += jump_length
+                sched.extend([jump_length] * (resamplings - 1))
+            else:
+                sched.extend([jump_length] * resamplings)
+            curr_t += jump_length
+        else:
+            residual = timesteps - curr_t
+            if len(sched) > 0:
+                sched[-1] += residual
+            else:
+                sched.append(residual)
+            curr_t += residual
+    return list(reversed(sched))
+
+
+def joint_inpaint(p, cfg, phar, pocket, phar_fixed, pocket_fixed, resamplings=1, jump_length=1,
+                  timesteps=None, noise=None, return_chain=False, checks=True):
+    """EnVariationalDiffusion.inpaint, en_diffusion.py:672-831 (return_frames=1).
+
+    Quirk Q14: the inputs are NOT normalised here (no self.normalize call, unlike forward /
+    sample_given_pocket): the known part is built from raw x and raw one_hot."""
+    T, nd = cfg['timesteps'], cfg['n_dims']
+    assert cfg['update_pocket_coords']
+    table = p['gamma.gamma']
+    timesteps = T if timesteps is None else timesteps
+    draw = noise if noise is not None else (lambda shape: torch.randn(shape))
+    phar_fixed = torch.as_tensor(phar_fixed).to(FLOAT)
+    pocket_fixed = torch.as_tensor(pocket_fixed).to(FLOAT)
+    if phar_fixed.dim() == 1:
+        phar_fixed = phar_fixed.unsqueeze(1)
+    if pocket_fixed.dim() == 1:
+        pocket_fixed = pocket_fixed.unsqueeze(1)
+    pm, qm = phar['mask'].to(INT), pocket['mask'].to(INT)
+    n_samples = len(phar['size'])
+    comb = torch.cat((pm, qm))
+    xh0_phar = torch.cat([phar['x'].to(FLOAT), phar['one_hot'].to(FLOAT)], dim=1)
+    xh0_pocket = torch.cat([pocket['x'].to(FLOAT), pocket['one_hot'].to(FLOAT)], dim=1)
+    fp, fq = phar_fixed.bool().view(-1), pocket_fixed.bool().view(-1)
+    known_idx = torch.cat((pm[fp], qm[fq]))
+
+    def com_known(xp, xq):
+        return scatter_mean(torch.cat((xp[fp], xq[fq])), known_idx, n_samples)
+
+    mean_known = com_known(xh0_phar[:, :nd], xh0_pocket[:, :nd])                     # :703-713
+    xh0_phar[:, :nd] = xh0_phar[:, :nd] - mean_known[pm]
+    xh0_pocket[:, :nd] = xh0_pocket[:, :nd] - mean_known[qm]
+    z_phar, z_pocket = combined_noise(draw, pm, qm, nd, cfg['phar_nf'], cfg['residue_nf'])
+    schedule = get_repaint_schedule(resamplings, jump_length, timesteps)
+    chain = []
+    s = timesteps - 1
+    for i, n_denoise_steps in enumerate(schedule):
+        for j in range(n_denoise_steps):
+            s_array = torch.full((n_samples, 1), fill_value=s)
+            t_array = s_array + 1
+            s_array = s_array / timesteps
+            t_array = t_array / timesteps
+            gamma_s = gamma_lookup(table, s_array, T)
+            # known nodes from the input: noised_representation :298-313 (its own combined draw, taken FIRST)
+            alpha_s, sigma_s = alpha_of(gamma_s), sigma_of(gamma_s)
+            e_phar, e_pocket = combined_noise(draw, pm, qm, nd, cfg['phar_nf'], cfg['residue_nf'])
+            zk_phar = alpha_s[pm] * xh0_phar + sigma_s[pm] * e_phar
+            zk_pocket = alpha_s[qm] * xh0_pocket + sigma_s[qm] * e_pocket
+            zu_phar, zu_pocket = joint_sample_p_zs_given_zt(p, cfg, s_array, t_array, z_phar, z_pocket, pm, qm,
+                                                            draw, checks)
+            com_noised = com_known(zk_phar[:, :nd], zk_pocket[:, :nd])                # :757-776
+            com_denoised = com_known(zu_phar[:, :nd], zu_pocket[:, :nd])
+            zk_phar[:, :nd] = zk_phar[:, :nd] + (com_denoised - com_noised)[pm]
+            zk_pocket[:, :nd] = zk_pocket[:, :nd] + (com_denoised - com_noised)[qm]
+            z_phar = zk_phar * phar_fixed + zu_phar * (1 - phar_fixed)               # :779-782
+            z_pocket = zk_pocket * pocket_fixed + zu_pocket * (1 - pocket_fixed)
+            if checks:
+                assert_mean_zero_with_mask(torch.cat((z_phar[:, :nd], z_pocket[:, :nd]), dim=0), comb)
+            if return_chain:
+                chain.append((z_phar.clone(), z_pocket.clone()))
+            if j == n_denoise_steps - 1 and i < len(schedule) - 1:                   # jump back :796-811
+                t = s + jump_length
+                t_arr = torch.full((n_samples, 1), fill_value=t) / timesteps
+                gamma_t = gamma_lookup(table, t_arr, T)
+                z_phar, z_pocket = joint_sample_p_zt_given_zs(cfg, z_phar, z_pocket, pm, qm, gamma_t, gamma_s, draw)
+                if return_chain:
+                    chain.append((z_phar.clone(), z_pocket.clone()))
+                s = t
+            s -= 1
+    out = joint_sample_p_xh_given_z0(p, cfg, z_phar, z_pocket, pm, qm, n_samples, draw)
+    res = _joint_finish(*out, pm, qm, checks)
+    return res + (chain,) if return_chain else res
+
+
+# --------------------------------------------------------------------------
 # node-count prior  (en_diffusion.py:952-1022)
 # --------------------------------------------------------------------------
 def n1_given_n2_log_prob(histogram: np.ndarray, n1: Sequence[int], n2: Sequence[int]) -> torch.Tensor:

@@ -1,0 +1,201 @@
+"""Golden vectors for the JOINT model (mode 'joint'): EnVariationalDiffusion.sample / .inpaint and
+EGNNDynamics with update_pocket_coords=True, produced by importing the real reference
+(/root/reference/DiffPhar) in the build container.  Writes tests/golden/g9_joint.npz.
+
+    python tests/golden/make_golden_joint.py
+
+Fixtures hold inputs, every raw Gaussian draw (in call order) and outputs - never weights (those are
+regenerated from the seed by cmd-gen_amd/synthetic.py) and never reference source.
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from make_golden import HIST, import_reference, pockets_to_torch  # noqa: E402  (also puts the repo on sys.path)
+
+from cmdgen_amd.synthetic import ModelConfig, make_pockets, make_state_dict, min_cutoff_margin  # noqa: E402
+
+
+def build_joint(mods, cfg, seed, gain):
+    with contextlib.redirect_stdout(io.StringIO()):
+        dyn = mods['dynamics'].EGNNDynamics(
+            phar_nf=cfg.phar_nf, residue_nf=cfg.residue_nf, n_dims=3, joint_nf=cfg.joint_nf,
+            hidden_nf=cfg.hidden_nf, device='cpu', act_fn=torch.nn.SiLU(), n_layers=cfg.n_layers,
+            attention=cfg.attention, tanh=cfg.tanh, norm_constant=cfg.norm_constant,
+            inv_sublayers=cfg.inv_sublayers, sin_embedding=cfg.sin_embedding,
+            normalization_factor=cfg.normalization_factor, aggregation_method=cfg.aggregation_method,
+            edge_cutoff=cfg.edge_cutoff, update_pocket_coords=True)
+        ddpm = mods['en_diffusion'].EnVariationalDiffusion(
+            dynamics=dyn, phar_nf=cfg.phar_nf, residue_nf=cfg.residue_nf, n_dims=3, timesteps=cfg.timesteps,
+            noise_schedule=cfg.noise_schedule, noise_precision=cfg.noise_precision, loss_type='l2',
+            norm_values=list(cfg.norm_values), size_histogram=HIST)
+    sd = make_state_dict(cfg, seed=seed, coord_gain=gain, prefix='')
+    res = ddpm.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    ddpm.eval()
+    return ddpm
+
+
+def instrument(ddpm, nseed):
+    """Record every raw randn (before the COM projection) and the cutoff margin of every evaluation."""
+    draws, margins = [], []
+    gen = torch.Generator().manual_seed(nseed)
+
+    def rec_gauss(size, device):
+        n = torch.randn(size, generator=gen)
+        draws.append(n.numpy().copy())
+        return n
+
+    def rec_cog(size, phar_indices, pocket_indices):
+        x = torch.randn(size, generator=gen)
+        draws.append(x.numpy().copy())
+        return type(ddpm).remove_mean_batch(x, torch.cat((phar_indices, pocket_indices)))
+
+    ddpm.sample_gaussian = rec_gauss
+    ddpm.sample_center_gravity_zero_gaussian_batch = rec_cog
+    orig_edges = type(ddpm.dynamics).get_edges.__get__(ddpm.dynamics)
+
+    def rec_edges(mask, x):
+        margins.append(min_cutoff_margin(x.numpy(), mask.numpy(), 6.0))
+        return orig_edges(mask, x)
+    ddpm.dynamics.get_edges = rec_edges
+    return draws, margins
+
+
+def pack_draws(draws, Nl, Np, P, R):
+    """[D, Nl*(3+P) + Np*(3+R)]: per combined draw the phar block [Nl,3+P] then the pocket block [Np,3+R]
+    (x columns = the raw, un-projected draw) - the layout cmdgen_sample_joint takes."""
+    assert len(draws) % 3 == 0
+    out = []
+    for k in range(0, len(draws), 3):
+        zx, zp, zq = draws[k:k + 3]
+        assert zx.shape == (Nl + Np, 3) and zp.shape == (Nl, P) and zq.shape == (Np, R)
+        out.append(np.concatenate([np.concatenate([zx[:Nl], zp], 1).ravel(), np.concatenate([zx[Nl:], zq], 1).ravel()]))
+    return np.stack(out).astype(np.float32)
+
+
+def main():
+    mods = import_reference()
+    g = {}
+
+    # ---------------- joint dynamics: EGNNDynamics.forward with update_pocket_coords=True
+    for name, H, L, B, seed in [('jd_h32_b3', 32, 2, 3, 41), ('jd_h256_b2', 256, 5, 2, 42)]:
+        cfg = ModelConfig(hidden_nf=H, n_layers=L, update_pocket_coords=True)
+        ddpm = build_joint(mods, cfg, seed, 1.0)
+        first = 100 * seed
+        while True:
+            pb = make_pockets(B, 'CA', ragged=True, first_index=first)
+            rng = np.random.Generator(np.random.PCG64(first))
+            nl = pb.num_nodes_phar
+            pmask = np.repeat(np.arange(B), nl)
+            com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(B)])
+            xp = (com[pmask] + rng.normal(size=(len(pmask), 3)) * 3.0).astype(np.float32)
+            xh_phar = np.concatenate([xp, rng.normal(size=(len(pmask), 8)).astype(np.float32)], 1)
+            xq = (pb.x + rng.normal(size=pb.x.shape) * 0.3).astype(np.float32)
+            xh_pocket = np.concatenate([xq, (pb.one_hot / 4 + rng.normal(size=pb.one_hot.shape) * 0.2).astype(np.float32)], 1)
+            allx = np.concatenate([xp, xq]); allm = np.concatenate([pmask, pb.mask])
+            if min_cutoff_margin(allx, allm, 6.0) > 2e-3:
+                break
+            first += 1000
+        t = rng.uniform(size=(B, 1)).astype(np.float32)
+        with torch.no_grad():
+            ep, eq = ddpm.dynamics(torch.from_numpy(xh_phar), torch.from_numpy(xh_pocket), torch.from_numpy(t),
+                                   torch.from_numpy(pmask), torch.from_numpy(pb.mask))
+        g[f'dyn/{name}/meta'] = np.asarray([H, L, B, 20, seed, first], dtype=np.int64)
+        g[f'dyn/{name}/xh_phar'], g[f'dyn/{name}/xh_pocket'], g[f'dyn/{name}/t'] = xh_phar, xh_pocket, t
+        g[f'dyn/{name}/phar_mask'], g[f'dyn/{name}/pocket_mask'] = pmask, pb.mask
+        g[f'dyn/{name}/eps_phar'], g[f'dyn/{name}/eps_pocket'] = ep.numpy(), eq.numpy()
+        print('dyn', name, 'first', first, 'max|vel|', float(np.abs(ep.numpy()[:, :3]).max()))
+
+    # ---------------- EnVariationalDiffusion.sample (unconditional joint generation)
+    for name, H, L, B, K, seed in [('js_h32_K5', 32, 2, 3, 5, 51), ('js_h256_K4', 256, 5, 2, 4, 52)]:
+        cfg = ModelConfig(hidden_nf=H, n_layers=L, update_pocket_coords=True)
+        ddpm = build_joint(mods, cfg, seed, 1.0)
+        nl = np.asarray([6, 9, 5][:B], dtype=np.int64)
+        npk = np.asarray([14, 11, 17][:B], dtype=np.int64)
+        nseed = seed
+        while True:
+            draws, margins = instrument(ddpm, nseed)
+            steps = []
+            orig = type(ddpm).sample_p_zs_given_zt.__get__(ddpm)
+
+            def rec_step(*a, **k):
+                o = orig(*a, **k)
+                steps.append(np.concatenate([o[0].numpy().ravel(), o[1].numpy().ravel()]))
+                return o
+            ddpm.sample_p_zs_given_zt = rec_step
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                xh_phar, xh_pocket, pm, qm = ddpm.sample(B, torch.from_numpy(nl), torch.from_numpy(npk), timesteps=K)
+            if min(margins) > 2e-3:
+                break
+            nseed += 1000
+        g[f'sample/{name}/meta'] = np.asarray([H, L, B, 20, seed, K], dtype=np.int64)
+        g[f'sample/{name}/num_phar'], g[f'sample/{name}/num_pocket'] = nl, npk
+        g[f'sample/{name}/noise'] = pack_draws(draws, int(nl.sum()), int(npk.sum()), 8, 20)
+        g[f'sample/{name}/z_steps'] = np.stack(steps)
+        g[f'sample/{name}/xh_phar'], g[f'sample/{name}/xh_pocket'] = xh_phar.numpy(), xh_pocket.numpy()
+        print('sample', name, 'draws', len(draws) // 3, 'min margin', min(margins))
+
+    # ---------------- EnVariationalDiffusion.inpaint (RePaint); the generate_phars call fixes every pocket node
+    cases = [('ji_h32_K6_r1j1', 32, 2, 3, 6, 1, 1, 61, 'pocket'),
+             ('ji_h32_K6_r2j2', 32, 2, 3, 6, 2, 2, 62, 'pocket'),
+             ('ji_h64_K5_r2j1_partial', 64, 2, 2, 5, 2, 1, 63, 'partial'),
+             ('ji_h256_K4_r1j1', 256, 5, 2, 4, 1, 1, 64, 'pocket')]
+    for name, H, L, B, K, R_, J_, seed, fixed in cases:
+        cfg = ModelConfig(hidden_nf=H, n_layers=L, update_pocket_coords=True)
+        ddpm = build_joint(mods, cfg, seed, 1.0)
+        first, nseed = 100 * seed, seed
+        while True:
+            pb = make_pockets(B, 'CA', ragged=True, first_index=first)
+            nl = pb.num_nodes_phar
+            pmask = np.repeat(np.arange(B), nl)
+            rng = np.random.Generator(np.random.PCG64(first))
+            if fixed == 'partial':      # a few known phar nodes near the pocket centre as well
+                com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(B)])
+                phar_x = (com[pmask] + rng.normal(size=(len(pmask), 3)) * 2.0).astype(np.float32)
+                phar_oh = np.eye(8, dtype=np.float32)[rng.integers(0, 8, size=len(pmask))]
+                phar_fixed = (rng.uniform(size=len(pmask)) < 0.4).astype(np.float32)
+                pocket_fixed = (rng.uniform(size=len(pb.mask)) < 0.8).astype(np.float32)
+                for b in range(B):
+                    pocket_fixed[np.nonzero(pb.mask == b)[0][0]] = 1.0
+            else:                       # lightning_modules.py:466-486
+                phar_x = np.zeros((len(pmask), 3), dtype=np.float32)
+                phar_oh = np.zeros((len(pmask), 8), dtype=np.float32)
+                phar_fixed = np.zeros(len(pmask), dtype=np.float32)
+                pocket_fixed = np.ones(len(pb.mask), dtype=np.float32)
+            draws, margins = instrument(ddpm, nseed)
+            phar = {'x': torch.from_numpy(phar_x.copy()), 'one_hot': torch.from_numpy(phar_oh.copy()),
+                    'size': torch.from_numpy(nl.copy()), 'mask': torch.from_numpy(pmask.copy())}
+            pocket = pockets_to_torch(pb)
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                xh_phar, xh_pocket, pm, qm = ddpm.inpaint(
+                    phar, pocket, torch.from_numpy(phar_fixed.copy()), torch.from_numpy(pocket_fixed.copy()),
+                    resamplings=R_, jump_length=J_, timesteps=K)
+            if min(margins) > 2e-3:
+                break
+            first += 1000
+            nseed += 1000
+        g[f'inpaint/{name}/meta'] = np.asarray([H, L, B, 20, seed, K, R_, J_, first], dtype=np.int64)
+        g[f'inpaint/{name}/phar_x'], g[f'inpaint/{name}/phar_one_hot'] = phar_x, phar_oh
+        g[f'inpaint/{name}/phar_fixed'], g[f'inpaint/{name}/pocket_fixed'] = phar_fixed, pocket_fixed
+        g[f'inpaint/{name}/noise'] = pack_draws(draws, len(pmask), len(pb.mask), 8, 20)
+        g[f'inpaint/{name}/xh_phar'], g[f'inpaint/{name}/xh_pocket'] = xh_phar.numpy(), xh_pocket.numpy()
+        g[f'inpaint/{name}/n_evals'] = np.asarray(len(margins))
+        print('inpaint', name, 'first', first, 'draws', len(draws) // 3, 'evals', len(margins), 'min margin', min(margins))
+
+    # ---------------- RePaint schedules
+    sched_cases = [(1, 1, 10), (3, 1, 7), (2, 2, 6), (5, 10, 50), (10, 10, 500), (4, 3, 11), (2, 20, 10)]
+    for r, j, T in sched_cases:
+        g[f'schedule/r{r}_j{j}_T{T}'] = np.asarray(ddpm.get_repaint_schedule(r, j, T), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'g9_joint.npz'), **g)
+    print('wrote g9_joint.npz', sum(v.nbytes for v in g.values()), 'bytes raw')
+
+
+if __name__ == '__main__':
+    main()

@@ -87,3 +87,45 @@ def loss_case(g):
     pocket = {'x': torch.from_numpy(pb.x.copy()), 'one_hot': torch.from_numpy(pb.one_hot.copy()),
               'size': torch.from_numpy(pb.size.copy()), 'mask': torch.from_numpy(pb.mask.copy())}
     return cfg, sd, phar, pocket, HIST
+
+
+# ---------------------------------------------------------------- joint model (G9)
+class JointNoiseTape:
+    """Replays packed combined draws ([D, Nl*(3+P) + Np*(3+R)], make_golden_joint.pack_draws) as the
+    three randn calls the reference makes per combined draw: x [Nl+Np,3], h_phar [Nl,P], h_pocket [Np,R]."""
+    def __init__(self, arr, Nl, Np, P=8, R=20):
+        self.arr, self.Nl, self.Np, self.P, self.R = arr, Nl, Np, P, R
+        self.i = 0          # combined draws consumed
+        self.sub = 0
+
+    def __call__(self, shape):
+        row = self.arr[self.i]
+        a = row[:self.Nl * (3 + self.P)].reshape(self.Nl, 3 + self.P)
+        b = row[self.Nl * (3 + self.P):].reshape(self.Np, 3 + self.R)
+        out = [np.concatenate([a[:, :3], b[:, :3]]), a[:, 3:], b[:, 3:]][self.sub]
+        assert tuple(out.shape) == tuple(shape), (out.shape, shape)
+        self.sub += 1
+        if self.sub == 3:
+            self.sub, self.i = 0, self.i + 1
+        return torch.from_numpy(np.ascontiguousarray(out))
+
+
+def joint_cfg(H, L, R=20, timesteps=500):
+    return ModelConfig(hidden_nf=int(H), n_layers=int(L), residue_nf=int(R), timesteps=timesteps,
+                       update_pocket_coords=True)
+
+
+def joint_cases(g, kind):
+    return sorted({k.split('/')[1] for k in g if k.startswith(kind + '/')})
+
+
+def joint_inpaint_case(g, name):
+    H, L, B, R, seed, K, resamplings, jump, first = [int(v) for v in g[f'inpaint/{name}/meta']]
+    cfg = joint_cfg(H, L, R)
+    sd = make_state_dict(cfg, seed=seed, coord_gain=1.0)
+    pb = make_pockets(B, 'CA', ragged=True, first_index=first)
+    nl = pb.num_nodes_phar
+    phar = {'x': g[f'inpaint/{name}/phar_x'], 'one_hot': g[f'inpaint/{name}/phar_one_hot'],
+            'size': nl, 'mask': np.repeat(np.arange(B, dtype=np.int64), nl)}
+    pocket = {'x': pb.x, 'one_hot': pb.one_hot, 'size': pb.size, 'mask': pb.mask}
+    return cfg, sd, phar, pocket, K, resamplings, jump
