@@ -28,6 +28,12 @@ void cmdgen_launch_debug_noise(unsigned long long seed, long long pocket_id, int
 void cmdgen_launch_chain_final(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
                                const float* eps, float* xo, float* po, unsigned int* cog, hipStream_t s);
 
+void cmdgen_launch_joint_init(const Layout& lay, const Dims& d, const JointBuf& c, const float* phx, const float* phoh,
+                              const float* px, const float* poh, hipStream_t s);
+void cmdgen_launch_joint_step(const Layout& lay, const Dims& d, const JointBuf& c, const float* ep, const float* eq, hipStream_t s);
+void cmdgen_launch_joint_final(const Layout& lay, const Dims& d, const JointBuf& c, const float* ep, const float* eq,
+                               float* xo, float* po, unsigned int* cog, hipStream_t s);
+
 static std::string g_create_error;
 
 struct DevBuf {
@@ -71,6 +77,17 @@ struct cmdgen_handle {
     const float* graph_noise = nullptr; float* graph_zsteps = nullptr; float* graph_psteps = nullptr; hipStream_t graph_stream = nullptr;
     unsigned long long graph_seed = 0;
     int graph_steps = 0;
+    // joint-model chain
+    std::vector<void*> joint_allocs;
+    JointBuf joint{};
+    float* eps_pocket_tmp = nullptr;       // [Np][3+R] evaluation output of the joint chain
+    unsigned int* joint_cog = nullptr;
+    int joint_steps = -1;                  // denoising steps of the prepared plan
+    std::vector<int> joint_key;            // (K, resamplings, jump, inpaint) of the prepared plan
+    bool last_chain_joint = false;
+    hipGraphExec_t joint_graph = nullptr;
+    const void* jg_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned long long jg_seed = 0; int jg_steps = 0;
     bool kernel_profiling = false;
     std::vector<hipEvent_t> prof_events[3];
 };
@@ -109,6 +126,8 @@ extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle
         2 * cfg->residue_nf > CMDGEN_MAX_SMALL || cfg->joint_nf < 1 || cfg->joint_nf + 1 > CMDGEN_MAX_SMALL)
         return fail(nullptr, CMDGEN_EINVAL, "feature sizes exceed the small-MLP bound %d", CMDGEN_MAX_SMALL);
     if (cfg->timesteps < 1) return fail(nullptr, CMDGEN_EINVAL, "timesteps < 1");
+    if (cfg->update_pocket_coords && cfg->no_com_projection)
+        return fail(nullptr, CMDGEN_EINVAL, "update_pocket_coords (joint model) and no_com_projection (SimpleConditionalDDPM) are exclusive");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
         return fail(nullptr, CMDGEN_EHIP, "no usable HIP device %d (found %d)", device, ndev);
@@ -123,6 +142,7 @@ extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle
     d.P = cfg->phar_nf; d.R = cfg->residue_nf; d.J = cfg->joint_nf; d.H = H; d.L = cfg->n_layers;
     d.condition_time = cfg->condition_time ? 1 : 0; d.dyn = d.J + d.condition_time;
     d.attention = cfg->attention ? 1 : 0; d.use_tanh = cfg->tanh ? 1 : 0; d.no_com = cfg->no_com_projection ? 1 : 0;
+    d.joint = cfg->update_pocket_coords ? 1 : 0;
     d.cutoff2 = cfg->edge_cutoff < 0.f ? -1.f : cfg->edge_cutoff * cfg->edge_cutoff;
     d.norm_constant = cfg->norm_constant; d.norm_factor = cfg->normalization_factor; d.coords_range = cfg->coords_range;
     d.norm_x = cfg->norm_x; d.norm_h = cfg->norm_h; d.bias_h = cfg->bias_h;
@@ -136,10 +156,11 @@ extern "C" void cmdgen_destroy(cmdgen_handle* h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->step_graph) hipGraphExecDestroy(h->step_graph);
+    if (h->joint_graph) hipGraphExecDestroy(h->joint_graph);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     if (h->ev_in) hipEventDestroy(h->ev_in);
     if (h->ev_out) hipEventDestroy(h->ev_out);
-    free_pool(h->weight_allocs); free_pool(h->layout_allocs); free_pool(h->chain_allocs);
+    free_pool(h->weight_allocs); free_pool(h->layout_allocs); free_pool(h->chain_allocs); free_pool(h->joint_allocs);
     delete h;
 }
 
@@ -208,6 +229,7 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
     if (!h) return CMDGEN_EINVAL;
     hipSetDevice(h->device);
     if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+    if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
     free_pool(h->weight_allocs);
     h->layers.clear();
     const Dims& d = h->dims;
@@ -288,6 +310,7 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
 #undef UP
     h->finalized = true;
     h->user_coef_K = -1; h->chain_K = -1;      // a new gamma table invalidates any step table
+    h->joint_steps = -1; h->joint_key.clear();
     return CMDGEN_OK;
 }
 
@@ -303,7 +326,9 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+    if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
     free_pool(h->layout_allocs); free_pool(h->chain_allocs); h->chain_K = -1;
+    free_pool(h->joint_allocs); h->joint_steps = -1; h->joint_key.clear();
     h->have_layout = false;
     const Dims& d = h->dims;
     const int B = (int)batch;
@@ -314,7 +339,7 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
         vph[b] = (int)nph[b]; vpk[b] = (int)npk[b]; bph[b] = (int)Nl; bpk[b] = (int)Np;
         Nl += nph[b]; Np += npk[b];
         const int64_t n = nph[b] + npk[b];
-        ecap += n * n; eccap += nph[b] * n;           // dense bound per sample: never overflows
+        ecap += n * n; eccap += (d.joint ? n : nph[b]) * n;   // dense bound per sample: never overflows
         if (n > max_n) max_n = (int)n;
     }
     const int64_t N = Nl + Np;
@@ -328,6 +353,8 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
     int rc; void* p;
     Layout& L = h->lay; Work& w = h->work;
     L.B = B; L.Nl = (int)Nl; L.Np = (int)Np; L.N = (int)N; L.max_n = max_n;
+    L.Nm = d.joint ? (int)N : (int)Nl;
+    const int64_t Nm = L.Nm;
 #define ALLOC_I(dst, vec) do { rc = dev_alloc(h, h->layout_allocs, &p, (vec).size() * sizeof(int), false); if (rc) return rc; \
         HIPCHK(h, hipMemcpy(p, (vec).data(), (vec).size() * sizeof(int), hipMemcpyHostToDevice)); dst = (const int*)p; } while (0)
     ALLOC_I(L.num_phar, vph); ALLOC_I(L.num_pocket, vpk); ALLOC_I(L.phar_base, bph); ALLOC_I(L.pocket_base, bpk);
@@ -339,11 +366,11 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
     h->d_gid = (int64_t*)p; L.pocket_gid = h->d_gid;
     const size_t H = d.H;
 #define ALLOC(dst, type, count, zero) do { rc = dev_alloc(h, h->layout_allocs, &p, (size_t)(count) * sizeof(type), zero); if (rc) return rc; dst = (type*)p; } while (0)
-    ALLOC(w.X0, float4, Nl, true); ALLOC(w.XP, float4, Np, true);
-    ALLOC(w.XL, float4, (size_t)d.L * Nl, true); ALLOC(w.ACC, float4, (size_t)d.L * Nl, true);
+    ALLOC(w.X0, float4, Nm, true); ALLOC(w.XP, float4, Np, true);
+    ALLOC(w.XL, float4, (size_t)d.L * Nm, true); ALLOC(w.ACC, float4, (size_t)d.L * Nm, true);
     ALLOC(w.h, float, N * H, true); ALLOC(w.P, float, N * H, true); ALLOC(w.Q, float, N * H, true);
     ALLOC(w.Pc, float, N * H, true); ALLOC(w.Qc, float, N * H, true); ALLOC(w.agg, float, N * H, true);
-    ALLOC(w.degL, int, N, true); ALLOC(w.pocketE, int, B, true); ALLOC(w.pocketEph, int, B, true); ALLOC(w.pocketEns, int, B, true);
+    ALLOC(w.degL, int, N, true); ALLOC(w.pocketE, int, B, true); ALLOC(w.pocketEph, int, B, true); ALLOC(w.pocketEns, int, B, true); ALLOC(w.pocketEnsQ, int, B, true);
     ALLOC(w.erow, int, ecap, false); ALLOC(w.ecol, int, ecap, false); ALLOC(w.ed0, float, ecap, false);
     ALLOC(w.crow, int, eccap, false); ALLOC(w.ccol, int, eccap, false); ALLOC(w.cd0, float, eccap, false);
     ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true);
@@ -358,7 +385,7 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
             const double n = (double)(nph[b] + npk[b]);
             const double deg = h->cfg.edge_cutoff < 0.f ? n : (n <= 128.0 ? 6.0 : 36.0);
             e_est += n * (deg < n ? deg : n);
-            ec_est += (double)nph[b] * (deg < n ? deg : n) * 0.5;
+            ec_est += (double)(d.joint ? n : nph[b]) * (deg < n ? deg : n) * 0.5;
         }
         // thresholds from sweeps on MI355X (profiles/r01_tile_sweep.txt)
         auto pick = [&](double rows) { return rows / 64.0 >= 3.0 * h->n_cus ? 64 : (rows / 32.0 >= 1.5 * h->n_cus ? 32 : 16); };
@@ -408,11 +435,12 @@ extern "C" int cmdgen_dynamics_forward(cmdgen_handle* h, const float* xh_phar, c
                                        const float* t, float* eps_phar, float* eps_pocket, cmdgen_stream stream) {
     int rc = check_ready(h); if (rc) return rc;
     if (!xh_phar || !xh_pocket || !t || !eps_phar) return fail(h, CMDGEN_EINVAL, "null device pointer");
+    if (h->dims.joint && !eps_pocket) return fail(h, CMDGEN_EINVAL, "joint mode (update_pocket_coords) needs eps_pocket: the pocket velocity is part of the output");
     hipSetDevice(h->device);
     hipStream_t s = (hipStream_t)stream;
     EvalLaunch a = make_launch(h);
     cmdgen_launch_eval(a, xh_phar, xh_pocket, t, nullptr, nullptr, eps_phar, eps_pocket, s, nullptr);
-    cmdgen_launch_nan_fix(a, eps_phar, s);
+    if (!h->dims.joint) cmdgen_launch_nan_fix(a, eps_phar, s);     // joint: k_vel_com applied the reset already
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;
 }
@@ -442,9 +470,9 @@ extern "C" int cmdgen_debug_read(cmdgen_handle* h, const char* what, float* host
     else if (k == "agg") { src = h->work.agg; have = (size_t)h->lay.N * d.H; }
     else if (k == "P") { src = h->work.P; have = (size_t)h->lay.N * d.H; }
     else if (k == "Q") { src = h->work.Q; have = (size_t)h->lay.N * d.H; }
-    else if (k == "x0") { src = h->work.X0; have = (size_t)h->lay.Nl * 4; }
-    else if (k == "xl") { src = h->work.XL; have = (size_t)d.L * h->lay.Nl * 4; }
-    else if (k == "acc") { src = h->work.ACC; have = (size_t)d.L * h->lay.Nl * 4; }
+    else if (k == "x0") { src = h->work.X0; have = (size_t)h->lay.Nm * 4; }
+    else if (k == "xl") { src = h->work.XL; have = (size_t)d.L * h->lay.Nm * 4; }
+    else if (k == "acc") { src = h->work.ACC; have = (size_t)d.L * h->lay.Nm * 4; }
     else return fail(h, CMDGEN_EINVAL, "unknown debug buffer '%s'", k.c_str());
     if (n > have) n = have;
     HIPCHK(h, hipMemcpy(host, src, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -521,6 +549,8 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
     if (!pocket_x || !pocket_onehot || !xh_phar_out || !xh_pocket_out) return fail(h, CMDGEN_EINVAL, "null device pointer");
     const int K = timesteps;
     if (K < 1 || K > h->cfg.timesteps) return fail(h, CMDGEN_EINVAL, "timesteps=%d must be in [1, %d]", K, h->cfg.timesteps);
+    if (h->dims.joint) return fail(h, CMDGEN_ESTATE, "this handle is the joint model (update_pocket_coords=1): use cmdgen_joint_chain");
+    h->last_chain_joint = false;
     hipSetDevice(h->device);
     hipStream_t caller = (hipStream_t)stream;
     hipStream_t s = caller;
@@ -598,14 +628,229 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
     return CMDGEN_OK;
 }
 
+
+// ---------------------------------------------------------------------------------
+// joint model: EnVariationalDiffusion.sample / .inpaint (en_diffusion.py:576-831)
+// ---------------------------------------------------------------------------------
+// get_repaint_schedule (en_diffusion.py:649-670): denoising steps to run before each jump back
+static std::vector<int> repaint_schedule(int resamplings, int jump_length, int timesteps) {
+    std::vector<int> sched;
+    int curr_t = 0;
+    while (curr_t < timesteps) {
+        if (curr_t + jump_length < timesteps) {
+            if (!sched.empty()) {
+                sched.back() += jump_length;
+                for (int i = 0; i < resamplings - 1; ++i) sched.push_back(jump_length);
+            } else {
+                for (int i = 0; i < resamplings; ++i) sched.push_back(jump_length);
+            }
+            curr_t += jump_length;
+        } else {
+            const int residual = timesteps - curr_t;
+            if (!sched.empty()) sched.back() += residual; else sched.push_back(residual);
+            curr_t += residual;
+        }
+    }
+    return std::vector<int>(sched.rbegin(), sched.rend());
+}
+
+struct JointPlan {
+    std::vector<float> coef, coef2;     // [n_steps+1][4], [n_steps+1][4]
+    std::vector<int> iop;               // [n_steps+1][4]
+    int n_steps = 0, n_draws = 0;
+};
+
+// The op table of one chain: one row per network evaluation, in execution order (the walk of :723-813).
+static JointPlan build_joint_plan(const std::vector<float>& gamma, int T, int K, int resamplings, int jump, bool inpaint) {
+    JointPlan p;
+    const std::vector<int> sched = inpaint ? repaint_schedule(resamplings, jump, K) : std::vector<int>{K};
+    auto g_at = [&](int step) { return gamma[(size_t)lrintf(((float)step / (float)K) * (float)T)]; };
+    int draw = 1;                       // draw 0 = z_T
+    int s = K - 1;
+    for (size_t i = 0; i < sched.size(); ++i) {
+        for (int j = 0; j < sched[i]; ++j) {
+            const float g_s = g_at(s), g_t = g_at(s + 1);
+            const float sigma2_ts = -expm1f(softplus_f(g_s) - softplus_f(g_t));
+            const float alpha_ts = expf(0.5f * (logsigmoid_f(-g_t) - logsigmoid_f(-g_s)));
+            const float sigma_ts = sqrtf(sigma2_ts);
+            const float sigma_s = sqrtf(sigmoid_h(g_s)), sigma_t = sqrtf(sigmoid_h(g_t));
+            p.coef.insert(p.coef.end(), {alpha_ts, sigma2_ts / alpha_ts / sigma_t, sigma_ts * sigma_s / sigma_t,
+                                         (float)(s + 1) / (float)K});
+            float re_a = 0.f, re_s = 0.f; int flags = 0;
+            const int draw0 = draw;
+            draw += inpaint ? 2 : 1;
+            if (j == sched[i] - 1 && i + 1 < sched.size()) {      // jump back s -> s + jump_length
+                const float g_t2 = g_at(s + jump);
+                re_s = sqrtf(-expm1f(softplus_f(g_s) - softplus_f(g_t2)));
+                re_a = expf(0.5f * (logsigmoid_f(-g_t2) - logsigmoid_f(-g_s)));
+                flags = 1; draw += 1;
+                s = s + jump;
+            }
+            p.coef2.insert(p.coef2.end(), {sqrtf(sigmoid_h(-g_s)), sigma_s, re_a, re_s});
+            p.iop.insert(p.iop.end(), {flags, draw0, 0, 0});
+            s -= 1;
+            p.n_steps += 1;
+        }
+    }
+    const float g0 = gamma[0];
+    p.coef.insert(p.coef.end(), {sqrtf(sigmoid_h(g0)), sqrtf(sigmoid_h(-g0)), expf(0.5f * g0), 0.f});
+    p.coef2.insert(p.coef2.end(), {0.f, 0.f, 0.f, 0.f});
+    p.iop.insert(p.iop.end(), {0, draw, 0, 0});
+    p.n_draws = draw + 1;
+    return p;
+}
+
+static int check_joint_args(cmdgen_handle* h, int K, int resamplings, int jump) {
+    if (!h->dims.joint) return fail(h, CMDGEN_ESTATE, "joint chains need a handle created with update_pocket_coords=1");
+    if (K < 1 || K > h->cfg.timesteps) return fail(h, CMDGEN_EINVAL, "timesteps=%d must be in [1, %d]", K, h->cfg.timesteps);
+    if (resamplings < 1 || jump < 1) return fail(h, CMDGEN_EINVAL, "resamplings and jump_length must be >= 1");
+    return 0;
+}
+
+extern "C" int cmdgen_joint_plan(cmdgen_handle* h, int32_t timesteps, int32_t resamplings, int32_t jump_length,
+                                 int32_t inpaint, int64_t* n_steps, int64_t* n_draws) {
+    if (!h) return CMDGEN_EINVAL;
+    if (!h->finalized) return fail(h, CMDGEN_ESTATE, "weights not finalised (cmdgen_finalize_weights)");
+    int rc = check_joint_args(h, timesteps, resamplings, jump_length); if (rc) return rc;
+    const JointPlan p = build_joint_plan(h->gamma, h->cfg.timesteps, timesteps, resamplings, jump_length, inpaint != 0);
+    if (n_steps) *n_steps = p.n_steps;
+    if (n_draws) *n_draws = p.n_draws;
+    return CMDGEN_OK;
+}
+
+static int prepare_joint(cmdgen_handle* h, int K, int resamplings, int jump, bool inpaint) {
+    const std::vector<int> key{K, resamplings, jump, inpaint ? 1 : 0};
+    if (h->joint_steps >= 0 && h->joint_key == key) return 0;
+    hipDeviceSynchronize();
+    if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
+    free_pool(h->joint_allocs);
+    h->joint_steps = -1;
+    const Dims& d = h->dims;
+    const JointPlan p = build_joint_plan(h->gamma, h->cfg.timesteps, K, resamplings, jump, inpaint);
+    void* q; int rc;
+    auto up = [&](const void* src, size_t bytes, const void** dst) -> int {
+        int r = dev_alloc(h, h->joint_allocs, &q, bytes, false); if (r) return r;
+        if (hipMemcpy(q, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemcpy H2D failed");
+        *dst = q; return 0;
+    };
+    const void* dp;
+    rc = up(p.coef.data(), p.coef.size() * sizeof(float), &dp); if (rc) return rc; h->joint.coef = (const float4*)dp;
+    rc = up(p.coef2.data(), p.coef2.size() * sizeof(float), &dp); if (rc) return rc; h->joint.coef2 = (const float4*)dp;
+    rc = up(p.iop.data(), p.iop.size() * sizeof(int), &dp); if (rc) return rc; h->joint.iop = (const int4*)dp;
+    const size_t np_ = (size_t)h->lay.Nl * (3 + d.P) * sizeof(float), nq_ = (size_t)h->lay.Np * (3 + d.R) * sizeof(float);
+#define JALLOC(dst, bytes) do { rc = dev_alloc(h, h->joint_allocs, &q, bytes, true); if (rc) return rc; dst = (float*)q; } while (0)
+    JALLOC(h->joint.z_phar, np_); JALLOC(h->joint.z_pocket, nq_);
+    JALLOC(h->joint.e_phar, np_); JALLOC(h->joint.e_pocket, nq_);
+    JALLOC(h->joint.zk_phar, np_); JALLOC(h->joint.zk_pocket, nq_);
+    JALLOC(h->joint.x0_phar, np_); JALLOC(h->joint.x0_pocket, nq_);
+    JALLOC(h->eps_pocket_tmp, nq_);
+#undef JALLOC
+    rc = dev_alloc(h, h->joint_allocs, &q, (size_t)(p.n_steps + 3) * 2 * sizeof(unsigned int), true); if (rc) return rc; h->joint.check = (unsigned int*)q;
+    rc = dev_alloc(h, h->joint_allocs, &q, sizeof(ChainState), true); if (rc) return rc; h->joint.state = (ChainState*)q;
+    rc = dev_alloc(h, h->joint_allocs, &q, 4 * sizeof(unsigned int), true); if (rc) return rc; h->joint_cog = (unsigned int*)q;
+    h->joint_steps = p.n_steps;
+    h->joint_key = key;
+    return 0;
+}
+
+extern "C" int cmdgen_joint_chain(cmdgen_handle* h, const float* phar_x, const float* phar_onehot,
+                                  const float* pocket_x, const float* pocket_onehot,
+                                  const float* phar_fixed, const float* pocket_fixed,
+                                  int32_t timesteps, int32_t resamplings, int32_t jump_length,
+                                  const float* noise, int64_t n_draws, uint64_t seed, const int64_t* pocket_ids_host,
+                                  float* xh_phar_out, float* xh_pocket_out, float* z_steps_out,
+                                  int32_t use_graph, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    rc = check_joint_args(h, timesteps, resamplings, jump_length); if (rc) return rc;
+    if (!xh_phar_out || !xh_pocket_out) return fail(h, CMDGEN_EINVAL, "null output pointer");
+    const bool inpaint = phar_fixed != nullptr || pocket_fixed != nullptr;
+    if (inpaint && (!phar_fixed || !pocket_fixed || !phar_x || !phar_onehot || !pocket_x || !pocket_onehot))
+        return fail(h, CMDGEN_EINVAL, "inpainting needs phar_x, phar_onehot, pocket_x, pocket_onehot and both fixed masks");
+    hipSetDevice(h->device);
+    hipStream_t caller = (hipStream_t)stream;
+    hipStream_t s = caller;
+    if (use_graph && caller == nullptr) {
+        if (!h->own_stream) {
+            HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+        }
+        HIPCHK(h, hipEventRecord(h->ev_in, caller));
+        HIPCHK(h, hipStreamWaitEvent(h->own_stream, h->ev_in, 0));
+        s = h->own_stream;
+    }
+    rc = prepare_joint(h, timesteps, resamplings, jump_length, inpaint); if (rc) return rc;
+    const int n_steps = h->joint_steps;
+    if (noise) {
+        int64_t need = 0;
+        cmdgen_joint_plan(h, timesteps, resamplings, jump_length, inpaint ? 1 : 0, nullptr, &need);
+        if (n_draws < need) return fail(h, CMDGEN_EINVAL, "noise holds %lld combined draws, the schedule needs %lld", (long long)n_draws, (long long)need);
+    }
+    h->last_chain_joint = true;
+    const Dims& d = h->dims;
+    {
+        std::vector<int64_t> gid(h->lay.B);
+        for (int b = 0; b < h->lay.B; ++b) gid[b] = pocket_ids_host ? pocket_ids_host[b] : b;
+        HIPCHK(h, hipMemcpyAsync(h->d_gid, gid.data(), gid.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    JointBuf c = h->joint;
+    c.fix_phar = inpaint ? phar_fixed : nullptr; c.fix_pocket = inpaint ? pocket_fixed : nullptr;
+    c.noise = noise; c.seed = seed; c.z_steps = z_steps_out;
+    const ChainState st0{-1, n_steps, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(c.state, &st0, sizeof st0, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemsetAsync(c.check, 0, (size_t)(n_steps + 3) * 2 * sizeof(unsigned int), s));
+    HIPCHK(h, hipMemsetAsync(h->joint_cog, 0, 4 * sizeof(unsigned int), s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    EvalLaunch a = make_launch(h);
+    if (h->kernel_profiling && !use_graph) a.prof_events = h->prof_events;
+    cmdgen_launch_joint_init(h->lay, d, c, phar_x, phar_onehot, pocket_x, pocket_onehot, s);
+    auto one_step = [&](hipStream_t ss) {
+        cmdgen_launch_eval(a, c.z_phar, c.z_pocket, nullptr, c.coef, c.state, h->work.eps_tmp, h->eps_pocket_tmp, ss, nullptr);
+        cmdgen_launch_joint_step(h->lay, d, c, h->work.eps_tmp, h->eps_pocket_tmp, ss);
+    };
+    if (use_graph) {
+        // as in cmdgen_sample_chain: the op index lives on the device, so G captured steps replay for any position
+        const void* key[6] = {noise, z_steps_out, (const void*)s, phar_fixed, pocket_fixed, nullptr};
+        const char* gs = getenv("CMDGEN_GRAPH_STEPS");
+        int G = gs ? atoi(gs) : 8;
+        if (G < 1) G = 1;
+        if (G > n_steps) G = n_steps;
+        if (h->joint_graph && (memcmp(key, h->jg_key, sizeof key) != 0 || h->jg_seed != seed || h->jg_steps != G)) {
+            hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr;
+        }
+        if (!h->joint_graph) {
+            hipGraph_t g = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < G; ++i) one_step(s);
+            HIPCHK(h, hipStreamEndCapture(s, &g));
+            HIPCHK(h, hipGraphInstantiate(&h->joint_graph, g, nullptr, nullptr, 0));
+            hipGraphDestroy(g);
+            memcpy(h->jg_key, key, sizeof key); h->jg_seed = seed; h->jg_steps = G;
+        }
+        for (int i = 0; i < n_steps / G; ++i) HIPCHK(h, hipGraphLaunch(h->joint_graph, s));
+        for (int i = 0; i < n_steps % G; ++i) one_step(s);
+    } else {
+        for (int i = 0; i < n_steps; ++i) one_step(s);
+    }
+    cmdgen_launch_eval(a, c.z_phar, c.z_pocket, nullptr, c.coef, c.state, h->work.eps_tmp, h->eps_pocket_tmp, s, nullptr);
+    cmdgen_launch_joint_final(h->lay, d, c, h->work.eps_tmp, h->eps_pocket_tmp, xh_phar_out, xh_pocket_out, h->joint_cog, s);
+    HIPCHK(h, hipGetLastError());
+    if (s != caller) {
+        HIPCHK(h, hipEventRecord(h->ev_out, s));
+        HIPCHK(h, hipStreamWaitEvent(caller, h->ev_out, 0));
+    }
+    return CMDGEN_OK;
+}
+
 extern "C" int cmdgen_chain_status(cmdgen_handle* h, float* max_rel, float* max_cog, int64_t* nan_resets, cmdgen_stream stream) {
     int rc = check_ready(h); if (rc) return rc;
-    if (h->chain_K < 0) return fail(h, CMDGEN_ESTATE, "no chain has run");
+    if (h->last_chain_joint ? h->joint_steps < 0 : h->chain_K < 0) return fail(h, CMDGEN_ESTATE, "no chain has run");
     hipSetDevice(h->device);
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
-    const int K = h->chain_K;
+    const int K = h->last_chain_joint ? h->joint_steps : h->chain_K;
     std::vector<unsigned int> chk((size_t)(K + 3) * 2);
-    HIPCHK(h, hipMemcpy(chk.data(), h->chain.check, chk.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(chk.data(), h->last_chain_joint ? h->joint.check : h->chain.check, chk.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
     float worst = 0.f;
     for (int i = 0; i < K + 2; ++i) {
         float largest, err;
@@ -614,7 +859,7 @@ extern "C" int cmdgen_chain_status(cmdgen_handle* h, float* max_rel, float* max_
         if (rel > worst) worst = rel;
     }
     if (max_rel) *max_rel = worst;
-    unsigned int cog; HIPCHK(h, hipMemcpy(&cog, h->d_cog, 4, hipMemcpyDeviceToHost));
+    unsigned int cog; HIPCHK(h, hipMemcpy(&cog, h->last_chain_joint ? h->joint_cog : h->d_cog, 4, hipMemcpyDeviceToHost));
     if (max_cog) memcpy(max_cog, &cog, 4);
     unsigned long long cnt[8];
     HIPCHK(h, hipMemcpy(cnt, h->work.counters, sizeof cnt, hipMemcpyDeviceToHost));
@@ -647,6 +892,7 @@ extern "C" int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar,
                                          float* eps_phar, cmdgen_kernel_times* out, cmdgen_stream stream) {
     int rc = check_ready(h); if (rc) return rc;
     if (!out) return fail(h, CMDGEN_EINVAL, "null output");
+    if (h->dims.joint) return fail(h, CMDGEN_ESTATE, "cmdgen_profile_evaluation supports the conditional model only");
     hipSetDevice(h->device);
     hipStream_t s = (hipStream_t)stream;
     const int L = h->dims.L;

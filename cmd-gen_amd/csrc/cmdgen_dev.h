@@ -69,6 +69,7 @@ struct Dims {
     int dyn;                    // J + condition_time
     int attention, use_tanh, condition_time;
     int no_com;                 // SimpleConditionalDDPM: no centre-of-mass projection in the sampler
+    int joint;                  // update_pocket_coords (mode 'joint'): pocket nodes move, velocity COM removed
     float cutoff2;              // cutoff^2, < 0: no cutoff
     float norm_constant, norm_factor, coords_range;
     float norm_x, norm_h, bias_h;
@@ -76,6 +77,7 @@ struct Dims {
 
 struct Layout {                 // one flat batch; all pointers device
     int B, Nl, Np, N;           // samples, phar nodes, pocket nodes, total
+    int Nm;                     // nodes whose coordinates move: Nl (conditional) or N (joint); flat ids < Nm
     int max_n;                  // max nodes of one sample
     const int* num_phar;        // [B]
     const int* num_pocket;      // [B]
@@ -86,10 +88,10 @@ struct Layout {                 // one flat batch; all pointers device
 };
 
 struct Work {                   // per-layout workspace; all pointers device
-    float4* X0;                 // [Nl] phar input coordinates of this evaluation
-    float4* XP;                 // [Np] pocket coordinates
-    float4* XL;                 // [L][Nl] phar coordinates entering block l (l >= 1 materialised by the node kernel)
-    float4* ACC;                // [L][Nl] sum of coordinate messages of block l (zeroed per evaluation)
+    float4* X0;                 // [Nm] input coordinates of the moving nodes of this evaluation
+    float4* XP;                 // [Np] pocket input coordinates
+    float4* XL;                 // [L][Nm] coordinates entering block l (l >= 1 materialised by the node kernel)
+    float4* ACC;                // [L][Nm] sum of coordinate messages of block l (zeroed per evaluation)
     float*  h;                  // [N][H]
     float*  P;                  // [N][H]  edge-MLP layer-0 receiver part (+b1)
     float*  Q;                  // [N][H]  sender part
@@ -100,9 +102,10 @@ struct Work {                   // per-layout workspace; all pointers device
     int*    pocketE;            // [B] edges per sample
     int*    pocketEph;          // [B] edges with phar receiver per sample
     int*    pocketEns;          // [B] ... of those that are not self loops
+    int*    pocketEnsQ;         // [B] edges with pocket receiver that are not self loops (joint mode's coordinate list)
     int*    erow; int* ecol; float* ed0;        // [Ecap] compact edge list sorted by flat (row, col); the first
                                                 //        pocketEph-sum entries are the phar-receiver edges
-    int*    crow; int* ccol; float* cd0;        // [Eccap] phar-receiver edges without self loops (coordinate update)
+    int*    crow; int* ccol; float* cd0;        // [Eccap] coordinate-update edges: moving receivers, self loops dropped
     int*    totals;             // [0]=E, [1]=Ec (coordinate list) of the current evaluation
     unsigned long long* counters;   // cmdgen_counters
     int*    nan_flag;           // [1] set by readout when any velocity is NaN
@@ -125,6 +128,27 @@ struct ChainBuf {               // device pointers owned by the handle for one c
     float* z_steps;             // [K][Nl][3+P] or null
     float* pocket_steps;        // [K][Np][3] or null
     unsigned int* check;        // [K+3][2] float bits: max|x|, max|sum x| per check point
+    ChainState* state;
+};
+
+struct JointBuf {               // joint-model chain (EnVariationalDiffusion.sample / .inpaint), device pointers
+    float* z_phar;              // [Nl][3+P] current z
+    float* z_pocket;            // [Np][3+R]
+    float* e_phar;              // [Nl][3+P] scratch: the combined draw in use (x part COM-projected)
+    float* e_pocket;            // [Np][3+R]
+    float* zk_phar;             // [Nl][3+P] scratch: noised known part (inpainting)
+    float* zk_pocket;           // [Np][3+R]
+    float* x0_phar;             // [Nl][3+P] centred known input [x | one_hot] (inpainting), raw scale (quirk Q14)
+    float* x0_pocket;           // [Np][3+R]
+    const float* fix_phar;      // [Nl] 1 = known; null: plain sampling
+    const float* fix_pocket;    // [Np]
+    const float4* coef;         // [n_steps+1] (alpha_ts, sigma2_ts/alpha_ts/sigma_t, sigma_ts*sigma_s/sigma_t, t); last: decode row
+    const float4* coef2;        // [n_steps]   (alpha_s, sigma_s, jump alpha_t|s, jump sigma_t|s)
+    const int4* iop;            // [n_steps+1] (flags: 1 = jump back after the step, first draw index, 0, 0)
+    const float* noise;         // [D][Nl*(3+P) + Np*(3+R)] or null
+    unsigned long long seed;
+    float* z_steps;             // [n_steps][Nl*(3+P) + Np*(3+R)] or null
+    unsigned int* check;        // [n_steps+3][2]
     ChainState* state;
 };
 

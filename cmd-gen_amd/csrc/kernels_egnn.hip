@@ -49,11 +49,16 @@ __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict
             const float* s = xh_phar + (size_t)(pb + i) * ldp;
             p = make_float4(s[0], s[1], s[2], 0.f);
             w.X0[pb + i] = p;
-            for (int l = 0; l < d.L; ++l) w.ACC[(size_t)l * lay.Nl + pb + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int l = 0; l < d.L; ++l) w.ACC[(size_t)l * lay.Nm + pb + i] = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
             const float* s = xh_pocket + (size_t)(qb + i - nl) * ldq;
             p = make_float4(s[0], s[1], s[2], 0.f);
             w.XP[qb + i - nl] = p;
+            if (d.joint) {                  // joint mode: pocket nodes move as well (dynamics.py:105-107)
+                const int n = lay.Nl + qb + i - nl;
+                w.X0[n] = p;
+                for (int l = 0; l < d.L; ++l) w.ACC[(size_t)l * lay.Nm + n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         spos[i] = p;
     }
@@ -77,13 +82,16 @@ __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict
     }
     __syncthreads();
     if (wave == 0) {
-        int e = 0, eph = 0, ens = 0;
+        int e = 0, eph = 0, ens = 0, ensq = 0;
         for (int i = lane; i < n; i += 64) {
             const int dg = sdeg[i] & 0x3fffffff; e += dg;
             if (i < nl) { eph += dg; ens += dg - ((sdeg[i] >> 30) & 1); }
+            else ensq += dg - ((sdeg[i] >> 30) & 1);
         }
-        for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o); eph += __shfl_xor(eph, o); ens += __shfl_xor(ens, o); }
-        if (lane == 0) { w.pocketE[b] = e; w.pocketEph[b] = eph; w.pocketEns[b] = ens; }
+        for (int o = 32; o > 0; o >>= 1) {
+            e += __shfl_xor(e, o); eph += __shfl_xor(eph, o); ens += __shfl_xor(ens, o); ensq += __shfl_xor(ensq, o);
+        }
+        if (lane == 0) { w.pocketE[b] = e; w.pocketEph[b] = eph; w.pocketEns[b] = ens; w.pocketEnsQ[b] = ensq; }
     }
     if (b == 0 && tid == 0) {
         if (chain) chain->step += 1;
@@ -96,8 +104,8 @@ __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict
 __global__ void k_edge_write(Layout lay, Work w, Dims d) {
     extern __shared__ float4 spos[];
     int* soff = reinterpret_cast<int*>(spos + lay.max_n);
-    __shared__ int s_base[4];
-    __shared__ int s_red[4][16];
+    __shared__ int s_base[5];
+    __shared__ int s_red[6][16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nl = lay.num_phar[b], np = lay.num_pocket[b], n = nl + np;
     const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
@@ -107,24 +115,31 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
     // numbering (dynamics.py:146): all phar receivers first (sample by sample), then all pocket
     // receivers.  So the phar-receiver edges - the only ones the coordinate update needs - are
     // the first Ec entries of the same list.
-    int e = 0, eph = 0, ephall = 0, ens = 0;
+    int e = 0, eph = 0, ephall = 0, ens = 0, ensall = 0, ensq = 0;
     for (int k = tid; k < lay.B; k += blockDim.x) {
-        const int pe = w.pocketE[k], pp = w.pocketEph[k];
-        ephall += pp;
-        if (k < b) { e += pe; eph += pp; ens += w.pocketEns[k]; }
+        const int pe = w.pocketE[k], pp = w.pocketEph[k], pn = w.pocketEns[k];
+        ephall += pp; ensall += pn;
+        if (k < b) { e += pe; eph += pp; ens += pn; ensq += w.pocketEnsQ[k]; }
     }
     for (int o = 32; o > 0; o >>= 1) {
         e += __shfl_xor(e, o); eph += __shfl_xor(eph, o); ephall += __shfl_xor(ephall, o); ens += __shfl_xor(ens, o);
+        ensall += __shfl_xor(ensall, o); ensq += __shfl_xor(ensq, o);
     }
-    if (lane == 0) { s_red[0][wave] = e; s_red[1][wave] = eph; s_red[2][wave] = ephall; s_red[3][wave] = ens; }
+    if (lane == 0) {
+        s_red[0][wave] = e; s_red[1][wave] = eph; s_red[2][wave] = ephall; s_red[3][wave] = ens;
+        s_red[4][wave] = ensall; s_red[5][wave] = ensq;
+    }
     __syncthreads();
     if (tid == 0) {
-        int te = 0, tp = 0, ta = 0, tn = 0;
-        for (int k = 0; k < nwaves; ++k) { te += s_red[0][k]; tp += s_red[1][k]; ta += s_red[2][k]; tn += s_red[3][k]; }
+        int te = 0, tp = 0, ta = 0, tn = 0, tna = 0, tq = 0;
+        for (int k = 0; k < nwaves; ++k) {
+            te += s_red[0][k]; tp += s_red[1][k]; ta += s_red[2][k]; tn += s_red[3][k]; tna += s_red[4][k]; tq += s_red[5][k];
+        }
         s_base[0] = tp;                     // phar-receiver section: edges of earlier samples' phar rows
         s_base[1] = ta + (te - tp);         // pocket-receiver section starts after ALL phar-receiver edges
         s_base[2] = ta;
         s_base[3] = tn;                     // coordinate list (phar receivers, self loops dropped)
+        s_base[4] = tna + tq;               // joint mode: its pocket-receiver section, same sectioning as the full list
     }
     // exclusive scan of the degrees inside the sample (wave 0, 64 at a time)
     if (wave == 0) {
@@ -149,11 +164,12 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
         const int gi = flat_node(i, nl, pb, qb, lay.Nl);
         int off = i < nl ? s_base[0] + soff[i] : s_base[1] + (soff[i] - eph_b);
         int coff = 0;
-        if (i < nl) {
+        const bool moving = i < nl || d.joint;           // receivers whose coordinates are updated
+        if (moving) {
             int selfs = 0;
-            for (int k = lane; k < i; k += 64) selfs += (w.degL[pb + qb + k] >> 30) & 1;
+            for (int k = (i < nl ? 0 : nl) + lane; k < i; k += 64) selfs += (w.degL[pb + qb + k] >> 30) & 1;
             for (int o = 32; o > 0; o >>= 1) selfs += __shfl_xor(selfs, o);
-            coff = s_base[3] + soff[i] - selfs;
+            coff = i < nl ? s_base[3] + soff[i] - selfs : s_base[4] + (soff[i] - eph_b) - selfs;
         }
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
@@ -169,7 +185,7 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
                 w.erow[pos] = gi; w.ecol[pos] = gj; w.ed0[pos] = r2;
             }
             off += __popcll(m);
-            if (i < nl) {
+            if (moving) {
                 const unsigned long long mc = __ballot(ok && j != i);
                 if (ok && j != i) {
                     const int cpos = coff + __popcll(mc & ((1ull << lane) - 1ull));
@@ -180,7 +196,8 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
         }
     }
     if (b == lay.B - 1 && tid == 0) {
-        const int E = s_base[1] + (w.pocketE[b] - eph_b), Ec = s_base[3] + w.pocketEns[b];
+        const int E = s_base[1] + (w.pocketE[b] - eph_b);
+        const int Ec = d.joint ? s_base[4] + w.pocketEnsQ[b] : s_base[3] + w.pocketEns[b];
         w.totals[0] = E; w.totals[1] = Ec;
         atomicAdd(&w.counters[1], (unsigned long long)E);
         atomicAdd(&w.counters[2], (unsigned long long)Ec);
@@ -312,17 +329,18 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
 }
 
 // ------------------------------------------------------------------------------------
-// positions: pocket rows never move (conditional mode); phar rows of block l are
+// positions: pocket rows never move in conditional mode (Nm = Nl; in joint mode Nm = N and every row
+// moves); moving rows of block l are
 // X[l] = X[l-1] + ACC[l-1] / normalization_factor, materialised by k_node(l) and formed on
 // the fly (same expression, same bits) by k_edge_msg(l), which runs before it.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 node_pos(const Layout& lay, const Work& w, const Dims& d, int n,
                                            int layer, bool lazy) {
-    if (n >= lay.Nl) return w.XP[n - lay.Nl];
+    if (n >= lay.Nm) return w.XP[n - lay.Nl];
     if (layer == 0) return w.X0[n];
-    if (!lazy) return w.XL[(size_t)layer * lay.Nl + n];
-    const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nl + n];
-    const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nl + n];
+    if (!lazy) return w.XL[(size_t)layer * lay.Nm + n];
+    const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nm + n];
+    const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
     return make_float4(p.x + a.x / d.norm_factor, p.y + a.y / d.norm_factor, p.z + a.z / d.norm_factor, 0.f);
 }
 
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     const int nvalid = min(MT, lay.N - row0);
     const int c4 = tid % LPR, rsub = tid / LPR;
     // the chain of GEMMs of this tile; each one's last iteration fetches the next one's first fragments
-    const bool want_pc = row0 < lay.Nl;
+    const bool want_pc = row0 < lay.Nm;              // the tile holds receivers that move
     const FragPtr f3a = frag_ptr<MT>(lw.W3, 2 * H / 8, 0, wave), f3b = frag_ptr<MT>(lw.W3, 2 * H / 8, H / 8, wave);
     const FragPtr f4 = frag_ptr<MT>(lw.W4, H / 8, 0, wave);
     const FragPtr fc = frag_ptr<MT>(lw.Wpq_c, H / 8, 0, want_pc ? wave : H / 64 + wave);
@@ -498,7 +516,7 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     // materialise the phar coordinates entering this block (see node_pos)
     if (layer >= 1 && tid < MT) {
         const int n = row0 + tid;
-        if (tid < nvalid && n < lay.Nl) w.XL[(size_t)layer * lay.Nl + n] = node_pos(lay, w, d, n, layer, true);
+        if (tid < nvalid && n < lay.Nm) w.XL[(size_t)layer * lay.Nm + n] = node_pos(lay, w, d, n, layer, true);
     }
     auto load_h = [&]() {
 #pragma unroll 4
@@ -581,8 +599,9 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
 }
 
 // ------------------------------------------------------------------------------------
-// k_edge_coord: EquivariantUpdate.coord_model on the edges whose receiver is a phar node
-// (pocket rows are multiplied by update_coords_mask = 0 in the reference, egnn_new.py:100-101):
+// k_edge_coord: EquivariantUpdate.coord_model on the edges whose receiver moves: phar nodes in
+// conditional mode (pocket rows are multiplied by update_coords_mask = 0, egnn_new.py:100-101), every
+// node in joint mode (update_coords_mask = None, dynamics.py:105-107):
 //   phi = w5 . SiLU(W7 SiLU(W6 [h_i, h_j, r, d0] + b6) + b7)
 //   ACC[l][i] += (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant) * tanh(phi) * coords_range
 // ------------------------------------------------------------------------------------
@@ -639,12 +658,12 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
             for (int e = 0; e < ne; ++e) {
                 const int rr = s_row[e];
                 if (rr != cur) {
-                    atomicAdd(reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nl + cur) + tid, sum);
+                    atomicAdd(reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nm + cur) + tid, sum);
                     cur = rr; sum = 0.f;
                 }
                 sum += s_tr[e][tid];
             }
-            atomicAdd(reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nl + cur) + tid, sum);
+            atomicAdd(reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nm + cur) + tid, sum);
         }
         lds_barrier();
     }
@@ -708,10 +727,10 @@ __global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, Sma
         }
         if (l32 == 0) {
             float vx = 0.f, vy = 0.f, vz = 0.f;
-            if (ph) {
+            if (n < lay.Nm) {
                 // x_final = X[L-1] + ACC[L-1]/nf ; vel = x_final - x_input
-                const float4 p = (d.L == 1) ? w.X0[n] : w.XL[(size_t)(d.L - 1) * lay.Nl + n];
-                const float4 a = w.ACC[(size_t)(d.L - 1) * lay.Nl + n];
+                const float4 p = (d.L == 1) ? w.X0[n] : w.XL[(size_t)(d.L - 1) * lay.Nm + n];
+                const float4 a = w.ACC[(size_t)(d.L - 1) * lay.Nm + n];
                 const float4 x0 = w.X0[n];
                 vx = (p.x + a.x / d.norm_factor) - x0.x;
                 vy = (p.y + a.y / d.norm_factor) - x0.y;
@@ -731,6 +750,35 @@ __global__ void k_nan_fix(Layout lay, Work w, Dims d, float* __restrict__ eps_ph
         float* o = eps_phar + (size_t)n * (3 + d.P);
         o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
     }
+}
+
+// Joint mode tail of EGNNDynamics.forward (dynamics.py:129-136): the batch-global NaN reset, then
+// remove_mean_batch(vel, mask) over ALL nodes of each sample.  One wave per sample; the sum runs in
+// index order (phar rows, then pocket rows) like the reference's scatter_add.
+__global__ __launch_bounds__(64) void k_vel_com(Layout lay, Work w, Dims d, float* __restrict__ eps_phar,
+                                                float* __restrict__ eps_pocket) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int nl = lay.num_phar[b], np = lay.num_pocket[b];
+    const int ldp = 3 + d.P, ldq = 3 + d.R;
+    float* vp = eps_phar + (size_t)lay.phar_base[b] * ldp;
+    float* vq = eps_pocket + (size_t)lay.pocket_base[b] * ldq;
+    const bool nan_reset = *w.nan_flag != 0;
+    if (b == 0 && lane == 0 && nan_reset) atomicAdd(&w.counters[4], 1ull);
+    if (nan_reset) {
+        for (int i = lane; i < nl; i += 64) { vp[i * ldp] = 0.f; vp[i * ldp + 1] = 0.f; vp[i * ldp + 2] = 0.f; }
+        for (int i = lane; i < np; i += 64) { vq[i * ldq] = 0.f; vq[i * ldq + 1] = 0.f; vq[i * ldq + 2] = 0.f; }
+    }
+    __syncthreads();
+    float mean = 0.f;
+    if (lane < 3) {
+        float s = 0.f;
+        for (int i = 0; i < nl; ++i) s += vp[i * ldp + lane];
+        for (int i = 0; i < np; ++i) s += vq[i * ldq + lane];
+        mean = s / fmaxf((float)(nl + np), 1.0f);
+    }
+    const float m0 = __shfl(mean, 0), m1 = __shfl(mean, 1), m2 = __shfl(mean, 2);
+    for (int i = lane; i < nl; i += 64) { vp[i * ldp] -= m0; vp[i * ldp + 1] -= m1; vp[i * ldp + 2] -= m2; }
+    for (int i = lane; i < np; i += 64) { vq[i * ldq] -= m0; vq[i * ldq + 1] -= m1; vq[i * ldq + 2] -= m2; }
 }
 
 // ------------------------------------------------------------------------------------
@@ -787,6 +835,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     const int nn = eps_pocket ? N : a.lay.Nl;
     hipLaunchKernelGGL(k_readout, dim3((nn + 7) / 8), dim3(256), (8 + a.d.dyn) * a.d.H * sizeof(float), s, a.lay, a.w, a.d, a.sw,
                        eps_phar, eps_pocket);
+    if (a.d.joint) hipLaunchKernelGGL(k_vel_com, dim3(B), dim3(64), 0, s, a.lay, a.w, a.d, eps_phar, eps_pocket);
     REC();
 #undef REC
 #undef PROF

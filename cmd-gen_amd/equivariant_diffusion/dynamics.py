@@ -46,7 +46,7 @@ class EGNNDynamics(nn.Module):
                          condition_time=condition_time, edge_cutoff=edge_cutoff, norm_constant=norm_constant,
                          normalization_factor=normalization_factor, aggregation_method=aggregation_method,
                          sin_embedding=sin_embedding, coords_range=self.egnn.coords_range,
-                         timesteps=1, norm_values=(1.0, 1.0), norm_biases=(None, 0.0))
+                         update_pocket_coords=bool(update_pocket_coords), timesteps=1, norm_values=(1.0, 1.0), norm_biases=(None, 0.0))
         self._gamma = np.zeros(2, dtype=np.float32)
         self._handle = None
         self._weights_sig = None
@@ -68,9 +68,6 @@ class EGNNDynamics(nn.Module):
         if p0.device.type != 'cuda':
             raise hip_backend.CmdgenError(
                 'EGNNDynamics runs on MI355X only: move the module to cuda (there is no CPU fallback)')
-        if self.update_pocket_coords:
-            raise NotImplementedError("joint mode (update_pocket_coords=True) is not built yet; the shipped "
-                                      "configs all use mode 'pocket_conditioning'")
         idx = p0.device.index if p0.device.index is not None else torch.cuda.current_device()
         if self._handle is None or self._handle.device_index != idx:
             self._handle = hip_backend.Handle(self._cfg, idx)

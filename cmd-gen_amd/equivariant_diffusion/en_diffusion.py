@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import utils
 from ..synthetic import gamma_table
 
 
@@ -76,11 +77,12 @@ class DistributionNodes:
 
 
 class EnVariationalDiffusion(nn.Module):
-    """Schedule algebra shared by the diffusion variants (en_diffusion.py:13-103, :849-906).
-
-    The joint sampler / RePaint inpainting of the reference's base class
-    (en_diffusion.py:576-831) is a later scope row; every shipped
-    config uses the conditional subclass."""
+    """The joint model (mode 'joint'): schedule algebra shared by the diffusion variants
+    (en_diffusion.py:13-103, :849-906) plus the joint sampler and RePaint inpainting
+    (en_diffusion.py:576-831), which run as cmdgen_joint_chain on the device.  Needs dynamics built with
+    update_pocket_coords=True (lightning_modules.py:125).  The subclass ConditionalDDPM replaces the
+    samplers with the pocket-conditioned one (every shipped config uses that)."""
+    use_hip_graph = True
 
     def __init__(self, dynamics: nn.Module, phar_nf: int, residue_nf: int, n_dims: int,
                  size_histogram: Dict, timesteps: int = 1000, parametrization='eps',
@@ -178,8 +180,120 @@ class EnVariationalDiffusion(nn.Module):
     def subspace_dimensionality(self, input_size):
         return (input_size - 1) * self.n_dims
 
-    def sample(self, *args, **kwargs):
-        raise NotImplementedError('joint sampling (en_diffusion.py:576-647) is not built yet (SURVEY 8f #2)')
+    # ---- joint sampler / RePaint inpainting (en_diffusion.py:576-831)
+    def get_repaint_schedule(self, resamplings, jump_length, timesteps):
+        """How many denoising steps to apply before each jump back (en_diffusion.py:649-670)."""
+        repaint_schedule = []
+        curr_t = 0
+        while curr_t < timesteps:
+            if curr_t + jump_length < timesteps:
+                if len(repaint_schedule) > 0:
+                    repaint_schedule[-1] += jump_length
+                    repaint_schedule.extend([jump_length] * (resamplings - 1))
+                else:
+                    repaint_schedule.extend([jump_length] * resamplings)
+                curr_t += jump_length
+            else:
+                residual = timesteps - curr_t
+                if len(repaint_schedule) > 0:
+                    repaint_schedule[-1] += residual
+                else:
+                    repaint_schedule.append(residual)
+                curr_t += residual
+        return list(reversed(repaint_schedule))
 
-    def inpaint(self, *args, **kwargs):
-        raise NotImplementedError('RePaint inpainting (en_diffusion.py:672-831) is not built yet (SURVEY 8f #2)')
+    def _joint_handle(self, nph, npk):
+        if not getattr(self.dynamics, 'update_pocket_coords', False):
+            raise ValueError("the joint sampler needs EGNNDynamics(update_pocket_coords=True) (mode 'joint', "
+                             "lightning_modules.py:125)")
+        h = self.dynamics.hip_handle()
+        h.set_layout(nph, npk)
+        return h
+
+    def _finish_joint(self, h, xh_phar, xh_pocket, z_steps, frame_of_step, return_frames):
+        st = h.chain_status()
+        self.last_chain_status = st
+        assert st['max_rel_com_error'] < 1e-2, f"Mean is not zero, relative_error {st['max_rel_com_error']}"
+        if st['nan_resets']:
+            print('Warning: detected nan, resetting EGNN output to zero.')
+        if st['max_cog'] > 5e-2 and return_frames == 1:
+            print(f"Warning CoG drift with error {st['max_cog']:.3f}. Projecting the positions down.")
+        if return_frames == 1:
+            return xh_phar, xh_pocket
+        # frames (en_diffusion.py:619-623 / :786-791): slot idx <- unnormalize_z(z after that step); slot 0 <- the result
+        out_phar = torch.zeros((return_frames,) + tuple(xh_phar.shape), device=xh_phar.device)
+        out_pocket = torch.zeros((return_frames,) + tuple(xh_pocket.shape), device=xh_phar.device)
+        nl = xh_phar.shape[0] * xh_phar.shape[1]
+        for step, idx in frame_of_step:
+            zp = z_steps[step, :nl].view_as(xh_phar)
+            zq = z_steps[step, nl:].view_as(xh_pocket)
+            out_phar[idx], out_pocket[idx] = self.unnormalize_z(zp, zq)
+        out_phar[0], out_pocket[0] = xh_phar, xh_pocket
+        return out_phar, out_pocket
+
+    @torch.no_grad()
+    def sample(self, n_samples, num_nodes_phar, num_nodes_pocket, return_frames=1, timesteps=None,
+               device='cuda', noise=None, seed=None, pocket_ids=None):
+        """Draw phar AND pocket nodes from the joint model (en_diffusion.py:576-647).
+
+        Extensions: ``noise`` [n_draws, Nl*(3+phar_nf) + Np*(3+residue_nf)] combined Gaussian draws to inject
+        (layout of cmdgen_joint_chain), ``seed`` / ``pocket_ids`` for the on-device Philox draws."""
+        timesteps = self.T if timesteps is None else timesteps
+        assert 0 < return_frames <= timesteps
+        assert timesteps % return_frames == 0
+        nph = torch.as_tensor(num_nodes_phar).detach().to('cpu', torch.int64).numpy()
+        npk = torch.as_tensor(num_nodes_pocket).detach().to('cpu', torch.int64).numpy()
+        assert len(nph) == n_samples and len(npk) == n_samples
+        h = self._joint_handle(nph, npk)
+        dev = next(self.dynamics.parameters()).device
+        if noise is not None:
+            noise = noise.detach().to(dev, torch.float32).contiguous()
+        xh_phar, xh_pocket, z_steps = h.joint_chain(
+            timesteps, noise=noise, seed=torch.initial_seed() if seed is None else seed, pocket_ids=pocket_ids,
+            want_steps=return_frames > 1, use_graph=self.use_hip_graph, device=dev)
+        frames = [(timesteps - 1 - s, (s * return_frames) // timesteps) for s in range(timesteps)
+                  if (s * return_frames) % timesteps == 0]
+        out = self._finish_joint(h, xh_phar, xh_pocket, z_steps, frames, return_frames)
+        phar_mask = utils.num_nodes_to_batch_mask(n_samples, torch.as_tensor(nph), dev)
+        pocket_mask = utils.num_nodes_to_batch_mask(n_samples, torch.as_tensor(npk), dev)
+        return out[0], out[1], phar_mask, pocket_mask
+
+    @torch.no_grad()
+    def inpaint(self, phar, pocket, phar_fixed, pocket_fixed, resamplings=1, jump_length=1, return_frames=1,
+                timesteps=None, noise=None, seed=None, pocket_ids=None):
+        """RePaint: sample while fixing parts of the input (en_diffusion.py:672-831).  As in the reference the
+        inputs are used raw (no normalize call there).  Extensions: noise / seed / pocket_ids as in sample()."""
+        timesteps = self.T if timesteps is None else timesteps
+        assert 0 < return_frames <= timesteps
+        assert timesteps % return_frames == 0
+        assert jump_length == 1 or return_frames == 1, "Chain visualization is only implemented for jump_length=1"
+        dev = pocket['x'].device
+        nph = phar['size'].detach().to('cpu', torch.int64).numpy()
+        npk = pocket['size'].detach().to('cpu', torch.int64).numpy()
+        for m in (phar['mask'], pocket['mask']):
+            if m.numel() > 1 and bool((m[1:] < m[:-1]).any()):
+                raise ValueError('batch masks must be ascending and contiguous')
+        h = self._joint_handle(nph, npk)
+        f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()
+        if noise is not None:
+            noise = f32(noise)
+        xh_phar, xh_pocket, z_steps = h.joint_chain(
+            timesteps, phar=(f32(phar['x']), f32(phar['one_hot'])), pocket=(f32(pocket['x']), f32(pocket['one_hot'])),
+            phar_fixed=f32(phar_fixed).reshape(-1), pocket_fixed=f32(pocket_fixed).reshape(-1),
+            resamplings=resamplings, jump_length=jump_length, noise=noise,
+            seed=torch.initial_seed() if seed is None else seed, pocket_ids=pocket_ids,
+            want_steps=return_frames > 1, use_graph=self.use_hip_graph)
+        frames = []
+        if return_frames > 1:       # walk the schedule as :723-813 do, noting which steps write a frame
+            schedule = self.get_repaint_schedule(resamplings, jump_length, timesteps)
+            s, step = timesteps - 1, 0
+            for i, n_denoise_steps in enumerate(schedule):
+                for j in range(n_denoise_steps):
+                    if (n_denoise_steps > jump_length or i == len(schedule) - 1) and (s * return_frames) % timesteps == 0:
+                        frames.append((step, (s * return_frames) // timesteps))
+                    if j == n_denoise_steps - 1 and i < len(schedule) - 1:
+                        s = s + jump_length
+                    s -= 1
+                    step += 1
+        out = self._finish_joint(h, xh_phar, xh_pocket, z_steps, frames, return_frames)
+        return out[0], out[1], phar['mask'], pocket['mask']

@@ -22,7 +22,7 @@ class CmdgenError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'phar_nf', 'residue_nf', 'joint_nf', 'hidden_nf', 'n_layers', 'inv_sublayers',
-        'attention', 'tanh', 'condition_time', 'timesteps', 'no_com_projection')] + \
+        'attention', 'tanh', 'condition_time', 'timesteps', 'no_com_projection', 'update_pocket_coords')] + \
         [(n, C.c_float) for n in ('edge_cutoff', 'norm_constant', 'normalization_factor',
                                   'coords_range', 'norm_x', 'norm_h', 'bias_h')]
 
@@ -54,6 +54,9 @@ SYMBOLS = [
     ('cmdgen_debug_noise', C.c_int, [_vp, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _fp, _vp]),
     ('cmdgen_sample_chain', C.c_int, [_vp, _fp, _fp, C.c_int32, _fp, C.c_uint64, _i64p, _fp, _fp, _fp, _fp,
                                       C.c_int32, _vp]),
+    ('cmdgen_joint_chain', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int64,
+                                     C.c_uint64, _i64p, _fp, _fp, _fp, C.c_int32, _vp]),
+    ('cmdgen_joint_plan', C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i64p, _i64p]),
     ('cmdgen_set_step_table', C.c_int, [_vp, C.c_int32, _vp]),
     ('cmdgen_chain_status', C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i64p, _vp]),
     ('cmdgen_get_counters', C.c_int, [_vp, C.POINTER(Counters), _vp]),
@@ -108,6 +111,7 @@ class Handle:
         c.condition_time = int(bool(cfg.get('condition_time', True)))
         c.timesteps = int(cfg['timesteps'])
         c.no_com_projection = int(bool(cfg.get('no_com_projection', False)))
+        c.update_pocket_coords = int(bool(cfg.get('update_pocket_coords', False)))
         ec = cfg.get('edge_cutoff')
         c.edge_cutoff = -1.0 if ec is None else float(ec)
         c.norm_constant = float(cfg['norm_constant'])
@@ -244,6 +248,49 @@ class Handle:
             self.h, _ptr(pocket_x), _ptr(pocket_onehot), int(timesteps), _ptr(noise), C.c_uint64(seed & (2 ** 64 - 1)),
             ids.ctypes.data_as(_i64p) if ids is not None else None, _ptr(xh_phar), _ptr(xh_pocket),
             _ptr(z_steps), _ptr(p_steps), int(bool(use_graph)), self._stream()), 'cmdgen_sample_chain')
+        return xh_phar, xh_pocket, z_steps
+
+    def joint_plan(self, timesteps: int, resamplings: int = 1, jump_length: int = 1, inpaint: bool = True):
+        """(denoising steps, combined noise draws) of a joint chain."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.cmdgen_joint_plan(self.h, int(timesteps), int(resamplings), int(jump_length),
+                                               int(bool(inpaint)), C.byref(a), C.byref(b)), 'cmdgen_joint_plan')
+        return a.value, b.value
+
+    def joint_chain(self, timesteps: int, phar=None, pocket=None, phar_fixed=None, pocket_fixed=None,
+                    resamplings: int = 1, jump_length: int = 1, noise=None, seed: int = 0,
+                    pocket_ids: Optional[Sequence[int]] = None, want_steps: bool = False, use_graph: bool = True,
+                    device=None):
+        """EnVariationalDiffusion.sample (no fixed masks) / .inpaint.  phar / pocket: (x [n,3], one_hot [n,F]) device
+        tensors (inpainting only); *_fixed: float [n] device tensors."""
+        import torch
+        P, R = self.cfg['phar_nf'], self.cfg['residue_nf']
+        inpaint = phar_fixed is not None or pocket_fixed is not None
+        row = self.n_phar * (3 + P) + self.n_pocket * (3 + R)
+        n_steps, n_draws = self.joint_plan(timesteps, resamplings, jump_length, inpaint)
+        ptrs = [None] * 6
+        if inpaint:
+            ptrs = [phar[0], phar[1], pocket[0], pocket[1], phar_fixed, pocket_fixed]
+            shapes = [(self.n_phar, 3), (self.n_phar, P), (self.n_pocket, 3), (self.n_pocket, R), (self.n_phar,), (self.n_pocket,)]
+            for t, sh in zip(ptrs, shapes):
+                assert t is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == sh, sh
+            device = ptrs[0].device
+        dev = device if device is not None else torch.device('cuda', self.device_index)
+        if noise is not None:
+            assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
+            assert noise.dim() == 2 and noise.shape[1] == row and noise.shape[0] >= n_draws, (noise.shape, n_draws, row)
+        xh_phar = torch.empty((self.n_phar, 3 + P), dtype=torch.float32, device=dev)
+        xh_pocket = torch.empty((self.n_pocket, 3 + R), dtype=torch.float32, device=dev)
+        z_steps = torch.empty((n_steps, row), dtype=torch.float32, device=dev) if want_steps else None
+        ids = None
+        if pocket_ids is not None:
+            ids = np.ascontiguousarray(np.asarray(pocket_ids, dtype=np.int64))
+            assert len(ids) == self.batch
+        self._check(self.lib.cmdgen_joint_chain(
+            self.h, *[_ptr(t) for t in ptrs], int(timesteps), int(resamplings), int(jump_length), _ptr(noise),
+            int(noise.shape[0]) if noise is not None else 0, C.c_uint64(seed & (2 ** 64 - 1)),
+            ids.ctypes.data_as(_i64p) if ids is not None else None, _ptr(xh_phar), _ptr(xh_pocket), _ptr(z_steps),
+            int(bool(use_graph)), self._stream()), 'cmdgen_joint_chain')
         return xh_phar, xh_pocket, z_steps
 
     def chain_status(self):

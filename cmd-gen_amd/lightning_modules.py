@@ -45,9 +45,6 @@ class PharPocketDDPM(nn.Module):
         ddpm_models = {'joint': EnVariationalDiffusion, 'pocket_conditioning': ConditionalDDPM,
                        'pocket_conditioning_simple': SimpleConditionalDDPM}
         assert mode in ddpm_models
-        if mode == 'joint':
-            raise NotImplementedError("mode 'joint' (EnVariationalDiffusion sample/inpaint) is not built yet; all shipped "
-                                      "configs use 'pocket_conditioning'")
         self.mode = mode
         assert pocket_representation in {'CA', 'full-atom'}
         self.pocket_representation = pocket_representation
@@ -218,9 +215,10 @@ class PharPocketDDPM(nn.Module):
 
         pocket_ids: residues as '<chain>:<resi>'; ref_ligand: '<chain>:<resi>' alternative.
         sanitize / largest_frag / relax_iter and the inpainting kwargs are accepted and have no
-        effect in conditional mode, as in the reference (quirk Q10)."""
+        effect in conditional mode, as in the reference (quirk Q10); in mode 'joint' the kwargs
+        (resamplings, jump_length) go to EnVariationalDiffusion.inpaint (lightning_modules.py:466-486)."""
         assert (pocket_ids is None) ^ (ref_ligand is None)
-        sampler_kw = {k: kwargs[k] for k in ('noise', 'seed') if k in kwargs}
+        sampler_kw = {k: kwargs.pop(k) for k in ('noise', 'seed') if k in kwargs}
         pdb_struct = utils.parse_pdb(pdb_file)
         if pocket_ids is not None:
             residues = [pdb_struct[x.split(':')[0]][(' ', int(x.split(':')[1]), ' ')] for x in pocket_ids]
@@ -246,7 +244,18 @@ class PharPocketDDPM(nn.Module):
         pocket_com_before = _scatter_mean(pocket['x'], pocket['mask'], n_samples)
         if num_nodes_phar is None:
             num_nodes_phar = self.ddpm.size_distribution.sample_conditional(n1=None, n2=pocket['size'])
-        if isinstance(self.ddpm, ConditionalDDPM):
+        if type(self.ddpm) == EnVariationalDiffusion:
+            # inpainting: every pocket node is fixed, every phar node is generated (lightning_modules.py:466-486)
+            num_nodes_phar = torch.as_tensor(num_nodes_phar, device=self.device)
+            phar_mask = utils.num_nodes_to_batch_mask(len(num_nodes_phar), num_nodes_phar, self.device)
+            phar = {'x': torch.zeros((len(phar_mask), self.x_dims), device=self.device, dtype=FLOAT_TYPE),
+                    'one_hot': torch.zeros((len(phar_mask), self.phar_nf), device=self.device, dtype=FLOAT_TYPE),
+                    'size': num_nodes_phar, 'mask': phar_mask}
+            phar_mask_fixed = torch.zeros(len(phar_mask), device=self.device)
+            pocket_mask_fixed = torch.ones(len(pocket['mask']), device=self.device)
+            xh_phar, xh_pocket, phar_mask, pocket_mask = self.ddpm.inpaint(
+                phar, pocket, phar_mask_fixed, pocket_mask_fixed, timesteps=timesteps, **sampler_kw, **kwargs)
+        elif isinstance(self.ddpm, ConditionalDDPM):
             xh_phar, xh_pocket, phar_mask, pocket_mask = self.ddpm.sample_given_pocket(
                 pocket, num_nodes_phar, timesteps=timesteps, **sampler_kw)
         else:

@@ -60,6 +60,9 @@ typedef struct cmdgen_config {
     int32_t timesteps;             /* T of the gamma table (500) */
     int32_t no_com_projection;     /* 0; 1 = SimpleConditionalDDPM (conditional_model.py:481-525): pocket centred once,
                                       no centre-of-mass projection of the samples */
+    int32_t update_pocket_coords;  /* 0; 1 = mode 'joint' (lightning_modules.py:125, dynamics.py:105-107, :133-136):
+                                      pocket nodes move too and the velocity's centre of mass is removed;
+                                      required by cmdgen_joint_chain */
     float   edge_cutoff;           /* 6.0; < 0 means no cutoff (complete graph per sample) */
     float   norm_constant;         /* 1  */
     float   normalization_factor;  /* 100 ('sum' aggregation only) */
@@ -111,7 +114,8 @@ int cmdgen_set_layout(cmdgen_handle* h, int64_t batch,
                       const int64_t* num_phar_host, const int64_t* num_pocket_host);
 
 /* ---- one network evaluation ------------------------------------------------------- */
-/* EGNNDynamics.forward (dynamics.py:75-139), conditional mode.
+/* EGNNDynamics.forward (dynamics.py:75-139); conditional mode, or joint mode when
+ * config.update_pocket_coords = 1 (then eps_pocket is required: its x columns are the pocket velocity).
  *   xh_phar   dev [Nl, 3+phar_nf]      xh_pocket dev [Np, 3+residue_nf]
  *   t         dev [batch]              (the reference's [B,1]; a single-sample batch uses t[0])
  *   eps_phar  dev [Nl, 3+phar_nf]  out
@@ -163,6 +167,37 @@ int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, const float* po
                         const int64_t* pocket_ids_host,
                         float* xh_phar_out, float* xh_pocket_out, float* z_steps_out,
                         float* pocket_steps_out, int32_t use_graph, cmdgen_stream stream);
+
+/* The JOINT model's loops (config.update_pocket_coords = 1), return_frames=1:
+ *   phar_fixed == NULL && pocket_fixed == NULL: EnVariationalDiffusion.sample (en_diffusion.py:576-647) -
+ *       phar AND pocket nodes start from noise; phar_x/phar_onehot/pocket_x/pocket_onehot are ignored (may be NULL).
+ *   otherwise: EnVariationalDiffusion.inpaint (en_diffusion.py:672-831), RePaint with the schedule of
+ *       get_repaint_schedule(resamplings, jump_length, timesteps) (:649-670).  generate_phars' inpainting
+ *       branch (lightning_modules.py:466-486) passes phar_x = 0, phar_onehot = 0, phar_fixed = 0, pocket_fixed = 1.
+ *   phar_x dev [Nl,3], phar_onehot dev [Nl,phar_nf], pocket_x dev [Np,3], pocket_onehot dev [Np,residue_nf]:
+ *       used RAW - the reference's inpaint never calls normalize (quirk kept);
+ *   phar_fixed dev [Nl], pocket_fixed dev [Np]: 1.0 = known node, 0.0 = node to generate;
+ *   noise  dev [n_draws][Nl*(3+phar_nf) + Np*(3+residue_nf)] or NULL (Philox on the device).  One row per
+ *       sample_combined_position_feature_noise call (:555-574) in the reference's call order: the phar block
+ *       [Nl,3+phar_nf] then the pocket block [Np,3+residue_nf]; x columns hold the raw draw (the centre-of-mass
+ *       projection is applied inside).  Draws: 1 (z_T) + per denoising step [1 if inpainting: known part] + 1
+ *       + [1 if the step is followed by a jump back] + 1 (final decode);
+ *   n_draws  rows available in `noise` (checked against the schedule; ignored when noise == NULL);
+ *   xh_phar_out dev [Nl,3+phar_nf], xh_pocket_out dev [Np,3+residue_nf]: x, one-hot h (floats);
+ *   z_steps_out dev [n_steps][Nl*(3+phar_nf) + Np*(3+residue_nf)] or NULL: z after every denoising step
+ *       (after the known/unknown merge, before any jump back); n_steps = sum of the schedule.
+ * Asynchronous on `stream`; cmdgen_chain_status reports the deferred mean-zero checks / CoG drift. */
+int cmdgen_joint_chain(cmdgen_handle* h, const float* phar_x, const float* phar_onehot,
+                       const float* pocket_x, const float* pocket_onehot,
+                       const float* phar_fixed, const float* pocket_fixed,
+                       int32_t timesteps, int32_t resamplings, int32_t jump_length,
+                       const float* noise, int64_t n_draws, uint64_t seed, const int64_t* pocket_ids_host,
+                       float* xh_phar_out, float* xh_pocket_out, float* z_steps_out,
+                       int32_t use_graph, cmdgen_stream stream);
+
+/* Number of denoising steps (= network evaluations - 1) and of combined noise draws cmdgen_joint_chain will use. */
+int cmdgen_joint_plan(cmdgen_handle* h, int32_t timesteps, int32_t resamplings, int32_t jump_length,
+                      int32_t inpaint, int64_t* n_steps, int64_t* n_draws);
 
 /* Optional: supply the per-step scalars of sample_p_zs_given_zt computed by the host
  * (e.g. with the same torch fp32 ops as the reference, bit for bit) instead of the

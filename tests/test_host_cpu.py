@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol():
     bound = {n for n, _, _ in hip_backend.SYMBOLS}
     assert declared == bound, declared ^ bound
     assert b'gfx950' in lib.cmdgen_version()
-    assert ctypes.sizeof(hip_backend.Config) == 18 * 4 and ctypes.sizeof(hip_backend.Counters) == 64
+    assert ctypes.sizeof(hip_backend.Config) == 19 * 4 and ctypes.sizeof(hip_backend.Counters) == 64
 
 
 def test_product_fails_loudly_without_gpu():
@@ -165,8 +165,11 @@ def test_checkpoint_round_trip_lightning_format(tmp_path):
     for k, v in model.state_dict().items():
         assert torch.equal(v, again.state_dict()[k])
     assert again.T == 500 and again.phar_nf == 8 and again.aa_nf == 20
-    with pytest.raises(NotImplementedError):
-        PharPocketDDPM(**{**_hparams(), 'mode': 'joint'})
+    # mode 'joint' builds the base diffusion class over dynamics that also move the pocket (lightning_modules.py:110-139)
+    jm = PharPocketDDPM(**{**_hparams(), 'mode': 'joint'})
+    assert type(jm.ddpm).__name__ == 'EnVariationalDiffusion' and jm.ddpm.dynamics.update_pocket_coords
+    assert set(jm.state_dict()) == set(model.state_dict())
+    assert jm.ddpm.get_repaint_schedule(2, 2, 6) == [4, 4, 2]            # en_diffusion.py:649-670 (G9 schedule/r2_j2_T6)
 
 
 def test_generate_phars_bookkeeping_with_stub_sampler(tmp_path, monkeypatch):
