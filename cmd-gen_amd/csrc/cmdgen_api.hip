@@ -385,7 +385,8 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
             const double n = (double)(nph[b] + npk[b]);
             const double deg = h->cfg.edge_cutoff < 0.f ? n : (n <= 128.0 ? 6.0 : 36.0);
             e_est += n * (deg < n ? deg : n);
-            ec_est += (double)(d.joint ? n : nph[b]) * (deg < n ? deg : n) * 0.5;
+            ec_est += d.joint ? n * (deg < n ? deg : n)                       // joint: every receiver moves
+                              : (double)nph[b] * (deg < n ? deg : n) * 0.5;
         }
         // thresholds from sweeps on MI355X (profiles/r01_tile_sweep.txt)
         auto pick = [&](double rows) { return rows / 64.0 >= 3.0 * h->n_cus ? 64 : (rows / 32.0 >= 1.5 * h->n_cus ? 32 : 16); };
