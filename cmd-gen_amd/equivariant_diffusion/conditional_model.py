@@ -37,26 +37,6 @@ class ConditionalDDPM(EnVariationalDiffusion):
     # ---- loss terms (conditional_model.py:20-106, :158-320).  VALUES only: the network evaluation runs in
     # the HIP library, which has no backward pass yet, so nothing here carries gradients (training is the
     # next scope row).  The scalar algebra around the evaluation is host torch.
-    @staticmethod
-    def _seg_sum(x, idx, n):
-        return torch.zeros((n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device).index_add_(0, idx, x)
-
-    def sum_except_batch(self, x, indices, n):
-        return self._seg_sum(x.sum(-1), indices, n)
-
-    @staticmethod
-    def cdf_standard_gaussian(x):
-        return 0.5 * (1. + torch.erf(x / math.sqrt(2)))
-
-    @staticmethod
-    def gaussian_KL(q_mu_minus_p_mu_squared, q_sigma, p_sigma, d):
-        return d * torch.log(p_sigma / q_sigma) + 0.5 * (d * q_sigma ** 2 + q_mu_minus_p_mu_squared) / \
-            (p_sigma ** 2) - 0.5 * d
-
-    @staticmethod
-    def sample_gaussian(size, device):
-        return torch.randn(size, device=device)
-
     def noised_representation(self, xh_phar, xh0_pocket, phar_mask, pocket_mask, gamma_t, eps=None):
         alpha_t, sigma_t = self.alpha(gamma_t, xh_phar), self.sigma(gamma_t, xh_phar)
         eps_phar = self.sample_gaussian((len(phar_mask), self.n_dims + self.phar_nf), phar_mask.device) \
@@ -78,12 +58,6 @@ class ConditionalDDPM(EnVariationalDiffusion):
                                 self.subspace_dimensionality(num_nodes))
         return kl_x + kl_h
 
-    def log_constants_p_x_given_z0(self, n_nodes, device):
-        B = len(n_nodes)
-        gamma_0 = self.gamma(torch.zeros((B, 1), device=device))
-        log_sigma_x = 0.5 * gamma_0.view(B)
-        return self.subspace_dimensionality(n_nodes) * (-log_sigma_x - 0.5 * np.log(2 * np.pi))
-
     def log_pxh_given_z0_without_constants(self, phar, z_0_phar, eps_phar, net_out_phar, gamma_0, epsilon=1e-10):
         nd, B = self.n_dims, len(phar['size'])
         sigma_0_cat = self.sigma(gamma_0, target_tensor=z_0_phar) * self.norm_values[1]
@@ -97,13 +71,6 @@ class ConditionalDDPM(EnVariationalDiffusion):
 
     def log_pN(self, N_phar, N_pocket):
         return self.size_distribution.log_prob_n1_given_n2(N_phar, N_pocket)
-
-    def delta_log_px(self, num_nodes):
-        return -self.subspace_dimensionality(num_nodes) * np.log(self.norm_values[0])
-
-    def xh_given_zt_and_epsilon(self, z_t, epsilon, gamma_t, batch_mask):
-        alpha_t, sigma_t = self.alpha(gamma_t, z_t), self.sigma(gamma_t, z_t)
-        return z_t / alpha_t[batch_mask] - epsilon * sigma_t[batch_mask] / alpha_t[batch_mask]
 
     @torch.no_grad()
     def forward(self, phar, pocket, return_info=False, t_int=None, eps=None):

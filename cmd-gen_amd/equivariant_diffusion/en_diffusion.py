@@ -9,6 +9,7 @@ and never sit on the per-step critical path.
 """
 from __future__ import annotations
 
+import math
 from typing import Dict
 
 import numpy as np
@@ -179,6 +180,157 @@ class EnVariationalDiffusion(nn.Module):
 
     def subspace_dimensionality(self, input_size):
         return (input_size - 1) * self.n_dims
+
+    # ---- loss algebra shared with ConditionalDDPM (en_diffusion.py:153-179, :328-330, :467-473, :834-847, :939-949)
+    @staticmethod
+    def _seg_sum(x, idx, n):
+        return torch.zeros((n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device).index_add_(0, idx, x)
+
+    def sum_except_batch(self, x, indices, n):
+        return self._seg_sum(x.sum(-1), indices, n)
+
+    @staticmethod
+    def cdf_standard_gaussian(x):
+        return 0.5 * (1. + torch.erf(x / math.sqrt(2)))
+
+    @staticmethod
+    def gaussian_KL(q_mu_minus_p_mu_squared, q_sigma, p_sigma, d):
+        return d * torch.log(p_sigma / q_sigma) + 0.5 * (d * q_sigma ** 2 + q_mu_minus_p_mu_squared) / \
+            (p_sigma ** 2) - 0.5 * d
+
+    @staticmethod
+    def sample_gaussian(size, device):
+        return torch.randn(size, device=device)
+
+    def log_constants_p_x_given_z0(self, n_nodes, device):
+        B = len(n_nodes)
+        gamma_0 = self.gamma(torch.zeros((B, 1), device=device))
+        log_sigma_x = 0.5 * gamma_0.view(B)
+        return self.subspace_dimensionality(n_nodes) * (-log_sigma_x - 0.5 * np.log(2 * np.pi))
+
+    def delta_log_px(self, num_nodes):
+        return -self.subspace_dimensionality(num_nodes) * np.log(self.norm_values[0])
+
+    def xh_given_zt_and_epsilon(self, z_t, epsilon, gamma_t, batch_mask):
+        alpha_t, sigma_t = self.alpha(gamma_t, z_t), self.sigma(gamma_t, z_t)
+        return z_t / alpha_t[batch_mask] - epsilon * sigma_t[batch_mask] / alpha_t[batch_mask]
+
+    # ---- the joint model's loss terms (en_diffusion.py:105-151, :181-257, :298-326, :332-465), VALUES only
+    def sample_combined_position_feature_noise(self, phar_mask, pocket_mask, eps=None):
+        """x noise for all nodes (COM-projected per sample) + feature noise (en_diffusion.py:555-574, :927-937).
+        ``eps`` = (raw phar block [Nl, 3+phar_nf], raw pocket block [Np, 3+residue_nf]) to inject a draw."""
+        nd, dev = self.n_dims, phar_mask.device
+        nl, B = len(phar_mask), int(max(int(phar_mask.max()), int(pocket_mask.max()))) + 1
+        if eps is None:
+            zx = self.sample_gaussian((nl + len(pocket_mask), nd), dev)
+            zh_l = self.sample_gaussian((nl, self.phar_nf), dev)
+            zh_p = self.sample_gaussian((len(pocket_mask), self.residue_nf), dev)
+        else:
+            zx = torch.cat([eps[0][:, :nd], eps[1][:, :nd]]).to(dev)
+            zh_l, zh_p = eps[0][:, nd:].to(dev), eps[1][:, nd:].to(dev)
+        comb = torch.cat((phar_mask, pocket_mask))
+        cnt = self._seg_sum(torch.ones(len(comb), device=dev), comb, B).clamp(min=1)
+        zx = zx - (self._seg_sum(zx, comb, B) / cnt[:, None])[comb]
+        return torch.cat([zx[:nl], zh_l], dim=1), torch.cat([zx[nl:], zh_p], dim=1)
+
+    def noised_representation(self, xh_phar, xh_pocket, phar_mask, pocket_mask, gamma_t, eps=None):
+        alpha_t, sigma_t = self.alpha(gamma_t, xh_phar), self.sigma(gamma_t, xh_phar)
+        eps_phar, eps_pocket = self.sample_combined_position_feature_noise(phar_mask, pocket_mask, eps)
+        z_t_phar = alpha_t[phar_mask] * xh_phar + sigma_t[phar_mask] * eps_phar
+        z_t_pocket = alpha_t[pocket_mask] * xh_pocket + sigma_t[pocket_mask] * eps_pocket
+        return z_t_phar, z_t_pocket, eps_phar, eps_pocket
+
+    def kl_prior_with_pocket(self, xh_phar, xh_pocket, mask_phar, mask_pocket, num_nodes):
+        B, nd = len(num_nodes), self.n_dims
+        gamma_T = self.gamma(torch.ones((B, 1), device=xh_phar.device))
+        alpha_T = self.alpha(gamma_T, xh_phar)
+        mu_l, mu_p = alpha_T[mask_phar] * xh_phar, alpha_T[mask_pocket] * xh_pocket
+        sigma_T = self.sigma(gamma_T, mu_l).squeeze()
+        one = torch.ones_like(sigma_T)
+        kl_h = self.gaussian_KL(self.sum_except_batch(mu_l[:, nd:] ** 2, mask_phar, B)
+                                + self.sum_except_batch(mu_p[:, nd:] ** 2, mask_pocket, B), sigma_T, one, d=1)
+        kl_x = self.gaussian_KL(self.sum_except_batch(mu_l[:, :nd] ** 2, mask_phar, B)
+                                + self.sum_except_batch(mu_p[:, :nd] ** 2, mask_pocket, B), sigma_T, one,
+                                self.subspace_dimensionality(num_nodes))
+        return kl_x + kl_h
+
+    def _log_ph_cat(self, z_h, onehot_norm, mask, sigma_0_cat, B, epsilon=1e-10):
+        onehot = onehot_norm * self.norm_values[1] + self.norm_biases[1]
+        centered = z_h * self.norm_values[1] + self.norm_biases[1] - 1
+        lp = torch.log(self.cdf_standard_gaussian((centered + 0.5) / sigma_0_cat[mask])
+                       - self.cdf_standard_gaussian((centered - 0.5) / sigma_0_cat[mask]) + epsilon)
+        lp = lp - torch.logsumexp(lp, dim=1, keepdim=True)
+        return self.sum_except_batch(lp * onehot, mask, B)
+
+    def log_pxh_given_z0_without_constants(self, phar, z_0_phar, eps_phar, net_out_phar, pocket, z_0_pocket,
+                                           eps_pocket, net_out_pocket, gamma_0, epsilon=1e-10):
+        nd, B = self.n_dims, len(phar['size'])
+        sigma_0_cat = self.sigma(gamma_0, target_tensor=z_0_phar) * self.norm_values[1]
+        lpx_l = -0.5 * self.sum_except_batch((eps_phar[:, :nd] - net_out_phar[:, :nd]) ** 2, phar['mask'], B)
+        lpx_p = -0.5 * self.sum_except_batch((eps_pocket[:, :nd] - net_out_pocket[:, :nd]) ** 2, pocket['mask'], B)
+        lph = self._log_ph_cat(z_0_phar[:, nd:], phar['one_hot'], phar['mask'], sigma_0_cat, B, epsilon) + \
+            self._log_ph_cat(z_0_pocket[:, nd:], pocket['one_hot'], pocket['mask'], sigma_0_cat, B, epsilon)
+        return lpx_l, lpx_p, lph
+
+    def log_pN(self, N_phar, N_pocket):
+        return self.size_distribution.log_prob(N_phar, N_pocket)
+
+    @torch.no_grad()
+    def forward(self, phar, pocket, return_info=False, t_int=None, eps=None):
+        """The joint model's 12 loss terms (+ info) of en_diffusion.py:332-465 as VALUES (no autograd graph: the
+        HIP evaluation has no backward pass).  ``t_int`` [B,1] and ``eps`` (list of combined draws, each a pair of
+        raw blocks, see sample_combined_position_feature_noise) may be supplied for reproducibility."""
+        phar, pocket = dict(phar), dict(pocket)
+        phar, pocket = self.normalize(phar, pocket)
+        B, nd, dev = len(phar['size']), self.n_dims, phar['x'].device
+        n_tot = phar['size'] + pocket['size']
+        delta_log_px = self.delta_log_px(n_tot)
+        if t_int is None:
+            t_int = torch.randint(0 if self.training else 1, self.T + 1, size=(B, 1), device=dev).float()
+        t_int = t_int.to(dev).float()
+        s_int = t_int - 1
+        t_is_zero = (t_int == 0).float()
+        s, t = s_int / self.T, t_int / self.T
+        gamma_s = self.inflate_batch_array(self.gamma(s), phar['x'])
+        gamma_t = self.inflate_batch_array(self.gamma(t), phar['x'])
+        xh_phar = torch.cat([phar['x'], phar['one_hot']], dim=1)
+        xh_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
+        draws = iter(eps) if eps is not None else None
+        nxt = (lambda: next(draws)) if draws is not None else (lambda: None)
+        pm, qm = phar['mask'], pocket['mask']
+        z_l, z_p, e_l, e_p = self.noised_representation(xh_phar, xh_pocket, pm, qm, gamma_t, nxt())
+        net_l, net_p = self.dynamics(z_l, z_p, t, pm, qm)
+        xh_phar_hat = self.xh_given_zt_and_epsilon(z_l, net_l, gamma_t, pm)
+        error_l = self.sum_except_batch((e_l - net_l) ** 2, pm, B)
+        error_p = self.sum_except_batch((e_p - net_p) ** 2, qm, B)
+        SNR_weight = (1 - self.SNR(gamma_s - gamma_t)).squeeze(1)
+        assert error_l.size() == SNR_weight.size()
+        neg_log_constants = -self.log_constants_p_x_given_z0(n_nodes=n_tot, device=dev)
+        kl_prior = self.kl_prior_with_pocket(xh_phar, xh_pocket, pm, qm, n_tot)
+        if self.training:
+            lpx_l, lpx_p, lph = self.log_pxh_given_z0_without_constants(phar, z_l, e_l, net_l, pocket, z_p, e_p, net_p, gamma_t)
+            tz = t_is_zero.squeeze()
+            loss_0_x_l, loss_0_x_p, loss_0_h = -lpx_l * tz, -lpx_p * tz, -lph * tz
+            error_l, error_p = error_l * (1 - t_is_zero).squeeze(), error_p * (1 - t_is_zero).squeeze()
+        else:
+            t_zeros = torch.zeros_like(s)
+            gamma_0 = self.inflate_batch_array(self.gamma(t_zeros), phar['x'])
+            z0_l, z0_p, e0_l, e0_p = self.noised_representation(xh_phar, xh_pocket, pm, qm, gamma_0, nxt())
+            n0_l, n0_p = self.dynamics(z0_l, z0_p, t_zeros, pm, qm)
+            lpx_l, lpx_p, lph = self.log_pxh_given_z0_without_constants(phar, z0_l, e0_l, n0_l, pocket, z0_p, e0_p, n0_p, gamma_0)
+            loss_0_x_l, loss_0_x_p, loss_0_h = -lpx_l, -lpx_p, -lph
+        log_pN = self.log_pN(phar['size'], pocket['size'])
+
+        def seg_mean(v, m):
+            cnt = self._seg_sum(torch.ones(len(m), device=dev), m, B).clamp(min=1)
+            return (self._seg_sum(v, m, B) / cnt).mean()
+        info = {'eps_hat_phar_x': seg_mean(net_l[:, :nd].abs().mean(1), pm),
+                'eps_hat_phar_h': seg_mean(net_l[:, nd:].abs().mean(1), pm),
+                'eps_hat_pocket_x': seg_mean(net_p[:, :nd].abs().mean(1), qm),
+                'eps_hat_pocket_h': seg_mean(net_p[:, nd:].abs().mean(1), qm)}
+        terms = (delta_log_px, error_l, error_p, SNR_weight, loss_0_x_l, loss_0_x_p, loss_0_h, neg_log_constants,
+                 kl_prior, log_pN, t_int.squeeze(), xh_phar_hat)
+        return (*terms, info) if return_info else terms
 
     # ---- joint sampler / RePaint inpainting (en_diffusion.py:576-831)
     def get_repaint_schedule(self, resamplings, jump_length, timesteps):

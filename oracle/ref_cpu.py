@@ -688,6 +688,98 @@ def ddpm_forward(p, cfg, phar, pocket, t_int, eps_draws, training, histogram):
             kl_prior, log_pN, t_int.squeeze(), xh_hat, info)
 
 
+def joint_log_prob(histogram: np.ndarray, n1: Sequence[int], n2: Sequence[int]) -> torch.Tensor:
+    """DistributionNodes.log_prob :996-1008: log of the (smoothed, normalised) joint histogram entry."""
+    hist = torch.tensor(histogram).float() + 1e-3
+    prob = hist / hist.sum()
+    logits = torch.log(prob.view(-1) / prob.view(-1).sum())                # Categorical normalises once more
+    idx = torch.tensor([int(a) * prob.shape[1] + int(b) for a, b in zip(n1, n2)])
+    return logits[idx]
+
+
+def joint_ddpm_forward(p, cfg, phar, pocket, t_int, draw, training, histogram):
+    """EnVariationalDiffusion.forward, en_diffusion.py:332-465 (the joint model's 12 loss terms + info) with
+    t_int [B,1] given and every Gaussian draw supplied by ``draw(shape)`` in the reference's call order."""
+    T, nd, nv, nb = cfg['timesteps'], cfg['n_dims'], cfg['norm_values'], cfg['norm_biases']
+    P, R = cfg['phar_nf'], cfg['residue_nf']
+    table = p['gamma.gamma']
+    B = len(phar['size'])
+    pm, qm = phar['mask'].to(INT), pocket['mask'].to(INT)
+    x_l, h_l = phar['x'].to(FLOAT) / nv[0], (phar['one_hot'].float() - nb[1]) / nv[1]        # normalize :874-889
+    x_p, h_p = pocket['x'].to(FLOAT) / nv[0], (pocket['one_hot'].float() - nb[1]) / nv[1]
+    n_tot = phar['size'] + pocket['size']
+    sub_d = (n_tot - 1) * nd                                                 # subspace_dimensionality :908-911
+    delta_log_px = -sub_d * np.log(nv[0])                                    # :328-330
+    t_int = t_int.float()
+    s_int = t_int - 1
+    t_is_zero = (t_int == 0).float()
+    t_is_not_zero = 1 - t_is_zero
+    s, t = s_int / T, t_int / T
+    gamma_s, gamma_t = gamma_lookup(table, s, T), gamma_lookup(table, t, T)
+    xh_l, xh_p = torch.cat([x_l, h_l], dim=1), torch.cat([x_p, h_p], dim=1)
+
+    def noised(gamma):                                                       # noised_representation :298-313
+        a, sg = alpha_of(gamma), sigma_of(gamma)
+        e_l, e_p = combined_noise(draw, pm, qm, nd, P, R)
+        return a[pm] * xh_l + sg[pm] * e_l, a[qm] * xh_p + sg[qm] * e_p, e_l, e_p
+
+    z_l, z_p, e_l, e_p = noised(gamma_t)
+    net_l, net_p = dynamics_forward(p, cfg, z_l, z_p, t, pm, qm)
+    a_t, s_t = alpha_of(gamma_t), sigma_of(gamma_t)
+    xh_hat = z_l / a_t[pm] - net_l * s_t[pm] / a_t[pm]                        # xh_given_zt_and_epsilon :467-473
+    error_l = _sum_except_batch((e_l - net_l) ** 2, pm, B)
+    error_p = _sum_except_batch((e_p - net_p) ** 2, qm, B)
+    SNR_weight = (1 - torch.exp(-(gamma_s - gamma_t))).squeeze(1)
+    gamma_0b = gamma_lookup(table, torch.zeros((B, 1)), T)
+    neg_log_constants = -(sub_d * (-(0.5 * gamma_0b.view(B)) - 0.5 * np.log(2 * np.pi)))    # :167-179
+    # kl_prior_with_pocket :105-151
+    gamma_T = gamma_lookup(table, torch.ones((B, 1)), T)
+    alpha_T = alpha_of(gamma_T)
+    mu_l, mu_p = alpha_T[pm] * xh_l, alpha_T[qm] * xh_p
+    sigma_T = sigma_of(gamma_T).squeeze()
+    ones = torch.ones_like(sigma_T)
+    kl_h = _gaussian_KL(_sum_except_batch(mu_l[:, nd:] ** 2, pm, B) + _sum_except_batch(mu_p[:, nd:] ** 2, qm, B),
+                        sigma_T, ones, 1)
+    kl_x = _gaussian_KL(_sum_except_batch(mu_l[:, :nd] ** 2, pm, B) + _sum_except_batch(mu_p[:, :nd] ** 2, qm, B),
+                        sigma_T, ones, sub_d)
+    kl_prior = kl_x + kl_h
+
+    def log_pxh(z0_l, eps_l, out_l, z0_p, eps_p, out_p, gamma_0, epsilon=1e-10):     # :181-257
+        sigma_0_cat = sigma_of(gamma_0) * nv[1]
+        lpx_l = -0.5 * _sum_except_batch((eps_l[:, :nd] - out_l[:, :nd]) ** 2, pm, B)
+        lpx_p = -0.5 * _sum_except_batch((eps_p[:, :nd] - out_p[:, :nd]) ** 2, qm, B)
+
+        def cat_logp(z_h, onehot_norm, mask):
+            onehot = onehot_norm * nv[1] + nb[1]
+            centered = z_h * nv[1] + nb[1] - 1
+            lp = torch.log(_cdf_std_gauss((centered + 0.5) / sigma_0_cat[mask])
+                           - _cdf_std_gauss((centered - 0.5) / sigma_0_cat[mask]) + epsilon)
+            lp = lp - torch.logsumexp(lp, dim=1, keepdim=True)
+            return _sum_except_batch(lp * onehot, mask, B)
+        return lpx_l, lpx_p, cat_logp(z0_l[:, nd:], h_l, pm) + cat_logp(z0_p[:, nd:], h_p, qm)
+
+    if training:
+        lpx_l, lpx_p, lph = log_pxh(z_l, e_l, net_l, z_p, e_p, net_p, gamma_t)
+        tz = t_is_zero.squeeze()
+        loss_0_x_l, loss_0_x_p, loss_0_h = -lpx_l * tz, -lpx_p * tz, -lph * tz
+        error_l = error_l * t_is_not_zero.squeeze()
+        error_p = error_p * t_is_not_zero.squeeze()
+    else:
+        t_zeros = torch.zeros_like(s)
+        gamma_0 = gamma_lookup(table, t_zeros, T)
+        z0_l, z0_p, e0_l, e0_p = noised(gamma_0)
+        n0_l, n0_p = dynamics_forward(p, cfg, z0_l, z0_p, t_zeros, pm, qm)
+        lpx_l, lpx_p, lph = log_pxh(z0_l, e0_l, n0_l, z0_p, e0_p, n0_p, gamma_0)
+        loss_0_x_l, loss_0_x_p, loss_0_h = -lpx_l, -lpx_p, -lph
+    log_pN = joint_log_prob(histogram, phar['size'].tolist(), pocket['size'].tolist())
+    info = {'eps_hat_phar_x': scatter_mean(net_l[:, :nd].abs().mean(1), pm).mean(),
+            'eps_hat_phar_h': scatter_mean(net_l[:, nd:].abs().mean(1), pm).mean(),
+            'eps_hat_pocket_x': scatter_mean(net_p[:, :nd].abs().mean(1), qm).mean(),
+            'eps_hat_pocket_h': scatter_mean(net_p[:, nd:].abs().mean(1), qm).mean()}
+    return (delta_log_px, error_l, error_p, SNR_weight, loss_0_x_l, loss_0_x_p, loss_0_h, neg_log_constants,
+            kl_prior, log_pN, t_int.squeeze(), xh_hat, info)
+
+
 def nll_from_terms(terms, cfg, phar_size, pocket_size, training, loss_type='l2'):
     """PharPocketDDPM.forward's assembly, lightning_modules.py:188-239."""
     (delta_log_px, error_t, error_t_pocket, snr_w, l0x, l0x_pocket, l0h, neg_log_const, kl_prior, log_pN, _, _, _) = terms

@@ -189,6 +189,54 @@ def main():
         g[f'inpaint/{name}/n_evals'] = np.asarray(len(margins))
         print('inpaint', name, 'first', first, 'draws', len(draws) // 3, 'evals', len(margins), 'min margin', min(margins))
 
+    # ---------------- loss terms of EnVariationalDiffusion.forward (train + eval), t_int and every draw pinned
+    for first in range(7100, 999999, 1000):
+        cfg = ModelConfig(hidden_nf=64, n_layers=2, update_pocket_coords=True)
+        ddpm = build_joint(mods, cfg, 71, 1.0)
+        B = 4
+        pb = make_pockets(B, 'CA', ragged=True, first_index=first)
+        rng = np.random.Generator(np.random.PCG64(first))
+        nl = np.asarray([6, 9, 5, 12], dtype=np.int64)
+        pmask = np.repeat(np.arange(B), nl)
+        com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(B)])
+        phar_x = (com[pmask] + rng.normal(size=(len(pmask), 3)) * 2.0).astype(np.float32)
+        phar_oh = np.eye(8, dtype=np.float32)[rng.integers(0, 8, size=len(pmask))]
+        # the dataset centres every complex on the joint COG (dataset.py:33-41)
+        allx = np.concatenate([phar_x, pb.x]); allm = np.concatenate([pmask, pb.mask])
+        cog = np.stack([allx[allm == b].mean(0) for b in range(B)]).astype(np.float32)
+        phar_x = phar_x - cog[pmask]; pocket_x = (pb.x - cog[pb.mask]).astype(np.float32)
+        t_pin = np.asarray([[0.], [137.], [500.], [42.]], dtype=np.float32)
+        real_randint = torch.randint
+        ok = True
+        out = {}
+        for mode in ('train', 'eval'):
+            ddpm.train() if mode == 'train' else ddpm.eval()
+            draws, margins = instrument(ddpm, 71 + (mode == 'eval'))
+            torch.randint = lambda lo, hi, size, device=None: torch.from_numpy(t_pin.copy())
+            phar = {'x': torch.from_numpy(phar_x.copy()), 'one_hot': torch.from_numpy(phar_oh.copy()),
+                    'size': torch.from_numpy(nl.copy()), 'mask': torch.from_numpy(pmask.copy())}
+            pocket = {'x': torch.from_numpy(pocket_x.copy()), 'one_hot': torch.from_numpy(pb.one_hot.copy()),
+                      'size': torch.from_numpy(pb.size.copy()), 'mask': torch.from_numpy(pb.mask.copy())}
+            with torch.no_grad():
+                terms = ddpm(phar, pocket, return_info=True)
+            torch.randint = real_randint
+            names = ['delta_log_px', 'error_t_phar', 'error_t_pocket', 'SNR_weight', 'loss_0_x_phar', 'loss_0_x_pocket',
+                     'loss_0_h', 'neg_log_constants', 'kl_prior', 'log_pN', 't_int', 'xh_phar_hat']
+            for n, v in zip(names, terms[:-1]):
+                out[f'loss/{mode}/{n}'] = np.asarray(v.numpy() if torch.is_tensor(v) else v, dtype=np.float32)
+            for kk, v in terms[-1].items():
+                out[f'loss/{mode}/info_{kk}'] = v.numpy()
+            out[f'loss/{mode}/noise'] = pack_draws(draws, len(pmask), len(pb.mask), 8, 20)
+            ok = ok and min(margins) > 2e-3
+            print('loss', mode, 'first', first, 'draws', len(draws) // 3, 'evals', len(margins), 'min margin', min(margins))
+        if ok:
+            g.update(out)
+            g['loss/phar_x'], g['loss/phar_one_hot'], g['loss/num_nodes_phar'] = phar_x, phar_oh, nl
+            g['loss/pocket_x'] = pocket_x
+            g['loss/t_int'] = t_pin
+            g['loss/meta'] = np.asarray([64, 2, B, 20, 71, first], dtype=np.int64)
+            break
+
     # ---------------- RePaint schedules
     sched_cases = [(1, 1, 10), (3, 1, 7), (2, 2, 6), (5, 10, 50), (10, 10, 500), (4, 3, 11), (2, 20, 10)]
     for r, j, T in sched_cases:

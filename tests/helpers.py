@@ -129,3 +129,20 @@ def joint_inpaint_case(g, name):
             'size': nl, 'mask': np.repeat(np.arange(B, dtype=np.int64), nl)}
     pocket = {'x': pb.x, 'one_hot': pb.one_hot, 'size': pb.size, 'mask': pb.mask}
     return cfg, sd, phar, pocket, K, resamplings, jump
+
+
+def joint_loss_case(g):
+    H, L, B, R, seed, first = [int(v) for v in g['loss/meta']]
+    cfg = joint_cfg(H, L, R)
+    sd = make_state_dict(cfg, seed=seed, coord_gain=1.0)
+    pb = make_pockets(B, 'CA', ragged=True, first_index=first)
+    nl = g['loss/num_nodes_phar']
+    phar = {'x': torch.from_numpy(g['loss/phar_x'].copy()), 'one_hot': torch.from_numpy(g['loss/phar_one_hot'].copy()),
+            'size': torch.from_numpy(nl.copy()), 'mask': torch.from_numpy(np.repeat(np.arange(B), nl))}
+    pocket = {'x': torch.from_numpy(g['loss/pocket_x'].copy()), 'one_hot': torch.from_numpy(pb.one_hot.copy()),
+              'size': torch.from_numpy(pb.size.copy()), 'mask': torch.from_numpy(pb.mask.copy())}
+    return cfg, sd, phar, pocket, HIST
+
+
+LOSS_NAMES = ['delta_log_px', 'error_t_phar', 'error_t_pocket', 'SNR_weight', 'loss_0_x_phar', 'loss_0_x_pocket',
+              'loss_0_h', 'neg_log_constants', 'kl_prior', 'log_pN', 't_int', 'xh_phar_hat']

@@ -282,7 +282,7 @@ def test_joint_inpaint_full_size_properties_and_sharding():
 
 
 # ------------------------------------------------------------------ Python API (the reference's classes)
-def small_joint_module(H=64, L=2):
+def small_joint_module(H=64, L=2, hist=None):
     from cmdgen_amd.equivariant_diffusion.dynamics import EGNNDynamics
     from cmdgen_amd.equivariant_diffusion.en_diffusion import EnVariationalDiffusion
     dyn = EGNNDynamics(phar_nf=8, residue_nf=20, n_dims=3, joint_nf=32, hidden_nf=H, n_layers=L, attention=True,
@@ -290,7 +290,7 @@ def small_joint_module(H=64, L=2):
                        aggregation_method='sum', edge_cutoff=6.0, update_pocket_coords=True)
     ddpm = EnVariationalDiffusion(dynamics=dyn, phar_nf=8, residue_nf=20, n_dims=3, timesteps=500,
                                   noise_schedule='polynomial_2', noise_precision=1e-5, loss_type='l2',
-                                  norm_values=[1, 4], size_histogram=np.ones((30, 70)))
+                                  norm_values=[1, 4], size_histogram=np.ones((30, 70)) if hist is None else hist)
     return ddpm
 
 
@@ -367,3 +367,26 @@ def test_generate_phars_joint_mode_end_to_end(tmp_path):
                       '--jump_length', '1', '--outdir', str(tmp_path)])
     written = json.load(open(tmp_path / cli.DEFAULT_JSON))
     assert written == plain and sorted(written) == ['Molecule_1', 'Molecule_2', 'Molecule_3', 'Molecule_4']
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_joint_loss_terms_match_reference(mode):
+    """EnVariationalDiffusion.forward (en_diffusion.py:332-465): the 12 loss terms + info with t_int and every
+    Gaussian draw pinned (G9 loss case, t = 0 and t = T included), evaluation on the GPU; <= 2e-5 relative."""
+    from helpers import joint_loss_case, LOSS_NAMES
+    cfg, sd, phar, pocket, hist = joint_loss_case(G9)
+    ddpm = small_joint_module(64, 2, hist)
+    ddpm.load_state_dict({kk[len('ddpm.'):]: torch.from_numpy(v) for kk, v in sd.items()}, strict=True)
+    ddpm = ddpm.cuda()
+    ddpm.train() if mode == 'train' else ddpm.eval()
+    Nl, Np = len(phar['mask']), len(pocket['mask'])
+    eps = [(dev(row[:Nl * 11].reshape(Nl, 11)), dev(row[Nl * 11:].reshape(Np, 23))) for row in G9[f'loss/{mode}/noise']]
+    cu = lambda d: {kk: v.cuda() for kk, v in d.items()}
+    terms = ddpm(cu(phar), cu(pocket), return_info=True, t_int=dev(G9['loss/t_int']), eps=eps)
+    for n, v in zip(LOSS_NAMES, terms[:-1]):
+        want = G9[f'loss/{mode}/{n}']
+        got = np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v, dtype=np.float32)
+        assert got.shape == want.shape, n
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (n, got, want)
+    for kk, v in terms[-1].items():
+        assert abs(float(v) - float(G9[f'loss/{mode}/info_{kk}'])) < 2e-5, kk

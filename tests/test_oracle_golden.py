@@ -196,3 +196,23 @@ def test_g9_repaint_schedules():
             assert ref_cpu.get_repaint_schedule(r, j, T) == want.tolist()
             n += 1
     assert n == 7
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_g9_joint_loss_terms(mode):
+    from helpers import joint_loss_case, LOSS_NAMES
+    cfg, sd, phar, pocket, hist = joint_loss_case(G9)
+    p = ref_cpu.to_torch_params(sd)
+    tape = JointNoiseTape(G9[f'loss/{mode}/noise'], len(phar['mask']), len(pocket['mask']))
+    with torch.no_grad():
+        terms = ref_cpu.joint_ddpm_forward(p, cfg.as_dict(), phar, pocket, torch.from_numpy(G9['loss/t_int']), tape,
+                                           training=(mode == 'train'), histogram=hist)
+    assert tape.i == (1 if mode == 'train' else 2)
+    for n, v in zip(LOSS_NAMES, terms[:-1]):
+        want = G9[f'loss/{mode}/{n}']
+        got = np.asarray(v.numpy() if torch.is_tensor(v) else v, dtype=np.float32)
+        assert got.shape == want.shape, n
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (n, got, want)
+    for kk, v in terms[-1].items():
+        assert abs(float(v) - float(G9[f'loss/{mode}/info_{kk}'])) < 1e-5, kk
+    assert np.abs(G9[f'loss/{mode}/error_t_pocket']).max() > 0        # the joint loss has pocket terms
