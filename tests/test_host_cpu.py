@@ -237,3 +237,25 @@ def test_dataset_npz_schema_centering_and_collate(tmp_path):
     assert len(batch['pocket_c_alpha']) == int(pb.size[3] + pb.size[1])
     raw = ProcessedLigandPharPocketDataset(str(f), center=False)
     assert float(torch.cat([raw[0]['phar_coords'], raw[0]['pocket_c_alpha']]).mean(0).abs().max()) > 1.0
+
+
+def test_consensus_posp_matches_reference_script(tmp_path):
+    """get_phar/GMM_json.py (run unmodified by tests/golden/make_golden_posp.py) vs cmdgen_amd.get_phar: same
+    GMM (scikit-learn, random_state=42), same typing rule, same .posp text; the lines parse the way
+    GCPG/utils/file_utils.py:67-102 splits them."""
+    import json
+    from cmdgen_amd import get_phar
+    cases = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g10_posp.json')))['cases']
+    assert len(cases) == 3
+    for c in cases:
+        clusters = get_phar.gmm_consensus(c['input'])
+        text = ''.join(line + '\n' for line in get_phar.posp_lines(clusters))
+        assert text == c['posp']
+        for line in text.strip().split('\n'):
+            types, x, y, z = line.strip().split(' ')
+            assert types in get_phar.IDX2PHAR.values() and all(np.isfinite(float(v)) for v in (x, y, z))
+    assert any(len(c['posp'].splitlines()) < 7 for c in cases)          # a 'NegIonizable' cluster is dropped (quirk kept)
+    src = tmp_path / 'in.json'
+    src.write_text(json.dumps(cases[0]['input']))
+    lines = get_phar.main([str(src), '--out', str(tmp_path / 'o.posp')])
+    assert (tmp_path / 'o.posp').read_text() == cases[0]['posp'] and len(lines) == len(cases[0]['posp'].splitlines())
