@@ -216,3 +216,40 @@ def test_g9_joint_loss_terms(mode):
     for kk, v in terms[-1].items():
         assert abs(float(v) - float(G9[f'loss/{mode}/info_{kk}'])) < 1e-5, kk
     assert np.abs(G9[f'loss/{mode}/error_t_pocket']).max() > 0        # the joint loss has pocket terms
+
+
+# ---------------------------------------------------------------- training step (G11)
+def _oracle_training_grads():
+    from helpers import loss_case
+    g6 = load_golden('g6_loss.npz')
+    cfg, sd, phar, pocket, hist = loss_case(g6)
+    p = ref_cpu.to_torch_params(sd)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith('dynamics.')}
+    p2 = dict(p); p2.update(leaves)
+    terms = ref_cpu.ddpm_forward(p2, cfg.as_dict(), phar, pocket, torch.from_numpy(g6['t_int']), [torch.from_numpy(g6['eps0'])],
+                                 training=True, histogram=hist)
+    nll = ref_cpu.nll_from_terms(terms, cfg.as_dict(), phar['size'], pocket['size'], training=True)
+    loss = nll.mean(0)
+    loss.backward()
+    return loss.detach(), nll.detach(), leaves
+
+
+def test_g11_oracle_autograd_matches_reference_gradients():
+    """The oracle is differentiable torch code: its autograd gradients of the training loss must equal the
+    reference's (make_golden_grad.py) - this pins the oracle as the checker of the HIP backward pass."""
+    g = load_golden('g11_train.npz')
+    loss, nll, leaves = _oracle_training_grads()
+    assert abs(float(loss) - float(g['step0/loss'])) < 1e-6
+    assert np.abs(nll.numpy() - g['step0/nll']).max() < 1e-5
+    n = 0
+    for key, want in g.items():
+        if key.startswith('grad/'):
+            name = key[len('grad/'):]
+            if name == 'gamma.gamma':               # requires_grad=False in the reference (en_diffusion.py:1180-1182)
+                assert not want.any()
+                continue
+            got = leaves[name].grad
+            got = np.zeros_like(want) if got is None else got.numpy()
+            assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-3), name
+            n += 1
+    assert n == 50
