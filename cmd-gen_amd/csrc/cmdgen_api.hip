@@ -34,82 +34,9 @@ void cmdgen_launch_joint_step(const Layout& lay, const Dims& d, const JointBuf& 
 void cmdgen_launch_joint_final(const Layout& lay, const Dims& d, const JointBuf& c, const float* ep, const float* eq,
                                float* xo, float* po, unsigned int* cog, hipStream_t s);
 
-static std::string g_create_error;
+#include "cmdgen_host.h"
 
-struct DevBuf {
-    void* p = nullptr; size_t bytes = 0;
-};
-
-struct cmdgen_handle {
-    cmdgen_config cfg{};
-    int device = 0;
-    std::string err;
-    Dims dims{};
-    // weights
-    std::map<std::string, std::vector<float>> staged;
-    bool finalized = false;
-    std::vector<void*> weight_allocs;
-    std::vector<LayerW> layers;
-    SmallW small{};
-    std::vector<float> gamma;              // host copy of the table [T+1]
-    // layout + workspace
-    bool have_layout = false;
-    std::vector<int64_t> cur_nphar, cur_npocket;
-    std::vector<void*> layout_allocs;
-    Layout lay{};
-    Work work{};
-    int64_t ecap = 0, eccap = 0;
-    int edge_grid = 512, coord_grid = 256;
-    int n_cus = 256;
-    int node_mt = 64, edge_mt = 64, coord_mt = 64;   // rows per tile, chosen in cmdgen_set_layout
-    int64_t* d_gid = nullptr;
-    // chain
-    std::vector<void*> chain_allocs;
-    ChainBuf chain{};
-    int chain_K = -1;
-    bool chain_steps_out = false;
-    unsigned int* d_cog = nullptr;
-    std::vector<float> user_coef;          // optional host-supplied step table
-    int user_coef_K = -1;
-    hipGraphExec_t step_graph = nullptr;
-    hipStream_t own_stream = nullptr;      // used when the caller's stream is the legacy default stream (not capturable)
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    const float* graph_noise = nullptr; float* graph_zsteps = nullptr; float* graph_psteps = nullptr; hipStream_t graph_stream = nullptr;
-    unsigned long long graph_seed = 0;
-    int graph_steps = 0;
-    // joint-model chain
-    std::vector<void*> joint_allocs;
-    JointBuf joint{};
-    float* eps_pocket_tmp = nullptr;       // [Np][3+R] evaluation output of the joint chain
-    unsigned int* joint_cog = nullptr;
-    int joint_steps = -1;                  // denoising steps of the prepared plan
-    std::vector<int> joint_key;            // (K, resamplings, jump, inpaint) of the prepared plan
-    bool last_chain_joint = false;
-    hipGraphExec_t joint_graph = nullptr;
-    const void* jg_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    unsigned long long jg_seed = 0; int jg_steps = 0;
-    bool kernel_profiling = false;
-    std::vector<hipEvent_t> prof_events[3];
-};
-
-static int fail(cmdgen_handle* h, int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    if (h) h->err = buf; else g_create_error = buf;
-    return code;
-}
-#define HIPCHK(h, call) do { hipError_t _e = (call); if (_e != hipSuccess) \
-    return fail(h, CMDGEN_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
-
-static int dev_alloc(cmdgen_handle* h, std::vector<void*>& pool, void** out, size_t bytes, bool zero) {
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess) return fail(h, CMDGEN_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    pool.push_back(*out);
-    if (zero) { e = hipMemset(*out, 0, bytes); if (e != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemset failed"); }
-    return 0;
-}
-static void free_pool(std::vector<void*>& pool) { for (void* p : pool) hipFree(p); pool.clear(); }
+std::string g_create_error;
 
 extern "C" const char* cmdgen_version(void) { return "cmdgen_hip 0.1 (gfx950)"; }
 
@@ -161,6 +88,7 @@ extern "C" void cmdgen_destroy(cmdgen_handle* h) {
     if (h->ev_in) hipEventDestroy(h->ev_in);
     if (h->ev_out) hipEventDestroy(h->ev_out);
     free_pool(h->weight_allocs); free_pool(h->layout_allocs); free_pool(h->chain_allocs); free_pool(h->joint_allocs);
+    cmdgen_train_free(h->train);
     delete h;
 }
 
@@ -329,6 +257,7 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
     if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
     free_pool(h->layout_allocs); free_pool(h->chain_allocs); h->chain_K = -1;
     free_pool(h->joint_allocs); h->joint_steps = -1; h->joint_key.clear();
+    cmdgen_train_free(h->train); h->train = nullptr;
     h->have_layout = false;
     const Dims& d = h->dims;
     const int B = (int)batch;
@@ -414,14 +343,14 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
     return CMDGEN_OK;
 }
 
-static int check_ready(cmdgen_handle* h) {
+int check_ready(cmdgen_handle* h) {
     if (!h) return CMDGEN_EINVAL;
     if (!h->finalized) return fail(h, CMDGEN_ESTATE, "weights not finalised (cmdgen_finalize_weights)");
     if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
     return 0;
 }
 
-static EvalLaunch make_launch(cmdgen_handle* h) {
+EvalLaunch make_launch(cmdgen_handle* h) {
     EvalLaunch a; a.lay = h->lay; a.w = h->work; a.d = h->dims; a.sw = h->small; a.layers = h->layers.data();
     a.edge_grid = h->edge_grid; a.coord_grid = h->coord_grid;
     a.prof_events = nullptr; a.ablate = 0;

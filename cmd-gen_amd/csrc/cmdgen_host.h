@@ -1,0 +1,98 @@
+// cmdgen_host.h - host-side state shared by cmdgen_api.hip and cmdgen_train.hip
+#pragma once
+#include "cmdgen_dev.h"
+#include "../../include/cmdgen_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <vector>
+
+extern std::string g_create_error;
+struct TrainState;               // cmdgen_train.hip
+void cmdgen_train_free(TrainState*);
+
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+};
+
+struct cmdgen_handle {
+    cmdgen_config cfg{};
+    int device = 0;
+    std::string err;
+    Dims dims{};
+    // weights
+    std::map<std::string, std::vector<float>> staged;
+    bool finalized = false;
+    std::vector<void*> weight_allocs;
+    std::vector<LayerW> layers;
+    SmallW small{};
+    std::vector<float> gamma;              // host copy of the table [T+1]
+    // layout + workspace
+    bool have_layout = false;
+    std::vector<int64_t> cur_nphar, cur_npocket;
+    std::vector<void*> layout_allocs;
+    Layout lay{};
+    Work work{};
+    int64_t ecap = 0, eccap = 0;
+    int edge_grid = 512, coord_grid = 256;
+    int n_cus = 256;
+    int node_mt = 64, edge_mt = 64, coord_mt = 64;   // rows per tile, chosen in cmdgen_set_layout
+    int64_t* d_gid = nullptr;
+    // chain
+    std::vector<void*> chain_allocs;
+    ChainBuf chain{};
+    int chain_K = -1;
+    bool chain_steps_out = false;
+    unsigned int* d_cog = nullptr;
+    std::vector<float> user_coef;          // optional host-supplied step table
+    int user_coef_K = -1;
+    hipGraphExec_t step_graph = nullptr;
+    hipStream_t own_stream = nullptr;      // used when the caller's stream is the legacy default stream (not capturable)
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    const float* graph_noise = nullptr; float* graph_zsteps = nullptr; float* graph_psteps = nullptr; hipStream_t graph_stream = nullptr;
+    unsigned long long graph_seed = 0;
+    int graph_steps = 0;
+    // joint-model chain
+    std::vector<void*> joint_allocs;
+    JointBuf joint{};
+    float* eps_pocket_tmp = nullptr;       // [Np][3+R] evaluation output of the joint chain
+    unsigned int* joint_cog = nullptr;
+    int joint_steps = -1;                  // denoising steps of the prepared plan
+    std::vector<int> joint_key;            // (K, resamplings, jump, inpaint) of the prepared plan
+    bool last_chain_joint = false;
+    hipGraphExec_t joint_graph = nullptr;
+    const void* jg_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned long long jg_seed = 0; int jg_steps = 0;
+    TrainState* train = nullptr;           // training workspace (cmdgen_train.hip)
+    bool kernel_profiling = false;
+    std::vector<hipEvent_t> prof_events[3];
+};
+
+inline int fail(cmdgen_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+#define HIPCHK(h, call) do { hipError_t _e = (call); if (_e != hipSuccess) \
+    return fail(h, CMDGEN_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+
+inline int dev_alloc(cmdgen_handle* h, std::vector<void*>& pool, void** out, size_t bytes, bool zero) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) return fail(h, CMDGEN_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    pool.push_back(*out);
+    if (zero) { e = hipMemset(*out, 0, bytes); if (e != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemset failed"); }
+    return 0;
+}
+inline void free_pool(std::vector<void*>& pool) { for (void* p : pool) hipFree(p); pool.clear(); }
+
+
+int check_ready(cmdgen_handle* h);
+EvalLaunch make_launch(cmdgen_handle* h);

@@ -1,0 +1,435 @@
+// cmdgen_train.hip - the training step behind the C ABI: forward with saved activations,
+// backward to parameter gradients, AdamW(amsgrad) and the gradient norm, all on flat fp32 parameter / gradient
+// buffers owned by the caller (one contiguous bucket: a single RCCL all-reduce per step for data parallelism).
+// Conditional mode (update_pocket_coords = 0).  Kernels: kernels_train.hip.
+#include "cmdgen_host.h"
+
+void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s);
+void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                  int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s);
+void tr_silu(const float* in, float* out, size_t n, hipStream_t s);
+void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
+void tr_scale(float* x, float a, size_t n, hipStream_t s);
+void tr_axpy(float* y, const float* x, float a, size_t n, hipStream_t s);
+void tr_edge_geom(int E, const int* row, const int* col, const float4* X, float nc, float* r, float4* cd, hipStream_t s);
+void tr_edge_pre(int E, int H, const int* row, const int* col, const float* P, const float* Q, const float* W1, int ldw,
+                 const float* r, const float* d0, float* pre, float* act, hipStream_t s);
+void tr_att_msg(int E, int H, const int* row, const float* m2, const float* wa, const float* ba, int attention, float* z,
+                float* agg, hipStream_t s);
+void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* wa, const float* z, int attention,
+                    const float* dagg, float* dm2, float* dz, hipStream_t s);
+void tr_coord_out(int E, int H, const int* row, const float* c2, const float* w5, const float4* cd, int use_tanh, float range,
+                  float* phi, float* accx, hipStream_t s);
+void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, const float* phi, int use_tanh, float range,
+                      float nc, const float* dacc, int n_moving, float* dphi, float4* dcd, hipStream_t s);
+void tr_geom_bwd(int E, const int* row, const int* col, const float4* X, float nc, const float4* dcd, const float* dr,
+                 int n_moving, float* dX, hipStream_t s);
+void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s);
+void tr_scatter_rows(int E, int H, const int* idx, const float* src, float* dst, hipStream_t s);
+void tr_rowdot(int E, int H, const float* X, const float* w, int ldw, float* out, hipStream_t s);
+void tr_colsum(int E, int H, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s);
+void tr_sum(int n, const float* x, float* out, hipStream_t s);
+void tr_concat_time(int N, int J, int dyn, const float* enc, const float* t, const int* node_sample, float* out, hipStream_t s);
+void tr_positions(int Nl, int Np, const float* xp, int ldp, const float* xq, int ldq, float4* X, hipStream_t s);
+void tr_move(int N, int n_moving, const float4* X, const float* accx, float nf, float4* Xn, hipStream_t s);
+void tr_eps_out(int Nl, int P, const float4* XL, const float4* X0, const float* dec, float* eps, hipStream_t s);
+void tr_eps_bwd(int Nl, int P, const float* deps, float* dX, float* ddec, hipStream_t s);
+void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
+              float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s);
+void tr_sqsum(size_t n, const float* x, float* out, hipStream_t s);
+
+// ---------------------------------------------------------------------------------
+// flat parameter layout: the reference's registration order (state_dict order below 'dynamics.'), weight then bias
+// ---------------------------------------------------------------------------------
+struct PRef { size_t w = 0, b = 0; int out = 0, in = 0; bool has_bias = true; std::string name; };
+
+struct ParamTable {
+    PRef pe0, pe2, pd0, pd2, re0, re2, rd0, rd2, emb, embo;
+    struct Blk { PRef e0, e2, n0, n2, att, c0, c2, c4; };
+    std::vector<Blk> blk;
+    std::vector<PRef*> order;
+    size_t total = 0;
+};
+
+static void build_table(const Dims& d, ParamTable& t) {
+    t.blk.resize(d.L);
+    t.order.clear();
+    size_t off = 0;
+    auto add = [&](PRef& r, const std::string& name, int out, int in, bool bias) {
+        r.name = name; r.out = out; r.in = in; r.has_bias = bias;
+        r.w = off; off += (size_t)out * in;
+        if (bias) { r.b = off; off += out; }
+        t.order.push_back(&r);
+    };
+    const int P = d.P, R = d.R, J = d.J, H = d.H;
+    add(t.pe0, "phar_encoder.0", 2 * P, P, true);      add(t.pe2, "phar_encoder.2", J, 2 * P, true);
+    add(t.pd0, "phar_decoder.0", 2 * P, J, true);      add(t.pd2, "phar_decoder.2", P, 2 * P, true);
+    add(t.re0, "residue_encoder.0", 2 * R, R, true);   add(t.re2, "residue_encoder.2", J, 2 * R, true);
+    add(t.rd0, "residue_decoder.0", 2 * R, J, true);   add(t.rd2, "residue_decoder.2", R, 2 * R, true);
+    add(t.emb, "egnn.embedding", H, d.dyn, true);      add(t.embo, "egnn.embedding_out", d.dyn, H, true);
+    for (int l = 0; l < d.L; ++l) {
+        const std::string g = "egnn.e_block_" + std::to_string(l) + ".gcl_0.", c = "egnn.e_block_" + std::to_string(l) + ".gcl_equiv.";
+        ParamTable::Blk& b = t.blk[l];
+        add(b.e0, g + "edge_mlp.0", H, 2 * H + 2, true);   add(b.e2, g + "edge_mlp.2", H, H, true);
+        add(b.n0, g + "node_mlp.0", H, 2 * H, true);       add(b.n2, g + "node_mlp.2", H, H, true);
+        if (d.attention) add(b.att, g + "att_mlp.0", 1, H, true);
+        add(b.c0, c + "coord_mlp.0", H, 2 * H + 2, true);  add(b.c2, c + "coord_mlp.2", H, H, true);
+        add(b.c4, c + "coord_mlp.4", 1, H, false);
+    }
+    t.total = off;
+}
+
+struct TrainState {
+    ParamTable tab;
+    std::vector<void*> node_allocs, edge_allocs;
+    int E = 0, Ec = 0;                  // edges of the last forward
+    size_t ecap = 0, eccap = 0;
+    bool have_forward = false;
+    const float* theta = nullptr;       // parameters used by the last forward (backward reads the same)
+    const float* xh_phar = nullptr; const float* xh_pocket = nullptr;
+    // node level
+    float *enc1_l, *enca_l, *enc1_p, *enca_p, *enc_out, *hdyn, *h /* [L+1][N][H] */, *P, *Q, *aggn /* [L] */,
+          *pre3 /* [L] */, *nact, *accx, *hfin, *dec1, *deca, *dec_out;
+    float4* X;                          // [L+1][N]
+    // edge level (saved per block)
+    float *pre1, *pre2, *z, *pre6, *pre7, *phi;
+    // edge level scratch
+    float *actA, *actB, *r, *rc, *dr, *dz, *dphi;
+    float4 *cd, *dcd;
+    // backward node level
+    float *dh, *dX, *dacc, *dagg, *dP, *dQ, *dn, *dhfin, *ddec, *ddeca, *dhdyn, *denca_l, *denca_p;
+    float* d_scalar;                    // [4] device scalars (sum of squares, ...)
+};
+
+void cmdgen_train_free(TrainState* t) {
+    if (!t) return;
+    free_pool(t->node_allocs); free_pool(t->edge_allocs);
+    delete t;
+}
+
+static int ensure_state(cmdgen_handle* h) {
+    if (h->train) return 0;
+    if (h->dims.joint) return fail(h, CMDGEN_ESTATE, "the training step supports the conditional model only (update_pocket_coords = 0)");
+    TrainState* t = new TrainState();
+    build_table(h->dims, t->tab);
+    const Dims& d = h->dims;
+    const size_t N = h->lay.N, Nl = h->lay.Nl, Np = h->lay.Np, H = d.H, L = d.L;
+    int rc; void* p;
+#define NA(dst, type, count) do { rc = dev_alloc(h, t->node_allocs, &p, (size_t)(count) * sizeof(type), true); \
+        if (rc) { cmdgen_train_free(t); return rc; } dst = (type*)p; } while (0)
+    NA(t->enc1_l, float, Nl * 2 * d.P); NA(t->enca_l, float, Nl * 2 * d.P);
+    NA(t->enc1_p, float, Np * 2 * d.R); NA(t->enca_p, float, Np * 2 * d.R);
+    NA(t->enc_out, float, N * d.J); NA(t->hdyn, float, N * d.dyn);
+    NA(t->h, float, (L + 1) * N * H); NA(t->X, float4, (L + 1) * N);
+    NA(t->P, float, N * H); NA(t->Q, float, N * H); NA(t->aggn, float, L * N * H); NA(t->pre3, float, L * N * H);
+    NA(t->nact, float, N * H); NA(t->accx, float, N * 4); NA(t->hfin, float, N * d.dyn);
+    NA(t->dec1, float, Nl * 2 * d.P); NA(t->deca, float, Nl * 2 * d.P); NA(t->dec_out, float, Nl * d.P);
+    NA(t->dh, float, N * H); NA(t->dX, float, N * 4); NA(t->dacc, float, N * 4); NA(t->dagg, float, N * H);
+    NA(t->dP, float, N * H); NA(t->dQ, float, N * H); NA(t->dn, float, N * H); NA(t->dhfin, float, N * d.dyn);
+    NA(t->ddec, float, Nl * d.P); NA(t->ddeca, float, Nl * 2 * d.P); NA(t->dhdyn, float, N * d.dyn);
+    NA(t->denca_l, float, Nl * 2 * d.P); NA(t->denca_p, float, Np * 2 * d.R);
+    NA(t->d_scalar, float, 4);
+#undef NA
+    h->train = t;
+    return 0;
+}
+
+static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
+    if ((size_t)E <= t->ecap && (size_t)Ec <= t->eccap) return 0;
+    hipDeviceSynchronize();
+    free_pool(t->edge_allocs);
+    const size_t ec = (size_t)(E * 1.25) + 64, ecc = (size_t)(Ec * 1.25) + 64, H = h->dims.H, L = h->dims.L;
+    const size_t em = ec > ecc ? ec : ecc;
+    int rc; void* p;
+#define EA(dst, type, count) do { rc = dev_alloc(h, t->edge_allocs, &p, (size_t)(count) * sizeof(type), false); \
+        if (rc) return rc; dst = (type*)p; } while (0)
+    EA(t->pre1, float, L * ec * H); EA(t->pre2, float, L * ec * H); EA(t->z, float, L * ec);
+    EA(t->pre6, float, L * ecc * H); EA(t->pre7, float, L * ecc * H); EA(t->phi, float, L * ecc);
+    EA(t->actA, float, em * H); EA(t->actB, float, em * H);
+    EA(t->r, float, ec); EA(t->rc, float, ecc); EA(t->dr, float, em); EA(t->dz, float, ec); EA(t->dphi, float, ecc);
+    EA(t->cd, float4, ecc); EA(t->dcd, float4, ecc);
+#undef EA
+    t->ecap = ec; t->eccap = ecc;
+    return 0;
+}
+
+// y[M, out] = x[M, in(ldx)] W^T + b      (W, b inside the flat buffer)
+static void linear(const float* theta, const PRef& r, int col0, int in, int M, const float* x, int ldx, float* y, int ldy,
+                   bool bias, bool accumulate, hipStream_t s) {
+    cmdgen_sgemm(false, true, M, r.out, in, x, ldx, theta + r.w + col0, r.in, y, ldy, (bias && r.has_bias) ? theta + r.b : nullptr,
+                 1.0f, accumulate, 1, s);
+}
+// dx[M, in] (+)= dy[M, out] W[:, col0:col0+in]
+static void linear_dgrad(const float* theta, const PRef& r, int col0, int in, int M, const float* dy, int lddy, float* dx,
+                         int lddx, bool accumulate, hipStream_t s) {
+    cmdgen_sgemm(false, false, M, in, r.out, dy, lddy, theta + r.w + col0, r.in, dx, lddx, nullptr, 1.0f, accumulate, 1, s);
+}
+// dW[:, col0:col0+in] += dy^T x ;  split over the M rows (edges / nodes)
+static void linear_wgrad(float* grad, const PRef& r, int col0, int in, int M, const float* dy, int lddy, const float* x,
+                         int ldx, hipStream_t s) {
+    const int split = M > 4096 ? (M + 2047) / 2048 : 1;
+    cmdgen_sgemm(true, false, r.out, in, M, dy, lddy, x, ldx, grad + r.w + col0, r.in, nullptr, 1.0f, true, split, s);
+}
+
+extern "C" int cmdgen_param_count(cmdgen_handle* h, int64_t* n) {
+    if (!h || !n) return CMDGEN_EINVAL;
+    ParamTable t; build_table(h->dims, t);
+    *n = (int64_t)t.total;
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_param_offset(cmdgen_handle* h, const char* name, int64_t* offset, int64_t* count) {
+    if (!h || !name) return CMDGEN_EINVAL;
+    ParamTable t; build_table(h->dims, t);
+    const std::string k = name;
+    for (const PRef* r : t.order) {
+        if (k == r->name + ".weight") { if (offset) *offset = (int64_t)r->w; if (count) *count = (int64_t)r->out * r->in; return CMDGEN_OK; }
+        if (r->has_bias && k == r->name + ".bias") { if (offset) *offset = (int64_t)r->b; if (count) *count = r->out; return CMDGEN_OK; }
+    }
+    return fail(h, CMDGEN_EINVAL, "no trainable tensor '%s'", name);
+}
+
+extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const float* xh_phar, const float* xh_pocket,
+                                    const float* t_arr, float* eps_phar, cmdgen_stream stream) {
+    if (!h) return CMDGEN_EINVAL;
+    if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
+    if (!theta || !xh_phar || !xh_pocket || !t_arr || !eps_phar) return fail(h, CMDGEN_EINVAL, "null device pointer");
+    hipSetDevice(h->device);
+    int rc = ensure_state(h); if (rc) return rc;
+    TrainState* t = h->train;
+    hipStream_t s = (hipStream_t)stream;
+    const Dims& d = h->dims;
+    const int N = h->lay.N, Nl = h->lay.Nl, Np = h->lay.Np, H = d.H, L = d.L, P = d.P, R = d.R, J = d.J;
+    const int ldp = 3 + P, ldq = 3 + R, ld1 = 2 * H + 2;
+    // radius graph (same compact lists as the sampler), then the edge counts come to the host: grids and the
+    // activation store are sized from them
+    EvalLaunch a = make_launch(h);
+    cmdgen_launch_edges(a, xh_phar, xh_pocket, s);
+    int tot[2];
+    HIPCHK(h, hipMemcpyAsync(tot, h->work.totals, sizeof tot, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    const int E = tot[0], Ec = tot[1];
+    rc = ensure_edges(h, t, E, Ec); if (rc) return rc;
+    t->E = E; t->Ec = Ec; t->theta = theta; t->xh_phar = xh_phar; t->xh_pocket = xh_pocket;
+    const Work& w = h->work;
+    const ParamTable& tb = t->tab;
+    const size_t NH = (size_t)N * H;
+    tr_positions(Nl, Np, xh_phar, ldp, xh_pocket, ldq, t->X, s);
+    // encoders (dynamics.py:84-86)
+    linear(theta, tb.pe0, 0, P, Nl, xh_phar + 3, ldp, t->enc1_l, 2 * P, true, false, s);
+    tr_silu(t->enc1_l, t->enca_l, (size_t)Nl * 2 * P, s);
+    linear(theta, tb.pe2, 0, 2 * P, Nl, t->enca_l, 2 * P, t->enc_out, J, true, false, s);
+    linear(theta, tb.re0, 0, R, Np, xh_pocket + 3, ldq, t->enc1_p, 2 * R, true, false, s);
+    tr_silu(t->enc1_p, t->enca_p, (size_t)Np * 2 * R, s);
+    linear(theta, tb.re2, 0, 2 * R, Np, t->enca_p, 2 * R, t->enc_out + (size_t)Nl * J, J, true, false, s);
+    if (d.condition_time) tr_concat_time(N, J, d.dyn, t->enc_out, t_arr, h->lay.node_sample, t->hdyn, s);
+    else HIPCHK(h, hipMemcpyAsync(t->hdyn, t->enc_out, (size_t)N * J * sizeof(float), hipMemcpyDeviceToDevice, s));
+    linear(theta, tb.emb, 0, d.dyn, N, t->hdyn, d.dyn, t->h, H, true, false, s);
+    for (int l = 0; l < L; ++l) {
+        const ParamTable::Blk& b = tb.blk[l];
+        const float* hl = t->h + (size_t)l * NH;
+        float* hn = t->h + (size_t)(l + 1) * NH;
+        const float4* Xl = t->X + (size_t)l * N;
+        float* pre1 = t->pre1 + (size_t)l * t->ecap * H; float* pre2 = t->pre2 + (size_t)l * t->ecap * H;
+        float* pre6 = t->pre6 + (size_t)l * t->eccap * H; float* pre7 = t->pre7 + (size_t)l * t->eccap * H;
+        float* aggn = t->aggn + (size_t)l * NH; float* pre3 = t->pre3 + (size_t)l * NH;
+        tr_edge_geom(E, w.erow, w.ecol, Xl, d.norm_constant, t->r, nullptr, s);
+        tr_edge_geom(Ec, w.crow, w.ccol, Xl, d.norm_constant, t->rc, t->cd, s);
+        // GCL edge model (egnn_new.py:31-47)
+        linear(theta, b.e0, 0, H, N, hl, H, t->P, H, true, false, s);
+        linear(theta, b.e0, H, H, N, hl, H, t->Q, H, false, false, s);
+        tr_edge_pre(E, H, w.erow, w.ecol, t->P, t->Q, theta + b.e0.w, ld1, t->r, w.ed0, pre1, t->actA, s);
+        linear(theta, b.e2, 0, H, E, t->actA, H, pre2, H, true, false, s);
+        tr_silu(pre2, t->actB, (size_t)E * H, s);
+        HIPCHK(h, hipMemsetAsync(aggn, 0, NH * sizeof(float), s));
+        tr_att_msg(E, H, w.erow, t->actB, d.attention ? theta + b.att.w : nullptr, d.attention ? theta + b.att.b : nullptr,
+                   d.attention, t->z + (size_t)l * t->ecap, aggn, s);
+        tr_scale(aggn, d.norm_factor, NH, s);                                         // 'sum' aggregation / normalization_factor
+        // GCL node model (egnn_new.py:48-58)
+        linear(theta, b.n0, 0, H, N, hl, H, pre3, H, true, false, s);
+        linear(theta, b.n0, H, H, N, aggn, H, pre3, H, false, true, s);
+        tr_silu(pre3, t->nact, NH, s);
+        HIPCHK(h, hipMemcpyAsync(hn, hl, NH * sizeof(float), hipMemcpyDeviceToDevice, s));
+        linear(theta, b.n2, 0, H, N, t->nact, H, hn, H, true, true, s);
+        // EquivariantUpdate (egnn_new.py:87-104) on the receivers that move
+        linear(theta, b.c0, 0, H, N, hn, H, t->P, H, true, false, s);
+        linear(theta, b.c0, H, H, N, hn, H, t->Q, H, false, false, s);
+        tr_edge_pre(Ec, H, w.crow, w.ccol, t->P, t->Q, theta + b.c0.w, ld1, t->rc, w.cd0, pre6, t->actA, s);
+        linear(theta, b.c2, 0, H, Ec, t->actA, H, pre7, H, true, false, s);
+        tr_silu(pre7, t->actB, (size_t)Ec * H, s);
+        HIPCHK(h, hipMemsetAsync(t->accx, 0, (size_t)N * 4 * sizeof(float), s));
+        tr_coord_out(Ec, H, w.crow, t->actB, theta + b.c4.w, t->cd, d.use_tanh, d.coords_range, t->phi + (size_t)l * t->eccap,
+                     t->accx, s);
+        tr_move(N, h->lay.Nm, Xl, t->accx, d.norm_factor, t->X + (size_t)(l + 1) * N, s);
+    }
+    // readout (egnn_new.py:205, dynamics.py:110-127): embedding_out, phar decoder, velocity
+    linear(theta, tb.embo, 0, H, N, t->h + (size_t)L * NH, H, t->hfin, d.dyn, true, false, s);
+    linear(theta, tb.pd0, 0, J, Nl, t->hfin, d.dyn, t->dec1, 2 * P, true, false, s);
+    tr_silu(t->dec1, t->deca, (size_t)Nl * 2 * P, s);
+    linear(theta, tb.pd2, 0, 2 * P, Nl, t->deca, 2 * P, t->dec_out, P, true, false, s);
+    tr_eps_out(Nl, P, t->X + (size_t)L * N, t->X, t->dec_out, eps_phar, s);
+    HIPCHK(h, hipGetLastError());
+    t->have_forward = true;
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, float* grad, cmdgen_stream stream) {
+    if (!h || !h->train || !h->train->have_forward) return fail(h, CMDGEN_ESTATE, "cmdgen_train_backward needs a preceding cmdgen_train_forward");
+    if (!d_eps_phar || !grad) return fail(h, CMDGEN_EINVAL, "null device pointer");
+    hipSetDevice(h->device);
+    TrainState* t = h->train;
+    hipStream_t s = (hipStream_t)stream;
+    const Dims& d = h->dims;
+    const float* theta = t->theta;
+    const int N = h->lay.N, Nl = h->lay.Nl, Np = h->lay.Np, H = d.H, L = d.L, P = d.P, R = d.R, J = d.J;
+    const int ldp = 3 + P, ldq = 3 + R, ld1 = 2 * H + 2;
+    const int E = t->E, Ec = t->Ec, Nm = h->lay.Nm;
+    const Work& w = h->work;
+    const ParamTable& tb = t->tab;
+    const size_t NH = (size_t)N * H;
+    auto bias_grad = [&](const PRef& r, int M, const float* dy, int ld) { tr_colsum(M, r.out, dy, ld, nullptr, grad + r.b, 1, s); };
+    // readout
+    HIPCHK(h, hipMemsetAsync(t->dX, 0, (size_t)N * 4 * sizeof(float), s));
+    tr_eps_bwd(Nl, P, d_eps_phar, t->dX, t->ddec, s);
+    linear_wgrad(grad, tb.pd2, 0, 2 * P, Nl, t->ddec, P, t->deca, 2 * P, s);
+    bias_grad(tb.pd2, Nl, t->ddec, P);
+    linear_dgrad(theta, tb.pd2, 0, 2 * P, Nl, t->ddec, P, t->ddeca, 2 * P, false, s);
+    tr_silu_bwd(t->ddeca, t->dec1, (size_t)Nl * 2 * P, s);
+    linear_wgrad(grad, tb.pd0, 0, J, Nl, t->ddeca, 2 * P, t->hfin, d.dyn, s);
+    bias_grad(tb.pd0, Nl, t->ddeca, 2 * P);
+    HIPCHK(h, hipMemsetAsync(t->dhfin, 0, (size_t)N * d.dyn * sizeof(float), s));
+    linear_dgrad(theta, tb.pd0, 0, J, Nl, t->ddeca, 2 * P, t->dhfin, d.dyn, false, s);
+    linear_wgrad(grad, tb.embo, 0, H, N, t->dhfin, d.dyn, t->h + (size_t)L * NH, H, s);
+    bias_grad(tb.embo, N, t->dhfin, d.dyn);
+    linear_dgrad(theta, tb.embo, 0, H, N, t->dhfin, d.dyn, t->dh, H, false, s);
+    for (int l = L - 1; l >= 0; --l) {
+        const ParamTable::Blk& b = tb.blk[l];
+        const float* hl = t->h + (size_t)l * NH;
+        const float* hn = t->h + (size_t)(l + 1) * NH;
+        const float4* Xl = t->X + (size_t)l * N;
+        const float* pre1 = t->pre1 + (size_t)l * t->ecap * H; const float* pre2 = t->pre2 + (size_t)l * t->ecap * H;
+        const float* pre6 = t->pre6 + (size_t)l * t->eccap * H; const float* pre7 = t->pre7 + (size_t)l * t->eccap * H;
+        const float* aggn = t->aggn + (size_t)l * NH; const float* pre3 = t->pre3 + (size_t)l * NH;
+        const float* phi = t->phi + (size_t)l * t->eccap; const float* z = t->z + (size_t)l * t->ecap;
+        // ---- EquivariantUpdate: x_{l+1} = x_l + acc / nf ; dX holds dL/dx_{l+1} and becomes dL/dx_l
+        HIPCHK(h, hipMemcpyAsync(t->dacc, t->dX, (size_t)N * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        tr_scale(t->dacc, d.norm_factor, (size_t)N * 4, s);
+        tr_edge_geom(Ec, w.crow, w.ccol, Xl, d.norm_constant, t->rc, nullptr, s);
+        tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dacc, Nm, t->dphi, t->dcd, s);
+        tr_silu(pre7, t->actB, (size_t)Ec * H, s);                                    // c2
+        tr_colsum(Ec, H, t->actB, H, t->dphi, grad + b.c4.w, 1, s);                   // d coord_mlp.4
+        tr_outer_silu_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, s);          // actB <- dpre7
+        tr_silu(pre6, t->actA, (size_t)Ec * H, s);                                    // c1
+        linear_wgrad(grad, b.c2, 0, H, Ec, t->actB, H, t->actA, H, s);
+        bias_grad(b.c2, Ec, t->actB, H);
+        linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s);        // actA <- dc1
+        tr_silu_bwd(t->actA, pre6, (size_t)Ec * H, s);                                // actA <- dpre6
+        HIPCHK(h, hipMemsetAsync(t->dP, 0, NH * sizeof(float), s));
+        HIPCHK(h, hipMemsetAsync(t->dQ, 0, NH * sizeof(float), s));
+        tr_scatter_rows(Ec, H, w.crow, t->actA, t->dP, s);
+        tr_scatter_rows(Ec, H, w.ccol, t->actA, t->dQ, s);
+        tr_colsum(Ec, H, t->actA, H, t->rc, grad + b.c0.w + 2 * H, ld1, s);           // radial column
+        tr_colsum(Ec, H, t->actA, H, w.cd0, grad + b.c0.w + 2 * H + 1, ld1, s);       // d0 column
+        tr_rowdot(Ec, H, t->actA, theta + b.c0.w + 2 * H, ld1, t->dr, s);
+        tr_geom_bwd(Ec, w.crow, w.ccol, Xl, d.norm_constant, t->dcd, t->dr, Nm, t->dX, s);
+        bias_grad(b.c0, N, t->dP, H);
+        linear_wgrad(grad, b.c0, 0, H, N, t->dP, H, hn, H, s);
+        linear_wgrad(grad, b.c0, H, H, N, t->dQ, H, hn, H, s);
+        linear_dgrad(theta, b.c0, 0, H, N, t->dP, H, t->dh, H, true, s);
+        linear_dgrad(theta, b.c0, H, H, N, t->dQ, H, t->dh, H, true, s);
+        // ---- node model: h_{l+1} = h_l + W4 SiLU(W3 [h_l | aggn] + b3) + b4 ; dh holds dL/dh_{l+1}
+        tr_silu(pre3, t->nact, NH, s);
+        linear_wgrad(grad, b.n2, 0, H, N, t->dh, H, t->nact, H, s);
+        bias_grad(b.n2, N, t->dh, H);
+        linear_dgrad(theta, b.n2, 0, H, N, t->dh, H, t->dn, H, false, s);
+        tr_silu_bwd(t->dn, pre3, NH, s);                                              // dn <- dpre3
+        bias_grad(b.n0, N, t->dn, H);
+        linear_wgrad(grad, b.n0, 0, H, N, t->dn, H, hl, H, s);
+        linear_wgrad(grad, b.n0, H, H, N, t->dn, H, aggn, H, s);
+        linear_dgrad(theta, b.n0, 0, H, N, t->dn, H, t->dh, H, true, s);              // dh is now dL/dh_l (residual kept)
+        linear_dgrad(theta, b.n0, H, H, N, t->dn, H, t->dagg, H, false, s);
+        tr_scale(t->dagg, d.norm_factor, NH, s);
+        // ---- edge model
+        tr_silu(pre2, t->actB, (size_t)E * H, s);                                     // m2
+        tr_att_msg_bwd(E, H, w.erow, t->actB, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, t->actA, t->dz, s);
+        if (d.attention) {
+            tr_colsum(E, H, t->actB, H, t->dz, grad + b.att.w, 1, s);
+            tr_sum(E, t->dz, grad + b.att.b, s);
+        }
+        tr_silu_bwd(t->actA, pre2, (size_t)E * H, s);                                 // actA <- dpre2
+        tr_silu(pre1, t->actB, (size_t)E * H, s);                                     // m1
+        linear_wgrad(grad, b.e2, 0, H, E, t->actA, H, t->actB, H, s);
+        bias_grad(b.e2, E, t->actA, H);
+        linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s);         // actB <- dm1
+        tr_silu_bwd(t->actB, pre1, (size_t)E * H, s);                                 // actB <- dpre1
+        HIPCHK(h, hipMemsetAsync(t->dP, 0, NH * sizeof(float), s));
+        HIPCHK(h, hipMemsetAsync(t->dQ, 0, NH * sizeof(float), s));
+        tr_scatter_rows(E, H, w.erow, t->actB, t->dP, s);
+        tr_scatter_rows(E, H, w.ecol, t->actB, t->dQ, s);
+        tr_edge_geom(E, w.erow, w.ecol, Xl, d.norm_constant, t->r, nullptr, s);
+        tr_colsum(E, H, t->actB, H, t->r, grad + b.e0.w + 2 * H, ld1, s);
+        tr_colsum(E, H, t->actB, H, w.ed0, grad + b.e0.w + 2 * H + 1, ld1, s);
+        tr_rowdot(E, H, t->actB, theta + b.e0.w + 2 * H, ld1, t->dr, s);
+        tr_geom_bwd(E, w.erow, w.ecol, Xl, d.norm_constant, nullptr, t->dr, Nm, t->dX, s);
+        bias_grad(b.e0, N, t->dP, H);
+        linear_wgrad(grad, b.e0, 0, H, N, t->dP, H, hl, H, s);
+        linear_wgrad(grad, b.e0, H, H, N, t->dQ, H, hl, H, s);
+        linear_dgrad(theta, b.e0, 0, H, N, t->dP, H, t->dh, H, true, s);
+        linear_dgrad(theta, b.e0, H, H, N, t->dQ, H, t->dh, H, true, s);
+    }
+    // embedding and encoders
+    linear_wgrad(grad, tb.emb, 0, d.dyn, N, t->dh, H, t->hdyn, d.dyn, s);
+    bias_grad(tb.emb, N, t->dh, H);
+    linear_dgrad(theta, tb.emb, 0, d.dyn, N, t->dh, H, t->dhdyn, d.dyn, false, s);
+    linear_wgrad(grad, tb.pe2, 0, 2 * P, Nl, t->dhdyn, d.dyn, t->enca_l, 2 * P, s);
+    bias_grad(tb.pe2, Nl, t->dhdyn, d.dyn);
+    linear_dgrad(theta, tb.pe2, 0, 2 * P, Nl, t->dhdyn, d.dyn, t->denca_l, 2 * P, false, s);
+    tr_silu_bwd(t->denca_l, t->enc1_l, (size_t)Nl * 2 * P, s);
+    linear_wgrad(grad, tb.pe0, 0, P, Nl, t->denca_l, 2 * P, t->xh_phar + 3, ldp, s);
+    bias_grad(tb.pe0, Nl, t->denca_l, 2 * P);
+    const float* dq = t->dhdyn + (size_t)Nl * d.dyn;
+    linear_wgrad(grad, tb.re2, 0, 2 * R, Np, dq, d.dyn, t->enca_p, 2 * R, s);
+    bias_grad(tb.re2, Np, dq, d.dyn);
+    linear_dgrad(theta, tb.re2, 0, 2 * R, Np, dq, d.dyn, t->denca_p, 2 * R, false, s);
+    tr_silu_bwd(t->denca_p, t->enc1_p, (size_t)Np * 2 * R, s);
+    linear_wgrad(grad, tb.re0, 0, R, Np, t->denca_p, 2 * R, t->xh_pocket + 3, ldq, s);
+    bias_grad(tb.re0, Np, t->denca_p, 2 * R);
+    HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_grad_sqnorm(cmdgen_handle* h, const float* grad, int64_t n, float* out_host, cmdgen_stream stream) {
+    if (!h || !grad || !out_host || n < 1) return fail(h, CMDGEN_EINVAL, "bad arguments");
+    hipSetDevice(h->device);
+    int rc = ensure_state(h); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipMemsetAsync(h->train->d_scalar, 0, sizeof(float), s));
+    tr_sqsum((size_t)n, grad, h->train->d_scalar, s);
+    HIPCHK(h, hipMemcpyAsync(out_host, h->train->d_scalar, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_adamw_step(cmdgen_handle* h, float* theta, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                 float* max_exp_avg_sq, int64_t n, int64_t step, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, float clip_coef, cmdgen_stream stream) {
+    if (!h || !theta || !grad || !exp_avg || !exp_avg_sq || !max_exp_avg_sq || n < 1 || step < 1) return fail(h, CMDGEN_EINVAL, "bad arguments");
+    hipSetDevice(h->device);
+    const float bias1 = 1.0f - powf(beta1, (float)step);
+    const float bias2 = 1.0f - powf(beta2, (float)step);
+    tr_adamw((size_t)n, theta, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bias1,
+             sqrtf(bias2), clip_coef, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}
+
+// C[M,N] = A op B through the training GEMM (test aid)
+extern "C" int cmdgen_debug_sgemm(cmdgen_handle* h, int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, const float* A,
+                                  int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias,
+                                  int32_t accumulate, int32_t split_k, cmdgen_stream stream) {
+    if (!h || !A || !B || !C) return fail(h, CMDGEN_EINVAL, "null pointer");
+    hipSetDevice(h->device);
+    cmdgen_sgemm(ta != 0, tb != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, 1.0f, accumulate != 0, split_k, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}

@@ -852,6 +852,13 @@ void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* 
     }
 }
 
+// radius graph only (the training path builds its own evaluation on top of the same compact lists)
+void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s) {
+    const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + sizeof(int));
+    hipLaunchKernelGGL(k_edge_count, dim3(a.lay.B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket, (ChainState*)nullptr);
+    hipLaunchKernelGGL(k_edge_write, dim3(a.lay.B), dim3(256), shm, s, a.lay, a.w, a.d);
+}
+
 void cmdgen_launch_nan_fix(const EvalLaunch& a, float* eps_phar, hipStream_t s) {
     hipLaunchKernelGGL(k_nan_fix, dim3((a.lay.Nl + 255) / 256), dim3(256), 0, s, a.lay, a.w, a.d, eps_phar);
 }

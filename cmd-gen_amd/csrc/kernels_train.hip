@@ -1,0 +1,486 @@
+// kernels_train.hip - device kernels of the TRAINING step: the same network as
+// kernels_egnn.hip, evaluated layer by layer with every activation the backward pass needs kept in HBM,
+// and the backward pass itself (dgrad + wgrad of every Linear, the gather/scatter adjoints, the geometry
+// adjoints).  Unlike the sampling path this one is not fused: 288 GB of HBM3E holds all edge-level
+// activations of a batch with room to spare (a [E,H] fp32 tensor is ~25 MB at B=64), so the GEMMs run as one
+// generic exact-fp32 MFMA kernel on plain row-major operands (weights are read straight from the flat
+// parameter buffer the optimizer updates - no re-packing per step) and the rest is bandwidth-bound
+// elementwise work.  Fusing it like the sampler is the obvious next step; correctness comes first.
+#include "cmdgen_dev.h"
+
+// ------------------------------------------------------------------------------------
+// C[M,N] (+)= alpha * op(A)[M,K] * op(B)[K,N] (+ bias[N])          exact fp32 on v_mfma_f32_32x32x2_f32
+//   TA = false: A stored [M][K] (lda)      TA = true: A stored [K][M] (lda)     (wgrad: A = dY^T)
+//   TB = true : B stored [N][K] (ldb) - the nn.Linear weight layout (forward)
+//   TB = false: B stored [K][N] (ldb) - dgrad (dX = dY W) and wgrad (dW = dY^T X)
+// 64x64 tile per workgroup (4 waves, 32x32 each), K tile 16, both operands staged through LDS as
+// [row][k] so that one ds_read_b128 per lane feeds four MFMA k-steps (same pairing as the sampler's
+// tiles).  blockIdx.z splits K (wgrad over tens of thousands of edges); split results are combined with
+// float atomics.  All loads are bounds-checked scalars: operands are arbitrary sub-blocks (column slices of
+// edge_mlp.0, feature columns of xh) with arbitrary leading dimensions.
+// ------------------------------------------------------------------------------------
+#define TG_KT 16
+#define TG_LD (TG_KT + 4)
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float* __restrict__ A, int lda,
+                                               const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                               const float* __restrict__ bias, float alpha, int accumulate, int kchunk) {
+    __shared__ __attribute__((aligned(16))) float As[64 * TG_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * TG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int k_begin = blockIdx.z * kchunk, k_end = min(K, k_begin + kchunk);
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k0 = k_begin; k0 < k_end; k0 += TG_KT) {
+        // stage A tile: As[m][k]
+        if (!TA) {
+            const int m = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gm = m0 + m, gk = k0 + kq + j;
+                As[m * TG_LD + kq + j] = (gm < M && gk < k_end) ? A[(size_t)gm * lda + gk] : 0.f;
+            }
+        } else {
+            const int k = tid >> 4, mq = (tid & 15) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gm = m0 + mq + j, gk = k0 + k;
+                As[(mq + j) * TG_LD + k] = (gm < M && gk < k_end) ? A[(size_t)gk * lda + gm] : 0.f;
+            }
+        }
+        if (TB) {
+            const int n = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gn = n0 + n, gk = k0 + kq + j;
+                Bs[n * TG_LD + kq + j] = (gn < N && gk < k_end) ? B[(size_t)gn * ldb + gk] : 0.f;
+            }
+        } else {
+            const int k = tid >> 4, nq = (tid & 15) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gn = n0 + nq + j, gk = k0 + k;
+                Bs[(nq + j) * TG_LD + k] = (gn < N && gk < k_end) ? B[(size_t)gk * ldb + gn] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < TG_KT / 8; ++kb) {
+            const float4 a = *reinterpret_cast<const float4*>(As + (wm + (lane & 31)) * TG_LD + kb * 8 + 4 * (lane >> 5));
+            const float4 b = *reinterpret_cast<const float4*>(Bs + (wn + (lane & 31)) * TG_LD + kb * 8 + 4 * (lane >> 5));
+            CMDGEN_MFMA32(acc, a.x, b.x);
+            CMDGEN_MFMA32(acc, a.y, b.y);
+            CMDGEN_MFMA32(acc, a.z, b.z);
+            CMDGEN_MFMA32(acc, a.w, b.w);
+        }
+        __syncthreads();
+    }
+    const int gn = n0 + wn + (lane & 31);
+    if (gn >= N) return;
+    const float bv = (bias && blockIdx.z == 0) ? bias[gn] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm >= M) continue;
+        float* c = C + (size_t)gm * ldc + gn;
+        const float v = alpha * acc[r] + bv;
+        if (gridDim.z > 1) atomicAdd(c, v);
+        else if (accumulate) *c += v;
+        else *c = v;
+    }
+}
+
+void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                  int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0) return;
+    int kchunk = K, z = 1;
+    if (split_k > 1) {
+        kchunk = ((K + split_k - 1) / split_k + TG_KT - 1) / TG_KT * TG_KT;
+        z = (K + kchunk - 1) / kchunk;
+    }
+    // split-K partials are combined with atomics: the destination must already hold the value to add to
+    const dim3 grid((N + 63) / 64, (M + 63) / 64, z), block(256);
+    const int acc = accumulate ? 1 : 0;
+    if (!ta && tb) hipLaunchKernelGGL((k_sgemm<false, true>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk);
+    else if (!ta && !tb) hipLaunchKernelGGL((k_sgemm<false, false>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk);
+    else if (ta && !tb) hipLaunchKernelGGL((k_sgemm<true, false>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk);
+    else hipLaunchKernelGGL((k_sgemm<true, true>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk);
+}
+
+// ------------------------------------------------------------------------------------
+// elementwise / gather / scatter pieces.  Edge-level tensors are [E][H] row-major; a wave walks one row.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_exact(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float dsilu(float v) {            // d/dv v*sigmoid(v) = s * (1 + v * (1 - s))
+    const float s = 1.0f / (1.0f + expf(-v));
+    return s * (1.0f + v * (1.0f - s));
+}
+
+// out = SiLU(in)   (n elements)
+__global__ void k_silu(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = silu_exact(in[i]);
+}
+// g <- g * SiLU'(pre)
+__global__ void k_silu_bwd(float* __restrict__ g, const float* __restrict__ pre, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) g[i] *= dsilu(pre[i]);
+}
+__global__ void k_scale(float* __restrict__ x, float d, size_t n) {      // x /= d (a true division, as the reference)
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] /= d;
+}
+__global__ void k_axpy(float* __restrict__ y, const float* __restrict__ x, float a, size_t n) {   // y += a x
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += a * x[i];
+}
+
+// squared distance and coord2diff of every edge of a list (egnn_new.py:265-271) from positions X [N] (float4)
+__global__ void k_edge_geom(int E, const int* __restrict__ row, const int* __restrict__ col, const float4* __restrict__ X,
+                            float norm_constant, float* __restrict__ r_out, float4* __restrict__ cd_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const float4 a = X[row[e]], b = X[col[e]];
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    const float r = dx * dx + dy * dy + dz * dz;
+    r_out[e] = r;
+    if (cd_out) {
+        const float den = sqrtf(r + 1e-8f) + norm_constant;
+        cd_out[e] = make_float4(dx / den, dy / den, dz / den, 0.f);
+    }
+}
+
+// pre[e][c] = P[row e][c] + Q[col e][c] + wr[c] r_e + wd[c] d0_e ; act = SiLU(pre).  wr/wd: column 2H / 2H+1 of the
+// first-layer weight (stride ldw between output channels).
+__global__ void k_edge_pre(int E, int H, const int* __restrict__ row, const int* __restrict__ col,
+                           const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ W1, int ldw,
+                           const float* __restrict__ r, const float* __restrict__ d0, float* __restrict__ pre,
+                           float* __restrict__ act) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const float re = r[e], de = d0[e];
+    const float* p = P + (size_t)row[e] * H;
+    const float* q = Q + (size_t)col[e] * H;
+    for (int c = lane; c < H; c += 64) {
+        const float v = p[c] + q[c] + W1[(size_t)c * ldw + 2 * H] * re + W1[(size_t)c * ldw + 2 * H + 1] * de;
+        pre[(size_t)e * H + c] = v;
+        act[(size_t)e * H + c] = silu_exact(v);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// attention gate + message + segment sum (egnn_new.py:37-47): z = wa . m2 + ba, att = sigmoid(z) (1 when the
+// model has no attention), agg[row] += m2 * att.  Saves z.
+__global__ void k_att_msg(int E, int H, const int* __restrict__ row, const float* __restrict__ m2,
+                          const float* __restrict__ wa, const float* __restrict__ ba, int attention,
+                          float* __restrict__ z_out, float* __restrict__ agg) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const float* m = m2 + (size_t)e * H;
+    float att = 1.0f;
+    if (attention) {
+        float s = 0.f;
+        for (int c = lane; c < H; c += 64) s += m[c] * wa[c];
+        s = wave_sum(s) + ba[0];
+        if (lane == 0) z_out[e] = s;
+        att = 1.0f / (1.0f + expf(-s));
+    }
+    float* a = agg + (size_t)row[e] * H;
+    for (int c = lane; c < H; c += 64) atomicAdd(a + c, m[c] * att);
+}
+
+// adjoint of k_att_msg: dmsg = dagg[row]; dm2 = dmsg*att + dz*wa, dz = (sum_c dmsg*m2) att (1-att); writes dm2 over
+// the scratch row and dz[e].
+__global__ void k_att_msg_bwd(int E, int H, const int* __restrict__ row, const float* __restrict__ m2,
+                              const float* __restrict__ wa, const float* __restrict__ z, int attention,
+                              const float* __restrict__ dagg, float* __restrict__ dm2, float* __restrict__ dz_out) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const float* m = m2 + (size_t)e * H;
+    const float* g = dagg + (size_t)row[e] * H;
+    float att = 1.0f, dz = 0.f;
+    if (attention) {
+        att = 1.0f / (1.0f + expf(-z[e]));
+        float s = 0.f;
+        for (int c = lane; c < H; c += 64) s += g[c] * m[c];
+        dz = wave_sum(s) * att * (1.0f - att);
+        if (lane == 0) dz_out[e] = dz;
+    }
+    for (int c = lane; c < H; c += 64) dm2[(size_t)e * H + c] = g[c] * att + (attention ? dz * wa[c] : 0.f);
+}
+
+// coordinate head (egnn_new.py:87-104): phi = w5 . c2, g = tanh(phi) * range (or phi), accx[row] += cd * g
+__global__ void k_coord_out(int E, int H, const int* __restrict__ row, const float* __restrict__ c2,
+                            const float* __restrict__ w5, const float4* __restrict__ cd, int use_tanh, float range,
+                            float* __restrict__ phi_out, float* __restrict__ accx /* [N][4] */) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const float* m = c2 + (size_t)e * H;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += m[c] * w5[c];
+    s = wave_sum(s);
+    if (lane == 0) {
+        phi_out[e] = s;
+        const float g = use_tanh ? tanhf(s) * range : s;
+        const float4 d = cd[e];
+        float* a = accx + (size_t)row[e] * 4;
+        atomicAdd(a, d.x * g); atomicAdd(a + 1, d.y * g); atomicAdd(a + 2, d.z * g);
+    }
+}
+
+// adjoint of k_coord_out + coord2diff: given dacc [N][4] (gradient of the per-node coordinate sums),
+//   dphi = (cd . dacc[row]) * range * (1 - tanh^2 phi);  dcd = g * dacc[row]
+// writes dphi[e] and accumulates the geometry part (through cd, and through r when dr != null) into dX.
+// dc2[e][c] = dphi * w5[c] is formed by the caller's k_outer_silu_bwd.
+__global__ void k_coord_out_bwd(int E, const int* __restrict__ row, const int* __restrict__ col,
+                                const float4* __restrict__ X, const float* __restrict__ phi, int use_tanh, float range,
+                                float norm_constant, const float* __restrict__ dacc, int n_moving,
+                                float* __restrict__ dphi_out, float4* __restrict__ dcd_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int i = row[e], j = col[e];
+    const float4 a = X[i], b = X[j];
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    const float r = dx * dx + dy * dy + dz * dz;
+    const float den = sqrtf(r + 1e-8f) + norm_constant;
+    const float cx = dx / den, cy = dy / den, cz = dz / den;
+    const float* da = dacc + (size_t)i * 4;
+    const float p = phi[e];
+    const float th = use_tanh ? tanhf(p) : 0.f;
+    const float g = use_tanh ? th * range : p;
+    const float dg = cx * da[0] + cy * da[1] + cz * da[2];
+    dphi_out[e] = use_tanh ? dg * range * (1.0f - th * th) : dg;
+    dcd_out[e] = make_float4(g * da[0], g * da[1], g * da[2], 0.f);
+    (void)n_moving;
+}
+
+// geometry adjoint of one edge list: given dcd[e] (may be null) and dr[e] (may be null) accumulate dX:
+//   cd = diff / (sqrt(r + 1e-8) + nc), r = |diff|^2
+__global__ void k_geom_bwd(int E, const int* __restrict__ row, const int* __restrict__ col, const float4* __restrict__ X,
+                           float norm_constant, const float4* __restrict__ dcd, const float* __restrict__ dr,
+                           int n_moving, float* __restrict__ dX /* [N][4] */) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int i = row[e], j = col[e];
+    if (i == j) return;                                   // diff is identically zero: no dependence on x
+    const float4 a = X[i], b = X[j];
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    const float r = dx * dx + dy * dy + dz * dz;
+    const float sq = sqrtf(r + 1e-8f), den = sq + norm_constant;
+    float gx = 0.f, gy = 0.f, gz = 0.f, gr = dr ? dr[e] : 0.f;
+    if (dcd) {
+        const float4 d = dcd[e];
+        gx = d.x / den; gy = d.y / den; gz = d.z / den;
+        const float dden = -(d.x * dx + d.y * dy + d.z * dz) / (den * den);
+        gr += dden * 0.5f / sq;
+    }
+    gx += 2.0f * dx * gr; gy += 2.0f * dy * gr; gz += 2.0f * dz * gr;
+    if (i < n_moving) { float* p = dX + (size_t)i * 4; atomicAdd(p, gx); atomicAdd(p + 1, gy); atomicAdd(p + 2, gz); }
+    if (j < n_moving) { float* p = dX + (size_t)j * 4; atomicAdd(p, -gx); atomicAdd(p + 1, -gy); atomicAdd(p + 2, -gz); }
+}
+
+// g[e][c] = s[e] * w[c] * SiLU'(pre[e][c])      (dpre7 from dphi and w5)
+__global__ void k_outer_silu_bwd(int E, int H, const float* __restrict__ s, const float* __restrict__ w,
+                                 const float* __restrict__ pre, float* __restrict__ g) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const float se = s[e];
+    for (int c = lane; c < H; c += 64) g[(size_t)e * H + c] = se * w[c] * dsilu(pre[(size_t)e * H + c]);
+}
+
+// dst[idx[e]][c] += src[e][c]
+__global__ void k_scatter_rows(int E, int H, const int* __restrict__ idx, const float* __restrict__ src, float* __restrict__ dst) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    float* d = dst + (size_t)idx[e] * H;
+    for (int c = lane; c < H; c += 64) atomicAdd(d + c, src[(size_t)e * H + c]);
+}
+// dst[e][c] = src[idx[e]][c]
+__global__ void k_gather_rows(int E, int H, const int* __restrict__ idx, const float* __restrict__ src, float* __restrict__ dst) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const float* s = src + (size_t)idx[e] * H;
+    for (int c = lane; c < H; c += 64) dst[(size_t)e * H + c] = s[c];
+}
+// out[e] = sum_c X[e][c] * w[c * ldw]
+__global__ void k_rowdot(int E, int H, const float* __restrict__ X, const float* __restrict__ w, int ldw, float* __restrict__ out) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += X[(size_t)e * H + c] * w[(size_t)c * ldw];
+    s = wave_sum(s);
+    if (lane == 0) out[e] = s;
+}
+// out[c * ldo] += sum_e s[e] * X[e][c]   (s may be null = 1): bias gradients, radial / d0 column gradients, att and
+// coordinate-head weight gradients.  One workgroup per 256-row chunk, one column per thread (coalesced rows).
+__global__ void k_colsum(int E, int ncols, const float* __restrict__ X, int ldx, const float* __restrict__ s,
+                         float* __restrict__ out, int ldo) {
+    const int c = threadIdx.x;
+    if (c >= ncols) return;
+    const int e0 = blockIdx.x * 256, e1 = min(E, e0 + 256);
+    float acc = 0.f;
+    for (int e = e0; e < e1; ++e) acc += (s ? s[e] : 1.0f) * X[(size_t)e * ldx + c];
+    atomicAdd(out + (size_t)c * ldo, acc);
+}
+__global__ void k_sum(int n, const float* __restrict__ x, float* __restrict__ out) {    // out[0] += sum x
+    float v = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v += x[i];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, v);
+}
+
+// node features entering the embedding: [encoder output (J) | t of the sample] (dynamics.py:88-99)
+__global__ void k_concat_time(int N, int J, int dyn, const float* __restrict__ enc /* [N][J] */, const float* __restrict__ t,
+                              const int* __restrict__ node_sample, float* __restrict__ out /* [N][dyn] */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * dyn) return;
+    const int n = i / dyn, k = i - n * dyn;
+    out[i] = k < J ? enc[(size_t)n * J + k] : t[node_sample[n]];
+}
+// positions [N][4] from the two input blocks
+__global__ void k_positions(int Nl, int Np, const float* __restrict__ xh_phar, int ldp, const float* __restrict__ xh_pocket,
+                            int ldq, float4* __restrict__ X) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Nl + Np) return;
+    const float* s = n < Nl ? xh_phar + (size_t)n * ldp : xh_pocket + (size_t)(n - Nl) * ldq;
+    X[n] = make_float4(s[0], s[1], s[2], 0.f);
+}
+// X_next = X + accx / nf for moving rows, copy otherwise
+__global__ void k_move(int N, int n_moving, const float4* __restrict__ X, const float* __restrict__ accx, float nf,
+                       float4* __restrict__ Xn) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float4 p = X[n];
+    if (n < n_moving) { p.x += accx[(size_t)n * 4] / nf; p.y += accx[(size_t)n * 4 + 1] / nf; p.z += accx[(size_t)n * 4 + 2] / nf; }
+    Xn[n] = p;
+}
+// eps_phar[n] = [X_L - X_0 | decoded features]
+__global__ void k_eps_out(int Nl, int P, const float4* __restrict__ XL, const float4* __restrict__ X0,
+                          const float* __restrict__ dec /* [Nl][P] */, float* __restrict__ eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nl * (3 + P)) return;
+    const int n = i / (3 + P), k = i - n * (3 + P);
+    float v;
+    if (k < 3) { const float4 a = XL[n], b = X0[n]; v = k == 0 ? a.x - b.x : k == 1 ? a.y - b.y : a.z - b.z; }
+    else v = dec[(size_t)n * P + k - 3];
+    eps[i] = v;
+}
+// split d_eps [Nl][3+P] into dX [N][4] (phar rows) and ddec [Nl][P]
+__global__ void k_eps_bwd(int Nl, int P, const float* __restrict__ deps, float* __restrict__ dX, float* __restrict__ ddec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nl * (3 + P)) return;
+    const int n = i / (3 + P), k = i - n * (3 + P);
+    if (k < 3) dX[(size_t)n * 4 + k] = deps[i]; else ddec[(size_t)n * P + k - 3] = deps[i];
+}
+
+// ------------------------------------------------------------------------------------
+// optimizer: AdamW with amsgrad (torch.optim.AdamW semantics, lightning_modules.py:141-143) on the flat buffers,
+// with the norm clipping coefficient folded in (clip_grad_norm_: g *= clip when clip < 1).
+// ------------------------------------------------------------------------------------
+__global__ void k_adamw(size_t n, float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                        float* __restrict__ v, float* __restrict__ vmax, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, float bias1, float bias2_sqrt, float clip) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = grad[i] * clip;
+    float p = theta[i];
+    p *= 1.0f - lr * weight_decay;
+    const float mi = m[i] + (g - m[i]) * (1.0f - beta1);           // lerp, as torch
+    const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
+    const float vm = fmaxf(vmax[i], vi);
+    m[i] = mi; v[i] = vi; vmax[i] = vm;
+    const float denom = sqrtf(vm) / bias2_sqrt + eps;
+    theta[i] = p - (lr / bias1) * (mi / denom);
+}
+__global__ void k_sqsum(size_t n, const float* __restrict__ x, float* __restrict__ out) {
+    float v = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v += x[i] * x[i];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, v);
+}
+
+// ------------------------------------------------------------------------------------
+// launch helpers (C++ linkage, used by cmdgen_train.hip)
+// ------------------------------------------------------------------------------------
+#define EW_GRID(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256)
+#define ROW_GRID(E) dim3((unsigned)(((E) + 3) / 4)), dim3(256)        // one wave per row, 4 rows per workgroup
+
+void tr_silu(const float* in, float* out, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_silu, EW_GRID(n), 0, s, in, out, n); }
+void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_silu_bwd, EW_GRID(n), 0, s, g, pre, n); }
+void tr_scale(float* x, float d, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_scale, EW_GRID(n), 0, s, x, d, n); }
+void tr_axpy(float* y, const float* x, float a, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_axpy, EW_GRID(n), 0, s, y, x, a, n); }
+void tr_edge_geom(int E, const int* row, const int* col, const float4* X, float nc, float* r, float4* cd, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_edge_geom, EW_GRID(E), 0, s, E, row, col, X, nc, r, cd);
+}
+void tr_edge_pre(int E, int H, const int* row, const int* col, const float* P, const float* Q, const float* W1, int ldw,
+                 const float* r, const float* d0, float* pre, float* act, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_edge_pre, ROW_GRID(E), 0, s, E, H, row, col, P, Q, W1, ldw, r, d0, pre, act);
+}
+void tr_att_msg(int E, int H, const int* row, const float* m2, const float* wa, const float* ba, int attention, float* z,
+                float* agg, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_att_msg, ROW_GRID(E), 0, s, E, H, row, m2, wa, ba, attention, z, agg);
+}
+void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* wa, const float* z, int attention,
+                    const float* dagg, float* dm2, float* dz, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_att_msg_bwd, ROW_GRID(E), 0, s, E, H, row, m2, wa, z, attention, dagg, dm2, dz);
+}
+void tr_coord_out(int E, int H, const int* row, const float* c2, const float* w5, const float4* cd, int use_tanh, float range,
+                  float* phi, float* accx, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_coord_out, ROW_GRID(E), 0, s, E, H, row, c2, w5, cd, use_tanh, range, phi, accx);
+}
+void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, const float* phi, int use_tanh, float range,
+                      float nc, const float* dacc, int n_moving, float* dphi, float4* dcd, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_coord_out_bwd, EW_GRID(E), 0, s, E, row, col, X, phi, use_tanh, range, nc, dacc, n_moving, dphi, dcd);
+}
+void tr_geom_bwd(int E, const int* row, const int* col, const float4* X, float nc, const float4* dcd, const float* dr,
+                 int n_moving, float* dX, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_geom_bwd, EW_GRID(E), 0, s, E, row, col, X, nc, dcd, dr, n_moving, dX);
+}
+void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_outer_silu_bwd, ROW_GRID(E), 0, s, E, H, sv, w, pre, g);
+}
+void tr_scatter_rows(int E, int H, const int* idx, const float* src, float* dst, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_scatter_rows, ROW_GRID(E), 0, s, E, H, idx, src, dst);
+}
+void tr_gather_rows(int E, int H, const int* idx, const float* src, float* dst, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_gather_rows, ROW_GRID(E), 0, s, E, H, idx, src, dst);
+}
+void tr_rowdot(int E, int H, const float* X, const float* w, int ldw, float* out, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_rowdot, ROW_GRID(E), 0, s, E, H, X, w, ldw, out);
+}
+void tr_colsum(int E, int ncols, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_colsum, dim3((E + 255) / 256), dim3(256), 0, s, E, ncols, X, ldx, sv, out, ldo);
+}
+void tr_sum(int n, const float* x, float* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_sum, dim3(min((n + 255) / 256, 1024)), dim3(256), 0, s, n, x, out);
+}
+void tr_concat_time(int N, int J, int dyn, const float* enc, const float* t, const int* node_sample, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_concat_time, EW_GRID((size_t)N * dyn), 0, s, N, J, dyn, enc, t, node_sample, out);
+}
+void tr_positions(int Nl, int Np, const float* xp, int ldp, const float* xq, int ldq, float4* X, hipStream_t s) {
+    hipLaunchKernelGGL(k_positions, EW_GRID(Nl + Np), 0, s, Nl, Np, xp, ldp, xq, ldq, X);
+}
+void tr_move(int N, int n_moving, const float4* X, const float* accx, float nf, float4* Xn, hipStream_t s) {
+    hipLaunchKernelGGL(k_move, EW_GRID(N), 0, s, N, n_moving, X, accx, nf, Xn);
+}
+void tr_eps_out(int Nl, int P, const float4* XL, const float4* X0, const float* dec, float* eps, hipStream_t s) {
+    if (Nl) hipLaunchKernelGGL(k_eps_out, EW_GRID((size_t)Nl * (3 + P)), 0, s, Nl, P, XL, X0, dec, eps);
+}
+void tr_eps_bwd(int Nl, int P, const float* deps, float* dX, float* ddec, hipStream_t s) {
+    if (Nl) hipLaunchKernelGGL(k_eps_bwd, EW_GRID((size_t)Nl * (3 + P)), 0, s, Nl, P, deps, dX, ddec);
+}
+void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
+              float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_adamw, EW_GRID(n), 0, s, n, theta, grad, m, v, vmax, lr, b1, b2, eps, wd, bias1, bias2_sqrt, clip);
+}
+void tr_sqsum(size_t n, const float* x, float* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_sqsum, dim3((unsigned)(n / 4096 + 1 > 1024 ? 1024 : n / 4096 + 1)), dim3(256), 0, s, n, x, out);
+}

@@ -73,11 +73,13 @@ class ConditionalDDPM(EnVariationalDiffusion):
         return self.size_distribution.log_prob_n1_given_n2(N_phar, N_pocket)
 
     @torch.no_grad()
-    def forward(self, phar, pocket, return_info=False, t_int=None, eps=None):
+    def forward(self, phar, pocket, return_info=False, t_int=None, eps=None, _net=None):
         """The 12 loss terms (+ info) of conditional_model.py:198-320 as VALUES (no autograd graph).
 
         t_int [B,1] and eps (list of the Gaussian draws, one per noised_representation call) may be
-        supplied for reproducibility; otherwise they are drawn like the reference does."""
+        supplied for reproducibility; otherwise they are drawn like the reference does.  ``_net`` replaces the
+        network evaluation (training.HipTrainer passes the activation-saving training forward); the tensors the
+        analytic loss gradient needs are left in ``self._last_train_ctx``."""
         phar, pocket = dict(phar), dict(pocket)
         phar, pocket = self.normalize(phar, pocket)
         B, nd, dev = len(phar['size']), self.n_dims, phar['x'].device
@@ -99,7 +101,8 @@ class ConditionalDDPM(EnVariationalDiffusion):
         nxt = (lambda: next(draws).to(dev)) if draws is not None else (lambda: None)
         z_t, xh_pocket, eps_t = self.noised_representation(xh0_phar, xh0_pocket, phar['mask'], pocket['mask'],
                                                            gamma_t, nxt())
-        net_out, _ = self.dynamics(z_t, xh_pocket, t, phar['mask'], pocket['mask'])
+        net_out, _ = (_net or self.dynamics)(z_t, xh_pocket, t, phar['mask'], pocket['mask'])
+        self._last_train_ctx = {'eps_t': eps_t, 'net_out': net_out, 't_is_zero': t_is_zero}
         xh_phar_hat = self.xh_given_zt_and_epsilon(z_t, net_out, gamma_t, phar['mask'])
         error_t = self.sum_except_batch((eps_t - net_out) ** 2, phar['mask'], B)
         SNR_weight = (1 - self.SNR(gamma_s - gamma_t)).squeeze(1)
@@ -228,11 +231,11 @@ class SimpleConditionalDDPM(ConditionalDDPM):
         return tot / cnt[:, None]
 
     @torch.no_grad()
-    def forward(self, phar, pocket, return_info=False, t_int=None, eps=None):
+    def forward(self, phar, pocket, return_info=False, t_int=None, eps=None, _net=None):
         phar, pocket = dict(phar), dict(pocket)
         com = self._pocket_com(pocket)
         phar['x'] = phar['x'] - com[phar['mask']]
         pocket['x'] = pocket['x'] - com[pocket['mask']]
-        return super().forward(phar, pocket, return_info, t_int=t_int, eps=eps)
+        return super().forward(phar, pocket, return_info, t_int=t_int, eps=eps, _net=_net)
 
     # sample_given_pocket: the library centres the pocket itself when no_com_projection is set

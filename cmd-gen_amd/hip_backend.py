@@ -57,6 +57,15 @@ SYMBOLS = [
     ('cmdgen_joint_chain', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int64,
                                      C.c_uint64, _i64p, _fp, _fp, _fp, C.c_int32, _vp]),
     ('cmdgen_joint_plan', C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i64p, _i64p]),
+    ('cmdgen_param_count', C.c_int, [_vp, _i64p]),
+    ('cmdgen_param_offset', C.c_int, [_vp, C.c_char_p, _i64p, _i64p]),
+    ('cmdgen_train_forward', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _vp]),
+    ('cmdgen_train_backward', C.c_int, [_vp, _fp, _fp, _vp]),
+    ('cmdgen_grad_sqnorm', C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_float), _vp]),
+    ('cmdgen_adamw_step', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.c_float, _vp]),
+    ('cmdgen_debug_sgemm', C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, _fp,
+                                     C.c_int32, _fp, C.c_int32, _fp, C.c_int32, C.c_int32, _vp]),
     ('cmdgen_set_step_table', C.c_int, [_vp, C.c_int32, _vp]),
     ('cmdgen_chain_status', C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i64p, _vp]),
     ('cmdgen_get_counters', C.c_int, [_vp, C.POINTER(Counters), _vp]),
@@ -292,6 +301,60 @@ class Handle:
             ids.ctypes.data_as(_i64p) if ids is not None else None, _ptr(xh_phar), _ptr(xh_pocket), _ptr(z_steps),
             int(bool(use_graph)), self._stream()), 'cmdgen_joint_chain')
         return xh_phar, xh_pocket, z_steps
+
+    # ---- training step (flat parameter / gradient buffers are torch tensors owned by the caller)
+    def param_count(self) -> int:
+        n = C.c_int64(0)
+        self._check(self.lib.cmdgen_param_count(self.h, C.byref(n)), 'cmdgen_param_count')
+        return n.value
+
+    def param_offset(self, name: str):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.cmdgen_param_offset(self.h, name.encode(), C.byref(a), C.byref(b)), 'cmdgen_param_offset')
+        return a.value, b.value
+
+    def train_forward(self, theta, xh_phar, xh_pocket, t):
+        import torch
+        assert theta.is_cuda and theta.dtype == torch.float32 and theta.is_contiguous() and theta.numel() == self.param_count()
+        P, R = self.cfg['phar_nf'], self.cfg['residue_nf']
+        assert tuple(xh_phar.shape) == (self.n_phar, 3 + P) and tuple(xh_pocket.shape) == (self.n_pocket, 3 + R)
+        assert xh_phar.is_contiguous() and xh_pocket.is_contiguous() and xh_phar.dtype == torch.float32
+        t = t.reshape(-1).to(torch.float32).contiguous()
+        assert t.numel() == self.batch
+        eps = torch.empty_like(xh_phar)
+        self._keep = (theta, xh_phar, xh_pocket, t)          # the backward pass reads them again
+        self._check(self.lib.cmdgen_train_forward(self.h, _ptr(theta), _ptr(xh_phar), _ptr(xh_pocket), _ptr(t), _ptr(eps),
+                                                  self._stream()), 'cmdgen_train_forward')
+        return eps
+
+    def train_backward(self, d_eps, grad):
+        import torch
+        assert d_eps.is_cuda and d_eps.dtype == torch.float32 and d_eps.is_contiguous()
+        assert grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous() and grad.numel() == self.param_count()
+        self._check(self.lib.cmdgen_train_backward(self.h, _ptr(d_eps), _ptr(grad), self._stream()), 'cmdgen_train_backward')
+
+    def grad_sqnorm(self, grad) -> float:
+        out = C.c_float(0)
+        self._check(self.lib.cmdgen_grad_sqnorm(self.h, _ptr(grad), grad.numel(), C.byref(out), self._stream()), 'cmdgen_grad_sqnorm')
+        return out.value
+
+    def adamw_step(self, theta, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8,
+                   weight_decay=1e-12, clip_coef=1.0):
+        self._check(self.lib.cmdgen_adamw_step(self.h, _ptr(theta), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                               _ptr(max_exp_avg_sq), theta.numel(), int(step), float(lr), float(betas[0]),
+                                               float(betas[1]), float(eps), float(weight_decay), float(clip_coef),
+                                               self._stream()), 'cmdgen_adamw_step')
+
+    def debug_sgemm(self, A, B, ta=False, tb=True, bias=None, C_out=None, accumulate=False, split_k=1):
+        import torch
+        M = A.shape[1] if ta else A.shape[0]
+        K = A.shape[0] if ta else A.shape[1]
+        N = B.shape[0] if tb else B.shape[1]
+        out = torch.zeros((M, N), dtype=torch.float32, device=A.device) if C_out is None else C_out
+        self._check(self.lib.cmdgen_debug_sgemm(self.h, int(ta), int(tb), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0),
+                                                _ptr(out), out.stride(0), _ptr(bias), int(accumulate), int(split_k),
+                                                self._stream()), 'cmdgen_debug_sgemm')
+        return out
 
     def chain_status(self):
         a, b, n = C.c_float(0), C.c_float(0), C.c_int64(0)

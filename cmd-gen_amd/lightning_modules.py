@@ -129,13 +129,13 @@ class PharPocketDDPM(nn.Module):
                   'mask': data['pocket_mask'].to(self.device, INT_TYPE)}
         return phar, pocket
 
-    def forward(self, data, t_int=None, eps=None):
+    def forward(self, data, t_int=None, eps=None, _net=None):
         """-> (nll [B], info) as lightning_modules.py:188-239.  Loss VALUES (evaluation / monitoring): the HIP
         evaluation has no backward pass yet, so this cannot drive an optimizer (SURVEY.md section 8f #1)."""
         phar, pocket = self.get_phar_and_pocket(data)
         delta_log_px, error_t_phar, error_t_pocket, SNR_weight, loss_0_x_phar, loss_0_x_pocket, loss_0_h, \
             neg_log_const_0, kl_prior, log_pN, t_int_, xh_phar_hat, info = \
-            self.ddpm(phar, pocket, return_info=True, t_int=t_int, eps=eps)
+            self.ddpm(phar, pocket, return_info=True, t_int=t_int, eps=eps, **({'_net': _net} if _net is not None else {}))
         dev = error_t_phar.device
         error_t_pocket, loss_0_x_pocket = error_t_pocket.to(dev), loss_0_x_pocket.to(dev)
         if self.loss_type == 'l2' and self.training:

@@ -1,0 +1,127 @@
+"""The training step of PharPocketDDPM on the HIP training path.
+
+Counterpart of ``training_step`` (lightning_modules.py:245-260), ``configure_optimizers`` (:141-143,
+AdamW amsgrad, weight_decay 1e-12), ``configure_gradient_clipping`` (:543-568, adaptive norm clipping from a queue
+of recent gradient norms) and the DDP gradient averaging Lightning sets up (train.py:111-121).
+
+Design: every trainable tensor of ``EGNNDynamics`` lives in ONE flat fp32 device buffer ``theta`` (the module's
+parameters are re-pointed to views of it, so ``state_dict`` / checkpoints / sampling keep working with no copies);
+``grad`` and the three AdamW moment buffers have the same layout.  One step =
+  loss terms on the activation-saving forward (``cmdgen_train_forward``)  ->  analytic dL/d eps (a few torch ops on
+  device)  ->  ``cmdgen_train_backward`` (parameter gradients)  ->  one ``all_reduce`` of the flat gradient over
+  RCCL when ``world_size > 1``  ->  gradient norm, clipping coefficient  ->  ``cmdgen_adamw_step``.
+Only the l2 training objective of the shipped configs and the conditional model are supported.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import utils
+
+
+class HipTrainer:
+    def __init__(self, model, lr: Optional[float] = None, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-12, clip_grad: Optional[bool] = None, process_group=None):
+        if model.mode == 'joint':
+            raise NotImplementedError("the training step is built for the conditional model (mode 'pocket_conditioning')")
+        if model.loss_type != 'l2':
+            raise NotImplementedError("only diffusion_loss_type 'l2' (all shipped configs) has an analytic loss gradient here")
+        self.model = model
+        self.ddpm = model.ddpm
+        self.dyn = model.ddpm.dynamics
+        self.lr = float(model.lr if lr is None else lr)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.clip_grad = bool(getattr(model, 'clip_grad', True) if clip_grad is None else clip_grad)
+        self.gradnorm_queue = utils.Queue()
+        self.gradnorm_queue.add(3000)                      # large value that will be flushed (lightning_modules.py:78-80)
+        self.group = process_group
+        self.step_count = 0
+        h = self.dyn.hip_handle()
+        self.h = h
+        n = h.param_count()
+        dev = next(self.dyn.parameters()).device
+        self.theta = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.theta)
+        self.exp_avg = torch.zeros_like(self.theta)
+        self.exp_avg_sq = torch.zeros_like(self.theta)
+        self.max_exp_avg_sq = torch.zeros_like(self.theta)
+        # re-point the module's parameters at views of the flat buffer (zero-copy; names as in the state_dict)
+        seen = 0
+        for name, p in self.dyn.named_parameters():
+            off, cnt = h.param_offset(name)
+            assert cnt == p.numel(), name
+            view = self.theta[off:off + cnt].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            seen += cnt
+        assert seen == n, (seen, n)
+        self.last_info: Dict[str, float] = {}
+
+    # ------------------------------------------------------------------
+    def _net(self, z_t, xh_pocket, t, phar_mask, pocket_mask):
+        eps = self.h.train_forward(self.theta, z_t.to(torch.float32).contiguous(), xh_pocket.to(torch.float32).contiguous(), t)
+        return eps, None
+
+    @torch.no_grad()
+    def loss_and_grad(self, data, t_int=None, eps=None):
+        """-> (loss, nll [B], info); leaves dL/d theta (this rank's batch mean) in ``self.grad``."""
+        model = self.model
+        model.train()
+        phar, pocket = model.get_phar_and_pocket(data)
+        B = len(phar['size'])
+        self.h.set_layout(phar['size'].detach().to('cpu', torch.int64).numpy(),
+                          pocket['size'].detach().to('cpu', torch.int64).numpy())
+        nll, info = model.forward(data, t_int=t_int, eps=eps, _net=self._net)
+        loss = nll.mean(0)
+        ctx = self.ddpm._last_train_ctx
+        eps_t, net_out, t_is_zero = ctx['eps_t'], ctx['net_out'], ctx['t_is_zero'].squeeze(1)
+        nd, pnf = self.ddpm.n_dims, self.ddpm.phar_nf
+        n_b = phar['size'].to(torch.float32)
+        # d loss / d net_out: loss = mean_b [ 0.5 * error_t/((nd+P) n_b) * (t != 0) + loss_0_x/(nd n_b) * (t == 0) + const ]
+        # (lightning_modules.py:198-217; conditional_model.py:243-262, :291-301)
+        diff = net_out - eps_t
+        w_t = ((1.0 - t_is_zero) / ((nd + pnf) * n_b) / B)[phar['mask']]
+        w_0 = (t_is_zero / (nd * n_b) / B)[phar['mask']]
+        d_eps = diff * w_t[:, None]
+        d_eps[:, :nd] += diff[:, :nd] * w_0[:, None]
+        self.grad.zero_()
+        self.h.train_backward(d_eps.contiguous(), self.grad)
+        return loss, nll, info
+
+    def _allreduce(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(self.group)
+            if world > 1:
+                dist.all_reduce(self.grad, group=self.group)          # one flat bucket over RCCL
+                self.grad.div_(world)
+
+    def optimizer_step(self, max_grad_norm: Optional[float] = None):
+        """Adaptive clipping + AdamW(amsgrad) on the flat buffers; returns (grad_norm, max_grad_norm)."""
+        grad_norm = float(np.sqrt(self.h.grad_sqnorm(self.grad)))
+        clip = 1.0
+        if self.clip_grad:
+            if max_grad_norm is None:                                  # 150 % of the recent mean + 2 stdev
+                max_grad_norm = 1.5 * self.gradnorm_queue.mean() + 2 * self.gradnorm_queue.std()
+            clip = min(1.0, float(max_grad_norm) / (grad_norm + 1e-6))     # torch.nn.utils.clip_grad_norm_
+            self.gradnorm_queue.add(float(max_grad_norm) if grad_norm > max_grad_norm else grad_norm)
+            if grad_norm > max_grad_norm:
+                print(f'Clipped gradient with value {grad_norm:.1f} while allowed {max_grad_norm:.1f}')
+        self.step_count += 1
+        self.h.adamw_step(self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, self.step_count,
+                          self.lr, self.betas, self.eps, self.weight_decay, clip)
+        self.dyn._weights_sig = None            # the sampler's packed copy of the weights is stale now
+        return grad_norm, max_grad_norm
+
+    def training_step(self, data, t_int=None, eps=None, max_grad_norm: Optional[float] = None):
+        loss, nll, info = self.loss_and_grad(data, t_int=t_int, eps=eps)
+        self._allreduce()
+        grad_norm, mx = self.optimizer_step(max_grad_norm)
+        info = dict(info)
+        info['loss'] = loss
+        info['grad_norm'] = grad_norm
+        self.last_info = info
+        return info

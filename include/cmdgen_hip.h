@@ -199,6 +199,44 @@ int cmdgen_joint_chain(cmdgen_handle* h, const float* phar_x, const float* phar_
 int cmdgen_joint_plan(cmdgen_handle* h, int32_t timesteps, int32_t resamplings, int32_t jump_length,
                       int32_t inpaint, int64_t* n_steps, int64_t* n_draws);
 
+/* ---- training step (conditional model) -------------------------------------------------- */
+/* The trainable tensors of EGNNDynamics live in ONE flat fp32 device buffer owned by the caller, in the
+ * reference's registration order (the state_dict order below 'ddpm.dynamics.': weight then bias of every
+ * nn.Linear, dynamics.py:21-60, egnn_new.py:15-29, :78-83) - so that the gradient is one contiguous bucket
+ * (a single RCCL all-reduce per step replaces DDP's bucketing, train.py:111-121) and the optimizer is one
+ * elementwise kernel.  cmdgen_param_count / cmdgen_param_offset describe the layout
+ * (name e.g. "egnn.e_block_0.gcl_0.edge_mlp.0.weight"). */
+int cmdgen_param_count(cmdgen_handle* h, int64_t* n_params);
+int cmdgen_param_offset(cmdgen_handle* h, const char* name, int64_t* offset, int64_t* count);
+
+/* EGNNDynamics.forward (dynamics.py:75-139) on the parameters `theta`, keeping every activation the backward
+ * pass needs (after cmdgen_set_layout; no cmdgen_finalize_weights needed).  t dev [batch].  Writes
+ * eps_phar dev [Nl, 3+phar_nf].  Synchronises the stream once (the edge count sizes the activation store). */
+int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const float* xh_phar, const float* xh_pocket,
+                         const float* t, float* eps_phar, cmdgen_stream stream);
+
+/* Backward of the last cmdgen_train_forward: given dL/d eps_phar (dev [Nl, 3+phar_nf]) ADDS dL/d theta into
+ * `grad` (dev, same layout as theta; zero it first for a fresh gradient).  What autograd does for
+ * loss.backward() in the reference's training_step (lightning_modules.py:245-260). */
+int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, float* grad, cmdgen_stream stream);
+
+/* Sum of squares of a device vector -> host float (the global gradient norm of utils.get_grad_norm,
+ * utils.py:39-61, is its square root).  Synchronises the stream. */
+int cmdgen_grad_sqnorm(cmdgen_handle* h, const float* grad, int64_t n, float* out_host, cmdgen_stream stream);
+
+/* One torch.optim.AdamW(amsgrad=True) update (lightning_modules.py:141-143) of the flat buffer, with the norm
+ * clipping coefficient of clip_grad_norm_ folded in (pass 1.0 for none; lightning_modules.py:543-568 computes
+ * it on the host).  `step` counts from 1.  All pointers dev [n]. */
+int cmdgen_adamw_step(cmdgen_handle* h, float* theta, const float* grad, float* exp_avg, float* exp_avg_sq,
+                      float* max_exp_avg_sq, int64_t n, int64_t step, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, float clip_coef, cmdgen_stream stream);
+
+/* C[M,N] (+)= op(A) op(B) (+ bias) through the training path's exact-fp32 MFMA GEMM (test aid):
+ * ta: A stored [K][M]; tb: B stored [N][K] (nn.Linear weight). */
+int cmdgen_debug_sgemm(cmdgen_handle* h, int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, const float* A,
+                       int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias,
+                       int32_t accumulate, int32_t split_k, cmdgen_stream stream);
+
 /* Optional: supply the per-step scalars of sample_p_zs_given_zt computed by the host
  * (e.g. with the same torch fp32 ops as the reference, bit for bit) instead of the
  * library's own libm evaluation.  coef_host is [K+1][4]:
