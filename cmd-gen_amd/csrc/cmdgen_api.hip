@@ -252,13 +252,6 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
         memcmp(h->cur_npocket.data(), npk, batch * sizeof(int64_t)) == 0)
         return CMDGEN_OK;
     hipSetDevice(h->device);
-    hipDeviceSynchronize();
-    if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
-    if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
-    free_pool(h->layout_allocs); free_pool(h->chain_allocs); h->chain_K = -1;
-    free_pool(h->joint_allocs); h->joint_steps = -1; h->joint_key.clear();
-    cmdgen_train_free(h->train); h->train = nullptr;
-    h->have_layout = false;
     const Dims& d = h->dims;
     const int B = (int)batch;
     std::vector<int> vph(B), vpk(B), bph(B), bpk(B);
@@ -279,32 +272,62 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
         for (int i = 0; i < vph[b]; ++i) ns[bph[b] + i] = b;
         for (int i = 0; i < vpk[b]; ++i) ns[Nl + bpk[b] + i] = b;
     }
+    // graphs bake the layout into their kernel arguments; chain buffers are sized by it
+    if (h->own_stream) hipStreamSynchronize(h->own_stream);
+    if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+    if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
     int rc; void* p;
     Layout& L = h->lay; Work& w = h->work;
+    // Workspaces are capacity-based: a new batch that fits the current capacities (every training step and every
+    // dataset batch has its own ragged layout) only re-uploads the small index arrays - no hipMalloc/hipFree.
+    const bool fits = h->cap_B >= B && h->cap_Nl >= Nl && h->cap_Np >= Np && h->cap_N >= N && h->cap_e >= ecap && h->cap_ec >= eccap;
+    if (!fits) {
+        hipDeviceSynchronize();
+        free_pool(h->layout_allocs); free_pool(h->chain_allocs); h->chain_K = -1;
+        free_pool(h->joint_allocs); h->joint_steps = -1; h->joint_key.clear();
+        cmdgen_train_free(h->train); h->train = nullptr;
+        h->have_layout = false;
+        auto grow = [](int64_t v) { return v + v / 4 + 64; };
+        const int64_t cB = h->cap_B ? grow(B) : B, cNl = h->cap_B ? grow(Nl) : Nl, cNp = h->cap_B ? grow(Np) : Np;
+        const int64_t cN = cNl + cNp, ce = h->cap_B ? grow(ecap) : ecap, cec = h->cap_B ? grow(eccap) : eccap;
+        const int64_t cNm = d.joint ? cN : cNl;
+#define ALLOC(dst, type, count, zero) do { rc = dev_alloc(h, h->layout_allocs, &p, (size_t)(count) * sizeof(type), zero); if (rc) return rc; dst = (type*)p; } while (0)
+        ALLOC(L.num_phar, const int, cB, true); ALLOC(L.num_pocket, const int, cB, true);
+        ALLOC(L.phar_base, const int, cB, true); ALLOC(L.pocket_base, const int, cB, true);
+        ALLOC(L.node_sample, const int, cN, true);
+        ALLOC(h->d_gid, int64_t, cB, true); L.pocket_gid = h->d_gid;
+        const size_t H = d.H;
+        ALLOC(w.X0, float4, cNm, true); ALLOC(w.XP, float4, cNp, true);
+        ALLOC(w.XL, float4, (size_t)d.L * cNm, true); ALLOC(w.ACC, float4, (size_t)d.L * cNm, true);
+        ALLOC(w.h, float, cN * H, true); ALLOC(w.P, float, cN * H, true); ALLOC(w.Q, float, cN * H, true);
+        ALLOC(w.Pc, float, cN * H, true); ALLOC(w.Qc, float, cN * H, true); ALLOC(w.agg, float, cN * H, true);
+        ALLOC(w.degL, int, cN, true); ALLOC(w.pocketE, int, cB, true); ALLOC(w.pocketEph, int, cB, true);
+        ALLOC(w.pocketEns, int, cB, true); ALLOC(w.pocketEnsQ, int, cB, true);
+        ALLOC(w.erow, int, ce, false); ALLOC(w.ecol, int, ce, false); ALLOC(w.ed0, float, ce, false);
+        ALLOC(w.crow, int, cec, false); ALLOC(w.ccol, int, cec, false); ALLOC(w.cd0, float, cec, false);
+        ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true);
+        ALLOC(w.eps_tmp, float, (size_t)cNl * (3 + d.P), true);
+#undef ALLOC
+        h->cap_B = cB; h->cap_Nl = cNl; h->cap_Np = cNp; h->cap_N = cN; h->cap_e = ce; h->cap_ec = cec;
+    } else {
+        // chain / joint buffers are sized by the exact layout and cheap: rebuilt on the next chain
+        free_pool(h->chain_allocs); h->chain_K = -1;
+        free_pool(h->joint_allocs); h->joint_steps = -1; h->joint_key.clear();
+    }
     L.B = B; L.Nl = (int)Nl; L.Np = (int)Np; L.N = (int)N; L.max_n = max_n;
     L.Nm = d.joint ? (int)N : (int)Nl;
-    const int64_t Nm = L.Nm;
-#define ALLOC_I(dst, vec) do { rc = dev_alloc(h, h->layout_allocs, &p, (vec).size() * sizeof(int), false); if (rc) return rc; \
-        HIPCHK(h, hipMemcpy(p, (vec).data(), (vec).size() * sizeof(int), hipMemcpyHostToDevice)); dst = (const int*)p; } while (0)
-    ALLOC_I(L.num_phar, vph); ALLOC_I(L.num_pocket, vpk); ALLOC_I(L.phar_base, bph); ALLOC_I(L.pocket_base, bpk);
-    ALLOC_I(L.node_sample, ns);
-#undef ALLOC_I
-    std::vector<int64_t> gid(B); for (int b = 0; b < B; ++b) gid[b] = b;
-    rc = dev_alloc(h, h->layout_allocs, &p, B * sizeof(int64_t), false); if (rc) return rc;
-    HIPCHK(h, hipMemcpy(p, gid.data(), B * sizeof(int64_t), hipMemcpyHostToDevice));
-    h->d_gid = (int64_t*)p; L.pocket_gid = h->d_gid;
-    const size_t H = d.H;
-#define ALLOC(dst, type, count, zero) do { rc = dev_alloc(h, h->layout_allocs, &p, (size_t)(count) * sizeof(type), zero); if (rc) return rc; dst = (type*)p; } while (0)
-    ALLOC(w.X0, float4, Nm, true); ALLOC(w.XP, float4, Np, true);
-    ALLOC(w.XL, float4, (size_t)d.L * Nm, true); ALLOC(w.ACC, float4, (size_t)d.L * Nm, true);
-    ALLOC(w.h, float, N * H, true); ALLOC(w.P, float, N * H, true); ALLOC(w.Q, float, N * H, true);
-    ALLOC(w.Pc, float, N * H, true); ALLOC(w.Qc, float, N * H, true); ALLOC(w.agg, float, N * H, true);
-    ALLOC(w.degL, int, N, true); ALLOC(w.pocketE, int, B, true); ALLOC(w.pocketEph, int, B, true); ALLOC(w.pocketEns, int, B, true); ALLOC(w.pocketEnsQ, int, B, true);
-    ALLOC(w.erow, int, ecap, false); ALLOC(w.ecol, int, ecap, false); ALLOC(w.ed0, float, ecap, false);
-    ALLOC(w.crow, int, eccap, false); ALLOC(w.ccol, int, eccap, false); ALLOC(w.cd0, float, eccap, false);
-    ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true);
-    ALLOC(w.eps_tmp, float, (size_t)Nl * (3 + d.P), true);
-#undef ALLOC
+    // (plain hipMemcpy: ordered after all earlier work of the blocking streams that may still read the old arrays)
+#define UP_I(dst, vec) HIPCHK(h, hipMemcpy((void*)(dst), (vec).data(), (vec).size() * sizeof(int), hipMemcpyHostToDevice))
+    UP_I(L.num_phar, vph); UP_I(L.num_pocket, vpk); UP_I(L.phar_base, bph); UP_I(L.pocket_base, bpk); UP_I(L.node_sample, ns);
+#undef UP_I
+    {
+        std::vector<int64_t> gid(B); for (int b = 0; b < B; ++b) gid[b] = b;
+        HIPCHK(h, hipMemcpy(h->d_gid, gid.data(), B * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    if (fits) {   // reused buffers: restore the invariants a fresh (zeroed) workspace has
+        HIPCHK(h, hipMemset(w.agg, 0, (size_t)N * d.H * sizeof(float)));
+        HIPCHK(h, hipMemset(w.totals, 0, 4 * sizeof(int)));
+    }
     h->ecap = ecap; h->eccap = eccap;
     {   // Rows per tile: the largest tile that still gives every CU a few workgroups.  Edge counts
         // are only known on the device, so they are estimated from the layout (C-alpha pockets

@@ -40,6 +40,7 @@ struct cmdgen_handle {
     Layout lay{};
     Work work{};
     int64_t ecap = 0, eccap = 0;
+    int64_t cap_B = 0, cap_Nl = 0, cap_Np = 0, cap_N = 0, cap_e = 0, cap_ec = 0;   // allocated capacities of the workspaces
     int edge_grid = 512, coord_grid = 256;
     int n_cus = 256;
     int node_mt = 64, edge_mt = 64, coord_mt = 64;   // rows per tile, chosen in cmdgen_set_layout

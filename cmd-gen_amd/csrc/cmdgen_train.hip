@@ -113,7 +113,8 @@ static int ensure_state(cmdgen_handle* h) {
     TrainState* t = new TrainState();
     build_table(h->dims, t->tab);
     const Dims& d = h->dims;
-    const size_t N = h->lay.N, Nl = h->lay.Nl, Np = h->lay.Np, H = d.H, L = d.L;
+    // sized by the layout CAPACITIES (cmdgen_set_layout): the state survives every new batch that fits them
+    const size_t N = h->cap_N, Nl = h->cap_Nl, Np = h->cap_Np, H = d.H, L = d.L;
     int rc; void* p;
 #define NA(dst, type, count) do { rc = dev_alloc(h, t->node_allocs, &p, (size_t)(count) * sizeof(type), true); \
         if (rc) { cmdgen_train_free(t); return rc; } dst = (type*)p; } while (0)
@@ -167,8 +168,7 @@ static void linear_dgrad(const float* theta, const PRef& r, int col0, int in, in
 // dW[:, col0:col0+in] += dy^T x ;  split over the M rows (edges / nodes)
 static void linear_wgrad(float* grad, const PRef& r, int col0, int in, int M, const float* dy, int lddy, const float* x,
                          int ldx, hipStream_t s) {
-    const int split = M > 4096 ? (M + 2047) / 2048 : 1;
-    cmdgen_sgemm(true, false, r.out, in, M, dy, lddy, x, ldx, grad + r.w + col0, r.in, nullptr, 1.0f, true, split, s);
+    cmdgen_sgemm(true, false, r.out, in, M, dy, lddy, x, ldx, grad + r.w + col0, r.in, nullptr, 1.0f, true, 0, s);
 }
 
 extern "C" int cmdgen_param_count(cmdgen_handle* h, int64_t* n) {

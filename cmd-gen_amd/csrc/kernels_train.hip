@@ -19,10 +19,12 @@
 // float atomics.  All loads are bounds-checked scalars: operands are arbitrary sub-blocks (column slices of
 // edge_mlp.0, feature columns of xh) with arbitrary leading dimensions.
 // ------------------------------------------------------------------------------------
-#define TG_KT 16
+#define TG_KT 32
 #define TG_LD (TG_KT + 4)
 
-template <bool TA, bool TB>
+// VEC: every 4-element group a thread loads is 16-byte aligned and entirely in range (host-checked: base pointers,
+// leading dimensions, the contiguous extent and the k chunking are multiples of 4) -> one global_load_dwordx4.
+template <bool TA, bool TB, bool VECA, bool VECB>
 __global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float* __restrict__ A, int lda,
                                                const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                                                const float* __restrict__ bias, float alpha, int accumulate, int kchunk) {
@@ -35,38 +37,51 @@ __global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float*
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // operand stored [row][k] (k contiguous): thread -> (row = tid/8 + 32*p, k4 = (tid%8)*4), p = 0,1
+    // operand stored [k][row] (row contiguous): thread -> (k = tid/16 + 16*p, row4 = (tid%16)*4), p = 0,1
+    auto stage = [&](float* S, const float* __restrict__ G, int ld, bool trans, bool VEC, int r0, int R, int k0) {
+        if (!trans) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int r = (tid >> 3) + 32 * p, kq = (tid & 7) * 4;
+                const int gr = r0 + r, gk = k0 + kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gr < R) {
+                    const float* src = G + (size_t)gr * ld + gk;
+                    if (VEC && gk + 3 < k_end) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (gk < k_end) v.x = src[0];
+                        if (gk + 1 < k_end) v.y = src[1];
+                        if (gk + 2 < k_end) v.z = src[2];
+                        if (gk + 3 < k_end) v.w = src[3];
+                    }
+                }
+                *reinterpret_cast<float4*>(S + r * TG_LD + kq) = v;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int k = (tid >> 4) + 16 * p, rq = (tid & 15) * 4;
+                const int gk = k0 + k, gr = r0 + rq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gk < k_end) {
+                    const float* src = G + (size_t)gk * ld + gr;
+                    if (VEC && gr + 3 < R) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (gr < R) v.x = src[0];
+                        if (gr + 1 < R) v.y = src[1];
+                        if (gr + 2 < R) v.z = src[2];
+                        if (gr + 3 < R) v.w = src[3];
+                    }
+                }
+                S[(rq + 0) * TG_LD + k] = v.x; S[(rq + 1) * TG_LD + k] = v.y;
+                S[(rq + 2) * TG_LD + k] = v.z; S[(rq + 3) * TG_LD + k] = v.w;
+            }
+        }
+    };
     for (int k0 = k_begin; k0 < k_end; k0 += TG_KT) {
-        // stage A tile: As[m][k]
-        if (!TA) {
-            const int m = tid >> 2, kq = (tid & 3) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gm = m0 + m, gk = k0 + kq + j;
-                As[m * TG_LD + kq + j] = (gm < M && gk < k_end) ? A[(size_t)gm * lda + gk] : 0.f;
-            }
-        } else {
-            const int k = tid >> 4, mq = (tid & 15) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gm = m0 + mq + j, gk = k0 + k;
-                As[(mq + j) * TG_LD + k] = (gm < M && gk < k_end) ? A[(size_t)gk * lda + gm] : 0.f;
-            }
-        }
-        if (TB) {
-            const int n = tid >> 2, kq = (tid & 3) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gn = n0 + n, gk = k0 + kq + j;
-                Bs[n * TG_LD + kq + j] = (gn < N && gk < k_end) ? B[(size_t)gn * ldb + gk] : 0.f;
-            }
-        } else {
-            const int k = tid >> 4, nq = (tid & 15) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gn = n0 + nq + j, gk = k0 + k;
-                Bs[(nq + j) * TG_LD + k] = (gn < N && gk < k_end) ? B[(size_t)gk * ldb + gn] : 0.f;
-            }
-        }
+        stage(As, A, lda, TA, VECA, m0, M, k0);
+        stage(Bs, B, ldb, !TB, VECB, n0, N, k0);
         __syncthreads();
 #pragma unroll
         for (int kb = 0; kb < TG_KT / 8; ++kb) {
@@ -94,9 +109,17 @@ __global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float*
     }
 }
 
+// split_k: 0 = choose so that the launch fills the chip (wgrad: few output tiles, K = thousands of rows); 1 = none
 void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                   int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) return;
+    const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
+    if (split_k == 0) {
+        split_k = (1024 + tiles - 1) / tiles;
+        const int max_split = (K + 127) / 128;
+        if (split_k > max_split) split_k = max_split;
+        if (split_k < 1) split_k = 1;
+    }
     int kchunk = K, z = 1;
     if (split_k > 1) {
         kchunk = ((K + split_k - 1) / split_k + TG_KT - 1) / TG_KT * TG_KT;
@@ -105,10 +128,15 @@ void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda
     // split-K partials are combined with atomics: the destination must already hold the value to add to
     const dim3 grid((N + 63) / 64, (M + 63) / 64, z), block(256);
     const int acc = accumulate ? 1 : 0;
-    if (!ta && tb) hipLaunchKernelGGL((k_sgemm<false, true>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk);
-    else if (!ta && !tb) hipLaunchKernelGGL((k_sgemm<false, false>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk);
-    else if (ta && !tb) hipLaunchKernelGGL((k_sgemm<true, false>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk);
-    else hipLaunchKernelGGL((k_sgemm<true, true>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk);
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool va = al(A) && (lda % 4 == 0), vb = al(B) && (ldb % 4 == 0);      // weights inside the flat buffer may be unaligned
+#define SG(TA_, TB_, VA_, VB_) hipLaunchKernelGGL((k_sgemm<TA_, TB_, VA_, VB_>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk)
+#define SG2(TA_, TB_) do { if (va && vb) SG(TA_, TB_, true, true); else if (va) SG(TA_, TB_, true, false); \
+                           else if (vb) SG(TA_, TB_, false, true); else SG(TA_, TB_, false, false); } while (0)
+    if (!ta && tb) SG2(false, true); else if (!ta && !tb) SG2(false, false);
+    else if (ta && !tb) SG2(true, false); else SG2(true, true);
+#undef SG2
+#undef SG
 }
 
 // ------------------------------------------------------------------------------------
@@ -325,7 +353,7 @@ __global__ void k_colsum(int E, int ncols, const float* __restrict__ X, int ldx,
                          float* __restrict__ out, int ldo) {
     const int c = threadIdx.x;
     if (c >= ncols) return;
-    const int e0 = blockIdx.x * 256, e1 = min(E, e0 + 256);
+    const int e0 = blockIdx.x * 32, e1 = min(E, e0 + 32);
     float acc = 0.f;
     for (int e = e0; e < e1; ++e) acc += (s ? s[e] : 1.0f) * X[(size_t)e * ldx + c];
     atomicAdd(out + (size_t)c * ldo, acc);
@@ -457,7 +485,7 @@ void tr_rowdot(int E, int H, const float* X, const float* w, int ldw, float* out
     if (E) hipLaunchKernelGGL(k_rowdot, ROW_GRID(E), 0, s, E, H, X, w, ldw, out);
 }
 void tr_colsum(int E, int ncols, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_colsum, dim3((E + 255) / 256), dim3(256), 0, s, E, ncols, X, ldx, sv, out, ldo);
+    if (E) hipLaunchKernelGGL(k_colsum, dim3((E + 31) / 32), dim3(256), 0, s, E, ncols, X, ldx, sv, out, ldo);
 }
 void tr_sum(int n, const float* x, float* out, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_sum, dim3(min((n + 255) / 256, 1024)), dim3(256), 0, s, n, x, out);

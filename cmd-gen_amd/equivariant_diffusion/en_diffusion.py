@@ -48,6 +48,17 @@ class DistributionNodes:
         self.m = torch.distributions.Categorical(prob.view(-1), validate_args=True)
         self.n1_given_n2 = [torch.distributions.Categorical(prob[:, j], validate_args=True) for j in range(n2)]
         self.n2_given_n1 = [torch.distributions.Categorical(prob[i, :], validate_args=True) for i in range(n1)]
+        # the conditional log-probabilities of every (n1, n2) pair, evaluated once by the same Categorical objects:
+        # the per-sample Python loop of the reference (:1010-1022) becomes one device gather (no host syncs per step)
+        self._lp_n1_given_n2 = torch.stack([m.log_prob(torch.arange(n1)) for m in self.n1_given_n2], dim=1)
+        self._lp_n2_given_n1 = torch.stack([m.log_prob(torch.arange(n2)) for m in self.n2_given_n1], dim=0)
+        self._lp_cache = {}
+
+    def _table(self, which, device):
+        key = (which, str(device))
+        if key not in self._lp_cache:
+            self._lp_cache[key] = (self._lp_n1_given_n2 if which == 1 else self._lp_n2_given_n1).to(device)
+        return self._lp_cache[key]
 
     def sample(self, n_samples=1):
         idx = self.m.sample((n_samples,))
@@ -68,13 +79,11 @@ class DistributionNodes:
 
     def log_prob_n1_given_n2(self, n1, n2):
         assert n1.dim() == 1 and n2.dim() == 1
-        lp = torch.stack([self.n1_given_n2[int(c)].log_prob(i.cpu()) for i, c in zip(n1, n2)])
-        return lp.to(n1.device)
+        return self._table(1, n1.device)[n1.long(), n2.long()]
 
     def log_prob_n2_given_n1(self, n2, n1):
         assert n1.dim() == 1 and n2.dim() == 1
-        lp = torch.stack([self.n2_given_n1[int(c)].log_prob(i.cpu()) for i, c in zip(n2, n1)])
-        return lp.to(n2.device)
+        return self._table(2, n2.device)[n1.long(), n2.long()]
 
 
 class EnVariationalDiffusion(nn.Module):

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Training-step throughput (BASELINE configs[3] shape on one GPU, fp32): PharPocketDDPM training_step on synthetic
+CrossDocked-shaped complexes through cmdgen_amd.training.HipTrainer.  With --gpus N (launched by torch.distributed.run)
+every rank trains on its own batch and the flat gradient is all-reduced over RCCL.  Prints one JSON line.
+
+    python tools/bench_train.py [--batch 64] [--steps 20] [--warmup 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cmdgen_amd  # noqa: E402,F401
+from cmdgen_amd.lightning_modules import PharPocketDDPM  # noqa: E402
+from cmdgen_amd.synthetic import ModelConfig, make_pockets, make_state_dict  # noqa: E402
+from cmdgen_amd.training import HipTrainer  # noqa: E402
+
+
+def synthetic_batch(B, first, dev):
+    pb = make_pockets(B, 'CA', ragged=True, first_index=first)
+    rng = np.random.Generator(np.random.PCG64(first))
+    nl = pb.num_nodes_phar
+    pm = np.repeat(np.arange(B), nl)
+    com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(B)])
+    px = (com[pm] + rng.normal(size=(len(pm), 3)) * 2.5).astype(np.float32)
+    poh = np.eye(8, dtype=np.float32)[rng.integers(0, 8, size=len(pm))]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return {'phar_coords': t(px), 'phar_one_hot': t(poh), 'num_phar_atoms': t(nl), 'phar_mask': t(pm),
+            'pocket_c_alpha': t(pb.x), 'pocket_one_hot': t(pb.one_hot), 'num_pocket_nodes': t(pb.size),
+            'pocket_mask': t(pb.mask)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=64, help='complexes per GPU')
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--profile', action='store_true', help='print the per-kernel time table of 3 steps (torch.profiler)')
+    a = ap.parse_args()
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl')
+    dev = torch.device('cuda', local)
+    cfg = ModelConfig()
+    hp = dict(outdir='out', dataset='crossdock', datadir='data', batch_size=a.batch, lr=1e-3,
+              egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=256, n_layers=5, attention=True,
+                                    tanh=True, norm_constant=1, inv_sublayers=1, sin_embedding=False,
+                                    aggregation_method='sum', normalization_factor=100),
+              diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
+                                         diffusion_noise_precision=1e-5, diffusion_loss_type='l2', normalize_factors=[1, 4]),
+              num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
+              eval_params=Namespace(n_eval_samples=100, eval_batch_size=100), mode='pocket_conditioning',
+              node_histogram=np.ones((30, 70)), pocket_representation='CA')
+    model = PharPocketDDPM(**hp)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed=0).items()}, strict=True)
+    model = model.to(dev)
+    tr = HipTrainer(model)
+    batches = [synthetic_batch(a.batch, 50000 + 1000 * rank + 100 * i, dev) for i in range(4)]
+    torch.manual_seed(rank)
+    for i in range(a.warmup):
+        tr.training_step(batches[i % 4])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    losses = []
+    for i in range(a.steps):
+        losses.append(float(tr.training_step(batches[i % 4])['loss']))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        td = torch.tensor([dt], device=dev)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dt = float(td)
+    if a.profile and rank == 0:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            for i in range(3):
+                tr.training_step(batches[i % 4])
+            torch.cuda.synchronize()
+        rows = [(e.key, e.device_time_total, e.count) for e in prof.key_averages() if e.device_time_total > 0]
+        rows.sort(key=lambda r: -r[1])
+        tot = sum(r[1] for r in rows)
+        sys.stderr.write('device time of 3 steps: %.2f ms\n' % (tot / 1e3))
+        for k, us, n in rows[:28]:
+            sys.stderr.write('%8.2f ms %5.1f%% %6d  %s\n' % (us / 1e3, 100 * us / tot, n, k[:110]))
+        crow = [(e.key, e.self_cpu_time_total, e.count) for e in prof.key_averages() if e.self_cpu_time_total > 0]
+        crow.sort(key=lambda r: -r[1])
+        sys.stderr.write('host self time of 3 steps: %.2f ms\n' % (sum(r[1] for r in crow) / 1e3))
+        for k, us, n in crow[:14]:
+            sys.stderr.write('%8.2f ms %6d  %s\n' % (us / 1e3, n, k[:90]))
+    # phase split on one more step (events around forward / backward / optimizer)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record(); tr.loss_and_grad(batches[0]); ev[1].record(); tr._allreduce(); ev[2].record(); tr.optimizer_step(); ev[3].record()
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(json.dumps({'metric': 'training complexes/s', 'value': a.batch * world * a.steps / dt, 'n_gpus': world,
+                          'ms_per_step': dt / a.steps * 1e3, 'batch_per_gpu': a.batch, 'dtype': 'f32',
+                          'first_loss': losses[0], 'last_loss': losses[-1],
+                          'phase_ms': {'loss_and_grad': ev[0].elapsed_time(ev[1]), 'allreduce': ev[1].elapsed_time(ev[2]),
+                                       'clip_and_adamw': ev[2].elapsed_time(ev[3])}}))
+
+
+if __name__ == '__main__':
+    main()
