@@ -158,6 +158,19 @@ __global__ void k_silu_bwd(float* __restrict__ g, const float* __restrict__ pre,
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) g[i] *= dsilu(pre[i]);
 }
+__global__ void k_silu4(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = in[i];
+    out[i] = make_float4(silu_exact(v.x), silu_exact(v.y), silu_exact(v.z), silu_exact(v.w));
+}
+__global__ void k_silu_bwd4(float4* __restrict__ g, const float4* __restrict__ pre, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 p = pre[i]; float4 v = g[i];
+    v.x *= dsilu(p.x); v.y *= dsilu(p.y); v.z *= dsilu(p.z); v.w *= dsilu(p.w);
+    g[i] = v;
+}
 __global__ void k_scale(float* __restrict__ x, float d, size_t n) {      // x /= d (a true division, as the reference)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] /= d;
@@ -358,6 +371,34 @@ __global__ void k_colsum(int E, int ncols, const float* __restrict__ X, int ldx,
     for (int e = e0; e < e1; ++e) acc += (s ? s[e] : 1.0f) * X[(size_t)e * ldx + c];
     atomicAdd(out + (size_t)c * ldo, acc);
 }
+// aligned fast path (ncols % 4 == 0, ldx % 4 == 0, 16-byte aligned X): 128 rows per workgroup, a thread owns four
+// columns of every fourth row (16-byte loads, independent accumulators), the four row groups are combined in LDS, so a
+// workgroup issues ncols atomics for 128 rows instead of ncols per 32 rows (the atomics all hit the same few lines).
+__global__ __launch_bounds__(256) void k_colsum4(int E, int ncols, const float* __restrict__ X, int ldx,
+                                                 const float* __restrict__ s, float* __restrict__ out, int ldo) {
+    __shared__ float4 red[4][64];
+    const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int e0 = blockIdx.x * 128, e1 = min(E, e0 + 128);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (4 * cg < ncols) {
+#pragma unroll 4
+        for (int e = e0 + rg; e < e1; e += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(X + (size_t)e * ldx + 4 * cg);
+            const float w = s ? s[e] : 1.0f;
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+    }
+    red[rg][cg] = acc;
+    __syncthreads();
+    if (rg == 0 && 4 * cg < ncols) {
+        const float4 a = red[0][cg], b = red[1][cg], c = red[2][cg], d = red[3][cg];
+        float* o = out + (size_t)(4 * cg) * ldo;
+        atomicAdd(o, (a.x + b.x) + (c.x + d.x));
+        atomicAdd(o + ldo, (a.y + b.y) + (c.y + d.y));
+        atomicAdd(o + 2 * (size_t)ldo, (a.z + b.z) + (c.z + d.z));
+        atomicAdd(o + 3 * (size_t)ldo, (a.w + b.w) + (c.w + d.w));
+    }
+}
 __global__ void k_sum(int n, const float* __restrict__ x, float* __restrict__ out) {    // out[0] += sum x
     float v = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v += x[i];
@@ -441,8 +482,17 @@ __global__ void k_sqsum(size_t n, const float* __restrict__ x, float* __restrict
 #define EW_GRID(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256)
 #define ROW_GRID(E) dim3((unsigned)(((E) + 3) / 4)), dim3(256)        // one wave per row, 4 rows per workgroup
 
-void tr_silu(const float* in, float* out, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_silu, EW_GRID(n), 0, s, in, out, n); }
-void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_silu_bwd, EW_GRID(n), 0, s, g, pre, n); }
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+void tr_silu(const float* in, float* out, size_t n, hipStream_t s) {
+    if (!n) return;
+    if (n % 4 == 0 && al16(in) && al16(out)) hipLaunchKernelGGL(k_silu4, EW_GRID(n / 4), 0, s, (const float4*)in, (float4*)out, n / 4);
+    else hipLaunchKernelGGL(k_silu, EW_GRID(n), 0, s, in, out, n);
+}
+void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s) {
+    if (!n) return;
+    if (n % 4 == 0 && al16(g) && al16(pre)) hipLaunchKernelGGL(k_silu_bwd4, EW_GRID(n / 4), 0, s, (float4*)g, (const float4*)pre, n / 4);
+    else hipLaunchKernelGGL(k_silu_bwd, EW_GRID(n), 0, s, g, pre, n);
+}
 void tr_scale(float* x, float d, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_scale, EW_GRID(n), 0, s, x, d, n); }
 void tr_axpy(float* y, const float* x, float a, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_axpy, EW_GRID(n), 0, s, y, x, a, n); }
 void tr_edge_geom(int E, const int* row, const int* col, const float4* X, float nc, float* r, float4* cd, hipStream_t s) {
@@ -485,7 +535,11 @@ void tr_rowdot(int E, int H, const float* X, const float* w, int ldw, float* out
     if (E) hipLaunchKernelGGL(k_rowdot, ROW_GRID(E), 0, s, E, H, X, w, ldw, out);
 }
 void tr_colsum(int E, int ncols, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_colsum, dim3((E + 31) / 32), dim3(256), 0, s, E, ncols, X, ldx, sv, out, ldo);
+    if (!E) return;
+    if (ncols % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ncols <= 256)
+        hipLaunchKernelGGL(k_colsum4, dim3((E + 127) / 128), dim3(256), 0, s, E, ncols, X, ldx, sv, out, ldo);
+    else
+        hipLaunchKernelGGL(k_colsum, dim3((E + 31) / 32), dim3(256), 0, s, E, ncols, X, ldx, sv, out, ldo);
 }
 void tr_sum(int n, const float* x, float* out, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_sum, dim3(min((n + 255) / 256, 1024)), dim3(256), 0, s, n, x, out);
