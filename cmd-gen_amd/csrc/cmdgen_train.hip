@@ -6,7 +6,8 @@
 
 void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s);
 void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                  int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s);
+                  int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s,
+                  int epi = 0, float* aux = nullptr, int ldaux = 0);
 void tr_silu(const float* in, float* out, size_t n, hipStream_t s);
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
 void tr_scale(float* x, float a, size_t n, hipStream_t s);
@@ -17,7 +18,7 @@ void tr_edge_pre(int E, int H, const int* row, const int* col, const float* P, c
 void tr_att_msg(int E, int H, const int* row, const float* m2, const float* wa, const float* ba, int attention, float* z,
                 float* agg, hipStream_t s);
 void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* wa, const float* z, int attention,
-                    const float* dagg, float* dm2, float* dz, hipStream_t s);
+                    const float* dagg, const float* pre2, float* dm2, float* dz, hipStream_t s);
 void tr_coord_out(int E, int H, const int* row, const float* c2, const float* w5, const float4* cd, int use_tanh, float range,
                   float* phi, float* accx, hipStream_t s);
 void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, const float* phi, int use_tanh, float range,
@@ -57,8 +58,9 @@ static void build_table(const Dims& d, ParamTable& t) {
     size_t off = 0;
     auto add = [&](PRef& r, const std::string& name, int out, int in, bool bias) {
         r.name = name; r.out = out; r.in = in; r.has_bias = bias;
-        r.w = off; off += (size_t)out * in;
-        if (bias) { r.b = off; off += out; }
+        off = (off + 3) & ~(size_t)3;                       // every tensor starts 16-byte aligned (vector loads in the GEMM);
+        r.w = off; off += (size_t)out * in;                 // the padding floats are never read and stay zero
+        if (bias) { off = (off + 3) & ~(size_t)3; r.b = off; off += out; }
         t.order.push_back(&r);
     };
     const int P = d.P, R = d.R, J = d.J, H = d.H;
@@ -76,7 +78,7 @@ static void build_table(const Dims& d, ParamTable& t) {
         add(b.c0, c + "coord_mlp.0", H, 2 * H + 2, true);  add(b.c2, c + "coord_mlp.2", H, H, true);
         add(b.c4, c + "coord_mlp.4", 1, H, false);
     }
-    t.total = off;
+    t.total = (off + 3) & ~(size_t)3;
 }
 
 struct TrainState {
@@ -93,6 +95,7 @@ struct TrainState {
     float4* X;                          // [L+1][N]
     // edge level (saved per block)
     float *pre1, *pre2, *z, *pre6, *pre7, *phi;
+    float *act1, *act2, *act6, *act7;   // SiLU of the above, written by the producing kernel (nothing is recomputed)
     // edge level scratch
     float *actA, *actB, *r, *rc, *dr, *dz, *dphi;
     float4 *cd, *dcd;
@@ -123,7 +126,7 @@ static int ensure_state(cmdgen_handle* h) {
     NA(t->enc_out, float, N * d.J); NA(t->hdyn, float, N * d.dyn);
     NA(t->h, float, (L + 1) * N * H); NA(t->X, float4, (L + 1) * N);
     NA(t->P, float, N * H); NA(t->Q, float, N * H); NA(t->aggn, float, L * N * H); NA(t->pre3, float, L * N * H);
-    NA(t->nact, float, N * H); NA(t->accx, float, N * 4); NA(t->hfin, float, N * d.dyn);
+    NA(t->nact, float, L * N * H); NA(t->accx, float, N * 4); NA(t->hfin, float, N * d.dyn);
     NA(t->dec1, float, Nl * 2 * d.P); NA(t->deca, float, Nl * 2 * d.P); NA(t->dec_out, float, Nl * d.P);
     NA(t->dh, float, N * H); NA(t->dX, float, N * 4); NA(t->dacc, float, N * 4); NA(t->dagg, float, N * H);
     NA(t->dP, float, N * H); NA(t->dQ, float, N * H); NA(t->dn, float, N * H); NA(t->dhfin, float, N * d.dyn);
@@ -145,6 +148,7 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
 #define EA(dst, type, count) do { rc = dev_alloc(h, t->edge_allocs, &p, (size_t)(count) * sizeof(type), false); \
         if (rc) return rc; dst = (type*)p; } while (0)
     EA(t->pre1, float, L * ec * H); EA(t->pre2, float, L * ec * H); EA(t->z, float, L * ec);
+    EA(t->act1, float, L * ec * H); EA(t->act2, float, L * ec * H); EA(t->act6, float, L * ecc * H); EA(t->act7, float, L * ecc * H);
     EA(t->pre6, float, L * ecc * H); EA(t->pre7, float, L * ecc * H); EA(t->phi, float, L * ecc);
     EA(t->actA, float, em * H); EA(t->actB, float, em * H);
     EA(t->r, float, ec); EA(t->rc, float, ecc); EA(t->dr, float, em); EA(t->dz, float, ec); EA(t->dphi, float, ecc);
@@ -156,14 +160,15 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
 
 // y[M, out] = x[M, in(ldx)] W^T + b      (W, b inside the flat buffer)
 static void linear(const float* theta, const PRef& r, int col0, int in, int M, const float* x, int ldx, float* y, int ldy,
-                   bool bias, bool accumulate, hipStream_t s) {
+                   bool bias, bool accumulate, hipStream_t s, float* act = nullptr) {
     cmdgen_sgemm(false, true, M, r.out, in, x, ldx, theta + r.w + col0, r.in, y, ldy, (bias && r.has_bias) ? theta + r.b : nullptr,
-                 1.0f, accumulate, 1, s);
+                 1.0f, accumulate, 1, s, act ? 1 : 0, act, ldy);      // act: SiLU(y) written alongside y
 }
 // dx[M, in] (+)= dy[M, out] W[:, col0:col0+in]
 static void linear_dgrad(const float* theta, const PRef& r, int col0, int in, int M, const float* dy, int lddy, float* dx,
-                         int lddx, bool accumulate, hipStream_t s) {
-    cmdgen_sgemm(false, false, M, in, r.out, dy, lddy, theta + r.w + col0, r.in, dx, lddx, nullptr, 1.0f, accumulate, 1, s);
+                         int lddx, bool accumulate, hipStream_t s, const float* pre = nullptr) {
+    cmdgen_sgemm(false, false, M, in, r.out, dy, lddy, theta + r.w + col0, r.in, dx, lddx, nullptr, 1.0f, accumulate, 1, s,
+                 pre ? 2 : 0, const_cast<float*>(pre), lddx);       // pre: dx *= SiLU'(pre) (the activation that fed this Linear)
 }
 // dW[:, col0:col0+in] += dy^T x ;  split over the M rows (edges / nodes)
 static void linear_wgrad(float* grad, const PRef& r, int col0, int in, int M, const float* dy, int lddy, const float* x,
@@ -233,32 +238,32 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
         float* pre1 = t->pre1 + (size_t)l * t->ecap * H; float* pre2 = t->pre2 + (size_t)l * t->ecap * H;
         float* pre6 = t->pre6 + (size_t)l * t->eccap * H; float* pre7 = t->pre7 + (size_t)l * t->eccap * H;
         float* aggn = t->aggn + (size_t)l * NH; float* pre3 = t->pre3 + (size_t)l * NH;
+        float* act1 = t->act1 + (size_t)l * t->ecap * H; float* act2 = t->act2 + (size_t)l * t->ecap * H;
+        float* act6 = t->act6 + (size_t)l * t->eccap * H; float* act7 = t->act7 + (size_t)l * t->eccap * H;
+        float* nact = t->nact + (size_t)l * NH;
         tr_edge_geom(E, w.erow, w.ecol, Xl, d.norm_constant, t->r, nullptr, s);
         tr_edge_geom(Ec, w.crow, w.ccol, Xl, d.norm_constant, t->rc, t->cd, s);
         // GCL edge model (egnn_new.py:31-47)
         linear(theta, b.e0, 0, H, N, hl, H, t->P, H, true, false, s);
         linear(theta, b.e0, H, H, N, hl, H, t->Q, H, false, false, s);
-        tr_edge_pre(E, H, w.erow, w.ecol, t->P, t->Q, theta + b.e0.w, ld1, t->r, w.ed0, pre1, t->actA, s);
-        linear(theta, b.e2, 0, H, E, t->actA, H, pre2, H, true, false, s);
-        tr_silu(pre2, t->actB, (size_t)E * H, s);
+        tr_edge_pre(E, H, w.erow, w.ecol, t->P, t->Q, theta + b.e0.w, ld1, t->r, w.ed0, pre1, act1, s);
+        linear(theta, b.e2, 0, H, E, act1, H, pre2, H, true, false, s, act2);
         HIPCHK(h, hipMemsetAsync(aggn, 0, NH * sizeof(float), s));
-        tr_att_msg(E, H, w.erow, t->actB, d.attention ? theta + b.att.w : nullptr, d.attention ? theta + b.att.b : nullptr,
+        tr_att_msg(E, H, w.erow, act2, d.attention ? theta + b.att.w : nullptr, d.attention ? theta + b.att.b : nullptr,
                    d.attention, t->z + (size_t)l * t->ecap, aggn, s);
         tr_scale(aggn, d.norm_factor, NH, s);                                         // 'sum' aggregation / normalization_factor
         // GCL node model (egnn_new.py:48-58)
         linear(theta, b.n0, 0, H, N, hl, H, pre3, H, true, false, s);
-        linear(theta, b.n0, H, H, N, aggn, H, pre3, H, false, true, s);
-        tr_silu(pre3, t->nact, NH, s);
+        linear(theta, b.n0, H, H, N, aggn, H, pre3, H, false, true, s, nact);
         HIPCHK(h, hipMemcpyAsync(hn, hl, NH * sizeof(float), hipMemcpyDeviceToDevice, s));
-        linear(theta, b.n2, 0, H, N, t->nact, H, hn, H, true, true, s);
+        linear(theta, b.n2, 0, H, N, nact, H, hn, H, true, true, s);
         // EquivariantUpdate (egnn_new.py:87-104) on the receivers that move
         linear(theta, b.c0, 0, H, N, hn, H, t->P, H, true, false, s);
         linear(theta, b.c0, H, H, N, hn, H, t->Q, H, false, false, s);
-        tr_edge_pre(Ec, H, w.crow, w.ccol, t->P, t->Q, theta + b.c0.w, ld1, t->rc, w.cd0, pre6, t->actA, s);
-        linear(theta, b.c2, 0, H, Ec, t->actA, H, pre7, H, true, false, s);
-        tr_silu(pre7, t->actB, (size_t)Ec * H, s);
+        tr_edge_pre(Ec, H, w.crow, w.ccol, t->P, t->Q, theta + b.c0.w, ld1, t->rc, w.cd0, pre6, act6, s);
+        linear(theta, b.c2, 0, H, Ec, act6, H, pre7, H, true, false, s, act7);
         HIPCHK(h, hipMemsetAsync(t->accx, 0, (size_t)N * 4 * sizeof(float), s));
-        tr_coord_out(Ec, H, w.crow, t->actB, theta + b.c4.w, t->cd, d.use_tanh, d.coords_range, t->phi + (size_t)l * t->eccap,
+        tr_coord_out(Ec, H, w.crow, act7, theta + b.c4.w, t->cd, d.use_tanh, d.coords_range, t->phi + (size_t)l * t->eccap,
                      t->accx, s);
         tr_move(N, h->lay.Nm, Xl, t->accx, d.norm_factor, t->X + (size_t)(l + 1) * N, s);
     }
@@ -311,19 +316,19 @@ extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, 
         const float* pre6 = t->pre6 + (size_t)l * t->eccap * H; const float* pre7 = t->pre7 + (size_t)l * t->eccap * H;
         const float* aggn = t->aggn + (size_t)l * NH; const float* pre3 = t->pre3 + (size_t)l * NH;
         const float* phi = t->phi + (size_t)l * t->eccap; const float* z = t->z + (size_t)l * t->ecap;
+        const float* act1 = t->act1 + (size_t)l * t->ecap * H; const float* act2 = t->act2 + (size_t)l * t->ecap * H;
+        const float* act6 = t->act6 + (size_t)l * t->eccap * H; const float* act7 = t->act7 + (size_t)l * t->eccap * H;
+        const float* nact = t->nact + (size_t)l * NH;
         // ---- EquivariantUpdate: x_{l+1} = x_l + acc / nf ; dX holds dL/dx_{l+1} and becomes dL/dx_l
         HIPCHK(h, hipMemcpyAsync(t->dacc, t->dX, (size_t)N * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
         tr_scale(t->dacc, d.norm_factor, (size_t)N * 4, s);
         tr_edge_geom(Ec, w.crow, w.ccol, Xl, d.norm_constant, t->rc, nullptr, s);
         tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dacc, Nm, t->dphi, t->dcd, s);
-        tr_silu(pre7, t->actB, (size_t)Ec * H, s);                                    // c2
-        tr_colsum(Ec, H, t->actB, H, t->dphi, grad + b.c4.w, 1, s);                   // d coord_mlp.4
+        tr_colsum(Ec, H, act7, H, t->dphi, grad + b.c4.w, 1, s);                      // d coord_mlp.4 (c2 = act7)
         tr_outer_silu_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, s);          // actB <- dpre7
-        tr_silu(pre6, t->actA, (size_t)Ec * H, s);                                    // c1
-        linear_wgrad(grad, b.c2, 0, H, Ec, t->actB, H, t->actA, H, s);
+        linear_wgrad(grad, b.c2, 0, H, Ec, t->actB, H, act6, H, s);                   // c1 = act6
         bias_grad(b.c2, Ec, t->actB, H);
-        linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s);        // actA <- dc1
-        tr_silu_bwd(t->actA, pre6, (size_t)Ec * H, s);                                // actA <- dpre6
+        linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
         HIPCHK(h, hipMemsetAsync(t->dP, 0, NH * sizeof(float), s));
         HIPCHK(h, hipMemsetAsync(t->dQ, 0, NH * sizeof(float), s));
         tr_scatter_rows(Ec, H, w.crow, t->actA, t->dP, s);
@@ -338,11 +343,9 @@ extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, 
         linear_dgrad(theta, b.c0, 0, H, N, t->dP, H, t->dh, H, true, s);
         linear_dgrad(theta, b.c0, H, H, N, t->dQ, H, t->dh, H, true, s);
         // ---- node model: h_{l+1} = h_l + W4 SiLU(W3 [h_l | aggn] + b3) + b4 ; dh holds dL/dh_{l+1}
-        tr_silu(pre3, t->nact, NH, s);
-        linear_wgrad(grad, b.n2, 0, H, N, t->dh, H, t->nact, H, s);
+        linear_wgrad(grad, b.n2, 0, H, N, t->dh, H, nact, H, s);
         bias_grad(b.n2, N, t->dh, H);
-        linear_dgrad(theta, b.n2, 0, H, N, t->dh, H, t->dn, H, false, s);
-        tr_silu_bwd(t->dn, pre3, NH, s);                                              // dn <- dpre3
+        linear_dgrad(theta, b.n2, 0, H, N, t->dh, H, t->dn, H, false, s, pre3);       // dn <- dn1 * SiLU'(pre3) = dpre3
         bias_grad(b.n0, N, t->dn, H);
         linear_wgrad(grad, b.n0, 0, H, N, t->dn, H, hl, H, s);
         linear_wgrad(grad, b.n0, H, H, N, t->dn, H, aggn, H, s);
@@ -350,18 +353,14 @@ extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, 
         linear_dgrad(theta, b.n0, H, H, N, t->dn, H, t->dagg, H, false, s);
         tr_scale(t->dagg, d.norm_factor, NH, s);
         // ---- edge model
-        tr_silu(pre2, t->actB, (size_t)E * H, s);                                     // m2
-        tr_att_msg_bwd(E, H, w.erow, t->actB, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, t->actA, t->dz, s);
+        tr_att_msg_bwd(E, H, w.erow, act2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, pre2, t->actA, t->dz, s);   // actA <- dpre2
         if (d.attention) {
-            tr_colsum(E, H, t->actB, H, t->dz, grad + b.att.w, 1, s);
+            tr_colsum(E, H, act2, H, t->dz, grad + b.att.w, 1, s);
             tr_sum(E, t->dz, grad + b.att.b, s);
         }
-        tr_silu_bwd(t->actA, pre2, (size_t)E * H, s);                                 // actA <- dpre2
-        tr_silu(pre1, t->actB, (size_t)E * H, s);                                     // m1
-        linear_wgrad(grad, b.e2, 0, H, E, t->actA, H, t->actB, H, s);
+        linear_wgrad(grad, b.e2, 0, H, E, t->actA, H, act1, H, s);                    // m1 = act1
         bias_grad(b.e2, E, t->actA, H);
-        linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s);         // actB <- dm1
-        tr_silu_bwd(t->actB, pre1, (size_t)E * H, s);                                 // actB <- dpre1
+        linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
         HIPCHK(h, hipMemsetAsync(t->dP, 0, NH * sizeof(float), s));
         HIPCHK(h, hipMemsetAsync(t->dQ, 0, NH * sizeof(float), s));
         tr_scatter_rows(E, H, w.erow, t->actB, t->dP, s);

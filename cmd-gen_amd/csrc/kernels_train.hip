@@ -19,6 +19,12 @@
 // float atomics.  All loads are bounds-checked scalars: operands are arbitrary sub-blocks (column slices of
 // edge_mlp.0, feature columns of xh) with arbitrary leading dimensions.
 // ------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_exact(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float dsilu(float v) {            // d/dv v*sigmoid(v) = s * (1 + v * (1 - s))
+    const float s = 1.0f / (1.0f + expf(-v));
+    return s * (1.0f + v * (1.0f - s));
+}
+
 #define TG_KT 32
 #define TG_LD (TG_KT + 4)
 
@@ -27,7 +33,8 @@
 template <bool TA, bool TB, bool VECA, bool VECB>
 __global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float* __restrict__ A, int lda,
                                                const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-                                               const float* __restrict__ bias, float alpha, int accumulate, int kchunk) {
+                                               const float* __restrict__ bias, float alpha, int accumulate, int kchunk,
+                                               int epi, float* __restrict__ aux, int ldaux) {
     __shared__ __attribute__((aligned(16))) float As[64 * TG_LD];
     __shared__ __attribute__((aligned(16))) float Bs[64 * TG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,16 +109,21 @@ __global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float*
         const int gm = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (gm >= M) continue;
         float* c = C + (size_t)gm * ldc + gn;
-        const float v = alpha * acc[r] + bv;
-        if (gridDim.z > 1) atomicAdd(c, v);
-        else if (accumulate) *c += v;
-        else *c = v;
+        float v = alpha * acc[r] + bv;
+        if (gridDim.z > 1) { atomicAdd(c, v); continue; }
+        if (accumulate) v += *c;
+        // epilogues (never with split-K): 1 = also write SiLU(v) to aux (forward: pre-activation and activation in one
+        // pass); 2 = multiply by SiLU'(aux) (dgrad through the activation that produced this operand)
+        if (epi == 2) v *= dsilu(aux[(size_t)gm * ldaux + gn]);
+        *c = v;
+        if (epi == 1) aux[(size_t)gm * ldaux + gn] = silu_exact(v);
     }
 }
 
 // split_k: 0 = choose so that the launch fills the chip (wgrad: few output tiles, K = thousands of rows); 1 = none
 void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                  int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s) {
+                  int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s,
+                  int epi = 0, float* aux = nullptr, int ldaux = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return;
     const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
     if (split_k == 0) {
@@ -130,7 +142,7 @@ void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda
     const int acc = accumulate ? 1 : 0;
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool va = al(A) && (lda % 4 == 0), vb = al(B) && (ldb % 4 == 0);      // weights inside the flat buffer may be unaligned
-#define SG(TA_, TB_, VA_, VB_) hipLaunchKernelGGL((k_sgemm<TA_, TB_, VA_, VB_>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk)
+#define SG(TA_, TB_, VA_, VB_) hipLaunchKernelGGL((k_sgemm<TA_, TB_, VA_, VB_>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk, z > 1 ? 0 : epi, aux, ldaux)
 #define SG2(TA_, TB_) do { if (va && vb) SG(TA_, TB_, true, true); else if (va) SG(TA_, TB_, true, false); \
                            else if (vb) SG(TA_, TB_, false, true); else SG(TA_, TB_, false, false); } while (0)
     if (!ta && tb) SG2(false, true); else if (!ta && !tb) SG2(false, false);
@@ -142,12 +154,6 @@ void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda
 // ------------------------------------------------------------------------------------
 // elementwise / gather / scatter pieces.  Edge-level tensors are [E][H] row-major; a wave walks one row.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ float silu_exact(float v) { return v / (1.0f + expf(-v)); }
-__device__ __forceinline__ float dsilu(float v) {            // d/dv v*sigmoid(v) = s * (1 + v * (1 - s))
-    const float s = 1.0f / (1.0f + expf(-v));
-    return s * (1.0f + v * (1.0f - s));
-}
-
 // out = SiLU(in)   (n elements)
 __global__ void k_silu(const float* __restrict__ in, float* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -238,11 +244,12 @@ __global__ void k_att_msg(int E, int H, const int* __restrict__ row, const float
     for (int c = lane; c < H; c += 64) atomicAdd(a + c, m[c] * att);
 }
 
-// adjoint of k_att_msg: dmsg = dagg[row]; dm2 = dmsg*att + dz*wa, dz = (sum_c dmsg*m2) att (1-att); writes dm2 over
-// the scratch row and dz[e].
+// adjoint of k_att_msg: dmsg = dagg[row]; dm2 = dmsg*att + dz*wa, dz = (sum_c dmsg*m2) att (1-att); writes
+// dpre2 = dm2 * SiLU'(pre2) to the scratch row and dz[e].
 __global__ void k_att_msg_bwd(int E, int H, const int* __restrict__ row, const float* __restrict__ m2,
                               const float* __restrict__ wa, const float* __restrict__ z, int attention,
-                              const float* __restrict__ dagg, float* __restrict__ dm2, float* __restrict__ dz_out) {
+                              const float* __restrict__ dagg, const float* __restrict__ pre2, float* __restrict__ dm2,
+                              float* __restrict__ dz_out) {
     const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= E) return;
     const float* m = m2 + (size_t)e * H;
@@ -255,7 +262,8 @@ __global__ void k_att_msg_bwd(int E, int H, const int* __restrict__ row, const f
         dz = wave_sum(s) * att * (1.0f - att);
         if (lane == 0) dz_out[e] = dz;
     }
-    for (int c = lane; c < H; c += 64) dm2[(size_t)e * H + c] = g[c] * att + (attention ? dz * wa[c] : 0.f);
+    for (int c = lane; c < H; c += 64)          // dpre2 = dm2 * SiLU'(pre2)
+        dm2[(size_t)e * H + c] = (g[c] * att + (attention ? dz * wa[c] : 0.f)) * dsilu(pre2[(size_t)e * H + c]);
 }
 
 // coordinate head (egnn_new.py:87-104): phi = w5 . c2, g = tanh(phi) * range (or phi), accx[row] += cd * g
@@ -507,8 +515,8 @@ void tr_att_msg(int E, int H, const int* row, const float* m2, const float* wa, 
     if (E) hipLaunchKernelGGL(k_att_msg, ROW_GRID(E), 0, s, E, H, row, m2, wa, ba, attention, z, agg);
 }
 void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* wa, const float* z, int attention,
-                    const float* dagg, float* dm2, float* dz, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_att_msg_bwd, ROW_GRID(E), 0, s, E, H, row, m2, wa, z, attention, dagg, dm2, dz);
+                    const float* dagg, const float* pre2, float* dm2, float* dz, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_att_msg_bwd, ROW_GRID(E), 0, s, E, H, row, m2, wa, z, attention, dagg, pre2, dm2, dz);
 }
 void tr_coord_out(int E, int H, const int* row, const float* c2, const float* w5, const float4* cd, int use_tanh, float range,
                   float* phi, float* accx, hipStream_t s) {

@@ -204,7 +204,8 @@ int cmdgen_joint_plan(cmdgen_handle* h, int32_t timesteps, int32_t resamplings, 
  * reference's registration order (the state_dict order below 'ddpm.dynamics.': weight then bias of every
  * nn.Linear, dynamics.py:21-60, egnn_new.py:15-29, :78-83) - so that the gradient is one contiguous bucket
  * (a single RCCL all-reduce per step replaces DDP's bucketing, train.py:111-121) and the optimizer is one
- * elementwise kernel.  cmdgen_param_count / cmdgen_param_offset describe the layout
+ * elementwise kernel.  Every tensor starts on a 16-byte boundary (a few zero padding floats in between).
+ * cmdgen_param_count (buffer length incl. padding) / cmdgen_param_offset describe the layout
  * (name e.g. "egnn.e_block_0.gcl_0.edge_mlp.0.weight"). */
 int cmdgen_param_count(cmdgen_handle* h, int64_t* n_params);
 int cmdgen_param_offset(cmdgen_handle* h, const char* name, int64_t* offset, int64_t* count);

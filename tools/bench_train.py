@@ -42,6 +42,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='complexes per GPU')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--cpu-baseline', action='store_true', help='also time the oracle (torch CPU autograd) on the same batch shape')
     ap.add_argument('--profile', action='store_true', help='print the per-kernel time table of 3 steps (torch.profiler)')
     a = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -99,6 +100,37 @@ def main():
         sys.stderr.write('host self time of 3 steps: %.2f ms\n' % (sum(r[1] for r in crow) / 1e3))
         for k, us, n in crow[:14]:
             sys.stderr.write('%8.2f ms %6d  %s\n' % (us / 1e3, n, k[:90]))
+    cpu = None
+    if a.cpu_baseline and rank == 0:
+        from oracle import ref_cpu          # bench-only use of the oracle, as bench.py's cpu_baseline leg
+        sd = make_state_dict(cfg, seed=0)
+        b0 = {k: v.cpu() for k, v in batches[0].items()}
+        phar = {'x': b0['phar_coords'], 'one_hot': b0['phar_one_hot'], 'size': b0['num_phar_atoms'], 'mask': b0['phar_mask']}
+        pocket = {'x': b0['pocket_c_alpha'], 'one_hot': b0['pocket_one_hot'], 'size': b0['num_pocket_nodes'], 'mask': b0['pocket_mask']}
+        best = None
+        for nt in (8, 16, 32, 64):
+            torch.set_num_threads(nt)
+            p = ref_cpu.to_torch_params(sd)
+            leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith('dynamics.')}
+            p2 = dict(p); p2.update(leaves)
+            opt = torch.optim.AdamW(list(leaves.values()), lr=1e-3, amsgrad=True, weight_decay=1e-12)
+            ts = []
+            for it in range(3):
+                t0c = time.perf_counter()
+                opt.zero_grad()
+                t_int = torch.randint(0, 501, (a.batch, 1)).float()
+                eps = [torch.randn(len(phar['mask']), 11)]
+                terms = ref_cpu.ddpm_forward(p2, cfg.as_dict(), phar, pocket, t_int, eps, training=True, histogram=np.ones((30, 70)))
+                nll = ref_cpu.nll_from_terms(terms, cfg.as_dict(), phar['size'], pocket['size'], training=True)
+                nll.mean(0).backward()
+                opt.step()
+                ts.append(time.perf_counter() - t0c)
+            sec = min(ts[1:])
+            if best is None or sec < best[0]:
+                best = (sec, nt)
+        cpu = {'value': a.batch / best[0], 'unit': 'complexes/s', 'cores': best[1], 'kind': 'port',
+               'sample': '1 training step (forward + autograd backward + AdamW) of the oracle on the same batch, best of a thread sweep',
+               's_per_step': best[0]}
     # phase split on one more step (events around forward / backward / optimizer)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     ev[0].record(); tr.loss_and_grad(batches[0]); ev[1].record(); tr._allreduce(); ev[2].record(); tr.optimizer_step(); ev[3].record()
@@ -106,7 +138,7 @@ def main():
     if rank == 0:
         print(json.dumps({'metric': 'training complexes/s', 'value': a.batch * world * a.steps / dt, 'n_gpus': world,
                           'ms_per_step': dt / a.steps * 1e3, 'batch_per_gpu': a.batch, 'dtype': 'f32',
-                          'first_loss': losses[0], 'last_loss': losses[-1],
+                          'first_loss': losses[0], 'last_loss': losses[-1], 'cpu_baseline': cpu,
                           'phase_ms': {'loss_and_grad': ev[0].elapsed_time(ev[1]), 'allreduce': ev[1].elapsed_time(ev[2]),
                                        'clip_and_adamw': ev[2].elapsed_time(ev[3])}}))
 
