@@ -71,6 +71,7 @@ struct cmdgen_handle {
     const void* jg_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned long long jg_seed = 0; int jg_steps = 0;
     TrainState* train = nullptr;           // training workspace (cmdgen_train.hip)
+    bool train_bf16 = false;               // GEMM operand precision of the training step (cmdgen_train_set_precision)
     bool kernel_profiling = false;
     std::vector<hipEvent_t> prof_events[3];
 };

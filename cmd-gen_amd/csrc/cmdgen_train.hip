@@ -7,7 +7,7 @@
 void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s);
 void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                   int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s,
-                  int epi = 0, float* aux = nullptr, int ldaux = 0);
+                  int epi = 0, float* aux = nullptr, int ldaux = 0, bool bf16 = false);
 void tr_silu(const float* in, float* out, size_t n, hipStream_t s);
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
 void tr_scale(float* x, float a, size_t n, hipStream_t s);
@@ -87,6 +87,7 @@ struct TrainState {
     int E = 0, Ec = 0;                  // edges of the last forward
     size_t ecap = 0, eccap = 0;
     bool have_forward = false;
+    bool bf16 = false;                  // GEMM operands in bf16 (fp32 accumulation); default exact fp32
     const float* theta = nullptr;       // parameters used by the last forward (backward reads the same)
     const float* xh_phar = nullptr; const float* xh_pocket = nullptr;
     // node level
@@ -115,6 +116,7 @@ static int ensure_state(cmdgen_handle* h) {
     if (h->dims.joint) return fail(h, CMDGEN_ESTATE, "the training step supports the conditional model only (update_pocket_coords = 0)");
     TrainState* t = new TrainState();
     build_table(h->dims, t->tab);
+    t->bf16 = h->train_bf16;
     const Dims& d = h->dims;
     // sized by the layout CAPACITIES (cmdgen_set_layout): the state survives every new batch that fits them
     const size_t N = h->cap_N, Nl = h->cap_Nl, Np = h->cap_Np, H = d.H, L = d.L;
@@ -158,22 +160,28 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
     return 0;
 }
 
+// GEMM operand precision of the call in progress (TrainState::bf16; the tiny encoder / decoder products with K < 64
+// always run in fp32)
+static thread_local bool g_bf16 = false;
+static inline bool use_bf16(int K) { return g_bf16 && K >= 64; }
+
 // y[M, out] = x[M, in(ldx)] W^T + b      (W, b inside the flat buffer)
 static void linear(const float* theta, const PRef& r, int col0, int in, int M, const float* x, int ldx, float* y, int ldy,
                    bool bias, bool accumulate, hipStream_t s, float* act = nullptr) {
     cmdgen_sgemm(false, true, M, r.out, in, x, ldx, theta + r.w + col0, r.in, y, ldy, (bias && r.has_bias) ? theta + r.b : nullptr,
-                 1.0f, accumulate, 1, s, act ? 1 : 0, act, ldy);      // act: SiLU(y) written alongside y
+                 1.0f, accumulate, 1, s, act ? 1 : 0, act, ldy, use_bf16(in));      // act: SiLU(y) written alongside y
 }
 // dx[M, in] (+)= dy[M, out] W[:, col0:col0+in]
 static void linear_dgrad(const float* theta, const PRef& r, int col0, int in, int M, const float* dy, int lddy, float* dx,
                          int lddx, bool accumulate, hipStream_t s, const float* pre = nullptr) {
     cmdgen_sgemm(false, false, M, in, r.out, dy, lddy, theta + r.w + col0, r.in, dx, lddx, nullptr, 1.0f, accumulate, 1, s,
-                 pre ? 2 : 0, const_cast<float*>(pre), lddx);       // pre: dx *= SiLU'(pre) (the activation that fed this Linear)
+                 pre ? 2 : 0, const_cast<float*>(pre), lddx, use_bf16(r.out));   // pre: dx *= SiLU'(pre) (the activation that fed this Linear)
 }
 // dW[:, col0:col0+in] += dy^T x ;  split over the M rows (edges / nodes)
 static void linear_wgrad(float* grad, const PRef& r, int col0, int in, int M, const float* dy, int lddy, const float* x,
                          int ldx, hipStream_t s) {
-    cmdgen_sgemm(true, false, r.out, in, M, dy, lddy, x, ldx, grad + r.w + col0, r.in, nullptr, 1.0f, true, 0, s);
+    cmdgen_sgemm(true, false, r.out, in, M, dy, lddy, x, ldx, grad + r.w + col0, r.in, nullptr, 1.0f, true, 0, s, 0, nullptr, 0,
+                 g_bf16 && r.out >= 64 && in >= 64);
 }
 
 extern "C" int cmdgen_param_count(cmdgen_handle* h, int64_t* n) {
@@ -215,6 +223,7 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     HIPCHK(h, hipStreamSynchronize(s));
     const int E = tot[0], Ec = tot[1];
     rc = ensure_edges(h, t, E, Ec); if (rc) return rc;
+    g_bf16 = t->bf16;
     t->E = E; t->Ec = Ec; t->theta = theta; t->xh_phar = xh_phar; t->xh_pocket = xh_pocket;
     const Work& w = h->work;
     const ParamTable& tb = t->tab;
@@ -283,6 +292,7 @@ extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, 
     if (!d_eps_phar || !grad) return fail(h, CMDGEN_EINVAL, "null device pointer");
     hipSetDevice(h->device);
     TrainState* t = h->train;
+    g_bf16 = t->bf16;
     hipStream_t s = (hipStream_t)stream;
     const Dims& d = h->dims;
     const float* theta = t->theta;
@@ -397,6 +407,16 @@ extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, 
     return CMDGEN_OK;
 }
 
+extern "C" int cmdgen_train_set_precision(cmdgen_handle* h, int32_t bf16_gemm) {
+    if (!h) return CMDGEN_EINVAL;
+    if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
+    hipSetDevice(h->device);
+    int rc = ensure_state(h); if (rc) return rc;
+    h->train->bf16 = bf16_gemm != 0;
+    h->train_bf16 = bf16_gemm != 0;
+    return CMDGEN_OK;
+}
+
 extern "C" int cmdgen_grad_sqnorm(cmdgen_handle* h, const float* grad, int64_t n, float* out_host, cmdgen_stream stream) {
     if (!h || !grad || !out_host || n < 1) return fail(h, CMDGEN_EINVAL, "bad arguments");
     hipSetDevice(h->device);
@@ -428,7 +448,8 @@ extern "C" int cmdgen_debug_sgemm(cmdgen_handle* h, int32_t ta, int32_t tb, int3
                                   int32_t accumulate, int32_t split_k, cmdgen_stream stream) {
     if (!h || !A || !B || !C) return fail(h, CMDGEN_EINVAL, "null pointer");
     hipSetDevice(h->device);
-    cmdgen_sgemm(ta != 0, tb != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, 1.0f, accumulate != 0, split_k, (hipStream_t)stream);
+    cmdgen_sgemm(ta != 0, tb != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, 1.0f, (accumulate & 1) != 0, split_k, (hipStream_t)stream,
+                 0, nullptr, 0, (accumulate & 2) != 0);
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;
 }

@@ -120,10 +120,109 @@ __global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float*
     }
 }
 
+// The same GEMM with bf16 OPERANDS and fp32 accumulation (v_mfma_f32_32x32x16_bf16: 16x the fp32 matrix rate) - the
+// opt-in mixed-precision policy of the training step (master weights, optimizer state, activations in HBM and all
+// elementwise math stay fp32; operands are rounded to nearest-even bf16 while they are staged into LDS).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define TGH_LD (TG_KT + 8)      // halfs per LDS row: 80 bytes, keeps the 16-byte operand reads aligned
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);     // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <bool TA, bool TB, bool VECA, bool VECB>
+__global__ __launch_bounds__(256) void k_sgemm_bf16(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                    const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                    const float* __restrict__ bias, float alpha, int accumulate, int kchunk,
+                                                    int epi, float* __restrict__ aux, int ldaux) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[64 * TGH_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[64 * TGH_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int k_begin = blockIdx.z * kchunk, k_end = min(K, k_begin + kchunk);
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    auto stage = [&](unsigned short* S, const float* __restrict__ G, int ld, bool trans, bool VEC, int r0, int R, int k0) {
+        if (!trans) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int r = (tid >> 3) + 32 * p, kq = (tid & 7) * 4;
+                const int gr = r0 + r, gk = k0 + kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gr < R) {
+                    const float* src = G + (size_t)gr * ld + gk;
+                    if (VEC && gk + 3 < k_end) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (gk < k_end) v.x = src[0];
+                        if (gk + 1 < k_end) v.y = src[1];
+                        if (gk + 2 < k_end) v.z = src[2];
+                        if (gk + 3 < k_end) v.w = src[3];
+                    }
+                }
+                uint2 pk;
+                pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+                pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+                *reinterpret_cast<uint2*>(S + r * TGH_LD + kq) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int k = (tid >> 4) + 16 * p, rq = (tid & 15) * 4;
+                const int gk = k0 + k, gr = r0 + rq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gk < k_end) {
+                    const float* src = G + (size_t)gk * ld + gr;
+                    if (VEC && gr + 3 < R) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (gr < R) v.x = src[0];
+                        if (gr + 1 < R) v.y = src[1];
+                        if (gr + 2 < R) v.z = src[2];
+                        if (gr + 3 < R) v.w = src[3];
+                    }
+                }
+                S[(rq + 0) * TGH_LD + k] = f2bf(v.x); S[(rq + 1) * TGH_LD + k] = f2bf(v.y);
+                S[(rq + 2) * TGH_LD + k] = f2bf(v.z); S[(rq + 3) * TGH_LD + k] = f2bf(v.w);
+            }
+        }
+    };
+    for (int k0 = k_begin; k0 < k_end; k0 += TG_KT) {
+        stage(As, A, lda, TA, VECA, m0, M, k0);
+        stage(Bs, B, ldb, !TB, VECB, n0, N, k0);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < TG_KT / 16; ++ks) {      // lanes 0-31 supply k 0..7, lanes 32-63 k 8..15 of the 16-k step
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (wm + (lane & 31)) * TGH_LD + ks * 16 + 8 * (lane >> 5));
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + (wn + (lane & 31)) * TGH_LD + ks * 16 + 8 * (lane >> 5));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int gn = n0 + wn + (lane & 31);
+    if (gn >= N) return;
+    const float bv = (bias && blockIdx.z == 0) ? bias[gn] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm >= M) continue;
+        float* c = C + (size_t)gm * ldc + gn;
+        float v = alpha * acc[r] + bv;
+        if (gridDim.z > 1) { atomicAdd(c, v); continue; }
+        if (accumulate) v += *c;
+        if (epi == 2) v *= dsilu(aux[(size_t)gm * ldaux + gn]);
+        *c = v;
+        if (epi == 1) aux[(size_t)gm * ldaux + gn] = silu_exact(v);
+    }
+}
+
 // split_k: 0 = choose so that the launch fills the chip (wgrad: few output tiles, K = thousands of rows); 1 = none
 void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                   int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s,
-                  int epi = 0, float* aux = nullptr, int ldaux = 0) {
+                  int epi = 0, float* aux = nullptr, int ldaux = 0, bool bf16 = false) {
     if (M <= 0 || N <= 0 || K <= 0) return;
     const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
     if (split_k == 0) {
@@ -142,7 +241,8 @@ void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda
     const int acc = accumulate ? 1 : 0;
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool va = al(A) && (lda % 4 == 0), vb = al(B) && (ldb % 4 == 0);      // weights inside the flat buffer may be unaligned
-#define SG(TA_, TB_, VA_, VB_) hipLaunchKernelGGL((k_sgemm<TA_, TB_, VA_, VB_>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk, z > 1 ? 0 : epi, aux, ldaux)
+#define SG(TA_, TB_, VA_, VB_) do { if (bf16) hipLaunchKernelGGL((k_sgemm_bf16<TA_, TB_, VA_, VB_>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk, z > 1 ? 0 : epi, aux, ldaux); \
+        else hipLaunchKernelGGL((k_sgemm<TA_, TB_, VA_, VB_>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk, z > 1 ? 0 : epi, aux, ldaux); } while (0)
 #define SG2(TA_, TB_) do { if (va && vb) SG(TA_, TB_, true, true); else if (va) SG(TA_, TB_, true, false); \
                            else if (vb) SG(TA_, TB_, false, true); else SG(TA_, TB_, false, false); } while (0)
     if (!ta && tb) SG2(false, true); else if (!ta && !tb) SG2(false, false);

@@ -61,6 +61,7 @@ SYMBOLS = [
     ('cmdgen_param_offset', C.c_int, [_vp, C.c_char_p, _i64p, _i64p]),
     ('cmdgen_train_forward', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _vp]),
     ('cmdgen_train_backward', C.c_int, [_vp, _fp, _fp, _vp]),
+    ('cmdgen_train_set_precision', C.c_int, [_vp, C.c_int32]),
     ('cmdgen_grad_sqnorm', C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_float), _vp]),
     ('cmdgen_adamw_step', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, _vp]),
@@ -333,6 +334,9 @@ class Handle:
         assert grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous() and grad.numel() == self.param_count()
         self._check(self.lib.cmdgen_train_backward(self.h, _ptr(d_eps), _ptr(grad), self._stream()), 'cmdgen_train_backward')
 
+    def train_set_precision(self, bf16_gemm: bool):
+        self._check(self.lib.cmdgen_train_set_precision(self.h, int(bool(bf16_gemm))), 'cmdgen_train_set_precision')
+
     def grad_sqnorm(self, grad) -> float:
         out = C.c_float(0)
         self._check(self.lib.cmdgen_grad_sqnorm(self.h, _ptr(grad), grad.numel(), C.byref(out), self._stream()), 'cmdgen_grad_sqnorm')
@@ -345,14 +349,14 @@ class Handle:
                                                float(betas[1]), float(eps), float(weight_decay), float(clip_coef),
                                                self._stream()), 'cmdgen_adamw_step')
 
-    def debug_sgemm(self, A, B, ta=False, tb=True, bias=None, C_out=None, accumulate=False, split_k=1):
+    def debug_sgemm(self, A, B, ta=False, tb=True, bias=None, C_out=None, accumulate=False, split_k=1, bf16=False):
         import torch
         M = A.shape[1] if ta else A.shape[0]
         K = A.shape[0] if ta else A.shape[1]
         N = B.shape[0] if tb else B.shape[1]
         out = torch.zeros((M, N), dtype=torch.float32, device=A.device) if C_out is None else C_out
         self._check(self.lib.cmdgen_debug_sgemm(self.h, int(ta), int(tb), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0),
-                                                _ptr(out), out.stride(0), _ptr(bias), int(accumulate), int(split_k),
+                                                _ptr(out), out.stride(0), _ptr(bias), int(accumulate) | (2 if bf16 else 0), int(split_k),
                                                 self._stream()), 'cmdgen_debug_sgemm')
         return out
 

@@ -24,7 +24,8 @@ from . import utils
 
 class HipTrainer:
     def __init__(self, model, lr: Optional[float] = None, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-12, clip_grad: Optional[bool] = None, process_group=None):
+                 weight_decay: float = 1e-12, clip_grad: Optional[bool] = None, process_group=None,
+                 gemm_dtype: str = 'fp32'):
         if model.mode == 'joint':
             raise NotImplementedError("the training step is built for the conditional model (mode 'pocket_conditioning')")
         if model.loss_type != 'l2':
@@ -58,6 +59,8 @@ class HipTrainer:
             p.data = view
             seen += cnt
         assert seen <= n < seen + 4 * (len(list(self.dyn.parameters())) + 1), (seen, n)     # + alignment padding
+        assert gemm_dtype in ('fp32', 'bf16')
+        self.gemm_dtype = gemm_dtype        # 'bf16': GEMM operands in bf16, fp32 accumulation (mixed precision); default exact fp32
         self.last_info: Dict[str, float] = {}
 
     # ------------------------------------------------------------------
@@ -74,6 +77,7 @@ class HipTrainer:
         B = len(phar['size'])
         self.h.set_layout(phar['size'].detach().to('cpu', torch.int64).numpy(),
                           pocket['size'].detach().to('cpu', torch.int64).numpy())
+        self.h.train_set_precision(self.gemm_dtype == 'bf16')
         nll, info = model.forward(data, t_int=t_int, eps=eps, _net=self._net)
         loss = nll.mean(0)
         ctx = self.ddpm._last_train_ctx

@@ -221,6 +221,11 @@ int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const float* xh_p
  * loss.backward() in the reference's training_step (lightning_modules.py:245-260). */
 int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, float* grad, cmdgen_stream stream);
 
+/* GEMM operand precision of the training step: 0 (default) = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = operands
+ * rounded to bf16 while staged, fp32 accumulation (v_mfma_f32_32x32x16_bf16).  Parameters, gradients, optimizer state,
+ * stored activations and all elementwise math stay fp32 either way. */
+int cmdgen_train_set_precision(cmdgen_handle* h, int32_t bf16_gemm);
+
 /* Sum of squares of a device vector -> host float (the global gradient norm of utils.get_grad_norm,
  * utils.py:39-61, is its square root).  Synchronises the stream. */
 int cmdgen_grad_sqnorm(cmdgen_handle* h, const float* grad, int64_t n, float* out_host, cmdgen_stream stream);
@@ -233,7 +238,7 @@ int cmdgen_adamw_step(cmdgen_handle* h, float* theta, const float* grad, float* 
                       float eps, float weight_decay, float clip_coef, cmdgen_stream stream);
 
 /* C[M,N] (+)= op(A) op(B) (+ bias) through the training path's exact-fp32 MFMA GEMM (test aid):
- * ta: A stored [K][M]; tb: B stored [N][K] (nn.Linear weight). */
+ * ta: A stored [K][M]; tb: B stored [N][K] (nn.Linear weight); accumulate bit 0: C += ..., bit 1: bf16 operands. */
 int cmdgen_debug_sgemm(cmdgen_handle* h, int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, const float* A,
                        int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias,
                        int32_t accumulate, int32_t split_k, cmdgen_stream stream);

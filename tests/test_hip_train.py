@@ -99,7 +99,7 @@ def test_training_forward_and_backward_vs_oracle_autograd(H, L, B, kw):
     want, _ = ref_cpu.dynamics_forward(p2, cfg.as_dict(), torch.from_numpy(xh_phar), torch.from_numpy(xh_pocket),
                                        torch.from_numpy(t), torch.from_numpy(pm), torch.from_numpy(pb.mask))
     got = eps.cpu().numpy()
-    assert np.abs(got - want.detach().numpy()).max() <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert np.abs(got - want.detach().numpy()).max() <= 2e-5 * max(1.0, float(want.detach().abs().max()))
     # the inference kernels agree with the training forward as well (same weights, packed vs flat)
     h.load_state_dict(sd)
     inf, _ = h.dynamics_forward(dev(xh_phar), dev(xh_pocket), dev(t))
@@ -208,3 +208,46 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
     losses = [float(tr.training_step(data)['loss']) for _ in range(30)]
     assert np.isfinite(losses).all()
     assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]), losses
+
+
+# ------------------------------------------------------------------ bf16 GEMM operands (opt-in mixed precision)
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False)])
+def test_bf16_gemm_equals_fp32_product_of_rounded_operands(ta, tb):
+    """bf16 mode rounds the operands (nearest-even) and accumulates in fp32: it must match an fp64 product of the
+    bf16-rounded operands to fp32 accuracy - this also pins the operand layout of v_mfma_f32_32x32x16_bf16."""
+    h = make_handle(ModelConfig(hidden_nf=64, n_layers=1))
+    g = torch.Generator().manual_seed(2)
+    for M, N, K in [(64, 64, 64), (130, 70, 96), (257, 256, 1000), (33, 5, 77)]:
+        A = torch.randn((K, M) if ta else (M, K), generator=g).cuda()
+        B = torch.randn((N, K) if tb else (K, N), generator=g).cuda()
+        Ar, Br = A.to(torch.bfloat16).double(), B.to(torch.bfloat16).double()
+        want = (Ar.t() if ta else Ar) @ (Br.t() if tb else Br)
+        got = h.debug_sgemm(A, B, ta=ta, tb=tb, bf16=True)
+        assert (got.double() - want).abs().max() <= 2e-5 * max(1.0, float(want.abs().max())), (M, N, K)
+        exact = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+        assert (got.double() - exact).abs().max() > 1e-4 * float(exact.abs().max())      # it really is the bf16 path
+
+
+def test_bf16_training_gradients_close_and_loss_falls():
+    g = load_golden('g11_train.npz')
+    from cmdgen_amd.training import HipTrainer
+    model, tr, data, g6 = build_trainer()
+    tr.gemm_dtype = 'bf16'
+    t_int, eps = dev(g6['t_int']), [dev(g6['eps0'])]
+    loss, nll, info = tr.loss_and_grad(data, t_int=t_int, eps=eps)
+    assert abs(float(loss) - float(g['step0/loss'])) < 5e-3 * abs(float(g['step0/loss']))
+    grad = tr.grad.cpu().numpy()
+    # direction and size of the whole gradient agree with the fp32 reference to bf16 accuracy
+    ref = np.zeros_like(grad)
+    for key, want in g.items():
+        if key.startswith('grad/') and key != 'grad/gamma.gamma':
+            off, cnt = tr.h.param_offset(key[len('grad/dynamics.'):])
+            ref[off:off + cnt] = want.reshape(-1)
+    cos = float(np.dot(grad, ref) / (np.linalg.norm(grad) * np.linalg.norm(ref)))
+    assert cos > 0.999, cos
+    assert abs(np.linalg.norm(grad) / np.linalg.norm(ref) - 1.0) < 2e-2
+    assert np.abs(grad - ref).max() > 1e-6 * np.abs(ref).max()            # not the fp32 path
+    tr.lr = 2e-3
+    torch.manual_seed(0)
+    losses = [float(tr.training_step(data)['loss']) for _ in range(30)]
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]), losses

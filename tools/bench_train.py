@@ -42,6 +42,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='complexes per GPU')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16'], help='GEMM operand precision (fp32 accumulation either way)')
     ap.add_argument('--cpu-baseline', action='store_true', help='also time the oracle (torch CPU autograd) on the same batch shape')
     ap.add_argument('--profile', action='store_true', help='print the per-kernel time table of 3 steps (torch.profiler)')
     a = ap.parse_args()
@@ -65,7 +66,7 @@ def main():
     model = PharPocketDDPM(**hp)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed=0).items()}, strict=True)
     model = model.to(dev)
-    tr = HipTrainer(model)
+    tr = HipTrainer(model, gemm_dtype=a.gemm)
     batches = [synthetic_batch(a.batch, 50000 + 1000 * rank + 100 * i, dev) for i in range(4)]
     torch.manual_seed(rank)
     for i in range(a.warmup):
@@ -89,7 +90,8 @@ def main():
             for i in range(3):
                 tr.training_step(batches[i % 4])
             torch.cuda.synchronize()
-        rows = [(e.key, e.device_time_total, e.count) for e in prof.key_averages() if e.device_time_total > 0]
+        rows = [(e.key, e.device_time_total, e.count) for e in prof.key_averages()
+                if e.device_time_total > 0 and not e.key.startswith(('aten::', 'hip'))]      # device kernels / memcpy / memset only
         rows.sort(key=lambda r: -r[1])
         tot = sum(r[1] for r in rows)
         sys.stderr.write('device time of 3 steps: %.2f ms\n' % (tot / 1e3))
@@ -137,7 +139,7 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         print(json.dumps({'metric': 'training complexes/s', 'value': a.batch * world * a.steps / dt, 'n_gpus': world,
-                          'ms_per_step': dt / a.steps * 1e3, 'batch_per_gpu': a.batch, 'dtype': 'f32',
+                          'ms_per_step': dt / a.steps * 1e3, 'batch_per_gpu': a.batch, 'dtype': 'f32' if a.gemm == 'fp32' else 'bf16 GEMM operands, f32 accumulate/master',
                           'first_loss': losses[0], 'last_loss': losses[-1], 'cpu_baseline': cpu,
                           'phase_ms': {'loss_and_grad': ev[0].elapsed_time(ev[1]), 'allreduce': ev[1].elapsed_time(ev[2]),
                                        'clip_and_adamw': ev[2].elapsed_time(ev[3])}}))
