@@ -99,7 +99,10 @@ class PharPocketDDPM(nn.Module):
             ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
         else:
             import numpy.core.multiarray as _ncm
-            safe = [argparse.Namespace, np.ndarray, np.dtype, _ncm._reconstruct, _ncm.scalar]
+            import pathlib
+            # the reference passes outdir as a pathlib.Path (train.py:64-66), so real checkpoints carry one
+            safe = [argparse.Namespace, np.ndarray, np.dtype, _ncm._reconstruct, _ncm.scalar,
+                    pathlib.PosixPath, pathlib.PurePosixPath, pathlib.Path, pathlib.PurePath]
             try:
                 safe += [type(np.dtype(np.float64)), type(np.dtype(np.int64)), type(np.dtype(np.float32))]
             except Exception:
