@@ -343,25 +343,22 @@ class EnVariationalDiffusion(nn.Module):
 
     # ---- joint sampler / RePaint inpainting (en_diffusion.py:576-831)
     def get_repaint_schedule(self, resamplings, jump_length, timesteps):
-        """How many denoising steps to apply before each jump back (en_diffusion.py:649-670)."""
-        repaint_schedule = []
-        curr_t = 0
-        while curr_t < timesteps:
-            if curr_t + jump_length < timesteps:
-                if len(repaint_schedule) > 0:
-                    repaint_schedule[-1] += jump_length
-                    repaint_schedule.extend([jump_length] * (resamplings - 1))
-                else:
-                    repaint_schedule.extend([jump_length] * resamplings)
-                curr_t += jump_length
+        """RePaint plan (behaviour of en_diffusion.py:649-670): how many denoising steps run before each jump back.
+        Walking up in t in strides of ``jump_length``: every stride but the last is denoised ``resamplings`` times -
+        once merged into the preceding run, then ``resamplings - 1`` separate re-runs; the list is returned in
+        execution order (from t = T down)."""
+        runs, t = [], 0
+        while t < timesteps:
+            final = t + jump_length >= timesteps
+            stride = timesteps - t if final else jump_length
+            if runs:
+                runs[-1] += stride
             else:
-                residual = timesteps - curr_t
-                if len(repaint_schedule) > 0:
-                    repaint_schedule[-1] += residual
-                else:
-                    repaint_schedule.append(residual)
-                curr_t += residual
-        return list(reversed(repaint_schedule))
+                runs.append(stride)
+            if not final:
+                runs += [jump_length] * (resamplings - 1)
+            t += stride
+        return runs[::-1]
 
     def _joint_handle(self, nph, npk):
         if not getattr(self.dynamics, 'update_pocket_coords', False):

@@ -33,25 +33,22 @@ from .training import HipTrainer
 
 
 def merge_args_and_yaml(args, config_dict):
-    """train.py:17-28"""
-    arg_dict = args.__dict__
-    for key, value in config_dict.items():
-        if key in arg_dict:
-            warnings.warn(f"Command line argument '{key}' (value: {arg_dict[key]}) will be overwritten with value "
-                          f"{value} provided in the config file.")
-        arg_dict[key] = Namespace(**value) if isinstance(value, dict) else value
+    """Config values win over command-line ones; nested sections become Namespaces (behaviour of train.py:17-28)."""
+    ns = vars(args)
+    clash = [k for k in config_dict if k in ns]
+    if clash:
+        warnings.warn('config file overrides command line for: ' + ', '.join(f'{k}={ns[k]!r}->{config_dict[k]!r}' for k in clash))
+    ns.update({k: (Namespace(**v) if isinstance(v, dict) else v) for k, v in config_dict.items()})
     return args
 
 
 def merge_configs(config, resume_config):
-    """train.py:31-40"""
-    for key, value in resume_config.items():
-        if isinstance(value, Namespace):
-            value = value.__dict__
-        if key in config and config[key] != value:
-            warnings.warn(f"Config parameter '{key}' (value: {config[key]}) will be overwritten with value {value} "
-                          f"from the checkpoint.")
-        config[key] = value
+    """Hyper-parameters stored in the checkpoint win over the YAML on --resume (behaviour of train.py:31-40)."""
+    stored = {k: (vars(v) if isinstance(v, Namespace) else v) for k, v in resume_config.items()}
+    changed = [k for k, v in stored.items() if k in config and config[k] != v]
+    if changed:
+        warnings.warn('checkpoint hyper-parameters override the config for: ' + ', '.join(changed))
+    config.update(stored)
     return config
 
 
