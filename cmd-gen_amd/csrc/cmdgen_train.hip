@@ -1,7 +1,7 @@
 // cmdgen_train.hip - the training step behind the C ABI: forward with saved activations,
 // backward to parameter gradients, AdamW(amsgrad) and the gradient norm, all on flat fp32 parameter / gradient
 // buffers owned by the caller (one contiguous bucket: a single RCCL all-reduce per step for data parallelism).
-// Conditional mode (update_pocket_coords = 0).  Kernels: kernels_train.hip.
+// Conditional and joint (update_pocket_coords = 1) models.  Kernels: kernels_train.hip.
 #include "cmdgen_host.h"
 
 void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s);
@@ -33,8 +33,10 @@ void tr_sum(int n, const float* x, float* out, hipStream_t s);
 void tr_concat_time(int N, int J, int dyn, const float* enc, const float* t, const int* node_sample, float* out, hipStream_t s);
 void tr_positions(int Nl, int Np, const float* xp, int ldp, const float* xq, int ldq, float4* X, hipStream_t s);
 void tr_move(int N, int n_moving, const float4* X, const float* accx, float nf, float4* Xn, hipStream_t s);
-void tr_eps_out(int Nl, int P, const float4* XL, const float4* X0, const float* dec, float* eps, hipStream_t s);
-void tr_eps_bwd(int Nl, int P, const float* deps, float* dX, float* ddec, hipStream_t s);
+void tr_velocity(int n_moving, const float4* XL, const float4* X0, float* vel, hipStream_t s);
+void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s);
+void tr_eps_out(int n_rows, int F, int row0, const float* vel, const float* dec, float* eps, hipStream_t s);
+void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, float* ddec, hipStream_t s);
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
               float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s);
 void tr_sqsum(size_t n, const float* x, float* out, hipStream_t s);
@@ -102,6 +104,7 @@ struct TrainState {
     float4 *cd, *dcd;
     // backward node level
     float *dh, *dX, *dacc, *dagg, *dP, *dQ, *dn, *dhfin, *ddec, *ddeca, *dhdyn, *denca_l, *denca_p;
+    float *vel, *qdec1, *qdeca, *qdec_out, *dqdec, *dqdeca;     // velocity [N][4]; residue decoder (joint model's pocket output)
     float* d_scalar;                    // [4] device scalars (sum of squares, ...)
 };
 
@@ -113,7 +116,6 @@ void cmdgen_train_free(TrainState* t) {
 
 static int ensure_state(cmdgen_handle* h) {
     if (h->train) return 0;
-    if (h->dims.joint) return fail(h, CMDGEN_ESTATE, "the training step supports the conditional model only (update_pocket_coords = 0)");
     TrainState* t = new TrainState();
     build_table(h->dims, t->tab);
     t->bf16 = h->train_bf16;
@@ -134,6 +136,8 @@ static int ensure_state(cmdgen_handle* h) {
     NA(t->dP, float, N * H); NA(t->dQ, float, N * H); NA(t->dn, float, N * H); NA(t->dhfin, float, N * d.dyn);
     NA(t->ddec, float, Nl * d.P); NA(t->ddeca, float, Nl * 2 * d.P); NA(t->dhdyn, float, N * d.dyn);
     NA(t->denca_l, float, Nl * 2 * d.P); NA(t->denca_p, float, Np * 2 * d.R);
+    NA(t->vel, float, N * 4); NA(t->qdec1, float, Np * 2 * d.R); NA(t->qdeca, float, Np * 2 * d.R);
+    NA(t->qdec_out, float, Np * d.R); NA(t->dqdec, float, Np * d.R); NA(t->dqdeca, float, Np * 2 * d.R);
     NA(t->d_scalar, float, 4);
 #undef NA
     h->train = t;
@@ -203,10 +207,11 @@ extern "C" int cmdgen_param_offset(cmdgen_handle* h, const char* name, int64_t* 
 }
 
 extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const float* xh_phar, const float* xh_pocket,
-                                    const float* t_arr, float* eps_phar, cmdgen_stream stream) {
+                                    const float* t_arr, float* eps_phar, float* eps_pocket, cmdgen_stream stream) {
     if (!h) return CMDGEN_EINVAL;
     if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
     if (!theta || !xh_phar || !xh_pocket || !t_arr || !eps_phar) return fail(h, CMDGEN_EINVAL, "null device pointer");
+    if (h->dims.joint && !eps_pocket) return fail(h, CMDGEN_EINVAL, "the joint model's loss needs eps_pocket");
     hipSetDevice(h->device);
     int rc = ensure_state(h); if (rc) return rc;
     TrainState* t = h->train;
@@ -281,13 +286,22 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     linear(theta, tb.pd0, 0, J, Nl, t->hfin, d.dyn, t->dec1, 2 * P, true, false, s);
     tr_silu(t->dec1, t->deca, (size_t)Nl * 2 * P, s);
     linear(theta, tb.pd2, 0, 2 * P, Nl, t->deca, 2 * P, t->dec_out, P, true, false, s);
-    tr_eps_out(Nl, P, t->X + (size_t)L * N, t->X, t->dec_out, eps_phar, s);
+    tr_velocity(h->lay.Nm, t->X + (size_t)L * N, t->X, t->vel, s);
+    if (d.joint) tr_center_per_sample(h->lay, t->vel, s);                     // dynamics.py:133-136
+    tr_eps_out(Nl, P, 0, t->vel, t->dec_out, eps_phar, s);
+    if (eps_pocket) {                                                         // residue decoder + pocket velocity (zero unless joint)
+        linear(theta, tb.rd0, 0, J, Np, t->hfin + (size_t)Nl * d.dyn, d.dyn, t->qdec1, 2 * R, true, false, s);
+        tr_silu(t->qdec1, t->qdeca, (size_t)Np * 2 * R, s);
+        linear(theta, tb.rd2, 0, 2 * R, Np, t->qdeca, 2 * R, t->qdec_out, R, true, false, s);
+        tr_eps_out(Np, R, Nl, t->vel, t->qdec_out, eps_pocket, s);
+    }
     HIPCHK(h, hipGetLastError());
     t->have_forward = true;
     return CMDGEN_OK;
 }
 
-extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, float* grad, cmdgen_stream stream) {
+extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, const float* d_eps_pocket, float* grad,
+                                     cmdgen_stream stream) {
     if (!h || !h->train || !h->train->have_forward) return fail(h, CMDGEN_ESTATE, "cmdgen_train_backward needs a preceding cmdgen_train_forward");
     if (!d_eps_phar || !grad) return fail(h, CMDGEN_EINVAL, "null device pointer");
     hipSetDevice(h->device);
@@ -305,14 +319,26 @@ extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, 
     auto bias_grad = [&](const PRef& r, int M, const float* dy, int ld) { tr_colsum(M, r.out, dy, ld, nullptr, grad + r.b, 1, s); };
     // readout
     HIPCHK(h, hipMemsetAsync(t->dX, 0, (size_t)N * 4 * sizeof(float), s));
-    tr_eps_bwd(Nl, P, d_eps_phar, t->dX, t->ddec, s);
+    tr_eps_bwd(Nl, P, 0, d_eps_phar, t->dX, t->ddec, s);
+    HIPCHK(h, hipMemsetAsync(t->dhfin, 0, (size_t)N * d.dyn * sizeof(float), s));
+    if (d_eps_pocket) {     // the pocket output exists in the loss (joint model): velocity rows Nl.. and the residue decoder
+        tr_eps_bwd(Np, R, Nl, d_eps_pocket, t->dX, t->dqdec, s);
+        linear_wgrad(grad, tb.rd2, 0, 2 * R, Np, t->dqdec, R, t->qdeca, 2 * R, s);
+        bias_grad(tb.rd2, Np, t->dqdec, R);
+        linear_dgrad(theta, tb.rd2, 0, 2 * R, Np, t->dqdec, R, t->dqdeca, 2 * R, false, s);
+        tr_silu_bwd(t->dqdeca, t->qdec1, (size_t)Np * 2 * R, s);
+        linear_wgrad(grad, tb.rd0, 0, J, Np, t->dqdeca, 2 * R, t->hfin + (size_t)Nl * d.dyn, d.dyn, s);
+        bias_grad(tb.rd0, Np, t->dqdeca, 2 * R);
+        linear_dgrad(theta, tb.rd0, 0, J, Np, t->dqdeca, 2 * R, t->dhfin + (size_t)Nl * d.dyn, d.dyn, false, s);
+    }
+    if (d.joint) tr_center_per_sample(h->lay, t->dX, s);      // adjoint of the velocity's mean removal (a symmetric projection)
+    if (!d.joint && Np) HIPCHK(h, hipMemsetAsync(t->dX + (size_t)Nl * 4, 0, (size_t)Np * 4 * sizeof(float), s));   // pocket rows do not move
     linear_wgrad(grad, tb.pd2, 0, 2 * P, Nl, t->ddec, P, t->deca, 2 * P, s);
     bias_grad(tb.pd2, Nl, t->ddec, P);
     linear_dgrad(theta, tb.pd2, 0, 2 * P, Nl, t->ddec, P, t->ddeca, 2 * P, false, s);
     tr_silu_bwd(t->ddeca, t->dec1, (size_t)Nl * 2 * P, s);
     linear_wgrad(grad, tb.pd0, 0, J, Nl, t->ddeca, 2 * P, t->hfin, d.dyn, s);
     bias_grad(tb.pd0, Nl, t->ddeca, 2 * P);
-    HIPCHK(h, hipMemsetAsync(t->dhfin, 0, (size_t)N * d.dyn * sizeof(float), s));
     linear_dgrad(theta, tb.pd0, 0, J, Nl, t->ddeca, 2 * P, t->dhfin, d.dyn, false, s);
     linear_wgrad(grad, tb.embo, 0, H, N, t->dhfin, d.dyn, t->h + (size_t)L * NH, H, s);
     bias_grad(tb.embo, N, t->dhfin, d.dyn);

@@ -539,23 +539,47 @@ __global__ void k_move(int N, int n_moving, const float4* __restrict__ X, const 
     if (n < n_moving) { p.x += accx[(size_t)n * 4] / nf; p.y += accx[(size_t)n * 4 + 1] / nf; p.z += accx[(size_t)n * 4 + 2] / nf; }
     Xn[n] = p;
 }
-// eps_phar[n] = [X_L - X_0 | decoded features]
-__global__ void k_eps_out(int Nl, int P, const float4* __restrict__ XL, const float4* __restrict__ X0,
-                          const float* __restrict__ dec /* [Nl][P] */, float* __restrict__ eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Nl * (3 + P)) return;
-    const int n = i / (3 + P), k = i - n * (3 + P);
-    float v;
-    if (k < 3) { const float4 a = XL[n], b = X0[n]; v = k == 0 ? a.x - b.x : k == 1 ? a.y - b.y : a.z - b.z; }
-    else v = dec[(size_t)n * P + k - 3];
-    eps[i] = v;
+// velocity of the moving nodes, vel[n] = X_L[n] - X_0[n] ([N][4]); joint mode then removes its per-sample mean
+// (remove_mean_batch over all nodes, dynamics.py:133-136)
+__global__ void k_velocity(int n_moving, const float4* __restrict__ XL, const float4* __restrict__ X0, float* __restrict__ vel) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_moving) return;
+    const float4 a = XL[n], b = X0[n];
+    vel[(size_t)n * 4] = a.x - b.x; vel[(size_t)n * 4 + 1] = a.y - b.y; vel[(size_t)n * 4 + 2] = a.z - b.z;
 }
-// split d_eps [Nl][3+P] into dX [N][4] (phar rows) and ddec [Nl][P]
-__global__ void k_eps_bwd(int Nl, int P, const float* __restrict__ deps, float* __restrict__ dX, float* __restrict__ ddec) {
+// v[n] -= mean over the nodes of n's sample (one wave per sample; phar rows then pocket rows).  The projection is
+// symmetric, so the same kernel is its own adjoint (applied to the incoming velocity gradient in backward).
+__global__ __launch_bounds__(64) void k_center_per_sample(Layout lay, float* __restrict__ v /* [N][4] */) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int nl = lay.num_phar[b], np = lay.num_pocket[b], pb = lay.phar_base[b], qb = lay.Nl + lay.pocket_base[b];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int i = lane; i < nl + np; i += 64) {
+        const float* p = v + (size_t)(i < nl ? pb + i : qb + i - nl) * 4;
+        sx += p[0]; sy += p[1]; sz += p[2];
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+    const float c = fmaxf((float)(nl + np), 1.0f);
+    sx /= c; sy /= c; sz /= c;
+    for (int i = lane; i < nl + np; i += 64) {
+        float* p = v + (size_t)(i < nl ? pb + i : qb + i - nl) * 4;
+        p[0] -= sx; p[1] -= sy; p[2] -= sz;
+    }
+}
+// eps[n] = [vel[row0 + n] | decoded features]   (rows of one node type; F = feature count)
+__global__ void k_eps_out(int n_rows, int F, int row0, const float* __restrict__ vel, const float* __restrict__ dec,
+                          float* __restrict__ eps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Nl * (3 + P)) return;
-    const int n = i / (3 + P), k = i - n * (3 + P);
-    if (k < 3) dX[(size_t)n * 4 + k] = deps[i]; else ddec[(size_t)n * P + k - 3] = deps[i];
+    if (i >= n_rows * (3 + F)) return;
+    const int n = i / (3 + F), k = i - n * (3 + F);
+    eps[i] = k < 3 ? vel[(size_t)(row0 + n) * 4 + k] : dec[(size_t)n * F + k - 3];
+}
+// split d_eps [n_rows][3+F] into dvel [N][4] (rows row0..) and ddec [n_rows][F]
+__global__ void k_eps_bwd(int n_rows, int F, int row0, const float* __restrict__ deps, float* __restrict__ dvel,
+                          float* __restrict__ ddec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * (3 + F)) return;
+    const int n = i / (3 + F), k = i - n * (3 + F);
+    if (k < 3) dvel[(size_t)(row0 + n) * 4 + k] = deps[i]; else ddec[(size_t)n * F + k - 3] = deps[i];
 }
 
 // ------------------------------------------------------------------------------------
@@ -661,11 +685,17 @@ void tr_positions(int Nl, int Np, const float* xp, int ldp, const float* xq, int
 void tr_move(int N, int n_moving, const float4* X, const float* accx, float nf, float4* Xn, hipStream_t s) {
     hipLaunchKernelGGL(k_move, EW_GRID(N), 0, s, N, n_moving, X, accx, nf, Xn);
 }
-void tr_eps_out(int Nl, int P, const float4* XL, const float4* X0, const float* dec, float* eps, hipStream_t s) {
-    if (Nl) hipLaunchKernelGGL(k_eps_out, EW_GRID((size_t)Nl * (3 + P)), 0, s, Nl, P, XL, X0, dec, eps);
+void tr_velocity(int n_moving, const float4* XL, const float4* X0, float* vel, hipStream_t s) {
+    if (n_moving) hipLaunchKernelGGL(k_velocity, EW_GRID(n_moving), 0, s, n_moving, XL, X0, vel);
 }
-void tr_eps_bwd(int Nl, int P, const float* deps, float* dX, float* ddec, hipStream_t s) {
-    if (Nl) hipLaunchKernelGGL(k_eps_bwd, EW_GRID((size_t)Nl * (3 + P)), 0, s, Nl, P, deps, dX, ddec);
+void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s) {
+    hipLaunchKernelGGL(k_center_per_sample, dim3(lay.B), dim3(64), 0, s, lay, v);
+}
+void tr_eps_out(int n_rows, int F, int row0, const float* vel, const float* dec, float* eps, hipStream_t s) {
+    if (n_rows) hipLaunchKernelGGL(k_eps_out, EW_GRID((size_t)n_rows * (3 + F)), 0, s, n_rows, F, row0, vel, dec, eps);
+}
+void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, float* ddec, hipStream_t s) {
+    if (n_rows) hipLaunchKernelGGL(k_eps_bwd, EW_GRID((size_t)n_rows * (3 + F)), 0, s, n_rows, F, row0, deps, dvel, ddec);
 }
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
               float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s) {

@@ -285,7 +285,7 @@ class EnVariationalDiffusion(nn.Module):
         return self.size_distribution.log_prob(N_phar, N_pocket)
 
     @torch.no_grad()
-    def forward(self, phar, pocket, return_info=False, t_int=None, eps=None):
+    def forward(self, phar, pocket, return_info=False, t_int=None, eps=None, _net=None):
         """The joint model's 12 loss terms (+ info) of en_diffusion.py:332-465 as VALUES (no autograd graph: the
         HIP evaluation has no backward pass).  ``t_int`` [B,1] and ``eps`` (list of combined draws, each a pair of
         raw blocks, see sample_combined_position_feature_noise) may be supplied for reproducibility."""
@@ -308,7 +308,9 @@ class EnVariationalDiffusion(nn.Module):
         nxt = (lambda: next(draws)) if draws is not None else (lambda: None)
         pm, qm = phar['mask'], pocket['mask']
         z_l, z_p, e_l, e_p = self.noised_representation(xh_phar, xh_pocket, pm, qm, gamma_t, nxt())
-        net_l, net_p = self.dynamics(z_l, z_p, t, pm, qm)
+        net_l, net_p = (_net or self.dynamics)(z_l, z_p, t, pm, qm)
+        self._last_train_ctx = {'eps_t': e_l, 'net_out': net_l, 'eps_t_pocket': e_p, 'net_out_pocket': net_p,
+                                't_is_zero': t_is_zero}
         xh_phar_hat = self.xh_given_zt_and_epsilon(z_l, net_l, gamma_t, pm)
         error_l = self.sum_except_batch((e_l - net_l) ** 2, pm, B)
         error_p = self.sum_except_batch((e_p - net_p) ** 2, qm, B)

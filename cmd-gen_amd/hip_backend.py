@@ -59,8 +59,8 @@ SYMBOLS = [
     ('cmdgen_joint_plan', C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i64p, _i64p]),
     ('cmdgen_param_count', C.c_int, [_vp, _i64p]),
     ('cmdgen_param_offset', C.c_int, [_vp, C.c_char_p, _i64p, _i64p]),
-    ('cmdgen_train_forward', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _vp]),
-    ('cmdgen_train_backward', C.c_int, [_vp, _fp, _fp, _vp]),
+    ('cmdgen_train_forward', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
+    ('cmdgen_train_backward', C.c_int, [_vp, _fp, _fp, _fp, _vp]),
     ('cmdgen_train_set_precision', C.c_int, [_vp, C.c_int32]),
     ('cmdgen_grad_sqnorm', C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_float), _vp]),
     ('cmdgen_adamw_step', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
@@ -314,7 +314,7 @@ class Handle:
         self._check(self.lib.cmdgen_param_offset(self.h, name.encode(), C.byref(a), C.byref(b)), 'cmdgen_param_offset')
         return a.value, b.value
 
-    def train_forward(self, theta, xh_phar, xh_pocket, t):
+    def train_forward(self, theta, xh_phar, xh_pocket, t, want_pocket: bool = False):
         import torch
         assert theta.is_cuda and theta.dtype == torch.float32 and theta.is_contiguous() and theta.numel() == self.param_count()
         P, R = self.cfg['phar_nf'], self.cfg['residue_nf']
@@ -323,16 +323,19 @@ class Handle:
         t = t.reshape(-1).to(torch.float32).contiguous()
         assert t.numel() == self.batch
         eps = torch.empty_like(xh_phar)
+        eps_q = torch.empty_like(xh_pocket) if want_pocket else None
         self._keep = (theta, xh_phar, xh_pocket, t)          # the backward pass reads them again
         self._check(self.lib.cmdgen_train_forward(self.h, _ptr(theta), _ptr(xh_phar), _ptr(xh_pocket), _ptr(t), _ptr(eps),
-                                                  self._stream()), 'cmdgen_train_forward')
-        return eps
+                                                  _ptr(eps_q), self._stream()), 'cmdgen_train_forward')
+        return (eps, eps_q) if want_pocket else eps
 
-    def train_backward(self, d_eps, grad):
+    def train_backward(self, d_eps, grad, d_eps_pocket=None):
         import torch
         assert d_eps.is_cuda and d_eps.dtype == torch.float32 and d_eps.is_contiguous()
+        assert d_eps_pocket is None or (d_eps_pocket.is_cuda and d_eps_pocket.dtype == torch.float32 and d_eps_pocket.is_contiguous())
         assert grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous() and grad.numel() == self.param_count()
-        self._check(self.lib.cmdgen_train_backward(self.h, _ptr(d_eps), _ptr(grad), self._stream()), 'cmdgen_train_backward')
+        self._check(self.lib.cmdgen_train_backward(self.h, _ptr(d_eps), _ptr(d_eps_pocket), _ptr(grad), self._stream()),
+                    'cmdgen_train_backward')
 
     def train_set_precision(self, bf16_gemm: bool):
         self._check(self.lib.cmdgen_train_set_precision(self.h, int(bool(bf16_gemm))), 'cmdgen_train_set_precision')

@@ -10,7 +10,7 @@ parameters are re-pointed to views of it, so ``state_dict`` / checkpoints / samp
   loss terms on the activation-saving forward (``cmdgen_train_forward``)  ->  analytic dL/d eps (a few torch ops on
   device)  ->  ``cmdgen_train_backward`` (parameter gradients)  ->  one ``all_reduce`` of the flat gradient over
   RCCL when ``world_size > 1``  ->  gradient norm, clipping coefficient  ->  ``cmdgen_adamw_step``.
-Only the l2 training objective of the shipped configs and the conditional model are supported.
+Only the l2 training objective of the shipped configs is supported; both model variants (conditional and joint) train.
 """
 from __future__ import annotations
 
@@ -26,8 +26,7 @@ class HipTrainer:
     def __init__(self, model, lr: Optional[float] = None, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-12, clip_grad: Optional[bool] = None, process_group=None,
                  gemm_dtype: str = 'fp32'):
-        if model.mode == 'joint':
-            raise NotImplementedError("the training step is built for the conditional model (mode 'pocket_conditioning')")
+        self.joint = model.mode == 'joint'
         if model.loss_type != 'l2':
             raise NotImplementedError("only diffusion_loss_type 'l2' (all shipped configs) has an analytic loss gradient here")
         self.model = model
@@ -65,8 +64,9 @@ class HipTrainer:
 
     # ------------------------------------------------------------------
     def _net(self, z_t, xh_pocket, t, phar_mask, pocket_mask):
-        eps = self.h.train_forward(self.theta, z_t.to(torch.float32).contiguous(), xh_pocket.to(torch.float32).contiguous(), t)
-        return eps, None
+        out = self.h.train_forward(self.theta, z_t.to(torch.float32).contiguous(), xh_pocket.to(torch.float32).contiguous(), t,
+                                   want_pocket=self.joint)
+        return out if self.joint else (out, None)
 
     @torch.no_grad()
     def loss_and_grad(self, data, t_int=None, eps=None):
@@ -91,8 +91,15 @@ class HipTrainer:
         w_0 = (t_is_zero / (nd * n_b) / B)[phar['mask']]
         d_eps = diff * w_t[:, None]
         d_eps[:, :nd] += diff[:, :nd] * w_0[:, None]
+        d_eps_q = None
+        if self.joint:      # the pocket is generated too: the same two terms on its nodes (lightning_modules.py:201-208)
+            rnf, n_q = self.ddpm.residue_nf, pocket['size'].to(torch.float32)
+            diff_q = ctx['net_out_pocket'] - ctx['eps_t_pocket']
+            d_eps_q = diff_q * ((1.0 - t_is_zero) / ((nd + rnf) * n_q) / B)[pocket['mask']][:, None]
+            d_eps_q[:, :nd] += diff_q[:, :nd] * (t_is_zero / (nd * n_q) / B)[pocket['mask']][:, None]
+            d_eps_q = d_eps_q.contiguous()
         self.grad.zero_()
-        self.h.train_backward(d_eps.contiguous(), self.grad)
+        self.h.train_backward(d_eps.contiguous(), self.grad, d_eps_q)
         return loss, nll, info
 
     def _allreduce(self):

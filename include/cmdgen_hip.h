@@ -212,14 +212,18 @@ int cmdgen_param_offset(cmdgen_handle* h, const char* name, int64_t* offset, int
 
 /* EGNNDynamics.forward (dynamics.py:75-139) on the parameters `theta`, keeping every activation the backward
  * pass needs (after cmdgen_set_layout; no cmdgen_finalize_weights needed).  t dev [batch].  Writes
- * eps_phar dev [Nl, 3+phar_nf].  Synchronises the stream once (the edge count sizes the activation store). */
+ * eps_phar dev [Nl, 3+phar_nf] and, when non-NULL, eps_pocket dev [Np, 3+residue_nf] (required for the joint model,
+ * config.update_pocket_coords = 1; the conditional loss never uses it).  Synchronises the stream once (the edge count
+ * sizes the activation store). */
 int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const float* xh_phar, const float* xh_pocket,
-                         const float* t, float* eps_phar, cmdgen_stream stream);
+                         const float* t, float* eps_phar, float* eps_pocket, cmdgen_stream stream);
 
-/* Backward of the last cmdgen_train_forward: given dL/d eps_phar (dev [Nl, 3+phar_nf]) ADDS dL/d theta into
+/* Backward of the last cmdgen_train_forward: given dL/d eps_phar (dev [Nl, 3+phar_nf]) and optionally
+ * dL/d eps_pocket (dev [Np, 3+residue_nf], NULL = zero) ADDS dL/d theta into
  * `grad` (dev, same layout as theta; zero it first for a fresh gradient).  What autograd does for
  * loss.backward() in the reference's training_step (lightning_modules.py:245-260). */
-int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, float* grad, cmdgen_stream stream);
+int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, const float* d_eps_pocket, float* grad,
+                          cmdgen_stream stream);
 
 /* GEMM operand precision of the training step: 0 (default) = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = operands
  * rounded to bf16 while staged, fp32 accumulation (v_mfma_f32_32x32x16_bf16).  Parameters, gradients, optimizer state,
