@@ -22,8 +22,8 @@ from cmdgen_amd.synthetic import ModelConfig, make_pockets, make_state_dict  # n
 from cmdgen_amd.training import HipTrainer  # noqa: E402
 
 
-def synthetic_batch(B, first, dev):
-    pb = make_pockets(B, 'CA', ragged=True, first_index=first)
+def synthetic_batch(B, first, dev, rep='CA'):
+    pb = make_pockets(B, rep, ragged=True, first_index=first)
     rng = np.random.Generator(np.random.PCG64(first))
     nl = pb.num_nodes_phar
     pm = np.repeat(np.arange(B), nl)
@@ -42,6 +42,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='complexes per GPU')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--representation', default='CA', choices=['CA', 'full-atom'])
     ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16'], help='GEMM operand precision (fp32 accumulation either way)')
     ap.add_argument('--cpu-baseline', action='store_true', help='also time the oracle (torch CPU autograd) on the same batch shape')
     ap.add_argument('--profile', action='store_true', help='print the per-kernel time table of 3 steps (torch.profiler)')
@@ -53,8 +54,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group('nccl')
     dev = torch.device('cuda', local)
-    cfg = ModelConfig()
-    hp = dict(outdir='out', dataset='crossdock', datadir='data', batch_size=a.batch, lr=1e-3,
+    cfg = ModelConfig(residue_nf=20 if a.representation == 'CA' else 11)
+    hp = dict(outdir='out', dataset='crossdock' if a.representation == 'CA' else 'crossdock_full', datadir='data', batch_size=a.batch, lr=1e-3,
               egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=256, n_layers=5, attention=True,
                                     tanh=True, norm_constant=1, inv_sublayers=1, sin_embedding=False,
                                     aggregation_method='sum', normalization_factor=100),
@@ -62,12 +63,12 @@ def main():
                                          diffusion_noise_precision=1e-5, diffusion_loss_type='l2', normalize_factors=[1, 4]),
               num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
               eval_params=Namespace(n_eval_samples=100, eval_batch_size=100), mode='pocket_conditioning',
-              node_histogram=np.ones((30, 70)), pocket_representation='CA')
+              node_histogram=np.ones((30, 500)), pocket_representation=a.representation)
     model = PharPocketDDPM(**hp)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed=0).items()}, strict=True)
     model = model.to(dev)
     tr = HipTrainer(model, gemm_dtype=a.gemm)
-    batches = [synthetic_batch(a.batch, 50000 + 1000 * rank + 100 * i, dev) for i in range(4)]
+    batches = [synthetic_batch(a.batch, 50000 + 1000 * rank + 100 * i, dev, a.representation) for i in range(4)]
     torch.manual_seed(rank)
     for i in range(a.warmup):
         tr.training_step(batches[i % 4])
@@ -122,7 +123,7 @@ def main():
                 opt.zero_grad()
                 t_int = torch.randint(0, 501, (a.batch, 1)).float()
                 eps = [torch.randn(len(phar['mask']), 11)]
-                terms = ref_cpu.ddpm_forward(p2, cfg.as_dict(), phar, pocket, t_int, eps, training=True, histogram=np.ones((30, 70)))
+                terms = ref_cpu.ddpm_forward(p2, cfg.as_dict(), phar, pocket, t_int, eps, training=True, histogram=np.ones((30, 500)))
                 nll = ref_cpu.nll_from_terms(terms, cfg.as_dict(), phar['size'], pocket['size'], training=True)
                 nll.mean(0).backward()
                 opt.step()
