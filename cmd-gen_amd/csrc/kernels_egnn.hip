@@ -259,16 +259,48 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
     BCarry<MT> carry;                                  // weight fragments of the projection, in flight during the encoders
     const FragPtr f0 = frag_ptr<MT>(lw0.Wpq_e, H / 8, 0, tid >> 6);
     gemm_prefetch<MT>(f0, carry);
-    for (int r = 0; r < MT; ++r)                       // stage input features (row-major, coalesced)
-        for (int k = tid; k < Fmax; k += nthr) {
-            const int n = row0 + r;
-            float v = 0.f;
-            if (r < nvalid) {
-                if (n < lay.Nl) { if (k < d.P) v = xh_phar[(size_t)n * ldp + 3 + k]; }
-                else if (k < d.R) v = xh_pocket[(size_t)(n - lay.Nl) * ldq + 3 + k];
+    const float t_chain = t_arr ? 0.f : coef[chain->step].w;     // two dependent loads: issued now, needed three phases later
+    // The eight encoder tensors (2.8k floats at the shipped sizes) are copied into LDS first, sixteen loads per thread in
+    // flight at a time: the FMA loops below then read them at LDS latency.  Read from global inside those loops they
+    // cost one dependent L2 round trip per unrolled batch (3 passes x up to 10 batches - most of this kernel's time).
+    extern __shared__ float s_enc[];
+    const int seg_n[8] = {2 * d.P * d.P, 2 * d.P, d.J * 2 * d.P, d.J, 2 * d.R * d.R, 2 * d.R, d.J * 2 * d.R, d.J};
+    const float* const seg_p[8] = {sw.pe0_w, sw.pe0_b, sw.pe2_w, sw.pe2_b, sw.re0_w, sw.re0_b, sw.re2_w, sw.re2_b};
+    int seg_o[9];
+    seg_o[0] = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) seg_o[q + 1] = seg_o[q] + seg_n[q];
+    for (int base = 0; base < seg_o[8]; base += 16 * nthr) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int gi = base + q * nthr + tid;
+            v[q] = 0.f;
+            if (gi < seg_o[8]) {
+                int sg = 0;
+#pragma unroll
+                for (int u = 1; u < 8; ++u) sg += gi >= seg_o[u];
+                v[q] = seg_p[sg][gi - seg_o[sg]];
             }
-            s_in[r][k] = v;
         }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int gi = base + q * nthr + tid;
+            if (gi < seg_o[8]) s_enc[gi] = v[q];
+        }
+    }
+    const float *pe0w = s_enc + seg_o[0], *pe0b = s_enc + seg_o[1], *pe2w = s_enc + seg_o[2], *pe2b = s_enc + seg_o[3];
+    const float *re0w = s_enc + seg_o[4], *re0b = s_enc + seg_o[5], *re2w = s_enc + seg_o[6], *re2b = s_enc + seg_o[7];
+    for (int idx = tid; idx < MT * Fmax; idx += nthr) {   // stage input features: one (row, feature) pair per thread, so the
+        const int r = idx / Fmax, k = idx - r * Fmax;     // loads of a tile are all in flight together (a per-row loop
+        const int n = row0 + r;                           // serialised 16 L2 round trips on 20 active lanes)
+        float v = 0.f;
+        if (r < nvalid) {
+            if (n < lay.Nl) { if (k < d.P) v = xh_phar[(size_t)n * ldp + 3 + k]; }
+            else if (k < d.R) v = xh_pocket[(size_t)(n - lay.Nl) * ldq + 3 + k];
+        }
+        s_in[r][k] = v;
+    }
     lds_barrier();
     // encoder layer 0 + SiLU: thread -> (row r, output o)
     for (int idx = tid; idx < MT * F1max; idx += nthr) {
@@ -278,8 +310,8 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         const bool ph = n < lay.Nl;
         const int F = ph ? d.P : d.R;
         if (o >= 2 * F) continue;
-        const float* W = (ph ? sw.pe0_w : sw.re0_w) + (size_t)o * F;
-        float s = (ph ? sw.pe0_b : sw.re0_b)[o];
+        const float* W = (ph ? pe0w : re0w) + o * F;
+        float s = (ph ? pe0b : re0b)[o];
 #pragma unroll 4
         for (int k = 0; k < F; ++k) s = fmaf(s_in[r][k], W[k], s);
         s_h1[r][o] = silu_f(s);
@@ -294,12 +326,12 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
             if (j < d.J) {
                 const bool ph = n < lay.Nl;
                 const int F2 = 2 * (ph ? d.P : d.R);
-                const float* W = (ph ? sw.pe2_w : sw.re2_w) + (size_t)j * F2;
-                s = (ph ? sw.pe2_b : sw.re2_b)[j];
+                const float* W = (ph ? pe2w : re2w) + j * F2;
+                s = (ph ? pe2b : re2b)[j];
 #pragma unroll 4
                 for (int k = 0; k < F2; ++k) s = fmaf(s_h1[r][k], W[k], s);
             } else {
-                s = t_arr ? t_arr[lay.node_sample[n]] : coef[chain->step].w;
+                s = t_arr ? t_arr[lay.node_sample[n]] : t_chain;
             }
         }
         s_h2[r][j] = s;
@@ -311,11 +343,16 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         float accr[MT];
 #pragma unroll
         for (int r = 0; r < MT; ++r) accr[r] = bc;
-#pragma unroll 4
-        for (int k = 0; k < d.dyn; ++k) {
-            const float wk = sw.emb_wT[(size_t)k * H + c];
+        for (int k0 = 0; k0 < d.dyn; k0 += 16) {       // sixteen weight loads in flight, then their FMAs (k ascending as before)
+            float wk[16];
 #pragma unroll
-            for (int r = 0; r < MT; ++r) accr[r] = fmaf(s_h2[r][k], wk, accr[r]);
+            for (int j = 0; j < 16; ++j) wk[j] = k0 + j < d.dyn ? sw.emb_wT[(size_t)(k0 + j) * H + c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (k0 + j < d.dyn) {
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) accr[r] = fmaf(s_h2[r][k0 + j], wk[j], accr[r]);
+                }
         }
 #pragma unroll
         for (int r = 0; r < MT; ++r) {
@@ -787,7 +824,9 @@ __global__ __launch_bounds__(64) void k_vel_com(Layout lay, Work w, Dims d, floa
 template <int H, int MT> static void launch_embed(const EvalLaunch& a, const float* xp, const float* xq, const float* t,
                                                   const float4* coef, ChainState* chain, hipStream_t s) {
     const int nt = (a.lay.N + MT - 1) / MT;
-    hipLaunchKernelGGL((k_embed<H, MT>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
+    const Dims& d = a.d;
+    const size_t shm = sizeof(float) * (size_t)(2 * d.P * d.P + 2 * d.P + d.J * 2 * d.P + d.J + 2 * d.R * d.R + 2 * d.R + d.J * 2 * d.R + d.J);
+    hipLaunchKernelGGL((k_embed<H, MT>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
                        (const ChainState*)chain);
 }
 template <int H, int MT> static void launch_node(const EvalLaunch& a, int l, hipStream_t s) {
