@@ -105,9 +105,13 @@ __global__ __launch_bounds__(64) void k_chain_init(Layout lay, Dims d, ChainBuf 
     record_com_check(c.check, c.z_phar, ld, pb, nl, 1.0f, lane);
 }
 
-// one posterior step z_t -> z_s (sample_p_zs_given_zt, conditional_model.py:342-374)
+// one posterior step z_t -> z_s (sample_p_zs_given_zt, conditional_model.py:342-374).
+// The sample's z (<= a few hundred floats) and eps are pulled into LDS with all loads in flight, the index-order sums
+// (COM, checks) then walk LDS instead of paying one global round trip per node; every sum keeps its order, so the
+// results are bit-identical to the straightforward version.
 __global__ __launch_bounds__(64) void k_ddpm_step(Layout lay, Dims d, ChainBuf c, Work w,
                                                   const float* __restrict__ eps) {
+    extern __shared__ float s_z[];                  // [nl * ld] z of this sample
     const int b = blockIdx.x, lane = threadIdx.x;
     const int nl = lay.num_phar[b], np = lay.num_pocket[b];
     const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
@@ -115,25 +119,29 @@ __global__ __launch_bounds__(64) void k_ddpm_step(Layout lay, Dims d, ChainBuf c
     const int step = c.state->step;                 // 0-based index of this posterior step
     const float4 cf = c.coef[step];
     const bool nan_reset = *w.nan_flag != 0;
-    // the reference checks z_t (the step's input) after the update; same numbers, recorded first
-    if (!d.no_com) record_com_check(c.check + 2 * (1 + step), c.z_phar, ld, pb, nl, 1.0f, lane);
+    float* zg = c.z_phar + (size_t)pb * ld;
+    const float* eg = eps + (size_t)pb * ld;
+    const int cnt = nl * ld;
+    for (int idx = lane; idx < cnt; idx += 64) s_z[idx] = zg[idx];
     __syncthreads();
-    for (int idx = lane; idx < nl * ld; idx += 64) {
-        const int i = idx / ld, k = idx % ld;
-        const size_t o = (size_t)(pb + i) * ld + k;
-        float e = eps[o];
+    // the reference checks z_t (the step's input) after the update; same numbers, recorded first
+    if (!d.no_com) record_com_check(c.check + 2 * (1 + step), s_z, ld, 0, nl, 1.0f, lane);
+    __syncthreads();
+    for (int idx = lane; idx < cnt; idx += 64) {
+        const int i = idx / ld, k = idx - i * ld;
+        float e = eg[idx];
         if (nan_reset && k < 3) e = 0.f;
-        const float mu = c.z_phar[o] / cf.x - cf.y * e;
-        c.z_phar[o] = mu + cf.z * draw(c, lay, 1 + step, b, i, pb + i, k, ld);
+        const float mu = s_z[idx] / cf.x - cf.y * e;
+        s_z[idx] = mu + cf.z * draw(c, lay, 1 + step, b, i, pb + i, k, ld);
     }
     __syncthreads();
-    if (!d.no_com) remove_com(c.z_phar, ld, pb, nl, c.xh_pocket, ldq, qb, np, lane);
+    if (!d.no_com) remove_com(s_z, ld, 0, nl, c.xh_pocket, ldq, qb, np, lane);
     __syncthreads();
-    if (c.z_steps)
-        for (int idx = lane; idx < nl * ld; idx += 64) {
-            const size_t o = (size_t)pb * ld + idx;
-            c.z_steps[(size_t)step * lay.Nl * ld + o] = c.z_phar[o];
-        }
+    for (int idx = lane; idx < cnt; idx += 64) {
+        const float v = s_z[idx];
+        zg[idx] = v;
+        if (c.z_steps) c.z_steps[(size_t)step * lay.Nl * ld + (size_t)pb * ld + idx] = v;
+    }
     if (c.pocket_steps)
         for (int idx = lane; idx < np * 3; idx += 64) {
             const int i = idx / 3, k = idx - 3 * i;
@@ -215,7 +223,8 @@ void cmdgen_launch_chain_init(const Layout& lay, const Dims& d, const ChainBuf& 
 }
 void cmdgen_launch_ddpm_step(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
                              const float* eps, hipStream_t s) {
-    hipLaunchKernelGGL(k_ddpm_step, dim3(lay.B), dim3(64), 0, s, lay, d, c, w, eps);
+    // dynamic LDS: the largest sample's z.  (max_n bounds nl; 3 + P floats per node)
+    hipLaunchKernelGGL(k_ddpm_step, dim3(lay.B), dim3(64), (size_t)lay.max_n * (3 + d.P) * sizeof(float), s, lay, d, c, w, eps);
 }
 void cmdgen_launch_chain_final(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
                                const float* eps, float* xo, float* po, unsigned int* cog, hipStream_t s) {

@@ -104,13 +104,17 @@ __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict
 __global__ void k_edge_write(Layout lay, Work w, Dims d) {
     extern __shared__ float4 spos[];
     int* soff = reinterpret_cast<int*>(spos + lay.max_n);
+    int* sdg = soff + lay.max_n;                 // the sample's degree words (k_edge_count), read many times below
     __shared__ int s_base[5];
     __shared__ int s_red[6][16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nl = lay.num_phar[b], np = lay.num_pocket[b], n = nl + np;
     const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
     const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    for (int i = tid; i < n; i += blockDim.x) spos[i] = i < nl ? w.X0[pb + i] : w.XP[qb + i - nl];
+    for (int i = tid; i < n; i += blockDim.x) {
+        spos[i] = i < nl ? w.X0[pb + i] : w.XP[qb + i - nl];
+        sdg[i] = w.degL[pb + qb + i];
+    }
     // The compact list is ordered like torch.where on the N x N adjacency of the flat node
     // numbering (dynamics.py:146): all phar receivers first (sample by sample), then all pocket
     // receivers.  So the phar-receiver edges - the only ones the coordinate update needs - are
@@ -146,7 +150,7 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
         int carry = 0;
         for (int c = 0; c < n; c += 64) {
             const int i = c + lane;
-            const int v = i < n ? (w.degL[pb + qb + i] & 0x3fffffff) : 0;
+            const int v = i < n ? (sdg[i] & 0x3fffffff) : 0;
             int s = v;
             for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(s, o); if (lane >= o) s += t; }
             if (i < n) soff[i] = carry + s - v;
@@ -167,7 +171,7 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
         const bool moving = i < nl || d.joint;           // receivers whose coordinates are updated
         if (moving) {
             int selfs = 0;
-            for (int k = (i < nl ? 0 : nl) + lane; k < i; k += 64) selfs += (w.degL[pb + qb + k] >> 30) & 1;
+            for (int k = (i < nl ? 0 : nl) + lane; k < i; k += 64) selfs += (sdg[k] >> 30) & 1;
             for (int o = 32; o > 0; o >>= 1) selfs += __shfl_xor(selfs, o);
             coff = i < nl ? s_base[3] + soff[i] - selfs : s_base[4] + (soff[i] - eph_b) - selfs;
         }
@@ -850,7 +854,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
                           float* eps_phar, float* eps_pocket, hipStream_t s,
                           hipEvent_t* ev /* null or 2*(3+3L) events */) {
     const int B = a.lay.B, N = a.lay.N;
-    const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + sizeof(int));
+    const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + 2 * sizeof(int));
     int e = 0;
 #define REC() do { if (ev) hipEventRecord(ev[e++], s); } while (0)
 #define PROF(k) do { if (a.prof_events) { hipEvent_t pe; hipEventCreate(&pe); hipEventRecord(pe, s); a.prof_events[k].push_back(pe); } } while (0)
@@ -893,7 +897,7 @@ void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* 
 
 // radius graph only (the training path builds its own evaluation on top of the same compact lists)
 void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s) {
-    const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + sizeof(int));
+    const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + 2 * sizeof(int));
     hipLaunchKernelGGL(k_edge_count, dim3(a.lay.B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket, (ChainState*)nullptr);
     hipLaunchKernelGGL(k_edge_write, dim3(a.lay.B), dim3(256), shm, s, a.lay, a.w, a.d);
 }
