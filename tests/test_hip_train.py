@@ -349,3 +349,47 @@ def test_joint_training_gradients_vs_oracle_autograd():
     tr.lr = 2e-3
     losses = [float(tr.training_step(data)['loss']) for _ in range(40)]
     assert np.isfinite(losses).all() and np.mean(losses[-8:]) < 0.93 * np.mean(losses[:8]), losses    # fresh t / noise each step: noisy
+
+
+def test_one_handle_many_layouts_soak():
+    """Workspaces are capacity-based: a handle that has seen a big batch reuses its buffers for every later layout that
+    fits.  Walk one handle through shrinking / growing ragged layouts, mixing evaluations, graph and eager chains and
+    training forward/backward, and check every result against the oracle (stale state from a previous layout - graphs,
+    index arrays, the agg-is-zero invariant, activation stores - would show up here)."""
+    cfg = ModelConfig(hidden_nf=64, n_layers=2)
+    sd = make_state_dict(cfg, seed=77, coord_gain=1.0)
+    p = ref_cpu.to_torch_params(sd)
+    h = make_handle(cfg)
+    h.load_state_dict(sd)
+    theta = flat_theta(h, sd)
+    rng = np.random.Generator(np.random.PCG64(5))
+    for it, B in enumerate([6, 2, 5, 1, 7, 3, 6, 2]):
+        pb, pm, xh_phar, xh_pocket, t = case_inputs(cfg, B, 910000 + 37 * it, rng)
+        h.set_layout(pb.num_nodes_phar, pb.size)
+        with torch.no_grad():
+            want, _ = ref_cpu.dynamics_forward(p, cfg.as_dict(), torch.from_numpy(xh_phar), torch.from_numpy(xh_pocket),
+                                               torch.from_numpy(t), torch.from_numpy(pm), torch.from_numpy(pb.mask))
+        want = want.numpy()
+        tol = 2e-5 * max(1.0, float(np.abs(want).max()))
+        got, _ = h.dynamics_forward(dev(xh_phar), dev(xh_pocket), dev(t))
+        assert np.abs(got.cpu().numpy() - want).max() <= tol, (it, B)
+        if it % 2 == 0:         # training path on the same handle and layout
+            eps = h.train_forward(theta, dev(xh_phar), dev(xh_pocket), dev(t))
+            assert np.abs(eps.cpu().numpy() - want).max() <= tol, (it, B)
+            g1 = torch.zeros_like(theta); g2 = torch.zeros_like(theta)
+            d_eps = dev(rng.normal(size=want.shape).astype(np.float32))
+            h.train_backward(d_eps, g1)
+            h.train_forward(theta, dev(xh_phar), dev(xh_pocket), dev(t))
+            h.train_backward(d_eps, g2)
+            assert float((g1 - g2).abs().max()) <= 1e-3 * float(g1.abs().max())      # repeatable up to atomics order
+        # a short chain, graph replay vs eager launches with the same injected noise
+        K = 4
+        noise = dev(rng.normal(size=(K + 2, len(pm), 11)).astype(np.float32))
+        px, poh = dev(pb.x), dev(pb.one_hot)
+        a = h.sample_chain(px, poh, K, noise=noise, use_graph=True)
+        b = h.sample_chain(px, poh, K, noise=noise, use_graph=False)
+        assert torch.equal(a[0][:, 3:], b[0][:, 3:])
+        sc = max(1.0, float(a[0][:, :3].abs().max()))
+        assert float((a[0][:, :3] - b[0][:, :3]).abs().max()) <= 1e-4 * sc, (it, B)
+        st = h.chain_status()
+        assert st['max_rel_com_error'] < 1e-2
