@@ -393,3 +393,45 @@ def test_one_handle_many_layouts_soak():
         assert float((a[0][:, :3] - b[0][:, :3]).abs().max()) <= 1e-4 * sc, (it, B)
         st = h.chain_status()
         assert st['max_rel_com_error'] < 1e-2
+
+
+def test_simple_conditional_training_gradients_vs_oracle_autograd():
+    """mode 'pocket_conditioning_simple' (SimpleConditionalDDPM: pocket-centred frame, no COM projection) trains through
+    the same path; gradient of the l2 training loss vs autograd through the oracle."""
+    from argparse import Namespace
+    from cmdgen_amd.lightning_modules import PharPocketDDPM
+    from cmdgen_amd.training import HipTrainer
+    g6 = load_golden('g6_loss.npz')
+    cfg, sd, phar, pocket, hist = loss_case(g6)
+    cfg.no_com_projection = True
+    hp = dict(outdir='out', dataset='crossdock', datadir='data', batch_size=4, lr=1e-3,
+              egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=cfg.hidden_nf, n_layers=cfg.n_layers,
+                                    attention=True, tanh=True, norm_constant=1, inv_sublayers=1, sin_embedding=False,
+                                    aggregation_method='sum', normalization_factor=100),
+              diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
+                                         diffusion_noise_precision=1e-5, diffusion_loss_type='l2', normalize_factors=[1, 4]),
+              num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
+              eval_params=Namespace(n_eval_samples=100, eval_batch_size=100), mode='pocket_conditioning_simple',
+              node_histogram=hist, pocket_representation='CA')
+    model = PharPocketDDPM(**hp)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.cuda()
+    tr = HipTrainer(model)
+    data = {'phar_coords': phar['x'], 'phar_one_hot': phar['one_hot'], 'num_phar_atoms': phar['size'], 'phar_mask': phar['mask'],
+            'pocket_c_alpha': pocket['x'], 'pocket_one_hot': pocket['one_hot'], 'num_pocket_nodes': pocket['size'],
+            'pocket_mask': pocket['mask']}
+    t_int = torch.tensor([[3.], [137.], [500.], [42.]])          # no t = 0 here: keeps every evaluation clear of the cutoff
+    loss, nll, info = tr.loss_and_grad(data, t_int=t_int.cuda(), eps=[dev(g6['eps0'])])
+    p = ref_cpu.to_torch_params(sd)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith('dynamics.')}
+    p2 = dict(p); p2.update(leaves)
+    terms = ref_cpu.ddpm_forward(p2, cfg.as_dict(), phar, pocket, t_int, [torch.from_numpy(g6['eps0'])], training=True,
+                                 histogram=hist)
+    want = ref_cpu.nll_from_terms(terms, cfg.as_dict(), phar['size'], pocket['size'], training=True)
+    want.mean(0).backward()
+    assert np.abs(nll.cpu().numpy() - want.detach().numpy()).max() < 2e-5 * max(1.0, float(want.detach().abs().max()))
+    grad = tr.grad.cpu().numpy()
+    for name, leaf in leaves.items():
+        off, cnt = tr.h.param_offset(name[len('dynamics.'):])
+        g_want = np.zeros(cnt, np.float32) if leaf.grad is None else leaf.grad.numpy().reshape(-1)
+        assert np.abs(grad[off:off + cnt] - g_want).max() <= GRAD_TOL * max(float(np.abs(g_want).max()), 1e-6), name
