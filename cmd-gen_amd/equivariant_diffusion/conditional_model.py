@@ -102,11 +102,11 @@ class ConditionalDDPM(EnVariationalDiffusion):
         z_t, xh_pocket, eps_t = self.noised_representation(xh0_phar, xh0_pocket, phar['mask'], pocket['mask'],
                                                            gamma_t, nxt())
         net_out, _ = (_net or self.dynamics)(z_t, xh_pocket, t, phar['mask'], pocket['mask'])
-        self._last_train_ctx = {'eps_t': eps_t, 'net_out': net_out, 't_is_zero': t_is_zero}
         xh_phar_hat = self.xh_given_zt_and_epsilon(z_t, net_out, gamma_t, phar['mask'])
         error_t = self.sum_except_batch((eps_t - net_out) ** 2, phar['mask'], B)
         SNR_weight = (1 - self.SNR(gamma_s - gamma_t)).squeeze(1)
         assert error_t.size() == SNR_weight.size()
+        self._last_train_ctx = {'eps_t': eps_t, 'net_out': net_out, 't_is_zero': t_is_zero, 'SNR_weight': SNR_weight}
         neg_log_constants = -self.log_constants_p_x_given_z0(n_nodes=phar['size'], device=dev)
         kl_prior = self.kl_prior(xh0_phar, phar['mask'], phar['size'])
         if self.training:

@@ -309,13 +309,13 @@ class EnVariationalDiffusion(nn.Module):
         pm, qm = phar['mask'], pocket['mask']
         z_l, z_p, e_l, e_p = self.noised_representation(xh_phar, xh_pocket, pm, qm, gamma_t, nxt())
         net_l, net_p = (_net or self.dynamics)(z_l, z_p, t, pm, qm)
-        self._last_train_ctx = {'eps_t': e_l, 'net_out': net_l, 'eps_t_pocket': e_p, 'net_out_pocket': net_p,
-                                't_is_zero': t_is_zero}
         xh_phar_hat = self.xh_given_zt_and_epsilon(z_l, net_l, gamma_t, pm)
         error_l = self.sum_except_batch((e_l - net_l) ** 2, pm, B)
         error_p = self.sum_except_batch((e_p - net_p) ** 2, qm, B)
         SNR_weight = (1 - self.SNR(gamma_s - gamma_t)).squeeze(1)
         assert error_l.size() == SNR_weight.size()
+        self._last_train_ctx = {'eps_t': e_l, 'net_out': net_l, 'eps_t_pocket': e_p, 'net_out_pocket': net_p,
+                                't_is_zero': t_is_zero, 'SNR_weight': SNR_weight}
         neg_log_constants = -self.log_constants_p_x_given_z0(n_nodes=n_tot, device=dev)
         kl_prior = self.kl_prior_with_pocket(xh_phar, xh_pocket, pm, qm, n_tot)
         if self.training:

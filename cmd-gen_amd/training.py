@@ -10,7 +10,7 @@ parameters are re-pointed to views of it, so ``state_dict`` / checkpoints / samp
   loss terms on the activation-saving forward (``cmdgen_train_forward``)  ->  analytic dL/d eps (a few torch ops on
   device)  ->  ``cmdgen_train_backward`` (parameter gradients)  ->  one ``all_reduce`` of the flat gradient over
   RCCL when ``world_size > 1``  ->  gradient norm, clipping coefficient  ->  ``cmdgen_adamw_step``.
-Only the l2 training objective of the shipped configs is supported; both model variants (conditional and joint) train.
+Both objectives ('l2' of the shipped configs, 'vlb' with a predefined schedule) and all model variants train.
 """
 from __future__ import annotations
 
@@ -27,8 +27,7 @@ class HipTrainer:
                  weight_decay: float = 1e-12, clip_grad: Optional[bool] = None, process_group=None,
                  gemm_dtype: str = 'fp32'):
         self.joint = model.mode == 'joint'
-        if model.loss_type != 'l2':
-            raise NotImplementedError("only diffusion_loss_type 'l2' (all shipped configs) has an analytic loss gradient here")
+        assert model.loss_type in ('l2', 'vlb')
         self.model = model
         self.ddpm = model.ddpm
         self.dyn = model.ddpm.dynamics
@@ -84,19 +83,27 @@ class HipTrainer:
         eps_t, net_out, t_is_zero = ctx['eps_t'], ctx['net_out'], ctx['t_is_zero'].squeeze(1)
         nd, pnf = self.ddpm.n_dims, self.ddpm.phar_nf
         n_b = phar['size'].to(torch.float32)
-        # d loss / d net_out: loss = mean_b [ 0.5 * error_t/((nd+P) n_b) * (t != 0) + loss_0_x/(nd n_b) * (t == 0) + const ]
-        # (lightning_modules.py:198-217; conditional_model.py:243-262, :291-301)
+        # d loss / d net_out (lightning_modules.py:198-217; conditional_model.py:243-262, :291-301):
+        #   l2 : loss = mean_b [ 0.5 * error_t/((nd+P) n_b) * (t != 0) + loss_0_x/(nd n_b) * (t == 0) + const ]
+        #   vlb: loss = mean_b [ -T/2 * SNR_weight_b * error_t * (t != 0) + loss_0_x * (t == 0) + const ]
+        # with error_t = sum (eps - net)^2 and loss_0_x = 0.5 * sum over x of (eps - net)^2
         diff = net_out - eps_t
-        w_t = ((1.0 - t_is_zero) / ((nd + pnf) * n_b) / B)[phar['mask']]
-        w_0 = (t_is_zero / (nd * n_b) / B)[phar['mask']]
+        l2 = model.loss_type == 'l2'
+        if l2:
+            s_t, s_0 = 1.0 / ((nd + pnf) * n_b), 1.0 / (nd * n_b)
+        else:
+            s_t, s_0 = -self.ddpm.T * ctx['SNR_weight'], torch.ones_like(n_b)
+        w_t = ((1.0 - t_is_zero) * s_t / B)[phar['mask']]
+        w_0 = (t_is_zero * s_0 / B)[phar['mask']]
         d_eps = diff * w_t[:, None]
         d_eps[:, :nd] += diff[:, :nd] * w_0[:, None]
         d_eps_q = None
         if self.joint:      # the pocket is generated too: the same two terms on its nodes (lightning_modules.py:201-208)
             rnf, n_q = self.ddpm.residue_nf, pocket['size'].to(torch.float32)
             diff_q = ctx['net_out_pocket'] - ctx['eps_t_pocket']
-            d_eps_q = diff_q * ((1.0 - t_is_zero) / ((nd + rnf) * n_q) / B)[pocket['mask']][:, None]
-            d_eps_q[:, :nd] += diff_q[:, :nd] * (t_is_zero / (nd * n_q) / B)[pocket['mask']][:, None]
+            q_t, q_0 = (1.0 / ((nd + rnf) * n_q), 1.0 / (nd * n_q)) if l2 else (s_t, s_0)
+            d_eps_q = diff_q * ((1.0 - t_is_zero) * q_t / B)[pocket['mask']][:, None]
+            d_eps_q[:, :nd] += diff_q[:, :nd] * (t_is_zero * q_0 / B)[pocket['mask']][:, None]
             d_eps_q = d_eps_q.contiguous()
         self.grad.zero_()
         self.h.train_backward(d_eps.contiguous(), self.grad, d_eps_q)

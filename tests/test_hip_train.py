@@ -435,3 +435,26 @@ def test_simple_conditional_training_gradients_vs_oracle_autograd():
         off, cnt = tr.h.param_offset(name[len('dynamics.'):])
         g_want = np.zeros(cnt, np.float32) if leaf.grad is None else leaf.grad.numpy().reshape(-1)
         assert np.abs(grad[off:off + cnt] - g_want).max() <= GRAD_TOL * max(float(np.abs(g_want).max()), 1e-6), name
+
+
+def test_vlb_objective_gradients_vs_oracle_autograd():
+    """diffusion_loss_type 'vlb' (predefined schedule): loss_t = -T/2 SNR_weight error_t, un-normalised L0, minus
+    delta_log_px and log_pN (lightning_modules.py:209-231); gradient vs autograd through the oracle."""
+    model, tr, data, g6 = build_trainer()
+    model.loss_type = 'vlb'
+    cfg, sd, phar, pocket, hist = loss_case(g6)
+    t_int, eps = dev(g6['t_int']), [dev(g6['eps0'])]
+    loss, nll, info = tr.loss_and_grad(data, t_int=t_int, eps=eps)
+    p = ref_cpu.to_torch_params(sd)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith('dynamics.')}
+    p2 = dict(p); p2.update(leaves)
+    terms = ref_cpu.ddpm_forward(p2, cfg.as_dict(), phar, pocket, torch.from_numpy(g6['t_int']), [torch.from_numpy(g6['eps0'])],
+                                 training=True, histogram=hist)
+    want = ref_cpu.nll_from_terms(terms, cfg.as_dict(), phar['size'], pocket['size'], training=True, loss_type='vlb')
+    want.mean(0).backward()
+    assert np.abs(nll.cpu().numpy() - want.detach().numpy()).max() < 2e-5 * max(1.0, float(want.detach().abs().max()))
+    grad = tr.grad.cpu().numpy()
+    for name, leaf in leaves.items():
+        off, cnt = tr.h.param_offset(name[len('dynamics.'):])
+        g_want = np.zeros(cnt, np.float32) if leaf.grad is None else leaf.grad.numpy().reshape(-1)
+        assert np.abs(grad[off:off + cnt] - g_want).max() <= GRAD_TOL * max(float(np.abs(g_want).max()), 1e-6), name
