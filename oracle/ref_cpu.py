@@ -9,7 +9,12 @@ loudly when the HIP library is missing.
 Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function
 here against fixtures under ``tests/golden/`` that were produced by importing
 the real reference (``/root/reference/DiffPhar``) in the build container with
-``tests/golden/make_golden.py`` (script committed next to the vectors).
+``tests/golden/make_golden.py`` (schedule, evaluation, edges, conditional chains,
+loss terms, node-count prior), ``make_golden_joint.py`` (joint evaluation, ``sample``,
+RePaint ``inpaint``, schedules, joint loss) and ``make_golden_grad.py`` (the
+reference's autograd gradients of the training loss, which autograd through this
+file reproduces - so it is also the pinned checker of the HIP backward pass).
+The scripts are committed next to the vectors.
 
 Op order follows the reference's eager sequence on purpose (same ``cat`` then
 ``addmm`` shapes, same association in the posterior mean, the N_total x N_total
