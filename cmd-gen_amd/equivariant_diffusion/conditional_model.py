@@ -13,7 +13,7 @@ import math
 import numpy as np
 import torch
 
-from .en_diffusion import EnVariationalDiffusion
+from .en_diffusion import EnVariationalDiffusion, fresh_seed
 from .. import utils
 
 
@@ -147,7 +147,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
         Reference arguments: pocket dict(x, one_hot, size, mask), num_nodes_phar [B],
         return_frames, timesteps.  Extensions (keyword-only in spirit):
           noise      [K+2, Nl, 3+phar_nf] Gaussian draws to inject (parity / reproducibility);
-          seed       Philox seed for on-device draws (default: torch.initial_seed());
+          seed       Philox seed for on-device draws (default: a fresh one per call from torch's global generator);
           pocket_ids global pocket indices so a shard draws the same noise as the full batch.
         Returns (xh_phar, xh_pocket, phar_mask, pocket_mask) like the reference; with
         return_frames > 1 the first two carry a leading frame axis.
@@ -172,7 +172,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
         if noise is not None:
             noise = noise.detach().to(device, torch.float32).contiguous()
         if seed is None:
-            seed = torch.initial_seed()
+            seed = fresh_seed()
         want_steps = return_frames > 1
         xh_phar, xh_pocket, z_steps = h.sample_chain(px, poh, timesteps, noise=noise, seed=seed,
                                                      pocket_ids=pocket_ids, want_steps=want_steps,

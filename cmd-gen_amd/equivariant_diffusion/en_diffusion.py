@@ -86,6 +86,13 @@ class DistributionNodes:
         return self._table(2, n2.device)[n1.long(), n2.long()]
 
 
+def fresh_seed() -> int:
+    """Philox seed of one sampling call when the caller gives none: drawn from torch's global generator, so every
+    call gets new noise (the reference draws fresh torch.randn noise per call) while torch.manual_seed(...) still
+    makes a run reproducible."""
+    return int(torch.randint(0, 2 ** 63 - 1, (1,), dtype=torch.int64).item())
+
+
 class EnVariationalDiffusion(nn.Module):
     """The joint model (mode 'joint'): schedule algebra shared by the diffusion variants
     (en_diffusion.py:13-103, :849-906) plus the joint sampler and RePaint inpainting
@@ -154,6 +161,10 @@ class EnVariationalDiffusion(nn.Module):
         final row: sigma_0, alpha_0, SNR(-gamma_0/2), t=0 from :108-131)."""
         table = self.gamma.gamma.detach().cpu()
         T, K = self.T, timesteps
+        cache = self.__dict__.setdefault('_step_tables', {})        # K tiny torch ops x 15 per call otherwise
+        hit = cache.get(K)
+        if hit is not None and torch.equal(hit[0], table):
+            return hit[1]
         z = torch.zeros(1, 1)
         rows = []
         look = lambda t: table[torch.round(t * T).long()]
@@ -166,7 +177,9 @@ class EnVariationalDiffusion(nn.Module):
             rows.append([a_ts.item(), (s2 / a_ts / sig_t).item(), (s_ts * sig_s / sig_t).item(), t_arr.item()])
         g0 = look(torch.zeros(1, 1))
         rows.append([self.sigma(g0, z).item(), self.alpha(g0, z).item(), self.SNR(-0.5 * g0).item(), 0.0])
-        return np.asarray(rows, dtype=np.float32)
+        out = np.asarray(rows, dtype=np.float32)
+        cache[K] = (table.clone(), out)
+        return out
 
     # ---- normalisation (en_diffusion.py:874-906)
     def normalize(self, phar=None, pocket=None):
@@ -409,7 +422,7 @@ class EnVariationalDiffusion(nn.Module):
         if noise is not None:
             noise = noise.detach().to(dev, torch.float32).contiguous()
         xh_phar, xh_pocket, z_steps = h.joint_chain(
-            timesteps, noise=noise, seed=torch.initial_seed() if seed is None else seed, pocket_ids=pocket_ids,
+            timesteps, noise=noise, seed=fresh_seed() if seed is None else seed, pocket_ids=pocket_ids,
             want_steps=return_frames > 1, use_graph=self.use_hip_graph, device=dev)
         frames = [(timesteps - 1 - s, (s * return_frames) // timesteps) for s in range(timesteps)
                   if (s * return_frames) % timesteps == 0]
@@ -441,7 +454,7 @@ class EnVariationalDiffusion(nn.Module):
             timesteps, phar=(f32(phar['x']), f32(phar['one_hot'])), pocket=(f32(pocket['x']), f32(pocket['one_hot'])),
             phar_fixed=f32(phar_fixed).reshape(-1), pocket_fixed=f32(pocket_fixed).reshape(-1),
             resamplings=resamplings, jump_length=jump_length, noise=noise,
-            seed=torch.initial_seed() if seed is None else seed, pocket_ids=pocket_ids,
+            seed=fresh_seed() if seed is None else seed, pocket_ids=pocket_ids,
             want_steps=return_frames > 1, use_graph=self.use_hip_graph)
         frames = []
         if return_frames > 1:       # walk the schedule as :723-813 do, noting which steps write a frame

@@ -146,3 +146,37 @@ def joint_loss_case(g):
 
 LOSS_NAMES = ['delta_log_px', 'error_t_phar', 'error_t_pocket', 'SNR_weight', 'loss_0_x_phar', 'loss_0_x_pocket',
               'loss_0_h', 'neg_log_constants', 'kl_prior', 'log_pN', 't_int', 'xh_phar_hat']
+
+
+# ---------------------------------------------------------------- round-2 goldens (make_golden_r2.py)
+def bounded_case(g, name):
+    """G13: chains of a model with noise_precision 0.05 / norm_values [1, 0.5] (|x| stays O(10 A))."""
+    H, L, B, R, seed, K, gain1, first, T = [int(v) for v in g[name + '/meta']]
+    cfg = ModelConfig(hidden_nf=H, n_layers=L, residue_nf=R, timesteps=T, noise_precision=float(g[name + '/noise_precision']),
+                      norm_values=tuple(float(v) for v in g[name + '/norm_values']))
+    sd = make_state_dict(cfg, seed=seed, coord_gain=1.0 if gain1 else 1e-3)
+    pb = make_pockets(B, 'CA', ragged=bool(int(g[name + '/ragged'])), n_phar=8, first_index=first)
+    return cfg, sd, pb, K
+
+
+def fullsize_chain_case(g, name='chain_fa366_K5'):
+    """G12: BASELINE configs[4]'s real shape - 366 full-atom pocket atoms + 15 phar points per sample."""
+    H, L, B, R, seed, K, gain1, first = [int(v) for v in g[name + '/meta']]
+    cfg = cfg_from_meta(H, L, R)
+    sd = make_state_dict(cfg, seed=seed, coord_gain=1.0 if gain1 else 1e-3)
+    pb = make_pockets(B, 'full-atom', n_phar=15, first_index=first)
+    return cfg, sd, pb, K
+
+
+def g5_case(g):
+    H, L, B, R, seed, gain1, first = [int(v) for v in g['meta']]
+    cfg = cfg_from_meta(H, L, R)
+    sd = make_state_dict(cfg, seed=seed, coord_gain=1.0 if gain1 else 1e-3)
+    pm, qm = masks_from_sizes(g['pocket_size'], g['num_nodes_phar'])
+    inp = dict(xh_phar=g['xh_phar'], xh_pocket=g['xh_pocket'], t=g['t'], mask_phar=pm, mask_pocket=qm)
+    return cfg, sd, inp
+
+
+def pocket_dict(pb):
+    return {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot),
+            'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
