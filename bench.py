@@ -11,13 +11,19 @@ pockets (weak scaling, no data-path collective); time = MAX over ranks.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--timesteps T]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  Also reported: the algorithmic-FLOP roofline of the dominant
-kernel (edge message, fp32 MFMA) measured live with HIP events, and the oracle's CPU rate on
-the host cores (a baseline, not the target).
+Both forms work: started WITHOUT a torch.distributed environment and with --gpus N > 1, this process touches no
+GPU, starts the N ranks itself (torch.distributed.run, one rank per GPU over RCCL) and relays rank 0's JSON line.
+
+Prints ONE JSON line (rank 0).  Also reported: the algorithmic-FLOP roofline of the dominant kernel measured live
+with HIP events on the launch stream, the north-star shape (256 pockets) next to the headline, and the oracle's CPU
+rate on the host cores (a baseline, not the target).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,7 +40,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Pe
 PEAK_HBM_TBS = 8.0
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=3)
@@ -46,7 +52,61 @@ def parse():
     p.add_argument('--no-graph', action='store_true')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=12.0)
-    return p.parse_args()
+    p.add_argument('--north-star-batch', type=int, default=256,
+                   help='also time one chain at the north-star shape (pockets on one GPU; 0 = skip; N=1 only)')
+    p.add_argument('--dry-run-launch', action='store_true',
+                   help='launch logic only (CPU, gloo, no sampling): used by tests/test_bench_launch.py')
+    return p.parse_args(argv)
+
+
+# --------------------------------------------------------------------------------------------- launching N ranks
+def self_launch(args, argv):
+    """--gpus N without a torch.distributed environment: start the N ranks as children of a process that has not
+    touched the GPU (never re-exec a process that has) and relay rank 0's line; exit code = the launcher's."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+    if r.returncode != 0 or line is None:
+        sys.stderr.write(r.stdout[-4000:])
+        sys.exit(r.returncode or 1)
+    print(line)
+    sys.exit(0)
+
+
+# --------------------------------------------------------------------------------------------- accounting
+def kernel_source_sha():
+    """Identity of the kernel sources a PMC measurement belongs to (profiles/kernel_traffic.json is stamped with it)."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'cmd-gen_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'cmd-gen_amd', 'csrc', '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def node_flop_per_launch(H, L, nodes, moving):
+    """Algorithmic FLOP of ONE k_node launch, averaged over the L launches of an evaluation - what the launch needs,
+    per row: node_mlp 2*(2H*H) + 2*(H*H) = 6H^2; Q_c 2H^2 on every row, P_c 2H^2 on rows that move only (phar rows:
+    pocket rows never receive a coordinate update, egnn_new.py:100-101); P|Q of the next block 4H^2 except in the last
+    block (block 0's P|Q belong to k_embed)."""
+    per_block = [nodes * 8.0 * H * H + moving * 2.0 * H * H + (nodes * 4.0 * H * H if l + 1 < L else 0.0) for l in range(L)]
+    return sum(per_block) / L
+
+
+def whole_job_flop(H, L, dyn, edges, coord_edges, nodes, moving):
+    """F_alg of SURVEY 8d with P_c counted on moving rows only: L*[2(H^2+H)(E+Ec) + 12H^2 N + 2H^2 Nm] + in/out
+    embeddings (2*dyn*H per node each)."""
+    return L * (2.0 * (H * H + H) * (edges + coord_edges) + 12.0 * H * H * nodes + 2.0 * H * H * moving) + 4.0 * dyn * H * nodes
 
 
 def cpu_baseline(cfg, sd, batch, rep, n_phar, budget_s):
@@ -86,16 +146,38 @@ def cpu_baseline(cfg, sd, batch, rep, n_phar, budget_s):
             if el >= budget_s or evals >= 400:
                 break
     return {'value': cpu_batch * evals / el, 'unit': 'pocket-steps/s', 'cores': int(best_n), 'kind': 'port',
-            'sample': f'{evals} network evaluations (chains of {K} steps + final decode) of the same model on '
-                      f'{cpu_batch} {rep} pockets, torch {torch.__version__} CPU fp32 with {best_n} of {ncpu} '
+            'sample': f'{evals} network evaluations (chains of {K} steps + final decode, i.e. phar points still inside the '
+                      f'pocket: the edge-rich geometry of `steady_state_evaluation`, not the drifted one of the headline chain) '
+                      f'of the same model on {cpu_batch} {rep} pockets, torch {torch.__version__} CPU fp32 with {best_n} of {ncpu} '
                       f'hardware threads (best of {cands}), {el:.1f} s'}
 
 
-def main():
-    args = parse()
+def dry_run(args, world, rank):
+    """Launch logic without a GPU: N ranks rendezvous over gloo, agree on the rank count, rank 0 prints the line."""
+    import torch.distributed as dist
+    n_ranks = 1
+    if world > 1:
+        dist.init_process_group('gloo')
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        n_ranks = int(ones.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'metric': 'denoising steps/sec', 'value': 0.0, 'unit': 'pocket-steps/s', 'n_gpus': n_ranks,
+                          'steps': args.steps, 'warmup': args.warmup, 'dry_run': True}))
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args, argv)                   # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.dry_run_launch:
+        return dry_run(args, world, rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -106,8 +188,13 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local_rank if world > 1 else 0)
     n_gpus = world
-    if args.gpus != world and rank == 0:
-        print(f'note: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}', file=sys.stderr)
+    if dist is not None:                          # the ranks that actually run (RCCL all-reduce of ones)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        n_gpus = int(ones.item())
+        assert n_gpus == world, (n_gpus, world)
+    if args.gpus != n_gpus and rank == 0:
+        print(f'note: --gpus {args.gpus} but {n_gpus} ranks were launched; reporting n_gpus={n_gpus}', file=sys.stderr)
 
     B, T, rep = args.batch, args.timesteps, args.representation
     cfg = ModelConfig(residue_nf=20 if rep == 'CA' else 11, timesteps=T)
@@ -150,17 +237,16 @@ def main():
 
     result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: per-launch HIP events around every launch of the three MFMA
-        # kernels during one more (eager) chain on the same stream; the kernel with the largest summed time is
-        # the dominant one.  Algorithmic FLOP per launch: edge message 2(H^2+H) per edge,
-        # node 14 H^2 per node, coord 2(H^2+H) per phar-receiver edge.
-        H = cfg.hidden_nf
-        L = cfg.n_layers
+        H, L, dyn = cfg.hidden_nf, cfg.n_layers, cfg.joint_nf + 1
+        nl_tot = int(pb.num_nodes_phar.sum())
+        # ---- roofline of the dominant kernel: HIP events on the launch stream around EVERY launch of the three MFMA
+        # kernels during one more chain of the same workload (eager launches: a graph replay has no per-kernel events).
+        # Algorithmic FLOP per launch: edge kernels 2(H^2+H) per listed edge (device counters); node kernel see
+        # node_flop_per_launch (what each launch needs, not 14 H^2 on every row).
         with torch.cuda.stream(stream):
             h.reset_counters()
             h.set_kernel_profiling(True)
-            Kp = min(T, 200)
-            h.sample_chain(px, poh, Kp, noise=None, seed=7, pocket_ids=pb.pocket_index, use_graph=False)
+            h.sample_chain(px, poh, T, noise=None, seed=0, pocket_ids=pb.pocket_index, use_graph=False)
             prof = h.kernel_profile()
             h.set_kernel_profiling(False)
             pc = h.counters()
@@ -170,10 +256,9 @@ def main():
                                       torch.full((B,), 0.5, device=dev))
         # ---- steady-state micro-benchmark: one evaluation at the geometry a TRAINED model holds -
         # phar points uniform in a 5 A ball at the pocket centre (random-init weights let the chain drift away,
-        # which roughly halves the edge count).  Eager launches, 30 repetitions.
+        # which roughly halves the edge count).  Graph-replayed, timed with HIP events on the launch stream.
         with torch.cuda.stream(stream):
             rng = np.random.Generator(np.random.PCG64(12345 + rank))
-            nl_tot = int(pb.num_nodes_phar.sum())
             pm_np = np.repeat(np.arange(B), pb.num_nodes_phar)
             com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(B)])
             v = rng.normal(size=(nl_tot, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
@@ -181,56 +266,58 @@ def main():
             xh_in = torch.from_numpy(np.concatenate([xin, rng.normal(size=(nl_tot, cfg.phar_nf)).astype(np.float32)], 1)).to(dev)
             xq_in = torch.from_numpy(np.concatenate([pb.x, pb.one_hot / cfg.norm_values[1]], 1).astype(np.float32)).to(dev)
             t_in = torch.full((B,), 0.5, device=dev)
-            for _ in range(3):
-                h.dynamics_forward(xh_in, xq_in, t_in, want_pocket=False)
-            torch.cuda.synchronize(dev)
             h.reset_counters()
-            t1 = time.perf_counter()
-            reps = 30
-            for _ in range(reps):
-                h.dynamics_forward(xh_in, xq_in, t_in, want_pocket=False)
-            torch.cuda.synchronize(dev)
-            dt_micro = (time.perf_counter() - t1) / reps
+            ms_eval = h.time_evaluation(xh_in, xq_in, t_in, graph_len=10, replays=20 if rep == 'CA' else 3)
             mc = h.counters()
-        steady = {'us_per_evaluation': 1e6 * dt_micro, 'pocket_evaluations_per_s': B / dt_micro,
-                  'edges_per_pocket': mc['edges'] / max(mc['evaluations'], 1) / B,
-                  'coord_edges_per_pocket': mc['edges_phar'] / max(mc['evaluations'], 1) / B,
-                  'alg_tflops': (L * (2.0 * (H * H + H) * (mc['edges'] + mc['edges_phar']) + 917504.0 * (H / 256.0) ** 2 * mc['nodes'])
-                                 + 33792.0 * (H / 256.0) * mc['nodes']) / max(mc['evaluations'], 1) / dt_micro / 1e12}
+        dt_micro = ms_eval * 1e-3
+        m_ev = max(mc['evaluations'], 1)
+        steady = {'us_per_evaluation': 1e3 * ms_eval, 'pocket_evaluations_per_s': B / dt_micro,
+                  'edges_per_pocket': mc['edges'] / m_ev / B, 'coord_edges_per_pocket': mc['edges_phar'] / m_ev / B,
+                  'edges_per_s': mc['edges'] / m_ev / dt_micro,
+                  'alg_tflops': whole_job_flop(H, L, dyn, mc['edges'], mc['edges_phar'], mc['nodes'], m_ev * nl_tot) / m_ev / dt_micro / 1e12,
+                  'timing': 'hipGraph of 10 evaluations replayed, HIP events on the launch stream'}
         ev = max(pc['evaluations'], 1)
         units = {'edge_msg': pc['edges'] / ev, 'node': pc['nodes'] / ev, 'edge_coord': pc['edges_phar'] / ev}
-        flop_unit = {'edge_msg': 2.0 * (H * H + H), 'node': 14.0 * H * H, 'edge_coord': 2.0 * (H * H + H)}
+        flop_launch = {'edge_msg': 2.0 * (H * H + H) * units['edge_msg'],
+                       'node': node_flop_per_launch(H, L, pc['nodes'] / ev, nl_tot),
+                       'edge_coord': 2.0 * (H * H + H) * units['edge_coord']}
         kname = {'edge_msg': 'k_edge_msg (GCL.edge_model + attention + segment sum)',
                  'node': 'k_node (GCL.node_model + P/Q projections for the coord MLP and the next block)',
                  'edge_coord': 'k_edge_coord (EquivariantUpdate.coord_model)'}
         per_kernel = {}
         for k, (ms_k, n_k) in prof.items():
             avg = ms_k / max(n_k, 1)
-            fl = flop_unit[k] * units[k]
-            per_kernel[k] = {'total_ms': ms_k, 'launches': n_k, 'avg_launch_ms': avg, 'flop_per_launch': fl,
-                             'tflops': (fl / (avg * 1e-3) / 1e12) if avg > 0 else 0.0}
+            per_kernel[k] = {'total_ms': ms_k, 'launches': n_k, 'avg_launch_ms': avg, 'flop_per_launch': flop_launch[k],
+                             'tflops': (flop_launch[k] / (avg * 1e-3) / 1e12) if avg > 0 else 0.0}
         dom = max(per_kernel, key=lambda k: per_kernel[k]['total_ms'])
         achieved = per_kernel[dom]['tflops']
         avg_ms, launches, flop_per_launch = per_kernel[dom]['avg_launch_ms'], per_kernel[dom]['launches'], per_kernel[dom]['flop_per_launch']
-        # whole-job algorithmic FLOP (SURVEY 8d F_alg) for the timed region
-        f_alg = L * (2.0 * (H * H + H) * (cnt['edges'] + cnt['edges_phar']) + 917504.0 * (H / 256.0) ** 2 * cnt['nodes']) \
-            + 33792.0 * (H / 256.0) * cnt['nodes']
-        traffic = None
+        # whole-job algorithmic FLOP for the timed region
+        f_alg = whole_job_flop(H, L, dyn, cnt['edges'], cnt['edges_phar'], cnt['nodes'], cnt['evaluations'] * nl_tot)
+        # HBM-side bytes per launch from the PMC passes (tools/collect_traffic.py), only when they were taken on
+        # exactly these kernel sources
+        traffic, traffic_note = None, 'no profiles/kernel_traffic.json'
         tpath = os.path.join(ROOT, 'profiles', 'kernel_traffic.json')
+        sha = kernel_source_sha()
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get('workload_batch') == B and tj.get('representation') == rep:
-                    traffic = tj.get('hbm_bytes_per_launch', {}).get(dom) if isinstance(tj.get('hbm_bytes_per_launch'), dict) else None
-            except Exception:
-                traffic = None
+                if tj.get('kernel_source_sha') != sha:
+                    traffic_note = f"stale: measured on kernel sources {tj.get('kernel_source_sha')}, these are {sha}"
+                elif tj.get('workload_batch') != B or tj.get('representation') != rep:
+                    traffic_note = 'measured on another workload'
+                else:
+                    traffic = tj.get('hbm_bytes_per_launch', {}).get(dom)
+                    traffic_note = tj.get('source')
+            except Exception as e:          # noqa: BLE001
+                traffic_note = f'unreadable: {e}'
         result = {
             'metric': 'denoising steps/sec', 'value': value, 'unit': 'pocket-steps/s',
             'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
-                'workload': f'BASELINE.json configs[1]: batch {B} CrossDocked-shaped {rep} pockets per GPU '
+                'workload': f'BASELINE.json configs[{1 if rep == "CA" else 4}]: batch {B} CrossDocked-shaped {rep} pockets per GPU '
                             f'(Np={int(pb.size[0])}, Nl={args.n_phar}), {T}-step DDPM sampling '
                             f'(sample_given_pocket: {evals_per_chain} network evaluations per pocket), fp32; '
                             f'one bench step = one such chain',
@@ -241,27 +328,55 @@ def main():
                 'us_per_denoising_step': 1e6 * elapsed / (args.steps * evals_per_chain),
                 'edges_per_pocket_eval': cnt['edges'] / max(cnt['evaluations'], 1) / B,
                 'phar_edges_per_pocket_eval': cnt['edges_phar'] / max(cnt['evaluations'], 1) / B,
+                'edges_per_s': n_gpus * cnt['edges'] / elapsed,
                 'whole_step_alg_tflops': f_alg / elapsed / 1e12,
                 'chain_status': st,
                 'kernel_ms_one_evaluation': kt,
                 'steady_state_evaluation': steady,
+                'kernel_source_sha': sha,
             },
             'roofline': {
                 'bound': 'mfma', 'kernel': kname[dom],
                 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_note': traffic_note,
                 'flop_per_launch': flop_per_launch, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
                 'units_per_launch': units[dom],
                 'whole_job_frac': f_alg / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 # the north-star also asks for the HBM view: PMC bytes per launch / launch time / 8 TB/s (not the binding roofline)
                 'hbm_frac_from_pmc': (traffic / (avg_ms * 1e-3) / (PEAK_HBM_TBS * 1e12)) if traffic else None,
-                'per_kernel': {k: {kk: v[kk] for kk in ('total_ms', 'avg_launch_ms', 'tflops')} | {'frac': v['tflops'] / PEAK_FP32_MFMA_TFLOPS}
+                'per_kernel': {k: {kk: v[kk] for kk in ('total_ms', 'avg_launch_ms', 'tflops', 'flop_per_launch')} | {'frac': v['tflops'] / PEAK_FP32_MFMA_TFLOPS}
                                for k, v in per_kernel.items()},
             },
         }
+        # ---- the north-star shape on the same line: 256 pockets on one GPU, one chain of the same length
+        if n_gpus == 1 and args.north_star_batch and args.north_star_batch != B and rep == 'CA':
+            Bn = args.north_star_batch
+            pbn = make_pockets(Bn, rep, n_phar=args.n_phar)
+            with torch.cuda.stream(stream):
+                h.set_layout(pbn.num_nodes_phar, pbn.size)
+                pxn, pohn = torch.from_numpy(pbn.x).to(dev), torch.from_numpy(pbn.one_hot).to(dev)
+                h.sample_chain(pxn, pohn, min(T, 64), noise=None, seed=5, pocket_ids=pbn.pocket_index, use_graph=use_graph)   # warm
+                h.sample_chain(pxn, pohn, T, noise=None, seed=5, pocket_ids=pbn.pocket_index, use_graph=use_graph)            # captures the T-step graph
+                torch.cuda.synchronize(dev)
+                h.reset_counters()
+                t1 = time.perf_counter()
+                h.sample_chain(pxn, pohn, T, noise=None, seed=6, pocket_ids=pbn.pocket_index, use_graph=use_graph)
+                torch.cuda.synchronize(dev)
+                dtn = time.perf_counter() - t1
+                cn = h.counters()
+            result['config']['north_star_shape'] = {
+                'pockets': Bn, 'value': Bn * evals_per_chain / dtn, 'unit': 'pocket-steps/s',
+                'us_per_denoising_step': 1e6 * dtn / evals_per_chain,
+                'whole_job_frac': whole_job_flop(H, L, dyn, cn['edges'], cn['edges_phar'], cn['nodes'],
+                                                 cn['evaluations'] * int(pbn.num_nodes_phar.sum())) / dtn / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                'edges_per_s': cn['edges'] / dtn}
         if not args.no_cpu_baseline and n_gpus == 1:      # timed on rank 0 at N=1 only
             result['cpu_baseline'] = cpu_baseline(cfg, sd, B, rep, args.n_phar, args.cpu_seconds)
-            result['config']['gpu_over_cpu'] = value / result['cpu_baseline']['value']
+            cpu_v = result['cpu_baseline']['value']
+            result['config']['gpu_over_cpu'] = value / cpu_v
+            result['config']['gpu_over_cpu_same_geometry'] = steady['pocket_evaluations_per_s'] / cpu_v
+            if 'north_star_shape' in result['config']:
+                result['config']['north_star_shape']['gpu_over_cpu'] = result['config']['north_star_shape']['value'] / cpu_v
         else:
             result['cpu_baseline'] = None
     if dist is not None:

@@ -18,6 +18,7 @@ void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* 
                         const float* t_arr, const float4* coef, ChainState* chain, float* eps_phar,
                         float* eps_pocket, hipStream_t s, hipEvent_t* ev);
 void cmdgen_launch_nan_fix(const EvalLaunch& a, float* eps_phar, hipStream_t s);
+void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s);
 void cmdgen_launch_edge_msg_only(const EvalLaunch& a, int layer, hipStream_t s);
 void cmdgen_launch_chain_init(const Layout& lay, const Dims& d, const ChainBuf& c, const float* px,
                               const float* poh, hipStream_t s);
@@ -245,6 +246,11 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
 // ---------------------------------------------------------------------------------
 // layout
 // ---------------------------------------------------------------------------------
+// dynamic LDS of k_edge_count / k_edge_write: float4 position + two ints per node (kernels_egnn.hip)
+static inline size_t edge_lds_bytes(int max_n) { return (size_t)max_n * (sizeof(float4) + 2 * sizeof(int)); }
+static const size_t kEdgeLdsMax = 156 * 1024;      // 160 KiB per CU minus k_edge_write's small static arrays
+void cmdgen_edge_kernels_allow_lds(size_t bytes);  // kernels_egnn.hip: hipFuncSetAttribute above the 64 KiB default
+
 extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t* nph, const int64_t* npk) {
     if (!h || batch < 1 || !nph || !npk) return fail(h, CMDGEN_EINVAL, "bad layout arguments");
     if (h->have_layout && (int64_t)h->cur_nphar.size() == batch &&
@@ -266,14 +272,20 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
     }
     const int64_t N = Nl + Np;
     if (N < 1 || ecap > (int64_t)2000000000) return fail(h, CMDGEN_EINVAL, "batch too large for int32 edge indexing (dense bound %lld)", (long long)ecap);
-    if ((size_t)max_n * 20 > 150 * 1024) return fail(h, CMDGEN_EINVAL, "a sample has %d nodes; the per-sample neighbour search keeps positions in LDS (max ~7600)", max_n);
+    if (edge_lds_bytes(max_n) > kEdgeLdsMax)
+        return fail(h, CMDGEN_EINVAL, "a sample has %d nodes; the per-sample neighbour search keeps positions and offsets in LDS (%d B per node, at most %d nodes)",
+                    max_n, 24, (int)(kEdgeLdsMax / 24));
     std::vector<int> ns(N);
     for (int b = 0; b < B; ++b) {
         for (int i = 0; i < vph[b]; ++i) ns[bph[b] + i] = b;
         for (int i = 0; i < vpk[b]; ++i) ns[Nl + bpk[b] + i] = b;
     }
-    // graphs bake the layout into their kernel arguments; chain buffers are sized by it
+    // graphs bake the layout into their kernel arguments; chain buffers are sized by it.  Kernels of the previous
+    // layout may still be reading the index arrays rewritten below: wait for the streams this handle has been
+    // given (ordering contract in include/cmdgen_hip.h; torch's side streams are non-blocking, so the null-stream
+    // copies below are not ordered against them by themselves).
     if (h->own_stream) hipStreamSynchronize(h->own_stream);
+    if (h->have_layout) hipStreamSynchronize(h->last_stream);
     if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
     if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
     int rc; void* p;
@@ -314,6 +326,7 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
         free_pool(h->chain_allocs); h->chain_K = -1;
         free_pool(h->joint_allocs); h->joint_steps = -1; h->joint_key.clear();
     }
+    if (edge_lds_bytes(max_n) > 64 * 1024) cmdgen_edge_kernels_allow_lds(edge_lds_bytes(max_n));
     L.B = B; L.Nl = (int)Nl; L.Np = (int)Np; L.N = (int)N; L.max_n = max_n;
     L.Nm = d.joint ? (int)N : (int)Nl;
     // (plain hipMemcpy: ordered after all earlier work of the blocking streams that may still read the old arrays)
@@ -373,6 +386,20 @@ int check_ready(cmdgen_handle* h) {
     return 0;
 }
 
+// Entry of every call that queues evaluation work: readiness, device, the stream for cmdgen_set_layout's ordering
+// contract, and the workspace invariant "agg is zero between blocks" after a debug prefix run.
+int begin_work(cmdgen_handle* h, hipStream_t s) {
+    if (!h) return CMDGEN_EINVAL;
+    if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
+    hipSetDevice(h->device);
+    h->last_stream = s;
+    if (h->agg_dirty) {
+        HIPCHK(h, hipMemsetAsync(h->work.agg, 0, (size_t)h->lay.N * h->dims.H * sizeof(float), s));
+        h->agg_dirty = false;
+    }
+    return 0;
+}
+
 EvalLaunch make_launch(cmdgen_handle* h) {
     EvalLaunch a; a.lay = h->lay; a.w = h->work; a.d = h->dims; a.sw = h->small; a.layers = h->layers.data();
     a.edge_grid = h->edge_grid; a.coord_grid = h->coord_grid;
@@ -389,12 +416,72 @@ extern "C" int cmdgen_dynamics_forward(cmdgen_handle* h, const float* xh_phar, c
     int rc = check_ready(h); if (rc) return rc;
     if (!xh_phar || !xh_pocket || !t || !eps_phar) return fail(h, CMDGEN_EINVAL, "null device pointer");
     if (h->dims.joint && !eps_pocket) return fail(h, CMDGEN_EINVAL, "joint mode (update_pocket_coords) needs eps_pocket: the pocket velocity is part of the output");
-    hipSetDevice(h->device);
     hipStream_t s = (hipStream_t)stream;
+    rc = begin_work(h, s); if (rc) return rc;
     EvalLaunch a = make_launch(h);
     cmdgen_launch_eval(a, xh_phar, xh_pocket, t, nullptr, nullptr, eps_phar, eps_pocket, s, nullptr);
     if (!h->dims.joint) cmdgen_launch_nan_fix(a, eps_phar, s);     // joint: k_vel_com applied the reset already
     HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_debug_eval_prefix(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket, const float* t,
+                                        int32_t block, int32_t stage, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!xh_phar || !xh_pocket || !t) return fail(h, CMDGEN_EINVAL, "null device pointer");
+    if (block < 0 || block >= h->dims.L || stage < 1 || stage > 3) return fail(h, CMDGEN_EINVAL, "block in [0, n_layers), stage in 1..3");
+    hipStream_t s = (hipStream_t)stream;
+    rc = begin_work(h, s); if (rc) return rc;
+    EvalLaunch a = make_launch(h);
+    a.stop_block = block; a.stop_stage = stage;
+    cmdgen_launch_eval(a, xh_phar, xh_pocket, t, nullptr, nullptr, h->work.eps_tmp, nullptr, s, nullptr);
+    h->agg_dirty = true;                               // stage 1 leaves the segment sums in agg
+    HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_radius_graph(cmdgen_handle* h, const float* x, const int64_t* counts_host, int64_t batch,
+                                   int32_t* row_dev, int32_t* col_dev, int64_t cap, int64_t* n_edges, cmdgen_stream stream) {
+    if (!h || !x || !counts_host || batch < 1 || !row_dev || !col_dev || !n_edges) return fail(h, CMDGEN_EINVAL, "bad radius-graph arguments");
+    hipSetDevice(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)batch;
+    std::vector<int> cnt(B), base(B), zeros(B, 0);
+    int64_t N = 0, need = 0; int max_n = 0;
+    for (int b = 0; b < B; ++b) {
+        if (counts_host[b] < 0) return fail(h, CMDGEN_EINVAL, "negative node count");
+        cnt[b] = (int)counts_host[b]; base[b] = (int)N; N += counts_host[b]; need += counts_host[b] * counts_host[b];
+        if (cnt[b] > max_n) max_n = cnt[b];
+    }
+    if (N < 1 || need > (int64_t)2000000000) return fail(h, CMDGEN_EINVAL, "bad total node count / dense bound");
+    if (cap < need) return fail(h, CMDGEN_EINVAL, "edge capacity %lld below the dense bound %lld", (long long)cap, (long long)need);
+    if (edge_lds_bytes(max_n) > kEdgeLdsMax) return fail(h, CMDGEN_EINVAL, "a sample has %d nodes (at most %d)", max_n, (int)(kEdgeLdsMax / 24));
+    if (edge_lds_bytes(max_n) > 64 * 1024) cmdgen_edge_kernels_allow_lds(edge_lds_bytes(max_n));
+    // every node is presented to the radius-graph kernels as a (non-moving) pocket node of a scratch layout
+    std::vector<void*> pool; void* p; int rc = 0;
+    Layout L{}; Work w{};
+    Dims d = h->dims; d.R = 0; d.joint = 0; d.L = 0;                         // rows of x are [3] wide
+#define TMP(dst, type, count) do { if (!rc) { rc = dev_alloc(h, pool, &p, (size_t)(count) * sizeof(type), true); dst = (type*)p; } } while (0)
+    int *d_np, *d_zero, *d_base;
+    TMP(d_np, int, B); TMP(d_zero, int, B); TMP(d_base, int, B);
+    TMP(w.X0, float4, 1); TMP(w.ACC, float4, 1); TMP(w.XP, float4, N); TMP(w.degL, int, N);
+    TMP(w.pocketE, int, B); TMP(w.pocketEph, int, B); TMP(w.pocketEns, int, B); TMP(w.pocketEnsQ, int, B);
+    TMP(w.ed0, float, need); TMP(w.totals, int, 4); TMP(w.counters, unsigned long long, 8); TMP(w.nan_flag, int, 4);
+#undef TMP
+    if (rc) { free_pool(pool); return rc; }
+    w.erow = row_dev; w.ecol = col_dev;
+    hipMemcpy(d_np, cnt.data(), B * sizeof(int), hipMemcpyHostToDevice);
+    hipMemcpy(d_base, base.data(), B * sizeof(int), hipMemcpyHostToDevice);
+    L.B = B; L.Nl = 0; L.Np = (int)N; L.N = (int)N; L.Nm = 0; L.max_n = max_n;
+    L.num_phar = d_zero; L.num_pocket = d_np; L.phar_base = d_zero; L.pocket_base = d_base;
+    EvalLaunch a{}; a.lay = L; a.w = w; a.d = d;
+    cmdgen_launch_edges(a, x /* no phar rows are read */, x, s);
+    hipError_t e = hipStreamSynchronize(s);
+    int tot[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(tot, w.totals, sizeof tot, hipMemcpyDeviceToHost);
+    free_pool(pool);
+    if (e != hipSuccess) return fail(h, CMDGEN_EHIP, "radius graph failed: %s", hipGetErrorString(e));
+    *n_edges = tot[0];
     return CMDGEN_OK;
 }
 
@@ -525,6 +612,8 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
         s = h->own_stream;
     }
     rc = prepare_chain(h, K, z_steps_out != nullptr); if (rc) return rc;
+    rc = begin_work(h, s); if (rc) return rc;
+    h->last_stream = caller;
     const Dims& d = h->dims;
     // global pocket ids for the Philox key
     {
@@ -738,6 +827,8 @@ extern "C" int cmdgen_joint_chain(cmdgen_handle* h, const float* phar_x, const f
         s = h->own_stream;
     }
     rc = prepare_joint(h, timesteps, resamplings, jump_length, inpaint); if (rc) return rc;
+    rc = begin_work(h, s); if (rc) return rc;
+    h->last_stream = caller;
     const int n_steps = h->joint_steps;
     if (noise) {
         int64_t need = 0;
@@ -851,8 +942,8 @@ extern "C" int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar,
     int rc = check_ready(h); if (rc) return rc;
     if (!out) return fail(h, CMDGEN_EINVAL, "null output");
     if (h->dims.joint) return fail(h, CMDGEN_ESTATE, "cmdgen_profile_evaluation supports the conditional model only");
-    hipSetDevice(h->device);
     hipStream_t s = (hipStream_t)stream;
+    rc = begin_work(h, s); if (rc) return rc;
     const int L = h->dims.L;
     const int nev = 2 * (3 + 3 * L);
     std::vector<hipEvent_t> ev(nev);
@@ -871,6 +962,45 @@ extern "C" int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar,
     out->readout_ms = ms(i++);
     out->edge_msg_launches = L; out->node_launches = L; out->edge_coord_launches = L;
     for (auto& e : ev) hipEventDestroy(e);
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_time_evaluation(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket, const float* t,
+                                      float* eps_phar, int32_t graph_len, int32_t replays, float* mean_ms, cmdgen_stream stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!xh_phar || !xh_pocket || !t || !eps_phar || !mean_ms || graph_len < 1 || replays < 1) return fail(h, CMDGEN_EINVAL, "bad arguments");
+    if (h->dims.joint) return fail(h, CMDGEN_ESTATE, "cmdgen_time_evaluation supports the conditional model only");
+    hipStream_t caller = (hipStream_t)stream, s = caller;
+    if (caller == nullptr) {                             // the legacy default stream cannot be captured
+        if (!h->own_stream) {
+            HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+        }
+        HIPCHK(h, hipDeviceSynchronize());
+        s = h->own_stream;
+    }
+    rc = begin_work(h, s); if (rc) return rc;
+    EvalLaunch a = make_launch(h);
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < graph_len; ++i) {
+        cmdgen_launch_eval(a, xh_phar, xh_pocket, t, nullptr, nullptr, eps_phar, nullptr, s, nullptr);
+        cmdgen_launch_nan_fix(a, eps_phar, s);
+    }
+    HIPCHK(h, hipStreamEndCapture(s, &g));
+    HIPCHK(h, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipGraphLaunch(ge, s));                    // warm
+    HIPCHK(h, hipEventRecord(e0, s));
+    for (int i = 0; i < replays; ++i) HIPCHK(h, hipGraphLaunch(ge, s));
+    HIPCHK(h, hipEventRecord(e1, s));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    *mean_ms = ms / ((float)replays * (float)graph_len);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipGraphExecDestroy(ge);
     return CMDGEN_OK;
 }
 

@@ -159,6 +159,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int node_mt, edge_mt, coord_mt;   // rows per tile (64, 32 or 16) chosen per launch from the row counts
     std::vector<hipEvent_t>* prof_events;  // when non-null: [3] vectors, event pairs around every msg / node / coord launch
     int ablate;                 // timing-only builds of the edge kernel (cmdgen_time_edge_kernel); 0 in production
+    int stop_block = -1, stop_stage = 0;   // cmdgen_debug_eval_prefix: stop after stage 1..3 of this block (-1: run everything)
 };
 
 // ---------------------------------------------------------------------------------

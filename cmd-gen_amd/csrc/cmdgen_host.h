@@ -72,6 +72,8 @@ struct cmdgen_handle {
     unsigned long long jg_seed = 0; int jg_steps = 0;
     TrainState* train = nullptr;           // training workspace (cmdgen_train.hip)
     bool train_bf16 = false;               // GEMM operand precision of the training step (cmdgen_train_set_precision)
+    bool agg_dirty = false;                // cmdgen_debug_eval_prefix left segment sums in work.agg
+    hipStream_t last_stream = nullptr;     // stream most recently handed to this handle (ordering contract of cmdgen_set_layout)
     bool kernel_profiling = false;
     std::vector<hipEvent_t> prof_events[3];
 };
@@ -97,4 +99,5 @@ inline void free_pool(std::vector<void*>& pool) { for (void* p : pool) hipFree(p
 
 
 int check_ready(cmdgen_handle* h);
+int begin_work(cmdgen_handle* h, hipStream_t s);   // check_ready + device + workspace invariants; remembers the stream
 EvalLaunch make_launch(cmdgen_handle* h);

@@ -216,6 +216,7 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     int rc = ensure_state(h); if (rc) return rc;
     TrainState* t = h->train;
     hipStream_t s = (hipStream_t)stream;
+    h->last_stream = s;
     const Dims& d = h->dims;
     const int N = h->lay.N, Nl = h->lay.Nl, Np = h->lay.Np, H = d.H, L = d.L, P = d.P, R = d.R, J = d.J;
     const int ldp = 3 + P, ldq = 3 + R, ld1 = 2 * H + 2;
@@ -308,6 +309,7 @@ extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, 
     TrainState* t = h->train;
     g_bf16 = t->bf16;
     hipStream_t s = (hipStream_t)stream;
+    h->last_stream = s;
     const Dims& d = h->dims;
     const float* theta = t->theta;
     const int N = h->lay.N, Nl = h->lay.Nl, Np = h->lay.Np, H = d.H, L = d.L, P = d.P, R = d.R, J = d.J;
@@ -448,6 +450,7 @@ extern "C" int cmdgen_grad_sqnorm(cmdgen_handle* h, const float* grad, int64_t n
     hipSetDevice(h->device);
     int rc = ensure_state(h); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    h->last_stream = s;
     HIPCHK(h, hipMemsetAsync(h->train->d_scalar, 0, sizeof(float), s));
     tr_sqsum((size_t)n, grad, h->train->d_scalar, s);
     HIPCHK(h, hipMemcpyAsync(out_host, h->train->d_scalar, sizeof(float), hipMemcpyDeviceToHost, s));

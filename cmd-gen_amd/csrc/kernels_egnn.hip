@@ -865,14 +865,18 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     MT_DISPATCH(a.node_mt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
     REC();
     for (int l = 0; l < a.d.L; ++l) {
+        const int stop = a.stop_block == l ? a.stop_stage : 0;        // parity aid: leave intermediates in the workspace
         REC();
         PROF(0); MT_DISPATCH(a.edge_mt, launch_msg, a, l, s); PROF(0);
         REC(); REC();
+        if (stop == 1) return;
         PROF(1); MT_DISPATCH(a.node_mt, launch_node, a, l, s); PROF(1);
         REC(); REC();
+        if (stop == 2) return;
         PROF(2);
         MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF(2);
         REC();
+        if (stop == 3) return;
     }
     REC();
     const int nn = eps_pocket ? N : a.lay.Nl;
@@ -900,6 +904,12 @@ void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float*
     const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + 2 * sizeof(int));
     hipLaunchKernelGGL(k_edge_count, dim3(a.lay.B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket, (ChainState*)nullptr);
     hipLaunchKernelGGL(k_edge_write, dim3(a.lay.B), dim3(256), shm, s, a.lay, a.w, a.d);
+}
+
+// dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel (samples of more than ~2700 nodes)
+void cmdgen_edge_kernels_allow_lds(size_t bytes) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 void cmdgen_launch_nan_fix(const EvalLaunch& a, float* eps_phar, hipStream_t s) {

@@ -98,8 +98,26 @@ class EGNNDynamics(nn.Module):
         return h.dynamics_forward(xp, xr, t.detach(), want_pocket=True)
 
     def get_edges(self, batch_mask=None, x=None):
-        """Radius graph of the last evaluation as [2, E] int64 (row-major sorted, self loops kept;
-        dynamics.py:141-147).  Arguments are accepted for signature compatibility."""
-        if self._handle is None:
-            raise RuntimeError('get_edges returns the graph of the last forward(); call forward first')
-        return torch.from_numpy(self._handle.get_edges().astype(np.int64))
+        """Radius graph as [2, E] int64: pairs (i, j), self loops included, with batch_mask[i] == batch_mask[j] and
+        ||x_i - x_j|| <= edge_cutoff, sorted by (i, j) like torch.where on the adjacency (dynamics.py:141-147).
+
+        With arguments: the graph of exactly what is given (any mask, e.g. the phar-rows-first concatenation
+        forward() uses); the distance tests and the compaction run in the HIP radius-graph kernels, torch only
+        sorts indices.  Without arguments: the graph the last forward() built (kept for inspection)."""
+        if batch_mask is None and x is None:
+            if self._handle is None:
+                raise RuntimeError('get_edges() without arguments returns the graph of the last forward(); call forward first')
+            return torch.from_numpy(self._handle.get_edges().astype(np.int64))
+        h = self.hip_handle()
+        dev = next(self.parameters()).device
+        mask = batch_mask.detach().to(dev, torch.int64).reshape(-1)
+        xx = x.detach().to(dev, torch.float32)
+        n = mask.numel()
+        if n == 0:
+            return torch.zeros((2, 0), dtype=torch.int64, device=dev)
+        order = torch.sort(mask, stable=True).indices                 # samples back to back, original order inside
+        counts = torch.bincount(mask[order]).cpu().numpy()
+        row, col = h.radius_graph(xx[order].contiguous(), counts[counts > 0])
+        row, col = order[row.long()], order[col.long()]               # back to the caller's numbering
+        key = torch.sort(row * n + col).indices                       # torch.where order: by (row, col)
+        return torch.stack([row[key], col[key]])

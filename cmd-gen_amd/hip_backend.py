@@ -51,6 +51,8 @@ SYMBOLS = [
     ('cmdgen_dynamics_forward', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _vp]),
     ('cmdgen_get_edges', C.c_int, [_vp, _vp, _vp, C.c_int64, _i64p, _vp]),
     ('cmdgen_debug_read', C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t, _vp]),
+    ('cmdgen_debug_eval_prefix', C.c_int, [_vp, _fp, _fp, _fp, C.c_int32, C.c_int32, _vp]),
+    ('cmdgen_radius_graph', C.c_int, [_vp, _fp, _i64p, C.c_int64, _vp, _vp, C.c_int64, _i64p, _vp]),
     ('cmdgen_debug_noise', C.c_int, [_vp, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _fp, _vp]),
     ('cmdgen_sample_chain', C.c_int, [_vp, _fp, _fp, C.c_int32, _fp, C.c_uint64, _i64p, _fp, _fp, _fp, _fp,
                                       C.c_int32, _vp]),
@@ -72,6 +74,7 @@ SYMBOLS = [
     ('cmdgen_get_counters', C.c_int, [_vp, C.POINTER(Counters), _vp]),
     ('cmdgen_reset_counters', C.c_int, [_vp, _vp]),
     ('cmdgen_profile_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.POINTER(KernelTimes), _vp]),
+    ('cmdgen_time_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
     ('cmdgen_time_edge_kernel', C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
     ('cmdgen_set_kernel_profiling', C.c_int, [_vp, C.c_int32]),
     ('cmdgen_get_kernel_profile', C.c_int, [_vp, C.POINTER(C.c_float), _i64p, _vp]),
@@ -220,6 +223,30 @@ class Handle:
         self._check(self.lib.cmdgen_get_edges(self.h, row.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
                                               cap, C.byref(n), self._stream()), 'cmdgen_get_edges')
         return np.stack([row[:n.value], col[:n.value]])
+
+    def radius_graph(self, x, counts):
+        """EGNNDynamics.get_edges for arbitrary coordinates: x device [sum counts, 3] (samples back to back),
+        counts per sample -> int32 device tensors (row, col) sorted by (row, col)."""
+        import torch
+        cnt = np.ascontiguousarray(np.asarray(counts, dtype=np.int64))
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (int(cnt.sum()), 3)
+        cap = int((cnt * cnt).sum())
+        row = torch.empty(max(cap, 1), dtype=torch.int32, device=x.device)
+        col = torch.empty(max(cap, 1), dtype=torch.int32, device=x.device)
+        n = C.c_int64(0)
+        self._check(self.lib.cmdgen_radius_graph(self.h, _ptr(x), cnt.ctypes.data_as(_i64p), len(cnt), _ptr(row), _ptr(col),
+                                                 cap, C.byref(n), self._stream()), 'cmdgen_radius_graph')
+        return row[:n.value], col[:n.value]
+
+    def debug_eval_prefix(self, xh_phar, xh_pocket, t, block: int, stage: int):
+        """Run one evaluation up to (block, stage) - stage 1 after the edge-message kernel, 2 after the node kernel,
+        3 after the coordinate kernel - and leave the intermediates for debug_read (parity aid)."""
+        import torch
+        t = t.reshape(-1).to(torch.float32).contiguous()
+        if t.numel() == 1 and self.batch > 1:
+            t = t.expand(self.batch).contiguous()
+        self._check(self.lib.cmdgen_debug_eval_prefix(self.h, _ptr(xh_phar), _ptr(xh_pocket), _ptr(t), int(block), int(stage),
+                                                      self._stream()), 'cmdgen_debug_eval_prefix')
 
     def debug_read(self, what: str, n: int):
         out = np.empty(n, dtype=np.float32)
@@ -386,6 +413,16 @@ class Handle:
         self._check(self.lib.cmdgen_profile_evaluation(self.h, _ptr(xh_phar), _ptr(xh_pocket), _ptr(t), _ptr(eps),
                                                        C.byref(kt), self._stream()), 'cmdgen_profile_evaluation')
         return {n: getattr(kt, n) for n, _ in KernelTimes._fields_}
+
+    def time_evaluation(self, xh_phar, xh_pocket, t, graph_len: int = 10, replays: int = 10) -> float:
+        """ms per evaluation, graph-replayed and timed with HIP events on the launch stream."""
+        import torch
+        t = t.reshape(-1).to(torch.float32).contiguous()
+        eps = torch.empty_like(xh_phar)
+        ms = C.c_float(0)
+        self._check(self.lib.cmdgen_time_evaluation(self.h, _ptr(xh_phar), _ptr(xh_pocket), _ptr(t), _ptr(eps), int(graph_len),
+                                                    int(replays), C.byref(ms), self._stream()), 'cmdgen_time_evaluation')
+        return ms.value
 
     def time_edge_kernel(self, layer: int, reps: int) -> float:
         ms = C.c_float(0)

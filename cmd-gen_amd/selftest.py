@@ -14,10 +14,15 @@ def smoke_check(verbose=True):
     from .synthetic import ModelConfig, make_state_dict, make_pockets
     from . import hip_backend
     assert torch.cuda.is_available(), 'smoke() needs an MI355X'
-    cfg = ModelConfig()                 # the shipped C-alpha model: H=256, L=5
-    sd = make_state_dict(cfg, seed=0)
+    # The shipped C-alpha network (H=256, L=5) with a noise schedule that keeps |x| at O(10 A) for the whole chain
+    # (noise_precision 0.05: 1/alpha_T = 4.5; norm_values [1, 0.5] so that check_issues_norm_values,
+    # en_diffusion.py:63-77, accepts it): there the north-star's "coords within 1e-4 RMS" is meaningful as an ABSOLUTE
+    # bound.  (With the shipped precision 1e-5 random-init weights inflate x by 1/alpha_T = 316 to ~800 A, where one
+    # fp32 ulp is already 6e-5 A.)  Trained-like coordinate head so that eps_x really steers the chain.
+    cfg = ModelConfig(noise_precision=0.05, norm_values=(1.0, 0.5))
+    sd = make_state_dict(cfg, seed=0, coord_gain=1.0)
     pb = make_pockets(4, 'CA', n_phar=8)
-    K = 4
+    K = 20
     dev = torch.device('cuda:0')
     h = hip_backend.Handle(cfg.as_dict(), 0)
     h.load_state_dict(sd)
@@ -38,11 +43,10 @@ def smoke_check(verbose=True):
     got = xh_phar.cpu().numpy()
     want = ref_phar.numpy()
     rms = float(np.sqrt(np.mean((got[:, :3] - want[:, :3]) ** 2)))
-    scale = max(1.0, float(np.abs(want[:, :3]).max()))
     if verbose:
-        print(f'smoke: coords RMS vs oracle {rms:.3e} (scale {scale:.1f}), types equal: '
-              f'{bool(np.array_equal(got[:, 3:], want[:, 3:]))}, status {st}')
-    assert rms < 1e-4 * scale, rms
+        print(f'smoke: {K}-step chain, coords RMS vs oracle {rms:.3e} A ABSOLUTE (max |x| {float(np.abs(want[:, :3]).max()):.1f} A), '
+              f'types equal: {bool(np.array_equal(got[:, 3:], want[:, 3:]))}, status {st}')
+    assert rms < 1e-4, rms
     assert np.array_equal(got[:, 3:], want[:, 3:])
     assert st['max_rel_com_error'] < 1e-2
     return rms

@@ -2,7 +2,7 @@
 its own nodes (edges never cross samples, dynamics.py:143), so sampling needs NO data-path
 collective.  One process per GPU takes a contiguous block of pockets; device noise is keyed
 by the GLOBAL pocket index, so results do not depend on the sharding.  The only
-torch.distributed traffic is the optional gather of finished samples to rank 0.
+torch.distributed traffic is the optional all_gather of the finished samples.
 
 The reference has no multi-GPU sampling code; its DDP gradient
 all-reduce belongs to the training row (section 8f #1).
@@ -52,21 +52,51 @@ def slice_pocket(pocket: Dict[str, torch.Tensor], num_nodes_phar, lo: int, hi: i
     return sub, torch.as_tensor(num_nodes_phar)[lo:hi]
 
 
+def pocket_cost(num_pocket, num_phar, edge_cutoff=6.0) -> np.ndarray:
+    """Relative cost of one pocket's chain: (Np + Nl) * degree, i.e. ~ its edge count.
+    The degree estimate is the one cmdgen_set_layout uses to size its grids: C-alpha pockets have ~6 neighbours
+    within 6 A, full-atom ones ~36; without a cutoff every sample is a complete graph."""
+    n = np.asarray(num_pocket, dtype=np.float64) + np.asarray(num_phar, dtype=np.float64)
+    deg = n if edge_cutoff is None else np.minimum(n, np.where(n <= 128, 6.0, 36.0))
+    return n * deg
+
+
+def _gather_rows(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """all_gather of per-rank tensors with different row counts (rows concatenated in rank order): one small
+    all_gather of the counts, one of the row-padded payload - device tensors stay on the device (RCCL over xGMI
+    with the nccl backend, gloo on CPU), nothing is pickled through the host."""
+    import torch.distributed as dist
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)])
+
+
 def sample_sharded(sample_fn: Callable, pocket: Dict[str, torch.Tensor], num_nodes_phar,
-                   rank: int, world: int, gather: bool = True, group=None, **kw):
+                   rank: int, world: int, gather: bool = True, group=None, balance: bool = True,
+                   edge_cutoff=6.0, **kw):
     """Run `sample_fn(sub_pocket, sub_num_nodes_phar, pocket_ids=global ids, **kw)` on this
     rank's block and (optionally) gather (xh_phar, xh_pocket) of all ranks in pocket order.
 
+    Blocks are contiguous and balanced by the pockets' estimated edge counts (`pocket_cost`), not by their number:
+    a ragged batch would otherwise leave ranks idle behind the one holding the big pockets.
     `sample_fn` is ConditionalDDPM.sample_given_pocket in production."""
     n = len(pocket['size'])
-    lo, hi = shard_bounds(n, world)[rank]
+    if balance:
+        cost = pocket_cost(pocket['size'].detach().cpu().numpy(), torch.as_tensor(num_nodes_phar).cpu().numpy(), edge_cutoff)
+        lo, hi = balanced_shard_bounds(cost, world)[rank]
+    else:
+        lo, hi = shard_bounds(n, world)[rank]
     sub, nph = slice_pocket(pocket, num_nodes_phar, lo, hi)
     ids = list(range(lo, hi))
     xh_phar, xh_pocket, phar_mask, pocket_mask = sample_fn(sub, nph, pocket_ids=ids, **kw)
     if not gather or world == 1:
         return xh_phar, xh_pocket, phar_mask + lo, pocket_mask + lo
-    import torch.distributed as dist
-    outs = [None] * world
-    dist.all_gather_object(outs, (xh_phar.cpu(), xh_pocket.cpu(), (phar_mask + lo).cpu(), (pocket_mask + lo).cpu()),
-                           group=group)
-    return tuple(torch.cat([o[i] for o in outs]) for i in range(4))
+    return (_gather_rows(xh_phar, world, group), _gather_rows(xh_pocket, world, group),
+            _gather_rows(phar_mask + lo, world, group), _gather_rows(pocket_mask + lo, world, group))

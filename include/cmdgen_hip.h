@@ -112,6 +112,11 @@ int cmdgen_finalize_weights(cmdgen_handle* h);
  * Sizes workspaces; cheap when the layout is unchanged. */
 int cmdgen_set_layout(cmdgen_handle* h, int64_t batch,
                       const int64_t* num_phar_host, const int64_t* num_pocket_host);
+/* Ordering contract: the call rewrites index arrays that kernels of the PREVIOUS layout read.  Before touching
+ * them it waits for the stream most recently passed to this handle (and its internal stream); work the caller
+ * queued for this handle on any OTHER stream must be complete before calling.  Limits: a sample's nodes are kept
+ * in LDS by the neighbour search (24 B per node; at most ~6500 nodes per sample), the dense edge bound
+ * sum(n_b^2) must fit int32. */
 
 /* ---- one network evaluation ------------------------------------------------------- */
 /* EGNNDynamics.forward (dynamics.py:75-139); conditional mode, or joint mode when
@@ -131,6 +136,22 @@ int cmdgen_dynamics_forward(cmdgen_handle* h, const float* xh_phar, const float*
  * Synchronises the stream.  Debug / parity aid. */
 int cmdgen_get_edges(cmdgen_handle* h, int32_t* row_host, int32_t* col_host, int64_t cap,
                      int64_t* n_edges, cmdgen_stream stream);
+
+/* EGNNDynamics.get_edges(batch_mask, x) (dynamics.py:141-147) for ARBITRARY coordinates, independent of the
+ * handle's batch layout: x dev [sum counts, 3] holds `batch` samples back to back (ascending mask), counts_host
+ * their sizes.  Writes the edges (same sample, ||x_i - x_j|| <= edge_cutoff, self loops kept) sorted by (row, col)
+ * to the DEVICE arrays row_dev / col_dev (int32, capacity `cap` >= sum counts^2, else CMDGEN_EINVAL) and the
+ * count to *n_edges.  Synchronises the stream. */
+int cmdgen_radius_graph(cmdgen_handle* h, const float* x, const int64_t* counts_host, int64_t batch,
+                        int32_t* row_dev, int32_t* col_dev, int64_t cap, int64_t* n_edges, cmdgen_stream stream);
+
+/* Parity aid: run one evaluation only up to a point, so that intermediates the fused kernels never keep can be
+ * read with cmdgen_debug_read: all of blocks 0..block-1, then of block `block` stage 1 = after the edge-message
+ * kernel ("agg" holds the un-normalised segment sums of e_ij, egnn_new.py:50-52), 2 = after the node kernel ("h"
+ * is the block's output, "agg" is zero again), 3 = after the coordinate kernel ("acc" row `block` holds the sums
+ * of trans, egnn_new.py:91-98).  Leaves the workspace unusable for a chain until the next full evaluation. */
+int cmdgen_debug_eval_prefix(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket, const float* t,
+                             int32_t block, int32_t stage, cmdgen_stream stream);
 
 /* Copy an internal activation of the last evaluation to host (parity aid):
  * what = "h" [N, hidden] after the last block, "x" [Nl, 4] final phar coordinates. */
@@ -273,6 +294,12 @@ int cmdgen_reset_counters(cmdgen_handle* h, cmdgen_stream stream);
 int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket,
                               const float* t, float* eps_phar, cmdgen_kernel_times* out,
                               cmdgen_stream stream);
+/* Steady-state timing of one network evaluation (bench.py's trained-geometry micro-benchmark): `graph_len`
+ * evaluations of the given inputs are captured into a hipGraph, replayed `replays` times after one warm-up replay
+ * and timed with HIP events on the launch stream.  *mean_ms = time per evaluation.  Counters advance as usual. */
+int cmdgen_time_evaluation(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket, const float* t,
+                           float* eps_phar, int32_t graph_len, int32_t replays, float* mean_ms, cmdgen_stream stream);
+
 /* Replays the edge-message kernel of block `layer` `reps` times on the state left by the
  * last evaluation and returns the mean launch duration in ms (hipEvents on `stream`). */
 int cmdgen_time_edge_kernel(cmdgen_handle* h, int32_t layer, int32_t reps, float* mean_ms,
