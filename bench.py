@@ -88,7 +88,7 @@ def self_launch(args, argv):
 def kernel_source_sha():
     """Identity of the kernel sources a PMC measurement belongs to (profiles/kernel_traffic.json is stamped with it)."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'cmd-gen_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'cmd-gen_amd', 'csrc', '*.h'))):
+    for f in sorted(glob.glob(os.path.join(ROOT, 'cmdgen_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'cmdgen_amd', 'csrc', '*.h'))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, 'rb').read())
     return h.hexdigest()[:16]

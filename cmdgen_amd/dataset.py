@@ -42,18 +42,27 @@ class ProcessedLigandPharPocketDataset(torch.utils.data.Dataset):
 
     @staticmethod
     def collate_fn(batch):
-        out = {}
-        for prop in batch[0].keys():
-            if prop == 'names':
-                out[prop] = [x[prop] for x in batch]
-            elif prop in ('num_phar_atoms', 'num_pocket_nodes'):
-                out[prop] = torch.tensor([x[prop] for x in batch])
-            elif 'mask' in prop:
-                # batch indices restart at zero; float, as the reference builds them (quirk Q13)
-                out[prop] = torch.cat([i * torch.ones(len(x[prop])) for i, x in enumerate(batch)], dim=0)
-            else:
-                out[prop] = torch.cat([x[prop] for x in batch], dim=0)
-        return out
+        """List of complexes -> one flat batch dict (the format PharPocketDDPM.get_phar_and_pocket reads): names as a
+        list, node counts as an int tensor, every per-node array concatenated, and the two masks rebuilt as the
+        complex's position in THIS batch - float valued, as the reference leaves them (quirk Q13: they are cast to
+        int64 on the device later, lightning_modules.py:177, :184)."""
+        keys = list(batch[0])
+        counts = {'phar_mask': torch.tensor([len(c['phar_mask']) for c in batch]),
+                  'pocket_mask': torch.tensor([len(c['pocket_mask']) for c in batch])}
+        position = torch.arange(len(batch), dtype=torch.float32)
+
+        def merge(key):
+            column = [c[key] for c in batch]
+            if key == 'names':
+                return column
+            if key in ('num_phar_atoms', 'num_pocket_nodes'):
+                return torch.tensor(column)
+            if key in counts:
+                return torch.repeat_interleave(position, counts[key])
+            if 'mask' in key:
+                return torch.repeat_interleave(position, torch.tensor([len(v) for v in column]))
+            return torch.cat(column, dim=0)
+        return {key: merge(key) for key in keys}
 
 
 def write_synthetic_npz(path, n_complexes=6, seed=0, representation='CA'):

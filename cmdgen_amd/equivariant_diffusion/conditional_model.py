@@ -34,9 +34,9 @@ class ConditionalDDPM(EnVariationalDiffusion):
     def sample(self, *args):
         raise NotImplementedError('Conditional model does not support sampling without given pocket.')
 
-    # ---- loss terms (conditional_model.py:20-106, :158-320).  VALUES only: the network evaluation runs in
-    # the HIP library, which has no backward pass yet, so nothing here carries gradients (training is the
-    # next scope row).  The scalar algebra around the evaluation is host torch.
+    # ---- loss terms (conditional_model.py:20-106, :158-320) as VALUES: the network evaluation runs in the HIP
+    # library and no autograd graph is built here.  Training uses training.HipTrainer: the activation-saving forward
+    # (``_net``) plus the library's own backward pass with the analytic gradient of these terms.
     def noised_representation(self, xh_phar, xh0_pocket, phar_mask, pocket_mask, gamma_t, eps=None):
         alpha_t, sigma_t = self.alpha(gamma_t, xh_phar), self.sigma(gamma_t, xh_phar)
         eps_phar = self.sample_gaussian((len(phar_mask), self.n_dims + self.phar_nf), phar_mask.device) \

@@ -133,8 +133,9 @@ class PharPocketDDPM(nn.Module):
         return phar, pocket
 
     def forward(self, data, t_int=None, eps=None, _net=None):
-        """-> (nll [B], info) as lightning_modules.py:188-239.  Loss VALUES (evaluation / monitoring): the HIP
-        evaluation has no backward pass yet, so this cannot drive an optimizer (SURVEY.md section 8f #1)."""
+        """-> (nll [B], info) as lightning_modules.py:188-239.  Loss VALUES (evaluation / monitoring) - no autograd
+        graph is built; the optimizer is driven by training.HipTrainer, which runs the HIP library's own backward
+        pass (cmdgen_train_forward / cmdgen_train_backward) with the analytic gradient of this loss."""
         phar, pocket = self.get_phar_and_pocket(data)
         delta_log_px, error_t_phar, error_t_pocket, SNR_weight, loss_0_x_phar, loss_0_x_pocket, loss_0_h, \
             neg_log_const_0, kl_prior, log_pN, t_int_, xh_phar_hat, info = \

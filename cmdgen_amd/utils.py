@@ -165,45 +165,3 @@ def get_pocket_from_ligand(pdb_model: Model, ligand_id: str, dist_cutoff: float 
         if is_aa(res.get_resname(), standard=True) and torch.cdist(xyz, lig_xyz).min() < dist_cutoff:
             out.append(res)
     return out
-
-
-# ---------------------------------------------------------------- small helpers of the reference's utils.py
-def reverse_tensor(x):
-    """Rows in reverse order (utils.py:32-33)."""
-    return x.flip(0)
-
-
-def get_grad_norm(parameters, norm_type: float = 2.0):
-    """Global norm of the ``.grad`` of ``parameters`` (utils.py:39-61): the norm of the per-tensor norms.
-    (The HIP trainer keeps one flat gradient buffer and uses ``cmdgen_grad_sqnorm`` instead.)"""
-    if isinstance(parameters, torch.Tensor):
-        parameters = [parameters]
-    grads = [p.grad.detach() for p in parameters if p.grad is not None]
-    if not grads:
-        return torch.tensor(0.)
-    dev = grads[0].device
-    return torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g, float(norm_type)).to(dev) for g in grads]),
-                                    float(norm_type))
-
-
-def write_xyz_file(coords, atom_types, filename):
-    """XYZ text: count, blank comment line, then ``<type> x y z`` with three decimals (utils.py:64-70)."""
-    assert len(coords) == len(atom_types)
-    rows = [f"{t} {float(c[0]):.3f} {float(c[1]):.3f} {float(c[2]):.3f}" for t, c in zip(atom_types, coords)]
-    with open(filename, 'w') as f:
-        f.write(f"{len(rows)}\n\n" + ''.join(r + '\n' for r in rows))
-
-
-def residues_to_atoms(x_ca, dataset_info):
-    """C-alpha nodes as carbon atoms: same coordinates, one-hot 'C' in the atom vocabulary (utils.py:87-93)."""
-    n_types = len(dataset_info['atom_encoder'])
-    one_hot = torch.zeros(*x_ca.shape[:-1], n_types, dtype=torch.long, device=x_ca.device)
-    one_hot[..., dataset_info['atom_encoder']['C']] = 1
-    return x_ca, one_hot
-
-
-def get_residue_with_resi(pdb_chain, resi):
-    """The single residue of a chain whose sequence number is ``resi`` (utils.py:96-99)."""
-    hits = [r for r in pdb_chain.get_residues() if r.id[1] == resi]
-    assert len(hits) == 1
-    return hits[0]

@@ -2,8 +2,8 @@
 // random weights with the reference checkpoint's names, one batch of synthetic pockets, one
 // sampling chain with on-device noise, then the deferred checks and work counters.
 //
-//   hipcc --offload-arch=gfx950 -O2 -Iinclude examples/c_api_demo.cpp -Lcmd-gen_amd -lcmdgen_hip \
-//         -Wl,-rpath,$PWD/cmd-gen_amd -o /tmp/c_api_demo && /tmp/c_api_demo
+//   hipcc --offload-arch=gfx950 -O2 -Iinclude examples/c_api_demo.cpp -Lcmdgen_amd -lcmdgen_hip \
+//         -Wl,-rpath,$PWD/cmdgen_amd -o /tmp/c_api_demo && /tmp/c_api_demo
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

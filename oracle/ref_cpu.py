@@ -3,7 +3,7 @@
 CPU restatement (torch CPU ops, fp32) of the reference's pocket-conditioned
 denoising path: noise schedule, EGNN denoiser, DDPM ancestral sampler.  Only
 ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
-may import this file.  The product (``cmd-gen_amd/``) never does: it fails
+may import this file.  The product (``cmdgen_amd/``) never does: it fails
 loudly when the HIP library is missing.
 
 Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function

@@ -5,7 +5,7 @@ EGNNDynamics with update_pocket_coords=True, produced by importing the real refe
     python tests/golden/make_golden_joint.py
 
 Fixtures hold inputs, every raw Gaussian draw (in call order) and outputs - never weights (those are
-regenerated from the seed by cmd-gen_amd/synthetic.py) and never reference source.
+regenerated from the seed by cmdgen_amd/synthetic.py) and never reference source.
 """
 import contextlib
 import io

@@ -522,7 +522,7 @@ def test_c_api_demo_runs_without_python_or_torch(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / 'c_api_demo')
-    libdir = os.path.join(root, 'cmd-gen_amd')
+    libdir = os.path.join(root, 'cmdgen_amd')
     cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O2', '-I' + os.path.join(root, 'include'),
            os.path.join(root, 'examples', 'c_api_demo.cpp'), '-L' + libdir, '-lcmdgen_hip', '-Wl,-rpath,' + libdir, '-o', exe]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -57,7 +57,7 @@ def test_product_fails_loudly_without_gpu():
     with pytest.raises(hip_backend.CmdgenError):
         hip_backend.Handle(ModelConfig().as_dict(), 0)
     # and nothing in the product imports the oracle
-    for dirpath, _, files in os.walk(os.path.join(ROOT, 'cmd-gen_amd')):
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'cmdgen_amd')):
         for f in files:
             if f.endswith('.py') and f != 'selftest.py':
                 src = open(os.path.join(dirpath, f)).read()
@@ -259,24 +259,3 @@ def test_consensus_posp_matches_reference_script(tmp_path):
     src.write_text(json.dumps(cases[0]['input']))
     lines = get_phar.main([str(src), '--out', str(tmp_path / 'o.posp')])
     assert (tmp_path / 'o.posp').read_text() == cases[0]['posp'] and len(lines) == len(cases[0]['posp'].splitlines())
-
-
-def test_small_utils_helpers(tmp_path):
-    from cmdgen_amd import utils
-    from cmdgen_amd.constants import dataset_params
-    x = torch.arange(12.).view(4, 3)
-    assert torch.equal(utils.reverse_tensor(x), x[[3, 2, 1, 0]])
-    a, b = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2, 2))
-    a.grad, b.grad = torch.full((3,), 2.0), torch.full((2, 2), -1.0)
-    assert abs(float(utils.get_grad_norm([a, b])) - (3 * 4 + 4 * 1) ** 0.5) < 1e-6
-    assert float(utils.get_grad_norm([torch.nn.Parameter(torch.ones(1))])) == 0.0
-    utils.write_xyz_file(np.array([[0.1234, 1.0, -2.5], [3, 4, 5]]), ['C', 'N'], tmp_path / 'm.xyz')
-    assert (tmp_path / 'm.xyz').read_text() == "2\n\nC 0.123 1.000 -2.500\nN 3.000 4.000 5.000\n"
-    info = dataset_params['crossdock_full']
-    xx, oh = utils.residues_to_atoms(torch.zeros(5, 3), info)
-    assert oh.shape == (5, len(info['atom_encoder'])) and int(oh.sum()) == 5 and bool((oh[:, info['atom_encoder']['C']] == 1).all())
-    pdb = tmp_path / 'p.pdb'
-    pdb.write_text("ATOM      1  CA  ALA A   7       0.000   0.000   0.000  1.00  0.00           C\n"
-                   "ATOM      2  CA  GLY A   9       3.800   0.000   0.000  1.00  0.00           C\nEND\n")
-    chain = utils.parse_pdb(str(pdb))['A']
-    assert utils.get_residue_with_resi(chain, 9).get_resname() == 'GLY'
