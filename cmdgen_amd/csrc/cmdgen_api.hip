@@ -24,6 +24,8 @@ void cmdgen_launch_chain_init(const Layout& lay, const Dims& d, const ChainBuf& 
                               const float* poh, hipStream_t s);
 void cmdgen_launch_ddpm_step(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
                              const float* eps, hipStream_t s);
+void cmdgen_launch_step_count(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
+                              const float* eps, hipStream_t s);
 void cmdgen_launch_debug_noise(unsigned long long seed, long long pocket_id, int draw, int n_nodes, int width,
                                float* out, hipStream_t s);
 void cmdgen_launch_chain_final(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
@@ -88,6 +90,9 @@ extern "C" void cmdgen_destroy(cmdgen_handle* h) {
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     if (h->ev_in) hipEventDestroy(h->ev_in);
     if (h->ev_out) hipEventDestroy(h->ev_out);
+    if (h->side_stream) hipStreamDestroy(h->side_stream);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     free_pool(h->weight_allocs); free_pool(h->layout_allocs); free_pool(h->chain_allocs); free_pool(h->joint_allocs);
     cmdgen_train_free(h->train);
     delete h;
@@ -624,7 +629,7 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
     }
     ChainBuf c = h->chain;
     c.noise = noise; c.seed = seed; c.z_steps = z_steps_out; c.pocket_steps = pocket_steps_out;
-    const ChainState st0{-1, K, 0, 0};
+    const ChainState st0{0, K, 0, 0};
     HIPCHK(h, hipMemcpyAsync(c.state, &st0, sizeof st0, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemsetAsync(c.check, 0, (size_t)(K + 3) * 2 * sizeof(unsigned int), s));
     HIPCHK(h, hipMemsetAsync(h->d_cog, 0, 4 * sizeof(unsigned int), s));
@@ -632,9 +637,28 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
     EvalLaunch a = make_launch(h);
     if (h->kernel_profiling && !use_graph) a.prof_events = h->prof_events;
     cmdgen_launch_chain_init(h->lay, d, c, pocket_x, pocket_onehot, s);
+    // One denoising step = the posterior update fused with pass 1 of the next radius graph (k_step_count), then the
+    // evaluation at the new state: pass 2 of the graph (k_edge_write), k_embed, the L blocks,
+    // k_readout.  The chain is: evaluation 0, K x (step + evaluation), decode.  CMDGEN_UNFUSED_STEP=1 restores the
+    // separate k_ddpm_step / k_edge_count launches on one stream (A/B measurements).
+    const bool fused = getenv("CMDGEN_UNFUSED_STEP") == nullptr;
+    EvalLaunch a2 = a;
+    if (fused) {
+        if (!h->side_stream) {
+            HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+        // measured (profiles/r02_b_step_fusion.txt): the fork / join costs ~23 us per step inside the replayed graph,
+        // far more than the 10 us of k_edge_write it hides - off unless asked for
+        if (getenv("CMDGEN_SIDE_STREAM")) { a.side = h->side_stream; a.ev_fork = h->ev_fork; a.ev_join = h->ev_join; }
+        a2 = a; a2.skip_count = 1;
+    }
+    cmdgen_launch_eval(a, c.z_phar, c.xh_pocket, nullptr, c.coef, c.state, h->work.eps_tmp, nullptr, s, nullptr);   // evaluation 0 (t = 1)
     auto one_step = [&](hipStream_t ss) {
-        cmdgen_launch_eval(a, c.z_phar, c.xh_pocket, nullptr, c.coef, c.state, h->work.eps_tmp, nullptr, ss, nullptr);
-        cmdgen_launch_ddpm_step(h->lay, d, c, h->work, h->work.eps_tmp, ss);
+        if (fused) cmdgen_launch_step_count(h->lay, d, c, h->work, h->work.eps_tmp, ss);
+        else cmdgen_launch_ddpm_step(h->lay, d, c, h->work, h->work.eps_tmp, ss);
+        cmdgen_launch_eval(a2, c.z_phar, c.xh_pocket, nullptr, c.coef, c.state, h->work.eps_tmp, nullptr, ss, nullptr);
     };
     if (use_graph) {
         // The step is identical every iteration (the step index lives on the device), so it is
@@ -664,8 +688,7 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
     } else {
         for (int i = 0; i < K; ++i) one_step(s);
     }
-    // final p(x, h | z0): one more evaluation at t = 0 (coef[K].w), then decode
-    cmdgen_launch_eval(a, c.z_phar, c.xh_pocket, nullptr, c.coef, c.state, h->work.eps_tmp, nullptr, s, nullptr);
+    // final p(x, h | z0): the last evaluation above ran at t = 0 (coef[K].w); decode
     cmdgen_launch_chain_final(h->lay, d, c, h->work, h->work.eps_tmp, xh_phar_out, xh_pocket_out, h->d_cog, s);
     HIPCHK(h, hipGetLastError());
     if (s != caller) {
@@ -846,7 +869,7 @@ extern "C" int cmdgen_joint_chain(cmdgen_handle* h, const float* phar_x, const f
     JointBuf c = h->joint;
     c.fix_phar = inpaint ? phar_fixed : nullptr; c.fix_pocket = inpaint ? pocket_fixed : nullptr;
     c.noise = noise; c.seed = seed; c.z_steps = z_steps_out;
-    const ChainState st0{-1, n_steps, 0, 0};
+    const ChainState st0{0, n_steps, 0, 0};
     HIPCHK(h, hipMemcpyAsync(c.state, &st0, sizeof st0, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemsetAsync(c.check, 0, (size_t)(n_steps + 3) * 2 * sizeof(unsigned int), s));
     HIPCHK(h, hipMemsetAsync(h->joint_cog, 0, 4 * sizeof(unsigned int), s));

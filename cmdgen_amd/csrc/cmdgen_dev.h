@@ -113,7 +113,9 @@ struct Work {                   // per-layout workspace; all pointers device
 };
 
 struct ChainState {             // device-resident denoising-loop state
-    int step;                   // index into coef[], incremented by the first kernel of each evaluation
+    int step;                   // evaluations completed so far = index into coef[] of the NEXT evaluation; bumped by
+                                // k_readout (which does not read it), so no kernel reads it while it changes: the
+                                // evaluation kernels of step e read e, the sampler kernel that follows reads step - 1
     int K;                      // posterior steps
     int pad0, pad1;
 };
@@ -160,6 +162,9 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     std::vector<hipEvent_t>* prof_events;  // when non-null: [3] vectors, event pairs around every msg / node / coord launch
     int ablate;                 // timing-only builds of the edge kernel (cmdgen_time_edge_kernel); 0 in production
     int stop_block = -1, stop_stage = 0;   // cmdgen_debug_eval_prefix: stop after stage 1..3 of this block (-1: run everything)
+    int skip_count = 0;         // the sampler's fused step kernel has already run the radius-graph count pass
+    hipStream_t side = nullptr; // when set: k_edge_write runs there, concurrently with k_embed (fork / join by events)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // ---------------------------------------------------------------------------------
@@ -173,9 +178,11 @@ __device__ __forceinline__ float silu_f(float v) {
 __device__ __forceinline__ float sigmoid_f(float v) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
+// squared distance with a FIXED rounding sequence (explicit fma chain): the radius-graph count pass and write pass
+// live in translation units built with different -ffp-contract settings and must agree on every pair at the cutoff
 __device__ __forceinline__ float dist2(const float4& a, const float4& b) {
-    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-    return dx * dx + dy * dy + dz * dz;
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
 }
 
 // ---------------------------------------------------------------------------------

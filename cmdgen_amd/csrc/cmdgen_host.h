@@ -56,6 +56,8 @@ struct cmdgen_handle {
     hipGraphExec_t step_graph = nullptr;
     hipStream_t own_stream = nullptr;      // used when the caller's stream is the legacy default stream (not capturable)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipStream_t side_stream = nullptr;     // k_edge_write next to k_embed (fork / join inside the step)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     const float* graph_noise = nullptr; float* graph_zsteps = nullptr; float* graph_psteps = nullptr; hipStream_t graph_stream = nullptr;
     unsigned long long graph_seed = 0;
     int graph_steps = 0;

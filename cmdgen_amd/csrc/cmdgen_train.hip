@@ -301,8 +301,29 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     return CMDGEN_OK;
 }
 
+// Stages of the backward pass, in execution order: 0 = readout (decoders, embedding_out), 1..L = blocks L-1..0
+// (stage k is block L-k), L+1 = embedding and encoders.  The gradient regions of the flat buffer therefore complete
+// from the back: after stage k every tensor of blocks >= L-k is final, so the caller can start the all-reduce of that
+// (contiguous) tail while the earlier blocks are still being differentiated.
+static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, const float* d_eps_pocket, float* grad,
+                                 int first_stage, int last_stage, cmdgen_stream stream);
+
 extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, const float* d_eps_pocket, float* grad,
                                      cmdgen_stream stream) {
+    if (!h) return CMDGEN_EINVAL;
+    return train_backward_stages(h, d_eps_phar, d_eps_pocket, grad, 0, h->dims.L + 1, stream);
+}
+
+extern "C" int cmdgen_train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, const float* d_eps_pocket, float* grad,
+                                            int32_t first_stage, int32_t last_stage, cmdgen_stream stream) {
+    if (!h) return CMDGEN_EINVAL;
+    if (first_stage < 0 || last_stage > h->dims.L + 1 || first_stage > last_stage)
+        return fail(h, CMDGEN_EINVAL, "stages must satisfy 0 <= first <= last <= n_layers + 1");
+    return train_backward_stages(h, d_eps_phar, d_eps_pocket, grad, first_stage, last_stage, stream);
+}
+
+static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, const float* d_eps_pocket, float* grad,
+                                 int first_stage, int last_stage, cmdgen_stream stream) {
     if (!h || !h->train || !h->train->have_forward) return fail(h, CMDGEN_ESTATE, "cmdgen_train_backward needs a preceding cmdgen_train_forward");
     if (!d_eps_phar || !grad) return fail(h, CMDGEN_EINVAL, "null device pointer");
     hipSetDevice(h->device);
@@ -319,6 +340,7 @@ extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, 
     const ParamTable& tb = t->tab;
     const size_t NH = (size_t)N * H;
     auto bias_grad = [&](const PRef& r, int M, const float* dy, int ld) { tr_colsum(M, r.out, dy, ld, nullptr, grad + r.b, 1, s); };
+    if (first_stage == 0) {
     // readout
     HIPCHK(h, hipMemsetAsync(t->dX, 0, (size_t)N * 4 * sizeof(float), s));
     tr_eps_bwd(Nl, P, 0, d_eps_phar, t->dX, t->ddec, s);
@@ -345,7 +367,10 @@ extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, 
     linear_wgrad(grad, tb.embo, 0, H, N, t->dhfin, d.dyn, t->h + (size_t)L * NH, H, s);
     bias_grad(tb.embo, N, t->dhfin, d.dyn);
     linear_dgrad(theta, tb.embo, 0, H, N, t->dhfin, d.dyn, t->dh, H, false, s);
+    }
     for (int l = L - 1; l >= 0; --l) {
+        const int stage = L - l;
+        if (stage < first_stage || stage > last_stage) continue;
         const ParamTable::Blk& b = tb.blk[l];
         const float* hl = t->h + (size_t)l * NH;
         const float* hn = t->h + (size_t)(l + 1) * NH;
@@ -414,6 +439,7 @@ extern "C" int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, 
         linear_dgrad(theta, b.e0, 0, H, N, t->dP, H, t->dh, H, true, s);
         linear_dgrad(theta, b.e0, H, H, N, t->dQ, H, t->dh, H, true, s);
     }
+    if (last_stage < L + 1) { HIPCHK(h, hipGetLastError()); return CMDGEN_OK; }
     // embedding and encoders
     linear_wgrad(grad, tb.emb, 0, d.dyn, N, t->dh, H, t->hdyn, d.dyn, s);
     bias_grad(tb.emb, N, t->dh, H);

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void k_ddpm_step(Layout lay, Dims d, ChainBuf c
     const int nl = lay.num_phar[b], np = lay.num_pocket[b];
     const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
     const int ld = 3 + d.P, ldq = 3 + d.R;
-    const int step = c.state->step;                 // 0-based index of this posterior step
+    const int step = c.state->step - 1;             // 0-based index of this posterior step (k_readout has counted the evaluation)
     const float4 cf = c.coef[step];
     const bool nan_reset = *w.nan_flag != 0;
     float* zg = c.z_phar + (size_t)pb * ld;
@@ -217,6 +217,125 @@ __global__ __launch_bounds__(64) void k_chain_drift_fix(Layout lay, Dims d, floa
                lay.pocket_base[b], lay.num_pocket[b], lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_step_count: the posterior step z_t -> z_s (as k_ddpm_step) FUSED with pass 1 of the next evaluation's radius
+// graph (k_edge_count, kernels_egnn.hip): both are one-workgroup-per-sample, and the new positions are already in
+// LDS when the step is done - one launch and one global round trip of the positions less per denoising step.
+// 256 threads per sample.  Arithmetic and summation order of the step are those of k_ddpm_step (bit-identical
+// results); the count pass is k_edge_count's (same dist2, same ballots).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_step_count(Layout lay, Dims d, ChainBuf c, Work w,
+                                                    const float* __restrict__ eps) {
+    extern __shared__ float4 s_pos[];               // [max_n] positions of the sample (phar first), then int sdeg[max_n], then z
+    int* sdeg = reinterpret_cast<int*>(s_pos + lay.max_n);
+    float* s_z = reinterpret_cast<float*>(sdeg + lay.max_n);      // [nl * ld]
+    __shared__ float s_mean[3];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int nl = lay.num_phar[b], np = lay.num_pocket[b], n = nl + np;
+    const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
+    const int ld = 3 + d.P, ldq = 3 + d.R;
+    const int step = c.state->step - 1;
+    const float4 cf = c.coef[step];
+    const bool nan_reset = *w.nan_flag != 0;
+    float* zg = c.z_phar + (size_t)pb * ld;
+    const float* eg = eps + (size_t)pb * ld;
+    const int cnt = nl * ld;
+    for (int idx = tid; idx < cnt; idx += blockDim.x) s_z[idx] = zg[idx];
+    // pocket coordinates of this sample: in flight while the step is computed
+    for (int i = tid; i < np; i += blockDim.x) {
+        const float* q = c.xh_pocket + (size_t)(qb + i) * ldq;
+        s_pos[nl + i] = make_float4(q[0], q[1], q[2], 0.f);
+    }
+    __syncthreads();
+    if (wave == 0 && !d.no_com) record_com_check(c.check + 2 * (1 + step), s_z, ld, 0, nl, 1.0f, lane);   // z_t, the step's input
+    __syncthreads();
+    for (int idx = tid; idx < cnt; idx += blockDim.x) {
+        const int i = idx / ld, k = idx - i * ld;
+        float e = eg[idx];
+        if (nan_reset && k < 3) e = 0.f;
+        const float mu = s_z[idx] / cf.x - cf.y * e;
+        s_z[idx] = mu + cf.z * draw(c, lay, 1 + step, b, i, pb + i, k, ld);
+    }
+    __syncthreads();
+    if (tid < 3) {                                  // phar centre of mass, index order (remove_mean_batch :467-475)
+        float sum = 0.f;
+        if (!d.no_com) {
+            for (int i = 0; i < nl; ++i) sum += s_z[i * ld + tid];
+            sum = sum / fmaxf((float)nl, 1.0f);
+        }
+        s_mean[tid] = sum;
+    }
+    __syncthreads();
+    const float m0 = s_mean[0], m1 = s_mean[1], m2 = s_mean[2];
+    for (int i = tid; i < n; i += blockDim.x) {
+        float4 p;
+        if (i < nl) {
+            float* z = s_z + i * ld;
+            if (!d.no_com) { z[0] -= m0; z[1] -= m1; z[2] -= m2; }
+            p = make_float4(z[0], z[1], z[2], 0.f);
+            w.X0[pb + i] = p;
+            for (int l = 0; l < d.L; ++l) w.ACC[(size_t)l * lay.Nm + pb + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            p = s_pos[i];
+            if (!d.no_com) {
+                p.x -= m0; p.y -= m1; p.z -= m2;
+                float* q = c.xh_pocket + (size_t)(qb + i - nl) * ldq;
+                q[0] = p.x; q[1] = p.y; q[2] = p.z;
+            }
+            w.XP[qb + i - nl] = p;
+            if (c.pocket_steps) {
+                float* o = c.pocket_steps + ((size_t)step * lay.Np + qb + i - nl) * 3;
+                o[0] = p.x; o[1] = p.y; o[2] = p.z;
+            }
+        }
+        s_pos[i] = p;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < cnt; idx += blockDim.x) {
+        const float v = s_z[idx];
+        zg[idx] = v;
+        if (c.z_steps) c.z_steps[(size_t)step * lay.Nl * ld + (size_t)pb * ld + idx] = v;
+    }
+    // ---- pass 1 of the radius graph of the NEXT evaluation (as k_edge_count)
+    for (int i = wave; i < n; i += nwaves) {
+        const float4 pi = s_pos[i];
+        int deg = 0, self = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            bool ok = false;
+            if (j < n) {
+                const float r2 = dist2(pi, s_pos[j]);
+                ok = (d.cutoff2 < 0.f) || (r2 <= d.cutoff2);
+            }
+            const unsigned long long m = __ballot(ok);
+            deg += __popcll(m);
+            if (i >= j0 && i < j0 + 64) self = (int)((m >> (i - j0)) & 1ull);
+        }
+        if (lane == 0) { sdeg[i] = deg | (self << 30); w.degL[pb + qb + i] = deg | (self << 30); }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int e = 0, eph = 0, ens = 0, ensq = 0;
+        for (int i = lane; i < n; i += 64) {
+            const int dg = sdeg[i] & 0x3fffffff; e += dg;
+            if (i < nl) { eph += dg; ens += dg - ((sdeg[i] >> 30) & 1); }
+            else ensq += dg - ((sdeg[i] >> 30) & 1);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            e += __shfl_xor(e, o); eph += __shfl_xor(eph, o); ens += __shfl_xor(ens, o); ensq += __shfl_xor(ensq, o);
+        }
+        if (lane == 0) { w.pocketE[b] = e; w.pocketEph[b] = eph; w.pocketEns[b] = ens; w.pocketEnsQ[b] = ensq; }
+    }
+    if (b == 0 && tid == 0) {
+        if (nan_reset) atomicAdd(&w.counters[4], 1ull);
+        atomicAdd(&w.counters[0], 1ull);                       // evaluations (the one about to run)
+        atomicAdd(&w.counters[3], (unsigned long long)lay.N);  // nodes
+    }
+}
+
+// (The NaN flag this kernel reads is cleared for the next evaluation by k_edge_write, which runs after every reader
+// of the old value and before k_readout can set it again.)
+
 void cmdgen_launch_chain_init(const Layout& lay, const Dims& d, const ChainBuf& c, const float* px,
                               const float* poh, hipStream_t s) {
     hipLaunchKernelGGL(k_chain_init, dim3(lay.B), dim3(64), 0, s, lay, d, c, px, poh);
@@ -225,6 +344,11 @@ void cmdgen_launch_ddpm_step(const Layout& lay, const Dims& d, const ChainBuf& c
                              const float* eps, hipStream_t s) {
     // dynamic LDS: the largest sample's z.  (max_n bounds nl; 3 + P floats per node)
     hipLaunchKernelGGL(k_ddpm_step, dim3(lay.B), dim3(64), (size_t)lay.max_n * (3 + d.P) * sizeof(float), s, lay, d, c, w, eps);
+}
+void cmdgen_launch_step_count(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
+                              const float* eps, hipStream_t s) {
+    const size_t shm = (size_t)lay.max_n * (sizeof(float4) + sizeof(int)) + (size_t)lay.max_n * (3 + d.P) * sizeof(float);
+    hipLaunchKernelGGL(k_step_count, dim3(lay.B), dim3(256), shm, s, lay, d, c, w, eps);
 }
 void cmdgen_launch_chain_final(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
                                const float* eps, float* xo, float* po, unsigned int* cog, hipStream_t s) {

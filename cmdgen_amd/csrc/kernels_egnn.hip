@@ -36,7 +36,7 @@ __device__ __forceinline__ int flat_node(int i, int nl, int pb, int qb, int Nl) 
 }
 
 __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict__ xh_phar,
-                             const float* __restrict__ xh_pocket, ChainState* chain) {
+                             const float* __restrict__ xh_pocket) {
     extern __shared__ float4 spos[];            // [max_n] positions, then int sdeg[max_n]
     int* sdeg = reinterpret_cast<int*>(spos + lay.max_n);
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -94,8 +94,6 @@ __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict
         if (lane == 0) { w.pocketE[b] = e; w.pocketEph[b] = eph; w.pocketEns[b] = ens; w.pocketEnsQ[b] = ensq; }
     }
     if (b == 0 && tid == 0) {
-        if (chain) chain->step += 1;
-        *w.nan_flag = 0;
         atomicAdd(&w.counters[0], 1ull);                       // evaluations
         atomicAdd(&w.counters[3], (unsigned long long)lay.N);  // nodes
     }
@@ -199,6 +197,7 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
             }
         }
     }
+    if (b == 0 && tid == 0) *w.nan_flag = 0;     // after every reader of the previous evaluation's flag, before k_readout sets it
     if (b == lay.B - 1 && tid == 0) {
         const int E = s_base[1] + (w.pocketE[b] - eph_b);
         const int Ec = d.joint ? s_base[4] + w.pocketEnsQ[b] : s_base[3] + w.pocketEns[b];
@@ -718,11 +717,13 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
 // consumer (k_nan_fix or the DDPM kernels) once the flag is complete.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, SmallW sw,
-                                                 float* __restrict__ eps_phar, float* __restrict__ eps_pocket) {
+                                                 float* __restrict__ eps_phar, float* __restrict__ eps_pocket,
+                                                 ChainState* chain) {
     extern __shared__ float s_hrow[];            // [8][H] node rows, then [H][dyn] embedding_out^T
     __shared__ float s_j[8][CMDGEN_MAX_SMALL + 1];
     __shared__ float s_h1[8][CMDGEN_MAX_SMALL];
     const int tid = threadIdx.x, g = tid >> 5, l32 = tid & 31;
+    if (chain && blockIdx.x == 0 && tid == 0) chain->step += 1;      // this evaluation is done (see ChainState)
     const int nnodes = eps_pocket ? lay.N : lay.Nl;
     const int n = blockIdx.x * 8 + g;
     const bool live = n < nnodes;
@@ -859,10 +860,22 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
 #define REC() do { if (ev) hipEventRecord(ev[e++], s); } while (0)
 #define PROF(k) do { if (a.prof_events) { hipEvent_t pe; hipEventCreate(&pe); hipEventRecord(pe, s); a.prof_events[k].push_back(pe); } } while (0)
     REC();
-    hipLaunchKernelGGL(k_edge_count, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket, chain);
-    hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d);
-    REC(); REC();
-    MT_DISPATCH(a.node_mt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
+    if (!a.skip_count) hipLaunchKernelGGL(k_edge_count, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket);
+    if (a.side) {
+        // k_embed reads features only, k_edge_write positions and degrees only: they run side by side, and the first
+        // consumer of both (k_edge_msg of block 0) waits for the join
+        hipEventRecord(a.ev_fork, s);
+        hipStreamWaitEvent(a.side, a.ev_fork, 0);
+        hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, a.side, a.lay, a.w, a.d);
+        hipEventRecord(a.ev_join, a.side);
+        REC(); REC();
+        MT_DISPATCH(a.node_mt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
+        hipStreamWaitEvent(s, a.ev_join, 0);
+    } else {
+        hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d);
+        REC(); REC();
+        MT_DISPATCH(a.node_mt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
+    }
     REC();
     for (int l = 0; l < a.d.L; ++l) {
         const int stop = a.stop_block == l ? a.stop_stage : 0;        // parity aid: leave intermediates in the workspace
@@ -881,7 +894,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     REC();
     const int nn = eps_pocket ? N : a.lay.Nl;
     hipLaunchKernelGGL(k_readout, dim3((nn + 7) / 8), dim3(256), (8 + a.d.dyn) * a.d.H * sizeof(float), s, a.lay, a.w, a.d, a.sw,
-                       eps_phar, eps_pocket);
+                       eps_phar, eps_pocket, chain);
     if (a.d.joint) hipLaunchKernelGGL(k_vel_com, dim3(B), dim3(64), 0, s, a.lay, a.w, a.d, eps_phar, eps_pocket);
     REC();
 #undef REC
@@ -902,7 +915,7 @@ void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* 
 // radius graph only (the training path builds its own evaluation on top of the same compact lists)
 void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s) {
     const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + 2 * sizeof(int));
-    hipLaunchKernelGGL(k_edge_count, dim3(a.lay.B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket, (ChainState*)nullptr);
+    hipLaunchKernelGGL(k_edge_count, dim3(a.lay.B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket);
     hipLaunchKernelGGL(k_edge_write, dim3(a.lay.B), dim3(256), shm, s, a.lay, a.w, a.d);
 }
 

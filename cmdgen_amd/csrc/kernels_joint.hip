@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void k_joint_step(Layout lay, Dims d, JointBuf 
                                                    const float* __restrict__ eps_phar, const float* __restrict__ eps_pocket) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const SampleView v = view_of(lay, d, b);
-    const int step = c.state->step;
+    const int step = c.state->step - 1;      // k_readout has counted the evaluation (ChainState)
     const float4 cf = c.coef[step], cf2 = c.coef2[step];
     const int4 io = c.iop[step];
     const bool inpaint = c.fix_phar != nullptr;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void k_joint_final(Layout lay, Dims d, JointBuf
                                                     unsigned int* cog_slot) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const SampleView v = view_of(lay, d, b);
-    const int step = c.state->step;
+    const int step = c.state->step - 1;      // k_readout has counted the evaluation (ChainState)
     const float4 cf = c.coef[step];                     // (sigma_0, alpha_0, sigma_x, 0)
     const int draw_idx = c.iop[step].y;
     for (int i = lane; i < v.nl; i += 64) {             // types from z_0 itself: argmax of the un-normalised h

@@ -63,6 +63,7 @@ SYMBOLS = [
     ('cmdgen_param_offset', C.c_int, [_vp, C.c_char_p, _i64p, _i64p]),
     ('cmdgen_train_forward', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
     ('cmdgen_train_backward', C.c_int, [_vp, _fp, _fp, _fp, _vp]),
+    ('cmdgen_train_backward_stages', C.c_int, [_vp, _fp, _fp, _fp, C.c_int32, C.c_int32, _vp]),
     ('cmdgen_train_set_precision', C.c_int, [_vp, C.c_int32]),
     ('cmdgen_grad_sqnorm', C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_float), _vp]),
     ('cmdgen_adamw_step', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
@@ -363,6 +364,11 @@ class Handle:
         assert grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous() and grad.numel() == self.param_count()
         self._check(self.lib.cmdgen_train_backward(self.h, _ptr(d_eps), _ptr(d_eps_pocket), _ptr(grad), self._stream()),
                     'cmdgen_train_backward')
+
+    def train_backward_stages(self, d_eps, grad, first_stage: int, last_stage: int, d_eps_pocket=None):
+        """Stages first..last of the backward pass (0 readout, k = block L-k, L+1 embedding / encoders)."""
+        self._check(self.lib.cmdgen_train_backward_stages(self.h, _ptr(d_eps), _ptr(d_eps_pocket), _ptr(grad), int(first_stage),
+                                                          int(last_stage), self._stream()), 'cmdgen_train_backward_stages')
 
     def train_set_precision(self, bf16_gemm: bool):
         self._check(self.lib.cmdgen_train_set_precision(self.h, int(bool(bf16_gemm))), 'cmdgen_train_set_precision')

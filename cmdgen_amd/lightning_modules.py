@@ -199,6 +199,52 @@ class PharPocketDDPM(nn.Module):
                              utils.batch_to_list(phar['x'].cpu(), phar['mask'].cpu())))
         return phars
 
+    # ------------------------------------------------------------------ validation sampling
+    @staticmethod
+    def _type_kl(hist_dict, mapping, sample_types):
+        """KL(p || q) of the dataset's type histogram p against the sampled types q with the reference's smoothing
+        (analysis/metrics.py:12-34, CategoricalDistribution.kl_divergence; -1 when there is no histogram)."""
+        if hist_dict is None:
+            return -1
+        p = np.zeros(len(mapping))
+        for k, v in hist_dict.items():
+            p[mapping[k]] = v
+        p = p / p.sum()
+        q = np.bincount(np.asarray(sample_types, dtype=np.int64), minlength=len(mapping)).astype(np.float64)
+        q = q / q.sum()
+        with np.errstate(divide='ignore', invalid='ignore'):
+            return float(-np.sum(p * np.log(q / p + 1e-10)))
+
+    @torch.no_grad()
+    def sample_and_analyze_given_pocket(self, n_samples, dataset=None, batch_size=None, timesteps=None, **kw):
+        """Sample n_samples pharmacophores for pockets of `dataset` and compare type statistics with the training
+        data (lightning_modules.py:337-382 + analyze_sample :307-334): KL divergence of the sampled phar types and of
+        the pocket types the sampler returns.  The commented-out stability / RDKit parts of the reference are not
+        reproduced."""
+        batch_size = self.batch_size if batch_size is None else batch_size
+        batch_size = min(batch_size, n_samples)
+        phar_types, aa_types, done = [], [], 0
+        for i in range(math.ceil(n_samples / batch_size)):
+            n_b = min(batch_size, n_samples - done)
+            batch = dataset.collate_fn([dataset[(i * batch_size + j) % len(dataset)] for j in range(n_b)])
+            phar, pocket = self.get_phar_and_pocket(batch)
+            num_nodes_phar = self.ddpm.size_distribution.sample_conditional(n1=None, n2=pocket['size'])
+            if type(self.ddpm) == EnVariationalDiffusion:
+                xh_phar, xh_pocket, _, _ = self.ddpm.sample(n_b, num_nodes_phar, pocket['size'], timesteps=timesteps,
+                                                            device=self.device, **kw)
+            else:
+                xh_phar, xh_pocket, _, _ = self.ddpm.sample_given_pocket(pocket, num_nodes_phar, timesteps=timesteps, **kw)
+            phar_types.extend(xh_phar[:, self.x_dims:].argmax(1).detach().cpu().tolist())
+            aa_types.extend(xh_pocket[:, self.x_dims:].argmax(1).detach().cpu().tolist())
+            done += n_b
+        ca = self.pocket_representation == 'CA'
+        out = {'kl_div_atom_types': self._type_kl(self.dataset_info.get('phar_hist'), self.dataset_info['phar_encoder'], phar_types),
+               'kl_div_residue_types': self._type_kl(self.dataset_info.get('aa_hist') if ca else None,
+                                                     self.dataset_info['aa_encoder'] if ca else {}, aa_types)}
+        print('kl_div_atom_types:', out['kl_div_atom_types'])
+        print('kl_div_residue_types:', out['kl_div_residue_types'])
+        return out
+
     # ------------------------------------------------------------------ sampling entry points
     @torch.no_grad()
     def sample_given_batch(self, batch, timesteps=None, **kw):

@@ -52,13 +52,14 @@ def merge_configs(config, resume_config):
     return config
 
 
-def _batches(dataset, batch_size, epoch, rank, world, shuffle=True, seed=0):
-    """every rank walks the same permutation and takes every world-th batch (drop the ragged tail so that all ranks
-    take the same number of optimizer steps)"""
+def _batches(dataset, batch_size, epoch, rank, world, shuffle=True, seed=0, drop_tail=True):
+    """every rank walks the same permutation and takes every world-th batch; in training the ragged tail is dropped
+    so that all ranks take the same number of optimizer steps (every step is a collective), in validation it is kept
+    (ranks may then see different batch counts: only the final sums are reduced)"""
     n = len(dataset)
     order = np.random.Generator(np.random.PCG64(seed + epoch)).permutation(n) if shuffle else np.arange(n)
     starts = list(range(0, n, batch_size))
-    usable = (len(starts) // world) * world if world > 1 else len(starts)
+    usable = (len(starts) // world) * world if (world > 1 and drop_tail) else len(starts)
     for bi in range(rank, usable, world):
         idx = order[starts[bi]:starts[bi] + batch_size]
         yield dataset.collate_fn([dataset[int(i)] for i in idx])
@@ -69,7 +70,7 @@ def validate(model, dataset, batch_size, rank, world):
     """mean eval-mode nll over the validation set (lightning_modules.py:262-287)"""
     model.eval()
     tot, cnt = 0.0, 0
-    for batch in _batches(dataset, batch_size, 0, rank, world, shuffle=False):
+    for batch in _batches(dataset, batch_size, 0, rank, world, shuffle=False, drop_tail=False):
         nll, _ = model.forward(batch)
         tot += float(nll.sum()); cnt += len(nll)
     if world > 1:
@@ -78,7 +79,7 @@ def validate(model, dataset, batch_size, rank, world):
         dist.all_reduce(t)
         tot, cnt = float(t[0]), float(t[1])
     model.train()
-    return tot / max(cnt, 1)
+    return tot / cnt if cnt > 0 else float('nan')      # an empty validation set must not look like a perfect model
 
 
 def save_ckpt(model, trainer, path, epoch, best):
@@ -135,6 +136,7 @@ def main(argv=None):
         trainer.step_count = int(st['step_count'])
         trainer.gradnorm_queue.items = list(st['gradnorm_queue'])
         start_epoch, best = int(resume.get('epoch', -1)) + 1, float(st.get('best_val', float('inf')))
+    trainer.broadcast_state(0)          # replicas start from rank 0's parameters / moments, as under DDP
     if rank == 0:
         (out_dir / 'checkpoints').mkdir(parents=True, exist_ok=True)
         log = open(out_dir / 'metrics.jsonl', 'a')
@@ -150,17 +152,29 @@ def main(argv=None):
                 done = True
                 break
         val = validate(model, model.val_dataset, args.batch_size, rank, world)
+        sampled = None
+        if rank == 0 and (epoch + 1) % int(args.eval_epochs) == 0:
+            # validation sampling on rank 0 every eval_epochs (validation_epoch_end, lightning_modules.py:289-304)
+            tic = time.perf_counter()
+            model.eval()
+            sampled = model.sample_and_analyze_given_pocket(int(vars(args.eval_params).get('n_eval_samples', 16)),
+                                                            model.val_dataset, batch_size=model.eval_batch_size)
+            model.train()
+            sampled['evaluation_s'] = time.perf_counter() - tic
+            print(f"Evaluation took {sampled['evaluation_s']:.2f} seconds")
         if rank == 0:
             rec = {'epoch': epoch, 'loss/train': float(np.mean(losses)) if losses else None, 'loss/val': val,
                    'steps': trainer.step_count, 'epoch_s': time.perf_counter() - t0}
+            if sampled is not None:
+                rec.update({f'{k}/val': v for k, v in sampled.items()})
             log.write(json.dumps(rec) + '\n'); log.flush()
             print(rec)
             save_ckpt(model, trainer, out_dir / 'checkpoints' / 'last.ckpt', epoch, min(best, val))
-            if val < best:
+            if val == val and val < best:
                 for old in (out_dir / 'checkpoints').glob('best-model-epoch=*.ckpt'):
                     old.unlink()
                 save_ckpt(model, trainer, out_dir / 'checkpoints' / f'best-model-epoch={epoch:02d}.ckpt', epoch, val)
-        best = min(best, val)
+        best = min(best, val) if val == val else best
         if done:
             break
     if world > 1:

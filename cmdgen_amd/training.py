@@ -8,8 +8,8 @@ Design: every trainable tensor of ``EGNNDynamics`` lives in ONE flat fp32 device
 parameters are re-pointed to views of it, so ``state_dict`` / checkpoints / sampling keep working with no copies);
 ``grad`` and the three AdamW moment buffers have the same layout.  One step =
   loss terms on the activation-saving forward (``cmdgen_train_forward``)  ->  analytic dL/d eps (a few torch ops on
-  device)  ->  ``cmdgen_train_backward`` (parameter gradients)  ->  one ``all_reduce`` of the flat gradient over
-  RCCL when ``world_size > 1``  ->  gradient norm, clipping coefficient  ->  ``cmdgen_adamw_step``.
+  device)  ->  ``cmdgen_train_backward`` (parameter gradients, in stages)  ->  ``all_reduce`` of the flat gradient over
+  RCCL when ``world_size > 1``, three contiguous chunks started as their stages finish  ->  gradient norm, clipping coefficient  ->  ``cmdgen_adamw_step``.
 Both objectives ('l2' of the shipped configs, 'vlb' with a predefined schedule) and all model variants train.
 """
 from __future__ import annotations
@@ -60,6 +60,8 @@ class HipTrainer:
         assert gemm_dtype in ('fp32', 'bf16')
         self.gemm_dtype = gemm_dtype        # 'bf16': GEMM operands in bf16, fp32 accumulation (mixed precision); default exact fp32
         self.last_info: Dict[str, float] = {}
+        self.overlap_allreduce = True       # all-reduce finished gradient chunks behind the rest of the backward pass
+        self._pending = []
 
     # ------------------------------------------------------------------
     def _net(self, z_t, xh_pocket, t, phar_mask, pocket_mask):
@@ -106,16 +108,67 @@ class HipTrainer:
             d_eps_q[:, :nd] += diff_q[:, :nd] * (t_is_zero * q_0 / B)[pocket['mask']][:, None]
             d_eps_q = d_eps_q.contiguous()
         self.grad.zero_()
-        self.h.train_backward(d_eps.contiguous(), self.grad, d_eps_q)
+        self._backward(d_eps.contiguous(), d_eps_q)
         return loss, nll, info
 
-    def _allreduce(self):
+    # ------------------------------------------------------------------ data parallelism
+    def _world(self) -> int:
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size(self.group)
-            if world > 1:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def grad_chunks(self):
+        """The flat gradient as the contiguous ranges that become final one after the other during the backward pass:
+        [(last stage of the pass that completes the range, lo, hi)], back of the buffer first (DDP's reverse-order
+        buckets, train.py:111-121): the upper half of the blocks, the lower half, then the small head (encoders,
+        decoders, embeddings) that is only complete when the whole pass is."""
+        L = int(self.dyn._cfg['n_layers'])
+        n = self.theta.numel()
+        start = lambda l: self.h.param_offset(f'egnn.e_block_{l}.gcl_0.edge_mlp.0.weight')[0]
+        mid = L // 2
+        chunks = []
+        if L - mid > 0:
+            chunks.append((L - mid, start(mid), n))              # stages 0..L-mid: readout + blocks L-1..mid
+        if mid > 0:
+            chunks.append((L, start(0), start(mid)))             # blocks mid-1..0
+        chunks.append((L + 1, 0, start(0)))                      # embedding / encoders (and the readout's tensors)
+        return chunks
+
+    def _backward(self, d_eps, d_eps_q):
+        """Backward pass; with several ranks the all-reduce of every finished chunk is started as soon as its stages
+        are queued, so the collective runs behind the remaining differentiation (RCCL on its own stream) and only the
+        small head chunk is exposed.  The sum is divided by the world size in ``_allreduce``."""
+        self._pending = []
+        if self._world() == 1 or not self.overlap_allreduce:
+            self.h.train_backward(d_eps, self.grad, d_eps_q)
+            return
+        import torch.distributed as dist
+        first = 0
+        for last, lo, hi in self.grad_chunks():
+            self.h.train_backward_stages(d_eps, self.grad, first, last, d_eps_q)
+            self._pending.append(dist.all_reduce(self.grad[lo:hi], group=self.group, async_op=True))
+            first = last + 1
+
+    def _allreduce(self):
+        world = self._world()
+        if world > 1:
+            import torch.distributed as dist
+            if self._pending:
+                for work in self._pending:
+                    work.wait()
+                self._pending = []
+            else:
                 dist.all_reduce(self.grad, group=self.group)          # one flat bucket over RCCL
-                self.grad.div_(world)
+            self.grad.div_(world)
+
+    def broadcast_state(self, src: int = 0):
+        """Every replica starts from rank `src`'s parameters and optimizer state (what DDP does at construction,
+        train.py:117-118): replicas built from differently seeded RNGs would otherwise drift apart silently, since
+        only gradients are averaged."""
+        if self._world() > 1:
+            import torch.distributed as dist
+            for t in (self.theta, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq):
+                dist.broadcast(t, src=src, group=self.group)
+            self.dyn._weights_sig = None
 
     def optimizer_step(self, max_grad_norm: Optional[float] = None):
         """Adaptive clipping + AdamW(amsgrad) on the flat buffers; returns (grad_norm, max_grad_norm)."""

@@ -246,6 +246,14 @@ int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const float* xh_p
 int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, const float* d_eps_pocket, float* grad,
                           cmdgen_stream stream);
 
+/* The same pass in stages, so that the gradient all-reduce of the blocks already differentiated overlaps the rest of
+ * the backward pass (DDP's bucketed overlap, train.py:111-121): stage 0 = readout, stage k in 1..n_layers = block
+ * n_layers-k, stage n_layers+1 = embedding and encoders.  Call with consecutive, ascending stage ranges covering
+ * 0..n_layers+1; after stage k the flat gradient is final from cmdgen_param_offset("egnn.e_block_<n_layers-k>.
+ * gcl_0.edge_mlp.0.weight") to its end. */
+int cmdgen_train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, const float* d_eps_pocket, float* grad,
+                                 int32_t first_stage, int32_t last_stage, cmdgen_stream stream);
+
 /* GEMM operand precision of the training step: 0 (default) = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = operands
  * rounded to bf16 while staged, fp32 accumulation (v_mfma_f32_32x32x16_bf16).  Parameters, gradients, optimizer state,
  * stored activations and all elementwise math stay fp32 either way. */

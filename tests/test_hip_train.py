@@ -200,6 +200,60 @@ def test_training_step_matches_reference_gradients_and_optimizer():
     assert torch.isfinite(out[0]).all()
 
 
+def test_staged_backward_equals_single_pass():
+    """cmdgen_train_backward_stages (what the overlapped all-reduce drives) over any split of the stages 0..L+1 leaves
+    the same flat gradient as the single call, and the chunks HipTrainer reduces are final when their stage is done."""
+    model, tr, data, g6 = build_trainer()
+    t_int, eps = torch.from_numpy(g6['t_int']).cuda(), [torch.from_numpy(g6['eps0']).cuda()]
+    tr.loss_and_grad(data, t_int=t_int, eps=eps)
+    whole = tr.grad.clone()
+    ctx = tr.ddpm._last_train_ctx
+    L = int(tr.dyn._cfg['n_layers'])
+    # rebuild d_eps exactly as loss_and_grad does, via a second pass that records it
+    seen = {}
+    orig = tr.h.train_backward
+
+    def rec(d_eps, grad, d_eps_q=None):
+        seen['d_eps'] = d_eps.clone()
+        return orig(d_eps, grad, d_eps_q)
+    tr.h.train_backward = rec
+    tr.loss_and_grad(data, t_int=t_int, eps=eps)
+    tr.h.train_backward = orig
+    assert torch.allclose(tr.grad, whole, rtol=0, atol=2e-6 * float(whole.abs().max()))    # float atomics: equal up to summation order
+    d_eps = seen['d_eps']
+    for split in ([(0, L + 1)], [(0, 0), (1, L), (L + 1, L + 1)], [(s, s) for s in range(L + 2)]):
+        tr.grad.zero_()
+        final_from = tr.theta.numel()
+        for first, last in split:
+            tr.h.train_backward_stages(d_eps, tr.grad, first, last)
+            torch.cuda.synchronize()
+            if 1 <= last <= L:                                           # blocks >= L-last are final now
+                lo = tr.h.param_offset(f'egnn.e_block_{L - last}.gcl_0.edge_mlp.0.weight')[0]
+                assert torch.allclose(tr.grad[lo:], whole[lo:], rtol=0, atol=1e-6 * float(whole.abs().max()))
+                final_from = lo
+        assert torch.allclose(tr.grad, whole, rtol=0, atol=2e-6 * float(whole.abs().max())), split
+    chunks = tr.grad_chunks()
+    assert chunks[0][2] == tr.theta.numel() and chunks[-1][1] == 0 and chunks[-1][0] == L + 1
+    with pytest.raises(hip_backend.CmdgenError):
+        tr.h.train_backward_stages(d_eps, tr.grad, 3, 2)
+
+
+def test_sample_and_analyze_given_pocket_reports_type_kl(tmp_path):
+    """Validation sampling (lightning_modules.py:337-382): n_samples pockets of a dataset, sampled phar types and
+    returned pocket types against the training histograms.  The pocket types come back exactly as they went in, so
+    their KL equals that of the dataset's own composition."""
+    from cmdgen_amd.dataset import ProcessedLigandPharPocketDataset, write_synthetic_npz
+    model, tr, data, g6 = build_trainer()
+    write_synthetic_npz(tmp_path / 'val.npz', n_complexes=6, seed=3)
+    ds = ProcessedLigandPharPocketDataset(tmp_path / 'val.npz')
+    model.eval()
+    torch.manual_seed(0)
+    out = model.sample_and_analyze_given_pocket(5, ds, batch_size=2, timesteps=5)
+    assert set(out) == {'kl_div_atom_types', 'kl_div_residue_types'} and all(np.isfinite(v) for v in out.values())
+    types = np.concatenate([ds[i % len(ds)]['pocket_one_hot'].argmax(1).numpy() for i in (0, 1, 2, 3, 4)])
+    assert abs(out['kl_div_residue_types'] - model._type_kl(model.dataset_info['aa_hist'], model.dataset_info['aa_encoder'], types)) < 1e-9
+
+
 def test_training_reduces_the_loss_on_a_fixed_batch():
     """20 steps with fresh t / noise per step on one synthetic batch: the objective must fall (sanity of the whole loop)."""
     model, tr, data, g6 = build_trainer()
@@ -274,7 +328,7 @@ def test_train_driver_end_to_end(tmp_path):
                            'aggregation_method': 'sum', 'normalization_factor': 100},
            'diffusion_params': {'diffusion_steps': 500, 'diffusion_noise_schedule': 'polynomial_2',
                                 'diffusion_noise_precision': 1e-5, 'diffusion_loss_type': 'l2', 'normalize_factors': [1, 4]},
-           'eval_epochs': 50, 'eval_params': {'n_eval_samples': 10, 'eval_batch_size': 10}}
+           'eval_epochs': 2, 'eval_params': {'n_eval_samples': 7, 'eval_batch_size': 4}}
     cfg_path = tmp_path / 'cfg.yml'
     cfg_path.write_text(yaml.safe_dump(cfg))
     out = train_cli.main(['--config', str(cfg_path)])
@@ -283,6 +337,10 @@ def test_train_driver_end_to_end(tmp_path):
     assert (ckdir / 'last.ckpt').exists() and len(list(ckdir.glob('best-model-epoch=*.ckpt'))) == 1
     rows = [json.loads(x) for x in (tmp_path / 'logs' / 'unit' / 'metrics.jsonl').read_text().splitlines()]
     assert [r['epoch'] for r in rows] == [0, 1] and all(np.isfinite(r['loss/val']) for r in rows)
+    # validation sampling on rank 0 every eval_epochs (validation_epoch_end, lightning_modules.py:289-304): epoch 1 only
+    assert 'kl_div_atom_types/val' not in rows[0]
+    assert np.isfinite(rows[1]['kl_div_atom_types/val']) and np.isfinite(rows[1]['kl_div_residue_types/val'])
+    assert rows[1]['kl_div_residue_types/val'] >= 0 and rows[1]['evaluation_s/val'] > 0
     # the sampler loads what the trainer wrote (Lightning checkpoint format) and the weights did move
     best = next(ckdir.glob('best-model-epoch=*.ckpt'))
     model = PharPocketDDPM.load_from_checkpoint(str(best), map_location='cuda').cuda()
