@@ -94,12 +94,19 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def node_flop_per_launch(H, L, nodes, moving):
+def coord_flop_per_launch(H, L, coord_edges, nodes, split_proj):
+    """EquivariantUpdate.coord_model: 2(H^2+H) per listed edge; with split_proj the launch also carries the next
+    block's P|Q projections (4 H^2 per row) in L-1 of the L launches."""
+    return 2.0 * (H * H + H) * coord_edges + (nodes * 4.0 * H * H * (L - 1) / L if split_proj else 0.0)
+
+
+def node_flop_per_launch(H, L, nodes, moving, split_proj=False):
     """Algorithmic FLOP of ONE k_node launch, averaged over the L launches of an evaluation - what the launch needs,
     per row: node_mlp 2*(2H*H) + 2*(H*H) = 6H^2; Q_c 2H^2 on every row, P_c 2H^2 on rows that move only (phar rows:
     pocket rows never receive a coordinate update, egnn_new.py:100-101); P|Q of the next block 4H^2 except in the last
     block (block 0's P|Q belong to k_embed)."""
-    per_block = [nodes * 8.0 * H * H + moving * 2.0 * H * H + (nodes * 4.0 * H * H if l + 1 < L else 0.0) for l in range(L)]
+    per_block = [nodes * 8.0 * H * H + moving * 2.0 * H * H + (nodes * 4.0 * H * H if (l + 1 < L and not split_proj) else 0.0)
+                 for l in range(L)]
     return sum(per_block) / L
 
 
@@ -278,12 +285,14 @@ def main(argv=None):
                   'timing': 'hipGraph of 10 evaluations replayed, HIP events on the launch stream'}
         ev = max(pc['evaluations'], 1)
         units = {'edge_msg': pc['edges'] / ev, 'node': pc['nodes'] / ev, 'edge_coord': pc['edges_phar'] / ev}
+        split = False       # (a split of the next block's P|Q into the coordinate launch was measured and dropped: profiles/r02_f)
         flop_launch = {'edge_msg': 2.0 * (H * H + H) * units['edge_msg'],
-                       'node': node_flop_per_launch(H, L, pc['nodes'] / ev, nl_tot),
-                       'edge_coord': 2.0 * (H * H + H) * units['edge_coord']}
+                       'node': node_flop_per_launch(H, L, pc['nodes'] / ev, nl_tot, split),
+                       'edge_coord': coord_flop_per_launch(H, L, units['edge_coord'], pc['nodes'] / ev, split)}
         kname = {'edge_msg': 'k_edge_msg (GCL.edge_model + attention + segment sum)',
-                 'node': 'k_node (GCL.node_model + P/Q projections for the coord MLP and the next block)',
-                 'edge_coord': 'k_edge_coord (EquivariantUpdate.coord_model)'}
+                 'node': 'k_node (GCL.node_model + P_c|Q_c projections' + ('' if split else ' + P|Q of the next block') + ')',
+                 'edge_coord': 'k_coord_proj (EquivariantUpdate.coord_model + P|Q projections of the next block)' if split
+                               else 'k_edge_coord (EquivariantUpdate.coord_model)'}
         per_kernel = {}
         for k, (ms_k, n_k) in prof.items():
             avg = ms_k / max(n_k, 1)
@@ -334,6 +343,7 @@ def main(argv=None):
                 'kernel_ms_one_evaluation': kt,
                 'steady_state_evaluation': steady,
                 'kernel_source_sha': sha,
+                'launch': {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid')},
             },
             'roofline': {
                 'bound': 'mfma', 'kernel': kname[dom],

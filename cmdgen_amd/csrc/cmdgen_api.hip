@@ -988,6 +988,20 @@ extern "C" int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar,
     return CMDGEN_OK;
 }
 
+extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
+    if (!h || !key || !value) return CMDGEN_EINVAL;
+    if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
+    const std::string k = key;
+    const EvalLaunch a = make_launch(h);
+    if (k == "node_mt") *value = a.node_mt;
+    else if (k == "edge_mt") *value = a.edge_mt;
+    else if (k == "coord_mt") *value = a.coord_mt;
+    else if (k == "edge_grid") *value = a.edge_grid;
+    else if (k == "coord_grid") *value = a.coord_grid;
+    else return fail(h, CMDGEN_EINVAL, "unknown query '%s'", key);
+    return CMDGEN_OK;
+}
+
 extern "C" int cmdgen_time_evaluation(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket, const float* t,
                                       float* eps_phar, int32_t graph_len, int32_t replays, float* mean_ms, cmdgen_stream stream) {
     int rc = check_ready(h); if (rc) return rc;

@@ -75,6 +75,7 @@ SYMBOLS = [
     ('cmdgen_get_counters', C.c_int, [_vp, C.POINTER(Counters), _vp]),
     ('cmdgen_reset_counters', C.c_int, [_vp, _vp]),
     ('cmdgen_profile_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.POINTER(KernelTimes), _vp]),
+    ('cmdgen_query', C.c_int, [_vp, C.c_char_p, _i64p]),
     ('cmdgen_time_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
     ('cmdgen_time_edge_kernel', C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
     ('cmdgen_set_kernel_profiling', C.c_int, [_vp, C.c_int32]),
@@ -419,6 +420,11 @@ class Handle:
         self._check(self.lib.cmdgen_profile_evaluation(self.h, _ptr(xh_phar), _ptr(xh_pocket), _ptr(t), _ptr(eps),
                                                        C.byref(kt), self._stream()), 'cmdgen_profile_evaluation')
         return {n: getattr(kt, n) for n, _ in KernelTimes._fields_}
+
+    def query(self, key: str) -> int:
+        v = C.c_int64(0)
+        self._check(self.lib.cmdgen_query(self.h, key.encode(), C.byref(v)), 'cmdgen_query')
+        return v.value
 
     def time_evaluation(self, xh_phar, xh_pocket, t, graph_len: int = 10, replays: int = 10) -> float:
         """ms per evaluation, graph-replayed and timed with HIP events on the launch stream."""

@@ -302,6 +302,11 @@ int cmdgen_reset_counters(cmdgen_handle* h, cmdgen_stream stream);
 int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket,
                               const float* t, float* eps_phar, cmdgen_kernel_times* out,
                               cmdgen_stream stream);
+/* Launch configuration chosen for the current layout (measurement aid): key = "node_mt" | "edge_mt" | "coord_mt"
+ * (rows per tile of the three MFMA kernels), "edge_grid" | "coord_grid" (workgroups of the persistent-style edge
+ * kernels). */
+int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value);
+
 /* Steady-state timing of one network evaluation (bench.py's trained-geometry micro-benchmark): `graph_len`
  * evaluations of the given inputs are captured into a hipGraph, replayed `replays` times after one warm-up replay
  * and timed with HIP events on the launch stream.  *mean_ms = time per evaluation.  Counters advance as usual. */
