@@ -25,82 +25,76 @@ __device__ __forceinline__ float dsilu(float v) {            // d/dv v*sigmoid(v
     return s * (1.0f + v * (1.0f - s));
 }
 
-#define TG_KT 32
-#define TG_LD (TG_KT + 4)
+// k extent KT of one staged tile is a template parameter: 64 for launches with few workgroups (node-level products: one
+// workgroup per CU, so fewer, fatter barrier-separated iterations and the register prefetch below are what hides the
+// global latency), 32 for big launches (edge-level products: 18 KB of LDS per workgroup keeps 8 of them on a CU, which
+// hides it better - 61 vs 54 TF/s on [25600,256]x[256,256]).
+#define TG_LD(KT) ((KT) + 4)
+#define TG_P(KT) ((KT) / 16)     // float4 fetches per thread and operand tile: 64 rows x KT k over 256 threads
 
+// One 64 x KT operand tile: fetch() brings this thread's TG_P float4 pieces into registers (so the NEXT tile's
+// global loads are in flight while the current tile's MFMAs run - a small GEMM such as a node-level [3.8k,256]x[256,256]
+// product has one workgroup per CU and nothing else to hide that latency behind), put_*() writes them to LDS as [row][k].
+//   operand stored [row][k] (k contiguous): thread -> (row = tid/16 + 16*p, k4 = (tid%16)*4)
+//   operand stored [k][row] (row contiguous): thread -> (k = tid/16 + 16*p, row4 = (tid%16)*4)
 // VEC: every 4-element group a thread loads is 16-byte aligned and entirely in range (host-checked: base pointers,
 // leading dimensions, the contiguous extent and the k chunking are multiples of 4) -> one global_load_dwordx4.
-template <bool TA, bool TB, bool VECA, bool VECB>
-__global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float* __restrict__ A, int lda,
-                                               const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-                                               const float* __restrict__ bias, float alpha, int accumulate, int kchunk,
-                                               int epi, float* __restrict__ aux, int ldaux) {
-    __shared__ __attribute__((aligned(16))) float As[64 * TG_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[64 * TG_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int k_begin = blockIdx.z * kchunk, k_end = min(K, k_begin + kchunk);
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    f32x16 acc;
+template <int KT, bool TRANS, bool VEC>
+__device__ __forceinline__ void tg_fetch(float4 (&v)[TG_P(KT)], const float* __restrict__ G, int ld, int r0, int R, int k0, int k_end) {
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // operand stored [row][k] (k contiguous): thread -> (row = tid/8 + 32*p, k4 = (tid%8)*4), p = 0,1
-    // operand stored [k][row] (row contiguous): thread -> (k = tid/16 + 16*p, row4 = (tid%16)*4), p = 0,1
-    auto stage = [&](float* S, const float* __restrict__ G, int ld, bool trans, bool VEC, int r0, int R, int k0) {
-        if (!trans) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int r = (tid >> 3) + 32 * p, kq = (tid & 7) * 4;
-                const int gr = r0 + r, gk = k0 + kq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gr < R) {
-                    const float* src = G + (size_t)gr * ld + gk;
-                    if (VEC && gk + 3 < k_end) v = *reinterpret_cast<const float4*>(src);
-                    else {
-                        if (gk < k_end) v.x = src[0];
-                        if (gk + 1 < k_end) v.y = src[1];
-                        if (gk + 2 < k_end) v.z = src[2];
-                        if (gk + 3 < k_end) v.w = src[3];
-                    }
+    for (int p = 0; p < TG_P(KT); ++p) {
+        v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!TRANS) {
+            constexpr int TPR = KT / 4, RPP = 256 / TPR;      // threads per row, rows per pass
+            const int gr = r0 + tid / TPR + RPP * p, gk = k0 + (tid % TPR) * 4;
+            if (gr < R) {
+                const float* src = G + (size_t)gr * ld + gk;
+                if (VEC && gk + 3 < k_end) v[p] = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (gk < k_end) v[p].x = src[0];
+                    if (gk + 1 < k_end) v[p].y = src[1];
+                    if (gk + 2 < k_end) v[p].z = src[2];
+                    if (gk + 3 < k_end) v[p].w = src[3];
                 }
-                *reinterpret_cast<float4*>(S + r * TG_LD + kq) = v;
             }
         } else {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int k = (tid >> 4) + 16 * p, rq = (tid & 15) * 4;
-                const int gk = k0 + k, gr = r0 + rq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gk < k_end) {
-                    const float* src = G + (size_t)gk * ld + gr;
-                    if (VEC && gr + 3 < R) v = *reinterpret_cast<const float4*>(src);
-                    else {
-                        if (gr < R) v.x = src[0];
-                        if (gr + 1 < R) v.y = src[1];
-                        if (gr + 2 < R) v.z = src[2];
-                        if (gr + 3 < R) v.w = src[3];
-                    }
+            const int gk = k0 + (tid >> 4) + 16 * p, gr = r0 + (tid & 15) * 4;
+            if (gk < k_end) {
+                const float* src = G + (size_t)gk * ld + gr;
+                if (VEC && gr + 3 < R) v[p] = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (gr < R) v[p].x = src[0];
+                    if (gr + 1 < R) v[p].y = src[1];
+                    if (gr + 2 < R) v[p].z = src[2];
+                    if (gr + 3 < R) v[p].w = src[3];
                 }
-                S[(rq + 0) * TG_LD + k] = v.x; S[(rq + 1) * TG_LD + k] = v.y;
-                S[(rq + 2) * TG_LD + k] = v.z; S[(rq + 3) * TG_LD + k] = v.w;
             }
         }
-    };
-    for (int k0 = k_begin; k0 < k_end; k0 += TG_KT) {
-        stage(As, A, lda, TA, VECA, m0, M, k0);
-        stage(Bs, B, ldb, !TB, VECB, n0, N, k0);
-        __syncthreads();
-#pragma unroll
-        for (int kb = 0; kb < TG_KT / 8; ++kb) {
-            const float4 a = *reinterpret_cast<const float4*>(As + (wm + (lane & 31)) * TG_LD + kb * 8 + 4 * (lane >> 5));
-            const float4 b = *reinterpret_cast<const float4*>(Bs + (wn + (lane & 31)) * TG_LD + kb * 8 + 4 * (lane >> 5));
-            CMDGEN_MFMA32(acc, a.x, b.x);
-            CMDGEN_MFMA32(acc, a.y, b.y);
-            CMDGEN_MFMA32(acc, a.z, b.z);
-            CMDGEN_MFMA32(acc, a.w, b.w);
-        }
-        __syncthreads();
     }
+}
+template <int KT, bool TRANS>
+__device__ __forceinline__ void tg_put_f32(float* S, const float4 (&v)[TG_P(KT)]) {
+    const int tid = threadIdx.x;
+    constexpr int TPR = KT / 4, RPP = 256 / TPR;
+#pragma unroll
+    for (int p = 0; p < TG_P(KT); ++p) {
+        if (!TRANS) *reinterpret_cast<float4*>(S + (tid / TPR + RPP * p) * TG_LD(KT) + (tid % TPR) * 4) = v[p];
+        else {
+            const int k = (tid >> 4) + 16 * p, rq = (tid & 15) * 4;
+            S[(rq + 0) * TG_LD(KT) + k] = v[p].x; S[(rq + 1) * TG_LD(KT) + k] = v[p].y;
+            S[(rq + 2) * TG_LD(KT) + k] = v[p].z; S[(rq + 3) * TG_LD(KT) + k] = v[p].w;
+        }
+    }
+}
+
+// shared epilogue: C (+)= alpha * acc + bias, split-K partials by atomics, the two SiLU epilogues
+__device__ __forceinline__ void tg_epilogue(const f32x16& acc, int M, int N, float* __restrict__ C, int ldc,
+                                            const float* __restrict__ bias, float alpha, int accumulate, int epi,
+                                            float* __restrict__ aux, int ldaux) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int gn = n0 + wn + (lane & 31);
     if (gn >= N) return;
     const float bv = (bias && blockIdx.z == 0) ? bias[gn] : 0.f;
@@ -120,26 +114,13 @@ __global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float*
     }
 }
 
-// The same GEMM with bf16 OPERANDS and fp32 accumulation (v_mfma_f32_32x32x16_bf16: 16x the fp32 matrix rate) - the
-// opt-in mixed-precision policy of the training step (master weights, optimizer state, activations in HBM and all
-// elementwise math stay fp32; operands are rounded to nearest-even bf16 while they are staged into LDS).
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-#define TGH_LD (TG_KT + 8)      // halfs per LDS row: 80 bytes, keeps the 16-byte operand reads aligned
-
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);     // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-
-template <bool TA, bool TB, bool VECA, bool VECB>
-__global__ __launch_bounds__(256) void k_sgemm_bf16(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                    const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-                                                    const float* __restrict__ bias, float alpha, int accumulate, int kchunk,
-                                                    int epi, float* __restrict__ aux, int ldaux) {
-    __shared__ __attribute__((aligned(16))) unsigned short As[64 * TGH_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[64 * TGH_LD];
+template <int KT, bool TA, bool TB, bool VECA, bool VECB>
+__global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float* __restrict__ A, int lda,
+                                               const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                               const float* __restrict__ bias, float alpha, int accumulate, int kchunk,
+                                               int epi, float* __restrict__ aux, int ldaux) {
+    __shared__ __attribute__((aligned(16))) float As[64 * TG_LD(KT)];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * TG_LD(KT)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int k_begin = blockIdx.z * kchunk, k_end = min(K, k_begin + kchunk);
@@ -147,76 +128,96 @@ __global__ __launch_bounds__(256) void k_sgemm_bf16(int M, int N, int K, const f
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    auto stage = [&](unsigned short* S, const float* __restrict__ G, int ld, bool trans, bool VEC, int r0, int R, int k0) {
-        if (!trans) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int r = (tid >> 3) + 32 * p, kq = (tid & 7) * 4;
-                const int gr = r0 + r, gk = k0 + kq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gr < R) {
-                    const float* src = G + (size_t)gr * ld + gk;
-                    if (VEC && gk + 3 < k_end) v = *reinterpret_cast<const float4*>(src);
-                    else {
-                        if (gk < k_end) v.x = src[0];
-                        if (gk + 1 < k_end) v.y = src[1];
-                        if (gk + 2 < k_end) v.z = src[2];
-                        if (gk + 3 < k_end) v.w = src[3];
-                    }
-                }
-                uint2 pk;
-                pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-                pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
-                *reinterpret_cast<uint2*>(S + r * TGH_LD + kq) = pk;
-            }
-        } else {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int k = (tid >> 4) + 16 * p, rq = (tid & 15) * 4;
-                const int gk = k0 + k, gr = r0 + rq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gk < k_end) {
-                    const float* src = G + (size_t)gk * ld + gr;
-                    if (VEC && gr + 3 < R) v = *reinterpret_cast<const float4*>(src);
-                    else {
-                        if (gr < R) v.x = src[0];
-                        if (gr + 1 < R) v.y = src[1];
-                        if (gr + 2 < R) v.z = src[2];
-                        if (gr + 3 < R) v.w = src[3];
-                    }
-                }
-                S[(rq + 0) * TGH_LD + k] = f2bf(v.x); S[(rq + 1) * TGH_LD + k] = f2bf(v.y);
-                S[(rq + 2) * TGH_LD + k] = f2bf(v.z); S[(rq + 3) * TGH_LD + k] = f2bf(v.w);
-            }
-        }
-    };
-    for (int k0 = k_begin; k0 < k_end; k0 += TG_KT) {
-        stage(As, A, lda, TA, VECA, m0, M, k0);
-        stage(Bs, B, ldb, !TB, VECB, n0, N, k0);
+    float4 ra[TG_P(KT)], rb[TG_P(KT)];
+    tg_fetch<KT, TA, VECA>(ra, A, lda, m0, M, k_begin, k_end);
+    tg_fetch<KT, !TB, VECB>(rb, B, ldb, n0, N, k_begin, k_end);
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+        tg_put_f32<KT, TA>(As, ra);
+        tg_put_f32<KT, !TB>(Bs, rb);
         __syncthreads();
+        if (k0 + KT < k_end) {                        // next tile's loads fly during this tile's MFMAs
+            tg_fetch<KT, TA, VECA>(ra, A, lda, m0, M, k0 + KT, k_end);
+            tg_fetch<KT, !TB, VECB>(rb, B, ldb, n0, N, k0 + KT, k_end);
+        }
 #pragma unroll
-        for (int ks = 0; ks < TG_KT / 16; ++ks) {      // lanes 0-31 supply k 0..7, lanes 32-63 k 8..15 of the 16-k step
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (wm + (lane & 31)) * TGH_LD + ks * 16 + 8 * (lane >> 5));
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + (wn + (lane & 31)) * TGH_LD + ks * 16 + 8 * (lane >> 5));
+        for (int kb = 0; kb < KT / 8; ++kb) {
+            const float4 a = *reinterpret_cast<const float4*>(As + (wm + (lane & 31)) * TG_LD(KT) + kb * 8 + 4 * (lane >> 5));
+            const float4 b = *reinterpret_cast<const float4*>(Bs + (wn + (lane & 31)) * TG_LD(KT) + kb * 8 + 4 * (lane >> 5));
+            CMDGEN_MFMA32(acc, a.x, b.x);
+            CMDGEN_MFMA32(acc, a.y, b.y);
+            CMDGEN_MFMA32(acc, a.z, b.z);
+            CMDGEN_MFMA32(acc, a.w, b.w);
+        }
+        __syncthreads();
+    }
+    tg_epilogue(acc, M, N, C, ldc, bias, alpha, accumulate, epi, aux, ldaux);
+}
+
+// The same GEMM with bf16 OPERANDS and fp32 accumulation (v_mfma_f32_32x32x16_bf16: 16x the fp32 matrix rate) - the
+// opt-in mixed-precision policy of the training step (master weights, optimizer state, activations in HBM and all
+// elementwise math stay fp32; operands are rounded to nearest-even bf16 while they are staged into LDS).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define TGH_LD(KT) ((KT) + 8)   // halfs per LDS row: keeps the 16-byte operand reads aligned
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);     // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+template <int KT, bool TRANS>
+__device__ __forceinline__ void tg_put_bf16(unsigned short* S, const float4 (&v)[TG_P(KT)]) {
+    const int tid = threadIdx.x;
+    constexpr int TPR = KT / 4, RPP = 256 / TPR;
+#pragma unroll
+    for (int p = 0; p < TG_P(KT); ++p) {
+        if (!TRANS) {
+            uint2 pk;
+            pk.x = (unsigned)f2bf(v[p].x) | ((unsigned)f2bf(v[p].y) << 16);
+            pk.y = (unsigned)f2bf(v[p].z) | ((unsigned)f2bf(v[p].w) << 16);
+            *reinterpret_cast<uint2*>(S + (tid / TPR + RPP * p) * TGH_LD(KT) + (tid % TPR) * 4) = pk;
+        } else {
+            const int k = (tid >> 4) + 16 * p, rq = (tid & 15) * 4;
+            S[(rq + 0) * TGH_LD(KT) + k] = f2bf(v[p].x); S[(rq + 1) * TGH_LD(KT) + k] = f2bf(v[p].y);
+            S[(rq + 2) * TGH_LD(KT) + k] = f2bf(v[p].z); S[(rq + 3) * TGH_LD(KT) + k] = f2bf(v[p].w);
+        }
+    }
+}
+
+template <int KT, bool TA, bool TB, bool VECA, bool VECB>
+__global__ __launch_bounds__(256) void k_sgemm_bf16(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                    const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                    const float* __restrict__ bias, float alpha, int accumulate, int kchunk,
+                                                    int epi, float* __restrict__ aux, int ldaux) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[64 * TGH_LD(KT)];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[64 * TGH_LD(KT)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int k_begin = blockIdx.z * kchunk, k_end = min(K, k_begin + kchunk);
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 ra[TG_P(KT)], rb[TG_P(KT)];
+    tg_fetch<KT, TA, VECA>(ra, A, lda, m0, M, k_begin, k_end);
+    tg_fetch<KT, !TB, VECB>(rb, B, ldb, n0, N, k_begin, k_end);
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+        tg_put_bf16<KT, TA>(As, ra);
+        tg_put_bf16<KT, !TB>(Bs, rb);
+        __syncthreads();
+        if (k0 + KT < k_end) {
+            tg_fetch<KT, TA, VECA>(ra, A, lda, m0, M, k0 + KT, k_end);
+            tg_fetch<KT, !TB, VECB>(rb, B, ldb, n0, N, k0 + KT, k_end);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KT / 16; ++ks) {      // lanes 0-31 supply k 0..7, lanes 32-63 k 8..15 of the 16-k step
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (wm + (lane & 31)) * TGH_LD(KT) + ks * 16 + 8 * (lane >> 5));
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + (wn + (lane & 31)) * TGH_LD(KT) + ks * 16 + 8 * (lane >> 5));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
         __syncthreads();
     }
-    const int gn = n0 + wn + (lane & 31);
-    if (gn >= N) return;
-    const float bv = (bias && blockIdx.z == 0) ? bias[gn] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gm = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (gm >= M) continue;
-        float* c = C + (size_t)gm * ldc + gn;
-        float v = alpha * acc[r] + bv;
-        if (gridDim.z > 1) { atomicAdd(c, v); continue; }
-        if (accumulate) v += *c;
-        if (epi == 2) v *= dsilu(aux[(size_t)gm * ldaux + gn]);
-        *c = v;
-        if (epi == 1) aux[(size_t)gm * ldaux + gn] = silu_exact(v);
-    }
+    tg_epilogue(acc, M, N, C, ldc, bias, alpha, accumulate, epi, aux, ldaux);
 }
 
 // split_k: 0 = choose so that the launch fills the chip (wgrad: few output tiles, K = thousands of rows); 1 = none
@@ -233,7 +234,7 @@ void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda
     }
     int kchunk = K, z = 1;
     if (split_k > 1) {
-        kchunk = ((K + split_k - 1) / split_k + TG_KT - 1) / TG_KT * TG_KT;
+        kchunk = ((K + split_k - 1) / split_k + 63) / 64 * 64;
         z = (K + kchunk - 1) / kchunk;
     }
     // split-K partials are combined with atomics: the destination must already hold the value to add to
@@ -241,14 +242,17 @@ void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda
     const int acc = accumulate ? 1 : 0;
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool va = al(A) && (lda % 4 == 0), vb = al(B) && (ldb % 4 == 0);      // weights inside the flat buffer may be unaligned
-#define SG(TA_, TB_, VA_, VB_) do { if (bf16) hipLaunchKernelGGL((k_sgemm_bf16<TA_, TB_, VA_, VB_>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk, z > 1 ? 0 : epi, aux, ldaux); \
-        else hipLaunchKernelGGL((k_sgemm<TA_, TB_, VA_, VB_>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk, z > 1 ? 0 : epi, aux, ldaux); } while (0)
+    const bool fat = (long)grid.x * grid.y * grid.z < 1024;      // few workgroups: 64-wide k tiles (see TG_LD)
+#define SGK(KT_, TA_, TB_, VA_, VB_) do { if (bf16) hipLaunchKernelGGL((k_sgemm_bf16<KT_, TA_, TB_, VA_, VB_>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk, z > 1 ? 0 : epi, aux, ldaux); \
+        else hipLaunchKernelGGL((k_sgemm<KT_, TA_, TB_, VA_, VB_>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, acc, kchunk, z > 1 ? 0 : epi, aux, ldaux); } while (0)
+#define SG(TA_, TB_, VA_, VB_) do { if (fat) SGK(64, TA_, TB_, VA_, VB_); else SGK(32, TA_, TB_, VA_, VB_); } while (0)
 #define SG2(TA_, TB_) do { if (va && vb) SG(TA_, TB_, true, true); else if (va) SG(TA_, TB_, true, false); \
                            else if (vb) SG(TA_, TB_, false, true); else SG(TA_, TB_, false, false); } while (0)
     if (!ta && tb) SG2(false, true); else if (!ta && !tb) SG2(false, false);
     else if (ta && !tb) SG2(true, false); else SG2(true, true);
 #undef SG2
 #undef SG
+#undef SGK
 }
 
 // ------------------------------------------------------------------------------------
