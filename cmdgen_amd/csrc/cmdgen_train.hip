@@ -8,6 +8,12 @@ void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float*
 void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                   int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s,
                   int epi = 0, float* aux = nullptr, int ldaux = 0, bool bf16 = false);
+struct WgradBatch {               // kernels_train.hip: up to 8 weight gradients dW (+)= dY^T X (+ bias gradients) in one launch
+    const float* dy[8]; const float* x[8]; float* dw[8]; float* db[8];
+    int M[8], N[8], lddy[8], ldx[8], ldw[8];
+    int n;
+};
+void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s);
 void tr_silu(const float* in, float* out, size_t n, hipStream_t s);
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
 void tr_scale(float* x, float a, size_t n, hipStream_t s);
@@ -340,6 +346,14 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     const ParamTable& tb = t->tab;
     const size_t NH = (size_t)N * H;
     auto bias_grad = [&](const PRef& r, int M, const float* dy, int ld) { tr_colsum(M, r.out, dy, ld, nullptr, grad + r.b, 1, s); };
+    // node-level weight (and bias) gradients of a block are collected and launched together (cmdgen_wgrad_group)
+    WgradBatch wb; wb.n = 0;
+    auto defer_wgrad = [&](const PRef& r, int col0, int in, const float* dy, const float* x, bool with_bias) {
+        const int q = wb.n++;
+        wb.dy[q] = dy; wb.x[q] = x; wb.dw[q] = grad + r.w + col0; wb.db[q] = (with_bias && r.has_bias) ? grad + r.b : nullptr;
+        wb.M[q] = r.out; wb.N[q] = in; wb.lddy[q] = r.out; wb.ldx[q] = in; wb.ldw[q] = r.in;
+    };
+    auto flush_wgrads = [&]() { cmdgen_wgrad_group(wb, N, g_bf16, s); wb.n = 0; };
     if (first_stage == 0) {
     // readout
     HIPCHK(h, hipMemsetAsync(t->dX, 0, (size_t)N * 4 * sizeof(float), s));
@@ -389,8 +403,12 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dacc, Nm, t->dphi, t->dcd, s);
         tr_colsum(Ec, H, act7, H, t->dphi, grad + b.c4.w, 1, s);                      // d coord_mlp.4 (c2 = act7)
         tr_outer_silu_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, s);          // actB <- dpre7
-        linear_wgrad(grad, b.c2, 0, H, Ec, t->actB, H, act6, H, s);                   // c1 = act6
-        bias_grad(b.c2, Ec, t->actB, H);
+        {   // weight and bias gradient of coord_mlp.2 in one launch (c1 = act6)
+            WgradBatch one; one.n = 1;
+            one.dy[0] = t->actB; one.x[0] = act6; one.dw[0] = grad + b.c2.w; one.db[0] = grad + b.c2.b;
+            one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.c2.in;
+            cmdgen_wgrad_group(one, Ec, g_bf16, s);
+        }
         linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
         HIPCHK(h, hipMemsetAsync(t->dP, 0, NH * sizeof(float), s));
         HIPCHK(h, hipMemsetAsync(t->dQ, 0, NH * sizeof(float), s));
@@ -400,18 +418,16 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         tr_colsum(Ec, H, t->actA, H, w.cd0, grad + b.c0.w + 2 * H + 1, ld1, s);       // d0 column
         tr_rowdot(Ec, H, t->actA, theta + b.c0.w + 2 * H, ld1, t->dr, s);
         tr_geom_bwd(Ec, w.crow, w.ccol, Xl, d.norm_constant, t->dcd, t->dr, Nm, t->dX, s);
-        bias_grad(b.c0, N, t->dP, H);
-        linear_wgrad(grad, b.c0, 0, H, N, t->dP, H, hn, H, s);
-        linear_wgrad(grad, b.c0, H, H, N, t->dQ, H, hn, H, s);
         linear_dgrad(theta, b.c0, 0, H, N, t->dP, H, t->dh, H, true, s);
         linear_dgrad(theta, b.c0, H, H, N, t->dQ, H, t->dh, H, true, s);
         // ---- node model: h_{l+1} = h_l + W4 SiLU(W3 [h_l | aggn] + b3) + b4 ; dh holds dL/dh_{l+1}
-        linear_wgrad(grad, b.n2, 0, H, N, t->dh, H, nact, H, s);
-        bias_grad(b.n2, N, t->dh, H);
+        // weight / bias gradients of coord_mlp.0 (both halves) and node_mlp.2: one grouped launch, while dP, dQ and dh
+        // still hold what they are the gradients of (dP / dQ are reused by the edge model below, dh moves on to dL/dh_l)
+        defer_wgrad(b.c0, 0, H, t->dP, hn, true);
+        defer_wgrad(b.c0, H, H, t->dQ, hn, false);
+        defer_wgrad(b.n2, 0, H, t->dh, nact, true);
+        flush_wgrads();
         linear_dgrad(theta, b.n2, 0, H, N, t->dh, H, t->dn, H, false, s, pre3);       // dn <- dn1 * SiLU'(pre3) = dpre3
-        bias_grad(b.n0, N, t->dn, H);
-        linear_wgrad(grad, b.n0, 0, H, N, t->dn, H, hl, H, s);
-        linear_wgrad(grad, b.n0, H, H, N, t->dn, H, aggn, H, s);
         linear_dgrad(theta, b.n0, 0, H, N, t->dn, H, t->dh, H, true, s);              // dh is now dL/dh_l (residual kept)
         linear_dgrad(theta, b.n0, H, H, N, t->dn, H, t->dagg, H, false, s);
         tr_scale(t->dagg, d.norm_factor, NH, s);
@@ -421,8 +437,12 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             tr_colsum(E, H, act2, H, t->dz, grad + b.att.w, 1, s);
             tr_sum(E, t->dz, grad + b.att.b, s);
         }
-        linear_wgrad(grad, b.e2, 0, H, E, t->actA, H, act1, H, s);                    // m1 = act1
-        bias_grad(b.e2, E, t->actA, H);
+        {   // weight and bias gradient of edge_mlp.2 in one launch (m1 = act1)
+            WgradBatch one; one.n = 1;
+            one.dy[0] = t->actA; one.x[0] = act1; one.dw[0] = grad + b.e2.w; one.db[0] = grad + b.e2.b;
+            one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.e2.in;
+            cmdgen_wgrad_group(one, E, g_bf16, s);
+        }
         linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
         HIPCHK(h, hipMemsetAsync(t->dP, 0, NH * sizeof(float), s));
         HIPCHK(h, hipMemsetAsync(t->dQ, 0, NH * sizeof(float), s));
@@ -433,9 +453,12 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         tr_colsum(E, H, t->actB, H, w.ed0, grad + b.e0.w + 2 * H + 1, ld1, s);
         tr_rowdot(E, H, t->actB, theta + b.e0.w + 2 * H, ld1, t->dr, s);
         tr_geom_bwd(E, w.erow, w.ecol, Xl, d.norm_constant, nullptr, t->dr, Nm, t->dX, s);
-        bias_grad(b.e0, N, t->dP, H);
-        linear_wgrad(grad, b.e0, 0, H, N, t->dP, H, hl, H, s);
-        linear_wgrad(grad, b.e0, H, H, N, t->dQ, H, hl, H, s);
+        // node_mlp.0 (both halves) and edge_mlp.0 (both halves): the second grouped launch of the block
+        defer_wgrad(b.n0, 0, H, t->dn, hl, true);
+        defer_wgrad(b.n0, H, H, t->dn, aggn, false);
+        defer_wgrad(b.e0, 0, H, t->dP, hl, true);
+        defer_wgrad(b.e0, H, H, t->dQ, hl, false);
+        flush_wgrads();
         linear_dgrad(theta, b.e0, 0, H, N, t->dP, H, t->dh, H, true, s);
         linear_dgrad(theta, b.e0, H, H, N, t->dQ, H, t->dh, H, true, s);
     }

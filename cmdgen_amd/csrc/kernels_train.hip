@@ -220,6 +220,117 @@ __global__ __launch_bounds__(256) void k_sgemm_bf16(int M, int N, int K, const f
     tg_epilogue(acc, M, N, C, ldc, bias, alpha, accumulate, epi, aux, ldaux);
 }
 
+// ------------------------------------------------------------------------------------
+// Grouped weight gradients: up to 8 products dW_p (+)= dY_p^T X_p (and, optionally, db_p += column sums of dY_p) in ONE
+// launch.  The node-level weight gradients of a block are seven [256 x 256] products over K = #nodes: each alone is a
+// 16-tile launch that needs split-K to fill the chip and still costs ~23 us of launch + atomic latency; together they
+// are one launch of the same duration.  Operands: dY_p [K][M_p] (lddy), X_p [K][N_p] (ldx), both 16-byte aligned with
+// leading dimensions that are multiples of 4; results are added with float atomics (the destination holds the running
+// gradient).  blockIdx.z = problem * zsplit + k-split.
+// ------------------------------------------------------------------------------------
+struct WgradBatch {
+    const float* dy[8]; const float* x[8]; float* dw[8]; float* db[8];
+    int M[8], N[8], lddy[8], ldx[8], ldw[8];
+    int n;
+};
+
+template <bool BF>
+__global__ __launch_bounds__(256) void k_wgrad_group(WgradBatch g, int K, int kchunk, int zsplit) {
+    constexpr int KT = 64;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 64 * TG_LD(KT)];
+    float* As = smem; float* Bs = smem + 64 * TG_LD(KT);
+    unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* Bh = Ah + 64 * TGH_LD(KT);
+    const int p = blockIdx.z / zsplit, kz = blockIdx.z - p * zsplit;
+    const int M = g.M[p], N = g.N[p];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    if (m0 >= M || n0 >= N) return;
+    const int k_begin = kz * kchunk, k_end = min(K, k_begin + kchunk);
+    if (k_begin >= k_end) return;
+    const float* __restrict__ A = g.dy[p]; const float* __restrict__ B = g.x[p];
+    const int lda = g.lddy[p], ldb = g.ldx[p];
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const bool want_bias = g.db[p] != nullptr && n0 == 0;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 ra[TG_P(KT)], rb[TG_P(KT)];
+    float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);      // this thread's rows m0 + (tid&15)*4 .. +3, its k slots
+    tg_fetch<KT, true, true>(ra, A, lda, m0, M, k_begin, k_end);
+    tg_fetch<KT, true, true>(rb, B, ldb, n0, N, k_begin, k_end);
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+        if (want_bias) {
+#pragma unroll
+            for (int q = 0; q < TG_P(KT); ++q) { colsum.x += ra[q].x; colsum.y += ra[q].y; colsum.z += ra[q].z; colsum.w += ra[q].w; }
+        }
+        if (BF) { tg_put_bf16<KT, true>(Ah, ra); tg_put_bf16<KT, true>(Bh, rb); }
+        else { tg_put_f32<KT, true>(As, ra); tg_put_f32<KT, true>(Bs, rb); }
+        __syncthreads();
+        if (k0 + KT < k_end) {
+            tg_fetch<KT, true, true>(ra, A, lda, m0, M, k0 + KT, k_end);
+            tg_fetch<KT, true, true>(rb, B, ldb, n0, N, k0 + KT, k_end);
+        }
+        if (BF) {
+#pragma unroll
+            for (int ks = 0; ks < KT / 16; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ah + (wm + (lane & 31)) * TGH_LD(KT) + ks * 16 + 8 * (lane >> 5));
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bh + (wn + (lane & 31)) * TGH_LD(KT) + ks * 16 + 8 * (lane >> 5));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < KT / 8; ++kb) {
+                const float4 a = *reinterpret_cast<const float4*>(As + (wm + (lane & 31)) * TG_LD(KT) + kb * 8 + 4 * (lane >> 5));
+                const float4 b = *reinterpret_cast<const float4*>(Bs + (wn + (lane & 31)) * TG_LD(KT) + kb * 8 + 4 * (lane >> 5));
+                CMDGEN_MFMA32(acc, a.x, b.x);
+                CMDGEN_MFMA32(acc, a.y, b.y);
+                CMDGEN_MFMA32(acc, a.z, b.z);
+                CMDGEN_MFMA32(acc, a.w, b.w);
+            }
+        }
+        __syncthreads();
+    }
+    float* C = g.dw[p];
+    const int ldc = g.ldw[p];
+    const int gn = n0 + wn + (lane & 31);
+    if (gn < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (gm < M) atomicAdd(C + (size_t)gm * ldc + gn, acc[r]);
+        }
+    }
+    if (want_bias) {            // 16 threads (tid >> 4) hold partial sums of the same four rows: combine through LDS
+        float* red = smem;       // [16][64]
+        const int rq = (tid & 15) * 4, slot = tid >> 4;
+        red[slot * 64 + rq + 0] = colsum.x; red[slot * 64 + rq + 1] = colsum.y;
+        red[slot * 64 + rq + 2] = colsum.z; red[slot * 64 + rq + 3] = colsum.w;
+        __syncthreads();
+        if (tid < 64 && m0 + tid < M) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += red[q * 64 + tid];
+            atomicAdd(g.db[p] + m0 + tid, sum);
+        }
+    }
+}
+
+void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s) {
+    if (g.n <= 0 || K <= 0) return;
+    int tm = 1, tn = 1;
+    for (int p = 0; p < g.n; ++p) { tm = max(tm, (g.M[p] + 63) / 64); tn = max(tn, (g.N[p] + 63) / 64); }
+    int zsplit = (1024 + tm * tn * g.n - 1) / (tm * tn * g.n);
+    const int max_split = (K + 127) / 128;
+    if (zsplit > max_split) zsplit = max_split;
+    if (zsplit < 1) zsplit = 1;
+    const int kchunk = ((K + zsplit - 1) / zsplit + 63) / 64 * 64;
+    zsplit = (K + kchunk - 1) / kchunk;
+    const dim3 grid(tn, tm, g.n * zsplit), block(256);
+    if (bf16) hipLaunchKernelGGL(k_wgrad_group<true>, grid, block, 0, s, g, K, kchunk, zsplit);
+    else hipLaunchKernelGGL(k_wgrad_group<false>, grid, block, 0, s, g, K, kchunk, zsplit);
+}
+
 // split_k: 0 = choose so that the launch fills the chip (wgrad: few output tiles, K = thousands of rows); 1 = none
 void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                   int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s,
