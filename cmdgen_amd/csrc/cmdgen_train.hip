@@ -31,6 +31,10 @@ void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, co
                       float nc, const float* dacc, int n_moving, float* dphi, float4* dcd, hipStream_t s);
 void tr_geom_bwd(int E, const int* row, const int* col, const float4* X, float nc, const float4* dcd, const float* dr,
                  int n_moving, float* dX, hipStream_t s);
+void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float* g, const float* d0, const float* Wcol, int ldw,
+                      const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ, float* dWcol, float* dX,
+                      float* scratch, hipStream_t s);
+size_t tr_edge_tail_scratch_floats(size_t E, size_t H);
 void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s);
 void tr_scatter_rows(int E, int H, const int* idx, const float* src, float* dst, hipStream_t s);
 void tr_rowdot(int E, int H, const float* X, const float* w, int ldw, float* out, hipStream_t s);
@@ -106,7 +110,7 @@ struct TrainState {
     float *pre1, *pre2, *z, *pre6, *pre7, *phi;
     float *act1, *act2, *act6, *act7;   // SiLU of the above, written by the producing kernel (nothing is recomputed)
     // edge level scratch
-    float *actA, *actB, *r, *rc, *dr, *dz, *dphi;
+    float *actA, *actB, *r, *rc, *dr, *dz, *dphi, *tail_scratch;
     float4 *cd, *dcd;
     // backward node level
     float *dh, *dX, *dacc, *dagg, *dP, *dQ, *dn, *dhfin, *ddec, *ddeca, *dhdyn, *denca_l, *denca_p;
@@ -165,6 +169,7 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
     EA(t->actA, float, em * H); EA(t->actB, float, em * H);
     EA(t->r, float, ec); EA(t->rc, float, ecc); EA(t->dr, float, em); EA(t->dz, float, ec); EA(t->dphi, float, ecc);
     EA(t->cd, float4, ecc); EA(t->dcd, float4, ecc);
+    EA(t->tail_scratch, float, tr_edge_tail_scratch_floats(em, H));
 #undef EA
     t->ecap = ec; t->eccap = ecc;
     return 0;
@@ -412,12 +417,9 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
         HIPCHK(h, hipMemsetAsync(t->dP, 0, NH * sizeof(float), s));
         HIPCHK(h, hipMemsetAsync(t->dQ, 0, NH * sizeof(float), s));
-        tr_scatter_rows(Ec, H, w.crow, t->actA, t->dP, s);
-        tr_scatter_rows(Ec, H, w.ccol, t->actA, t->dQ, s);
-        tr_colsum(Ec, H, t->actA, H, t->rc, grad + b.c0.w + 2 * H, ld1, s);           // radial column
-        tr_colsum(Ec, H, t->actA, H, w.cd0, grad + b.c0.w + 2 * H + 1, ld1, s);       // d0 column
-        tr_rowdot(Ec, H, t->actA, theta + b.c0.w + 2 * H, ld1, t->dr, s);
-        tr_geom_bwd(Ec, w.crow, w.ccol, Xl, d.norm_constant, t->dcd, t->dr, Nm, t->dX, s);
+        // adjoints of the gathers, the radial / d0 column gradients, d radial and the geometry adjoint: one pass over dpre6
+        tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
+                         t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, s);
         linear_dgrad(theta, b.c0, 0, H, N, t->dP, H, t->dh, H, true, s);
         linear_dgrad(theta, b.c0, H, H, N, t->dQ, H, t->dh, H, true, s);
         // ---- node model: h_{l+1} = h_l + W4 SiLU(W3 [h_l | aggn] + b3) + b4 ; dh holds dL/dh_{l+1}
@@ -446,13 +448,8 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
         HIPCHK(h, hipMemsetAsync(t->dP, 0, NH * sizeof(float), s));
         HIPCHK(h, hipMemsetAsync(t->dQ, 0, NH * sizeof(float), s));
-        tr_scatter_rows(E, H, w.erow, t->actB, t->dP, s);
-        tr_scatter_rows(E, H, w.ecol, t->actB, t->dQ, s);
-        tr_edge_geom(E, w.erow, w.ecol, Xl, d.norm_constant, t->r, nullptr, s);
-        tr_colsum(E, H, t->actB, H, t->r, grad + b.e0.w + 2 * H, ld1, s);
-        tr_colsum(E, H, t->actB, H, w.ed0, grad + b.e0.w + 2 * H + 1, ld1, s);
-        tr_rowdot(E, H, t->actB, theta + b.e0.w + 2 * H, ld1, t->dr, s);
-        tr_geom_bwd(E, w.erow, w.ecol, Xl, d.norm_constant, nullptr, t->dr, Nm, t->dX, s);
+        tr_edge_tail_bwd(E, H, w.erow, w.ecol, t->actB, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
+                         t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, s);
         // node_mlp.0 (both halves) and edge_mlp.0 (both halves): the second grouped launch of the block
         defer_wgrad(b.n0, 0, H, t->dn, hl, true);
         defer_wgrad(b.n0, H, H, t->dn, aggn, false);

@@ -551,6 +551,110 @@ __global__ void k_geom_bwd(int E, const int* __restrict__ row, const int* __rest
     if (j < n_moving) { float* p = dX + (size_t)j * 4; atomicAdd(p, -gx); atomicAdd(p + 1, -gy); atomicAdd(p + 2, -gz); }
 }
 
+// ------------------------------------------------------------------------------------
+// k_edge_tail_bwd: everything the backward pass does with g = dL/d pre1 [E][H] of an edge list (pre1 = P[row] + Q[col]
+// + w_r r + w_d d0, the first layer of the edge / coordinate MLP), in ONE pass over g instead of seven launches:
+//   dP[row] += g (adjoint of the gather of P; rows are sorted, so a wave sums a receiver's run in registers and adds
+//   once per run), dQ[col] += g (atomics), dW[:, 2H] += sum_e r_e g_e and dW[:, 2H+1] += sum_e d0_e g_e (the radial /
+//   d0 columns of the Linear, strided by ldw), dr_e = g_e . w_r, and the geometry adjoint of k_geom_bwd for that dr_e
+//   (plus dcd_e for the coordinate list) into dX.  A wave takes TAIL_EPW consecutive edges (a workgroup 4 x that).
+// ------------------------------------------------------------------------------------
+#define TAIL_EPW 8              // edges per wave: short serial runs, thousands of waves in flight
+__global__ __launch_bounds__(256) void k_edge_tail_bwd(int E, int H, const int* __restrict__ row, const int* __restrict__ col,
+                                                       const float* __restrict__ g, const float* __restrict__ d0,
+                                                       const float* __restrict__ Wcol /* W + 2H, stride ldw */, int ldw,
+                                                       const float4* __restrict__ X, float norm_constant,
+                                                       const float4* __restrict__ dcd, int n_moving,
+                                                       float* __restrict__ dP, float* __restrict__ dQ,
+                                                       float* __restrict__ scratch /* [workgroups][2][H] */, float* __restrict__ dX) {
+    __shared__ float red[2][4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // a lane owns columns lane, lane + 64, lane + 128, lane + 192: every load / atomic of the wave is one contiguous
+    // 256-byte piece of a row (the shape float atomics run at full rate in, MI355X_MICROARCH.md "Global float atomics")
+    const int NC = (H + 63) / 64;
+    const int e0 = blockIdx.x * (4 * TAIL_EPW) + wave * TAIL_EPW, e1 = min(E, e0 + TAIL_EPW);
+    const int ne = max(e1 - e0, 0);
+    float wr[4], accR[4], accD[4], run[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        wr[q] = (q < NC && c < H) ? Wcol[(size_t)c * ldw] : 0.f;
+        accR[q] = accD[q] = run[q] = 0.f;
+    }
+    // lane l < ne owns edge e0 + l for the per-edge scalars: indices, geometry, and later the geometry adjoint
+    int my_i = -1, my_j = -1; float my_r = 0.f, my_d0 = 0.f, dxl = 0.f, dyl = 0.f, dzl = 0.f;
+    if (lane < ne) {
+        my_i = row[e0 + lane]; my_j = col[e0 + lane]; my_d0 = d0[e0 + lane];
+        const float4 a = X[my_i], b = X[my_j];
+        dxl = a.x - b.x; dyl = a.y - b.y; dzl = a.z - b.z;
+        my_r = dxl * dxl + dyl * dyl + dzl * dzl;
+    }
+    float my_gr = 0.f;
+    int cur = __shfl(my_i, 0);
+#pragma unroll
+    for (int k = 0; k < TAIL_EPW; ++k) {
+        if (k < ne) {                                        // wave-uniform
+            const int e = e0 + k;
+            const int i = __shfl(my_i, k), j = __shfl(my_j, k);
+            const float r = __shfl(my_r, k), dd = __shfl(my_d0, k);
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int c = lane + 64 * q; v[q] = (c < H) ? g[(size_t)e * H + c] : 0.f; }
+            if (i != cur) {                                  // the receiver's run ended: one add per run
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int c = lane + 64 * q; if (c < H) atomicAdd(dP + (size_t)cur * H + c, run[q]); run[q] = 0.f; }
+                cur = i;
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = lane + 64 * q;
+                accR[q] += r * v[q]; accD[q] += dd * v[q]; run[q] += v[q]; dot += v[q] * wr[q];
+                if (c < H) atomicAdd(dQ + (size_t)j * H + c, v[q]);
+            }
+            const float gr = wave_sum(dot);                  // dL/d radial of this edge
+            if (lane == k) my_gr = gr;
+        }
+    }
+    if (ne > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int c = lane + 64 * q; if (c < H) atomicAdd(dP + (size_t)cur * H + c, run[q]); }
+    }
+    if (lane < ne && my_i != my_j) {                         // geometry adjoint, one lane per edge (as k_geom_bwd)
+        const float sq = sqrtf(my_r + 1e-8f), den = sq + norm_constant;
+        float gx = 0.f, gy = 0.f, gz = 0.f, gr = my_gr;
+        if (dcd) {
+            const float4 d = dcd[e0 + lane];
+            gx = d.x / den; gy = d.y / den; gz = d.z / den;
+            const float dden = -(d.x * dxl + d.y * dyl + d.z * dzl) / (den * den);
+            gr += dden * 0.5f / sq;
+        }
+        gx += 2.0f * dxl * gr; gy += 2.0f * dyl * gr; gz += 2.0f * dzl * gr;
+        if (my_i < n_moving) { float* p = dX + (size_t)my_i * 4; atomicAdd(p, gx); atomicAdd(p + 1, gy); atomicAdd(p + 2, gz); }
+        if (my_j < n_moving) { float* p = dX + (size_t)my_j * 4; atomicAdd(p, -gx); atomicAdd(p + 1, -gy); atomicAdd(p + 2, -gz); }
+    }
+    // column sums: per-workgroup partials go to a scratch row (plain stores); k_tail_colsum_reduce adds them up.  (Hundreds
+    // of workgroups adding into the same 2H addresses with float atomics serialise at the memory side.)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { red[0][wave][lane + 64 * q] = accR[q]; red[1][wave][lane + 64 * q] = accD[q]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * H; idx += 256) {
+        const int which = idx / H, c = idx - which * H;
+        scratch[((size_t)blockIdx.x * 2 + which) * H + c] = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
+    }
+}
+// dWcol[which + c * ldw] += sum over workgroups of scratch[wg][which][c]; one workgroup per (which, 64-column group)
+__global__ __launch_bounds__(256) void k_tail_colsum_reduce(int nwg, int H, const float* __restrict__ scratch,
+                                                            float* __restrict__ dWcol, int ldw) {
+    __shared__ float red[4][64];
+    const int which = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float sum = 0.f;
+    if (c < H) for (int w = part; w < nwg; w += 4) sum += scratch[((size_t)w * 2 + which) * H + c];
+    red[part][threadIdx.x & 63] = sum;
+    __syncthreads();
+    if (part == 0 && c < H) dWcol[which + (size_t)c * ldw] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // g[e][c] = s[e] * w[c] * SiLU'(pre[e][c])      (dpre7 from dphi and w5)
 __global__ void k_outer_silu_bwd(int E, int H, const float* __restrict__ s, const float* __restrict__ w,
                                  const float* __restrict__ pre, float* __restrict__ g) {
@@ -769,6 +873,16 @@ void tr_geom_bwd(int E, const int* row, const int* col, const float4* X, float n
                  int n_moving, float* dX, hipStream_t s) {
     if (E) hipLaunchKernelGGL(k_geom_bwd, EW_GRID(E), 0, s, E, row, col, X, nc, dcd, dr, n_moving, dX);
 }
+void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float* g, const float* d0, const float* Wcol, int ldw,
+                      const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ, float* dWcol, float* dX,
+                      float* scratch, hipStream_t s) {
+    if (!E) return;
+    const int nwg = (E + 4 * TAIL_EPW - 1) / (4 * TAIL_EPW);
+    hipLaunchKernelGGL(k_edge_tail_bwd, dim3(nwg), dim3(256), 0, s, E, H, row, col, g, d0, Wcol, ldw, X, nc, dcd, n_moving, dP, dQ,
+                       scratch, dX);
+    hipLaunchKernelGGL(k_tail_colsum_reduce, dim3((H + 63) / 64, 2), dim3(256), 0, s, nwg, H, scratch, dWcol, ldw);
+}
+size_t tr_edge_tail_scratch_floats(size_t E, size_t H) { return ((E + 4 * TAIL_EPW - 1) / (4 * TAIL_EPW)) * 2 * H; }
 void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s) {
     if (E) hipLaunchKernelGGL(k_outer_silu_bwd, ROW_GRID(E), 0, s, E, H, sv, w, pre, g);
 }
