@@ -228,8 +228,8 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
         GET(g + "edge_mlp.2.bias", H); UP(lw.b2);
         if (d.attention) {
             GET(g + "att_mlp.0.weight", H); UP(lw.wa);
-            GET(g + "att_mlp.0.bias", 1); lw.ba = (*v)[0];
-        } else { lw.wa = lw.b2; lw.ba = 0.f; }
+            GET(g + "att_mlp.0.bias", 1); UP(lw.ba);
+        } else { lw.wa = lw.b2; lw.ba = lw.b2; }
         rc = square(g + "node_mlp.0.weight", 2 * H, &lw.W3); if (rc) return rc;
         GET(g + "node_mlp.0.bias", H); UP(lw.b3);
         rc = square(g + "node_mlp.2.weight", H, &lw.W4); if (rc) return rc;

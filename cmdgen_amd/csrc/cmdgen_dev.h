@@ -39,7 +39,7 @@ struct LayerW {                 // device pointers to one EquivariantBlock's pac
     WPack W2;                   // edge_mlp.2 [H][H]
     const float*  b2;
     const float*  wa;           // att_mlp.0 weight [H]
-    float         ba;
+    const float*  ba;           // att_mlp.0 bias [1] (device pointer: the training forward reads it straight from theta)
     // GCL.node_mlp (egnn_new.py:21-24)
     WPack W3;                   // node_mlp.0 [H][2H]  (in = [h | agg])
     const float*  b3;
@@ -154,6 +154,20 @@ struct JointBuf {               // joint-model chain (EnVariationalDiffusion.sam
     ChainState* state;
 };
 
+struct TrainSave {              // activation store of the TRAINING forward (cmdgen_train.hip); every pointer null when sampling.
+    // The fused evaluation kernels write what the backward pass reads, so the training forward IS the sampler's
+    // evaluation (3 launches per block) instead of a layer-by-layer pass.  Per-block arrays: base pointer + l * stride.
+    float *enc1_l, *enca_l, *enc1_p, *enca_p;   // encoder layer 0, pre-activation and SiLU: [Nl][2P], [Np][2R]
+    float *hdyn;                                // [N][dyn] encoder output | time column
+    float *h;                                   // [L+1][N][H] node features entering every block (h[L] = final)
+    float *pre1, *act1, *pre2, *act2, *z;       // edge MLP: [L][ecap][H] x4, attention logit [L][ecap]
+    float *aggn, *pre3, *nact;                  // node MLP: [L][N][H]
+    float *pre6, *act6, *pre7, *act7, *phi;     // coordinate MLP: [L][eccap][H] x4, head output before tanh [L][eccap]
+    float *hfin, *dec1, *deca, *dec_out;        // readout: [N][dyn], phar decoder [Nl][2P] x2, [Nl][P]
+    float *qdec1, *qdeca, *qdec_out;            // residue decoder (joint model) [Np][2R] x2, [Np][R]
+    size_t ecap, eccap;                         // row capacities of the per-block edge arrays
+};
+
 struct EvalLaunch {             // everything one evaluation's launches need (host side)
     Layout lay; Work w; Dims d; SmallW sw;
     const LayerW* layers;       // host array [L]
@@ -162,7 +176,8 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     std::vector<hipEvent_t>* prof_events;  // when non-null: [3] vectors, event pairs around every msg / node / coord launch
     int ablate;                 // timing-only builds of the edge kernel (cmdgen_time_edge_kernel); 0 in production
     int stop_block = -1, stop_stage = 0;   // cmdgen_debug_eval_prefix: stop after stage 1..3 of this block (-1: run everything)
-    int skip_count = 0;         // the sampler's fused step kernel has already run the radius-graph count pass
+    const TrainSave* save = nullptr;   // training forward: keep the activations (see TrainSave)
+    int skip_count = 0;         // 1: the radius-graph count pass has run (fused step kernel); 2: both passes have (training)
     hipStream_t side = nullptr; // when set: k_edge_write runs there, concurrently with k_embed (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };

@@ -5,6 +5,14 @@
 #include "cmdgen_host.h"
 
 void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s);
+void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, const float* t_arr, const float4* coef,
+                        ChainState* chain, float* eps_phar, float* eps_pocket, hipStream_t s, hipEvent_t* ev);
+void cmdgen_launch_nan_fix(const EvalLaunch& a, float* eps_phar, hipStream_t s);
+void cmdgen_launch_save_positions(const EvalLaunch& a, float4* X, hipStream_t s);
+struct RepackFrag { int src_off, ld, out, in, row_split, col_shift; float* dst32; float* dst16; };      // kernels_train.hip
+struct RepackMisc { int src_off, ld, rows, cols; float* dst; };
+void tr_repack(const float* theta, const void* frag_tab, int n_frag, int max_frag4, const void* misc_tab, int n_misc, int max_misc,
+               hipStream_t s);
 void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                   int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s,
                   int epi = 0, float* aux = nullptr, int ldaux = 0, bool bf16 = false);
@@ -116,11 +124,19 @@ struct TrainState {
     float *dh, *dX, *dacc, *dagg, *dP, *dQ, *dn, *dhfin, *ddec, *ddeca, *dhdyn, *denca_l, *denca_p;
     float *vel, *qdec1, *qdeca, *qdec_out, *dqdec, *dqdeca;     // velocity [N][4]; residue decoder (joint model's pocket output)
     float* d_scalar;                    // [4] device scalars (sum of squares, ...)
+    // the fused forward (the sampler's evaluation kernels with save hooks): per-step packed copies of the parameters
+    std::vector<void*> pack_allocs;
+    std::vector<LayerW> layers;         // device pointers: packed fragments + vectors inside theta (rebuilt per call: theta is the caller's)
+    struct PackBlk { float *pq_e32, *pq_e16, *w2_32, *w2_16, *w3_32, *w3_16, *w4_32, *w4_16, *pq_c32, *pq_c16, *w7_32, *w7_16, *rd_e, *rd_c; };
+    std::vector<PackBlk> pack;          // rd_e / rd_c: [2][H] radial column then d0 column of edge_mlp.0 / coord_mlp.0
+    float *emb_wT = nullptr, *embo_wT = nullptr;
+    void *frag_tab = nullptr, *misc_tab = nullptr;
+    int n_frag = 0, n_misc = 0, max_frag4 = 0, max_misc = 0;
 };
 
 void cmdgen_train_free(TrainState* t) {
     if (!t) return;
-    free_pool(t->node_allocs); free_pool(t->edge_allocs);
+    free_pool(t->node_allocs); free_pool(t->edge_allocs); free_pool(t->pack_allocs);
     delete t;
 }
 
@@ -150,6 +166,52 @@ static int ensure_state(cmdgen_handle* h) {
     NA(t->qdec_out, float, Np * d.R); NA(t->dqdec, float, Np * d.R); NA(t->dqdeca, float, Np * 2 * d.R);
     NA(t->d_scalar, float, 4);
 #undef NA
+    {   // packed-parameter buffers and the (offset-based, theta-independent) re-pack tables
+        const ParamTable& tb = t->tab;
+        std::vector<RepackFrag> ft; std::vector<RepackMisc> mt;
+        auto alloc = [&](size_t floats, float** out) -> int {
+            int r = dev_alloc(h, t->pack_allocs, &p, floats * sizeof(float), true); if (!r) *out = (float*)p; return r; };
+        const int ld1 = 2 * (int)H + 2;
+        t->pack.resize(L);
+        for (size_t l = 0; l < L && !rc; ++l) {
+            TrainState::PackBlk& k = t->pack[l];
+            const ParamTable::Blk& b = tb.blk[l];
+            auto frag = [&](const PRef& r, int out, int in, int row_split, int col_shift, float** d32, float** d16) {
+                if (rc) return;
+                rc = alloc((size_t)out * in, d32); if (rc) return;
+                rc = alloc((size_t)out * in, d16); if (rc) return;
+                ft.push_back(RepackFrag{(int)r.w, r.in, out, in, row_split, col_shift, *d32, *d16});
+            };
+            frag(b.e0, 2 * (int)H, (int)H, (int)H, (int)H, &k.pq_e32, &k.pq_e16);      // rows 0..H-1: columns 0..H-1 (-> P); rows H..: columns H..2H-1 (-> Q)
+            frag(b.e2, (int)H, (int)H, 0, 0, &k.w2_32, &k.w2_16);
+            frag(b.n0, (int)H, 2 * (int)H, 0, 0, &k.w3_32, &k.w3_16);
+            frag(b.n2, (int)H, (int)H, 0, 0, &k.w4_32, &k.w4_16);
+            frag(b.c0, 2 * (int)H, (int)H, (int)H, (int)H, &k.pq_c32, &k.pq_c16);
+            frag(b.c2, (int)H, (int)H, 0, 0, &k.w7_32, &k.w7_16);
+            if (!rc) rc = alloc(2 * H, &k.rd_e);
+            if (!rc) rc = alloc(2 * H, &k.rd_c);
+            if (!rc) {
+                mt.push_back(RepackMisc{(int)b.e0.w + 2 * (int)H, ld1, (int)H, 2, k.rd_e});
+                mt.push_back(RepackMisc{(int)b.c0.w + 2 * (int)H, ld1, (int)H, 2, k.rd_c});
+            }
+        }
+        if (!rc) rc = alloc((size_t)H * d.dyn, &t->emb_wT);
+        if (!rc) rc = alloc((size_t)H * d.dyn, &t->embo_wT);
+        if (!rc) {
+            mt.push_back(RepackMisc{(int)tb.emb.w, d.dyn, (int)H, d.dyn, t->emb_wT});       // [H][dyn] -> [dyn][H]
+            mt.push_back(RepackMisc{(int)tb.embo.w, (int)H, d.dyn, (int)H, t->embo_wT});    // [dyn][H] -> [H][dyn]
+            rc = dev_alloc(h, t->pack_allocs, &p, ft.size() * sizeof(RepackFrag), false);
+        }
+        if (!rc) {
+            t->frag_tab = p; hipMemcpy(p, ft.data(), ft.size() * sizeof(RepackFrag), hipMemcpyHostToDevice);
+            rc = dev_alloc(h, t->pack_allocs, &p, mt.size() * sizeof(RepackMisc), false);
+        }
+        if (!rc) { t->misc_tab = p; hipMemcpy(p, mt.data(), mt.size() * sizeof(RepackMisc), hipMemcpyHostToDevice); }
+        if (rc) { cmdgen_train_free(t); return rc; }
+        t->n_frag = (int)ft.size(); t->n_misc = (int)mt.size();
+        for (const RepackFrag& f : ft) t->max_frag4 = std::max(t->max_frag4, f.out * f.in / 4);
+        for (const RepackMisc& m : mt) t->max_misc = std::max(t->max_misc, m.rows * m.cols);
+    }
     h->train = t;
     return 0;
 }
@@ -245,68 +307,43 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     const Work& w = h->work;
     const ParamTable& tb = t->tab;
     const size_t NH = (size_t)N * H;
-    tr_positions(Nl, Np, xh_phar, ldp, xh_pocket, ldq, t->X, s);
-    // encoders (dynamics.py:84-86)
-    linear(theta, tb.pe0, 0, P, Nl, xh_phar + 3, ldp, t->enc1_l, 2 * P, true, false, s);
-    tr_silu(t->enc1_l, t->enca_l, (size_t)Nl * 2 * P, s);
-    linear(theta, tb.pe2, 0, 2 * P, Nl, t->enca_l, 2 * P, t->enc_out, J, true, false, s);
-    linear(theta, tb.re0, 0, R, Np, xh_pocket + 3, ldq, t->enc1_p, 2 * R, true, false, s);
-    tr_silu(t->enc1_p, t->enca_p, (size_t)Np * 2 * R, s);
-    linear(theta, tb.re2, 0, 2 * R, Np, t->enca_p, 2 * R, t->enc_out + (size_t)Nl * J, J, true, false, s);
-    if (d.condition_time) tr_concat_time(N, J, d.dyn, t->enc_out, t_arr, h->lay.node_sample, t->hdyn, s);
-    else HIPCHK(h, hipMemcpyAsync(t->hdyn, t->enc_out, (size_t)N * J * sizeof(float), hipMemcpyDeviceToDevice, s));
-    linear(theta, tb.emb, 0, d.dyn, N, t->hdyn, d.dyn, t->h, H, true, false, s);
+    // The forward pass IS the sampler's fused evaluation (k_embed, then per block k_edge_msg / k_node / k_edge_coord, then
+    // k_readout) with save hooks that keep what the backward pass reads (TrainSave): ~20 launches instead of ~190, GEMMs on
+    // the fragment-streaming tile kernels.  The parameters the optimizer has just updated are re-packed on the device.
+    tr_repack(theta, t->frag_tab, t->n_frag, t->max_frag4, t->misc_tab, t->n_misc, t->max_misc, s);
+    t->layers.assign(L, LayerW{});
     for (int l = 0; l < L; ++l) {
         const ParamTable::Blk& b = tb.blk[l];
-        const float* hl = t->h + (size_t)l * NH;
-        float* hn = t->h + (size_t)(l + 1) * NH;
-        const float4* Xl = t->X + (size_t)l * N;
-        float* pre1 = t->pre1 + (size_t)l * t->ecap * H; float* pre2 = t->pre2 + (size_t)l * t->ecap * H;
-        float* pre6 = t->pre6 + (size_t)l * t->eccap * H; float* pre7 = t->pre7 + (size_t)l * t->eccap * H;
-        float* aggn = t->aggn + (size_t)l * NH; float* pre3 = t->pre3 + (size_t)l * NH;
-        float* act1 = t->act1 + (size_t)l * t->ecap * H; float* act2 = t->act2 + (size_t)l * t->ecap * H;
-        float* act6 = t->act6 + (size_t)l * t->eccap * H; float* act7 = t->act7 + (size_t)l * t->eccap * H;
-        float* nact = t->nact + (size_t)l * NH;
-        tr_edge_geom(E, w.erow, w.ecol, Xl, d.norm_constant, t->r, nullptr, s);
-        tr_edge_geom(Ec, w.crow, w.ccol, Xl, d.norm_constant, t->rc, t->cd, s);
-        // GCL edge model (egnn_new.py:31-47)
-        linear(theta, b.e0, 0, H, N, hl, H, t->P, H, true, false, s);
-        linear(theta, b.e0, H, H, N, hl, H, t->Q, H, false, false, s);
-        tr_edge_pre(E, H, w.erow, w.ecol, t->P, t->Q, theta + b.e0.w, ld1, t->r, w.ed0, pre1, act1, s);
-        linear(theta, b.e2, 0, H, E, act1, H, pre2, H, true, false, s, act2);
-        HIPCHK(h, hipMemsetAsync(aggn, 0, NH * sizeof(float), s));
-        tr_att_msg(E, H, w.erow, act2, d.attention ? theta + b.att.w : nullptr, d.attention ? theta + b.att.b : nullptr,
-                   d.attention, t->z + (size_t)l * t->ecap, aggn, s);
-        tr_scale(aggn, d.norm_factor, NH, s);                                         // 'sum' aggregation / normalization_factor
-        // GCL node model (egnn_new.py:48-58)
-        linear(theta, b.n0, 0, H, N, hl, H, pre3, H, true, false, s);
-        linear(theta, b.n0, H, H, N, aggn, H, pre3, H, false, true, s, nact);
-        HIPCHK(h, hipMemcpyAsync(hn, hl, NH * sizeof(float), hipMemcpyDeviceToDevice, s));
-        linear(theta, b.n2, 0, H, N, nact, H, hn, H, true, true, s);
-        // EquivariantUpdate (egnn_new.py:87-104) on the receivers that move
-        linear(theta, b.c0, 0, H, N, hn, H, t->P, H, true, false, s);
-        linear(theta, b.c0, H, H, N, hn, H, t->Q, H, false, false, s);
-        tr_edge_pre(Ec, H, w.crow, w.ccol, t->P, t->Q, theta + b.c0.w, ld1, t->rc, w.cd0, pre6, act6, s);
-        linear(theta, b.c2, 0, H, Ec, act6, H, pre7, H, true, false, s, act7);
-        HIPCHK(h, hipMemsetAsync(t->accx, 0, (size_t)N * 4 * sizeof(float), s));
-        tr_coord_out(Ec, H, w.crow, act7, theta + b.c4.w, t->cd, d.use_tanh, d.coords_range, t->phi + (size_t)l * t->eccap,
-                     t->accx, s);
-        tr_move(N, h->lay.Nm, Xl, t->accx, d.norm_factor, t->X + (size_t)(l + 1) * N, s);
+        const TrainState::PackBlk& k = t->pack[l];
+        LayerW& lw = t->layers[l];
+        lw.Wpq_e = WPack{(const float4*)k.pq_e32, (const float4*)k.pq_e16}; lw.b1 = theta + b.e0.b; lw.wr_e = k.rd_e; lw.wd_e = k.rd_e + H;
+        lw.W2 = WPack{(const float4*)k.w2_32, (const float4*)k.w2_16}; lw.b2 = theta + b.e2.b;
+        lw.wa = d.attention ? theta + b.att.w : theta + b.e2.b; lw.ba = d.attention ? theta + b.att.b : theta + b.e2.b;
+        lw.W3 = WPack{(const float4*)k.w3_32, (const float4*)k.w3_16}; lw.b3 = theta + b.n0.b;
+        lw.W4 = WPack{(const float4*)k.w4_32, (const float4*)k.w4_16}; lw.b4 = theta + b.n2.b;
+        lw.Wpq_c = WPack{(const float4*)k.pq_c32, (const float4*)k.pq_c16}; lw.b6 = theta + b.c0.b; lw.wr_c = k.rd_c; lw.wd_c = k.rd_c + H;
+        lw.W7 = WPack{(const float4*)k.w7_32, (const float4*)k.w7_16}; lw.b7 = theta + b.c2.b; lw.w5 = theta + b.c4.w;
     }
-    // readout (egnn_new.py:205, dynamics.py:110-127): embedding_out, phar decoder, velocity
-    linear(theta, tb.embo, 0, H, N, t->h + (size_t)L * NH, H, t->hfin, d.dyn, true, false, s);
-    linear(theta, tb.pd0, 0, J, Nl, t->hfin, d.dyn, t->dec1, 2 * P, true, false, s);
-    tr_silu(t->dec1, t->deca, (size_t)Nl * 2 * P, s);
-    linear(theta, tb.pd2, 0, 2 * P, Nl, t->deca, 2 * P, t->dec_out, P, true, false, s);
-    tr_velocity(h->lay.Nm, t->X + (size_t)L * N, t->X, t->vel, s);
-    if (d.joint) tr_center_per_sample(h->lay, t->vel, s);                     // dynamics.py:133-136
-    tr_eps_out(Nl, P, 0, t->vel, t->dec_out, eps_phar, s);
-    if (eps_pocket) {                                                         // residue decoder + pocket velocity (zero unless joint)
-        linear(theta, tb.rd0, 0, J, Np, t->hfin + (size_t)Nl * d.dyn, d.dyn, t->qdec1, 2 * R, true, false, s);
-        tr_silu(t->qdec1, t->qdeca, (size_t)Np * 2 * R, s);
-        linear(theta, tb.rd2, 0, 2 * R, Np, t->qdeca, 2 * R, t->qdec_out, R, true, false, s);
-        tr_eps_out(Np, R, Nl, t->vel, t->qdec_out, eps_pocket, s);
-    }
+    SmallW sw{};
+    sw.pe0_w = theta + tb.pe0.w; sw.pe0_b = theta + tb.pe0.b; sw.pe2_w = theta + tb.pe2.w; sw.pe2_b = theta + tb.pe2.b;
+    sw.pd0_w = theta + tb.pd0.w; sw.pd0_b = theta + tb.pd0.b; sw.pd2_w = theta + tb.pd2.w; sw.pd2_b = theta + tb.pd2.b;
+    sw.re0_w = theta + tb.re0.w; sw.re0_b = theta + tb.re0.b; sw.re2_w = theta + tb.re2.w; sw.re2_b = theta + tb.re2.b;
+    sw.rd0_w = theta + tb.rd0.w; sw.rd0_b = theta + tb.rd0.b; sw.rd2_w = theta + tb.rd2.w; sw.rd2_b = theta + tb.rd2.b;
+    sw.emb_wT = t->emb_wT; sw.emb_b = theta + tb.emb.b; sw.embo_wT = t->embo_wT; sw.embo_b = theta + tb.embo.b;
+    TrainSave sv{};
+    sv.enc1_l = t->enc1_l; sv.enca_l = t->enca_l; sv.enc1_p = t->enc1_p; sv.enca_p = t->enca_p; sv.hdyn = t->hdyn; sv.h = t->h;
+    sv.pre1 = t->pre1; sv.act1 = t->act1; sv.pre2 = t->pre2; sv.act2 = t->act2; sv.z = t->z;
+    sv.aggn = t->aggn; sv.pre3 = t->pre3; sv.nact = t->nact;
+    sv.pre6 = t->pre6; sv.act6 = t->act6; sv.pre7 = t->pre7; sv.act7 = t->act7; sv.phi = t->phi;
+    sv.hfin = t->hfin; sv.dec1 = t->dec1; sv.deca = t->deca; sv.dec_out = t->dec_out;
+    sv.qdec1 = t->qdec1; sv.qdeca = t->qdeca; sv.qdec_out = t->qdec_out;
+    sv.ecap = t->ecap; sv.eccap = t->eccap;
+    a.layers = t->layers.data(); a.sw = sw; a.save = &sv; a.skip_count = 2;
+    if (h->agg_dirty) { HIPCHK(h, hipMemsetAsync(h->work.agg, 0, NH * sizeof(float), s)); h->agg_dirty = false; }
+    cmdgen_launch_eval(a, xh_phar, xh_pocket, t_arr, nullptr, nullptr, eps_phar, eps_pocket, s, nullptr);
+    if (!d.joint) cmdgen_launch_nan_fix(a, eps_phar, s);                    // dynamics.py:129-131 (joint: inside k_vel_com)
+    cmdgen_launch_save_positions(a, t->X, s);
+    (void)Np; (void)ldp; (void)ldq; (void)ld1; (void)P; (void)R; (void)J; (void)w;
     HIPCHK(h, hipGetLastError());
     t->have_forward = true;
     return CMDGEN_OK;

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
                                              const float* __restrict__ xh_phar,
                                              const float* __restrict__ xh_pocket,
                                              const float* __restrict__ t_arr,
-                                             const float4* __restrict__ coef, const ChainState* chain) {
+                                             const float4* __restrict__ coef, const ChainState* chain, TrainSave sv) {
     __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     __shared__ float s_in[MT][CMDGEN_MAX_SMALL];
     __shared__ float s_h1[MT][CMDGEN_MAX_SMALL];
@@ -317,7 +317,12 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         float s = (ph ? pe0b : re0b)[o];
 #pragma unroll 4
         for (int k = 0; k < F; ++k) s = fmaf(s_in[r][k], W[k], s);
-        s_h1[r][o] = silu_f(s);
+        const float act = silu_f(s);
+        s_h1[r][o] = act;
+        if (sv.enc1_l) {                                   // training: layer-0 pre-activation and activation
+            if (ph) { sv.enc1_l[(size_t)n * 2 * F + o] = s; sv.enca_l[(size_t)n * 2 * F + o] = act; }
+            else { sv.enc1_p[(size_t)(n - lay.Nl) * 2 * F + o] = s; sv.enca_p[(size_t)(n - lay.Nl) * 2 * F + o] = act; }
+        }
     }
     lds_barrier();
     // encoder layer 2 -> joint space, then the time column (dynamics.py:92-99)
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
             } else {
                 s = t_arr ? t_arr[lay.node_sample[n]] : t_chain;
             }
+            if (sv.hdyn) sv.hdyn[(size_t)n * d.dyn + j] = s;
         }
         s_h2[r][j] = s;
     }
@@ -361,7 +367,10 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         for (int r = 0; r < MT; ++r) {
             const float s = r < nvalid ? accr[r] : 0.f;
             buf[r * LDA(H) + c] = s;
-            if (r < nvalid) w.h[(size_t)(row0 + r) * H + c] = s;
+            if (r < nvalid) {
+                w.h[(size_t)(row0 + r) * H + c] = s;
+                if (sv.h) sv.h[(size_t)(row0 + r) * H + c] = s;      // h entering block 0
+            }
         }
     }
     lds_barrier();
@@ -391,7 +400,8 @@ template <int H, int MT>
 __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, const int* s_col,
                                                 const float* s_r, const float* s_d0, int ne,
                                                 const float* __restrict__ P, const float* __restrict__ Q,
-                                                const float* __restrict__ wr, const float* __restrict__ wd) {
+                                                const float* __restrict__ wr, const float* __restrict__ wd,
+                                                float* __restrict__ pre_out = nullptr, float* __restrict__ act_out = nullptr) {
     constexpr int LPR = H / 4;                  // lanes per row (float4 each) -> 4 rows per pass
     const int ltid = threadIdx.x % H;           // (dual-group kernels run two groups of H threads)
     const int c4 = ltid % LPR, rsub = ltid / LPR;
@@ -405,10 +415,13 @@ __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, co
             const float4 p = reinterpret_cast<const float4*>(P + (size_t)s_row[e] * H)[c4];
             const float4 q = reinterpret_cast<const float4*>(Q + (size_t)s_col[e] * H)[c4];
             const float r = s_r[e], d0 = s_d0[e];
-            a.x = silu_f(p.x + q.x + wr4.x * r + wd4.x * d0);
-            a.y = silu_f(p.y + q.y + wr4.y * r + wd4.y * d0);
-            a.z = silu_f(p.z + q.z + wr4.z * r + wd4.z * d0);
-            a.w = silu_f(p.w + q.w + wr4.w * r + wd4.w * d0);
+            const float4 pre = make_float4(p.x + q.x + wr4.x * r + wd4.x * d0, p.y + q.y + wr4.y * r + wd4.y * d0,
+                                           p.z + q.z + wr4.z * r + wd4.z * d0, p.w + q.w + wr4.w * r + wd4.w * d0);
+            a.x = silu_f(pre.x); a.y = silu_f(pre.y); a.z = silu_f(pre.z); a.w = silu_f(pre.w);
+            if (pre_out) {                                 // training: rows of the tile in the compact list's order
+                reinterpret_cast<float4*>(pre_out + (size_t)e * H)[c4] = pre;
+                reinterpret_cast<float4*>(act_out + (size_t)e * H)[c4] = a;
+            }
         }
         *reinterpret_cast<float4*>(buf + e * LDA(H) + 4 * c4) = a;
     }
@@ -456,8 +469,8 @@ __device__ __forceinline__ int xcd_tile(int k, int ntiles) {
 // of the compact list.  Persistent-style grid: tiles are taken round-robin until the
 // device-side edge count is exhausted, so the launch geometry is static (graph-capturable).
 // ------------------------------------------------------------------------------------
-template <int H, int MT>
-__global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer, int ablate) {
+template <int H, int MT, bool SAVE>
+__global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer, int ablate, TrainSave sv) {
     __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     __shared__ int s_row[MT], s_col[MT];
     __shared__ float s_r[MT], s_d0[MT], s_att[MT];
@@ -479,18 +492,31 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
             s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
         }
         lds_barrier();
-        if (!(ablate & 2)) build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, lw.wr_e, lw.wd_e);
+        if (!(ablate & 2)) build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, lw.wr_e, lw.wd_e,
+                                                  SAVE ? sv.pre1 + ((size_t)layer * sv.ecap + e0) * H : nullptr,
+                                                  SAVE ? sv.act1 + ((size_t)layer * sv.ecap + e0) * H : nullptr);
         lds_barrier();
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
         if (!(ablate & 4)) tile_gemm<MT, H / 8>(buf, LDA(H), fw, fw, acc, carry);
         lds_barrier();                         // every wave is done reading the A tile
-        acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b2[col]); });   // m_ij
+        acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {                          // m_ij
+            const float pre = v + lw.b2[col], m = silu_f(pre);
+            buf[row * LDA(H) + col] = m;
+            if (SAVE && row < ne) {
+                const size_t o = ((size_t)layer * sv.ecap + e0 + row) * H + col;
+                sv.pre2[o] = pre; sv.act2[o] = m;
+            }
+        });
         lds_barrier();
         if (!(ablate & 16)) {   // attention gate: sigmoid(w_a . m_ij + b_a)
             int r; bool lead;
             const float s = tile_row_dot<H, MT>(buf, lw.wa, r, lead);
-            if (lead) s_att[r] = d.attention ? sigmoid_f(s + lw.ba) : 1.0f;
+            if (lead) {
+                const float zl = s + lw.ba[0];
+                s_att[r] = d.attention ? sigmoid_f(zl) : 1.0f;
+                if (SAVE && d.attention && r < ne) sv.z[(size_t)layer * sv.ecap + e0 + r] = zl;
+            }
         }
         lds_barrier();
         if (!(ablate & 8)) {
@@ -530,9 +556,9 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
 // then, while the new h tile is still in LDS, the projections every later kernel of this
 // evaluation gathers: P_c|Q_c for this block's coord MLP and P|Q for block l+1's edge MLP.
 // ------------------------------------------------------------------------------------
-template <int H, int MT>
+template <int H, int MT, bool SAVE>
 __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
-                                               int layer, int has_next) {
+                                               int layer, int has_next, TrainSave sv) {
     // Tiles of <= 32 rows keep two LDS images: buf0 = h (kept for the residual), buf1 = agg -> T -> h_new,
     // so h and agg are fetched together and the residual needs no second global read.  64-row tiles
     // (66 KB each) use one image so that two workgroups still fit a CU.
@@ -577,6 +603,7 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
                 v = *g;
                 *g = make_float4(0.f, 0.f, 0.f, 0.f);                                     // agg is zero between blocks
                 v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
+                if (SAVE) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * H)[c4] = v;
             }
             *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
         }
@@ -601,6 +628,7 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
             if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
             float4 v = av[pass];
             v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
+            if (SAVE && r < nvalid) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * H)[c4] = v;
             *reinterpret_cast<float4*>(buf0 + r * LDA(H) + 4 * c4) = hv[pass];
             *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
         }
@@ -617,7 +645,14 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
         tile_gemm<MT, H / 8>(buf1, LDA(H), f3b, f4, acc, carry);
     }
     lds_barrier();
-    acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf1[row * LDA(H) + col] = silu_f(v + lw.b3[col]); });
+    acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
+        const float pre = v + lw.b3[col], a = silu_f(pre);
+        buf1[row * LDA(H) + col] = a;
+        if (SAVE && row < nvalid) {
+            const size_t o = ((size_t)layer * lay.N + row0 + row) * H + col;
+            sv.pre3[o] = pre; sv.nact[o] = a;
+        }
+    });
     lds_barrier();
     acc_zero<MT>(acc);
     tile_gemm<MT, H / 8>(buf1, LDA(H), f4, fc, acc, carry);
@@ -629,6 +664,7 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
             const float hold = TWO ? buf0[row * LDA(H) + col] : *hp;
             hn = hold + (v + lw.b4[col]);                                                 // residual (egnn_new.py:57)
             *hp = hn;
+            if (SAVE) sv.h[((size_t)(layer + 1) * lay.N + row0 + row) * H + col] = hn;   // h entering block layer+1
         }
         buf1[row * LDA(H) + col] = hn;
     });
@@ -645,8 +681,8 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
 //   phi = w5 . SiLU(W7 SiLU(W6 [h_i, h_j, r, d0] + b6) + b7)
 //   ACC[l][i] += (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant) * tanh(phi) * coords_range
 // ------------------------------------------------------------------------------------
-template <int H, int MT>
-__global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer) {
+template <int H, int MT, bool SAVE>
+__global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer, TrainSave sv) {
     __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     __shared__ int s_row[MT], s_col[MT];
     __shared__ float s_r[MT], s_d0[MT];
@@ -675,18 +711,28 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
             s_cd[tid][0] = cx; s_cd[tid][1] = cy; s_cd[tid][2] = cz;
         }
         lds_barrier();
-        build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, lw.wr_c, lw.wd_c);
+        build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, lw.wr_c, lw.wd_c,
+                               SAVE ? sv.pre6 + ((size_t)layer * sv.eccap + e0) * H : nullptr,
+                               SAVE ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr);
         lds_barrier();
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
         tile_gemm<MT, H / 8>(buf, LDA(H), fw, fw, acc, carry);
         lds_barrier();
-        acc_foreach<MT>(acc, wave, [&](int row, int col, float v) { buf[row * LDA(H) + col] = silu_f(v + lw.b7[col]); });
+        acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
+            const float pre = v + lw.b7[col], a = silu_f(pre);
+            buf[row * LDA(H) + col] = a;
+            if (SAVE && row < ne) {
+                const size_t o = ((size_t)layer * sv.eccap + e0 + row) * H + col;
+                sv.pre7[o] = pre; sv.act7[o] = a;
+            }
+        });
         lds_barrier();
         {
             int r; bool lead;
             const float s = tile_row_dot<H, MT>(buf, lw.w5, r, lead);
             if (lead) {
+                if (SAVE && r < ne) sv.phi[(size_t)layer * sv.eccap + e0 + r] = s;
                 const float g = d.use_tanh ? tanhf(s) * d.coords_range : s;
                 s_tr[r][0] = s_cd[r][0] * g; s_tr[r][1] = s_cd[r][1] * g; s_tr[r][2] = s_cd[r][2] * g;
             }
@@ -718,7 +764,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, SmallW sw,
                                                  float* __restrict__ eps_phar, float* __restrict__ eps_pocket,
-                                                 ChainState* chain) {
+                                                 ChainState* chain, TrainSave sv) {
     extern __shared__ float s_hrow[];            // [8][H] node rows, then [H][dyn] embedding_out^T
     __shared__ float s_j[8][CMDGEN_MAX_SMALL + 1];
     __shared__ float s_h1[8][CMDGEN_MAX_SMALL];
@@ -745,6 +791,7 @@ __global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, Sma
                 s3 = fmaf(hr[k + 3], wt[(k + 3) * d.dyn], s3);
             }
             s_j[g][j] = (s0 + s1) + (s2 + s3);
+            if (sv.hfin) sv.hfin[(size_t)n * d.dyn + j] = s_j[g][j];
         }
     }
     __syncthreads();
@@ -754,7 +801,12 @@ __global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, Sma
         for (int o = l32; o < 2 * F; o += 32) {
             float s = B0[o];
             for (int k = 0; k < d.J; ++k) s = fmaf(s_j[g][k], W0[(size_t)o * d.J + k], s);
-            s_h1[g][o] = silu_f(s);
+            const float a = silu_f(s);
+            s_h1[g][o] = a;
+            if (sv.dec1) {
+                if (ph) { sv.dec1[(size_t)n * 2 * F + o] = s; sv.deca[(size_t)n * 2 * F + o] = a; }
+                else if (sv.qdec1) { sv.qdec1[(size_t)(n - lay.Nl) * 2 * F + o] = s; sv.qdeca[(size_t)(n - lay.Nl) * 2 * F + o] = a; }
+            }
         }
     }
     __syncthreads();
@@ -766,6 +818,10 @@ __global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, Sma
             float s = B2[o];
             for (int k = 0; k < 2 * F; ++k) s = fmaf(s_h1[g][k], W2[(size_t)o * 2 * F + k], s);
             out[3 + o] = s;
+            if (sv.dec_out) {
+                if (ph) sv.dec_out[(size_t)n * F + o] = s;
+                else if (sv.qdec_out) sv.qdec_out[(size_t)(n - lay.Nl) * F + o] = s;
+            }
         }
         if (l32 == 0) {
             float vx = 0.f, vy = 0.f, vz = 0.f;
@@ -832,19 +888,24 @@ template <int H, int MT> static void launch_embed(const EvalLaunch& a, const flo
     const Dims& d = a.d;
     const size_t shm = sizeof(float) * (size_t)(2 * d.P * d.P + 2 * d.P + d.J * 2 * d.P + d.J + 2 * d.R * d.R + 2 * d.R + d.J * 2 * d.R + d.J);
     hipLaunchKernelGGL((k_embed<H, MT>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
-                       (const ChainState*)chain);
+                       (const ChainState*)chain, a.save ? *a.save : TrainSave{});
 }
+// SAVE variants (training forward) keep the activations; the sampler's instantiations carry no trace of the stores
 template <int H, int MT> static void launch_node(const EvalLaunch& a, int l, hipStream_t s) {
     const int nt = (a.lay.N + MT - 1) / MT;
     const int has_next = l + 1 < a.d.L;
-    hipLaunchKernelGGL((k_node<H, MT>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[has_next ? l + 1 : l],
-                       l, has_next);
+    if (a.save) hipLaunchKernelGGL((k_node<H, MT, true>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
+                                   a.layers[has_next ? l + 1 : l], l, has_next, *a.save);
+    else hipLaunchKernelGGL((k_node<H, MT, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
+                            a.layers[has_next ? l + 1 : l], l, has_next, TrainSave{});
 }
 template <int H, int MT> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
-    hipLaunchKernelGGL((k_edge_msg<H, MT>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate);
+    if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save);
+    else hipLaunchKernelGGL((k_edge_msg<H, MT, false>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{});
 }
 template <int H, int MT> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
-    hipLaunchKernelGGL((k_edge_coord<H, MT>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l);
+    if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save);
+    else hipLaunchKernelGGL((k_edge_coord<H, MT, false>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
 }
 #define MT_DISPATCH(mt, FN, ...) do { if ((mt) == 64) FN<H, 64>(__VA_ARGS__); else if ((mt) == 32) FN<H, 32>(__VA_ARGS__); \
                                       else FN<H, 16>(__VA_ARGS__); } while (0)
@@ -861,7 +922,10 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
 #define PROF(k) do { if (a.prof_events) { hipEvent_t pe; hipEventCreate(&pe); hipEventRecord(pe, s); a.prof_events[k].push_back(pe); } } while (0)
     REC();
     if (!a.skip_count) hipLaunchKernelGGL(k_edge_count, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket);
-    if (a.side) {
+    if (a.skip_count == 2) {          // training forward: the graph was built (and its size read back) before the activation store was sized
+        REC(); REC();
+        MT_DISPATCH(a.node_mt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
+    } else if (a.side) {
         // k_embed reads features only, k_edge_write positions and degrees only: they run side by side, and the first
         // consumer of both (k_edge_msg of block 0) waits for the join
         hipEventRecord(a.ev_fork, s);
@@ -894,7 +958,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     REC();
     const int nn = eps_pocket ? N : a.lay.Nl;
     hipLaunchKernelGGL(k_readout, dim3((nn + 7) / 8), dim3(256), (8 + a.d.dyn) * a.d.H * sizeof(float), s, a.lay, a.w, a.d, a.sw,
-                       eps_phar, eps_pocket, chain);
+                       eps_phar, eps_pocket, chain, a.save ? *a.save : TrainSave{});
     if (a.d.joint) hipLaunchKernelGGL(k_vel_com, dim3(B), dim3(64), 0, s, a.lay, a.w, a.d, eps_phar, eps_pocket);
     REC();
 #undef REC
@@ -910,6 +974,27 @@ void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* 
         case 64:  launch_eval_H<64>(a, xh_phar, xh_pocket, t_arr, coef, chain, eps_phar, eps_pocket, s, ev); break;
         default: break;   // rejected in cmdgen_create
     }
+}
+
+// positions entering every block (and after the last) for ALL nodes, as the backward pass indexes them: X[l][n], l = 0..L
+__global__ void k_save_positions(Layout lay, Work w, Dims d, float4* __restrict__ X) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= lay.N) return;
+    for (int l = 0; l <= d.L; ++l) {
+        float4 p;
+        if (n >= lay.Nm) p = w.XP[n - lay.Nl];
+        else if (l == 0) p = w.X0[n];
+        else if (l < d.L) p = w.XL[(size_t)l * lay.Nm + n];
+        else {
+            const float4 q = (d.L == 1) ? w.X0[n] : w.XL[(size_t)(d.L - 1) * lay.Nm + n];
+            const float4 a = w.ACC[(size_t)(d.L - 1) * lay.Nm + n];
+            p = make_float4(q.x + a.x / d.norm_factor, q.y + a.y / d.norm_factor, q.z + a.z / d.norm_factor, 0.f);
+        }
+        X[(size_t)l * lay.N + n] = p;
+    }
+}
+void cmdgen_launch_save_positions(const EvalLaunch& a, float4* X, hipStream_t s) {
+    hipLaunchKernelGGL(k_save_positions, dim3((a.lay.N + 255) / 256), dim3(256), 0, s, a.lay, a.w, a.d, X);
 }
 
 // radius graph only (the training path builds its own evaluation on top of the same compact lists)

@@ -331,6 +331,47 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s) {
     else hipLaunchKernelGGL(k_wgrad_group<false>, grid, block, 0, s, g, K, kchunk, zsplit);
 }
 
+// ------------------------------------------------------------------------------------
+// Per-step re-pack of the parameters the optimizer has just updated into the layouts the fused evaluation kernels
+// stream (cmdgen_dev.h): every block's six Linears in both MFMA fragment orders, the transposed embedding tables and
+// the radial / d0 weight columns.  Two table-driven launches; ~36 MB of traffic per step.
+// ------------------------------------------------------------------------------------
+struct RepackFrag { int src_off, ld, out, in, row_split, col_shift; float* dst32; float* dst16; };
+struct RepackMisc { int src_off, ld, rows, cols; float* dst; };      // dst[c * rows + r] = theta[src_off + r * ld + c]
+
+__global__ void k_repack_frags(const float* __restrict__ theta, const RepackFrag* __restrict__ tab) {
+    const RepackFrag f = tab[blockIdx.y];
+    const int n4 = f.out * f.in / 4;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    auto fetch = [&](int row, int k) {
+        int r = row, c = k;
+        if (f.row_split && row >= f.row_split) { r = row - f.row_split; c = k + f.col_shift; }
+        const float* src = theta + f.src_off + (size_t)r * f.ld + c;
+        return make_float4(src[0], src[1], src[2], src[3]);
+    };
+    {   // v_mfma_f32_32x32x2_f32 order: [(nt * KB + kb) * 64 + lane] = W[32 nt + (lane & 31)][8 kb + 4 (lane >> 5) .. +3]
+        const int KB = f.in / 8, lane = idx & 63, kb = (idx >> 6) % KB, nt = (idx >> 6) / KB;
+        reinterpret_cast<float4*>(f.dst32)[idx] = fetch(32 * nt + (lane & 31), 8 * kb + 4 * (lane >> 5));
+    }
+    {   // v_mfma_f32_16x16x4_f32 order: [(nt * KB16 + kb) * 64 + lane] = W[16 nt + (lane & 15)][16 kb + 4 (lane >> 4) .. +3]
+        const int KB = f.in / 16, lane = idx & 63, kb = (idx >> 6) % KB, nt = (idx >> 6) / KB;
+        reinterpret_cast<float4*>(f.dst16)[idx] = fetch(16 * nt + (lane & 15), 16 * kb + 4 * (lane >> 4));
+    }
+}
+__global__ void k_repack_misc(const float* __restrict__ theta, const RepackMisc* __restrict__ tab) {
+    const RepackMisc m = tab[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m.rows * m.cols) return;
+    const int c = idx / m.rows, r = idx - c * m.rows;
+    m.dst[idx] = theta[m.src_off + (size_t)r * m.ld + c];
+}
+void tr_repack(const float* theta, const void* frag_tab, int n_frag, int max_frag4, const void* misc_tab, int n_misc, int max_misc,
+               hipStream_t s) {
+    hipLaunchKernelGGL(k_repack_frags, dim3((max_frag4 + 255) / 256, n_frag), dim3(256), 0, s, theta, (const RepackFrag*)frag_tab);
+    hipLaunchKernelGGL(k_repack_misc, dim3((max_misc + 255) / 256, n_misc), dim3(256), 0, s, theta, (const RepackMisc*)misc_tab);
+}
+
 // split_k: 0 = choose so that the launch fills the chip (wgrad: few output tiles, K = thousands of rows); 1 = none
 void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                   int ldc, const float* bias, float alpha, bool accumulate, int split_k, hipStream_t s,
