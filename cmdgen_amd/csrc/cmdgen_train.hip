@@ -159,7 +159,8 @@ static int ensure_state(cmdgen_handle* h) {
     NA(t->nact, float, L * N * H); NA(t->accx, float, N * 4); NA(t->hfin, float, N * d.dyn);
     NA(t->dec1, float, Nl * 2 * d.P); NA(t->deca, float, Nl * 2 * d.P); NA(t->dec_out, float, Nl * d.P);
     NA(t->dh, float, N * H); NA(t->dX, float, N * 4); NA(t->dacc, float, N * 4); NA(t->dagg, float, N * H);
-    NA(t->dP, float, N * H); NA(t->dQ, float, N * H); NA(t->dn, float, N * H); NA(t->dhfin, float, N * d.dyn);
+    NA(t->dP, float, 2 * N * H); t->dQ = t->dP + N * H;      // adjacent: zeroed by one memset
+    NA(t->dn, float, N * H); NA(t->dhfin, float, N * d.dyn);
     NA(t->ddec, float, Nl * d.P); NA(t->ddeca, float, Nl * 2 * d.P); NA(t->dhdyn, float, N * d.dyn);
     NA(t->denca_l, float, Nl * 2 * d.P); NA(t->denca_p, float, Np * 2 * d.R);
     NA(t->vel, float, N * 4); NA(t->qdec1, float, Np * 2 * d.R); NA(t->qdeca, float, Np * 2 * d.R);
@@ -452,8 +453,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             cmdgen_wgrad_group(one, Ec, g_bf16, s);
         }
         linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
-        HIPCHK(h, hipMemsetAsync(t->dP, 0, NH * sizeof(float), s));
-        HIPCHK(h, hipMemsetAsync(t->dQ, 0, NH * sizeof(float), s));
+        HIPCHK(h, hipMemsetAsync(t->dP, 0, (size_t)(t->dQ - t->dP) * sizeof(float) + NH * sizeof(float), s));    // dP and dQ
         // adjoints of the gathers, the radial / d0 column gradients, d radial and the geometry adjoint: one pass over dpre6
         tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
                          t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, s);
@@ -483,8 +483,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             cmdgen_wgrad_group(one, E, g_bf16, s);
         }
         linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
-        HIPCHK(h, hipMemsetAsync(t->dP, 0, NH * sizeof(float), s));
-        HIPCHK(h, hipMemsetAsync(t->dQ, 0, NH * sizeof(float), s));
+        HIPCHK(h, hipMemsetAsync(t->dP, 0, (size_t)(t->dQ - t->dP) * sizeof(float) + NH * sizeof(float), s));    // dP and dQ
         tr_edge_tail_bwd(E, H, w.erow, w.ecol, t->actB, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
                          t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, s);
         // node_mlp.0 (both halves) and edge_mlp.0 (both halves): the second grouped launch of the block

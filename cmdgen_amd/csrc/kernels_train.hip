@@ -684,18 +684,23 @@ __global__ __launch_bounds__(256) void k_edge_tail_bwd(int E, int H, const int* 
         scratch[((size_t)blockIdx.x * 2 + which) * H + c] = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
     }
 }
-// dWcol[which + c * ldw] += sum over workgroups of scratch[wg][which][c]; one workgroup per (which, 64-column group)
+// dWcol[which + c * ldw] += sum over workgroups of scratch[wg][which][c].  grid (H / 64, 2, slices): every workgroup sums
+// one slice of the partial rows for 64 columns (4 rows in flight per column) and adds its result with one atomic.
 __global__ __launch_bounds__(256) void k_tail_colsum_reduce(int nwg, int H, const float* __restrict__ scratch,
                                                             float* __restrict__ dWcol, int ldw) {
     __shared__ float red[4][64];
     const int which = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int per = (nwg + gridDim.z - 1) / gridDim.z;
+    const int w0 = blockIdx.z * per, w1 = min(nwg, w0 + per);
     float sum = 0.f;
-    if (c < H) for (int w = part; w < nwg; w += 4) sum += scratch[((size_t)w * 2 + which) * H + c];
+    if (c < H) {
+#pragma unroll 4
+        for (int w = w0 + part; w < w1; w += 4) sum += scratch[((size_t)w * 2 + which) * H + c];
+    }
     red[part][threadIdx.x & 63] = sum;
     __syncthreads();
-    if (part == 0 && c < H) dWcol[which + (size_t)c * ldw] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (part == 0 && c < H) atomicAdd(dWcol + which + (size_t)c * ldw, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
-
 // g[e][c] = s[e] * w[c] * SiLU'(pre[e][c])      (dpre7 from dphi and w5)
 __global__ void k_outer_silu_bwd(int E, int H, const float* __restrict__ s, const float* __restrict__ w,
                                  const float* __restrict__ pre, float* __restrict__ g) {
@@ -921,7 +926,7 @@ void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float*
     const int nwg = (E + 4 * TAIL_EPW - 1) / (4 * TAIL_EPW);
     hipLaunchKernelGGL(k_edge_tail_bwd, dim3(nwg), dim3(256), 0, s, E, H, row, col, g, d0, Wcol, ldw, X, nc, dcd, n_moving, dP, dQ,
                        scratch, dX);
-    hipLaunchKernelGGL(k_tail_colsum_reduce, dim3((H + 63) / 64, 2), dim3(256), 0, s, nwg, H, scratch, dWcol, ldw);
+    hipLaunchKernelGGL(k_tail_colsum_reduce, dim3((H + 63) / 64, 2, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, dWcol, ldw);
 }
 size_t tr_edge_tail_scratch_floats(size_t E, size_t H) { return ((E + 4 * TAIL_EPW - 1) / (4 * TAIL_EPW)) * 2 * H; }
 void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s) {
