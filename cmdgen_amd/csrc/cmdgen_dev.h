@@ -154,6 +154,13 @@ struct JointBuf {               // joint-model chain (EnVariationalDiffusion.sam
     ChainState* state;
 };
 
+struct PocketCache {            // chain-invariant part of k_embed's output for POCKET rows (conditional sampler): the pocket's
+                                // features never change during a chain and the embedding is affine in the time feature, so
+                                //   h(t) = c + t dh,  P(t) = P0 + t dP,  Q(t) = Q0 + t dQ   (dh, dP, dQ: one row of H values each)
+    const float *c, *P0, *Q0;   // [Np][H] values at t = 0   (null: no cache - every row takes the full path)
+    const float *dh, *dP, *dQ;  // [H]     value(t = 1) - value(t = 0)
+};
+
 struct TrainSave {              // activation store of the TRAINING forward (cmdgen_train.hip); every pointer null when sampling.
     // The fused evaluation kernels write what the backward pass reads, so the training forward IS the sampler's
     // evaluation (3 launches per block) instead of a layer-by-layer pass.  Per-block arrays: base pointer + l * stride.
@@ -177,6 +184,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int ablate;                 // timing-only builds of the edge kernel (cmdgen_time_edge_kernel); 0 in production
     int stop_block = -1, stop_stage = 0;   // cmdgen_debug_eval_prefix: stop after stage 1..3 of this block (-1: run everything)
     const TrainSave* save = nullptr;   // training forward: keep the activations (see TrainSave)
+    PocketCache pcache{};       // conditional chains: pocket tiles of k_embed are an axpy from the cache
     int skip_count = 0;         // 1: the radius-graph count pass has run (fused step kernel); 2: both passes have (training)
     hipStream_t side = nullptr; // when set: k_edge_write runs there, concurrently with k_embed (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -51,6 +51,7 @@ struct cmdgen_handle {
     int chain_K = -1;
     bool chain_steps_out = false;
     unsigned int* d_cog = nullptr;
+    float *pk_c = nullptr, *pk_P0 = nullptr, *pk_Q0 = nullptr, *pk_dh = nullptr, *pk_dP = nullptr, *pk_dQ = nullptr, *pk_t01 = nullptr;   // PocketCache storage
     std::vector<float> user_coef;          // optional host-supplied step table
     int user_coef_K = -1;
     hipGraphExec_t step_graph = nullptr;

@@ -249,7 +249,28 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
                                              const float* __restrict__ xh_phar,
                                              const float* __restrict__ xh_pocket,
                                              const float* __restrict__ t_arr,
-                                             const float4* __restrict__ coef, const ChainState* chain, TrainSave sv) {
+                                             const float4* __restrict__ coef, const ChainState* chain, TrainSave sv,
+                                             PocketCache pc) {
+    if (pc.c != nullptr && (int)blockIdx.x * MT >= lay.Nl) {
+        // A tile of pocket rows inside a conditional chain: nothing but the time feature has changed since the chain
+        // started (SURVEY section 7 "Static structure"), so h, P and Q are one fused multiply-add per element from the
+        // cache built at the chain's start (cmdgen_sample_chain) - no encoder, no embedding, no GEMM.
+        const int row0 = blockIdx.x * MT, nvalid = min(MT, lay.N - row0);
+        const float t = coef[chain->step].w;
+        constexpr int LPR = H / 4;
+        const int c4 = threadIdx.x % LPR, rsub = threadIdx.x / LPR;
+        const float4 dh = reinterpret_cast<const float4*>(pc.dh)[c4], dP = reinterpret_cast<const float4*>(pc.dP)[c4],
+                     dQ = reinterpret_cast<const float4*>(pc.dQ)[c4];
+        auto axpy = [&](const float4& a, const float4& b) { return make_float4(fmaf(t, b.x, a.x), fmaf(t, b.y, a.y), fmaf(t, b.z, a.z), fmaf(t, b.w, a.w)); };
+#pragma unroll 4
+        for (int r = rsub; r < nvalid; r += 4) {
+            const size_t q = (size_t)(row0 + r - lay.Nl) * LPR + c4, o = (size_t)(row0 + r) * LPR + c4;
+            reinterpret_cast<float4*>(w.h)[o] = axpy(reinterpret_cast<const float4*>(pc.c)[q], dh);
+            reinterpret_cast<float4*>(w.P)[o] = axpy(reinterpret_cast<const float4*>(pc.P0)[q], dP);
+            reinterpret_cast<float4*>(w.Q)[o] = axpy(reinterpret_cast<const float4*>(pc.Q0)[q], dQ);
+        }
+        return;
+    }
     __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     __shared__ float s_in[MT][CMDGEN_MAX_SMALL];
     __shared__ float s_h1[MT][CMDGEN_MAX_SMALL];
@@ -888,7 +909,7 @@ template <int H, int MT> static void launch_embed(const EvalLaunch& a, const flo
     const Dims& d = a.d;
     const size_t shm = sizeof(float) * (size_t)(2 * d.P * d.P + 2 * d.P + d.J * 2 * d.P + d.J + 2 * d.R * d.R + 2 * d.R + d.J * 2 * d.R + d.J);
     hipLaunchKernelGGL((k_embed<H, MT>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
-                       (const ChainState*)chain, a.save ? *a.save : TrainSave{});
+                       (const ChainState*)chain, a.save ? *a.save : TrainSave{}, (chain && !t) ? a.pcache : PocketCache{});
 }
 // SAVE variants (training forward) keep the activations; the sampler's instantiations carry no trace of the stores
 template <int H, int MT> static void launch_node(const EvalLaunch& a, int l, hipStream_t s) {
@@ -973,6 +994,40 @@ void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* 
         case 128: launch_eval_H<128>(a, xh_phar, xh_pocket, t_arr, coef, chain, eps_phar, eps_pocket, s, ev); break;
         case 64:  launch_eval_H<64>(a, xh_phar, xh_pocket, t_arr, coef, chain, eps_phar, eps_pocket, s, ev); break;
         default: break;   // rejected in cmdgen_create
+    }
+}
+
+// Chain-start cache of k_embed's pocket rows: stage 0 copies the rows of an evaluation at t = 0, stage 1 turns row 0 of
+// an evaluation at t = 1 into the three difference vectors (identical for every pocket row: the time column of the embedding
+// and its image under the first edge-MLP layer).
+__global__ void k_pocket_cache(Layout lay, Work w, int H, float* __restrict__ c, float* __restrict__ P0, float* __restrict__ Q0,
+                               float* __restrict__ dh, float* __restrict__ dP, float* __restrict__ dQ, int stage) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t base = (size_t)lay.Nl * H;
+    if (stage == 0) {
+        if (i < (size_t)lay.Np * H) { c[i] = w.h[base + i]; P0[i] = w.P[base + i]; Q0[i] = w.Q[base + i]; }
+    } else if (i < (size_t)H) {
+        dh[i] = w.h[base + i] - c[i]; dP[i] = w.P[base + i] - P0[i]; dQ[i] = w.Q[base + i] - Q0[i];
+    }
+}
+template <int H> static void embed_only_H(const EvalLaunch& a, const float* xp, const float* xq, const float* t, hipStream_t s) {
+    MT_DISPATCH(a.node_mt, launch_embed, a, xp, xq, t, nullptr, nullptr, s);
+}
+// builds the cache from two embed-only passes with the time feature pinned to 0 and to 1 (t01: device [2][B])
+void cmdgen_build_pocket_cache(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, const float* t01,
+                               float* c, float* P0, float* Q0, float* dh, float* dP, float* dQ, hipStream_t s) {
+    if (a.lay.Np == 0) return;
+    const int H = a.d.H;
+    for (int stage = 0; stage < 2; ++stage) {
+        const float* t = t01 + (size_t)stage * a.lay.B;
+        switch (H) {
+            case 256: embed_only_H<256>(a, xh_phar, xh_pocket, t, s); break;
+            case 128: embed_only_H<128>(a, xh_phar, xh_pocket, t, s); break;
+            case 64:  embed_only_H<64>(a, xh_phar, xh_pocket, t, s); break;
+            default: break;
+        }
+        const size_t n = stage == 0 ? (size_t)a.lay.Np * H : (size_t)H;
+        hipLaunchKernelGGL(k_pocket_cache, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.lay, a.w, H, c, P0, Q0, dh, dP, dQ, stage);
     }
 }
 
