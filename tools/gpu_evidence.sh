@@ -1,0 +1,27 @@
+#!/bin/bash
+# One pass over everything profiles/ cites (run on the GPU box: gpurun -- 'bash tools/gpu_evidence.sh <tag>').
+# Writes under gpurun_out/<tag>_*; kernel_traffic.json is stamped with the hash of the kernel sources it was measured on.
+tag=${1:-r02_z}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+o=gpurun_out
+set -o pipefail
+run() { echo "== $*" >&2; timeout -k 10 "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: stopping" >&2; exit 1; fi; return $rc; }
+run 700 python -m pytest tests -m gpu -q > $o/${tag}_gpu_tests.log 2>&1; tail -3 $o/${tag}_gpu_tests.log
+run 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $o/${tag}_smoke.txt
+run 300 python bench.py --steps 5 --warmup 2 > $o/${tag}_bench_b64.json 2> $o/${tag}_bench_b64.err
+BARGS="--steps 1 --warmup 0 --no-cpu-baseline --north-star-batch 0"
+run 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --north-star-batch 0 > /dev/null 2>&1
+cp $(find $o/${tag}_stats -name "*kernel_stats.csv" | head -1) $o/${tag}_kernel_stats_b64_T1000.csv; rm -rf $o/${tag}_stats
+run 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py $BARGS > /dev/null 2>&1
+run 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py $BARGS > /dev/null 2>&1
+run 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_ACTIVE_INST_LDS --output-format csv -d $o/pmc_sq -- python3 bench.py $BARGS > /dev/null 2>&1
+run 100 python3 tools/collect_traffic.py $o/pmc_fetch $o/pmc_write --sq $o/pmc_sq --out $o/kernel_traffic.json --command "python3 bench.py $BARGS" > $o/${tag}_pmc_summary.json
+rm -rf $o/pmc_fetch $o/pmc_write $o/pmc_sq
+run 300 python bench.py --batch 256 --steps 2 --warmup 1 --north-star-batch 0 --no-cpu-baseline > $o/${tag}_bench_b256.json 2>/dev/null
+run 300 python bench.py --representation full-atom --batch 64 --timesteps 200 --steps 1 --warmup 1 --north-star-batch 0 --cpu-seconds 8 > $o/${tag}_bench_fullatom_b64.json 2>/dev/null
+run 400 python bench.py --representation full-atom --batch 256 --timesteps 100 --steps 1 --warmup 1 --north-star-batch 0 --no-cpu-baseline > $o/${tag}_bench_fullatom_b256.json 2>/dev/null
+for a in "--batch 64" "--batch 256" "--batch 256 --gemm bf16" "--batch 64 --gemm bf16"; do run 200 python tools/bench_train.py --steps 10 --warmup 3 $a 2>/dev/null | tail -1; done > $o/${tag}_train.jsonl
+run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_tstats -- python3 tools/bench_train.py --steps 4 --warmup 2 > /dev/null 2>&1
+cp $(find $o/${tag}_tstats -name "*kernel_stats.csv" | head -1) $o/${tag}_train_kernel_stats_b64.csv; rm -rf $o/${tag}_tstats
+run 200 python tools/bench_joint.py --batch 64 --timesteps 1000 2>/dev/null | tail -1 > $o/${tag}_joint.json
+echo done
