@@ -9,12 +9,12 @@ run() { echo "== $*" >&2; timeout -k 10 "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc
 run 700 python -m pytest tests -m gpu -q > $o/${tag}_gpu_tests.log 2>&1; tail -3 $o/${tag}_gpu_tests.log
 run 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $o/${tag}_smoke.txt
 run 300 python bench.py --steps 5 --warmup 2 > $o/${tag}_bench_b64.json 2> $o/${tag}_bench_b64.err
-BARGS="--steps 1 --warmup 0 --no-cpu-baseline --north-star-batch 0"
+BARGS="--steps 1 --warmup 0 --timesteps 200 --no-cpu-baseline --north-star-batch 0"     # PMC passes serialise every dispatch: a 200-step chain is plenty
 run 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --north-star-batch 0 > /dev/null 2>&1
 cp $(find $o/${tag}_stats -name "*kernel_stats.csv" | head -1) $o/${tag}_kernel_stats_b64_T1000.csv; rm -rf $o/${tag}_stats
-run 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py $BARGS > /dev/null 2>&1
-run 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py $BARGS > /dev/null 2>&1
-run 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_ACTIVE_INST_LDS --output-format csv -d $o/pmc_sq -- python3 bench.py $BARGS > /dev/null 2>&1
+run 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py $BARGS > /dev/null 2> $o/pmc_fetch.err
+run 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py $BARGS > /dev/null 2> $o/pmc_write.err
+run 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_ACTIVE_INST_LDS --output-format csv -d $o/pmc_sq -- python3 bench.py $BARGS > /dev/null 2> $o/pmc_sq.err
 run 100 python3 tools/collect_traffic.py $o/pmc_fetch $o/pmc_write --sq $o/pmc_sq --out $o/kernel_traffic.json --command "python3 bench.py $BARGS" > $o/${tag}_pmc_summary.json
 rm -rf $o/pmc_fetch $o/pmc_write $o/pmc_sq
 run 300 python bench.py --batch 256 --steps 2 --warmup 1 --north-star-batch 0 --no-cpu-baseline > $o/${tag}_bench_b256.json 2>/dev/null
