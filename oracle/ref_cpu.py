@@ -13,7 +13,10 @@ the real reference (``/root/reference/DiffPhar``) in the build container with
 loss terms, node-count prior), ``make_golden_joint.py`` (joint evaluation, ``sample``,
 RePaint ``inpaint``, schedules, joint loss) and ``make_golden_grad.py`` (the
 reference's autograd gradients of the training loss, which autograd through this
-file reproduces - so it is also the pinned checker of the HIP backward pass).
+file reproduces - so it is also the pinned checker of the HIP backward pass) and
+``make_golden_r2.py`` (per-block intermediates m_ij / e_ij / agg / trans / h / x, the full-atom shape of BASELINE
+configs[4] at Np=366, and chains of a model whose coordinates stay O(10 A), where this file agrees with the reference to
+the north-star's 1e-4 A RMS as an ABSOLUTE bound over K=50 and full K=T=500 chains).
 The scripts are committed next to the vectors.
 
 Op order follows the reference's eager sequence on purpose (same ``cat`` then
