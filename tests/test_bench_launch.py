@@ -38,3 +38,28 @@ def test_launched_by_torchrun_uses_the_given_ranks():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2
+
+
+def test_roofline_flop_accounting_matches_the_kernel():
+    """Per-launch FLOP of k_node = what a launch needs (P_c on moving rows only, no next-block P|Q in the last block):
+    2.897 GFLOP at the headline shape - the figure SQ_INSTS_MFMA x 2048 FLOP gives (profiles/r01_e_pmc…) - not 14 H^2 N."""
+    sys.path.insert(0, ROOT)
+    import bench
+    H, L, N, Nl = 256, 5, 64 * 59, 64 * 15
+    got = bench.node_flop_per_launch(H, L, N, Nl)
+    assert abs(got - 1414758 * 2048) / got < 2e-3
+    assert got < 14 * H * H * N
+    # whole job: L blocks of edge work + 12 H^2 per node + 2 H^2 per moving node, plus the embeddings
+    f = bench.whole_job_flop(H, L, 33, 1000.0, 100.0, N, Nl)
+    assert abs(f - (L * (2 * (H * H + H) * 1100.0 + 12 * H * H * N + 2 * H * H * Nl) + 4 * 33 * H * N)) < 1.0
+
+
+def test_traffic_file_is_tied_to_the_kernel_sources():
+    """profiles/kernel_traffic.json carries the hash of the kernel sources it was measured on; bench.py uses it only
+    when that equals the hash of the sources it runs (a stale PMC number must not be pasted into a new line)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    sha = bench.kernel_source_sha()
+    assert len(sha) == 16 and sha == bench.kernel_source_sha()
+    tj = json.load(open(os.path.join(ROOT, 'profiles', 'kernel_traffic.json')))
+    assert 'kernel_source_sha' in tj and set(tj['hbm_bytes_per_launch']) >= {'edge_msg', 'node', 'edge_coord'}
