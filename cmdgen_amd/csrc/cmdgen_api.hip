@@ -80,6 +80,10 @@ extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle
     d.norm_x = cfg->norm_x; d.norm_h = cfg->norm_h; d.bias_h = cfg->bias_h;
     h->n_cus = prop.multiProcessorCount;
     h->edge_grid = 2 * prop.multiProcessorCount;      // two 66 KB-LDS workgroups per CU at 64-row tiles
+    {   // matrix engine of the sampler's tiles of >= 32 rows (cmdgen_set_gemm_mode); CMDGEN_GEMM=fp32|split overrides the default
+        const char* gm = getenv("CMDGEN_GEMM");
+        h->gemm_split = gm ? (strcmp(gm, "fp32") != 0) : true;
+    }
     *out = h;
     return CMDGEN_OK;
 }
@@ -152,12 +156,42 @@ static std::vector<float> pack_frag16(const float* W, int out, int ld, int c0, i
     return p;
 }
 
+// round-to-nearest-even bf16 of a finite float (weights are finite: cmdgen_load_weights' callers check)
+static inline unsigned short bf16_rne(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_val(unsigned short b) { const uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// same matrix as three bf16 pieces per weight (w = w0 + w1 + w2 exactly up to 2^-24 |w|) in v_mfma_f32_32x32x16_bf16
+// fragment order, the three pieces of a fragment contiguous (cmdgen_split.h)
+static std::vector<unsigned short> pack_split(const float* W, int out, int ld, int c0, int in) {
+    const int NT = out / 32, KB = in / 16;
+    std::vector<unsigned short> p((size_t)NT * KB * 3 * 64 * 8);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const float w = W[(size_t)(32 * nt + (lane & 31)) * ld + c0 + 16 * kb + 8 * (lane >> 5) + j];
+                    const unsigned short h0 = bf16_rne(w); const float r1 = w - bf16_val(h0);
+                    const unsigned short h1 = bf16_rne(r1); const float r2 = r1 - bf16_val(h1);
+                    const unsigned short h2 = bf16_rne(r2);
+                    const size_t base = (((size_t)nt * KB + kb) * 3) * 64 * 8;
+                    p[base + (0 * 64 + lane) * 8 + j] = h0; p[base + (1 * 64 + lane) * 8 + j] = h1; p[base + (2 * 64 + lane) * 8 + j] = h2;
+                }
+    return p;
+}
+
 static int upload_pack(cmdgen_handle* h, const float* W, int out, int in, WPack* wp) {
     const float* dp;
     std::vector<float> p = pack_frag(W, out, in, 0, in);
     int r = upload(h, p, &dp); if (r) return r; wp->w32 = (const float4*)dp;
     p = pack_frag16(W, out, in, 0, in);
     r = upload(h, p, &dp); if (r) return r; wp->w16 = (const float4*)dp;
+    const std::vector<unsigned short> ps = pack_split(W, out, in, 0, in);
+    void* q; r = dev_alloc(h, h->weight_allocs, &q, ps.size() * sizeof(unsigned short), false); if (r) return r;
+    if (hipMemcpy(q, ps.data(), ps.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemcpy H2D failed");
+    wp->ws = q;
     return 0;
 }
 
@@ -412,6 +446,10 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.edge_grid = h->edge_grid; a.coord_grid = h->coord_grid;
     a.prof_events = nullptr; a.ablate = 0;
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
+    a.split = h->gemm_split ? 1 : 0;
+    // split engine: the node kernel's 32-row tiles (two LDS images, h kept for the residual) beat its 64-row ones at every
+    // size measured (B=256 C-alpha 87 vs 132 us, full-atom B=64 134 vs 182 us; profiles/r02_o_tile_sweep_split.txt)
+    if (a.split && a.node_mt == 64 && !getenv("CMDGEN_NODE_MT")) a.node_mt = 32;
     return a;
 }
 
@@ -1009,6 +1047,19 @@ extern "C" int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar,
     return CMDGEN_OK;
 }
 
+extern "C" int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16) {
+    if (!h) return CMDGEN_EINVAL;
+    if (h->gemm_split != (split_bf16 != 0)) {
+        // captured graphs bake the kernel choice in; the pocket cache is rebuilt per chain anyway
+        hipSetDevice(h->device);
+        if (h->own_stream) hipStreamSynchronize(h->own_stream);
+        if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+        if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
+        h->gemm_split = split_bf16 != 0;
+    }
+    return CMDGEN_OK;
+}
+
 extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     if (!h || !key || !value) return CMDGEN_EINVAL;
     if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
@@ -1019,6 +1070,7 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "coord_mt") *value = a.coord_mt;
     else if (k == "edge_grid") *value = a.edge_grid;
     else if (k == "coord_grid") *value = a.coord_grid;
+    else if (k == "gemm_split") *value = a.split;
     else return fail(h, CMDGEN_EINVAL, "unknown query '%s'", key);
     return CMDGEN_OK;
 }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
+#include "cmdgen_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -25,9 +26,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // (0,4),(1,5),(2,6),(3,7): a fixed re-association of the fp32 dot product.
 // ---------------------------------------------------------------------------------
 
-struct WPack {                  // one Linear weight in both MFMA fragment orders (see above / below)
+struct WPack {                  // one Linear weight in the MFMA fragment orders (see above / below)
     const float4* w32;          // v_mfma_f32_32x32x2_f32 order  (64- and 32-row tiles)
     const float4* w16;          // v_mfma_f32_16x16x4_f32 order  (16-row tiles)
+    const void*   ws;           // three bf16 pieces per weight in v_mfma_f32_32x32x16_bf16 order (cmdgen_split.h); null in training
 };
 
 struct LayerW {                 // device pointers to one EquivariantBlock's packed weights
@@ -186,6 +188,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     const TrainSave* save = nullptr;   // training forward: keep the activations (see TrainSave)
     PocketCache pcache{};       // conditional chains: pocket tiles of k_embed are an axpy from the cache
     int skip_count = 0;         // 1: the radius-graph count pass has run (fused step kernel); 2: both passes have (training)
+    int split = 0;              // 1: tiles of >= 32 rows multiply on the bf16 matrix pipe (Eng<MT, true>); never with `save`
     hipStream_t side = nullptr; // when set: k_edge_write runs there, concurrently with k_embed (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -390,6 +393,35 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ ldsA, int ld
 #undef LOADA32
     }
 }
+
+// ---------------------------------------------------------------------------------
+// GEMM engine of a tile kernel.  SP = false: the exact fp32 MFMA path above.  SP = true (MT >= 32): the same tile, the
+// same fp32 LDS image and the same accumulator layout, multiplied on the bf16 matrix pipe as six bf16 products per fp32
+// product (cmdgen_split.h: fp32-accurate, ~2x the delivered matrix rate; the split of the A fragments runs on the VALU
+// in the shadow of the MFMAs, the weights are stored pre-split).
+// ---------------------------------------------------------------------------------
+template <int MT, bool SP> struct Eng;
+template <int MT> struct Eng<MT, false> {
+    typedef FragPtr Frag;
+    typedef BCarry<MT> Carry;
+    static __device__ __forceinline__ Frag frag(const WPack& W, int kb_total8, int kb0_8, int cg) { return frag_ptr<MT>(W, kb_total8, kb0_8, cg); }
+    static __device__ __forceinline__ void prefetch(const Frag& f, Carry& c) { gemm_prefetch<MT>(f, c); }
+    template <int KB8>
+    static __device__ __forceinline__ void gemm(const float* lds, int lda, const Frag cur, const Frag next, TileAcc<MT>& acc, Carry& c) {
+        tile_gemm<MT, KB8>(lds, lda, cur, next, acc, c);
+    }
+};
+template <int MT> struct Eng<MT, true> {
+    static_assert(MT == 64 || MT == 32, "the split path has 32x32 MFMA tiles only");
+    typedef SFragPtr Frag;
+    typedef SCarry Carry;
+    static __device__ __forceinline__ Frag frag(const WPack& W, int kb_total8, int kb0_8, int cg) { return sfrag_ptr(W.ws, kb_total8 / 2, kb0_8 / 2, cg); }
+    static __device__ __forceinline__ void prefetch(const Frag& f, Carry& c) { split_prefetch(f, c); }
+    template <int KB8>
+    static __device__ __forceinline__ void gemm(const float* lds, int lda, const Frag cur, const Frag next, TileAcc<MT>& acc, Carry& c) {
+        tile_gemm_rsplit<MT, KB8 / 2>(lds, lda, cur, next, acc.a, c);
+    }
+};
 
 // Philox4x32-10 (Salmon et al. 2011), counter-based: results depend only on (key, counter).
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

@@ -44,6 +44,7 @@ struct cmdgen_handle {
     int edge_grid = 512, coord_grid = 256;
     int n_cus = 256;
     int node_mt = 64, edge_mt = 64, coord_mt = 64;   // rows per tile, chosen in cmdgen_set_layout
+    bool gemm_split = true;                // tiles of >= 32 rows multiply on the bf16 matrix pipe (cmdgen_set_gemm_mode)
     int64_t* d_gid = nullptr;
     // chain
     std::vector<void*> chain_allocs;

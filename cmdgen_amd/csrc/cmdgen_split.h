@@ -1,0 +1,153 @@
+// cmdgen_split.h - fp32-accurate tile GEMM on the bf16 matrix pipe of gfx950 ("split" engine).
+//
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 FLOP/clk/SIMD) and does not co-execute with
+// VALU work; v_mfma_f32_32x32x16_bf16 runs at 16x that rate and holds the vector issue port for only 8 of
+// its 32 cycles.  An fp32 value is the exact sum of three bf16 values (8 + 8 + 8 significant bits, each
+// piece rounded to nearest-even from the remainder of the previous one):  a = a0 + a1 + a2, |a2| <= 2^-16 |a|.
+// A product of two such values keeps every term down to 2^-16 |a||b| with SIX bf16 products
+//     a b  ~=  a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)            (dropped: <= 3 * 2^-24 |a||b|)
+// each of which is EXACT in the fp32 accumulator (8 x 8 bits), so the only rounding left is the fp32
+// accumulation itself - the same kind and size of error an fp32 fmaf chain makes (measured against fp64 on
+// [.,256] x [256,256] products: max 1.96e-6 / rms 1.87e-7 against 2.42e-6 / 2.24e-7 for the fmaf chain;
+// tools/split_gemm_test.cpp, profiles/r02_m_split_gemm.txt).  Six bf16 MFMAs per 16 k-values cost 192
+// cycles against 512 for the eight fp32 MFMAs they replace; delivered on MI355X (the chip lowers its clock
+// under dense bf16 MFMA): 160-200 TF/s fp32-equivalent for a chain of [64,256] x [256,256] tile products
+// against 157 TF/s PEAK for the fp32 instruction.
+//
+// Layouts
+//   A (LDS): the fp32 tile exactly as the fp32-MFMA kernels keep it (rows x (K + 4) floats).  Every wave
+//            splits the fragments it reads in registers (5.5 VALU operations per element, issued in the
+//            shadow of the MFMAs), so producers and epilogues of the tile kernels do not change and a
+//            64-row tile still needs 66 KB (two workgroups per CU).
+//   B (global, L2-resident): per Linear weight W[out][in]
+//            Ws[((nt * KB16 + kb) * 3 + s) * 64 + lane] = 8 bf16 { W_s[o][k .. k+7] },
+//            o = 32 nt + (lane & 31), k = 16 kb + 8 (lane >> 5): one 16-byte load per lane and piece,
+//            the three pieces of a fragment contiguous (3 KiB per (nt, kb)); split once on the host.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 sbf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 sbf16x2;
+typedef float sf32x16 __attribute__((ext_vector_type(16)));
+
+// two floats -> packed bf16 pair (round to nearest even; v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    const sbf16x2 h = __builtin_convertvector(v, sbf16x2);
+    return __builtin_bit_cast(uint32_t, h);
+}
+// the three bf16 pieces of two floats, each piece packed {a, b}
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    p0 = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);     // exact
+    p1 = cvt_pk_bf16(ra, rb);
+    const float qa = ra - __uint_as_float(p1 << 16), qb = rb - __uint_as_float(p1 & 0xffff0000u);   // exact
+    p2 = cvt_pk_bf16(qa, qb);
+}
+struct SFragPtr { const sbf16x8* p; unsigned ns; };     // a wave's first n-tile; ns = stride between n-tiles (16-byte units)
+
+// cg = the wave's 64-column group; kb16_total = K / 16 of the packed matrix; kb0 = first k-block of this GEMM
+__device__ __forceinline__ SFragPtr sfrag_ptr(const void* Ws, int kb16_total, int kb0, int cg) {
+    const int lane = threadIdx.x & 63;
+    SFragPtr f;
+    f.p = reinterpret_cast<const sbf16x8*>(Ws) + ((size_t)(2 * cg) * kb16_total + kb0) * 192 + lane;
+    f.ns = (unsigned)kb16_total * 192u;
+    return f;
+}
+
+// B fragments in flight: two register sets of [2 n-tiles][3 pieces].  A GEMM enters with its k-block 0 in set 0
+// (fetched by the previous GEMM's last block or by split_prefetch) and leaves with block 0 of `next` there.
+struct SCarry { sbf16x8 b[2][2][3]; };
+
+__device__ __forceinline__ void split_load_set(const sbf16x8* q0, const sbf16x8* q1, sbf16x8 (&dst)[2][3]) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { dst[0][s] = q0[s * 64]; dst[1][s] = q1[s * 64]; }
+}
+__device__ __forceinline__ void split_prefetch(const SFragPtr& f, SCarry& c) { split_load_set(f.p, f.p + f.ns, c.b[0]); }
+
+// eight consecutive k-values of one row (two float4) -> the three bf16 fragments of v_mfma_f32_32x32x16_bf16
+__device__ __forceinline__ void split8(const float4& lo, const float4& hi, sbf16x8& p0, sbf16x8& p1, sbf16x8& p2) {
+    uint32_t a[4], b[4], c[4];
+    split3_pair(lo.x, lo.y, a[0], b[0], c[0]);
+    split3_pair(lo.z, lo.w, a[1], b[1], c[1]);
+    split3_pair(hi.x, hi.y, a[2], b[2], c[2]);
+    split3_pair(hi.z, hi.w, a[3], b[3], c[3]);
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 va = {a[0], a[1], a[2], a[3]}, vb = {b[0], b[1], b[2], b[3]}, vc = {c[0], c[1], c[2], c[3]};
+    p0 = __builtin_bit_cast(sbf16x8, va); p1 = __builtin_bit_cast(sbf16x8, vb); p2 = __builtin_bit_cast(sbf16x8, vc);
+}
+
+// acc[m][n] += A(lds fp32, row stride lda floats) x W^T over KB16 * 16 k-values; MT = 64 or 32 rows, the wave's 64 columns.
+// The k loop is rolled (two k-blocks per iteration, running pointers): fully unrolled, every fragment address of a GEMM
+// becomes a loop-invariant 64-bit value that the persistent tile loops hoist and spill, and seven unrolled GEMMs of the
+// node kernel would not fit the instruction cache.  Per block: the weight fragments of the NEXT block are requested
+// (one block = 24 MFMAs = 768 cycles at 64 rows ahead), the fp32 A fragments of the block after next are read from
+// LDS, and the split of the next block's A fragments is interleaved with this block's MFMAs.
+template <int MT, int KB16>
+__device__ __forceinline__ void tile_gemm_rsplit(const float* ldsA, int lda, const SFragPtr cur, const SFragPtr next,
+                                                 sf32x16 (&acc)[MT / 32][2], SCarry& carry) {
+    static_assert(KB16 % 2 == 0, "K must be a multiple of 32");
+    constexpr int NMT = MT / 32;
+    const int lane = threadIdx.x & 63;
+    const float* ap = ldsA + (lane & 31) * lda + (lane >> 5) * 8;
+    const sbf16x8* q0 = cur.p + 192;                  // k-block 1
+    const sbf16x8* q1 = q0 + cur.ns;
+    float4 raw[2][NMT][2];                            // fp32 fragments of the next two k-blocks
+    sbf16x8 a[2][NMT][3];                             // split fragments of this and the next k-block
+#define RS_LOADA(SET, PTR)                                                                                           \
+    _Pragma("unroll") for (int m = 0; m < NMT; ++m) {                                                                \
+        raw[SET][m][0] = *reinterpret_cast<const float4*>((PTR) + m * 32 * lda);                                     \
+        raw[SET][m][1] = *reinterpret_cast<const float4*>((PTR) + m * 32 * lda + 4); }
+#define RS_SPLIT(DST, SET)                                                                                           \
+    _Pragma("unroll") for (int m = 0; m < NMT; ++m) split8(raw[SET][m][0], raw[SET][m][1], a[DST][m][0], a[DST][m][1], a[DST][m][2]);
+#define RS_MFMAS(AS, BS)                                                                                             \
+    _Pragma("unroll") for (int m = 0; m < NMT; ++m)                                                                  \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                              \
+            /* small terms first; every product is exact in fp32, the accumulation rounds like an fp32 sum */        \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][2], carry.b[BS][n][0], acc[m][n], 0, 0, 0); \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][1], carry.b[BS][n][1], acc[m][n], 0, 0, 0); \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], carry.b[BS][n][2], acc[m][n], 0, 0, 0); \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][1], carry.b[BS][n][0], acc[m][n], 0, 0, 0); \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], carry.b[BS][n][1], acc[m][n], 0, 0, 0); \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], carry.b[BS][n][0], acc[m][n], 0, 0, 0); \
+        }
+    // one MFMA, then a few VALU operations of the next block's split, ...
+#define RS_INTERLEAVE()                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NMT * 12; ++i) {                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
+    RS_LOADA(0, ap)
+    RS_LOADA(1, ap + 16)
+    RS_SPLIT(0, 0)
+    ap += 32;                                         // k-block 2
+#pragma unroll 1
+    for (int kb = 0; kb < KB16; kb += 2) {
+        const bool more = kb + 2 < KB16;              // wave-uniform
+        // ---- even block: a[0] x set 0; request set 1 <- block kb+1; raw[0] <- A block kb+2; split raw[1] -> a[1]
+        split_load_set(q0, q1, carry.b[1]);
+        if (more) { RS_LOADA(0, ap) }
+        __builtin_amdgcn_sched_barrier(0);
+        RS_SPLIT(1, 1)
+        RS_MFMAS(0, 0)
+        RS_INTERLEAVE()
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- odd block: a[1] x set 1; request set 0 <- block kb+2 (or block 0 of the next GEMM); raw[1] <- A block kb+3
+        q0 = more ? q0 + 192 : next.p;
+        q1 = more ? q1 + 192 : next.p + next.ns;
+        split_load_set(q0, q1, carry.b[0]);
+        q0 += 192; q1 += 192;
+        if (more) { RS_LOADA(1, ap + 16) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) { RS_SPLIT(0, 0) }
+        RS_MFMAS(1, 1)
+        RS_INTERLEAVE()
+        __builtin_amdgcn_sched_barrier(0);
+        ap += 32;
+    }
+#undef RS_LOADA
+#undef RS_SPLIT
+#undef RS_MFMAS
+#undef RS_INTERLEAVE
+}

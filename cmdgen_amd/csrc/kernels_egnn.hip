@@ -222,21 +222,22 @@ __device__ __forceinline__ void store_acc_rows(const TileAcc<MT>& acc, int wave,
 // P|Q = BUF x Wpq^T for an MT-row tile already resident in LDS: two passes of H columns.
 // `carry` holds the first fragments of the first pass; `after` is the GEMM that follows this call
 // (its first fragments are fetched by the last iteration here).
-template <int H, int MT>
+template <int H, int MT, bool SP>
 __device__ __forceinline__ void tile_project_pq(const float* buf, const WPack& Wpq,
                                                 const float* __restrict__ bias_p, float* __restrict__ Pout,
                                                 float* __restrict__ Qout, int row0, int nvalid,
-                                                bool want_p, BCarry<MT>& carry, const FragPtr after) {
+                                                bool want_p, typename Eng<MT, SP>::Carry& carry, const typename Eng<MT, SP>::Frag after) {
+    typedef Eng<MT, SP> G;
     const int wave = threadIdx.x >> 6;
-    const FragPtr fp = frag_ptr<MT>(Wpq, H / 8, 0, wave), fq = frag_ptr<MT>(Wpq, H / 8, 0, H / 64 + wave);
+    const typename G::Frag fp = G::frag(Wpq, H / 8, 0, wave), fq = G::frag(Wpq, H / 8, 0, H / 64 + wave);
     TileAcc<MT> acc;
     if (want_p) {
         acc_zero<MT>(acc);
-        tile_gemm<MT, H / 8>(buf, LDA(H), fp, fq, acc, carry);
+        G::template gemm<H / 8>(buf, LDA(H), fp, fq, acc, carry);
         store_acc_rows<H, MT>(acc, wave, Pout, row0, nvalid, bias_p);
     }
     acc_zero<MT>(acc);
-    tile_gemm<MT, H / 8>(buf, LDA(H), fq, after, acc, carry);
+    G::template gemm<H / 8>(buf, LDA(H), fq, after, acc, carry);
     store_acc_rows<H, MT>(acc, wave, Qout, row0, nvalid, nullptr);
 }
 
@@ -244,7 +245,7 @@ __device__ __forceinline__ void tile_project_pq(const float* buf, const WPack& W
 // k_embed: h0 = embedding([encoder(features) | t]) for an MT-node tile, then P/Q of block 0.
 // Encoders are tiny (8->16->32, R->2R->32): plain FMA loops through LDS.
 // ------------------------------------------------------------------------------------
-template <int H, int MT>
+template <int H, int MT, bool SP>
 __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW sw, LayerW lw0,
                                              const float* __restrict__ xh_phar,
                                              const float* __restrict__ xh_pocket,
@@ -280,9 +281,10 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
     const int nvalid = min(MT, lay.N - row0);
     const int ldp = 3 + d.P, ldq = 3 + d.R;
     const int Fmax = max(d.P, d.R), F1max = 2 * Fmax;
-    BCarry<MT> carry;                                  // weight fragments of the projection, in flight during the encoders
-    const FragPtr f0 = frag_ptr<MT>(lw0.Wpq_e, H / 8, 0, tid >> 6);
-    gemm_prefetch<MT>(f0, carry);
+    typedef Eng<MT, SP> G;
+    typename G::Carry carry;                           // weight fragments of the projection, in flight during the encoders
+    const typename G::Frag f0 = G::frag(lw0.Wpq_e, H / 8, 0, tid >> 6);
+    G::prefetch(f0, carry);
     const float t_chain = t_arr ? 0.f : coef[chain->step].w;     // two dependent loads: issued now, needed three phases later
     // The eight encoder tensors (2.8k floats at the shipped sizes) are copied into LDS first, sixteen loads per thread in
     // flight at a time: the FMA loops below then read them at LDS latency.  Read from global inside those loops they
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         }
     }
     lds_barrier();
-    tile_project_pq<H, MT>(buf, lw0.Wpq_e, lw0.b1, w.P, w.Q, row0, nvalid, true, carry, f0);
+    tile_project_pq<H, MT, SP>(buf, lw0.Wpq_e, lw0.b1, w.P, w.Q, row0, nvalid, true, carry, f0);
 }
 
 // ------------------------------------------------------------------------------------
@@ -490,7 +492,7 @@ __device__ __forceinline__ int xcd_tile(int k, int ntiles) {
 // of the compact list.  Persistent-style grid: tiles are taken round-robin until the
 // device-side edge count is exhausted, so the launch geometry is static (graph-capturable).
 // ------------------------------------------------------------------------------------
-template <int H, int MT, bool SAVE>
+template <int H, int MT, bool SAVE, bool SP>
 __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer, int ablate, TrainSave sv) {
     __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     __shared__ int s_row[MT], s_col[MT];
@@ -498,9 +500,10 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
     const int tid = threadIdx.x, wave = tid >> 6;
     const int E = w.totals[0];
     const int ntiles = (E + MT - 1) / MT;
-    const FragPtr fw = frag_ptr<MT>(lw.W2, H / 8, 0, wave);
-    BCarry<MT> carry;
-    if (xcd_tile(0, ntiles) >= 0) gemm_prefetch<MT>(fw, carry);   // refilled for the next tile by each GEMM's last iteration
+    typedef Eng<MT, SP> G;
+    const typename G::Frag fw = G::frag(lw.W2, H / 8, 0, wave);
+    typename G::Carry carry;
+    if (xcd_tile(0, ntiles) >= 0) G::prefetch(fw, carry);         // refilled for the next tile by each GEMM's last iteration
     for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
         lds_barrier();
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
-        if (!(ablate & 4)) tile_gemm<MT, H / 8>(buf, LDA(H), fw, fw, acc, carry);
+        if (!(ablate & 4)) G::template gemm<H / 8>(buf, LDA(H), fw, fw, acc, carry);
         lds_barrier();                         // every wave is done reading the A tile
         acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {                          // m_ij
             const float pre = v + lw.b2[col], m = silu_f(pre);
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
 // then, while the new h tile is still in LDS, the projections every later kernel of this
 // evaluation gathers: P_c|Q_c for this block's coord MLP and P|Q for block l+1's edge MLP.
 // ------------------------------------------------------------------------------------
-template <int H, int MT, bool SAVE>
+template <int H, int MT, bool SAVE, bool SP>
 __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
                                                int layer, int has_next, TrainSave sv) {
     // Tiles of <= 32 rows keep two LDS images: buf0 = h (kept for the residual), buf1 = agg -> T -> h_new,
@@ -594,12 +597,14 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     const int c4 = tid % LPR, rsub = tid / LPR;
     // the chain of GEMMs of this tile; each one's last iteration fetches the next one's first fragments
     const bool want_pc = row0 < lay.Nm;              // the tile holds receivers that move
-    const FragPtr f3a = frag_ptr<MT>(lw.W3, 2 * H / 8, 0, wave), f3b = frag_ptr<MT>(lw.W3, 2 * H / 8, H / 8, wave);
-    const FragPtr f4 = frag_ptr<MT>(lw.W4, H / 8, 0, wave);
-    const FragPtr fc = frag_ptr<MT>(lw.Wpq_c, H / 8, 0, want_pc ? wave : H / 64 + wave);
-    const FragPtr fn = frag_ptr<MT>(lw_next.Wpq_e, H / 8, 0, wave);
-    BCarry<MT> carry;
-    gemm_prefetch<MT>(f3a, carry);
+    typedef Eng<MT, SP> G;
+    typedef typename G::Frag Frag;
+    const Frag f3a = G::frag(lw.W3, 2 * H / 8, 0, wave), f3b = G::frag(lw.W3, 2 * H / 8, H / 8, wave);
+    const Frag f4 = G::frag(lw.W4, H / 8, 0, wave);
+    const Frag fc = G::frag(lw.Wpq_c, H / 8, 0, want_pc ? wave : H / 64 + wave);
+    const Frag fn = G::frag(lw_next.Wpq_e, H / 8, 0, wave);
+    typename G::Carry carry;
+    G::prefetch(f3a, carry);
     // materialise the phar coordinates entering this block (see node_pos)
     if (layer >= 1 && tid < MT) {
         const int n = row0 + tid;
@@ -654,16 +659,16 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
             *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
         }
         lds_barrier();
-        tile_gemm<MT, H / 8>(buf0, LDA(H), f3a, f3b, acc, carry);                         // h part of [h | agg]
-        tile_gemm<MT, H / 8>(buf1, LDA(H), f3b, f4, acc, carry);                          // agg part
+        G::template gemm<H / 8>(buf0, LDA(H), f3a, f3b, acc, carry);                         // h part of [h | agg]
+        G::template gemm<H / 8>(buf1, LDA(H), f3b, f4, acc, carry);                          // agg part
     } else {
         load_h();
         lds_barrier();
-        tile_gemm<MT, H / 8>(buf0, LDA(H), f3a, f3b, acc, carry);
+        G::template gemm<H / 8>(buf0, LDA(H), f3a, f3b, acc, carry);
         lds_barrier();
         load_agg();
         lds_barrier();
-        tile_gemm<MT, H / 8>(buf1, LDA(H), f3b, f4, acc, carry);
+        G::template gemm<H / 8>(buf1, LDA(H), f3b, f4, acc, carry);
     }
     lds_barrier();
     acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     });
     lds_barrier();
     acc_zero<MT>(acc);
-    tile_gemm<MT, H / 8>(buf1, LDA(H), f4, fc, acc, carry);
+    G::template gemm<H / 8>(buf1, LDA(H), f4, fc, acc, carry);
     lds_barrier();
     acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
         float hn = 0.f;
@@ -691,8 +696,8 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     });
     lds_barrier();
     // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
-    tile_project_pq<H, MT>(buf1, lw.Wpq_c, lw.b6, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
-    if (has_next) tile_project_pq<H, MT>(buf1, lw_next.Wpq_e, lw_next.b1, w.P, w.Q, row0, nvalid, true, carry, fn);
+    tile_project_pq<H, MT, SP>(buf1, lw.Wpq_c, lw.b6, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
+    if (has_next) tile_project_pq<H, MT, SP>(buf1, lw_next.Wpq_e, lw_next.b1, w.P, w.Q, row0, nvalid, true, carry, fn);
 }
 
 // ------------------------------------------------------------------------------------
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
 //   phi = w5 . SiLU(W7 SiLU(W6 [h_i, h_j, r, d0] + b6) + b7)
 //   ACC[l][i] += (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant) * tanh(phi) * coords_range
 // ------------------------------------------------------------------------------------
-template <int H, int MT, bool SAVE>
+template <int H, int MT, bool SAVE, bool SP>
 __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer, TrainSave sv) {
     __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     __shared__ int s_row[MT], s_col[MT];
@@ -711,9 +716,10 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
     const int tid = threadIdx.x, wave = tid >> 6;
     const int E = w.totals[1];
     const int ntiles = (E + MT - 1) / MT;
-    const FragPtr fw = frag_ptr<MT>(lw.W7, H / 8, 0, wave);
-    BCarry<MT> carry;
-    if (xcd_tile(0, ntiles) >= 0) gemm_prefetch<MT>(fw, carry);
+    typedef Eng<MT, SP> G;
+    const typename G::Frag fw = G::frag(lw.W7, H / 8, 0, wave);
+    typename G::Carry carry;
+    if (xcd_tile(0, ntiles) >= 0) G::prefetch(fw, carry);
     for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
@@ -738,7 +744,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
         lds_barrier();
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
-        tile_gemm<MT, H / 8>(buf, LDA(H), fw, fw, acc, carry);
+        G::template gemm<H / 8>(buf, LDA(H), fw, fw, acc, carry);
         lds_barrier();
         acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
             const float pre = v + lw.b7[col], a = silu_f(pre);
@@ -903,33 +909,37 @@ __global__ __launch_bounds__(64) void k_vel_com(Layout lay, Work w, Dims d, floa
 // ------------------------------------------------------------------------------------
 // host-callable launchers (C++ linkage, used by cmdgen_api.hip)
 // ------------------------------------------------------------------------------------
-template <int H, int MT> static void launch_embed(const EvalLaunch& a, const float* xp, const float* xq, const float* t,
+template <int H, int MT, bool SP> static void launch_embed(const EvalLaunch& a, const float* xp, const float* xq, const float* t,
                                                   const float4* coef, ChainState* chain, hipStream_t s) {
     const int nt = (a.lay.N + MT - 1) / MT;
     const Dims& d = a.d;
     const size_t shm = sizeof(float) * (size_t)(2 * d.P * d.P + 2 * d.P + d.J * 2 * d.P + d.J + 2 * d.R * d.R + 2 * d.R + d.J * 2 * d.R + d.J);
-    hipLaunchKernelGGL((k_embed<H, MT>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
+    hipLaunchKernelGGL((k_embed<H, MT, SP>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
                        (const ChainState*)chain, a.save ? *a.save : TrainSave{}, (chain && !t) ? a.pcache : PocketCache{});
 }
 // SAVE variants (training forward) keep the activations; the sampler's instantiations carry no trace of the stores
-template <int H, int MT> static void launch_node(const EvalLaunch& a, int l, hipStream_t s) {
+template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, int l, hipStream_t s) {
     const int nt = (a.lay.N + MT - 1) / MT;
     const int has_next = l + 1 < a.d.L;
-    if (a.save) hipLaunchKernelGGL((k_node<H, MT, true>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
+    if (a.save) hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
                                    a.layers[has_next ? l + 1 : l], l, has_next, *a.save);
-    else hipLaunchKernelGGL((k_node<H, MT, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
+    else hipLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
                             a.layers[has_next ? l + 1 : l], l, has_next, TrainSave{});
 }
-template <int H, int MT> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save);
-    else hipLaunchKernelGGL((k_edge_msg<H, MT, false>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{});
+template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
+    if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, false>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save);
+    else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{});
 }
-template <int H, int MT> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save);
-    else hipLaunchKernelGGL((k_edge_coord<H, MT, false>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
+template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
+    if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, false>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save);
+    else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
 }
-#define MT_DISPATCH(mt, FN, ...) do { if ((mt) == 64) FN<H, 64>(__VA_ARGS__); else if ((mt) == 32) FN<H, 32>(__VA_ARGS__); \
-                                      else FN<H, 16>(__VA_ARGS__); } while (0)
+// tiles of >= 32 rows run on the split-bf16 engine when the launch asks for it (never the training forward: its packs
+// hold no split weights); 16-row tiles are always fp32 MFMA (there the L2 weight stream, not the matrix rate, binds)
+#define MT_DISPATCH(mt, FN, ...) do { const bool sp_ = a.split && !a.save;                                                   \
+        if ((mt) == 64) { if (sp_) FN<H, 64, true>(__VA_ARGS__); else FN<H, 64, false>(__VA_ARGS__); }                       \
+        else if ((mt) == 32) { if (sp_) FN<H, 32, true>(__VA_ARGS__); else FN<H, 32, false>(__VA_ARGS__); }                 \
+        else FN<H, 16, false>(__VA_ARGS__); } while (0)
 
 template <int H>
 static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket,

@@ -76,6 +76,7 @@ SYMBOLS = [
     ('cmdgen_reset_counters', C.c_int, [_vp, _vp]),
     ('cmdgen_profile_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.POINTER(KernelTimes), _vp]),
     ('cmdgen_query', C.c_int, [_vp, C.c_char_p, _i64p]),
+    ('cmdgen_set_gemm_mode', C.c_int, [_vp, C.c_int32]),
     ('cmdgen_time_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
     ('cmdgen_time_edge_kernel', C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
     ('cmdgen_set_kernel_profiling', C.c_int, [_vp, C.c_int32]),
@@ -420,6 +421,10 @@ class Handle:
         self._check(self.lib.cmdgen_profile_evaluation(self.h, _ptr(xh_phar), _ptr(xh_pocket), _ptr(t), _ptr(eps),
                                                        C.byref(kt), self._stream()), 'cmdgen_profile_evaluation')
         return {n: getattr(kt, n) for n, _ in KernelTimes._fields_}
+
+    def set_gemm_mode(self, split_bf16: bool) -> None:
+        """Matrix engine of the sampler's tiles of >= 32 rows: True = split-bf16 (fp32-accurate, default), False = fp32 MFMA."""
+        self._check(self.lib.cmdgen_set_gemm_mode(self.h, int(bool(split_bf16))), 'cmdgen_set_gemm_mode')
 
     def query(self, key: str) -> int:
         v = C.c_int64(0)

@@ -302,9 +302,19 @@ int cmdgen_reset_counters(cmdgen_handle* h, cmdgen_stream stream);
 int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket,
                               const float* t, float* eps_phar, cmdgen_kernel_times* out,
                               cmdgen_stream stream);
+/* Matrix engine of the SAMPLER's tile kernels (evaluation, chains; the training step has its own switch above):
+ *   1 (default) = split-bf16: every fp32 operand is the exact sum of three bf16 pieces and every fp32 product is six
+ *       exact bf16 products accumulated in fp32 on v_mfma_f32_32x32x16_bf16 - fp32-accurate (the dropped terms are
+ *       <= 3 * 2^-24 |a||b|, below the fp32 accumulation rounding both engines share) at about twice the delivered
+ *       rate of the fp32 matrix instruction; used by tiles of >= 32 rows;
+ *   0 = v_mfma_f32_32x32x2_f32 / 16x16x4_f32 everywhere (bitwise an fmaf chain).
+ * 16-row tiles (small batches) always use the fp32 instruction.  Environment CMDGEN_GEMM=fp32|split sets the
+ * default of new handles.  Changing the mode drops captured step graphs (they are re-captured on the next chain). */
+int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16);
+
 /* Launch configuration chosen for the current layout (measurement aid): key = "node_mt" | "edge_mt" | "coord_mt"
  * (rows per tile of the three MFMA kernels), "edge_grid" | "coord_grid" (workgroups of the persistent-style edge
- * kernels). */
+ * kernels), "gemm_split" (the mode above). */
 int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value);
 
 /* Steady-state timing of one network evaluation (bench.py's trained-geometry micro-benchmark): `graph_len`
