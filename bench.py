@@ -37,6 +37,10 @@ from cmdgen_amd import hip_backend  # noqa: E402
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# dense bf16 MFMA peak of the same guide ("~2.5 PF"): 256 CUs x 4 SIMDs x 1024 FLOP/clk (v_mfma_f32_32x32x16_bf16:
+# 32768 FLOP per 32 cycles) x 2.4 GHz.  The split engine EXECUTES six bf16 MFMA FLOPs per algorithmic fp32 FLOP.
+PEAK_BF16_MFMA_TFLOPS = 2516.6
+SPLIT_MFMAS_PER_PRODUCT = 6
 PEAK_HBM_TBS = 8.0
 
 
@@ -54,6 +58,9 @@ def parse(argv=None):
     p.add_argument('--cpu-seconds', type=float, default=12.0)
     p.add_argument('--north-star-batch', type=int, default=256,
                    help='also time one chain at the north-star shape (pockets on one GPU; 0 = skip; N=1 only)')
+    p.add_argument('--gemm', default=None, choices=['split', 'fp32'],
+                   help="matrix engine of tiles of >= 32 rows: 'split' (default of the library: fp32-accurate, six bf16 MFMAs "
+                        "per fp32 product) or 'fp32' (v_mfma_f32_32x32x2_f32)")
     p.add_argument('--dry-run-launch', action='store_true',
                    help='launch logic only (CPU, gloo, no sampling): used by tests/test_bench_launch.py')
     return p.parse_args(argv)
@@ -208,6 +215,8 @@ def main(argv=None):
     sd = make_state_dict(cfg, seed=0)
     h = hip_backend.Handle(cfg.as_dict(), dev.index)
     h.load_state_dict(sd)
+    if args.gemm is not None:
+        h.set_gemm_mode(args.gemm == 'split')
     pb = make_pockets(B, rep, n_phar=args.n_phar, first_index=rank * B)     # shard = global pockets [rank*B, (rank+1)*B)
     h.set_layout(pb.num_nodes_phar, pb.size)
     px, poh = torch.from_numpy(pb.x).to(dev), torch.from_numpy(pb.one_hot).to(dev)
@@ -293,11 +302,21 @@ def main(argv=None):
                  'node': 'k_node (GCL.node_model + P_c|Q_c projections' + ('' if split else ' + P|Q of the next block') + ')',
                  'edge_coord': 'k_coord_proj (EquivariantUpdate.coord_model + P|Q projections of the next block)' if split
                                else 'k_edge_coord (EquivariantUpdate.coord_model)'}
+        # which matrix instruction each kernel's tiles ran on: the split engine serves tiles of >= 32 rows
+        launch_cfg = {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid', 'gemm_split')}
+        mt_of = {'edge_msg': launch_cfg['edge_mt'], 'node': launch_cfg['node_mt'], 'edge_coord': launch_cfg['coord_mt']}
+        on_split = {k: bool(launch_cfg['gemm_split']) and mt_of[k] >= 32 for k in mt_of}
         per_kernel = {}
         for k, (ms_k, n_k) in prof.items():
             avg = ms_k / max(n_k, 1)
+            tf = (flop_launch[k] / (avg * 1e-3) / 1e12) if avg > 0 else 0.0
             per_kernel[k] = {'total_ms': ms_k, 'launches': n_k, 'avg_launch_ms': avg, 'flop_per_launch': flop_launch[k],
-                             'tflops': (flop_launch[k] / (avg * 1e-3) / 1e12) if avg > 0 else 0.0}
+                             'tflops': tf, 'rows_per_tile': mt_of[k],
+                             'mfma': 'v_mfma_f32_32x32x16_bf16 x6 per fp32 product (split engine)' if on_split[k]
+                                     else ('v_mfma_f32_16x16x4_f32' if mt_of[k] == 16 else 'v_mfma_f32_32x32x2_f32'),
+                             # what the matrix pipe executes: six bf16 FLOPs per algorithmic FLOP against the bf16 peak
+                             'executed_frac_of_pipe_peak': (tf * SPLIT_MFMAS_PER_PRODUCT / PEAK_BF16_MFMA_TFLOPS) if on_split[k]
+                                                           else tf / PEAK_FP32_MFMA_TFLOPS}
         dom = max(per_kernel, key=lambda k: per_kernel[k]['total_ms'])
         achieved = per_kernel[dom]['tflops']
         avg_ms, launches, flop_per_launch = per_kernel[dom]['avg_launch_ms'], per_kernel[dom]['launches'], per_kernel[dom]['flop_per_launch']
@@ -328,7 +347,8 @@ def main(argv=None):
             'config': {
                 'workload': f'BASELINE.json configs[{1 if rep == "CA" else 4}]: batch {B} CrossDocked-shaped {rep} pockets per GPU '
                             f'(Np={int(pb.size[0])}, Nl={args.n_phar}), {T}-step DDPM sampling '
-                            f'(sample_given_pocket: {evals_per_chain} network evaluations per pocket), fp32; '
+                            f'(sample_given_pocket: {evals_per_chain} network evaluations per pocket), fp32 '
+                            f'({"split-bf16 matrix engine on tiles of >= 32 rows: fp32-accurate" if launch_cfg["gemm_split"] else "fp32 MFMA"}); '
                             f'one bench step = one such chain',
                 'pockets_per_gpu': B, 'timesteps': T, 'representation': rep,
                 'model': f'EGNN denoiser hidden_nf={H} n_layers={L} joint_nf={cfg.joint_nf} cutoff={cfg.edge_cutoff}, '
@@ -343,7 +363,7 @@ def main(argv=None):
                 'kernel_ms_one_evaluation': kt,
                 'steady_state_evaluation': steady,
                 'kernel_source_sha': sha,
-                'launch': {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid')},
+                'launch': launch_cfg,
             },
             'roofline': {
                 'bound': 'mfma', 'kernel': kname[dom],
@@ -351,10 +371,16 @@ def main(argv=None):
                 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_note': traffic_note,
                 'flop_per_launch': flop_per_launch, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
                 'units_per_launch': units[dom],
+                # `achieved` and `frac` are ALGORITHMIC fp32 FLOP/s against the fp32 matrix peak (the path computes in fp32).
+                # Tiles of >= 32 rows execute each fp32 product as six exact bf16 products on the 16x faster bf16 pipe
+                # (cmdgen_split.h), so the fp32-equivalent rate may exceed what the fp32 instruction could deliver;
+                # `mfma` names the instruction of the dominant kernel, `executed_frac_of_pipe_peak` prices the executed
+                # (6x) FLOPs against that pipe's own dense peak (2516.6 TF bf16 / 157.3 TF fp32).
+                'mfma': per_kernel[dom]['mfma'], 'executed_frac_of_pipe_peak': per_kernel[dom]['executed_frac_of_pipe_peak'],
                 'whole_job_frac': f_alg / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 # the north-star also asks for the HBM view: PMC bytes per launch / launch time / 8 TB/s (not the binding roofline)
                 'hbm_frac_from_pmc': (traffic / (avg_ms * 1e-3) / (PEAK_HBM_TBS * 1e12)) if traffic else None,
-                'per_kernel': {k: {kk: v[kk] for kk in ('total_ms', 'avg_launch_ms', 'tflops', 'flop_per_launch')} | {'frac': v['tflops'] / PEAK_FP32_MFMA_TFLOPS}
+                'per_kernel': {k: {kk: v[kk] for kk in ('total_ms', 'avg_launch_ms', 'tflops', 'flop_per_launch', 'rows_per_tile', 'mfma', 'executed_frac_of_pipe_peak')} | {'frac': v['tflops'] / PEAK_FP32_MFMA_TFLOPS}
                                for k, v in per_kernel.items()},
             },
         }

@@ -360,6 +360,7 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
         ALLOC(w.crow, int, cec, false); ALLOC(w.ccol, int, cec, false); ALLOC(w.cd0, float, cec, false);
         ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true);
         ALLOC(w.eps_tmp, float, (size_t)cNl * (3 + d.P), true);
+        ALLOC(w.dbg, unsigned long long, 64, true);
 #undef ALLOC
         h->cap_B = cB; h->cap_Nl = cNl; h->cap_Np = cNp; h->cap_N = cN; h->cap_e = ce; h->cap_ec = cec;
     } else {
@@ -1134,6 +1135,15 @@ extern "C" int cmdgen_time_edge_kernel(cmdgen_handle* h, int32_t layer, int32_t 
     // the replays accumulated into agg; restore the invariant "agg is zero between blocks"
     HIPCHK(h, hipMemsetAsync(h->work.agg, 0, (size_t)h->lay.N * h->dims.H * sizeof(float), s));
     hipEventDestroy(e0); hipEventDestroy(e1);
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_debug_stamps(cmdgen_handle* h, uint64_t* out64, int32_t reset) {
+    if (!h || !h->have_layout || !out64) return CMDGEN_EINVAL;
+    hipSetDevice(h->device);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out64, h->work.dbg, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(h, hipMemset(h->work.dbg, 0, 64 * sizeof(uint64_t)));
     return CMDGEN_OK;
 }
 

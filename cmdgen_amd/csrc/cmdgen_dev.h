@@ -112,6 +112,7 @@ struct Work {                   // per-layout workspace; all pointers device
     unsigned long long* counters;   // cmdgen_counters
     int*    nan_flag;           // [1] set by readout when any velocity is NaN
     float*  eps_tmp;            // [Nl][3+P] evaluation output used by the chain
+    unsigned long long* dbg;    // [64] diagnostic builds only (-DCMDGEN_STAMPS): summed in-kernel cycle stamps
 };
 
 struct ChainState {             // device-resident denoising-loop state

@@ -504,6 +504,13 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
     const typename G::Frag fw = G::frag(lw.W2, H / 8, 0, wave);
     typename G::Carry carry;
     if (xcd_tile(0, ntiles) >= 0) G::prefetch(fw, carry);         // refilled for the next tile by each GEMM's last iteration
+#ifdef CMDGEN_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_t;
+#define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
     for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
@@ -516,14 +523,18 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
             s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
         }
         lds_barrier();
+        STAMP(0);
         if (!(ablate & 2)) build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, lw.wr_e, lw.wd_e,
                                                   SAVE ? sv.pre1 + ((size_t)layer * sv.ecap + e0) * H : nullptr,
                                                   SAVE ? sv.act1 + ((size_t)layer * sv.ecap + e0) * H : nullptr);
         lds_barrier();
+        STAMP(1);
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
         if (!(ablate & 4)) G::template gemm<H / 8>(buf, LDA(H), fw, fw, acc, carry);
+        STAMP(2);
         lds_barrier();                         // every wave is done reading the A tile
+        STAMP(3);
         acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {                          // m_ij
             const float pre = v + lw.b2[col], m = silu_f(pre);
             buf[row * LDA(H) + col] = m;
@@ -533,6 +544,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
             }
         });
         lds_barrier();
+        STAMP(4);
         if (!(ablate & 16)) {   // attention gate: sigmoid(w_a . m_ij + b_a)
             int r; bool lead;
             const float s = tile_row_dot<H, MT>(buf, lw.wa, r, lead);
@@ -543,6 +555,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
             }
         }
         lds_barrier();
+        STAMP(5);
         if (!(ablate & 8)) {
             // Segment sum over the tile's rows, one column per thread, edge order preserved
             // (= the reference's sequential scatter_add_).  All LDS reads are issued up front
@@ -571,7 +584,16 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
             atomicAdd(w.agg + (size_t)s_row[seg0] * H + c, sum);     // ... or into the next one
         }
         lds_barrier();
+        STAMP(6);
     }
+#ifdef CMDGEN_STAMPS
+    if ((tid & 63) == 0) {      // lane 0 of every wave: [wave][phase] sums, [32 + wave] = wave lifetime, [40] = waves
+        for (int i = 0; i < 7; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
+        atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
+        atomicAdd(&w.dbg[40], 1ull);
+    }
+#endif
+#undef STAMP
 }
 
 // ------------------------------------------------------------------------------------

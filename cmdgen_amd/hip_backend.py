@@ -77,6 +77,7 @@ SYMBOLS = [
     ('cmdgen_profile_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.POINTER(KernelTimes), _vp]),
     ('cmdgen_query', C.c_int, [_vp, C.c_char_p, _i64p]),
     ('cmdgen_set_gemm_mode', C.c_int, [_vp, C.c_int32]),
+    ('cmdgen_debug_stamps', C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int32]),
     ('cmdgen_time_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
     ('cmdgen_time_edge_kernel', C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
     ('cmdgen_set_kernel_profiling', C.c_int, [_vp, C.c_int32]),
@@ -425,6 +426,12 @@ class Handle:
     def set_gemm_mode(self, split_bf16: bool) -> None:
         """Matrix engine of the sampler's tiles of >= 32 rows: True = split-bf16 (fp32-accurate, default), False = fp32 MFMA."""
         self._check(self.lib.cmdgen_set_gemm_mode(self.h, int(bool(split_bf16))), 'cmdgen_set_gemm_mode')
+
+    def debug_stamps(self, reset: bool = True):
+        """Diagnostic builds (-DCMDGEN_STAMPS): the 64 summed in-kernel cycle counters (zero in production builds)."""
+        out = (C.c_uint64 * 64)()
+        self._check(self.lib.cmdgen_debug_stamps(self.h, out, int(reset)), 'cmdgen_debug_stamps')
+        return list(out)
 
     def query(self, key: str) -> int:
         v = C.c_int64(0)

@@ -312,6 +312,10 @@ int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar, const floa
  * default of new handles.  Changing the mode drops captured step graphs (they are re-captured on the next chain). */
 int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16);
 
+/* Diagnostic builds only (kernels compiled with -DCMDGEN_STAMPS): 64 summed in-kernel cycle stamps of k_edge_msg
+ * ([wave][phase], wave lifetimes, wave count); all zero in production builds.  Synchronises the device. */
+int cmdgen_debug_stamps(cmdgen_handle* h, uint64_t* out64, int32_t reset);
+
 /* Launch configuration chosen for the current layout (measurement aid): key = "node_mt" | "edge_mt" | "coord_mt"
  * (rows per tile of the three MFMA kernels), "edge_grid" | "coord_grid" (workgroups of the persistent-style edge
  * kernels), "gemm_split" (the mode above). */

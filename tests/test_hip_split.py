@@ -1,0 +1,108 @@
+"""GPU parity tests of the split-bf16 matrix engine (cmdgen_amd/csrc/cmdgen_split.h, cmdgen_set_gemm_mode).
+
+Tiles of >= 32 rows multiply every fp32 product as six exact bf16 products accumulated in fp32; 16-row tiles keep
+v_mfma_f32_16x16x4_f32.  Small fixtures pick 16-row tiles by themselves, so these tests FORCE 32- and 64-row tiles
+(CMDGEN_*_MT) to put all three MFMA kernels and k_embed on the split engine, and run the same case on the fp32
+engine next to it.  Same tolerances as everywhere else: one evaluation max|d eps| <= 2e-5 * max(1, max|eps|) against the
+reference's output, chains <= 1e-4 A ABSOLUTE coordinate RMS in the bounded regime, types exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, cases_of, dynamics_case, rms, bounded_case, fullsize_chain_case
+from cmdgen_amd import hip_backend
+from test_hip_parity_r2 import dev, new_handle, host_step_table, EVAL_TOL
+
+pytestmark = pytest.mark.gpu
+
+G2 = load_golden('g2_dynamics.npz')
+G12 = load_golden('g12_fullsize.npz')
+G13 = load_golden('g13_bounded.npz')
+
+
+def force_tiles(monkeypatch, mt):
+    for k in ('CMDGEN_NODE_MT', 'CMDGEN_EDGE_MT', 'CMDGEN_COORD_MT'):
+        monkeypatch.setenv(k, str(mt))
+
+
+@pytest.mark.parametrize('mt', [32, 64])
+@pytest.mark.parametrize('name', cases_of(G2))
+def test_evaluation_on_both_engines_matches_reference(name, mt, monkeypatch):
+    """Every G2 evaluation fixture (H in {64,128,256}, flags on/off, ragged) with all tiles forced to mt rows."""
+    force_tiles(monkeypatch, mt)
+    cfg, sd, inp = dynamics_case(G2, name)
+    want = G2[name + '/eps_phar']
+    errs = {}
+    for split in (True, False):
+        h = new_handle(cfg, sd)
+        h.set_gemm_mode(split)
+        h.set_layout(G2[name + '/num_nodes_phar'], G2[name + '/pocket_size'])
+        assert h.query('gemm_split') == int(split) and h.query('edge_mt') == mt
+        eps, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']))
+        torch.cuda.synchronize()
+        errs[split] = float(np.abs(eps.cpu().numpy() - want).max())
+        h.close()
+    tol = EVAL_TOL * max(1.0, float(np.abs(want).max()))
+    print(f'{name} mt={mt}: max|d eps| split {errs[True]:.2e}  fp32 {errs[False]:.2e}  (tolerance {tol:.1e})')
+    assert errs[True] <= tol and errs[False] <= tol
+
+
+def test_fullsize_evaluation_split_error_is_at_the_fp32_engines_level():
+    """configs[4]'s shape (Np=366): the split engine's deviation from the reference is of the size of the fp32 engine's."""
+    name = 'dyn_fa366_b2'
+    cfg, sd, inp = dynamics_case(G12, name)
+    want = G12[name + '/eps_phar']
+    errs = {}
+    for split in (True, False):
+        h = new_handle(cfg, sd)
+        h.set_gemm_mode(split)
+        h.set_layout(G12[name + '/num_nodes_phar'], G12[name + '/pocket_size'])
+        eps, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']))
+        torch.cuda.synchronize()
+        errs[split] = rms(eps.cpu().numpy(), want)
+        h.close()
+    print(f'RMS deviation from the reference: split {errs[True]:.3e}, fp32 {errs[False]:.3e}')
+    assert errs[True] <= 3.0 * errs[False] + 1e-7
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+@pytest.mark.parametrize('name', cases_of(G13))
+def test_bounded_chain_on_split_engine_absolute_rms(name, use_graph, monkeypatch):
+    """The absolute 1e-4 A bound with EVERY tile kernel of every step on the split engine (32-row tiles forced):
+    K = 50 and the full K = T = 500 reference chains, recorded noise."""
+    force_tiles(monkeypatch, 32)
+    cfg, sd, pb, K = bounded_case(G13, name)
+    h = new_handle(cfg, sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    assert h.query('gemm_split') == 1 and h.query('node_mt') == 32 and h.query('edge_mt') == 32
+    h.set_step_table(K, host_step_table(cfg, K))
+    xh_phar, xh_pocket, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=dev(G13[name + '/noise']), use_graph=use_graph)
+    st = h.chain_status()
+    want = G13[name + '/xh_phar']
+    err = rms(xh_phar[:, :3].cpu().numpy(), want[:, :3])
+    print(f'{name} graph={use_graph} split engine: coordinate RMS vs reference {err:.3e} A')
+    assert err <= 1e-4
+    assert np.array_equal(xh_phar[:, 3:].cpu().numpy(), want[:, 3:])
+    assert st['max_rel_com_error'] < 1e-2 and st['nan_resets'] == 0
+    h.close()
+
+
+def test_mode_switch_recaptures_the_step_graph(monkeypatch):
+    """cmdgen_set_gemm_mode between two graph-replayed chains of one handle: both match the reference chain."""
+    force_tiles(monkeypatch, 32)
+    name = cases_of(G13)[0]
+    cfg, sd, pb, K = bounded_case(G13, name)
+    h = new_handle(cfg, sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    h.set_step_table(K, host_step_table(cfg, K))
+    want = G13[name + '/xh_phar']
+    outs = []
+    for split in (True, False, True):
+        h.set_gemm_mode(split)
+        xh_phar, _, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=dev(G13[name + '/noise']), use_graph=True)
+        assert rms(xh_phar[:, :3].cpu().numpy(), want[:, :3]) <= 1e-4
+        outs.append(xh_phar.cpu().numpy())
+    assert np.array_equal(outs[0][:, 3:], outs[1][:, 3:])
+    assert np.allclose(outs[0], outs[2], atol=1e-5)          # same engine, same chain (up to float atomics at tile seams)
+    h.close()

@@ -19,3 +19,15 @@ names = {0: 'full', 4: 'no gemm', 32: 'no valu role', 36: 'neither'} if os.envir
 for m, n in names.items():
     ts = [h.time_edge_kernel(2 | (m << 8), 50) * 1e3 for _ in range(3)]
     print(f'{n:16s} {min(ts):8.1f} us')
+if os.environ.get('STAMPS'):
+    import json
+    for m, n in {0: 'full', 27: 'gemm only'}.items():
+        h.debug_stamps(True)
+        h.time_edge_kernel(2 | (m << 8), 10)
+        s = h.debug_stamps(True)
+        nw = max(s[40], 1) / 4
+        names = ['idx+pos', 'build', 'gemm', 'barrier after gemm', 'epilogue', 'att', 'segsum']
+        print(n, 'mean cycles per wave per launch, wave 0..3:')
+        for i, nm in enumerate(names):
+            print(f'  {nm:20s}', [round(s[w * 8 + i] / nw) for w in range(4)])
+        print('  lifetime            ', [round(s[32 + w] / nw) for w in range(4)])
