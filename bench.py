@@ -255,8 +255,9 @@ def main(argv=None):
     if rank == 0:
         H, L, dyn = cfg.hidden_nf, cfg.n_layers, cfg.joint_nf + 1
         nl_tot = int(pb.num_nodes_phar.sum())
-        # ---- roofline of the dominant kernel: HIP events on the launch stream around EVERY launch of the three MFMA
-        # kernels during one more chain of the same workload (eager launches: a graph replay has no per-kernel events).
+        # ---- roofline of the dominant kernel: EVERY launch of the three MFMA kernels during one more chain of the same
+        # workload carries its own start / stop HIP events (hipExtLaunchKernelGGL on the launch stream: the dispatch's own
+        # begin / end timestamps, what rocprofv3 --kernel-trace reports; eager launches: a graph replay has no per-kernel events).
         # Algorithmic FLOP per launch: edge kernels 2(H^2+H) per listed edge (device counters); node kernel see
         # node_flop_per_launch (what each launch needs, not 14 H^2 on every row).
         with torch.cuda.stream(stream):

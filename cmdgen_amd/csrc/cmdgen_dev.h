@@ -183,7 +183,8 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     const LayerW* layers;       // host array [L]
     int edge_grid, coord_grid;  // workgroups of the persistent-style edge kernels (tiles are taken round-robin)
     int node_mt, edge_mt, coord_mt;   // rows per tile (64, 32 or 16) chosen per launch from the row counts
-    std::vector<hipEvent_t>* prof_events;  // when non-null: [3] vectors, event pairs around every msg / node / coord launch
+    std::vector<hipEvent_t>* prof_events;  // when non-null: [3] vectors, (start, stop) event pairs of every msg / node / coord launch
+    mutable hipEvent_t pe_start = nullptr, pe_stop = nullptr;   // the pair the next profiled launch carries (hipExtLaunchKernelGGL)
     int ablate;                 // timing-only builds of the edge kernel (cmdgen_time_edge_kernel); 0 in production
     int stop_block = -1, stop_stage = 0;   // cmdgen_debug_eval_prefix: stop after stage 1..3 of this block (-1: run everything)
     const TrainSave* save = nullptr;   // training forward: keep the activations (see TrainSave)

@@ -15,6 +15,7 @@
 // with a 4-float row pad (conflict-free ds_read_b128); the B operand (weights) streams from
 // L2 in MFMA fragment order (cmdgen_dev.h).
 #include "cmdgen_dev.h"
+#include <hip/hip_ext.h>
 
 #define LDA(H) ((H) + 4)
 
@@ -945,15 +946,21 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
     const int has_next = l + 1 < a.d.L;
     if (a.save) hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
                                    a.layers[has_next ? l + 1 : l], l, has_next, *a.save);
+    else if (a.pe_start) hipExtLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
+                                               a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next, TrainSave{});
     else hipLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
                             a.layers[has_next ? l + 1 : l], l, has_next, TrainSave{});
 }
 template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
     if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, false>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save);
+    else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
+                                               a.layers[l], l, a.ablate, TrainSave{});
     else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{});
 }
 template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
     if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, false>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save);
+    else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
+                                               a.layers[l], l, TrainSave{});
     else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
 }
 // tiles of >= 32 rows run on the split-bf16 engine when the launch asks for it (never the training forward: its packs
@@ -972,7 +979,11 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + 2 * sizeof(int));
     int e = 0;
 #define REC() do { if (ev) hipEventRecord(ev[e++], s); } while (0)
-#define PROF(k) do { if (a.prof_events) { hipEvent_t pe; hipEventCreate(&pe); hipEventRecord(pe, s); a.prof_events[k].push_back(pe); } } while (0)
+    // kernel profiling: the launch itself carries a start and a stop event (hipExtLaunchKernelGGL: the timestamps of the dispatch
+    // packet, i.e. what rocprofv3 reports), not events recorded around it on the stream (those include the launch gap)
+#define PROF_BEGIN(k) do { if (a.prof_events && !a.save) { hipEventCreate(&a.pe_start); hipEventCreate(&a.pe_stop); \
+                           a.prof_events[k].push_back(a.pe_start); a.prof_events[k].push_back(a.pe_stop); } } while (0)
+#define PROF_END() do { a.pe_start = nullptr; a.pe_stop = nullptr; } while (0)
     REC();
     if (!a.skip_count) hipLaunchKernelGGL(k_edge_count, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket);
     if (a.skip_count == 2) {          // training forward: the graph was built (and its size read back) before the activation store was sized
@@ -997,14 +1008,13 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     for (int l = 0; l < a.d.L; ++l) {
         const int stop = a.stop_block == l ? a.stop_stage : 0;        // parity aid: leave intermediates in the workspace
         REC();
-        PROF(0); MT_DISPATCH(a.edge_mt, launch_msg, a, l, s); PROF(0);
+        PROF_BEGIN(0); MT_DISPATCH(a.edge_mt, launch_msg, a, l, s); PROF_END();
         REC(); REC();
         if (stop == 1) return;
-        PROF(1); MT_DISPATCH(a.node_mt, launch_node, a, l, s); PROF(1);
+        PROF_BEGIN(1); MT_DISPATCH(a.node_mt, launch_node, a, l, s); PROF_END();
         REC(); REC();
         if (stop == 2) return;
-        PROF(2);
-        MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF(2);
+        PROF_BEGIN(2); MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF_END();
         REC();
         if (stop == 3) return;
     }
@@ -1015,7 +1025,8 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     if (a.d.joint) hipLaunchKernelGGL(k_vel_com, dim3(B), dim3(64), 0, s, a.lay, a.w, a.d, eps_phar, eps_pocket);
     REC();
 #undef REC
-#undef PROF
+#undef PROF_BEGIN
+#undef PROF_END
 }
 
 void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket,
