@@ -384,20 +384,33 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
         HIPCHK(h, hipMemset(w.totals, 0, 4 * sizeof(int)));
     }
     h->ecap = ecap; h->eccap = eccap;
-    {   // Rows per tile: the largest tile that still gives every CU a few workgroups.  Edge counts
-        // are only known on the device, so they are estimated from the layout (C-alpha pockets
-        // have ~6 neighbours within 6 A, full-atom ones ~36; a phar node keeps >= its self loop).
+    {   // Rows per tile: the largest tile that still gives every CU a few workgroups.  Edge counts are only known on
+        // the device, so they are estimated from the layout for the geometry a trained model holds and every chain starts
+        // from - the phar points inside the pocket (measured on CrossDocked-shaped pockets, bench.py's steady_state_evaluation:
+        // C-alpha 9.2 neighbours per node within 6 A and 15 coordinate edges per phar node; full-atom 36 and 54).  A chain of
+        // an untrained model drifts to fewer edges; the persistent edge grids just find fewer tiles then.
         double e_est = 0.0, ec_est = 0.0;
         for (int b = 0; b < B; ++b) {
             const double n = (double)(nph[b] + npk[b]);
-            const double deg = h->cfg.edge_cutoff < 0.f ? n : (n <= 128.0 ? 6.0 : 36.0);
-            e_est += n * (deg < n ? deg : n);
-            ec_est += d.joint ? n * (deg < n ? deg : n)                       // joint: every receiver moves
-                              : (double)nph[b] * (deg < n ? deg : n) * 0.5;
+            const bool full = h->cfg.edge_cutoff < 0.f;
+            const double deg = full ? n : (n <= 128.0 ? 9.0 : 36.0);
+            const double dnode = deg < n ? deg : n;
+            double dphar = full ? n : 0.6 * (double)nph[b] + (n <= 128.0 ? 0.15 : 0.13) * (double)npk[b];   // receivers that move
+            if (dphar > n) dphar = n;
+            e_est += n * dnode;
+            ec_est += d.joint ? n * dnode : (double)nph[b] * dphar;                   // joint: every receiver moves
         }
-        // thresholds from sweeps on MI355X (profiles/r01_tile_sweep.txt)
+        // thresholds from sweeps on MI355X (fp32 engine: profiles/r01_tile_sweep.txt; split engine:
+        // profiles/r02_o_tile_sweep_split.txt, r02_z_tiles_trained_geometry.txt)
         auto pick = [&](double rows) { return rows / 64.0 >= 3.0 * h->n_cus ? 64 : (rows / 32.0 >= 1.5 * h->n_cus ? 32 : 16); };
         h->node_mt = pick((double)N); h->edge_mt = pick(e_est); h->coord_mt = pick(ec_est);
+        if (h->gemm_split) {
+            // node kernel: 32-row tiles (two LDS images) as soon as they put a workgroup on 0.6 of the CUs (96 C-alpha pockets),
+            // never 64 rows; coordinate kernel: 64-row tiles only for very long lists - its list shrinks to a few tiles when a
+            // chain drifts, and a lone 64-row tile costs 15 us where a 32-row one costs 10
+            h->node_mt = (double)N / 32.0 >= 0.6 * h->n_cus ? 32 : 16;
+            h->coord_mt = ec_est / 64.0 >= 6.0 * h->n_cus ? 64 : (ec_est / 32.0 >= 1.5 * h->n_cus ? 32 : 16);
+        }
         const char* ev;
         if ((ev = getenv("CMDGEN_NODE_MT"))) h->node_mt = atoi(ev);
         if ((ev = getenv("CMDGEN_EDGE_MT"))) h->edge_mt = atoi(ev);
@@ -448,8 +461,8 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.prof_events = nullptr; a.ablate = 0;
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     a.split = h->gemm_split ? 1 : 0;
-    // split engine: the node kernel's 32-row tiles (two LDS images, h kept for the residual) beat its 64-row ones at every
-    // size measured (B=256 C-alpha 87 vs 132 us, full-atom B=64 134 vs 182 us; profiles/r02_o_tile_sweep_split.txt)
+    // (tiles were chosen for the engine in force at cmdgen_set_layout; after a later cmdgen_set_gemm_mode the node kernel
+    // still avoids its 64-row tiles on the split engine: 87 vs 132 us at B=256, profiles/r02_o_tile_sweep_split.txt)
     if (a.split && a.node_mt == 64 && !getenv("CMDGEN_NODE_MT")) a.node_mt = 32;
     return a;
 }

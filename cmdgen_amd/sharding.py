@@ -54,10 +54,10 @@ def slice_pocket(pocket: Dict[str, torch.Tensor], num_nodes_phar, lo: int, hi: i
 
 def pocket_cost(num_pocket, num_phar, edge_cutoff=6.0) -> np.ndarray:
     """Relative cost of one pocket's chain: (Np + Nl) * degree, i.e. ~ its edge count.
-    The degree estimate is the one cmdgen_set_layout uses to size its grids: C-alpha pockets have ~6 neighbours
+    The degree estimate is the one cmdgen_set_layout uses to size its grids: C-alpha pockets have ~9 neighbours
     within 6 A, full-atom ones ~36; without a cutoff every sample is a complete graph."""
     n = np.asarray(num_pocket, dtype=np.float64) + np.asarray(num_phar, dtype=np.float64)
-    deg = n if edge_cutoff is None else np.minimum(n, np.where(n <= 128, 6.0, 36.0))
+    deg = n if edge_cutoff is None else np.minimum(n, np.where(n <= 128, 9.0, 36.0))
     return n * deg
 
 
