@@ -272,6 +272,42 @@ __device__ __forceinline__ void acc_foreach(const TileAcc<MT>& acc, int wave, F 
     }
 }
 
+// the same walk with the wave-local column-tile index n (0..3 at 16 rows, 0..1 otherwise), for epilogues that keep
+// per-column vectors (biases) in registers: ColVec holds v[col] for the lane's columns, fetched at kernel start so that no
+// epilogue waits for an L2 round trip of its own
+template <int MT, class F>
+__device__ __forceinline__ void acc_foreach_n(const TileAcc<MT>& acc, int wave, F f) {
+    const int lane = threadIdx.x & 63;
+    if constexpr (MT == 16) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f(4 * (lane >> 4) + r, wave * 64 + n * 16 + (lane & 15), n, acc.a[n][r]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT / 32; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    f(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), wave * 64 + n * 32 + (lane & 31), n, acc.a[m][n][r]);
+    }
+}
+template <int MT> struct ColVec { float v[MT == 16 ? 4 : 2]; };
+template <int MT>
+__device__ __forceinline__ ColVec<MT> col_load(const float* __restrict__ vec, int wave) {
+    const int lane = threadIdx.x & 63;
+    ColVec<MT> c;
+    if constexpr (MT == 16) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) c.v[n] = vec[wave * 64 + n * 16 + (lane & 15)];
+    } else {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) c.v[n] = vec[wave * 64 + n * 32 + (lane & 31)];
+    }
+    return c;
+}
+
 #define CMDGEN_MFMA32(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, ACC, 0, 0, 0)
 #define CMDGEN_MFMA16(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, ACC, 0, 0, 0)
 

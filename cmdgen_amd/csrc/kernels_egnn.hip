@@ -214,9 +214,9 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
 // out[row][col] = acc + bias (bias may be null) for rows < nvalid
 template <int H, int MT>
 __device__ __forceinline__ void store_acc_rows(const TileAcc<MT>& acc, int wave, float* __restrict__ out,
-                                               int row0, int nvalid, const float* __restrict__ bias) {
-    acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
-        if (row < nvalid) out[(size_t)(row0 + row) * H + col] = v + (bias ? bias[col] : 0.f);
+                                               int row0, int nvalid, const ColVec<MT>* bias) {
+    acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {
+        if (row < nvalid) out[(size_t)(row0 + row) * H + col] = v + (bias ? bias->v[n] : 0.f);
     });
 }
 
@@ -225,7 +225,7 @@ __device__ __forceinline__ void store_acc_rows(const TileAcc<MT>& acc, int wave,
 // (its first fragments are fetched by the last iteration here).
 template <int H, int MT, bool SP>
 __device__ __forceinline__ void tile_project_pq(const float* buf, const WPack& Wpq,
-                                                const float* __restrict__ bias_p, float* __restrict__ Pout,
+                                                const ColVec<MT>& bias_p, float* __restrict__ Pout,
                                                 float* __restrict__ Qout, int row0, int nvalid,
                                                 bool want_p, typename Eng<MT, SP>::Carry& carry, const typename Eng<MT, SP>::Frag after) {
     typedef Eng<MT, SP> G;
@@ -235,7 +235,7 @@ __device__ __forceinline__ void tile_project_pq(const float* buf, const WPack& W
     if (want_p) {
         acc_zero<MT>(acc);
         G::template gemm<H / 8>(buf, LDA(H), fp, fq, acc, carry);
-        store_acc_rows<H, MT>(acc, wave, Pout, row0, nvalid, bias_p);
+        store_acc_rows<H, MT>(acc, wave, Pout, row0, nvalid, &bias_p);
     }
     acc_zero<MT>(acc);
     G::template gemm<H / 8>(buf, LDA(H), fq, after, acc, carry);
@@ -286,6 +286,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
     typename G::Carry carry;                           // weight fragments of the projection, in flight during the encoders
     const typename G::Frag f0 = G::frag(lw0.Wpq_e, H / 8, 0, tid >> 6);
     G::prefetch(f0, carry);
+    const ColVec<MT> b1v = col_load<MT>(lw0.b1, tid >> 6);       // needed by the projection's epilogue four phases later
     const float t_chain = t_arr ? 0.f : coef[chain->step].w;     // two dependent loads: issued now, needed three phases later
     // The eight encoder tensors (2.8k floats at the shipped sizes) are copied into LDS first, sixteen loads per thread in
     // flight at a time: the FMA loops below then read them at LDS latency.  Read from global inside those loops they
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
         }
     }
     lds_barrier();
-    tile_project_pq<H, MT, SP>(buf, lw0.Wpq_e, lw0.b1, w.P, w.Q, row0, nvalid, true, carry, f0);
+    tile_project_pq<H, MT, SP>(buf, lw0.Wpq_e, b1v, w.P, w.Q, row0, nvalid, true, carry, f0);
 }
 
 // ------------------------------------------------------------------------------------
@@ -424,13 +425,11 @@ template <int H, int MT>
 __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, const int* s_col,
                                                 const float* s_r, const float* s_d0, int ne,
                                                 const float* __restrict__ P, const float* __restrict__ Q,
-                                                const float* __restrict__ wr, const float* __restrict__ wd,
+                                                const float4& wr4, const float4& wd4,      // this thread's four columns of w_r, w_d
                                                 float* __restrict__ pre_out = nullptr, float* __restrict__ act_out = nullptr) {
     constexpr int LPR = H / 4;                  // lanes per row (float4 each) -> 4 rows per pass
-    const int ltid = threadIdx.x % H;           // (dual-group kernels run two groups of H threads)
+    const int ltid = threadIdx.x % H;
     const int c4 = ltid % LPR, rsub = ltid / LPR;
-    const float4 wr4 = reinterpret_cast<const float4*>(wr)[c4];
-    const float4 wd4 = reinterpret_cast<const float4*>(wd)[c4];
 #pragma unroll 8
     for (int pass = 0; pass < MT / 4; ++pass) {
         const int e = pass * 4 + rsub;
@@ -453,7 +452,7 @@ __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, co
 
 // per-row dot product of the LDS tile with a weight vector: H/MT threads per row
 template <int H, int MT>
-__device__ __forceinline__ float tile_row_dot(const float* buf, const float* __restrict__ wv, int& r_out, bool& lead) {
+__device__ __forceinline__ float tile_row_dot(const float* buf, const float* wv, int& r_out, bool& lead) {
     constexpr int TPR = H / MT;                 // threads per row (4, 8 or 16 at H=256)
     constexpr int CPT = H / TPR;                // columns per thread (= MT)
     const int ltid = threadIdx.x % H;
@@ -498,13 +497,20 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
     __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     __shared__ int s_row[MT], s_col[MT];
     __shared__ float s_r[MT], s_d0[MT], s_att[MT];
+    __shared__ __attribute__((aligned(16))) float s_wa[H];     // att_mlp weight: read by every tile's row dot (LDS broadcast, not 16 L1 round trips)
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int E = w.totals[0];
-    const int ntiles = (E + MT - 1) / MT;
+    s_wa[tid] = lw.wa[tid];                                    // visible after the first tile's barriers
+    const ColVec<MT> b2v = col_load<MT>(lw.b2, wave);          // per-column bias and the gate's bias: once per workgroup
+    const float ba0 = lw.ba[0];
+    const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_e)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_e)[tid % (H / 4)];
     typedef Eng<MT, SP> G;
     const typename G::Frag fw = G::frag(lw.W2, H / 8, 0, wave);
     typename G::Carry carry;
-    if (xcd_tile(0, ntiles) >= 0) G::prefetch(fw, carry);         // refilled for the next tile by each GEMM's last iteration
+    G::prefetch(fw, carry);     // before the edge count is known: the first fragments fly beside that load and the index / position
+                                // / gather round trips of the first tile (a workgroup that finds no tile has read 12-24 KB for nothing);
+                                // refilled for the next tile by each GEMM's last iteration
+    const int E = w.totals[0];
+    const int ntiles = (E + MT - 1) / MT;
 #ifdef CMDGEN_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_t;
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
         }
         lds_barrier();
         STAMP(0);
-        if (!(ablate & 2)) build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, lw.wr_e, lw.wd_e,
+        if (!(ablate & 2)) build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4,
                                                   SAVE ? sv.pre1 + ((size_t)layer * sv.ecap + e0) * H : nullptr,
                                                   SAVE ? sv.act1 + ((size_t)layer * sv.ecap + e0) * H : nullptr);
         lds_barrier();
@@ -536,8 +542,8 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
         STAMP(2);
         lds_barrier();                         // every wave is done reading the A tile
         STAMP(3);
-        acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {                          // m_ij
-            const float pre = v + lw.b2[col], m = silu_f(pre);
+        acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {                 // m_ij
+            const float pre = v + b2v.v[n], m = silu_f(pre);
             buf[row * LDA(H) + col] = m;
             if (SAVE && row < ne) {
                 const size_t o = ((size_t)layer * sv.ecap + e0 + row) * H + col;
@@ -548,9 +554,9 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
         STAMP(4);
         if (!(ablate & 16)) {   // attention gate: sigmoid(w_a . m_ij + b_a)
             int r; bool lead;
-            const float s = tile_row_dot<H, MT>(buf, lw.wa, r, lead);
+            const float s = tile_row_dot<H, MT>(buf, s_wa, r, lead);
             if (lead) {
-                const float zl = s + lw.ba[0];
+                const float zl = s + ba0;
                 s_att[r] = d.attention ? sigmoid_f(zl) : 1.0f;
                 if (SAVE && d.attention && r < ne) sv.z[(size_t)layer * sv.ecap + e0 + r] = zl;
             }
@@ -628,6 +634,10 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     const Frag fn = G::frag(lw_next.Wpq_e, H / 8, 0, wave);
     typename G::Carry carry;
     G::prefetch(f3a, carry);
+    // every epilogue's bias, fetched now: by the time an epilogue runs its values have long arrived (a load issued where
+    // it is used costs that epilogue an L2 round trip: k_node 38.3 -> 34.2 us at B=64)
+    const ColVec<MT> b3v = col_load<MT>(lw.b3, wave), b4v = col_load<MT>(lw.b4, wave), b6v = col_load<MT>(lw.b6, wave),
+                     b1nv = col_load<MT>(lw_next.b1, wave);
     // materialise the phar coordinates entering this block (see node_pos)
     if (layer >= 1 && tid < MT) {
         const int n = row0 + tid;
@@ -694,8 +704,8 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
         G::template gemm<H / 8>(buf1, LDA(H), f3b, f4, acc, carry);
     }
     lds_barrier();
-    acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
-        const float pre = v + lw.b3[col], a = silu_f(pre);
+    acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {
+        const float pre = v + b3v.v[n], a = silu_f(pre);
         buf1[row * LDA(H) + col] = a;
         if (SAVE && row < nvalid) {
             const size_t o = ((size_t)layer * lay.N + row0 + row) * H + col;
@@ -706,12 +716,12 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     acc_zero<MT>(acc);
     G::template gemm<H / 8>(buf1, LDA(H), f4, fc, acc, carry);
     lds_barrier();
-    acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
+    acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {
         float hn = 0.f;
         if (row < nvalid) {
             float* hp = w.h + (size_t)(row0 + row) * H + col;
             const float hold = TWO ? buf0[row * LDA(H) + col] : *hp;
-            hn = hold + (v + lw.b4[col]);                                                 // residual (egnn_new.py:57)
+            hn = hold + (v + b4v.v[n]);                                                 // residual (egnn_new.py:57)
             *hp = hn;
             if (SAVE) sv.h[((size_t)(layer + 1) * lay.N + row0 + row) * H + col] = hn;   // h entering block layer+1
         }
@@ -719,8 +729,8 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     });
     lds_barrier();
     // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
-    tile_project_pq<H, MT, SP>(buf1, lw.Wpq_c, lw.b6, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
-    if (has_next) tile_project_pq<H, MT, SP>(buf1, lw_next.Wpq_e, lw_next.b1, w.P, w.Q, row0, nvalid, true, carry, fn);
+    tile_project_pq<H, MT, SP>(buf1, lw.Wpq_c, b6v, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
+    if (has_next) tile_project_pq<H, MT, SP>(buf1, lw_next.Wpq_e, b1nv, w.P, w.Q, row0, nvalid, true, carry, fn);
 }
 
 // ------------------------------------------------------------------------------------
@@ -736,13 +746,17 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
     __shared__ int s_row[MT], s_col[MT];
     __shared__ float s_r[MT], s_d0[MT];
     __shared__ float s_cd[MT][3], s_tr[MT][3];
+    __shared__ __attribute__((aligned(16))) float s_w5[H];     // coord_mlp.4 weight, staged once per workgroup (see k_edge_msg)
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int E = w.totals[1];
-    const int ntiles = (E + MT - 1) / MT;
+    s_w5[tid] = lw.w5[tid];
+    const ColVec<MT> b7v = col_load<MT>(lw.b7, wave);
+    const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_c)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_c)[tid % (H / 4)];
     typedef Eng<MT, SP> G;
     const typename G::Frag fw = G::frag(lw.W7, H / 8, 0, wave);
     typename G::Carry carry;
-    if (xcd_tile(0, ntiles) >= 0) G::prefetch(fw, carry);
+    G::prefetch(fw, carry);                                    // unconditional, see k_edge_msg
+    const int E = w.totals[1];
+    const int ntiles = (E + MT - 1) / MT;
     for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
@@ -761,7 +775,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
             s_cd[tid][0] = cx; s_cd[tid][1] = cy; s_cd[tid][2] = cz;
         }
         lds_barrier();
-        build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, lw.wr_c, lw.wd_c,
+        build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, wr4, wd4,
                                SAVE ? sv.pre6 + ((size_t)layer * sv.eccap + e0) * H : nullptr,
                                SAVE ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr);
         lds_barrier();
@@ -769,8 +783,8 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
         acc_zero<MT>(acc);
         G::template gemm<H / 8>(buf, LDA(H), fw, fw, acc, carry);
         lds_barrier();
-        acc_foreach<MT>(acc, wave, [&](int row, int col, float v) {
-            const float pre = v + lw.b7[col], a = silu_f(pre);
+        acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {
+            const float pre = v + b7v.v[n], a = silu_f(pre);
             buf[row * LDA(H) + col] = a;
             if (SAVE && row < ne) {
                 const size_t o = ((size_t)layer * sv.eccap + e0 + row) * H + col;
@@ -780,7 +794,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
         lds_barrier();
         {
             int r; bool lead;
-            const float s = tile_row_dot<H, MT>(buf, lw.w5, r, lead);
+            const float s = tile_row_dot<H, MT>(buf, s_w5, r, lead);
             if (lead) {
                 if (SAVE && r < ne) sv.phi[(size_t)layer * sv.eccap + e0 + r] = s;
                 const float g = d.use_tanh ? tanhf(s) * d.coords_range : s;
