@@ -525,7 +525,9 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
             int row = -1, col = -1; float r = 0.f, d0 = 0.f;
             if (tid < ne) {
                 row = w.erow[e0 + tid]; col = w.ecol[e0 + tid]; d0 = w.ed0[e0 + tid];
-                r = (ablate & 1) ? d0 : dist2(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
+                // block 0 sees the input positions: its radial IS the d0 the graph pass stored (same dist2, same operands, same
+                // bits) - no position round trip; later blocks form the lazily updated positions (node_pos)
+                r = ((ablate & 1) || layer == 0) ? d0 : dist2(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
             }
             s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
         }
