@@ -511,7 +511,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
                                 // refilled for the next tile by each GEMM's last iteration
     const int E = w.totals[0];
     const int ntiles = (E + MT - 1) / MT;
-#ifdef CMDGEN_STAMPS
+#if CMDGEN_STAMPS == 1
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_t;
 #define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
         lds_barrier();
         STAMP(6);
     }
-#ifdef CMDGEN_STAMPS
+#if CMDGEN_STAMPS == 1
     if ((tid & 63) == 0) {      // lane 0 of every wave: [wave][phase] sums, [32 + wave] = wave lifetime, [40] = waves
         for (int i = 0; i < 7; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
         atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
@@ -669,6 +669,13 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
             *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
         }
     };
+#if CMDGEN_STAMPS == 2      // diagnostic build: per-phase cycle stamps of this kernel into w.dbg (same layout as k_edge_msg's)
+    unsigned long long nst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nst_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long nst_begin = nst_t;
+#define NSTAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); nst_[i] += n_ - nst_t; nst_t = n_; } while (0)
+#else
+#define NSTAMP(i) do {} while (0)
+#endif
     TileAcc<MT> acc;
     acc_zero<MT>(acc);
     if constexpr (TWO) {
@@ -694,8 +701,10 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
             *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
         }
         lds_barrier();
+        NSTAMP(0);
         G::template gemm<H / 8>(buf0, LDA(H), f3a, f3b, acc, carry);                         // h part of [h | agg]
         G::template gemm<H / 8>(buf1, LDA(H), f3b, f4, acc, carry);                          // agg part
+        NSTAMP(1);
     } else {
         load_h();
         lds_barrier();
@@ -715,8 +724,10 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
         }
     });
     lds_barrier();
+    NSTAMP(2);
     acc_zero<MT>(acc);
     G::template gemm<H / 8>(buf1, LDA(H), f4, fc, acc, carry);
+    NSTAMP(3);
     lds_barrier();
     acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {
         float hn = 0.f;
@@ -730,9 +741,20 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
         buf1[row * LDA(H) + col] = hn;
     });
     lds_barrier();
+    NSTAMP(4);
     // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
     tile_project_pq<H, MT, SP>(buf1, lw.Wpq_c, b6v, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
+    NSTAMP(5);
     if (has_next) tile_project_pq<H, MT, SP>(buf1, lw_next.Wpq_e, b1nv, w.P, w.Q, row0, nvalid, true, carry, fn);
+    NSTAMP(6);
+#if CMDGEN_STAMPS == 2
+    if ((tid & 63) == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&w.dbg[wave * 8 + i], nst_[i]);
+        atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - nst_begin);
+        atomicAdd(&w.dbg[40], 1ull);
+    }
+#endif
+#undef NSTAMP
 }
 
 // ------------------------------------------------------------------------------------
