@@ -1,12 +1,13 @@
 #!/bin/bash
 # One pass over everything profiles/ cites (run on the GPU box: gpurun -- 'bash tools/gpu_evidence.sh <tag>').
 # Writes under gpurun_out/<tag>_*; kernel_traffic.json is stamped with the hash of the kernel sources it was measured on.
-tag=${1:-r02_v}
+tag=${1:-r02_w}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out
 set -o pipefail
 run() { echo "== $*" >&2; timeout -k 10 "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: stopping" >&2; exit 1; fi; return $rc; }
 run 700 python -m pytest tests -m gpu -q > $o/${tag}_gpu_tests.log 2>&1; tail -3 $o/${tag}_gpu_tests.log
+run 300 python -m pytest tests/test_hip_split.py -q -s 2>&1 | grep -E "max\|d eps\||RMS|passed|failed" > $o/${tag}_split_tests.log
 run 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $o/${tag}_smoke.txt
 run 300 python bench.py --steps 5 --warmup 2 > $o/${tag}_bench_b64.json 2> $o/${tag}_bench_b64.err
 BARGS="--steps 1 --warmup 0 --timesteps 200 --no-cpu-baseline --north-star-batch 0"     # PMC passes serialise every dispatch: a 200-step chain is plenty
@@ -28,4 +29,6 @@ for a in "--batch 64" "--batch 256" "--batch 256 --gemm bf16" "--batch 64 --gemm
 run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_tstats -- python3 tools/bench_train.py --steps 4 --warmup 2 > /dev/null 2>&1
 cp $(find $o/${tag}_tstats -name "*kernel_stats.csv" | head -1) $o/${tag}_train_kernel_stats_b64.csv; rm -rf $o/${tag}_tstats
 run 200 python tools/bench_joint.py --batch 64 --timesteps 1000 2>/dev/null | tail -1 > $o/${tag}_joint.json
+for b in 64 256; do run 100 python tools/steady_profile.py $b 2>/dev/null | tail -1; done > $o/${tag}_trained_geometry_profile.jsonl
+run 100 python tools/steady_profile.py 64 full-atom 2>/dev/null | tail -1 >> $o/${tag}_trained_geometry_profile.jsonl
 echo done
