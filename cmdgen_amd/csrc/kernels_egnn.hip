@@ -518,13 +518,23 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
 #else
 #define STAMP(i) do {} while (0)
 #endif
+    // The (row, col, d0) triple of a tile is requested one tile ahead (three registers): it arrives during the previous tile's
+    // build / GEMM, so a tile's first phase starts with the position loads instead of two dependent round trips.
+    int nx_row = -1, nx_col = -1; float nx_d0 = 0.f;
+    {
+        const int t0 = xcd_tile(0, ntiles);
+        if (t0 >= 0 && tid < MT && t0 * MT + tid < E) { nx_row = w.erow[t0 * MT + tid]; nx_col = w.ecol[t0 * MT + tid]; nx_d0 = w.ed0[t0 * MT + tid]; }
+    }
     for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
         if (tid < MT) {
-            int row = -1, col = -1; float r = 0.f, d0 = 0.f;
+            const int row = nx_row, col = nx_col; const float d0 = nx_d0;       // -1 / -1 / 0 beyond the list's end
+            nx_row = -1; nx_col = -1; nx_d0 = 0.f;
+            const int tn = xcd_tile(k + 1, ntiles);
+            if (tn >= 0 && tn * MT + tid < E) { nx_row = w.erow[tn * MT + tid]; nx_col = w.ecol[tn * MT + tid]; nx_d0 = w.ed0[tn * MT + tid]; }
+            float r = 0.f;
             if (tid < ne) {
-                row = w.erow[e0 + tid]; col = w.ecol[e0 + tid]; d0 = w.ed0[e0 + tid];
                 // block 0 sees the input positions: its radial IS the d0 the graph pass stored (same dist2, same operands, same
                 // bits) - no position round trip; later blocks form the lazily updated positions (node_pos)
                 r = ((ablate & 1) || layer == 0) ? d0 : dist2(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
