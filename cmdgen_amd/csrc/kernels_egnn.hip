@@ -791,13 +791,21 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
     G::prefetch(fw, carry);                                    // unconditional, see k_edge_msg
     const int E = w.totals[1];
     const int ntiles = (E + MT - 1) / MT;
+    int nx_row = -1, nx_col = -1; float nx_d0 = 0.f;           // the next tile's triple, one tile ahead (see k_edge_msg)
+    {
+        const int t0 = xcd_tile(0, ntiles);
+        if (t0 >= 0 && tid < MT && t0 * MT + tid < E) { nx_row = w.crow[t0 * MT + tid]; nx_col = w.ccol[t0 * MT + tid]; nx_d0 = w.cd0[t0 * MT + tid]; }
+    }
     for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
         if (tid < MT) {
-            int row = -1, col = -1; float r = 0.f, d0 = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+            const int row = nx_row, col = nx_col; const float d0 = nx_d0;               // phar receivers, self loops dropped
+            nx_row = -1; nx_col = -1; nx_d0 = 0.f;
+            const int tn = xcd_tile(k + 1, ntiles);
+            if (tn >= 0 && tn * MT + tid < E) { nx_row = w.crow[tn * MT + tid]; nx_col = w.ccol[tn * MT + tid]; nx_d0 = w.cd0[tn * MT + tid]; }
+            float r = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
             if (tid < ne) {
-                row = w.crow[e0 + tid]; col = w.ccol[e0 + tid]; d0 = w.cd0[e0 + tid];   // phar receivers, self loops dropped
                 const float4 pi = node_pos(lay, w, d, row, layer, false);
                 const float4 pj = node_pos(lay, w, d, col, layer, false);
                 cx = pi.x - pj.x; cy = pi.y - pj.y; cz = pi.z - pj.z;
