@@ -461,6 +461,13 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.prof_events = nullptr; a.ablate = 0;
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     a.split = h->gemm_split ? 1 : 0;
+    {   // k_embed: inside a conditional chain only the phar tiles take the full path (the pocket rows come from the per-chain
+        // cache), and they are few: 16-row tiles spread them over twice the CUs and halve the two projection passes of each
+        // (B=256: 120 tiles of 32 rows 38.6 us -> 240 tiles of 16 rows)
+        const char* ev = getenv("CMDGEN_EMBED_MT");
+        a.embed_mt = ev ? atoi(ev) : (((double)h->lay.Nl / 16.0 <= 2.0 * h->n_cus && !h->dims.joint) ? 16 : a.node_mt);
+        if (a.embed_mt != 16 && a.embed_mt != 32 && a.embed_mt != 64) a.embed_mt = a.node_mt;
+    }
     // (tiles were chosen for the engine in force at cmdgen_set_layout; after a later cmdgen_set_gemm_mode the node kernel
     // still avoids its 64-row tiles on the split engine: 87 vs 132 us at B=256, profiles/r02_o_tile_sweep_split.txt)
     if (a.split && a.node_mt == 64 && !getenv("CMDGEN_NODE_MT")) a.node_mt = 32;

@@ -183,6 +183,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     const LayerW* layers;       // host array [L]
     int edge_grid, coord_grid;  // workgroups of the persistent-style edge kernels (tiles are taken round-robin)
     int node_mt, edge_mt, coord_mt;   // rows per tile (64, 32 or 16) chosen per launch from the row counts
+    int embed_mt = 16;                // k_embed's tile (its critical path is a phar tile: encoders, embedding, two projections)
     std::vector<hipEvent_t>* prof_events;  // when non-null: [3] vectors, (start, stop) event pairs of every msg / node / coord launch
     mutable hipEvent_t pe_start = nullptr, pe_stop = nullptr;   // the pair the next profiled launch carries (hipExtLaunchKernelGGL)
     int ablate;                 // timing-only builds of the edge kernel (cmdgen_time_edge_kernel); 0 in production

@@ -1040,11 +1040,13 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
 #define PROF_BEGIN(k) do { if (a.prof_events && !a.save) { hipEventCreate(&a.pe_start); hipEventCreate(&a.pe_stop); \
                            a.prof_events[k].push_back(a.pe_start); a.prof_events[k].push_back(a.pe_stop); } } while (0)
 #define PROF_END() do { a.pe_start = nullptr; a.pe_stop = nullptr; } while (0)
+    // k_embed's tile: the small one only where the pocket cache serves the pocket rows (inside a conditional chain)
+    const int emt = (chain && !t_arr && a.pcache.c) ? a.embed_mt : a.node_mt;
     REC();
     if (!a.skip_count) hipLaunchKernelGGL(k_edge_count, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket);
     if (a.skip_count == 2) {          // training forward: the graph was built (and its size read back) before the activation store was sized
         REC(); REC();
-        MT_DISPATCH(a.node_mt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
+        MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
     } else if (a.side) {
         // k_embed reads features only, k_edge_write positions and degrees only: they run side by side, and the first
         // consumer of both (k_edge_msg of block 0) waits for the join
@@ -1053,12 +1055,12 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, a.side, a.lay, a.w, a.d);
         hipEventRecord(a.ev_join, a.side);
         REC(); REC();
-        MT_DISPATCH(a.node_mt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
+        MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
         hipStreamWaitEvent(s, a.ev_join, 0);
     } else {
         hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d);
         REC(); REC();
-        MT_DISPATCH(a.node_mt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
+        MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
     }
     REC();
     for (int l = 0; l < a.d.L; ++l) {
