@@ -106,3 +106,32 @@ def test_mode_switch_recaptures_the_step_graph(monkeypatch):
     assert np.array_equal(outs[0][:, 3:], outs[1][:, 3:])
     assert np.allclose(outs[0], outs[2], atol=1e-5)          # same engine, same chain (up to float atomics at tile seams)
     h.close()
+
+
+@pytest.mark.parametrize('mt', [32, 64])
+@pytest.mark.parametrize('seed', range(8))
+def test_fuzz_configurations_on_split_engine(seed, mt, monkeypatch):
+    """The randomised configurations of test_hip_parity (hidden_nf 64 / 128 / 256, 1-5 blocks, flags on / off, complete graphs,
+    no time conditioning, other vocabulary sizes, ragged batches) against the oracle with every tile kernel forced onto the
+    split engine - in particular the short k loops of hidden_nf 64 (K/16 = 4) and 128."""
+    import test_hip_parity
+    force_tiles(monkeypatch, mt)
+    test_hip_parity.test_fuzz_hyperparameters_and_layouts(seed)
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_fuzz_chains_on_split_engine(seed, monkeypatch):
+    """Randomised short chains (hidden_nf 64 / 128, with and without the COM projection, per-step states) vs the oracle chain,
+    32-row tiles forced: every evaluation of the chain on the split engine."""
+    import test_hip_parity
+    force_tiles(monkeypatch, 32)
+    test_hip_parity.test_fuzz_chains(seed)
+
+
+@pytest.mark.parametrize('mt', [32, 64])
+def test_joint_model_on_split_engine(mt, monkeypatch):
+    """The joint model's evaluation (every receiver moves, velocity COM removed): the ragged hidden_nf 64 / 128 / 256 fuzz of
+    test_hip_joint against the oracle with every tile forced onto the split engine."""
+    import test_hip_joint
+    force_tiles(monkeypatch, mt)
+    test_hip_joint.test_joint_dynamics_fuzz_vs_oracle()
