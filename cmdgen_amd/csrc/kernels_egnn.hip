@@ -100,13 +100,14 @@ __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict
     }
 }
 
-__global__ void k_edge_write(Layout lay, Work w, Dims d) {
+// (a device function: it is also the first B workgroups of k_write_embed)
+__device__ __forceinline__ void edge_write_body(const Layout& lay, const Work& w, const Dims& d, const int b) {
     extern __shared__ float4 spos[];
     int* soff = reinterpret_cast<int*>(spos + lay.max_n);
     int* sdg = soff + lay.max_n;                 // the sample's degree words (k_edge_count), read many times below
     __shared__ int s_base[5];
     __shared__ int s_red[6][16];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int nl = lay.num_phar[b], np = lay.num_pocket[b], n = nl + np;
     const int pb = lay.phar_base[b], qb = lay.pocket_base[b];
     const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -207,6 +208,7 @@ __global__ void k_edge_write(Layout lay, Work w, Dims d) {
         atomicAdd(&w.counters[2], (unsigned long long)Ec);
     }
 }
+__global__ void k_edge_write(Layout lay, Work w, Dims d) { edge_write_body(lay, w, d, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------
 // shared pieces of the tile kernels
@@ -247,17 +249,17 @@ __device__ __forceinline__ void tile_project_pq(const float* buf, const WPack& W
 // Encoders are tiny (8->16->32, R->2R->32): plain FMA loops through LDS.
 // ------------------------------------------------------------------------------------
 template <int H, int MT, bool SP>
-__global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW sw, LayerW lw0,
-                                             const float* __restrict__ xh_phar,
-                                             const float* __restrict__ xh_pocket,
-                                             const float* __restrict__ t_arr,
-                                             const float4* __restrict__ coef, const ChainState* chain, TrainSave sv,
-                                             PocketCache pc) {
-    if (pc.c != nullptr && (int)blockIdx.x * MT >= lay.Nl) {
+__device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, const Dims& d, const SmallW& sw, const LayerW& lw0,
+                                           const float* __restrict__ xh_phar,
+                                           const float* __restrict__ xh_pocket,
+                                           const float* __restrict__ t_arr,
+                                           const float4* __restrict__ coef, const ChainState* chain, const TrainSave& sv,
+                                           const PocketCache& pc, const int blk) {
+    if (pc.c != nullptr && blk * MT >= lay.Nl) {
         // A tile of pocket rows inside a conditional chain: nothing but the time feature has changed since the chain
         // started (SURVEY section 7 "Static structure"), so h, P and Q are one fused multiply-add per element from the
         // cache built at the chain's start (cmdgen_sample_chain) - no encoder, no embedding, no GEMM.
-        const int row0 = blockIdx.x * MT, nvalid = min(MT, lay.N - row0);
+        const int row0 = blk * MT, nvalid = min(MT, lay.N - row0);
         const float t = coef[chain->step].w;
         constexpr int LPR = H / 4;
         const int c4 = threadIdx.x % LPR, rsub = threadIdx.x / LPR;
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
     __shared__ float s_h1[MT][CMDGEN_MAX_SMALL];
     __shared__ float s_h2[MT][CMDGEN_MAX_SMALL + 1];
     const int tid = threadIdx.x, nthr = H;
-    const int row0 = blockIdx.x * MT;
+    const int row0 = blk * MT;
     const int nvalid = min(MT, lay.N - row0);
     const int ldp = 3 + d.P, ldq = 3 + d.R;
     const int Fmax = max(d.P, d.R), F1max = 2 * Fmax;
@@ -400,6 +402,24 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
     }
     lds_barrier();
     tile_project_pq<H, MT, SP>(buf, lw0.Wpq_e, b1v, w.P, w.Q, row0, nvalid, true, carry, f0);
+}
+template <int H, int MT, bool SP>
+__global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW sw, LayerW lw0, const float* __restrict__ xh_phar,
+                                             const float* __restrict__ xh_pocket, const float* __restrict__ t_arr,
+                                             const float4* __restrict__ coef, const ChainState* chain, TrainSave sv, PocketCache pc) {
+    embed_body<H, MT, SP>(lay, w, d, sw, lw0, xh_phar, xh_pocket, t_arr, coef, chain, sv, pc, (int)blockIdx.x);
+}
+// Pass 2 of the radius graph (one workgroup per sample, reads positions and degrees) and k_embed (node tiles, reads features and
+// the time) do not depend on each other and are both latency chains of a few workgroups per CU: ONE launch runs them side by
+// side - workgroups 0 .. B-1 write the edge lists, the rest are embedding tiles - instead of two dependent launches (a fork /
+// join on two streams inside the replayed graph cost more than it hid, profiles/r02_b_step_fusion.txt).  H = 256 only: both
+// bodies are written for 256 threads.
+template <int MT, bool SP>
+__global__ __launch_bounds__(256) void k_write_embed(Layout lay, Work w, Dims d, SmallW sw, LayerW lw0, const float* __restrict__ xh_phar,
+                                                     const float* __restrict__ xh_pocket, const float* __restrict__ t_arr,
+                                                     const float4* __restrict__ coef, const ChainState* chain, PocketCache pc) {
+    if ((int)blockIdx.x < lay.B) edge_write_body(lay, w, d, (int)blockIdx.x);
+    else embed_body<256, MT, SP>(lay, w, d, sw, lw0, xh_phar, xh_pocket, t_arr, coef, chain, TrainSave{}, pc, (int)blockIdx.x - lay.B);
 }
 
 // ------------------------------------------------------------------------------------
@@ -996,6 +1016,17 @@ template <int H, int MT, bool SP> static void launch_embed(const EvalLaunch& a, 
     hipLaunchKernelGGL((k_embed<H, MT, SP>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
                        (const ChainState*)chain, a.save ? *a.save : TrainSave{}, (chain && !t) ? a.pcache : PocketCache{});
 }
+template <int H, int MT, bool SP> static void launch_write_embed(const EvalLaunch& a, const float* xp, const float* xq, const float* t,
+                                                                 const float4* coef, ChainState* chain, hipStream_t s) {
+    if constexpr (H == 256) {
+        const int nt = (a.lay.N + MT - 1) / MT;
+        const Dims& d = a.d;
+        const size_t shm_e = sizeof(float) * (size_t)(2 * d.P * d.P + 2 * d.P + d.J * 2 * d.P + d.J + 2 * d.R * d.R + 2 * d.R + d.J * 2 * d.R + d.J);
+        const size_t shm_w = (size_t)a.lay.max_n * (sizeof(float4) + 2 * sizeof(int));
+        hipLaunchKernelGGL((k_write_embed<MT, SP>), dim3(a.lay.B + nt), dim3(256), shm_e > shm_w ? shm_e : shm_w, s, a.lay, a.w, a.d, a.sw,
+                           a.layers[0], xp, xq, t, coef, (const ChainState*)chain, (chain && !t) ? a.pcache : PocketCache{});
+    }
+}
 // SAVE variants (training forward) keep the activations; the sampler's instantiations carry no trace of the stores
 template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, int l, hipStream_t s) {
     const int nt = (a.lay.N + MT - 1) / MT;
@@ -1057,6 +1088,8 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         REC(); REC();
         MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
         hipStreamWaitEvent(s, a.ev_join, 0);
+    } else if (H == 256 && !ev && !a.save && shm <= 64 * 1024 && !getenv("CMDGEN_NO_WRITE_EMBED")) {
+        MT_DISPATCH(emt, launch_write_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);       // both in one launch
     } else {
         hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d);
         REC(); REC();
