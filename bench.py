@@ -61,6 +61,9 @@ def parse(argv=None):
     p.add_argument('--gemm', default=None, choices=['split', 'fp32'],
                    help="matrix engine of tiles of >= 32 rows: 'split' (default of the library: fp32-accurate, six bf16 MFMAs "
                         "per fp32 product) or 'fp32' (v_mfma_f32_32x32x2_f32)")
+    p.add_argument('--rehearse-on-one-gpu', action='store_true',
+                   help='N > 1 ranks that all use cuda:0 and rendezvous over gloo: runs the whole multi-rank path (sharded pockets, '
+                        'barriers, MAX-over-ranks timing, rank count) on a one-GPU box; the number is NOT a scaling result')
     p.add_argument('--dry-run-launch', action='store_true',
                    help='launch logic only (CPU, gloo, no sampling): used by tests/test_bench_launch.py')
     return p.parse_args(argv)
@@ -193,17 +196,22 @@ def main(argv=None):
     if args.dry_run_launch:
         return dry_run(args, world, rank)
     dist = None
+    one_gpu = args.rehearse_on_one_gpu
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        torch.cuda.set_device(0 if one_gpu else local_rank)
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    dev = torch.device('cuda', local_rank if (world > 1 and not one_gpu) else 0)
+    cdev = torch.device('cpu') if one_gpu else dev            # where the collectives' tensors live (gloo: host)
     n_gpus = world
     if dist is not None:                          # the ranks that actually run (RCCL all-reduce of ones)
-        ones = torch.ones(1, device=dev)
+        ones = torch.ones(1, device=cdev)
         dist.all_reduce(ones)
         n_gpus = int(ones.item())
         assert n_gpus == world, (n_gpus, world)
@@ -245,7 +253,7 @@ def main(argv=None):
         cnt = h.counters()
         st = h.chain_status()
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     evals_per_chain = T + 1
@@ -343,6 +351,7 @@ def main(argv=None):
         result = {
             'metric': 'denoising steps/sec', 'value': value, 'unit': 'pocket-steps/s',
             'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
+            **({'rehearsal': f'{world} ranks sharing cuda:0 over gloo (functional rehearsal of the multi-rank path, not a scaling result)'} if one_gpu and world > 1 else {}),
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {

@@ -341,3 +341,21 @@ def test_consecutive_sampling_calls_draw_fresh_noise():
     assert torch.allclose(a, a2, atol=1e-3 * max(1.0, float(a.abs().max())))   # reproducible under manual_seed
     # identical pockets inside one call still get different noise (keyed by pocket id)
     assert not torch.allclose(a[:6, :3] - a[:6, :3].mean(0), a[6:12, :3] - a[6:12, :3].mean(0))
+
+
+def test_bench_multi_rank_path_rehearsed_on_one_gpu():
+    """bench.py --gpus 2 with both ranks on cuda:0 over gloo (--rehearse-on-one-gpu): self-launch, per-rank pocket shards keyed by
+    global ids, barrier + MAX-over-ranks timing, rank count by all-reduce, ONE JSON line from rank 0 - the whole multi-rank path
+    on the hardware a one-GPU box has.  The value is not a scaling result."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rehearse-on-one-gpu', '--batch', '8',
+                        '--timesteps', '40', '--steps', '1', '--warmup', '1', '--no-cpu-baseline'], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['scaling'] == 'weak' and 'rehearsal' in out
+    assert out['config']['pockets_per_gpu'] == 8 and out['cpu_baseline'] is None
