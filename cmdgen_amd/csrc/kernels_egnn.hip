@@ -1088,7 +1088,8 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         REC(); REC();
         MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
         hipStreamWaitEvent(s, a.ev_join, 0);
-    } else if (H == 256 && !ev && !a.save && shm <= 64 * 1024 && !getenv("CMDGEN_NO_WRITE_EMBED")) {
+    } else if (H == 256 && !ev && !a.save && shm <= 64 * 1024 && (size_t)emt * 1812 + 1024 + (shm > 12288 ? shm : 12288) <= 160 * 1024 &&
+               !getenv("CMDGEN_NO_WRITE_EMBED")) {      // (static LDS of the embedding body is 1812 B per tile row; one launch must hold both bodies' LDS)
         MT_DISPATCH(emt, launch_write_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);       // both in one launch
     } else {
         hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d);
