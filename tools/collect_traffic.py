@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 KERNELS = {'edge_msg': 'k_edge_msg', 'node': 'k_node', 'edge_coord': 'k_edge_coord', 'embed': 'k_embed',
            'readout': 'k_readout', 'ddpm_step': 'k_ddpm_step', 'edge_count': 'k_edge_count', 'edge_write': 'k_edge_write',
-           'step_glue': 'k_step_glue'}
+           'step_glue': 'k_step_glue', 'write_embed': 'k_write_embed', 'step_count': 'k_step_count'}
 
 
 def read_counters(directory):
