@@ -1074,6 +1074,7 @@ extern "C" int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16) {
         // captured graphs bake the kernel choice in; the pocket cache is rebuilt per chain anyway
         hipSetDevice(h->device);
         if (h->own_stream) hipStreamSynchronize(h->own_stream);
+        if (h->have_layout) hipStreamSynchronize(h->last_stream);      // a replay of the graph destroyed below may still be running there
         if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
         if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
         h->gemm_split = split_bf16 != 0;
