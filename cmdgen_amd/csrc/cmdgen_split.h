@@ -14,6 +14,10 @@
 // under dense bf16 MFMA): 160-200 TF/s fp32-equivalent for a chain of [64,256] x [256,256] tile products
 // against 157 TF/s PEAK for the fp32 instruction.
 //
+// Non-finite operands: NaN stays NaN; an INFINITE operand also yields NaN here (its second piece is Inf - Inf) where the
+// fp32 instruction yields +-Inf - only reachable after an overflow, where the evaluation's NaN guard (dynamics.py:129-131)
+// then resets the step instead of propagating an infinite velocity.
+//
 // Layouts
 //   A (LDS): the fp32 tile exactly as the fp32-MFMA kernels keep it (rows x (K + 4) floats).  Every wave
 //            splits the fragments it reads in registers (5.5 VALU operations per element, issued in the
