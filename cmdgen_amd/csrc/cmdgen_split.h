@@ -155,3 +155,69 @@ __device__ __forceinline__ void tile_gemm_rsplit(const float* ldsA, int lda, con
 #undef RS_MFMAS
 #undef RS_INTERLEAVE
 }
+
+// ---------------------------------------------------------------------------------------------
+// Plane variant for tiles whose PRODUCER can split: the A operand lies in LDS as three bf16 planes
+// [rows][KH + 8] (KH = the k-range held at a time), written once per element by whoever builds the tile
+// (split_store4), so the GEMM loop carries no VALU work at all.  Used by the edge kernels with KH = K/2: two
+// half-K passes keep the tile at 52 KB (inside the 66 KB fp32 image it aliases), two workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+#define SPLIT_PLANE_LDA(KH) ((KH) + 8)            // bf16 elements per plane row: row stride (KH*2 + 16) bytes, conflict-free ds_read_b128
+
+// four consecutive k-values of one row -> the three planes (8 bytes each)
+__device__ __forceinline__ void split_store4(unsigned short* planes, int plane_elems, int off, const float4& v) {
+    uint32_t a0, a1, a2, b0, b1, b2;
+    split3_pair(v.x, v.y, a0, a1, a2);
+    split3_pair(v.z, v.w, b0, b1, b2);
+    *reinterpret_cast<uint2*>(planes + off) = make_uint2(a0, b0);
+    *reinterpret_cast<uint2*>(planes + plane_elems + off) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(planes + 2 * plane_elems + off) = make_uint2(a2, b2);
+}
+
+template <int MT, int KB16>
+__device__ __forceinline__ void tile_gemm_planes(const unsigned short* planes, int plane_elems, int lda,
+                                                 const SFragPtr cur, const SFragPtr next,
+                                                 sf32x16 (&acc)[MT / 32][2], SCarry& carry) {
+    static_assert(KB16 % 2 == 0, "the k-range of a pass must be a multiple of 32");
+    constexpr int NMT = MT / 32;
+    const int lane = threadIdx.x & 63;
+    const unsigned short* ap = planes + (lane & 31) * lda + (lane >> 5) * 8;
+    const sbf16x8* q0 = cur.p + 192;
+    const sbf16x8* q1 = q0 + cur.ns;
+    sbf16x8 a[2][NMT][3];
+#define PL_LOADA(SET, PTR)                                                                                           \
+    _Pragma("unroll") for (int m = 0; m < NMT; ++m)                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                                \
+            a[SET][m][s] = *reinterpret_cast<const sbf16x8*>((PTR) + s * plane_elems + m * 32 * lda);
+#define PL_MFMAS(AS, BS)                                                                                             \
+    _Pragma("unroll") for (int m = 0; m < NMT; ++m)                                                                  \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                              \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][2], carry.b[BS][n][0], acc[m][n], 0, 0, 0); \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][1], carry.b[BS][n][1], acc[m][n], 0, 0, 0); \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], carry.b[BS][n][2], acc[m][n], 0, 0, 0); \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][1], carry.b[BS][n][0], acc[m][n], 0, 0, 0); \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], carry.b[BS][n][1], acc[m][n], 0, 0, 0); \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], carry.b[BS][n][0], acc[m][n], 0, 0, 0); \
+        }
+    PL_LOADA(0, ap)
+#pragma unroll 1
+    for (int kb = 0; kb < KB16; kb += 2) {
+        const bool more = kb + 2 < KB16;
+        split_load_set(q0, q1, carry.b[1]);
+        PL_LOADA(1, ap + 16)
+        __builtin_amdgcn_sched_barrier(0);
+        PL_MFMAS(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        q0 = more ? q0 + 192 : next.p;
+        q1 = more ? q1 + 192 : next.p + next.ns;
+        split_load_set(q0, q1, carry.b[0]);
+        q0 += 192; q1 += 192;
+        if (more) { PL_LOADA(0, ap + 32) }
+        __builtin_amdgcn_sched_barrier(0);
+        PL_MFMAS(1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        ap += 32;
+    }
+#undef PL_LOADA
+#undef PL_MFMAS
+}

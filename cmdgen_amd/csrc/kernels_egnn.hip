@@ -470,6 +470,42 @@ __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, co
     }
 }
 
+// Half-K tile build for the plane variant of the split engine (H = 256): columns [128 half, 128 half + 128) of
+//   SiLU(P[row_e] + Q[col_e] + w_r radial_e + w_d d0_e)
+// split into three bf16 pieces ONCE, by the thread that computes them, and written as three planes [MT][136] - so the
+// GEMM that follows carries no conversion work (cmdgen_split.h, tile_gemm_planes).  w_r / w_d come from LDS (s_wr, s_wd).
+template <int MT>
+__device__ __forceinline__ void build_edge_half(unsigned short* planes, int half, const int* s_row, const int* s_col,
+                                                const float* s_r, const float* s_d0, int ne,
+                                                const float* __restrict__ P, const float* __restrict__ Q,
+                                                const float* s_wr, const float* s_wd) {
+    constexpr int H = 256, PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
+    const int c4 = threadIdx.x & 31, rsub = threadIdx.x >> 5;          // 32 lanes x 16 bytes = one half row, 8 rows per pass
+    const int col = half * (H / 2) + 4 * c4;
+    const float4 wr4 = *reinterpret_cast<const float4*>(s_wr + col), wd4 = *reinterpret_cast<const float4*>(s_wd + col);
+    float4 p[MT / 8], q[MT / 8];
+#pragma unroll
+    for (int pass = 0; pass < MT / 8; ++pass) {
+        const int e = pass * 8 + rsub;
+        p[pass] = make_float4(0.f, 0.f, 0.f, 0.f); q[pass] = p[pass];
+        if (e < ne) {
+            p[pass] = *reinterpret_cast<const float4*>(P + (size_t)s_row[e] * H + col);
+            q[pass] = *reinterpret_cast<const float4*>(Q + (size_t)s_col[e] * H + col);
+        }
+    }
+#pragma unroll
+    for (int pass = 0; pass < MT / 8; ++pass) {
+        const int e = pass * 8 + rsub;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < ne) {
+            const float r = s_r[e], d0 = s_d0[e];
+            a.x = silu_f(p[pass].x + q[pass].x + wr4.x * r + wd4.x * d0); a.y = silu_f(p[pass].y + q[pass].y + wr4.y * r + wd4.y * d0);
+            a.z = silu_f(p[pass].z + q[pass].z + wr4.z * r + wd4.z * d0); a.w = silu_f(p[pass].w + q[pass].w + wr4.w * r + wd4.w * d0);
+        }
+        split_store4(planes, PE, e * PLDA + 4 * c4, a);
+    }
+}
+
 // per-row dot product of the LDS tile with a weight vector: H/MT threads per row
 template <int H, int MT>
 __device__ __forceinline__ float tile_row_dot(const float* buf, const float* wv, int& r_out, bool& lead) {
@@ -520,6 +556,9 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
     __shared__ __attribute__((aligned(16))) float s_wa[H];     // att_mlp weight: read by every tile's row dot (LDS broadcast, not 16 L1 round trips)
     const int tid = threadIdx.x, wave = tid >> 6;
     s_wa[tid] = lw.wa[tid];                                    // visible after the first tile's barriers
+    constexpr bool PL = SP && H == 256 && !SAVE;               // plane variant: the producer splits (build_edge_half)
+    __shared__ __attribute__((aligned(16))) float s_wrd[PL ? 2 * H : 4];
+    if constexpr (PL) { s_wrd[tid] = lw.wr_e[tid]; s_wrd[H + tid] = lw.wd_e[tid]; }
     const ColVec<MT> b2v = col_load<MT>(lw.b2, wave);          // per-column bias and the gate's bias: once per workgroup
     const float ba0 = lw.ba[0];
     const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_e)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_e)[tid % (H / 4)];
@@ -563,14 +602,29 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
         }
         lds_barrier();
         STAMP(0);
+        TileAcc<MT> acc;
+        acc_zero<MT>(acc);
+        if constexpr (PL) {
+            // two half-K passes: build columns [0,128) as bf16 planes -> GEMM over k 0..127 -> build [128,256) -> GEMM over the rest
+            unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
+            constexpr int PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
+            const typename G::Frag fw1 = G::frag(lw.W2, H / 8, H / 16, wave);
+            if (!(ablate & 2)) build_edge_half<MT>(planes, 0, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, s_wrd, s_wrd + H);
+            lds_barrier();
+            if (!(ablate & 4)) tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw, fw1, acc.a, carry);
+            lds_barrier();
+            if (!(ablate & 2)) build_edge_half<MT>(planes, 1, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, s_wrd, s_wrd + H);
+            lds_barrier();
+            STAMP(1);
+            if (!(ablate & 4)) tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw1, fw, acc.a, carry);
+        } else {
         if (!(ablate & 2)) build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4,
                                                   SAVE ? sv.pre1 + ((size_t)layer * sv.ecap + e0) * H : nullptr,
                                                   SAVE ? sv.act1 + ((size_t)layer * sv.ecap + e0) * H : nullptr);
         lds_barrier();
         STAMP(1);
-        TileAcc<MT> acc;
-        acc_zero<MT>(acc);
         if (!(ablate & 4)) G::template gemm<H / 8>(buf, LDA(H), fw, fw, acc, carry);
+        }
         STAMP(2);
         lds_barrier();                         // every wave is done reading the A tile
         STAMP(3);
