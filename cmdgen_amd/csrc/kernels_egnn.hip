@@ -857,6 +857,9 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
     __shared__ __attribute__((aligned(16))) float s_w5[H];     // coord_mlp.4 weight, staged once per workgroup (see k_edge_msg)
     const int tid = threadIdx.x, wave = tid >> 6;
     s_w5[tid] = lw.w5[tid];
+    constexpr bool PL = SP && H == 256 && !SAVE;               // plane variant, see k_edge_msg
+    __shared__ __attribute__((aligned(16))) float s_wrd[PL ? 2 * H : 4];
+    if constexpr (PL) { s_wrd[tid] = lw.wr_c[tid]; s_wrd[H + tid] = lw.wd_c[tid]; }
     const ColVec<MT> b7v = col_load<MT>(lw.b7, wave);
     const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_c)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_c)[tid % (H / 4)];
     typedef Eng<MT, SP> G;
@@ -891,13 +894,26 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
             s_cd[tid][0] = cx; s_cd[tid][1] = cy; s_cd[tid][2] = cz;
         }
         lds_barrier();
+        TileAcc<MT> acc;
+        acc_zero<MT>(acc);
+        if constexpr (PL) {
+            unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
+            constexpr int PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
+            const typename G::Frag fw1 = G::frag(lw.W7, H / 8, H / 16, wave);
+            build_edge_half<MT>(planes, 0, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, s_wrd, s_wrd + H);
+            lds_barrier();
+            tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw, fw1, acc.a, carry);
+            lds_barrier();
+            build_edge_half<MT>(planes, 1, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, s_wrd, s_wrd + H);
+            lds_barrier();
+            tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw1, fw, acc.a, carry);
+        } else {
         build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, wr4, wd4,
                                SAVE ? sv.pre6 + ((size_t)layer * sv.eccap + e0) * H : nullptr,
                                SAVE ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr);
         lds_barrier();
-        TileAcc<MT> acc;
-        acc_zero<MT>(acc);
         G::template gemm<H / 8>(buf, LDA(H), fw, fw, acc, carry);
+        }
         lds_barrier();
         acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {
             const float pre = v + b7v.v[n], a = silu_f(pre);
