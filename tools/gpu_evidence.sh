@@ -1,7 +1,7 @@
 #!/bin/bash
 # One pass over everything profiles/ cites (run on the GPU box: gpurun -- 'bash tools/gpu_evidence.sh <tag>').
 # Writes under gpurun_out/<tag>_*; kernel_traffic.json is stamped with the hash of the kernel sources it was measured on.
-tag=${1:-r02_x}
+tag=${1:-r02_zz}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out
 set -o pipefail
