@@ -819,12 +819,20 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
             float* hp = w.h + (size_t)(row0 + row) * H + col;
             const float hold = TWO ? buf0[row * LDA(H) + col] : *hp;
             hn = hold + (v + b4v.v[n]);                                                 // residual (egnn_new.py:57)
-            *hp = hn;
+            if (MT != 32 || SAVE) *hp = hn;     // 32-row tiles of the sampler store h from the LDS image below, as whole rows
             if (SAVE) sv.h[((size_t)(layer + 1) * lay.N + row0 + row) * H + col] = hn;   // h entering block layer+1
         }
         buf1[row * LDA(H) + col] = hn;
     });
     lds_barrier();
+    if constexpr (MT == 32 && !SAVE) {      // h_new is in LDS for the projections anyway: it leaves as 1 KiB rows, 16 bytes per lane
+                                            // (B=256: +0.7 %; at 16 rows the scalar stores are as good, gpurun_out/r2zw_h_rowstore_ab.txt)
+#pragma unroll
+        for (int pass = 0; pass < MT / 4; ++pass) {
+            const int r = pass * 4 + rsub;
+            if (r < nvalid) reinterpret_cast<float4*>(w.h + (size_t)(row0 + r) * H)[c4] = *reinterpret_cast<const float4*>(buf1 + r * LDA(H) + 4 * c4);
+        }
+    }
     NSTAMP(4);
     // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
     tile_project_pq<H, MT, SP>(buf1, lw.Wpq_c, b6v, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
