@@ -275,6 +275,12 @@ __device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, con
         }
         return;
     }
+#if CMDGEN_STAMPS == 3
+    unsigned long long est_[8] = {0,0,0,0,0,0,0,0}, est_t = __builtin_amdgcn_s_memtime(); const unsigned long long est_b = est_t;
+#define ESTAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); est_[i] += n_ - est_t; est_t = n_; } while (0)
+#else
+#define ESTAMP(i) do {} while (0)
+#endif
     __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
     __shared__ float s_in[MT][CMDGEN_MAX_SMALL];
     __shared__ float s_h1[MT][CMDGEN_MAX_SMALL];
@@ -332,6 +338,7 @@ __device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, con
         s_in[r][k] = v;
     }
     lds_barrier();
+    ESTAMP(0);
     // encoder layer 0 + SiLU: thread -> (row r, output o)
     for (int idx = tid; idx < MT * F1max; idx += nthr) {
         const int r = idx / F1max, o = idx - r * F1max;
@@ -352,6 +359,7 @@ __device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, con
         }
     }
     lds_barrier();
+    ESTAMP(1);
     // encoder layer 2 -> joint space, then the time column (dynamics.py:92-99)
     for (int idx = tid; idx < MT * d.dyn; idx += nthr) {
         const int r = idx / d.dyn, j = idx - r * d.dyn;
@@ -373,6 +381,7 @@ __device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, con
         s_h2[r][j] = s;
     }
     lds_barrier();
+    ESTAMP(2);
     {   // embedding dyn -> H: one output column per thread, weights transposed [dyn][H] (coalesced)
         const int c = tid;
         const float bc = sw.emb_b[c];
@@ -401,7 +410,14 @@ __device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, con
         }
     }
     lds_barrier();
+    ESTAMP(3);
     tile_project_pq<H, MT, SP>(buf, lw0.Wpq_e, b1v, w.P, w.Q, row0, nvalid, true, carry, f0);
+    ESTAMP(4);
+#if CMDGEN_STAMPS == 3
+    if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; for (int i = 0; i < 5; ++i) atomicAdd(&w.dbg[wv * 8 + i], est_[i]);
+        atomicAdd(&w.dbg[32 + wv], __builtin_amdgcn_s_memtime() - est_b); atomicAdd(&w.dbg[40], 1ull); }
+#endif
+#undef ESTAMP
 }
 template <int H, int MT, bool SP>
 __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW sw, LayerW lw0, const float* __restrict__ xh_phar,
