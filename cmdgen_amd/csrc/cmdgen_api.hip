@@ -218,6 +218,16 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
     GET(dy + "residue_encoder.2.weight", d.J * 2 * d.R); UP(s.re2_w); GET(dy + "residue_encoder.2.bias", d.J); UP(s.re2_b);
     GET(dy + "residue_decoder.0.weight", 2 * d.R * d.J); UP(s.rd0_w); GET(dy + "residue_decoder.0.bias", 2 * d.R); UP(s.rd0_b);
     GET(dy + "residue_decoder.2.weight", d.R * 2 * d.R); UP(s.rd2_w); GET(dy + "residue_decoder.2.bias", d.R); UP(s.rd2_b);
+    {   // the encoders' tensors once more, contiguous, in the order k_embed lays them out in LDS
+        std::vector<float> pack;
+        for (const char* nm : {"phar_encoder.0.weight", "phar_encoder.0.bias", "phar_encoder.2.weight", "phar_encoder.2.bias",
+                               "residue_encoder.0.weight", "residue_encoder.0.bias", "residue_encoder.2.weight", "residue_encoder.2.bias"}) {
+            auto it = h->staged.find(dy + nm);
+            if (it == h->staged.end()) return fail(h, CMDGEN_ESTATE, "missing tensor '%s%s'", dy.c_str(), nm);
+            pack.insert(pack.end(), it->second.begin(), it->second.end());
+        }
+        rc = upload(h, pack, &s.enc_pack); if (rc) return rc;
+    }
     {   // embedding [H][dyn] -> transposed [dyn][H]
         GET(dy + "egnn.embedding.weight", H * d.dyn);
         std::vector<float> t((size_t)H * d.dyn);

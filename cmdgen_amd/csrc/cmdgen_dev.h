@@ -64,6 +64,8 @@ struct SmallW {                 // encoders / decoders / embeddings, plain [out]
     const float *rd0_w, *rd0_b, *rd2_w, *rd2_b;     // residue_decoder (:39-43)
     const float *emb_wT, *emb_b;                    // egnn.embedding, stored transposed [J+1][H]
     const float *embo_wT, *embo_b;                  // egnn.embedding_out, stored transposed [H][J+1]
+    const float *enc_pack;                          // the eight encoder tensors (pe0_w, pe0_b, pe2_w, pe2_b, re0_w, re0_b, re2_w, re2_b)
+                                                    // back to back in one buffer (k_embed copies them to LDS); null in training
 };
 
 struct Dims {

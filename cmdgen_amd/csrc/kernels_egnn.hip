@@ -306,6 +306,25 @@ __device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, con
     seg_o[0] = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) seg_o[q + 1] = seg_o[q] + seg_n[q];
+    // the tile's input features: requested first (registers), written to LDS after the encoder tensors, so that both sets of
+    // loads are in flight together (written where they were loaded, the second set waited for the first: two round trips)
+    constexpr int NIN = (MT * CMDGEN_MAX_SMALL + H - 1) / H;            // upper bound of (row, feature) pairs per thread
+    float vin[NIN];
+#pragma unroll
+    for (int q = 0; q < NIN; ++q) {
+        const int idx = tid + q * nthr;
+        vin[q] = 0.f;
+        if (idx < MT * Fmax) {
+            const int r = idx / Fmax, k = idx - r * Fmax, n = row0 + r;
+            if (r < nvalid) {
+                if (n < lay.Nl) { if (k < d.P) vin[q] = xh_phar[(size_t)n * ldp + 3 + k]; }
+                else if (k < d.R) vin[q] = xh_pocket[(size_t)(n - lay.Nl) * ldq + 3 + k];
+            }
+        }
+    }
+    if (sw.enc_pack) {          // sampler: the eight tensors lie contiguous in one device buffer (cmdgen_finalize_weights)
+        for (int i = tid; i < seg_o[8]; i += nthr) s_enc[i] = sw.enc_pack[i];
+    } else
     for (int base = 0; base < seg_o[8]; base += 16 * nthr) {
         float v[16];
 #pragma unroll
@@ -327,15 +346,10 @@ __device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, con
     }
     const float *pe0w = s_enc + seg_o[0], *pe0b = s_enc + seg_o[1], *pe2w = s_enc + seg_o[2], *pe2b = s_enc + seg_o[3];
     const float *re0w = s_enc + seg_o[4], *re0b = s_enc + seg_o[5], *re2w = s_enc + seg_o[6], *re2b = s_enc + seg_o[7];
-    for (int idx = tid; idx < MT * Fmax; idx += nthr) {   // stage input features: one (row, feature) pair per thread, so the
-        const int r = idx / Fmax, k = idx - r * Fmax;     // loads of a tile are all in flight together (a per-row loop
-        const int n = row0 + r;                           // serialised 16 L2 round trips on 20 active lanes)
-        float v = 0.f;
-        if (r < nvalid) {
-            if (n < lay.Nl) { if (k < d.P) v = xh_phar[(size_t)n * ldp + 3 + k]; }
-            else if (k < d.R) v = xh_pocket[(size_t)(n - lay.Nl) * ldq + 3 + k];
-        }
-        s_in[r][k] = v;
+#pragma unroll
+    for (int q = 0; q < NIN; ++q) {                       // one (row, feature) pair per thread and slot
+        const int idx = tid + q * nthr;
+        if (idx < MT * Fmax) { const int r = idx / Fmax; s_in[r][idx - r * Fmax] = vin[q]; }
     }
     lds_barrier();
     ESTAMP(0);
