@@ -229,19 +229,22 @@ template <int H, int MT, bool SP>
 __device__ __forceinline__ void tile_project_pq(const float* buf, const WPack& Wpq,
                                                 const ColVec<MT>& bias_p, float* __restrict__ Pout,
                                                 float* __restrict__ Qout, int row0, int nvalid,
-                                                bool want_p, typename Eng<MT, SP>::Carry& carry, const typename Eng<MT, SP>::Frag after) {
+                                                bool want_p, typename Eng<MT, SP>::Carry& carry, const typename Eng<MT, SP>::Frag after,
+                                                bool want_q = true) {
     typedef Eng<MT, SP> G;
     const int wave = threadIdx.x >> 6;
     const typename G::Frag fp = G::frag(Wpq, H / 8, 0, wave), fq = G::frag(Wpq, H / 8, 0, H / 64 + wave);
     TileAcc<MT> acc;
     if (want_p) {
         acc_zero<MT>(acc);
-        G::template gemm<H / 8>(buf, LDA(H), fp, fq, acc, carry);
+        G::template gemm<H / 8>(buf, LDA(H), fp, want_q ? fq : after, acc, carry);
         store_acc_rows<H, MT>(acc, wave, Pout, row0, nvalid, &bias_p);
     }
-    acc_zero<MT>(acc);
-    G::template gemm<H / 8>(buf, LDA(H), fq, after, acc, carry);
-    store_acc_rows<H, MT>(acc, wave, Qout, row0, nvalid, nullptr);
+    if (want_q) {
+        acc_zero<MT>(acc);
+        G::template gemm<H / 8>(buf, LDA(H), fq, after, acc, carry);
+        store_acc_rows<H, MT>(acc, wave, Qout, row0, nvalid, nullptr);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -254,7 +257,10 @@ __device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, con
                                            const float* __restrict__ xh_pocket,
                                            const float* __restrict__ t_arr,
                                            const float4* __restrict__ coef, const ChainState* chain, const TrainSave& sv,
-                                           const PocketCache& pc, const int blk) {
+                                           const PocketCache& pc, const int blk, const int part = 2) {
+    // part: 2 = the whole tile; 0 / 1 = one workgroup of a PAIR that shares a full-path tile inside a chain: both run the
+    // encoders and the embedding (cheap), 0 writes h and projects P, 1 projects Q - the two 16-row projection passes were 40 %
+    // of the tile's critical path when one workgroup ran them back to back (profiles/r02_b_step_fusion.txt, cycle stamps)
     if (pc.c != nullptr && blk * MT >= lay.Nl) {
         // A tile of pocket rows inside a conditional chain: nothing but the time feature has changed since the chain
         // started (SURVEY section 7 "Static structure"), so h, P and Q are one fused multiply-add per element from the
@@ -292,7 +298,7 @@ __device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, con
     const int Fmax = max(d.P, d.R), F1max = 2 * Fmax;
     typedef Eng<MT, SP> G;
     typename G::Carry carry;                           // weight fragments of the projection, in flight during the encoders
-    const typename G::Frag f0 = G::frag(lw0.Wpq_e, H / 8, 0, tid >> 6);
+    const typename G::Frag f0 = G::frag(lw0.Wpq_e, H / 8, 0, (part == 1 ? H / 64 : 0) + (tid >> 6));
     G::prefetch(f0, carry);
     const ColVec<MT> b1v = col_load<MT>(lw0.b1, tid >> 6);       // needed by the projection's epilogue four phases later
     const float t_chain = t_arr ? 0.f : coef[chain->step].w;     // two dependent loads: issued now, needed three phases later
@@ -417,7 +423,7 @@ __device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, con
         for (int r = 0; r < MT; ++r) {
             const float s = r < nvalid ? accr[r] : 0.f;
             buf[r * LDA(H) + c] = s;
-            if (r < nvalid) {
+            if (r < nvalid && part != 1) {
                 w.h[(size_t)(row0 + r) * H + c] = s;
                 if (sv.h) sv.h[(size_t)(row0 + r) * H + c] = s;      // h entering block 0
             }
@@ -425,7 +431,7 @@ __device__ __forceinline__ void embed_body(const Layout& lay, const Work& w, con
     }
     lds_barrier();
     ESTAMP(3);
-    tile_project_pq<H, MT, SP>(buf, lw0.Wpq_e, b1v, w.P, w.Q, row0, nvalid, true, carry, f0);
+    tile_project_pq<H, MT, SP>(buf, lw0.Wpq_e, b1v, w.P, w.Q, row0, nvalid, part != 1, carry, f0, part != 0);
     ESTAMP(4);
 #if CMDGEN_STAMPS == 3
     if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; for (int i = 0; i < 5; ++i) atomicAdd(&w.dbg[wv * 8 + i], est_[i]);
@@ -447,9 +453,13 @@ __global__ __launch_bounds__(H) void k_embed(Layout lay, Work w, Dims d, SmallW 
 template <int MT, bool SP>
 __global__ __launch_bounds__(256) void k_write_embed(Layout lay, Work w, Dims d, SmallW sw, LayerW lw0, const float* __restrict__ xh_phar,
                                                      const float* __restrict__ xh_pocket, const float* __restrict__ t_arr,
-                                                     const float4* __restrict__ coef, const ChainState* chain, PocketCache pc) {
-    if ((int)blockIdx.x < lay.B) edge_write_body(lay, w, d, (int)blockIdx.x);
-    else embed_body<256, MT, SP>(lay, w, d, sw, lw0, xh_phar, xh_pocket, t_arr, coef, chain, TrainSave{}, pc, (int)blockIdx.x - lay.B);
+                                                     const float4* __restrict__ coef, const ChainState* chain, PocketCache pc, int npair) {
+    // workgroups: [0, B) edge lists | [B, B + 2 npair) pairs over the first npair tiles (the full-path tiles of a chain) |
+    // the rest: one workgroup per remaining tile
+    const int i = (int)blockIdx.x - lay.B;
+    if (i < 0) edge_write_body(lay, w, d, (int)blockIdx.x);
+    else if (i < 2 * npair) embed_body<256, MT, SP>(lay, w, d, sw, lw0, xh_phar, xh_pocket, t_arr, coef, chain, TrainSave{}, pc, i >> 1, i & 1);
+    else embed_body<256, MT, SP>(lay, w, d, sw, lw0, xh_phar, xh_pocket, t_arr, coef, chain, TrainSave{}, pc, i - npair, 2);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1131,8 +1141,10 @@ template <int H, int MT, bool SP> static void launch_write_embed(const EvalLaunc
         const Dims& d = a.d;
         const size_t shm_e = sizeof(float) * (size_t)(2 * d.P * d.P + 2 * d.P + d.J * 2 * d.P + d.J + 2 * d.R * d.R + 2 * d.R + d.J * 2 * d.R + d.J);
         const size_t shm_w = (size_t)a.lay.max_n * (sizeof(float4) + 2 * sizeof(int));
-        hipLaunchKernelGGL((k_write_embed<MT, SP>), dim3(a.lay.B + nt), dim3(256), shm_e > shm_w ? shm_e : shm_w, s, a.lay, a.w, a.d, a.sw,
-                           a.layers[0], xp, xq, t, coef, (const ChainState*)chain, (chain && !t) ? a.pcache : PocketCache{});
+        const PocketCache pc = (chain && !t) ? a.pcache : PocketCache{};
+        const int npair = pc.c ? (a.lay.Nl + MT - 1) / MT : 0;        // pairs only where the other tiles are cache tiles
+        hipLaunchKernelGGL((k_write_embed<MT, SP>), dim3(a.lay.B + nt + npair), dim3(256), shm_e > shm_w ? shm_e : shm_w, s, a.lay, a.w, a.d, a.sw,
+                           a.layers[0], xp, xq, t, coef, (const ChainState*)chain, pc, npair);
     }
 }
 // SAVE variants (training forward) keep the activations; the sampler's instantiations carry no trace of the stores
