@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64) void k_chain_drift_fix(Layout lay, Dims d, floa
 // 256 threads per sample.  Arithmetic and summation order of the step are those of k_ddpm_step (bit-identical
 // results); the count pass is k_edge_count's (same dist2, same ballots).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_step_count(Layout lay, Dims d, ChainBuf c, Work w,
+__global__ __launch_bounds__(1024) void k_step_count(Layout lay, Dims d, ChainBuf c, Work w,
                                                     const float* __restrict__ eps) {
     extern __shared__ float4 s_pos[];               // [max_n] positions of the sample (phar first), then int sdeg[max_n], then z
     int* sdeg = reinterpret_cast<int*>(s_pos + lay.max_n);
@@ -348,7 +348,7 @@ void cmdgen_launch_ddpm_step(const Layout& lay, const Dims& d, const ChainBuf& c
 void cmdgen_launch_step_count(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
                               const float* eps, hipStream_t s) {
     const size_t shm = (size_t)lay.max_n * (sizeof(float4) + sizeof(int)) + (size_t)lay.max_n * (3 + d.P) * sizeof(float);
-    hipLaunchKernelGGL(k_step_count, dim3(lay.B), dim3(256), shm, s, lay, d, c, w, eps);
+    hipLaunchKernelGGL(k_step_count, dim3(lay.B), dim3(lay.max_n > 128 ? 1024 : 256), shm, s, lay, d, c, w, eps);     // 16 waves for big samples (one receiver per wave at a time)
 }
 void cmdgen_launch_chain_final(const Layout& lay, const Dims& d, const ChainBuf& c, const Work& w,
                                const float* eps, float* xo, float* po, unsigned int* cog, hipStream_t s) {

@@ -1194,7 +1194,9 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     // k_embed's tile: the small one only where the pocket cache serves the pocket rows (inside a conditional chain)
     const int emt = (chain && !t_arr && a.pcache.c) ? a.embed_mt : a.node_mt;
     REC();
-    if (!a.skip_count) hipLaunchKernelGGL(k_edge_count, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket);
+    // per-sample graph kernels: one wave scans one receiver at a time, so big samples (full-atom pockets: 381 nodes) get 16 waves
+    const int gthr = a.lay.max_n > 128 ? 1024 : 256;
+    if (!a.skip_count) hipLaunchKernelGGL(k_edge_count, dim3(B), dim3(gthr), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket);
     if (a.skip_count == 2) {          // training forward: the graph was built (and its size read back) before the activation store was sized
         REC(); REC();
         MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
@@ -1203,16 +1205,16 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         // consumer of both (k_edge_msg of block 0) waits for the join
         hipEventRecord(a.ev_fork, s);
         hipStreamWaitEvent(a.side, a.ev_fork, 0);
-        hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, a.side, a.lay, a.w, a.d);
+        hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(gthr), shm, a.side, a.lay, a.w, a.d);
         hipEventRecord(a.ev_join, a.side);
         REC(); REC();
         MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
         hipStreamWaitEvent(s, a.ev_join, 0);
-    } else if (H == 256 && !ev && !a.save && shm <= 64 * 1024 && (size_t)emt * 1812 + 1024 + (shm > 12288 ? shm : 12288) <= 160 * 1024 &&
+    } else if (H == 256 && !ev && !a.save && gthr == 256 && shm <= 64 * 1024 && (size_t)emt * 1812 + 1024 + (shm > 12288 ? shm : 12288) <= 160 * 1024 &&
                !getenv("CMDGEN_NO_WRITE_EMBED")) {      // (static LDS of the embedding body is 1812 B per tile row; one launch must hold both bodies' LDS)
         MT_DISPATCH(emt, launch_write_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);       // both in one launch
     } else {
-        hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(256), shm, s, a.lay, a.w, a.d);
+        hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(gthr), shm, s, a.lay, a.w, a.d);
         REC(); REC();
         MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
     }
@@ -1310,8 +1312,9 @@ void cmdgen_launch_save_positions(const EvalLaunch& a, float4* X, hipStream_t s)
 // radius graph only (the training path builds its own evaluation on top of the same compact lists)
 void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s) {
     const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + 2 * sizeof(int));
-    hipLaunchKernelGGL(k_edge_count, dim3(a.lay.B), dim3(256), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket);
-    hipLaunchKernelGGL(k_edge_write, dim3(a.lay.B), dim3(256), shm, s, a.lay, a.w, a.d);
+    const int gthr = a.lay.max_n > 128 ? 1024 : 256;
+    hipLaunchKernelGGL(k_edge_count, dim3(a.lay.B), dim3(gthr), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket);
+    hipLaunchKernelGGL(k_edge_write, dim3(a.lay.B), dim3(gthr), shm, s, a.lay, a.w, a.d);
 }
 
 // dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel (samples of more than ~2700 nodes)
