@@ -58,6 +58,10 @@ void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, flo
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
               float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s);
 void tr_sqsum(size_t n, const float* x, float* out, hipStream_t s);
+void tr_noise(const Layout& lay, const Dims& d, const float* px, const float* poh, const float* qx, const float* qoh, const float* tab,
+              const float* eps, float* z_t, float* xh_pocket, float* klsum, hipStream_t s);
+void tr_loss(const Layout& lay, const Dims& d, int l2, float T, const float* net, const float* eps, const float* z_t, const float* poh,
+             const float* tab, const float* klsum, float* terms, float* d_eps, float* means, hipStream_t s);
 
 // ---------------------------------------------------------------------------------
 // flat parameter layout: the reference's registration order (state_dict order below 'dynamics.'), weight then bias
@@ -513,6 +517,36 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     tr_silu_bwd(t->denca_p, t->enc1_p, (size_t)Np * 2 * R, s);
     linear_wgrad(grad, tb.re0, 0, R, Np, t->denca_p, 2 * R, t->xh_pocket + 3, ldq, s);
     bias_grad(tb.re0, Np, t->denca_p, 2 * R);
+    HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_train_noise(cmdgen_handle* h, const float* phar_x, const float* phar_one_hot, const float* pocket_x,
+                                  const float* pocket_one_hot, const float* tab, const float* eps, float* z_t, float* xh_pocket,
+                                  float* kl_sums, cmdgen_stream stream) {
+    if (!h) return CMDGEN_EINVAL;
+    if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
+    if (h->dims.joint) return fail(h, CMDGEN_ESTATE, "cmdgen_train_noise is the conditional model's noising");
+    if (!phar_x || !phar_one_hot || !pocket_x || !pocket_one_hot || !tab || !eps || !z_t || !xh_pocket || !kl_sums)
+        return fail(h, CMDGEN_EINVAL, "null device pointer");
+    hipSetDevice(h->device);
+    h->last_stream = (hipStream_t)stream;
+    tr_noise(h->lay, h->dims, phar_x, phar_one_hot, pocket_x, pocket_one_hot, tab, eps, z_t, xh_pocket, kl_sums, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_train_loss(cmdgen_handle* h, int32_t l2, float T, const float* net_out, const float* eps, const float* z_t,
+                                 const float* phar_one_hot, const float* tab, const float* kl_sums, float* terms, float* d_eps,
+                                 float* means, cmdgen_stream stream) {
+    if (!h) return CMDGEN_EINVAL;
+    if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
+    if (h->dims.joint) return fail(h, CMDGEN_ESTATE, "cmdgen_train_loss is the conditional model's loss");
+    if (!net_out || !eps || !z_t || !phar_one_hot || !tab || !kl_sums || !terms || !d_eps || !means)
+        return fail(h, CMDGEN_EINVAL, "null device pointer");
+    hipSetDevice(h->device);
+    h->last_stream = (hipStream_t)stream;
+    tr_loss(h->lay, h->dims, l2, T, net_out, eps, z_t, phar_one_hot, tab, kl_sums, terms, d_eps, means, (hipStream_t)stream);
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;
 }

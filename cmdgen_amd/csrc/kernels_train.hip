@@ -875,6 +875,187 @@ __global__ void k_sqsum(size_t n, const float* __restrict__ x, float* __restrict
 }
 
 // ------------------------------------------------------------------------------------
+// The loss side of the conditional training step (conditional_model.py:198-320 + lightning_modules.py:188-239 of the
+// reference) as three launches instead of ~270 small tensor ops: the noising of a batch (normalize, remove_mean_batch,
+// noised_representation), the per-sample loss terms together with dL/d eps, and their batch means.  One workgroup per
+// sample (a sample has tens of phar nodes and tens to hundreds of pocket nodes); the per-sample scalars that depend
+// only on t and on the node counts (alpha_t, sigma_t, SNR weight, the normalisation constants, log p(N)) come from the
+// host in `tab`, column-major [TT_COLS][B].
+// ------------------------------------------------------------------------------------
+enum { TT_ALPHA_T = 0, TT_SIGMA_T, TT_T0, TT_SNRW, TT_ALPHA_TT, TT_SIGMA_TT, TT_NEGLOGC, TT_DLOGPX, TT_LOGPN, TT_TINT, TT_T, TT_S0CAT, TT_COLS };
+enum { TS_NLL = 0, TS_ERR_T, TS_LOSS_0, TS_KL, TS_ABS_X, TS_ABS_H, TS_LOSS_0X, TS_LOSS_0H, TS_LOSS_T, TS_COLS = 12 };
+
+// sum of up to three per-thread values over a 256-thread workgroup; every thread gets the totals
+__device__ __forceinline__ void wg_sum3(float& a, float& b, float& c, float* red /* [12] */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[w] = a; red[4 + w] = b; red[8 + w] = c; }
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]); b = (red[4] + red[5]) + (red[6] + red[7]); c = (red[8] + red[9]) + (red[10] + red[11]);
+}
+
+// z_t, the centred pocket and the two sums of the prior KL term of every sample
+__global__ __launch_bounds__(256) void k_train_noise(Layout lay, Dims d, const float* __restrict__ px, const float* __restrict__ poh,
+                                                     const float* __restrict__ qx, const float* __restrict__ qoh,
+                                                     const float* __restrict__ tab, const float* __restrict__ eps,
+                                                     float* __restrict__ z_t, float* __restrict__ xh_pocket, float* __restrict__ klsum) {
+    __shared__ float red[12];
+    const int b = blockIdx.x, B = lay.B, tid = threadIdx.x;
+    const int n = lay.num_phar[b], base = lay.phar_base[b], m = lay.num_pocket[b], qbase = lay.pocket_base[b];
+    const int P = d.P, R = d.R, ldp = 3 + P, ldq = 3 + R;
+    const float alpha = tab[TT_ALPHA_T * B + b], sigma = tab[TT_SIGMA_T * B + b], alphaT = tab[TT_ALPHA_TT * B + b];
+    const float cnt = (float)max(n, 1);
+    // phar centre of mass of the normalised coordinates (remove_mean_batch #1)
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float* x = px + (size_t)(base + i) * 3;
+        sx += x[0] / d.norm_x; sy += x[1] / d.norm_x; sz += x[2] / d.norm_x;
+    }
+    wg_sum3(sx, sy, sz, red);
+    const float m1x = sx / cnt, m1y = sy / cnt, m1z = sz / cnt;
+    // z_t = alpha xh0 + sigma eps (x part still with its mean), the KL sums of alpha_T xh0
+    float zx = 0.f, zy = 0.f, zz = 0.f, klx = 0.f, klh = 0.f, dummy = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const size_t g = (size_t)(base + i);
+        const float* x = px + g * 3; const float* e = eps + g * ldp; float* z = z_t + g * ldp;
+        const float x0 = x[0] / d.norm_x - m1x, x1 = x[1] / d.norm_x - m1y, x2 = x[2] / d.norm_x - m1z;
+        const float a0 = alphaT * x0, a1 = alphaT * x1, a2 = alphaT * x2;
+        klx += a0 * a0 + a1 * a1 + a2 * a2;
+        const float z0 = alpha * x0 + sigma * e[0], z1 = alpha * x1 + sigma * e[1], z2 = alpha * x2 + sigma * e[2];
+        z[0] = z0; z[1] = z1; z[2] = z2; zx += z0; zy += z1; zz += z2;
+        for (int c = 0; c < P; ++c) {
+            const float h = (poh[g * P + c] - d.bias_h) / d.norm_h, ah = alphaT * h;
+            klh += ah * ah;
+            z[3 + c] = alpha * h + sigma * e[3 + c];
+        }
+    }
+    wg_sum3(zx, zy, zz, red);
+    wg_sum3(klx, klh, dummy, red);
+    const float m2x = zx / cnt, m2y = zy / cnt, m2z = zz / cnt;
+    for (int i = tid; i < n; i += 256) {            // remove_mean_batch #2 (each thread revisits the rows it wrote)
+        float* z = z_t + (size_t)(base + i) * ldp;
+        z[0] -= m2x; z[1] -= m2y; z[2] -= m2z;
+    }
+    for (int i = tid; i < m; i += 256) {
+        const size_t g = (size_t)(qbase + i);
+        const float* x = qx + g * 3; float* o = xh_pocket + g * ldq;
+        o[0] = (x[0] / d.norm_x - m1x) - m2x; o[1] = (x[1] / d.norm_x - m1y) - m2y; o[2] = (x[2] / d.norm_x - m1z) - m2z;
+        for (int c = 0; c < R; ++c) o[3 + c] = (qoh[g * R + c] - d.bias_h) / d.norm_h;
+    }
+    if (tid == 0) { klsum[2 * b] = klx; klsum[2 * b + 1] = klh; }
+}
+
+__device__ __forceinline__ float cdf_std_gauss(float x) { return 0.5f * (1.0f + erff(x / 1.41421356237309515f)); }
+
+// per-sample loss terms and dL/d net_out.  l2: the 'l2' training objective (lightning_modules.py:198-205), else the vlb
+// weighting (:206-212); both in training mode (t = 0 handled by the t_is_zero masks, conditional_model.py:265-272).
+__global__ __launch_bounds__(256) void k_train_loss(Layout lay, Dims d, int l2, float T, const float* __restrict__ net,
+                                                    const float* __restrict__ eps, const float* __restrict__ z_t,
+                                                    const float* __restrict__ poh, const float* __restrict__ tab,
+                                                    const float* __restrict__ klsum, float* __restrict__ terms,
+                                                    float* __restrict__ d_eps) {
+    __shared__ float red[12];
+    const int b = blockIdx.x, B = lay.B, tid = threadIdx.x;
+    const int n = lay.num_phar[b], base = lay.phar_base[b];
+    const int P = d.P, ldp = 3 + P;
+    const float t0 = tab[TT_T0 * B + b], snrw = tab[TT_SNRW * B + b], s0cat = tab[TT_S0CAT * B + b];
+    const float nf = (float)n;
+    const float s_t = l2 ? 1.0f / ((float)(3 + P) * nf) : -T * snrw, s_0 = l2 ? 1.0f / (3.0f * nf) : 1.0f;
+    const float w_t = (1.0f - t0) * s_t / (float)B, w_0 = t0 * s_0 / (float)B;
+    float ex = 0.f, eh = 0.f, lph = 0.f, ax = 0.f, ah = 0.f, dummy = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const size_t g = (size_t)(base + i);
+        const float* o = net + g * ldp; const float* e = eps + g * ldp; float* de = d_eps + g * ldp;
+        float sabs = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float df = o[c] - e[c];
+            ex += df * df; sabs += fabsf(o[c]);
+            de[c] = df * w_t + df * w_0;
+        }
+        ax += sabs / 3.0f;
+        sabs = 0.f;
+        for (int c = 0; c < P; ++c) {
+            const float df = o[3 + c] - e[3 + c];
+            eh += df * df; sabs += fabsf(o[3 + c]);
+            de[3 + c] = df * w_t;
+        }
+        ah += sabs / (float)P;
+        // log p(h | z_0): integrate the normal around each class over the unit bin, normalise over the classes
+        const float* z = z_t + g * ldp + 3;
+        float mx = -INFINITY;
+        for (int c = 0; c < P; ++c) {
+            const float ctr = z[c] * d.norm_h + d.bias_h - 1.0f;
+            const float lp = logf(cdf_std_gauss((ctr + 0.5f) / s0cat) - cdf_std_gauss((ctr - 0.5f) / s0cat) + 1e-10f);
+            mx = fmaxf(mx, lp);
+        }
+        float se = 0.f, dot = 0.f, ohs = 0.f;
+        for (int c = 0; c < P; ++c) {
+            const float ctr = z[c] * d.norm_h + d.bias_h - 1.0f;
+            const float lp = logf(cdf_std_gauss((ctr + 0.5f) / s0cat) - cdf_std_gauss((ctr - 0.5f) / s0cat) + 1e-10f);
+            se += expf(lp - mx);
+            const float oh = ((poh[g * P + c] - d.bias_h) / d.norm_h) * d.norm_h + d.bias_h;
+            dot += lp * oh; ohs += oh;
+        }
+        lph += dot - (mx + logf(se)) * ohs;
+    }
+    wg_sum3(ex, eh, lph, red);
+    wg_sum3(ax, ah, dummy, red);
+    if (tid == 0) {
+        const float alphaT = tab[TT_ALPHA_TT * B + b], sigT = tab[TT_SIGMA_TT * B + b];
+        (void)alphaT;
+        const float dsub = (nf - 1.0f) * 3.0f;
+        // gaussian_KL(|mu|^2, sigma_T, 1, dim) = dim log(1 / sigma_T) + 0.5 (dim sigma_T^2 + |mu|^2) - 0.5 dim
+        const float kl_h = logf(1.0f / sigT) + 0.5f * (sigT * sigT + klsum[2 * b + 1]) - 0.5f;
+        const float kl_x = dsub * logf(1.0f / sigT) + 0.5f * (dsub * sigT * sigT + klsum[2 * b]) / 1.0f - 0.5f * dsub;
+        const float kl = kl_x + kl_h;
+        float err_t = (ex + eh) * (1.0f - t0);
+        const float loss_0x = 0.5f * ex * t0, loss_0h = -lph * t0;
+        float loss_t, loss_0, nll;
+        if (l2) {
+            err_t = err_t / ((float)(3 + P) * nf);
+            loss_t = 0.5f * err_t;
+            loss_0 = loss_0x / (3.0f * nf) + loss_0h;
+            nll = loss_t + loss_0 + kl;
+        } else {
+            loss_t = -T * 0.5f * snrw * err_t;
+            loss_0 = loss_0x + loss_0h + tab[TT_NEGLOGC * B + b];
+            nll = loss_t + loss_0 + kl - tab[TT_DLOGPX * B + b] - tab[TT_LOGPN * B + b];
+        }
+        const float cnt = (float)max(n, 1);
+        float* o = terms + (size_t)b * TS_COLS;
+        o[TS_NLL] = nll; o[TS_ERR_T] = err_t; o[TS_LOSS_0] = loss_0; o[TS_KL] = kl; o[TS_ABS_X] = ax / cnt; o[TS_ABS_H] = ah / cnt;
+        o[TS_LOSS_0X] = loss_0x; o[TS_LOSS_0H] = loss_0h; o[TS_LOSS_T] = loss_t;
+    }
+}
+
+// means over the batch of every per-sample term column (one workgroup; B is at most a few thousand)
+__global__ __launch_bounds__(256) void k_train_means(int B, const float* __restrict__ terms, float* __restrict__ means) {
+    __shared__ float red[12];
+    for (int c = 0; c < TS_COLS; c += 3) {
+        float a = 0.f, b2 = 0.f, c2 = 0.f;
+        for (int i = threadIdx.x; i < B; i += 256) {
+            const float* o = terms + (size_t)i * TS_COLS + c;
+            a += o[0]; b2 += o[1]; c2 += o[2];
+        }
+        wg_sum3(a, b2, c2, red);
+        if (threadIdx.x == 0) { means[c] = a / (float)B; means[c + 1] = b2 / (float)B; means[c + 2] = c2 / (float)B; }
+    }
+}
+
+void tr_noise(const Layout& lay, const Dims& d, const float* px, const float* poh, const float* qx, const float* qoh, const float* tab,
+              const float* eps, float* z_t, float* xh_pocket, float* klsum, hipStream_t s) {
+    hipLaunchKernelGGL(k_train_noise, dim3(lay.B), dim3(256), 0, s, lay, d, px, poh, qx, qoh, tab, eps, z_t, xh_pocket, klsum);
+}
+void tr_loss(const Layout& lay, const Dims& d, int l2, float T, const float* net, const float* eps, const float* z_t, const float* poh,
+             const float* tab, const float* klsum, float* terms, float* d_eps, float* means, hipStream_t s) {
+    hipLaunchKernelGGL(k_train_loss, dim3(lay.B), dim3(256), 0, s, lay, d, l2, T, net, eps, z_t, poh, tab, klsum, terms, d_eps);
+    hipLaunchKernelGGL(k_train_means, dim3(1), dim3(256), 0, s, lay.B, terms, means);
+}
+
+// ------------------------------------------------------------------------------------
 // launch helpers (C++ linkage, used by cmdgen_train.hip)
 // ------------------------------------------------------------------------------------
 #define EW_GRID(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256)

@@ -65,6 +65,8 @@ SYMBOLS = [
     ('cmdgen_train_backward', C.c_int, [_vp, _fp, _fp, _fp, _vp]),
     ('cmdgen_train_backward_stages', C.c_int, [_vp, _fp, _fp, _fp, C.c_int32, C.c_int32, _vp]),
     ('cmdgen_train_set_precision', C.c_int, [_vp, C.c_int32]),
+    ('cmdgen_train_noise', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
+    ('cmdgen_train_loss', C.c_int, [_vp, C.c_int32, C.c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
     ('cmdgen_grad_sqnorm', C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_float), _vp]),
     ('cmdgen_adamw_step', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, _vp]),
@@ -375,6 +377,35 @@ class Handle:
 
     def train_set_precision(self, bf16_gemm: bool):
         self._check(self.lib.cmdgen_train_set_precision(self.h, int(bool(bf16_gemm))), 'cmdgen_train_set_precision')
+
+    TT_COLS, TS_COLS = 12, 12        # include/cmdgen_hip.h: CMDGEN_TT_COLS / CMDGEN_TS_COLS
+
+    def train_noise(self, phar_x, phar_one_hot, pocket_x, pocket_one_hot, tab, eps):
+        """-> (z_t, xh_pocket, kl_sums): the fused noising of the conditional training step (cmdgen_train_noise)."""
+        import torch
+        P, R = self.cfg['phar_nf'], self.cfg['residue_nf']
+        for t, shape in ((phar_x, (self.n_phar, 3)), (phar_one_hot, (self.n_phar, P)), (pocket_x, (self.n_pocket, 3)),
+                         (pocket_one_hot, (self.n_pocket, R)), (tab, (self.TT_COLS, self.batch)), (eps, (self.n_phar, 3 + P))):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape, (tuple(t.shape), shape)
+        z_t = torch.empty((self.n_phar, 3 + P), dtype=torch.float32, device=eps.device)
+        xh_pocket = torch.empty((self.n_pocket, 3 + R), dtype=torch.float32, device=eps.device)
+        kl = torch.empty((self.batch, 2), dtype=torch.float32, device=eps.device)
+        self._check(self.lib.cmdgen_train_noise(self.h, _ptr(phar_x), _ptr(phar_one_hot), _ptr(pocket_x), _ptr(pocket_one_hot),
+                                                _ptr(tab), _ptr(eps), _ptr(z_t), _ptr(xh_pocket), _ptr(kl), self._stream()),
+                    'cmdgen_train_noise')
+        return z_t, xh_pocket, kl
+
+    def train_loss(self, l2: bool, T: float, net_out, eps, z_t, phar_one_hot, tab, kl_sums):
+        """-> (terms [B, TS_COLS], means [TS_COLS], d_eps): per-sample loss terms, their batch means and d loss / d net_out."""
+        import torch
+        assert net_out.is_cuda and net_out.is_contiguous() and net_out.shape == eps.shape == z_t.shape
+        terms = torch.zeros((self.batch, self.TS_COLS), dtype=torch.float32, device=eps.device)
+        means = torch.empty(self.TS_COLS, dtype=torch.float32, device=eps.device)
+        d_eps = torch.empty_like(net_out)
+        self._check(self.lib.cmdgen_train_loss(self.h, int(bool(l2)), float(T), _ptr(net_out), _ptr(eps), _ptr(z_t), _ptr(phar_one_hot),
+                                               _ptr(tab), _ptr(kl_sums), _ptr(terms), _ptr(d_eps), _ptr(means), self._stream()),
+                    'cmdgen_train_loss')
+        return terms, means, d_eps
 
     def grad_sqnorm(self, grad) -> float:
         out = C.c_float(0)

@@ -61,6 +61,9 @@ class HipTrainer:
         self.gemm_dtype = gemm_dtype        # 'bf16': GEMM operands in bf16, fp32 accumulation (mixed precision); default exact fp32
         self.last_info: Dict[str, float] = {}
         self.overlap_allreduce = True       # all-reduce finished gradient chunks behind the rest of the backward pass
+        self.fused_loss = True              # conditional model: noising and loss terms as three library launches (cmdgen_train_noise / _loss)
+        self._gamma_host = self._logpn_host = None
+        self._last_fused = None
         self._pending = []
 
     # ------------------------------------------------------------------
@@ -69,9 +72,76 @@ class HipTrainer:
                                    want_pocket=self.joint)
         return out if self.joint else (out, None)
 
+    # ------------------------------------------------------------------ fused loss side (conditional model)
+    def _fused_ok(self) -> bool:
+        from .equivariant_diffusion.en_diffusion import PredefinedNoiseSchedule
+        from .equivariant_diffusion.conditional_model import ConditionalDDPM
+        return self.fused_loss and type(self.ddpm) is ConditionalDDPM and isinstance(self.ddpm.gamma, PredefinedNoiseSchedule)
+
+    def _sample_table(self, t_int, n_phar, n_pocket):
+        """[TT_COLS, B] per-sample scalars of one step (include/cmdgen_hip.h): everything ConditionalDDPM.forward derives
+        from t and the node counts alone (conditional_model.py:206-221, :49-59, en_diffusion.py:227-234), made on the host
+        with the reference's fp32 op sequence."""
+        ddpm = self.ddpm
+        if self._gamma_host is None:
+            self._gamma_host = ddpm.gamma.gamma.detach().to('cpu', torch.float32)
+            self._logpn_host = ddpm.size_distribution._table(1, torch.device('cpu')).to(torch.float32)
+        g = self._gamma_host
+        T = float(ddpm.T)
+        t_int = t_int.to('cpu', torch.float32).reshape(-1)
+        s, t = (t_int - 1) / T, t_int / T
+        gamma_s, gamma_t = g[torch.round(s * T).long()], g[torch.round(t * T).long()]
+        gamma_T, gamma_0 = g[int(round(T))], g[0]
+        n = torch.as_tensor(n_phar, dtype=torch.float32)
+        sub = (n - 1) * ddpm.n_dims
+        nv0, nv1 = float(ddpm.norm_values[0]), float(ddpm.norm_values[1])
+        sigma_t = torch.sqrt(torch.sigmoid(gamma_t))
+        tab = torch.stack([
+            torch.sqrt(torch.sigmoid(-gamma_t)), sigma_t, (t_int == 0).float(), 1 - torch.exp(-(gamma_s - gamma_t)),
+            torch.sqrt(torch.sigmoid(-gamma_T)).expand_as(n), torch.sqrt(torch.sigmoid(gamma_T)).expand_as(n),
+            -(sub * (-(0.5 * gamma_0) - 0.5 * np.log(2 * np.pi))), -sub * np.log(nv0),
+            self._logpn_host[torch.as_tensor(n_phar).long(), torch.as_tensor(n_pocket).long()],
+            t_int, t, sigma_t * nv1]).to(torch.float32).contiguous()
+        return tab
+
+    @torch.no_grad()
+    def _loss_and_grad_fused(self, data, t_int=None, eps=None):
+        """The conditional model's training loss with the three fused launches of the library (cmdgen_train_noise /
+        cmdgen_train_loss) around the activation-saving forward; same values as PharPocketDDPM.forward(training mode)."""
+        model, ddpm, h = self.model, self.ddpm, self.h
+        model.train()
+        dev = self.theta.device
+        f32 = lambda k: data[k].to(dev, torch.float32).contiguous()
+        px, poh, qx, qoh = f32('phar_coords'), f32('phar_one_hot'), f32('pocket_c_alpha'), f32('pocket_one_hot')
+        n_l = data['num_phar_atoms'].detach().to('cpu', torch.int64).numpy()
+        n_p = data['num_pocket_nodes'].detach().to('cpu', torch.int64).numpy()
+        B = len(n_l)
+        h.set_layout(n_l, n_p)
+        h.train_set_precision(self.gemm_dtype == 'bf16')
+        if t_int is None:
+            t_int = torch.randint(0, ddpm.T + 1, size=(B, 1)).float()          # training mode: t = 0 included
+        tab = self._sample_table(t_int, n_l, n_p).to(dev, non_blocking=True)
+        if eps is None:
+            e = torch.randn((px.shape[0], ddpm.n_dims + ddpm.phar_nf), device=dev)
+        else:
+            e = next(iter(eps)).to(dev, torch.float32).contiguous()
+        z_t, xh_pocket, kl = h.train_noise(px, poh, qx, qoh, tab, e)
+        net_out = h.train_forward(self.theta, z_t, xh_pocket, tab[10])
+        terms, means, d_eps = h.train_loss(model.loss_type == 'l2', float(ddpm.T), net_out, e, z_t, poh, tab, kl)
+        self.grad.zero_()
+        self._backward(d_eps, None)
+        tm = tab.mean(1)
+        info = {'eps_hat_phar_x': means[4], 'eps_hat_phar_h': means[5], 'error_t_phar': means[1],
+                'error_t_pocket': torch.zeros((), device=dev), 'SNR_weight': tm[3], 'loss_0': means[2], 'kl_prior': means[3],
+                'delta_log_px': tm[7], 'neg_log_const_0': tm[6], 'log_pN': tm[8]}
+        self._last_fused = {'terms': terms, 'tab': tab, 'z_t': z_t, 'xh_pocket': xh_pocket, 'eps_t': e, 'net_out': net_out, 'd_eps': d_eps}
+        return means[0], terms[:, 0], info
+
     @torch.no_grad()
     def loss_and_grad(self, data, t_int=None, eps=None):
         """-> (loss, nll [B], info); leaves dL/d theta (this rank's batch mean) in ``self.grad``."""
+        if self._fused_ok():
+            return self._loss_and_grad_fused(data, t_int=t_int, eps=eps)
         model = self.model
         model.train()
         phar, pocket = model.get_phar_and_pocket(data)

@@ -254,6 +254,31 @@ int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, const float
 int cmdgen_train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, const float* d_eps_pocket, float* grad,
                                  int32_t first_stage, int32_t last_stage, cmdgen_stream stream);
 
+/* The loss side of ConditionalDDPM.forward in training mode (conditional_model.py:198-320) and of
+ * PharPocketDDPM.forward (lightning_modules.py:188-239), fused: three launches per step instead of a few hundred
+ * small tensor operations.  Per-sample scalars that depend only on t and on the node counts are made by the host
+ * and passed as `tab`, dev, COLUMN-major [CMDGEN_TT_COLS][batch]:
+ *   0 alpha_t, 1 sigma_t, 2 t_is_zero, 3 SNR weight 1 - SNR(gamma_s - gamma_t), 4 alpha_T, 5 sigma_T,
+ *   6 -log_constants_p_x_given_z0, 7 delta_log_px, 8 log p(N), 9 t_int, 10 t = t_int / T (column 10 is the `t`
+ *   argument of cmdgen_train_forward), 11 sigma_t * norm_values[1].
+ * cmdgen_train_noise: normalize + remove_mean_batch + noised_representation (conditional_model.py:80-106, :467-475):
+ *   from the raw batch (phar_x [Nl,3], phar_one_hot [Nl,phar_nf], pocket_x [Np,3], pocket_one_hot [Np,residue_nf]) and the
+ *   Gaussian draw eps [Nl,3+phar_nf] writes z_t [Nl,3+phar_nf], xh_pocket [Np,3+residue_nf] (the network's inputs) and
+ *   kl_sums [batch,2] (sum of (alpha_T x)^2 and (alpha_T h)^2 of the clean sample, for kl_prior, :49-59).
+ * cmdgen_train_loss: from net_out = eps_phar of cmdgen_train_forward writes
+ *   terms [batch, CMDGEN_TS_COLS]: 0 nll, 1 error_t (as logged), 2 loss_0, 3 kl_prior, 4 / 5 mean |eps_hat| of x / h,
+ *   6 loss_0_x, 7 loss_0_h, 8 loss_t;   means [CMDGEN_TS_COLS] = their batch means (means[0] is the loss);
+ *   d_eps [Nl,3+phar_nf] = d loss / d net_out, the input of cmdgen_train_backward.
+ *   l2 != 0: loss_type 'l2' (lightning_modules.py:198-205); 0: the vlb weighting (:206-212) with T diffusion steps. */
+#define CMDGEN_TT_COLS 12
+#define CMDGEN_TS_COLS 12
+int cmdgen_train_noise(cmdgen_handle* h, const float* phar_x, const float* phar_one_hot, const float* pocket_x,
+                       const float* pocket_one_hot, const float* tab, const float* eps, float* z_t, float* xh_pocket,
+                       float* kl_sums, cmdgen_stream stream);
+int cmdgen_train_loss(cmdgen_handle* h, int32_t l2, float T, const float* net_out, const float* eps, const float* z_t,
+                      const float* phar_one_hot, const float* tab, const float* kl_sums, float* terms, float* d_eps,
+                      float* means, cmdgen_stream stream);
+
 /* GEMM operand precision of the training step: 0 (default) = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = operands
  * rounded to bf16 while staged, fp32 accumulation (v_mfma_f32_32x32x16_bf16).  Parameters, gradients, optimizer state,
  * stored activations and all elementwise math stay fp32 either way. */

@@ -200,6 +200,39 @@ def test_training_step_matches_reference_gradients_and_optimizer():
     assert torch.isfinite(out[0]).all()
 
 
+@pytest.mark.parametrize('loss_type', ['l2', 'vlb'])
+def test_fused_loss_side_equals_the_tensor_op_path(loss_type):
+    """cmdgen_train_noise / cmdgen_train_loss (three launches) against ConditionalDDPM.forward + PharPocketDDPM.forward
+    evaluated with tensor operations on the same draws: every logged term, the per-sample nll, dL/d eps and the
+    parameter gradient; one sample at t = 0 so that the L0 terms are exercised."""
+    model, tr, data, g6 = build_trainer()
+    model.loss_type = loss_type
+    t_int = dev(g6['t_int']).clone()
+    t_int[1] = 0
+    eps = [dev(g6['eps0'])]
+    tr.fused_loss = False
+    loss_a, nll_a, info_a = tr.loss_and_grad(data, t_int=t_int, eps=eps)
+    grad_a = tr.grad.clone()
+    ctx = tr.ddpm._last_train_ctx
+    tr.fused_loss = True
+    assert tr._fused_ok()
+    loss_b, nll_b, info_b = tr.loss_and_grad(data, t_int=t_int, eps=eps)
+    f = tr._last_fused
+    assert (f['net_out'] - ctx['net_out']).abs().max() <= 2e-5 * float(ctx['net_out'].abs().max())
+    scale = max(1.0, float(nll_a.abs().max()))
+    assert float((nll_a - nll_b).abs().max()) <= 2e-5 * scale, (nll_a, nll_b)
+    assert abs(float(loss_a) - float(loss_b)) <= 2e-5 * scale
+    assert set(info_a) == set(info_b)
+    for k in info_a:
+        a, b = float(info_a[k]), float(info_b[k])
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (k, a, b)
+    assert float((tr.grad - grad_a).abs().max()) <= GRAD_TOL * float(grad_a.abs().max())
+    assert float(f['terms'][1, 6]) > 0 and float(f['terms'][1, 8]) == 0          # the t = 0 sample carries L0, not L_t
+    # without injected draws the fused path makes its own t and eps and still trains
+    l0, _, _ = tr.loss_and_grad(data)
+    assert np.isfinite(float(l0)) and torch.isfinite(tr.grad).all()
+
+
 def test_staged_backward_equals_single_pass():
     """cmdgen_train_backward_stages (what the overlapped all-reduce drives) over any split of the stages 0..L+1 leaves
     the same flat gradient as the single call, and the chunks HipTrainer reduces are final when their stage is done."""
@@ -207,7 +240,6 @@ def test_staged_backward_equals_single_pass():
     t_int, eps = torch.from_numpy(g6['t_int']).cuda(), [torch.from_numpy(g6['eps0']).cuda()]
     tr.loss_and_grad(data, t_int=t_int, eps=eps)
     whole = tr.grad.clone()
-    ctx = tr.ddpm._last_train_ctx
     L = int(tr.dyn._cfg['n_layers'])
     # rebuild d_eps exactly as loss_and_grad does, via a second pass that records it
     seen = {}
