@@ -1103,6 +1103,8 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "edge_grid") *value = a.edge_grid;
     else if (k == "coord_grid") *value = a.coord_grid;
     else if (k == "gemm_split") *value = a.split;
+    else if (k == "train_edges") *value = h->train_E;
+    else if (k == "train_coord_edges") *value = h->train_Ec;
     else return fail(h, CMDGEN_EINVAL, "unknown query '%s'", key);
     return CMDGEN_OK;
 }

@@ -75,6 +75,7 @@ struct cmdgen_handle {
     const void* jg_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned long long jg_seed = 0; int jg_steps = 0;
     TrainState* train = nullptr;           // training workspace (cmdgen_train.hip)
+    int train_E = 0, train_Ec = 0;         // message / coordinate edges of the last cmdgen_train_forward (cmdgen_query)
     bool train_bf16 = false;               // GEMM operand precision of the training step (cmdgen_train_set_precision)
     bool agg_dirty = false;                // cmdgen_debug_eval_prefix left segment sums in work.agg
     hipStream_t last_stream = nullptr;     // stream most recently handed to this handle (ordering contract of cmdgen_set_layout)

@@ -22,6 +22,10 @@ struct WgradBatch {               // kernels_train.hip: up to 8 weight gradients
     int n;
 };
 void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s);
+struct RepackSplitT { int src_off, ld; void* dst; };                                                      // kernels_train.hip
+void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s);
+void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
+                        const float* pre, hipStream_t s);
 void tr_silu(const float* in, float* out, size_t n, hipStream_t s);
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
 void tr_scale(float* x, float a, size_t n, hipStream_t s);
@@ -111,6 +115,7 @@ struct TrainState {
     int E = 0, Ec = 0;                  // edges of the last forward
     size_t ecap = 0, eccap = 0;
     bool have_forward = false;
+    bool split_packs_valid = false;     // the last forward re-packed the transposed split fragments (backward may use them)
     bool bf16 = false;                  // GEMM operands in bf16 (fp32 accumulation); default exact fp32
     const float* theta = nullptr;       // parameters used by the last forward (backward reads the same)
     const float* xh_phar = nullptr; const float* xh_pocket = nullptr;
@@ -131,11 +136,13 @@ struct TrainState {
     // the fused forward (the sampler's evaluation kernels with save hooks): per-step packed copies of the parameters
     std::vector<void*> pack_allocs;
     std::vector<LayerW> layers;         // device pointers: packed fragments + vectors inside theta (rebuilt per call: theta is the caller's)
-    struct PackBlk { float *pq_e32, *pq_e16, *w2_32, *w2_16, *w3_32, *w3_16, *w4_32, *w4_16, *pq_c32, *pq_c16, *w7_32, *w7_16, *rd_e, *rd_c; };
+    struct PackBlk { float *pq_e32, *pq_e16, *w2_32, *w2_16, *w3_32, *w3_16, *w4_32, *w4_16, *pq_c32, *pq_c16, *w7_32, *w7_16, *rd_e, *rd_c;
+                     // split-bf16 fragment packs of the TRANSPOSED 256 x 256 blocks (data gradients, cmdgen_dgrad_split); H = 256 only
+                     void *t_e0a, *t_e0b, *t_e2, *t_n0a, *t_n0b, *t_n2, *t_c0a, *t_c0b, *t_c2; };
     std::vector<PackBlk> pack;          // rd_e / rd_c: [2][H] radial column then d0 column of edge_mlp.0 / coord_mlp.0
     float *emb_wT = nullptr, *embo_wT = nullptr;
-    void *frag_tab = nullptr, *misc_tab = nullptr;
-    int n_frag = 0, n_misc = 0, max_frag4 = 0, max_misc = 0;
+    void *frag_tab = nullptr, *misc_tab = nullptr, *split_tab = nullptr;
+    int n_frag = 0, n_misc = 0, max_frag4 = 0, max_misc = 0, n_split = 0;
 };
 
 void cmdgen_train_free(TrainState* t) {
@@ -199,6 +206,25 @@ static int ensure_state(cmdgen_handle* h) {
                 mt.push_back(RepackMisc{(int)b.e0.w + 2 * (int)H, ld1, (int)H, 2, k.rd_e});
                 mt.push_back(RepackMisc{(int)b.c0.w + 2 * (int)H, ld1, (int)H, 2, k.rd_c});
             }
+        }
+        std::vector<RepackSplitT> st;
+        if (H == 256) {
+            for (size_t l = 0; l < L && !rc; ++l) {
+                TrainState::PackBlk& k = t->pack[l];
+                const ParamTable::Blk& b = tb.blk[l];
+                auto tp = [&](const PRef& r, int col0, void** dst) {
+                    if (rc) return;
+                    float* q = nullptr;
+                    rc = alloc((size_t)H * H * 6 / 4, &q); if (rc) return;          // three bf16 pieces per weight
+                    *dst = q;
+                    st.push_back(RepackSplitT{(int)r.w + col0, r.in, q});
+                };
+                tp(b.e0, 0, &k.t_e0a); tp(b.e0, (int)H, &k.t_e0b); tp(b.e2, 0, &k.t_e2);
+                tp(b.n0, 0, &k.t_n0a); tp(b.n0, (int)H, &k.t_n0b); tp(b.n2, 0, &k.t_n2);
+                tp(b.c0, 0, &k.t_c0a); tp(b.c0, (int)H, &k.t_c0b); tp(b.c2, 0, &k.t_c2);
+            }
+            if (!rc) rc = dev_alloc(h, t->pack_allocs, &p, st.size() * sizeof(RepackSplitT), false);
+            if (!rc) { t->split_tab = p; hipMemcpy(p, st.data(), st.size() * sizeof(RepackSplitT), hipMemcpyHostToDevice); t->n_split = (int)st.size(); }
         }
         if (!rc) rc = alloc((size_t)H * d.dyn, &t->emb_wT);
         if (!rc) rc = alloc((size_t)H * d.dyn, &t->embo_wT);
@@ -308,6 +334,7 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     const int E = tot[0], Ec = tot[1];
     rc = ensure_edges(h, t, E, Ec); if (rc) return rc;
     g_bf16 = t->bf16;
+    h->train_E = E; h->train_Ec = Ec;
     t->E = E; t->Ec = Ec; t->theta = theta; t->xh_phar = xh_phar; t->xh_pocket = xh_pocket;
     const Work& w = h->work;
     const ParamTable& tb = t->tab;
@@ -316,6 +343,8 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     // k_readout) with save hooks that keep what the backward pass reads (TrainSave): ~20 launches instead of ~190, GEMMs on
     // the fragment-streaming tile kernels.  The parameters the optimizer has just updated are re-packed on the device.
     tr_repack(theta, t->frag_tab, t->n_frag, t->max_frag4, t->misc_tab, t->n_misc, t->max_misc, s);
+    if (h->gemm_split && !t->bf16) tr_repack_split_t(theta, t->split_tab, t->n_split, s);       // data gradients on the split engine
+    t->split_packs_valid = h->gemm_split && !t->bf16 && t->n_split > 0;
     t->layers.assign(L, LayerW{});
     for (int l = 0; l < L; ++l) {
         const ParamTable::Blk& b = tb.blk[l];
@@ -401,6 +430,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         wb.M[q] = r.out; wb.N[q] = in; wb.lddy[q] = r.out; wb.ldx[q] = in; wb.ldw[q] = r.in;
     };
     auto flush_wgrads = [&]() { cmdgen_wgrad_group(wb, N, g_bf16, s); wb.n = 0; };
+    const bool sp = t->split_packs_valid && !g_bf16 && H == 256;      // [.,256] x [256,256] data gradients on the split engine
     if (first_stage == 0) {
     // readout
     HIPCHK(h, hipMemsetAsync(t->dX, 0, (size_t)N * 4 * sizeof(float), s));
@@ -456,13 +486,18 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.c2.in;
             cmdgen_wgrad_group(one, Ec, g_bf16, s);
         }
-        linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
+        const TrainState::PackBlk& pk = t->pack[l];
+        if (sp) cmdgen_dgrad_split(Ec, t->actB, pk.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s);
+        else linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
         HIPCHK(h, hipMemsetAsync(t->dP, 0, (size_t)(t->dQ - t->dP) * sizeof(float) + NH * sizeof(float), s));    // dP and dQ
         // adjoints of the gathers, the radial / d0 column gradients, d radial and the geometry adjoint: one pass over dpre6
         tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
                          t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, s);
-        linear_dgrad(theta, b.c0, 0, H, N, t->dP, H, t->dh, H, true, s);
-        linear_dgrad(theta, b.c0, H, H, N, t->dQ, H, t->dh, H, true, s);
+        if (sp) cmdgen_dgrad_split(N, t->dP, pk.t_c0a, t->dQ, pk.t_c0b, t->dh, true, 1.0f, nullptr, s);
+        else {
+            linear_dgrad(theta, b.c0, 0, H, N, t->dP, H, t->dh, H, true, s);
+            linear_dgrad(theta, b.c0, H, H, N, t->dQ, H, t->dh, H, true, s);
+        }
         // ---- node model: h_{l+1} = h_l + W4 SiLU(W3 [h_l | aggn] + b3) + b4 ; dh holds dL/dh_{l+1}
         // weight / bias gradients of coord_mlp.0 (both halves) and node_mlp.2: one grouped launch, while dP, dQ and dh
         // still hold what they are the gradients of (dP / dQ are reused by the edge model below, dh moves on to dL/dh_l)
@@ -470,10 +505,16 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         defer_wgrad(b.c0, H, H, t->dQ, hn, false);
         defer_wgrad(b.n2, 0, H, t->dh, nact, true);
         flush_wgrads();
-        linear_dgrad(theta, b.n2, 0, H, N, t->dh, H, t->dn, H, false, s, pre3);       // dn <- dn1 * SiLU'(pre3) = dpre3
-        linear_dgrad(theta, b.n0, 0, H, N, t->dn, H, t->dh, H, true, s);              // dh is now dL/dh_l (residual kept)
-        linear_dgrad(theta, b.n0, H, H, N, t->dn, H, t->dagg, H, false, s);
-        tr_scale(t->dagg, d.norm_factor, NH, s);
+        if (sp) {
+            cmdgen_dgrad_split(N, t->dh, pk.t_n2, nullptr, nullptr, t->dn, false, 1.0f, pre3, s);
+            cmdgen_dgrad_split(N, t->dn, pk.t_n0a, nullptr, nullptr, t->dh, true, 1.0f, nullptr, s);
+            cmdgen_dgrad_split(N, t->dn, pk.t_n0b, nullptr, nullptr, t->dagg, false, d.norm_factor, nullptr, s);
+        } else {
+            linear_dgrad(theta, b.n2, 0, H, N, t->dh, H, t->dn, H, false, s, pre3);       // dn <- dn1 * SiLU'(pre3) = dpre3
+            linear_dgrad(theta, b.n0, 0, H, N, t->dn, H, t->dh, H, true, s);              // dh is now dL/dh_l (residual kept)
+            linear_dgrad(theta, b.n0, H, H, N, t->dn, H, t->dagg, H, false, s);
+            tr_scale(t->dagg, d.norm_factor, NH, s);
+        }
         // ---- edge model
         tr_att_msg_bwd(E, H, w.erow, act2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, pre2, t->actA, t->dz, s);   // actA <- dpre2
         if (d.attention) {
@@ -486,7 +527,8 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.e2.in;
             cmdgen_wgrad_group(one, E, g_bf16, s);
         }
-        linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
+        if (sp) cmdgen_dgrad_split(E, t->actA, pk.t_e2, nullptr, nullptr, t->actB, false, 1.0f, pre1, s);
+        else linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
         HIPCHK(h, hipMemsetAsync(t->dP, 0, (size_t)(t->dQ - t->dP) * sizeof(float) + NH * sizeof(float), s));    // dP and dQ
         tr_edge_tail_bwd(E, H, w.erow, w.ecol, t->actB, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
                          t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, s);
@@ -496,8 +538,11 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         defer_wgrad(b.e0, 0, H, t->dP, hl, true);
         defer_wgrad(b.e0, H, H, t->dQ, hl, false);
         flush_wgrads();
-        linear_dgrad(theta, b.e0, 0, H, N, t->dP, H, t->dh, H, true, s);
-        linear_dgrad(theta, b.e0, H, H, N, t->dQ, H, t->dh, H, true, s);
+        if (sp) cmdgen_dgrad_split(N, t->dP, pk.t_e0a, t->dQ, pk.t_e0b, t->dh, true, 1.0f, nullptr, s);
+        else {
+            linear_dgrad(theta, b.e0, 0, H, N, t->dP, H, t->dh, H, true, s);
+            linear_dgrad(theta, b.e0, H, H, N, t->dQ, H, t->dh, H, true, s);
+        }
     }
     if (last_stage < L + 1) { HIPCHK(h, hipGetLastError()); return CMDGEN_OK; }
     // embedding and encoders

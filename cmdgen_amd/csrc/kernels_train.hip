@@ -7,6 +7,7 @@
 // parameter buffer the optimizer updates - no re-packing per step) and the rest is bandwidth-bound
 // elementwise work.  Fusing it like the sampler is the obvious next step; correctness comes first.
 #include "cmdgen_dev.h"
+#include "cmdgen_split.h"
 
 // ------------------------------------------------------------------------------------
 // C[M,N] (+)= alpha * op(A)[M,K] * op(B)[K,N] (+ bias[N])          exact fp32 on v_mfma_f32_32x32x2_f32
@@ -406,6 +407,126 @@ void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda
 #undef SG2
 #undef SG
 #undef SGK
+}
+
+// ------------------------------------------------------------------------------------
+// Data gradients on the split-bf16 matrix engine (cmdgen_split.h: fp32-accurate, six bf16 MFMAs per fp32 product):
+//   Y[M][256] (+)= ( A0[M][256] W0 + A1[M][256] W1 ) / div  (* SiLU'(pre[M][256]))
+// where W0 / W1 are 256 x 256 sub-blocks W[:, col0 : col0 + 256] of nn.Linear weights (dX = dY W), streamed as split
+// fragment packs of their TRANSPOSES (k_repack_split_t, re-made every step from the parameters the optimizer has just
+// updated).  All [.,256] x [256,256] products of the backward pass have this shape: the second layer of the edge /
+// coordinate MLP over the edges, and the seven node-level products of a block - the two halves of edge_mlp.0 and
+// coord_mlp.0 (A0 = dP, A1 = dQ: one launch instead of two), node_mlp.2, and the two halves of node_mlp.0.
+// One workgroup per MT rows: the A tile is staged once in LDS as fp32, every wave splits the fragments it reads in
+// registers in the shadow of the MFMAs (tile_gemm_rsplit), the weight fragments stream from L2.
+// ------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __restrict__ A0, const void* __restrict__ W0,
+                                                        const float* __restrict__ A1, const void* __restrict__ W1,
+                                                        float* __restrict__ Y, int accumulate, float div,
+                                                        const float* __restrict__ pre) {
+    // the A operand as three bf16 planes [MT][136] of one half of the k range at a time (tile_gemm_planes): the thread
+    // that loads an element splits it once; the next half's rows are requested before this half's MFMAs start
+    constexpr int HH = 256, PLDA = SPLIT_PLANE_LDA(HH / 2), PE = MT * PLDA, NP = MT / 8;
+    constexpr int LDO = HH + 4, SMEM = 3 * PE * 2 > 32 * LDO * 4 ? 3 * PE * 2 : 32 * LDO * 4;   // planes / 32-row fp32 output image
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned short* planes = reinterpret_cast<unsigned short*>(smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row0 = blockIdx.x * MT;
+    const int c4 = tid & 31, rsub = tid >> 5;            // 32 lanes x 16 bytes = one half row, 8 rows per pass
+    SCarry carry;
+    const int nstage = A1 ? 4 : 2;                        // (source, half)
+    auto frag_of = [&](int st) { return sfrag_ptr((st >> 1) ? W1 : W0, HH / 16, (st & 1) * (HH / 32), wave); };
+    split_prefetch(frag_of(0), carry);
+    float4 v[NP];
+    auto fetch = [&](int st) {
+        const float* A = (st >> 1) ? A1 : A0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = row0 + p * 8 + rsub;
+            v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < M) v[p] = *reinterpret_cast<const float4*>(A + (size_t)r * HH + (st & 1) * (HH / 2) + 4 * c4);
+        }
+    };
+    fetch(0);
+    sf32x16 acc[MT / 32][2];
+#pragma unroll
+    for (int m = 0; m < MT / 32; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+#pragma unroll 1
+    for (int st = 0; st < nstage; ++st) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) split_store4(planes, PE, (p * 8 + rsub) * PLDA + 4 * c4, v[p]);
+        __syncthreads();
+        if (st + 1 < nstage) fetch(st + 1);
+        tile_gemm_planes<MT, HH / 32>(planes, PE, PLDA, frag_of(st), frag_of(st + 1 < nstage ? st + 1 : st), acc, carry);
+        __syncthreads();
+    }
+    // Epilogue through LDS, 32 rows at a time (the fp32 image of 32 rows, 33 KB, aliases the planes): whole 1 KB rows leave
+    // as 16-byte pieces, and SiLU'(pre) / the running value of Y are read the same way.  Accumulator element r of tile
+    // (m, n) is row m*32 + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column wave*64 + n*32 + (lane & 31).
+    float* obuf = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int m = 0; m < MT / 32; ++m) {
+        if (m) __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                obuf[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDO + wave * 64 + n * 32 + (lane & 31)] = acc[m][n][r];
+        __syncthreads();
+        const int q4 = tid & 63, rs = tid >> 6;          // a wave writes one row per pass
+        float4 pv[8], yv[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int row = row0 + m * 32 + p * 4 + rs;
+            if (row < M) {
+                if (pre) pv[p] = reinterpret_cast<const float4*>(pre + (size_t)row * HH)[q4];
+                if (accumulate) yv[p] = reinterpret_cast<const float4*>(Y + (size_t)row * HH)[q4];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int rl = p * 4 + rs, row = row0 + m * 32 + rl;
+            if (row < M) {
+                float4 x = *reinterpret_cast<const float4*>(obuf + rl * LDO + 4 * q4);
+                if (div != 1.0f) { x.x = x.x / div; x.y = x.y / div; x.z = x.z / div; x.w = x.w / div; }
+                if (pre) { x.x *= dsilu(pv[p].x); x.y *= dsilu(pv[p].y); x.z *= dsilu(pv[p].z); x.w *= dsilu(pv[p].w); }
+                if (accumulate) { x.x += yv[p].x; x.y += yv[p].y; x.z += yv[p].z; x.w += yv[p].w; }
+                reinterpret_cast<float4*>(Y + (size_t)row * HH)[q4] = x;
+            }
+        }
+    }
+}
+
+// split fragment packs of transposed weight sub-blocks: dst = pack of Wt, Wt[o'][k] = theta[src_off + k * ld + o'] (o', k < 256)
+struct RepackSplitT { int src_off, ld; void* dst; };
+__global__ void k_repack_split_t(const float* __restrict__ theta, const RepackSplitT* __restrict__ tab) {
+    const RepackSplitT f = tab[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;         // (nt * 16 + kb) * 64 + lane, nt < 8, kb < 16
+    if (idx >= 8 * 16 * 64) return;
+    const int lane = idx & 63, kb = (idx >> 6) & 15, nt = idx >> 10;
+    const int o = 32 * nt + (lane & 31), k = 16 * kb + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = theta[f.src_off + (size_t)(k + j) * f.ld + o];
+    sbf16x8 p0, p1, p2;
+    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p0, p1, p2);
+    sbf16x8* d = reinterpret_cast<sbf16x8*>(f.dst) + (size_t)((nt * 16 + kb) * 3) * 64 + lane;
+    d[0] = p0; d[64] = p1; d[128] = p2;
+}
+void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_repack_split_t, dim3(8 * 16 * 64 / 256, n), dim3(256), 0, s, theta, (const RepackSplitT*)tab);
+}
+void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
+                        const float* pre, hipStream_t s) {
+    if (M <= 0) return;
+    static const char* mt = getenv("CMDGEN_DGRAD_MT");
+    if (mt ? atoi(mt) == 64 : M >= 24576) hipLaunchKernelGGL((k_dgrad_split<64>), dim3((M + 63) / 64), dim3(256), 0, s, M, A0, W0, A1, W1, Y, accumulate ? 1 : 0, div, pre);
+    else hipLaunchKernelGGL((k_dgrad_split<32>), dim3((M + 31) / 32), dim3(256), 0, s, M, A0, W0, A1, W1, Y, accumulate ? 1 : 0, div, pre);
 }
 
 // ------------------------------------------------------------------------------------

@@ -343,7 +343,7 @@ int cmdgen_debug_stamps(cmdgen_handle* h, uint64_t* out64, int32_t reset);
 
 /* Launch configuration chosen for the current layout (measurement aid): key = "node_mt" | "edge_mt" | "coord_mt"
  * (rows per tile of the three MFMA kernels), "edge_grid" | "coord_grid" (workgroups of the persistent-style edge
- * kernels), "gemm_split" (the mode above). */
+ * kernels), "gemm_split" (the mode above), "train_edges" | "train_coord_edges" (edges of the last cmdgen_train_forward). */
 int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value);
 
 /* Steady-state timing of one network evaluation (bench.py's trained-geometry micro-benchmark): `graph_len`

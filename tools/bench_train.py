@@ -142,6 +142,8 @@ def main():
         print(json.dumps({'metric': 'training complexes/s', 'value': a.batch * world * a.steps / dt, 'n_gpus': world,
                           'ms_per_step': dt / a.steps * 1e3, 'batch_per_gpu': a.batch, 'dtype': 'f32' if a.gemm == 'fp32' else 'bf16 GEMM operands, f32 accumulate/master',
                           'first_loss': losses[0], 'last_loss': losses[-1], 'cpu_baseline': cpu,
+                          'graph_of_last_step': {'nodes': tr.h.n_phar + tr.h.n_pocket, 'edges': tr.h.query('train_edges'),
+                                                 'coord_edges': tr.h.query('train_coord_edges')},
                           'phase_ms': {'loss_and_grad': ev[0].elapsed_time(ev[1]), 'allreduce': ev[1].elapsed_time(ev[2]),
                                        'clip_and_adamw': ev[2].elapsed_time(ev[3])}}))
 

@@ -42,3 +42,13 @@ for name, a, b in marks:
     ws = (step[a - 1][1] if a else t0); we = step[b - 1][1]
     bz = sum(e - s for s, e, _ in step[a:b])
     print(f'{name:40s} wall {1e-3 * (we - ws):8.0f} us  busy {1e-3 * bz:8.0f} us  launches {b - a}')
+# every launch of the kernels named on the command line (after the trace directory), in order: duration and grid
+if len(sys.argv) > 2:
+    full = list(csv.DictReader(open(f)))
+    full.sort(key=lambda r: int(r['Start_Timestamp']))
+    full = full[lo:hi]
+    for pat in sys.argv[2:]:
+        print('--', pat)
+        for r in full:
+            if pat in r['Kernel_Name']:
+                print(f"{1e-3 * (int(r['End_Timestamp']) - int(r['Start_Timestamp'])):8.1f} us  grid {r.get('Grid_Size', '?'):>8s} wg {r.get('Workgroup_Size', '?'):>5s}  {r['Kernel_Name'][:60]}")
