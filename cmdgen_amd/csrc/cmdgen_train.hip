@@ -47,6 +47,11 @@ void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float*
                       const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ, float* dWcol, float* dX,
                       float* scratch, hipStream_t s);
 size_t tr_edge_tail_scratch_floats(size_t E, size_t H);
+size_t tr_partial_scratch_floats(size_t E, size_t H);
+void tr_gate_bwd(int E, int H, const int* row, const float* pre2, const float* wa, const float* z, int attention, const float* dagg,
+                 float* dpre2, float* scratch, float* d_wa, float* d_ba, hipStream_t s);
+void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
+                 hipStream_t s);
 void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s);
 void tr_scatter_rows(int E, int H, const int* idx, const float* src, float* dst, hipStream_t s);
 void tr_rowdot(int E, int H, const float* X, const float* w, int ldw, float* out, hipStream_t s);
@@ -125,7 +130,7 @@ struct TrainState {
     float4* X;                          // [L+1][N]
     // edge level (saved per block)
     float *pre1, *pre2, *z, *pre6, *pre7, *phi;
-    float *act1, *act2, *act6, *act7;   // SiLU of the above, written by the producing kernel (nothing is recomputed)
+    float *act1, *act6;                 // SiLU of pre1 / pre6, written by the producing kernel (the x operands of two weight gradients)
     // edge level scratch
     float *actA, *actB, *r, *rc, *dr, *dz, *dphi, *tail_scratch;
     float4 *cd, *dcd;
@@ -257,12 +262,12 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
 #define EA(dst, type, count) do { rc = dev_alloc(h, t->edge_allocs, &p, (size_t)(count) * sizeof(type), false); \
         if (rc) return rc; dst = (type*)p; } while (0)
     EA(t->pre1, float, L * ec * H); EA(t->pre2, float, L * ec * H); EA(t->z, float, L * ec);
-    EA(t->act1, float, L * ec * H); EA(t->act2, float, L * ec * H); EA(t->act6, float, L * ecc * H); EA(t->act7, float, L * ecc * H);
+    EA(t->act1, float, L * ec * H); EA(t->act6, float, L * ecc * H);      // SiLU(pre2) / SiLU(pre7) are recomputed by their one consumer
     EA(t->pre6, float, L * ecc * H); EA(t->pre7, float, L * ecc * H); EA(t->phi, float, L * ecc);
     EA(t->actA, float, em * H); EA(t->actB, float, em * H);
     EA(t->r, float, ec); EA(t->rc, float, ecc); EA(t->dr, float, em); EA(t->dz, float, ec); EA(t->dphi, float, ecc);
     EA(t->cd, float4, ecc); EA(t->dcd, float4, ecc);
-    EA(t->tail_scratch, float, tr_edge_tail_scratch_floats(em, H));
+    EA(t->tail_scratch, float, std::max(tr_edge_tail_scratch_floats(em, H), tr_partial_scratch_floats(em, H)));
 #undef EA
     t->ecap = ec; t->eccap = ecc;
     return 0;
@@ -366,9 +371,9 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     sw.emb_wT = t->emb_wT; sw.emb_b = theta + tb.emb.b; sw.embo_wT = t->embo_wT; sw.embo_b = theta + tb.embo.b;
     TrainSave sv{};
     sv.enc1_l = t->enc1_l; sv.enca_l = t->enca_l; sv.enc1_p = t->enc1_p; sv.enca_p = t->enca_p; sv.hdyn = t->hdyn; sv.h = t->h;
-    sv.pre1 = t->pre1; sv.act1 = t->act1; sv.pre2 = t->pre2; sv.act2 = t->act2; sv.z = t->z;
+    sv.pre1 = t->pre1; sv.act1 = t->act1; sv.pre2 = t->pre2; sv.act2 = nullptr; sv.z = t->z;
     sv.aggn = t->aggn; sv.pre3 = t->pre3; sv.nact = t->nact;
-    sv.pre6 = t->pre6; sv.act6 = t->act6; sv.pre7 = t->pre7; sv.act7 = t->act7; sv.phi = t->phi;
+    sv.pre6 = t->pre6; sv.act6 = t->act6; sv.pre7 = t->pre7; sv.act7 = nullptr; sv.phi = t->phi;
     sv.hfin = t->hfin; sv.dec1 = t->dec1; sv.deca = t->deca; sv.dec_out = t->dec_out;
     sv.qdec1 = t->qdec1; sv.qdeca = t->qdeca; sv.qdec_out = t->qdec_out;
     sv.ecap = t->ecap; sv.eccap = t->eccap;
@@ -470,16 +475,20 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         const float* pre6 = t->pre6 + (size_t)l * t->eccap * H; const float* pre7 = t->pre7 + (size_t)l * t->eccap * H;
         const float* aggn = t->aggn + (size_t)l * NH; const float* pre3 = t->pre3 + (size_t)l * NH;
         const float* phi = t->phi + (size_t)l * t->eccap; const float* z = t->z + (size_t)l * t->ecap;
-        const float* act1 = t->act1 + (size_t)l * t->ecap * H; const float* act2 = t->act2 + (size_t)l * t->ecap * H;
-        const float* act6 = t->act6 + (size_t)l * t->eccap * H; const float* act7 = t->act7 + (size_t)l * t->eccap * H;
+        const float* act1 = t->act1 + (size_t)l * t->ecap * H;
+        const float* act6 = t->act6 + (size_t)l * t->eccap * H;
         const float* nact = t->nact + (size_t)l * NH;
         // ---- EquivariantUpdate: x_{l+1} = x_l + acc / nf ; dX holds dL/dx_{l+1} and becomes dL/dx_l
         HIPCHK(h, hipMemcpyAsync(t->dacc, t->dX, (size_t)N * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
         tr_scale(t->dacc, d.norm_factor, (size_t)N * 4, s);
         tr_edge_geom(Ec, w.crow, w.ccol, Xl, d.norm_constant, t->rc, nullptr, s);
         tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dacc, Nm, t->dphi, t->dcd, s);
-        tr_colsum(Ec, H, act7, H, t->dphi, grad + b.c4.w, 1, s);                      // d coord_mlp.4 (c2 = act7)
-        tr_outer_silu_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, s);          // actB <- dpre7
+        if (H <= 256 && H % 4 == 0) tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, t->tail_scratch, grad + b.c4.w, s);   // actB <- dpre7, d coord_mlp.4
+        else {
+            tr_silu(pre7, t->actA, (size_t)Ec * H, s);                                    // c2 (not stored by the forward)
+            tr_colsum(Ec, H, t->actA, H, t->dphi, grad + b.c4.w, 1, s);
+            tr_outer_silu_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, s);
+        }
         {   // weight and bias gradient of coord_mlp.2 in one launch (c1 = act6)
             WgradBatch one; one.n = 1;
             one.dy[0] = t->actB; one.x[0] = act6; one.dw[0] = grad + b.c2.w; one.db[0] = grad + b.c2.b;
@@ -516,10 +525,16 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             tr_scale(t->dagg, d.norm_factor, NH, s);
         }
         // ---- edge model
-        tr_att_msg_bwd(E, H, w.erow, act2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, pre2, t->actA, t->dz, s);   // actA <- dpre2
-        if (d.attention) {
-            tr_colsum(E, H, act2, H, t->dz, grad + b.att.w, 1, s);
-            tr_sum(E, t->dz, grad + b.att.b, s);
+        if (H <= 256 && H % 4 == 0)                                                       // actA <- dpre2, d att_mlp
+            tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, t->actA, t->tail_scratch,
+                        d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, s);
+        else {
+            tr_silu(pre2, t->actB, (size_t)E * H, s);                                     // m2 (not stored by the forward)
+            tr_att_msg_bwd(E, H, w.erow, t->actB, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, pre2, t->actA, t->dz, s);
+            if (d.attention) {
+                tr_colsum(E, H, t->actB, H, t->dz, grad + b.att.w, 1, s);
+                tr_sum(E, t->dz, grad + b.att.b, s);
+            }
         }
         {   // weight and bias gradient of edge_mlp.2 in one launch (m1 = act1)
             WgradBatch one; one.n = 1;

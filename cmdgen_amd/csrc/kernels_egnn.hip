@@ -546,6 +546,28 @@ __device__ __forceinline__ void build_edge_half(unsigned short* planes, int half
     }
 }
 
+// Training save hook: the LDS tile holds PRE-activations.  They and their SiLU leave for HBM as whole rows (16 bytes per
+// lane - scattered 4-byte stores straight from the accumulators cost several times the bandwidth), and the tile is left
+// holding SiLU(pre) as the sampler's epilogue would have written it.  pre_out / act_out (may be null: the consumer
+// recomputes it) point at the tile's first row.
+template <int H, int MT>
+__device__ __forceinline__ void save_rows_silu(float* buf, int nvalid, float* __restrict__ pre_out, float* __restrict__ act_out) {
+    constexpr int LPR = H / 4;
+    const int c4 = threadIdx.x % LPR, rsub = threadIdx.x / LPR;
+#pragma unroll
+    for (int pass = 0; pass < MT / 4; ++pass) {
+        const int r = pass * 4 + rsub;
+        float4* cell = reinterpret_cast<float4*>(buf + r * LDA(H) + 4 * c4);
+        const float4 p = *cell;
+        const float4 a = make_float4(silu_f(p.x), silu_f(p.y), silu_f(p.z), silu_f(p.w));
+        if (r < nvalid) {
+            reinterpret_cast<float4*>(pre_out + (size_t)r * H)[c4] = p;
+            if (act_out) reinterpret_cast<float4*>(act_out + (size_t)r * H)[c4] = a;
+        }
+        *cell = a;
+    }
+}
+
 // per-row dot product of the LDS tile with a weight vector: H/MT threads per row
 template <int H, int MT>
 __device__ __forceinline__ float tile_row_dot(const float* buf, const float* wv, int& r_out, bool& lead) {
@@ -669,14 +691,15 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
         lds_barrier();                         // every wave is done reading the A tile
         STAMP(3);
         acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {                 // m_ij
-            const float pre = v + b2v.v[n], m = silu_f(pre);
-            buf[row * LDA(H) + col] = m;
-            if (SAVE && row < ne) {
-                const size_t o = ((size_t)layer * sv.ecap + e0 + row) * H + col;
-                sv.pre2[o] = pre; sv.act2[o] = m;
-            }
+            const float pre = v + b2v.v[n];
+            buf[row * LDA(H) + col] = SAVE ? pre : silu_f(pre);
         });
         lds_barrier();
+        if constexpr (SAVE) {
+            const size_t o = ((size_t)layer * sv.ecap + e0) * H;
+            save_rows_silu<H, MT>(buf, ne, sv.pre2 + o, sv.act2 ? sv.act2 + o : nullptr);
+            lds_barrier();
+        }
         STAMP(4);
         if (!(ablate & 16)) {   // attention gate: sigmoid(w_a . m_ij + b_a)
             int r; bool lead;
@@ -840,14 +863,15 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
     }
     lds_barrier();
     acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {
-        const float pre = v + b3v.v[n], a = silu_f(pre);
-        buf1[row * LDA(H) + col] = a;
-        if (SAVE && row < nvalid) {
-            const size_t o = ((size_t)layer * lay.N + row0 + row) * H + col;
-            sv.pre3[o] = pre; sv.nact[o] = a;
-        }
+        const float pre = v + b3v.v[n];
+        buf1[row * LDA(H) + col] = SAVE ? pre : silu_f(pre);
     });
     lds_barrier();
+    if constexpr (SAVE) {
+        const size_t o = ((size_t)layer * lay.N + row0) * H;
+        save_rows_silu<H, MT>(buf1, nvalid, sv.pre3 + o, sv.nact + o);
+        lds_barrier();
+    }
     NSTAMP(2);
     acc_zero<MT>(acc);
     G::template gemm<H / 8>(buf1, LDA(H), f4, fc, acc, carry);
@@ -859,18 +883,21 @@ __global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, Layer
             float* hp = w.h + (size_t)(row0 + row) * H + col;
             const float hold = TWO ? buf0[row * LDA(H) + col] : *hp;
             hn = hold + (v + b4v.v[n]);                                                 // residual (egnn_new.py:57)
-            if (MT != 32 || SAVE) *hp = hn;     // 32-row tiles of the sampler store h from the LDS image below, as whole rows
-            if (SAVE) sv.h[((size_t)(layer + 1) * lay.N + row0 + row) * H + col] = hn;   // h entering block layer+1
+            if (MT != 32 && !SAVE) *hp = hn;    // 32-row tiles and the training forward store h from the LDS image below, as whole rows
         }
         buf1[row * LDA(H) + col] = hn;
     });
     lds_barrier();
-    if constexpr (MT == 32 && !SAVE) {      // h_new is in LDS for the projections anyway: it leaves as 1 KiB rows, 16 bytes per lane
+    if constexpr (MT == 32 || SAVE) {       // h_new is in LDS for the projections anyway: it leaves as 1 KiB rows, 16 bytes per lane
                                             // (B=256: +0.7 %; at 16 rows the scalar stores are as good, gpurun_out/r2zw_h_rowstore_ab.txt)
 #pragma unroll
         for (int pass = 0; pass < MT / 4; ++pass) {
             const int r = pass * 4 + rsub;
-            if (r < nvalid) reinterpret_cast<float4*>(w.h + (size_t)(row0 + r) * H)[c4] = *reinterpret_cast<const float4*>(buf1 + r * LDA(H) + 4 * c4);
+            if (r < nvalid) {
+                const float4 hv = *reinterpret_cast<const float4*>(buf1 + r * LDA(H) + 4 * c4);
+                reinterpret_cast<float4*>(w.h + (size_t)(row0 + r) * H)[c4] = hv;
+                if (SAVE) reinterpret_cast<float4*>(sv.h + ((size_t)(layer + 1) * lay.N + row0 + r) * H)[c4] = hv;   // h entering block layer+1
+            }
         }
     }
     NSTAMP(4);
@@ -964,14 +991,15 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
         }
         lds_barrier();
         acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {
-            const float pre = v + b7v.v[n], a = silu_f(pre);
-            buf[row * LDA(H) + col] = a;
-            if (SAVE && row < ne) {
-                const size_t o = ((size_t)layer * sv.eccap + e0 + row) * H + col;
-                sv.pre7[o] = pre; sv.act7[o] = a;
-            }
+            const float pre = v + b7v.v[n];
+            buf[row * LDA(H) + col] = SAVE ? pre : silu_f(pre);
         });
         lds_barrier();
+        if constexpr (SAVE) {
+            const size_t o = ((size_t)layer * sv.eccap + e0) * H;
+            save_rows_silu<H, MT>(buf, ne, sv.pre7 + o, sv.act7 ? sv.act7 + o : nullptr);
+            lds_barrier();
+        }
         {
             int r; bool lead;
             const float s = tile_row_dot<H, MT>(buf, s_w5, r, lead);

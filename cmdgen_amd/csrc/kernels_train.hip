@@ -644,6 +644,125 @@ __global__ void k_att_msg_bwd(int E, int H, const int* __restrict__ row, const f
         dm2[(size_t)e * H + c] = (g[c] * att + (attention ? dz * wa[c] : 0.f)) * dsilu(pre2[(size_t)e * H + c]);
 }
 
+// ------------------------------------------------------------------------------------
+// The same adjoint in ONE pass over pre2, together with the two reductions that used to follow it (k_colsum4 over m2
+// with weights dz, k_sum over dz): m2 = SiLU(pre2) is recomputed with the forward's own silu_f instead of being read
+// (the forward no longer stores it), d att_mlp.weight[c] += sum_e dz_e m2[e][c] and d att_mlp.bias += sum_e dz_e are
+// accumulated per workgroup (32 consecutive edges, 8 per wave, a lane owns four consecutive columns) and written to a
+// scratch row; k_partial_reduce adds the rows up.  H <= 256, H % 4 == 0.
+// ------------------------------------------------------------------------------------
+#define GATE_EPW 8
+__global__ __launch_bounds__(256) void k_gate_bwd(int E, int H, const int* __restrict__ row, const float* __restrict__ pre2,
+                                                  const float* __restrict__ wa, const float* __restrict__ z, int attention,
+                                                  const float* __restrict__ dagg, float* __restrict__ dpre2,
+                                                  float* __restrict__ scratch /* [workgroups][H + 4] */) {
+    __shared__ float red[4][260];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool on = 4 * lane < H;
+    const int e0 = blockIdx.x * (4 * GATE_EPW) + wave * GATE_EPW, e1 = min(E, e0 + GATE_EPW);
+    float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), cs = w4;
+    if (on && attention) w4 = reinterpret_cast<const float4*>(wa)[lane];
+    float sdz = 0.f;
+    float4 pv[GATE_EPW], gv[GATE_EPW];
+    float zv[GATE_EPW];
+#pragma unroll
+    for (int k = 0; k < GATE_EPW; ++k) {            // all rows of the wave requested before the first is used
+        const int e = e0 + k;
+        pv[k] = gv[k] = make_float4(0.f, 0.f, 0.f, 0.f); zv[k] = 0.f;
+        if (e < e1) {
+            if (on) {
+                pv[k] = reinterpret_cast<const float4*>(pre2 + (size_t)e * H)[lane];
+                gv[k] = reinterpret_cast<const float4*>(dagg + (size_t)row[e] * H)[lane];
+            }
+            if (attention) zv[k] = z[e];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < GATE_EPW; ++k) {
+        const int e = e0 + k;
+        if (e < e1) {                                // wave-uniform
+            const float4 p = pv[k], g = gv[k];
+            float att = 1.0f, dz = 0.f;
+            if (attention) {
+                const float4 m = make_float4(silu_f(p.x), silu_f(p.y), silu_f(p.z), silu_f(p.w));
+                att = 1.0f / (1.0f + expf(-zv[k]));
+                dz = wave_sum(g.x * m.x + g.y * m.y + g.z * m.z + g.w * m.w) * att * (1.0f - att);
+                cs.x += dz * m.x; cs.y += dz * m.y; cs.z += dz * m.z; cs.w += dz * m.w;
+                sdz += dz;
+            }
+            if (on) {
+                float4 o;
+                o.x = (g.x * att + dz * w4.x) * dsilu(p.x); o.y = (g.y * att + dz * w4.y) * dsilu(p.y);
+                o.z = (g.z * att + dz * w4.z) * dsilu(p.z); o.w = (g.w * att + dz * w4.w) * dsilu(p.w);
+                reinterpret_cast<float4*>(dpre2 + (size_t)e * H)[lane] = o;
+            }
+        }
+    }
+    if (!attention) return;
+    *reinterpret_cast<float4*>(&red[wave][4 * lane]) = cs;
+    if (lane == 0) red[wave][256] = sdz;
+    __syncthreads();
+    float* out = scratch + (size_t)blockIdx.x * (H + 4);
+    for (int c = threadIdx.x; c < H; c += 256) out[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (threadIdx.x == 0) out[H] = (red[0][256] + red[1][256]) + (red[2][256] + red[3][256]);
+}
+
+// dpre7[e][c] = dphi_e w5[c] SiLU'(pre7[e][c]) and, in the same pass, the partial sums of d coord_mlp.4.weight[c] =
+// sum_e dphi_e SiLU(pre7[e][c]) (c2 is recomputed, not read); same workgroup shape and scratch layout as k_gate_bwd.
+__global__ __launch_bounds__(256) void k_head_bwd(int E, int H, const float* __restrict__ dphi, const float* __restrict__ w5,
+                                                  const float* __restrict__ pre7, float* __restrict__ dpre7,
+                                                  float* __restrict__ scratch /* [workgroups][H + 4] */) {
+    __shared__ float red[4][260];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool on = 4 * lane < H;
+    const int e0 = blockIdx.x * (4 * GATE_EPW) + wave * GATE_EPW, e1 = min(E, e0 + GATE_EPW);
+    float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), cs = w4;
+    if (on) w4 = reinterpret_cast<const float4*>(w5)[lane];
+    float4 pv[GATE_EPW]; float sv[GATE_EPW];
+#pragma unroll
+    for (int k = 0; k < GATE_EPW; ++k) {
+        const int e = e0 + k;
+        pv[k] = make_float4(0.f, 0.f, 0.f, 0.f); sv[k] = 0.f;
+        if (e < e1) { sv[k] = dphi[e]; if (on) pv[k] = reinterpret_cast<const float4*>(pre7 + (size_t)e * H)[lane]; }
+    }
+#pragma unroll
+    for (int k = 0; k < GATE_EPW; ++k) {
+        const int e = e0 + k;
+        if (e < e1 && on) {
+            const float4 p = pv[k]; const float se = sv[k];
+            cs.x += se * silu_f(p.x); cs.y += se * silu_f(p.y); cs.z += se * silu_f(p.z); cs.w += se * silu_f(p.w);
+            reinterpret_cast<float4*>(dpre7 + (size_t)e * H)[lane] =
+                make_float4(se * w4.x * dsilu(p.x), se * w4.y * dsilu(p.y), se * w4.z * dsilu(p.z), se * w4.w * dsilu(p.w));
+        }
+    }
+    *reinterpret_cast<float4*>(&red[wave][4 * lane]) = cs;
+    __syncthreads();
+    float* out = scratch + (size_t)blockIdx.x * (H + 4);
+    for (int c = threadIdx.x; c < H; c += 256) out[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// out_w[c] += sum over workgroups of scratch[wg][c] (c < H), out_b[0] += sum of scratch[wg][H] (when out_b).  grid
+// ((H + 1 + 63) / 64, slices): every workgroup sums one slice of the rows for 64 columns and adds its result with one atomic.
+__global__ __launch_bounds__(256) void k_partial_reduce(int nwg, int H, const float* __restrict__ scratch, float* __restrict__ out_w,
+                                                        float* __restrict__ out_b) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int ncol = H + (out_b ? 1 : 0);
+    const int per = (nwg + gridDim.y - 1) / gridDim.y;
+    const int w0 = blockIdx.y * per, w1 = min(nwg, w0 + per);
+    float sum = 0.f;
+    if (c < ncol) {
+#pragma unroll 4
+        for (int w = w0 + part; w < w1; w += 4) sum += scratch[(size_t)w * (H + 4) + c];
+    }
+    red[part][threadIdx.x & 63] = sum;
+    __syncthreads();
+    if (part == 0 && c < ncol) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        atomicAdd(c < H ? out_w + c : out_b, t);
+    }
+}
+
 // coordinate head (egnn_new.py:87-104): phi = w5 . c2, g = tanh(phi) * range (or phi), accx[row] += cd * g
 __global__ void k_coord_out(int E, int H, const int* __restrict__ row, const float* __restrict__ c2,
                             const float* __restrict__ w5, const float4* __restrict__ cd, int use_tanh, float range,
@@ -1209,6 +1328,23 @@ void tr_att_msg(int E, int H, const int* row, const float* m2, const float* wa, 
 void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* wa, const float* z, int attention,
                     const float* dagg, const float* pre2, float* dm2, float* dz, hipStream_t s) {
     if (E) hipLaunchKernelGGL(k_att_msg_bwd, ROW_GRID(E), 0, s, E, H, row, m2, wa, z, attention, dagg, pre2, dm2, dz);
+}
+size_t tr_partial_scratch_floats(size_t E, size_t H) { return ((E + 4 * GATE_EPW - 1) / (4 * GATE_EPW)) * (H + 4); }
+// the attention gate's adjoint with its two parameter gradients (d_wa [H], d_ba [1]; ignored without attention)
+void tr_gate_bwd(int E, int H, const int* row, const float* pre2, const float* wa, const float* z, int attention, const float* dagg,
+                 float* dpre2, float* scratch, float* d_wa, float* d_ba, hipStream_t s) {
+    if (!E) return;
+    const int nwg = (E + 4 * GATE_EPW - 1) / (4 * GATE_EPW);
+    hipLaunchKernelGGL(k_gate_bwd, dim3(nwg), dim3(256), 0, s, E, H, row, pre2, wa, z, attention, dagg, dpre2, scratch);
+    if (attention) hipLaunchKernelGGL(k_partial_reduce, dim3((H + 1 + 63) / 64, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, d_wa, d_ba);
+}
+// dpre7 from dphi, and d coord_mlp.4.weight
+void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
+                 hipStream_t s) {
+    if (!E) return;
+    const int nwg = (E + 4 * GATE_EPW - 1) / (4 * GATE_EPW);
+    hipLaunchKernelGGL(k_head_bwd, dim3(nwg), dim3(256), 0, s, E, H, dphi, w5, pre7, dpre7, scratch);
+    hipLaunchKernelGGL(k_partial_reduce, dim3((H + 63) / 64, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, d_w5, (float*)nullptr);
 }
 void tr_coord_out(int E, int H, const int* row, const float* c2, const float* w5, const float4* cd, int use_tanh, float range,
                   float* phi, float* accx, hipStream_t s) {
