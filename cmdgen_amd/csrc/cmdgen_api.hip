@@ -355,10 +355,15 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
         const int64_t cN = cNl + cNp, ce = h->cap_B ? grow(ecap) : ecap, cec = h->cap_B ? grow(eccap) : eccap;
         const int64_t cNm = d.joint ? cN : cNl;
 #define ALLOC(dst, type, count, zero) do { rc = dev_alloc(h, h->layout_allocs, &p, (size_t)(count) * sizeof(type), zero); if (rc) return rc; dst = (type*)p; } while (0)
-        ALLOC(L.num_phar, const int, cB, true); ALLOC(L.num_pocket, const int, cB, true);
-        ALLOC(L.phar_base, const int, cB, true); ALLOC(L.pocket_base, const int, cB, true);
-        ALLOC(L.node_sample, const int, cN, true);
-        ALLOC(h->d_gid, int64_t, cB, true); L.pocket_gid = h->d_gid;
+        // the index arrays live in ONE block, [gid (int64) | num_phar | num_pocket | phar_base | pocket_base | node_sample]: a new
+        // layout (every training step has its own) is one host-to-device copy instead of six
+        {
+            int* blk = nullptr;
+            ALLOC(blk, int, 6 * cB + cN, true);
+            h->d_gid = reinterpret_cast<int64_t*>(blk); L.pocket_gid = h->d_gid;
+            L.num_phar = blk + 2 * cB; L.num_pocket = blk + 3 * cB; L.phar_base = blk + 4 * cB; L.pocket_base = blk + 5 * cB;
+            L.node_sample = blk + 6 * cB;
+        }
         const size_t H = d.H;
         ALLOC(w.X0, float4, cNm, true); ALLOC(w.XP, float4, cNp, true);
         ALLOC(w.XL, float4, (size_t)d.L * cNm, true); ALLOC(w.ACC, float4, (size_t)d.L * cNm, true);
@@ -382,12 +387,16 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
     L.B = B; L.Nl = (int)Nl; L.Np = (int)Np; L.N = (int)N; L.max_n = max_n;
     L.Nm = d.joint ? (int)N : (int)Nl;
     // (plain hipMemcpy: ordered after all earlier work of the blocking streams that may still read the old arrays)
-#define UP_I(dst, vec) HIPCHK(h, hipMemcpy((void*)(dst), (vec).data(), (vec).size() * sizeof(int), hipMemcpyHostToDevice))
-    UP_I(L.num_phar, vph); UP_I(L.num_pocket, vpk); UP_I(L.phar_base, bph); UP_I(L.pocket_base, bpk); UP_I(L.node_sample, ns);
-#undef UP_I
     {
-        std::vector<int64_t> gid(B); for (int b = 0; b < B; ++b) gid[b] = b;
-        HIPCHK(h, hipMemcpy(h->d_gid, gid.data(), B * sizeof(int64_t), hipMemcpyHostToDevice));
+        const int64_t cB = h->cap_B;
+        std::vector<int> stage((size_t)(6 * cB + N), 0);
+        int64_t* gid = reinterpret_cast<int64_t*>(stage.data());
+        for (int b = 0; b < B; ++b) {
+            gid[b] = b;
+            stage[2 * cB + b] = vph[b]; stage[3 * cB + b] = vpk[b]; stage[4 * cB + b] = bph[b]; stage[5 * cB + b] = bpk[b];
+        }
+        memcpy(stage.data() + 6 * cB, ns.data(), (size_t)N * sizeof(int));
+        HIPCHK(h, hipMemcpy((void*)h->d_gid, stage.data(), stage.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     if (fits) {   // reused buffers: restore the invariants a fresh (zeroed) workspace has
         HIPCHK(h, hipMemset(w.agg, 0, (size_t)N * d.H * sizeof(float)));

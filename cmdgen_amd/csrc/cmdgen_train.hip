@@ -65,7 +65,8 @@ void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s);
 void tr_eps_out(int n_rows, int F, int row0, const float* vel, const float* dec, float* eps, hipStream_t s);
 void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, float* ddec, hipStream_t s);
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
-              float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s);
+              float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s, const float* sqnorm = nullptr,
+              float max_norm = 0.f);
 void tr_sqsum(size_t n, const float* x, float* out, hipStream_t s);
 void tr_noise(const Layout& lay, const Dims& d, const float* px, const float* poh, const float* qx, const float* qoh, const float* tab,
               const float* eps, float* z_t, float* xh_pocket, float* klsum, hipStream_t s);
@@ -644,6 +645,30 @@ extern "C" int cmdgen_adamw_step(cmdgen_handle* h, float* theta, const float* gr
     tr_adamw((size_t)n, theta, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bias1,
              sqrtf(bias2), clip_coef, (hipStream_t)stream);
     HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_adamw_step_clipped(cmdgen_handle* h, float* theta, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                         float* max_exp_avg_sq, int64_t n, int64_t step, float lr, float beta1, float beta2,
+                                         float eps, float weight_decay, float max_grad_norm, float* grad_norm_host,
+                                         cmdgen_stream stream) {
+    if (!h || !theta || !grad || !exp_avg || !exp_avg_sq || !max_exp_avg_sq || !grad_norm_host || n < 1 || step < 1)
+        return fail(h, CMDGEN_EINVAL, "bad arguments");
+    hipSetDevice(h->device);
+    int rc = ensure_state(h); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    h->last_stream = s;
+    float* sq = h->train->d_scalar;
+    HIPCHK(h, hipMemsetAsync(sq, 0, sizeof(float), s));
+    tr_sqsum((size_t)n, grad, sq, s);
+    const float bias1 = 1.0f - powf(beta1, (float)step), bias2 = 1.0f - powf(beta2, (float)step);
+    // the update is queued behind the norm without a host round trip: the clipping coefficient is formed on the device
+    tr_adamw((size_t)n, theta, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bias1, sqrtf(bias2), 1.0f, s,
+             max_grad_norm > 0.f ? sq : nullptr, max_grad_norm);
+    float sqh = 0.f;
+    HIPCHK(h, hipMemcpyAsync(&sqh, sq, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    *grad_norm_host = sqrtf(sqh);
     return CMDGEN_OK;
 }
 

@@ -1094,9 +1094,11 @@ __global__ void k_eps_bwd(int n_rows, int F, int row0, const float* __restrict__
 // ------------------------------------------------------------------------------------
 __global__ void k_adamw(size_t n, float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
                         float* __restrict__ v, float* __restrict__ vmax, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, float bias1, float bias2_sqrt, float clip) {
+                        float weight_decay, float bias1, float bias2_sqrt, float clip, const float* __restrict__ sqnorm,
+                        float max_norm) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (sqnorm) clip = fminf(1.0f, max_norm / (sqrtf(sqnorm[0]) + 1e-6f));      // clip_grad_norm_'s coefficient from the device-side norm
     const float g = grad[i] * clip;
     float p = theta[i];
     p *= 1.0f - lr * weight_decay;
@@ -1412,8 +1414,9 @@ void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, flo
     if (n_rows) hipLaunchKernelGGL(k_eps_bwd, EW_GRID((size_t)n_rows * (3 + F)), 0, s, n_rows, F, row0, deps, dvel, ddec);
 }
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
-              float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_adamw, EW_GRID(n), 0, s, n, theta, grad, m, v, vmax, lr, b1, b2, eps, wd, bias1, bias2_sqrt, clip);
+              float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s, const float* sqnorm = nullptr,
+              float max_norm = 0.f) {
+    if (n) hipLaunchKernelGGL(k_adamw, EW_GRID(n), 0, s, n, theta, grad, m, v, vmax, lr, b1, b2, eps, wd, bias1, bias2_sqrt, clip, sqnorm, max_norm);
 }
 void tr_sqsum(size_t n, const float* x, float* out, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_sqsum, dim3((unsigned)(n / 4096 + 1 > 1024 ? 1024 : n / 4096 + 1)), dim3(256), 0, s, n, x, out);

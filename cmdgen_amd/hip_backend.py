@@ -70,6 +70,8 @@ SYMBOLS = [
     ('cmdgen_grad_sqnorm', C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_float), _vp]),
     ('cmdgen_adamw_step', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, _vp]),
+    ('cmdgen_adamw_step_clipped', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                            C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), _vp]),
     ('cmdgen_debug_sgemm', C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, _fp,
                                      C.c_int32, _fp, C.c_int32, _fp, C.c_int32, C.c_int32, _vp]),
     ('cmdgen_set_step_table', C.c_int, [_vp, C.c_int32, _vp]),
@@ -418,6 +420,16 @@ class Handle:
                                                _ptr(max_exp_avg_sq), theta.numel(), int(step), float(lr), float(betas[0]),
                                                float(betas[1]), float(eps), float(weight_decay), float(clip_coef),
                                                self._stream()), 'cmdgen_adamw_step')
+
+    def adamw_step_clipped(self, theta, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8,
+                           weight_decay=1e-12, max_grad_norm=0.0) -> float:
+        """Norm + clipping (coefficient formed on the device; max_grad_norm <= 0: none) + AdamW; returns the gradient norm."""
+        out = C.c_float(0)
+        self._check(self.lib.cmdgen_adamw_step_clipped(self.h, _ptr(theta), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                                       _ptr(max_exp_avg_sq), theta.numel(), int(step), float(lr), float(betas[0]),
+                                                       float(betas[1]), float(eps), float(weight_decay), float(max_grad_norm),
+                                                       C.byref(out), self._stream()), 'cmdgen_adamw_step_clipped')
+        return out.value
 
     def debug_sgemm(self, A, B, ta=False, tb=True, bias=None, C_out=None, accumulate=False, split_k=1, bf16=False):
         import torch

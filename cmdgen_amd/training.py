@@ -84,24 +84,27 @@ class HipTrainer:
         with the reference's fp32 op sequence."""
         ddpm = self.ddpm
         if self._gamma_host is None:
-            self._gamma_host = ddpm.gamma.gamma.detach().to('cpu', torch.float32)
-            self._logpn_host = ddpm.size_distribution._table(1, torch.device('cpu')).to(torch.float32)
-        g = self._gamma_host
-        T = float(ddpm.T)
-        t_int = t_int.to('cpu', torch.float32).reshape(-1)
-        s, t = (t_int - 1) / T, t_int / T
-        gamma_s, gamma_t = g[torch.round(s * T).long()], g[torch.round(t * T).long()]
-        gamma_T, gamma_0 = g[int(round(T))], g[0]
-        n = torch.as_tensor(n_phar, dtype=torch.float32)
-        sub = (n - 1) * ddpm.n_dims
+            self._gamma_host = ddpm.gamma.gamma.detach().to('cpu', torch.float32).numpy().copy()
+            self._logpn_host = ddpm.size_distribution._table(1, torch.device('cpu')).to(torch.float32).numpy().copy()
+        g, f32 = self._gamma_host, np.float32
+        T = f32(ddpm.T)
+        t_int = np.asarray(t_int.detach().to('cpu', torch.float32)).reshape(-1)
+        s, t = (t_int - f32(1)) / T, t_int / T
+        gamma_s, gamma_t = g[np.rint(s * T).astype(np.int64)], g[np.rint(t * T).astype(np.int64)]     # s = -1/T wraps to gamma[T], as the reference's lookup
+        gamma_T, gamma_0 = g[int(round(float(T)))], g[0]
+        sigmoid = lambda x: (f32(1) / (f32(1) + np.exp(-x, dtype=f32))).astype(f32)
+        n = np.asarray(n_phar, dtype=f32)
+        sub = (n - f32(1)) * f32(ddpm.n_dims)
         nv0, nv1 = float(ddpm.norm_values[0]), float(ddpm.norm_values[1])
-        sigma_t = torch.sqrt(torch.sigmoid(gamma_t))
-        tab = torch.stack([
-            torch.sqrt(torch.sigmoid(-gamma_t)), sigma_t, (t_int == 0).float(), 1 - torch.exp(-(gamma_s - gamma_t)),
-            torch.sqrt(torch.sigmoid(-gamma_T)).expand_as(n), torch.sqrt(torch.sigmoid(gamma_T)).expand_as(n),
-            -(sub * (-(0.5 * gamma_0) - 0.5 * np.log(2 * np.pi))), -sub * np.log(nv0),
-            self._logpn_host[torch.as_tensor(n_phar).long(), torch.as_tensor(n_pocket).long()],
-            t_int, t, sigma_t * nv1]).to(torch.float32).contiguous()
+        sigma_t = np.sqrt(sigmoid(gamma_t))
+        one = np.ones_like(n)
+        tab = np.stack([
+            np.sqrt(sigmoid(-gamma_t)), sigma_t, (t_int == 0).astype(f32), f32(1) - np.exp(-(gamma_s - gamma_t), dtype=f32),
+            np.sqrt(sigmoid(-gamma_T)) * one, np.sqrt(sigmoid(gamma_T)) * one,
+            -(sub * f32(-(0.5 * gamma_0) - 0.5 * np.log(2 * np.pi))), -sub * f32(np.log(nv0)),
+            self._logpn_host[np.asarray(n_phar, dtype=np.int64), np.asarray(n_pocket, dtype=np.int64)],
+            t_int, t, sigma_t * f32(nv1)]).astype(f32)
+        tab = torch.from_numpy(np.ascontiguousarray(tab))
         return tab
 
     @torch.no_grad()
@@ -113,8 +116,8 @@ class HipTrainer:
         dev = self.theta.device
         f32 = lambda k: data[k].to(dev, torch.float32).contiguous()
         px, poh, qx, qoh = f32('phar_coords'), f32('phar_one_hot'), f32('pocket_c_alpha'), f32('pocket_one_hot')
-        n_l = data['num_phar_atoms'].detach().to('cpu', torch.int64).numpy()
-        n_p = data['num_pocket_nodes'].detach().to('cpu', torch.int64).numpy()
+        sizes = torch.stack([data['num_phar_atoms'].reshape(-1), data['num_pocket_nodes'].reshape(-1)]).detach().to('cpu', torch.int64).numpy()
+        n_l, n_p = np.ascontiguousarray(sizes[0]), np.ascontiguousarray(sizes[1])       # one device-to-host copy for both
         B = len(n_l)
         h.set_layout(n_l, n_p)
         h.train_set_precision(self.gemm_dtype == 'bf16')
@@ -242,18 +245,18 @@ class HipTrainer:
 
     def optimizer_step(self, max_grad_norm: Optional[float] = None):
         """Adaptive clipping + AdamW(amsgrad) on the flat buffers; returns (grad_norm, max_grad_norm)."""
-        grad_norm = float(np.sqrt(self.h.grad_sqnorm(self.grad)))
-        clip = 1.0
+        self.step_count += 1
+        if self.clip_grad and max_grad_norm is None:                   # 150 % of the recent mean + 2 stdev
+            max_grad_norm = 1.5 * self.gradnorm_queue.mean() + 2 * self.gradnorm_queue.std()
+        # norm -> clipping coefficient -> update are queued back to back (the coefficient is formed on the device from the
+        # bound known beforehand); the norm itself is only read back for the queue of recent norms
+        grad_norm = self.h.adamw_step_clipped(self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq,
+                                              self.step_count, self.lr, self.betas, self.eps, self.weight_decay,
+                                              float(max_grad_norm) if self.clip_grad else 0.0)
         if self.clip_grad:
-            if max_grad_norm is None:                                  # 150 % of the recent mean + 2 stdev
-                max_grad_norm = 1.5 * self.gradnorm_queue.mean() + 2 * self.gradnorm_queue.std()
-            clip = min(1.0, float(max_grad_norm) / (grad_norm + 1e-6))     # torch.nn.utils.clip_grad_norm_
             self.gradnorm_queue.add(float(max_grad_norm) if grad_norm > max_grad_norm else grad_norm)
             if grad_norm > max_grad_norm:
                 print(f'Clipped gradient with value {grad_norm:.1f} while allowed {max_grad_norm:.1f}')
-        self.step_count += 1
-        self.h.adamw_step(self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, self.step_count,
-                          self.lr, self.betas, self.eps, self.weight_decay, clip)
         self.dyn._weights_sig = None            # the sampler's packed copy of the weights is stale now
         return grad_norm, max_grad_norm
 

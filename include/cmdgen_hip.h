@@ -295,6 +295,16 @@ int cmdgen_adamw_step(cmdgen_handle* h, float* theta, const float* grad, float* 
                       float* max_exp_avg_sq, int64_t n, int64_t step, float lr, float beta1, float beta2,
                       float eps, float weight_decay, float clip_coef, cmdgen_stream stream);
 
+/* Gradient norm, clipping and the AdamW update in one queue-up (lightning_modules.py:543-568 + :141-143): the norm of
+ * `grad` is reduced on the device, the update applies clip_grad_norm_'s coefficient min(1, max_grad_norm / (norm + 1e-6))
+ * formed on the device (max_grad_norm <= 0: no clipping), and the norm comes back in *grad_norm_host for the caller's
+ * queue of recent norms - the host round trip between norm and update of cmdgen_grad_sqnorm + cmdgen_adamw_step is gone.
+ * Synchronises the stream. */
+int cmdgen_adamw_step_clipped(cmdgen_handle* h, float* theta, const float* grad, float* exp_avg, float* exp_avg_sq,
+                              float* max_exp_avg_sq, int64_t n, int64_t step, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, float max_grad_norm, float* grad_norm_host,
+                              cmdgen_stream stream);
+
 /* C[M,N] (+)= op(A) op(B) (+ bias) through the training path's exact-fp32 MFMA GEMM (test aid):
  * ta: A stored [K][M]; tb: B stored [N][K] (nn.Linear weight); accumulate bit 0: C += ..., bit 1: bf16 operands. */
 int cmdgen_debug_sgemm(cmdgen_handle* h, int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, const float* A,

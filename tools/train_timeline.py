@@ -52,3 +52,11 @@ if len(sys.argv) > 2:
         for r in full:
             if pat in r['Kernel_Name']:
                 print(f"{1e-3 * (int(r['End_Timestamp']) - int(r['Start_Timestamp'])):8.1f} us  grid {r.get('Grid_Size', '?'):>8s} wg {r.get('Workgroup_Size', '?'):>5s}  {r['Kernel_Name'][:60]}")
+# per-kernel totals of the step
+tot = collections.defaultdict(lambda: [0, 0])
+for s_, e_, n_ in step:
+    k = n_.split('(')[0][:60]
+    tot[k][0] += e_ - s_; tot[k][1] += 1
+print('-- per kernel, this step')
+for k, (t, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:30]:
+    print(f'{1e-3 * t:8.1f} us {c:4d} x {k}')
