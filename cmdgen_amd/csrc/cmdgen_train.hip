@@ -40,7 +40,7 @@ void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* 
 void tr_coord_out(int E, int H, const int* row, const float* c2, const float* w5, const float4* cd, int use_tanh, float range,
                   float* phi, float* accx, hipStream_t s);
 void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, const float* phi, int use_tanh, float range,
-                      float nc, const float* dacc, int n_moving, float* dphi, float4* dcd, hipStream_t s);
+                      float nc, const float* dacc, float dacc_div, int n_moving, float* dphi, float4* dcd, hipStream_t s);
 void tr_geom_bwd(int E, const int* row, const int* col, const float4* X, float nc, const float4* dcd, const float* dr,
                  int n_moving, float* dX, hipStream_t s);
 void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float* g, const float* d0, const float* Wcol, int ldw,
@@ -49,9 +49,9 @@ void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float*
 size_t tr_edge_tail_scratch_floats(size_t E, size_t H);
 size_t tr_partial_scratch_floats(size_t E, size_t H);
 void tr_gate_bwd(int E, int H, const int* row, const float* pre2, const float* wa, const float* z, int attention, const float* dagg,
-                 float* dpre2, float* scratch, float* d_wa, float* d_ba, hipStream_t s);
+                 float* dpre2, float* scratch, float* d_wa, float* d_ba, float* zero, size_t zero_floats, hipStream_t s);
 void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
-                 hipStream_t s);
+                 float* zero, size_t zero_floats, hipStream_t s);
 void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s);
 void tr_scatter_rows(int E, int H, const int* idx, const float* src, float* dst, hipStream_t s);
 void tr_rowdot(int E, int H, const float* X, const float* w, int ldw, float* out, hipStream_t s);
@@ -480,11 +480,11 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         const float* act6 = t->act6 + (size_t)l * t->eccap * H;
         const float* nact = t->nact + (size_t)l * NH;
         // ---- EquivariantUpdate: x_{l+1} = x_l + acc / nf ; dX holds dL/dx_{l+1} and becomes dL/dx_l
-        HIPCHK(h, hipMemcpyAsync(t->dacc, t->dX, (size_t)N * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
-        tr_scale(t->dacc, d.norm_factor, (size_t)N * 4, s);
-        tr_edge_geom(Ec, w.crow, w.ccol, Xl, d.norm_constant, t->rc, nullptr, s);
-        tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dacc, Nm, t->dphi, t->dcd, s);
-        if (H <= 256 && H % 4 == 0) tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, t->tail_scratch, grad + b.c4.w, s);   // actB <- dpre7, d coord_mlp.4
+        // (dL/d acc = dX / normalization_factor is formed where it is read; every later kernel of the block only adds to dX)
+        tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, Nm, t->dphi, t->dcd, s);
+        const size_t pq_floats = (size_t)(t->dQ - t->dP) + NH;                            // dP and dQ, adjacent
+        const bool fused_small = H <= 256 && H % 4 == 0;
+        if (fused_small) tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, t->tail_scratch, grad + b.c4.w, t->dP, pq_floats, s);   // actB <- dpre7, d coord_mlp.4; clears dP | dQ
         else {
             tr_silu(pre7, t->actA, (size_t)Ec * H, s);                                    // c2 (not stored by the forward)
             tr_colsum(Ec, H, t->actA, H, t->dphi, grad + b.c4.w, 1, s);
@@ -499,7 +499,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         const TrainState::PackBlk& pk = t->pack[l];
         if (sp) cmdgen_dgrad_split(Ec, t->actB, pk.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s);
         else linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
-        HIPCHK(h, hipMemsetAsync(t->dP, 0, (size_t)(t->dQ - t->dP) * sizeof(float) + NH * sizeof(float), s));    // dP and dQ
+        if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
         // adjoints of the gathers, the radial / d0 column gradients, d radial and the geometry adjoint: one pass over dpre6
         tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
                          t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, s);
@@ -526,9 +526,9 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             tr_scale(t->dagg, d.norm_factor, NH, s);
         }
         // ---- edge model
-        if (H <= 256 && H % 4 == 0)                                                       // actA <- dpre2, d att_mlp
+        if (fused_small)                                                                  // actA <- dpre2, d att_mlp; clears dP | dQ
             tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, t->actA, t->tail_scratch,
-                        d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, s);
+                        d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, t->dP, pq_floats, s);
         else {
             tr_silu(pre2, t->actB, (size_t)E * H, s);                                     // m2 (not stored by the forward)
             tr_att_msg_bwd(E, H, w.erow, t->actB, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, pre2, t->actA, t->dz, s);
@@ -545,7 +545,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         }
         if (sp) cmdgen_dgrad_split(E, t->actA, pk.t_e2, nullptr, nullptr, t->actB, false, 1.0f, pre1, s);
         else linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
-        HIPCHK(h, hipMemsetAsync(t->dP, 0, (size_t)(t->dQ - t->dP) * sizeof(float) + NH * sizeof(float), s));    // dP and dQ
+        if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
         tr_edge_tail_bwd(E, H, w.erow, w.ecol, t->actB, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
                          t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, s);
         // node_mlp.0 (both halves) and edge_mlp.0 (both halves): the second grouped launch of the block

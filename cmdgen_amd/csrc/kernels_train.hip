@@ -655,9 +655,12 @@ __global__ void k_att_msg_bwd(int E, int H, const int* __restrict__ row, const f
 __global__ __launch_bounds__(256) void k_gate_bwd(int E, int H, const int* __restrict__ row, const float* __restrict__ pre2,
                                                   const float* __restrict__ wa, const float* __restrict__ z, int attention,
                                                   const float* __restrict__ dagg, float* __restrict__ dpre2,
-                                                  float* __restrict__ scratch /* [workgroups][H + 4] */) {
+                                                  float* __restrict__ scratch /* [workgroups][H + 4] */,
+                                                  float4* __restrict__ zero, size_t zero_n4) {
     __shared__ float red[4][260];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // side duty: clear the buffer the NEXT kernel of the pass accumulates into (dP | dQ) - one memset launch less per list
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero_n4; i += (size_t)gridDim.x * 256) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool on = 4 * lane < H;
     const int e0 = blockIdx.x * (4 * GATE_EPW) + wave * GATE_EPW, e1 = min(E, e0 + GATE_EPW);
     float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), cs = w4;
@@ -711,9 +714,11 @@ __global__ __launch_bounds__(256) void k_gate_bwd(int E, int H, const int* __res
 // sum_e dphi_e SiLU(pre7[e][c]) (c2 is recomputed, not read); same workgroup shape and scratch layout as k_gate_bwd.
 __global__ __launch_bounds__(256) void k_head_bwd(int E, int H, const float* __restrict__ dphi, const float* __restrict__ w5,
                                                   const float* __restrict__ pre7, float* __restrict__ dpre7,
-                                                  float* __restrict__ scratch /* [workgroups][H + 4] */) {
+                                                  float* __restrict__ scratch /* [workgroups][H + 4] */,
+                                                  float4* __restrict__ zero, size_t zero_n4) {
     __shared__ float red[4][260];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero_n4; i += (size_t)gridDim.x * 256) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool on = 4 * lane < H;
     const int e0 = blockIdx.x * (4 * GATE_EPW) + wave * GATE_EPW, e1 = min(E, e0 + GATE_EPW);
     float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), cs = w4;
@@ -788,7 +793,7 @@ __global__ void k_coord_out(int E, int H, const int* __restrict__ row, const flo
 // dc2[e][c] = dphi * w5[c] is formed by the caller's k_outer_silu_bwd.
 __global__ void k_coord_out_bwd(int E, const int* __restrict__ row, const int* __restrict__ col,
                                 const float4* __restrict__ X, const float* __restrict__ phi, int use_tanh, float range,
-                                float norm_constant, const float* __restrict__ dacc, int n_moving,
+                                float norm_constant, const float* __restrict__ dacc, float dacc_div, int n_moving,
                                 float* __restrict__ dphi_out, float4* __restrict__ dcd_out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
@@ -798,7 +803,8 @@ __global__ void k_coord_out_bwd(int E, const int* __restrict__ row, const int* _
     const float r = dx * dx + dy * dy + dz * dz;
     const float den = sqrtf(r + 1e-8f) + norm_constant;
     const float cx = dx / den, cy = dy / den, cz = dz / den;
-    const float* da = dacc + (size_t)i * 4;
+    const float4 dv = *reinterpret_cast<const float4*>(dacc + (size_t)i * 4);
+    const float da[3] = {dv.x / dacc_div, dv.y / dacc_div, dv.z / dacc_div};      // dL/d acc = dL/dx_{l+1} / normalization_factor
     const float p = phi[e];
     const float th = use_tanh ? tanhf(p) : 0.f;
     const float g = use_tanh ? th * range : p;
@@ -1334,18 +1340,18 @@ void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* 
 size_t tr_partial_scratch_floats(size_t E, size_t H) { return ((E + 4 * GATE_EPW - 1) / (4 * GATE_EPW)) * (H + 4); }
 // the attention gate's adjoint with its two parameter gradients (d_wa [H], d_ba [1]; ignored without attention)
 void tr_gate_bwd(int E, int H, const int* row, const float* pre2, const float* wa, const float* z, int attention, const float* dagg,
-                 float* dpre2, float* scratch, float* d_wa, float* d_ba, hipStream_t s) {
-    if (!E) return;
+                 float* dpre2, float* scratch, float* d_wa, float* d_ba, float* zero, size_t zero_floats, hipStream_t s) {
+    if (!E) { if (zero_floats) hipMemsetAsync(zero, 0, zero_floats * sizeof(float), s); return; }
     const int nwg = (E + 4 * GATE_EPW - 1) / (4 * GATE_EPW);
-    hipLaunchKernelGGL(k_gate_bwd, dim3(nwg), dim3(256), 0, s, E, H, row, pre2, wa, z, attention, dagg, dpre2, scratch);
+    hipLaunchKernelGGL(k_gate_bwd, dim3(nwg), dim3(256), 0, s, E, H, row, pre2, wa, z, attention, dagg, dpre2, scratch, (float4*)zero, zero_floats / 4);
     if (attention) hipLaunchKernelGGL(k_partial_reduce, dim3((H + 1 + 63) / 64, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, d_wa, d_ba);
 }
 // dpre7 from dphi, and d coord_mlp.4.weight
 void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
-                 hipStream_t s) {
-    if (!E) return;
+                 float* zero, size_t zero_floats, hipStream_t s) {
+    if (!E) { if (zero_floats) hipMemsetAsync(zero, 0, zero_floats * sizeof(float), s); return; }
     const int nwg = (E + 4 * GATE_EPW - 1) / (4 * GATE_EPW);
-    hipLaunchKernelGGL(k_head_bwd, dim3(nwg), dim3(256), 0, s, E, H, dphi, w5, pre7, dpre7, scratch);
+    hipLaunchKernelGGL(k_head_bwd, dim3(nwg), dim3(256), 0, s, E, H, dphi, w5, pre7, dpre7, scratch, (float4*)zero, zero_floats / 4);
     hipLaunchKernelGGL(k_partial_reduce, dim3((H + 63) / 64, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, d_w5, (float*)nullptr);
 }
 void tr_coord_out(int E, int H, const int* row, const float* c2, const float* w5, const float4* cd, int use_tanh, float range,
@@ -1353,8 +1359,8 @@ void tr_coord_out(int E, int H, const int* row, const float* c2, const float* w5
     if (E) hipLaunchKernelGGL(k_coord_out, ROW_GRID(E), 0, s, E, H, row, c2, w5, cd, use_tanh, range, phi, accx);
 }
 void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, const float* phi, int use_tanh, float range,
-                      float nc, const float* dacc, int n_moving, float* dphi, float4* dcd, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_coord_out_bwd, EW_GRID(E), 0, s, E, row, col, X, phi, use_tanh, range, nc, dacc, n_moving, dphi, dcd);
+                      float nc, const float* dacc, float dacc_div, int n_moving, float* dphi, float4* dcd, hipStream_t s) {
+    if (E) hipLaunchKernelGGL(k_coord_out_bwd, EW_GRID(E), 0, s, E, row, col, X, phi, use_tanh, range, nc, dacc, dacc_div, n_moving, dphi, dcd);
 }
 void tr_geom_bwd(int E, const int* row, const int* col, const float4* X, float nc, const float4* dcd, const float* dr,
                  int n_moving, float* dX, hipStream_t s) {
