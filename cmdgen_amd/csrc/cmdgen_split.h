@@ -65,11 +65,13 @@ __device__ __forceinline__ SFragPtr sfrag_ptr(const void* Ws, int kb16_total, in
 // (fetched by the previous GEMM's last block or by split_prefetch) and leaves with block 0 of `next` there.
 struct SCarry { sbf16x8 b[2][2][3]; };
 
+template <int NPC = 3>
 __device__ __forceinline__ void split_load_set(const sbf16x8* q0, const sbf16x8* q1, sbf16x8 (&dst)[2][3]) {
 #pragma unroll
-    for (int s = 0; s < 3; ++s) { dst[0][s] = q0[s * 64]; dst[1][s] = q1[s * 64]; }
+    for (int s = 0; s < NPC; ++s) { dst[0][s] = q0[s * 64]; dst[1][s] = q1[s * 64]; }
 }
-__device__ __forceinline__ void split_prefetch(const SFragPtr& f, SCarry& c) { split_load_set(f.p, f.p + f.ns, c.b[0]); }
+template <int NPC = 3>
+__device__ __forceinline__ void split_prefetch(const SFragPtr& f, SCarry& c) { split_load_set<NPC>(f.p, f.p + f.ns, c.b[0]); }
 
 // eight consecutive k-values of one row (two float4) -> the three bf16 fragments of v_mfma_f32_32x32x16_bf16
 __device__ __forceinline__ void split8(const float4& lo, const float4& hi, sbf16x8& p0, sbf16x8& p1, sbf16x8& p2) {
@@ -174,7 +176,8 @@ __device__ __forceinline__ void split_store4(unsigned short* planes, int plane_e
     *reinterpret_cast<uint2*>(planes + 2 * plane_elems + off) = make_uint2(a2, b2);
 }
 
-template <int MT, int KB16>
+// NPC = 1: only the leading piece of both operands (plain bf16 operands, fp32 accumulation - the training step's opt-in mixed precision)
+template <int MT, int KB16, int NPC = 3>
 __device__ __forceinline__ void tile_gemm_planes(const unsigned short* planes, int plane_elems, int lda,
                                                  const SFragPtr cur, const SFragPtr next,
                                                  sf32x16 (&acc)[MT / 32][2], SCarry& carry) {
@@ -187,30 +190,32 @@ __device__ __forceinline__ void tile_gemm_planes(const unsigned short* planes, i
     sbf16x8 a[2][NMT][3];
 #define PL_LOADA(SET, PTR)                                                                                           \
     _Pragma("unroll") for (int m = 0; m < NMT; ++m)                                                                  \
-        _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                                \
+        _Pragma("unroll") for (int s = 0; s < NPC; ++s)                                                              \
             a[SET][m][s] = *reinterpret_cast<const sbf16x8*>((PTR) + s * plane_elems + m * 32 * lda);
 #define PL_MFMAS(AS, BS)                                                                                             \
     _Pragma("unroll") for (int m = 0; m < NMT; ++m)                                                                  \
         _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                              \
+            if constexpr (NPC == 3) {                                                                                \
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][2], carry.b[BS][n][0], acc[m][n], 0, 0, 0); \
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][1], carry.b[BS][n][1], acc[m][n], 0, 0, 0); \
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], carry.b[BS][n][2], acc[m][n], 0, 0, 0); \
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][1], carry.b[BS][n][0], acc[m][n], 0, 0, 0); \
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], carry.b[BS][n][1], acc[m][n], 0, 0, 0); \
+            }                                                                                                        \
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], carry.b[BS][n][0], acc[m][n], 0, 0, 0); \
         }
     PL_LOADA(0, ap)
 #pragma unroll 1
     for (int kb = 0; kb < KB16; kb += 2) {
         const bool more = kb + 2 < KB16;
-        split_load_set(q0, q1, carry.b[1]);
+        split_load_set<NPC>(q0, q1, carry.b[1]);
         PL_LOADA(1, ap + 16)
         __builtin_amdgcn_sched_barrier(0);
         PL_MFMAS(0, 0)
         __builtin_amdgcn_sched_barrier(0);
         q0 = more ? q0 + 192 : next.p;
         q1 = more ? q1 + 192 : next.p + next.ns;
-        split_load_set(q0, q1, carry.b[0]);
+        split_load_set<NPC>(q0, q1, carry.b[0]);
         q0 += 192; q1 += 192;
         if (more) { PL_LOADA(0, ap + 32) }
         __builtin_amdgcn_sched_barrier(0);

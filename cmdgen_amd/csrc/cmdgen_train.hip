@@ -25,7 +25,7 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s);
 struct RepackSplitT { int src_off, ld; void* dst; };                                                      // kernels_train.hip
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s);
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
-                        const float* pre, hipStream_t s);
+                        const float* pre, hipStream_t s, int pieces = 3);
 void tr_silu(const float* in, float* out, size_t n, hipStream_t s);
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
 void tr_scale(float* x, float a, size_t n, hipStream_t s);
@@ -349,8 +349,8 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     // k_readout) with save hooks that keep what the backward pass reads (TrainSave): ~20 launches instead of ~190, GEMMs on
     // the fragment-streaming tile kernels.  The parameters the optimizer has just updated are re-packed on the device.
     tr_repack(theta, t->frag_tab, t->n_frag, t->max_frag4, t->misc_tab, t->n_misc, t->max_misc, s);
-    if (h->gemm_split && !t->bf16) tr_repack_split_t(theta, t->split_tab, t->n_split, s);       // data gradients on the split engine
-    t->split_packs_valid = h->gemm_split && !t->bf16 && t->n_split > 0;
+    if (h->gemm_split || t->bf16) tr_repack_split_t(theta, t->split_tab, t->n_split, s);        // data gradients on the bf16 matrix pipe
+    t->split_packs_valid = (h->gemm_split || t->bf16) && t->n_split > 0;
     t->layers.assign(L, LayerW{});
     for (int l = 0; l < L; ++l) {
         const ParamTable::Blk& b = tb.blk[l];
@@ -436,7 +436,8 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         wb.M[q] = r.out; wb.N[q] = in; wb.lddy[q] = r.out; wb.ldx[q] = in; wb.ldw[q] = r.in;
     };
     auto flush_wgrads = [&]() { cmdgen_wgrad_group(wb, N, g_bf16, s); wb.n = 0; };
-    const bool sp = t->split_packs_valid && !g_bf16 && H == 256;      // [.,256] x [256,256] data gradients on the split engine
+    const bool sp = t->split_packs_valid && H == 256;                 // [.,256] x [256,256] data gradients on the bf16 matrix pipe:
+    const int pcs = g_bf16 ? 1 : 3;                                   // three pieces per operand (fp32-accurate) or the leading one (bf16 operands)
     if (first_stage == 0) {
     // readout
     HIPCHK(h, hipMemsetAsync(t->dX, 0, (size_t)N * 4 * sizeof(float), s));
@@ -497,13 +498,13 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             cmdgen_wgrad_group(one, Ec, g_bf16, s);
         }
         const TrainState::PackBlk& pk = t->pack[l];
-        if (sp) cmdgen_dgrad_split(Ec, t->actB, pk.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s);
+        if (sp) cmdgen_dgrad_split(Ec, t->actB, pk.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s, pcs);
         else linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
         if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
         // adjoints of the gathers, the radial / d0 column gradients, d radial and the geometry adjoint: one pass over dpre6
         tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
                          t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, s);
-        if (sp) cmdgen_dgrad_split(N, t->dP, pk.t_c0a, t->dQ, pk.t_c0b, t->dh, true, 1.0f, nullptr, s);
+        if (sp) cmdgen_dgrad_split(N, t->dP, pk.t_c0a, t->dQ, pk.t_c0b, t->dh, true, 1.0f, nullptr, s, pcs);
         else {
             linear_dgrad(theta, b.c0, 0, H, N, t->dP, H, t->dh, H, true, s);
             linear_dgrad(theta, b.c0, H, H, N, t->dQ, H, t->dh, H, true, s);
@@ -516,9 +517,9 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         defer_wgrad(b.n2, 0, H, t->dh, nact, true);
         flush_wgrads();
         if (sp) {
-            cmdgen_dgrad_split(N, t->dh, pk.t_n2, nullptr, nullptr, t->dn, false, 1.0f, pre3, s);
-            cmdgen_dgrad_split(N, t->dn, pk.t_n0a, nullptr, nullptr, t->dh, true, 1.0f, nullptr, s);
-            cmdgen_dgrad_split(N, t->dn, pk.t_n0b, nullptr, nullptr, t->dagg, false, d.norm_factor, nullptr, s);
+            cmdgen_dgrad_split(N, t->dh, pk.t_n2, nullptr, nullptr, t->dn, false, 1.0f, pre3, s, pcs);
+            cmdgen_dgrad_split(N, t->dn, pk.t_n0a, nullptr, nullptr, t->dh, true, 1.0f, nullptr, s, pcs);
+            cmdgen_dgrad_split(N, t->dn, pk.t_n0b, nullptr, nullptr, t->dagg, false, d.norm_factor, nullptr, s, pcs);
         } else {
             linear_dgrad(theta, b.n2, 0, H, N, t->dh, H, t->dn, H, false, s, pre3);       // dn <- dn1 * SiLU'(pre3) = dpre3
             linear_dgrad(theta, b.n0, 0, H, N, t->dn, H, t->dh, H, true, s);              // dh is now dL/dh_l (residual kept)
@@ -543,7 +544,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.e2.in;
             cmdgen_wgrad_group(one, E, g_bf16, s);
         }
-        if (sp) cmdgen_dgrad_split(E, t->actA, pk.t_e2, nullptr, nullptr, t->actB, false, 1.0f, pre1, s);
+        if (sp) cmdgen_dgrad_split(E, t->actA, pk.t_e2, nullptr, nullptr, t->actB, false, 1.0f, pre1, s, pcs);
         else linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
         if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
         tr_edge_tail_bwd(E, H, w.erow, w.ecol, t->actB, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
@@ -554,7 +555,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         defer_wgrad(b.e0, 0, H, t->dP, hl, true);
         defer_wgrad(b.e0, H, H, t->dQ, hl, false);
         flush_wgrads();
-        if (sp) cmdgen_dgrad_split(N, t->dP, pk.t_e0a, t->dQ, pk.t_e0b, t->dh, true, 1.0f, nullptr, s);
+        if (sp) cmdgen_dgrad_split(N, t->dP, pk.t_e0a, t->dQ, pk.t_e0b, t->dh, true, 1.0f, nullptr, s, pcs);
         else {
             linear_dgrad(theta, b.e0, 0, H, N, t->dP, H, t->dh, H, true, s);
             linear_dgrad(theta, b.e0, H, H, N, t->dQ, H, t->dh, H, true, s);

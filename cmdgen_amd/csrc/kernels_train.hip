@@ -239,8 +239,13 @@ struct WgradBatch {
 template <bool BF>
 __global__ __launch_bounds__(256) void k_wgrad_group(WgradBatch g, int K, int kchunk, int zsplit) {
     constexpr int KT = 64;
-    __shared__ __attribute__((aligned(16))) float smem[2 * 64 * TG_LD(KT)];
-    float* As = smem; float* Bs = smem + 64 * TG_LD(KT);
+    // fp32 path: both operands lie in memory k-major ([k][channel]) and stay that way in LDS ([k][WG_LDK]): v_mfma_f32_32x32x2
+    // takes ONE value per lane (row = lane % 32, k = lane / 32), so a wave reads 32 consecutive channels of two k rows per
+    // MFMA straight from the staged rows - no transposition on the way in (the [channel][k] image needed scalar, bank-
+    // conflicting LDS stores: 32 per thread and k step).  WG_LDK = 96: the two k rows of a read fall on disjoint banks.
+    constexpr int WG_LDK = 96;
+    __shared__ __attribute__((aligned(16))) float smem[2 * KT * WG_LDK];
+    float* As = smem; float* Bs = smem + KT * WG_LDK;
     unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);
     unsigned short* Bh = Ah + 64 * TGH_LD(KT);
     const int p = blockIdx.z / zsplit, kz = blockIdx.z - p * zsplit;
@@ -267,7 +272,13 @@ __global__ __launch_bounds__(256) void k_wgrad_group(WgradBatch g, int K, int kc
             for (int q = 0; q < TG_P(KT); ++q) { colsum.x += ra[q].x; colsum.y += ra[q].y; colsum.z += ra[q].z; colsum.w += ra[q].w; }
         }
         if (BF) { tg_put_bf16<KT, true>(Ah, ra); tg_put_bf16<KT, true>(Bh, rb); }
-        else { tg_put_f32<KT, true>(As, ra); tg_put_f32<KT, true>(Bs, rb); }
+        else {
+#pragma unroll
+            for (int q = 0; q < TG_P(KT); ++q) {        // thread -> (k = tid / 16 + 16 q, channels (tid % 16) * 4 .. + 3), as fetched
+                *reinterpret_cast<float4*>(As + ((tid >> 4) + 16 * q) * WG_LDK + (tid & 15) * 4) = ra[q];
+                *reinterpret_cast<float4*>(Bs + ((tid >> 4) + 16 * q) * WG_LDK + (tid & 15) * 4) = rb[q];
+            }
+        }
         __syncthreads();
         if (k0 + KT < k_end) {
             tg_fetch<KT, true, true>(ra, A, lda, m0, M, k0 + KT, k_end);
@@ -281,15 +292,10 @@ __global__ __launch_bounds__(256) void k_wgrad_group(WgradBatch g, int K, int kc
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
             }
         } else {
+            const float* ap = As + (lane >> 5) * WG_LDK + wm + (lane & 31);
+            const float* bp = Bs + (lane >> 5) * WG_LDK + wn + (lane & 31);
 #pragma unroll
-            for (int kb = 0; kb < KT / 8; ++kb) {
-                const float4 a = *reinterpret_cast<const float4*>(As + (wm + (lane & 31)) * TG_LD(KT) + kb * 8 + 4 * (lane >> 5));
-                const float4 b = *reinterpret_cast<const float4*>(Bs + (wn + (lane & 31)) * TG_LD(KT) + kb * 8 + 4 * (lane >> 5));
-                CMDGEN_MFMA32(acc, a.x, b.x);
-                CMDGEN_MFMA32(acc, a.y, b.y);
-                CMDGEN_MFMA32(acc, a.z, b.z);
-                CMDGEN_MFMA32(acc, a.w, b.w);
-            }
+            for (int k2 = 0; k2 < KT / 2; ++k2) CMDGEN_MFMA32(acc, ap[k2 * 2 * WG_LDK], bp[k2 * 2 * WG_LDK]);
         }
         __syncthreads();
     }
@@ -322,7 +328,8 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s) {
     if (g.n <= 0 || K <= 0) return;
     int tm = 1, tn = 1;
     for (int p = 0; p < g.n; ++p) { tm = max(tm, (g.M[p] + 63) / 64); tn = max(tn, (g.N[p] + 63) / 64); }
-    int zsplit = (1024 + tm * tn * g.n - 1) / (tm * tn * g.n);
+    static const int target_wgs = getenv("CMDGEN_WGRAD_WGS") ? atoi(getenv("CMDGEN_WGRAD_WGS")) : 768;      // 3 workgroups (49 KB of LDS each) per CU; sweep: profiles/r02_t3_training_round2.txt
+    int zsplit = (target_wgs + tm * tn * g.n - 1) / (tm * tn * g.n);
     const int max_split = (K + 127) / 128;
     if (zsplit > max_split) zsplit = max_split;
     if (zsplit < 1) zsplit = 1;
@@ -420,7 +427,7 @@ void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda
 // One workgroup per MT rows: the A tile is staged once in LDS as fp32, every wave splits the fragments it reads in
 // registers in the shadow of the MFMAs (tile_gemm_rsplit), the weight fragments stream from L2.
 // ------------------------------------------------------------------------------------
-template <int MT>
+template <int MT, int NPC>
 __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __restrict__ A0, const void* __restrict__ W0,
                                                         const float* __restrict__ A1, const void* __restrict__ W1,
                                                         float* __restrict__ Y, int accumulate, float div,
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __re
     SCarry carry;
     const int nstage = A1 ? 4 : 2;                        // (source, half)
     auto frag_of = [&](int st) { return sfrag_ptr((st >> 1) ? W1 : W0, HH / 16, (st & 1) * (HH / 32), wave); };
-    split_prefetch(frag_of(0), carry);
+    split_prefetch<NPC>(frag_of(0), carry);
     float4 v[NP];
     auto fetch = [&](int st) {
         const float* A = (st >> 1) ? A1 : A0;
@@ -459,10 +466,13 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __re
 #pragma unroll 1
     for (int st = 0; st < nstage; ++st) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) split_store4(planes, PE, (p * 8 + rsub) * PLDA + 4 * c4, v[p]);
+        for (int p = 0; p < NP; ++p) {
+            if constexpr (NPC == 3) split_store4(planes, PE, (p * 8 + rsub) * PLDA + 4 * c4, v[p]);
+            else *reinterpret_cast<uint2*>(planes + (p * 8 + rsub) * PLDA + 4 * c4) = make_uint2(cvt_pk_bf16(v[p].x, v[p].y), cvt_pk_bf16(v[p].z, v[p].w));
+        }
         __syncthreads();
         if (st + 1 < nstage) fetch(st + 1);
-        tile_gemm_planes<MT, HH / 32>(planes, PE, PLDA, frag_of(st), frag_of(st + 1 < nstage ? st + 1 : st), acc, carry);
+        tile_gemm_planes<MT, HH / 32, NPC>(planes, PE, PLDA, frag_of(st), frag_of(st + 1 < nstage ? st + 1 : st), acc, carry);
         __syncthreads();
     }
     // Epilogue through LDS, 32 rows at a time (the fp32 image of 32 rows, 33 KB, aliases the planes): whole 1 KB rows leave
@@ -521,12 +531,18 @@ __global__ void k_repack_split_t(const float* __restrict__ theta, const RepackSp
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_repack_split_t, dim3(8 * 16 * 64 / 256, n), dim3(256), 0, s, theta, (const RepackSplitT*)tab);
 }
+// pieces = 3: fp32-accurate (split engine); 1: the operands' leading bf16 piece only (= operands rounded to nearest-even
+// bf16, fp32 accumulation: cmdgen_train_set_precision(1))
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
-                        const float* pre, hipStream_t s) {
+                        const float* pre, hipStream_t s, int pieces = 3) {
     if (M <= 0) return;
     static const char* mt = getenv("CMDGEN_DGRAD_MT");
-    if (mt ? atoi(mt) == 64 : M >= 24576) hipLaunchKernelGGL((k_dgrad_split<64>), dim3((M + 63) / 64), dim3(256), 0, s, M, A0, W0, A1, W1, Y, accumulate ? 1 : 0, div, pre);
-    else hipLaunchKernelGGL((k_dgrad_split<32>), dim3((M + 31) / 32), dim3(256), 0, s, M, A0, W0, A1, W1, Y, accumulate ? 1 : 0, div, pre);
+    const bool big = mt ? atoi(mt) == 64 : M >= 24576;
+    const int acc = accumulate ? 1 : 0;
+#define DG(MT_, NP_) hipLaunchKernelGGL((k_dgrad_split<MT_, NP_>), dim3((M + MT_ - 1) / MT_), dim3(256), 0, s, M, A0, W0, A1, W1, Y, acc, div, pre)
+    if (pieces == 3) { if (big) DG(64, 3); else DG(32, 3); }
+    else { if (big) DG(64, 1); else DG(32, 1); }
+#undef DG
 }
 
 // ------------------------------------------------------------------------------------
