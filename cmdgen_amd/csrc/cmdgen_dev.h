@@ -193,7 +193,8 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     const TrainSave* save = nullptr;   // training forward: keep the activations (see TrainSave)
     PocketCache pcache{};       // conditional chains: pocket tiles of k_embed are an axpy from the cache
     int skip_count = 0;         // 1: the radius-graph count pass has run (fused step kernel); 2: both passes have (training)
-    int split = 0;              // 1: tiles of >= 32 rows multiply on the bf16 matrix pipe (Eng<MT, true>); never with `save`
+    int split = 0;              // 1: tiles of >= 32 rows multiply on the bf16 matrix pipe (Eng<MT, true>)
+    int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     hipStream_t side = nullptr; // when set: k_edge_write runs there, concurrently with k_embed (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };

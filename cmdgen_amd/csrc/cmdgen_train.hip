@@ -22,7 +22,7 @@ struct WgradBatch {               // kernels_train.hip: up to 8 weight gradients
     int n;
 };
 void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s);
-struct RepackSplitT { int src_off, ld; void* dst; };                                                      // kernels_train.hip
+struct RepackSplitT { int src_off, ld; void* dst; int transpose; };                                       // kernels_train.hip
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s);
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
                         const float* pre, hipStream_t s, int pieces = 3);
@@ -144,7 +144,8 @@ struct TrainState {
     std::vector<LayerW> layers;         // device pointers: packed fragments + vectors inside theta (rebuilt per call: theta is the caller's)
     struct PackBlk { float *pq_e32, *pq_e16, *w2_32, *w2_16, *w3_32, *w3_16, *w4_32, *w4_16, *pq_c32, *pq_c16, *w7_32, *w7_16, *rd_e, *rd_c;
                      // split-bf16 fragment packs of the TRANSPOSED 256 x 256 blocks (data gradients, cmdgen_dgrad_split); H = 256 only
-                     void *t_e0a, *t_e0b, *t_e2, *t_n0a, *t_n0b, *t_n2, *t_c0a, *t_c0b, *t_c2; };
+                     void *t_e0a, *t_e0b, *t_e2, *t_n0a, *t_n0b, *t_n2, *t_c0a, *t_c0b, *t_c2;
+                     void *s_e2, *s_c2; };       // split packs of edge_mlp.2 / coord_mlp.2 themselves: the forward's two edge kernels
     std::vector<PackBlk> pack;          // rd_e / rd_c: [2][H] radial column then d0 column of edge_mlp.0 / coord_mlp.0
     float *emb_wT = nullptr, *embo_wT = nullptr;
     void *frag_tab = nullptr, *misc_tab = nullptr, *split_tab = nullptr;
@@ -218,13 +219,14 @@ static int ensure_state(cmdgen_handle* h) {
             for (size_t l = 0; l < L && !rc; ++l) {
                 TrainState::PackBlk& k = t->pack[l];
                 const ParamTable::Blk& b = tb.blk[l];
-                auto tp = [&](const PRef& r, int col0, void** dst) {
+                auto tp = [&](const PRef& r, int col0, void** dst, int transpose = 1) {
                     if (rc) return;
                     float* q = nullptr;
                     rc = alloc((size_t)H * H * 6 / 4, &q); if (rc) return;          // three bf16 pieces per weight
                     *dst = q;
-                    st.push_back(RepackSplitT{(int)r.w + col0, r.in, q});
+                    st.push_back(RepackSplitT{(int)r.w + col0, r.in, q, transpose});
                 };
+                tp(b.e2, 0, &k.s_e2, 0); tp(b.c2, 0, &k.s_c2, 0);
                 tp(b.e0, 0, &k.t_e0a); tp(b.e0, (int)H, &k.t_e0b); tp(b.e2, 0, &k.t_e2);
                 tp(b.n0, 0, &k.t_n0a); tp(b.n0, (int)H, &k.t_n0b); tp(b.n2, 0, &k.t_n2);
                 tp(b.c0, 0, &k.t_c0a); tp(b.c0, (int)H, &k.t_c0b); tp(b.c2, 0, &k.t_c2);
@@ -349,20 +351,20 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     // k_readout) with save hooks that keep what the backward pass reads (TrainSave): ~20 launches instead of ~190, GEMMs on
     // the fragment-streaming tile kernels.  The parameters the optimizer has just updated are re-packed on the device.
     tr_repack(theta, t->frag_tab, t->n_frag, t->max_frag4, t->misc_tab, t->n_misc, t->max_misc, s);
-    if (h->gemm_split || t->bf16) tr_repack_split_t(theta, t->split_tab, t->n_split, s);        // data gradients on the bf16 matrix pipe
-    t->split_packs_valid = (h->gemm_split || t->bf16) && t->n_split > 0;
+    if (h->gemm_split || t->bf16) tr_repack_split_t(theta, t->split_tab, t->n_split, s);        // data gradients (and the forward's two
+    t->split_packs_valid = (h->gemm_split || t->bf16) && t->n_split > 0;                         // edge kernels) on the bf16 matrix pipe
     t->layers.assign(L, LayerW{});
     for (int l = 0; l < L; ++l) {
         const ParamTable::Blk& b = tb.blk[l];
         const TrainState::PackBlk& k = t->pack[l];
         LayerW& lw = t->layers[l];
         lw.Wpq_e = WPack{(const float4*)k.pq_e32, (const float4*)k.pq_e16}; lw.b1 = theta + b.e0.b; lw.wr_e = k.rd_e; lw.wd_e = k.rd_e + H;
-        lw.W2 = WPack{(const float4*)k.w2_32, (const float4*)k.w2_16}; lw.b2 = theta + b.e2.b;
+        lw.W2 = WPack{(const float4*)k.w2_32, (const float4*)k.w2_16, H == 256 ? k.s_e2 : nullptr}; lw.b2 = theta + b.e2.b;
         lw.wa = d.attention ? theta + b.att.w : theta + b.e2.b; lw.ba = d.attention ? theta + b.att.b : theta + b.e2.b;
         lw.W3 = WPack{(const float4*)k.w3_32, (const float4*)k.w3_16}; lw.b3 = theta + b.n0.b;
         lw.W4 = WPack{(const float4*)k.w4_32, (const float4*)k.w4_16}; lw.b4 = theta + b.n2.b;
         lw.Wpq_c = WPack{(const float4*)k.pq_c32, (const float4*)k.pq_c16}; lw.b6 = theta + b.c0.b; lw.wr_c = k.rd_c; lw.wd_c = k.rd_c + H;
-        lw.W7 = WPack{(const float4*)k.w7_32, (const float4*)k.w7_16}; lw.b7 = theta + b.c2.b; lw.w5 = theta + b.c4.w;
+        lw.W7 = WPack{(const float4*)k.w7_32, (const float4*)k.w7_16, H == 256 ? k.s_c2 : nullptr}; lw.b7 = theta + b.c2.b; lw.w5 = theta + b.c4.w;
     }
     SmallW sw{};
     sw.pe0_w = theta + tb.pe0.w; sw.pe0_b = theta + tb.pe0.b; sw.pe2_w = theta + tb.pe2.w; sw.pe2_b = theta + tb.pe2.b;
@@ -379,6 +381,7 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     sv.qdec1 = t->qdec1; sv.qdeca = t->qdeca; sv.qdec_out = t->qdec_out;
     sv.ecap = t->ecap; sv.eccap = t->eccap;
     a.layers = t->layers.data(); a.sw = sw; a.save = &sv; a.skip_count = 2;
+    a.save_split = (h->gemm_split && t->split_packs_valid && H == 256) ? 1 : 0;
     if (h->agg_dirty) { HIPCHK(h, hipMemsetAsync(h->work.agg, 0, NH * sizeof(float), s)); h->agg_dirty = false; }
     cmdgen_launch_eval(a, xh_phar, xh_pocket, t_arr, nullptr, nullptr, eps_phar, eps_pocket, s, nullptr);
     if (!d.joint) cmdgen_launch_nan_fix(a, eps_phar, s);                    // dynamics.py:129-131 (joint: inside k_vel_com)

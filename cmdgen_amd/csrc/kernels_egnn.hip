@@ -518,7 +518,9 @@ template <int MT>
 __device__ __forceinline__ void build_edge_half(unsigned short* planes, int half, const int* s_row, const int* s_col,
                                                 const float* s_r, const float* s_d0, int ne,
                                                 const float* __restrict__ P, const float* __restrict__ Q,
-                                                const float* s_wr, const float* s_wd) {
+                                                const float* s_wr, const float* s_wd,
+                                                float* __restrict__ pre_out = nullptr, float* __restrict__ act_out = nullptr) {
+    // pre_out / act_out (training forward): the tile's first row of the stored pre-activations / activations
     constexpr int H = 256, PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
     const int c4 = threadIdx.x & 31, rsub = threadIdx.x >> 5;          // 32 lanes x 16 bytes = one half row, 8 rows per pass
     const int col = half * (H / 2) + 4 * c4;
@@ -539,8 +541,13 @@ __device__ __forceinline__ void build_edge_half(unsigned short* planes, int half
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < ne) {
             const float r = s_r[e], d0 = s_d0[e];
-            a.x = silu_f(p[pass].x + q[pass].x + wr4.x * r + wd4.x * d0); a.y = silu_f(p[pass].y + q[pass].y + wr4.y * r + wd4.y * d0);
-            a.z = silu_f(p[pass].z + q[pass].z + wr4.z * r + wd4.z * d0); a.w = silu_f(p[pass].w + q[pass].w + wr4.w * r + wd4.w * d0);
+            const float4 pre = make_float4(p[pass].x + q[pass].x + wr4.x * r + wd4.x * d0, p[pass].y + q[pass].y + wr4.y * r + wd4.y * d0,
+                                           p[pass].z + q[pass].z + wr4.z * r + wd4.z * d0, p[pass].w + q[pass].w + wr4.w * r + wd4.w * d0);
+            a = make_float4(silu_f(pre.x), silu_f(pre.y), silu_f(pre.z), silu_f(pre.w));
+            if (pre_out) {
+                *reinterpret_cast<float4*>(pre_out + (size_t)e * H + col) = pre;
+                *reinterpret_cast<float4*>(act_out + (size_t)e * H + col) = a;
+            }
         }
         split_store4(planes, PE, e * PLDA + 4 * c4, a);
     }
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
     __shared__ __attribute__((aligned(16))) float s_wa[H];     // att_mlp weight: read by every tile's row dot (LDS broadcast, not 16 L1 round trips)
     const int tid = threadIdx.x, wave = tid >> 6;
     s_wa[tid] = lw.wa[tid];                                    // visible after the first tile's barriers
-    constexpr bool PL = SP && H == 256 && !SAVE;               // plane variant: the producer splits (build_edge_half)
+    constexpr bool PL = SP && H == 256;                        // plane variant: the producer splits (build_edge_half)
     __shared__ __attribute__((aligned(16))) float s_wrd[PL ? 2 * H : 4];
     if constexpr (PL) { s_wrd[tid] = lw.wr_e[tid]; s_wrd[H + tid] = lw.wd_e[tid]; }
     const ColVec<MT> b2v = col_load<MT>(lw.b2, wave);          // per-column bias and the gate's bias: once per workgroup
@@ -671,11 +678,13 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
             constexpr int PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
             const typename G::Frag fw1 = G::frag(lw.W2, H / 8, H / 16, wave);
-            if (!(ablate & 2)) build_edge_half<MT>(planes, 0, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, s_wrd, s_wrd + H);
+            float* pre1_o = SAVE ? sv.pre1 + ((size_t)layer * sv.ecap + e0) * H : nullptr;
+            float* act1_o = SAVE ? sv.act1 + ((size_t)layer * sv.ecap + e0) * H : nullptr;
+            if (!(ablate & 2)) build_edge_half<MT>(planes, 0, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, s_wrd, s_wrd + H, pre1_o, act1_o);
             lds_barrier();
             if (!(ablate & 4)) tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw, fw1, acc.a, carry);
             lds_barrier();
-            if (!(ablate & 2)) build_edge_half<MT>(planes, 1, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, s_wrd, s_wrd + H);
+            if (!(ablate & 2)) build_edge_half<MT>(planes, 1, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, s_wrd, s_wrd + H, pre1_o, act1_o);
             lds_barrier();
             STAMP(1);
             if (!(ablate & 4)) tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw1, fw, acc.a, carry);
@@ -932,7 +941,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
     __shared__ __attribute__((aligned(16))) float s_w5[H];     // coord_mlp.4 weight, staged once per workgroup (see k_edge_msg)
     const int tid = threadIdx.x, wave = tid >> 6;
     s_w5[tid] = lw.w5[tid];
-    constexpr bool PL = SP && H == 256 && !SAVE;               // plane variant, see k_edge_msg
+    constexpr bool PL = SP && H == 256;                        // plane variant, see k_edge_msg
     __shared__ __attribute__((aligned(16))) float s_wrd[PL ? 2 * H : 4];
     if constexpr (PL) { s_wrd[tid] = lw.wr_c[tid]; s_wrd[H + tid] = lw.wd_c[tid]; }
     const ColVec<MT> b7v = col_load<MT>(lw.b7, wave);
@@ -975,11 +984,13 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
             constexpr int PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
             const typename G::Frag fw1 = G::frag(lw.W7, H / 8, H / 16, wave);
-            build_edge_half<MT>(planes, 0, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, s_wrd, s_wrd + H);
+            float* pre6_o = SAVE ? sv.pre6 + ((size_t)layer * sv.eccap + e0) * H : nullptr;
+            float* act6_o = SAVE ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr;
+            build_edge_half<MT>(planes, 0, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, s_wrd, s_wrd + H, pre6_o, act6_o);
             lds_barrier();
             tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw, fw1, acc.a, carry);
             lds_barrier();
-            build_edge_half<MT>(planes, 1, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, s_wrd, s_wrd + H);
+            build_edge_half<MT>(planes, 1, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, s_wrd, s_wrd + H, pre6_o, act6_o);
             lds_barrier();
             tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw1, fw, acc.a, carry);
         } else {
@@ -1159,8 +1170,10 @@ template <int H, int MT, bool SP> static void launch_embed(const EvalLaunch& a, 
     const int nt = (a.lay.N + MT - 1) / MT;
     const Dims& d = a.d;
     const size_t shm = sizeof(float) * (size_t)(2 * d.P * d.P + 2 * d.P + d.J * 2 * d.P + d.J + 2 * d.R * d.R + 2 * d.R + d.J * 2 * d.R + d.J);
-    hipLaunchKernelGGL((k_embed<H, MT, SP>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
-                       (const ChainState*)chain, a.save ? *a.save : TrainSave{}, (chain && !t) ? a.pcache : PocketCache{});
+    if (a.save) hipLaunchKernelGGL((k_embed<H, MT, false>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
+                                   (const ChainState*)chain, *a.save, PocketCache{});          // training packs: fp32 fragments only
+    else hipLaunchKernelGGL((k_embed<H, MT, SP>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
+                            (const ChainState*)chain, TrainSave{}, (chain && !t) ? a.pcache : PocketCache{});
 }
 template <int H, int MT, bool SP> static void launch_write_embed(const EvalLaunch& a, const float* xp, const float* xq, const float* t,
                                                                  const float4* coef, ChainState* chain, hipStream_t s) {
@@ -1187,20 +1200,22 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
                             a.layers[has_next ? l + 1 : l], l, has_next, TrainSave{});
 }
 template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, false>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save);
+    // training forward: the split engine only where the step re-packs split weights (H = 256: edge_mlp.2 / coord_mlp.2)
+    if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
                                                a.layers[l], l, a.ablate, TrainSave{});
     else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{});
 }
 template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, false>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save);
+    if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, SP && H == 256>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
                                                a.layers[l], l, TrainSave{});
     else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
 }
-// tiles of >= 32 rows run on the split-bf16 engine when the launch asks for it (never the training forward: its packs
-// hold no split weights); 16-row tiles are always fp32 MFMA (there the L2 weight stream, not the matrix rate, binds)
-#define MT_DISPATCH(mt, FN, ...) do { const bool sp_ = a.split && !a.save;                                                   \
+// tiles of >= 32 rows run on the split-bf16 engine when the launch asks for it (the training forward: only its two edge
+// kernels, and only when the step re-packed split weights for them - save_split); 16-row tiles are always fp32 MFMA
+// (there the L2 weight stream, not the matrix rate, binds)
+#define MT_DISPATCH(mt, FN, ...) do { const bool sp_ = a.split && (!a.save || a.save_split);                                                 \
         if ((mt) == 64) { if (sp_) FN<H, 64, true>(__VA_ARGS__); else FN<H, 64, false>(__VA_ARGS__); }                       \
         else if ((mt) == 32) { if (sp_) FN<H, 32, true>(__VA_ARGS__); else FN<H, 32, false>(__VA_ARGS__); }                 \
         else FN<H, 16, false>(__VA_ARGS__); } while (0)

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __re
 }
 
 // split fragment packs of transposed weight sub-blocks: dst = pack of Wt, Wt[o'][k] = theta[src_off + k * ld + o'] (o', k < 256)
-struct RepackSplitT { int src_off, ld; void* dst; };
+struct RepackSplitT { int src_off, ld; void* dst; int transpose; };      // transpose = 0: the pack of W itself (forward: Y = X W^T)
 __global__ void k_repack_split_t(const float* __restrict__ theta, const RepackSplitT* __restrict__ tab) {
     const RepackSplitT f = tab[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;         // (nt * 16 + kb) * 64 + lane, nt < 8, kb < 16
@@ -522,7 +522,7 @@ __global__ void k_repack_split_t(const float* __restrict__ theta, const RepackSp
     const int o = 32 * nt + (lane & 31), k = 16 * kb + 8 * (lane >> 5);
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = theta[f.src_off + (size_t)(k + j) * f.ld + o];
+    for (int j = 0; j < 8; ++j) v[j] = f.transpose ? theta[f.src_off + (size_t)(k + j) * f.ld + o] : theta[f.src_off + (size_t)o * f.ld + k + j];
     sbf16x8 p0, p1, p2;
     split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p0, p1, p2);
     sbf16x8* d = reinterpret_cast<sbf16x8*>(f.dst) + (size_t)((nt * 16 + kb) * 3) * 64 + lane;
