@@ -100,6 +100,9 @@ extern "C" void cmdgen_destroy(cmdgen_handle* h) {
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     free_pool(h->weight_allocs); free_pool(h->layout_allocs); free_pool(h->chain_allocs); free_pool(h->joint_allocs);
+    for (int i = 0; i < 2; ++i) { if (h->idx_stage[i]) hipHostFree(h->idx_stage[i]); if (h->idx_ev[i]) hipEventDestroy(h->idx_ev[i]); }
+    if (h->h_norm) hipHostFree(h->h_norm);
+    if (h->norm_ev) hipEventDestroy(h->norm_ev);
     cmdgen_train_free(h->train);
     delete h;
 }
@@ -302,7 +305,14 @@ static inline size_t edge_lds_bytes(int max_n) { return (size_t)max_n * (sizeof(
 static const size_t kEdgeLdsMax = 156 * 1024;      // 160 KiB per CU minus k_edge_write's small static arrays
 void cmdgen_edge_kernels_allow_lds(size_t bytes);  // kernels_egnn.hip: hipFuncSetAttribute above the 64 KiB default
 
+static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, const int64_t* npk, bool on_stream, hipStream_t stream);
 extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t* nph, const int64_t* npk) {
+    return set_layout_impl(h, batch, nph, npk, false, nullptr);
+}
+extern "C" int cmdgen_set_layout_on_stream(cmdgen_handle* h, int64_t batch, const int64_t* nph, const int64_t* npk, cmdgen_stream stream) {
+    return set_layout_impl(h, batch, nph, npk, true, (hipStream_t)stream);
+}
+static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, const int64_t* npk, bool on_stream, hipStream_t stream) {
     if (!h || batch < 1 || !nph || !npk) return fail(h, CMDGEN_EINVAL, "bad layout arguments");
     if (h->have_layout && (int64_t)h->cur_nphar.size() == batch &&
         memcmp(h->cur_nphar.data(), nph, batch * sizeof(int64_t)) == 0 &&
@@ -335,8 +345,17 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
     // layout may still be reading the index arrays rewritten below: wait for the streams this handle has been
     // given (ordering contract in include/cmdgen_hip.h; torch's side streams are non-blocking, so the null-stream
     // copies below are not ordered against them by themselves).
-    if (h->own_stream) hipStreamSynchronize(h->own_stream);
-    if (h->have_layout) hipStreamSynchronize(h->last_stream);
+    // (cmdgen_set_layout_on_stream: when the new layout fits the workspaces nothing is waited for - the index arrays go to
+    // the OTHER of two device blocks, copied from pinned staging in stream order, so kernels of the previous layout that
+    // are still running on `stream` keep reading theirs)
+    const bool fits_now = h->cap_B >= B && h->cap_Nl >= Nl && h->cap_Np >= Np && h->cap_N >= N && h->cap_e >= ecap && h->cap_ec >= eccap;
+    const bool no_wait = on_stream && fits_now && h->have_layout && h->chain_allocs.empty() && h->joint_allocs.empty() &&
+                         (h->last_stream == stream) && !h->step_graph && !h->joint_graph;
+    if (!no_wait) {
+        if (h->own_stream) hipStreamSynchronize(h->own_stream);
+        if (h->have_layout) hipStreamSynchronize(h->last_stream);
+        if (on_stream) hipStreamSynchronize(stream);
+    }
     if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
     if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
     int rc; void* p;
@@ -358,11 +377,14 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
         // the index arrays live in ONE block, [gid (int64) | num_phar | num_pocket | phar_base | pocket_base | node_sample]: a new
         // layout (every training step has its own) is one host-to-device copy instead of six
         {
-            int* blk = nullptr;
-            ALLOC(blk, int, 6 * cB + cN, true);
-            h->d_gid = reinterpret_cast<int64_t*>(blk); L.pocket_gid = h->d_gid;
-            L.num_phar = blk + 2 * cB; L.num_pocket = blk + 3 * cB; L.phar_base = blk + 4 * cB; L.pocket_base = blk + 5 * cB;
-            L.node_sample = blk + 6 * cB;
+            h->idx_ints = 6 * cB + cN;
+            for (int i = 0; i < 2; ++i) {
+                ALLOC(h->idx_blk[i], int, h->idx_ints, true);
+                if (h->idx_stage[i]) hipHostFree(h->idx_stage[i]);
+                HIPCHK(h, hipHostMalloc((void**)&h->idx_stage[i], (size_t)h->idx_ints * sizeof(int), hipHostMallocDefault));
+                if (!h->idx_ev[i]) HIPCHK(h, hipEventCreateWithFlags(&h->idx_ev[i], hipEventDisableTiming));
+            }
+            h->idx_cur = 0;
         }
         const size_t H = d.H;
         ALLOC(w.X0, float4, cNm, true); ALLOC(w.XP, float4, cNp, true);
@@ -386,21 +408,36 @@ extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t*
     if (edge_lds_bytes(max_n) > 64 * 1024) cmdgen_edge_kernels_allow_lds(edge_lds_bytes(max_n));
     L.B = B; L.Nl = (int)Nl; L.Np = (int)Np; L.N = (int)N; L.max_n = max_n;
     L.Nm = d.joint ? (int)N : (int)Nl;
-    // (plain hipMemcpy: ordered after all earlier work of the blocking streams that may still read the old arrays)
     {
         const int64_t cB = h->cap_B;
-        std::vector<int> stage((size_t)(6 * cB + N), 0);
-        int64_t* gid = reinterpret_cast<int64_t*>(stage.data());
+        const int cur = (h->idx_cur ^= 1);
+        int* blk = h->idx_blk[cur];
+        h->d_gid = reinterpret_cast<int64_t*>(blk); L.pocket_gid = h->d_gid;
+        L.num_phar = blk + 2 * cB; L.num_pocket = blk + 3 * cB; L.phar_base = blk + 4 * cB; L.pocket_base = blk + 5 * cB;
+        L.node_sample = blk + 6 * cB;
+        int* stage = h->idx_stage[cur];
+        hipEventSynchronize(h->idx_ev[cur]);              // the copy that last used this staging buffer (two layouts ago) is long done
+        memset(stage, 0, (size_t)(6 * cB) * sizeof(int));
+        int64_t* gid = reinterpret_cast<int64_t*>(stage);
         for (int b = 0; b < B; ++b) {
             gid[b] = b;
             stage[2 * cB + b] = vph[b]; stage[3 * cB + b] = vpk[b]; stage[4 * cB + b] = bph[b]; stage[5 * cB + b] = bpk[b];
         }
-        memcpy(stage.data() + 6 * cB, ns.data(), (size_t)N * sizeof(int));
-        HIPCHK(h, hipMemcpy((void*)h->d_gid, stage.data(), stage.size() * sizeof(int), hipMemcpyHostToDevice));
-    }
-    if (fits) {   // reused buffers: restore the invariants a fresh (zeroed) workspace has
-        HIPCHK(h, hipMemset(w.agg, 0, (size_t)N * d.H * sizeof(float)));
-        HIPCHK(h, hipMemset(w.totals, 0, 4 * sizeof(int)));
+        memcpy(stage + 6 * cB, ns.data(), (size_t)N * sizeof(int));
+        const size_t bytes = (size_t)(6 * cB + N) * sizeof(int);
+        if (no_wait) {
+            HIPCHK(h, hipMemcpyAsync(blk, stage, bytes, hipMemcpyHostToDevice, stream));
+            HIPCHK(h, hipEventRecord(h->idx_ev[cur], stream));
+            HIPCHK(h, hipMemsetAsync(w.agg, 0, (size_t)N * d.H * sizeof(float), stream));
+            HIPCHK(h, hipMemsetAsync(w.totals, 0, 4 * sizeof(int), stream));
+        } else {
+            // (plain hipMemcpy: ordered after all earlier work of the blocking streams that may still read the old arrays)
+            HIPCHK(h, hipMemcpy(blk, stage, bytes, hipMemcpyHostToDevice));
+            if (fits) {   // reused buffers: restore the invariants a fresh (zeroed) workspace has
+                HIPCHK(h, hipMemset(w.agg, 0, (size_t)N * d.H * sizeof(float)));
+                HIPCHK(h, hipMemset(w.totals, 0, 4 * sizeof(int)));
+            }
+        }
     }
     h->ecap = ecap; h->eccap = eccap;
     {   // Rows per tile: the largest tile that still gives every CU a few workgroups.  Edge counts are only known on

@@ -46,6 +46,11 @@ struct cmdgen_handle {
     int node_mt = 64, edge_mt = 64, coord_mt = 64;   // rows per tile, chosen in cmdgen_set_layout
     bool gemm_split = true;                // tiles of >= 32 rows multiply on the bf16 matrix pipe (cmdgen_set_gemm_mode)
     int64_t* d_gid = nullptr;
+    int* idx_blk[2] = {nullptr, nullptr};  // two copies of the index block: a new layout is written to the one the previous layout's kernels do not read
+    int* idx_stage[2] = {nullptr, nullptr}; // pinned staging of the same size (cmdgen_set_layout_on_stream)
+    hipEvent_t idx_ev[2] = {nullptr, nullptr};
+    int idx_cur = 0;
+    int64_t idx_ints = 0;
     // chain
     std::vector<void*> chain_allocs;
     ChainBuf chain{};
@@ -75,6 +80,7 @@ struct cmdgen_handle {
     const void* jg_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned long long jg_seed = 0; int jg_steps = 0;
     TrainState* train = nullptr;           // training workspace (cmdgen_train.hip)
+    float* h_norm = nullptr; hipEvent_t norm_ev = nullptr; bool norm_pending = false;   // deferred gradient-norm readback (pinned host float)
     int train_E = 0, train_Ec = 0;         // message / coordinate edges of the last cmdgen_train_forward (cmdgen_query)
     bool train_bf16 = false;               // GEMM operand precision of the training step (cmdgen_train_set_precision)
     bool agg_dirty = false;                // cmdgen_debug_eval_prefix left segment sums in work.agg

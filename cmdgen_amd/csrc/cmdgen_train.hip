@@ -652,11 +652,12 @@ extern "C" int cmdgen_adamw_step(cmdgen_handle* h, float* theta, const float* gr
     return CMDGEN_OK;
 }
 
+extern "C" int cmdgen_last_grad_norm(cmdgen_handle* h, float* grad_norm_host);
 extern "C" int cmdgen_adamw_step_clipped(cmdgen_handle* h, float* theta, const float* grad, float* exp_avg, float* exp_avg_sq,
                                          float* max_exp_avg_sq, int64_t n, int64_t step, float lr, float beta1, float beta2,
                                          float eps, float weight_decay, float max_grad_norm, float* grad_norm_host,
                                          cmdgen_stream stream) {
-    if (!h || !theta || !grad || !exp_avg || !exp_avg_sq || !max_exp_avg_sq || !grad_norm_host || n < 1 || step < 1)
+    if (!h || !theta || !grad || !exp_avg || !exp_avg_sq || !max_exp_avg_sq || n < 1 || step < 1)
         return fail(h, CMDGEN_EINVAL, "bad arguments");
     hipSetDevice(h->device);
     int rc = ensure_state(h); if (rc) return rc;
@@ -669,10 +670,22 @@ extern "C" int cmdgen_adamw_step_clipped(cmdgen_handle* h, float* theta, const f
     // the update is queued behind the norm without a host round trip: the clipping coefficient is formed on the device
     tr_adamw((size_t)n, theta, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bias1, sqrtf(bias2), 1.0f, s,
              max_grad_norm > 0.f ? sq : nullptr, max_grad_norm);
-    float sqh = 0.f;
-    HIPCHK(h, hipMemcpyAsync(&sqh, sq, sizeof(float), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
-    *grad_norm_host = sqrtf(sqh);
+    // (the readback state lives in the handle: a later cmdgen_set_layout that outgrows the workspaces frees the training state)
+    if (!h->h_norm) { HIPCHK(h, hipHostMalloc((void**)&h->h_norm, sizeof(float), hipHostMallocDefault)); HIPCHK(h, hipEventCreateWithFlags(&h->norm_ev, hipEventDisableTiming)); }
+    HIPCHK(h, hipMemcpyAsync(h->h_norm, sq, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipEventRecord(h->norm_ev, s));
+    h->norm_pending = true;
+    if (!grad_norm_host) return CMDGEN_OK;          // deferred: cmdgen_last_grad_norm collects it (the host keeps queueing the next step)
+    return cmdgen_last_grad_norm(h, grad_norm_host);
+}
+
+extern "C" int cmdgen_last_grad_norm(cmdgen_handle* h, float* grad_norm_host) {
+    if (!h || !grad_norm_host) return CMDGEN_EINVAL;
+    if (!h->norm_pending) return fail(h, CMDGEN_ESTATE, "no gradient norm outstanding (cmdgen_adamw_step_clipped)");
+    hipSetDevice(h->device);
+    HIPCHK(h, hipEventSynchronize(h->norm_ev));
+    *grad_norm_host = sqrtf(*h->h_norm);
+    h->norm_pending = false;
     return CMDGEN_OK;
 }
 

@@ -48,6 +48,7 @@ SYMBOLS = [
     ('cmdgen_load_weights', C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t]),
     ('cmdgen_finalize_weights', C.c_int, [_vp]),
     ('cmdgen_set_layout', C.c_int, [_vp, C.c_int64, _i64p, _i64p]),
+    ('cmdgen_set_layout_on_stream', C.c_int, [_vp, C.c_int64, _i64p, _i64p, _vp]),
     ('cmdgen_dynamics_forward', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _vp]),
     ('cmdgen_get_edges', C.c_int, [_vp, _vp, _vp, C.c_int64, _i64p, _vp]),
     ('cmdgen_debug_read', C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t, _vp]),
@@ -72,6 +73,7 @@ SYMBOLS = [
                                     C.c_float, C.c_float, C.c_float, _vp]),
     ('cmdgen_adamw_step_clipped', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
                                             C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), _vp]),
+    ('cmdgen_last_grad_norm', C.c_int, [_vp, C.POINTER(C.c_float)]),
     ('cmdgen_debug_sgemm', C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, _fp,
                                      C.c_int32, _fp, C.c_int32, _fp, C.c_int32, C.c_int32, _vp]),
     ('cmdgen_set_step_table', C.c_int, [_vp, C.c_int32, _vp]),
@@ -192,14 +194,19 @@ class Handle:
         self._check(self.lib.cmdgen_finalize_weights(self.h), 'cmdgen_finalize_weights')
 
     # ---- layout
-    def set_layout(self, num_phar: Sequence[int], num_pocket: Sequence[int]):
+    def set_layout(self, num_phar: Sequence[int], num_pocket: Sequence[int], on_stream: bool = False):
+        """on_stream: order the upload on torch's current stream instead of waiting for the device (cmdgen_set_layout_on_stream)."""
         a = np.ascontiguousarray(np.asarray(num_phar, dtype=np.int64))
         b = np.ascontiguousarray(np.asarray(num_pocket, dtype=np.int64))
         assert a.shape == b.shape and a.ndim == 1
         key = (a.tobytes(), b.tobytes())
         if key != self._layout_key:
-            self._check(self.lib.cmdgen_set_layout(self.h, len(a), a.ctypes.data_as(_i64p), b.ctypes.data_as(_i64p)),
-                        'cmdgen_set_layout')
+            if on_stream:
+                self._check(self.lib.cmdgen_set_layout_on_stream(self.h, len(a), a.ctypes.data_as(_i64p), b.ctypes.data_as(_i64p),
+                                                                 self._stream()), 'cmdgen_set_layout_on_stream')
+            else:
+                self._check(self.lib.cmdgen_set_layout(self.h, len(a), a.ctypes.data_as(_i64p), b.ctypes.data_as(_i64p)),
+                            'cmdgen_set_layout')
             self._layout_key = key
         self.batch, self.n_phar, self.n_pocket = len(a), int(a.sum()), int(b.sum())
 
@@ -422,13 +429,19 @@ class Handle:
                                                self._stream()), 'cmdgen_adamw_step')
 
     def adamw_step_clipped(self, theta, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8,
-                           weight_decay=1e-12, max_grad_norm=0.0) -> float:
-        """Norm + clipping (coefficient formed on the device; max_grad_norm <= 0: none) + AdamW; returns the gradient norm."""
+                           weight_decay=1e-12, max_grad_norm=0.0, defer: bool = False):
+        """Norm + clipping (coefficient formed on the device; max_grad_norm <= 0: none) + AdamW; returns the gradient norm,
+        or None with defer=True (collect it with last_grad_norm(); nothing is waited for here)."""
         out = C.c_float(0)
         self._check(self.lib.cmdgen_adamw_step_clipped(self.h, _ptr(theta), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
                                                        _ptr(max_exp_avg_sq), theta.numel(), int(step), float(lr), float(betas[0]),
                                                        float(betas[1]), float(eps), float(weight_decay), float(max_grad_norm),
-                                                       C.byref(out), self._stream()), 'cmdgen_adamw_step_clipped')
+                                                       None if defer else C.byref(out), self._stream()), 'cmdgen_adamw_step_clipped')
+        return None if defer else out.value
+
+    def last_grad_norm(self) -> float:
+        out = C.c_float(0)
+        self._check(self.lib.cmdgen_last_grad_norm(self.h, C.byref(out)), 'cmdgen_last_grad_norm')
         return out.value
 
     def debug_sgemm(self, A, B, ta=False, tb=True, bias=None, C_out=None, accumulate=False, split_k=1, bf16=False):

@@ -64,6 +64,10 @@ class HipTrainer:
         self.fused_loss = True              # conditional model: noising and loss terms as three library launches (cmdgen_train_noise / _loss)
         self._gamma_host = self._logpn_host = None
         self._last_fused = None
+        self.pipelined = False              # True: a step does not wait for its own gradient norm (see optimizer_step)
+        self._norm_pending = None
+        self.last_grad_norm = None
+        self._tab_pinned, self._tab_slot = [None, None], 0
         self._pending = []
 
     # ------------------------------------------------------------------
@@ -116,14 +120,29 @@ class HipTrainer:
         dev = self.theta.device
         f32 = lambda k: data[k].to(dev, torch.float32).contiguous()
         px, poh, qx, qoh = f32('phar_coords'), f32('phar_one_hot'), f32('pocket_c_alpha'), f32('pocket_one_hot')
-        sizes = torch.stack([data['num_phar_atoms'].reshape(-1), data['num_pocket_nodes'].reshape(-1)]).detach().to('cpu', torch.int64).numpy()
-        n_l, n_p = np.ascontiguousarray(sizes[0]), np.ascontiguousarray(sizes[1])       # one device-to-host copy for both
+        # node counts: taken from the batch's host copies when the loader kept them (keys '<name>_cpu': no wait on the device,
+        # so the previous step's backward pass can still be running), else one device-to-host copy for both
+        if 'num_phar_atoms_cpu' in data:
+            n_l = np.ascontiguousarray(data['num_phar_atoms_cpu'].numpy().astype(np.int64))
+            n_p = np.ascontiguousarray(data['num_pocket_nodes_cpu'].numpy().astype(np.int64))
+        else:
+            sizes = torch.stack([data['num_phar_atoms'].reshape(-1), data['num_pocket_nodes'].reshape(-1)]).detach().to('cpu', torch.int64).numpy()
+            n_l, n_p = np.ascontiguousarray(sizes[0]), np.ascontiguousarray(sizes[1])
         B = len(n_l)
-        h.set_layout(n_l, n_p)
+        h.set_layout(n_l, n_p, on_stream=self.pipelined)
         h.train_set_precision(self.gemm_dtype == 'bf16')
         if t_int is None:
             t_int = torch.randint(0, ddpm.T + 1, size=(B, 1)).float()          # training mode: t = 0 included
-        tab = self._sample_table(t_int, n_l, n_p).to(dev, non_blocking=True)
+        tab = self._sample_table(t_int, n_l, n_p)
+        if self.pipelined:      # pinned staging, two buffers: the copy is stream-ordered and never waits for the previous step
+            self._tab_slot ^= 1
+            pin = self._tab_pinned[self._tab_slot]
+            if pin is None or pin.shape != tab.shape:
+                pin = self._tab_pinned[self._tab_slot] = torch.empty(tab.shape, dtype=torch.float32).pin_memory()
+            pin.copy_(tab)
+            tab = pin.to(dev, non_blocking=True)
+        else:
+            tab = tab.to(dev, non_blocking=True)
         if eps is None:
             e = torch.randn((px.shape[0], ddpm.n_dims + ddpm.phar_nf), device=dev)
         else:
@@ -243,8 +262,23 @@ class HipTrainer:
                 dist.broadcast(t, src=src, group=self.group)
             self.dyn._weights_sig = None
 
+    def _collect_norm(self):
+        """The deferred gradient norm of the previous step enters the queue of recent norms (pipelined mode)."""
+        if self._norm_pending is not None:
+            mx = self._norm_pending
+            self._norm_pending = None
+            grad_norm = self.h.last_grad_norm()
+            self.last_grad_norm = grad_norm
+            if self.clip_grad:
+                self.gradnorm_queue.add(float(mx) if grad_norm > mx else grad_norm)
+                if grad_norm > mx:
+                    print(f'Clipped gradient with value {grad_norm:.1f} while allowed {mx:.1f}')
+
     def optimizer_step(self, max_grad_norm: Optional[float] = None):
-        """Adaptive clipping + AdamW(amsgrad) on the flat buffers; returns (grad_norm, max_grad_norm)."""
+        """Adaptive clipping + AdamW(amsgrad) on the flat buffers; returns (grad_norm, max_grad_norm).  With
+        ``self.pipelined`` the norm is NOT waited for (returned as None, collected before the next step's bound is formed:
+        ``last_grad_norm`` then holds it), so the host goes on to queue the next step behind this one."""
+        self._collect_norm()
         self.step_count += 1
         if self.clip_grad and max_grad_norm is None:                   # 150 % of the recent mean + 2 stdev
             max_grad_norm = 1.5 * self.gradnorm_queue.mean() + 2 * self.gradnorm_queue.std()
@@ -252,12 +286,16 @@ class HipTrainer:
         # bound known beforehand); the norm itself is only read back for the queue of recent norms
         grad_norm = self.h.adamw_step_clipped(self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq,
                                               self.step_count, self.lr, self.betas, self.eps, self.weight_decay,
-                                              float(max_grad_norm) if self.clip_grad else 0.0)
+                                              float(max_grad_norm) if self.clip_grad else 0.0, defer=self.pipelined)
+        self.dyn._weights_sig = None            # the sampler's packed copy of the weights is stale now
+        if self.pipelined:
+            self._norm_pending = float(max_grad_norm) if self.clip_grad else float('inf')
+            return None, max_grad_norm
+        self.last_grad_norm = grad_norm
         if self.clip_grad:
             self.gradnorm_queue.add(float(max_grad_norm) if grad_norm > max_grad_norm else grad_norm)
             if grad_norm > max_grad_norm:
                 print(f'Clipped gradient with value {grad_norm:.1f} while allowed {max_grad_norm:.1f}')
-        self.dyn._weights_sig = None            # the sampler's packed copy of the weights is stale now
         return grad_norm, max_grad_norm
 
     def training_step(self, data, t_int=None, eps=None, max_grad_norm: Optional[float] = None):

@@ -117,6 +117,13 @@ int cmdgen_set_layout(cmdgen_handle* h, int64_t batch,
  * queued for this handle on any OTHER stream must be complete before calling.  Limits: a sample's nodes are kept
  * in LDS by the neighbour search (24 B per node; at most ~6500 nodes per sample), the dense edge bound
  * sum(n_b^2) must fit int32. */
+/* The same, ordered on `stream` instead of waited for: when the new layout fits the workspaces already allocated (every
+ * training step has its own ragged layout of about the same size) and `stream` is the stream this handle was last given,
+ * the index arrays are written to the second of two device blocks from pinned staging with a stream-ordered copy, so
+ * kernels of the previous layout still running on `stream` are not disturbed and the host does not wait.  Otherwise it
+ * behaves as cmdgen_set_layout (and also waits for `stream`). */
+int cmdgen_set_layout_on_stream(cmdgen_handle* h, int64_t batch, const int64_t* num_phar_host,
+                                const int64_t* num_pocket_host, cmdgen_stream stream);
 
 /* ---- one network evaluation ------------------------------------------------------- */
 /* EGNNDynamics.forward (dynamics.py:75-139); conditional mode, or joint mode when
@@ -299,11 +306,15 @@ int cmdgen_adamw_step(cmdgen_handle* h, float* theta, const float* grad, float* 
  * `grad` is reduced on the device, the update applies clip_grad_norm_'s coefficient min(1, max_grad_norm / (norm + 1e-6))
  * formed on the device (max_grad_norm <= 0: no clipping), and the norm comes back in *grad_norm_host for the caller's
  * queue of recent norms - the host round trip between norm and update of cmdgen_grad_sqnorm + cmdgen_adamw_step is gone.
- * Synchronises the stream. */
+ * Synchronises the stream - unless grad_norm_host is NULL: then the norm is copied to pinned host memory behind the update
+ * and cmdgen_last_grad_norm collects it later (it is only needed before the NEXT step's bound is formed), so the host can
+ * queue the next step's noising and graph build while this step's backward pass is still running. */
 int cmdgen_adamw_step_clipped(cmdgen_handle* h, float* theta, const float* grad, float* exp_avg, float* exp_avg_sq,
                               float* max_exp_avg_sq, int64_t n, int64_t step, float lr, float beta1, float beta2,
                               float eps, float weight_decay, float max_grad_norm, float* grad_norm_host,
                               cmdgen_stream stream);
+/* The norm of the last cmdgen_adamw_step_clipped called with grad_norm_host = NULL (waits for that update only). */
+int cmdgen_last_grad_norm(cmdgen_handle* h, float* grad_norm_host);
 
 /* C[M,N] (+)= op(A) op(B) (+ bias) through the training path's exact-fp32 MFMA GEMM (test aid):
  * ta: A stored [K][M]; tb: B stored [N][K] (nn.Linear weight); accumulate bit 0: C += ..., bit 1: bf16 operands. */

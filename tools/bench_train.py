@@ -33,7 +33,9 @@ def synthetic_batch(B, first, dev, rep='CA'):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     return {'phar_coords': t(px), 'phar_one_hot': t(poh), 'num_phar_atoms': t(nl), 'phar_mask': t(pm),
             'pocket_c_alpha': t(pb.x), 'pocket_one_hot': t(pb.one_hot), 'num_pocket_nodes': t(pb.size),
-            'pocket_mask': t(pb.mask)}
+            'pocket_mask': t(pb.mask),
+            # host copies of the node counts, as a collate function has them before the batch is moved to the device
+            'num_phar_atoms_cpu': torch.from_numpy(np.ascontiguousarray(nl)), 'num_pocket_nodes_cpu': torch.from_numpy(np.ascontiguousarray(pb.size))}
 
 
 def main():
@@ -44,6 +46,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--representation', default='CA', choices=['CA', 'full-atom'])
     ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16'], help='GEMM operand precision (fp32 accumulation either way)')
+    ap.add_argument('--no-pipeline', action='store_true', help='wait for every step\'s gradient norm before queueing the next step (HipTrainer.pipelined = False)')
     ap.add_argument('--cpu-baseline', action='store_true', help='also time the oracle (torch CPU autograd) on the same batch shape')
     ap.add_argument('--profile', action='store_true', help='print the per-kernel time table of 3 steps (torch.profiler)')
     a = ap.parse_args()
@@ -68,6 +71,7 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed=0).items()}, strict=True)
     model = model.to(dev)
     tr = HipTrainer(model, gemm_dtype=a.gemm)
+    tr.pipelined = not a.no_pipeline
     batches = [synthetic_batch(a.batch, 50000 + 1000 * rank + 100 * i, dev, a.representation) for i in range(4)]
     torch.manual_seed(rank)
     for i in range(a.warmup):
@@ -78,9 +82,10 @@ def main():
     t0 = time.perf_counter()
     losses = []
     for i in range(a.steps):
-        losses.append(float(tr.training_step(batches[i % 4])['loss']))
+        losses.append(tr.training_step(batches[i % 4])['loss'])          # device scalars: read after the loop
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    losses = [float(x) for x in losses]
     if world > 1:
         td = torch.tensor([dt], device=dev)
         dist.all_reduce(td, op=dist.ReduceOp.MAX)
@@ -141,7 +146,7 @@ def main():
     if rank == 0:
         print(json.dumps({'metric': 'training complexes/s', 'value': a.batch * world * a.steps / dt, 'n_gpus': world,
                           'ms_per_step': dt / a.steps * 1e3, 'batch_per_gpu': a.batch, 'dtype': 'f32' if a.gemm == 'fp32' else 'bf16 GEMM operands, f32 accumulate/master',
-                          'first_loss': losses[0], 'last_loss': losses[-1], 'cpu_baseline': cpu,
+                          'first_loss': losses[0], 'last_loss': losses[-1], 'cpu_baseline': cpu, 'pipelined': tr.pipelined,
                           'graph_of_last_step': {'nodes': tr.h.n_phar + tr.h.n_pocket, 'edges': tr.h.query('train_edges'),
                                                  'coord_edges': tr.h.query('train_coord_edges')},
                           'phase_ms': {'loss_and_grad': ev[0].elapsed_time(ev[1]), 'allreduce': ev[1].elapsed_time(ev[2]),
