@@ -128,6 +128,7 @@ def main(argv=None):
     model = model.to(torch.device('cuda', local))
     model.setup('fit')
     trainer = HipTrainer(model, gemm_dtype=gemm)
+    trainer.pipelined = True            # a step does not wait for its own gradient norm (training.HipTrainer.optimizer_step)
     start_epoch, best = 0, float('inf')
     if resume is not None and 'hip_trainer' in resume:
         st = resume['hip_trainer']
@@ -146,11 +147,16 @@ def main(argv=None):
         t0 = time.perf_counter()
         losses = []
         for batch in _batches(model.train_dataset, args.batch_size, epoch, rank, world):
+            # the collate output is on the host: keep its node counts there, so a step never waits on the device for them
+            batch = dict(batch)
+            batch['num_phar_atoms_cpu'], batch['num_pocket_nodes_cpu'] = batch['num_phar_atoms'].cpu(), batch['num_pocket_nodes'].cpu()
             info = trainer.training_step(batch)
-            losses.append(float(info['loss']))
+            losses.append(info['loss'])             # device scalars: read once per epoch, the steps stay pipelined
             if max_steps is not None and trainer.step_count >= max_steps:
                 done = True
                 break
+        losses = [float(x) for x in losses]
+        trainer._collect_norm()             # the last step's norm enters the queue before it is checkpointed
         val = validate(model, model.val_dataset, args.batch_size, rank, world)
         sampled = None
         if rank == 0 and (epoch + 1) % int(args.eval_epochs) == 0:

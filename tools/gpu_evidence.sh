@@ -25,7 +25,7 @@ run 400 python bench.py --representation full-atom --batch 256 --timesteps 100 -
 run 300 python bench.py --gemm fp32 --batch 256 --steps 2 --warmup 1 --north-star-batch 0 --no-cpu-baseline > $o/${tag}_bench_b256_fp32engine.json 2>/dev/null
 run 300 python bench.py --gemm fp32 --representation full-atom --batch 64 --timesteps 200 --steps 1 --warmup 1 --north-star-batch 0 --no-cpu-baseline > $o/${tag}_bench_fullatom_b64_fp32engine.json 2>/dev/null
 run 300 python bench.py --gemm fp32 --steps 3 --warmup 1 --north-star-batch 0 --no-cpu-baseline > $o/${tag}_bench_b64_fp32engine.json 2>/dev/null
-for a in "--batch 64" "--batch 256" "--batch 256 --gemm bf16" "--batch 64 --gemm bf16"; do run 200 python tools/bench_train.py --steps 10 --warmup 3 $a 2>/dev/null | tail -1; done > $o/${tag}_train.jsonl
+for a in "--batch 64" "--batch 256" "--batch 256 --gemm bf16" "--batch 64 --gemm bf16" "--batch 64 --no-pipeline" "--batch 256 --no-pipeline"; do run 200 python tools/bench_train.py --steps 30 --warmup 5 $a 2>/dev/null | tail -1; done > $o/${tag}_train.jsonl
 run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_tstats -- python3 tools/bench_train.py --steps 4 --warmup 2 > /dev/null 2>&1
 cp $(find $o/${tag}_tstats -name "*kernel_stats.csv" | head -1) $o/${tag}_train_kernel_stats_b64.csv; rm -rf $o/${tag}_tstats
 run 200 python tools/bench_joint.py --batch 64 --timesteps 1000 2>/dev/null | tail -1 > $o/${tag}_joint.json
