@@ -47,6 +47,9 @@ void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float*
                       const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ, float* dWcol, float* dX,
                       float* scratch, hipStream_t s);
 size_t tr_edge_tail_scratch_floats(size_t E, size_t H);
+void cmdgen_dgrad_tail(int E, const float* dY, const void* Wt, const float* pre1, const int* row, const int* col, const float* d0,
+                       const float* Wcol, int ldw, const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ,
+                       float* dWcol, float* dX, float* scratch, int pieces, hipStream_t s);
 size_t tr_partial_scratch_floats(size_t E, size_t H);
 void tr_gate_bwd(int E, int H, const int* row, const float* pre2, const float* wa, const float* z, int attention, const float* dagg,
                  float* dpre2, float* scratch, float* d_wa, float* d_ba, float* zero, size_t zero_floats, hipStream_t s);
@@ -501,12 +504,19 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             cmdgen_wgrad_group(one, Ec, g_bf16, s);
         }
         const TrainState::PackBlk& pk = t->pack[l];
-        if (sp) cmdgen_dgrad_split(Ec, t->actB, pk.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s, pcs);
-        else linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
+        static const bool no_fuse_tail = getenv("CMDGEN_NO_DGRAD_TAIL") != nullptr;
+        const bool tail_fused = sp && !no_fuse_tail;
         if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
-        // adjoints of the gathers, the radial / d0 column gradients, d radial and the geometry adjoint: one pass over dpre6
-        tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
-                         t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, s);
+        if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
+            cmdgen_dgrad_tail(Ec, t->actB, pk.t_c2, pre6, w.crow, w.ccol, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
+                              t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, pcs, s);
+        else {
+            if (sp) cmdgen_dgrad_split(Ec, t->actB, pk.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s, pcs);
+            else linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
+            // adjoints of the gathers, the radial / d0 column gradients, d radial and the geometry adjoint: one pass over dpre6
+            tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
+                             t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, s);
+        }
         if (sp) cmdgen_dgrad_split(N, t->dP, pk.t_c0a, t->dQ, pk.t_c0b, t->dh, true, 1.0f, nullptr, s, pcs);
         else {
             linear_dgrad(theta, b.c0, 0, H, N, t->dP, H, t->dh, H, true, s);
@@ -547,11 +557,16 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.e2.in;
             cmdgen_wgrad_group(one, E, g_bf16, s);
         }
-        if (sp) cmdgen_dgrad_split(E, t->actA, pk.t_e2, nullptr, nullptr, t->actB, false, 1.0f, pre1, s, pcs);
-        else linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
         if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
-        tr_edge_tail_bwd(E, H, w.erow, w.ecol, t->actB, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
-                         t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, s);
+        if (tail_fused)
+            cmdgen_dgrad_tail(E, t->actA, pk.t_e2, pre1, w.erow, w.ecol, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
+                              t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, pcs, s);
+        else {
+            if (sp) cmdgen_dgrad_split(E, t->actA, pk.t_e2, nullptr, nullptr, t->actB, false, 1.0f, pre1, s, pcs);
+            else linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
+            tr_edge_tail_bwd(E, H, w.erow, w.ecol, t->actB, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
+                             t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, s);
+        }
         // node_mlp.0 (both halves) and edge_mlp.0 (both halves): the second grouped launch of the block
         defer_wgrad(b.n0, 0, H, t->dn, hl, true);
         defer_wgrad(b.n0, H, H, t->dn, aggn, false);

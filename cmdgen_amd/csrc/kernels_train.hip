@@ -427,19 +427,15 @@ void cmdgen_sgemm(bool ta, bool tb, int M, int N, int K, const float* A, int lda
 // One workgroup per MT rows: the A tile is staged once in LDS as fp32, every wave splits the fragments it reads in
 // registers in the shadow of the MFMAs (tile_gemm_rsplit), the weight fragments stream from L2.
 // ------------------------------------------------------------------------------------
+// the GEMM part: acc = A0[row0 .. row0+MT) W0 (+ A1 W1).  The A operand lies in LDS as three bf16 planes [MT][136] of one
+// half of the k range at a time (tile_gemm_planes): the thread that loads an element splits it once; the next half's rows
+// are requested before this half's MFMAs start.  Ends with a barrier (the planes may be overwritten).
 template <int MT, int NPC>
-__global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __restrict__ A0, const void* __restrict__ W0,
-                                                        const float* __restrict__ A1, const void* __restrict__ W1,
-                                                        float* __restrict__ Y, int accumulate, float div,
-                                                        const float* __restrict__ pre) {
-    // the A operand as three bf16 planes [MT][136] of one half of the k range at a time (tile_gemm_planes): the thread
-    // that loads an element splits it once; the next half's rows are requested before this half's MFMAs start
+__device__ __forceinline__ void dgrad_tile_gemm(unsigned short* planes, int M, int row0, const float* __restrict__ A0,
+                                                const void* __restrict__ W0, const float* __restrict__ A1,
+                                                const void* __restrict__ W1, sf32x16 (&acc)[MT / 32][2]) {
     constexpr int HH = 256, PLDA = SPLIT_PLANE_LDA(HH / 2), PE = MT * PLDA, NP = MT / 8;
-    constexpr int LDO = HH + 4, SMEM = 3 * PE * 2 > 32 * LDO * 4 ? 3 * PE * 2 : 32 * LDO * 4;   // planes / 32-row fp32 output image
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
-    unsigned short* planes = reinterpret_cast<unsigned short*>(smem);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int row0 = blockIdx.x * MT;
+    const int tid = threadIdx.x, wave = tid >> 6;
     const int c4 = tid & 31, rsub = tid >> 5;            // 32 lanes x 16 bytes = one half row, 8 rows per pass
     SCarry carry;
     const int nstage = A1 ? 4 : 2;                        // (source, half)
@@ -456,7 +452,6 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __re
         }
     };
     fetch(0);
-    sf32x16 acc[MT / 32][2];
 #pragma unroll
     for (int m = 0; m < MT / 32; ++m)
 #pragma unroll
@@ -475,6 +470,20 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __re
         tile_gemm_planes<MT, HH / 32, NPC>(planes, PE, PLDA, frag_of(st), frag_of(st + 1 < nstage ? st + 1 : st), acc, carry);
         __syncthreads();
     }
+}
+
+template <int MT, int NPC>
+__global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __restrict__ A0, const void* __restrict__ W0,
+                                                        const float* __restrict__ A1, const void* __restrict__ W1,
+                                                        float* __restrict__ Y, int accumulate, float div,
+                                                        const float* __restrict__ pre) {
+    constexpr int HH = 256, PLDA = SPLIT_PLANE_LDA(HH / 2), PE = MT * PLDA;
+    constexpr int LDO = HH + 4, SMEM = 3 * PE * 2 > 32 * LDO * 4 ? 3 * PE * 2 : 32 * LDO * 4;   // planes / 32-row fp32 output image
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row0 = blockIdx.x * MT;
+    sf32x16 acc[MT / 32][2];
+    dgrad_tile_gemm<MT, NPC>(reinterpret_cast<unsigned short*>(smem), M, row0, A0, W0, A1, W1, acc);
     // Epilogue through LDS, 32 rows at a time (the fp32 image of 32 rows, 33 KB, aliases the planes): whole 1 KB rows leave
     // as 16-byte pieces, and SiLU'(pre) / the running value of Y are read the same way.  Accumulator element r of tile
     // (m, n) is row m*32 + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column wave*64 + n*32 + (lane & 31).
@@ -947,6 +956,118 @@ __global__ __launch_bounds__(256) void k_edge_tail_bwd(int E, int H, const int* 
         scratch[((size_t)blockIdx.x * 2 + which) * H + c] = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
     }
 }
+// ------------------------------------------------------------------------------------
+// k_dgrad_tail: the data gradient through the second layer of an edge / coordinate MLP AND everything k_edge_tail_bwd does
+// with its result, in one kernel: g = (dY W2) * SiLU'(pre1) of a 32-edge tile never leaves the chip (one [E,256] tensor
+// less written and read per list and block).  GEMM as k_dgrad_split<32>; the accumulators go to LDS, every wave applies
+// SiLU'(pre1) to the eight rows it owns (whole-row reads of pre1) and then runs the tail on the same rows: receiver runs
+// into dP, dQ atomics, the radial / d0 column partial sums, dL/d radial and the geometry adjoint - lanes own columns
+// lane + 64 q exactly as in k_edge_tail_bwd (contiguous 256-byte atomics).  Scratch layout and reduce kernel are shared.
+// ------------------------------------------------------------------------------------
+struct TailArgs {
+    const int* row; const int* col; const float* d0; const float* Wcol; int ldw;
+    const float4* X; float norm_constant; const float4* dcd; int n_moving;
+    float* dP; float* dQ; float* scratch; float* dX;
+};
+template <int NPC>
+__global__ __launch_bounds__(256, 3) void k_dgrad_tail(int M, const float* __restrict__ A0, const void* __restrict__ W0,
+                                                       const float* __restrict__ pre, TailArgs ta) {
+    constexpr int MT = 32, HH = 256, PLDA = SPLIT_PLANE_LDA(HH / 2), PE = MT * PLDA;
+    constexpr int LDO = HH + 4, SMEM = 3 * PE * 2 > 32 * LDO * 4 ? 3 * PE * 2 : 32 * LDO * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row0 = blockIdx.x * MT;
+    // the tail's per-edge scalars: requested before the GEMM, used after it
+    const int e0 = row0 + wave * 8, ne = max(0, min(8, M - e0));
+    int my_i = -1, my_j = -1; float my_r = 0.f, my_d0 = 0.f, dxl = 0.f, dyl = 0.f, dzl = 0.f;
+    if (lane < ne) {
+        my_i = ta.row[e0 + lane]; my_j = ta.col[e0 + lane]; my_d0 = ta.d0[e0 + lane];
+        const float4 a = ta.X[my_i], b = ta.X[my_j];
+        dxl = a.x - b.x; dyl = a.y - b.y; dzl = a.z - b.z;
+        my_r = dxl * dxl + dyl * dyl + dzl * dzl;
+    }
+    float wr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wr[q] = ta.Wcol[(size_t)(lane + 64 * q) * ta.ldw];
+    sf32x16 acc[1][2];
+    dgrad_tile_gemm<MT, NPC>(reinterpret_cast<unsigned short*>(smem), M, row0, A0, W0, nullptr, nullptr, acc);
+    float* obuf = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            obuf[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDO + wave * 64 + n * 32 + (lane & 31)] = acc[0][n][r];
+    __syncthreads();
+    // SiLU'(pre1) on this wave's rows 8 wave .. 8 wave + 7 (the same rows its tail walks: no barrier in between)
+    {
+        float4 pv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k < ne) pv[k] = reinterpret_cast<const float4*>(pre + (size_t)(e0 + k) * HH)[lane];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < ne) {
+                float4* cell = reinterpret_cast<float4*>(obuf + (wave * 8 + k) * LDO + 4 * lane);
+                float4 x = *cell;
+                x.x *= dsilu(pv[k].x); x.y *= dsilu(pv[k].y); x.z *= dsilu(pv[k].z); x.w *= dsilu(pv[k].w);
+                *cell = x;
+            }
+    }
+    float accR[4] = {0.f, 0.f, 0.f, 0.f}, accD[4] = {0.f, 0.f, 0.f, 0.f}, run[4] = {0.f, 0.f, 0.f, 0.f};
+    float my_gr = 0.f;
+    int cur = __shfl(my_i, 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k < ne) {                                        // wave-uniform
+            const int i = __shfl(my_i, k), j = __shfl(my_j, k);
+            const float r = __shfl(my_r, k), dd = __shfl(my_d0, k);
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = obuf[(wave * 8 + k) * LDO + lane + 64 * q];
+            if (i != cur) {                                  // the receiver's run ended: one add per run
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { atomicAdd(ta.dP + (size_t)cur * HH + lane + 64 * q, run[q]); run[q] = 0.f; }
+                cur = i;
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                accR[q] += r * v[q]; accD[q] += dd * v[q]; run[q] += v[q]; dot += v[q] * wr[q];
+                atomicAdd(ta.dQ + (size_t)j * HH + lane + 64 * q, v[q]);
+            }
+            const float gr = wave_sum(dot);                  // dL/d radial of this edge
+            if (lane == k) my_gr = gr;
+        }
+    }
+    if (ne > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicAdd(ta.dP + (size_t)cur * HH + lane + 64 * q, run[q]);
+    }
+    if (lane < ne && my_i != my_j) {                         // geometry adjoint, one lane per edge (as k_geom_bwd)
+        const float sq = sqrtf(my_r + 1e-8f), den = sq + ta.norm_constant;
+        float gx = 0.f, gy = 0.f, gz = 0.f, gr = my_gr;
+        if (ta.dcd) {
+            const float4 d = ta.dcd[e0 + lane];
+            gx = d.x / den; gy = d.y / den; gz = d.z / den;
+            const float dden = -(d.x * dxl + d.y * dyl + d.z * dzl) / (den * den);
+            gr += dden * 0.5f / sq;
+        }
+        gx += 2.0f * dxl * gr; gy += 2.0f * dyl * gr; gz += 2.0f * dzl * gr;
+        if (my_i < ta.n_moving) { float* p = ta.dX + (size_t)my_i * 4; atomicAdd(p, gx); atomicAdd(p + 1, gy); atomicAdd(p + 2, gz); }
+        if (my_j < ta.n_moving) { float* p = ta.dX + (size_t)my_j * 4; atomicAdd(p, -gx); atomicAdd(p + 1, -gy); atomicAdd(p + 2, -gz); }
+    }
+    // column sums: per-workgroup partials to the scratch row (k_tail_colsum_reduce adds them up)
+    __syncthreads();                                         // every wave is done with the output image
+    float* red = obuf;                                       // [2][4][256]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { red[(0 * 4 + wave) * 256 + lane + 64 * q] = accR[q]; red[(1 * 4 + wave) * 256 + lane + 64 * q] = accD[q]; }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * HH; idx += 256) {
+        const int which = idx / HH, c = idx - which * HH;
+        ta.scratch[((size_t)blockIdx.x * 2 + which) * HH + c] =
+            (red[(which * 4 + 0) * 256 + c] + red[(which * 4 + 1) * 256 + c]) + (red[(which * 4 + 2) * 256 + c] + red[(which * 4 + 3) * 256 + c]);
+    }
+}
+
 // dWcol[which + c * ldw] += sum over workgroups of scratch[wg][which][c].  grid (H / 64, 2, slices): every workgroup sums
 // one slice of the partial rows for 64 columns (4 rows in flight per column) and adds its result with one atomic.
 __global__ __launch_bounds__(256) void k_tail_colsum_reduce(int nwg, int H, const float* __restrict__ scratch,
@@ -1390,6 +1511,17 @@ void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float*
     hipLaunchKernelGGL(k_edge_tail_bwd, dim3(nwg), dim3(256), 0, s, E, H, row, col, g, d0, Wcol, ldw, X, nc, dcd, n_moving, dP, dQ,
                        scratch, dX);
     hipLaunchKernelGGL(k_tail_colsum_reduce, dim3((H + 63) / 64, 2, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, dWcol, ldw);
+}
+// fused: g = (dY W2^T-pack) * SiLU'(pre1) and its whole tail (H = 256; W = split pack of the transposed weight)
+void cmdgen_dgrad_tail(int E, const float* dY, const void* Wt, const float* pre1, const int* row, const int* col, const float* d0,
+                       const float* Wcol, int ldw, const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ,
+                       float* dWcol, float* dX, float* scratch, int pieces, hipStream_t s) {
+    if (E <= 0) return;
+    const int nwg = (E + 31) / 32;
+    const TailArgs ta{row, col, d0, Wcol, ldw, X, nc, dcd, n_moving, dP, dQ, scratch, dX};
+    if (pieces == 3) hipLaunchKernelGGL((k_dgrad_tail<3>), dim3(nwg), dim3(256), 0, s, E, dY, Wt, pre1, ta);
+    else hipLaunchKernelGGL((k_dgrad_tail<1>), dim3(nwg), dim3(256), 0, s, E, dY, Wt, pre1, ta);
+    hipLaunchKernelGGL(k_tail_colsum_reduce, dim3(4, 2, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, 256, scratch, dWcol, ldw);
 }
 size_t tr_edge_tail_scratch_floats(size_t E, size_t H) { return ((E + 4 * TAIL_EPW - 1) / (4 * TAIL_EPW)) * 2 * H; }
 void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s) {
