@@ -25,7 +25,9 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s);
 struct RepackSplitT { int src_off, ld; void* dst; int transpose; };                                       // kernels_train.hip
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s);
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
-                        const float* pre, hipStream_t s, int pieces = 3);
+                        const float* pre, hipStream_t s, int pieces = 3, const void* W0b = nullptr, float* Yb = nullptr,
+                        bool accumulate_b = false, float div_b = 1.0f);
+void tr_reduce_pair(int E, int H, const float* scratch_a, float* out_w, float* out_b, const float* scratch_t, float* dWcol, int ldw, hipStream_t s);
 void tr_silu(const float* in, float* out, size_t n, hipStream_t s);
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
 void tr_scale(float* x, float a, size_t n, hipStream_t s);
@@ -49,12 +51,13 @@ void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float*
 size_t tr_edge_tail_scratch_floats(size_t E, size_t H);
 void cmdgen_dgrad_tail(int E, const float* dY, const void* Wt, const float* pre1, const int* row, const int* col, const float* d0,
                        const float* Wcol, int ldw, const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ,
-                       float* dWcol, float* dX, float* scratch, int pieces, hipStream_t s);
+                       float* dWcol, float* dX, float* scratch, int pieces, hipStream_t s, bool defer_reduce = false);
 size_t tr_partial_scratch_floats(size_t E, size_t H);
 void tr_gate_bwd(int E, int H, const int* row, const float* pre2, const float* wa, const float* z, int attention, const float* dagg,
-                 float* dpre2, float* scratch, float* d_wa, float* d_ba, float* zero, size_t zero_floats, hipStream_t s);
+                 float* dpre2, float* scratch, float* d_wa, float* d_ba, float* zero, size_t zero_floats, hipStream_t s,
+                 bool defer_reduce = false);
 void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
-                 float* zero, size_t zero_floats, hipStream_t s);
+                 float* zero, size_t zero_floats, hipStream_t s, bool defer_reduce = false);
 void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s);
 void tr_scatter_rows(int E, int H, const int* idx, const float* src, float* dst, hipStream_t s);
 void tr_rowdot(int E, int H, const float* X, const float* w, int ldw, float* out, hipStream_t s);
@@ -136,7 +139,7 @@ struct TrainState {
     float *pre1, *pre2, *z, *pre6, *pre7, *phi;
     float *act1, *act6;                 // SiLU of pre1 / pre6, written by the producing kernel (the x operands of two weight gradients)
     // edge level scratch
-    float *actA, *actB, *r, *rc, *dr, *dz, *dphi, *tail_scratch;
+    float *actA, *actB, *r, *rc, *dr, *dz, *dphi, *tail_scratch, *part_scratch;
     float4 *cd, *dcd;
     // backward node level
     float *dh, *dX, *dacc, *dagg, *dP, *dQ, *dn, *dhfin, *ddec, *ddeca, *dhdyn, *denca_l, *denca_p;
@@ -274,6 +277,7 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
     EA(t->r, float, ec); EA(t->rc, float, ecc); EA(t->dr, float, em); EA(t->dz, float, ec); EA(t->dphi, float, ecc);
     EA(t->cd, float4, ecc); EA(t->dcd, float4, ecc);
     EA(t->tail_scratch, float, std::max(tr_edge_tail_scratch_floats(em, H), tr_partial_scratch_floats(em, H)));
+    EA(t->part_scratch, float, tr_partial_scratch_floats(em, H));
 #undef EA
     t->ecap = ec; t->eccap = ecc;
     return 0;
@@ -491,7 +495,11 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, Nm, t->dphi, t->dcd, s);
         const size_t pq_floats = (size_t)(t->dQ - t->dP) + NH;                            // dP and dQ, adjacent
         const bool fused_small = H <= 256 && H % 4 == 0;
-        if (fused_small) tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, t->tail_scratch, grad + b.c4.w, t->dP, pq_floats, s);   // actB <- dpre7, d coord_mlp.4; clears dP | dQ
+        const TrainState::PackBlk& pk = t->pack[l];
+        static const bool no_fuse_tail = getenv("CMDGEN_NO_DGRAD_TAIL") != nullptr;
+        const bool tail_fused = sp && !no_fuse_tail;
+        const bool pair = tail_fused && fused_small;          // the list's two reductions (head / gate partials, tail partials) as one launch
+        if (fused_small) tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, pair ? t->part_scratch : t->tail_scratch, grad + b.c4.w, t->dP, pq_floats, s, pair);   // actB <- dpre7, d coord_mlp.4; clears dP | dQ
         else {
             tr_silu(pre7, t->actA, (size_t)Ec * H, s);                                    // c2 (not stored by the forward)
             tr_colsum(Ec, H, t->actA, H, t->dphi, grad + b.c4.w, 1, s);
@@ -503,13 +511,11 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.c2.in;
             cmdgen_wgrad_group(one, Ec, g_bf16, s);
         }
-        const TrainState::PackBlk& pk = t->pack[l];
-        static const bool no_fuse_tail = getenv("CMDGEN_NO_DGRAD_TAIL") != nullptr;
-        const bool tail_fused = sp && !no_fuse_tail;
         if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
         if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
             cmdgen_dgrad_tail(Ec, t->actB, pk.t_c2, pre6, w.crow, w.ccol, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
-                              t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, pcs, s);
+                              t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
+        if (pair) tr_reduce_pair(Ec, H, t->part_scratch, grad + b.c4.w, nullptr, t->tail_scratch, grad + b.c0.w + 2 * H, ld1, s);
         else {
             if (sp) cmdgen_dgrad_split(Ec, t->actB, pk.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s, pcs);
             else linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
@@ -531,8 +537,8 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         flush_wgrads();
         if (sp) {
             cmdgen_dgrad_split(N, t->dh, pk.t_n2, nullptr, nullptr, t->dn, false, 1.0f, pre3, s, pcs);
-            cmdgen_dgrad_split(N, t->dn, pk.t_n0a, nullptr, nullptr, t->dh, true, 1.0f, nullptr, s, pcs);
-            cmdgen_dgrad_split(N, t->dn, pk.t_n0b, nullptr, nullptr, t->dagg, false, d.norm_factor, nullptr, s, pcs);
+            cmdgen_dgrad_split(N, t->dn, pk.t_n0a, nullptr, nullptr, t->dh, true, 1.0f, nullptr, s, pcs,       // dh += dpre3 W3[:, :H] and
+                               pk.t_n0b, t->dagg, false, d.norm_factor);                                        // dagg = dpre3 W3[:, H:] / nf: one launch
         } else {
             linear_dgrad(theta, b.n2, 0, H, N, t->dh, H, t->dn, H, false, s, pre3);       // dn <- dn1 * SiLU'(pre3) = dpre3
             linear_dgrad(theta, b.n0, 0, H, N, t->dn, H, t->dh, H, true, s);              // dh is now dL/dh_l (residual kept)
@@ -541,8 +547,8 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         }
         // ---- edge model
         if (fused_small)                                                                  // actA <- dpre2, d att_mlp; clears dP | dQ
-            tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, t->actA, t->tail_scratch,
-                        d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, t->dP, pq_floats, s);
+            tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, t->actA, pair ? t->part_scratch : t->tail_scratch,
+                        d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, t->dP, pq_floats, s, pair);
         else {
             tr_silu(pre2, t->actB, (size_t)E * H, s);                                     // m2 (not stored by the forward)
             tr_att_msg_bwd(E, H, w.erow, t->actB, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, pre2, t->actA, t->dz, s);
@@ -560,7 +566,9 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
         if (tail_fused)
             cmdgen_dgrad_tail(E, t->actA, pk.t_e2, pre1, w.erow, w.ecol, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
-                              t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, pcs, s);
+                              t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
+        if (pair) tr_reduce_pair(E, H, t->part_scratch, d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr,
+                                 t->tail_scratch, grad + b.e0.w + 2 * H, ld1, s);
         else {
             if (sp) cmdgen_dgrad_split(E, t->actA, pk.t_e2, nullptr, nullptr, t->actB, false, 1.0f, pre1, s, pcs);
             else linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1

@@ -476,7 +476,10 @@ template <int MT, int NPC>
 __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __restrict__ A0, const void* __restrict__ W0,
                                                         const float* __restrict__ A1, const void* __restrict__ W1,
                                                         float* __restrict__ Y, int accumulate, float div,
-                                                        const float* __restrict__ pre) {
+                                                        const float* __restrict__ pre, const void* __restrict__ W0b,
+                                                        float* __restrict__ Yb, int accumulate_b, float div_b) {
+    // gridDim.y = 2: a second product of the same A0 (W0b -> Yb; the two halves of node_mlp.0 share dpre3) in the same launch
+    if (blockIdx.y) { W0 = W0b; Y = Yb; accumulate = accumulate_b; div = div_b; }
     constexpr int HH = 256, PLDA = SPLIT_PLANE_LDA(HH / 2), PE = MT * PLDA;
     constexpr int LDO = HH + 4, SMEM = 3 * PE * 2 > 32 * LDO * 4 ? 3 * PE * 2 : 32 * LDO * 4;   // planes / 32-row fp32 output image
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
@@ -543,12 +546,14 @@ void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s
 // pieces = 3: fp32-accurate (split engine); 1: the operands' leading bf16 piece only (= operands rounded to nearest-even
 // bf16, fp32 accumulation: cmdgen_train_set_precision(1))
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
-                        const float* pre, hipStream_t s, int pieces = 3) {
+                        const float* pre, hipStream_t s, int pieces = 3, const void* W0b = nullptr, float* Yb = nullptr,
+                        bool accumulate_b = false, float div_b = 1.0f) {
     if (M <= 0) return;
     static const char* mt = getenv("CMDGEN_DGRAD_MT");
     const bool big = mt ? atoi(mt) == 64 : M >= 24576;
-    const int acc = accumulate ? 1 : 0;
-#define DG(MT_, NP_) hipLaunchKernelGGL((k_dgrad_split<MT_, NP_>), dim3((M + MT_ - 1) / MT_), dim3(256), 0, s, M, A0, W0, A1, W1, Y, acc, div, pre)
+    const int acc = accumulate ? 1 : 0, ny = W0b ? 2 : 1;
+#define DG(MT_, NP_) hipLaunchKernelGGL((k_dgrad_split<MT_, NP_>), dim3((M + MT_ - 1) / MT_, ny), dim3(256), 0, s, M, A0, W0, A1, W1, Y, acc, div, pre, \
+                                        W0b, Yb, accumulate_b ? 1 : 0, div_b)
     if (pieces == 3) { if (big) DG(64, 3); else DG(32, 3); }
     else { if (big) DG(64, 1); else DG(32, 1); }
 #undef DG
@@ -1474,22 +1479,61 @@ void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* 
                     const float* dagg, const float* pre2, float* dm2, float* dz, hipStream_t s) {
     if (E) hipLaunchKernelGGL(k_att_msg_bwd, ROW_GRID(E), 0, s, E, H, row, m2, wa, z, attention, dagg, pre2, dm2, dz);
 }
+// The two reductions of an edge list in one launch: blockIdx.y = 0 is k_partial_reduce's job (gate / head partial sums,
+// scratch rows of H + 4 floats), blockIdx.y = 1, 2 are k_tail_colsum_reduce's (radial / d0 column partials, rows of 2 H).
+__global__ __launch_bounds__(256) void k_reduce_pair(int nwg_a, int H, const float* __restrict__ scratch_a, float* __restrict__ out_w,
+                                                     float* __restrict__ out_b, int nwg_t, const float* __restrict__ scratch_t,
+                                                     float* __restrict__ dWcol, int ldw) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const bool job_a = blockIdx.y == 0;
+    if (job_a && !out_w) return;                 // (a model without attention has no gate parameters)
+    const int which = (int)blockIdx.y - 1;
+    const int nwg = job_a ? nwg_a : nwg_t;
+    const int ncol = job_a ? H + (out_b ? 1 : 0) : H;
+    const int per = (nwg + gridDim.z - 1) / gridDim.z;
+    const int w0 = blockIdx.z * per, w1 = min(nwg, w0 + per);
+    float sum = 0.f;
+    if (c < ncol) {
+        if (job_a) {
+#pragma unroll 4
+            for (int w = w0 + part; w < w1; w += 4) sum += scratch_a[(size_t)w * (H + 4) + c];
+        } else {
+#pragma unroll 4
+            for (int w = w0 + part; w < w1; w += 4) sum += scratch_t[((size_t)w * 2 + which) * H + c];
+        }
+    }
+    red[part][threadIdx.x & 63] = sum;
+    __syncthreads();
+    if (part == 0 && c < ncol) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (job_a) atomicAdd(c < H ? out_w + c : out_b, t);
+        else atomicAdd(dWcol + which + (size_t)c * ldw, t);
+    }
+}
+void tr_reduce_pair(int E, int H, const float* scratch_a, float* out_w, float* out_b, const float* scratch_t, float* dWcol, int ldw, hipStream_t s) {
+    if (E <= 0) return;
+    const int nwg = (E + 31) / 32;               // both producers take 32 edges per workgroup
+    hipLaunchKernelGGL(k_reduce_pair, dim3((H + 1 + 63) / 64, 3, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch_a, out_w, out_b,
+                       nwg, scratch_t, dWcol, ldw);
+}
 size_t tr_partial_scratch_floats(size_t E, size_t H) { return ((E + 4 * GATE_EPW - 1) / (4 * GATE_EPW)) * (H + 4); }
 // the attention gate's adjoint with its two parameter gradients (d_wa [H], d_ba [1]; ignored without attention)
 void tr_gate_bwd(int E, int H, const int* row, const float* pre2, const float* wa, const float* z, int attention, const float* dagg,
-                 float* dpre2, float* scratch, float* d_wa, float* d_ba, float* zero, size_t zero_floats, hipStream_t s) {
+                 float* dpre2, float* scratch, float* d_wa, float* d_ba, float* zero, size_t zero_floats, hipStream_t s,
+                 bool defer_reduce = false) {       // defer_reduce: the caller adds the partial sums up later (tr_reduce_pair)
     if (!E) { if (zero_floats) hipMemsetAsync(zero, 0, zero_floats * sizeof(float), s); return; }
     const int nwg = (E + 4 * GATE_EPW - 1) / (4 * GATE_EPW);
     hipLaunchKernelGGL(k_gate_bwd, dim3(nwg), dim3(256), 0, s, E, H, row, pre2, wa, z, attention, dagg, dpre2, scratch, (float4*)zero, zero_floats / 4);
-    if (attention) hipLaunchKernelGGL(k_partial_reduce, dim3((H + 1 + 63) / 64, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, d_wa, d_ba);
+    if (attention && !defer_reduce) hipLaunchKernelGGL(k_partial_reduce, dim3((H + 1 + 63) / 64, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, d_wa, d_ba);
 }
 // dpre7 from dphi, and d coord_mlp.4.weight
 void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
-                 float* zero, size_t zero_floats, hipStream_t s) {
+                 float* zero, size_t zero_floats, hipStream_t s, bool defer_reduce = false) {
     if (!E) { if (zero_floats) hipMemsetAsync(zero, 0, zero_floats * sizeof(float), s); return; }
     const int nwg = (E + 4 * GATE_EPW - 1) / (4 * GATE_EPW);
     hipLaunchKernelGGL(k_head_bwd, dim3(nwg), dim3(256), 0, s, E, H, dphi, w5, pre7, dpre7, scratch, (float4*)zero, zero_floats / 4);
-    hipLaunchKernelGGL(k_partial_reduce, dim3((H + 63) / 64, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, d_w5, (float*)nullptr);
+    if (!defer_reduce) hipLaunchKernelGGL(k_partial_reduce, dim3((H + 63) / 64, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, d_w5, (float*)nullptr);
 }
 void tr_coord_out(int E, int H, const int* row, const float* c2, const float* w5, const float4* cd, int use_tanh, float range,
                   float* phi, float* accx, hipStream_t s) {
@@ -1515,13 +1559,13 @@ void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float*
 // fused: g = (dY W2^T-pack) * SiLU'(pre1) and its whole tail (H = 256; W = split pack of the transposed weight)
 void cmdgen_dgrad_tail(int E, const float* dY, const void* Wt, const float* pre1, const int* row, const int* col, const float* d0,
                        const float* Wcol, int ldw, const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ,
-                       float* dWcol, float* dX, float* scratch, int pieces, hipStream_t s) {
+                       float* dWcol, float* dX, float* scratch, int pieces, hipStream_t s, bool defer_reduce = false) {
     if (E <= 0) return;
     const int nwg = (E + 31) / 32;
     const TailArgs ta{row, col, d0, Wcol, ldw, X, nc, dcd, n_moving, dP, dQ, scratch, dX};
     if (pieces == 3) hipLaunchKernelGGL((k_dgrad_tail<3>), dim3(nwg), dim3(256), 0, s, E, dY, Wt, pre1, ta);
     else hipLaunchKernelGGL((k_dgrad_tail<1>), dim3(nwg), dim3(256), 0, s, E, dY, Wt, pre1, ta);
-    hipLaunchKernelGGL(k_tail_colsum_reduce, dim3(4, 2, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, 256, scratch, dWcol, ldw);
+    if (!defer_reduce) hipLaunchKernelGGL(k_tail_colsum_reduce, dim3(4, 2, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, 256, scratch, dWcol, ldw);
 }
 size_t tr_edge_tail_scratch_floats(size_t E, size_t H) { return ((E + 4 * TAIL_EPW - 1) / (4 * TAIL_EPW)) * 2 * H; }
 void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s) {
