@@ -480,7 +480,7 @@ class Handle:
         return {n: getattr(kt, n) for n, _ in KernelTimes._fields_}
 
     def set_gemm_mode(self, split_bf16: bool) -> None:
-        """Matrix engine of the sampler's tiles of >= 32 rows: True = split-bf16 (fp32-accurate, default), False = fp32 MFMA."""
+        """Matrix engine of tiles of >= 32 rows (sampler and training step): True = split-bf16 (fp32-accurate, default), False = fp32 MFMA."""
         self._check(self.lib.cmdgen_set_gemm_mode(self.h, int(bool(split_bf16))), 'cmdgen_set_gemm_mode')
 
     def debug_stamps(self, reset: bool = True):

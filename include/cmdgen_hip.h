@@ -286,9 +286,10 @@ int cmdgen_train_loss(cmdgen_handle* h, int32_t l2, float T, const float* net_ou
                       const float* phar_one_hot, const float* tab, const float* kl_sums, float* terms, float* d_eps,
                       float* means, cmdgen_stream stream);
 
-/* GEMM operand precision of the training step: 0 (default) = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = operands
- * rounded to bf16 while staged, fp32 accumulation (v_mfma_f32_32x32x16_bf16).  Parameters, gradients, optimizer state,
- * stored activations and all elementwise math stay fp32 either way. */
+/* GEMM operand precision of the training step's backward products: 0 (default) = fp32 results (fp32-accurate split-bf16
+ * products or, with cmdgen_set_gemm_mode(0), the fp32 matrix instruction), 1 = operands rounded to bf16 (nearest-even),
+ * fp32 accumulation on v_mfma_f32_32x32x16_bf16.  Parameters, gradients, optimizer state, stored activations and all
+ * elementwise math stay fp32 either way. */
 int cmdgen_train_set_precision(cmdgen_handle* h, int32_t bf16_gemm);
 
 /* Sum of squares of a device vector -> host float (the global gradient norm of utils.get_grad_norm,
@@ -348,7 +349,8 @@ int cmdgen_reset_counters(cmdgen_handle* h, cmdgen_stream stream);
 int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket,
                               const float* t, float* eps_phar, cmdgen_kernel_times* out,
                               cmdgen_stream stream);
-/* Matrix engine of the SAMPLER's tile kernels (evaluation, chains; the training step has its own switch above):
+/* Matrix engine of the tile kernels (evaluation, chains, and the fp32 products of the training step: its two forward
+ * edge kernels and every [.,256] x [256,256] data gradient; cmdgen_train_set_precision is the separate bf16-OPERAND switch):
  *   1 (default) = split-bf16: every fp32 operand is the exact sum of three bf16 pieces and every fp32 product is six
  *       exact bf16 products accumulated in fp32 on v_mfma_f32_32x32x16_bf16 - fp32-accurate (the dropped terms are
  *       <= 3 * 2^-24 |a||b|, below the fp32 accumulation rounding both engines share) at about twice the delivered

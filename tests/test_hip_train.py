@@ -265,6 +265,29 @@ def test_pipelined_steps_equal_waiting_steps():
     assert float(d.max()) <= 5 * 1e-3 * 2 and float(d.mean()) <= 2e-6, (float(d.max()), float(d.mean()))
 
 
+def test_training_step_on_the_fp32_instruction_matches_the_split_engine():
+    """cmdgen_set_gemm_mode(0) puts the whole step back on v_mfma_f32_32x32x2_f32 (forward tiles, k_sgemm data gradients, the
+    unfused tail pass): same loss, same gradient as the default split-bf16 engine, and G11 holds for it too."""
+    g = load_golden('g11_train.npz')
+    model, tr, data, g6 = build_trainer()
+    t_int, eps = dev(g6['t_int']), [dev(g6['eps0'])]
+    loss_s, nll_s, _ = tr.loss_and_grad(data, t_int=t_int, eps=eps)
+    grad_s = tr.grad.clone()
+    assert tr.h.query('gemm_split') == 1
+    tr.h.set_gemm_mode(False)
+    assert tr.h.query('gemm_split') == 0
+    loss_f, nll_f, _ = tr.loss_and_grad(data, t_int=t_int, eps=eps)
+    grad_f = tr.grad.clone()
+    tr.h.set_gemm_mode(True)
+    assert abs(float(loss_s) - float(loss_f)) < 2e-6 and abs(float(loss_f) - float(g['step0/loss'])) < 2e-6
+    assert float((grad_s - grad_f).abs().max()) <= GRAD_TOL * float(grad_f.abs().max())
+    gf = grad_f.cpu().numpy()
+    for key, want in g.items():
+        if key.startswith('grad/') and key != 'grad/gamma.gamma':
+            off, cnt = tr.h.param_offset(key[len('grad/dynamics.'):])
+            assert np.abs(gf[off:off + cnt].reshape(want.shape) - want).max() <= GRAD_TOL * max(float(np.abs(want).max()), 1e-6), key
+
+
 def test_staged_backward_equals_single_pass():
     """cmdgen_train_backward_stages (what the overlapped all-reduce drives) over any split of the stages 0..L+1 leaves
     the same flat gradient as the single call, and the chunks HipTrainer reduces are final when their stage is done."""
