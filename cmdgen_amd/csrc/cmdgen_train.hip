@@ -723,3 +723,31 @@ extern "C" int cmdgen_debug_sgemm(cmdgen_handle* h, int32_t ta, int32_t tb, int3
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;
 }
+
+// Y[M,256] (+)= (A0 W0[:, :256] + A1 W1[:, :256]) / div * SiLU'(pre) through the training step's data-gradient kernel (test aid):
+// W0 / W1 dev [256][256] row-major nn.Linear weights (dX = dY W), packed here as the step packs them.  tile_rows 0 = the
+// launcher's choice, 32 / 64 forces the tile; pieces 3 (fp32-accurate) or 1 (bf16 operands).
+extern "C" int cmdgen_debug_dgrad(cmdgen_handle* h, int32_t M, const float* A0, const float* W0, const float* A1, const float* W1,
+                                  float* Y, int32_t accumulate, float div, const float* pre, int32_t pieces, int32_t tile_rows,
+                                  cmdgen_stream stream) {
+    if (!h || !A0 || !W0 || !Y || (A1 && !W1) || M < 1 || (pieces != 1 && pieces != 3)) return fail(h, CMDGEN_EINVAL, "bad arguments");
+    hipSetDevice(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    void* packs = nullptr; void* tab = nullptr;
+    const size_t pack_bytes = (size_t)256 * 256 * 6;
+    HIPCHK(h, hipMalloc(&packs, 2 * pack_bytes));
+    HIPCHK(h, hipMalloc(&tab, 2 * sizeof(RepackSplitT)));
+    // offsets are relative to W0: the second matrix is addressed through the pointer difference (both are device pointers)
+    const RepackSplitT t2[2] = {{0, 256, packs, 1}, {(int)(A1 ? W1 - W0 : 0), 256, (char*)packs + pack_bytes, 1}};
+    HIPCHK(h, hipMemcpyAsync(tab, t2, sizeof t2, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    tr_repack_split_t(W0, tab, A1 ? 2 : 1, s);
+    if (tile_rows) setenv("CMDGEN_DGRAD_MT_DEBUG", tile_rows == 64 ? "64" : "32", 1); else unsetenv("CMDGEN_DGRAD_MT_DEBUG");
+    cmdgen_dgrad_split(M, A0, packs, A1, A1 ? (char*)packs + pack_bytes : nullptr, Y, accumulate != 0, div, pre, s, pieces);
+    unsetenv("CMDGEN_DGRAD_MT_DEBUG");
+    hipError_t e = hipStreamSynchronize(s);
+    hipFree(packs); hipFree(tab);
+    HIPCHK(h, e);
+    HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}

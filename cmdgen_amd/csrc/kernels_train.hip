@@ -550,7 +550,8 @@ void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1,
                         bool accumulate_b = false, float div_b = 1.0f) {
     if (M <= 0) return;
     static const char* mt = getenv("CMDGEN_DGRAD_MT");
-    const bool big = mt ? atoi(mt) == 64 : M >= 24576;
+    const char* dbg = getenv("CMDGEN_DGRAD_MT_DEBUG");           // set by cmdgen_debug_dgrad only
+    const bool big = dbg ? atoi(dbg) == 64 : (mt ? atoi(mt) == 64 : M >= 24576);
     const int acc = accumulate ? 1 : 0, ny = W0b ? 2 : 1;
 #define DG(MT_, NP_) hipLaunchKernelGGL((k_dgrad_split<MT_, NP_>), dim3((M + MT_ - 1) / MT_, ny), dim3(256), 0, s, M, A0, W0, A1, W1, Y, acc, div, pre, \
                                         W0b, Yb, accumulate_b ? 1 : 0, div_b)

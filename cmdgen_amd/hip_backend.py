@@ -74,6 +74,7 @@ SYMBOLS = [
     ('cmdgen_adamw_step_clipped', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
                                             C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), _vp]),
     ('cmdgen_last_grad_norm', C.c_int, [_vp, C.POINTER(C.c_float)]),
+    ('cmdgen_debug_dgrad', C.c_int, [_vp, C.c_int32, _fp, _fp, _fp, _fp, _fp, C.c_int32, C.c_float, _fp, C.c_int32, C.c_int32, _vp]),
     ('cmdgen_debug_sgemm', C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, _fp,
                                      C.c_int32, _fp, C.c_int32, _fp, C.c_int32, C.c_int32, _vp]),
     ('cmdgen_set_step_table', C.c_int, [_vp, C.c_int32, _vp]),
@@ -443,6 +444,15 @@ class Handle:
         out = C.c_float(0)
         self._check(self.lib.cmdgen_last_grad_norm(self.h, C.byref(out)), 'cmdgen_last_grad_norm')
         return out.value
+
+    def debug_dgrad(self, A0, W0, A1=None, W1=None, Y=None, accumulate=False, div=1.0, pre=None, pieces=3, tile_rows=0):
+        """Y (+)= (A0 W0 + A1 W1) / div * SiLU'(pre) through k_dgrad_split (test aid); W0 / W1 views of one [2, 256, 256] tensor."""
+        import torch
+        M = A0.shape[0]
+        out = torch.zeros((M, 256), dtype=torch.float32, device=A0.device) if Y is None else Y
+        self._check(self.lib.cmdgen_debug_dgrad(self.h, M, _ptr(A0), _ptr(W0), _ptr(A1), _ptr(W1), _ptr(out), int(accumulate), float(div),
+                                                _ptr(pre), int(pieces), int(tile_rows), self._stream()), 'cmdgen_debug_dgrad')
+        return out
 
     def debug_sgemm(self, A, B, ta=False, tb=True, bias=None, C_out=None, accumulate=False, split_k=1, bf16=False):
         import torch

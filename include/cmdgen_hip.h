@@ -349,6 +349,14 @@ int cmdgen_reset_counters(cmdgen_handle* h, cmdgen_stream stream);
 int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket,
                               const float* t, float* eps_phar, cmdgen_kernel_times* out,
                               cmdgen_stream stream);
+/* Y[M,256] (+)= (A0 W0 + A1 W1) / div * SiLU'(pre) through the training step's data-gradient kernel (test aid; A1 / pre may be
+ * NULL): W0 / W1 dev [256][256] row-major nn.Linear weights (dX = dY W; when both are given they must lie in ONE device
+ * allocation), packed as the step packs them.  pieces: 3 = fp32-accurate split products, 1 = bf16 operands; tile_rows: 0 =
+ * the launcher's choice, 32 / 64 = forced.  Synchronises the stream. */
+int cmdgen_debug_dgrad(cmdgen_handle* h, int32_t M, const float* A0, const float* W0, const float* A1, const float* W1,
+                       float* Y, int32_t accumulate, float div, const float* pre, int32_t pieces, int32_t tile_rows,
+                       cmdgen_stream stream);
+
 /* Matrix engine of the tile kernels (evaluation, chains, and the fp32 products of the training step: its two forward
  * edge kernels and every [.,256] x [256,256] data gradient; cmdgen_train_set_precision is the separate bf16-OPERAND switch):
  *   1 (default) = split-bf16: every fp32 operand is the exact sum of three bf16 pieces and every fp32 product is six

@@ -126,6 +126,30 @@ def test_training_forward_and_backward_vs_oracle_autograd(H, L, B, kw):
     assert np.abs(g2.cpu().numpy() - 2 * grad).max() <= 1e-3 * np.abs(grad).max()
 
 
+@pytest.mark.parametrize('tile_rows', [32, 64])
+def test_data_gradient_kernel_all_modes(tile_rows):
+    """k_dgrad_split on both tile sizes: ragged M (partial last tile), one and two sources, accumulate, the division and
+    SiLU' epilogues, against fp64; the single-piece mode against the fp64 product of the bf16-rounded operands."""
+    h = make_handle(ModelConfig(hidden_nf=64, n_layers=1))
+    g = torch.Generator().manual_seed(3)
+    W = (torch.rand(2, 256, 256, generator=g) / 8 - 1 / 16).cuda()
+    dsilu = lambda v: torch.sigmoid(v) * (1 + v * (1 - torch.sigmoid(v)))
+    for M in (1, 31, 64, 257, 1000):
+        A0, A1 = torch.randn(M, 256, generator=g).cuda(), torch.randn(M, 256, generator=g).cuda()
+        pre, Y0 = torch.randn(M, 256, generator=g).cuda(), torch.randn(M, 256, generator=g).cuda()
+        want1 = A0.double() @ W[0].double()
+        got = h.debug_dgrad(A0, W[0], tile_rows=tile_rows)
+        assert (got.double() - want1).abs().max() <= 2e-6 * float(want1.abs().max()) + 1e-6, M
+        want2 = Y0.double() + (A0.double() @ W[0].double() + A1.double() @ W[1].double()) / 100.0 * dsilu(pre.double())
+        Y = Y0.clone()
+        h.debug_dgrad(A0, W[0], A1, W[1], Y=Y, accumulate=True, div=100.0, pre=pre, tile_rows=tile_rows)
+        assert (Y.double() - want2).abs().max() <= 3e-6 * float(want2.abs().max()) + 1e-6, M
+        bf = lambda t: t.to(torch.bfloat16).double()
+        want3 = bf(A0) @ bf(W[0])
+        got3 = h.debug_dgrad(A0, W[0], pieces=1, tile_rows=tile_rows)
+        assert (got3.double() - want3).abs().max() <= 2e-5 * float(want3.abs().max()) + 1e-6, M
+
+
 # ------------------------------------------------------------------ the reference's training step (G11)
 def build_trainer(lr=1e-3):
     from argparse import Namespace
