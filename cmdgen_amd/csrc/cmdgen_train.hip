@@ -22,6 +22,7 @@ struct WgradBatch {               // kernels_train.hip: up to 8 weight gradients
     int n;
 };
 void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s);
+extern bool g_wgrad_split;
 struct RepackSplitT { int src_off, ld; void* dst; int transpose; };                                       // kernels_train.hip
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s);
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
@@ -446,6 +447,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         wb.M[q] = r.out; wb.N[q] = in; wb.lddy[q] = r.out; wb.ldx[q] = in; wb.ldw[q] = r.in;
     };
     auto flush_wgrads = [&]() { cmdgen_wgrad_group(wb, N, g_bf16, s); wb.n = 0; };
+    g_wgrad_split = h->gemm_split || g_bf16;                          // weight gradients on the bf16 matrix pipe too (kernels_train.hip)
     const bool sp = t->split_packs_valid && H == 256;                 // [.,256] x [256,256] data gradients on the bf16 matrix pipe:
     const int pcs = g_bf16 ? 1 : 3;                                   // three pieces per operand (fp32-accurate) or the leading one (bf16 operands)
     if (first_stage == 0) {

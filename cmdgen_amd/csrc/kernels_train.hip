@@ -324,10 +324,147 @@ __global__ __launch_bounds__(256) void k_wgrad_group(WgradBatch g, int K, int kc
     }
 }
 
+// ------------------------------------------------------------------------------------
+// The same grouped products on the split-bf16 engine (cmdgen_split.h; every M_p, N_p a multiple of 64, operands 16-byte
+// aligned): the fp32 instruction needs 512 matrix-pipe cycles per 16 k values of a 32 x 32 tile, six bf16 MFMAs need 192.
+// BOTH operands are activations here, so both are split while they are staged: a thread loads eight consecutive k rows of
+// four channels (8 x 16 bytes), splits the eight k values of each channel into the three bf16 pieces in registers (the
+// fragment layout of v_mfma_f32_32x32x16_bf16 wants eight consecutive k per lane: the k-major memory layout is transposed
+// in registers, not with scalar LDS stores) and writes one 16-byte piece per channel and plane: planes [channel][64 + 8].
+// Threads 0-127 stage dY, 128-255 stage X; the next k tile's rows are in flight during the MFMAs.  NPC = 1: leading pieces
+// only (bf16 operands).
+// ------------------------------------------------------------------------------------
+template <int NPC>
+__global__ __launch_bounds__(256, 2) void k_wgrad_split(WgradBatch g, int K, int kchunk, int zsplit) {
+    constexpr int KT = 64, PLD = KT + 8, PE = 64 * PLD;               // bf16 elements per plane row / per plane
+    __shared__ __attribute__((aligned(16))) unsigned short planes[2 * NPC * PE];
+    const int p = blockIdx.z / zsplit, kz = blockIdx.z - p * zsplit;
+    const int M = g.M[p], N = g.N[p];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    if (m0 >= M || n0 >= N) return;
+    const int k_begin = kz * kchunk, k_end = min(K, k_begin + kchunk);
+    if (k_begin >= k_end) return;
+    const bool isB = tid >= 128;
+    const int t = tid & 127, cg = t & 15, kb = t >> 4;                 // channels 4 cg .. 4 cg + 3, k rows 8 kb .. 8 kb + 7 of the tile
+    const float* __restrict__ G = isB ? g.x[p] : g.dy[p];
+    const int ld = isB ? g.ldx[p] : g.lddy[p];
+    const float* gsrc = G + (isB ? n0 : m0) + 4 * cg;
+    unsigned short* mine = planes + (isB ? NPC * PE : 0);
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const bool want_bias = g.db[p] != nullptr && n0 == 0 && !isB;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 v[8];
+    float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + 8 * kb + i;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < k_end) v[i] = *reinterpret_cast<const float4*>(gsrc + (size_t)k * ld);
+        }
+    };
+    fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+        if (want_bias) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { colsum.x += v[i].x; colsum.y += v[i].y; colsum.z += v[i].z; colsum.w += v[i].w; }
+        }
+        {   // transpose in registers: channel c gets the eight k values v[0..7].c, split into the pieces, one 16-byte store per plane
+            const float c0[8] = {v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x};
+            const float c1[8] = {v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y};
+            const float c2[8] = {v[0].z, v[1].z, v[2].z, v[3].z, v[4].z, v[5].z, v[6].z, v[7].z};
+            const float c3[8] = {v[0].w, v[1].w, v[2].w, v[3].w, v[4].w, v[5].w, v[6].w, v[7].w};
+            const float* cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned short* dst = mine + (4 * cg + c) * PLD + 8 * kb;
+                if constexpr (NPC == 3) {
+                    sbf16x8 p0, p1, p2;
+                    split8(make_float4(cc[c][0], cc[c][1], cc[c][2], cc[c][3]), make_float4(cc[c][4], cc[c][5], cc[c][6], cc[c][7]), p0, p1, p2);
+                    *reinterpret_cast<sbf16x8*>(dst) = p0; *reinterpret_cast<sbf16x8*>(dst + PE) = p1; *reinterpret_cast<sbf16x8*>(dst + 2 * PE) = p2;
+                } else {
+                    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                    const u4 q = {cvt_pk_bf16(cc[c][0], cc[c][1]), cvt_pk_bf16(cc[c][2], cc[c][3]), cvt_pk_bf16(cc[c][4], cc[c][5]), cvt_pk_bf16(cc[c][6], cc[c][7])};
+                    *reinterpret_cast<u4*>(dst) = q;
+                }
+            }
+        }
+        __syncthreads();
+        if (k0 + KT < k_end) fetch(k0 + KT);
+        const unsigned short* ap = planes + (wm + (lane & 31)) * PLD + 8 * (lane >> 5);
+        const unsigned short* bp = planes + NPC * PE + (wn + (lane & 31)) * PLD + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KT / 16; ++ks) {
+            sbf16x8 a[NPC], b[NPC];
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) {
+                a[q] = *reinterpret_cast<const sbf16x8*>(ap + q * PE + ks * 16);
+                b[q] = *reinterpret_cast<const sbf16x8*>(bp + q * PE + ks * 16);
+            }
+            if constexpr (NPC == 3) {       // small terms first; every product is exact in fp32
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* C = g.dw[p];
+    const int ldc = g.ldw[p];
+    const int gn = n0 + wn + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        atomicAdd(C + (size_t)gm * ldc + gn, acc[r]);
+    }
+    if (g.db[p] != nullptr && n0 == 0) {   // 8 threads (kb) hold partial sums of the same four channels: combine through LDS
+        float* red = reinterpret_cast<float*>(planes);       // [8][64]
+        if (!isB) *reinterpret_cast<float4*>(red + kb * 64 + 4 * cg) = colsum;
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum += red[q * 64 + tid];
+            atomicAdd(g.db[p] + m0 + tid, sum);
+        }
+    }
+}
+
+bool g_wgrad_split = true;       // cmdgen_train.hip sets it per call from the handle's matrix-engine mode
 void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s) {
     if (g.n <= 0 || K <= 0) return;
     int tm = 1, tn = 1;
     for (int p = 0; p < g.n; ++p) { tm = max(tm, (g.M[p] + 63) / 64); tn = max(tn, (g.N[p] + 63) / 64); }
+    {   // the register-transposing kernel when every problem allows it: always for bf16 operands (one plane per operand: 2.8 vs
+        // 3.0 ms per step at B=64, 7.5 vs 8.2 at B=256); with three pieces per operand (fp32-accurate, CMDGEN_WGRAD_SPLIT=1) it
+        // only ties the fp32 instruction - 144 KB of LDS traffic per 64 k values of a 64 x 64 tile bind it, not the matrix pipe
+        static const bool want3 = getenv("CMDGEN_WGRAD_SPLIT") != nullptr;
+        bool sp = bf16 || (g_wgrad_split && want3);
+        for (int p = 0; p < g.n && sp; ++p)
+            sp = g.M[p] % 64 == 0 && g.N[p] % 64 == 0 && g.lddy[p] % 4 == 0 && g.ldx[p] % 4 == 0 &&
+                 (reinterpret_cast<uintptr_t>(g.dy[p]) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.x[p]) & 15) == 0;
+        if (sp) {
+            int tm = 1, tn = 1;
+            for (int p = 0; p < g.n; ++p) { tm = max(tm, g.M[p] / 64); tn = max(tn, g.N[p] / 64); }
+            static const int wgs = getenv("CMDGEN_WGRAD_SPLIT_WGS") ? atoi(getenv("CMDGEN_WGRAD_SPLIT_WGS")) : 512;
+            int zsplit = (wgs + tm * tn * g.n - 1) / (tm * tn * g.n);
+            const int max_split = (K + 127) / 128;
+            if (zsplit > max_split) zsplit = max_split;
+            if (zsplit < 1) zsplit = 1;
+            const int kchunk = ((K + zsplit - 1) / zsplit + 63) / 64 * 64;
+            zsplit = (K + kchunk - 1) / kchunk;
+            const dim3 grid(tn, tm, g.n * zsplit);
+            if (bf16) hipLaunchKernelGGL(k_wgrad_split<1>, grid, dim3(256), 0, s, g, K, kchunk, zsplit);
+            else hipLaunchKernelGGL(k_wgrad_split<3>, grid, dim3(256), 0, s, g, K, kchunk, zsplit);
+            return;
+        }
+    }
     static const int target_wgs = getenv("CMDGEN_WGRAD_WGS") ? atoi(getenv("CMDGEN_WGRAD_WGS")) : 768;      // 3 workgroups (49 KB of LDS each) per CU; sweep: profiles/r02_t3_training_round2.txt
     int zsplit = (target_wgs + tm * tn * g.n - 1) / (tm * tn * g.n);
     const int max_split = (K + 127) / 128;
