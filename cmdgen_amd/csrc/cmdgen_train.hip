@@ -753,3 +753,20 @@ extern "C" int cmdgen_debug_dgrad(cmdgen_handle* h, int32_t M, const float* A0, 
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;
 }
+
+// dW[M][N] += dY^T X, db[M] += column sums of dY, through the training step's grouped weight-gradient launch (test aid).
+// mode 0: fp32 instruction (k_wgrad_group<false>); 1: bf16 operands (k_wgrad_split<1> where the shape allows, else k_wgrad_group<true>);
+// 3: three-piece split (k_wgrad_split<3>, needs CMDGEN_WGRAD_SPLIT=1 in the environment, else as mode 0).
+extern "C" int cmdgen_debug_wgrad(cmdgen_handle* h, int32_t K, int32_t M, int32_t N, const float* dY, const float* X, float* dW,
+                                  float* db, int32_t mode, cmdgen_stream stream) {
+    if (!h || !dY || !X || !dW || K < 1 || M < 1 || N < 1) return fail(h, CMDGEN_EINVAL, "bad arguments");
+    hipSetDevice(h->device);
+    WgradBatch one; one.n = 1;
+    one.dy[0] = dY; one.x[0] = X; one.dw[0] = dW; one.db[0] = db;
+    one.M[0] = M; one.N[0] = N; one.lddy[0] = M; one.ldx[0] = N; one.ldw[0] = N;
+    g_wgrad_split = mode == 3;
+    cmdgen_wgrad_group(one, K, mode == 1, (hipStream_t)stream);
+    g_wgrad_split = true;
+    HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}

@@ -74,6 +74,7 @@ SYMBOLS = [
     ('cmdgen_adamw_step_clipped', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
                                             C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), _vp]),
     ('cmdgen_last_grad_norm', C.c_int, [_vp, C.POINTER(C.c_float)]),
+    ('cmdgen_debug_wgrad', C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, C.c_int32, _vp]),
     ('cmdgen_debug_dgrad', C.c_int, [_vp, C.c_int32, _fp, _fp, _fp, _fp, _fp, C.c_int32, C.c_float, _fp, C.c_int32, C.c_int32, _vp]),
     ('cmdgen_debug_sgemm', C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, _fp,
                                      C.c_int32, _fp, C.c_int32, _fp, C.c_int32, C.c_int32, _vp]),
@@ -444,6 +445,15 @@ class Handle:
         out = C.c_float(0)
         self._check(self.lib.cmdgen_last_grad_norm(self.h, C.byref(out)), 'cmdgen_last_grad_norm')
         return out.value
+
+    def debug_wgrad(self, dY, X, dW, db=None, mode=0):
+        """dW += dY^T X, db += column sums of dY through the weight-gradient launch (test aid); mode 0 fp32, 1 bf16 operands, 3 split."""
+        K, M = dY.shape
+        N = X.shape[1]
+        assert X.shape[0] == K and tuple(dW.shape) == (M, N) and dY.is_contiguous() and X.is_contiguous() and dW.is_contiguous()
+        self._check(self.lib.cmdgen_debug_wgrad(self.h, K, M, N, _ptr(dY), _ptr(X), _ptr(dW), _ptr(db), int(mode), self._stream()),
+                    'cmdgen_debug_wgrad')
+        return dW
 
     def debug_dgrad(self, A0, W0, A1=None, W1=None, Y=None, accumulate=False, div=1.0, pre=None, pieces=3, tile_rows=0):
         """Y (+)= (A0 W0 + A1 W1) / div * SiLU'(pre) through k_dgrad_split (test aid); W0 / W1 views of one [2, 256, 256] tensor."""

@@ -357,6 +357,12 @@ int cmdgen_debug_dgrad(cmdgen_handle* h, int32_t M, const float* A0, const float
                        float* Y, int32_t accumulate, float div, const float* pre, int32_t pieces, int32_t tile_rows,
                        cmdgen_stream stream);
 
+/* dW[M,N] += dY^T X (dY dev [K,M], X dev [K,N], both contiguous), db[M] += column sums of dY (db may be NULL), through the
+ * training step's weight-gradient launch (test aid).  mode 0 = fp32 instruction, 1 = bf16 operands, 3 = three-piece split
+ * (only with CMDGEN_WGRAD_SPLIT=1 in the environment; otherwise as 0). */
+int cmdgen_debug_wgrad(cmdgen_handle* h, int32_t K, int32_t M, int32_t N, const float* dY, const float* X, float* dW,
+                       float* db, int32_t mode, cmdgen_stream stream);
+
 /* Matrix engine of the tile kernels (evaluation, chains, and the fp32 products of the training step: its two forward
  * edge kernels and every [.,256] x [256,256] data gradient; cmdgen_train_set_precision is the separate bf16-OPERAND switch):
  *   1 (default) = split-bf16: every fp32 operand is the exact sum of three bf16 pieces and every fp32 product is six

@@ -150,6 +150,25 @@ def test_data_gradient_kernel_all_modes(tile_rows):
         assert (got3.double() - want3).abs().max() <= 2e-5 * float(want3.abs().max()) + 1e-6, M
 
 
+@pytest.mark.parametrize('mode', [0, 1])
+def test_weight_gradient_launch(mode):
+    """k_wgrad_group (fp32 instruction) and k_wgrad_split<1> (bf16 operands, register-transposed staging): dW += dY^T X with the
+    bias gradient folded in, on 256 x 256 and on a shape only the generic kernel takes, K not a multiple of anything."""
+    h = make_handle(ModelConfig(hidden_nf=64, n_layers=1))
+    g = torch.Generator().manual_seed(4)
+    for K, M, N in [(3001, 256, 256), (130, 64, 128), (777, 40, 24)]:
+        dY, X = torch.randn(K, M, generator=g).cuda(), torch.randn(K, N, generator=g).cuda()
+        dW0, db0 = torch.randn(M, N, generator=g).cuda(), torch.randn(M, generator=g).cuda()
+        dW, db = dW0.clone(), db0.clone()
+        h.debug_wgrad(dY, X, dW, db, mode=mode)
+        torch.cuda.synchronize()
+        r = (lambda t: t.to(torch.bfloat16).double()) if mode == 1 else (lambda t: t.double())
+        want = dW0.double() + r(dY).t() @ r(X)
+        tol = 2e-5 if mode == 1 else 1e-5
+        assert (dW.double() - want).abs().max() <= tol * float(want.abs().max()), (K, M, N)
+        assert (db.double() - (db0.double() + dY.double().sum(0))).abs().max() <= 1e-5 * float(dY.abs().sum(0).max()), (K, M, N)
+
+
 # ------------------------------------------------------------------ the reference's training step (G11)
 def build_trainer(lr=1e-3):
     from argparse import Namespace
