@@ -21,13 +21,12 @@ struct WgradBatch {               // kernels_train.hip: up to 8 weight gradients
     int M[8], N[8], lddy[8], ldx[8], ldw[8];
     int n;
 };
-void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s);
-extern bool g_wgrad_split;
+void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bool split3 = false);
 struct RepackSplitT { int src_off, ld; void* dst; int transpose; };                                       // kernels_train.hip
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s);
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
                         const float* pre, hipStream_t s, int pieces = 3, const void* W0b = nullptr, float* Yb = nullptr,
-                        bool accumulate_b = false, float div_b = 1.0f);
+                        bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0);
 void tr_reduce_pair(int E, int H, const float* scratch_a, float* out_w, float* out_b, const float* scratch_t, float* dWcol, int ldw, hipStream_t s);
 void tr_silu(const float* in, float* out, size_t n, hipStream_t s);
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
@@ -446,8 +445,8 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         wb.dy[q] = dy; wb.x[q] = x; wb.dw[q] = grad + r.w + col0; wb.db[q] = (with_bias && r.has_bias) ? grad + r.b : nullptr;
         wb.M[q] = r.out; wb.N[q] = in; wb.lddy[q] = r.out; wb.ldx[q] = in; wb.ldw[q] = r.in;
     };
-    auto flush_wgrads = [&]() { cmdgen_wgrad_group(wb, N, g_bf16, s); wb.n = 0; };
-    g_wgrad_split = h->gemm_split || g_bf16;                          // weight gradients on the bf16 matrix pipe too (kernels_train.hip)
+    auto flush_wgrads = [&]() { cmdgen_wgrad_group(wb, N, g_bf16, s, h->gemm_split); wb.n = 0; };
+    const bool w3 = h->gemm_split;                                    // (three-piece weight gradients: opt-in, see cmdgen_wgrad_group)
     const bool sp = t->split_packs_valid && H == 256;                 // [.,256] x [256,256] data gradients on the bf16 matrix pipe:
     const int pcs = g_bf16 ? 1 : 3;                                   // three pieces per operand (fp32-accurate) or the leading one (bf16 operands)
     if (first_stage == 0) {
@@ -511,7 +510,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             WgradBatch one; one.n = 1;
             one.dy[0] = t->actB; one.x[0] = act6; one.dw[0] = grad + b.c2.w; one.db[0] = grad + b.c2.b;
             one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.c2.in;
-            cmdgen_wgrad_group(one, Ec, g_bf16, s);
+            cmdgen_wgrad_group(one, Ec, g_bf16, s, w3);
         }
         if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
         if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
@@ -563,7 +562,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             WgradBatch one; one.n = 1;
             one.dy[0] = t->actA; one.x[0] = act1; one.dw[0] = grad + b.e2.w; one.db[0] = grad + b.e2.b;
             one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.e2.in;
-            cmdgen_wgrad_group(one, E, g_bf16, s);
+            cmdgen_wgrad_group(one, E, g_bf16, s, w3);
         }
         if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
         if (tail_fused)
@@ -744,9 +743,8 @@ extern "C" int cmdgen_debug_dgrad(cmdgen_handle* h, int32_t M, const float* A0, 
     HIPCHK(h, hipMemcpyAsync(tab, t2, sizeof t2, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipStreamSynchronize(s));
     tr_repack_split_t(W0, tab, A1 ? 2 : 1, s);
-    if (tile_rows) setenv("CMDGEN_DGRAD_MT_DEBUG", tile_rows == 64 ? "64" : "32", 1); else unsetenv("CMDGEN_DGRAD_MT_DEBUG");
-    cmdgen_dgrad_split(M, A0, packs, A1, A1 ? (char*)packs + pack_bytes : nullptr, Y, accumulate != 0, div, pre, s, pieces);
-    unsetenv("CMDGEN_DGRAD_MT_DEBUG");
+    cmdgen_dgrad_split(M, A0, packs, A1, A1 ? (char*)packs + pack_bytes : nullptr, Y, accumulate != 0, div, pre, s, pieces, nullptr, nullptr,
+                       false, 1.0f, tile_rows == 64 ? 64 : (tile_rows ? 32 : 0));
     hipError_t e = hipStreamSynchronize(s);
     hipFree(packs); hipFree(tab);
     HIPCHK(h, e);
@@ -764,9 +762,7 @@ extern "C" int cmdgen_debug_wgrad(cmdgen_handle* h, int32_t K, int32_t M, int32_
     WgradBatch one; one.n = 1;
     one.dy[0] = dY; one.x[0] = X; one.dw[0] = dW; one.db[0] = db;
     one.M[0] = M; one.N[0] = N; one.lddy[0] = M; one.ldx[0] = N; one.ldw[0] = N;
-    g_wgrad_split = mode == 3;
-    cmdgen_wgrad_group(one, K, mode == 1, (hipStream_t)stream);
-    g_wgrad_split = true;
+    cmdgen_wgrad_group(one, K, mode == 1, (hipStream_t)stream, mode == 3);
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;
 }

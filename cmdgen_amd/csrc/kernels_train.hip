@@ -436,8 +436,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(WgradBatch g, int K, int
     }
 }
 
-bool g_wgrad_split = true;       // cmdgen_train.hip sets it per call from the handle's matrix-engine mode
-void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s) {
+// split3: allow the three-piece fp32-accurate variant of k_wgrad_split (still needs CMDGEN_WGRAD_SPLIT=1: it only ties the fp32 instruction)
+void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bool split3 = false) {
     if (g.n <= 0 || K <= 0) return;
     int tm = 1, tn = 1;
     for (int p = 0; p < g.n; ++p) { tm = max(tm, (g.M[p] + 63) / 64); tn = max(tn, (g.N[p] + 63) / 64); }
@@ -445,7 +445,7 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s) {
         // 3.0 ms per step at B=64, 7.5 vs 8.2 at B=256); with three pieces per operand (fp32-accurate, CMDGEN_WGRAD_SPLIT=1) it
         // only ties the fp32 instruction - 144 KB of LDS traffic per 64 k values of a 64 x 64 tile bind it, not the matrix pipe
         static const bool want3 = getenv("CMDGEN_WGRAD_SPLIT") != nullptr;
-        bool sp = bf16 || (g_wgrad_split && want3);
+        bool sp = bf16 || (split3 && want3);
         for (int p = 0; p < g.n && sp; ++p)
             sp = g.M[p] % 64 == 0 && g.N[p] % 64 == 0 && g.lddy[p] % 4 == 0 && g.ldx[p] % 4 == 0 &&
                  (reinterpret_cast<uintptr_t>(g.dy[p]) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.x[p]) & 15) == 0;
@@ -684,11 +684,10 @@ void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s
 // bf16, fp32 accumulation: cmdgen_train_set_precision(1))
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
                         const float* pre, hipStream_t s, int pieces = 3, const void* W0b = nullptr, float* Yb = nullptr,
-                        bool accumulate_b = false, float div_b = 1.0f) {
+                        bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0) {
     if (M <= 0) return;
     static const char* mt = getenv("CMDGEN_DGRAD_MT");
-    const char* dbg = getenv("CMDGEN_DGRAD_MT_DEBUG");           // set by cmdgen_debug_dgrad only
-    const bool big = dbg ? atoi(dbg) == 64 : (mt ? atoi(mt) == 64 : M >= 24576);
+    const bool big = force_mt ? force_mt == 64 : (mt ? atoi(mt) == 64 : M >= 24576);     // force_mt: cmdgen_debug_dgrad
     const int acc = accumulate ? 1 : 0, ny = W0b ? 2 : 1;
 #define DG(MT_, NP_) hipLaunchKernelGGL((k_dgrad_split<MT_, NP_>), dim3((M + MT_ - 1) / MT_, ny), dim3(256), 0, s, M, A0, W0, A1, W1, Y, acc, div, pre, \
                                         W0b, Yb, accumulate_b ? 1 : 0, div_b)
