@@ -31,20 +31,10 @@ void tr_reduce_pair(int E, int H, const float* scratch_a, float* out_w, float* o
 void tr_silu(const float* in, float* out, size_t n, hipStream_t s);
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
 void tr_scale(float* x, float a, size_t n, hipStream_t s);
-void tr_axpy(float* y, const float* x, float a, size_t n, hipStream_t s);
-void tr_edge_geom(int E, const int* row, const int* col, const float4* X, float nc, float* r, float4* cd, hipStream_t s);
-void tr_edge_pre(int E, int H, const int* row, const int* col, const float* P, const float* Q, const float* W1, int ldw,
-                 const float* r, const float* d0, float* pre, float* act, hipStream_t s);
-void tr_att_msg(int E, int H, const int* row, const float* m2, const float* wa, const float* ba, int attention, float* z,
-                float* agg, hipStream_t s);
 void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* wa, const float* z, int attention,
                     const float* dagg, const float* pre2, float* dm2, float* dz, hipStream_t s);
-void tr_coord_out(int E, int H, const int* row, const float* c2, const float* w5, const float4* cd, int use_tanh, float range,
-                  float* phi, float* accx, hipStream_t s);
 void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, const float* phi, int use_tanh, float range,
                       float nc, const float* dacc, float dacc_div, int n_moving, float* dphi, float4* dcd, hipStream_t s);
-void tr_geom_bwd(int E, const int* row, const int* col, const float4* X, float nc, const float4* dcd, const float* dr,
-                 int n_moving, float* dX, hipStream_t s);
 void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float* g, const float* d0, const float* Wcol, int ldw,
                       const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ, float* dWcol, float* dX,
                       float* scratch, hipStream_t s);
@@ -59,16 +49,9 @@ void tr_gate_bwd(int E, int H, const int* row, const float* pre2, const float* w
 void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
                  float* zero, size_t zero_floats, hipStream_t s, bool defer_reduce = false);
 void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s);
-void tr_scatter_rows(int E, int H, const int* idx, const float* src, float* dst, hipStream_t s);
-void tr_rowdot(int E, int H, const float* X, const float* w, int ldw, float* out, hipStream_t s);
 void tr_colsum(int E, int H, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s);
 void tr_sum(int n, const float* x, float* out, hipStream_t s);
-void tr_concat_time(int N, int J, int dyn, const float* enc, const float* t, const int* node_sample, float* out, hipStream_t s);
-void tr_positions(int Nl, int Np, const float* xp, int ldp, const float* xq, int ldq, float4* X, hipStream_t s);
-void tr_move(int N, int n_moving, const float4* X, const float* accx, float nf, float4* Xn, hipStream_t s);
-void tr_velocity(int n_moving, const float4* XL, const float4* X0, float* vel, hipStream_t s);
 void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s);
-void tr_eps_out(int n_rows, int F, int row0, const float* vel, const float* dec, float* eps, hipStream_t s);
 void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, float* ddec, hipStream_t s);
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
               float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s, const float* sqnorm = nullptr,

@@ -1,11 +1,9 @@
-// kernels_train.hip - device kernels of the TRAINING step: the same network as
-// kernels_egnn.hip, evaluated layer by layer with every activation the backward pass needs kept in HBM,
-// and the backward pass itself (dgrad + wgrad of every Linear, the gather/scatter adjoints, the geometry
-// adjoints).  Unlike the sampling path this one is not fused: 288 GB of HBM3E holds all edge-level
-// activations of a batch with room to spare (a [E,H] fp32 tensor is ~25 MB at B=64), so the GEMMs run as one
-// generic exact-fp32 MFMA kernel on plain row-major operands (weights are read straight from the flat
-// parameter buffer the optimizer updates - no re-packing per step) and the rest is bandwidth-bound
-// elementwise work.  Fusing it like the sampler is the obvious next step; correctness comes first.
+// kernels_train.hip - device kernels of the TRAINING step other than its forward pass (which is the
+// sampler's fused evaluation in kernels_egnn.hip, instantiated with save hooks): the loss side (noising, loss terms,
+// dL/d eps), the backward pass - data gradients on the split-bf16 engine (k_dgrad_split; k_dgrad_tail with the whole
+// tail pass of an edge list inside), grouped weight gradients (k_wgrad_group, k_wgrad_split), the gate / head adjoints
+// with their parameter reductions, the stand-alone tail pass and the generic exact-fp32 GEMM of the fp32-instruction
+// mode and of the small encoder / decoder products -, the per-step re-packing of the parameters, and AdamW.
 #include "cmdgen_dev.h"
 #include "cmdgen_split.h"
 
@@ -726,68 +724,14 @@ __global__ void k_scale(float* __restrict__ x, float d, size_t n) {      // x /=
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] /= d;
 }
-__global__ void k_axpy(float* __restrict__ y, const float* __restrict__ x, float a, size_t n) {   // y += a x
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] += a * x[i];
-}
 
-// squared distance and coord2diff of every edge of a list (egnn_new.py:265-271) from positions X [N] (float4)
-__global__ void k_edge_geom(int E, const int* __restrict__ row, const int* __restrict__ col, const float4* __restrict__ X,
-                            float norm_constant, float* __restrict__ r_out, float4* __restrict__ cd_out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    const float4 a = X[row[e]], b = X[col[e]];
-    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-    const float r = dx * dx + dy * dy + dz * dz;
-    r_out[e] = r;
-    if (cd_out) {
-        const float den = sqrtf(r + 1e-8f) + norm_constant;
-        cd_out[e] = make_float4(dx / den, dy / den, dz / den, 0.f);
-    }
-}
 
-// pre[e][c] = P[row e][c] + Q[col e][c] + wr[c] r_e + wd[c] d0_e ; act = SiLU(pre).  wr/wd: column 2H / 2H+1 of the
-// first-layer weight (stride ldw between output channels).
-__global__ void k_edge_pre(int E, int H, const int* __restrict__ row, const int* __restrict__ col,
-                           const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ W1, int ldw,
-                           const float* __restrict__ r, const float* __restrict__ d0, float* __restrict__ pre,
-                           float* __restrict__ act) {
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= E) return;
-    const float re = r[e], de = d0[e];
-    const float* p = P + (size_t)row[e] * H;
-    const float* q = Q + (size_t)col[e] * H;
-    for (int c = lane; c < H; c += 64) {
-        const float v = p[c] + q[c] + W1[(size_t)c * ldw + 2 * H] * re + W1[(size_t)c * ldw + 2 * H + 1] * de;
-        pre[(size_t)e * H + c] = v;
-        act[(size_t)e * H + c] = silu_exact(v);
-    }
-}
 
 __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
-// attention gate + message + segment sum (egnn_new.py:37-47): z = wa . m2 + ba, att = sigmoid(z) (1 when the
-// model has no attention), agg[row] += m2 * att.  Saves z.
-__global__ void k_att_msg(int E, int H, const int* __restrict__ row, const float* __restrict__ m2,
-                          const float* __restrict__ wa, const float* __restrict__ ba, int attention,
-                          float* __restrict__ z_out, float* __restrict__ agg) {
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= E) return;
-    const float* m = m2 + (size_t)e * H;
-    float att = 1.0f;
-    if (attention) {
-        float s = 0.f;
-        for (int c = lane; c < H; c += 64) s += m[c] * wa[c];
-        s = wave_sum(s) + ba[0];
-        if (lane == 0) z_out[e] = s;
-        att = 1.0f / (1.0f + expf(-s));
-    }
-    float* a = agg + (size_t)row[e] * H;
-    for (int c = lane; c < H; c += 64) atomicAdd(a + c, m[c] * att);
-}
 
 // adjoint of k_att_msg: dmsg = dagg[row]; dm2 = dmsg*att + dz*wa, dz = (sum_c dmsg*m2) att (1-att); writes
 // dpre2 = dm2 * SiLU'(pre2) to the scratch row and dz[e].
@@ -935,24 +879,6 @@ __global__ __launch_bounds__(256) void k_partial_reduce(int nwg, int H, const fl
     }
 }
 
-// coordinate head (egnn_new.py:87-104): phi = w5 . c2, g = tanh(phi) * range (or phi), accx[row] += cd * g
-__global__ void k_coord_out(int E, int H, const int* __restrict__ row, const float* __restrict__ c2,
-                            const float* __restrict__ w5, const float4* __restrict__ cd, int use_tanh, float range,
-                            float* __restrict__ phi_out, float* __restrict__ accx /* [N][4] */) {
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= E) return;
-    const float* m = c2 + (size_t)e * H;
-    float s = 0.f;
-    for (int c = lane; c < H; c += 64) s += m[c] * w5[c];
-    s = wave_sum(s);
-    if (lane == 0) {
-        phi_out[e] = s;
-        const float g = use_tanh ? tanhf(s) * range : s;
-        const float4 d = cd[e];
-        float* a = accx + (size_t)row[e] * 4;
-        atomicAdd(a, d.x * g); atomicAdd(a + 1, d.y * g); atomicAdd(a + 2, d.z * g);
-    }
-}
 
 // adjoint of k_coord_out + coord2diff: given dacc [N][4] (gradient of the per-node coordinate sums),
 //   dphi = (cd . dacc[row]) * range * (1 - tanh^2 phi);  dcd = g * dacc[row]
@@ -981,30 +907,6 @@ __global__ void k_coord_out_bwd(int E, const int* __restrict__ row, const int* _
     (void)n_moving;
 }
 
-// geometry adjoint of one edge list: given dcd[e] (may be null) and dr[e] (may be null) accumulate dX:
-//   cd = diff / (sqrt(r + 1e-8) + nc), r = |diff|^2
-__global__ void k_geom_bwd(int E, const int* __restrict__ row, const int* __restrict__ col, const float4* __restrict__ X,
-                           float norm_constant, const float4* __restrict__ dcd, const float* __restrict__ dr,
-                           int n_moving, float* __restrict__ dX /* [N][4] */) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    const int i = row[e], j = col[e];
-    if (i == j) return;                                   // diff is identically zero: no dependence on x
-    const float4 a = X[i], b = X[j];
-    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-    const float r = dx * dx + dy * dy + dz * dz;
-    const float sq = sqrtf(r + 1e-8f), den = sq + norm_constant;
-    float gx = 0.f, gy = 0.f, gz = 0.f, gr = dr ? dr[e] : 0.f;
-    if (dcd) {
-        const float4 d = dcd[e];
-        gx = d.x / den; gy = d.y / den; gz = d.z / den;
-        const float dden = -(d.x * dx + d.y * dy + d.z * dz) / (den * den);
-        gr += dden * 0.5f / sq;
-    }
-    gx += 2.0f * dx * gr; gy += 2.0f * dy * gr; gz += 2.0f * dz * gr;
-    if (i < n_moving) { float* p = dX + (size_t)i * 4; atomicAdd(p, gx); atomicAdd(p + 1, gy); atomicAdd(p + 2, gz); }
-    if (j < n_moving) { float* p = dX + (size_t)j * 4; atomicAdd(p, -gx); atomicAdd(p + 1, -gy); atomicAdd(p + 2, -gz); }
-}
 
 // ------------------------------------------------------------------------------------
 // k_edge_tail_bwd: everything the backward pass does with g = dL/d pre1 [E][H] of an edge list (pre1 = P[row] + Q[col]
@@ -1236,29 +1138,6 @@ __global__ void k_outer_silu_bwd(int E, int H, const float* __restrict__ s, cons
     for (int c = lane; c < H; c += 64) g[(size_t)e * H + c] = se * w[c] * dsilu(pre[(size_t)e * H + c]);
 }
 
-// dst[idx[e]][c] += src[e][c]
-__global__ void k_scatter_rows(int E, int H, const int* __restrict__ idx, const float* __restrict__ src, float* __restrict__ dst) {
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= E) return;
-    float* d = dst + (size_t)idx[e] * H;
-    for (int c = lane; c < H; c += 64) atomicAdd(d + c, src[(size_t)e * H + c]);
-}
-// dst[e][c] = src[idx[e]][c]
-__global__ void k_gather_rows(int E, int H, const int* __restrict__ idx, const float* __restrict__ src, float* __restrict__ dst) {
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= E) return;
-    const float* s = src + (size_t)idx[e] * H;
-    for (int c = lane; c < H; c += 64) dst[(size_t)e * H + c] = s[c];
-}
-// out[e] = sum_c X[e][c] * w[c * ldw]
-__global__ void k_rowdot(int E, int H, const float* __restrict__ X, const float* __restrict__ w, int ldw, float* __restrict__ out) {
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= E) return;
-    float s = 0.f;
-    for (int c = lane; c < H; c += 64) s += X[(size_t)e * H + c] * w[(size_t)c * ldw];
-    s = wave_sum(s);
-    if (lane == 0) out[e] = s;
-}
 // out[c * ldo] += sum_e s[e] * X[e][c]   (s may be null = 1): bias gradients, radial / d0 column gradients, att and
 // coordinate-head weight gradients.  One workgroup per 256-row chunk, one column per thread (coalesced rows).
 __global__ void k_colsum(int E, int ncols, const float* __restrict__ X, int ldx, const float* __restrict__ s,
@@ -1305,39 +1184,6 @@ __global__ void k_sum(int n, const float* __restrict__ x, float* __restrict__ ou
     if ((threadIdx.x & 63) == 0) atomicAdd(out, v);
 }
 
-// node features entering the embedding: [encoder output (J) | t of the sample] (dynamics.py:88-99)
-__global__ void k_concat_time(int N, int J, int dyn, const float* __restrict__ enc /* [N][J] */, const float* __restrict__ t,
-                              const int* __restrict__ node_sample, float* __restrict__ out /* [N][dyn] */) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * dyn) return;
-    const int n = i / dyn, k = i - n * dyn;
-    out[i] = k < J ? enc[(size_t)n * J + k] : t[node_sample[n]];
-}
-// positions [N][4] from the two input blocks
-__global__ void k_positions(int Nl, int Np, const float* __restrict__ xh_phar, int ldp, const float* __restrict__ xh_pocket,
-                            int ldq, float4* __restrict__ X) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= Nl + Np) return;
-    const float* s = n < Nl ? xh_phar + (size_t)n * ldp : xh_pocket + (size_t)(n - Nl) * ldq;
-    X[n] = make_float4(s[0], s[1], s[2], 0.f);
-}
-// X_next = X + accx / nf for moving rows, copy otherwise
-__global__ void k_move(int N, int n_moving, const float4* __restrict__ X, const float* __restrict__ accx, float nf,
-                       float4* __restrict__ Xn) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float4 p = X[n];
-    if (n < n_moving) { p.x += accx[(size_t)n * 4] / nf; p.y += accx[(size_t)n * 4 + 1] / nf; p.z += accx[(size_t)n * 4 + 2] / nf; }
-    Xn[n] = p;
-}
-// velocity of the moving nodes, vel[n] = X_L[n] - X_0[n] ([N][4]); joint mode then removes its per-sample mean
-// (remove_mean_batch over all nodes, dynamics.py:133-136)
-__global__ void k_velocity(int n_moving, const float4* __restrict__ XL, const float4* __restrict__ X0, float* __restrict__ vel) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_moving) return;
-    const float4 a = XL[n], b = X0[n];
-    vel[(size_t)n * 4] = a.x - b.x; vel[(size_t)n * 4 + 1] = a.y - b.y; vel[(size_t)n * 4 + 2] = a.z - b.z;
-}
 // v[n] -= mean over the nodes of n's sample (one wave per sample; phar rows then pocket rows).  The projection is
 // symmetric, so the same kernel is its own adjoint (applied to the incoming velocity gradient in backward).
 __global__ __launch_bounds__(64) void k_center_per_sample(Layout lay, float* __restrict__ v /* [N][4] */) {
@@ -1355,14 +1201,6 @@ __global__ __launch_bounds__(64) void k_center_per_sample(Layout lay, float* __r
         float* p = v + (size_t)(i < nl ? pb + i : qb + i - nl) * 4;
         p[0] -= sx; p[1] -= sy; p[2] -= sz;
     }
-}
-// eps[n] = [vel[row0 + n] | decoded features]   (rows of one node type; F = feature count)
-__global__ void k_eps_out(int n_rows, int F, int row0, const float* __restrict__ vel, const float* __restrict__ dec,
-                          float* __restrict__ eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows * (3 + F)) return;
-    const int n = i / (3 + F), k = i - n * (3 + F);
-    eps[i] = k < 3 ? vel[(size_t)(row0 + n) * 4 + k] : dec[(size_t)n * F + k - 3];
 }
 // split d_eps [n_rows][3+F] into dvel [N][4] (rows row0..) and ddec [n_rows][F]
 __global__ void k_eps_bwd(int n_rows, int F, int row0, const float* __restrict__ deps, float* __restrict__ dvel,
@@ -1609,18 +1447,6 @@ void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s) {
     else hipLaunchKernelGGL(k_silu_bwd, EW_GRID(n), 0, s, g, pre, n);
 }
 void tr_scale(float* x, float d, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_scale, EW_GRID(n), 0, s, x, d, n); }
-void tr_axpy(float* y, const float* x, float a, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_axpy, EW_GRID(n), 0, s, y, x, a, n); }
-void tr_edge_geom(int E, const int* row, const int* col, const float4* X, float nc, float* r, float4* cd, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_edge_geom, EW_GRID(E), 0, s, E, row, col, X, nc, r, cd);
-}
-void tr_edge_pre(int E, int H, const int* row, const int* col, const float* P, const float* Q, const float* W1, int ldw,
-                 const float* r, const float* d0, float* pre, float* act, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_edge_pre, ROW_GRID(E), 0, s, E, H, row, col, P, Q, W1, ldw, r, d0, pre, act);
-}
-void tr_att_msg(int E, int H, const int* row, const float* m2, const float* wa, const float* ba, int attention, float* z,
-                float* agg, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_att_msg, ROW_GRID(E), 0, s, E, H, row, m2, wa, ba, attention, z, agg);
-}
 void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* wa, const float* z, int attention,
                     const float* dagg, const float* pre2, float* dm2, float* dz, hipStream_t s) {
     if (E) hipLaunchKernelGGL(k_att_msg_bwd, ROW_GRID(E), 0, s, E, H, row, m2, wa, z, attention, dagg, pre2, dm2, dz);
@@ -1681,17 +1507,9 @@ void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* 
     hipLaunchKernelGGL(k_head_bwd, dim3(nwg), dim3(256), 0, s, E, H, dphi, w5, pre7, dpre7, scratch, (float4*)zero, zero_floats / 4);
     if (!defer_reduce) hipLaunchKernelGGL(k_partial_reduce, dim3((H + 63) / 64, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, d_w5, (float*)nullptr);
 }
-void tr_coord_out(int E, int H, const int* row, const float* c2, const float* w5, const float4* cd, int use_tanh, float range,
-                  float* phi, float* accx, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_coord_out, ROW_GRID(E), 0, s, E, H, row, c2, w5, cd, use_tanh, range, phi, accx);
-}
 void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, const float* phi, int use_tanh, float range,
                       float nc, const float* dacc, float dacc_div, int n_moving, float* dphi, float4* dcd, hipStream_t s) {
     if (E) hipLaunchKernelGGL(k_coord_out_bwd, EW_GRID(E), 0, s, E, row, col, X, phi, use_tanh, range, nc, dacc, dacc_div, n_moving, dphi, dcd);
-}
-void tr_geom_bwd(int E, const int* row, const int* col, const float4* X, float nc, const float4* dcd, const float* dr,
-                 int n_moving, float* dX, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_geom_bwd, EW_GRID(E), 0, s, E, row, col, X, nc, dcd, dr, n_moving, dX);
 }
 void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float* g, const float* d0, const float* Wcol, int ldw,
                       const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ, float* dWcol, float* dX,
@@ -1717,15 +1535,6 @@ size_t tr_edge_tail_scratch_floats(size_t E, size_t H) { return ((E + 4 * TAIL_E
 void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s) {
     if (E) hipLaunchKernelGGL(k_outer_silu_bwd, ROW_GRID(E), 0, s, E, H, sv, w, pre, g);
 }
-void tr_scatter_rows(int E, int H, const int* idx, const float* src, float* dst, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_scatter_rows, ROW_GRID(E), 0, s, E, H, idx, src, dst);
-}
-void tr_gather_rows(int E, int H, const int* idx, const float* src, float* dst, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_gather_rows, ROW_GRID(E), 0, s, E, H, idx, src, dst);
-}
-void tr_rowdot(int E, int H, const float* X, const float* w, int ldw, float* out, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_rowdot, ROW_GRID(E), 0, s, E, H, X, w, ldw, out);
-}
 void tr_colsum(int E, int ncols, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s) {
     if (!E) return;
     if (ncols % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ncols <= 256)
@@ -1736,23 +1545,8 @@ void tr_colsum(int E, int ncols, const float* X, int ldx, const float* sv, float
 void tr_sum(int n, const float* x, float* out, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_sum, dim3(min((n + 255) / 256, 1024)), dim3(256), 0, s, n, x, out);
 }
-void tr_concat_time(int N, int J, int dyn, const float* enc, const float* t, const int* node_sample, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_concat_time, EW_GRID((size_t)N * dyn), 0, s, N, J, dyn, enc, t, node_sample, out);
-}
-void tr_positions(int Nl, int Np, const float* xp, int ldp, const float* xq, int ldq, float4* X, hipStream_t s) {
-    hipLaunchKernelGGL(k_positions, EW_GRID(Nl + Np), 0, s, Nl, Np, xp, ldp, xq, ldq, X);
-}
-void tr_move(int N, int n_moving, const float4* X, const float* accx, float nf, float4* Xn, hipStream_t s) {
-    hipLaunchKernelGGL(k_move, EW_GRID(N), 0, s, N, n_moving, X, accx, nf, Xn);
-}
-void tr_velocity(int n_moving, const float4* XL, const float4* X0, float* vel, hipStream_t s) {
-    if (n_moving) hipLaunchKernelGGL(k_velocity, EW_GRID(n_moving), 0, s, n_moving, XL, X0, vel);
-}
 void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s) {
     hipLaunchKernelGGL(k_center_per_sample, dim3(lay.B), dim3(64), 0, s, lay, v);
-}
-void tr_eps_out(int n_rows, int F, int row0, const float* vel, const float* dec, float* eps, hipStream_t s) {
-    if (n_rows) hipLaunchKernelGGL(k_eps_out, EW_GRID((size_t)n_rows * (3 + F)), 0, s, n_rows, F, row0, vel, dec, eps);
 }
 void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, float* ddec, hipStream_t s) {
     if (n_rows) hipLaunchKernelGGL(k_eps_bwd, EW_GRID((size_t)n_rows * (3 + F)), 0, s, n_rows, F, row0, deps, dvel, ddec);
