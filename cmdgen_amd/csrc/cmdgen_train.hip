@@ -28,11 +28,8 @@ void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1,
                         const float* pre, hipStream_t s, int pieces = 3, const void* W0b = nullptr, float* Yb = nullptr,
                         bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0);
 void tr_reduce_pair(int E, int H, const float* scratch_a, float* out_w, float* out_b, const float* scratch_t, float* dWcol, int ldw, hipStream_t s);
-void tr_silu(const float* in, float* out, size_t n, hipStream_t s);
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
 void tr_scale(float* x, float a, size_t n, hipStream_t s);
-void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* wa, const float* z, int attention,
-                    const float* dagg, const float* pre2, float* dm2, float* dz, hipStream_t s);
 void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, const float* phi, int use_tanh, float range,
                       float nc, const float* dacc, float dacc_div, int n_moving, float* dphi, float4* dcd, hipStream_t s);
 void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float* g, const float* d0, const float* Wcol, int ldw,
@@ -48,9 +45,7 @@ void tr_gate_bwd(int E, int H, const int* row, const float* pre2, const float* w
                  bool defer_reduce = false);
 void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
                  float* zero, size_t zero_floats, hipStream_t s, bool defer_reduce = false);
-void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s);
 void tr_colsum(int E, int H, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s);
-void tr_sum(int n, const float* x, float* out, hipStream_t s);
 void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s);
 void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, float* ddec, hipStream_t s);
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
@@ -122,10 +117,10 @@ struct TrainState {
     float *pre1, *pre2, *z, *pre6, *pre7, *phi;
     float *act1, *act6;                 // SiLU of pre1 / pre6, written by the producing kernel (the x operands of two weight gradients)
     // edge level scratch
-    float *actA, *actB, *r, *rc, *dr, *dz, *dphi, *tail_scratch, *part_scratch;
-    float4 *cd, *dcd;
+    float *actA, *actB, *dphi, *tail_scratch, *part_scratch;
+    float4* dcd;
     // backward node level
-    float *dh, *dX, *dacc, *dagg, *dP, *dQ, *dn, *dhfin, *ddec, *ddeca, *dhdyn, *denca_l, *denca_p;
+    float *dh, *dX, *dagg, *dP, *dQ, *dn, *dhfin, *ddec, *ddeca, *dhdyn, *denca_l, *denca_p;
     float *vel, *qdec1, *qdeca, *qdec_out, *dqdec, *dqdeca;     // velocity [N][4]; residue decoder (joint model's pocket output)
     float* d_scalar;                    // [4] device scalars (sum of squares, ...)
     // the fused forward (the sampler's evaluation kernels with save hooks): per-step packed copies of the parameters
@@ -165,7 +160,7 @@ static int ensure_state(cmdgen_handle* h) {
     NA(t->P, float, N * H); NA(t->Q, float, N * H); NA(t->aggn, float, L * N * H); NA(t->pre3, float, L * N * H);
     NA(t->nact, float, L * N * H); NA(t->accx, float, N * 4); NA(t->hfin, float, N * d.dyn);
     NA(t->dec1, float, Nl * 2 * d.P); NA(t->deca, float, Nl * 2 * d.P); NA(t->dec_out, float, Nl * d.P);
-    NA(t->dh, float, N * H); NA(t->dX, float, N * 4); NA(t->dacc, float, N * 4); NA(t->dagg, float, N * H);
+    NA(t->dh, float, N * H); NA(t->dX, float, N * 4); NA(t->dagg, float, N * H);
     NA(t->dP, float, 2 * N * H); t->dQ = t->dP + N * H;      // adjacent: zeroed by one memset
     NA(t->dn, float, N * H); NA(t->dhfin, float, N * d.dyn);
     NA(t->ddec, float, Nl * d.P); NA(t->ddeca, float, Nl * 2 * d.P); NA(t->dhdyn, float, N * d.dyn);
@@ -257,8 +252,8 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
     EA(t->act1, float, L * ec * H); EA(t->act6, float, L * ecc * H);      // SiLU(pre2) / SiLU(pre7) are recomputed by their one consumer
     EA(t->pre6, float, L * ecc * H); EA(t->pre7, float, L * ecc * H); EA(t->phi, float, L * ecc);
     EA(t->actA, float, em * H); EA(t->actB, float, em * H);
-    EA(t->r, float, ec); EA(t->rc, float, ecc); EA(t->dr, float, em); EA(t->dz, float, ec); EA(t->dphi, float, ecc);
-    EA(t->cd, float4, ecc); EA(t->dcd, float4, ecc);
+    EA(t->dphi, float, ecc);
+    EA(t->dcd, float4, ecc);
     EA(t->tail_scratch, float, std::max(tr_edge_tail_scratch_floats(em, H), tr_partial_scratch_floats(em, H)));
     EA(t->part_scratch, float, tr_partial_scratch_floats(em, H));
 #undef EA
@@ -478,24 +473,18 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         // (dL/d acc = dX / normalization_factor is formed where it is read; every later kernel of the block only adds to dX)
         tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, Nm, t->dphi, t->dcd, s);
         const size_t pq_floats = (size_t)(t->dQ - t->dP) + NH;                            // dP and dQ, adjacent
-        const bool fused_small = H <= 256 && H % 4 == 0;
         const TrainState::PackBlk& pk = t->pack[l];
         static const bool no_fuse_tail = getenv("CMDGEN_NO_DGRAD_TAIL") != nullptr;
         const bool tail_fused = sp && !no_fuse_tail;
-        const bool pair = tail_fused && fused_small;          // the list's two reductions (head / gate partials, tail partials) as one launch
-        if (fused_small) tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, pair ? t->part_scratch : t->tail_scratch, grad + b.c4.w, t->dP, pq_floats, s, pair);   // actB <- dpre7, d coord_mlp.4; clears dP | dQ
-        else {
-            tr_silu(pre7, t->actA, (size_t)Ec * H, s);                                    // c2 (not stored by the forward)
-            tr_colsum(Ec, H, t->actA, H, t->dphi, grad + b.c4.w, 1, s);
-            tr_outer_silu_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, s);
-        }
+        const bool pair = tail_fused;                         // the list's two reductions (head / gate partials, tail partials) as one launch
+        // actB <- dpre7, d coord_mlp.4; also clears dP | dQ (hidden_nf is 64, 128 or 256: cmdgen_create)
+        tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, pair ? t->part_scratch : t->tail_scratch, grad + b.c4.w, t->dP, pq_floats, s, pair);
         {   // weight and bias gradient of coord_mlp.2 in one launch (c1 = act6)
             WgradBatch one; one.n = 1;
             one.dy[0] = t->actB; one.x[0] = act6; one.dw[0] = grad + b.c2.w; one.db[0] = grad + b.c2.b;
             one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.c2.in;
             cmdgen_wgrad_group(one, Ec, g_bf16, s, w3);
         }
-        if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
         if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
             cmdgen_dgrad_tail(Ec, t->actB, pk.t_c2, pre6, w.crow, w.ccol, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
                               t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
@@ -530,24 +519,15 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             tr_scale(t->dagg, d.norm_factor, NH, s);
         }
         // ---- edge model
-        if (fused_small)                                                                  // actA <- dpre2, d att_mlp; clears dP | dQ
-            tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, t->actA, pair ? t->part_scratch : t->tail_scratch,
-                        d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, t->dP, pq_floats, s, pair);
-        else {
-            tr_silu(pre2, t->actB, (size_t)E * H, s);                                     // m2 (not stored by the forward)
-            tr_att_msg_bwd(E, H, w.erow, t->actB, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, pre2, t->actA, t->dz, s);
-            if (d.attention) {
-                tr_colsum(E, H, t->actB, H, t->dz, grad + b.att.w, 1, s);
-                tr_sum(E, t->dz, grad + b.att.b, s);
-            }
-        }
+        // actA <- dpre2, d att_mlp; also clears dP | dQ
+        tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, t->actA, pair ? t->part_scratch : t->tail_scratch,
+                    d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, t->dP, pq_floats, s, pair);
         {   // weight and bias gradient of edge_mlp.2 in one launch (m1 = act1)
             WgradBatch one; one.n = 1;
             one.dy[0] = t->actA; one.x[0] = act1; one.dw[0] = grad + b.e2.w; one.db[0] = grad + b.e2.b;
             one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.e2.in;
             cmdgen_wgrad_group(one, E, g_bf16, s, w3);
         }
-        if (!fused_small) HIPCHK(h, hipMemsetAsync(t->dP, 0, pq_floats * sizeof(float), s));
         if (tail_fused)
             cmdgen_dgrad_tail(E, t->actA, pk.t_e2, pre1, w.erow, w.ecol, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
                               t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);

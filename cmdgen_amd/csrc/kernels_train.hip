@@ -694,24 +694,10 @@ void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1,
 #undef DG
 }
 
-// ------------------------------------------------------------------------------------
-// elementwise / gather / scatter pieces.  Edge-level tensors are [E][H] row-major; a wave walks one row.
-// ------------------------------------------------------------------------------------
-// out = SiLU(in)   (n elements)
-__global__ void k_silu(const float* __restrict__ in, float* __restrict__ out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = silu_exact(in[i]);
-}
 // g <- g * SiLU'(pre)
 __global__ void k_silu_bwd(float* __restrict__ g, const float* __restrict__ pre, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) g[i] *= dsilu(pre[i]);
-}
-__global__ void k_silu4(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const float4 v = in[i];
-    out[i] = make_float4(silu_exact(v.x), silu_exact(v.y), silu_exact(v.z), silu_exact(v.w));
 }
 __global__ void k_silu_bwd4(float4* __restrict__ g, const float4* __restrict__ pre, size_t n4) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -733,27 +719,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 
-// adjoint of k_att_msg: dmsg = dagg[row]; dm2 = dmsg*att + dz*wa, dz = (sum_c dmsg*m2) att (1-att); writes
-// dpre2 = dm2 * SiLU'(pre2) to the scratch row and dz[e].
-__global__ void k_att_msg_bwd(int E, int H, const int* __restrict__ row, const float* __restrict__ m2,
-                              const float* __restrict__ wa, const float* __restrict__ z, int attention,
-                              const float* __restrict__ dagg, const float* __restrict__ pre2, float* __restrict__ dm2,
-                              float* __restrict__ dz_out) {
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= E) return;
-    const float* m = m2 + (size_t)e * H;
-    const float* g = dagg + (size_t)row[e] * H;
-    float att = 1.0f, dz = 0.f;
-    if (attention) {
-        att = 1.0f / (1.0f + expf(-z[e]));
-        float s = 0.f;
-        for (int c = lane; c < H; c += 64) s += g[c] * m[c];
-        dz = wave_sum(s) * att * (1.0f - att);
-        if (lane == 0) dz_out[e] = dz;
-    }
-    for (int c = lane; c < H; c += 64)          // dpre2 = dm2 * SiLU'(pre2)
-        dm2[(size_t)e * H + c] = (g[c] * att + (attention ? dz * wa[c] : 0.f)) * dsilu(pre2[(size_t)e * H + c]);
-}
 
 // ------------------------------------------------------------------------------------
 // The same adjoint in ONE pass over pre2, together with the two reductions that used to follow it (k_colsum4 over m2
@@ -1129,14 +1094,6 @@ __global__ __launch_bounds__(256) void k_tail_colsum_reduce(int nwg, int H, cons
     __syncthreads();
     if (part == 0 && c < H) atomicAdd(dWcol + which + (size_t)c * ldw, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
-// g[e][c] = s[e] * w[c] * SiLU'(pre[e][c])      (dpre7 from dphi and w5)
-__global__ void k_outer_silu_bwd(int E, int H, const float* __restrict__ s, const float* __restrict__ w,
-                                 const float* __restrict__ pre, float* __restrict__ g) {
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= E) return;
-    const float se = s[e];
-    for (int c = lane; c < H; c += 64) g[(size_t)e * H + c] = se * w[c] * dsilu(pre[(size_t)e * H + c]);
-}
 
 // out[c * ldo] += sum_e s[e] * X[e][c]   (s may be null = 1): bias gradients, radial / d0 column gradients, att and
 // coordinate-head weight gradients.  One workgroup per 256-row chunk, one column per thread (coalesced rows).
@@ -1176,12 +1133,6 @@ __global__ __launch_bounds__(256) void k_colsum4(int E, int ncols, const float* 
         atomicAdd(o + 2 * (size_t)ldo, (a.z + b.z) + (c.z + d.z));
         atomicAdd(o + 3 * (size_t)ldo, (a.w + b.w) + (c.w + d.w));
     }
-}
-__global__ void k_sum(int n, const float* __restrict__ x, float* __restrict__ out) {    // out[0] += sum x
-    float v = 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v += x[i];
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, v);
 }
 
 // v[n] -= mean over the nodes of n's sample (one wave per sample; phar rows then pocket rows).  The projection is
@@ -1436,21 +1387,12 @@ void tr_loss(const Layout& lay, const Dims& d, int l2, float T, const float* net
 #define ROW_GRID(E) dim3((unsigned)(((E) + 3) / 4)), dim3(256)        // one wave per row, 4 rows per workgroup
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-void tr_silu(const float* in, float* out, size_t n, hipStream_t s) {
-    if (!n) return;
-    if (n % 4 == 0 && al16(in) && al16(out)) hipLaunchKernelGGL(k_silu4, EW_GRID(n / 4), 0, s, (const float4*)in, (float4*)out, n / 4);
-    else hipLaunchKernelGGL(k_silu, EW_GRID(n), 0, s, in, out, n);
-}
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s) {
     if (!n) return;
     if (n % 4 == 0 && al16(g) && al16(pre)) hipLaunchKernelGGL(k_silu_bwd4, EW_GRID(n / 4), 0, s, (float4*)g, (const float4*)pre, n / 4);
     else hipLaunchKernelGGL(k_silu_bwd, EW_GRID(n), 0, s, g, pre, n);
 }
 void tr_scale(float* x, float d, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_scale, EW_GRID(n), 0, s, x, d, n); }
-void tr_att_msg_bwd(int E, int H, const int* row, const float* m2, const float* wa, const float* z, int attention,
-                    const float* dagg, const float* pre2, float* dm2, float* dz, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_att_msg_bwd, ROW_GRID(E), 0, s, E, H, row, m2, wa, z, attention, dagg, pre2, dm2, dz);
-}
 // The two reductions of an edge list in one launch: blockIdx.y = 0 is k_partial_reduce's job (gate / head partial sums,
 // scratch rows of H + 4 floats), blockIdx.y = 1, 2 are k_tail_colsum_reduce's (radial / d0 column partials, rows of 2 H).
 __global__ __launch_bounds__(256) void k_reduce_pair(int nwg_a, int H, const float* __restrict__ scratch_a, float* __restrict__ out_w,
@@ -1532,18 +1474,12 @@ void cmdgen_dgrad_tail(int E, const float* dY, const void* Wt, const float* pre1
     if (!defer_reduce) hipLaunchKernelGGL(k_tail_colsum_reduce, dim3(4, 2, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, 256, scratch, dWcol, ldw);
 }
 size_t tr_edge_tail_scratch_floats(size_t E, size_t H) { return ((E + 4 * TAIL_EPW - 1) / (4 * TAIL_EPW)) * 2 * H; }
-void tr_outer_silu_bwd(int E, int H, const float* sv, const float* w, const float* pre, float* g, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_outer_silu_bwd, ROW_GRID(E), 0, s, E, H, sv, w, pre, g);
-}
 void tr_colsum(int E, int ncols, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s) {
     if (!E) return;
     if (ncols % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ncols <= 256)
         hipLaunchKernelGGL(k_colsum4, dim3((E + 127) / 128), dim3(256), 0, s, E, ncols, X, ldx, sv, out, ldo);
     else
         hipLaunchKernelGGL(k_colsum, dim3((E + 31) / 32), dim3(256), 0, s, E, ncols, X, ldx, sv, out, ldo);
-}
-void tr_sum(int n, const float* x, float* out, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_sum, dim3(min((n + 255) / 256, 1024)), dim3(256), 0, s, n, x, out);
 }
 void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s) {
     hipLaunchKernelGGL(k_center_per_sample, dim3(lay.B), dim3(64), 0, s, lay, v);
