@@ -331,6 +331,46 @@ def test_training_step_on_the_fp32_instruction_matches_the_split_engine():
             assert np.abs(gf[off:off + cnt].reshape(want.shape) - want).max() <= GRAD_TOL * max(float(np.abs(want).max()), 1e-6), key
 
 
+def test_training_gradient_at_bench_size_both_engines():
+    """The benchmark's own shape (64 CrossDocked-shaped complexes: 3.7k nodes, 36k / 16k edges; H=256, L=5): the gradient of
+    the split-engine step (fused data-gradient + tail kernels, forward edge kernels on the bf16 pipe) against the same step
+    on the fp32 instruction with the stand-alone tail pass - every tensor to GRAD_TOL of its own scale - and the loss."""
+    import importlib.util, os
+    from argparse import Namespace
+    from cmdgen_amd.lightning_modules import PharPocketDDPM
+    from cmdgen_amd.training import HipTrainer
+    spec = importlib.util.spec_from_file_location('bench_train', os.path.join(os.path.dirname(__file__), '..', 'tools', 'bench_train.py'))
+    bt = importlib.util.module_from_spec(spec); spec.loader.exec_module(bt)
+    cfg = ModelConfig()
+    hp = dict(outdir='out', dataset='crossdock', datadir='data', batch_size=64, lr=1e-3,
+              egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=256, n_layers=5, attention=True, tanh=True,
+                                    norm_constant=1, inv_sublayers=1, sin_embedding=False, aggregation_method='sum', normalization_factor=100),
+              diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2', diffusion_noise_precision=1e-5,
+                                         diffusion_loss_type='l2', normalize_factors=[1, 4]),
+              num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
+              eval_params=Namespace(n_eval_samples=100, eval_batch_size=100), mode='pocket_conditioning',
+              node_histogram=np.ones((30, 500)), pocket_representation='CA')
+    model = PharPocketDDPM(**hp)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed=0).items()}, strict=True)
+    tr = HipTrainer(model.cuda())
+    batch = bt.synthetic_batch(64, 7000, torch.device('cuda', 0))
+    gen = torch.Generator().manual_seed(11)
+    t_int = torch.randint(0, 501, (64, 1), generator=gen).float()
+    eps = [torch.randn((int(batch['num_phar_atoms'].sum()), 11), generator=gen).cuda()]
+    loss_s, _, _ = tr.loss_and_grad(batch, t_int=t_int, eps=eps)
+    grad_s = tr.grad.clone()
+    assert tr.h.query('train_edges') > 24576          # the big-list code paths
+    tr.h.set_gemm_mode(False)
+    loss_f, _, _ = tr.loss_and_grad(batch, t_int=t_int, eps=eps)
+    grad_f = tr.grad.clone()
+    tr.h.set_gemm_mode(True)
+    assert abs(float(loss_s) - float(loss_f)) <= 2e-6 * max(1.0, abs(float(loss_f)))
+    for name, p in tr.dyn.named_parameters():
+        off, cnt = tr.h.param_offset(name)
+        a, b = grad_s[off:off + cnt], grad_f[off:off + cnt]
+        assert float((a - b).abs().max()) <= GRAD_TOL * max(float(b.abs().max()), 1e-6), name
+
+
 def test_staged_backward_equals_single_pass():
     """cmdgen_train_backward_stages (what the overlapped all-reduce drives) over any split of the stages 0..L+1 leaves
     the same flat gradient as the single call, and the chunks HipTrainer reduces are final when their stage is done."""
