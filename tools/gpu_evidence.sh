@@ -28,6 +28,14 @@ run 300 python bench.py --gemm fp32 --steps 3 --warmup 1 --north-star-batch 0 --
 for a in "--batch 64" "--batch 256" "--batch 256 --gemm bf16" "--batch 64 --gemm bf16" "--batch 64 --no-pipeline" "--batch 256 --no-pipeline"; do run 200 python tools/bench_train.py --steps 30 --warmup 5 $a 2>/dev/null | tail -1; done > $o/${tag}_train.jsonl
 run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_tstats -- python3 tools/bench_train.py --steps 4 --warmup 2 > /dev/null 2>&1
 cp $(find $o/${tag}_tstats -name "*kernel_stats.csv" | head -1) $o/${tag}_train_kernel_stats_b64.csv; rm -rf $o/${tag}_tstats
+# PMC passes over the training step (HBM-side bytes per launch, wait fractions) and a per-launch timeline of one step
+TA="--steps 2 --warmup 1 --no-pipeline"
+run 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/tp_fetch -- python3 tools/bench_train.py $TA > /dev/null 2>&1
+run 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/tp_write -- python3 tools/bench_train.py $TA > /dev/null 2>&1
+run 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $o/tp_sq -- python3 tools/bench_train.py $TA > /dev/null 2>&1
+run 100 python3 tools/pmc_train.py $o/tp_fetch $o/tp_write $o/tp_sq > $o/${tag}_train_pmc.json; rm -rf $o/tp_fetch $o/tp_write $o/tp_sq
+run 300 rocprofv3 --kernel-trace --output-format csv -d $o/tl -- python3 tools/bench_train.py --steps 4 --warmup 2 --no-pipeline > /dev/null 2>&1
+run 100 python3 tools/train_timeline.py $o/tl > $o/${tag}_train_timeline.txt; rm -rf $o/tl
 run 200 python tools/bench_joint.py --batch 64 --timesteps 1000 2>/dev/null | tail -1 > $o/${tag}_joint.json
 for b in 64 256; do run 100 python tools/steady_profile.py $b 2>/dev/null | tail -1; done > $o/${tag}_trained_geometry_profile.jsonl
 run 100 python tools/steady_profile.py 64 full-atom 2>/dev/null | tail -1 >> $o/${tag}_trained_geometry_profile.jsonl
