@@ -22,6 +22,33 @@ import torch
 from . import utils
 
 
+def per_sample_table(gamma, log_pn, T, n_dims, norm_values, t_int, n_phar, n_pocket) -> torch.Tensor:
+    """[12, B] fp32 table of everything ConditionalDDPM.forward derives from t and the node counts alone
+    (conditional_model.py:206-221, :49-59; en_diffusion.py:227-234), made on the host in numpy with the reference's fp32 op
+    sequence - the `tab` argument of cmdgen_train_noise / cmdgen_train_loss (rows as listed in include/cmdgen_hip.h):
+    alpha_t, sigma_t, t_is_zero, SNR weight, alpha_T, sigma_T, -log_constants_p_x_given_z0, delta_log_px, log p(N), t_int, t,
+    sigma_t * norm_values[1].  gamma: the predefined schedule's lookup table [T+1]; log_pn: log p(n_phar | n_pocket) table."""
+    g, f32 = np.asarray(gamma, dtype=np.float32), np.float32
+    Tf = f32(T)
+    t_int = np.asarray(torch.as_tensor(t_int).detach().to('cpu', torch.float32)).reshape(-1)
+    s, t = (t_int - f32(1)) / Tf, t_int / Tf
+    gamma_s, gamma_t = g[np.rint(s * Tf).astype(np.int64)], g[np.rint(t * Tf).astype(np.int64)]     # s = -1/T wraps to gamma[T], as the reference's lookup
+    gamma_T, gamma_0 = g[int(round(float(Tf)))], g[0]
+    sigmoid = lambda x: (f32(1) / (f32(1) + np.exp(-x, dtype=f32))).astype(f32)
+    n = np.asarray(n_phar, dtype=f32)
+    sub = (n - f32(1)) * f32(n_dims)
+    nv0, nv1 = float(norm_values[0]), float(norm_values[1])
+    sigma_t = np.sqrt(sigmoid(gamma_t))
+    one = np.ones_like(n)
+    tab = np.stack([
+        np.sqrt(sigmoid(-gamma_t)), sigma_t, (t_int == 0).astype(f32), f32(1) - np.exp(-(gamma_s - gamma_t), dtype=f32),
+        np.sqrt(sigmoid(-gamma_T)) * one, np.sqrt(sigmoid(gamma_T)) * one,
+        -(sub * f32(-(0.5 * gamma_0) - 0.5 * np.log(2 * np.pi))), -sub * f32(np.log(nv0)),
+        np.asarray(log_pn, dtype=f32)[np.asarray(n_phar, dtype=np.int64), np.asarray(n_pocket, dtype=np.int64)],
+        t_int, t, sigma_t * f32(nv1)]).astype(f32)
+    return torch.from_numpy(np.ascontiguousarray(tab))
+
+
 class HipTrainer:
     def __init__(self, model, lr: Optional[float] = None, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-12, clip_grad: Optional[bool] = None, process_group=None,
@@ -83,33 +110,12 @@ class HipTrainer:
         return self.fused_loss and type(self.ddpm) is ConditionalDDPM and isinstance(self.ddpm.gamma, PredefinedNoiseSchedule)
 
     def _sample_table(self, t_int, n_phar, n_pocket):
-        """[TT_COLS, B] per-sample scalars of one step (include/cmdgen_hip.h): everything ConditionalDDPM.forward derives
-        from t and the node counts alone (conditional_model.py:206-221, :49-59, en_diffusion.py:227-234), made on the host
-        with the reference's fp32 op sequence."""
+        """[TT_COLS, B] per-sample scalars of one step (include/cmdgen_hip.h), see ``per_sample_table``."""
         ddpm = self.ddpm
         if self._gamma_host is None:
             self._gamma_host = ddpm.gamma.gamma.detach().to('cpu', torch.float32).numpy().copy()
             self._logpn_host = ddpm.size_distribution._table(1, torch.device('cpu')).to(torch.float32).numpy().copy()
-        g, f32 = self._gamma_host, np.float32
-        T = f32(ddpm.T)
-        t_int = np.asarray(t_int.detach().to('cpu', torch.float32)).reshape(-1)
-        s, t = (t_int - f32(1)) / T, t_int / T
-        gamma_s, gamma_t = g[np.rint(s * T).astype(np.int64)], g[np.rint(t * T).astype(np.int64)]     # s = -1/T wraps to gamma[T], as the reference's lookup
-        gamma_T, gamma_0 = g[int(round(float(T)))], g[0]
-        sigmoid = lambda x: (f32(1) / (f32(1) + np.exp(-x, dtype=f32))).astype(f32)
-        n = np.asarray(n_phar, dtype=f32)
-        sub = (n - f32(1)) * f32(ddpm.n_dims)
-        nv0, nv1 = float(ddpm.norm_values[0]), float(ddpm.norm_values[1])
-        sigma_t = np.sqrt(sigmoid(gamma_t))
-        one = np.ones_like(n)
-        tab = np.stack([
-            np.sqrt(sigmoid(-gamma_t)), sigma_t, (t_int == 0).astype(f32), f32(1) - np.exp(-(gamma_s - gamma_t), dtype=f32),
-            np.sqrt(sigmoid(-gamma_T)) * one, np.sqrt(sigmoid(gamma_T)) * one,
-            -(sub * f32(-(0.5 * gamma_0) - 0.5 * np.log(2 * np.pi))), -sub * f32(np.log(nv0)),
-            self._logpn_host[np.asarray(n_phar, dtype=np.int64), np.asarray(n_pocket, dtype=np.int64)],
-            t_int, t, sigma_t * f32(nv1)]).astype(f32)
-        tab = torch.from_numpy(np.ascontiguousarray(tab))
-        return tab
+        return per_sample_table(self._gamma_host, self._logpn_host, ddpm.T, ddpm.n_dims, ddpm.norm_values, t_int, n_phar, n_pocket)
 
     @torch.no_grad()
     def _loss_and_grad_fused(self, data, t_int=None, eps=None):

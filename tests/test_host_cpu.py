@@ -259,3 +259,28 @@ def test_consensus_posp_matches_reference_script(tmp_path):
     src.write_text(json.dumps(cases[0]['input']))
     lines = get_phar.main([str(src), '--out', str(tmp_path / 'o.posp')])
     assert (tmp_path / 'o.posp').read_text() == cases[0]['posp'] and len(lines) == len(cases[0]['posp'].splitlines())
+
+
+def test_per_sample_table_matches_the_tensor_op_scalars():
+    """training.per_sample_table (numpy on the host: the `tab` argument of cmdgen_train_noise / cmdgen_train_loss) against the
+    same per-sample scalars formed with ConditionalDDPM's own tensor operations, t = 0 and t = T included."""
+    from cmdgen_amd.training import per_sample_table
+    model = PharPocketDDPM(**_hparams())
+    ddpm = model.ddpm
+    B = 7
+    t_int = torch.tensor([0., 1., 2., 17., 250., 499., 500.][:B]).reshape(B, 1)
+    n_phar, n_pocket = torch.tensor([3, 5, 8, 12, 15, 20, 9]), torch.tensor([30, 44, 51, 38, 60, 47, 33])
+    tab = per_sample_table(ddpm.gamma.gamma.detach().numpy(), ddpm.size_distribution._table(1, torch.device('cpu')).numpy(), ddpm.T,
+                           ddpm.n_dims, ddpm.norm_values, t_int, n_phar.numpy(), n_pocket.numpy())
+    assert tuple(tab.shape) == (12, B) and tab.dtype == torch.float32
+    x = torch.zeros(B, 3)
+    s, t = (t_int - 1) / ddpm.T, t_int / ddpm.T
+    gamma_s, gamma_t = ddpm.inflate_batch_array(ddpm.gamma(s), x), ddpm.inflate_batch_array(ddpm.gamma(t), x)
+    ones = torch.ones((B, 1))
+    want = [ddpm.alpha(gamma_t, x).reshape(-1), ddpm.sigma(gamma_t, x).reshape(-1), (t_int == 0).float().reshape(-1),
+            (1 - ddpm.SNR(gamma_s - gamma_t)).reshape(-1), ddpm.alpha(ddpm.gamma(ones), x).reshape(-1), ddpm.sigma(ddpm.gamma(ones), x).reshape(-1),
+            -ddpm.log_constants_p_x_given_z0(n_nodes=n_phar, device='cpu'), ddpm.delta_log_px(n_phar).float(), ddpm.log_pN(n_phar, n_pocket),
+            t_int.reshape(-1), t.reshape(-1), ddpm.sigma(gamma_t, x).reshape(-1) * ddpm.norm_values[1]]
+    for i, w in enumerate(want):
+        w = torch.as_tensor(w, dtype=torch.float32).reshape(-1)
+        assert torch.allclose(tab[i], w, rtol=2e-6, atol=1e-7), (i, tab[i], w)
