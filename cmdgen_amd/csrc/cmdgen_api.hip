@@ -1060,11 +1060,11 @@ extern "C" int cmdgen_chain_status(cmdgen_handle* h, float* max_rel, float* max_
     std::vector<unsigned int> chk((size_t)(K + 3) * 2);
     HIPCHK(h, hipMemcpy(chk.data(), h->last_chain_joint ? h->joint.check : h->chain.check, chk.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
     float worst = 0.f;
-    for (int i = 0; i < K + 2; ++i) {
+    for (int i = 0; i < K + 2 && worst == worst; ++i) {
         float largest, err;
         memcpy(&largest, &chk[2 * i], 4); memcpy(&err, &chk[2 * i + 1], 4);
         const float rel = err / (largest + 1e-10f);
-        if (rel > worst) worst = rel;
+        if (rel > worst || rel != rel) worst = rel;      // a NaN sticks: the reference's `assert rel_error < 1e-2` fails on it
     }
     if (max_rel) *max_rel = worst;
     unsigned int cog; HIPCHK(h, hipMemcpy(&cog, h->last_chain_joint ? h->joint_cog : h->d_cog, 4, hipMemcpyDeviceToHost));
@@ -1173,24 +1173,34 @@ extern "C" int cmdgen_time_evaluation(cmdgen_handle* h, const float* xh_phar, co
     rc = begin_work(h, s); if (rc) return rc;
     EvalLaunch a = make_launch(h);
     hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-    HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    // every exit below releases what it holds: a failure between Begin- and EndCapture must still end the capture (the
+    // caller's stream would otherwise stay in capture mode and poison every later launch on it)
+    hipError_t err = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (err != hipSuccess) return fail(h, CMDGEN_EHIP, "hipStreamBeginCapture: %s", hipGetErrorString(err));
     for (int i = 0; i < graph_len; ++i) {
         cmdgen_launch_eval(a, xh_phar, xh_pocket, t, nullptr, nullptr, eps_phar, nullptr, s, nullptr);
         cmdgen_launch_nan_fix(a, eps_phar, s);
     }
-    HIPCHK(h, hipStreamEndCapture(s, &g));
-    HIPCHK(h, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    hipGraphDestroy(g);
-    hipEvent_t e0, e1;
-    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-    HIPCHK(h, hipGraphLaunch(ge, s));                    // warm
-    HIPCHK(h, hipEventRecord(e0, s));
-    for (int i = 0; i < replays; ++i) HIPCHK(h, hipGraphLaunch(ge, s));
-    HIPCHK(h, hipEventRecord(e1, s));
-    HIPCHK(h, hipEventSynchronize(e1));
-    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    const hipError_t launch_err = hipGetLastError();
+    err = hipStreamEndCapture(s, &g);                    // always: also after a failed launch
+    if (err == hipSuccess && launch_err != hipSuccess) err = launch_err;
+    if (err == hipSuccess) err = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (g) hipGraphDestroy(g);
+    if (err == hipSuccess) err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
+    if (err == hipSuccess) err = hipGraphLaunch(ge, s);  // warm
+    if (err == hipSuccess) err = hipEventRecord(e0, s);
+    for (int i = 0; i < replays && err == hipSuccess; ++i) err = hipGraphLaunch(ge, s);
+    if (err == hipSuccess) err = hipEventRecord(e1, s);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (ge) hipGraphExecDestroy(ge);
+    if (err != hipSuccess) return fail(h, CMDGEN_EHIP, "cmdgen_time_evaluation: %s", hipGetErrorString(err));
     *mean_ms = ms / ((float)replays * (float)graph_len);
-    hipEventDestroy(e0); hipEventDestroy(e1); hipGraphExecDestroy(ge);
     return CMDGEN_OK;
 }
 

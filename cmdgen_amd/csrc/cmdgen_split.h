@@ -159,6 +159,90 @@ __device__ __forceinline__ void tile_gemm_rsplit(const float* ldsA, int lda, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// 16-row tiles: v_mfma_f32_16x16x32_bf16 (16 cycles per MFMA; six per fp32 product = 96 matrix cycles per 32 k-values
+// and 16x16 tile against 256 for the eight v_mfma_f32_16x16x4_f32 they replace).  Same split, same fp32 LDS image, same
+// accumulator layout as the fp32 16-row path (row = 4 (lane >> 4) + reg, col = lane & 15).
+//   B (global): Ws16[((nt * KB32 + kb) * 3 + s) * 64 + lane] = 8 bf16 { W_s[o][k_j] }, o = 16 nt + (lane & 15), g = lane >> 4,
+//               k_j = 32 kb + 4 g + j (j < 4) and 32 kb + 16 + 4 g + (j - 4) (j >= 4)
+//   A (LDS):    the lane reads two float4 of row (lane & 15) at k = 32 kb + 4 g and 32 kb + 16 + 4 g - the conflict-free
+//               ds_read_b128 pattern of the fp32 16-row path, twice (the MFMA's k order inside a block is free as long as A and B agree)
+// The weight stream is what binds a 16-row tile (one workgroup streams every weight of the block for 16 rows: 6 B per
+// weight here against 4 B on the fp32 instruction), so fragments are requested THREE k-blocks ahead of their use (a ring
+// of four register sets, 36 KB in flight per wave); the kernel needs the 512-register budget of one wave per SIMD.
+// ---------------------------------------------------------------------------------------------
+struct S16FragPtr { const sbf16x8* p; unsigned ns; };   // a wave's first 16-column tile; ns = stride between n-tiles (16-byte units)
+__device__ __forceinline__ S16FragPtr sfrag16_ptr(const void* Ws16, int kb32_total, int kb0, int cg) {
+    const int lane = threadIdx.x & 63;
+    S16FragPtr f;
+    f.p = reinterpret_cast<const sbf16x8*>(Ws16) + ((size_t)(4 * cg) * kb32_total + kb0) * 192 + lane;
+    f.ns = (unsigned)kb32_total * 192u;
+    return f;
+}
+struct S16Carry { sbf16x8 b[4][4][3]; };                // ring of four k-blocks x [4 n-tiles][3 pieces]
+__device__ __forceinline__ void split16_load_set(const sbf16x8* q, unsigned ns, sbf16x8 (&dst)[4][3]) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) dst[n][s] = q[n * ns + s * 64];
+}
+// a GEMM enters with its k-blocks 0, 1, 2 in sets 0, 1, 2 and leaves with those of `next` there
+__device__ __forceinline__ void split16_prefetch(const S16FragPtr& f, S16Carry& c) {
+    split16_load_set(f.p, f.ns, c.b[0]); split16_load_set(f.p + 192, f.ns, c.b[1]); split16_load_set(f.p + 384, f.ns, c.b[2]);
+}
+
+typedef float sf32x4 __attribute__((ext_vector_type(4)));
+template <int KB32>
+__device__ __forceinline__ void tile_gemm_rsplit16(const float* ldsA, int lda, const S16FragPtr cur, const S16FragPtr next,
+                                                   sf32x4 (&acc)[4], S16Carry& carry) {
+    static_assert(KB32 % 4 == 0, "K must be a multiple of 128");
+    const int lane = threadIdx.x & 63;
+    const float* ap = ldsA + (lane & 15) * lda + (lane >> 4) * 4;
+    float4 raw[2][2];
+    sbf16x8 a[2][3];
+#define R16_LOADA(SET, PTR) { raw[SET][0] = *reinterpret_cast<const float4*>(PTR); raw[SET][1] = *reinterpret_cast<const float4*>((PTR) + 16); }
+#define R16_SPLIT(DST, SET) split8(raw[SET][0], raw[SET][1], a[DST][0], a[DST][1], a[DST][2]);
+    // small terms first, n-tiles interleaved so that consecutive MFMAs never share an accumulator
+#define R16_MFMAS(AS, BS)                                                                                                   \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS][2], carry.b[BS][n][0], acc[n], 0, 0, 0); \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS][1], carry.b[BS][n][1], acc[n], 0, 0, 0); \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS][0], carry.b[BS][n][2], acc[n], 0, 0, 0); \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS][1], carry.b[BS][n][0], acc[n], 0, 0, 0); \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS][0], carry.b[BS][n][1], acc[n], 0, 0, 0); \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS][0], carry.b[BS][n][0], acc[n], 0, 0, 0);
+    // the 16-cycle MFMA holds the vector issue port for 8 cycles: two VALU operations of the next block's split fit each gap
+#define R16_INTERLEAVE()                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 24; ++i) {                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+    // block i: MFMAs on set i % 4; set (i + 3) % 4 <- weight block i + 3 (or block i + 3 - KB32 of `next`);
+    // raw[i % 2] <- A block i + 2; a[(i + 1) % 2] <- split of raw[(i + 1) % 2]
+#define R16_BLOCK(I)                                                                                                        \
+    {                                                                                                                       \
+        const bool tail = kb + (I) + 3 >= KB32;                      /* wave-uniform */                                     \
+        const sbf16x8* q = tail ? next.p + (unsigned)(kb + (I) + 3 - KB32) * 192u : cur.p + (unsigned)(kb + (I) + 3) * 192u; \
+        split16_load_set(q, tail ? next.ns : cur.ns, carry.b[((I) + 3) & 3]);                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        if (kb + (I) + 1 < KB32) { R16_SPLIT(((I) + 1) & 1, ((I) + 1) & 1) }                                                \
+        R16_MFMAS((I) & 1, (I) & 3)                                                                                         \
+        R16_INTERLEAVE()                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        if (kb + (I) + 2 < KB32) { R16_LOADA((I) & 1, ap + (kb + (I) + 2) * 32) }                                           \
+    }
+    R16_LOADA(0, ap)
+    R16_LOADA(1, ap + 32)
+    R16_SPLIT(0, 0)
+#pragma unroll 1
+    for (int kb = 0; kb < KB32; kb += 4) {
+        R16_BLOCK(0) R16_BLOCK(1) R16_BLOCK(2) R16_BLOCK(3)
+    }
+#undef R16_LOADA
+#undef R16_SPLIT
+#undef R16_MFMAS
+#undef R16_INTERLEAVE
+#undef R16_BLOCK
+}
+
+// ---------------------------------------------------------------------------------------------
 // Plane variant for tiles whose PRODUCER can split: the A operand lies in LDS as three bf16 planes
 // [rows][KH + 8] (KH = the k-range held at a time), written once per element by whoever builds the tile
 // (split_store4), so the GEMM loop carries no VALU work at all.  Used by the edge kernels with KH = K/2: two

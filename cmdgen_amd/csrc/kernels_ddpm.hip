@@ -36,22 +36,27 @@ __device__ __forceinline__ void remove_com(float* zx, int ld, int pb, int nl, fl
 }
 
 __device__ __forceinline__ void atomic_max_pos(unsigned int* slot, float v) {
-    atomicMax(slot, __float_as_uint(fabsf(v)));     // non-negative floats order like their bits
+    atomicMax(slot, __float_as_uint(fabsf(v)) & 0x7fffffffu);     // non-negative floats order like their bits (a NaN's sign bit is cleared: any NaN ranks above +Inf)
 }
 
-// records the two maxima assert_mean_zero_with_mask compares (en_diffusion.py:919-924)
+// max that keeps a NaN (fmaxf drops it): torch's x.abs().max() returns NaN as soon as one element is NaN, and the
+// reference's assertion then fails (NaN < 1e-2 is False) - so a NaN must survive into the recorded maxima
+__device__ __forceinline__ float max_nan(float a, float b) { return (a != a || b != b) ? __uint_as_float(0x7fc00000u) : fmaxf(a, b); }
+
+// records the two maxima assert_mean_zero_with_mask compares (en_diffusion.py:919-924).  Non-negative floats order like
+// their bits and the quiet NaN 0x7fc00000 lies above +Inf, so atomicMax on the bits keeps a NaN once one sample has it.
 __device__ __forceinline__ void record_com_check(unsigned int* slot2, const float* zx, int ld, int pb,
                                                  int nl, float scale, int lane) {
     float mx = 0.f;
     for (int i = lane; i < nl; i += 64) {
         const float* p = zx + (size_t)(pb + i) * ld;
-        mx = fmaxf(mx, fmaxf(fabsf(p[0] * scale), fmaxf(fabsf(p[1] * scale), fabsf(p[2] * scale))));
+        mx = max_nan(mx, max_nan(fabsf(p[0] * scale), max_nan(fabsf(p[1] * scale), fabsf(p[2] * scale))));
     }
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    for (int o = 32; o > 0; o >>= 1) mx = max_nan(mx, __shfl_xor(mx, o));
     float s = 0.f;
     if (lane < 3) for (int i = 0; i < nl; ++i) s += zx[(size_t)(pb + i) * ld + lane] * scale;
     s = fabsf(s);
-    s = fmaxf(s, fmaxf(__shfl(s, 1), __shfl(s, 2)));
+    s = max_nan(s, max_nan(__shfl(s, 1), __shfl(s, 2)));
     if (lane == 0) { atomic_max_pos(slot2, mx); atomic_max_pos(slot2 + 1, s); }
 }
 
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(64) void k_chain_final(Layout lay, Dims d, ChainBuf
     float s = 0.f;
     if (lane < 3) for (int i = 0; i < nl; ++i) s += xh_phar_out[(size_t)(pb + i) * ld + lane];
     s = fabsf(s);
-    s = fmaxf(s, fmaxf(__shfl(s, 1), __shfl(s, 2)));
+    s = max_nan(s, max_nan(__shfl(s, 1), __shfl(s, 2)));
     if (lane == 0) atomic_max_pos(cog_slot, s);
     if (b == 0 && lane == 0 && nan_reset) atomicAdd(&w.counters[4], 1ull);
 }
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(64) void k_chain_final(Layout lay, Dims d, ChainBuf
 __global__ __launch_bounds__(64) void k_chain_drift_fix(Layout lay, Dims d, float* __restrict__ xh_phar_out,
                                                         float* __restrict__ xh_pocket_out,
                                                         const unsigned int* cog_slot) {
-    if (d.no_com || __uint_as_float(*cog_slot) <= 5e-2f) return;       // the simple variant's re-centring is the identity (:500-501)
+    if (d.no_com || !(__uint_as_float(*cog_slot) > 5e-2f)) return;       // the simple variant's re-centring is the identity (:500-501)
     const int b = blockIdx.x, lane = threadIdx.x;
     remove_com(xh_phar_out, 3 + d.P, lay.phar_base[b], lay.num_phar[b], xh_pocket_out, 3 + d.R,
                lay.pocket_base[b], lay.num_pocket[b], lane);

@@ -18,8 +18,11 @@ __device__ __forceinline__ SampleView view_of(const Layout& lay, const Dims& d, 
     return SampleView{lay.num_phar[b], lay.num_pocket[b], lay.phar_base[b], lay.pocket_base[b], 3 + d.P, 3 + d.R};
 }
 
+// max that keeps a NaN, and the bit-ordered atomic maximum that keeps one too (see kernels_ddpm.hip: the reference's
+// assertions fail on NaN, so it must reach the host)
+__device__ __forceinline__ float max_nan(float a, float b) { return (a != a || b != b) ? __uint_as_float(0x7fc00000u) : fmaxf(a, b); }
 __device__ __forceinline__ void atomic_max_pos(unsigned int* slot, float v) {
-    atomicMax(slot, __float_as_uint(fabsf(v)));
+    atomicMax(slot, __float_as_uint(fabsf(v)) & 0x7fffffffu);
 }
 
 // raw standard normal of combined draw `draw_idx` for node `i` (phar: 0..nl-1, pocket: 0..np-1) component k
@@ -96,20 +99,20 @@ __device__ __forceinline__ void record_check(unsigned int* slot2, const float* z
     float mx = 0.f;
     for (int i = lane; i < v.nl; i += 64) {
         const float* p = zp + (size_t)(v.pb + i) * v.ldp;
-        mx = fmaxf(mx, fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2]))));
+        mx = max_nan(mx, max_nan(fabsf(p[0]), max_nan(fabsf(p[1]), fabsf(p[2]))));
     }
     for (int i = lane; i < v.np; i += 64) {
         const float* p = zq + (size_t)(v.qb + i) * v.ldq;
-        mx = fmaxf(mx, fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2]))));
+        mx = max_nan(mx, max_nan(fabsf(p[0]), max_nan(fabsf(p[1]), fabsf(p[2]))));
     }
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    for (int o = 32; o > 0; o >>= 1) mx = max_nan(mx, __shfl_xor(mx, o));
     float s = 0.f;
     if (lane < 3) {
         for (int i = 0; i < v.nl; ++i) s += zp[(size_t)(v.pb + i) * v.ldp + lane];
         for (int i = 0; i < v.np; ++i) s += zq[(size_t)(v.qb + i) * v.ldq + lane];
     }
     s = fabsf(s);
-    s = fmaxf(s, fmaxf(__shfl(s, 1), __shfl(s, 2)));
+    s = max_nan(s, max_nan(__shfl(s, 1), __shfl(s, 2)));
     if (lane == 0) { atomic_max_pos(slot2, mx); atomic_max_pos(slot2 + 1, s); }
 }
 
@@ -273,14 +276,14 @@ __global__ __launch_bounds__(64) void k_joint_final(Layout lay, Dims d, JointBuf
         for (int i = 0; i < v.np; ++i) s += xh_pocket_out[(size_t)(v.qb + i) * v.ldq + lane];
     }
     s = fabsf(s);
-    s = fmaxf(s, fmaxf(__shfl(s, 1), __shfl(s, 2)));
+    s = max_nan(s, max_nan(__shfl(s, 1), __shfl(s, 2)));
     if (lane == 0) atomic_max_pos(cog_slot, s);
 }
 
 // batch-wide CoG drift above 5e-2: every sample is re-centred over all its nodes (:636-641)
 __global__ __launch_bounds__(64) void k_joint_drift_fix(Layout lay, Dims d, float* __restrict__ xh_phar_out,
                                                         float* __restrict__ xh_pocket_out, const unsigned int* cog_slot) {
-    if (__uint_as_float(*cog_slot) <= 5e-2f) return;
+    if (!(__uint_as_float(*cog_slot) > 5e-2f)) return;
     const SampleView v = view_of(lay, d, blockIdx.x);
     remove_mean_all(xh_phar_out, xh_pocket_out, v, threadIdx.x);
 }

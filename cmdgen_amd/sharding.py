@@ -27,17 +27,23 @@ def shard_bounds(n_items: int, world: int) -> List[Tuple[int, int]]:
 
 
 def balanced_shard_bounds(cost: Sequence[float], world: int) -> List[Tuple[int, int]]:
-    """Contiguous blocks with near-equal summed cost (e.g. (Np+Nl)*degree per pocket)."""
+    """Contiguous blocks with near-equal summed cost (e.g. (Np+Nl)*degree per pocket).  With at least as many items as
+    ranks every rank gets at least one item, however skewed the costs are (an idle GPU helps nobody, and a rank without
+    pockets has no chain to run); blocks can be empty only when there are fewer items than ranks, as in `shard_bounds`."""
     cost = np.asarray(cost, dtype=np.float64)
+    n = len(cost)
     cum = np.concatenate([[0.0], np.cumsum(cost)])
     total = cum[-1]
     cuts = [0]
     for r in range(1, world):
         target = total * r / world
         k = int(np.searchsorted(cum, target))
-        k = min(max(k, cuts[-1]), len(cost))
+        if n >= world:
+            k = min(max(k, cuts[-1] + 1), n - (world - r))      # leave one item for this rank and one for each later rank
+        else:
+            k = min(max(k, cuts[-1]), n)
         cuts.append(k)
-    cuts.append(len(cost))
+    cuts.append(n)
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
@@ -66,10 +72,14 @@ def _gather_rows(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
     all_gather of the counts, one of the row-padded payload - device tensors stay on the device (RCCL over xGMI
     with the nccl backend, gloo on CPU), nothing is pickled through the host."""
     import torch.distributed as dist
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    # (rows, columns) of every rank: a rank whose block is empty (fewer pockets than ranks) does not know the row width -
+    # it takes it from the ranks that have rows
+    n = torch.tensor([t.shape[0], t.shape[1] if t.dim() > 1 else 0], dtype=torch.int64, device=t.device)
+    shapes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(shapes, n, group=group)
+    counts = [int(c[0].item()) for c in shapes]
+    if t.shape[0] == 0 and t.dim() > 1:
+        t = torch.zeros((0, max(int(c[1].item()) for c in shapes)), dtype=t.dtype, device=t.device)
     cap = max(max(counts), 1)
     pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[:t.shape[0]] = t
@@ -93,9 +103,26 @@ def sample_sharded(sample_fn: Callable, pocket: Dict[str, torch.Tensor], num_nod
         lo, hi = balanced_shard_bounds(cost, world)[rank]
     else:
         lo, hi = shard_bounds(n, world)[rank]
+    if kw.get('seed') is None and world > 1:
+        # device noise is keyed by (seed, global pocket id): the ranks must agree on the seed, and each rank's own global
+        # generator need not be in the same state - rank 0 draws it, everybody takes rank 0's
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            from .equivariant_diffusion.en_diffusion import fresh_seed
+            box = [fresh_seed() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            kw['seed'] = int(box[0])
     sub, nph = slice_pocket(pocket, num_nodes_phar, lo, hi)
     ids = list(range(lo, hi))
-    xh_phar, xh_pocket, phar_mask, pocket_mask = sample_fn(sub, nph, pocket_ids=ids, **kw)
+    if hi > lo:
+        xh_phar, xh_pocket, phar_mask, pocket_mask = sample_fn(sub, nph, pocket_ids=ids, **kw)
+    else:
+        # an empty block (fewer pockets than ranks): nothing to sample; this rank still takes part in the gathers
+        dev = pocket['x'].device
+        xh_phar = torch.zeros((0, 0), dtype=torch.float32, device=dev)
+        xh_pocket = torch.zeros((0, 3 + pocket['one_hot'].shape[1]), dtype=torch.float32, device=dev)
+        phar_mask = torch.zeros((0,), dtype=torch.int64, device=dev)
+        pocket_mask = torch.zeros((0,), dtype=torch.int64, device=dev)
     if not gather or world == 1:
         return xh_phar, xh_pocket, phar_mask + lo, pocket_mask + lo
     return (_gather_rows(xh_phar, world, group), _gather_rows(xh_pocket, world, group),

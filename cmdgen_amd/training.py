@@ -91,6 +91,7 @@ class HipTrainer:
         self.fused_loss = True              # conditional model: noising and loss terms as three library launches (cmdgen_train_noise / _loss)
         self._gamma_host = self._logpn_host = None
         self._last_fused = None
+        self._net_inputs = None
         self.pipelined = False              # True: a step does not wait for its own gradient norm (see optimizer_step)
         self._norm_pending = None
         self.last_grad_norm = None
@@ -99,8 +100,13 @@ class HipTrainer:
 
     # ------------------------------------------------------------------
     def _net(self, z_t, xh_pocket, t, phar_mask, pocket_mask):
-        out = self.h.train_forward(self.theta, z_t.to(torch.float32).contiguous(), xh_pocket.to(torch.float32).contiguous(), t,
-                                   want_pocket=self.joint)
+        # cmdgen_train_forward keeps the raw device pointers of its two inputs: the backward pass reads their feature columns
+        # for the weight gradients of phar_encoder.0 / residue_encoder.0.  Hold the exact tensors handed over (possibly the
+        # temporaries .to().contiguous() made) until the pass has run - otherwise the caching allocator may give their
+        # blocks to the loss side's temporaries in between.
+        z, q = z_t.to(torch.float32).contiguous(), xh_pocket.to(torch.float32).contiguous()
+        self._net_inputs = (z, q)
+        out = self.h.train_forward(self.theta, z, q, t, want_pocket=self.joint)
         return out if self.joint else (out, None)
 
     # ------------------------------------------------------------------ fused loss side (conditional model)
@@ -207,6 +213,7 @@ class HipTrainer:
             d_eps_q = d_eps_q.contiguous()
         self.grad.zero_()
         self._backward(d_eps.contiguous(), d_eps_q)
+        self._net_inputs = None         # (stream-ordered allocator: blocks freed now are reused only behind the queued pass)
         return loss, nll, info
 
     # ------------------------------------------------------------------ data parallelism

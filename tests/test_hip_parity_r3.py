@@ -1,0 +1,137 @@
+"""GPU parity tests, round 3: the in-loop guards driven INTO their triggered branches, and the sampling
+chain at BASELINE configs[1]'s literal size against the reference (golden G14).
+
+* CoG-drift re-projection (conditional_model.py:451-457): a final draw scaled so that |x| ~ 1e6 A leaves several ulp of
+  centre-of-mass residual (> 5e-2 A) after the COM projection; the reference then projects once more.  HIP result vs oracle.
+* ``assert_mean_zero_with_mask`` (en_diffusion.py:919-924) can only fail through a non-finite state (a finite state after
+  the projection has a relative COM error of ~1e-7): an infinite draw makes the sample's mean infinite and its
+  coordinates NaN; ``x.abs().max()`` is then NaN and ``rel_error < 1e-2`` is False.  The device-side maxima must carry
+  the NaN (fmaxf drops it) so that the deferred check raises the reference's AssertionError.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import NoiseTape, load_golden, pocket_dict, rms
+from cmdgen_amd import hip_backend
+from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def new_handle(cfg, sd):
+    h = hip_backend.Handle(cfg.as_dict(), 0)
+    h.load_state_dict(sd)
+    return h
+
+
+def host_step_table(cfg, K):
+    """Per-step scalars evaluated exactly as the reference does (bit-identical table, oracle-side helper)."""
+    from oracle import ref_cpu
+    table = ref_cpu.gamma_table(cfg.noise_schedule, cfg.timesteps, cfg.noise_precision)
+    coef = ref_cpu.step_coefficients(table, cfg.timesteps, K).numpy()
+    g0 = table[0]
+    final = np.array([[float(torch.sqrt(torch.sigmoid(g0))), float(torch.sqrt(torch.sigmoid(-g0))),
+                       float(torch.exp(0.5 * g0)), 0.0]], np.float32)
+    return np.concatenate([coef, final])
+
+
+def small_case(seed=91, B=3, K=4):
+    cfg = ModelConfig(hidden_nf=64, n_layers=2, timesteps=500)
+    sd = make_state_dict(cfg, seed=seed, coord_gain=1e-3)
+    pb = make_pockets(B, 'CA', ragged=True, n_phar=8, first_index=100 * seed)
+    Nl = int(pb.num_nodes_phar.sum())
+    noise = np.random.Generator(np.random.PCG64(seed)).normal(size=(K + 2, Nl, 11)).astype(np.float32)
+    return cfg, sd, pb, K, noise
+
+
+def oracle_chain(cfg, sd, pb, K, noise):
+    """-> oracle outputs and how often it projected onto the COM-free subspace (K+2 draws, +1 when the drift fix fires)"""
+    from oracle import ref_cpu
+    calls = [0]
+    orig = ref_cpu.remove_mean_batch
+
+    def counting(*a, **k):
+        calls[0] += 1
+        return orig(*a, **k)
+    ref_cpu.remove_mean_batch = counting
+    try:
+        with torch.no_grad():
+            out = ref_cpu.sample_given_pocket(ref_cpu.to_torch_params(sd), cfg.as_dict(), pocket_dict(pb), pb.num_nodes_phar,
+                                              timesteps=K, noise=NoiseTape(noise))
+    finally:
+        ref_cpu.remove_mean_batch = orig
+    return out, calls[0]
+
+
+# ----------------------------------------------------------------------------- a16: the drift fix, taken
+@pytest.mark.parametrize('use_graph', [False, True])
+@pytest.mark.parametrize('amp, fires', [(1.0, False), (1e8, True), (1e9, True)])
+def test_cog_drift_reprojection_matches_oracle(amp, fires, use_graph):
+    cfg, sd, pb, K, noise = small_case()
+    noise[K + 1, :, :3] *= amp          # x = mu_x + exp(gamma_0 / 2) * draw: |x| ~ 3e-3 * amp
+    (want, want_p, _, _), n_proj = oracle_chain(cfg, sd, pb, K, noise)
+    assert n_proj == K + 2 + (1 if fires else 0)                       # the oracle took / did not take the branch
+    h = new_handle(cfg, sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    h.set_step_table(K, host_step_table(cfg, K))
+    got, got_p, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=dev(noise), use_graph=use_graph)
+    st = h.chain_status()
+    assert (st['max_cog'] > 5e-2) == fires, st                         # the drift the device recorded BEFORE the fix
+    assert st['max_rel_com_error'] < 1e-2                               # relative error stays ~1e-7: no assertion
+    got, got_p, want, want_p = got.cpu().numpy(), got_p.cpu().numpy(), want.numpy(), want_p.numpy()
+    # same operations in the same order on (nearly) the same numbers: agreement to a few units in the last place of |x|
+    tol = 4.0 * float(np.spacing(np.float32(np.abs(want[:, :3]).max()))) if fires else 1e-4 * max(1.0, float(np.abs(want[:, :3]).max()))
+    assert float(np.abs(got[:, :3] - want[:, :3]).max()) <= tol
+    assert float(np.abs(got_p[:, :3] - want_p[:, :3]).max()) <= tol
+    assert np.array_equal(got[:, 3:], want[:, 3:]) and np.array_equal(got_p[:, 3:], want_p[:, 3:])
+    if fires:
+        # the re-projection moved the result: without it the pocket would sit where the last in-loop projection left it.
+        # The second projection subtracts each sample's residual mean (|residual| / n_b); recompute it from the oracle's output.
+        pm = np.repeat(np.arange(len(pb.size)), pb.num_nodes_phar)
+        resid = np.stack([want[pm == b, :3].sum(0) for b in range(len(pb.size))])
+        assert np.abs(resid).max() <= st['max_cog'] * 4 + 1.0              # still ulp-sized, not grown
+    h.close()
+
+
+# ----------------------------------------------------------------------------- a16: the assertion, failing
+def test_mean_zero_assertion_fires_like_reference():
+    from oracle import ref_cpu
+    cfg, sd, pb, K, noise = small_case(seed=92)
+    noise[2, 5, 1] = np.inf             # one infinite draw in the second posterior step
+    with pytest.raises(AssertionError, match='Mean is not zero, relative_error nan'):
+        with torch.no_grad():
+            ref_cpu.sample_given_pocket(ref_cpu.to_torch_params(sd), cfg.as_dict(), pocket_dict(pb), pb.num_nodes_phar,
+                                        timesteps=K, noise=NoiseTape(noise))
+    # C ABI: the deferred check reports NaN (not 0: fmaxf / `rel > worst` would both have dropped it)
+    h = new_handle(cfg, sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    h.set_step_table(K, host_step_table(cfg, K))
+    for use_graph in (False, True):
+        h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=dev(noise), use_graph=use_graph)
+        st = h.chain_status()
+        assert np.isnan(st['max_rel_com_error']), st
+        assert st['nan_resets'] >= 1                                    # the evaluations after it saw NaN positions (dynamics.py:129-131)
+    h.close()
+    # Python mirror: the same exception, the same text
+    from cmdgen_amd.equivariant_diffusion.dynamics import EGNNDynamics
+    from cmdgen_amd.equivariant_diffusion.conditional_model import ConditionalDDPM
+    dyn = EGNNDynamics(phar_nf=8, residue_nf=20, n_dims=3, joint_nf=32, hidden_nf=64, n_layers=2, attention=True,
+                       tanh=True, norm_constant=1, inv_sublayers=1, normalization_factor=100, aggregation_method='sum',
+                       edge_cutoff=6.0, update_pocket_coords=False)
+    ddpm = ConditionalDDPM(dynamics=dyn, phar_nf=8, residue_nf=20, n_dims=3, timesteps=500,
+                           noise_schedule='polynomial_2', noise_precision=1e-5, loss_type='l2', norm_values=[1, 4],
+                           size_histogram=np.ones((30, 70)))
+    ddpm.load_state_dict({k[len('ddpm.'):]: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    ddpm = ddpm.cuda()
+    pocket = {k: v.cuda() for k, v in pocket_dict(pb).items()}
+    with pytest.raises(AssertionError, match='Mean is not zero, relative_error nan'):
+        ddpm.sample_given_pocket(pocket, torch.from_numpy(pb.num_nodes_phar), timesteps=K, noise=torch.from_numpy(noise))
+    # and a clean chain right after on the same model still passes its checks
+    noise[2, 5, 1] = 0.5
+    ddpm.sample_given_pocket(pocket, torch.from_numpy(pb.num_nodes_phar), timesteps=K, noise=torch.from_numpy(noise))
+    assert ddpm.last_chain_status['max_rel_com_error'] < 1e-2

@@ -39,13 +39,13 @@ def oracle_sampler(cfg, sd, K):
     return fn
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_pockets=5):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(2)
     cfg = ModelConfig(hidden_nf=64, n_layers=2)
     sd = make_state_dict(cfg, seed=5)
-    pb = make_pockets(5, 'CA', ragged=True)
+    pb = make_pockets(n_pockets, 'CA', ragged=True)
     pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot),
               'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
     out = sharding.sample_sharded(oracle_sampler(cfg, sd, 3), pocket, pb.num_nodes_phar, rank, world)
@@ -74,6 +74,49 @@ def test_two_rank_sharded_sampling_equals_single_process():
     want = sharding.sample_sharded(oracle_sampler(cfg, sd, 3), pocket, pb.num_nodes_phar, 0, 1)
     for a, b in zip(got, want):
         assert np.array_equal(a, b.numpy())          # bit-identical: shards are independent
+
+
+def test_rank_with_an_empty_block_still_joins_the_gather():
+    """fewer pockets than ranks: the rank without pockets runs no chain, contributes zero rows of the right width and
+    the gathered result is the single-process result (it used to call the sampler with an empty batch and leave the
+    other ranks waiting in all_gather)"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = ModelConfig(hidden_nf=64, n_layers=2)
+    sd = make_state_dict(cfg, seed=5)
+    pb = make_pockets(1, 'CA', ragged=True)
+    pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot),
+              'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
+    want = sharding.sample_sharded(oracle_sampler(cfg, sd, 3), pocket, pb.num_nodes_phar, 0, 1)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b.numpy())
+
+
+def test_skewed_costs_leave_no_rank_empty():
+    # the searchsorted cuts alone gave [0, 1, 1, 1, 4] here: ranks 1 and 2 without pockets although there are 4 for 4 ranks
+    b = sharding.balanced_shard_bounds([100, 1, 1, 1], 4)
+    assert b == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    # 8 full-atom pockets on 8 GPUs, the first one 2.5x the others
+    b = sharding.balanced_shard_bounds([2.5] + [1.0] * 7, 8)
+    assert all(hi - lo == 1 for lo, hi in b) and b[0][0] == 0 and b[-1][1] == 8
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n, world = int(rng.integers(1, 40)), int(rng.integers(1, 9))
+        cost = rng.pareto(0.7, size=n) + 1e-3
+        b = sharding.balanced_shard_bounds(cost, world)
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        if n >= world:
+            assert all(hi > lo for lo, hi in b)
+        else:
+            assert all(hi >= lo for lo, hi in b)
 
 
 def test_shard_bounds():
