@@ -312,16 +312,17 @@ def main(argv=None):
                  'edge_coord': 'k_coord_proj (EquivariantUpdate.coord_model + P|Q projections of the next block)' if split
                                else 'k_edge_coord (EquivariantUpdate.coord_model)'}
         # which matrix instruction each kernel's tiles ran on: the split engine serves tiles of >= 32 rows
-        launch_cfg = {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid', 'gemm_split')}
+        launch_cfg = {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid', 'gemm_split', 'node16_split')}
         mt_of = {'edge_msg': launch_cfg['edge_mt'], 'node': launch_cfg['node_mt'], 'edge_coord': launch_cfg['coord_mt']}
         on_split = {k: bool(launch_cfg['gemm_split']) and mt_of[k] >= 32 for k in mt_of}
+        on_split['node'] = on_split['node'] or bool(launch_cfg['node16_split'] and mt_of['node'] == 16)
         per_kernel = {}
         for k, (ms_k, n_k) in prof.items():
             avg = ms_k / max(n_k, 1)
             tf = (flop_launch[k] / (avg * 1e-3) / 1e12) if avg > 0 else 0.0
             per_kernel[k] = {'total_ms': ms_k, 'launches': n_k, 'avg_launch_ms': avg, 'flop_per_launch': flop_launch[k],
                              'tflops': tf, 'rows_per_tile': mt_of[k],
-                             'mfma': 'v_mfma_f32_32x32x16_bf16 x6 per fp32 product (split engine)' if on_split[k]
+                             'mfma': ('v_mfma_f32_16x16x32_bf16' if mt_of[k] == 16 else 'v_mfma_f32_32x32x16_bf16') + ' x6 per fp32 product (split engine)' if on_split[k]
                                      else ('v_mfma_f32_16x16x4_f32' if mt_of[k] == 16 else 'v_mfma_f32_32x32x2_f32'),
                              # what the matrix pipe executes: six bf16 FLOPs per algorithmic FLOP against the bf16 peak
                              'executed_frac_of_pipe_peak': (tf * SPLIT_MFMAS_PER_PRODUCT / PEAK_BF16_MFMA_TFLOPS) if on_split[k]

@@ -185,6 +185,27 @@ static std::vector<unsigned short> pack_split(const float* W, int out, int ld, i
     return p;
 }
 
+// the same three pieces in v_mfma_f32_16x16x32_bf16 fragment order (16-row tiles; k order inside a block of 32 as the
+// A-side reads it: lane group g holds k = 4g .. 4g+3 and 16+4g .. 16+4g+3, cmdgen_split.h)
+static std::vector<unsigned short> pack_split16(const float* W, int out, int ld, int c0, int in) {
+    const int NT = out / 16, KB = in / 32;
+    std::vector<unsigned short> p((size_t)NT * KB * 3 * 64 * 8);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int g = lane >> 4;
+                    const int k = 32 * kb + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+                    const float w = W[(size_t)(16 * nt + (lane & 15)) * ld + c0 + k];
+                    const unsigned short h0 = bf16_rne(w); const float r1 = w - bf16_val(h0);
+                    const unsigned short h1 = bf16_rne(r1); const float r2 = r1 - bf16_val(h1);
+                    const unsigned short h2 = bf16_rne(r2);
+                    const size_t base = (((size_t)nt * KB + kb) * 3) * 64 * 8;
+                    p[base + (0 * 64 + lane) * 8 + j] = h0; p[base + (1 * 64 + lane) * 8 + j] = h1; p[base + (2 * 64 + lane) * 8 + j] = h2;
+                }
+    return p;
+}
+
 static int upload_pack(cmdgen_handle* h, const float* W, int out, int in, WPack* wp) {
     const float* dp;
     std::vector<float> p = pack_frag(W, out, in, 0, in);
@@ -195,6 +216,13 @@ static int upload_pack(cmdgen_handle* h, const float* W, int out, int in, WPack*
     void* q; r = dev_alloc(h, h->weight_allocs, &q, ps.size() * sizeof(unsigned short), false); if (r) return r;
     if (hipMemcpy(q, ps.data(), ps.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemcpy H2D failed");
     wp->ws = q;
+    wp->ws16 = nullptr;
+    if (in % 128 == 0) {        // the 16-row split GEMM walks four k-blocks of 32 per iteration
+        const std::vector<unsigned short> p16 = pack_split16(W, out, in, 0, in);
+        r = dev_alloc(h, h->weight_allocs, &q, p16.size() * sizeof(unsigned short), false); if (r) return r;
+        if (hipMemcpy(q, p16.data(), p16.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemcpy H2D failed");
+        wp->ws16 = q;
+    }
     return 0;
 }
 
@@ -517,6 +545,9 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.prof_events = nullptr; a.ablate = 0;
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     a.split = h->gemm_split ? 1 : 0;
+    {   // 16-row node tiles on the split engine too (v_mfma_f32_16x16x32_bf16; H >= 128): k_node<256,16> 35.0 -> 31.4 us at B=64 -
+        // bound by the 6 B/weight stream of one workgroup per 16 rows, not by the matrix pipe (profiles/r03_b_*); CMDGEN_NODE16_SPLIT=0 opts out
+        const char* ev = getenv("CMDGEN_NODE16_SPLIT"); a.split16 = (a.split && h->dims.H >= 128 && !(ev && atoi(ev) == 0)) ? 1 : 0; }
     {   // k_embed: inside a conditional chain only the phar tiles take the full path (the pocket rows come from the per-chain
         // cache), and they are few: 16-row tiles spread them over twice the CUs and halve the two projection passes of each
         // (B=256: 120 tiles of 32 rows 38.6 us -> 240 tiles of 16 rows)
@@ -1149,6 +1180,7 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "edge_grid") *value = a.edge_grid;
     else if (k == "coord_grid") *value = a.coord_grid;
     else if (k == "gemm_split") *value = a.split;
+    else if (k == "node16_split") *value = a.split16;
     else if (k == "train_edges") *value = h->train_E;
     else if (k == "train_coord_edges") *value = h->train_Ec;
     else return fail(h, CMDGEN_EINVAL, "unknown query '%s'", key);

@@ -30,6 +30,7 @@ struct WPack {                  // one Linear weight in the MFMA fragment orders
     const float4* w32;          // v_mfma_f32_32x32x2_f32 order  (64- and 32-row tiles)
     const float4* w16;          // v_mfma_f32_16x16x4_f32 order  (16-row tiles)
     const void*   ws;           // three bf16 pieces per weight in v_mfma_f32_32x32x16_bf16 order (cmdgen_split.h); null in training
+    const void*   ws16;         // the same pieces in v_mfma_f32_16x16x32_bf16 order (16-row tiles on the split engine); null in training
 };
 
 struct LayerW {                 // device pointers to one EquivariantBlock's packed weights
@@ -194,6 +195,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     PocketCache pcache{};       // conditional chains: pocket tiles of k_embed are an axpy from the cache
     int skip_count = 0;         // 1: the radius-graph count pass has run (fused step kernel); 2: both passes have (training)
     int split = 0;              // 1: tiles of >= 32 rows multiply on the bf16 matrix pipe (Eng<MT, true>)
+    int split16 = 0;            // 1: 16-row node tiles too (Eng<16, true>; CMDGEN_NODE16_SPLIT=1)
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     hipStream_t side = nullptr; // when set: k_edge_write runs there, concurrently with k_embed (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -453,8 +455,18 @@ template <int MT> struct Eng<MT, false> {
         tile_gemm<MT, KB8>(lds, lda, cur, next, acc, c);
     }
 };
+template <> struct Eng<16, true> {     // 16-row tiles: v_mfma_f32_16x16x32_bf16, register split, fragments three k-blocks ahead
+    typedef S16FragPtr Frag;
+    typedef S16Carry Carry;
+    static __device__ __forceinline__ Frag frag(const WPack& W, int kb_total8, int kb0_8, int cg) { return sfrag16_ptr(W.ws16, kb_total8 / 4, kb0_8 / 4, cg); }
+    static __device__ __forceinline__ void prefetch(const Frag& f, Carry& c) { split16_prefetch(f, c); }
+    template <int KB8>
+    static __device__ __forceinline__ void gemm(const float* lds, int lda, const Frag cur, const Frag next, TileAcc<16>& acc, Carry& c) {
+        tile_gemm_rsplit16<KB8 / 4>(lds, lda, cur, next, acc.a, c);
+    }
+};
 template <int MT> struct Eng<MT, true> {
-    static_assert(MT == 64 || MT == 32, "the split path has 32x32 MFMA tiles only");
+    static_assert(MT == 64 || MT == 32, "32x32 MFMA tiles (16-row tiles: the specialisation above)");
     typedef SFragPtr Frag;
     typedef SCarry Carry;
     static __device__ __forceinline__ Frag frag(const WPack& W, int kb_total8, int kb0_8, int cg) { return sfrag_ptr(W.ws, kb_total8 / 2, kb0_8 / 2, cg); }

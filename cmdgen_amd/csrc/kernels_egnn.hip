@@ -768,7 +768,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
 // evaluation gathers: P_c|Q_c for this block's coord MLP and P|Q for block l+1's edge MLP.
 // ------------------------------------------------------------------------------------
 template <int H, int MT, bool SAVE, bool SP>
-__global__ __launch_bounds__(H, 2) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
+__global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
                                                int layer, int has_next, TrainSave sv) {
     // Tiles of <= 32 rows keep two LDS images: buf0 = h (kept for the residual), buf1 = agg -> T -> h_new,
     // so h and agg are fetched together and the residual needs no second global read.  64-row tiles
@@ -1190,6 +1190,10 @@ template <int H, int MT, bool SP> static void launch_write_embed(const EvalLaunc
 }
 // SAVE variants (training forward) keep the activations; the sampler's instantiations carry no trace of the stores
 template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, int l, hipStream_t s) {
+    if constexpr (MT == 16 && !SP && H >= 128) {
+        // 16-row tiles on the split engine (v_mfma_f32_16x16x32_bf16): opt-in, see DESIGN section 4a for why it is not the default
+        if (a.split16 && !a.save && a.layers[l].W3.ws16) { launch_node<H, 16, true>(a, l, s); return; }
+    }
     const int nt = (a.lay.N + MT - 1) / MT;
     const int has_next = l + 1 < a.d.L;
     if (a.save) hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],

@@ -135,3 +135,47 @@ def test_joint_model_on_split_engine(mt, monkeypatch):
     import test_hip_joint
     force_tiles(monkeypatch, mt)
     test_hip_joint.test_joint_dynamics_fuzz_vs_oracle()
+
+
+# ----------------------------------------------------------------------------- 16-row tiles on the split engine (round 3)
+@pytest.mark.parametrize('name', [n for n in cases_of(G2) if '_h256_' in n or '_h128_' in n])
+def test_node_kernel_16_row_split_tiles_match_reference(name, monkeypatch):
+    """k_node<H, 16> on v_mfma_f32_16x16x32_bf16 (Eng<16, true>, CMDGEN_NODE16_SPLIT=1): every G2 evaluation fixture with
+    H >= 128 against the reference's output, next to the fp32 16-row kernel."""
+    monkeypatch.setenv('CMDGEN_NODE_MT', '16')
+    cfg, sd, inp = dynamics_case(G2, name)
+    want = G2[name + '/eps_phar']
+    errs = {}
+    for s16 in ('1', '0'):
+        monkeypatch.setenv('CMDGEN_NODE16_SPLIT', s16)
+        h = new_handle(cfg, sd)
+        h.set_layout(G2[name + '/num_nodes_phar'], G2[name + '/pocket_size'])
+        assert h.query('node_mt') == 16
+        eps, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']))
+        torch.cuda.synchronize()
+        errs[s16] = float(np.abs(eps.cpu().numpy() - want).max())
+        h.close()
+    tol = EVAL_TOL * max(1.0, float(np.abs(want).max()))
+    print(f'{name} node tiles of 16 rows: max|d eps| split {errs["1"]:.2e}  fp32 {errs["0"]:.2e}  (tolerance {tol:.1e})')
+    assert errs['1'] <= tol and errs['0'] <= tol
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+@pytest.mark.parametrize('name', cases_of(G13))
+def test_bounded_chain_with_16_row_split_node_tiles(name, use_graph, monkeypatch):
+    """The G13 reference chains (K = 50, K = T = 500) with the node kernel on 16-row split tiles: 1e-4 A absolute."""
+    monkeypatch.setenv('CMDGEN_NODE_MT', '16')
+    monkeypatch.setenv('CMDGEN_NODE16_SPLIT', '1')
+    cfg, sd, pb, K = bounded_case(G13, name)
+    h = new_handle(cfg, sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    h.set_step_table(K, host_step_table(cfg, K))
+    xh_phar, xh_pocket, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=dev(G13[name + '/noise']), use_graph=use_graph)
+    st = h.chain_status()
+    want = G13[name + '/xh_phar']
+    err = rms(xh_phar[:, :3].cpu().numpy(), want[:, :3])
+    print(f'{name} graph={use_graph} 16-row split node tiles: coordinate RMS vs reference {err:.3e} A')
+    assert err <= 1e-4
+    assert np.array_equal(xh_phar[:, 3:].cpu().numpy(), want[:, 3:])
+    assert st['max_rel_com_error'] < 1e-2 and st['nan_resets'] == 0
+    h.close()
