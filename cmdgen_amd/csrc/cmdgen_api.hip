@@ -423,7 +423,7 @@ static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, 
         ALLOC(w.pocketEns, int, cB, true); ALLOC(w.pocketEnsQ, int, cB, true);
         ALLOC(w.erow, int, ce, false); ALLOC(w.ecol, int, ce, false); ALLOC(w.ed0, float, ce, false);
         ALLOC(w.crow, int, cec, false); ALLOC(w.ccol, int, cec, false); ALLOC(w.cd0, float, cec, false);
-        ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true);
+        ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true); ALLOC(w.sync, int, 4, true);
         ALLOC(w.eps_tmp, float, (size_t)cNl * (3 + d.P), true);
         ALLOC(w.dbg, unsigned long long, 64, true);
 #undef ALLOC
@@ -545,6 +545,11 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.prof_events = nullptr; a.ablate = 0;
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     a.split = h->gemm_split ? 1 : 0;
+    a.n_cus = h->n_cus;
+    {   // k_coord_msg (coordinate update of block l-1 + messages of block l in one launch): measured and OFF by default -
+        // the tiles that wait are the launch's critical path (coordinate chain + message chain in series, exactly as two
+        // launches), and at the trained geometry every message tile waits: profiles/r03_c_merged_coord_msg.txt
+        const char* ev = getenv("CMDGEN_MERGE_COORD"); a.merge_coord = (h->dims.H == 256 && ev && atoi(ev) != 0) ? 1 : 0; }
     {   // 16-row node tiles on the split engine too (v_mfma_f32_16x16x32_bf16; H >= 128): k_node<256,16> 35.0 -> 31.4 us at B=64 -
         // bound by the 6 B/weight stream of one workgroup per 16 rows, not by the matrix pipe (profiles/r03_b_*); CMDGEN_NODE16_SPLIT=0 opts out
         const char* ev = getenv("CMDGEN_NODE16_SPLIT"); a.split16 = (a.split && h->dims.H >= 128 && !(ev && atoi(ev) == 0)) ? 1 : 0; }
@@ -1103,6 +1108,8 @@ extern "C" int cmdgen_chain_status(cmdgen_handle* h, float* max_rel, float* max_
     unsigned long long cnt[8];
     HIPCHK(h, hipMemcpy(cnt, h->work.counters, sizeof cnt, hipMemcpyDeviceToHost));
     if (nan_resets) *nan_resets = (int64_t)cnt[4];
+    if (cnt[5] != 0)        // k_coord_msg: a message tile gave up waiting for the coordinate sums of its own launch (never seen; would mean wrong positions)
+        return fail(h, CMDGEN_EHIP, "k_coord_msg: %llu waits for the in-launch coordinate sums timed out; results of this chain are invalid (CMDGEN_MERGE_COORD=0 disables the merged launch)", cnt[5]);
     return CMDGEN_OK;
 }
 

@@ -114,6 +114,7 @@ struct Work {                   // per-layout workspace; all pointers device
     int*    totals;             // [0]=E, [1]=Ec (coordinate list) of the current evaluation
     unsigned long long* counters;   // cmdgen_counters
     int*    nan_flag;           // [1] set by readout when any velocity is NaN
+    int*    sync;               // [4] [0]: coordinate-role workgroups of the running k_coord_msg launch that have finished (reset by k_node)
     float*  eps_tmp;            // [Nl][3+P] evaluation output used by the chain
     unsigned long long* dbg;    // [64] diagnostic builds only (-DCMDGEN_STAMPS): summed in-kernel cycle stamps
 };
@@ -195,7 +196,9 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     PocketCache pcache{};       // conditional chains: pocket tiles of k_embed are an axpy from the cache
     int skip_count = 0;         // 1: the radius-graph count pass has run (fused step kernel); 2: both passes have (training)
     int split = 0;              // 1: tiles of >= 32 rows multiply on the bf16 matrix pipe (Eng<MT, true>)
-    int split16 = 0;            // 1: 16-row node tiles too (Eng<16, true>; CMDGEN_NODE16_SPLIT=1)
+    int split16 = 0;            // 1: 16-row node tiles too (Eng<16, true>; CMDGEN_NODE16_SPLIT=0 opts out)
+    int merge_coord = 0;        // 1: k_edge_coord(l-1) and k_edge_msg(l) share a launch (k_coord_msg; sampler, H = 256)
+    int n_cus = 256;
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     hipStream_t side = nullptr; // when set: k_edge_write runs there, concurrently with k_embed (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

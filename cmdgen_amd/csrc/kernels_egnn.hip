@@ -469,12 +469,17 @@ __global__ __launch_bounds__(256) void k_write_embed(Layout lay, Work w, Dims d,
 // the fly (same expression, same bits) by k_edge_msg(l), which runs before it.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 node_pos(const Layout& lay, const Work& w, const Dims& d, int n,
-                                           int layer, bool lazy) {
+                                           int layer, bool lazy, bool fresh = false) {
     if (n >= lay.Nm) return w.XP[n - lay.Nl];
     if (layer == 0) return w.X0[n];
     if (!lazy) return w.XL[(size_t)layer * lay.Nm + n];
     const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nm + n];
-    const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
+    float4 a;
+    if (fresh) {    // the sums were added by other workgroups of THIS launch (k_coord_msg): L2-served loads (global_load ... sc1)
+        const float* q = reinterpret_cast<const float*>(w.ACC + (size_t)(layer - 1) * lay.Nm + n);
+        a.x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a.y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.z = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a.w = 0.f;
+    } else a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
     return make_float4(p.x + a.x / d.norm_factor, p.y + a.y / d.norm_factor, p.z + a.z / d.norm_factor, 0.f);
 }
 
@@ -601,9 +606,10 @@ __device__ __forceinline__ float tile_row_dot(const float* buf, const float* wv,
 // Giving every XCD group one contiguous range of tiles keeps the P/Q rows it gathers (edges are sorted
 // by sample and receiver) inside that L2 instead of spreading every sample over all eight.
 // Placement only affects speed, never results.  Returns the k-th tile of this workgroup or -1.
-__device__ __forceinline__ int xcd_tile(int k, int ntiles) {
-    const int g = blockIdx.x & 7, nb = gridDim.x;
-    const int wg_in_g = blockIdx.x >> 3;
+__device__ __forceinline__ int xcd_tile(int k, int ntiles, int vb = (int)blockIdx.x, int nb = (int)gridDim.x) {
+    // vb / nb: the workgroup's index / count inside its role (a launch may hold two roles: k_coord_msg); vb % 8 == blockIdx % 8
+    const int g = vb & 7;
+    const int wg_in_g = vb >> 3;
     const int wgs_in_g = (nb - g + 7) >> 3;                 // workgroups whose blockIdx % 8 == g
     const int per_g = (ntiles + 7) >> 3;                    // tiles per XCD group (last group may be short)
     const int t = wg_in_g + k * wgs_in_g;
@@ -612,21 +618,62 @@ __device__ __forceinline__ int xcd_tile(int k, int ntiles) {
     return tile < ntiles ? tile : -1;
 }
 
+// number of workgroups of a role of nb workgroups that xcd_tile gives at least one of ntiles tiles (the same on every workgroup)
+__device__ __forceinline__ int xcd_active_wgs(int ntiles, int nb) {
+    const int per_g = (ntiles + 7) >> 3;
+    int n = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int wgs_in_g = (nb - g + 7) >> 3;
+        const int tiles_g = max(0, min(per_g, ntiles - g * per_g));
+        n += min(wgs_in_g, tiles_g);
+    }
+    return n;
+}
+
 // ------------------------------------------------------------------------------------
-// k_edge_msg: GCL.edge_model + attention gate + segment sum by receiver for MT-edge tiles
+// LDS of an edge-tile workgroup, shared by the two edge bodies (a launch that holds both - k_coord_msg - runs them one
+// after the other in the same bytes).
+// ------------------------------------------------------------------------------------
+template <int H, int MT> struct EdgeLds {
+    float buf[MT * LDA(H)];                 // A tile (fp32 image or bf16 planes), then the epilogue's m tile
+    int s_row[MT], s_col[MT];
+    float s_r[MT], s_d0[MT], s_att[MT];
+    float s_cd[MT][3], s_tr[MT][3];         // coordinate body only
+    float s_vec[H];                         // att_mlp / coord_mlp.4 weight: read by every tile's row dot (LDS broadcast, not 16 L1 round trips)
+    float s_wrd[2 * H];                     // radial / d0 weight columns (plane variant)
+};
+
+// Wait (one lane spins, bounded) until every coordinate-role workgroup of this launch has added its sums: `done` counts
+// them.  A give-up is counted in counters[5] and reported by cmdgen_chain_status - a wrong result, never a hung GPU.
+__device__ __forceinline__ void wait_coord_done(const Work& w, const int* done, int target) {
+    if ((threadIdx.x & 63) == 0) {
+        int it = 0;
+        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++it > (1 << 22)) { atomicAdd(&w.counters[5], 1ull); break; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // keeps the position loads below the poll (nothing to invalidate: see node_pos)
+}
+
+// ------------------------------------------------------------------------------------
+// edge_msg_body / k_edge_msg: GCL.edge_model + attention gate + segment sum by receiver for MT-edge tiles
 // of the compact list.  Persistent-style grid: tiles are taken round-robin until the
 // device-side edge count is exhausted, so the launch geometry is static (graph-capturable).
+// vb / nb: this workgroup's index / the number of workgroups walking the list.  done != null (k_coord_msg): the
+// coordinate sums of the previous block are being added by workgroups of the SAME launch; a tile that reads positions
+// of moving nodes waits for them first (tiles of pocket-pocket edges do not).
 // ------------------------------------------------------------------------------------
 template <int H, int MT, bool SAVE, bool SP>
-__global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer, int ablate, TrainSave sv) {
-    __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
-    __shared__ int s_row[MT], s_col[MT];
-    __shared__ float s_r[MT], s_d0[MT], s_att[MT];
-    __shared__ __attribute__((aligned(16))) float s_wa[H];     // att_mlp weight: read by every tile's row dot (LDS broadcast, not 16 L1 round trips)
+__device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT>& L, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
+                                              const int layer, const int ablate, const TrainSave& sv, const int vb, const int nb,
+                                              const int* done, const int done_target) {
+    float* buf = L.buf; int* s_row = L.s_row; int* s_col = L.s_col;
+    float* s_r = L.s_r; float* s_d0 = L.s_d0; float* s_att = L.s_att; float* s_wa = L.s_vec; float* s_wrd = L.s_wrd;
     const int tid = threadIdx.x, wave = tid >> 6;
     s_wa[tid] = lw.wa[tid];                                    // visible after the first tile's barriers
-    constexpr bool PL = SP && H == 256;                        // plane variant: the producer splits (build_edge_half)
-    __shared__ __attribute__((aligned(16))) float s_wrd[PL ? 2 * H : 4];
+    constexpr bool PL = SP && H == 256 && MT >= 32;            // plane variant: the producer splits (build_edge_half)
     if constexpr (PL) { s_wrd[tid] = lw.wr_e[tid]; s_wrd[H + tid] = lw.wd_e[tid]; }
     const ColVec<MT> b2v = col_load<MT>(lw.b2, wave);          // per-column bias and the gate's bias: once per workgroup
     const float ba0 = lw.ba[0];
@@ -639,6 +686,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
                                 // refilled for the next tile by each GEMM's last iteration
     const int E = w.totals[0];
     const int ntiles = (E + MT - 1) / MT;
+    bool coord_seen = done == nullptr || layer == 0;           // wave-uniform: the previous block's coordinate sums are complete
 #if CMDGEN_STAMPS == 1
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_t;
@@ -650,22 +698,27 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
     // build / GEMM, so a tile's first phase starts with the position loads instead of two dependent round trips.
     int nx_row = -1, nx_col = -1; float nx_d0 = 0.f;
     {
-        const int t0 = xcd_tile(0, ntiles);
+        const int t0 = xcd_tile(0, ntiles, vb, nb);
         if (t0 >= 0 && tid < MT && t0 * MT + tid < E) { nx_row = w.erow[t0 * MT + tid]; nx_col = w.ecol[t0 * MT + tid]; nx_d0 = w.ed0[t0 * MT + tid]; }
     }
-    for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
+    for (int k = 0, tile; (tile = xcd_tile(k, ntiles, vb, nb)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
         if (tid < MT) {
             const int row = nx_row, col = nx_col; const float d0 = nx_d0;       // -1 / -1 / 0 beyond the list's end
             nx_row = -1; nx_col = -1; nx_d0 = 0.f;
-            const int tn = xcd_tile(k + 1, ntiles);
+            const int tn = xcd_tile(k + 1, ntiles, vb, nb);
             if (tn >= 0 && tn * MT + tid < E) { nx_row = w.erow[tn * MT + tid]; nx_col = w.ecol[tn * MT + tid]; nx_d0 = w.ed0[tn * MT + tid]; }
+            if (!coord_seen) {
+                // (MT <= 64: these are lanes of wave 0 only) does any edge of the tile end in a node that moves?
+                const bool touch = row >= 0 && (row < lay.Nm || col < lay.Nm);
+                if (__ballot(touch) != 0ull) { wait_coord_done(w, done, done_target); coord_seen = true; }
+            }
             float r = 0.f;
             if (tid < ne) {
                 // block 0 sees the input positions: its radial IS the d0 the graph pass stored (same dist2, same operands, same
                 // bits) - no position round trip; later blocks form the lazily updated positions (node_pos)
-                r = ((ablate & 1) || layer == 0) ? d0 : dist2(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
+                r = ((ablate & 1) || layer == 0) ? d0 : dist2(node_pos(lay, w, d, row, layer, true, done != nullptr), node_pos(lay, w, d, col, layer, true, done != nullptr));
             }
             s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
         }
@@ -760,6 +813,11 @@ __global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, L
 #endif
 #undef STAMP
 }
+template <int H, int MT, bool SAVE, bool SP>
+__global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer, int ablate, TrainSave sv) {
+    __shared__ __attribute__((aligned(16))) EdgeLds<H, MT> L;
+    edge_msg_body<H, MT, SAVE, SP>(L, lay, w, d, lw, layer, ablate, sv, (int)blockIdx.x, (int)gridDim.x, nullptr, 0);
+}
 
 // ------------------------------------------------------------------------------------
 // k_node: GCL.node_model for an MT-node tile (egnn_new.py:48-58)
@@ -796,6 +854,7 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
     // it is used costs that epilogue an L2 round trip: k_node 38.3 -> 34.2 us at B=64)
     const ColVec<MT> b3v = col_load<MT>(lw.b3, wave), b4v = col_load<MT>(lw.b4, wave), b6v = col_load<MT>(lw.b6, wave),
                      b1nv = col_load<MT>(lw_next.b1, wave);
+    if (blockIdx.x == 0 && tid == 0) w.sync[0] = 0;  // the count of finished coordinate-role workgroups of k_coord_msg (the launches before and after this one)
     // materialise the phar coordinates entering this block (see node_pos)
     if (layer >= 1 && tid < MT) {
         const int n = row0 + tid;
@@ -926,44 +985,42 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
 }
 
 // ------------------------------------------------------------------------------------
-// k_edge_coord: EquivariantUpdate.coord_model on the edges whose receiver moves: phar nodes in
+// edge_coord_body / k_edge_coord: EquivariantUpdate.coord_model on the edges whose receiver moves: phar nodes in
 // conditional mode (pocket rows are multiplied by update_coords_mask = 0, egnn_new.py:100-101), every
 // node in joint mode (update_coords_mask = None, dynamics.py:105-107):
 //   phi = w5 . SiLU(W7 SiLU(W6 [h_i, h_j, r, d0] + b6) + b7)
 //   ACC[l][i] += (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant) * tanh(phi) * coords_range
 // ------------------------------------------------------------------------------------
 template <int H, int MT, bool SAVE, bool SP>
-__global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer, TrainSave sv) {
-    __shared__ __attribute__((aligned(16))) float buf[MT * LDA(H)];
-    __shared__ int s_row[MT], s_col[MT];
-    __shared__ float s_r[MT], s_d0[MT];
-    __shared__ float s_cd[MT][3], s_tr[MT][3];
-    __shared__ __attribute__((aligned(16))) float s_w5[H];     // coord_mlp.4 weight, staged once per workgroup (see k_edge_msg)
+__device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT>& L, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
+                                                const int layer, const TrainSave& sv, const int vb, const int nb) {
+    float* buf = L.buf; int* s_row = L.s_row; int* s_col = L.s_col;
+    float* s_r = L.s_r; float* s_d0 = L.s_d0; float* s_w5 = L.s_vec; float* s_wrd = L.s_wrd;
+    float (*s_cd)[3] = L.s_cd; float (*s_tr)[3] = L.s_tr;
     const int tid = threadIdx.x, wave = tid >> 6;
-    s_w5[tid] = lw.w5[tid];
-    constexpr bool PL = SP && H == 256;                        // plane variant, see k_edge_msg
-    __shared__ __attribute__((aligned(16))) float s_wrd[PL ? 2 * H : 4];
+    s_w5[tid] = lw.w5[tid];                                    // coord_mlp.4 weight, staged once per workgroup (see edge_msg_body)
+    constexpr bool PL = SP && H == 256 && MT >= 32;            // plane variant, see edge_msg_body
     if constexpr (PL) { s_wrd[tid] = lw.wr_c[tid]; s_wrd[H + tid] = lw.wd_c[tid]; }
     const ColVec<MT> b7v = col_load<MT>(lw.b7, wave);
     const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_c)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_c)[tid % (H / 4)];
     typedef Eng<MT, SP> G;
     const typename G::Frag fw = G::frag(lw.W7, H / 8, 0, wave);
     typename G::Carry carry;
-    G::prefetch(fw, carry);                                    // unconditional, see k_edge_msg
+    G::prefetch(fw, carry);                                    // unconditional, see edge_msg_body
     const int E = w.totals[1];
     const int ntiles = (E + MT - 1) / MT;
-    int nx_row = -1, nx_col = -1; float nx_d0 = 0.f;           // the next tile's triple, one tile ahead (see k_edge_msg)
+    int nx_row = -1, nx_col = -1; float nx_d0 = 0.f;           // the next tile's triple, one tile ahead (see edge_msg_body)
     {
-        const int t0 = xcd_tile(0, ntiles);
+        const int t0 = xcd_tile(0, ntiles, vb, nb);
         if (t0 >= 0 && tid < MT && t0 * MT + tid < E) { nx_row = w.crow[t0 * MT + tid]; nx_col = w.ccol[t0 * MT + tid]; nx_d0 = w.cd0[t0 * MT + tid]; }
     }
-    for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
+    for (int k = 0, tile; (tile = xcd_tile(k, ntiles, vb, nb)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
         if (tid < MT) {
             const int row = nx_row, col = nx_col; const float d0 = nx_d0;               // phar receivers, self loops dropped
             nx_row = -1; nx_col = -1; nx_d0 = 0.f;
-            const int tn = xcd_tile(k + 1, ntiles);
+            const int tn = xcd_tile(k + 1, ntiles, vb, nb);
             if (tn >= 0 && tn * MT + tid < E) { nx_row = w.crow[tn * MT + tid]; nx_col = w.ccol[tn * MT + tid]; nx_d0 = w.cd0[tn * MT + tid]; }
             float r = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
             if (tid < ne) {
@@ -1036,6 +1093,38 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
         }
         lds_barrier();
     }
+}
+template <int H, int MT, bool SAVE, bool SP>
+__global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer, TrainSave sv) {
+    __shared__ __attribute__((aligned(16))) EdgeLds<H, MT> L;
+    edge_coord_body<H, MT, SAVE, SP>(L, lay, w, d, lw, layer, sv, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------
+// k_coord_msg: the coordinate update of block l-1 and the edge messages of block l in ONE launch (sampler, H = 256).
+// Between them lies only a data dependency on the coordinate sums - not on every tile: workgroups [0, n_coord) first walk
+// the coordinate list and count themselves done (their float atomics drained); then EVERY workgroup walks the message list,
+// and only a tile that touches a moving node waits for that count (tiles of pocket-pocket edges start at once).  A chain
+// of an untrained model drifts to a handful of coordinate edges: their 8.5 us latency chain used to be a launch of its own.
+// The grid is at most two workgroups per CU (what __launch_bounds__(256, 2) guarantees co-resident), so every
+// coordinate-role workgroup is running or done when anyone waits; the wait is bounded all the same (wait_coord_done).
+// k_node of the block in between resets the count.
+// ------------------------------------------------------------------------------------
+template <int MTE, int MTC, bool SPE, bool SPC>
+__global__ __launch_bounds__(256, 2) void k_coord_msg(Layout lay, Work w, Dims d, LayerW lw_c, LayerW lw_m, int layer_m, int n_coord) {
+    union alignas(16) Both { EdgeLds<256, MTE> m; EdgeLds<256, MTC> c; };
+    __shared__ Both L;
+    const int bid = (int)blockIdx.x;
+    const int ntiles_c = (w.totals[1] + MTC - 1) / MTC;
+    if (bid < n_coord && xcd_tile(0, ntiles_c, bid, n_coord) >= 0) {
+        edge_coord_body<256, MTC, false, SPC>(L.c, lay, w, d, lw_c, layer_m - 1, TrainSave{}, bid, n_coord);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's atomics into ACC have been performed
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(w.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (only workgroups that own a coordinate tile count themselves: a drifted chain has a handful, and hundreds of adds to
+    // one word would take microseconds; every workgroup derives the same target from the list's length)
+    edge_msg_body<256, MTE, false, SPE>(L.m, lay, w, d, lw_m, layer_m, 0, TrainSave{}, bid, (int)gridDim.x, w.sync, xcd_active_wgs(ntiles_c, n_coord));
 }
 
 // ------------------------------------------------------------------------------------
@@ -1216,6 +1305,28 @@ template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, 
                                                a.layers[l], l, TrainSave{});
     else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
 }
+// the merged launch exists for the tile pairs cmdgen_set_layout picks on the split engine (everything else: two launches)
+template <int H> static bool launch_coord_msg(const EvalLaunch& a, int l /* block of the messages; < 0: only say whether the pair exists */, hipStream_t s) {
+    if constexpr (H != 256) return false;
+    else {
+        if (!a.split) return false;
+        if (l < 0) {
+            const int me = a.edge_mt, mc = a.coord_mt;
+            return (me == 64 && (mc == 64 || mc == 32)) || (me == 32 && (mc == 32 || mc == 16)) || (me == 16 && mc == 16);
+        }
+        const int grid = a.edge_grid < 2 * a.n_cus ? a.edge_grid : 2 * a.n_cus;            // co-resident by __launch_bounds__(256, 2)
+        int n_coord = (a.coord_grid < grid ? a.coord_grid : grid) & ~7;
+        if (n_coord < 8 || grid < 8) return false;
+#define CM(ME, MC, SE, SC) if (a.edge_mt == ME && a.coord_mt == MC) {                                                                         \
+            if (a.pe_start) hipExtLaunchKernelGGL((k_coord_msg<ME, MC, SE, SC>), dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, \
+                                                  a.layers[l - 1], a.layers[l], l, n_coord);                                                   \
+            else hipLaunchKernelGGL((k_coord_msg<ME, MC, SE, SC>), dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l - 1], a.layers[l], l, n_coord); \
+            return true; }
+        CM(64, 64, true, true) CM(64, 32, true, true) CM(32, 32, true, true) CM(32, 16, true, false) CM(16, 16, false, false)
+#undef CM
+        return false;
+    }
+}
 // tiles of >= 32 rows run on the split-bf16 engine when the launch asks for it (the training forward: only its two edge
 // kernels, and only when the step re-packed split weights for them - save_split); 16-row tiles are always fp32 MFMA
 // (there the L2 weight stream, not the matrix rate, binds)
@@ -1266,16 +1377,23 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
     }
     REC();
+    // k_edge_coord(l-1) and k_edge_msg(l) in one launch (k_coord_msg) wherever nothing has to look in between
+    const bool merge = a.merge_coord && !a.save && !ev && a.stop_block < 0 && launch_coord_msg<H>(a, -1, s);
+    bool coord_pending = false;              // block l-1's coordinate update has not been launched yet
     for (int l = 0; l < a.d.L; ++l) {
         const int stop = a.stop_block == l ? a.stop_stage : 0;        // parity aid: leave intermediates in the workspace
         REC();
-        PROF_BEGIN(0); MT_DISPATCH(a.edge_mt, launch_msg, a, l, s); PROF_END();
+        PROF_BEGIN(0);
+        if (coord_pending) launch_coord_msg<H>(a, l, s); else MT_DISPATCH(a.edge_mt, launch_msg, a, l, s);
+        PROF_END();
+        coord_pending = false;
         REC(); REC();
         if (stop == 1) return;
         PROF_BEGIN(1); MT_DISPATCH(a.node_mt, launch_node, a, l, s); PROF_END();
         REC(); REC();
         if (stop == 2) return;
-        PROF_BEGIN(2); MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF_END();
+        if (merge && l + 1 < a.d.L) coord_pending = true;
+        else { PROF_BEGIN(2); MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF_END(); }
         REC();
         if (stop == 3) return;
     }
