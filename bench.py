@@ -41,6 +41,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Pe
 # 32768 FLOP per 32 cycles) x 2.4 GHz.  The split engine EXECUTES six bf16 MFMA FLOPs per algorithmic fp32 FLOP.
 PEAK_BF16_MFMA_TFLOPS = 2516.6
 SPLIT_MFMAS_PER_PRODUCT = 6
+# the ceiling of a kernel that runs on the split engine, in ALGORITHMIC fp32 FLOP/s: the bf16 pipe's dense peak / 6
+PEAK_SPLIT_FP32_EQUIV_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_MFMAS_PER_PRODUCT
 PEAK_HBM_TBS = 8.0
 
 
@@ -61,6 +63,12 @@ def parse(argv=None):
     p.add_argument('--gemm', default=None, choices=['split', 'fp32'],
                    help="matrix engine of tiles of >= 32 rows: 'split' (default of the library: fp32-accurate, six bf16 MFMAs "
                         "per fp32 product) or 'fp32' (v_mfma_f32_32x32x2_f32)")
+    p.add_argument('--strong', action='store_true',
+                   help='strong scaling: BASELINE configs[2] verbatim - ONE batch of --global-batch pockets (default 512) split over the '
+                        'N ranks (no data-path collective), instead of --batch pockets per rank')
+    p.add_argument('--global-batch', type=int, default=512)
+    p.add_argument('--no-extra-shapes', action='store_true',
+                   help='skip the other records of the default line (trained-geometry chain, full-atom shape, training step)')
     p.add_argument('--rehearse-on-one-gpu', action='store_true',
                    help='N > 1 ranks that all use cuda:0 and rendezvous over gloo: runs the whole multi-rank path (sharded pockets, '
                         'barriers, MAX-over-ranks timing, rank count) on a one-GPU box; the number is NOT a scaling result')
@@ -169,20 +177,157 @@ def cpu_baseline(cfg, sd, batch, rep, n_phar, budget_s):
                       f'hardware threads (best of {cands}), {el:.1f} s'}
 
 
+
+# --------------------------------------------------------------------------------------------- the other records of the line
+def kernel_table(h, prof, pc, H, L, nl_tot):
+    """Per-kernel roofline entries from one profiled eager chain: prof = {kernel: (total ms, launches)} (every launch carried its own
+    HIP start / stop events), pc = device counters of that chain.  -> (per_kernel, dominant kernel, launch config, units per launch)."""
+    ev = max(pc['evaluations'], 1)
+    units = {'edge_msg': pc['edges'] / ev, 'node': pc['nodes'] / ev, 'edge_coord': pc['edges_phar'] / ev}
+    flop_launch = {'edge_msg': 2.0 * (H * H + H) * units['edge_msg'],
+                   'node': node_flop_per_launch(H, L, pc['nodes'] / ev, nl_tot, False),
+                   'edge_coord': coord_flop_per_launch(H, L, units['edge_coord'], pc['nodes'] / ev, False)}
+    launch_cfg = {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid', 'gemm_split', 'node16_split')}
+    mt_of = {'edge_msg': launch_cfg['edge_mt'], 'node': launch_cfg['node_mt'], 'edge_coord': launch_cfg['coord_mt']}
+    on_split = {k: bool(launch_cfg['gemm_split']) and mt_of[k] >= 32 for k in mt_of}
+    on_split['node'] = on_split['node'] or bool(launch_cfg['node16_split'] and mt_of['node'] == 16)
+    per_kernel = {}
+    for k, (ms_k, n_k) in prof.items():
+        avg = ms_k / max(n_k, 1)
+        tf = (flop_launch[k] / (avg * 1e-3) / 1e12) if avg > 0 else 0.0
+        peak = PEAK_SPLIT_FP32_EQUIV_TFLOPS if on_split[k] else PEAK_FP32_MFMA_TFLOPS
+        per_kernel[k] = {'total_ms': ms_k, 'launches': n_k, 'avg_launch_ms': avg, 'flop_per_launch': flop_launch[k],
+                         'tflops': tf, 'rows_per_tile': mt_of[k],
+                         'mfma': ('v_mfma_f32_16x16x32_bf16' if mt_of[k] == 16 else 'v_mfma_f32_32x32x16_bf16') + ' x6 per fp32 product (split engine)' if on_split[k]
+                                 else ('v_mfma_f32_16x16x4_f32' if mt_of[k] == 16 else 'v_mfma_f32_32x32x2_f32'),
+                         # the ceiling of the pipe the kernel executes on, in algorithmic fp32 FLOP/s: the bf16 pipe's dense peak / 6
+                         # for split-engine kernels (six bf16 MFMAs per fp32 product), the fp32 instruction's otherwise
+                         'peak': peak, 'frac': tf / peak, 'frac_of_fp32_instruction_peak': tf / PEAK_FP32_MFMA_TFLOPS}
+    dom = max(per_kernel, key=lambda k: per_kernel[k]['total_ms'])
+    return per_kernel, dom, launch_cfg, units
+
+
+KERNEL_NAMES = {'edge_msg': 'k_edge_msg (GCL.edge_model + attention + segment sum)',
+                'node': 'k_node (GCL.node_model + P_c|Q_c projections + P|Q of the next block)',
+                'edge_coord': 'k_edge_coord (EquivariantUpdate.coord_model)'}
+PER_KERNEL_KEYS = ('total_ms', 'avg_launch_ms', 'tflops', 'flop_per_launch', 'rows_per_tile', 'mfma', 'peak', 'frac', 'frac_of_fp32_instruction_peak')
+
+
+def chain_record(cfg, sd, pb, K, dev, stream, use_graph, prof_steps=0, gemm=None):
+    """One warm chain (captures the step graph), one timed chain of K posterior steps on a fresh handle; optionally a short
+    eager chain with per-launch events for the dominant kernel's roofline.  -> dict"""
+    H, L, dyn = cfg.hidden_nf, cfg.n_layers, cfg.joint_nf + 1
+    B, nl_tot = len(pb.size), int(pb.num_nodes_phar.sum())
+    h = hip_backend.Handle(cfg.as_dict(), dev.index)
+    h.load_state_dict(sd)
+    if gemm is not None:
+        h.set_gemm_mode(gemm == 'split')
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    px, poh = torch.from_numpy(pb.x).to(dev), torch.from_numpy(pb.one_hot).to(dev)
+    with torch.cuda.stream(stream):
+        h.sample_chain(px, poh, K, noise=None, seed=11, pocket_ids=pb.pocket_index, use_graph=use_graph)
+        torch.cuda.synchronize(dev)
+        h.reset_counters()
+        t0 = time.perf_counter()
+        h.sample_chain(px, poh, K, noise=None, seed=12, pocket_ids=pb.pocket_index, use_graph=use_graph)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        c = h.counters()
+        st = h.chain_status()
+        ev = max(c['evaluations'], 1)
+        f_alg = whole_job_flop(H, L, dyn, c['edges'], c['edges_phar'], c['nodes'], ev * nl_tot)
+        rec = {'pockets': B, 'posterior_steps': K, 'value': B * (K + 1) / dt, 'unit': 'pocket-steps/s',
+               'us_per_denoising_step': 1e6 * dt / (K + 1), 'edges_per_pocket_eval': c['edges'] / ev / B,
+               'coord_edges_per_pocket_eval': c['edges_phar'] / ev / B, 'edges_per_s': c['edges'] / dt,
+               'whole_step_alg_tflops': f_alg / dt / 1e12, 'whole_job_frac': f_alg / dt / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
+               'whole_job_frac_of_fp32_instruction_peak': f_alg / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+               'chain_status': st}
+        if prof_steps:
+            h.reset_counters()
+            h.set_kernel_profiling(True)
+            h.sample_chain(px, poh, prof_steps, noise=None, seed=12, pocket_ids=pb.pocket_index, use_graph=False)
+            prof = h.kernel_profile()
+            h.set_kernel_profiling(False)
+            per_kernel, dom, launch_cfg, units = kernel_table(h, prof, h.counters(), H, L, nl_tot)
+            rec['launch'] = launch_cfg
+            rec['roofline'] = {'bound': 'mfma', 'kernel': KERNEL_NAMES[dom], 'achieved': per_kernel[dom]['tflops'], 'peak': per_kernel[dom]['peak'],
+                               'unit': 'TFLOP/s', 'frac': per_kernel[dom]['frac'], 'mfma': per_kernel[dom]['mfma'],
+                               'frac_of_fp32_instruction_peak': per_kernel[dom]['frac_of_fp32_instruction_peak'],
+                               'avg_launch_ms': per_kernel[dom]['avg_launch_ms'], 'flop_per_launch': per_kernel[dom]['flop_per_launch'],
+                               'units_per_launch': units[dom], 'timing': f'per-launch HIP events of an eager chain of {prof_steps} steps in the geometry the chain starts from',
+                               'per_kernel': {k: {kk: v[kk] for kk in PER_KERNEL_KEYS} for k, v in per_kernel.items()}}
+    h.close()
+    return rec
+
+
+def training_step_record(dev):
+    """BASELINE configs[3]'s per-GPU work: one training step (fused loss side, activation-saving forward, backward to parameter
+    gradients, adaptive clipping + AdamW) of the C-alpha model on 64 ragged synthetic complexes, fp32 results and bf16 GEMM operands."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import bench_train
+    out = {}
+    for gemm in ('fp32', 'bf16'):
+        cfg, model, tr = bench_train.build_trainer(64, 'CA', gemm, dev)
+        batches = [bench_train.synthetic_batch(64, 50000 + 100 * i, dev) for i in range(4)]
+        torch.manual_seed(0)
+        dt, losses = bench_train.time_training(tr, batches, 20, 3, dev)
+        E, Ec = tr.h.query('train_edges'), tr.h.query('train_coord_edges')
+        N, Nl = tr.h.n_phar + tr.h.n_pocket, tr.h.n_phar
+        f_fwd = whole_job_flop(cfg.hidden_nf, cfg.n_layers, cfg.joint_nf + 1, E, Ec, N, Nl)
+        rec = {'ms_per_step': 1e3 * dt / 20, 'complexes_per_s': 64 * 20 / dt, 'first_loss': losses[0], 'last_loss': losses[-1],
+               'graph_of_last_batch': {'nodes': N, 'edges': E, 'coord_edges': Ec},
+               # forward = the evaluation's algorithmic FLOP on this graph; the backward pass is twice that (data + weight gradients)
+               'alg_gflop_per_step': 3.0 * f_fwd / 1e9, 'whole_step_alg_tflops': 3.0 * f_fwd / (dt / 20) / 1e12,
+               'whole_step_frac_of_fp32_instruction_peak': 3.0 * f_fwd / (dt / 20) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+               'whole_step_frac_of_split_ceiling': 3.0 * f_fwd / (dt / 20) / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS}
+        if gemm == 'fp32':
+            try:        # the step's dominant kernel and its share of the device time (torch.profiler over 3 more steps)
+                from torch.profiler import profile, ProfilerActivity
+                with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                    for i in range(3):
+                        tr.training_step(batches[i % 4])
+                    torch.cuda.synchronize(dev)
+                rows = [(e.key, e.device_time_total, e.count) for e in prof.key_averages() if e.device_time_total > 0 and not e.key.startswith(('aten::', 'hip'))]
+                tot = sum(r[1] for r in rows)
+                rows.sort(key=lambda r: -r[1])
+                rec['device_ms_per_step'] = tot / 3e3
+                rec['launches_per_step'] = sum(r[2] for r in rows) / 3.0
+                rec['top_kernels'] = [{'kernel': k.split('(')[0][:80], 'share_of_device_time': us / tot, 'ms_per_step': us / 3e3, 'launches_per_step': n / 3.0}
+                                      for k, us, n in rows[:5]]
+            except Exception as e:          # noqa: BLE001  (profiler unavailable: the timing above stands by itself)
+                rec['top_kernels'] = f'unavailable: {type(e).__name__}'
+        out['fp32_results' if gemm == 'fp32' else 'bf16_gemm_operands'] = rec
+        del tr, model
+    out['workload'] = ('BASELINE.json configs[3] per GPU: training_step of PharPocketDDPM (lightning_modules.py:245-260) on 64 ragged '
+                       'CrossDocked-shaped C-alpha complexes, H=256, L=5, l2 loss, AdamW(amsgrad) + adaptive clipping, pipelined steps')
+    return out
+
+
 def dry_run(args, world, rank):
     """Launch logic without a GPU: N ranks rendezvous over gloo, agree on the rank count, rank 0 prints the line."""
     import torch.distributed as dist
     n_ranks = 1
+    B, first = args.batch, rank * args.batch
+    if args.strong:                               # the block of the ONE global batch this rank would sample
+        from cmdgen_amd.sharding import shard_bounds
+        lo, hi = shard_bounds(args.global_batch, world)[rank]
+        B, first = hi - lo, lo
+    blocks = [[first, first + B]]
     if world > 1:
         dist.init_process_group('gloo')
         ones = torch.ones(1)
         dist.all_reduce(ones)
         n_ranks = int(ones.item())
+        mine = torch.tensor([first, first + B], dtype=torch.int64)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        blocks = [g.tolist() for g in got]
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({'metric': 'denoising steps/sec', 'value': 0.0, 'unit': 'pocket-steps/s', 'n_gpus': n_ranks,
-                          'steps': args.steps, 'warmup': args.warmup, 'dry_run': True}))
+                          'steps': args.steps, 'warmup': args.warmup, 'dry_run': True, 'scaling': 'strong' if args.strong else 'weak',
+                          'pocket_blocks': blocks}))
 
 
 def main(argv=None):
@@ -219,13 +364,19 @@ def main(argv=None):
         print(f'note: --gpus {args.gpus} but {n_gpus} ranks were launched; reporting n_gpus={n_gpus}', file=sys.stderr)
 
     B, T, rep = args.batch, args.timesteps, args.representation
+    first_pocket = rank * B                       # weak scaling: every rank has its own B pockets
+    if args.strong:                               # configs[2]: one batch of 512 pockets, contiguous blocks of it per rank
+        from cmdgen_amd.sharding import shard_bounds
+        lo, hi = shard_bounds(args.global_batch, world)[rank]
+        B, first_pocket = hi - lo, lo
+        assert B >= 1, 'more ranks than pockets'
     cfg = ModelConfig(residue_nf=20 if rep == 'CA' else 11, timesteps=T)
     sd = make_state_dict(cfg, seed=0)
     h = hip_backend.Handle(cfg.as_dict(), dev.index)
     h.load_state_dict(sd)
     if args.gemm is not None:
         h.set_gemm_mode(args.gemm == 'split')
-    pb = make_pockets(B, rep, n_phar=args.n_phar, first_index=rank * B)     # shard = global pockets [rank*B, (rank+1)*B)
+    pb = make_pockets(B, rep, n_phar=args.n_phar, first_index=first_pocket)     # shard = global pockets [first, first + B)
     h.set_layout(pb.num_nodes_phar, pb.size)
     px, poh = torch.from_numpy(pb.x).to(dev), torch.from_numpy(pb.one_hot).to(dev)
     use_graph = not args.no_graph
@@ -257,7 +408,8 @@ def main(argv=None):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     evals_per_chain = T + 1
-    value = n_gpus * B * evals_per_chain * args.steps / elapsed
+    total_pockets = args.global_batch if args.strong else n_gpus * B
+    value = total_pockets * evals_per_chain * args.steps / elapsed
 
     result = None
     if rank == 0:
@@ -301,33 +453,8 @@ def main(argv=None):
                   'edges_per_s': mc['edges'] / m_ev / dt_micro,
                   'alg_tflops': whole_job_flop(H, L, dyn, mc['edges'], mc['edges_phar'], mc['nodes'], m_ev * nl_tot) / m_ev / dt_micro / 1e12,
                   'timing': 'hipGraph of 10 evaluations replayed, HIP events on the launch stream'}
-        ev = max(pc['evaluations'], 1)
-        units = {'edge_msg': pc['edges'] / ev, 'node': pc['nodes'] / ev, 'edge_coord': pc['edges_phar'] / ev}
-        split = False       # (a split of the next block's P|Q into the coordinate launch was measured and dropped: profiles/r02_f)
-        flop_launch = {'edge_msg': 2.0 * (H * H + H) * units['edge_msg'],
-                       'node': node_flop_per_launch(H, L, pc['nodes'] / ev, nl_tot, split),
-                       'edge_coord': coord_flop_per_launch(H, L, units['edge_coord'], pc['nodes'] / ev, split)}
-        kname = {'edge_msg': 'k_edge_msg (GCL.edge_model + attention + segment sum)',
-                 'node': 'k_node (GCL.node_model + P_c|Q_c projections' + ('' if split else ' + P|Q of the next block') + ')',
-                 'edge_coord': 'k_coord_proj (EquivariantUpdate.coord_model + P|Q projections of the next block)' if split
-                               else 'k_edge_coord (EquivariantUpdate.coord_model)'}
-        # which matrix instruction each kernel's tiles ran on: the split engine serves tiles of >= 32 rows
-        launch_cfg = {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid', 'gemm_split', 'node16_split')}
-        mt_of = {'edge_msg': launch_cfg['edge_mt'], 'node': launch_cfg['node_mt'], 'edge_coord': launch_cfg['coord_mt']}
-        on_split = {k: bool(launch_cfg['gemm_split']) and mt_of[k] >= 32 for k in mt_of}
-        on_split['node'] = on_split['node'] or bool(launch_cfg['node16_split'] and mt_of['node'] == 16)
-        per_kernel = {}
-        for k, (ms_k, n_k) in prof.items():
-            avg = ms_k / max(n_k, 1)
-            tf = (flop_launch[k] / (avg * 1e-3) / 1e12) if avg > 0 else 0.0
-            per_kernel[k] = {'total_ms': ms_k, 'launches': n_k, 'avg_launch_ms': avg, 'flop_per_launch': flop_launch[k],
-                             'tflops': tf, 'rows_per_tile': mt_of[k],
-                             'mfma': ('v_mfma_f32_16x16x32_bf16' if mt_of[k] == 16 else 'v_mfma_f32_32x32x16_bf16') + ' x6 per fp32 product (split engine)' if on_split[k]
-                                     else ('v_mfma_f32_16x16x4_f32' if mt_of[k] == 16 else 'v_mfma_f32_32x32x2_f32'),
-                             # what the matrix pipe executes: six bf16 FLOPs per algorithmic FLOP against the bf16 peak
-                             'executed_frac_of_pipe_peak': (tf * SPLIT_MFMAS_PER_PRODUCT / PEAK_BF16_MFMA_TFLOPS) if on_split[k]
-                                                           else tf / PEAK_FP32_MFMA_TFLOPS}
-        dom = max(per_kernel, key=lambda k: per_kernel[k]['total_ms'])
+        per_kernel, dom, launch_cfg, units = kernel_table(h, prof, pc, H, L, nl_tot)
+        kname = KERNEL_NAMES
         achieved = per_kernel[dom]['tflops']
         avg_ms, launches, flop_per_launch = per_kernel[dom]['avg_launch_ms'], per_kernel[dom]['launches'], per_kernel[dom]['flop_per_launch']
         # whole-job algorithmic FLOP for the timed region
@@ -353,10 +480,12 @@ def main(argv=None):
             'metric': 'denoising steps/sec', 'value': value, 'unit': 'pocket-steps/s',
             'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
             **({'rehearsal': f'{world} ranks sharing cuda:0 over gloo (functional rehearsal of the multi-rank path, not a scaling result)'} if one_gpu and world > 1 else {}),
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
-                'workload': f'BASELINE.json configs[{1 if rep == "CA" else 4}]: batch {B} CrossDocked-shaped {rep} pockets per GPU '
+                'workload': (f'BASELINE.json configs[2]: ONE batch of {args.global_batch} CrossDocked-shaped {rep} pockets sharded over {n_gpus} GPUs '
+                             f'({B} on rank 0), no data-path collective; ' if args.strong else '') +
+                            f'BASELINE.json configs[{1 if rep == "CA" else 4}]: batch {B} CrossDocked-shaped {rep} pockets per GPU '
                             f'(Np={int(pb.size[0])}, Nl={args.n_phar}), {T}-step DDPM sampling '
                             f'(sample_given_pocket: {evals_per_chain} network evaluations per pocket), fp32 '
                             f'({"split-bf16 matrix engine on tiles of >= 32 rows: fp32-accurate" if launch_cfg["gemm_split"] else "fp32 MFMA"}); '
@@ -375,24 +504,29 @@ def main(argv=None):
                 'steady_state_evaluation': steady,
                 'kernel_source_sha': sha,
                 'launch': launch_cfg,
+                # north_star: "sampled coords within 1e-4 RMS of reference".  Where it is asserted as an ABSOLUTE bound: the reference's
+                # own chain at this config's literal size in the bounded-|x| regime (golden G14: 64 pockets, H=256, L=5, K=T=1000:
+                # 7.7e-5 A over the whole batch, types identical; tests/test_hip_parity_r3.py).  With the shipped 1e-5 schedule and
+                # UNTRAINED weights a chain inflates coordinates to ~800 A (ulp 6e-5 A): there the tests state the bound relative to |x|.
+                'parity': 'coordinate RMS vs the reference <= 1e-4 A absolute at this size in the bounded-|x| regime (G14: 7.7e-5 A, types exact); '
+                          '<= 1e-4 * max(1, |x|) for the shipped noise_precision=1e-5 with untrained weights (|x| ~ 800 A: 3.2e-4 A at K=1000)',
             },
             'roofline': {
                 'bound': 'mfma', 'kernel': kname[dom],
-                'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_note': traffic_note,
+                'achieved': achieved, 'peak': per_kernel[dom]['peak'], 'unit': 'TFLOP/s',
+                'frac': per_kernel[dom]['frac'], 'traffic': traffic, 'traffic_note': traffic_note,
                 'flop_per_launch': flop_per_launch, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
                 'units_per_launch': units[dom],
-                # `achieved` and `frac` are ALGORITHMIC fp32 FLOP/s against the fp32 matrix peak (the path computes in fp32).
-                # Tiles of >= 32 rows execute each fp32 product as six exact bf16 products on the 16x faster bf16 pipe
-                # (cmdgen_split.h), so the fp32-equivalent rate may exceed what the fp32 instruction could deliver;
-                # `mfma` names the instruction of the dominant kernel, `executed_frac_of_pipe_peak` prices the executed
-                # (6x) FLOPs against that pipe's own dense peak (2516.6 TF bf16 / 157.3 TF fp32).
-                'mfma': per_kernel[dom]['mfma'], 'executed_frac_of_pipe_peak': per_kernel[dom]['executed_frac_of_pipe_peak'],
-                'whole_job_frac': f_alg / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                # `achieved` is ALGORITHMIC fp32 FLOP/s; `peak` is the ceiling of the pipe the dominant kernel executes on:
+                # 157.3 TF for the fp32 instruction, 2516.6 / 6 = 419.4 TF fp32-equivalent for a split-engine kernel (each fp32
+                # product = six exact bf16 products on the bf16 pipe, cmdgen_split.h) - so no `frac` can exceed 1.  The
+                # fraction of the fp32 INSTRUCTION's peak (what round 2 reported) stays as `frac_of_fp32_instruction_peak`.
+                'mfma': per_kernel[dom]['mfma'], 'frac_of_fp32_instruction_peak': per_kernel[dom]['frac_of_fp32_instruction_peak'],
+                'whole_job_frac': f_alg / elapsed / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
+                'whole_job_frac_of_fp32_instruction_peak': f_alg / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 # the north-star also asks for the HBM view: PMC bytes per launch / launch time / 8 TB/s (not the binding roofline)
                 'hbm_frac_from_pmc': (traffic / (avg_ms * 1e-3) / (PEAK_HBM_TBS * 1e12)) if traffic else None,
-                'per_kernel': {k: {kk: v[kk] for kk in ('total_ms', 'avg_launch_ms', 'tflops', 'flop_per_launch', 'rows_per_tile', 'mfma', 'executed_frac_of_pipe_peak')} | {'frac': v['tflops'] / PEAK_FP32_MFMA_TFLOPS}
-                               for k, v in per_kernel.items()},
+                'per_kernel': {k: {kk: v[kk] for kk in PER_KERNEL_KEYS} for k, v in per_kernel.items()},
             },
         }
         # ---- the north-star shape on the same line: 256 pockets on one GPU, one chain of the same length
@@ -415,15 +549,33 @@ def main(argv=None):
                 'pockets': Bn, 'value': Bn * evals_per_chain / dtn, 'unit': 'pocket-steps/s',
                 'us_per_denoising_step': 1e6 * dtn / evals_per_chain,
                 'whole_job_frac': whole_job_flop(H, L, dyn, cn['edges'], cn['edges_phar'], cn['nodes'],
+                                                 cn['evaluations'] * int(pbn.num_nodes_phar.sum())) / dtn / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
+                'whole_job_frac_of_fp32_instruction_peak': whole_job_flop(H, L, dyn, cn['edges'], cn['edges_phar'], cn['nodes'],
                                                  cn['evaluations'] * int(pbn.num_nodes_phar.sum())) / dtn / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 'edges_per_s': cn['edges'] / dtn}
+        if n_gpus == 1 and rep == 'CA' and not args.no_extra_shapes and not args.strong:
+            # ---- the same chain where the phar points stay inside the pocket for all K steps (the geometry a trained model holds):
+            # noise_precision 0.1 / norm_values [1, 0.25] give 1/alpha_T = 3.2 instead of 316, so untrained weights cannot inflate the
+            # coordinates (max|x| ~ 17 A) and the chain keeps ~500 edges per pocket-evaluation instead of ~230
+            cfg_t = ModelConfig(residue_nf=20, timesteps=T, noise_precision=0.1, norm_values=(1.0, 0.25))
+            tg = chain_record(cfg_t, make_state_dict(cfg_t, seed=0), pb, T, dev, stream, use_graph, prof_steps=16, gemm=args.gemm)
+            tg['model'] = 'same architecture and weights generator, noise_precision=0.1, norm_values=[1, 0.25] (bounded-|x| regime)'
+            result['config']['trained_geometry_chain'] = tg
+            # ---- BASELINE configs[4]: 256 full-atom pockets (Np=366), 100 strided steps of the T-step model
+            cfg_f = ModelConfig(residue_nf=11, timesteps=T)
+            fa = chain_record(cfg_f, make_state_dict(cfg_f, seed=0), make_pockets(256, 'full-atom', n_phar=args.n_phar), 100, dev, stream,
+                              use_graph, prof_steps=6, gemm=args.gemm)
+            fa['workload'] = 'BASELINE.json configs[4]: 256 full-atom pockets (Np=366, Nl=15), 100 strided steps of the 1000-step model'
+            result['config']['fullatom_shape'] = fa
+            # ---- BASELINE configs[3]'s per-GPU work: the training step
+            result['config']['training_step'] = training_step_record(dev)
         if not args.no_cpu_baseline and n_gpus == 1:      # timed on rank 0 at N=1 only
             result['cpu_baseline'] = cpu_baseline(cfg, sd, B, rep, args.n_phar, args.cpu_seconds)
             cpu_v = result['cpu_baseline']['value']
-            result['config']['gpu_over_cpu'] = value / cpu_v
+            # stated only between numbers of the SAME geometry: the CPU sample runs with the phar points inside the pocket
             result['config']['gpu_over_cpu_same_geometry'] = steady['pocket_evaluations_per_s'] / cpu_v
-            if 'north_star_shape' in result['config']:
-                result['config']['north_star_shape']['gpu_over_cpu'] = result['config']['north_star_shape']['value'] / cpu_v
+            if 'trained_geometry_chain' in result['config']:
+                result['config']['trained_geometry_chain']['gpu_over_cpu'] = result['config']['trained_geometry_chain']['value'] / cpu_v
         else:
             result['cpu_baseline'] = None
     if dist is not None:

@@ -207,6 +207,23 @@ def make_pockets(n_pockets: int, representation: str = 'CA', n_pocket_nodes: int
         pocket_index=np.arange(first_index, first_index + n_pockets, dtype=np.int64))
 
 
+def make_training_batch(n_complexes: int, first_index: int, representation: str = 'CA', ragged: bool = True) -> Dict[str, np.ndarray]:
+    """One synthetic training batch in the NPZ / collate schema of the dataset path (dataset.py:7-64,
+    process_crossdock_ca_only.py:195-207): ragged CrossDocked-shaped pockets, pharmacophore points scattered 2.5 A around
+    the pocket centre, uniform types.  numpy arrays; keys as PharPocketDDPM.get_phar_and_pocket reads them, plus the node
+    counts once more under '<name>_cpu' (what a collate function has on the host before the batch moves to the device)."""
+    pb = make_pockets(n_complexes, representation, ragged=ragged, first_index=first_index)
+    rng = np.random.Generator(np.random.PCG64(first_index))
+    nl = pb.num_nodes_phar
+    pm = np.repeat(np.arange(n_complexes), nl)
+    com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(n_complexes)])
+    px = (com[pm] + rng.normal(size=(len(pm), 3)) * 2.5).astype(np.float32)
+    poh = np.eye(8, dtype=np.float32)[rng.integers(0, 8, size=len(pm))]
+    return {'phar_coords': px, 'phar_one_hot': poh, 'num_phar_atoms': nl, 'phar_mask': pm,
+            'pocket_c_alpha': pb.x, 'pocket_one_hot': pb.one_hot, 'num_pocket_nodes': pb.size, 'pocket_mask': pb.mask,
+            'num_phar_atoms_cpu': nl, 'num_pocket_nodes_cpu': pb.size}
+
+
 def min_cutoff_margin(x: np.ndarray, mask: np.ndarray, cutoff: float) -> float:
     """Smallest | ||x_i - x_j|| - cutoff | over same-sample pairs (float64).
 

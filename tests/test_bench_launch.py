@@ -25,6 +25,17 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert out['n_gpus'] == 2 and out['steps'] == 1
 
 
+def test_strong_scaling_splits_one_global_batch():
+    """--strong = BASELINE configs[2] verbatim: ONE batch of 512 pockets in contiguous blocks over the ranks (weak scaling keeps
+    --batch pockets per rank)."""
+    out = _run(['--gpus', '2', '--strong'])
+    assert out['scaling'] == 'strong' and out['pocket_blocks'] == [[0, 256], [256, 512]]
+    out = _run(['--gpus', '2', '--strong', '--global-batch', '7'])
+    assert out['pocket_blocks'] == [[0, 4], [4, 7]]
+    out = _run(['--gpus', '2'])
+    assert out['scaling'] == 'weak' and out['pocket_blocks'] == [[0, 64], [64, 128]]
+
+
 def test_single_rank_does_not_spawn():
     assert _run(['--gpus', '1'])['n_gpus'] == 1
 

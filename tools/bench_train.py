@@ -23,19 +23,84 @@ from cmdgen_amd.training import HipTrainer  # noqa: E402
 
 
 def synthetic_batch(B, first, dev, rep='CA'):
-    pb = make_pockets(B, rep, ragged=True, first_index=first)
-    rng = np.random.Generator(np.random.PCG64(first))
-    nl = pb.num_nodes_phar
-    pm = np.repeat(np.arange(B), nl)
-    com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(B)])
-    px = (com[pm] + rng.normal(size=(len(pm), 3)) * 2.5).astype(np.float32)
-    poh = np.eye(8, dtype=np.float32)[rng.integers(0, 8, size=len(pm))]
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    return {'phar_coords': t(px), 'phar_one_hot': t(poh), 'num_phar_atoms': t(nl), 'phar_mask': t(pm),
-            'pocket_c_alpha': t(pb.x), 'pocket_one_hot': t(pb.one_hot), 'num_pocket_nodes': t(pb.size),
-            'pocket_mask': t(pb.mask),
-            # host copies of the node counts, as a collate function has them before the batch is moved to the device
-            'num_phar_atoms_cpu': torch.from_numpy(np.ascontiguousarray(nl)), 'num_pocket_nodes_cpu': torch.from_numpy(np.ascontiguousarray(pb.size))}
+    from cmdgen_amd.synthetic import make_training_batch
+    nb = make_training_batch(B, first, rep)
+    return {k: (torch.from_numpy(np.ascontiguousarray(v)) if k.endswith('_cpu') else torch.from_numpy(np.ascontiguousarray(v)).to(dev))
+            for k, v in nb.items()}
+
+
+def build_trainer(batch, representation, gemm, dev, pipelined=True, mode='pocket_conditioning'):
+    """PharPocketDDPM with the shipped hyper-parameters (configs/crossdocked_ca_cond.yml) and seeded weights -> HipTrainer"""
+    cfg = ModelConfig(residue_nf=20 if representation == 'CA' else 11, update_pocket_coords=(mode == 'joint'))
+    hp = dict(outdir='out', dataset='crossdock' if representation == 'CA' else 'crossdock_full', datadir='data', batch_size=batch, lr=1e-3,
+              egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=256, n_layers=5, attention=True,
+                                    tanh=True, norm_constant=1, inv_sublayers=1, sin_embedding=False,
+                                    aggregation_method='sum', normalization_factor=100),
+              diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
+                                         diffusion_noise_precision=1e-5, diffusion_loss_type='l2', normalize_factors=[1, 4]),
+              num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
+              eval_params=Namespace(n_eval_samples=100, eval_batch_size=100), mode=mode,
+              node_histogram=np.ones((30, 500)), pocket_representation=representation)
+    model = PharPocketDDPM(**hp)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed=0).items()}, strict=True)
+    model = model.to(dev)
+    tr = HipTrainer(model, gemm_dtype=gemm)
+    tr.pipelined = pipelined
+    return cfg, model, tr
+
+
+def time_training(tr, batches, steps, warmup, dev, dist=None):
+    """-> (seconds for `steps` training steps after `warmup`, losses); MAX over ranks when distributed"""
+    for i in range(warmup):
+        tr.training_step(batches[i % len(batches)])
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    losses = []
+    for i in range(steps):
+        losses.append(tr.training_step(batches[i % len(batches)])['loss'])          # device scalars: read after the loop
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        td = torch.tensor([dt], device=dev)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dt = float(td)
+    return dt, [float(x) for x in losses]
+
+
+def exposed_allreduce_ms(tr, batch, dev, reps=5):
+    """What the gradient all-reduce costs a step: the same step with the chunked all-reduce overlapped with the backward pass
+    (the default), with one flat all-reduce after the pass, and with no all-reduce at all (group of one would skip it: the
+    backward pass alone).  -> dict of mean ms of loss_and_grad + _allreduce."""
+    out = {}
+
+    def run(label, overlap, skip):
+        tr.overlap_allreduce = overlap
+        ts = []
+        for _ in range(reps + 1):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            tr.loss_and_grad(batch)
+            if not skip:
+                tr._allreduce()
+            else:
+                for w in tr._pending:
+                    w.wait()
+                tr._pending = []
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        out[label] = 1e3 * float(np.mean(ts[1:]))
+    run('overlapped_chunks_ms', True, False)
+    run('flat_after_backward_ms', False, False)
+    world = tr._world
+    tr._world = lambda: 1                      # the pass without any collective
+    run('no_allreduce_ms', False, True)
+    tr._world = world
+    tr.overlap_allreduce = True
+    out['exposed_ms'] = out['overlapped_chunks_ms'] - out['no_allreduce_ms']
+    out['hidden_ms'] = out['flat_after_backward_ms'] - out['overlapped_chunks_ms']
+    return out
 
 
 def main():
@@ -48,48 +113,25 @@ def main():
     ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16'], help='GEMM operand precision (fp32 accumulation either way)')
     ap.add_argument('--no-pipeline', action='store_true', help='wait for every step\'s gradient norm before queueing the next step (HipTrainer.pipelined = False)')
     ap.add_argument('--cpu-baseline', action='store_true', help='also time the oracle (torch CPU autograd) on the same batch shape')
+    ap.add_argument('--gloo', action='store_true', help='rendezvous over gloo (rehearsal of the multi-rank path on a one-GPU box: all ranks on cuda:0)')
     ap.add_argument('--profile', action='store_true', help='print the per-kernel time table of 3 steps (torch.profiler)')
     a = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if a.gloo:
+        local = 0
     torch.cuda.set_device(local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo' if a.gloo else 'nccl', **({} if a.gloo else {'device_id': torch.device('cuda', local)}))
     dev = torch.device('cuda', local)
-    cfg = ModelConfig(residue_nf=20 if a.representation == 'CA' else 11)
-    hp = dict(outdir='out', dataset='crossdock' if a.representation == 'CA' else 'crossdock_full', datadir='data', batch_size=a.batch, lr=1e-3,
-              egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=256, n_layers=5, attention=True,
-                                    tanh=True, norm_constant=1, inv_sublayers=1, sin_embedding=False,
-                                    aggregation_method='sum', normalization_factor=100),
-              diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
-                                         diffusion_noise_precision=1e-5, diffusion_loss_type='l2', normalize_factors=[1, 4]),
-              num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
-              eval_params=Namespace(n_eval_samples=100, eval_batch_size=100), mode='pocket_conditioning',
-              node_histogram=np.ones((30, 500)), pocket_representation=a.representation)
-    model = PharPocketDDPM(**hp)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed=0).items()}, strict=True)
-    model = model.to(dev)
-    tr = HipTrainer(model, gemm_dtype=a.gemm)
-    tr.pipelined = not a.no_pipeline
+    cfg, model, tr = build_trainer(a.batch, a.representation, a.gemm, dev, pipelined=not a.no_pipeline)
     batches = [synthetic_batch(a.batch, 50000 + 1000 * rank + 100 * i, dev, a.representation) for i in range(4)]
     torch.manual_seed(rank)
-    for i in range(a.warmup):
-        tr.training_step(batches[i % 4])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    losses = []
-    for i in range(a.steps):
-        losses.append(tr.training_step(batches[i % 4])['loss'])          # device scalars: read after the loop
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    losses = [float(x) for x in losses]
-    if world > 1:
-        td = torch.tensor([dt], device=dev)
-        dist.all_reduce(td, op=dist.ReduceOp.MAX)
-        dt = float(td)
+    dt, losses = time_training(tr, batches, a.steps, a.warmup, dev, dist if world > 1 else None)
+    allreduce = exposed_allreduce_ms(tr, batches[0], dev) if world > 1 else None
     if a.profile and rank == 0:
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
@@ -149,7 +191,7 @@ def main():
                           'first_loss': losses[0], 'last_loss': losses[-1], 'cpu_baseline': cpu, 'pipelined': tr.pipelined,
                           'graph_of_last_step': {'nodes': tr.h.n_phar + tr.h.n_pocket, 'edges': tr.h.query('train_edges'),
                                                  'coord_edges': tr.h.query('train_coord_edges')},
-                          'phase_ms': {'loss_and_grad': ev[0].elapsed_time(ev[1]), 'allreduce': ev[1].elapsed_time(ev[2]),
+                          'allreduce_ms': allreduce, 'phase_ms': {'loss_and_grad': ev[0].elapsed_time(ev[1]), 'allreduce': ev[1].elapsed_time(ev[2]),
                                        'clip_and_adamw': ev[2].elapsed_time(ev[3])}}))
 
 
