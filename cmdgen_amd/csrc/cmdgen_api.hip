@@ -546,6 +546,11 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     a.split = h->gemm_split ? 1 : 0;
     a.n_cus = h->n_cus;
+    {   // k_coord_proj (library built with -DCMDGEN_EXPERIMENTS=1 only): the next block's P | Q projections as column-sliced tiles beside the coordinate tiles
+        const char* ev = getenv("CMDGEN_PROJ_SPLIT");
+        a.proj_split = (h->dims.H == 256 && h->gemm_split && !h->dims.joint && ev && atoi(ev) != 0) ? 1 : 0;      // measured: +1 % at B=64, -3.6 % at B=256 (profiles/r03_f): off
+        ev = getenv("CMDGEN_PROJ_MT"); a.proj_mt = ev ? atoi(ev) : 32;
+    }
     {   // k_coord_msg (coordinate update of block l-1 + messages of block l in one launch): measured and OFF by default -
         // the tiles that wait are the launch's critical path (coordinate chain + message chain in series, exactly as two
         // launches), and at the trained geometry every message tile waits: profiles/r03_c_merged_coord_msg.txt
@@ -1188,6 +1193,7 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "coord_grid") *value = a.coord_grid;
     else if (k == "gemm_split") *value = a.split;
     else if (k == "node16_split") *value = a.split16;
+    else if (k == "proj_split") *value = a.proj_split;
     else if (k == "train_edges") *value = h->train_E;
     else if (k == "train_coord_edges") *value = h->train_Ec;
     else return fail(h, CMDGEN_EINVAL, "unknown query '%s'", key);

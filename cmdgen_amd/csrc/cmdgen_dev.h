@@ -199,6 +199,9 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int split16 = 0;            // 1: 16-row node tiles too (Eng<16, true>; CMDGEN_NODE16_SPLIT=0 opts out)
     int merge_coord = 0;        // 1: k_edge_coord(l-1) and k_edge_msg(l) share a launch (k_coord_msg; sampler, H = 256)
     int n_cus = 256;
+    int proj_split = 0;         // 1: the next block's P | Q projections run as column-sliced tiles in the coordinate kernel's launch (k_coord_proj)
+    int proj_mt = 32;           //    rows per projection tile there (32 or 64)
+    mutable int node_skip_next = 0;   // set around the k_node launch whose next-block projections moved
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     hipStream_t side = nullptr; // when set: k_edge_write runs there, concurrently with k_embed (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

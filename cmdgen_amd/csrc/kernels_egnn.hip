@@ -1100,6 +1100,7 @@ __global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d,
     edge_coord_body<H, MT, SAVE, SP>(L, lay, w, d, lw, layer, sv, (int)blockIdx.x, (int)gridDim.x);
 }
 
+#if CMDGEN_EXPERIMENTS      // two merged-launch variants that were measured and lost (profiles/r03_c, r03_f); built only on request
 // ------------------------------------------------------------------------------------
 // k_coord_msg: the coordinate update of block l-1 and the edge messages of block l in ONE launch (sampler, H = 256).
 // Between them lies only a data dependency on the coordinate sums - not on every tile: workgroups [0, n_coord) first walk
@@ -1126,6 +1127,116 @@ __global__ __launch_bounds__(256, 2) void k_coord_msg(Layout lay, Work w, Dims d
     // one word would take microseconds; every workgroup derives the same target from the list's length)
     edge_msg_body<256, MTE, false, SPE>(L.m, lay, w, d, lw_m, layer_m, 0, TrainSave{}, bid, (int)gridDim.x, w.sync, xcd_active_wgs(ntiles_c, n_coord));
 }
+
+// ------------------------------------------------------------------------------------
+// k_coord_proj: the coordinate update of block l and the edge-MLP projections P | Q of block l+1 in ONE launch (sampler,
+// H = 256, split engine).  The two do not depend on each other: both read the h that k_node(l) wrote, the coordinate
+// tiles P_c | Q_c, and nothing either writes is read by the other.  What it buys: k_node's 16-row tile streams every weight
+// of its GEMM chain per 16 rows (that stream, not the matrix pipe, is what a small batch's k_node waits for, profiles/r03_b);
+// the P | Q projection here runs as MT-row x 256-column tiles - one weight slice per workgroup, 4x / 2x the rows per byte
+// of weights - beside a coordinate kernel that is a latency chain of a few tiles at this size.
+// Workgroups [0, 4 * ceil(N / MTP)): projection tiles of MTP rows x 128 columns (P low / high half, Q low / high half); the
+// rest: the coordinate list.
+// ------------------------------------------------------------------------------------
+// acc[m] += A(lds fp32 image, rows 32 m .. 32 m + 31) x W^T for ONE 32-column tile of a packed split weight (bp: that tile's
+// k-block 0, this lane), K = 256.  Register split of A as in tile_gemm_rsplit; the weight fragments run THREE k-blocks ahead in
+// a ring of four register sets: a projection tile is one GEMM on a workgroup that is alone on its CU, so nothing but the
+// depth of its own prefetch hides the L2 latency of its weight stream (one k-block ahead: 21 us for a 64-row tile, r03_f).
+template <int NMT>
+__device__ __forceinline__ void proj_gemm(const float* ldsA, const int lda, const sbf16x8* bp, sf32x16 (&acc)[NMT]) {
+    constexpr int KB16 = 16;
+    const int lane = threadIdx.x & 63;
+    const float* ap = ldsA + (lane & 31) * lda + (lane >> 5) * 8;
+    sbf16x8 b[4][3];
+    float4 raw[2][NMT][2];
+    sbf16x8 a[2][NMT][3];
+#define PG_LOADB(SET, KB) _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) b[SET][s_] = bp[(unsigned)(KB) * 192u + s_ * 64];
+#define PG_LOADA(SET, KB) _Pragma("unroll") for (int m = 0; m < NMT; ++m) {                                  \
+        raw[SET][m][0] = *reinterpret_cast<const float4*>(ap + m * 32 * lda + (KB) * 16);                      \
+        raw[SET][m][1] = *reinterpret_cast<const float4*>(ap + m * 32 * lda + (KB) * 16 + 4); }
+#define PG_SPLIT(DST, SET) _Pragma("unroll") for (int m = 0; m < NMT; ++m) split8(raw[SET][m][0], raw[SET][m][1], a[DST][m][0], a[DST][m][1], a[DST][m][2]);
+#define PG_MFMAS(AS, BS) _Pragma("unroll") for (int m = 0; m < NMT; ++m) {                                                              \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][2], b[BS][0], acc[m], 0, 0, 0);                                        \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][1], b[BS][1], acc[m], 0, 0, 0);                                        \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], b[BS][2], acc[m], 0, 0, 0);                                        \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][1], b[BS][0], acc[m], 0, 0, 0);                                        \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], b[BS][1], acc[m], 0, 0, 0);                                        \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], b[BS][0], acc[m], 0, 0, 0); }
+#define PG_INTERLEAVE() _Pragma("unroll") for (int i = 0; i < NMT * 6; ++i) {                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
+#define PG_BLOCK(I) {                                                                                         \
+        if (kb + (I) + 3 < KB16) { PG_LOADB(((I) + 3) & 3, kb + (I) + 3) }                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (kb + (I) + 1 < KB16) { PG_SPLIT(((I) + 1) & 1, ((I) + 1) & 1) }                                   \
+        PG_MFMAS((I) & 1, (I) & 3)                                                                            \
+        PG_INTERLEAVE()                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (kb + (I) + 2 < KB16) { PG_LOADA((I) & 1, kb + (I) + 2) } }
+    PG_LOADB(0, 0) PG_LOADB(1, 1) PG_LOADB(2, 2)
+    PG_LOADA(0, 0) PG_LOADA(1, 1)
+    PG_SPLIT(0, 0)
+#pragma unroll 1
+    for (int kb = 0; kb < KB16; kb += 4) { PG_BLOCK(0) PG_BLOCK(1) PG_BLOCK(2) PG_BLOCK(3) }
+#undef PG_LOADB
+#undef PG_LOADA
+#undef PG_SPLIT
+#undef PG_MFMAS
+#undef PG_INTERLEAVE
+#undef PG_BLOCK
+}
+
+// one projection tile: MTP = 32 NMT rows x 128 columns of P (jobs 0, 1) or Q (jobs 2, 3) of the NEXT block, h read from global
+template <int NMT>
+__device__ __forceinline__ void proj_pq_body(float* buf, const Layout& lay, const Work& w, const LayerW& lw_next, const int vb) {
+    constexpr int H = 256, LPR = H / 4, MTP = 32 * NMT;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile = vb >> 2, job = vb & 3;
+    const int row0 = tile * MTP, nvalid = min(MTP, lay.N - row0);
+    // Wpq_e is [2H out][H in] (rows 0..H-1 -> P, H.. -> Q) in 32-column tiles of 16 k-blocks x 3 pieces x 64 lanes
+    const int nt = job * 4 + wave;
+    const sbf16x8* bp = reinterpret_cast<const sbf16x8*>(lw_next.Wpq_e.ws) + (size_t)nt * (H / 16) * 192 + lane;
+    const int col = (job & 1) * 128 + wave * 32 + (lane & 31);
+    const float bias = job < 2 ? lw_next.b1[col] : 0.f;
+    const int c4 = tid % LPR, rsub = tid / LPR;
+    {
+        float4 hv[MTP / 4];
+#pragma unroll
+        for (int pass = 0; pass < MTP / 4; ++pass) {               // the whole tile in flight, then the LDS writes
+            const int r = pass * 4 + rsub;
+            hv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nvalid) hv[pass] = reinterpret_cast<const float4*>(w.h + (size_t)(row0 + r) * H)[c4];
+        }
+#pragma unroll
+        for (int pass = 0; pass < MTP / 4; ++pass) *reinterpret_cast<float4*>(buf + (pass * 4 + rsub) * LDA(H) + 4 * c4) = hv[pass];
+    }
+    lds_barrier();
+    sf32x16 acc[NMT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+    proj_gemm<NMT>(buf, LDA(H), bp, acc);
+    float* __restrict__ out = job < 2 ? w.P : w.Q;
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < nvalid) out[(size_t)(row0 + row) * H + col] = acc[m][r] + bias;
+        }
+}
+
+template <int MTC, bool SPC, int MTP>
+__global__ __launch_bounds__(256, 2) void k_coord_proj(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int n_proj) {
+    union alignas(16) Both { EdgeLds<256, MTC> c; float p[MTP * LDA(256)]; };
+    __shared__ Both L;
+    const int bid = (int)blockIdx.x;
+    if (bid < n_proj) proj_pq_body<MTP / 32>(L.p, lay, w, lw_next, bid);
+    else edge_coord_body<256, MTC, false, SPC>(L.c, lay, w, d, lw, layer, TrainSave{}, bid - n_proj, (int)gridDim.x - n_proj);
+}
+
+#endif  // CMDGEN_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------
 // k_readout: embedding_out (drop the time column), decoders, velocity, NaN flag
@@ -1284,7 +1395,7 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
         if (a.split16 && !a.save && a.layers[l].W3.ws16) { launch_node<H, 16, true>(a, l, s); return; }
     }
     const int nt = (a.lay.N + MT - 1) / MT;
-    const int has_next = l + 1 < a.d.L;
+    const int has_next = l + 1 < a.d.L && !a.node_skip_next;       // (skip: the next block's P | Q come from k_coord_proj)
     if (a.save) hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
                                    a.layers[has_next ? l + 1 : l], l, has_next, *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
@@ -1305,6 +1416,7 @@ template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, 
                                                a.layers[l], l, TrainSave{});
     else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
 }
+#if CMDGEN_EXPERIMENTS
 // the merged launch exists for the tile pairs cmdgen_set_layout picks on the split engine (everything else: two launches)
 template <int H> static bool launch_coord_msg(const EvalLaunch& a, int l /* block of the messages; < 0: only say whether the pair exists */, hipStream_t s) {
     if constexpr (H != 256) return false;
@@ -1327,6 +1439,29 @@ template <int H> static bool launch_coord_msg(const EvalLaunch& a, int l /* bloc
         return false;
     }
 }
+// coordinate tiles + next block's P | Q projection tiles in one launch; MTP from a.proj_mt (32 or 64)
+template <int H> static bool launch_coord_proj(const EvalLaunch& a, int l /* < 0: only say whether the variant exists */, hipStream_t s) {
+    if constexpr (H != 256) return false;
+    else {
+        if (!a.split || !a.layers[0].Wpq_e.ws) return false;
+        if (l < 0) return a.coord_mt == 64 || a.coord_mt == 32 || a.coord_mt == 16;
+        const int mtp = a.proj_mt == 64 ? 64 : 32;
+        const int n_proj = 4 * ((a.lay.N + mtp - 1) / mtp);
+        const int grid = n_proj + a.coord_grid;                 // (n_proj is a multiple of 4; xcd_tile's vb % 8 need not match blockIdx % 8: placement only)
+#define CP(MC, SC, MP) if (a.coord_mt == MC && mtp == MP) {                                                                                      \
+            if (a.pe_start) hipExtLaunchKernelGGL((k_coord_proj<MC, SC, MP>), dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, \
+                                                  a.layers[l], a.layers[l + 1], l, n_proj);                                                       \
+            else hipLaunchKernelGGL((k_coord_proj<MC, SC, MP>), dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[l + 1], l, n_proj); \
+            return true; }
+        CP(64, true, 64) CP(64, true, 32) CP(32, true, 64) CP(32, true, 32) CP(16, false, 64) CP(16, false, 32)
+#undef CP
+        return false;
+    }
+}
+#else
+template <int H> static bool launch_coord_msg(const EvalLaunch&, int, hipStream_t) { return false; }
+template <int H> static bool launch_coord_proj(const EvalLaunch&, int, hipStream_t) { return false; }
+#endif
 // tiles of >= 32 rows run on the split-bf16 engine when the launch asks for it (the training forward: only its two edge
 // kernels, and only when the step re-packed split weights for them - save_split); 16-row tiles are always fp32 MFMA
 // (there the L2 weight stream, not the matrix rate, binds)
@@ -1379,6 +1514,8 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     REC();
     // k_edge_coord(l-1) and k_edge_msg(l) in one launch (k_coord_msg) wherever nothing has to look in between
     const bool merge = a.merge_coord && !a.save && !ev && a.stop_block < 0 && launch_coord_msg<H>(a, -1, s);
+    // the next block's P | Q projections out of k_node into the coordinate kernel's launch (k_coord_proj)
+    const bool move_proj = !merge && a.proj_split && !a.save && !ev && a.stop_block < 0 && launch_coord_proj<H>(a, -1, s);
     bool coord_pending = false;              // block l-1's coordinate update has not been launched yet
     for (int l = 0; l < a.d.L; ++l) {
         const int stop = a.stop_block == l ? a.stop_stage : 0;        // parity aid: leave intermediates in the workspace
@@ -1389,10 +1526,13 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         coord_pending = false;
         REC(); REC();
         if (stop == 1) return;
+        a.node_skip_next = move_proj ? 1 : 0;
         PROF_BEGIN(1); MT_DISPATCH(a.node_mt, launch_node, a, l, s); PROF_END();
+        a.node_skip_next = 0;
         REC(); REC();
         if (stop == 2) return;
         if (merge && l + 1 < a.d.L) coord_pending = true;
+        else if (move_proj && l + 1 < a.d.L) { PROF_BEGIN(2); launch_coord_proj<H>(a, l, s); PROF_END(); }
         else { PROF_BEGIN(2); MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF_END(); }
         REC();
         if (stop == 3) return;
