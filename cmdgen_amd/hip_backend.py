@@ -102,12 +102,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH):
+    path = os.environ.get('CMDGEN_LIB', _LIB_PATH)      # diagnostic builds (-DCMDGEN_STAMPS=n, tools/build_variant.sh) only
+    if not os.path.exists(path):
         raise CmdgenError(
-            f'{_LIB_PATH} is missing: build it with `python __graft_entry__.py` '
+            f'{path} is missing: build it with `python __graft_entry__.py` '
             '(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.')
     import torch  # noqa: F401  - loads the process's HIP runtime first so both share it
-    lib = C.CDLL(_LIB_PATH)
+    lib = C.CDLL(path)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args
