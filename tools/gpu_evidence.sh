@@ -1,7 +1,7 @@
 #!/bin/bash
 # One pass over everything profiles/ cites (run on the GPU box: gpurun -- 'bash tools/gpu_evidence.sh <tag>').
 # Writes under gpurun_out/<tag>_*; kernel_traffic.json is stamped with the hash of the kernel sources it was measured on.
-tag=${1:-r02_zz}
+tag=${1:-r03_z}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out
 set -o pipefail
@@ -10,8 +10,8 @@ run 700 python -m pytest tests -m gpu -q > $o/${tag}_gpu_tests.log 2>&1; tail -3
 run 300 python -m pytest tests/test_hip_split.py -q -s 2>&1 | grep -E "max\|d eps\||RMS|passed|failed" > $o/${tag}_split_tests.log
 run 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $o/${tag}_smoke.txt
 run 300 python bench.py --steps 5 --warmup 2 > $o/${tag}_bench_b64.json 2> $o/${tag}_bench_b64.err
-BARGS="--steps 1 --warmup 0 --timesteps 200 --no-cpu-baseline --north-star-batch 0"     # PMC passes serialise every dispatch: a 200-step chain is plenty
-run 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --north-star-batch 0 > /dev/null 2>&1
+BARGS="--steps 1 --warmup 0 --timesteps 200 --no-cpu-baseline --north-star-batch 0 --no-extra-shapes"     # PMC passes serialise every dispatch: a 200-step chain is plenty
+run 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --north-star-batch 0 --no-extra-shapes > /dev/null 2>&1
 cp $(find $o/${tag}_stats -name "*kernel_stats.csv" | head -1) $o/${tag}_kernel_stats_b64_T1000.csv; rm -rf $o/${tag}_stats
 run 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py $BARGS > /dev/null 2> $o/pmc_fetch.err
 run 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py $BARGS > /dev/null 2> $o/pmc_write.err
