@@ -424,6 +424,8 @@ static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, 
         ALLOC(w.erow, int, ce, false); ALLOC(w.ecol, int, ce, false); ALLOC(w.ed0, float, ce, false);
         ALLOC(w.crow, int, cec, false); ALLOC(w.ccol, int, cec, false); ALLOC(w.cd0, float, cec, false);
         ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true); ALLOC(w.sync, int, 4, true);
+        // exchange buffers of k_node_pair: one pair of workgroups per two CUs at most (64 KB + two flags per pair)
+        ALLOC(w.pair_scratch, float, (size_t)(h->n_cus / 2) * 2 * 32 * H, true); ALLOC(w.pair_flags, int, (size_t)(h->n_cus / 2) * 2, true);
         ALLOC(w.eps_tmp, float, (size_t)cNl * (3 + d.P), true);
         ALLOC(w.dbg, unsigned long long, 64, true);
 #undef ALLOC
@@ -546,6 +548,12 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     a.split = h->gemm_split ? 1 : 0;
     a.n_cus = h->n_cus;
+    {   // k_node_pair (kernels_node_pair.hip: two workgroups share a 32-row tile by output columns, half the weight bytes per CU, one
+        // 32 KB exchange through L2): parity-green, 30.5 us against 30.2 us for the 16-row kernel at 64 pockets - the chip's L2 delivers
+        // ~17-22 TB/s to 236 CUs together, and what the halved stream saves the exchange and the doubled tile load give back
+        // (profiles/r03_k_node_pair.txt).  Opt-in: CMDGEN_NODE_PAIR=1.
+        const char* ev = getenv("CMDGEN_NODE_PAIR"); a.node_pair = (h->dims.H == 256 && h->gemm_split && h->node_mt == 16 && ev && atoi(ev) != 0) ? 1 : 0;
+        a.pair_cap = h->n_cus / 2; }
     {   // k_coord_proj (library built with -DCMDGEN_EXPERIMENTS=1 only): the next block's P | Q projections as column-sliced tiles beside the coordinate tiles
         const char* ev = getenv("CMDGEN_PROJ_SPLIT");
         a.proj_split = (h->dims.H == 256 && h->gemm_split && !h->dims.joint && ev && atoi(ev) != 0) ? 1 : 0;      // measured: +1 % at B=64, -3.6 % at B=256 (profiles/r03_f): off
@@ -1194,6 +1202,7 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "gemm_split") *value = a.split;
     else if (k == "node16_split") *value = a.split16;
     else if (k == "proj_split") *value = a.proj_split;
+    else if (k == "node_pair") *value = (a.node_pair && 2 * ((h->lay.N + 31) / 32) <= a.n_cus) ? 1 : 0;
     else if (k == "train_edges") *value = h->train_E;
     else if (k == "train_coord_edges") *value = h->train_Ec;
     else return fail(h, CMDGEN_EINVAL, "unknown query '%s'", key);

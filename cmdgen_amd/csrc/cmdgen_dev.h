@@ -115,6 +115,8 @@ struct Work {                   // per-layout workspace; all pointers device
     unsigned long long* counters;   // cmdgen_counters
     int*    nan_flag;           // [1] set by readout when any velocity is NaN
     int*    sync;               // [4] [0]: coordinate-role workgroups of the running k_coord_msg launch that have finished (reset by k_node)
+    float*  pair_scratch;       // [pair_cap][2][32][H] partial sums the two halves of a k_node_pair tile exchange (kernels_node_pair.hip)
+    int*    pair_flags;         // [pair_cap][2] "my partial sums are out"; zero between launches
     float*  eps_tmp;            // [Nl][3+P] evaluation output used by the chain
     unsigned long long* dbg;    // [64] diagnostic builds only (-DCMDGEN_STAMPS): summed in-kernel cycle stamps
 };
@@ -199,6 +201,8 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int split16 = 0;            // 1: 16-row node tiles too (Eng<16, true>; CMDGEN_NODE16_SPLIT=0 opts out)
     int merge_coord = 0;        // 1: k_edge_coord(l-1) and k_edge_msg(l) share a launch (k_coord_msg; sampler, H = 256)
     int n_cus = 256;
+    int node_pair = 0;          // 1: small batches run k_node as pairs of workgroups sharing a 32-row tile by output columns (k_node_pair)
+    int pair_cap = 0;           //    pairs the exchange buffers hold
     int proj_split = 0;         // 1: the next block's P | Q projections run as column-sliced tiles in the coordinate kernel's launch (k_coord_proj)
     int proj_mt = 32;           //    rows per projection tile there (32 or 64)
     mutable int node_skip_next = 0;   // set around the k_node launch whose next-block projections moved

@@ -179,3 +179,58 @@ def test_bounded_chain_with_16_row_split_node_tiles(name, use_graph, monkeypatch
     assert np.array_equal(xh_phar[:, 3:].cpu().numpy(), want[:, 3:])
     assert st['max_rel_com_error'] < 1e-2 and st['nan_resets'] == 0
     h.close()
+
+
+# ----------------------------------------------------------------------------- k_node_pair (round 3): two workgroups share a 32-row tile
+@pytest.mark.parametrize('name', [n for n in cases_of(G2) if '_h256_' in n])
+def test_node_pair_kernel_matches_reference(name, monkeypatch):
+    """k_node_pair (kernels_node_pair.hip: GEMM1 / projections cut by output columns, GEMM2 by K, partial sums exchanged through
+    L2 between the two workgroups of a pair) against the reference's output on every H = 256 evaluation fixture, next to the
+    single-workgroup 16-row kernel."""
+    cfg, sd, inp = dynamics_case(G2, name)
+    want = G2[name + '/eps_phar']
+    errs = {}
+    for pair in ('1', '0'):
+        monkeypatch.setenv('CMDGEN_NODE_PAIR', pair)
+        h = new_handle(cfg, sd)
+        h.set_layout(G2[name + '/num_nodes_phar'], G2[name + '/pocket_size'])
+        assert h.query('node_pair') == int(pair)
+        for _ in range(3):      # the flags must return to zero between launches: several evaluations in a row
+            eps, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']))
+        torch.cuda.synchronize()
+        errs[pair] = float(np.abs(eps.cpu().numpy() - want).max())
+        h.close()
+    tol = EVAL_TOL * max(1.0, float(np.abs(want).max()))
+    print(f'{name}: max|d eps| pair kernel {errs["1"]:.2e}  16-row kernel {errs["0"]:.2e}  (tolerance {tol:.1e})')
+    assert errs['1'] <= tol and errs['0'] <= tol
+
+
+def test_node_pair_kernel_at_headline_size_equals_single_workgroup_kernel(monkeypatch):
+    """64 pockets (118 pairs = 236 workgroups, one per CU): one evaluation at the trained geometry, pair kernel vs 16-row kernel,
+    and 200 graph-replayed steps with the pair kernel leave no wait that gave up (cmdgen_chain_status would raise)."""
+    from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
+    cfg = ModelConfig(timesteps=1000, noise_precision=0.1, norm_values=(1.0, 0.25))
+    sd = make_state_dict(cfg, seed=0)
+    pb = make_pockets(64, 'CA', n_phar=15)
+    rng = np.random.Generator(np.random.PCG64(5))
+    nl = int(pb.num_nodes_phar.sum())
+    com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(64)])
+    xh = np.concatenate([com[np.repeat(np.arange(64), 15)] + rng.normal(size=(nl, 3)) * 2.0, rng.normal(size=(nl, 8))], 1).astype(np.float32)
+    xq = np.concatenate([pb.x, pb.one_hot / 0.25], 1).astype(np.float32)
+    t = np.full((64, 1), 0.4, np.float32)
+    outs = {}
+    for pair in ('1', '0'):
+        monkeypatch.setenv('CMDGEN_NODE_PAIR', pair)
+        h = new_handle(cfg, sd)
+        h.set_layout(pb.num_nodes_phar, pb.size)
+        assert h.query('node_pair') == int(pair)
+        eps, _ = h.dynamics_forward(dev(xh), dev(xq), dev(t))
+        outs[pair] = eps.cpu().numpy()
+        if pair == '1':
+            h.sample_chain(dev(pb.x), dev(pb.one_hot), 200, noise=None, seed=3, pocket_ids=pb.pocket_index, use_graph=True)
+            st = h.chain_status()           # raises if any in-launch wait timed out
+            assert st['nan_resets'] == 0 and st['max_rel_com_error'] < 1e-2
+        h.close()
+    err = float(np.abs(outs['1'] - outs['0']).max())
+    print(f'pair kernel vs 16-row kernel at 64 pockets: max|d eps| {err:.2e} (max|eps| {np.abs(outs["0"]).max():.2f})')
+    assert err <= EVAL_TOL * max(1.0, float(np.abs(outs['0']).max()))

@@ -6,6 +6,11 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p build
 C=cmdgen_amd/csrc
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function -Wno-unused-value "$@" -c $C/kernels_egnn.hip -o build/kernels_egnn_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcmdgen_hip_$name.so $C/cmdgen_api.o build/kernels_egnn_$name.o $C/kernels_ddpm.o $C/kernels_joint.o $C/kernels_train.o $C/cmdgen_train.o
+# FILE=kernels_node_pair.hip tools/build_variant.sh ... rebuilds that file instead of kernels_egnn.hip
+f=${FILE:-kernels_egnn.hip}
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function -Wno-unused-value "$@" -c $C/$f -o build/${f%.hip}_$name.o
+egnn=$C/kernels_egnn.o; pairo=$C/kernels_node_pair.o
+[ "$f" = kernels_egnn.hip ] && egnn=build/kernels_egnn_$name.o
+[ "$f" = kernels_node_pair.hip ] && pairo=build/kernels_node_pair_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcmdgen_hip_$name.so $C/cmdgen_api.o $egnn $pairo $C/kernels_ddpm.o $C/kernels_joint.o $C/kernels_train.o $C/cmdgen_train.o
 echo build/libcmdgen_hip_$name.so
