@@ -548,6 +548,11 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     a.split = h->gemm_split ? 1 : 0;
     a.n_cus = h->n_cus;
+    {   // k_node64 (kernels_node64.hip: 64-row node tiles, both images in LDS, split pinned between the MFMAs): parity-green, 81.0 vs
+        // 83.2 us at 256 C-alpha pockets, 136 vs 125 us on full-atom pockets - its k-blocks are VALU-bound (four waves each split the
+        // same A fragments: 1130 cycles per k-block against 768 of MFMA; profiles/r03_m_node64.txt).  Opt-in: CMDGEN_NODE64=1.
+        const char* ev = getenv("CMDGEN_NODE64");
+        a.node64 = (h->dims.H == 256 && h->gemm_split && ev && atoi(ev) != 0) ? 1 : 0; }
     {   // k_node_pair (kernels_node_pair.hip: two workgroups share a 32-row tile by output columns, half the weight bytes per CU, one
         // 32 KB exchange through L2): parity-green, 30.5 us against 30.2 us for the 16-row kernel at 64 pockets - the chip's L2 delivers
         // ~17-22 TB/s to 236 CUs together, and what the halved stream saves the exchange and the doubled tile load give back
@@ -1202,6 +1207,7 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "gemm_split") *value = a.split;
     else if (k == "node16_split") *value = a.split16;
     else if (k == "proj_split") *value = a.proj_split;
+    else if (k == "node64") *value = a.node64;
     else if (k == "node_pair") *value = (a.node_pair && 2 * ((h->lay.N + 31) / 32) <= a.n_cus) ? 1 : 0;
     else if (k == "train_edges") *value = h->train_E;
     else if (k == "train_coord_edges") *value = h->train_Ec;

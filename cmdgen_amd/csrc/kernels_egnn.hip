@@ -20,6 +20,7 @@
 #define LDA(H) ((H) + 4)
 
 bool cmdgen_launch_node_pair(const EvalLaunch& a, int l, hipStream_t s);      // kernels_node_pair.hip: k_node for small batches
+bool cmdgen_launch_node64(const EvalLaunch& a, int l, hipStream_t s);         // kernels_node64.hip: k_node for large batches
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e.
 // drains every outstanding global store / atomic of the wave (1-3 us each time); the barriers of
@@ -1530,7 +1531,8 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         if (stop == 1) return;
         a.node_skip_next = move_proj ? 1 : 0;
         PROF_BEGIN(1);
-        if (!(a.node_pair && !move_proj && cmdgen_launch_node_pair(a, l, s))) MT_DISPATCH(a.node_mt, launch_node, a, l, s);
+        if (!(a.node64 && !move_proj && cmdgen_launch_node64(a, l, s)) && !(a.node_pair && !move_proj && cmdgen_launch_node_pair(a, l, s)))
+            MT_DISPATCH(a.node_mt, launch_node, a, l, s);
         PROF_END();
         a.node_skip_next = 0;
         REC(); REC();

@@ -234,3 +234,47 @@ def test_node_pair_kernel_at_headline_size_equals_single_workgroup_kernel(monkey
     err = float(np.abs(outs['1'] - outs['0']).max())
     print(f'pair kernel vs 16-row kernel at 64 pockets: max|d eps| {err:.2e} (max|eps| {np.abs(outs["0"]).max():.2f})')
     assert err <= EVAL_TOL * max(1.0, float(np.abs(outs['0']).max()))
+
+
+# ----------------------------------------------------------------------------- k_node64 (round 3): 64-row node tiles, both images in LDS
+@pytest.mark.parametrize('name', [n for n in cases_of(G2) if '_h256_' in n] + ['dyn_fa366_b2'])
+def test_node64_kernel_matches_reference(name, monkeypatch):
+    """k_node64 (kernels_node64.hip) forced on (CMDGEN_NODE64=1) against the reference's output: every H = 256 evaluation fixture
+    (ragged tiles, tiles that mix phar and pocket rows) and configs[4]'s shape (762 rows = 12 tiles), next to the 32-row kernel."""
+    G = G12 if name.startswith('dyn_fa') else G2
+    cfg, sd, inp = dynamics_case(G, name)
+    want = G[name + '/eps_phar']
+    errs = {}
+    for n64 in ('1', '0'):
+        monkeypatch.setenv('CMDGEN_NODE64', n64)
+        h = new_handle(cfg, sd)
+        h.set_layout(G[name + '/num_nodes_phar'], G[name + '/pocket_size'])
+        assert h.query('node64') == int(n64)
+        eps, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']))
+        eps, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']))      # agg must have been left zero
+        torch.cuda.synchronize()
+        errs[n64] = float(np.abs(eps.cpu().numpy() - want).max())
+        h.close()
+    tol = EVAL_TOL * max(1.0, float(np.abs(want).max()))
+    print(f'{name}: max|d eps| 64-row kernel {errs["1"]:.2e}  default {errs["0"]:.2e}  (tolerance {tol:.1e})')
+    assert errs['1'] <= tol and errs['0'] <= tol
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_bounded_chain_with_node64(use_graph, monkeypatch):
+    """The K = T = 500 reference chain of G13 with the node kernel on 64-row tiles: 1e-4 A absolute, types exact."""
+    monkeypatch.setenv('CMDGEN_NODE64', '1')
+    name = 'ca_h256_KT_np05'
+    cfg, sd, pb, K = bounded_case(G13, name)
+    h = new_handle(cfg, sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    assert h.query('node64') == 1
+    h.set_step_table(K, host_step_table(cfg, K))
+    xh_phar, xh_pocket, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=dev(G13[name + '/noise']), use_graph=use_graph)
+    st = h.chain_status()
+    want = G13[name + '/xh_phar']
+    err = rms(xh_phar[:, :3].cpu().numpy(), want[:, :3])
+    print(f'{name} graph={use_graph} 64-row node tiles: coordinate RMS vs reference {err:.3e} A')
+    assert err <= 1e-4 and np.array_equal(xh_phar[:, 3:].cpu().numpy(), want[:, 3:])
+    assert st['max_rel_com_error'] < 1e-2 and st['nan_resets'] == 0
+    h.close()

@@ -12,5 +12,7 @@ f=${FILE:-kernels_egnn.hip}
 egnn=$C/kernels_egnn.o; pairo=$C/kernels_node_pair.o
 [ "$f" = kernels_egnn.hip ] && egnn=build/kernels_egnn_$name.o
 [ "$f" = kernels_node_pair.hip ] && pairo=build/kernels_node_pair_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcmdgen_hip_$name.so $C/cmdgen_api.o $egnn $pairo $C/kernels_ddpm.o $C/kernels_joint.o $C/kernels_train.o $C/cmdgen_train.o
+n64o=$C/kernels_node64.o
+[ "$f" = kernels_node64.hip ] && n64o=build/kernels_node64_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcmdgen_hip_$name.so $C/cmdgen_api.o $egnn $pairo $n64o $C/kernels_ddpm.o $C/kernels_joint.o $C/kernels_train.o $C/cmdgen_train.o
 echo build/libcmdgen_hip_$name.so
