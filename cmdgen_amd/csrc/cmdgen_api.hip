@@ -548,11 +548,21 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     a.split = h->gemm_split ? 1 : 0;
     a.n_cus = h->n_cus;
-    {   // k_node64 (kernels_node64.hip: 64-row node tiles, both images in LDS, split pinned between the MFMAs): parity-green, 81.0 vs
-        // 83.2 us at 256 C-alpha pockets, 136 vs 125 us on full-atom pockets - its k-blocks are VALU-bound (four waves each split the
-        // same A fragments: 1130 cycles per k-block against 768 of MFMA; profiles/r03_m_node64.txt).  Opt-in: CMDGEN_NODE64=1.
+    {   // k_node64 (kernels_node64.hip: 64-row node tiles, the A operand as producer-side bf16 planes, one workgroup per CU) against
+        // k_node<H, 32> (register split, two workgroups per CU).  Per launch the 64-row kernel takes ~0.89 of a co-resident pair of
+        // 32-row tiles, a 32-row tile alone on its CU ~0.62 of that 64-row tile (profiles/r03_m_node64.txt), so the choice is a matter
+        // of how the tiles fill the CUs: compare the rounds each needs.  CMDGEN_NODE64 = 0 / 1 overrides.
         const char* ev = getenv("CMDGEN_NODE64");
-        a.node64 = (h->dims.H == 256 && h->gemm_split && ev && atoi(ev) != 0) ? 1 : 0; }
+        int on = 0;
+        if (h->dims.H == 256 && h->gemm_split && h->n_cus > 0 && h->have_layout) {
+            const int ncu = h->n_cus, t64 = (h->lay.N + 63) / 64, t32 = (h->lay.N + 31) / 32;
+            const float cost64 = (float)((t64 + ncu - 1) / ncu);
+            const int full = t32 / (2 * ncu), rem = t32 - full * 2 * ncu;
+            const float cost32 = 1.12f * full + (rem == 0 ? 0.f : rem <= ncu ? 0.62f : 1.12f);
+            on = cost64 < cost32;
+            if (ev) on = atoi(ev) != 0;
+        }
+        a.node64 = on; }
     {   // k_node_pair (kernels_node_pair.hip: two workgroups share a 32-row tile by output columns, half the weight bytes per CU, one
         // 32 KB exchange through L2): parity-green, 30.5 us against 30.2 us for the 16-row kernel at 64 pockets - the chip's L2 delivers
         // ~17-22 TB/s to 236 CUs together, and what the halved stream saves the exchange and the doubled tile load give back

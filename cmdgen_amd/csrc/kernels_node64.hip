@@ -1,84 +1,81 @@
-// kernels_node64.hip - k_node for LARGE batches: 64-row tiles, both operands' images in LDS, one workgroup per CU.
+// kernels_node64.hip - k_node for LARGE batches: 64-row tiles, the A operand as producer-side bf16 planes.
 //
-// Why.  A node tile streams every weight of the block's GEMM chain (GCL.node_model, egnn_new.py:48-58, and the first-layer
-// factorisation of the two edge MLPs): 7 H^2 x 6 B = 2.75 MB on the split engine, whatever its height.  With 32-row tiles
-// (kernels_egnn.hip, k_node<256,32>) 256 C-alpha pockets are 472 tiles = 1.3 GB of weight traffic per launch, full-atom pockets
-// 8.4 GB - 15.6 and 17.8 TB/s in the measured launch times, close to the streaming rate the chip's L2s deliver (17-22 TB/s,
-// tools/l2_stream_test.cpp).  A 64-row tile halves the bytes per row.  MEASURED (profiles/r03_m_node64.txt): no gain - the 32-row
-// kernel was not waiting for its stream after all; both variants spend ~1100 cycles per k-block where the MFMAs take 768, on the
-// VALU work of four waves that each split the same A fragments.  Kept opt-in (CMDGEN_NODE64=1) as the starting point of a
-// producer-side-planes version.  It needs what round 2's 64-row variant did not have: BOTH fp32 images in LDS (h kept for the residual,
-// agg -> T -> h_new: 2 x 66 KB, one workgroup per CU) and, with a single wave per SIMD, the register split of the A fragments
-// placed BETWEEN the MFMAs by hand (hipcc puts it in front of or behind a k-block's MFMAs: matrix pipe and VALU in series).
+// Why.  GCL.node_model + the projections (egnn_new.py:48-58 and the first-layer factorisation of the two edge MLPs) are a
+// chain of seven [rows, 256] x [256, 256] products per tile.  On the split engine (cmdgen_split.h: six bf16 MFMAs per fp32
+// product) the node kernels of kernels_egnn.hip keep the tile as an fp32 LDS image and every wave splits the fragments it
+// reads in registers - four waves splitting the SAME A fragments, ~130 VALU operations per k-block next to 24 MFMAs: measured
+// ~1100 cycles per k-block where the MFMAs take 768 (profiles/r03_m_node64.txt, which also holds the numbers of the register-split
+// 64-row variant this file replaced).  Here whoever WRITES the tile splits each element once and stores three bf16 planes (as the
+// edge kernels do), so the GEMM loops carry no conversion work at all: 24 MFMAs and 12 loads per k-block, one load pinned in the
+// shadow of every two MFMAs (~840 cycles per k-block).
 //
-// Tile: 64 rows x 256 columns, 4 waves x 64 columns (2 x 2 accumulator tiles of 32 x 32), v_mfma_f32_32x32x16_bf16, six bf16
-// products per fp32 product (cmdgen_split.h), weight fragments three k-blocks ahead in a ring of four register sets carried from
-// one GEMM of the chain into the next.
+// LDS: one plane image of 64 rows x 256 k (3 x 64 x 264 bf16 = 99 KB; one workgroup per CU) that holds, one after the other,
+// h, agg / nf, T = SiLU(.), h_new.  The residual's h comes back from L2 in the accumulator layout while the W4 product runs;
+// agg is requested into registers while the h-part of the first product runs.
+// Tile: 64 rows x 256 columns, 4 waves x 64 columns (2 x 2 accumulator tiles of 32 x 32), v_mfma_f32_32x32x16_bf16; weight
+// fragments three k-blocks ahead in a ring of four register sets carried from one GEMM of the chain into the next.
 #include "cmdgen_dev.h"
 #include <hip/hip_ext.h>
 
-#define NLDA 260            // floats per LDS row: 256 + 4 (conflict-free ds_read_b128)
+#define NPLD 264            // bf16 per plane row: 256 + 8 (row stride 528 B: conflict-free ds_read_b128)
 #define NROWS 64
+#define NPE (NROWS * NPLD)  // bf16 per plane
 #define NRING 4
 
 __device__ __forceinline__ void n64_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct N64Ring { sbf16x8 b[NRING][2][3]; };     // k-blocks x two 32-column tiles x three pieces
 
-// acc[m][n] += A(lds fp32 image, 64 rows, first k at `ap`) x W_n^T over K = 256 (16 k-blocks) for the wave's two 32-column tiles.
-// cur[n] / nxt[n]: WAVE-UNIFORM pointers to k-block 0 of tile n of this GEMM / the next one; the lane's 16 bytes at [lane + 64 piece].
-// On entry the ring holds k-blocks 0, 1, 2 of this GEMM in sets 0, 1, 2; on exit those of the next.  Per k-block: 24 MFMAs, and
-// between them, pinned by sched_barriers, the eight pair-splits (11 VALU operations each) of the NEXT block's two A fragments.
-__device__ __forceinline__ void n64_gemm(const float* ap, const sbf16x8* const (&cur)[2], const sbf16x8* const (&nxt)[2],
+// acc[m][n] += A(planes) x W_n^T over K = 256 (16 k-blocks) for the wave's two 32-column tiles.  planes: the three bf16 planes of
+// the 64-row tile; cur[n] / nxt[n]: WAVE-UNIFORM pointers to k-block 0 of tile n of this GEMM / the next one (the lane's 16 bytes at
+// [lane + 64 piece]).  On entry the ring holds k-blocks 0, 1, 2 of this GEMM in sets 0, 1, 2; on exit those of the next.
+__device__ __forceinline__ void n64_gemm(const unsigned short* planes, const sbf16x8* const (&cur)[2], const sbf16x8* const (&nxt)[2],
                                          sf32x16 (&acc)[2][2], N64Ring& ring) {
     constexpr int KB16 = 16;
     const int lane = threadIdx.x & 63;
-    float4 raw[2][2][2];                             // [set][m][half of the 8 k-values]
-    uint32_t pa[2][2][4], pb[2][2][4], pc[2][2][4];  // [set][m][pair]: the three bf16 pieces, as packed pairs
-    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-#define NG_FRAG(P, S, M) __builtin_bit_cast(sbf16x8, (u4v){P[S][M][0], P[S][M][1], P[S][M][2], P[S][M][3]})
-#define NG_LOADB(SET, KB) { const bool in_ = (KB) < KB16; _Pragma("unroll") for (int n = 0; n < 2; ++n) {                       \
-        const sbf16x8* q_ = in_ ? cur[n] + (unsigned)(KB) * 192u : nxt[n] + (unsigned)((KB) - KB16) * 192u;                       \
-        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) ring.b[SET][n][s_] = q_[lane + s_ * 64]; } }
-    // A reads run two blocks ahead; past the k-range they fetch the row's pad / the next row (in bounds, unused)
-#define NG_LOADA(SET, KB) _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                         \
-        raw[SET][m][0] = *reinterpret_cast<const float4*>(ap + m * 32 * NLDA + (KB) * 16);                                         \
-        raw[SET][m][1] = *reinterpret_cast<const float4*>(ap + m * 32 * NLDA + (KB) * 16 + 4); }
-#define NG_SP(DST, SET, M, J) { const float x_ = (J) == 0 ? raw[SET][M][0].x : (J) == 1 ? raw[SET][M][0].z : (J) == 2 ? raw[SET][M][1].x : raw[SET][M][1].z;   \
-                                const float y_ = (J) == 0 ? raw[SET][M][0].y : (J) == 1 ? raw[SET][M][0].w : (J) == 2 ? raw[SET][M][1].y : raw[SET][M][1].w;   \
-                                split3_pair(x_, y_, pa[DST][M][J], pb[DST][M][J], pc[DST][M][J]); }
-#define NG_SB() __builtin_amdgcn_sched_barrier(0);
-#define NG_MF(M, N, AP, AS, BS, BI) acc[M][N] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NG_FRAG(AP, AS, M), ring.b[BS][N][BI], acc[M][N], 0, 0, 0);
-    // three MFMAs (one piece pairing over three of the four accumulator tiles ...), then one pair-split of the next block; small terms first
-#define NG_TRIPLE(AS, BS, X0, X1, X2) X0 X1 X2 NG_SB()
-#define NG_BODY(AS, BS)                                                                                                                                      \
-        NG_MF(0, 0, pc, AS, BS, 0) NG_MF(0, 1, pc, AS, BS, 0) NG_MF(1, 0, pc, AS, BS, 0) NG_SB() NG_SP((AS) ^ 1, (AS) ^ 1, 0, 0) NG_SB()                    \
-        NG_MF(1, 1, pc, AS, BS, 0) NG_MF(0, 0, pb, AS, BS, 1) NG_MF(0, 1, pb, AS, BS, 1) NG_SB() NG_SP((AS) ^ 1, (AS) ^ 1, 0, 1) NG_SB()                    \
-        NG_MF(1, 0, pb, AS, BS, 1) NG_MF(1, 1, pb, AS, BS, 1) NG_MF(0, 0, pa, AS, BS, 2) NG_SB() NG_SP((AS) ^ 1, (AS) ^ 1, 0, 2) NG_SB()                    \
-        NG_MF(0, 1, pa, AS, BS, 2) NG_MF(1, 0, pa, AS, BS, 2) NG_MF(1, 1, pa, AS, BS, 2) NG_SB() NG_SP((AS) ^ 1, (AS) ^ 1, 0, 3) NG_SB()                    \
-        NG_MF(0, 0, pb, AS, BS, 0) NG_MF(0, 1, pb, AS, BS, 0) NG_MF(1, 0, pb, AS, BS, 0) NG_SB() NG_SP((AS) ^ 1, (AS) ^ 1, 1, 0) NG_SB()                    \
-        NG_MF(1, 1, pb, AS, BS, 0) NG_MF(0, 0, pa, AS, BS, 1) NG_MF(0, 1, pa, AS, BS, 1) NG_SB() NG_SP((AS) ^ 1, (AS) ^ 1, 1, 1) NG_SB()                    \
-        NG_MF(1, 0, pa, AS, BS, 1) NG_MF(1, 1, pa, AS, BS, 1) NG_MF(0, 0, pa, AS, BS, 0) NG_SB() NG_SP((AS) ^ 1, (AS) ^ 1, 1, 2) NG_SB()                    \
-        NG_MF(0, 1, pa, AS, BS, 0) NG_MF(1, 0, pa, AS, BS, 0) NG_MF(1, 1, pa, AS, BS, 0) NG_SB() NG_SP((AS) ^ 1, (AS) ^ 1, 1, 3) NG_SB()
-#define NG_BLOCK(I) {                                                                                         \
-        NG_LOADB(((I) + NRING - 1) & (NRING - 1), kb + (I) + NRING - 1)                                       \
-        NG_SB()                                                                                               \
-        NG_BODY((I) & 1, (I) & (NRING - 1))                                                                   \
-        NG_LOADA((I) & 1, kb + (I) + 2)                                                                       \
-        NG_SB() }
-    NG_LOADA(0, 0) NG_LOADA(1, 1)
-    NG_SP(0, 0, 0, 0) NG_SP(0, 0, 0, 1) NG_SP(0, 0, 0, 2) NG_SP(0, 0, 0, 3) NG_SP(0, 0, 1, 0) NG_SP(0, 0, 1, 1) NG_SP(0, 0, 1, 2) NG_SP(0, 0, 1, 3)
+    const unsigned short* ap = planes + (lane & 31) * NPLD + (lane >> 5) * 8;
+    sbf16x8 a[2][2][3];                              // [set][m][piece]
+    // one 16-byte load each: the weight fragment (tile n, piece s) of k-block KB into ring set SET / the A fragment (rows 32 m.., piece s)
+#define NG_LB(SET, KB, N, S) ring.b[SET][N][S] = (N == 0 ? q0_ : q1_)[lane + (S) * 64];
+    // (past the k-range the A reads fetch the row's pad / the next row: in bounds, unused)
+#define NG_LA(SET, KB, M, S) a[SET][M][S] = *reinterpret_cast<const sbf16x8*>(ap + (S) * NPE + (M) * 32 * NPLD + (KB) * 16);
+#define NG_LOADA(SET, KB) NG_LA(SET, KB, 0, 0) NG_LA(SET, KB, 0, 1) NG_LA(SET, KB, 0, 2) NG_LA(SET, KB, 1, 0) NG_LA(SET, KB, 1, 1) NG_LA(SET, KB, 1, 2)
+#define NG_MF(M, N, AS, AI, BS, BI) acc[M][N] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][M][AI], ring.b[BS][N][BI], acc[M][N], 0, 0, 0);
+    // one group = one load and the two MFMAs of one row half (pieces AI x BI), pinned: the loads issue in the shadow of the MFMAs
+    // instead of in a burst between k-blocks (which left the matrix pipe idle ~100 cycles per block).  Small terms first.
+#define NG_GRP(LOAD, M, AS, BS, AI, BI) LOAD NG_MF(M, 0, AS, AI, BS, BI) NG_MF(M, 1, AS, AI, BS, BI) __builtin_amdgcn_sched_barrier(0);
+#ifndef N64_EXP
+#define N64_EXP 0
+#endif
+#define NG_BLOCK(I) { constexpr int AS_ = (I) & 1, AN_ = ((I) + 1) & 1, BS_ = (I) & (NRING - 1), BN_ = ((I) + NRING - 1) & (NRING - 1);  \
+        const int ka_ = kb + (I) + 1, kq_ = kb + (I) + NRING - 1;                                             \
+        const bool in_ = kq_ < KB16; const unsigned ko_ = (unsigned)(in_ ? kq_ : kq_ - KB16) * 192u;           \
+        const sbf16x8* q0_ = (in_ ? cur[0] : nxt[0]) + ko_; const sbf16x8* q1_ = (in_ ? cur[1] : nxt[1]) + ko_; \
+        NG_GRP(NG_LA(AN_, ka_, 0, 2), 0, AS_, BS_, 2, 0) NG_GRP(NG_LA(AN_, ka_, 1, 2), 1, AS_, BS_, 2, 0)       \
+        NG_GRP(NG_LA(AN_, ka_, 0, 1), 0, AS_, BS_, 1, 1) NG_GRP(NG_LA(AN_, ka_, 1, 1), 1, AS_, BS_, 1, 1)       \
+        NG_GRP(NG_LA(AN_, ka_, 0, 0), 0, AS_, BS_, 0, 2) NG_GRP(NG_LA(AN_, ka_, 1, 0), 1, AS_, BS_, 0, 2)       \
+        NG_GRP(NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 1, 0) NG_GRP(NG_LB(BN_, kq_, 0, 1), 1, AS_, BS_, 1, 0)       \
+        NG_GRP(NG_LB(BN_, kq_, 0, 2), 0, AS_, BS_, 0, 1) NG_GRP(NG_LB(BN_, kq_, 1, 0), 1, AS_, BS_, 0, 1)       \
+        NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 0) NG_GRP(NG_LB(BN_, kq_, 1, 2), 1, AS_, BS_, 0, 0) }
+    NG_LOADA(0, 0)
 #pragma unroll 1
     for (int kb = 0; kb < KB16; kb += NRING) { NG_BLOCK(0) NG_BLOCK(1) NG_BLOCK(2) NG_BLOCK(3) }
-#undef NG_FRAG
-#undef NG_LOADB
+#undef NG_LB
+#undef NG_LA
 #undef NG_LOADA
-#undef NG_SP
-#undef NG_SB
 #undef NG_MF
-#undef NG_TRIPLE
-#undef NG_BODY
+#undef NG_GRP
 #undef NG_BLOCK
+}
+
+// two values of the SAME column and two rows (an accumulator register pair) -> the three planes: one packed conversion per piece,
+// low half to row ra, high half to row rb
+__device__ __forceinline__ void n64_split_store2(unsigned short* planes, int off_a, int off_b, float va, float vb) {
+    uint32_t p0, p1, p2;
+    split3_pair(va, vb, p0, p1, p2);
+    planes[off_a] = (unsigned short)p0;            planes[off_b] = (unsigned short)(p0 >> 16);
+    planes[NPE + off_a] = (unsigned short)p1;      planes[NPE + off_b] = (unsigned short)(p1 >> 16);
+    planes[2 * NPE + off_a] = (unsigned short)p2;  planes[2 * NPE + off_b] = (unsigned short)(p2 >> 16);
 }
 
 // a 32-column tile of a packed split weight ([nt][K/16][3 pieces][64 lanes] x 16 bytes) at k-block kb0: wave-uniform pointer
@@ -92,14 +89,13 @@ __device__ __forceinline__ float4 n64_node_pos(const Layout& lay, const Work& w,
     return make_float4(p.x + a.x / d.norm_factor, p.y + a.y / d.norm_factor, p.z + a.z / d.norm_factor, 0.f);
 }
 
-#define N64_FOREACH(ACC, BODY) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n) _Pragma("unroll") for (int r = 0; r < 16; ++r) { \
-        const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); const int col = 64 * wave + 32 * n + (lane & 31); const float v = ACC[m][n][r]; BODY }
+#define N64_ZERO(ACC) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n) _Pragma("unroll") for (int r = 0; r < 16; ++r) ACC[m][n][r] = 0.0f;
+// accumulator layout: register r of tile (m, n) -> row = 32 m + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = 64 wave + 32 n + (lane & 31)
+#define N64_ROW(M, R) ((M) * 32 + ((R) & 3) + 8 * ((R) >> 2) + 4 * (lane >> 5))
 
 __global__ __launch_bounds__(256, 1) void k_node64(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next) {
     constexpr int H = 256, LPR = H / 4;
-    __shared__ __attribute__((aligned(16))) float bufs[2 * NROWS * NLDA + 64];      // + the A prefetch's overshoot past the last row
-    float* buf0 = bufs;                          // h (kept for the residual)
-    float* buf1 = bufs + NROWS * NLDA;           // agg / nf  ->  T  ->  h_new
+    __shared__ __attribute__((aligned(16))) unsigned short planes[3 * NPE + 64];      // + the A prefetch's overshoot past the last row
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #if CMDGEN_STAMPS == 5      // diagnostic build: per-phase cycle stamps into w.dbg ([wave][phase] sums, [32 + wave] lifetime, [40] waves)
     unsigned long long nst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nst_t = __builtin_amdgcn_s_memtime();
@@ -127,76 +123,99 @@ __global__ __launch_bounds__(256, 1) void k_node64(Layout lay, Work w, Dims d, L
         const int n = row0 + tid;
         if (tid < nvalid && n < lay.Nm) w.XL[(size_t)layer * lay.Nm + n] = n64_node_pos(lay, w, d, n, layer);
     }
-    // both images in two batches of 32 rows: all loads of a batch in flight, then its LDS writes; agg is zeroed where it was read
+    // ---- h: rows in flight, then split once per element into the planes (four consecutive k per thread and row)
+    {
+        float4 hv[NROWS / 4];
 #pragma unroll
-    for (int bt = 0; bt < 2; ++bt) {
-        float4 hv[8], av[8];
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int r = bt * 32 + pass * 4 + rsub;
-            hv[pass] = make_float4(0.f, 0.f, 0.f, 0.f); av[pass] = hv[pass];
-            if (r < nvalid) {
-                hv[pass] = reinterpret_cast<const float4*>(w.h + (size_t)(row0 + r) * H)[c4];
-                av[pass] = reinterpret_cast<const float4*>(w.agg + (size_t)(row0 + r) * H)[c4];
-            }
+        for (int pass = 0; pass < NROWS / 4; ++pass) {
+            const int r = pass * 4 + rsub;
+            hv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nvalid) hv[pass] = reinterpret_cast<const float4*>(w.h + (size_t)(row0 + r) * H)[c4];
         }
-        if (bt == 1) {          // the first GEMM's weight fragments: requested behind the tile's own loads (vmcnt retires in order)
+        // the first GEMM's weight fragments: requested behind the tile's own loads (vmcnt retires in order)
 #pragma unroll
-            for (int kb = 0; kb < NRING - 1; ++kb)
+        for (int kb = 0; kb < NRING - 1; ++kb)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int s_ = 0; s_ < 3; ++s_) ring.b[kb][n][s_] = t3a[n][(unsigned)kb * 192u + lane + s_ * 64];
-        }
+                for (int s_ = 0; s_ < 3; ++s_) ring.b[kb][n][s_] = t3a[n][(unsigned)kb * 192u + lane + s_ * 64];
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int r = bt * 32 + pass * 4 + rsub;
-            if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
-            float4 v = av[pass];
-            v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
-            *reinterpret_cast<float4*>(buf0 + r * NLDA + 4 * c4) = hv[pass];
-            *reinterpret_cast<float4*>(buf1 + r * NLDA + 4 * c4) = v;
-        }
+        for (int pass = 0; pass < NROWS / 4; ++pass) split_store4(planes, NPE, (pass * 4 + rsub) * NPLD + 4 * c4, hv[pass]);
+    }
+    // agg: requested now, consumed after the h-part of the first product
+    float4 av[NROWS / 4];
+#pragma unroll
+    for (int pass = 0; pass < NROWS / 4; ++pass) {
+        const int r = pass * 4 + rsub;
+        av[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nvalid) av[pass] = reinterpret_cast<const float4*>(w.agg + (size_t)(row0 + r) * H)[c4];
     }
     n64_lds_barrier();
     NSTAMP(0);
-    const float* a0 = buf0 + (lane & 31) * NLDA + (lane >> 5) * 8;             // this lane's A row / k-slot (32x32x16: 8 k per lane)
-    const float* a1 = buf1 + (lane & 31) * NLDA + (lane >> 5) * 8;
     sf32x16 acc[2][2];
+    N64_ZERO(acc)
+    n64_gemm(planes, t3a, t3b, acc, ring);                                     // h part of [h | agg]
+    n64_lds_barrier();                                                         // every wave is done reading h
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-    n64_gemm(a0, t3a, t3b, acc, ring);                                         // h part of [h | agg]
-    n64_gemm(a1, t3b, t4, acc, ring);                                          // agg part
+    for (int pass = 0; pass < NROWS / 4; ++pass) {
+        const int r = pass * 4 + rsub;
+        if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
+        float4 v = av[pass];
+        v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
+        split_store4(planes, NPE, r * NPLD + 4 * c4, v);
+    }
+    n64_lds_barrier();
+    n64_gemm(planes, t3b, t4, acc, ring);                                      // agg part
     NSTAMP(1);
     n64_lds_barrier();                                                         // every wave is done reading agg
-    N64_FOREACH(acc, buf1[row * NLDA + col] = silu_f(v + (n == 0 ? b3c0 : b3c1));)
-    n64_lds_barrier();
-    NSTAMP(2);
+    // ---- T = SiLU(pre3): from the accumulators straight into the planes (register pairs r, r + 1 = two rows of one column)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+            for (int r = 0; r < 16; r += 2) {
+                const float bb = n == 0 ? b3c0 : b3c1;
+                const int col = colw + 32 * n;
+                n64_split_store2(planes, N64_ROW(m, r) * NPLD + col, N64_ROW(m, r + 1) * NPLD + col, silu_f(acc[m][n][r] + bb), silu_f(acc[m][n][r + 1] + bb));
+            }
+    // the residual's h, in the accumulator layout, requested now (L2) and consumed after the W4 product
+    float hold[2][2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = N64_ROW(m, r);
+                hold[m][n][r] = row < nvalid ? w.h[(size_t)(row0 + row) * H + colw + 32 * n] : 0.f;
+            }
+    n64_lds_barrier();
+    NSTAMP(2);
+    N64_ZERO(acc)
     {
         const sbf16x8* const nxt[2] = {job_tile(job0, 0), job_tile(job0, 1)};
-        n64_gemm(a1, t4, nxt, acc, ring);
+        n64_gemm(planes, t4, nxt, acc, ring);
     }
     NSTAMP(3);
     n64_lds_barrier();                                                         // every wave is done reading T
-    N64_FOREACH(acc, buf1[row * NLDA + col] = row < nvalid ? buf0[row * NLDA + col] + (v + (n == 0 ? b4c0 : b4c1)) : 0.f;)   // residual (egnn_new.py:57)
-    n64_lds_barrier();
+    // ---- h_new = h + (acc + b4): to global from the accumulators, and split into the planes for the projections
 #pragma unroll
-    for (int pass = 0; pass < NROWS / 4; ++pass) {                             // h_new leaves as whole 1 KiB rows
-        const int r = pass * 4 + rsub;
-        if (r < nvalid) reinterpret_cast<float4*>(w.h + (size_t)(row0 + r) * H)[c4] = *reinterpret_cast<const float4*>(buf1 + r * NLDA + 4 * c4);
-    }
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float bb = n == 0 ? b4c0 : b4c1;
+                const int col = colw + 32 * n, ra = N64_ROW(m, r), rb = N64_ROW(m, r + 1);
+                const float ha = hold[m][n][r] + (acc[m][n][r] + bb), hb = hold[m][n][r + 1] + (acc[m][n][r + 1] + bb);       // residual (egnn_new.py:57)
+                if (ra < nvalid) w.h[(size_t)(row0 + ra) * H + col] = ha;
+                if (rb < nvalid) w.h[(size_t)(row0 + rb) * H + col] = hb;
+                n64_split_store2(planes, ra * NPLD + col, rb * NPLD + col, ra < nvalid ? ha : 0.f, rb < nvalid ? hb : 0.f);
+            }
+    n64_lds_barrier();
     NSTAMP(4);
-    // projections, K = 256, A = h_new: one rolled loop over the jobs
+    // ---- projections, K = 256, A = h_new: one rolled loop over the jobs
 #pragma unroll 1
     for (unsigned rest = jobs; rest != 0u; rest &= rest - 1u) {
         const int j = __builtin_ctz(rest);
@@ -207,14 +226,17 @@ __global__ __launch_bounds__(256, 1) void k_node64(Layout lay, Work w, Dims d, L
         float* __restrict__ out = j == 0 ? w.Pc : j == 1 ? w.Qc : j == 2 ? w.P : w.Q;
         const float* bv = j == 0 ? lw.b6 : lw_next.b1;
         const float bias0 = (j == 0 || j == 2) ? bv[colw] : 0.f, bias1 = (j == 0 || j == 2) ? bv[colw + 32] : 0.f;       // (in flight during the GEMM)
+        N64_ZERO(acc)
+        n64_gemm(planes, tc, tn, acc, ring);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-        n64_gemm(a1, tc, tn, acc, ring);
-        N64_FOREACH(acc, if (row < nvalid) out[(size_t)(row0 + row) * H + col] = v + (n == 0 ? bias0 : bias1);)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = N64_ROW(m, r);
+                    if (row < nvalid) out[(size_t)(row0 + row) * H + colw + 32 * n] = acc[m][n][r] + (n == 0 ? bias0 : bias1);
+                }
     }
     NSTAMP(5);
 #if CMDGEN_STAMPS == 5

@@ -278,3 +278,30 @@ def test_bounded_chain_with_node64(use_graph, monkeypatch):
     assert err <= 1e-4 and np.array_equal(xh_phar[:, 3:].cpu().numpy(), want[:, 3:])
     assert st['max_rel_com_error'] < 1e-2 and st['nan_resets'] == 0
     h.close()
+
+
+def test_node64_is_chosen_by_tile_count_and_agrees_with_the_32_row_kernel(monkeypatch):
+    """Without CMDGEN_NODE64 the launcher picks the 64-row kernel where its tiles fill the CUs in fewer rounds (256 C-alpha pockets:
+    236 tiles of 64 rows on 256 CUs), not at the headline size (64 pockets: 59 tiles); a 20-step chain of 256 pockets with it equals
+    the 32-row kernel's to the engines' rounding (same pieces, same accumulation order per output tile)."""
+    from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
+    monkeypatch.delenv('CMDGEN_NODE64', raising=False)
+    cfg = ModelConfig(residue_nf=20, timesteps=1000, noise_precision=0.1, norm_values=(1.0, 0.25))
+    sd = make_state_dict(cfg, seed=3)
+    out = {}
+    for B, env, expect in ((64, None, 0), (256, None, 1), (256, '0', 0)):
+        if env is None: monkeypatch.delenv('CMDGEN_NODE64', raising=False)
+        else: monkeypatch.setenv('CMDGEN_NODE64', env)
+        pb = make_pockets(B, 'CA')
+        h = hip_backend.Handle(cfg.as_dict(), 0); h.load_state_dict(sd)
+        h.set_layout(pb.num_nodes_phar, pb.size)
+        if torch.cuda.get_device_properties(0).multi_processor_count == 256: assert h.query('node64') == expect
+        if B == 256:
+            xh, _, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), 20, seed=5)
+            out[h.query('node64')] = xh.cpu().numpy()
+            assert h.chain_status()['nan_resets'] == 0
+        h.close()
+    if len(out) == 2:
+        err = rms(out[1][:, :3], out[0][:, :3])
+        print(f'256 pockets, 20 steps: coordinate RMS 64-row vs 32-row node kernel {err:.2e} A (max|x| {np.abs(out[0][:, :3]).max():.1f})')
+        assert err <= 2e-5 and np.array_equal(out[1][:, 3:], out[0][:, 3:])
