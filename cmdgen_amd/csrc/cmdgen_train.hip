@@ -21,7 +21,7 @@ struct WgradBatch {               // kernels_train.hip: up to 8 weight gradients
     int M[8], N[8], lddy[8], ldx[8], ldw[8];
     int n;
 };
-void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bool split3 = false);
+void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bool split3 = false, bool force3 = false);
 struct RepackSplitT { int src_off, ld; void* dst; int transpose; };                                       // kernels_train.hip
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s);
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
@@ -717,7 +717,7 @@ extern "C" int cmdgen_debug_dgrad(cmdgen_handle* h, int32_t M, const float* A0, 
 
 // dW[M][N] += dY^T X, db[M] += column sums of dY, through the training step's grouped weight-gradient launch (test aid).
 // mode 0: fp32 instruction (k_wgrad_group<false>); 1: bf16 operands (k_wgrad_split<1> where the shape allows, else k_wgrad_group<true>);
-// 3: three-piece split (k_wgrad_split<3>, needs CMDGEN_WGRAD_SPLIT=1 in the environment, else as mode 0).
+// 3: three-piece split (k_wgrad_split128<3> / k_wgrad_split<3> where the shape allows, else as mode 0).
 extern "C" int cmdgen_debug_wgrad(cmdgen_handle* h, int32_t K, int32_t M, int32_t N, const float* dY, const float* X, float* dW,
                                   float* db, int32_t mode, cmdgen_stream stream) {
     if (!h || !dY || !X || !dW || K < 1 || M < 1 || N < 1) return fail(h, CMDGEN_EINVAL, "bad arguments");
@@ -725,7 +725,7 @@ extern "C" int cmdgen_debug_wgrad(cmdgen_handle* h, int32_t K, int32_t M, int32_
     WgradBatch one; one.n = 1;
     one.dy[0] = dY; one.x[0] = X; one.dw[0] = dW; one.db[0] = db;
     one.M[0] = M; one.N[0] = N; one.lddy[0] = M; one.ldx[0] = N; one.ldw[0] = N;
-    cmdgen_wgrad_group(one, K, mode == 1, (hipStream_t)stream, mode == 3);
+    cmdgen_wgrad_group(one, K, mode == 1, (hipStream_t)stream, mode == 3, mode == 3);
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;
 }

@@ -434,19 +434,169 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(WgradBatch g, int K, int
     }
 }
 
-// split3: allow the three-piece fp32-accurate variant of k_wgrad_split (still needs CMDGEN_WGRAD_SPLIT=1: it only ties the fp32 instruction)
-void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bool split3 = false) {
+// ------------------------------------------------------------------------------------
+// k_wgrad_split128: the same products on 128 x 128 output tiles (round 3).  k_wgrad_split's 64 x 64 tile gives a wave ONE
+// 32 x 32 accumulator: six 16-byte LDS reads per six MFMAs (144 KB of LDS reads per 64 k values of a tile - the LDS pipe, not the
+// matrix pipe, bound it, and three-piece weight gradients only tied the fp32 instruction).  Here a wave owns 64 x 64 (2 x 2
+// accumulators): twelve reads per 24 MFMAs, half the LDS bytes per FLOP; k tiles of 32 keep the two operands' planes at 60 KB
+// (two workgroups per CU: one stages and splits while the other multiplies).  Staging as before - a thread transposes eight
+// consecutive k rows of four channels in registers and writes one 16-byte piece per channel and plane - with the k-octet
+// position XOR-swizzled by the channel group, so the sixteen lanes of a store cycle fall on sixteen different bank groups
+// (channel rows four apart put them on four).  Every M_p, N_p a multiple of 128.
+// ------------------------------------------------------------------------------------
+template <int NPC>
+__global__ __launch_bounds__(256, 2) void k_wgrad_split128(WgradBatch g, int K, int kchunk, int zsplit) {
+    constexpr int KT = 32, PLD = KT + 8, TM = 128, PE = TM * PLD;     // bf16 elements per plane row / per plane
+    __shared__ __attribute__((aligned(16))) unsigned short planes[2 * NPC * PE];
+    const int p = blockIdx.z / zsplit, kz = blockIdx.z - p * zsplit;
+    const int M = g.M[p], N = g.N[p];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TM;
+    if (m0 >= M || n0 >= N) return;
+    const int k_begin = kz * kchunk, k_end = min(K, k_begin + kchunk);
+    if (k_begin >= k_end) return;
+    const bool isB = tid >= 128;
+    const int t = tid & 127, cg = t & 31, kb = t >> 5;                 // channels 4 cg .. 4 cg + 3, k rows 8 kb .. 8 kb + 7 of the tile
+    const float* __restrict__ G = isB ? g.x[p] : g.dy[p];
+    const int ld = isB ? g.ldx[p] : g.lddy[p];
+    const float* gsrc = G + (isB ? n0 : m0) + 4 * cg;
+    // octet kb of channel row ch lies at element 8 (kb ^ ((ch >> 4) & 3)) of the row
+    unsigned short* mine = planes + (isB ? NPC * PE : 0) + 4 * cg * PLD + 8 * (kb ^ ((cg >> 2) & 3));
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const bool want_bias = g.db[p] != nullptr && n0 == 0 && !isB;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    float4 v[8];
+    float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + 8 * kb + i;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < k_end) v[i] = *reinterpret_cast<const float4*>(gsrc + (size_t)k * ld);
+        }
+    };
+    // fragment rows of this lane: row (lane & 31) of each 32-row tile, k octet (lane >> 5) of a 16-k block; (row >> 4) & 3 = 2 (tile & 1) + ((lane >> 4) & 1)
+    const int lrow = lane & 31, loct = lane >> 5, lsw = (lane >> 4) & 1;
+    fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+        if (want_bias) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { colsum.x += v[i].x; colsum.y += v[i].y; colsum.z += v[i].z; colsum.w += v[i].w; }
+        }
+        {
+            const float c0[8] = {v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x};
+            const float c1[8] = {v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y};
+            const float c2[8] = {v[0].z, v[1].z, v[2].z, v[3].z, v[4].z, v[5].z, v[6].z, v[7].z};
+            const float c3[8] = {v[0].w, v[1].w, v[2].w, v[3].w, v[4].w, v[5].w, v[6].w, v[7].w};
+            const float* cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned short* dst = mine + c * PLD;
+                if constexpr (NPC == 3) {
+                    sbf16x8 p0, p1, p2;
+                    split8(make_float4(cc[c][0], cc[c][1], cc[c][2], cc[c][3]), make_float4(cc[c][4], cc[c][5], cc[c][6], cc[c][7]), p0, p1, p2);
+                    *reinterpret_cast<sbf16x8*>(dst) = p0; *reinterpret_cast<sbf16x8*>(dst + PE) = p1; *reinterpret_cast<sbf16x8*>(dst + 2 * PE) = p2;
+                } else {
+                    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                    const u4 q = {cvt_pk_bf16(cc[c][0], cc[c][1]), cvt_pk_bf16(cc[c][2], cc[c][3]), cvt_pk_bf16(cc[c][4], cc[c][5]), cvt_pk_bf16(cc[c][6], cc[c][7])};
+                    *reinterpret_cast<u4*>(dst) = q;
+                }
+            }
+        }
+        __syncthreads();
+        if (k0 + KT < k_end) fetch(k0 + KT);
+#pragma unroll
+        for (int ks = 0; ks < KT / 16; ++ks) {
+            sbf16x8 a[2][NPC], b[2][NPC];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                // tile rows wm + 32 m + lrow (wm a multiple of 64): channel group bits (row >> 4) & 3 = 2 m + lsw
+                const int oa = (wm + 32 * m + lrow) * PLD + 8 * ((2 * ks + loct) ^ (2 * m + lsw));
+                const int ob = NPC * PE + (wn + 32 * m + lrow) * PLD + 8 * ((2 * ks + loct) ^ (2 * m + lsw));
+#pragma unroll
+                for (int q = 0; q < NPC; ++q) {
+                    a[m][q] = *reinterpret_cast<const sbf16x8*>(planes + oa + q * PE);
+                    b[m][q] = *reinterpret_cast<const sbf16x8*>(planes + ob + q * PE);
+                }
+            }
+#define WG_MF(AI, BI) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n)                   \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][AI], b[n][BI], acc[m][n], 0, 0, 0);
+            if constexpr (NPC == 3) { WG_MF(2, 0) WG_MF(1, 1) WG_MF(0, 2) WG_MF(1, 0) WG_MF(0, 1) }      // small terms first; every product is exact in fp32
+            WG_MF(0, 0)
+#undef WG_MF
+        }
+        __syncthreads();
+    }
+    float* C = g.dw[p];
+    const int ldc = g.ldw[p];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int gn = n0 + wn + 32 * n + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                atomicAdd(C + (size_t)gm * ldc + gn, acc[m][n][r]);
+            }
+        }
+    if (g.db[p] != nullptr && n0 == 0) {   // 4 threads (kb) hold partial sums of the same four channels: combine through LDS
+        float* red = reinterpret_cast<float*>(planes);       // [4][128]
+        if (!isB) *reinterpret_cast<float4*>(red + kb * TM + 4 * cg) = colsum;
+        __syncthreads();
+        if (tid < TM) atomicAdd(g.db[p] + m0 + tid, (red[tid] + red[TM + tid]) + (red[2 * TM + tid] + red[3 * TM + tid]));
+    }
+}
+
+// split3: the handle runs on the split engine, so three-piece (fp32-accurate) weight gradients are allowed; force3: a test asks for them.
+// Which kernel (tools/bench_wgrad.py, profiles/r03_n_wgrad.txt; one 256 x 256 product, us per launch):
+//     K                fp32 instruction   three pieces 64-tile / 128-tile   bf16 operands 64-tile / 128-tile
+//     3 721 (nodes)          18               14 / 17                               12 / 13
+//    16 127                  32               32 / 35                               23 / 24
+//    36 147                  58               59 / 51                               38 / 37
+//   156 316                 253              227 / 175                             155 / 103
+// These products are tall and skinny (256 x 256 outputs over 1e4-1e5 rows): operand reads and the split-K atomics bind them, not the
+// matrix pipe.  The 128-tile kernel reads each operand row half as often and wins once K >= ~32k (three pieces) / ~64k (bf16); below
+// that the fp32 instruction (three pieces) and the 64-tile kernel (bf16) stay.  CMDGEN_WGRAD_SPLIT=0: never three pieces; =1: always
+// where the shape allows; CMDGEN_WGRAD_TILE=64: never the 128-tile kernel.
+void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bool split3 = false, bool force3 = false) {
     if (g.n <= 0 || K <= 0) return;
     int tm = 1, tn = 1;
     for (int p = 0; p < g.n; ++p) { tm = max(tm, (g.M[p] + 63) / 64); tn = max(tn, (g.N[p] + 63) / 64); }
-    {   // the register-transposing kernel when every problem allows it: always for bf16 operands (one plane per operand: 2.8 vs
-        // 3.0 ms per step at B=64, 7.5 vs 8.2 at B=256); with three pieces per operand (fp32-accurate, CMDGEN_WGRAD_SPLIT=1) it
-        // only ties the fp32 instruction - 144 KB of LDS traffic per 64 k values of a 64 x 64 tile bind it, not the matrix pipe
-        static const bool want3 = getenv("CMDGEN_WGRAD_SPLIT") != nullptr;
-        bool sp = bf16 || (split3 && want3);
-        for (int p = 0; p < g.n && sp; ++p)
-            sp = g.M[p] % 64 == 0 && g.N[p] % 64 == 0 && g.lddy[p] % 4 == 0 && g.ldx[p] % 4 == 0 &&
-                 (reinterpret_cast<uintptr_t>(g.dy[p]) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.x[p]) & 15) == 0;
+    {
+        static const int env3 = getenv("CMDGEN_WGRAD_SPLIT") ? atoi(getenv("CMDGEN_WGRAD_SPLIT")) : -1;
+        static const bool tile64 = getenv("CMDGEN_WGRAD_TILE") && atoi(getenv("CMDGEN_WGRAD_TILE")) == 64;
+        bool ok64 = true, ok128 = !tile64;
+        for (int p = 0; p < g.n; ++p) {
+            ok64 = ok64 && g.M[p] % 64 == 0 && g.N[p] % 64 == 0 && g.lddy[p] % 4 == 0 && g.ldx[p] % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(g.dy[p]) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.x[p]) & 15) == 0;
+            ok128 = ok128 && g.M[p] % 128 == 0 && g.N[p] % 128 == 0;
+        }
+        ok128 = ok128 && ok64;
+        const bool three = !bf16 && (force3 || (split3 && (env3 == 1 || (env3 != 0 && ok128 && K >= 32768))));
+        const bool sp = ok64 && (bf16 || three);
+        const bool sp128 = sp && ok128 && (force3 || env3 == 1 || K >= (bf16 ? 65536 : 32768));
+        if (sp128) {
+            int tm = 1, tn = 1, tiles = 0;
+            for (int p = 0; p < g.n; ++p) { tm = max(tm, g.M[p] / 128); tn = max(tn, g.N[p] / 128); tiles += (g.M[p] / 128) * (g.N[p] / 128); }
+            static const int wgs = getenv("CMDGEN_WGRAD_SPLIT_WGS") ? atoi(getenv("CMDGEN_WGRAD_SPLIT_WGS")) : 384;
+            int zsplit = (wgs + tiles - 1) / tiles;
+            const int max_split = (K + 127) / 128;
+            if (zsplit > max_split) zsplit = max_split;
+            if (zsplit < 1) zsplit = 1;
+            const int kchunk = ((K + zsplit - 1) / zsplit + 31) / 32 * 32;
+            zsplit = (K + kchunk - 1) / kchunk;
+            const dim3 grid(tn, tm, g.n * zsplit);
+            if (bf16) hipLaunchKernelGGL(k_wgrad_split128<1>, grid, dim3(256), 0, s, g, K, kchunk, zsplit);
+            else hipLaunchKernelGGL(k_wgrad_split128<3>, grid, dim3(256), 0, s, g, K, kchunk, zsplit);
+            return;
+        }
         if (sp) {
             int tm = 1, tn = 1;
             for (int p = 0; p < g.n; ++p) { tm = max(tm, g.M[p] / 64); tn = max(tn, g.N[p] / 64); }
@@ -973,6 +1123,9 @@ __global__ __launch_bounds__(256) void k_edge_tail_bwd(int E, int H, const int* 
 // into dP, dQ atomics, the radial / d0 column partial sums, dL/d radial and the geometry adjoint - lanes own columns
 // lane + 64 q exactly as in k_edge_tail_bwd (contiguous 256-byte atomics).  Scratch layout and reduce kernel are shared.
 // ------------------------------------------------------------------------------------
+#ifndef CMDGEN_TAIL_EXP
+#define CMDGEN_TAIL_EXP 0
+#endif
 struct TailArgs {
     const int* row; const int* col; const float* d0; const float* Wcol; int ldw;
     const float4* X; float norm_constant; const float4* dcd; int n_moving;
@@ -1041,7 +1194,9 @@ __global__ __launch_bounds__(256, 3) void k_dgrad_tail(int M, const float* __res
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 accR[q] += r * v[q]; accD[q] += dd * v[q]; run[q] += v[q]; dot += v[q] * wr[q];
+#if CMDGEN_TAIL_EXP != 1
                 atomicAdd(ta.dQ + (size_t)j * HH + lane + 64 * q, v[q]);
+#endif
             }
             const float gr = wave_sum(dot);                  // dL/d radial of this edge
             if (lane == k) my_gr = gr;

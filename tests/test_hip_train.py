@@ -150,13 +150,14 @@ def test_data_gradient_kernel_all_modes(tile_rows):
         assert (got3.double() - want3).abs().max() <= 2e-5 * float(want3.abs().max()) + 1e-6, M
 
 
-@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('mode', [0, 1, 3])
 def test_weight_gradient_launch(mode):
-    """k_wgrad_group (fp32 instruction) and k_wgrad_split<1> (bf16 operands, register-transposed staging): dW += dY^T X with the
-    bias gradient folded in, on 256 x 256 and on a shape only the generic kernel takes, K not a multiple of anything."""
+    """k_wgrad_group (fp32 instruction), bf16 operands (mode 1: k_wgrad_split<1>, and k_wgrad_split128<1> from K = 65536 up) and three
+    bf16 pieces per operand (mode 3: k_wgrad_split128<3> / k_wgrad_split<3>, fp32-accurate): dW += dY^T X with the bias gradient folded
+    in, on 256 x 256, on a 64-tile-only shape, on a shape only the generic kernel takes, K not a multiple of anything."""
     h = make_handle(ModelConfig(hidden_nf=64, n_layers=1))
     g = torch.Generator().manual_seed(4)
-    for K, M, N in [(3001, 256, 256), (130, 64, 128), (777, 40, 24)]:
+    for K, M, N in [(3001, 256, 256), (130, 64, 128), (777, 40, 24), (70001, 128, 256)]:
         dY, X = torch.randn(K, M, generator=g).cuda(), torch.randn(K, N, generator=g).cuda()
         dW0, db0 = torch.randn(M, N, generator=g).cuda(), torch.randn(M, generator=g).cuda()
         dW, db = dW0.clone(), db0.clone()

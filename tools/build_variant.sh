@@ -14,5 +14,7 @@ egnn=$C/kernels_egnn.o; pairo=$C/kernels_node_pair.o
 [ "$f" = kernels_node_pair.hip ] && pairo=build/kernels_node_pair_$name.o
 n64o=$C/kernels_node64.o
 [ "$f" = kernels_node64.hip ] && n64o=build/kernels_node64_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcmdgen_hip_$name.so $C/cmdgen_api.o $egnn $pairo $n64o $C/kernels_ddpm.o $C/kernels_joint.o $C/kernels_train.o $C/cmdgen_train.o
+traino=$C/kernels_train.o
+[ "$f" = kernels_train.hip ] && traino=build/kernels_train_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcmdgen_hip_$name.so $C/cmdgen_api.o $egnn $pairo $n64o $C/kernels_ddpm.o $C/kernels_joint.o $traino $C/cmdgen_train.o
 echo build/libcmdgen_hip_$name.so
