@@ -289,6 +289,46 @@ __device__ __forceinline__ void tile_gemm_planes(const unsigned short* planes, i
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], carry.b[BS][n][0], acc[m][n], 0, 0, 0); \
         }
     PL_LOADA(0, ap)
+    if constexpr (NPC == 3) {
+        // One load pinned in the shadow of every one or two MFMAs (sched_barrier after each group) instead of a burst of 9-12 loads and
+        // their address arithmetic between two k-blocks, which left the matrix pipe idle ~100 cycles per block (profiles/r03_m_node64.txt).
+        // Per accumulator the order of the six products is unchanged (small terms first).
+#define PL_LA(SET, PTR, M, S) a[SET][M][S] = *reinterpret_cast<const sbf16x8*>((PTR) + (S) * plane_elems + (M) * 32 * lda);
+#define PL_LB(SET, N, S) carry.b[SET][N][S] = ((N) == 0 ? q0 : q1)[(S) * 64];
+#define PL_MF(M, N, AS, AI, BS, BI) acc[M][N] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][M][AI], carry.b[BS][N][BI], acc[M][N], 0, 0, 0);
+#define PL_GRP(LOADS, M, AS, BS, AI, BI) LOADS PL_MF(M, 0, AS, AI, BS, BI) PL_MF(M, 1, AS, AI, BS, BI) __builtin_amdgcn_sched_barrier(0);
+#define PL_HALF(AS, BS, AN, BN, PTR)                                                                                              \
+        if constexpr (NMT == 2) {                                                                                                 \
+            PL_GRP(PL_LA(AN, PTR, 0, 2), 0, AS, BS, 2, 0) PL_GRP(PL_LA(AN, PTR, 1, 2), 1, AS, BS, 2, 0)                             \
+            PL_GRP(PL_LA(AN, PTR, 0, 1), 0, AS, BS, 1, 1) PL_GRP(PL_LA(AN, PTR, 1, 1), 1, AS, BS, 1, 1)                             \
+            PL_GRP(PL_LA(AN, PTR, 0, 0), 0, AS, BS, 0, 2) PL_GRP(PL_LA(AN, PTR, 1, 0), 1, AS, BS, 0, 2)                             \
+            PL_GRP(PL_LB(BN, 0, 0), 0, AS, BS, 1, 0) PL_GRP(PL_LB(BN, 0, 1), 1, AS, BS, 1, 0)                                       \
+            PL_GRP(PL_LB(BN, 0, 2), 0, AS, BS, 0, 1) PL_GRP(PL_LB(BN, 1, 0), 1, AS, BS, 0, 1)                                       \
+            PL_GRP(PL_LB(BN, 1, 1), 0, AS, BS, 0, 0) PL_GRP(PL_LB(BN, 1, 2), 1, AS, BS, 0, 0)                                       \
+        } else {                                                                                                                  \
+            PL_GRP(PL_LA(AN, PTR, 0, 2) PL_LB(BN, 0, 0), 0, AS, BS, 2, 0) PL_GRP(PL_LA(AN, PTR, 0, 1) PL_LB(BN, 0, 1), 0, AS, BS, 1, 1) \
+            PL_GRP(PL_LA(AN, PTR, 0, 0) PL_LB(BN, 0, 2), 0, AS, BS, 0, 2) PL_GRP(PL_LB(BN, 1, 0), 0, AS, BS, 1, 0)                  \
+            PL_GRP(PL_LB(BN, 1, 1), 0, AS, BS, 0, 1) PL_GRP(PL_LB(BN, 1, 2), 0, AS, BS, 0, 0)                                       \
+        }
+#pragma unroll 1
+        for (int kb = 0; kb < KB16; kb += 2) {
+            const bool more = kb + 2 < KB16;
+            const unsigned short* an = more ? ap + 32 : ap;          // (last block: re-reads its own fragments, unused)
+            __builtin_amdgcn_sched_barrier(0);
+            PL_HALF(0, 0, 1, 1, ap + 16)
+            q0 = more ? q0 + 192 : next.p;
+            q1 = more ? q1 + 192 : next.p + next.ns;
+            __builtin_amdgcn_sched_barrier(0);
+            PL_HALF(1, 1, 0, 0, an)
+            q0 += 192; q1 += 192;
+            ap += 32;
+        }
+#undef PL_LA
+#undef PL_LB
+#undef PL_MF
+#undef PL_GRP
+#undef PL_HALF
+    } else {
 #pragma unroll 1
     for (int kb = 0; kb < KB16; kb += 2) {
         const bool more = kb + 2 < KB16;
@@ -306,6 +346,7 @@ __device__ __forceinline__ void tile_gemm_planes(const unsigned short* planes, i
         PL_MFMAS(1, 1)
         __builtin_amdgcn_sched_barrier(0);
         ap += 32;
+    }
     }
 #undef PL_LOADA
 #undef PL_MFMAS
