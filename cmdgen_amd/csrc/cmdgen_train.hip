@@ -54,6 +54,11 @@ void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, flo
 void tr_sqsum(size_t n, const float* x, float* out, hipStream_t s);
 void tr_noise(const Layout& lay, const Dims& d, const float* px, const float* poh, const float* qx, const float* qoh, const float* tab,
               const float* eps, float* z_t, float* xh_pocket, float* klsum, hipStream_t s);
+void tr_noise_joint(const Layout& lay, const Dims& d, const float* px, const float* poh, const float* qx, const float* qoh, const float* tab,
+                    const float* raw_l, const float* raw_q, float* z_l, float* z_q, float* e_l, float* e_q, float* klsum, hipStream_t s);
+void tr_loss_joint(const Layout& lay, const Dims& d, int l2, float T, const float* net_l, const float* net_q, const float* e_l, const float* e_q,
+                   const float* z_l, const float* z_q, const float* poh, const float* qoh, const float* tab, const float* klsum, float* terms,
+                   float* d_l, float* d_q, float* means, hipStream_t s);
 void tr_loss(const Layout& lay, const Dims& d, int l2, float T, const float* net, const float* eps, const float* z_t, const float* poh,
              const float* tab, const float* klsum, float* terms, float* d_eps, float* means, hipStream_t s);
 
@@ -599,6 +604,42 @@ extern "C" int cmdgen_train_loss(cmdgen_handle* h, int32_t l2, float T, const fl
     hipSetDevice(h->device);
     h->last_stream = (hipStream_t)stream;
     tr_loss(h->lay, h->dims, l2, T, net_out, eps, z_t, phar_one_hot, tab, kl_sums, terms, d_eps, means, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_train_noise_joint(cmdgen_handle* h, const float* phar_x, const float* phar_one_hot, const float* pocket_x,
+                                        const float* pocket_one_hot, const float* tab, const float* draw_phar, const float* draw_pocket,
+                                        float* z_phar, float* z_pocket, float* eps_phar, float* eps_pocket, float* kl_sums,
+                                        cmdgen_stream stream) {
+    if (!h) return CMDGEN_EINVAL;
+    if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
+    if (!h->dims.joint) return fail(h, CMDGEN_ESTATE, "cmdgen_train_noise_joint is the joint model's noising");
+    if (!phar_x || !phar_one_hot || !pocket_x || !pocket_one_hot || !tab || !draw_phar || !draw_pocket || !z_phar || !z_pocket ||
+        !eps_phar || !eps_pocket || !kl_sums)
+        return fail(h, CMDGEN_EINVAL, "null device pointer");
+    hipSetDevice(h->device);
+    h->last_stream = (hipStream_t)stream;
+    tr_noise_joint(h->lay, h->dims, phar_x, phar_one_hot, pocket_x, pocket_one_hot, tab, draw_phar, draw_pocket, z_phar, z_pocket, eps_phar,
+                   eps_pocket, kl_sums, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_train_loss_joint(cmdgen_handle* h, int32_t l2, float T, const float* net_phar, const float* net_pocket,
+                                       const float* eps_phar, const float* eps_pocket, const float* z_phar, const float* z_pocket,
+                                       const float* phar_one_hot, const float* pocket_one_hot, const float* tab, const float* kl_sums,
+                                       float* terms, float* d_eps_phar, float* d_eps_pocket, float* means, cmdgen_stream stream) {
+    if (!h) return CMDGEN_EINVAL;
+    if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
+    if (!h->dims.joint) return fail(h, CMDGEN_ESTATE, "cmdgen_train_loss_joint is the joint model's loss");
+    if (!net_phar || !net_pocket || !eps_phar || !eps_pocket || !z_phar || !z_pocket || !phar_one_hot || !pocket_one_hot || !tab ||
+        !kl_sums || !terms || !d_eps_phar || !d_eps_pocket || !means)
+        return fail(h, CMDGEN_EINVAL, "null device pointer");
+    hipSetDevice(h->device);
+    h->last_stream = (hipStream_t)stream;
+    tr_loss_joint(h->lay, h->dims, l2, T, net_phar, net_pocket, eps_phar, eps_pocket, z_phar, z_pocket, phar_one_hot, pocket_one_hot, tab,
+                  kl_sums, terms, d_eps_phar, d_eps_pocket, means, (hipStream_t)stream);
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;
 }

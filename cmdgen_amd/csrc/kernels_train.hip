@@ -1387,20 +1387,28 @@ __global__ __launch_bounds__(256) void k_train_noise(Layout lay, Dims d, const f
     const int P = d.P, R = d.R, ldp = 3 + P, ldq = 3 + R;
     const float alpha = tab[TT_ALPHA_T * B + b], sigma = tab[TT_SIGMA_T * B + b], alphaT = tab[TT_ALPHA_TT * B + b];
     const float cnt = (float)max(n, 1);
-    // phar centre of mass of the normalised coordinates (remove_mean_batch #1)
+    // phar centre of mass of the normalised coordinates (remove_mean_batch #1); SimpleConditionalDDPM (d.no_com): the POCKET's centre
+    // of mass of the raw coordinates, subtracted before normalisation (conditional_model.py:481-525), and no projection afterwards
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int i = tid; i < n; i += 256) {
-        const float* x = px + (size_t)(base + i) * 3;
-        sx += x[0] / d.norm_x; sy += x[1] / d.norm_x; sz += x[2] / d.norm_x;
+    if (d.no_com) {
+        for (int i = tid; i < m; i += 256) { const float* x = qx + (size_t)(qbase + i) * 3; sx += x[0]; sy += x[1]; sz += x[2]; }
+    } else {
+        for (int i = tid; i < n; i += 256) {
+            const float* x = px + (size_t)(base + i) * 3;
+            sx += x[0] / d.norm_x; sy += x[1] / d.norm_x; sz += x[2] / d.norm_x;
+        }
     }
     wg_sum3(sx, sy, sz, red);
-    const float m1x = sx / cnt, m1y = sy / cnt, m1z = sz / cnt;
+    const float cq = (float)max(m, 1);
+    const float m1x = d.no_com ? sx / cq : sx / cnt, m1y = d.no_com ? sy / cq : sy / cnt, m1z = d.no_com ? sz / cq : sz / cnt;
+    // (conditional: m1 is in normalised units and subtracted after the division; simple: raw units, subtracted before it)
+#define TN_X(v, mm) (d.no_com ? ((v) - (mm)) / d.norm_x : (v) / d.norm_x - (mm))
     // z_t = alpha xh0 + sigma eps (x part still with its mean), the KL sums of alpha_T xh0
     float zx = 0.f, zy = 0.f, zz = 0.f, klx = 0.f, klh = 0.f, dummy = 0.f;
     for (int i = tid; i < n; i += 256) {
         const size_t g = (size_t)(base + i);
         const float* x = px + g * 3; const float* e = eps + g * ldp; float* z = z_t + g * ldp;
-        const float x0 = x[0] / d.norm_x - m1x, x1 = x[1] / d.norm_x - m1y, x2 = x[2] / d.norm_x - m1z;
+        const float x0 = TN_X(x[0], m1x), x1 = TN_X(x[1], m1y), x2 = TN_X(x[2], m1z);
         const float a0 = alphaT * x0, a1 = alphaT * x1, a2 = alphaT * x2;
         klx += a0 * a0 + a1 * a1 + a2 * a2;
         const float z0 = alpha * x0 + sigma * e[0], z1 = alpha * x1 + sigma * e[1], z2 = alpha * x2 + sigma * e[2];
@@ -1413,18 +1421,20 @@ __global__ __launch_bounds__(256) void k_train_noise(Layout lay, Dims d, const f
     }
     wg_sum3(zx, zy, zz, red);
     wg_sum3(klx, klh, dummy, red);
-    const float m2x = zx / cnt, m2y = zy / cnt, m2z = zz / cnt;
-    for (int i = tid; i < n; i += 256) {            // remove_mean_batch #2 (each thread revisits the rows it wrote)
-        float* z = z_t + (size_t)(base + i) * ldp;
-        z[0] -= m2x; z[1] -= m2y; z[2] -= m2z;
-    }
+    const float m2x = d.no_com ? 0.f : zx / cnt, m2y = d.no_com ? 0.f : zy / cnt, m2z = d.no_com ? 0.f : zz / cnt;
+    if (!d.no_com)
+        for (int i = tid; i < n; i += 256) {        // remove_mean_batch #2 (each thread revisits the rows it wrote)
+            float* z = z_t + (size_t)(base + i) * ldp;
+            z[0] -= m2x; z[1] -= m2y; z[2] -= m2z;
+        }
     for (int i = tid; i < m; i += 256) {
         const size_t g = (size_t)(qbase + i);
         const float* x = qx + g * 3; float* o = xh_pocket + g * ldq;
-        o[0] = (x[0] / d.norm_x - m1x) - m2x; o[1] = (x[1] / d.norm_x - m1y) - m2y; o[2] = (x[2] / d.norm_x - m1z) - m2z;
+        o[0] = TN_X(x[0], m1x) - m2x; o[1] = TN_X(x[1], m1y) - m2y; o[2] = TN_X(x[2], m1z) - m2z;
         for (int c = 0; c < R; ++c) o[3 + c] = (qoh[g * R + c] - d.bias_h) / d.norm_h;
     }
     if (tid == 0) { klsum[2 * b] = klx; klsum[2 * b + 1] = klh; }
+#undef TN_X
 }
 
 __device__ __forceinline__ float cdf_std_gauss(float x) { return 0.5f * (1.0f + erff(x / 1.41421356237309515f)); }
@@ -1486,7 +1496,7 @@ __global__ __launch_bounds__(256) void k_train_loss(Layout lay, Dims d, int l2, 
     if (tid == 0) {
         const float alphaT = tab[TT_ALPHA_TT * B + b], sigT = tab[TT_SIGMA_TT * B + b];
         (void)alphaT;
-        const float dsub = (nf - 1.0f) * 3.0f;
+        const float dsub = (d.no_com ? nf : nf - 1.0f) * 3.0f;      // subspace_dimensionality (SimpleConditionalDDPM: no projection)
         // gaussian_KL(|mu|^2, sigma_T, 1, dim) = dim log(1 / sigma_T) + 0.5 (dim sigma_T^2 + |mu|^2) - 0.5 dim
         const float kl_h = logf(1.0f / sigT) + 0.5f * (sigT * sigT + klsum[2 * b + 1]) - 0.5f;
         const float kl_x = dsub * logf(1.0f / sigT) + 0.5f * (dsub * sigT * sigT + klsum[2 * b]) / 1.0f - 0.5f * dsub;
@@ -1511,6 +1521,152 @@ __global__ __launch_bounds__(256) void k_train_loss(Layout lay, Dims d, int l2, 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// The same two launches for the JOINT model (EnVariationalDiffusion.forward in training mode, en_diffusion.py:332-465, and the
+// joint branch of lightning_modules.py:198-217): pocket nodes are noised and denoised too.  One workgroup per sample.
+//   k_train_noise_joint: normalize; the x-part of the draw loses its centre of mass over ALL nodes of the sample
+//     (sample_combined_position_feature_noise, :555-574); z = alpha_t xh + sigma_t eps for both parts; the prior-KL sums over both.
+//   k_train_loss_joint: error_t, L0 (x of both parts, the categorical likelihood of both one-hot blocks), kl_prior with
+//     (n_phar + n_pocket - 1) * 3 degrees of freedom, the 'l2' / vlb combination, dL/d net_out for both outputs.
+// terms columns 0..8 as in k_train_loss (error_t / |eps_hat| of the phar part), 9 error_t of the pocket part, 10 / 11 mean
+// |eps_hat| of the pocket's x / h.
+// ------------------------------------------------------------------------------------
+enum { TS_ERR_T_Q = 9, TS_ABS_X_Q = 10, TS_ABS_H_Q = 11 };
+
+__global__ __launch_bounds__(256) void k_train_noise_joint(Layout lay, Dims d, const float* __restrict__ px, const float* __restrict__ poh,
+                                                           const float* __restrict__ qx, const float* __restrict__ qoh,
+                                                           const float* __restrict__ tab, const float* __restrict__ raw_l,
+                                                           const float* __restrict__ raw_q, float* __restrict__ z_l, float* __restrict__ z_q,
+                                                           float* __restrict__ e_l, float* __restrict__ e_q, float* __restrict__ klsum) {
+    __shared__ float red[12];
+    const int b = blockIdx.x, B = lay.B, tid = threadIdx.x;
+    const int n = lay.num_phar[b], base = lay.phar_base[b], m = lay.num_pocket[b], qbase = lay.pocket_base[b];
+    const int P = d.P, R = d.R, ldp = 3 + P, ldq = 3 + R;
+    const float alpha = tab[TT_ALPHA_T * B + b], sigma = tab[TT_SIGMA_T * B + b], alphaT = tab[TT_ALPHA_TT * B + b];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int i = tid; i < n; i += 256) { const float* e = raw_l + (size_t)(base + i) * ldp; sx += e[0]; sy += e[1]; sz += e[2]; }
+    for (int i = tid; i < m; i += 256) { const float* e = raw_q + (size_t)(qbase + i) * ldq; sx += e[0]; sy += e[1]; sz += e[2]; }
+    wg_sum3(sx, sy, sz, red);
+    const float cnt = (float)max(n + m, 1);
+    const float mx = sx / cnt, my = sy / cnt, mz = sz / cnt;
+    float klx = 0.f, klh = 0.f, dummy = 0.f;
+    auto part = [&](int rows, int row0, int C, int ld, const float* x3, const float* oh, const float* raw, float* z, float* eo) {
+        for (int i = tid; i < rows; i += 256) {
+            const size_t g = (size_t)(row0 + i);
+            const float* x = x3 + g * 3; const float* e = raw + g * ld; float* zo = z + g * ld; float* ee = eo + g * ld;
+            const float en[3] = {e[0] - mx, e[1] - my, e[2] - mz};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float xn = x[c] / d.norm_x, a = alphaT * xn;
+                klx += a * a;
+                ee[c] = en[c];
+                zo[c] = alpha * xn + sigma * en[c];
+            }
+            for (int c = 0; c < C; ++c) {
+                const float hn = (oh[g * C + c] - d.bias_h) / d.norm_h, a = alphaT * hn;
+                klh += a * a;
+                ee[3 + c] = e[3 + c];
+                zo[3 + c] = alpha * hn + sigma * e[3 + c];
+            }
+        }
+    };
+    part(n, base, P, ldp, px, poh, raw_l, z_l, e_l);
+    part(m, qbase, R, ldq, qx, qoh, raw_q, z_q, e_q);
+    wg_sum3(klx, klh, dummy, red);
+    if (tid == 0) { klsum[2 * b] = klx; klsum[2 * b + 1] = klh; }
+}
+
+// log p(h | z_0) of one node (en_diffusion.py:298-326): the normal around each class integrated over the unit bin, normalised over the
+// classes, dotted with the node's one-hot row.  z: the node's normalised feature block; oh: its raw one-hot row.
+__device__ __forceinline__ float log_ph_row(const float* z, const float* oh, int C, const Dims& d, float s0cat) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+        const float ctr = z[c] * d.norm_h + d.bias_h - 1.0f;
+        mx = fmaxf(mx, logf(cdf_std_gauss((ctr + 0.5f) / s0cat) - cdf_std_gauss((ctr - 0.5f) / s0cat) + 1e-10f));
+    }
+    float se = 0.f, dot = 0.f, ohs = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float ctr = z[c] * d.norm_h + d.bias_h - 1.0f;
+        const float lp = logf(cdf_std_gauss((ctr + 0.5f) / s0cat) - cdf_std_gauss((ctr - 0.5f) / s0cat) + 1e-10f);
+        se += expf(lp - mx);
+        const float o = ((oh[c] - d.bias_h) / d.norm_h) * d.norm_h + d.bias_h;
+        dot += lp * o; ohs += o;
+    }
+    return dot - (mx + logf(se)) * ohs;
+}
+
+__global__ __launch_bounds__(256) void k_train_loss_joint(Layout lay, Dims d, int l2, float T, const float* __restrict__ net_l,
+                                                          const float* __restrict__ net_q, const float* __restrict__ e_l,
+                                                          const float* __restrict__ e_q, const float* __restrict__ z_l,
+                                                          const float* __restrict__ z_q, const float* __restrict__ poh,
+                                                          const float* __restrict__ qoh, const float* __restrict__ tab,
+                                                          const float* __restrict__ klsum, float* __restrict__ terms,
+                                                          float* __restrict__ d_l, float* __restrict__ d_q) {
+    __shared__ float red[12];
+    const int b = blockIdx.x, B = lay.B, tid = threadIdx.x;
+    const int n = lay.num_phar[b], base = lay.phar_base[b], m = lay.num_pocket[b], qbase = lay.pocket_base[b];
+    const int P = d.P, R = d.R;
+    const float t0 = tab[TT_T0 * B + b], snrw = tab[TT_SNRW * B + b], s0cat = tab[TT_S0CAT * B + b];
+    const float nf = (float)n, mf = (float)m;
+    float sums[2][5];                      // [part][x error, h error, log p(h), |eps_hat_x|, |eps_hat_h|]
+    auto part = [&](int which, int rows, int row0, int C, float cntf, const float* net, const float* eps, const float* z, const float* oh, float* de) {
+        const int ld = 3 + C;
+        const float s_t = l2 ? 1.0f / ((float)(3 + C) * cntf) : -T * snrw, s_0 = l2 ? 1.0f / (3.0f * cntf) : 1.0f;
+        const float w_t = (1.0f - t0) * s_t / (float)B, w_0 = t0 * s_0 / (float)B;
+        float ex = 0.f, eh = 0.f, lph = 0.f, ax = 0.f, ah = 0.f, dummy = 0.f;
+        for (int i = tid; i < rows; i += 256) {
+            const size_t g = (size_t)(row0 + i);
+            const float* o = net + g * ld; const float* e = eps + g * ld; float* dd = de + g * ld;
+            float sabs = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float df = o[c] - e[c];
+                ex += df * df; sabs += fabsf(o[c]);
+                dd[c] = df * w_t + df * w_0;
+            }
+            ax += sabs / 3.0f;
+            sabs = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float df = o[3 + c] - e[3 + c];
+                eh += df * df; sabs += fabsf(o[3 + c]);
+                dd[3 + c] = df * w_t;
+            }
+            ah += sabs / (float)C;
+            lph += log_ph_row(z + g * ld + 3, oh + g * C, C, d, s0cat);
+        }
+        wg_sum3(ex, eh, lph, red);
+        wg_sum3(ax, ah, dummy, red);
+        sums[which][0] = ex; sums[which][1] = eh; sums[which][2] = lph; sums[which][3] = ax; sums[which][4] = ah;
+    };
+    part(0, n, base, P, nf, net_l, e_l, z_l, poh, d_l);
+    part(1, m, qbase, R, mf, net_q, e_q, z_q, qoh, d_q);
+    if (tid == 0) {
+        const float sigT = tab[TT_SIGMA_TT * B + b];
+        const float dsub = (nf + mf - 1.0f) * 3.0f;
+        const float kl_h = logf(1.0f / sigT) + 0.5f * (sigT * sigT + klsum[2 * b + 1]) - 0.5f;
+        const float kl_x = dsub * logf(1.0f / sigT) + 0.5f * (dsub * sigT * sigT + klsum[2 * b]) / 1.0f - 0.5f * dsub;
+        const float kl = kl_x + kl_h;
+        float err_l = (sums[0][0] + sums[0][1]) * (1.0f - t0), err_q = (sums[1][0] + sums[1][1]) * (1.0f - t0);
+        const float l0x_l = 0.5f * sums[0][0] * t0, l0x_q = 0.5f * sums[1][0] * t0, l0h = -(sums[0][2] + sums[1][2]) * t0;
+        float loss_t, loss_0, nll;
+        if (l2) {
+            err_l = err_l / ((float)(3 + P) * nf); err_q = err_q / ((float)(3 + R) * mf);
+            loss_t = 0.5f * (err_l + err_q);
+            loss_0 = l0x_l / (3.0f * nf) + l0x_q / (3.0f * mf) + l0h;
+            nll = loss_t + loss_0 + kl;
+        } else {
+            loss_t = -T * 0.5f * snrw * (err_l + err_q);
+            loss_0 = l0x_l + l0x_q + l0h + tab[TT_NEGLOGC * B + b];
+            nll = loss_t + loss_0 + kl - tab[TT_DLOGPX * B + b] - tab[TT_LOGPN * B + b];
+        }
+        float* o = terms + (size_t)b * TS_COLS;
+        o[TS_NLL] = nll; o[TS_ERR_T] = err_l; o[TS_LOSS_0] = loss_0; o[TS_KL] = kl;
+        o[TS_ABS_X] = sums[0][3] / (float)max(n, 1); o[TS_ABS_H] = sums[0][4] / (float)max(n, 1);
+        o[TS_LOSS_0X] = l0x_l + l0x_q; o[TS_LOSS_0H] = l0h; o[TS_LOSS_T] = loss_t;
+        o[TS_ERR_T_Q] = err_q; o[TS_ABS_X_Q] = sums[1][3] / (float)max(m, 1); o[TS_ABS_H_Q] = sums[1][4] / (float)max(m, 1);
+    }
+}
+
 // means over the batch of every per-sample term column (one workgroup; B is at most a few thousand)
 __global__ __launch_bounds__(256) void k_train_means(int B, const float* __restrict__ terms, float* __restrict__ means) {
     __shared__ float red[12];
@@ -1532,6 +1688,18 @@ void tr_noise(const Layout& lay, const Dims& d, const float* px, const float* po
 void tr_loss(const Layout& lay, const Dims& d, int l2, float T, const float* net, const float* eps, const float* z_t, const float* poh,
              const float* tab, const float* klsum, float* terms, float* d_eps, float* means, hipStream_t s) {
     hipLaunchKernelGGL(k_train_loss, dim3(lay.B), dim3(256), 0, s, lay, d, l2, T, net, eps, z_t, poh, tab, klsum, terms, d_eps);
+    hipLaunchKernelGGL(k_train_means, dim3(1), dim3(256), 0, s, lay.B, terms, means);
+}
+
+void tr_noise_joint(const Layout& lay, const Dims& d, const float* px, const float* poh, const float* qx, const float* qoh, const float* tab,
+                    const float* raw_l, const float* raw_q, float* z_l, float* z_q, float* e_l, float* e_q, float* klsum, hipStream_t s) {
+    hipLaunchKernelGGL(k_train_noise_joint, dim3(lay.B), dim3(256), 0, s, lay, d, px, poh, qx, qoh, tab, raw_l, raw_q, z_l, z_q, e_l, e_q, klsum);
+}
+void tr_loss_joint(const Layout& lay, const Dims& d, int l2, float T, const float* net_l, const float* net_q, const float* e_l, const float* e_q,
+                   const float* z_l, const float* z_q, const float* poh, const float* qoh, const float* tab, const float* klsum, float* terms,
+                   float* d_l, float* d_q, float* means, hipStream_t s) {
+    hipLaunchKernelGGL(k_train_loss_joint, dim3(lay.B), dim3(256), 0, s, lay, d, l2, T, net_l, net_q, e_l, e_q, z_l, z_q, poh, qoh, tab, klsum,
+                       terms, d_l, d_q);
     hipLaunchKernelGGL(k_train_means, dim3(1), dim3(256), 0, s, lay.B, terms, means);
 }
 

@@ -68,6 +68,8 @@ SYMBOLS = [
     ('cmdgen_train_set_precision', C.c_int, [_vp, C.c_int32]),
     ('cmdgen_train_noise', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
     ('cmdgen_train_loss', C.c_int, [_vp, C.c_int32, C.c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
+    ('cmdgen_train_noise_joint', C.c_int, [_vp] + [_fp] * 12 + [_vp]),
+    ('cmdgen_train_loss_joint', C.c_int, [_vp, C.c_int32, C.c_float] + [_fp] * 14 + [_vp]),
     ('cmdgen_grad_sqnorm', C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_float), _vp]),
     ('cmdgen_adamw_step', C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, _vp]),
@@ -418,6 +420,37 @@ class Handle:
                                                _ptr(tab), _ptr(kl_sums), _ptr(terms), _ptr(d_eps), _ptr(means), self._stream()),
                     'cmdgen_train_loss')
         return terms, means, d_eps
+
+    def train_noise_joint(self, phar_x, phar_one_hot, pocket_x, pocket_one_hot, tab, draw_phar, draw_pocket):
+        """-> (z_phar, z_pocket, eps_phar, eps_pocket, kl_sums): the fused noising of the joint model's training step."""
+        import torch
+        P, R = self.cfg['phar_nf'], self.cfg['residue_nf']
+        for t, shape in ((phar_x, (self.n_phar, 3)), (phar_one_hot, (self.n_phar, P)), (pocket_x, (self.n_pocket, 3)),
+                         (pocket_one_hot, (self.n_pocket, R)), (tab, (self.TT_COLS, self.batch)), (draw_phar, (self.n_phar, 3 + P)),
+                         (draw_pocket, (self.n_pocket, 3 + R))):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape, (tuple(t.shape), shape)
+        z_l, z_q, e_l, e_q = (torch.empty_like(draw_phar), torch.empty_like(draw_pocket), torch.empty_like(draw_phar),
+                              torch.empty_like(draw_pocket))
+        kl = torch.empty((self.batch, 2), dtype=torch.float32, device=tab.device)
+        self._check(self.lib.cmdgen_train_noise_joint(self.h, _ptr(phar_x), _ptr(phar_one_hot), _ptr(pocket_x), _ptr(pocket_one_hot), _ptr(tab),
+                                                      _ptr(draw_phar), _ptr(draw_pocket), _ptr(z_l), _ptr(z_q), _ptr(e_l), _ptr(e_q), _ptr(kl),
+                                                      self._stream()), 'cmdgen_train_noise_joint')
+        return z_l, z_q, e_l, e_q, kl
+
+    def train_loss_joint(self, l2: bool, T: float, net_phar, net_pocket, eps_phar, eps_pocket, z_phar, z_pocket, phar_one_hot,
+                         pocket_one_hot, tab, kl_sums):
+        """-> (terms [B, TS_COLS], means [TS_COLS], d_eps_phar, d_eps_pocket) of the joint model's training loss."""
+        import torch
+        for a, b in ((net_phar, eps_phar), (net_pocket, eps_pocket)):
+            assert a.is_cuda and a.is_contiguous() and a.dtype == torch.float32 and a.shape == b.shape
+        terms = torch.zeros((self.batch, self.TS_COLS), dtype=torch.float32, device=tab.device)
+        means = torch.empty(self.TS_COLS, dtype=torch.float32, device=tab.device)
+        d_l, d_q = torch.empty_like(net_phar), torch.empty_like(net_pocket)
+        self._check(self.lib.cmdgen_train_loss_joint(self.h, int(bool(l2)), float(T), _ptr(net_phar), _ptr(net_pocket), _ptr(eps_phar),
+                                                     _ptr(eps_pocket), _ptr(z_phar), _ptr(z_pocket), _ptr(phar_one_hot), _ptr(pocket_one_hot),
+                                                     _ptr(tab), _ptr(kl_sums), _ptr(terms), _ptr(d_l), _ptr(d_q), _ptr(means), self._stream()),
+                    'cmdgen_train_loss_joint')
+        return terms, means, d_l, d_q
 
     def grad_sqnorm(self, grad) -> float:
         out = C.c_float(0)

@@ -22,12 +22,15 @@ import torch
 from . import utils
 
 
-def per_sample_table(gamma, log_pn, T, n_dims, norm_values, t_int, n_phar, n_pocket) -> torch.Tensor:
+def per_sample_table(gamma, log_pn, T, n_dims, norm_values, t_int, n_phar, n_pocket, variant: str = 'conditional') -> torch.Tensor:
     """[12, B] fp32 table of everything ConditionalDDPM.forward derives from t and the node counts alone
     (conditional_model.py:206-221, :49-59; en_diffusion.py:227-234), made on the host in numpy with the reference's fp32 op
     sequence - the `tab` argument of cmdgen_train_noise / cmdgen_train_loss (rows as listed in include/cmdgen_hip.h):
     alpha_t, sigma_t, t_is_zero, SNR weight, alpha_T, sigma_T, -log_constants_p_x_given_z0, delta_log_px, log p(N), t_int, t,
-    sigma_t * norm_values[1].  gamma: the predefined schedule's lookup table [T+1]; log_pn: log p(n_phar | n_pocket) table."""
+    sigma_t * norm_values[1].  gamma: the predefined schedule's lookup table [T+1]; log_pn: log p(n_phar | n_pocket) table.
+    variant: 'conditional' ((n_phar - 1) * n_dims degrees of freedom), 'simple' (SimpleConditionalDDPM, conditional_model.py:481-525:
+    n_phar * n_dims) or 'joint' (EnVariationalDiffusion, en_diffusion.py:332-465: (n_phar + n_pocket - 1) * n_dims, and `log_pn` is the
+    joint table log p(n_phar, n_pocket))."""
     g, f32 = np.asarray(gamma, dtype=np.float32), np.float32
     Tf = f32(T)
     t_int = np.asarray(torch.as_tensor(t_int).detach().to('cpu', torch.float32)).reshape(-1)
@@ -36,7 +39,10 @@ def per_sample_table(gamma, log_pn, T, n_dims, norm_values, t_int, n_phar, n_poc
     gamma_T, gamma_0 = g[int(round(float(Tf)))], g[0]
     sigmoid = lambda x: (f32(1) / (f32(1) + np.exp(-x, dtype=f32))).astype(f32)
     n = np.asarray(n_phar, dtype=f32)
-    sub = (n - f32(1)) * f32(n_dims)
+    if variant == 'joint':
+        sub = (n + np.asarray(n_pocket, dtype=f32) - f32(1)) * f32(n_dims)
+    else:
+        sub = (n if variant == 'simple' else n - f32(1)) * f32(n_dims)
     nv0, nv1 = float(norm_values[0]), float(norm_values[1])
     sigma_t = np.sqrt(sigmoid(gamma_t))
     one = np.ones_like(n)
@@ -88,7 +94,7 @@ class HipTrainer:
         self.gemm_dtype = gemm_dtype        # 'bf16': GEMM operands in bf16, fp32 accumulation (mixed precision); default exact fp32
         self.last_info: Dict[str, float] = {}
         self.overlap_allreduce = True       # all-reduce finished gradient chunks behind the rest of the backward pass
-        self.fused_loss = True              # conditional model: noising and loss terms as three library launches (cmdgen_train_noise / _loss)
+        self.fused_loss = True              # noising and loss terms as three library launches (cmdgen_train_noise / _loss[_joint])
         self._gamma_host = self._logpn_host = None
         self._last_fused = None
         self._net_inputs = None
@@ -109,24 +115,31 @@ class HipTrainer:
         out = self.h.train_forward(self.theta, z, q, t, want_pocket=self.joint)
         return out if self.joint else (out, None)
 
-    # ------------------------------------------------------------------ fused loss side (conditional model)
+    # ------------------------------------------------------------------ fused loss side
+    def _variant(self) -> Optional[str]:
+        from .equivariant_diffusion.en_diffusion import EnVariationalDiffusion
+        from .equivariant_diffusion.conditional_model import ConditionalDDPM, SimpleConditionalDDPM
+        return {ConditionalDDPM: 'conditional', SimpleConditionalDDPM: 'simple', EnVariationalDiffusion: 'joint'}.get(type(self.ddpm))
+
     def _fused_ok(self) -> bool:
         from .equivariant_diffusion.en_diffusion import PredefinedNoiseSchedule
-        from .equivariant_diffusion.conditional_model import ConditionalDDPM
-        return self.fused_loss and type(self.ddpm) is ConditionalDDPM and isinstance(self.ddpm.gamma, PredefinedNoiseSchedule)
+        return self.fused_loss and self._variant() is not None and isinstance(self.ddpm.gamma, PredefinedNoiseSchedule)
 
     def _sample_table(self, t_int, n_phar, n_pocket):
         """[TT_COLS, B] per-sample scalars of one step (include/cmdgen_hip.h), see ``per_sample_table``."""
-        ddpm = self.ddpm
+        ddpm, variant = self.ddpm, self._variant()
         if self._gamma_host is None:
             self._gamma_host = ddpm.gamma.gamma.detach().to('cpu', torch.float32).numpy().copy()
-            self._logpn_host = ddpm.size_distribution._table(1, torch.device('cpu')).to(torch.float32).numpy().copy()
-        return per_sample_table(self._gamma_host, self._logpn_host, ddpm.T, ddpm.n_dims, ddpm.norm_values, t_int, n_phar, n_pocket)
+            sd = ddpm.size_distribution
+            lp = sd.m.logits.view(sd.prob.shape) if variant == 'joint' else sd._table(1, torch.device('cpu'))     # log_pN (:297-299) / log p(n1 | n2)
+            self._logpn_host = lp.detach().to('cpu', torch.float32).numpy().copy()
+        return per_sample_table(self._gamma_host, self._logpn_host, ddpm.T, ddpm.n_dims, ddpm.norm_values, t_int, n_phar, n_pocket, variant)
 
     @torch.no_grad()
     def _loss_and_grad_fused(self, data, t_int=None, eps=None):
-        """The conditional model's training loss with the three fused launches of the library (cmdgen_train_noise /
-        cmdgen_train_loss) around the activation-saving forward; same values as PharPocketDDPM.forward(training mode)."""
+        """The training loss with the three fused launches of the library (cmdgen_train_noise / cmdgen_train_loss, or their _joint
+        forms) around the activation-saving forward; same values as PharPocketDDPM.forward(training mode) for ConditionalDDPM,
+        SimpleConditionalDDPM and the joint EnVariationalDiffusion."""
         model, ddpm, h = self.model, self.ddpm, self.h
         model.train()
         dev = self.theta.device
@@ -155,6 +168,27 @@ class HipTrainer:
             tab = pin.to(dev, non_blocking=True)
         else:
             tab = tab.to(dev, non_blocking=True)
+        tm = tab.mean(1)
+        info = {'SNR_weight': tm[3], 'delta_log_px': tm[7], 'neg_log_const_0': tm[6], 'log_pN': tm[8]}
+        if self.joint:
+            if eps is None:
+                e_l = torch.randn((px.shape[0], ddpm.n_dims + ddpm.phar_nf), device=dev)
+                e_q = torch.randn((qx.shape[0], ddpm.n_dims + ddpm.residue_nf), device=dev)
+            else:
+                e_l, e_q = (v.to(dev, torch.float32).contiguous() for v in next(iter(eps)))
+            z_t, z_q, e_l, e_q, kl = h.train_noise_joint(px, poh, qx, qoh, tab, e_l, e_q)
+            self._net_inputs = (z_t, z_q)
+            net_out, net_q = h.train_forward(self.theta, z_t, z_q, tab[10], want_pocket=True)
+            terms, means, d_eps, d_eps_q = h.train_loss_joint(model.loss_type == 'l2', float(ddpm.T), net_out, net_q, e_l, e_q, z_t, z_q,
+                                                              poh, qoh, tab, kl)
+            self.grad.zero_()
+            self._backward(d_eps, d_eps_q)
+            info.update({'eps_hat_phar_x': means[4], 'eps_hat_phar_h': means[5], 'eps_hat_pocket_x': means[10], 'eps_hat_pocket_h': means[11],
+                         'error_t_phar': means[1], 'error_t_pocket': means[9], 'loss_0': means[2], 'kl_prior': means[3]})
+            self._last_fused = {'terms': terms, 'tab': tab, 'z_t': z_t, 'xh_pocket': z_q, 'eps_t': e_l, 'eps_t_pocket': e_q, 'net_out': net_out,
+                                'net_out_pocket': net_q, 'd_eps': d_eps, 'd_eps_pocket': d_eps_q}
+            self._net_inputs = None
+            return means[0], terms[:, 0], info
         if eps is None:
             e = torch.randn((px.shape[0], ddpm.n_dims + ddpm.phar_nf), device=dev)
         else:
@@ -164,10 +198,8 @@ class HipTrainer:
         terms, means, d_eps = h.train_loss(model.loss_type == 'l2', float(ddpm.T), net_out, e, z_t, poh, tab, kl)
         self.grad.zero_()
         self._backward(d_eps, None)
-        tm = tab.mean(1)
-        info = {'eps_hat_phar_x': means[4], 'eps_hat_phar_h': means[5], 'error_t_phar': means[1],
-                'error_t_pocket': torch.zeros((), device=dev), 'SNR_weight': tm[3], 'loss_0': means[2], 'kl_prior': means[3],
-                'delta_log_px': tm[7], 'neg_log_const_0': tm[6], 'log_pN': tm[8]}
+        info.update({'eps_hat_phar_x': means[4], 'eps_hat_phar_h': means[5], 'error_t_phar': means[1],
+                     'error_t_pocket': torch.zeros((), device=dev), 'loss_0': means[2], 'kl_prior': means[3]})
         self._last_fused = {'terms': terms, 'tab': tab, 'z_t': z_t, 'xh_pocket': xh_pocket, 'eps_t': e, 'net_out': net_out, 'd_eps': d_eps}
         return means[0], terms[:, 0], info
 

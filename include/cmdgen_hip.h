@@ -268,7 +268,9 @@ int cmdgen_train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
  *   0 alpha_t, 1 sigma_t, 2 t_is_zero, 3 SNR weight 1 - SNR(gamma_s - gamma_t), 4 alpha_T, 5 sigma_T,
  *   6 -log_constants_p_x_given_z0, 7 delta_log_px, 8 log p(N), 9 t_int, 10 t = t_int / T (column 10 is the `t`
  *   argument of cmdgen_train_forward), 11 sigma_t * norm_values[1].
- * cmdgen_train_noise: normalize + remove_mean_batch + noised_representation (conditional_model.py:80-106, :467-475):
+ * cmdgen_train_noise: normalize + remove_mean_batch + noised_representation (conditional_model.py:80-106, :467-475; on a handle
+ *   configured with no_com_projection - SimpleConditionalDDPM, :481-525 - the pocket's centre of mass is subtracted instead and nothing
+ *   is projected, and the caller's `tab` counts n_phar * 3 degrees of freedom):
  *   from the raw batch (phar_x [Nl,3], phar_one_hot [Nl,phar_nf], pocket_x [Np,3], pocket_one_hot [Np,residue_nf]) and the
  *   Gaussian draw eps [Nl,3+phar_nf] writes z_t [Nl,3+phar_nf], xh_pocket [Np,3+residue_nf] (the network's inputs) and
  *   kl_sums [batch,2] (sum of (alpha_T x)^2 and (alpha_T h)^2 of the clean sample, for kl_prior, :49-59).
@@ -285,6 +287,23 @@ int cmdgen_train_noise(cmdgen_handle* h, const float* phar_x, const float* phar_
 int cmdgen_train_loss(cmdgen_handle* h, int32_t l2, float T, const float* net_out, const float* eps, const float* z_t,
                       const float* phar_one_hot, const float* tab, const float* kl_sums, float* terms, float* d_eps,
                       float* means, cmdgen_stream stream);
+
+/* The same two launches for the JOINT model (mode 'joint': EnVariationalDiffusion.forward in training mode, en_diffusion.py:332-465,
+ * with the joint branch of lightning_modules.py:198-217): the pocket is noised and denoised too.  `tab` as above with the node count
+ * n_phar + n_pocket in columns 6 and 7 and the JOINT log p(n_phar, n_pocket) in column 8.
+ * cmdgen_train_noise_joint: draw_phar [Nl,3+phar_nf] / draw_pocket [Np,3+residue_nf] are raw Gaussian draws; writes eps_phar / eps_pocket
+ *   (the draws with the x-part's centre of mass over all nodes of the sample removed, :555-574), z_phar / z_pocket = alpha_t xh +
+ *   sigma_t eps (the network's inputs) and kl_sums [batch,2] over both parts.
+ * cmdgen_train_loss_joint: net_phar / net_pocket = both outputs of cmdgen_train_forward; terms columns 0..8 as above (1, 4, 5 for the
+ *   phar part; 6 = loss_0_x of both parts), 9 error_t of the pocket part, 10 / 11 mean |eps_hat| of the pocket's x / h;
+ *   d_eps_phar / d_eps_pocket = d loss / d net outputs, the inputs of cmdgen_train_backward. */
+int cmdgen_train_noise_joint(cmdgen_handle* h, const float* phar_x, const float* phar_one_hot, const float* pocket_x,
+                             const float* pocket_one_hot, const float* tab, const float* draw_phar, const float* draw_pocket,
+                             float* z_phar, float* z_pocket, float* eps_phar, float* eps_pocket, float* kl_sums, cmdgen_stream stream);
+int cmdgen_train_loss_joint(cmdgen_handle* h, int32_t l2, float T, const float* net_phar, const float* net_pocket,
+                            const float* eps_phar, const float* eps_pocket, const float* z_phar, const float* z_pocket,
+                            const float* phar_one_hot, const float* pocket_one_hot, const float* tab, const float* kl_sums,
+                            float* terms, float* d_eps_phar, float* d_eps_pocket, float* means, cmdgen_stream stream);
 
 /* GEMM operand precision of the training step's backward products: 0 (default) = fp32 results (fp32-accurate split-bf16
  * products or, with cmdgen_set_gemm_mode(0), the fp32 matrix instruction), 1 = operands rounded to bf16 (nearest-even),

@@ -277,6 +277,78 @@ def test_fused_loss_side_equals_the_tensor_op_path(loss_type):
     assert np.isfinite(float(l0)) and torch.isfinite(tr.grad).all()
 
 
+def _variant_trainer(mode, loss_type='l2'):
+    """PharPocketDDPM + HipTrainer of another model variant on the fixtures' batches: 'joint' (G9) / 'pocket_conditioning_simple' (G6)."""
+    from argparse import Namespace
+    from helpers import joint_loss_case
+    from cmdgen_amd.lightning_modules import PharPocketDDPM
+    from cmdgen_amd.training import HipTrainer
+    if mode == 'joint':
+        g = load_golden('g9_joint.npz')
+        cfg, sd, phar, pocket, hist = joint_loss_case(g)
+    else:
+        g = load_golden('g6_loss.npz')
+        cfg, sd, phar, pocket, hist = loss_case(g)
+    hp = dict(outdir='out', dataset='crossdock', datadir='data', batch_size=4, lr=1e-3,
+              egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=cfg.hidden_nf, n_layers=cfg.n_layers,
+                                    attention=True, tanh=True, norm_constant=1, inv_sublayers=1, sin_embedding=False,
+                                    aggregation_method='sum', normalization_factor=100),
+              diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
+                                         diffusion_noise_precision=1e-5, diffusion_loss_type=loss_type, normalize_factors=[1, 4]),
+              num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
+              eval_params=Namespace(n_eval_samples=100, eval_batch_size=100), mode=mode, node_histogram=hist, pocket_representation='CA')
+    model = PharPocketDDPM(**hp)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.cuda()
+    data = {'phar_coords': phar['x'], 'phar_one_hot': phar['one_hot'], 'num_phar_atoms': phar['size'], 'phar_mask': phar['mask'],
+            'pocket_c_alpha': pocket['x'], 'pocket_one_hot': pocket['one_hot'], 'num_pocket_nodes': pocket['size'],
+            'pocket_mask': pocket['mask']}
+    return model, HipTrainer(model), data, g
+
+
+@pytest.mark.parametrize('mode,loss_type', [('joint', 'l2'), ('joint', 'vlb'), ('pocket_conditioning_simple', 'l2'),
+                                            ('pocket_conditioning_simple', 'vlb')])
+def test_fused_loss_side_of_the_joint_and_simple_variants(mode, loss_type):
+    """cmdgen_train_noise_joint / cmdgen_train_loss_joint (mode 'joint': EnVariationalDiffusion.forward, en_diffusion.py:332-465) and
+    cmdgen_train_noise / _loss on a no_com_projection handle (SimpleConditionalDDPM, conditional_model.py:481-525) against the same
+    model's forward evaluated with tensor operations on the same draws: per-sample nll, every logged term, the network's outputs and the
+    parameter gradient; one sample at t = 0."""
+    model, tr, data, g = _variant_trainer(mode, loss_type)
+    assert tr._variant() == ('joint' if mode == 'joint' else 'simple')
+    if mode == 'joint':
+        Nl, Np = len(data['phar_mask']), len(data['pocket_mask'])
+        row = g['loss/train/noise'][0]
+        eps = [(dev(row[:Nl * 11].reshape(Nl, 11).copy()), dev(row[Nl * 11:].reshape(Np, 23).copy()))]
+        t_int = dev(g['loss/t_int']).clone()
+    else:
+        eps = [dev(g['eps0'])]
+        t_int = dev(g['t_int']).clone()
+    t_int[1] = 0
+    tr.fused_loss = False
+    loss_a, nll_a, info_a = tr.loss_and_grad(data, t_int=t_int, eps=eps)
+    grad_a = tr.grad.clone()
+    ctx = dict(tr.ddpm._last_train_ctx)
+    tr.fused_loss = True
+    assert tr._fused_ok()
+    loss_b, nll_b, info_b = tr.loss_and_grad(data, t_int=t_int, eps=eps)
+    f = tr._last_fused
+    assert (f['net_out'] - ctx['net_out']).abs().max() <= 2e-5 * float(ctx['net_out'].abs().max())
+    if mode == 'joint':
+        assert (f['net_out_pocket'] - ctx['net_out_pocket']).abs().max() <= 2e-5 * float(ctx['net_out_pocket'].abs().max())
+        assert (f['eps_t_pocket'] - ctx['eps_t_pocket']).abs().max() <= 1e-6
+    scale = max(1.0, float(nll_a.abs().max()))
+    assert float((nll_a - nll_b).abs().max()) <= 2e-5 * scale, (nll_a, nll_b)
+    assert abs(float(loss_a) - float(loss_b)) <= 2e-5 * scale
+    assert set(info_a) == set(info_b), set(info_a) ^ set(info_b)
+    for k in info_a:
+        a, b = float(info_a[k]), float(info_b[k])
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (k, a, b)
+    assert float((tr.grad - grad_a).abs().max()) <= GRAD_TOL * float(grad_a.abs().max())
+    assert float(f['terms'][1, 6]) > 0 and float(f['terms'][1, 8]) == 0          # the t = 0 sample carries L0, not L_t
+    l0, _, _ = tr.loss_and_grad(data)                                             # own t and draws
+    assert np.isfinite(float(l0)) and torch.isfinite(tr.grad).all()
+
+
 def test_pipelined_steps_equal_waiting_steps():
     """HipTrainer.pipelined (no wait for a step's own gradient norm; layout and per-sample table uploaded in stream order
     from pinned staging, the index arrays into the second of two device blocks; node counts from the batch's host copies)

@@ -111,6 +111,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--representation', default='CA', choices=['CA', 'full-atom'])
     ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16'], help='GEMM operand precision (fp32 accumulation either way)')
+    ap.add_argument('--mode', default='pocket_conditioning', choices=['pocket_conditioning', 'pocket_conditioning_simple', 'joint'])
+    ap.add_argument('--unfused-loss', action='store_true', help='loss side with tensor operations (HipTrainer.fused_loss = False)')
     ap.add_argument('--no-pipeline', action='store_true', help='wait for every step\'s gradient norm before queueing the next step (HipTrainer.pipelined = False)')
     ap.add_argument('--cpu-baseline', action='store_true', help='also time the oracle (torch CPU autograd) on the same batch shape')
     ap.add_argument('--gloo', action='store_true', help='rendezvous over gloo (rehearsal of the multi-rank path on a one-GPU box: all ranks on cuda:0)')
@@ -127,7 +129,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo' if a.gloo else 'nccl', **({} if a.gloo else {'device_id': torch.device('cuda', local)}))
     dev = torch.device('cuda', local)
-    cfg, model, tr = build_trainer(a.batch, a.representation, a.gemm, dev, pipelined=not a.no_pipeline)
+    cfg, model, tr = build_trainer(a.batch, a.representation, a.gemm, dev, pipelined=not a.no_pipeline, mode=a.mode)
+    tr.fused_loss = not a.unfused_loss
     batches = [synthetic_batch(a.batch, 50000 + 1000 * rank + 100 * i, dev, a.representation) for i in range(4)]
     torch.manual_seed(rank)
     dt, losses = time_training(tr, batches, a.steps, a.warmup, dev, dist if world > 1 else None)
@@ -187,7 +190,7 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         print(json.dumps({'metric': 'training complexes/s', 'value': a.batch * world * a.steps / dt, 'n_gpus': world,
-                          'ms_per_step': dt / a.steps * 1e3, 'batch_per_gpu': a.batch, 'dtype': 'f32' if a.gemm == 'fp32' else 'bf16 GEMM operands, f32 accumulate/master',
+                          'ms_per_step': dt / a.steps * 1e3, 'batch_per_gpu': a.batch, 'mode': a.mode, 'fused_loss': bool(tr.fused_loss and tr._fused_ok()), 'dtype': 'f32' if a.gemm == 'fp32' else 'bf16 GEMM operands, f32 accumulate/master',
                           'first_loss': losses[0], 'last_loss': losses[-1], 'cpu_baseline': cpu, 'pipelined': tr.pipelined,
                           'graph_of_last_step': {'nodes': tr.h.n_phar + tr.h.n_pocket, 'edges': tr.h.query('train_edges'),
                                                  'coord_edges': tr.h.query('train_coord_edges')},
