@@ -260,6 +260,9 @@ __device__ __forceinline__ void split_store4(unsigned short* planes, int plane_e
     *reinterpret_cast<uint2*>(planes + 2 * plane_elems + off) = make_uint2(a2, b2);
 }
 
+#ifndef CMDGEN_PLANE_PIN
+#define CMDGEN_PLANE_PIN 1      // tile_gemm_planes: one load pinned after every one or two MFMAs (0: loads in a burst per k-block)
+#endif
 // NPC = 1: only the leading piece of both operands (plain bf16 operands, fp32 accumulation - the training step's opt-in mixed precision)
 template <int MT, int KB16, int NPC = 3>
 __device__ __forceinline__ void tile_gemm_planes(const unsigned short* planes, int plane_elems, int lda,
@@ -289,7 +292,7 @@ __device__ __forceinline__ void tile_gemm_planes(const unsigned short* planes, i
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], carry.b[BS][n][0], acc[m][n], 0, 0, 0); \
         }
     PL_LOADA(0, ap)
-    if constexpr (NPC == 3) {
+    if constexpr (NPC == 3 && CMDGEN_PLANE_PIN != 0) {
         // One load pinned in the shadow of every one or two MFMAs (sched_barrier after each group) instead of a burst of 9-12 loads and
         // their address arithmetic between two k-blocks, which left the matrix pipe idle ~100 cycles per block (profiles/r03_m_node64.txt).
         // Per accumulator the order of the six products is unchanged (small terms first).

@@ -4,6 +4,9 @@
 // tail pass of an edge list inside), grouped weight gradients (k_wgrad_group, k_wgrad_split), the gate / head adjoints
 // with their parameter reductions, the stand-alone tail pass and the generic exact-fp32 GEMM of the fp32-instruction
 // mode and of the small encoder / decoder products -, the per-step re-packing of the parameters, and AdamW.
+// the data-gradient kernels keep the plane GEMM's loads in a burst per k-block: pinned one by one under the MFMAs (the sampler's edge
+// kernels: -6 % per launch) k_dgrad_split<32,3> takes 1.23 instead of 0.95 ms per three steps (profiles/r03_n_wgrad.txt)
+#define CMDGEN_PLANE_PIN 0
 #include "cmdgen_dev.h"
 #include "cmdgen_split.h"
 
