@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round-3 golden fixtures from the REAL reference (build container only; /root/reference never travels).
 
-    python tests/golden/make_golden_r3.py [ca] [fa] [ca256]      # default: all
+    python tests/golden/make_golden_r3.py [ca] [fa] [ca256] [fa32]      # default: all
 
 Writes ``g14_fullsize_chains.npz`` (inputs' seeds, outputs and checkpoints only - never weights, never reference source):
 
@@ -13,6 +13,8 @@ Writes ``g14_fullsize_chains.npz`` (inputs' seeds, outputs and checkpoints only 
                     T=1000 model, same regime.
 * ``ca_b256_K50``   the north-star batch: 256 C-alpha pockets (15 104 nodes: the size at which the 64-row node kernel and the
                     64-row edge tiles take over), K=50 strided steps of a T=1000 model, same regime.
+* ``fa_b32_K10``    32 full-atom pockets (12 192 nodes, ~400k edges per evaluation: 64-row edge tiles and, on a 256-CU device,
+                    the 64-row node kernel on full-atom geometry), K=10 strided steps, same regime.
 
 The K+2 Gaussian draws of a chain are 42 MB and are NOT stored: they come from ``torch.Generator().manual_seed(noise_seed)``
 on the CPU, one ``torch.randn((Nl, 11), generator=gen)`` per draw, and the GPU test regenerates them the same way (same
@@ -129,7 +131,7 @@ def run_case(mods, name, rep, B, K, T, seed, nseed, window):
 
 
 def main():
-    which = set(sys.argv[1:]) or {'ca', 'fa', 'ca256'}
+    which = set(sys.argv[1:]) or {'ca', 'fa', 'ca256', 'fa32'}
     mods = import_reference()
     path = os.path.join(HERE, 'g14_fullsize_chains.npz')
     g = dict(np.load(path)) if os.path.exists(path) else {}
@@ -139,6 +141,8 @@ def main():
         g.update(run_case(mods, 'fa_b8_K100', 'full-atom', 8, 100, 1000, 82, 8200, 10))
     if 'ca256' in which:
         g.update(run_case(mods, 'ca_b256_K50', 'CA', 256, 50, 1000, 83, 8300, 25))
+    if 'fa32' in which:
+        g.update(run_case(mods, 'fa_b32_K10', 'full-atom', 32, 10, 1000, 84, 8400, 5))
     np.savez_compressed(path, **g)
     print('wrote', path, os.path.getsize(path), 'bytes')
 

@@ -168,11 +168,12 @@ def batch_rms(a, b):
 
 
 @pytest.mark.parametrize('engine', ['split', 'fp32'])
-@pytest.mark.parametrize('name', ['ca_b64_K1000', 'fa_b8_K100', 'ca_b256_K50'])
+@pytest.mark.parametrize('name', ['ca_b64_K1000', 'fa_b8_K100', 'ca_b256_K50', 'fa_b32_K10'])
 def test_fullsize_chain_matches_reference_g14(name, engine):
     """BASELINE configs[1] at its literal size (64 C-alpha pockets, H=256, L=5, K = T = 1000), configs[4]'s pocket shape
     (8 x 366 full-atom atoms, K = 100) and the north-star batch (256 C-alpha pockets, K = 50: on a 256-CU device the split engine
-    runs its node blocks on k_node64 here) against the REAL reference's chain, eager and graph, both matrix engines:
+    runs its node blocks on k_node64 here; and 32 full-atom pockets, K = 10: the same kernel on full-atom geometry) against the REAL
+    reference's chain, eager and graph, both matrix engines:
       * north_star's sentence, literally: coordinate RMS over the WHOLE batch (no sample excluded) <= 1e-4 A absolute, at
         every checkpoint (every 100 / 10 steps) and at the end; pocket translation likewise;
       * per sample: every sample none of whose pairs came within BAND of the cutoff (margins recorded by the fixture: the
