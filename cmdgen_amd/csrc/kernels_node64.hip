@@ -44,9 +44,6 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const sbf
     // one group = one load and the two MFMAs of one row half (pieces AI x BI), pinned: the loads issue in the shadow of the MFMAs
     // instead of in a burst between k-blocks (which left the matrix pipe idle ~100 cycles per block).  Small terms first.
 #define NG_GRP(LOAD, M, AS, BS, AI, BI) LOAD NG_MF(M, 0, AS, AI, BS, BI) NG_MF(M, 1, AS, AI, BS, BI) __builtin_amdgcn_sched_barrier(0);
-#ifndef N64_EXP
-#define N64_EXP 0
-#endif
 #define NG_BLOCK(I) { constexpr int AS_ = (I) & 1, AN_ = ((I) + 1) & 1, BS_ = (I) & (NRING - 1), BN_ = ((I) + NRING - 1) & (NRING - 1);  \
         const int ka_ = kb + (I) + 1, kq_ = kb + (I) + NRING - 1;                                             \
         const bool in_ = kq_ < KB16; const unsigned ko_ = (unsigned)(in_ ? kq_ : kq_ - KB16) * 192u;           \
