@@ -25,7 +25,7 @@ for S in (1, 2, 4):
     def run(i, k):
         h, x, oh, ids, st = parts[i]
         with torch.cuda.stream(st):
-            outs[i] = h.sample_chain(x, oh, k, seed=7, pocket_ids=ids)[0]
+            outs[i] = h.sample_chain(x, oh, k, seed=7, pocket_ids=ids, use_graph=os.environ.get('EAGER') is None)[0]
     for i in range(S): run(i, 20)        # graph capture, one handle at a time (stream capture is process-global)
     for k in (40, K):        # warm-up, then the timed chain
         torch.cuda.synchronize(); t0 = time.perf_counter()
