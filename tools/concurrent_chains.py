@@ -1,6 +1,6 @@
 """Do independent chains on separate HIP streams overlap on one MI355X?  One handle with B pockets against S handles with B / S pockets each
 (global pocket ids kept, so every pocket's draws and result are the same), each on its own stream, driven from S host threads.
-usage: python tools/concurrent_chains.py [B] [K]"""
+usage: python tools/concurrent_chains.py [B] [K] [only this number of streams]"""
 import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,7 +13,8 @@ cfg = ModelConfig(residue_nf=20, timesteps=1000)
 sd = make_state_dict(cfg, seed=0)
 dev = torch.device('cuda')
 results = {}
-for S in (1, 2, 4):
+ONLY = [int(sys.argv[3])] if len(sys.argv) > 3 else (1, 2, 4)
+for S in ONLY:
     parts = []
     for s in range(S):
         pb = make_pockets(B // S, 'CA', first_index=s * (B // S))
@@ -26,8 +27,8 @@ for S in (1, 2, 4):
         h, x, oh, ids, st = parts[i]
         with torch.cuda.stream(st):
             outs[i] = h.sample_chain(x, oh, k, seed=7, pocket_ids=ids, use_graph=os.environ.get('EAGER') is None)[0]
-    for i in range(S): run(i, 20)        # graph capture, one handle at a time (stream capture is process-global)
-    for k in (40, K):        # warm-up, then the timed chain
+    for i in range(S): run(i, K)         # graph capture and step table, one handle at a time
+    for k in (K, K):         # warm-up, then the timed chain
         torch.cuda.synchronize(); t0 = time.perf_counter()
         th = [threading.Thread(target=run, args=(i, k)) for i in range(S)]
         [t.start() for t in th]; [t.join() for t in th]
@@ -35,6 +36,6 @@ for S in (1, 2, 4):
     results[S] = torch.cat([o.cpu() for o in outs])
     print(f'{S} stream(s) x {B // S} pockets: {dt * 1e3:8.1f} ms for K={K}  -> {B * K / dt / 1e3:7.1f}k pocket-steps/s', flush=True)
     for p in parts: p[0].close()
-for S in (2, 4):
+for S in [x for x in ONLY if x != 1 and 1 in ONLY]:
     d = (results[S][:, :3] - results[1][:, :3]).abs().max().item()
     print(f'{S} streams vs 1: max |dx| {d:.2e} (|x| up to {results[1][:, :3].abs().max().item():.0f}), types equal {bool((results[S][:, 3:] == results[1][:, 3:]).all())}')
