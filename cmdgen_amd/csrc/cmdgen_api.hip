@@ -548,6 +548,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     a.split = h->gemm_split ? 1 : 0;
     a.n_cus = h->n_cus;
+    { const char* ev = getenv("CMDGEN_EDGE_FULLK"); a.edge_fullk = (h->dims.H == 256 && h->gemm_split && !(ev && atoi(ev) == 0)) ? 1 : 0; }
     {   // k_node64 (kernels_node64.hip: 64-row node tiles, the A operand as producer-side bf16 planes, one workgroup per CU) against
         // k_node<H, 32> (register split, two workgroups per CU).  Per launch the 64-row kernel takes ~0.89 of a co-resident pair of
         // 32-row tiles, a 32-row tile alone on its CU ~0.62 of that 64-row tile (profiles/r03_m_node64.txt), so the choice is a matter
@@ -1218,6 +1219,7 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "node16_split") *value = a.split16;
     else if (k == "proj_split") *value = a.proj_split;
     else if (k == "node64") *value = a.node64;
+    else if (k == "edge_fullk") *value = a.edge_fullk;
     else if (k == "node_pair") *value = (a.node_pair && 2 * ((h->lay.N + 31) / 32) <= a.n_cus) ? 1 : 0;
     else if (k == "train_edges") *value = h->train_E;
     else if (k == "train_coord_edges") *value = h->train_Ec;

@@ -201,6 +201,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int split16 = 0;            // 1: 16-row node tiles too (Eng<16, true>; CMDGEN_NODE16_SPLIT=0 opts out)
     int merge_coord = 0;        // 1: k_edge_coord(l-1) and k_edge_msg(l) share a launch (k_coord_msg; sampler, H = 256)
     int n_cus = 256;
+    int edge_fullk = 0;         // 1: 32-row edge tiles of the sampler build all 256 columns at once (full-K planes; CMDGEN_EDGE_FULLK=0 opts out)
     int node64 = 0;             // 1: large batches run k_node as 64-row tiles with both images in LDS (kernels_node64.hip)
     int node_pair = 0;          // 1: small batches run k_node as pairs of workgroups sharing a 32-row tile by output columns (k_node_pair)
     int pair_cap = 0;           //    pairs the exchange buffers hold

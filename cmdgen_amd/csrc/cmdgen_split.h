@@ -354,3 +354,57 @@ __device__ __forceinline__ void tile_gemm_planes(const unsigned short* planes, i
 #undef PL_LOADA
 #undef PL_MFMAS
 }
+
+// ---------------------------------------------------------------------------------------------
+// Full-K plane image for 32-row tiles (round 3): three planes of [32][256] bf16 with NO row pad (48 KB: three workgroups per CU) - the
+// 16-byte k-octet o of row r lies at octet o ^ (r & 31) of the row, so the sixteen rows of a ds_read_b128 phase fall on sixteen different
+// bank groups.  One build -> one GEMM over all 256 k-values per tile instead of two half-K passes: the tile's gathers are one round trip
+// instead of two (at 64 pockets a launch is one tile's latency chain, and the second gather was 2 us of it; profiles/r03_t_fullk.txt).
+// Carry contract as tile_gemm_planes (set 0 holds k-block 0 of `cur` on entry, of `next` on exit); loads pinned one by one under the MFMAs.
+// ---------------------------------------------------------------------------------------------
+#define SPLIT_SWZ_PE (32 * 256)                               // bf16 elements per plane
+__device__ __forceinline__ int split_swz_off(int row, int octet) { return row * 256 + ((octet ^ (row & 31)) << 3); }
+
+// four consecutive k-values (4 c4 .. 4 c4 + 3) of row e -> the three swizzled planes
+__device__ __forceinline__ void split_store4_swz(unsigned short* planes, int e, int c4, const float4& v) {
+    split_store4(planes, SPLIT_SWZ_PE, split_swz_off(e, c4 >> 1) + ((c4 & 1) << 2), v);
+}
+
+__device__ __forceinline__ void tile_gemm_planes_swz32(const unsigned short* planes, const SFragPtr cur, const SFragPtr next,
+                                                       sf32x16 (&acc)[1][2], SCarry& carry) {
+    constexpr int KB16 = 16, PE = SPLIT_SWZ_PE;
+    const int lane = threadIdx.x & 63, row = lane & 31, hi = lane >> 5;
+    const unsigned short* rp = planes + row * 256;
+    const sbf16x8* q0 = cur.p + 192;
+    const sbf16x8* q1 = q0 + cur.ns;
+    sbf16x8 a[2][3];
+#define SW_PTR(KB) (rp + (((2 * (KB) + hi) ^ row) << 3))
+#define SW_LA(SET, PTR, S) a[SET][S] = *reinterpret_cast<const sbf16x8*>((PTR) + (S) * PE);
+#define SW_LB(SET, N, S) carry.b[SET][N][S] = ((N) == 0 ? q0 : q1)[(S) * 64];
+#define SW_MF(N, AS, AI, BS, BI) acc[0][N] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][AI], carry.b[BS][N][BI], acc[0][N], 0, 0, 0);
+#define SW_GRP(LOADS, AS, BS, AI, BI) LOADS SW_MF(0, AS, AI, BS, BI) SW_MF(1, AS, AI, BS, BI) __builtin_amdgcn_sched_barrier(0);
+#define SW_HALF(AS, BS, AN, BN, PTR)                                                                                              \
+        SW_GRP(SW_LA(AN, PTR, 2) SW_LB(BN, 0, 0), AS, BS, 2, 0) SW_GRP(SW_LA(AN, PTR, 1) SW_LB(BN, 0, 1), AS, BS, 1, 1)             \
+        SW_GRP(SW_LA(AN, PTR, 0) SW_LB(BN, 0, 2), AS, BS, 0, 2) SW_GRP(SW_LB(BN, 1, 0), AS, BS, 1, 0)                               \
+        SW_GRP(SW_LB(BN, 1, 1), AS, BS, 0, 1) SW_GRP(SW_LB(BN, 1, 2), AS, BS, 0, 0)
+    { const unsigned short* p0 = SW_PTR(0); SW_LA(0, p0, 0) SW_LA(0, p0, 1) SW_LA(0, p0, 2) }
+#pragma unroll 1
+    for (int kb = 0; kb < KB16; kb += 2) {
+        const bool more = kb + 2 < KB16;
+        const unsigned short* p1 = SW_PTR(kb + 1);
+        const unsigned short* p2 = SW_PTR(more ? kb + 2 : kb);       // (last block: re-reads its own fragments, unused)
+        __builtin_amdgcn_sched_barrier(0);
+        SW_HALF(0, 0, 1, 1, p1)
+        q0 = more ? q0 + 192 : next.p;
+        q1 = more ? q1 + 192 : next.p + next.ns;
+        __builtin_amdgcn_sched_barrier(0);
+        SW_HALF(1, 1, 0, 0, p2)
+        q0 += 192; q1 += 192;
+    }
+#undef SW_PTR
+#undef SW_LA
+#undef SW_LB
+#undef SW_MF
+#undef SW_GRP
+#undef SW_HALF
+}

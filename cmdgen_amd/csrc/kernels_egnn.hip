@@ -561,6 +561,36 @@ __device__ __forceinline__ void build_edge_half(unsigned short* planes, int half
     }
 }
 
+// Full-K tile build for 32-row tiles (cmdgen_split.h, tile_gemm_planes_swz32): all 256 columns of the tile at once - 16 gathered rows
+// per thread in flight together, ONE round trip per tile - into the swizzled, unpadded plane image.  Thread -> columns 4 c4 .. 4 c4 + 3
+// (c4 = tid % 64) of rows pass * 4 + tid / 64; wr4 / wd4: the thread's four radial / d0 weights (fixed columns: registers, no LDS).
+__device__ __forceinline__ void build_edge_full32(unsigned short* planes, const int* s_row, const int* s_col, const float* s_r, const float* s_d0,
+                                                  int ne, const float* __restrict__ P, const float* __restrict__ Q, const float4& wr4, const float4& wd4) {
+    constexpr int H = 256, MT = 32;
+    const int c4 = threadIdx.x & 63, rsub = threadIdx.x >> 6;
+    float4 p[MT / 4], q[MT / 4];
+#pragma unroll
+    for (int pass = 0; pass < MT / 4; ++pass) {
+        const int e = pass * 4 + rsub;
+        p[pass] = make_float4(0.f, 0.f, 0.f, 0.f); q[pass] = p[pass];
+        if (e < ne) {
+            p[pass] = reinterpret_cast<const float4*>(P + (size_t)s_row[e] * H)[c4];
+            q[pass] = reinterpret_cast<const float4*>(Q + (size_t)s_col[e] * H)[c4];
+        }
+    }
+#pragma unroll
+    for (int pass = 0; pass < MT / 4; ++pass) {
+        const int e = pass * 4 + rsub;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < ne) {
+            const float r = s_r[e], d0 = s_d0[e];
+            a = make_float4(silu_f(p[pass].x + q[pass].x + wr4.x * r + wd4.x * d0), silu_f(p[pass].y + q[pass].y + wr4.y * r + wd4.y * d0),
+                            silu_f(p[pass].z + q[pass].z + wr4.z * r + wd4.z * d0), silu_f(p[pass].w + q[pass].w + wr4.w * r + wd4.w * d0));
+        }
+        split_store4_swz(planes, e, c4, a);
+    }
+}
+
 // Training save hook: the LDS tile holds PRE-activations.  They and their SiLU leave for HBM as whole rows (16 bytes per
 // lane - scattered 4-byte stores straight from the accumulators cost several times the bandwidth), and the tile is left
 // holding SiLU(pre) as the sampler's epilogue would have written it.  pre_out / act_out (may be null: the consumer
@@ -638,13 +668,15 @@ __device__ __forceinline__ int xcd_active_wgs(int ntiles, int nb) {
 // LDS of an edge-tile workgroup, shared by the two edge bodies (a launch that holds both - k_coord_msg - runs them one
 // after the other in the same bytes).
 // ------------------------------------------------------------------------------------
-template <int H, int MT> struct EdgeLds {
-    float buf[MT * LDA(H)];                 // A tile (fp32 image or bf16 planes), then the epilogue's m tile
+// FK (full-K planes, 32-row tiles of the sampler on the split engine): the A tile is three unpadded [32][256] bf16 planes (48 KB) and the
+// radial / d0 weights live in registers - 51.6 KB in all, three workgroups per CU.
+template <int H, int MT, bool FK = false> struct EdgeLds {
+    float buf[FK ? 3 * MT * H / 2 : MT * LDA(H)];   // A tile (fp32 image or bf16 planes), then the epilogue's m tile
     int s_row[MT], s_col[MT];
     float s_r[MT], s_d0[MT], s_att[MT];
     float s_cd[MT][3], s_tr[MT][3];         // coordinate body only
     float s_vec[H];                         // att_mlp / coord_mlp.4 weight: read by every tile's row dot (LDS broadcast, not 16 L1 round trips)
-    float s_wrd[2 * H];                     // radial / d0 weight columns (plane variant)
+    float s_wrd[FK ? 4 : 2 * H];            // radial / d0 weight columns (half-K plane variant)
 };
 
 // Wait (one lane spins, bounded) until every coordinate-role workgroup of this launch has added its sums: `done` counts
@@ -668,8 +700,8 @@ __device__ __forceinline__ void wait_coord_done(const Work& w, const int* done, 
 // coordinate sums of the previous block are being added by workgroups of the SAME launch; a tile that reads positions
 // of moving nodes waits for them first (tiles of pocket-pocket edges do not).
 // ------------------------------------------------------------------------------------
-template <int H, int MT, bool SAVE, bool SP>
-__device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT>& L, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
+template <int H, int MT, bool SAVE, bool SP, bool FK = false>
+__device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
                                               const int layer, const int ablate, const TrainSave& sv, const int vb, const int nb,
                                               const int* done, const int done_target) {
     float* buf = L.buf; int* s_row = L.s_row; int* s_col = L.s_col;
@@ -677,7 +709,8 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT>& L, const Layout& l
     const int tid = threadIdx.x, wave = tid >> 6;
     s_wa[tid] = lw.wa[tid];                                    // visible after the first tile's barriers
     constexpr bool PL = SP && H == 256 && MT >= 32;            // plane variant: the producer splits (build_edge_half)
-    if constexpr (PL) { s_wrd[tid] = lw.wr_e[tid]; s_wrd[H + tid] = lw.wd_e[tid]; }
+    static_assert(!FK || (PL && MT == 32 && !SAVE), "full-K planes: 32-row sampler tiles on the split engine");
+    if constexpr (PL && !FK) { s_wrd[tid] = lw.wr_e[tid]; s_wrd[H + tid] = lw.wd_e[tid]; }
     const ColVec<MT> b2v = col_load<MT>(lw.b2, wave);          // per-column bias and the gate's bias: once per workgroup
     const float ba0 = lw.ba[0];
     const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_e)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_e)[tid % (H / 4)];
@@ -729,7 +762,13 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT>& L, const Layout& l
         STAMP(0);
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
-        if constexpr (PL) {
+        if constexpr (FK) {
+            unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
+            if (!(ablate & 2)) build_edge_full32(planes, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4);
+            lds_barrier();
+            STAMP(1);
+            if (!(ablate & 4)) tile_gemm_planes_swz32(planes, fw, fw, acc.a, carry);
+        } else if constexpr (PL) {
             // two half-K passes: build columns [0,128) as bf16 planes -> GEMM over k 0..127 -> build [128,256) -> GEMM over the rest
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
             constexpr int PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
@@ -808,18 +847,21 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT>& L, const Layout& l
         STAMP(6);
     }
 #if CMDGEN_STAMPS == 1
-    if ((tid & 63) == 0) {      // lane 0 of every wave: [wave][phase] sums, [32 + wave] = wave lifetime, [40] = waves
+    // lane 0 of every wave of a SAMPLE of the workgroups that had a tile (every 4th: thousands of same-address atomics per launch would
+    // sit in front of the next launch's first loads): [wave][phase] sums, [32 + wave] = wave lifetime, [40] = waves, [41] = tile visits
+    if ((tid & 63) == 0 && (vb & 3) == 0 && xcd_tile(0, ntiles, vb, nb) >= 0) {
         for (int i = 0; i < 7; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
         atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
         atomicAdd(&w.dbg[40], 1ull);
+        if (wave == 0) { int nt = 0; while (xcd_tile(nt, ntiles, vb, nb) >= 0) ++nt; atomicAdd(&w.dbg[41], (unsigned long long)nt); }
     }
 #endif
 #undef STAMP
 }
-template <int H, int MT, bool SAVE, bool SP>
-__global__ __launch_bounds__(H, 2) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer, int ablate, TrainSave sv) {
-    __shared__ __attribute__((aligned(16))) EdgeLds<H, MT> L;
-    edge_msg_body<H, MT, SAVE, SP>(L, lay, w, d, lw, layer, ablate, sv, (int)blockIdx.x, (int)gridDim.x, nullptr, 0);
+template <int H, int MT, bool SAVE, bool SP, bool FK = false>
+__global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer, int ablate, TrainSave sv) {
+    __shared__ __attribute__((aligned(16))) EdgeLds<H, MT, FK> L;
+    edge_msg_body<H, MT, SAVE, SP, FK>(L, lay, w, d, lw, layer, ablate, sv, (int)blockIdx.x, (int)gridDim.x, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------------------
@@ -994,8 +1036,8 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
 //   phi = w5 . SiLU(W7 SiLU(W6 [h_i, h_j, r, d0] + b6) + b7)
 //   ACC[l][i] += (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant) * tanh(phi) * coords_range
 // ------------------------------------------------------------------------------------
-template <int H, int MT, bool SAVE, bool SP>
-__device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT>& L, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
+template <int H, int MT, bool SAVE, bool SP, bool FK = false>
+__device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
                                                 const int layer, const TrainSave& sv, const int vb, const int nb) {
     float* buf = L.buf; int* s_row = L.s_row; int* s_col = L.s_col;
     float* s_r = L.s_r; float* s_d0 = L.s_d0; float* s_w5 = L.s_vec; float* s_wrd = L.s_wrd;
@@ -1003,7 +1045,8 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT>& L, const Layout&
     const int tid = threadIdx.x, wave = tid >> 6;
     s_w5[tid] = lw.w5[tid];                                    // coord_mlp.4 weight, staged once per workgroup (see edge_msg_body)
     constexpr bool PL = SP && H == 256 && MT >= 32;            // plane variant, see edge_msg_body
-    if constexpr (PL) { s_wrd[tid] = lw.wr_c[tid]; s_wrd[H + tid] = lw.wd_c[tid]; }
+    static_assert(!FK || (PL && MT == 32 && !SAVE), "full-K planes: 32-row sampler tiles on the split engine");
+    if constexpr (PL && !FK) { s_wrd[tid] = lw.wr_c[tid]; s_wrd[H + tid] = lw.wd_c[tid]; }
     const ColVec<MT> b7v = col_load<MT>(lw.b7, wave);
     const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_c)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_c)[tid % (H / 4)];
     typedef Eng<MT, SP> G;
@@ -1040,7 +1083,12 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT>& L, const Layout&
         lds_barrier();
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
-        if constexpr (PL) {
+        if constexpr (FK) {
+            unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
+            build_edge_full32(planes, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, wr4, wd4);
+            lds_barrier();
+            tile_gemm_planes_swz32(planes, fw, fw, acc.a, carry);
+        } else if constexpr (PL) {
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
             constexpr int PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
             const typename G::Frag fw1 = G::frag(lw.W7, H / 8, H / 16, wave);
@@ -1097,10 +1145,10 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT>& L, const Layout&
         lds_barrier();
     }
 }
-template <int H, int MT, bool SAVE, bool SP>
-__global__ __launch_bounds__(H, 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer, TrainSave sv) {
-    __shared__ __attribute__((aligned(16))) EdgeLds<H, MT> L;
-    edge_coord_body<H, MT, SAVE, SP>(L, lay, w, d, lw, layer, sv, (int)blockIdx.x, (int)gridDim.x);
+template <int H, int MT, bool SAVE, bool SP, bool FK = false>
+__global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer, TrainSave sv) {
+    __shared__ __attribute__((aligned(16))) EdgeLds<H, MT, FK> L;
+    edge_coord_body<H, MT, SAVE, SP, FK>(L, lay, w, d, lw, layer, sv, (int)blockIdx.x, (int)gridDim.x);
 }
 
 #if CMDGEN_EXPERIMENTS      // two merged-launch variants that were measured and lost (profiles/r03_c, r03_f); built only on request
@@ -1413,6 +1461,21 @@ template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, in
                                                a.layers[l], l, a.ablate, TrainSave{});
     else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{});
 }
+// 32-row sampler tiles on the split engine: full-K planes (one build, one GEMM per tile; see cmdgen_split.h) unless CMDGEN_EDGE_FULLK=0
+static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
+    if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.edge_mt != 32) return false;
+    if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
+                                          a.layers[l], l, a.ablate, TrainSave{});
+    else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{});
+    return true;
+}
+static bool launch_coord_fullk(const EvalLaunch& a, int l, hipStream_t s) {
+    if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.coord_mt != 32) return false;
+    if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
+                                          a.layers[l], l, TrainSave{});
+    else hipLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
+    return true;
+}
 template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
     if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, SP && H == 256>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
@@ -1524,7 +1587,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         const int stop = a.stop_block == l ? a.stop_stage : 0;        // parity aid: leave intermediates in the workspace
         REC();
         PROF_BEGIN(0);
-        if (coord_pending) launch_coord_msg<H>(a, l, s); else MT_DISPATCH(a.edge_mt, launch_msg, a, l, s);
+        if (coord_pending) launch_coord_msg<H>(a, l, s); else if (!launch_msg_fullk(a, l, s)) MT_DISPATCH(a.edge_mt, launch_msg, a, l, s);
         PROF_END();
         coord_pending = false;
         REC(); REC();
@@ -1539,7 +1602,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         if (stop == 2) return;
         if (merge && l + 1 < a.d.L) coord_pending = true;
         else if (move_proj && l + 1 < a.d.L) { PROF_BEGIN(2); launch_coord_proj<H>(a, l, s); PROF_END(); }
-        else { PROF_BEGIN(2); MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF_END(); }
+        else { PROF_BEGIN(2); if (!launch_coord_fullk(a, l, s)) MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF_END(); }
         REC();
         if (stop == 3) return;
     }
