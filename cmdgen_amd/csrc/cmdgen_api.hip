@@ -419,7 +419,7 @@ static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, 
         ALLOC(w.XL, float4, (size_t)d.L * cNm, true); ALLOC(w.ACC, float4, (size_t)d.L * cNm, true);
         ALLOC(w.h, float, cN * H, true); ALLOC(w.P, float, cN * H, true); ALLOC(w.Q, float, cN * H, true);
         ALLOC(w.Pc, float, cN * H, true); ALLOC(w.Qc, float, cN * H, true); ALLOC(w.agg, float, cN * H, true);
-        ALLOC(w.degL, int, cN, true); ALLOC(w.pocketE, int, cB, true); ALLOC(w.pocketEph, int, cB, true);
+        ALLOC(w.degL, int, cN, true); ALLOC(w.need_qc, int, cN, true); ALLOC(w.pocketE, int, cB, true); ALLOC(w.pocketEph, int, cB, true);
         ALLOC(w.pocketEns, int, cB, true); ALLOC(w.pocketEnsQ, int, cB, true);
         ALLOC(w.erow, int, ce, false); ALLOC(w.ecol, int, ce, false); ALLOC(w.ed0, float, ce, false);
         ALLOC(w.crow, int, cec, false); ALLOC(w.ccol, int, cec, false); ALLOC(w.cd0, float, cec, false);
@@ -563,7 +563,8 @@ EvalLaunch make_launch(cmdgen_handle* h) {
             on = cost64 < cost32;
             if (ev) on = atoi(ev) != 0;
         }
-        a.node64 = on; }
+        a.node64 = on;
+        if (!on) a.w.need_qc = nullptr; }         // the graph pass fills the flags only for the kernel that reads them
     {   // k_node_pair (kernels_node_pair.hip: two workgroups share a 32-row tile by output columns, half the weight bytes per CU, one
         // 32 KB exchange through L2): parity-green, 30.5 us against 30.2 us for the 16-row kernel at 64 pockets - the chip's L2 delivers
         // ~17-22 TB/s to 236 CUs together, and what the halved stream saves the exchange and the doubled tile load give back

@@ -104,6 +104,7 @@ struct Work {                   // per-layout workspace; all pointers device
     float*  Qc;                 // [N][H]
     float*  agg;                // [N][H]  zero between blocks
     int*    degL;               // [N] degree in sample-local order
+    int*    need_qc;            // [N] 1: the node sends along an edge of this evaluation's coordinate list (its Q_c row will be read); may be null
     int*    pocketE;            // [B] edges per sample
     int*    pocketEph;          // [B] edges with phar receiver per sample
     int*    pocketEns;          // [B] ... of those that are not self loops

@@ -178,6 +178,8 @@ __device__ __forceinline__ void edge_write_body(const Layout& lay, const Work& w
             for (int o = 32; o > 0; o >>= 1) selfs += __shfl_xor(selfs, o);
             coff = i < nl ? s_base[3] + soff[i] - selfs : s_base[4] + (soff[i] - eph_b) - selfs;
         }
+        bool feeds = moving;                             // does node i send along an edge of the coordinate list?  (dist2 is symmetric:
+                                                         // i is a sender of a moving receiver j exactly when j is listed here as i's neighbour)
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
             bool ok = false; float r2 = 0.f;
@@ -186,6 +188,7 @@ __device__ __forceinline__ void edge_write_body(const Layout& lay, const Work& w
                 ok = (d.cutoff2 < 0.f) || (r2 <= d.cutoff2);
             }
             const unsigned long long m = __ballot(ok);
+            if (!moving) feeds = feeds || __ballot(ok && j < nl) != 0ull;
             if (ok) {
                 const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
                 const int gj = flat_node(j, nl, pb, qb, lay.Nl);
@@ -201,6 +204,10 @@ __device__ __forceinline__ void edge_write_body(const Layout& lay, const Work& w
                 coff += __popcll(mc);
             }
         }
+        // k_node64 computes the Q_c rows of a tile only if one of its nodes is flagged: in a drifted chain the pocket has no phar point
+        // within the cutoff and a sixth of its node-kernel work is a projection nobody reads (the 16- and 32-row kernels keep computing
+        // them: at 64 pockets their launch ends with the phar tiles, which need everything - skipping made it 0.4 us slower, r03_t)
+        if (lane == 0 && w.need_qc) w.need_qc[gi] = feeds ? 1 : 0;
     }
     if (b == 0 && tid == 0) *w.nan_flag = 0;     // after every reader of the previous evaluation's flag, before k_readout sets it
     if (b == lay.B - 1 && tid == 0) {

@@ -110,9 +110,11 @@ __global__ __launch_bounds__(256, 1) void k_node64(Layout lay, Work w, Dims d, L
     const sbf16x8* const t3b[2] = {n64_tile(lw.W3.ws, 32, 2 * wave, 16), n64_tile(lw.W3.ws, 32, 2 * wave + 1, 16)};
     const sbf16x8* const t4[2] = {n64_tile(lw.W4.ws, 16, 2 * wave, 0), n64_tile(lw.W4.ws, 16, 2 * wave + 1, 0)};
     // projections: jobs 0..3 = P_c, Q_c, P', Q' (bit j of `jobs` set: the job runs); Wpq rows 0..H-1 -> P (tiles 0..7), H.. -> Q (8..15)
-    const unsigned jobs = (want_pc ? 1u : 0u) | 2u | (has_next ? 12u : 0u);
+    // Q_c only where a row of the tile sends along a coordinate edge of this evaluation (flags of the graph pass, kernels_egnn.hip)
+    const bool want_qc = want_pc || !w.need_qc || __ballot(row0 + lane < lay.N && w.need_qc[row0 + lane] != 0) != 0ull;
+    const unsigned jobs = (want_pc ? 1u : 0u) | (want_qc ? 2u : 0u) | (has_next ? 12u : 0u);
     auto job_tile = [&](int j, int n) { return n64_tile(j < 2 ? lw.Wpq_c.ws : lw_next.Wpq_e.ws, 16, (j & 1) * 8 + 2 * wave + n, 0); };
-    const int job0 = __builtin_ctz(jobs);
+    const int job0 = jobs ? __builtin_ctz(jobs) : 1;             // (no job at all: the W4 product's look-ahead reads Q_c's first blocks, unused)
     N64Ring ring;
     const int colw = 64 * wave + (lane & 31);
     const float b3c0 = lw.b3[colw], b3c1 = lw.b3[colw + 32], b4c0 = lw.b4[colw], b4c1 = lw.b4[colw + 32];
