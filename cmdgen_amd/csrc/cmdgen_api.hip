@@ -548,6 +548,9 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     a.split = h->gemm_split ? 1 : 0;
     a.n_cus = h->n_cus;
+    {   // k_node_mixed (kernels_egnn.hip): +2.4 % on the drifted 64-pocket chain, -0.8 % per evaluation at the geometry a trained model holds
+        // (its pocket tiles then need Q_c: six units on 32 rows) - opt-in: CMDGEN_NODE_MIXED=1 (profiles/r03_u_node_mixed.txt)
+        const char* ev = getenv("CMDGEN_NODE_MIXED"); a.node_mixed = (h->dims.H == 256 && h->gemm_split && !h->dims.joint && ev && atoi(ev) != 0) ? 1 : 0; }
     { const char* ev = getenv("CMDGEN_EDGE_FULLK"); a.edge_fullk = (h->dims.H == 256 && h->gemm_split && !(ev && atoi(ev) == 0)) ? 1 : 0; }
     {   // k_node64 (kernels_node64.hip: 64-row node tiles, the A operand as producer-side bf16 planes, one workgroup per CU) against
         // k_node<H, 32> (register split, two workgroups per CU).  Per launch the 64-row kernel takes ~0.89 of a co-resident pair of
@@ -561,10 +564,10 @@ EvalLaunch make_launch(cmdgen_handle* h) {
             const int full = t32 / (2 * ncu), rem = t32 - full * 2 * ncu;
             const float cost32 = 1.12f * full + (rem == 0 ? 0.f : rem <= ncu ? 0.62f : 1.12f);
             on = cost64 < cost32;
-            if (ev) on = atoi(ev) != 0;
+            if (ev) on = atoi(ev) == 32 ? 32 : atoi(ev) != 0;
         }
         a.node64 = on;
-        if (!on) a.w.need_qc = nullptr; }         // the graph pass fills the flags only for the kernel that reads them
+        if (!on && !a.node_mixed) a.w.need_qc = nullptr; }         // the graph pass fills the flags only for the kernels that read them (k_node64, k_node_mixed)
     {   // k_node_pair (kernels_node_pair.hip: two workgroups share a 32-row tile by output columns, half the weight bytes per CU, one
         // 32 KB exchange through L2): parity-green, 30.5 us against 30.2 us for the 16-row kernel at 64 pockets - the chip's L2 delivers
         // ~17-22 TB/s to 236 CUs together, and what the halved stream saves the exchange and the doubled tile load give back
@@ -1221,6 +1224,7 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "proj_split") *value = a.proj_split;
     else if (k == "node64") *value = a.node64;
     else if (k == "edge_fullk") *value = a.edge_fullk;
+    else if (k == "node_mixed") *value = (a.node_mixed && a.split16 && a.node_mt == 16 && h->lay.Np > 0 && 2 * ((h->lay.Nl + 15) / 16) + (h->lay.Np + 31) / 32 <= a.n_cus) ? 1 : 0;
     else if (k == "node_pair") *value = (a.node_pair && 2 * ((h->lay.N + 31) / 32) <= a.n_cus) ? 1 : 0;
     else if (k == "train_edges") *value = h->train_E;
     else if (k == "train_coord_edges") *value = h->train_Ec;

@@ -208,6 +208,8 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int pair_cap = 0;           //    pairs the exchange buffers hold
     int proj_split = 0;         // 1: the next block's P | Q projections run as column-sliced tiles in the coordinate kernel's launch (k_coord_proj)
     int proj_mt = 32;           //    rows per projection tile there (32 or 64)
+    int node_mixed = 0;         // 1: small conditional batches run k_node as k_node_mixed (two workgroups per phar tile, 32-row plane tiles for the pocket)
+    mutable int coord_zero_rows = 0;  // set behind a k_node_mixed launch: the coordinate kernel zeroes the first rows of agg
     mutable int node_skip_next = 0;   // set around the k_node launch whose next-block projections moved
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     hipStream_t side = nullptr; // when set: k_edge_write runs there, concurrently with k_embed (fork / join by events)

@@ -15,6 +15,7 @@
 // with a 4-float row pad (conflict-free ds_read_b128); the B operand (weights) streams from
 // L2 in MFMA fragment order (cmdgen_dev.h).
 #include "cmdgen_dev.h"
+#include "cmdgen_node_planes.h"
 #include <hip/hip_ext.h>
 
 #define LDA(H) ((H) + 4)
@@ -877,20 +878,21 @@ __global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_msg(Layout lay, Work w, 
 // then, while the new h tile is still in LDS, the projections every later kernel of this
 // evaluation gathers: P_c|Q_c for this block's coord MLP and P|Q for block l+1's edge MLP.
 // ------------------------------------------------------------------------------------
-template <int H, int MT, bool SAVE, bool SP>
-__global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
-                                               int layer, int has_next, TrainSave sv) {
+// node_tile_body: the tile of rows row0 .. min(row0 + MT, row_end) - 1; bufs: (MT <= 32 ? 2 : 1) * MT * LDA(H) floats of LDS.
+// ROLE 0: everything (k_node).  ROLE 1 / 2 (k_node_mixed, phar tiles): TWO workgroups per tile both form h_new; 1 stores it and makes P_c | Q_c,
+// 2 makes P | Q of the next block; neither zeroes the tile's agg rows (both read them: the coordinate kernel that follows does).
+template <int H, int MT, bool SAVE, bool SP, int ROLE = 0>
+__device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw, const LayerW& lw_next,
+                                               const int layer, const int has_next, const TrainSave& sv, const int row0, const int row_end) {
     // Tiles of <= 32 rows keep two LDS images: buf0 = h (kept for the residual), buf1 = agg -> T -> h_new,
     // so h and agg are fetched together and the residual needs no second global read.  64-row tiles
     // (66 KB each) use one image so that two workgroups still fit a CU.
     constexpr bool TWO = MT <= 32;
-    __shared__ __attribute__((aligned(16))) float bufs[(TWO ? 2 : 1) * MT * LDA(H)];
     float* buf0 = bufs;
     float* buf1 = TWO ? bufs + MT * LDA(H) : bufs;
     constexpr int LPR = H / 4;
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int row0 = blockIdx.x * MT;
-    const int nvalid = min(MT, lay.N - row0);
+    const int nvalid = min(MT, row_end - row0);
     const int c4 = tid % LPR, rsub = tid / LPR;
     // the chain of GEMMs of this tile; each one's last iteration fetches the next one's first fragments
     const bool want_pc = row0 < lay.Nm;              // the tile holds receivers that move
@@ -898,8 +900,8 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
     typedef typename G::Frag Frag;
     const Frag f3a = G::frag(lw.W3, 2 * H / 8, 0, wave), f3b = G::frag(lw.W3, 2 * H / 8, H / 8, wave);
     const Frag f4 = G::frag(lw.W4, H / 8, 0, wave);
-    const Frag fc = G::frag(lw.Wpq_c, H / 8, 0, want_pc ? wave : H / 64 + wave);
     const Frag fn = G::frag(lw_next.Wpq_e, H / 8, 0, wave);
+    const Frag fc = ROLE == 2 ? fn : G::frag(lw.Wpq_c, H / 8, 0, want_pc ? wave : H / 64 + wave);      // the GEMM behind W4
     typename G::Carry carry;
     G::prefetch(f3a, carry);
     // every epilogue's bias, fetched now: by the time an epilogue runs its values have long arrived (a load issued where
@@ -908,7 +910,7 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
                      b1nv = col_load<MT>(lw_next.b1, wave);
     if (blockIdx.x == 0 && tid == 0) w.sync[0] = 0;  // the count of finished coordinate-role workgroups of k_coord_msg (the launches before and after this one)
     // materialise the phar coordinates entering this block (see node_pos)
-    if (layer >= 1 && tid < MT) {
+    if (ROLE != 2 && layer >= 1 && tid < MT) {
         const int n = row0 + tid;
         if (tid < nvalid && n < lay.Nm) w.XL[(size_t)layer * lay.Nm + n] = node_pos(lay, w, d, n, layer, true);
     }
@@ -929,7 +931,7 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
             if (r < nvalid) {
                 float4* g = reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H) + c4;
                 v = *g;
-                *g = make_float4(0.f, 0.f, 0.f, 0.f);                                     // agg is zero between blocks
+                if (ROLE == 0) *g = make_float4(0.f, 0.f, 0.f, 0.f);                      // agg is zero between blocks
                 v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
                 if (SAVE) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * H)[c4] = v;
             }
@@ -960,7 +962,7 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
 #pragma unroll
         for (int pass = 0; pass < MT / 4; ++pass) {
             const int r = pass * 4 + rsub;
-            if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
+            if (ROLE == 0 && r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
             float4 v = av[pass];
             v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
             if (SAVE && r < nvalid) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * H)[c4] = v;
@@ -1003,7 +1005,7 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
             float* hp = w.h + (size_t)(row0 + row) * H + col;
             const float hold = TWO ? buf0[row * LDA(H) + col] : *hp;
             hn = hold + (v + b4v.v[n]);                                                 // residual (egnn_new.py:57)
-            if (MT != 32 && !SAVE) *hp = hn;    // 32-row tiles and the training forward store h from the LDS image below, as whole rows
+            if (MT != 32 && !SAVE && ROLE != 2) *hp = hn;    // 32-row tiles and the training forward store h from the LDS image below, as whole rows
         }
         buf1[row * LDA(H) + col] = hn;
     });
@@ -1022,9 +1024,9 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
     }
     NSTAMP(4);
     // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
-    tile_project_pq<H, MT, SP>(buf1, lw.Wpq_c, b6v, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
+    if (ROLE != 2) tile_project_pq<H, MT, SP>(buf1, lw.Wpq_c, b6v, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
     NSTAMP(5);
-    if (has_next) tile_project_pq<H, MT, SP>(buf1, lw_next.Wpq_e, b1nv, w.P, w.Q, row0, nvalid, true, carry, fn);
+    if (has_next && ROLE != 1) tile_project_pq<H, MT, SP>(buf1, lw_next.Wpq_e, b1nv, w.P, w.Q, row0, nvalid, true, carry, fn);
     NSTAMP(6);
 #if CMDGEN_STAMPS == 2
     if ((tid & 63) == 0) {
@@ -1034,6 +1036,35 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
     }
 #endif
 #undef NSTAMP
+}
+template <int H, int MT, bool SAVE, bool SP>
+__global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
+                                               int layer, int has_next, TrainSave sv) {
+    __shared__ __attribute__((aligned(16))) float bufs[(MT <= 32 ? 2 : 1) * MT * LDA(H)];
+    node_tile_body<H, MT, SAVE, SP, 0>(bufs, lay, w, d, lw, lw_next, layer, has_next, sv, (int)blockIdx.x * MT, lay.N);
+}
+
+// ------------------------------------------------------------------------------------
+// k_node_mixed (round 3, sampler, H = 256, split engine, conditional model, small batches): k_node's launch at 64 pockets lasts as long as
+// its slowest tiles - the 60 phar tiles, which stream all seven weight units (W3 twice, W4, P_c, Q_c, P, Q of the next block) at ~4.3 us per
+// unit, while a CU's fill rate and not the matrix pipe sets that price.  Here a phar tile is TWO workgroups that both form h_new (three units)
+// and then split the projections (P_c | Q_c; P | Q of the next block): five units each; the CUs for the 60 extra workgroups come from the
+// pocket rows, which run as 32-row plane tiles (cmdgen_node_planes.h: 88 workgroups instead of 176, five or six units each).  Every
+// workgroup of the launch is resident at once (the launcher checks grid <= CUs).  The phar tiles' agg rows are zeroed by the coordinate
+// kernel that follows (both workgroups of a tile read them).  profiles/r03_u_node_mixed.txt.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void k_node_mixed(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next, int n_phar_wgs) {
+    constexpr int LDS_BYTES = (3 * 32 * NPLD + 64) * 2 > 2 * 16 * LDA(256) * 4 ? (3 * 32 * NPLD + 64) * 2 : 2 * 16 * LDA(256) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    const int bid = (int)blockIdx.x;
+    if (bid < n_phar_wgs) {
+        float* bufs = reinterpret_cast<float*>(smem);
+        if (!has_next) node_tile_body<256, 16, false, true, 1>(bufs, lay, w, d, lw, lw_next, layer, 0, TrainSave{}, bid * 16, lay.Nl);
+        else if (bid & 1) node_tile_body<256, 16, false, true, 2>(bufs, lay, w, d, lw, lw_next, layer, 1, TrainSave{}, (bid >> 1) * 16, lay.Nl);
+        else node_tile_body<256, 16, false, true, 1>(bufs, lay, w, d, lw, lw_next, layer, 1, TrainSave{}, (bid >> 1) * 16, lay.Nl);
+    } else {
+        node_planes_tile<32>(reinterpret_cast<unsigned short*>(smem), lay, w, d, lw, lw_next, layer, has_next, lay.Nl + (bid - n_phar_wgs) * 32, lay.N);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1045,7 +1076,12 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
 // ------------------------------------------------------------------------------------
 template <int H, int MT, bool SAVE, bool SP, bool FK = false>
 __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
-                                                const int layer, const TrainSave& sv, const int vb, const int nb) {
+                                                const int layer, const TrainSave& sv, const int vb, const int nb, const int zero_agg_rows = 0) {
+    // behind k_node_mixed: the phar tiles' agg rows are still as the node kernel read them (two workgroups per tile did): zero them for the next block
+    if (zero_agg_rows > 0) {
+        float4* a4 = reinterpret_cast<float4*>(w.agg);
+        for (int i = vb * (int)blockDim.x + (int)threadIdx.x; i < zero_agg_rows * (H / 4); i += nb * (int)blockDim.x) a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float* buf = L.buf; int* s_row = L.s_row; int* s_col = L.s_col;
     float* s_r = L.s_r; float* s_d0 = L.s_d0; float* s_w5 = L.s_vec; float* s_wrd = L.s_wrd;
     float (*s_cd)[3] = L.s_cd; float (*s_tr)[3] = L.s_tr;
@@ -1153,9 +1189,9 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
     }
 }
 template <int H, int MT, bool SAVE, bool SP, bool FK = false>
-__global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer, TrainSave sv) {
+__global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer, TrainSave sv, int zero_agg_rows) {
     __shared__ __attribute__((aligned(16))) EdgeLds<H, MT, FK> L;
-    edge_coord_body<H, MT, SAVE, SP, FK>(L, lay, w, d, lw, layer, sv, (int)blockIdx.x, (int)gridDim.x);
+    edge_coord_body<H, MT, SAVE, SP, FK>(L, lay, w, d, lw, layer, sv, (int)blockIdx.x, (int)gridDim.x, zero_agg_rows);
 }
 
 #if CMDGEN_EXPERIMENTS      // two merged-launch variants that were measured and lost (profiles/r03_c, r03_f); built only on request
@@ -1461,6 +1497,19 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
     else hipLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
                             a.layers[has_next ? l + 1 : l], l, has_next, TrainSave{});
 }
+// k_node_mixed where it applies (see the kernel): conditional sampler, H = 256, split engine with 16-row node tiles, the whole grid resident at once
+static bool launch_node_mixed(const EvalLaunch& a, int l, hipStream_t s) {
+    if (!a.node_mixed || a.save || !a.split || !a.split16 || a.d.H != 256 || a.d.joint || a.node_mt != 16 || a.lay.Np < 1 || a.lay.Nm != a.lay.Nl) return false;
+    if (!a.layers[l].W3.ws16 || !a.layers[l].W3.ws) return false;
+    const int has_next = l + 1 < a.d.L;
+    const int nph = (a.lay.Nl + 15) / 16, npk = (a.lay.Np + 31) / 32;
+    const int n_phar_wgs = has_next ? 2 * nph : nph;
+    if (n_phar_wgs + npk > a.n_cus) return false;
+    if (a.pe_start) hipExtLaunchKernelGGL(k_node_mixed, dim3(n_phar_wgs + npk), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l],
+                                          a.layers[has_next ? l + 1 : l], l, has_next, n_phar_wgs);
+    else hipLaunchKernelGGL(k_node_mixed, dim3(n_phar_wgs + npk), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next, n_phar_wgs);
+    return true;
+}
 template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
     // training forward: the split engine only where the step re-packs split weights (H = 256: edge_mlp.2 / coord_mlp.2)
     if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save);
@@ -1479,15 +1528,15 @@ static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
 static bool launch_coord_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.coord_mt != 32) return false;
     if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                          a.layers[l], l, TrainSave{});
-    else hipLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
+                                          a.layers[l], l, TrainSave{}, a.coord_zero_rows);
+    else hipLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{}, a.coord_zero_rows);
     return true;
 }
 template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, SP && H == 256>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save);
+    if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, SP && H == 256>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save, 0);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                               a.layers[l], l, TrainSave{});
-    else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
+                                               a.layers[l], l, TrainSave{}, a.coord_zero_rows);
+    else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{}, a.coord_zero_rows);
 }
 #if CMDGEN_EXPERIMENTS
 // the merged launch exists for the tile pairs cmdgen_set_layout picks on the split engine (everything else: two launches)
@@ -1601,7 +1650,9 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         if (stop == 1) return;
         a.node_skip_next = move_proj ? 1 : 0;
         PROF_BEGIN(1);
-        if (!(a.node64 && !move_proj && cmdgen_launch_node64(a, l, s)) && !(a.node_pair && !move_proj && cmdgen_launch_node_pair(a, l, s)))
+        a.coord_zero_rows = 0;
+        if (!merge && !move_proj && stop == 0 && launch_node_mixed(a, l, s)) a.coord_zero_rows = a.lay.Nl;      // (the coordinate launch below zeroes the phar rows of agg)
+        else if (!(a.node64 && !move_proj && cmdgen_launch_node64(a, l, s)) && !(a.node_pair && !move_proj && cmdgen_launch_node_pair(a, l, s)))
             MT_DISPATCH(a.node_mt, launch_node, a, l, s);
         PROF_END();
         a.node_skip_next = 0;

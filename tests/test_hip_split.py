@@ -305,3 +305,42 @@ def test_node64_is_chosen_by_tile_count_and_agrees_with_the_32_row_kernel(monkey
         err = rms(out[1][:, :3], out[0][:, :3])
         print(f'256 pockets, 20 steps: coordinate RMS 64-row vs 32-row node kernel {err:.2e} A (max|x| {np.abs(out[0][:, :3]).max():.1f})')
         assert err <= 2e-5 and np.array_equal(out[1][:, 3:], out[0][:, 3:])
+
+
+# ----------------------------------------------------------------------------- k_node_mixed (round 3, opt-in): two workgroups per phar tile + 32-row plane tiles
+@pytest.mark.parametrize('name', [n for n in cases_of(G2) if '_h256_' in n][:4])
+def test_node_mixed_kernel_matches_reference(name, monkeypatch):
+    """k_node_mixed (CMDGEN_NODE_MIXED=1: the phar tiles' projections split over two workgroups, pocket rows as 32-row plane tiles, the phar
+    rows of agg zeroed by the coordinate kernel) against the reference's output, twice in a row (agg must have been left zero)."""
+    monkeypatch.setenv('CMDGEN_NODE_MIXED', '1')
+    cfg, sd, inp = dynamics_case(G2, name)
+    want = G2[name + '/eps_phar']
+    h = new_handle(cfg, sd)
+    h.set_layout(G2[name + '/num_nodes_phar'], G2[name + '/pocket_size'])
+    assert h.query('node_mixed') == 1
+    for _ in range(2):
+        eps, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']))
+    torch.cuda.synchronize()
+    err = float(np.abs(eps.cpu().numpy() - want).max())
+    print(f'{name}: max|d eps| k_node_mixed {err:.2e}')
+    assert err <= EVAL_TOL * max(1.0, float(np.abs(want).max()))
+    h.close()
+
+
+def test_bounded_chain_with_node_mixed(monkeypatch):
+    """The K = T = 500 reference chain of G13 through k_node_mixed, graph-replayed: 1e-4 A absolute, types exact."""
+    monkeypatch.setenv('CMDGEN_NODE_MIXED', '1')
+    name = 'ca_h256_KT_np05'
+    cfg, sd, pb, K = bounded_case(G13, name)
+    h = new_handle(cfg, sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    assert h.query('node_mixed') == 1
+    h.set_step_table(K, host_step_table(cfg, K))
+    xh_phar, _, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=dev(G13[name + '/noise']), use_graph=True)
+    st = h.chain_status()
+    want = G13[name + '/xh_phar']
+    err = rms(xh_phar[:, :3].cpu().numpy(), want[:, :3])
+    print(f'{name} k_node_mixed: coordinate RMS vs reference {err:.3e} A')
+    assert err <= 1e-4 and np.array_equal(xh_phar[:, 3:].cpu().numpy(), want[:, 3:])
+    assert st['max_rel_com_error'] < 1e-2 and st['nan_resets'] == 0
+    h.close()
