@@ -183,9 +183,12 @@ def kernel_table(h, prof, pc, H, L, nl_tot):
     """Per-kernel roofline entries from one profiled eager chain: prof = {kernel: (total ms, launches)} (every launch carried its own
     HIP start / stop events), pc = device counters of that chain.  -> (per_kernel, dominant kernel, launch config, units per launch)."""
     ev = max(pc['evaluations'], 1)
-    units = {'edge_msg': pc['edges'] / ev, 'node': pc['nodes'] / ev, 'edge_coord': pc['edges_phar'] / ev}
+    # units one launch EXECUTES: the last block of a conditional evaluation skips tiles whose new h nobody reads (edges_skipped /
+    # node_rows_skipped are summed over launches; every evaluation launches each of the two kernels L times)
+    units = {'edge_msg': pc['edges'] / ev - pc.get('edges_skipped', 0) / (ev * L), 'node': pc['nodes'] / ev - pc.get('node_rows_skipped', 0) / (ev * L),
+             'edge_coord': pc['edges_phar'] / ev}
     flop_launch = {'edge_msg': 2.0 * (H * H + H) * units['edge_msg'],
-                   'node': node_flop_per_launch(H, L, pc['nodes'] / ev, nl_tot, False),
+                   'node': node_flop_per_launch(H, L, units['node'], nl_tot, False),
                    'edge_coord': coord_flop_per_launch(H, L, units['edge_coord'], pc['nodes'] / ev, False)}
     launch_cfg = {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid', 'gemm_split', 'node16_split', 'node64')}
     # node64: the 64-row planes node kernel took the launches (kernels_node64.hip; chosen per layout by tile count)

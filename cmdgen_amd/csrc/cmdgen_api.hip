@@ -567,7 +567,8 @@ EvalLaunch make_launch(cmdgen_handle* h) {
             if (ev) on = atoi(ev) == 32 ? 32 : atoi(ev) != 0;
         }
         a.node64 = on;
-        if (!on && !a.node_mixed) a.w.need_qc = nullptr; }         // the graph pass fills the flags only for the kernels that read them (k_node64, k_node_mixed)
+        { const char* dv = getenv("CMDGEN_DEAD_SKIP"); a.dead_skip = (!h->dims.joint && !(dv && atoi(dv) == 0)) ? 1 : 0; }
+        if (!on && !a.node_mixed && !a.dead_skip) a.w.need_qc = nullptr; }         // the graph pass fills the flags only for the kernels that read them (k_node64, k_node_mixed)
     {   // k_node_pair (kernels_node_pair.hip: two workgroups share a 32-row tile by output columns, half the weight bytes per CU, one
         // 32 KB exchange through L2): parity-green, 30.5 us against 30.2 us for the 16-row kernel at 64 pockets - the chip's L2 delivers
         // ~17-22 TB/s to 236 CUs together, and what the halved stream saves the exchange and the doubled tile load give back
@@ -1157,6 +1158,7 @@ extern "C" int cmdgen_get_counters(cmdgen_handle* h, cmdgen_counters* out, cmdge
     HIPCHK(h, hipMemcpy(cnt, h->work.counters, sizeof cnt, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
     out->evaluations = cnt[0]; out->edges = cnt[1]; out->edges_phar = cnt[2]; out->nodes = cnt[3]; out->nan_resets = cnt[4];
+    out->edges_skipped = cnt[6]; out->node_rows_skipped = cnt[7];
     return CMDGEN_OK;
 }
 
@@ -1224,6 +1226,7 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "proj_split") *value = a.proj_split;
     else if (k == "node64") *value = a.node64;
     else if (k == "edge_fullk") *value = a.edge_fullk;
+    else if (k == "dead_skip") *value = a.dead_skip;
     else if (k == "node_mixed") *value = (a.node_mixed && a.split16 && a.node_mt == 16 && h->lay.Np > 0 && 2 * ((h->lay.Nl + 15) / 16) + (h->lay.Np + 31) / 32 <= a.n_cus) ? 1 : 0;
     else if (k == "node_pair") *value = (a.node_pair && 2 * ((h->lay.N + 31) / 32) <= a.n_cus) ? 1 : 0;
     else if (k == "train_edges") *value = h->train_E;

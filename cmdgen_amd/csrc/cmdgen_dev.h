@@ -209,6 +209,8 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int proj_split = 0;         // 1: the next block's P | Q projections run as column-sliced tiles in the coordinate kernel's launch (k_coord_proj)
     int proj_mt = 32;           //    rows per projection tile there (32 or 64)
     int node_mixed = 0;         // 1: small conditional batches run k_node as k_node_mixed (two workgroups per phar tile, 32-row plane tiles for the pocket)
+    int dead_skip = 0;          // 1: the last block of a conditional evaluation skips tiles whose new h nobody reads (CMDGEN_DEAD_SKIP=0 opts out)
+    mutable int live_only = 0;  // set around the last block's launches when that applies
     mutable int coord_zero_rows = 0;  // set behind a k_node_mixed launch: the coordinate kernel zeroes the first rows of agg
     mutable int node_skip_next = 0;   // set around the k_node launch whose next-block projections moved
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)

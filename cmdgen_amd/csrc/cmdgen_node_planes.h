@@ -84,9 +84,10 @@ __device__ __forceinline__ float4 n64_node_pos(const Layout& lay, const Work& w,
 // One NROWS-row tile (64, or 32: one accumulator row per wave) of rows row0 .. min(row0 + NROWS, row_end) - 1.
 template <int NROWS>
 __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
-                                                 const LayerW& lw_next, const int layer, const int has_next, const int row0, const int row_end) {
+                                                 const LayerW& lw_next, const int layer, const int has_next_arg, const int row0, const int row_end) {
     constexpr int H = 256, LPR = H / 4, NMT = NROWS / 32, NPE = NROWS * NPLD;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int has_next = has_next_arg & 1, live_only = has_next_arg >> 1;      // bit 1: the last block of a conditional evaluation (see below)
 #if CMDGEN_STAMPS == 5      // diagnostic build: per-phase cycle stamps into w.dbg ([wave][phase] sums, [32 + wave] lifetime, [40] waves)
     unsigned long long nst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nst_t = __builtin_amdgcn_s_memtime();
     const unsigned long long nst_begin = nst_t;
@@ -97,6 +98,20 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
     const int nvalid = min(NROWS, row_end - row0);
     const bool want_pc = row0 < lay.Nm;
     const int c4 = tid % LPR, rsub = tid / LPR;
+    if (live_only && !want_pc && w.need_qc) {
+        // the new h of a pocket node is still read only if the node sends along a coordinate edge: a tile without one only restores
+        // "agg is zero between blocks" (kernels_egnn.hip, node_tile_body)
+        const int r = lane & (NROWS - 1);
+        if (__ballot(r < nvalid && w.need_qc[row0 + r] != 0) == 0ull) {
+#pragma unroll
+            for (int pass = 0; pass < NROWS / 4; ++pass) {
+                const int rr = pass * 4 + rsub;
+                if (rr < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + rr) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (tid == 0) atomicAdd(&w.counters[7], (unsigned long long)nvalid);
+            return;
+        }
+    }
     // the chain's weight tiles: this wave's columns 64 wave .. 64 wave + 63 = tiles 2 wave, 2 wave + 1 of every [H out] matrix
     const sbf16x8* const t3a[2] = {n64_tile(lw.W3.ws, 32, 2 * wave, 0), n64_tile(lw.W3.ws, 32, 2 * wave + 1, 0)};
     const sbf16x8* const t3b[2] = {n64_tile(lw.W3.ws, 32, 2 * wave, 16), n64_tile(lw.W3.ws, 32, 2 * wave + 1, 16)};

@@ -685,6 +685,7 @@ template <int H, int MT, bool FK = false> struct EdgeLds {
     float s_cd[MT][3], s_tr[MT][3];         // coordinate body only
     float s_vec[H];                         // att_mlp / coord_mlp.4 weight: read by every tile's row dot (LDS broadcast, not 16 L1 round trips)
     float s_wrd[FK ? 4 : 2 * H];            // radial / d0 weight columns (half-K plane variant)
+    int s_live[2];                          // last block of a conditional evaluation: does the tile hold a receiver whose h is still read?
 };
 
 // Wait (one lane spins, bounded) until every coordinate-role workgroup of this launch has added its sums: `done` counts
@@ -758,6 +759,13 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
                 const bool touch = row >= 0 && (row < lay.Nm || col < lay.Nm);
                 if (__ballot(touch) != 0ull) { wait_coord_done(w, done, done_target); coord_seen = true; }
             }
+            if (ablate & 64) {
+                // Last block of a conditional evaluation whose pocket output nobody reads: h_new of a node is still needed only if it moves
+                // or sends along a coordinate edge (the need_qc flags of the graph pass) - a tile without such a receiver is dead work
+                const bool live = row >= 0 && w.need_qc[row] != 0;
+                const unsigned long long any = __ballot(live);
+                if (tid == 0) L.s_live[k & 1] = any != 0ull;
+            }
             float r = 0.f;
             if (tid < ne) {
                 // block 0 sees the input positions: its radial IS the d0 the graph pass stored (same dist2, same operands, same
@@ -768,6 +776,10 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
         }
         lds_barrier();
         STAMP(0);
+        if ((ablate & 64) && !L.s_live[k & 1]) {                   // (s_live is double-buffered: no thread is two tiles behind)
+            if (tid == 0) atomicAdd(&w.counters[6], (unsigned long long)ne);
+            continue;
+        }
         TileAcc<MT> acc;
         acc_zero<MT>(acc);
         if constexpr (FK) {
@@ -883,7 +895,8 @@ __global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_msg(Layout lay, Work w, 
 // 2 makes P | Q of the next block; neither zeroes the tile's agg rows (both read them: the coordinate kernel that follows does).
 template <int H, int MT, bool SAVE, bool SP, int ROLE = 0>
 __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw, const LayerW& lw_next,
-                                               const int layer, const int has_next, const TrainSave& sv, const int row0, const int row_end) {
+                                               const int layer, const int has_next_arg, const TrainSave& sv, const int row0, const int row_end) {
+    const int has_next = has_next_arg & 1, live_only = has_next_arg >> 1;      // bit 1: skip tiles none of whose rows is still read (see below)
     // Tiles of <= 32 rows keep two LDS images: buf0 = h (kept for the residual), buf1 = agg -> T -> h_new,
     // so h and agg are fetched together and the residual needs no second global read.  64-row tiles
     // (66 KB each) use one image so that two workgroups still fit a CU.
@@ -896,6 +909,20 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
     const int c4 = tid % LPR, rsub = tid / LPR;
     // the chain of GEMMs of this tile; each one's last iteration fetches the next one's first fragments
     const bool want_pc = row0 < lay.Nm;              // the tile holds receivers that move
+    if (live_only && !want_pc && !SAVE) {
+        // Last block of a conditional evaluation whose pocket output nobody reads: the new h of a pocket node is needed only if the node
+        // sends along a coordinate edge (need_qc).  A tile without one only restores "agg is zero between blocks".
+        const int r = tid & (MT - 1);
+        if (__ballot(r < nvalid && w.need_qc[row0 + r] != 0) == 0ull) {
+#pragma unroll
+            for (int pass = 0; pass < MT / 4; ++pass) {
+                const int rr = pass * 4 + rsub;
+                if (rr < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + rr) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (tid == 0) atomicAdd(&w.counters[7], (unsigned long long)nvalid);
+            return;
+        }
+    }
     typedef Eng<MT, SP> G;
     typedef typename G::Frag Frag;
     const Frag f3a = G::frag(lw.W3, 2 * H / 8, 0, wave), f3b = G::frag(lw.W3, 2 * H / 8, H / 8, wave);
@@ -1493,9 +1520,9 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
     if (a.save) hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
                                    a.layers[has_next ? l + 1 : l], l, has_next, *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                               a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next, TrainSave{});
+                                               a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next | (a.live_only << 1), TrainSave{});
     else hipLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
-                            a.layers[has_next ? l + 1 : l], l, has_next, TrainSave{});
+                            a.layers[has_next ? l + 1 : l], l, has_next | (a.live_only << 1), TrainSave{});
 }
 // k_node_mixed where it applies (see the kernel): conditional sampler, H = 256, split engine with 16-row node tiles, the whole grid resident at once
 static bool launch_node_mixed(const EvalLaunch& a, int l, hipStream_t s) {
@@ -1514,15 +1541,15 @@ template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, in
     // training forward: the split engine only where the step re-packs split weights (H = 256: edge_mlp.2 / coord_mlp.2)
     if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                               a.layers[l], l, a.ablate, TrainSave{});
-    else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{});
+                                               a.layers[l], l, a.ablate | (a.live_only << 6), TrainSave{});
+    else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate | (a.live_only << 6), TrainSave{});
 }
 // 32-row sampler tiles on the split engine: full-K planes (one build, one GEMM per tile; see cmdgen_split.h) unless CMDGEN_EDGE_FULLK=0
 static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.edge_mt != 32) return false;
     if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                          a.layers[l], l, a.ablate, TrainSave{});
-    else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{});
+                                          a.layers[l], l, a.ablate | (a.live_only << 6), TrainSave{});
+    else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate | (a.live_only << 6), TrainSave{});
     return true;
 }
 static bool launch_coord_fullk(const EvalLaunch& a, int l, hipStream_t s) {
@@ -1639,7 +1666,10 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     // the next block's P | Q projections out of k_node into the coordinate kernel's launch (k_coord_proj)
     const bool move_proj = !merge && a.proj_split && !a.save && !ev && a.stop_block < 0 && launch_coord_proj<H>(a, -1, s);
     bool coord_pending = false;              // block l-1's coordinate update has not been launched yet
+    // dead work of the LAST block (conditional sampler, pocket output not asked for): see edge_msg_body / node_tile_body
+    const bool live_last = a.dead_skip && !eps_pocket && !a.save && !a.d.joint && a.stop_block < 0 && a.w.need_qc != nullptr && !merge && !move_proj;
     for (int l = 0; l < a.d.L; ++l) {
+        a.live_only = (live_last && l == a.d.L - 1) ? 1 : 0;
         const int stop = a.stop_block == l ? a.stop_stage : 0;        // parity aid: leave intermediates in the workspace
         REC();
         PROF_BEGIN(0);

@@ -29,7 +29,8 @@ class Config(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [('evaluations', C.c_uint64), ('edges', C.c_uint64), ('edges_phar', C.c_uint64),
-                ('nodes', C.c_uint64), ('nan_resets', C.c_uint64), ('reserved', C.c_uint64 * 3)]
+                ('nodes', C.c_uint64), ('nan_resets', C.c_uint64), ('edges_skipped', C.c_uint64), ('node_rows_skipped', C.c_uint64),
+                ('reserved', C.c_uint64 * 1)]
 
 
 class KernelTimes(C.Structure):
@@ -519,7 +520,7 @@ class Handle:
     def counters(self) -> Dict[str, int]:
         c = Counters()
         self._check(self.lib.cmdgen_get_counters(self.h, C.byref(c), self._stream()), 'cmdgen_get_counters')
-        return {k: int(getattr(c, k)) for k in ('evaluations', 'edges', 'edges_phar', 'nodes', 'nan_resets')}
+        return {k: int(getattr(c, k)) for k in ('evaluations', 'edges', 'edges_phar', 'nodes', 'nan_resets', 'edges_skipped', 'node_rows_skipped')}
 
     def reset_counters(self):
         self._check(self.lib.cmdgen_reset_counters(self.h, self._stream()), 'cmdgen_reset_counters')

@@ -81,7 +81,10 @@ typedef struct cmdgen_counters {
                                       the edge is not a self loop (a self loop's coord_diff is exactly 0) */
     uint64_t nodes;                /* sum over evaluations of nodes */
     uint64_t nan_resets;           /* evaluations whose velocity was reset (dynamics.py:129-131) */
-    uint64_t reserved[3];
+    uint64_t edges_skipped;        /* edges of k_edge_msg tiles that were skipped as dead work (last block of a conditional evaluation: no receiver
+                                      of the tile is still read), summed over launches: the executed edge work is edges * n_layers - this */
+    uint64_t node_rows_skipped;    /* rows of k_node tiles skipped for the same reason, summed over launches */
+    uint64_t reserved[1];
 } cmdgen_counters;
 
 /* Per-kernel timing of one profiled evaluation (hipEvent pairs on the launch stream). */

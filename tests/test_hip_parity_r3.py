@@ -12,9 +12,10 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import NoiseTape, load_golden, pocket_dict, rms
+from helpers import NoiseTape, load_golden, pocket_dict, rms, cases_of, dynamics_case
 from cmdgen_amd import hip_backend
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
+from test_hip_parity_r2 import EVAL_TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -225,3 +226,47 @@ def test_fullsize_chain_matches_reference_g14(name, engine):
               f'max {mx:.2e}; types identical in {n_types}/{B}; max|x| {float(G14[name + "/max_abs_x"]):.1f} A, '
               f'{float(G14[name + "/edges_per_pocket_eval"]):.0f} edges per pocket-evaluation')
     h.close()
+
+
+# ----------------------------------------------------------------------------- dead work of the last block (round 3)
+G2 = load_golden('g2_dynamics.npz')
+def test_last_block_dead_work_skip_changes_nothing(monkeypatch):
+    """The last EquivariantBlock of a conditional evaluation whose pocket output nobody asks for: the new h of a pocket node is read only if
+    the node sends along a coordinate edge, so message tiles without such a receiver and node tiles without such a row are skipped
+    (cmdgen_counters.edges_skipped / node_rows_skipped).  (i) every H = 256 evaluation fixture, pocket output not requested, against the
+    reference; (ii) a 300-step chain of 24 pockets with the skip on and off: the same result (to the run-to-run noise of the float atomics), work skipped only when on."""
+    for name in [n for n in cases_of(G2) if '_h256_' in n]:
+        cfg, sd, inp = dynamics_case(G2, name)
+        h = new_handle(cfg, sd)
+        h.set_layout(G2[name + '/num_nodes_phar'], G2[name + '/pocket_size'])
+        assert h.query('dead_skip') == 1
+        eps, none = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']), want_pocket=False)
+        eps2, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']), want_pocket=False)     # agg left zero
+        want = G2[name + '/eps_phar']
+        assert none is None
+        for e in (eps, eps2):
+            assert float(np.abs(e.cpu().numpy() - want).max()) <= EVAL_TOL * max(1.0, float(np.abs(want).max())), name
+        h.close()
+    cfg = ModelConfig(residue_nf=20, timesteps=1000)
+    sd = make_state_dict(cfg, seed=0)
+    pb = make_pockets(24, 'CA')
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('CMDGEN_DEAD_SKIP', flag)
+        h = new_handle(cfg, sd)
+        h.set_layout(pb.num_nodes_phar, pb.size)
+        assert h.query('dead_skip') == int(flag)
+        h.reset_counters()
+        xh, xp, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), 300, seed=11)
+        c = h.counters()
+        out[flag] = (xh.cpu().numpy(), xp.cpu().numpy(), c)
+        assert h.chain_status()['nan_resets'] == 0
+        h.close()
+    on, off = out['1'][2], out['0'][2]
+    print(f'24 pockets, 300 steps: {on["edges_skipped"] / on["evaluations"]:.0f} of {on["edges"] / on["evaluations"]:.0f} edges and '
+          f'{on["node_rows_skipped"] / on["evaluations"]:.0f} of {on["nodes"] / on["evaluations"]:.0f} node rows skipped per evaluation in the last block')
+    assert off['edges_skipped'] == 0 and off['node_rows_skipped'] == 0 and on['edges_skipped'] > 0 and on['node_rows_skipped'] > 0
+    # (float atomics at tile boundaries make two runs of the SAME code differ in the last bits; the skip adds nothing to that)
+    sc = max(1.0, float(np.abs(out['0'][0][:, :3]).max()))
+    assert np.abs(out['1'][0][:, :3] - out['0'][0][:, :3]).max() <= 2e-5 * sc and np.array_equal(out['1'][0][:, 3:], out['0'][0][:, 3:])
+    assert np.abs(out['1'][1][:, :3] - out['0'][1][:, :3]).max() <= 2e-5 * sc
