@@ -461,6 +461,9 @@ def main(argv=None):
         kname = KERNEL_NAMES
         achieved = per_kernel[dom]['tflops']
         avg_ms, launches, flop_per_launch = per_kernel[dom]['avg_launch_ms'], per_kernel[dom]['launches'], per_kernel[dom]['flop_per_launch']
+        p_ev = max(pc['evaluations'], 1)
+        reference_flop_per_launch = {'edge_msg': 2.0 * (H * H + H) * pc['edges'] / p_ev, 'node': node_flop_per_launch(H, L, pc['nodes'] / p_ev, nl_tot, False),
+                                     'edge_coord': per_kernel['edge_coord']['flop_per_launch'] if 'edge_coord' in per_kernel else 0.0}[dom]
         # whole-job algorithmic FLOP for the timed region
         f_alg = whole_job_flop(H, L, dyn, cnt['edges'], cnt['edges_phar'], cnt['nodes'], cnt['evaluations'] * nl_tot)
         # HBM-side bytes per launch from the PMC passes (tools/collect_traffic.py), only when they were taken on
@@ -526,6 +529,11 @@ def main(argv=None):
                 # product = six exact bf16 products on the bf16 pipe, cmdgen_split.h) - so no `frac` can exceed 1.  The
                 # fraction of the fp32 INSTRUCTION's peak (what round 2 reported) stays as `frac_of_fp32_instruction_peak`.
                 'mfma': per_kernel[dom]['mfma'], 'frac_of_fp32_instruction_peak': per_kernel[dom]['frac_of_fp32_instruction_peak'],
+                # `flop_per_launch` / `achieved` / `frac` count the work the kernel EXECUTED: since round 3 the last block of a conditional
+                # evaluation skips tiles whose output nobody reads.  Priced on the work the REFERENCE does in those launches
+                # (every row of every block - what rounds 1-2 reported, and what a recomputation from N, Nl and the launch time gives):
+                'frac_on_reference_work': (reference_flop_per_launch / (avg_ms * 1e-3) / 1e12 / per_kernel[dom]['peak']) if avg_ms > 0 else None,
+                'reference_flop_per_launch': reference_flop_per_launch,
                 'whole_job_frac': f_alg / elapsed / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
                 'whole_job_frac_of_fp32_instruction_peak': f_alg / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 # the north-star also asks for the HBM view: PMC bytes per launch / launch time / 8 TB/s (not the binding roofline)
