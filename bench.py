@@ -245,7 +245,10 @@ def chain_record(cfg, sd, pb, K, dev, stream, use_graph, prof_steps=0, gemm=None
                'coord_edges_per_pocket_eval': c['edges_phar'] / ev / B, 'edges_per_s': c['edges'] / dt,
                'whole_step_alg_tflops': f_alg / dt / 1e12, 'whole_job_frac': f_alg / dt / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
                'whole_job_frac_of_fp32_instruction_peak': f_alg / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-               'chain_status': st}
+               'chain_status': st,
+               # share of the reference's per-block edge / node-row work this chain did NOT execute because nobody reads its result
+               # (blocks skip tiles beyond L - l hops of a moving node; large in a drifted chain, ~0 where the phar points stay in the pocket)
+               'dead_work_skipped': {'edge_visits': c.get('edges_skipped', 0) / max(c['edges'] * L, 1), 'node_row_visits': c.get('node_rows_skipped', 0) / max(c['nodes'] * L, 1)}}
         if prof_steps:
             h.reset_counters()
             h.set_kernel_profiling(True)
@@ -503,6 +506,8 @@ def main(argv=None):
                 'hip_graph': use_graph, 'noise': 'on-device Philox4x32-10',
                 'us_per_denoising_step': 1e6 * elapsed / (args.steps * evals_per_chain),
                 'edges_per_pocket_eval': cnt['edges'] / max(cnt['evaluations'], 1) / B,
+                # share of the reference's per-block edge / node-row work the timed chains did NOT execute because nobody reads its result
+                'dead_work_skipped': {'edge_visits': cnt.get('edges_skipped', 0) / max(cnt['edges'] * L, 1), 'node_row_visits': cnt.get('node_rows_skipped', 0) / max(cnt['nodes'] * L, 1)},
                 'phar_edges_per_pocket_eval': cnt['edges_phar'] / max(cnt['evaluations'], 1) / B,
                 'edges_per_s': n_gpus * cnt['edges'] / elapsed,
                 'whole_step_alg_tflops': f_alg / elapsed / 1e12,
@@ -564,7 +569,8 @@ def main(argv=None):
                                                  cn['evaluations'] * int(pbn.num_nodes_phar.sum())) / dtn / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
                 'whole_job_frac_of_fp32_instruction_peak': whole_job_flop(H, L, dyn, cn['edges'], cn['edges_phar'], cn['nodes'],
                                                  cn['evaluations'] * int(pbn.num_nodes_phar.sum())) / dtn / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                'edges_per_s': cn['edges'] / dtn}
+                'edges_per_s': cn['edges'] / dtn,
+                'dead_work_skipped': {'edge_visits': cn.get('edges_skipped', 0) / max(cn['edges'] * L, 1), 'node_row_visits': cn.get('node_rows_skipped', 0) / max(cn['nodes'] * L, 1)}}
         if n_gpus == 1 and rep == 'CA' and not args.no_extra_shapes and not args.strong:
             # ---- the same chain where the phar points stay inside the pocket for all K steps (the geometry a trained model holds):
             # noise_precision 0.1 / norm_values [1, 0.25] give 1/alpha_T = 3.2 instead of 316, so untrained weights cannot inflate the

@@ -329,7 +329,7 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
 // layout
 // ---------------------------------------------------------------------------------
 // dynamic LDS of k_edge_count / k_edge_write: float4 position + two ints per node (kernels_egnn.hip)
-static inline size_t edge_lds_bytes(int max_n) { return (size_t)max_n * (sizeof(float4) + 2 * sizeof(int)); }
+static inline size_t edge_lds_bytes(int max_n) { return (size_t)max_n * (sizeof(float4) + 3 * sizeof(int)); }
 static const size_t kEdgeLdsMax = 156 * 1024;      // 160 KiB per CU minus k_edge_write's small static arrays
 void cmdgen_edge_kernels_allow_lds(size_t bytes);  // kernels_egnn.hip: hipFuncSetAttribute above the 64 KiB default
 
@@ -363,7 +363,7 @@ static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, 
     if (N < 1 || ecap > (int64_t)2000000000) return fail(h, CMDGEN_EINVAL, "batch too large for int32 edge indexing (dense bound %lld)", (long long)ecap);
     if (edge_lds_bytes(max_n) > kEdgeLdsMax)
         return fail(h, CMDGEN_EINVAL, "a sample has %d nodes; the per-sample neighbour search keeps positions and offsets in LDS (%d B per node, at most %d nodes)",
-                    max_n, 24, (int)(kEdgeLdsMax / 24));
+                    max_n, 28, (int)(kEdgeLdsMax / 28));
     std::vector<int> ns(N);
     for (int b = 0; b < B; ++b) {
         for (int i = 0; i < vph[b]; ++i) ns[bph[b] + i] = b;
@@ -421,7 +421,7 @@ static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, 
         ALLOC(w.Pc, float, cN * H, true); ALLOC(w.Qc, float, cN * H, true); ALLOC(w.agg, float, cN * H, true);
         ALLOC(w.degL, int, cN, true); ALLOC(w.need_qc, int, cN, true); ALLOC(w.pocketE, int, cB, true); ALLOC(w.pocketEph, int, cB, true);
         ALLOC(w.pocketEns, int, cB, true); ALLOC(w.pocketEnsQ, int, cB, true);
-        ALLOC(w.erow, int, ce, false); ALLOC(w.ecol, int, ce, false); ALLOC(w.ed0, float, ce, false);
+        ALLOC(w.erow, int, ce, false); ALLOC(w.ecol, int, ce, false); ALLOC(w.ed0, float, ce, false); ALLOC(w.ehop, int, ce, false);
         ALLOC(w.crow, int, cec, false); ALLOC(w.ccol, int, cec, false); ALLOC(w.cd0, float, cec, false);
         ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true); ALLOC(w.sync, int, 4, true);
         // exchange buffers of k_node_pair: one pair of workgroups per two CUs at most (64 KB + two flags per pair)
@@ -567,8 +567,10 @@ EvalLaunch make_launch(cmdgen_handle* h) {
             if (ev) on = atoi(ev) == 32 ? 32 : atoi(ev) != 0;
         }
         a.node64 = on;
-        { const char* dv = getenv("CMDGEN_DEAD_SKIP"); a.dead_skip = (!h->dims.joint && !(dv && atoi(dv) == 0)) ? 1 : 0; }
-        if (!on && !a.node_mixed && !a.dead_skip) a.w.need_qc = nullptr; }         // the graph pass fills the flags only for the kernels that read them (k_node64, k_node_mixed)
+        { const char* dv = getenv("CMDGEN_DEAD_SKIP"); a.dead_skip = h->dims.joint ? 0 : dv ? atoi(dv) : 2; }       // 2 (default): every block by hop level; 1: the last block only; 0: off (CMDGEN_DEAD_SKIP)
+        if (!on && !a.node_mixed && !a.dead_skip) a.w.need_qc = nullptr;
+        a.w.hop_levels = a.dead_skip >= 2 ? h->dims.L : 1;
+        if (!a.dead_skip) a.w.ehop = nullptr; }         // the graph pass fills the flags only for the kernels that read them (k_node64, k_node_mixed)
     {   // k_node_pair (kernels_node_pair.hip: two workgroups share a 32-row tile by output columns, half the weight bytes per CU, one
         // 32 KB exchange through L2): parity-green, 30.5 us against 30.2 us for the 16-row kernel at 64 pockets - the chip's L2 delivers
         // ~17-22 TB/s to 236 CUs together, and what the halved stream saves the exchange and the doubled tile load give back
@@ -647,7 +649,7 @@ extern "C" int cmdgen_radius_graph(cmdgen_handle* h, const float* x, const int64
     }
     if (N < 1 || need > (int64_t)2000000000) return fail(h, CMDGEN_EINVAL, "bad total node count / dense bound");
     if (cap < need) return fail(h, CMDGEN_EINVAL, "edge capacity %lld below the dense bound %lld", (long long)cap, (long long)need);
-    if (edge_lds_bytes(max_n) > kEdgeLdsMax) return fail(h, CMDGEN_EINVAL, "a sample has %d nodes (at most %d)", max_n, (int)(kEdgeLdsMax / 24));
+    if (edge_lds_bytes(max_n) > kEdgeLdsMax) return fail(h, CMDGEN_EINVAL, "a sample has %d nodes (at most %d)", max_n, (int)(kEdgeLdsMax / 28));
     if (edge_lds_bytes(max_n) > 64 * 1024) cmdgen_edge_kernels_allow_lds(edge_lds_bytes(max_n));
     // every node is presented to the radius-graph kernels as a (non-moving) pocket node of a scratch layout
     std::vector<void*> pool; void* p; int rc = 0;

@@ -104,11 +104,13 @@ struct Work {                   // per-layout workspace; all pointers device
     float*  Qc;                 // [N][H]
     float*  agg;                // [N][H]  zero between blocks
     int*    degL;               // [N] degree in sample-local order
-    int*    need_qc;            // [N] 1: the node sends along an edge of this evaluation's coordinate list (its Q_c row will be read); may be null
+    int     hop_levels;         // how many hop levels the graph pass computes into need_qc (1, or n_layers when every block skips its dead tiles)
+    int*    need_qc;            // [N] hop level from the moving nodes: 0 moves, 1 sends along a coordinate edge (its Q_c row is read), 2.. L, 255 none; may be null
     int*    pocketE;            // [B] edges per sample
     int*    pocketEph;          // [B] edges with phar receiver per sample
     int*    pocketEns;          // [B] ... of those that are not self loops
     int*    pocketEnsQ;         // [B] edges with pocket receiver that are not self loops (joint mode's coordinate list)
+    int*    ehop;               // [Ecap] hop level of every listed edge's RECEIVER (see need_qc); may be null
     int*    erow; int* ecol; float* ed0;        // [Ecap] compact edge list sorted by flat (row, col); the first
                                                 //        pocketEph-sum entries are the phar-receiver edges
     int*    crow; int* ccol; float* cd0;        // [Eccap] coordinate-update edges: moving receivers, self loops dropped
@@ -210,7 +212,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int proj_mt = 32;           //    rows per projection tile there (32 or 64)
     int node_mixed = 0;         // 1: small conditional batches run k_node as k_node_mixed (two workgroups per phar tile, 32-row plane tiles for the pocket)
     int dead_skip = 0;          // 1: the last block of a conditional evaluation skips tiles whose new h nobody reads (CMDGEN_DEAD_SKIP=0 opts out)
-    mutable int live_only = 0;  // set around the last block's launches when that applies
+    mutable int live_thr = 0;   // set around a block's launches when that applies: nodes within this many hops of a moving node are still read
     mutable int coord_zero_rows = 0;  // set behind a k_node_mixed launch: the coordinate kernel zeroes the first rows of agg
     mutable int node_skip_next = 0;   // set around the k_node launch whose next-block projections moved
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)

@@ -87,7 +87,7 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
                                                  const LayerW& lw_next, const int layer, const int has_next_arg, const int row0, const int row_end) {
     constexpr int H = 256, LPR = H / 4, NMT = NROWS / 32, NPE = NROWS * NPLD;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int has_next = has_next_arg & 1, live_only = has_next_arg >> 1;      // bit 1: the last block of a conditional evaluation (see below)
+    const int has_next = has_next_arg & 1, live_thr = has_next_arg >> 1;       // bits 1..: only tiles with a node within that many hops of a moving node (see below)
 #if CMDGEN_STAMPS == 5      // diagnostic build: per-phase cycle stamps into w.dbg ([wave][phase] sums, [32 + wave] lifetime, [40] waves)
     unsigned long long nst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nst_t = __builtin_amdgcn_s_memtime();
     const unsigned long long nst_begin = nst_t;
@@ -98,11 +98,11 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
     const int nvalid = min(NROWS, row_end - row0);
     const bool want_pc = row0 < lay.Nm;
     const int c4 = tid % LPR, rsub = tid / LPR;
-    if (live_only && !want_pc && w.need_qc) {
+    if (live_thr && !want_pc && w.need_qc) {
         // the new h of a pocket node is still read only if the node sends along a coordinate edge: a tile without one only restores
         // "agg is zero between blocks" (kernels_egnn.hip, node_tile_body)
         const int r = lane & (NROWS - 1);
-        if (__ballot(r < nvalid && w.need_qc[row0 + r] != 0) == 0ull) {
+        if (__ballot(r < nvalid && w.need_qc[row0 + r] <= live_thr) == 0ull) {
 #pragma unroll
             for (int pass = 0; pass < NROWS / 4; ++pass) {
                 const int rr = pass * 4 + rsub;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
     const sbf16x8* const t4[2] = {n64_tile(lw.W4.ws, 16, 2 * wave, 0), n64_tile(lw.W4.ws, 16, 2 * wave + 1, 0)};
     // projections: jobs 0..3 = P_c, Q_c, P', Q' (bit j of `jobs` set: the job runs); Wpq rows 0..H-1 -> P (tiles 0..7), H.. -> Q (8..15)
     // Q_c only where a row of the tile sends along a coordinate edge of this evaluation (flags of the graph pass, kernels_egnn.hip)
-    const bool want_qc = want_pc || !w.need_qc || __ballot((lane & (NROWS - 1)) < nvalid && w.need_qc[row0 + (lane & (NROWS - 1))] != 0) != 0ull;
+    const bool want_qc = want_pc || !w.need_qc || __ballot((lane & (NROWS - 1)) < nvalid && w.need_qc[row0 + (lane & (NROWS - 1))] <= 1) != 0ull;
     const unsigned jobs = (want_pc ? 1u : 0u) | (want_qc ? 2u : 0u) | (has_next ? 12u : 0u);
     auto job_tile = [&](int j, int n) { return n64_tile(j < 2 ? lw.Wpq_c.ws : lw_next.Wpq_e.ws, 16, (j & 1) * 8 + 2 * wave + n, 0); };
     const int job0 = jobs ? __builtin_ctz(jobs) : 1;             // (no job at all: the W4 product's look-ahead reads Q_c's first blocks, unused)

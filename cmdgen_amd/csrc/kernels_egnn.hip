@@ -109,6 +109,7 @@ __device__ __forceinline__ void edge_write_body(const Layout& lay, const Work& w
     extern __shared__ float4 spos[];
     int* soff = reinterpret_cast<int*>(spos + lay.max_n);
     int* sdg = soff + lay.max_n;                 // the sample's degree words (k_edge_count), read many times below
+    int* shop = sdg + lay.max_n;                 // hop levels (see below)
     __shared__ int s_base[5];
     __shared__ int s_red[6][16];
     const int tid = threadIdx.x;
@@ -205,10 +206,45 @@ __device__ __forceinline__ void edge_write_body(const Layout& lay, const Work& w
                 coff += __popcll(mc);
             }
         }
-        // k_node64 computes the Q_c rows of a tile only if one of its nodes is flagged: in a drifted chain the pocket has no phar point
-        // within the cutoff and a sixth of its node-kernel work is a projection nobody reads (the 16- and 32-row kernels keep computing
-        // them: at 64 pockets their launch ends with the phar tiles, which need everything - skipping made it 0.4 us slower, r03_t)
-        if (lane == 0 && w.need_qc) w.need_qc[gi] = feeds ? 1 : 0;
+        // Hop distance from the moving nodes along the graph's edges: 0 = moves, 1 = sends along a coordinate edge (its Q_c row is read), and
+        // below the levels 2 .. L; 255 = none of those.  k_node64 computes the Q_c rows of a tile only if it holds a node of level <= 1, and
+        // block l of a conditional evaluation whose pocket output nobody asks for only needs the nodes of level <= L - l (see edge_msg_body).
+        if (lane == 0 && w.need_qc) w.need_qc[gi] = moving ? 0 : feeds ? 1 : 255;
+    }
+    if (w.need_qc) {
+        // levels 2 .. hop_levels: a node not reached yet joins level k when one of its neighbours is at level k - 1 (positions still in LDS)
+        __shared__ int s_any[2];
+        __threadfence_block();
+        __syncthreads();
+        for (int i = tid; i < n; i += blockDim.x) shop[i] = w.need_qc[flat_node(i, nl, pb, qb, lay.Nl)];
+        if (tid == 0) { s_any[0] = 0; s_any[1] = 0; }
+        __syncthreads();
+        for (int level = 2; level <= w.hop_levels && !d.joint; ++level) {
+            for (int i = wave; i < n; i += nwaves) {
+                if (shop[i] != 255) continue;                                   // wave-uniform
+                const float4 pi = spos[i];
+                bool hit = false;
+                for (int j0 = 0; j0 < n && !hit; j0 += 64) {
+                    const int j = j0 + lane;
+                    const bool ok = j < n && shop[j] == level - 1 && ((d.cutoff2 < 0.f) || dist2(pi, spos[j]) <= d.cutoff2);
+                    hit = __ballot(ok) != 0ull;
+                }
+                if (hit && lane == 0) { shop[i] = level; w.need_qc[flat_node(i, nl, pb, qb, lay.Nl)] = level; s_any[level & 1] = 1; }
+            }
+            __syncthreads();
+            if (!s_any[level & 1]) break;                                       // nothing joined: nothing will
+            if (tid == 0) s_any[(level + 1) & 1] = 0;
+            __syncthreads();
+        }
+        // the receiver's level beside every listed edge: k_edge_msg fetches it with the tile's (row, col, d0) one tile ahead - no dependent load
+        if (w.ehop) {
+            __syncthreads();
+            for (int i = wave; i < n; i += nwaves) {
+                const int off = i < nl ? s_base[0] + soff[i] : s_base[1] + (soff[i] - eph_b);
+                const int dg = sdg[i] & 0x3fffffff, lvl = shop[i];
+                for (int e = lane; e < dg; e += 64) w.ehop[off + e] = lvl;
+            }
+        }
     }
     if (b == 0 && tid == 0) *w.nan_flag = 0;     // after every reader of the previous evaluation's flag, before k_readout sets it
     if (b == lay.B - 1 && tid == 0) {
@@ -718,6 +754,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
     const int tid = threadIdx.x, wave = tid >> 6;
     s_wa[tid] = lw.wa[tid];                                    // visible after the first tile's barriers
     constexpr bool PL = SP && H == 256 && MT >= 32;            // plane variant: the producer splits (build_edge_half)
+    const int live_thr = (ablate >> 6) & 15;                   // 0: every tile; else only tiles with a receiver of hop level <= live_thr
     static_assert(!FK || (PL && MT == 32 && !SAVE), "full-K planes: 32-row sampler tiles on the split engine");
     if constexpr (PL && !FK) { s_wrd[tid] = lw.wr_e[tid]; s_wrd[H + tid] = lw.wd_e[tid]; }
     const ColVec<MT> b2v = col_load<MT>(lw.b2, wave);          // per-column bias and the gate's bias: once per workgroup
@@ -741,28 +778,35 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
 #endif
     // The (row, col, d0) triple of a tile is requested one tile ahead (three registers): it arrives during the previous tile's
     // build / GEMM, so a tile's first phase starts with the position loads instead of two dependent round trips.
-    int nx_row = -1, nx_col = -1; float nx_d0 = 0.f;
+    int nx_row = -1, nx_col = -1, nx_hop = 255; float nx_d0 = 0.f;
     {
         const int t0 = xcd_tile(0, ntiles, vb, nb);
-        if (t0 >= 0 && tid < MT && t0 * MT + tid < E) { nx_row = w.erow[t0 * MT + tid]; nx_col = w.ecol[t0 * MT + tid]; nx_d0 = w.ed0[t0 * MT + tid]; }
+        if (t0 >= 0 && tid < MT && t0 * MT + tid < E) {
+            nx_row = w.erow[t0 * MT + tid]; nx_col = w.ecol[t0 * MT + tid]; nx_d0 = w.ed0[t0 * MT + tid];
+            if (live_thr) nx_hop = w.ehop[t0 * MT + tid];
+        }
     }
     for (int k = 0, tile; (tile = xcd_tile(k, ntiles, vb, nb)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
         if (tid < MT) {
-            const int row = nx_row, col = nx_col; const float d0 = nx_d0;       // -1 / -1 / 0 beyond the list's end
-            nx_row = -1; nx_col = -1; nx_d0 = 0.f;
+            const int row = nx_row, col = nx_col, hop = nx_hop; const float d0 = nx_d0;       // -1 / -1 / 255 / 0 beyond the list's end
+            nx_row = -1; nx_col = -1; nx_d0 = 0.f; nx_hop = 255;
             const int tn = xcd_tile(k + 1, ntiles, vb, nb);
-            if (tn >= 0 && tn * MT + tid < E) { nx_row = w.erow[tn * MT + tid]; nx_col = w.ecol[tn * MT + tid]; nx_d0 = w.ed0[tn * MT + tid]; }
+            if (tn >= 0 && tn * MT + tid < E) {
+                nx_row = w.erow[tn * MT + tid]; nx_col = w.ecol[tn * MT + tid]; nx_d0 = w.ed0[tn * MT + tid];
+                if (live_thr) nx_hop = w.ehop[tn * MT + tid];
+            }
             if (!coord_seen) {
                 // (MT <= 64: these are lanes of wave 0 only) does any edge of the tile end in a node that moves?
                 const bool touch = row >= 0 && (row < lay.Nm || col < lay.Nm);
                 if (__ballot(touch) != 0ull) { wait_coord_done(w, done, done_target); coord_seen = true; }
             }
-            if (ablate & 64) {
-                // Last block of a conditional evaluation whose pocket output nobody reads: h_new of a node is still needed only if it moves
-                // or sends along a coordinate edge (the need_qc flags of the graph pass) - a tile without such a receiver is dead work
-                const bool live = row >= 0 && w.need_qc[row] != 0;
+            if (live_thr) {
+                // A conditional evaluation whose pocket output nobody reads: after the last block only the moving nodes' h and the Q_c rows of
+                // the coordinate senders are used, so block l needs the new h of the nodes within L - l hops of a moving node only (levels of
+                // the graph pass; live_thr = L - l) - a tile without such a receiver is dead work
+                const bool live = hop <= live_thr;
                 const unsigned long long any = __ballot(live);
                 if (tid == 0) L.s_live[k & 1] = any != 0ull;
             }
@@ -776,7 +820,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
         }
         lds_barrier();
         STAMP(0);
-        if ((ablate & 64) && !L.s_live[k & 1]) {                   // (s_live is double-buffered: no thread is two tiles behind)
+        if (live_thr && !L.s_live[k & 1]) {                        // (s_live is double-buffered: no thread is two tiles behind)
             if (tid == 0) atomicAdd(&w.counters[6], (unsigned long long)ne);
             continue;
         }
@@ -896,7 +940,7 @@ __global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_msg(Layout lay, Work w, 
 template <int H, int MT, bool SAVE, bool SP, int ROLE = 0>
 __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw, const LayerW& lw_next,
                                                const int layer, const int has_next_arg, const TrainSave& sv, const int row0, const int row_end) {
-    const int has_next = has_next_arg & 1, live_only = has_next_arg >> 1;      // bit 1: skip tiles none of whose rows is still read (see below)
+    const int has_next = has_next_arg & 1;                                     // (bits 1.. carry the dead-tile threshold of the plane tiles: unused here)
     // Tiles of <= 32 rows keep two LDS images: buf0 = h (kept for the residual), buf1 = agg -> T -> h_new,
     // so h and agg are fetched together and the residual needs no second global read.  64-row tiles
     // (66 KB each) use one image so that two workgroups still fit a CU.
@@ -909,20 +953,8 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
     const int c4 = tid % LPR, rsub = tid / LPR;
     // the chain of GEMMs of this tile; each one's last iteration fetches the next one's first fragments
     const bool want_pc = row0 < lay.Nm;              // the tile holds receivers that move
-    if (live_only && !want_pc && !SAVE) {
-        // Last block of a conditional evaluation whose pocket output nobody reads: the new h of a pocket node is needed only if the node
-        // sends along a coordinate edge (need_qc).  A tile without one only restores "agg is zero between blocks".
-        const int r = tid & (MT - 1);
-        if (__ballot(r < nvalid && w.need_qc[row0 + r] != 0) == 0ull) {
-#pragma unroll
-            for (int pass = 0; pass < MT / 4; ++pass) {
-                const int rr = pass * 4 + rsub;
-                if (rr < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + rr) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (tid == 0) atomicAdd(&w.counters[7], (unsigned long long)nvalid);
-            return;
-        }
-    }
+    // (Dead tiles - edge_msg_body - are skipped by the plane tiles of cmdgen_node_planes.h only: the launches of this body end with their phar
+    // tiles, which are never dead, and the level check cost them 0.7 us at 64 pockets; profiles/r03_m_node64.txt.)
     typedef Eng<MT, SP> G;
     typedef typename G::Frag Frag;
     const Frag f3a = G::frag(lw.W3, 2 * H / 8, 0, wave), f3b = G::frag(lw.W3, 2 * H / 8, H / 8, wave);
@@ -1502,7 +1534,7 @@ template <int H, int MT, bool SP> static void launch_write_embed(const EvalLaunc
         const int nt = (a.lay.N + MT - 1) / MT;
         const Dims& d = a.d;
         const size_t shm_e = sizeof(float) * (size_t)(2 * d.P * d.P + 2 * d.P + d.J * 2 * d.P + d.J + 2 * d.R * d.R + 2 * d.R + d.J * 2 * d.R + d.J);
-        const size_t shm_w = (size_t)a.lay.max_n * (sizeof(float4) + 2 * sizeof(int));
+        const size_t shm_w = (size_t)a.lay.max_n * (sizeof(float4) + 3 * sizeof(int));
         const PocketCache pc = (chain && !t) ? a.pcache : PocketCache{};
         const int npair = pc.c ? (a.lay.Nl + MT - 1) / MT : 0;        // pairs only where the other tiles are cache tiles
         hipLaunchKernelGGL((k_write_embed<MT, SP>), dim3(a.lay.B + nt + npair), dim3(256), shm_e > shm_w ? shm_e : shm_w, s, a.lay, a.w, a.d, a.sw,
@@ -1520,9 +1552,9 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
     if (a.save) hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
                                    a.layers[has_next ? l + 1 : l], l, has_next, *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                               a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next | (a.live_only << 1), TrainSave{});
+                                               a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1), TrainSave{});
     else hipLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
-                            a.layers[has_next ? l + 1 : l], l, has_next | (a.live_only << 1), TrainSave{});
+                            a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1), TrainSave{});
 }
 // k_node_mixed where it applies (see the kernel): conditional sampler, H = 256, split engine with 16-row node tiles, the whole grid resident at once
 static bool launch_node_mixed(const EvalLaunch& a, int l, hipStream_t s) {
@@ -1541,15 +1573,15 @@ template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, in
     // training forward: the split engine only where the step re-packs split weights (H = 256: edge_mlp.2 / coord_mlp.2)
     if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                               a.layers[l], l, a.ablate | (a.live_only << 6), TrainSave{});
-    else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate | (a.live_only << 6), TrainSave{});
+                                               a.layers[l], l, a.ablate | (a.live_thr << 6), TrainSave{});
+    else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate | (a.live_thr << 6), TrainSave{});
 }
 // 32-row sampler tiles on the split engine: full-K planes (one build, one GEMM per tile; see cmdgen_split.h) unless CMDGEN_EDGE_FULLK=0
 static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.edge_mt != 32) return false;
     if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                          a.layers[l], l, a.ablate | (a.live_only << 6), TrainSave{});
-    else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate | (a.live_only << 6), TrainSave{});
+                                          a.layers[l], l, a.ablate | (a.live_thr << 6), TrainSave{});
+    else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate | (a.live_thr << 6), TrainSave{});
     return true;
 }
 static bool launch_coord_fullk(const EvalLaunch& a, int l, hipStream_t s) {
@@ -1625,7 +1657,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
                           float* eps_phar, float* eps_pocket, hipStream_t s,
                           hipEvent_t* ev /* null or 2*(3+3L) events */) {
     const int B = a.lay.B, N = a.lay.N;
-    const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + 2 * sizeof(int));
+    const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + 3 * sizeof(int));
     int e = 0;
 #define REC() do { if (ev) hipEventRecord(ev[e++], s); } while (0)
     // kernel profiling: the launch itself carries a start and a stop event (hipExtLaunchKernelGGL: the timestamps of the dispatch
@@ -1669,7 +1701,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     // dead work of the LAST block (conditional sampler, pocket output not asked for): see edge_msg_body / node_tile_body
     const bool live_last = a.dead_skip && !eps_pocket && !a.save && !a.d.joint && a.stop_block < 0 && a.w.need_qc != nullptr && !merge && !move_proj;
     for (int l = 0; l < a.d.L; ++l) {
-        a.live_only = (live_last && l == a.d.L - 1) ? 1 : 0;
+        a.live_thr = live_last ? (a.dead_skip >= 2 ? a.d.L - l : (l == a.d.L - 1 ? 1 : 0)) : 0;     // dead_skip 1: the last block only; 2: every block
         const int stop = a.stop_block == l ? a.stop_stage : 0;        // parity aid: leave intermediates in the workspace
         REC();
         PROF_BEGIN(0);
@@ -1773,7 +1805,7 @@ void cmdgen_launch_save_positions(const EvalLaunch& a, float4* X, hipStream_t s)
 
 // radius graph only (the training path builds its own evaluation on top of the same compact lists)
 void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s) {
-    const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + 2 * sizeof(int));
+    const size_t shm = (size_t)a.lay.max_n * (sizeof(float4) + 3 * sizeof(int));
     const int gthr = a.lay.max_n > 128 ? 1024 : 256;
     hipLaunchKernelGGL(k_edge_count, dim3(a.lay.B), dim3(gthr), shm, s, a.lay, a.w, a.d, xh_phar, xh_pocket);
     hipLaunchKernelGGL(k_edge_write, dim3(a.lay.B), dim3(gthr), shm, s, a.lay, a.w, a.d);

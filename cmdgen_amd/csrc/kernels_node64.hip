@@ -34,13 +34,13 @@ bool cmdgen_launch_node64(const EvalLaunch& a, int l, hipStream_t s) {
     if (a.node64 == 32) {
         const int nt32 = (a.lay.N + 31) / 32;
         if (a.pe_start) hipExtLaunchKernelGGL(k_node32p, dim3(nt32), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l],
-                                              a.layers[has_next ? l + 1 : l], l, has_next | (a.live_only << 1));
-        else hipLaunchKernelGGL(k_node32p, dim3(nt32), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next | (a.live_only << 1));
+                                              a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1));
+        else hipLaunchKernelGGL(k_node32p, dim3(nt32), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1));
         return true;
     }
     const int nt = (a.lay.N + 63) / 64;
     if (a.pe_start) hipExtLaunchKernelGGL(k_node64, dim3(nt), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l],
-                                          a.layers[has_next ? l + 1 : l], l, has_next | (a.live_only << 1));
-    else hipLaunchKernelGGL(k_node64, dim3(nt), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next | (a.live_only << 1));
+                                          a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1));
+    else hipLaunchKernelGGL(k_node64, dim3(nt), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1));
     return true;
 }

@@ -239,7 +239,7 @@ def test_last_block_dead_work_skip_changes_nothing(monkeypatch):
         cfg, sd, inp = dynamics_case(G2, name)
         h = new_handle(cfg, sd)
         h.set_layout(G2[name + '/num_nodes_phar'], G2[name + '/pocket_size'])
-        assert h.query('dead_skip') == 1
+        assert h.query('dead_skip') == 2
         eps, none = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']), want_pocket=False)
         eps2, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']), want_pocket=False)     # agg left zero
         want = G2[name + '/eps_phar']
@@ -251,7 +251,7 @@ def test_last_block_dead_work_skip_changes_nothing(monkeypatch):
     sd = make_state_dict(cfg, seed=0)
     pb = make_pockets(24, 'CA')
     out = {}
-    for flag in ('1', '0'):
+    for flag in ('2', '1', '0'):
         monkeypatch.setenv('CMDGEN_DEAD_SKIP', flag)
         h = new_handle(cfg, sd)
         h.set_layout(pb.num_nodes_phar, pb.size)
@@ -262,11 +262,38 @@ def test_last_block_dead_work_skip_changes_nothing(monkeypatch):
         out[flag] = (xh.cpu().numpy(), xp.cpu().numpy(), c)
         assert h.chain_status()['nan_resets'] == 0
         h.close()
-    on, off = out['1'][2], out['0'][2]
-    print(f'24 pockets, 300 steps: {on["edges_skipped"] / on["evaluations"]:.0f} of {on["edges"] / on["evaluations"]:.0f} edges and '
-          f'{on["node_rows_skipped"] / on["evaluations"]:.0f} of {on["nodes"] / on["evaluations"]:.0f} node rows skipped per evaluation in the last block')
-    assert off['edges_skipped'] == 0 and off['node_rows_skipped'] == 0 and on['edges_skipped'] > 0 and on['node_rows_skipped'] > 0
+    on, off, last = out['2'][2], out['0'][2], out['1'][2]
+    print(f'24 pockets, 300 steps: {on["edges_skipped"] / on["evaluations"]:.0f} of {5 * on["edges"] / on["evaluations"]:.0f} edge visits and '
+          f'{on["node_rows_skipped"] / on["evaluations"]:.0f} of {5 * on["nodes"] / on["evaluations"]:.0f} node-row visits skipped per evaluation (all blocks; the last block alone: {last["edges_skipped"] / last["evaluations"]:.0f} edges)')
+    assert off['edges_skipped'] == 0 and off['node_rows_skipped'] == 0 and on['edges_skipped'] > last['edges_skipped'] > 0
+    # (node tiles are skipped by the plane tiles of large batches only: k_node64; see test_node64_skips_dead_tiles_at_256_pockets)
     # (float atomics at tile boundaries make two runs of the SAME code differ in the last bits; the skip adds nothing to that)
     sc = max(1.0, float(np.abs(out['0'][0][:, :3]).max()))
-    assert np.abs(out['1'][0][:, :3] - out['0'][0][:, :3]).max() <= 2e-5 * sc and np.array_equal(out['1'][0][:, 3:], out['0'][0][:, 3:])
-    assert np.abs(out['1'][1][:, :3] - out['0'][1][:, :3]).max() <= 2e-5 * sc
+    for f in ('2', '1'):
+        assert np.abs(out[f][0][:, :3] - out['0'][0][:, :3]).max() <= 2e-5 * sc and np.array_equal(out[f][0][:, 3:], out['0'][0][:, 3:])
+        assert np.abs(out[f][1][:, :3] - out['0'][1][:, :3]).max() <= 2e-5 * sc
+
+
+def test_node64_skips_dead_tiles_at_256_pockets(monkeypatch):
+    """256 pockets (k_node64 on a 256-CU device): a drifted 60-step chain with every block skipping its dead tiles (default) against the same chain with
+    the skip off - same result to the run-to-run noise of the float atomics, node rows skipped only when on."""
+    cfg = ModelConfig(residue_nf=20, timesteps=1000)
+    sd = make_state_dict(cfg, seed=0)
+    pb = make_pockets(256, 'CA')
+    out = {}
+    for flag in ('2', '0'):
+        monkeypatch.setenv('CMDGEN_DEAD_SKIP', flag)
+        h = new_handle(cfg, sd)
+        h.set_layout(pb.num_nodes_phar, pb.size)
+        h.reset_counters()
+        xh, _, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), 60, seed=3)
+        out[flag] = (xh.cpu().numpy(), h.counters(), h.query('node64'))
+        assert h.chain_status()['nan_resets'] == 0
+        h.close()
+    on, off = out['2'][1], out['0'][1]
+    print(f'256 pockets, 60 steps: {on["edges_skipped"] / on["evaluations"]:.0f} of {5 * on["edges"] / on["evaluations"]:.0f} edge visits, '
+          f'{on["node_rows_skipped"] / on["evaluations"]:.0f} of {5 * on["nodes"] / on["evaluations"]:.0f} node-row visits skipped per evaluation; node64 {out["2"][2]}')
+    assert off['edges_skipped'] == 0 and off['node_rows_skipped'] == 0 and on['edges_skipped'] > 0
+    if out['2'][2]: assert on['node_rows_skipped'] > 0
+    sc = max(1.0, float(np.abs(out['0'][0][:, :3]).max()))
+    assert np.abs(out['2'][0][:, :3] - out['0'][0][:, :3]).max() <= 2e-5 * sc and np.array_equal(out['2'][0][:, 3:], out['0'][0][:, 3:])
