@@ -128,6 +128,12 @@ def node_flop_per_launch(H, L, nodes, moving, split_proj=False):
     return sum(per_block) / L
 
 
+def executed(c, L):
+    """(edges, nodes) summed over evaluations as the kernels EXECUTED them, per block on average: the counters' listed totals minus the dead tiles
+    that were skipped (cmdgen_counters.edges_skipped / node_rows_skipped are summed over the L launches of every evaluation)."""
+    return c['edges'] - c.get('edges_skipped', 0) / L, c['nodes'] - c.get('node_rows_skipped', 0) / L
+
+
 def whole_job_flop(H, L, dyn, edges, coord_edges, nodes, moving):
     """F_alg of SURVEY 8d with P_c counted on moving rows only: L*[2(H^2+H)(E+Ec) + 12H^2 N + 2H^2 Nm] + in/out
     embeddings (2*dyn*H per node each)."""
@@ -239,12 +245,14 @@ def chain_record(cfg, sd, pb, K, dev, stream, use_graph, prof_steps=0, gemm=None
         c = h.counters()
         st = h.chain_status()
         ev = max(c['evaluations'], 1)
-        f_alg = whole_job_flop(H, L, dyn, c['edges'], c['edges_phar'], c['nodes'], ev * nl_tot)
+        f_ref = whole_job_flop(H, L, dyn, c['edges'], c['edges_phar'], c['nodes'], ev * nl_tot)      # what the reference computes
+        f_alg = whole_job_flop(H, L, dyn, *(executed(c, L)[:1]), c['edges_phar'], executed(c, L)[1], ev * nl_tot)   # what ran
         rec = {'pockets': B, 'posterior_steps': K, 'value': B * (K + 1) / dt, 'unit': 'pocket-steps/s',
                'us_per_denoising_step': 1e6 * dt / (K + 1), 'edges_per_pocket_eval': c['edges'] / ev / B,
                'coord_edges_per_pocket_eval': c['edges_phar'] / ev / B, 'edges_per_s': c['edges'] / dt,
                'whole_step_alg_tflops': f_alg / dt / 1e12, 'whole_job_frac': f_alg / dt / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
                'whole_job_frac_of_fp32_instruction_peak': f_alg / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+               'reference_work_tflops': f_ref / dt / 1e12,       # the reference's FLOPs of these evaluations per second (not a pipe fraction: dead work is skipped)
                'chain_status': st,
                # share of the reference's per-block edge / node-row work this chain did NOT execute because nobody reads its result
                # (blocks skip tiles beyond L - l hops of a moving node; large in a drifted chain, ~0 where the phar points stay in the pocket)
@@ -468,7 +476,8 @@ def main(argv=None):
         reference_flop_per_launch = {'edge_msg': 2.0 * (H * H + H) * pc['edges'] / p_ev, 'node': node_flop_per_launch(H, L, pc['nodes'] / p_ev, nl_tot, False),
                                      'edge_coord': per_kernel['edge_coord']['flop_per_launch'] if 'edge_coord' in per_kernel else 0.0}[dom]
         # whole-job algorithmic FLOP for the timed region
-        f_alg = whole_job_flop(H, L, dyn, cnt['edges'], cnt['edges_phar'], cnt['nodes'], cnt['evaluations'] * nl_tot)
+        f_ref = whole_job_flop(H, L, dyn, cnt['edges'], cnt['edges_phar'], cnt['nodes'], cnt['evaluations'] * nl_tot)            # what the reference computes
+        f_alg = whole_job_flop(H, L, dyn, executed(cnt, L)[0], cnt['edges_phar'], executed(cnt, L)[1], cnt['evaluations'] * nl_tot)   # what ran
         # HBM-side bytes per launch from the PMC passes (tools/collect_traffic.py), only when they were taken on
         # exactly these kernel sources
         traffic, traffic_note = None, 'no profiles/kernel_traffic.json'
@@ -539,7 +548,8 @@ def main(argv=None):
                 # (every row of every block - what rounds 1-2 reported, and what a recomputation from N, Nl and the launch time gives):
                 'frac_on_reference_work': (reference_flop_per_launch / (avg_ms * 1e-3) / 1e12 / per_kernel[dom]['peak']) if avg_ms > 0 else None,
                 'reference_flop_per_launch': reference_flop_per_launch,
-                'whole_job_frac': f_alg / elapsed / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
+                'whole_job_frac': f_alg / elapsed / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,          # executed work (dead tiles are skipped since round 3)
+                'whole_job_reference_work_tflops': f_ref / elapsed / 1e12,                         # the reference's FLOPs of the same evaluations per second
                 'whole_job_frac_of_fp32_instruction_peak': f_alg / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 # the north-star also asks for the HBM view: PMC bytes per launch / launch time / 8 TB/s (not the binding roofline)
                 'hbm_frac_from_pmc': (traffic / (avg_ms * 1e-3) / (PEAK_HBM_TBS * 1e12)) if traffic else None,
@@ -565,10 +575,12 @@ def main(argv=None):
             result['config']['north_star_shape'] = {
                 'pockets': Bn, 'value': Bn * evals_per_chain / dtn, 'unit': 'pocket-steps/s',
                 'us_per_denoising_step': 1e6 * dtn / evals_per_chain,
-                'whole_job_frac': whole_job_flop(H, L, dyn, cn['edges'], cn['edges_phar'], cn['nodes'],
+                'whole_job_frac': whole_job_flop(H, L, dyn, executed(cn, L)[0], cn['edges_phar'], executed(cn, L)[1],
                                                  cn['evaluations'] * int(pbn.num_nodes_phar.sum())) / dtn / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
-                'whole_job_frac_of_fp32_instruction_peak': whole_job_flop(H, L, dyn, cn['edges'], cn['edges_phar'], cn['nodes'],
+                'whole_job_frac_of_fp32_instruction_peak': whole_job_flop(H, L, dyn, executed(cn, L)[0], cn['edges_phar'], executed(cn, L)[1],
                                                  cn['evaluations'] * int(pbn.num_nodes_phar.sum())) / dtn / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                'reference_work_tflops': whole_job_flop(H, L, dyn, cn['edges'], cn['edges_phar'], cn['nodes'],
+                                                 cn['evaluations'] * int(pbn.num_nodes_phar.sum())) / dtn / 1e12,
                 'edges_per_s': cn['edges'] / dtn,
                 'dead_work_skipped': {'edge_visits': cn.get('edges_skipped', 0) / max(cn['edges'] * L, 1), 'node_row_visits': cn.get('node_rows_skipped', 0) / max(cn['nodes'] * L, 1)}}
         if n_gpus == 1 and rep == 'CA' and not args.no_extra_shapes and not args.strong:

@@ -209,17 +209,28 @@ __device__ __forceinline__ void edge_write_body(const Layout& lay, const Work& w
         // Hop distance from the moving nodes along the graph's edges: 0 = moves, 1 = sends along a coordinate edge (its Q_c row is read), and
         // below the levels 2 .. L; 255 = none of those.  k_node64 computes the Q_c rows of a tile only if it holds a node of level <= 1, and
         // block l of a conditional evaluation whose pocket output nobody asks for only needs the nodes of level <= L - l (see edge_msg_body).
-        if (lane == 0 && w.need_qc) w.need_qc[gi] = moving ? 0 : feeds ? 1 : 255;
+        if (lane == 0 && w.need_qc) { const int lvl = moving ? 0 : feeds ? 1 : 255; shop[i] = lvl; w.need_qc[gi] = lvl; }
     }
     if (w.need_qc) {
         // levels 2 .. hop_levels: a node not reached yet joins level k when one of its neighbours is at level k - 1 (positions still in LDS)
         __shared__ int s_any[2];
-        __threadfence_block();
-        __syncthreads();
-        for (int i = tid; i < n; i += blockDim.x) shop[i] = w.need_qc[flat_node(i, nl, pb, qb, lay.Nl)];
-        if (tid == 0) { s_any[0] = 0; s_any[1] = 0; }
-        __syncthreads();
-        for (int level = 2; level <= w.hop_levels && !d.joint; ++level) {
+        __shared__ int s_near;
+        if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_near = 0; }
+        __syncthreads();                                                        // levels 0 / 1 / 255 of every node are in shop (LDS)
+        // Where at least half of the sample already sits at level <= 1 (the phar points are inside the pocket) the sweep below would reach
+        // everybody within a level or two and buy nothing: call the rest level 2 - conservative (a node is never skipped while it is needed),
+        // and the ~3 us the sweep costs a 59-node sample stay off the critical path of k_write_embed
+        if (w.hop_levels > 1 && !d.joint) {
+            int near = 0;
+            for (int i = tid; i < n; i += blockDim.x) near += shop[i] <= 1;
+            if (near) atomicAdd(&s_near, near);
+            __syncthreads();
+            if (2 * s_near >= n) {
+                for (int i = tid; i < n; i += blockDim.x) if (shop[i] == 255) { shop[i] = 2; w.need_qc[flat_node(i, nl, pb, qb, lay.Nl)] = 2; }
+                __syncthreads();
+            }
+        }
+        for (int level = 2; level <= w.hop_levels && !d.joint && 2 * s_near < n; ++level) {
             for (int i = wave; i < n; i += nwaves) {
                 if (shop[i] != 255) continue;                                   // wave-uniform
                 const float4 pi = spos[i];
