@@ -221,16 +221,22 @@ __device__ __forceinline__ void edge_write_body(const Layout& lay, const Work& w
         // everybody within a level or two and buy nothing: call the rest level 2 - conservative (a node is never skipped while it is needed),
         // and the ~3 us the sweep costs a 59-node sample stay off the critical path of k_write_embed
         if (w.hop_levels > 1 && !d.joint) {
-            int near = 0;
-            for (int i = tid; i < n; i += blockDim.x) near += shop[i] <= 1;
-            if (near) atomicAdd(&s_near, near);
+            int near = 0, ones = 0;                                              // per wave: nodes at level <= 1 / exactly 1 (the sweep's first frontier)
+            for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
+                const int i = i0 + tid;
+                const int lv = i < n ? shop[i] : 255;
+                near += __popcll(__ballot(lv <= 1)); ones += __popcll(__ballot(lv == 1));
+            }
+            if (lane == 0 && near) atomicAdd(&s_near, near);
+            if (lane == 0 && ones) s_any[1] = 1;                                 // (level 2 looks at s_any[(2 - 1) & 1] below)
             __syncthreads();
             if (2 * s_near >= n) {
                 for (int i = tid; i < n; i += blockDim.x) if (shop[i] == 255) { shop[i] = 2; w.need_qc[flat_node(i, nl, pb, qb, lay.Nl)] = 2; }
                 __syncthreads();
             }
         }
-        for (int level = 2; level <= w.hop_levels && !d.joint && 2 * s_near < n; ++level) {
+        // (an empty frontier ends the sweep before it starts: in a drifted chain no pocket node is within reach of a phar point)
+        for (int level = 2; level <= w.hop_levels && !d.joint && 2 * s_near < n && s_any[(level - 1) & 1]; ++level) {
             for (int i = wave; i < n; i += nwaves) {
                 if (shop[i] != 255) continue;                                   // wave-uniform
                 const float4 pi = spos[i];
