@@ -513,7 +513,8 @@ static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, 
         h->coord_grid = grid_for(ec_est, h->coord_mt);
         if ((ev = getenv("CMDGEN_EDGE_WGS_PER_CU"))) h->edge_grid = atoi(ev) * h->n_cus;
         if ((ev = getenv("CMDGEN_COORD_WGS_PER_CU"))) h->coord_grid = atoi(ev) * h->n_cus;
-        for (int* m : {&h->node_mt, &h->edge_mt, &h->coord_mt}) if (*m != 64 && *m != 32 && *m != 16) *m = 64;
+        if (h->node_mt != 64 && h->node_mt != 32 && h->node_mt != 16) h->node_mt = 64;
+        for (int* m : {&h->edge_mt, &h->coord_mt}) if (*m != 128 && *m != 64 && *m != 32 && *m != 16) *m = 64;     // 128: kernels_edge128.hip
     }
     h->cur_nphar.assign(nph, nph + B); h->cur_npocket.assign(npk, npk + B);
     h->have_layout = true;

@@ -1,0 +1,482 @@
+// kernels_edge128.hip - the two edge kernels of an EquivariantBlock for LARGE edge lists (sampler, H = 256, split engine):
+//   k_edge128<false>  GCL.edge_model + attention gate + segment sum by receiver         (egnn_new.py:31-52, :276-292)
+//   k_edge128<true>   EquivariantUpdate.coord_model on the coordinate list               (egnn_new.py:87-104)
+//
+// Why another pair of edge kernels.  The 64-row tiles of kernels_egnn.hip stream the whole split weight (256 x 256 x 6 B = 384 KB) and
+// gather 128 KB of P / Q rows through ONE CU's vector L1 per 64 edges - 512 KB per 12.3k cycles of matrix work, which is what that L1
+// delivers (~45 B/clk measured): the GEMM phases ran at 79 % behind their weight stream, the tile builds waited for gathers queued behind
+// the partner workgroup's stream, and the epilogue went through LDS three times (m tile out, row dots, 64-row scans); stamps in
+// profiles/r03_h: 51.5k cycles per wave and tile for 12.3k cycles of MFMA issue.  Here
+//   * a workgroup multiplies up to 128 rows per weight fragment (4 x 2 accumulator tiles of 32 x 32 per wave): half the weight bytes per edge;
+//     the A operand is built a QUARTER of K at a time (three bf16 planes of [128][64 + 8], 55 KB) so that two workgroups still share a CU and
+//     one's builds and epilogue run beside the other's MFMAs;
+//   * the epilogue stays in registers: SiLU on the accumulators, the gate's (or coord_mlp.4's) row dot as in-lane FMAs + a value-halving
+//     butterfly over the 32 lanes that hold a row (ds_swizzle), one 2 KB exchange of the four waves' partial sums, and the ordered segment
+//     sum by receiver as ONE MORE MATRIX PRODUCT: agg_tile[segment][col] = S[segment][row] x (att[row] m[row][col]), S the 0/1 membership
+//     matrix (exact in bf16), the gated messages split into three bf16 pieces straight from the accumulator registers - the 32 x 32
+//     accumulator layout (lane = column, registers = rows) IS the B-operand layout of v_mfma_f32_32x32x16_bf16 up to a fixed permutation of k,
+//     which the S fragments are built to match.  No m tile in LDS, no per-row scan, 48 MFMAs (+6 %) per tile;
+//   * every workgroup owns ONE contiguous chunk of the list, sized so that all workgroups of the launch finish together (a chunk is cut into
+//     equal tiles of 32 .. 128 rows; accumulator tiles beyond a tile's rows are not multiplied): no tail round of whole tiles.
+// Results: the same sums as kernels_egnn.hip up to fp32 re-association (row dots and segment sums add in another order); deterministic run
+// to run as long as a receiver's edges span at most two tiles (one float atomic each: commutative).
+#include "cmdgen_dev.h"
+#include <hip/hip_ext.h>
+#include <cstdlib>
+
+namespace {
+
+constexpr int H = 256;
+constexpr int MT = 128;                 // rows per tile (at most)
+constexpr int KQ = 64;                  // k-values per build / GEMM pass
+constexpr int PLDA = KQ + 8;            // bf16 per plane row: 144 B, conflict-free ds_read_b128 over 16 consecutive rows
+constexpr int PE = MT * PLDA;           // bf16 per plane
+constexpr unsigned NS = 16u * 192u;     // 16-byte units between the two 32-column tiles of a wave in a packed [H][H] split weight
+
+struct alignas(16) EdgeRec { int row, col; float r, d0; };
+
+struct alignas(16) E128Lds {
+    unsigned short planes[3 * PE + 64];         // three bf16 planes of the quarter in flight (+ the A prefetch's overshoot)
+    EdgeRec e[MT];                              // (receiver, sender, radial, d0) of the tile's rows; -1 / -1 / 0 / 0 beyond its end
+    float cd[MT][4];                            // coordinate kernel: coord_diff of the row, later coord_diff * tanh(phi) * range
+    float part[4][MT];                          // the four waves' partial row dots
+    float att[MT];                              // gate of each row
+    float wrd[2 * H];                           // radial / d0 columns of the first layer
+    int segrow[MT];                             // receiver of each segment of the tile
+    int segstart[MT + 1];                       // first row of each segment (coordinate kernel)
+    unsigned char seg[MT];                      // segment index of each row (255 beyond the tile's end)
+    int meta[4];                                // [0] segments, [1] live, [2] rows of the tile
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// lazily updated positions, as kernels_egnn.hip forms them (same expression, same bits)
+__device__ __forceinline__ float4 pos_lazy(const Layout& lay, const Work& w, const Dims& d, int n, int layer) {
+    if (n >= lay.Nm) return w.XP[n - lay.Nl];
+    if (layer == 0) return w.X0[n];
+    const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nm + n];
+    const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
+    return make_float4(p.x + a.x / d.norm_factor, p.y + a.y / d.norm_factor, p.z + a.z / d.norm_factor, 0.f);
+}
+__device__ __forceinline__ float4 pos_mat(const Layout& lay, const Work& w, int n, int layer) {
+    if (n >= lay.Nm) return w.XP[n - lay.Nl];
+    return layer == 0 ? w.X0[n] : w.XL[(size_t)layer * lay.Nm + n];
+}
+
+// the k-th chunk of this workgroup (XCD-aware: workgroups with equal blockIdx % 8 share an L2 and get one contiguous range of chunks)
+__device__ __forceinline__ int xcd_chunk(int k, int nch) {
+    const int vb = (int)blockIdx.x, nb = (int)gridDim.x;
+    const int g = vb & 7, wg_in_g = vb >> 3, wgs_in_g = (nb - g + 7) >> 3, per_g = (nch + 7) >> 3;
+    const int t = wg_in_g + k * wgs_in_g;
+    if (wgs_in_g == 0 || t >= per_g) return -1;
+    const int c = g * per_g + t;
+    return c < nch ? c : -1;
+}
+
+// ---- tile build: columns [64 q, 64 q + 64) of SiLU(P[row] + Q[col] + w_r r + w_d d0) as three bf16 planes, in two batches of 64 rows
+// (8 gathered float4 per thread and batch: with the 128 accumulators and the weight fragments a whole tile's 16 would spill).  The
+// gather of a batch and its use are separate calls so that a batch can be in flight during the GEMM over the previous quarter.
+// Rows beyond the tile's end repeat its last row (finite values in rows nobody reads; no divergent code).  Thread -> 16 bytes of a quarter
+// row (16 lanes per row, 4 consecutive rows per wave instruction: edges of one receiver share their P row's cache lines).
+struct Gath { float4 p[4], q[4]; };
+template <int NMT>
+__device__ __forceinline__ void gather_half(const E128Lds& L, const int tid, const int q, const int half, const int ne, const float* __restrict__ P,
+                                            const float* __restrict__ Q, Gath& g) {
+    const int c4 = tid & 15, rsub = tid >> 4;
+    const unsigned cofs = (unsigned)(q * KQ + 4 * c4) * 4u;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps)
+        if (half * 64 + ps * 16 < 32 * NMT) {
+            const int e = min(half * 64 + ps * 16 + rsub, ne - 1);
+            const int2 rc = *reinterpret_cast<const int2*>(&L.e[e]);
+            g.p[ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(P) + ((unsigned)rc.x * (unsigned)(H * 4) + cofs));
+            g.q[ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Q) + ((unsigned)rc.y * (unsigned)(H * 4) + cofs));
+        }
+}
+template <int NMT>
+__device__ __forceinline__ void store_half(E128Lds& L, const int tid, const int q, const int half, const int ne, const Gath& g) {
+    const int c4 = tid & 15, rsub = tid >> 4;
+    const int col = q * KQ + 4 * c4;
+    const float4 wr4 = *reinterpret_cast<const float4*>(L.wrd + col), wd4 = *reinterpret_cast<const float4*>(L.wrd + H + col);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps)
+        if (half * 64 + ps * 16 < 32 * NMT) {
+            const int e = half * 64 + ps * 16 + rsub;
+            const float2 rd = *reinterpret_cast<const float2*>(&L.e[min(e, ne - 1)].r);
+            const float r = rd.x, d0 = rd.y;
+            const float4 a = make_float4(silu_f(g.p[ps].x + g.q[ps].x + wr4.x * r + wd4.x * d0), silu_f(g.p[ps].y + g.q[ps].y + wr4.y * r + wd4.y * d0),
+                                         silu_f(g.p[ps].z + g.q[ps].z + wr4.z * r + wd4.z * d0), silu_f(g.p[ps].w + g.q[ps].w + wr4.w * r + wd4.w * d0));
+            split_store4(L.planes, PE, e * PLDA + 4 * c4, a);
+        }
+}
+
+// ---- one quarter of the tile product: acc[m][n] += planes(rows 32 m .., k-blocks 4 q .. 4 q + 3) x W^T for m < NMT.
+// bs[0] holds the weight fragments of k-block 4 q on entry and of k-block 4 q + 4 on exit (q < 3).  One load pinned beside every pair of MFMAs; per accumulator the six products of a k-block keep the
+// order of cmdgen_split.h (small terms first).  wb: the wave's first 32-column tile, k-block 0, this lane.
+template <int NMT>
+__device__ __forceinline__ void gemm_quarter(const unsigned short* planes, const int lane, const int q, const sbf16x8* __restrict__ wb,
+                                             sf32x16 (&acc)[NMT][2], sbf16x8 (&bs)[2][2][3]) {
+    const unsigned short* ap = planes + (lane & 31) * PLDA + (lane >> 5) * 8;
+    sbf16x8 a[2][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) a[0][s] = *reinterpret_cast<const sbf16x8*>(ap + s * PE);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        const sbf16x8* qn = wb + (unsigned)((4 * q + kq + 1) & 15) * 192u;      // next k-block (wave-uniform)
+        constexpr int BPG = NMT == 1 ? 6 : 3;                                   // weight loads per row group: all of them early in the k-block
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+            const int it = kq * NMT + m, cs = it & 1, nx = cs ^ 1, bc = kq & 1, bn = bc ^ 1;
+            const bool more_a = (m + 1 < NMT) || (kq < 3);
+            const bool more_b = kq < 3 || q < 3;                                // wave-uniform: not past the tile's last k-block
+            const unsigned short* an = ap + ((m + 1 < NMT) ? (m + 1) * 32 * PLDA + kq * 16 : (kq + 1) * 16);
+            const int b0 = m * BPG;                                             // first weight load of this group (of 6: (n, s) = (i & 1, i >> 1))
+#define E_MF(N, AI, BI) acc[m][N] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][AI], bs[bc][N][BI], acc[m][N], 0, 0, 0);
+#define E_LA(S) if (more_a) a[nx][S] = *reinterpret_cast<const sbf16x8*>(an + (S) * PE);
+#define E_LB(I) if ((I) < 6 && (I) >= b0 && (I) < b0 + BPG && more_b) bs[bn][(I) & 1][(I) >> 1] = qn[(unsigned)((I) & 1) * NS + (unsigned)((I) >> 1) * 64u];
+            E_LA(2) E_MF(0, 2, 0) E_MF(1, 2, 0) __builtin_amdgcn_sched_barrier(0);
+            E_LA(1) E_MF(0, 1, 1) E_MF(1, 1, 1) __builtin_amdgcn_sched_barrier(0);
+            E_LA(0) E_MF(0, 0, 2) E_MF(1, 0, 2) __builtin_amdgcn_sched_barrier(0);
+            E_LB(b0) E_LB(b0 + 3) E_MF(0, 1, 0) E_MF(1, 1, 0) __builtin_amdgcn_sched_barrier(0);
+            E_LB(b0 + 1) E_LB(b0 + 4) E_MF(0, 0, 1) E_MF(1, 0, 1) __builtin_amdgcn_sched_barrier(0);
+            E_LB(b0 + 2) E_LB(b0 + 5) E_MF(0, 0, 0) E_MF(1, 0, 0) __builtin_amdgcn_sched_barrier(0);
+#undef E_MF
+#undef E_LA
+#undef E_LB
+        }
+    }
+}
+
+#define E_SWZ(V, D) __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(V), ((D) << 10) | 0x1f))     // value of lane ^ D (D < 32)
+
+// Sum over the 32 lanes of a half wave of 32 values per lane, by value halving: after the five exchanges lane l of a half holds the
+// complete sum of value l & 31 (31 exchanges instead of 160 for a butterfly on every value).
+__device__ __forceinline__ float reduce32_over32(float (&v)[32], const int lane) {
+#define E_STAGE(N, D) {                                                                                           \
+        const bool up = (lane & (D)) != 0;                                                                        \
+        _Pragma("unroll") for (int i = 0; i < (N) / 2; ++i) {                                                     \
+            const float keep = up ? v[i + (N) / 2] : v[i], send = up ? v[i] : v[i + (N) / 2];                     \
+            v[i] = keep + E_SWZ(send, D); } }
+    E_STAGE(32, 16) E_STAGE(16, 8) E_STAGE(8, 4) E_STAGE(4, 2) E_STAGE(2, 1)
+#undef E_STAGE
+    return v[0];
+}
+
+// accumulator register r of row tile m -> row of the tile
+#define E_ROW(M, R) ((M) * 32 + ((R) & 3) + 8 * ((R) >> 2) + 4 * (lane >> 5))
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// One tile of NMT x 32 rows (ne of them listed) after its index phase: K in four build -> GEMM passes, then the epilogue in registers.
+struct TileCtx {
+    const float* P; const float* Q; const sbf16x8* wb;
+    float bias0, bias1, hv0, hv1, ba0;
+    int colw, layer;
+};
+template <bool COORD, int NMT>
+__device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, const Work& w, const Dims& d, const TileCtx& c, const int ne,
+                                             sbf16x8 (&bs)[2][2][3], unsigned long long (&st_)[8], unsigned long long& st_t) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));           // opaque: per-lane addresses derived from it are recomputed per tile instead of being hoisted out of the tile loop and spilled
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ P = c.P; const float* __restrict__ Q = c.Q; const sbf16x8* __restrict__ wb = c.wb;
+    const float bias0 = c.bias0, bias1 = c.bias1, hv0 = c.hv0, hv1 = c.hv1, ba0 = c.ba0;
+    const int colw = c.colw, layer = c.layer;
+#if CMDGEN_STAMPS == 6
+#define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+    sf32x16 acc[NMT][2];                                                                // start from the bias of the layer (b2 / b7)
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[m][0][r] = bias0; acc[m][1][r] = bias1; }
+    // ---------------- four build -> GEMM passes over a quarter of K each.  (Gathering the next quarter's first rows BEFORE the GEMM over
+    // this one was measured and lost: the 32 extra live registers spill around the GEMM and its waits cover the gather; profiles/r04_c.)
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        Gath g0;
+        gather_half<NMT>(L, tid, q, 0, ne, P, Q, g0);
+        if constexpr (NMT > 2) {
+            Gath g1;
+            gather_half<NMT>(L, tid, q, 1, ne, P, Q, g1);          // both batches in flight, the second lands while the first is consumed
+            store_half<NMT>(L, tid, q, 0, ne, g0);
+            store_half<NMT>(L, tid, q, 1, ne, g1);
+        } else {
+            store_half<NMT>(L, tid, q, 0, ne, g0);
+        }
+        lds_barrier();
+        STAMP(1);
+        gemm_quarter<NMT>(L.planes, lane, q, wb, acc, bs);
+        lds_barrier();                                                                  // every wave is done reading the planes
+        STAMP(2);
+    }
+    // ---------------- epilogue in registers: SiLU, the row dot (attention logit / coord_mlp.4)
+#pragma unroll
+    for (int mh = 0; mh < (NMT + 1) / 2; ++mh) {          // two row tiles (32 values per lane) at a time
+        float pl[32];
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 2 * mh + mm;
+                float dotp = 0.f;
+                if (m < NMT) {
+                    const float v0 = silu_f(acc[m < NMT ? m : 0][0][r]), v1 = silu_f(acc[m < NMT ? m : 0][1][r]);
+                    acc[m < NMT ? m : 0][0][r] = v0; acc[m < NMT ? m : 0][1][r] = v1;
+                    dotp = v0 * hv0 + v1 * hv1;
+                }
+                pl[mm * 16 + r] = dotp;
+            }
+        const float o = reduce32_over32(pl, lane);
+        // value 16 mm + r = lane & 31
+        const int l5 = lane & 31;
+        L.part[wave][E_ROW(2 * mh + (l5 >> 4), l5 & 15)] = o;
+    }
+    lds_barrier();
+    STAMP(3);
+    if (tid < MT) {
+        const float s = (L.part[0][tid] + L.part[1][tid]) + (L.part[2][tid] + L.part[3][tid]);
+        if (COORD) {
+            const float g = d.use_tanh ? tanhf(s) * d.coords_range : s;
+            L.cd[tid][0] *= g; L.cd[tid][1] *= g; L.cd[tid][2] *= g;
+        } else {
+            L.att[tid] = d.attention ? sigmoid_f(s + ba0) : 1.0f;
+        }
+    }
+    lds_barrier();
+    STAMP(5);
+    if constexpr (COORD) {
+        // ordered segment sums of the three components: one thread per (segment, component), rows in list order
+        const int nseg = L.meta[0];
+        for (int i = tid; i < 3 * nseg; i += 256) {
+            const int sgi = i / 3, comp = i - 3 * sgi;
+            const int rb = L.segstart[sgi], re = L.segstart[sgi + 1];
+            float sum = 0.f;
+            for (int e = rb; e < re; ++e) sum += L.cd[e][comp];
+            float* dst = reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nm + L.segrow[sgi]) + comp;
+            if (sgi == 0 || sgi == nseg - 1) atomicAdd(dst, sum); else *dst = sum;      // a receiver may continue in the neighbouring tiles; ACC is zero before the launch
+        }
+    } else {
+        // gated messages, then the segment sum as a matrix product (see the head of this file).  The index phase cut the tile at 32 segments,
+        // so one 32 x 32 accumulator tile per column tile takes every segment and each row tile's accumulators die as they are consumed.
+        const int nseg = L.meta[0];
+        const unsigned myseg = (unsigned)(lane & 31);
+        sf32x16 sa[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[n][r] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+            float4 g[4];
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) g[rq] = *reinterpret_cast<const float4*>(&L.att[E_ROW(m, 4 * rq)]);   // rows E_ROW(m, 4 rq) .. + 3 (one address per half wave: broadcast)
+            // S fragments of the two k-blocks of this row tile: k-slot j of lane half hf <-> row 32 m + 16 hb + 8 (j >> 2) + 4 hf + (j & 3),
+            // the row that accumulator register 8 hb + j of this lane half holds
+            sbf16x8 sf[2];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const unsigned g0 = *reinterpret_cast<const unsigned*>(&L.seg[E_ROW(m, 8 * hb)]);
+                const unsigned g1 = *reinterpret_cast<const unsigned*>(&L.seg[E_ROW(m, 8 * hb + 4)]);
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                u4 sv;
+                sv[0] = ((g0 & 0xffu) == myseg ? 0x3F80u : 0u) | (((g0 >> 8) & 0xffu) == myseg ? 0x3F800000u : 0u);
+                sv[1] = (((g0 >> 16) & 0xffu) == myseg ? 0x3F80u : 0u) | ((g0 >> 24) == myseg ? 0x3F800000u : 0u);
+                sv[2] = ((g1 & 0xffu) == myseg ? 0x3F80u : 0u) | (((g1 >> 8) & 0xffu) == myseg ? 0x3F800000u : 0u);
+                sv[3] = (((g1 >> 16) & 0xffu) == myseg ? 0x3F80u : 0u) | ((g1 >> 24) == myseg ? 0x3F800000u : 0u);
+                sf[hb] = __builtin_bit_cast(sbf16x8, sv);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    u4 p0, p1, p2;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int r = 8 * hb + 2 * jj;                                       // registers r, r + 1: rows of the same float4 of gates
+                        const float ga = (r & 2) ? g[r >> 2].z : g[r >> 2].x, gb = (r & 2) ? g[r >> 2].w : g[r >> 2].y;
+                        unsigned a0, a1, a2;
+                        split3_pair(acc[m][n][r] * ga, acc[m][n][r + 1] * gb, a0, a1, a2);
+                        p0[jj] = a0; p1[jj] = a1; p2[jj] = a2;
+                    }
+                    sa[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf[hb], __builtin_bit_cast(sbf16x8, p2), sa[n], 0, 0, 0);
+                    sa[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf[hb], __builtin_bit_cast(sbf16x8, p1), sa[n], 0, 0, 0);
+                    sa[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf[hb], __builtin_bit_cast(sbf16x8, p0), sa[n], 0, 0, 0);
+                }
+        }
+        // segment (r & 3) + 8 (r >> 2) + 4 hf of column colw + 32 n
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int sgi = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (sgi < nseg) {
+                float* dst = w.agg + (size_t)L.segrow[sgi] * H + colw;
+                if (sgi == 0 || sgi == nseg - 1) { atomicAdd(dst, sa[0][r]); atomicAdd(dst + 32, sa[1][r]); }   // the receiver may continue in the neighbouring tiles
+                else { dst[0] = sa[0][r]; dst[32] = sa[1][r]; }                                               // agg is zero between blocks
+            }
+        }
+    }
+#undef STAMP
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+template <bool COORD>
+__global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, LayerW lw, int layer, int live_thr) {
+    __shared__ E128Lds L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WPack& W = COORD ? lw.W7 : lw.W2;
+    const float* __restrict__ P = COORD ? w.Pc : w.P;
+    const float* __restrict__ Q = COORD ? w.Qc : w.Q;
+    const int* __restrict__ rowp = COORD ? w.crow : w.erow;
+    const int* __restrict__ colp = COORD ? w.ccol : w.ecol;
+    const float* __restrict__ d0p = COORD ? w.cd0 : w.ed0;
+    L.wrd[tid] = (COORD ? lw.wr_c : lw.wr_e)[tid]; L.wrd[H + tid] = (COORD ? lw.wd_c : lw.wd_e)[tid];       // visible after the first tile's barrier
+    const int colw = 64 * wave + (lane & 31);
+    const float* bvec = COORD ? lw.b7 : lw.b2;
+    const float* hvec = COORD ? lw.w5 : lw.wa;                                   // the row dot's weight vector
+    const float bias0 = bvec[colw], bias1 = bvec[colw + 32], hv0 = hvec[colw], hv1 = hvec[colw + 32];
+    const float ba0 = COORD ? 0.f : lw.ba[0];
+    const sbf16x8* __restrict__ wb = reinterpret_cast<const sbf16x8*>(W.ws) + (size_t)(2 * wave) * 16 * 192 + lane;
+    const int E = w.totals[COORD ? 1 : 0];
+    const int G = (int)gridDim.x;
+    int CH = (((E + G - 1) / G) + 31) & ~31;
+    if (CH < 32) CH = 32;
+    const int nch = (E + CH - 1) / CH;
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;       // diagnostic builds (-DCMDGEN_STAMPS=6): summed phase cycles
+#if CMDGEN_STAMPS == 6
+    st_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_t; int st_tiles = 0;
+#define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+    for (int kc = 0, c; (c = xcd_chunk(kc, nch)) >= 0; ++kc) {
+        const int cbeg = c * CH, cend = min(E, cbeg + CH);
+        const int ntile = (cend - cbeg + MT - 1) / MT;
+        const int trows = (((cend - cbeg + ntile - 1) / ntile) + 31) & ~31;         // equal tiles, a multiple of 32 rows, <= 128
+        // wave 0 keeps the next tile's (row, col, d0, level) one tile ahead: two rows per lane
+        int nrow[2] = {-1, -1}, ncol[2] = {-1, -1}, nhop[2] = {255, 255}; float nd0[2] = {0.f, 0.f};
+        int nx_e0 = -1;                                                             // the first row the prefetched records belong to
+        auto fetch = [&](int e0, int ne) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                nrow[u] = -1; ncol[u] = -1; nd0[u] = 0.f; nhop[u] = 255;
+                if (64 * u + lane < ne) {
+                    const int e = e0 + 64 * u + lane;
+                    nrow[u] = rowp[e]; ncol[u] = colp[e]; nd0[u] = d0p[e];
+                    if (!COORD && live_thr) nhop[u] = w.ehop[e];
+                }
+            }
+            nx_e0 = e0;
+        };
+        for (int e0 = cbeg; e0 < cend; ) {
+            const int ne_full = min(trows, cend - e0);
+            sbf16x8 bs[2][2][3];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) bs[0][i & 1][i >> 1] = wb[(unsigned)(i & 1) * NS + (unsigned)(i >> 1) * 64u];     // k-block 0, in flight during the index phase
+            // ---------------- index phase (wave 0): positions, radial, segments of the tile
+            if (wave == 0) {
+                if (nx_e0 != e0) fetch(e0, ne_full);                                // first tile of the chunk, or the previous tile was cut short (below)
+                int row[2], col[2], hop[2]; float d0[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { row[u] = nrow[u]; col[u] = ncol[u]; hop[u] = nhop[u]; d0[u] = nd0[u]; }
+                if (e0 + ne_full < cend) fetch(e0 + ne_full, min(trows, cend - e0 - ne_full));
+                // segments: runs of equal receivers (the lists are sorted by receiver)
+                const int prev0 = __shfl_up(row[0], 1);
+                const bool s0 = lane < ne_full && (lane == 0 || row[0] != prev0);
+                const int last0 = __shfl(row[0], 63);
+                const int prev1 = __shfl_up(row[1], 1);
+                const bool s1 = 64 + lane < ne_full && row[1] != (lane == 0 ? last0 : prev1);
+                const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
+                const unsigned long long below = (2ull << lane) - 1ull;                        // lanes <= this one
+                const int n0 = __popcll(m0);
+                const int sg0 = __popcll(m0 & below) - 1, sg1 = n0 + __popcll(m1 & below) - 1;
+                int ne = ne_full, ns = n0 + __popcll(m1);
+                if (!COORD && ns > 32) {
+                    // the message kernel's segment sum takes 32 segments per tile: cut the tile where the 33rd begins (the next tile starts there)
+                    ne = __popcll(__ballot(lane < ne_full && sg0 < 32)) + __popcll(__ballot(64 + lane < ne_full && sg1 < 32));
+                    ns = 32;
+                }
+                bool live = true;
+                if (!COORD && live_thr) live = (__ballot(lane < ne && hop[0] <= live_thr) | __ballot(64 + lane < ne && hop[1] <= live_thr)) != 0ull;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = 64 * u + lane;
+                    float r = 0.f;
+                    if (t < ne && live) {
+                        if (COORD) {
+                            const float4 pi = pos_mat(lay, w, row[u], layer), pj = pos_mat(lay, w, col[u], layer);
+                            float cx = pi.x - pj.x, cy = pi.y - pj.y, cz = pi.z - pj.z;
+                            r = cx * cx + cy * cy + cz * cz;
+                            const float den = sqrtf(r + 1e-8f) + d.norm_constant;              // coord2diff, egnn_new.py:265-271
+                            L.cd[t][0] = cx / den; L.cd[t][1] = cy / den; L.cd[t][2] = cz / den;
+                        } else {
+                            // block 0: the radial IS the d0 of the graph pass (same dist2, same operands); later blocks: lazily updated positions
+                            r = layer == 0 ? d0[u] : dist2(pos_lazy(lay, w, d, row[u], layer), pos_lazy(lay, w, d, col[u], layer));
+                        }
+                    }
+                    EdgeRec er; er.row = row[u]; er.col = col[u]; er.r = r; er.d0 = d0[u];
+                    L.e[t] = er;
+                }
+                L.seg[lane] = (unsigned char)(lane < ne ? sg0 : 255);
+                L.seg[64 + lane] = (unsigned char)(64 + lane < ne ? sg1 : 255);
+                if (s0 && lane < ne) { L.segrow[sg0] = row[0]; L.segstart[sg0] = lane; }
+                if (s1 && 64 + lane < ne) { L.segrow[sg1] = row[1]; L.segstart[sg1] = 64 + lane; }
+                if (lane == 0) { L.meta[0] = ns; L.meta[1] = live ? 1 : 0; L.meta[2] = ne; L.segstart[ns] = ne; }
+            }
+            lds_barrier();
+            STAMP(0);
+            const int ne = L.meta[2];
+            const int nmt = (ne + 31) >> 5;
+            if (!L.meta[1]) {                                                                   // dead tile (see edge_msg_body, kernels_egnn.hip)
+                if (tid == 0) atomicAdd(&w.counters[6], (unsigned long long)ne);
+                lds_barrier();                                                                  // meta is rewritten by the next index phase
+                e0 += ne;
+                continue;
+            }
+            {
+                TileCtx tc; tc.P = P; tc.Q = Q; tc.wb = wb; tc.bias0 = bias0; tc.bias1 = bias1; tc.hv0 = hv0; tc.hv1 = hv1; tc.ba0 = ba0; tc.colw = colw; tc.layer = layer;
+                switch (nmt) {
+                    case 4: tile_compute<COORD, 4>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
+                    case 3: tile_compute<COORD, 3>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
+                    case 2: tile_compute<COORD, 2>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
+                    default: tile_compute<COORD, 1>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
+                }
+            }
+            lds_barrier();                                                                      // the next index phase rewrites e / seg / meta
+            STAMP(4);
+            e0 += ne;
+#if CMDGEN_STAMPS == 6
+            ++st_tiles;
+#endif
+        }
+    }
+#if CMDGEN_STAMPS == 6
+    if (lane == 0 && (blockIdx.x & 3) == 0 && st_tiles > 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
+        atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
+        atomicAdd(&w.dbg[40], 1ull);
+        if (wave == 0) atomicAdd(&w.dbg[41], (unsigned long long)st_tiles);
+    }
+#endif
+#undef STAMP
+}
+
+}  // namespace
+
+// launchers: true when the 128-row kernels took the launch (H = 256, split engine, sampler)
+bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s) {
+    if (a.edge_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[l].W2.ws) return false;
+    const int grid = (getenv("CMDGEN_E128_WGS") ? atoi(getenv("CMDGEN_E128_WGS")) : 2) * a.n_cus;
+    if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l], l, a.live_thr);
+    else hipLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.live_thr);
+    return true;
+}
+bool cmdgen_launch_coord128(const EvalLaunch& a, int l, hipStream_t s) {
+    if (a.coord_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[l].W7.ws) return false;
+    const int grid = (getenv("CMDGEN_E128_WGS") ? atoi(getenv("CMDGEN_E128_WGS")) : 2) * a.n_cus;
+    if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l], l, 0);
+    else hipLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, 0);
+    return true;
+}

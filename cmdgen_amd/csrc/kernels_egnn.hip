@@ -22,6 +22,8 @@
 
 bool cmdgen_launch_node_pair(const EvalLaunch& a, int l, hipStream_t s);      // kernels_node_pair.hip: k_node for small batches
 bool cmdgen_launch_node64(const EvalLaunch& a, int l, hipStream_t s);         // kernels_node64.hip: k_node for large batches
+bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s);         // kernels_edge128.hip: the edge kernels for long lists (128-row tiles)
+bool cmdgen_launch_coord128(const EvalLaunch& a, int l, hipStream_t s);
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e.
 // drains every outstanding global store / atomic of the wave (1-3 us each time); the barriers of
@@ -1664,7 +1666,7 @@ template <int H> static bool launch_coord_proj(const EvalLaunch&, int, hipStream
 // kernels, and only when the step re-packed split weights for them - save_split); 16-row tiles are always fp32 MFMA
 // (there the L2 weight stream, not the matrix rate, binds)
 #define MT_DISPATCH(mt, FN, ...) do { const bool sp_ = a.split && (!a.save || a.save_split);                                                 \
-        if ((mt) == 64) { if (sp_) FN<H, 64, true>(__VA_ARGS__); else FN<H, 64, false>(__VA_ARGS__); }                       \
+        if ((mt) >= 64) { if (sp_) FN<H, 64, true>(__VA_ARGS__); else FN<H, 64, false>(__VA_ARGS__); }                       \
         else if ((mt) == 32) { if (sp_) FN<H, 32, true>(__VA_ARGS__); else FN<H, 32, false>(__VA_ARGS__); }                 \
         else FN<H, 16, false>(__VA_ARGS__); } while (0)
 
@@ -1722,7 +1724,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         const int stop = a.stop_block == l ? a.stop_stage : 0;        // parity aid: leave intermediates in the workspace
         REC();
         PROF_BEGIN(0);
-        if (coord_pending) launch_coord_msg<H>(a, l, s); else if (!launch_msg_fullk(a, l, s)) MT_DISPATCH(a.edge_mt, launch_msg, a, l, s);
+        if (coord_pending) launch_coord_msg<H>(a, l, s); else if (!cmdgen_launch_msg128(a, l, s) && !launch_msg_fullk(a, l, s)) MT_DISPATCH(a.edge_mt, launch_msg, a, l, s);
         PROF_END();
         coord_pending = false;
         REC(); REC();
@@ -1739,7 +1741,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         if (stop == 2) return;
         if (merge && l + 1 < a.d.L) coord_pending = true;
         else if (move_proj && l + 1 < a.d.L) { PROF_BEGIN(2); launch_coord_proj<H>(a, l, s); PROF_END(); }
-        else { PROF_BEGIN(2); if (!launch_coord_fullk(a, l, s)) MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF_END(); }
+        else { PROF_BEGIN(2); if (!cmdgen_launch_coord128(a, l, s) && !launch_coord_fullk(a, l, s)) MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF_END(); }
         REC();
         if (stop == 3) return;
     }
