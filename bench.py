@@ -72,6 +72,8 @@ def parse(argv=None):
     p.add_argument('--rehearse-on-one-gpu', action='store_true',
                    help='N > 1 ranks that all use cuda:0 and rendezvous over gloo: runs the whole multi-rank path (sharded pockets, '
                         'barriers, MAX-over-ranks timing, rank count) on a one-GPU box; the number is NOT a scaling result')
+    p.add_argument('--option', action='append', default=[], metavar='KEY=VALUE',
+                   help='launch option of every handle of this run (cmdgen_set_option, e.g. --option edge_mt=64 --option node64=0); A/B runs')
     p.add_argument('--dry-run-launch', action='store_true',
                    help='launch logic only (CPU, gloo, no sampling): used by tests/test_bench_launch.py')
     return p.parse_args(argv)
@@ -355,6 +357,7 @@ def main(argv=None):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.dry_run_launch:
         return dry_run(args, world, rank)
+    hip_backend.DEFAULT_OPTIONS.update(hip_backend.parse_options(','.join(args.option)))     # every Handle below starts with them
     dist = None
     one_gpu = args.rehearse_on_one_gpu
     if world > 1:

@@ -80,10 +80,7 @@ extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle
     d.norm_x = cfg->norm_x; d.norm_h = cfg->norm_h; d.bias_h = cfg->bias_h;
     h->n_cus = prop.multiProcessorCount;
     h->edge_grid = 2 * prop.multiProcessorCount;      // two 66 KB-LDS workgroups per CU at 64-row tiles
-    {   // matrix engine of the sampler's tiles of >= 32 rows (cmdgen_set_gemm_mode); CMDGEN_GEMM=fp32|split overrides the default
-        const char* gm = getenv("CMDGEN_GEMM");
-        h->gemm_split = gm ? (strcmp(gm, "fp32") != 0) : true;
-    }
+    h->gemm_split = true;                             // matrix engine of the tiles of >= 32 rows (cmdgen_set_gemm_mode)
     *out = h;
     return CMDGEN_OK;
 }
@@ -96,9 +93,6 @@ extern "C" void cmdgen_destroy(cmdgen_handle* h) {
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     if (h->ev_in) hipEventDestroy(h->ev_in);
     if (h->ev_out) hipEventDestroy(h->ev_out);
-    if (h->side_stream) hipStreamDestroy(h->side_stream);
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->ev_join) hipEventDestroy(h->ev_join);
     free_pool(h->weight_allocs); free_pool(h->layout_allocs); free_pool(h->chain_allocs); free_pool(h->joint_allocs);
     for (int i = 0; i < 2; ++i) { if (h->idx_stage[i]) hipHostFree(h->idx_stage[i]); if (h->idx_ev[i]) hipEventDestroy(h->idx_ev[i]); }
     if (h->h_norm) hipHostFree(h->h_norm);
@@ -333,6 +327,65 @@ static inline size_t edge_lds_bytes(int max_n) { return (size_t)max_n * (sizeof(
 static const size_t kEdgeLdsMax = 156 * 1024;      // 160 KiB per CU minus k_edge_write's small static arrays
 void cmdgen_edge_kernels_allow_lds(size_t bytes);  // kernels_egnn.hip: hipFuncSetAttribute above the 64 KiB default
 
+// Rows per tile and grids of the evaluation's launches for the current layout (cmdgen_set_layout, and again after cmdgen_set_option /
+// cmdgen_set_gemm_mode).
+static void pick_tiles(cmdgen_handle* h) {
+    // Rows per tile: the largest tile that still gives every CU a few workgroups.  Edge counts are only known on
+    // the device, so they are estimated from the layout for the geometry a trained model holds and every chain starts
+    // from - the phar points inside the pocket (measured on CrossDocked-shaped pockets, bench.py's steady_state_evaluation:
+    // C-alpha 9.2 neighbours per node within 6 A and 15 coordinate edges per phar node; full-atom 36 and 54).  A chain of
+    // an untrained model drifts to fewer edges; the persistent edge grids just find fewer tiles then.
+    double e_est = 0.0, ec_est = 0.0;
+    const int B = (int)h->cur_nphar.size();
+    const Dims& d = h->dims;
+    const int64_t N = (int64_t)h->lay.N;
+    const int64_t* nph = h->cur_nphar.data(); const int64_t* npk = h->cur_npocket.data();
+    for (int b = 0; b < B; ++b) {
+        const double n = (double)(nph[b] + npk[b]);
+        const bool full = h->cfg.edge_cutoff < 0.f;
+        const double deg = full ? n : (n <= 128.0 ? 9.0 : 36.0);
+        const double dnode = deg < n ? deg : n;
+        double dphar = full ? n : 0.6 * (double)nph[b] + (n <= 128.0 ? 0.15 : 0.13) * (double)npk[b];   // receivers that move
+        if (dphar > n) dphar = n;
+        e_est += n * dnode;
+        ec_est += d.joint ? n * dnode : (double)nph[b] * dphar;                   // joint: every receiver moves
+    }
+    // thresholds from sweeps on MI355X (fp32 engine: profiles/r01_tile_sweep.txt; split engine:
+    // profiles/r02_o_tile_sweep_split.txt, r02_z_tiles_trained_geometry.txt)
+    auto pick = [&](double rows) { return rows / 64.0 >= 3.0 * h->n_cus ? 64 : (rows / 32.0 >= 1.5 * h->n_cus ? 32 : 16); };
+    h->node_mt = pick((double)N); h->edge_mt = pick(e_est); h->coord_mt = pick(ec_est);
+    if (h->gemm_split) {
+        // node kernel: 32-row tiles (two LDS images) as soon as they put a workgroup on 0.6 of the CUs (96 C-alpha pockets),
+        // never 64 rows; coordinate kernel: 64-row tiles only for very long lists - its list shrinks to a few tiles when a
+        // chain drifts, and a lone 64-row tile costs 15 us where a 32-row one costs 10
+        h->node_mt = (double)N / 32.0 >= 0.6 * h->n_cus ? 32 : 16;
+        h->coord_mt = ec_est / 64.0 >= 6.0 * h->n_cus ? 64 : (ec_est / 32.0 >= 1.5 * h->n_cus ? 32 : 16);
+    }
+    // long lists on the split engine: the 128-row kernels of kernels_edge128.hip (every workgroup owns one chunk of the list; same-box
+    // A/B at 256 C-alpha pockets: messages -3 %, coordinate list -14 %; full-atom pockets: level; profiles/r04_d)
+    if (h->gemm_split && d.H == 256) {
+        if (e_est / 64.0 >= 4.0 * h->n_cus) h->edge_mt = 128;
+        if (ec_est / 32.0 >= 4.0 * h->n_cus) h->coord_mt = 128;
+    }
+    h->node_mt = (int)opt_of(h, "node_mt", h->node_mt);
+    h->edge_mt = (int)opt_of(h, "edge_mt", h->edge_mt);
+    h->coord_mt = (int)opt_of(h, "coord_mt", h->coord_mt);
+    // grids of the persistent-style edge kernels: enough workgroups for the estimated tile count, capped at
+    // what is co-resident per CU (2 at 64-row tiles, 4 below); surplus tiles are picked up by the loop
+    auto grid_for = [&](double rows, int mt) {
+        const double tiles = rows / mt + 1.0;
+        const int cap = (mt >= 64 ? 2 : 4) * h->n_cus;
+        int g = (int)(tiles * 1.25) + 8;
+        return g < h->n_cus / 4 ? h->n_cus / 4 : (g > cap ? cap : g);
+    };
+    h->edge_grid = grid_for(e_est, h->edge_mt);
+    h->coord_grid = grid_for(ec_est, h->coord_mt);
+    if (opt_set(h, "edge_wgs_per_cu")) h->edge_grid = (int)opt_of(h, "edge_wgs_per_cu", 2) * h->n_cus;
+    if (opt_set(h, "coord_wgs_per_cu")) h->coord_grid = (int)opt_of(h, "coord_wgs_per_cu", 2) * h->n_cus;
+    if (h->node_mt != 64 && h->node_mt != 32 && h->node_mt != 16) h->node_mt = 64;
+    for (int* m : {&h->edge_mt, &h->coord_mt}) if (*m != 128 && *m != 64 && *m != 32 && *m != 16) *m = 64;     // 128: kernels_edge128.hip
+}
+
 static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, const int64_t* npk, bool on_stream, hipStream_t stream);
 extern "C" int cmdgen_set_layout(cmdgen_handle* h, int64_t batch, const int64_t* nph, const int64_t* npk) {
     return set_layout_impl(h, batch, nph, npk, false, nullptr);
@@ -423,9 +476,7 @@ static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, 
         ALLOC(w.pocketEns, int, cB, true); ALLOC(w.pocketEnsQ, int, cB, true);
         ALLOC(w.erow, int, ce, false); ALLOC(w.ecol, int, ce, false); ALLOC(w.ed0, float, ce, false); ALLOC(w.ehop, int, ce, false);
         ALLOC(w.crow, int, cec, false); ALLOC(w.ccol, int, cec, false); ALLOC(w.cd0, float, cec, false);
-        ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true); ALLOC(w.sync, int, 4, true);
-        // exchange buffers of k_node_pair: one pair of workgroups per two CUs at most (64 KB + two flags per pair)
-        ALLOC(w.pair_scratch, float, (size_t)(h->n_cus / 2) * 2 * 32 * H, true); ALLOC(w.pair_flags, int, (size_t)(h->n_cus / 2) * 2, true);
+        ALLOC(w.totals, int, 4, true); ALLOC(w.counters, unsigned long long, 8, true); ALLOC(w.nan_flag, int, 4, true);
         ALLOC(w.eps_tmp, float, (size_t)cNl * (3 + d.P), true);
         ALLOC(w.dbg, unsigned long long, 64, true);
 #undef ALLOC
@@ -470,53 +521,8 @@ static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, 
         }
     }
     h->ecap = ecap; h->eccap = eccap;
-    {   // Rows per tile: the largest tile that still gives every CU a few workgroups.  Edge counts are only known on
-        // the device, so they are estimated from the layout for the geometry a trained model holds and every chain starts
-        // from - the phar points inside the pocket (measured on CrossDocked-shaped pockets, bench.py's steady_state_evaluation:
-        // C-alpha 9.2 neighbours per node within 6 A and 15 coordinate edges per phar node; full-atom 36 and 54).  A chain of
-        // an untrained model drifts to fewer edges; the persistent edge grids just find fewer tiles then.
-        double e_est = 0.0, ec_est = 0.0;
-        for (int b = 0; b < B; ++b) {
-            const double n = (double)(nph[b] + npk[b]);
-            const bool full = h->cfg.edge_cutoff < 0.f;
-            const double deg = full ? n : (n <= 128.0 ? 9.0 : 36.0);
-            const double dnode = deg < n ? deg : n;
-            double dphar = full ? n : 0.6 * (double)nph[b] + (n <= 128.0 ? 0.15 : 0.13) * (double)npk[b];   // receivers that move
-            if (dphar > n) dphar = n;
-            e_est += n * dnode;
-            ec_est += d.joint ? n * dnode : (double)nph[b] * dphar;                   // joint: every receiver moves
-        }
-        // thresholds from sweeps on MI355X (fp32 engine: profiles/r01_tile_sweep.txt; split engine:
-        // profiles/r02_o_tile_sweep_split.txt, r02_z_tiles_trained_geometry.txt)
-        auto pick = [&](double rows) { return rows / 64.0 >= 3.0 * h->n_cus ? 64 : (rows / 32.0 >= 1.5 * h->n_cus ? 32 : 16); };
-        h->node_mt = pick((double)N); h->edge_mt = pick(e_est); h->coord_mt = pick(ec_est);
-        if (h->gemm_split) {
-            // node kernel: 32-row tiles (two LDS images) as soon as they put a workgroup on 0.6 of the CUs (96 C-alpha pockets),
-            // never 64 rows; coordinate kernel: 64-row tiles only for very long lists - its list shrinks to a few tiles when a
-            // chain drifts, and a lone 64-row tile costs 15 us where a 32-row one costs 10
-            h->node_mt = (double)N / 32.0 >= 0.6 * h->n_cus ? 32 : 16;
-            h->coord_mt = ec_est / 64.0 >= 6.0 * h->n_cus ? 64 : (ec_est / 32.0 >= 1.5 * h->n_cus ? 32 : 16);
-        }
-        const char* ev;
-        if ((ev = getenv("CMDGEN_NODE_MT"))) h->node_mt = atoi(ev);
-        if ((ev = getenv("CMDGEN_EDGE_MT"))) h->edge_mt = atoi(ev);
-        if ((ev = getenv("CMDGEN_COORD_MT"))) h->coord_mt = atoi(ev);
-        // grids of the persistent-style edge kernels: enough workgroups for the estimated tile count, capped at
-        // what is co-resident per CU (2 at 64-row tiles, 4 below); surplus tiles are picked up by the loop
-        auto grid_for = [&](double rows, int mt) {
-            const double tiles = rows / mt + 1.0;
-            const int cap = (mt == 64 ? 2 : 4) * h->n_cus;
-            int g = (int)(tiles * 1.25) + 8;
-            return g < h->n_cus / 4 ? h->n_cus / 4 : (g > cap ? cap : g);
-        };
-        h->edge_grid = grid_for(e_est, h->edge_mt);
-        h->coord_grid = grid_for(ec_est, h->coord_mt);
-        if ((ev = getenv("CMDGEN_EDGE_WGS_PER_CU"))) h->edge_grid = atoi(ev) * h->n_cus;
-        if ((ev = getenv("CMDGEN_COORD_WGS_PER_CU"))) h->coord_grid = atoi(ev) * h->n_cus;
-        if (h->node_mt != 64 && h->node_mt != 32 && h->node_mt != 16) h->node_mt = 64;
-        for (int* m : {&h->edge_mt, &h->coord_mt}) if (*m != 128 && *m != 64 && *m != 32 && *m != 16) *m = 64;     // 128: kernels_edge128.hip
-    }
     h->cur_nphar.assign(nph, nph + B); h->cur_npocket.assign(npk, npk + B);
+    pick_tiles(h);
     h->have_layout = true;
     return CMDGEN_OK;
 }
@@ -549,58 +555,88 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.node_mt = h->node_mt; a.edge_mt = h->edge_mt; a.coord_mt = h->coord_mt;
     a.split = h->gemm_split ? 1 : 0;
     a.n_cus = h->n_cus;
-    {   // k_node_mixed (kernels_egnn.hip): +2.4 % on the drifted 64-pocket chain, -0.8 % per evaluation at the geometry a trained model holds
-        // (its pocket tiles then need Q_c: six units on 32 rows) - opt-in: CMDGEN_NODE_MIXED=1 (profiles/r03_u_node_mixed.txt)
-        const char* ev = getenv("CMDGEN_NODE_MIXED"); a.node_mixed = (h->dims.H == 256 && h->gemm_split && !h->dims.joint && ev && atoi(ev) != 0) ? 1 : 0; }
-    { const char* ev = getenv("CMDGEN_EDGE_FULLK"); a.edge_fullk = (h->dims.H == 256 && h->gemm_split && !(ev && atoi(ev) == 0)) ? 1 : 0; }
+    const bool sp256 = h->dims.H == 256 && h->gemm_split;
+    if (!sp256) { if (a.edge_mt == 128) a.edge_mt = 64; if (a.coord_mt == 128) a.coord_mt = 64; }      // the 128-row kernels are split-engine, H = 256
+    a.edge_fullk = (sp256 && opt_of(h, "edge_fullk", 1) != 0) ? 1 : 0;
+    a.e128_wgs = (int)opt_of(h, "e128_wgs_per_cu", 2);
+    a.write_embed = opt_of(h, "write_embed", 1) != 0 ? 1 : 0;
     {   // k_node64 (kernels_node64.hip: 64-row node tiles, the A operand as producer-side bf16 planes, one workgroup per CU) against
         // k_node<H, 32> (register split, two workgroups per CU).  Per launch the 64-row kernel takes ~0.89 of a co-resident pair of
         // 32-row tiles, a 32-row tile alone on its CU ~0.62 of that 64-row tile (profiles/r03_m_node64.txt), so the choice is a matter
-        // of how the tiles fill the CUs: compare the rounds each needs.  CMDGEN_NODE64 = 0 / 1 overrides.
-        const char* ev = getenv("CMDGEN_NODE64");
+        // of how the tiles fill the CUs: compare the rounds each needs.  Option "node64" = 0 / 1 (/ 32: the 32-row planes tile) overrides.
         int on = 0;
-        if (h->dims.H == 256 && h->gemm_split && h->n_cus > 0 && h->have_layout) {
+        if (sp256 && h->n_cus > 0 && h->have_layout) {
             const int ncu = h->n_cus, t64 = (h->lay.N + 63) / 64, t32 = (h->lay.N + 31) / 32;
             const float cost64 = (float)((t64 + ncu - 1) / ncu);
             const int full = t32 / (2 * ncu), rem = t32 - full * 2 * ncu;
             const float cost32 = 1.12f * full + (rem == 0 ? 0.f : rem <= ncu ? 0.62f : 1.12f);
             on = cost64 < cost32;
-            if (ev) on = atoi(ev) == 32 ? 32 : atoi(ev) != 0;
+            if (opt_set(h, "node64")) { const int64_t v = opt_of(h, "node64", 0); on = v == 32 ? 32 : v != 0; }
         }
         a.node64 = on;
-        { const char* dv = getenv("CMDGEN_DEAD_SKIP"); a.dead_skip = h->dims.joint ? 0 : dv ? atoi(dv) : 2; }       // 2 (default): every block by hop level; 1: the last block only; 0: off (CMDGEN_DEAD_SKIP)
-        if (!on && !a.node_mixed && !a.dead_skip) a.w.need_qc = nullptr;
+        a.dead_skip = h->dims.joint ? 0 : (int)opt_of(h, "dead_skip", 2);      // 2 (default): every block by hop level; 1: the last block only; 0: off
+        if (!on && !a.dead_skip) a.w.need_qc = nullptr;
         a.w.hop_levels = a.dead_skip >= 2 ? h->dims.L : 1;
-        if (!a.dead_skip) a.w.ehop = nullptr; }         // the graph pass fills the flags only for the kernels that read them (k_node64, k_node_mixed)
-    {   // k_node_pair (kernels_node_pair.hip: two workgroups share a 32-row tile by output columns, half the weight bytes per CU, one
-        // 32 KB exchange through L2): parity-green, 30.5 us against 30.2 us for the 16-row kernel at 64 pockets - the chip's L2 delivers
-        // ~17-22 TB/s to 236 CUs together, and what the halved stream saves the exchange and the doubled tile load give back
-        // (profiles/r03_k_node_pair.txt).  Opt-in: CMDGEN_NODE_PAIR=1.
-        const char* ev = getenv("CMDGEN_NODE_PAIR"); a.node_pair = (h->dims.H == 256 && h->gemm_split && h->node_mt == 16 && ev && atoi(ev) != 0) ? 1 : 0;
-        a.pair_cap = h->n_cus / 2; }
-    {   // k_coord_proj (library built with -DCMDGEN_EXPERIMENTS=1 only): the next block's P | Q projections as column-sliced tiles beside the coordinate tiles
-        const char* ev = getenv("CMDGEN_PROJ_SPLIT");
-        a.proj_split = (h->dims.H == 256 && h->gemm_split && !h->dims.joint && ev && atoi(ev) != 0) ? 1 : 0;      // measured: +1 % at B=64, -3.6 % at B=256 (profiles/r03_f): off
-        ev = getenv("CMDGEN_PROJ_MT"); a.proj_mt = ev ? atoi(ev) : 32;
+        if (!a.dead_skip) a.w.ehop = nullptr;           // the graph pass fills the flags only for the kernels that read them
     }
-    {   // k_coord_msg (coordinate update of block l-1 + messages of block l in one launch): measured and OFF by default -
-        // the tiles that wait are the launch's critical path (coordinate chain + message chain in series, exactly as two
-        // launches), and at the trained geometry every message tile waits: profiles/r03_c_merged_coord_msg.txt
-        const char* ev = getenv("CMDGEN_MERGE_COORD"); a.merge_coord = (h->dims.H == 256 && ev && atoi(ev) != 0) ? 1 : 0; }
-    {   // 16-row node tiles on the split engine too (v_mfma_f32_16x16x32_bf16; H >= 128): k_node<256,16> 35.0 -> 31.4 us at B=64 -
-        // bound by the 6 B/weight stream of one workgroup per 16 rows, not by the matrix pipe (profiles/r03_b_*); CMDGEN_NODE16_SPLIT=0 opts out
-        const char* ev = getenv("CMDGEN_NODE16_SPLIT"); a.split16 = (a.split && h->dims.H >= 128 && !(ev && atoi(ev) == 0)) ? 1 : 0; }
+    // 16-row node tiles on the split engine too (v_mfma_f32_16x16x32_bf16; H >= 128): k_node<256,16> 35.0 -> 31.4 us at B=64 -
+    // bound by the 6 B/weight stream of one workgroup per 16 rows, not by the matrix pipe (profiles/r03_b_*); option "node16_split" = 0 opts out
+    a.split16 = (a.split && h->dims.H >= 128 && opt_of(h, "node16_split", 1) != 0) ? 1 : 0;
     {   // k_embed: inside a conditional chain only the phar tiles take the full path (the pocket rows come from the per-chain
         // cache), and they are few: 16-row tiles spread them over twice the CUs and halve the two projection passes of each
         // (B=256: 120 tiles of 32 rows 38.6 us -> 240 tiles of 16 rows)
-        const char* ev = getenv("CMDGEN_EMBED_MT");
-        a.embed_mt = ev ? atoi(ev) : (((double)h->lay.Nl / 16.0 <= 2.0 * h->n_cus && !h->dims.joint) ? 16 : a.node_mt);
+        a.embed_mt = (int)opt_of(h, "embed_mt", (((double)h->lay.Nl / 16.0 <= 2.0 * h->n_cus && !h->dims.joint) ? 16 : a.node_mt));
         if (a.embed_mt != 16 && a.embed_mt != 32 && a.embed_mt != 64) a.embed_mt = a.node_mt;
     }
-    // (tiles were chosen for the engine in force at cmdgen_set_layout; after a later cmdgen_set_gemm_mode the node kernel
-    // still avoids its 64-row tiles on the split engine: 87 vs 132 us at B=256, profiles/r02_o_tile_sweep_split.txt)
-    if (a.split && a.node_mt == 64 && !getenv("CMDGEN_NODE_MT")) a.node_mt = 32;
+    // (the node kernel avoids its 64-row register-split tiles on the split engine: 87 vs 132 us at B=256, profiles/r02_o_tile_sweep_split.txt)
+    if (a.split && a.node_mt == 64 && !opt_set(h, "node_mt")) a.node_mt = 32;
     return a;
+}
+
+// ---------------------------------------------------------------------------------
+// options
+// ---------------------------------------------------------------------------------
+static const char* const kOptionKeys[] = {
+    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "edge_fullk", "node64", "node16_split",
+    "dead_skip", "write_embed", "fused_step", "pocket_cache", "graph_steps",
+    "wgrad_split", "wgrad_tile", "wgrad_split_wgs128", "wgrad_split_wgs64", "wgrad_wgs", "dgrad_mt", "dgrad_tail"};
+
+static void drop_graphs(cmdgen_handle* h) {
+    // captured graphs bake the kernel choice in; a replay of the graph destroyed here may still be running
+    hipSetDevice(h->device);
+    if (h->own_stream) hipStreamSynchronize(h->own_stream);
+    if (h->have_layout) hipStreamSynchronize(h->last_stream);
+    if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+    if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
+}
+static void refresh_tune(cmdgen_handle* h) {
+    TrainTune t;
+    t.wgrad_split = (int)opt_of(h, "wgrad_split", t.wgrad_split); t.wgrad_tile = (int)opt_of(h, "wgrad_tile", t.wgrad_tile);
+    t.wgrad_split_wgs128 = (int)opt_of(h, "wgrad_split_wgs128", t.wgrad_split_wgs128); t.wgrad_split_wgs64 = (int)opt_of(h, "wgrad_split_wgs64", t.wgrad_split_wgs64);
+    t.wgrad_wgs = (int)opt_of(h, "wgrad_wgs", t.wgrad_wgs); t.dgrad_mt = (int)opt_of(h, "dgrad_mt", t.dgrad_mt); t.dgrad_tail = (int)opt_of(h, "dgrad_tail", t.dgrad_tail);
+    h->tune = t;
+}
+
+extern "C" int cmdgen_set_option(cmdgen_handle* h, const char* key, int64_t value, int32_t unset) {
+    if (!h || !key) return fail(h, CMDGEN_EINVAL, "null argument");
+    bool known = false;
+    for (const char* k : kOptionKeys) known = known || strcmp(k, key) == 0;
+    if (!known) return fail(h, CMDGEN_EINVAL, "unknown option '%s'", key);
+    drop_graphs(h);
+    if (unset) h->opts.erase(key); else h->opts[key] = value;
+    refresh_tune(h);
+    if (h->have_layout) pick_tiles(h);
+    return CMDGEN_OK;
+}
+
+extern "C" int cmdgen_get_option(cmdgen_handle* h, const char* key, int64_t* value, int32_t* is_set) {
+    if (!h || !key) return fail(h, CMDGEN_EINVAL, "null argument");
+    bool known = false;
+    for (const char* k : kOptionKeys) known = known || strcmp(k, key) == 0;
+    if (!known) return fail(h, CMDGEN_EINVAL, "unknown option '%s'", key);
+    if (value) *value = opt_of(h, key, 0);
+    if (is_set) *is_set = opt_set(h, key) ? 1 : 0;
+    return CMDGEN_OK;
 }
 
 // ---------------------------------------------------------------------------------
@@ -842,27 +878,18 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
     cmdgen_launch_chain_init(h->lay, d, c, pocket_x, pocket_onehot, s);
     // One denoising step = the posterior update fused with pass 1 of the next radius graph (k_step_count), then the
     // evaluation at the new state: pass 2 of the graph (k_edge_write), k_embed, the L blocks,
-    // k_readout.  The chain is: evaluation 0, K x (step + evaluation), decode.  CMDGEN_UNFUSED_STEP=1 restores the
+    // k_readout.  The chain is: evaluation 0, K x (step + evaluation), decode.  Option "fused_step" = 0 restores the
     // separate k_ddpm_step / k_edge_count launches on one stream (A/B measurements).
-    const bool fused = getenv("CMDGEN_UNFUSED_STEP") == nullptr;
-    if (!getenv("CMDGEN_NO_POCKET_CACHE") && h->lay.Np > 0) {
+    const bool fused = opt_of(h, "fused_step", 1) != 0;
+    if (opt_of(h, "pocket_cache", 1) != 0 && h->lay.Np > 0) {
         // chain-invariant work once per chain: the pocket's features are fixed, so k_embed's output for pocket rows is
         // affine in the time feature - two embed-only passes (t = 0, t = 1) give the cache every later evaluation reads
         cmdgen_build_pocket_cache(a, c.z_phar, c.xh_pocket, h->pk_t01, h->pk_c, h->pk_P0, h->pk_Q0, h->pk_dh, h->pk_dP, h->pk_dQ, s);
         a.pcache = PocketCache{h->pk_c, h->pk_P0, h->pk_Q0, h->pk_dh, h->pk_dP, h->pk_dQ};
     }
     EvalLaunch a2 = a;
-    if (fused) {
-        if (!h->side_stream) {
-            HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-            HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        }
-        // measured (profiles/r02_b_step_fusion.txt): the fork / join costs ~23 us per step inside the replayed graph,
-        // far more than the 10 us of k_edge_write it hides - off unless asked for
-        if (getenv("CMDGEN_SIDE_STREAM")) { a.side = h->side_stream; a.ev_fork = h->ev_fork; a.ev_join = h->ev_join; }
-        a2 = a; a2.skip_count = 1;
-    }
+    if (fused) { a2 = a; a2.skip_count = 1; }         // (pass 2 of the graph on a side stream was measured and dropped: the fork / join costs ~23 us per
+                                                      // step inside the replayed graph, far more than the 10 us it hides; profiles/r02_b_step_fusion.txt)
     cmdgen_launch_eval(a, c.z_phar, c.xh_pocket, nullptr, c.coef, c.state, h->work.eps_tmp, nullptr, s, nullptr);   // evaluation 0 (t = 1)
     auto one_step = [&](hipStream_t ss) {
         if (fused) cmdgen_launch_step_count(h->lay, d, c, h->work, h->work.eps_tmp, ss);
@@ -877,8 +904,7 @@ extern "C" int cmdgen_sample_chain(cmdgen_handle* h, const float* pocket_x, cons
         }
         // G identical steps per graph launch amortise the per-replay floor (~10-16 us host side, a few us of
         // device idle): the step index lives on the device, so a G-step graph is just G copies of the step.
-        const char* gs = getenv("CMDGEN_GRAPH_STEPS");
-        int G = gs ? atoi(gs) : 8;
+        int G = (int)opt_of(h, "graph_steps", 8);
         if (G < 1) G = 1;
         if (G > K) G = K;
         if (h->step_graph && h->graph_steps != G) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
@@ -1093,8 +1119,7 @@ extern "C" int cmdgen_joint_chain(cmdgen_handle* h, const float* phar_x, const f
     if (use_graph) {
         // as in cmdgen_sample_chain: the op index lives on the device, so G captured steps replay for any position
         const void* key[6] = {noise, z_steps_out, (const void*)s, phar_fixed, pocket_fixed, nullptr};
-        const char* gs = getenv("CMDGEN_GRAPH_STEPS");
-        int G = gs ? atoi(gs) : 8;
+        int G = (int)opt_of(h, "graph_steps", 8);
         if (G < 1) G = 1;
         if (G > n_steps) G = n_steps;
         if (h->joint_graph && (memcmp(key, h->jg_key, sizeof key) != 0 || h->jg_seed != seed || h->jg_steps != G)) {
@@ -1145,8 +1170,6 @@ extern "C" int cmdgen_chain_status(cmdgen_handle* h, float* max_rel, float* max_
     unsigned long long cnt[8];
     HIPCHK(h, hipMemcpy(cnt, h->work.counters, sizeof cnt, hipMemcpyDeviceToHost));
     if (nan_resets) *nan_resets = (int64_t)cnt[4];
-    if (cnt[5] != 0)        // k_coord_msg: a message tile gave up waiting for the coordinate sums of its own launch (never seen; would mean wrong positions)
-        return fail(h, CMDGEN_EHIP, "k_coord_msg: %llu waits for the in-launch coordinate sums timed out; results of this chain are invalid (CMDGEN_MERGE_COORD=0 disables the merged launch)", cnt[5]);
     return CMDGEN_OK;
 }
 
@@ -1203,13 +1226,9 @@ extern "C" int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar,
 extern "C" int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16) {
     if (!h) return CMDGEN_EINVAL;
     if (h->gemm_split != (split_bf16 != 0)) {
-        // captured graphs bake the kernel choice in; the pocket cache is rebuilt per chain anyway
-        hipSetDevice(h->device);
-        if (h->own_stream) hipStreamSynchronize(h->own_stream);
-        if (h->have_layout) hipStreamSynchronize(h->last_stream);      // a replay of the graph destroyed below may still be running there
-        if (h->step_graph) { hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
-        if (h->joint_graph) { hipGraphExecDestroy(h->joint_graph); h->joint_graph = nullptr; }
+        drop_graphs(h);                 // captured graphs bake the kernel choice in; the pocket cache is rebuilt per chain anyway
         h->gemm_split = split_bf16 != 0;
+        if (h->have_layout) pick_tiles(h);
     }
     return CMDGEN_OK;
 }
@@ -1226,12 +1245,9 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "coord_grid") *value = a.coord_grid;
     else if (k == "gemm_split") *value = a.split;
     else if (k == "node16_split") *value = a.split16;
-    else if (k == "proj_split") *value = a.proj_split;
     else if (k == "node64") *value = a.node64;
     else if (k == "edge_fullk") *value = a.edge_fullk;
     else if (k == "dead_skip") *value = a.dead_skip;
-    else if (k == "node_mixed") *value = (a.node_mixed && a.split16 && a.node_mt == 16 && h->lay.Np > 0 && 2 * ((h->lay.Nl + 15) / 16) + (h->lay.Np + 31) / 32 <= a.n_cus) ? 1 : 0;
-    else if (k == "node_pair") *value = (a.node_pair && 2 * ((h->lay.N + 31) / 32) <= a.n_cus) ? 1 : 0;
     else if (k == "train_edges") *value = h->train_E;
     else if (k == "train_coord_edges") *value = h->train_Ec;
     else return fail(h, CMDGEN_EINVAL, "unknown query '%s'", key);

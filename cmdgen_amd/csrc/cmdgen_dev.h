@@ -117,9 +117,6 @@ struct Work {                   // per-layout workspace; all pointers device
     int*    totals;             // [0]=E, [1]=Ec (coordinate list) of the current evaluation
     unsigned long long* counters;   // cmdgen_counters
     int*    nan_flag;           // [1] set by readout when any velocity is NaN
-    int*    sync;               // [4] [0]: coordinate-role workgroups of the running k_coord_msg launch that have finished (reset by k_node)
-    float*  pair_scratch;       // [pair_cap][2][32][H] partial sums the two halves of a k_node_pair tile exchange (kernels_node_pair.hip)
-    int*    pair_flags;         // [pair_cap][2] "my partial sums are out"; zero between launches
     float*  eps_tmp;            // [Nl][3+P] evaluation output used by the chain
     unsigned long long* dbg;    // [64] diagnostic builds only (-DCMDGEN_STAMPS): summed in-kernel cycle stamps
 };
@@ -187,6 +184,15 @@ struct TrainSave {              // activation store of the TRAINING forward (cmd
     size_t ecap, eccap;                         // row capacities of the per-block edge arrays
 };
 
+struct TrainTune {              // launch choices of the training step's gradient kernels (cmdgen_set_option; defaults from sweeps on MI355X)
+    int wgrad_split = -1;       // weight gradients as three-piece split products: -1 = by shape (K >= 32k rows on 128 x 128 tiles), 0 = never, 1 = wherever the shape allows
+    int wgrad_tile = 0;         // 64: never the 128 x 128-tile kernel
+    int wgrad_split_wgs128 = 384, wgrad_split_wgs64 = 512;   // workgroups the split-K factor of the two split kernels aims at
+    int wgrad_wgs = 768;        // ... of the fp32-instruction kernel (3 workgroups of 49 KB LDS per CU; profiles/r02_t3_training_round2.txt)
+    int dgrad_mt = 0;           // rows per tile of the data-gradient kernel: 0 = by row count (64 from 24576 rows), 32, 64
+    int dgrad_tail = 1;         // 1: dpre of an edge list is consumed inside the second-layer data gradient (k_dgrad_tail)
+};
+
 struct EvalLaunch {             // everything one evaluation's launches need (host side)
     Layout lay; Work w; Dims d; SmallW sw;
     const LayerW* layers;       // host array [L]
@@ -201,23 +207,15 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     PocketCache pcache{};       // conditional chains: pocket tiles of k_embed are an axpy from the cache
     int skip_count = 0;         // 1: the radius-graph count pass has run (fused step kernel); 2: both passes have (training)
     int split = 0;              // 1: tiles of >= 32 rows multiply on the bf16 matrix pipe (Eng<MT, true>)
-    int split16 = 0;            // 1: 16-row node tiles too (Eng<16, true>; CMDGEN_NODE16_SPLIT=0 opts out)
-    int merge_coord = 0;        // 1: k_edge_coord(l-1) and k_edge_msg(l) share a launch (k_coord_msg; sampler, H = 256)
+    int split16 = 0;            // 1: 16-row node tiles too (Eng<16, true>; option "node16_split")
     int n_cus = 256;
-    int edge_fullk = 0;         // 1: 32-row edge tiles of the sampler build all 256 columns at once (full-K planes; CMDGEN_EDGE_FULLK=0 opts out)
+    int edge_fullk = 0;         // 1: 32-row edge tiles of the sampler build all 256 columns at once (full-K planes; option "edge_fullk")
     int node64 = 0;             // 1: large batches run k_node as 64-row tiles with both images in LDS (kernels_node64.hip)
-    int node_pair = 0;          // 1: small batches run k_node as pairs of workgroups sharing a 32-row tile by output columns (k_node_pair)
-    int pair_cap = 0;           //    pairs the exchange buffers hold
-    int proj_split = 0;         // 1: the next block's P | Q projections run as column-sliced tiles in the coordinate kernel's launch (k_coord_proj)
-    int proj_mt = 32;           //    rows per projection tile there (32 or 64)
-    int node_mixed = 0;         // 1: small conditional batches run k_node as k_node_mixed (two workgroups per phar tile, 32-row plane tiles for the pocket)
-    int dead_skip = 0;          // 1: the last block of a conditional evaluation skips tiles whose new h nobody reads (CMDGEN_DEAD_SKIP=0 opts out)
+    int dead_skip = 0;          // 2: every block of a conditional evaluation skips tiles whose new h nobody reads (by hop level); 1: the last block only; 0: off (option "dead_skip")
     mutable int live_thr = 0;   // set around a block's launches when that applies: nodes within this many hops of a moving node are still read
-    mutable int coord_zero_rows = 0;  // set behind a k_node_mixed launch: the coordinate kernel zeroes the first rows of agg
-    mutable int node_skip_next = 0;   // set around the k_node launch whose next-block projections moved
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
-    hipStream_t side = nullptr; // when set: k_edge_write runs there, concurrently with k_embed (fork / join by events)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int write_embed = 1;        // 1: pass 2 of the radius graph and k_embed share a launch (k_write_embed) where both fit (option "write_embed")
+    int e128_wgs = 2;           // workgroups per CU of the 128-row edge kernels (kernels_edge128.hip)
 };
 
 // ---------------------------------------------------------------------------------

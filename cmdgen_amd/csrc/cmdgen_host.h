@@ -63,8 +63,6 @@ struct cmdgen_handle {
     hipGraphExec_t step_graph = nullptr;
     hipStream_t own_stream = nullptr;      // used when the caller's stream is the legacy default stream (not capturable)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    hipStream_t side_stream = nullptr;     // k_edge_write next to k_embed (fork / join inside the step)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     const float* graph_noise = nullptr; float* graph_zsteps = nullptr; float* graph_psteps = nullptr; hipStream_t graph_stream = nullptr;
     unsigned long long graph_seed = 0;
     int graph_steps = 0;
@@ -85,6 +83,8 @@ struct cmdgen_handle {
     bool train_bf16 = false;               // GEMM operand precision of the training step (cmdgen_train_set_precision)
     bool agg_dirty = false;                // cmdgen_debug_eval_prefix left segment sums in work.agg
     hipStream_t last_stream = nullptr;     // stream most recently handed to this handle (ordering contract of cmdgen_set_layout)
+    std::map<std::string, int64_t> opts;   // cmdgen_set_option: explicit launch choices of this handle (absent key = the library's own choice)
+    TrainTune tune{};                      // the training step's part of them
     bool kernel_profiling = false;
     std::vector<hipEvent_t> prof_events[3];
 };
@@ -112,3 +112,5 @@ inline void free_pool(std::vector<void*>& pool) { for (void* p : pool) hipFree(p
 int check_ready(cmdgen_handle* h);
 int begin_work(cmdgen_handle* h, hipStream_t s);   // check_ready + device + workspace invariants; remembers the stream
 EvalLaunch make_launch(cmdgen_handle* h);
+inline int64_t opt_of(const cmdgen_handle* h, const char* key, int64_t dflt) { auto it = h->opts.find(key); return it == h->opts.end() ? dflt : it->second; }
+inline bool opt_set(const cmdgen_handle* h, const char* key) { return h->opts.find(key) != h->opts.end(); }

@@ -269,6 +269,7 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
 // GEMM operand precision of the call in progress (TrainState::bf16; the tiny encoder / decoder products with K < 64
 // always run in fp32)
 static thread_local bool g_bf16 = false;
+extern thread_local TrainTune g_train_tune;           // kernels_train.hip
 static inline bool use_bf16(int K) { return g_bf16 && K >= 64; }
 
 // y[M, out] = x[M, in(ldx)] W^T + b      (W, b inside the flat buffer)
@@ -325,13 +326,14 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     // radius graph (same compact lists as the sampler), then the edge counts come to the host: grids and the
     // activation store are sized from them
     EvalLaunch a = make_launch(h);
+    a.dead_skip = 0; a.w.need_qc = nullptr; a.w.ehop = nullptr; a.w.hop_levels = 1;       // the training forward skips nothing: no hop levels in its graph pass
     cmdgen_launch_edges(a, xh_phar, xh_pocket, s);
     int tot[2];
     HIPCHK(h, hipMemcpyAsync(tot, h->work.totals, sizeof tot, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     const int E = tot[0], Ec = tot[1];
     rc = ensure_edges(h, t, E, Ec); if (rc) return rc;
-    g_bf16 = t->bf16;
+    g_bf16 = t->bf16; g_train_tune = h->tune;
     h->train_E = E; h->train_Ec = Ec;
     t->E = E; t->Ec = Ec; t->theta = theta; t->xh_phar = xh_phar; t->xh_pocket = xh_pocket;
     const Work& w = h->work;
@@ -409,7 +411,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     if (!d_eps_phar || !grad) return fail(h, CMDGEN_EINVAL, "null device pointer");
     hipSetDevice(h->device);
     TrainState* t = h->train;
-    g_bf16 = t->bf16;
+    g_bf16 = t->bf16; g_train_tune = h->tune;
     hipStream_t s = (hipStream_t)stream;
     h->last_stream = s;
     const Dims& d = h->dims;
@@ -479,8 +481,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, Nm, t->dphi, t->dcd, s);
         const size_t pq_floats = (size_t)(t->dQ - t->dP) + NH;                            // dP and dQ, adjacent
         const TrainState::PackBlk& pk = t->pack[l];
-        static const bool no_fuse_tail = getenv("CMDGEN_NO_DGRAD_TAIL") != nullptr;
-        const bool tail_fused = sp && !no_fuse_tail;
+        const bool tail_fused = sp && g_train_tune.dgrad_tail != 0;
         const bool pair = tail_fused;                         // the list's two reductions (head / gate partials, tail partials) as one launch
         // actB <- dpre7, d coord_mlp.4; also clears dP | dQ (hidden_nf is 64, 128 or 256: cmdgen_create)
         tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, pair ? t->part_scratch : t->tail_scratch, grad + b.c4.w, t->dP, pq_floats, s, pair);
@@ -737,6 +738,7 @@ extern "C" int cmdgen_debug_dgrad(cmdgen_handle* h, int32_t M, const float* A0, 
                                   cmdgen_stream stream) {
     if (!h || !A0 || !W0 || !Y || (A1 && !W1) || M < 1 || (pieces != 1 && pieces != 3)) return fail(h, CMDGEN_EINVAL, "bad arguments");
     hipSetDevice(h->device);
+    g_train_tune = h->tune;
     hipStream_t s = (hipStream_t)stream;
     void* packs = nullptr; void* tab = nullptr;
     const size_t pack_bytes = (size_t)256 * 256 * 6;
@@ -763,6 +765,7 @@ extern "C" int cmdgen_debug_wgrad(cmdgen_handle* h, int32_t K, int32_t M, int32_
                                   float* db, int32_t mode, cmdgen_stream stream) {
     if (!h || !dY || !X || !dW || K < 1 || M < 1 || N < 1) return fail(h, CMDGEN_EINVAL, "bad arguments");
     hipSetDevice(h->device);
+    g_train_tune = h->tune;
     WgradBatch one; one.n = 1;
     one.dy[0] = dY; one.x[0] = X; one.dw[0] = dW; one.db[0] = db;
     one.M[0] = M; one.N[0] = N; one.lddy[0] = M; one.ldx[0] = N; one.ldw[0] = N;

@@ -22,7 +22,6 @@
 // to run as long as a receiver's edges span at most two tiles (one float atomic each: commutative).
 #include "cmdgen_dev.h"
 #include <hip/hip_ext.h>
-#include <cstdlib>
 
 namespace {
 
@@ -207,7 +206,9 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
         }
         lds_barrier();
         STAMP(1);
+        __builtin_amdgcn_s_setprio(1);                               // the matrix pipe is the scarce unit: its instructions win the issue arbitration against the partner workgroup's vector phases (+1..2 %, profiles/r04_d)
         gemm_quarter<NMT>(L.planes, lane, q, wb, acc, bs);
+        __builtin_amdgcn_s_setprio(0);
         lds_barrier();                                                                  // every wave is done reading the planes
         STAMP(2);
     }
@@ -468,14 +469,14 @@ __global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, 
 // launchers: true when the 128-row kernels took the launch (H = 256, split engine, sampler)
 bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s) {
     if (a.edge_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[l].W2.ws) return false;
-    const int grid = (getenv("CMDGEN_E128_WGS") ? atoi(getenv("CMDGEN_E128_WGS")) : 2) * a.n_cus;
+    const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 2 ? a.e128_wgs : 2) * a.n_cus;
     if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l], l, a.live_thr);
     else hipLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.live_thr);
     return true;
 }
 bool cmdgen_launch_coord128(const EvalLaunch& a, int l, hipStream_t s) {
     if (a.coord_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[l].W7.ws) return false;
-    const int grid = (getenv("CMDGEN_E128_WGS") ? atoi(getenv("CMDGEN_E128_WGS")) : 2) * a.n_cus;
+    const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 2 ? a.e128_wgs : 2) * a.n_cus;
     if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l], l, 0);
     else hipLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, 0);
     return true;

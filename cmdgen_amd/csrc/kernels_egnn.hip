@@ -20,7 +20,6 @@
 
 #define LDA(H) ((H) + 4)
 
-bool cmdgen_launch_node_pair(const EvalLaunch& a, int l, hipStream_t s);      // kernels_node_pair.hip: k_node for small batches
 bool cmdgen_launch_node64(const EvalLaunch& a, int l, hipStream_t s);         // kernels_node64.hip: k_node for large batches
 bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s);         // kernels_edge128.hip: the edge kernels for long lists (128-row tiles)
 bool cmdgen_launch_coord128(const EvalLaunch& a, int l, hipStream_t s);
@@ -535,17 +534,12 @@ __global__ __launch_bounds__(256) void k_write_embed(Layout lay, Work w, Dims d,
 // the fly (same expression, same bits) by k_edge_msg(l), which runs before it.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 node_pos(const Layout& lay, const Work& w, const Dims& d, int n,
-                                           int layer, bool lazy, bool fresh = false) {
+                                           int layer, bool lazy) {
     if (n >= lay.Nm) return w.XP[n - lay.Nl];
     if (layer == 0) return w.X0[n];
     if (!lazy) return w.XL[(size_t)layer * lay.Nm + n];
     const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nm + n];
-    float4 a;
-    if (fresh) {    // the sums were added by other workgroups of THIS launch (k_coord_msg): L2-served loads (global_load ... sc1)
-        const float* q = reinterpret_cast<const float*>(w.ACC + (size_t)(layer - 1) * lay.Nm + n);
-        a.x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a.y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.z = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a.w = 0.f;
-    } else a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
+    const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
     return make_float4(p.x + a.x / d.norm_factor, p.y + a.y / d.norm_factor, p.z + a.z / d.norm_factor, 0.f);
 }
 
@@ -702,8 +696,8 @@ __device__ __forceinline__ float tile_row_dot(const float* buf, const float* wv,
 // Giving every XCD group one contiguous range of tiles keeps the P/Q rows it gathers (edges are sorted
 // by sample and receiver) inside that L2 instead of spreading every sample over all eight.
 // Placement only affects speed, never results.  Returns the k-th tile of this workgroup or -1.
-__device__ __forceinline__ int xcd_tile(int k, int ntiles, int vb = (int)blockIdx.x, int nb = (int)gridDim.x) {
-    // vb / nb: the workgroup's index / count inside its role (a launch may hold two roles: k_coord_msg); vb % 8 == blockIdx % 8
+__device__ __forceinline__ int xcd_tile(int k, int ntiles) {
+    const int vb = (int)blockIdx.x, nb = (int)gridDim.x;
     const int g = vb & 7;
     const int wg_in_g = vb >> 3;
     const int wgs_in_g = (nb - g + 7) >> 3;                 // workgroups whose blockIdx % 8 == g
@@ -714,22 +708,8 @@ __device__ __forceinline__ int xcd_tile(int k, int ntiles, int vb = (int)blockId
     return tile < ntiles ? tile : -1;
 }
 
-// number of workgroups of a role of nb workgroups that xcd_tile gives at least one of ntiles tiles (the same on every workgroup)
-__device__ __forceinline__ int xcd_active_wgs(int ntiles, int nb) {
-    const int per_g = (ntiles + 7) >> 3;
-    int n = 0;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const int wgs_in_g = (nb - g + 7) >> 3;
-        const int tiles_g = max(0, min(per_g, ntiles - g * per_g));
-        n += min(wgs_in_g, tiles_g);
-    }
-    return n;
-}
-
 // ------------------------------------------------------------------------------------
-// LDS of an edge-tile workgroup, shared by the two edge bodies (a launch that holds both - k_coord_msg - runs them one
-// after the other in the same bytes).
+// LDS of an edge-tile workgroup, shared by the two edge bodies.
 // ------------------------------------------------------------------------------------
 // FK (full-K planes, 32-row tiles of the sampler on the split engine): the A tile is three unpadded [32][256] bf16 planes (48 KB) and the
 // radial / d0 weights live in registers - 51.6 KB in all, three workgroups per CU.
@@ -743,37 +723,20 @@ template <int H, int MT, bool FK = false> struct EdgeLds {
     int s_live[2];                          // last block of a conditional evaluation: does the tile hold a receiver whose h is still read?
 };
 
-// Wait (one lane spins, bounded) until every coordinate-role workgroup of this launch has added its sums: `done` counts
-// them.  A give-up is counted in counters[5] and reported by cmdgen_chain_status - a wrong result, never a hung GPU.
-__device__ __forceinline__ void wait_coord_done(const Work& w, const int* done, int target) {
-    if ((threadIdx.x & 63) == 0) {
-        int it = 0;
-        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++it > (1 << 22)) { atomicAdd(&w.counters[5], 1ull); break; }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // keeps the position loads below the poll (nothing to invalidate: see node_pos)
-}
-
 // ------------------------------------------------------------------------------------
 // edge_msg_body / k_edge_msg: GCL.edge_model + attention gate + segment sum by receiver for MT-edge tiles
 // of the compact list.  Persistent-style grid: tiles are taken round-robin until the
 // device-side edge count is exhausted, so the launch geometry is static (graph-capturable).
-// vb / nb: this workgroup's index / the number of workgroups walking the list.  done != null (k_coord_msg): the
-// coordinate sums of the previous block are being added by workgroups of the SAME launch; a tile that reads positions
-// of moving nodes waits for them first (tiles of pocket-pocket edges do not).
+// live_thr: 0 = every tile; else only tiles with a receiver within that many hops of a moving node (dead work).
 // ------------------------------------------------------------------------------------
 template <int H, int MT, bool SAVE, bool SP, bool FK = false>
 __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
-                                              const int layer, const int ablate, const TrainSave& sv, const int vb, const int nb,
-                                              const int* done, const int done_target) {
+                                              const int layer, const int ablate, const TrainSave& sv, const int live_thr) {
     float* buf = L.buf; int* s_row = L.s_row; int* s_col = L.s_col;
     float* s_r = L.s_r; float* s_d0 = L.s_d0; float* s_att = L.s_att; float* s_wa = L.s_vec; float* s_wrd = L.s_wrd;
     const int tid = threadIdx.x, wave = tid >> 6;
     s_wa[tid] = lw.wa[tid];                                    // visible after the first tile's barriers
     constexpr bool PL = SP && H == 256 && MT >= 32;            // plane variant: the producer splits (build_edge_half)
-    const int live_thr = (ablate >> 6) & 15;                   // 0: every tile; else only tiles with a receiver of hop level <= live_thr
     static_assert(!FK || (PL && MT == 32 && !SAVE), "full-K planes: 32-row sampler tiles on the split engine");
     if constexpr (PL && !FK) { s_wrd[tid] = lw.wr_e[tid]; s_wrd[H + tid] = lw.wd_e[tid]; }
     const ColVec<MT> b2v = col_load<MT>(lw.b2, wave);          // per-column bias and the gate's bias: once per workgroup
@@ -787,7 +750,6 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
                                 // refilled for the next tile by each GEMM's last iteration
     const int E = w.totals[0];
     const int ntiles = (E + MT - 1) / MT;
-    bool coord_seen = done == nullptr || layer == 0;           // wave-uniform: the previous block's coordinate sums are complete
 #if CMDGEN_STAMPS == 1
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_t;
@@ -799,27 +761,22 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
     // build / GEMM, so a tile's first phase starts with the position loads instead of two dependent round trips.
     int nx_row = -1, nx_col = -1, nx_hop = 255; float nx_d0 = 0.f;
     {
-        const int t0 = xcd_tile(0, ntiles, vb, nb);
+        const int t0 = xcd_tile(0, ntiles);
         if (t0 >= 0 && tid < MT && t0 * MT + tid < E) {
             nx_row = w.erow[t0 * MT + tid]; nx_col = w.ecol[t0 * MT + tid]; nx_d0 = w.ed0[t0 * MT + tid];
             if (live_thr) nx_hop = w.ehop[t0 * MT + tid];
         }
     }
-    for (int k = 0, tile; (tile = xcd_tile(k, ntiles, vb, nb)) >= 0; ++k) {
+    for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
         if (tid < MT) {
             const int row = nx_row, col = nx_col, hop = nx_hop; const float d0 = nx_d0;       // -1 / -1 / 255 / 0 beyond the list's end
             nx_row = -1; nx_col = -1; nx_d0 = 0.f; nx_hop = 255;
-            const int tn = xcd_tile(k + 1, ntiles, vb, nb);
+            const int tn = xcd_tile(k + 1, ntiles);
             if (tn >= 0 && tn * MT + tid < E) {
                 nx_row = w.erow[tn * MT + tid]; nx_col = w.ecol[tn * MT + tid]; nx_d0 = w.ed0[tn * MT + tid];
                 if (live_thr) nx_hop = w.ehop[tn * MT + tid];
-            }
-            if (!coord_seen) {
-                // (MT <= 64: these are lanes of wave 0 only) does any edge of the tile end in a node that moves?
-                const bool touch = row >= 0 && (row < lay.Nm || col < lay.Nm);
-                if (__ballot(touch) != 0ull) { wait_coord_done(w, done, done_target); coord_seen = true; }
             }
             if (live_thr) {
                 // A conditional evaluation whose pocket output nobody reads: after the last block only the moving nodes' h and the Q_c rows of
@@ -833,7 +790,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
             if (tid < ne) {
                 // block 0 sees the input positions: its radial IS the d0 the graph pass stored (same dist2, same operands, same
                 // bits) - no position round trip; later blocks form the lazily updated positions (node_pos)
-                r = ((ablate & 1) || layer == 0) ? d0 : dist2(node_pos(lay, w, d, row, layer, true, done != nullptr), node_pos(lay, w, d, col, layer, true, done != nullptr));
+                r = ((ablate & 1) || layer == 0) ? d0 : dist2(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
             }
             s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
         }
@@ -932,19 +889,19 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
 #if CMDGEN_STAMPS == 1
     // lane 0 of every wave of a SAMPLE of the workgroups that had a tile (every 4th: thousands of same-address atomics per launch would
     // sit in front of the next launch's first loads): [wave][phase] sums, [32 + wave] = wave lifetime, [40] = waves, [41] = tile visits
-    if ((tid & 63) == 0 && (vb & 3) == 0 && xcd_tile(0, ntiles, vb, nb) >= 0) {
+    if ((tid & 63) == 0 && (blockIdx.x & 3) == 0 && xcd_tile(0, ntiles) >= 0) {
         for (int i = 0; i < 7; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
         atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
         atomicAdd(&w.dbg[40], 1ull);
-        if (wave == 0) { int nt = 0; while (xcd_tile(nt, ntiles, vb, nb) >= 0) ++nt; atomicAdd(&w.dbg[41], (unsigned long long)nt); }
+        if (wave == 0) { int nt = 0; while (xcd_tile(nt, ntiles) >= 0) ++nt; atomicAdd(&w.dbg[41], (unsigned long long)nt); }
     }
 #endif
 #undef STAMP
 }
 template <int H, int MT, bool SAVE, bool SP, bool FK = false>
-__global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer, int ablate, TrainSave sv) {
+__global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer, int ablate, TrainSave sv, int live_thr) {
     __shared__ __attribute__((aligned(16))) EdgeLds<H, MT, FK> L;
-    edge_msg_body<H, MT, SAVE, SP, FK>(L, lay, w, d, lw, layer, ablate, sv, (int)blockIdx.x, (int)gridDim.x, nullptr, 0);
+    edge_msg_body<H, MT, SAVE, SP, FK>(L, lay, w, d, lw, layer, ablate, sv, live_thr);
 }
 
 // ------------------------------------------------------------------------------------
@@ -954,9 +911,7 @@ __global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_msg(Layout lay, Work w, 
 // evaluation gathers: P_c|Q_c for this block's coord MLP and P|Q for block l+1's edge MLP.
 // ------------------------------------------------------------------------------------
 // node_tile_body: the tile of rows row0 .. min(row0 + MT, row_end) - 1; bufs: (MT <= 32 ? 2 : 1) * MT * LDA(H) floats of LDS.
-// ROLE 0: everything (k_node).  ROLE 1 / 2 (k_node_mixed, phar tiles): TWO workgroups per tile both form h_new; 1 stores it and makes P_c | Q_c,
-// 2 makes P | Q of the next block; neither zeroes the tile's agg rows (both read them: the coordinate kernel that follows does).
-template <int H, int MT, bool SAVE, bool SP, int ROLE = 0>
+template <int H, int MT, bool SAVE, bool SP>
 __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw, const LayerW& lw_next,
                                                const int layer, const int has_next_arg, const TrainSave& sv, const int row0, const int row_end) {
     const int has_next = has_next_arg & 1;                                     // (bits 1.. carry the dead-tile threshold of the plane tiles: unused here)
@@ -979,16 +934,15 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
     const Frag f3a = G::frag(lw.W3, 2 * H / 8, 0, wave), f3b = G::frag(lw.W3, 2 * H / 8, H / 8, wave);
     const Frag f4 = G::frag(lw.W4, H / 8, 0, wave);
     const Frag fn = G::frag(lw_next.Wpq_e, H / 8, 0, wave);
-    const Frag fc = ROLE == 2 ? fn : G::frag(lw.Wpq_c, H / 8, 0, want_pc ? wave : H / 64 + wave);      // the GEMM behind W4
+    const Frag fc = G::frag(lw.Wpq_c, H / 8, 0, want_pc ? wave : H / 64 + wave);      // the GEMM behind W4
     typename G::Carry carry;
     G::prefetch(f3a, carry);
     // every epilogue's bias, fetched now: by the time an epilogue runs its values have long arrived (a load issued where
     // it is used costs that epilogue an L2 round trip: k_node 38.3 -> 34.2 us at B=64)
     const ColVec<MT> b3v = col_load<MT>(lw.b3, wave), b4v = col_load<MT>(lw.b4, wave), b6v = col_load<MT>(lw.b6, wave),
                      b1nv = col_load<MT>(lw_next.b1, wave);
-    if (blockIdx.x == 0 && tid == 0) w.sync[0] = 0;  // the count of finished coordinate-role workgroups of k_coord_msg (the launches before and after this one)
     // materialise the phar coordinates entering this block (see node_pos)
-    if (ROLE != 2 && layer >= 1 && tid < MT) {
+    if (layer >= 1 && tid < MT) {
         const int n = row0 + tid;
         if (tid < nvalid && n < lay.Nm) w.XL[(size_t)layer * lay.Nm + n] = node_pos(lay, w, d, n, layer, true);
     }
@@ -1009,7 +963,7 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
             if (r < nvalid) {
                 float4* g = reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H) + c4;
                 v = *g;
-                if (ROLE == 0) *g = make_float4(0.f, 0.f, 0.f, 0.f);                      // agg is zero between blocks
+                *g = make_float4(0.f, 0.f, 0.f, 0.f);                      // agg is zero between blocks
                 v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
                 if (SAVE) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * H)[c4] = v;
             }
@@ -1040,7 +994,7 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
 #pragma unroll
         for (int pass = 0; pass < MT / 4; ++pass) {
             const int r = pass * 4 + rsub;
-            if (ROLE == 0 && r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
+            if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
             float4 v = av[pass];
             v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
             if (SAVE && r < nvalid) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * H)[c4] = v;
@@ -1083,7 +1037,7 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
             float* hp = w.h + (size_t)(row0 + row) * H + col;
             const float hold = TWO ? buf0[row * LDA(H) + col] : *hp;
             hn = hold + (v + b4v.v[n]);                                                 // residual (egnn_new.py:57)
-            if (MT != 32 && !SAVE && ROLE != 2) *hp = hn;    // 32-row tiles and the training forward store h from the LDS image below, as whole rows
+            if (MT != 32 && !SAVE) *hp = hn;    // 32-row tiles and the training forward store h from the LDS image below, as whole rows
         }
         buf1[row * LDA(H) + col] = hn;
     });
@@ -1102,9 +1056,9 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
     }
     NSTAMP(4);
     // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
-    if (ROLE != 2) tile_project_pq<H, MT, SP>(buf1, lw.Wpq_c, b6v, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
+    tile_project_pq<H, MT, SP>(buf1, lw.Wpq_c, b6v, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
     NSTAMP(5);
-    if (has_next && ROLE != 1) tile_project_pq<H, MT, SP>(buf1, lw_next.Wpq_e, b1nv, w.P, w.Q, row0, nvalid, true, carry, fn);
+    if (has_next) tile_project_pq<H, MT, SP>(buf1, lw_next.Wpq_e, b1nv, w.P, w.Q, row0, nvalid, true, carry, fn);
     NSTAMP(6);
 #if CMDGEN_STAMPS == 2
     if ((tid & 63) == 0) {
@@ -1119,30 +1073,7 @@ template <int H, int MT, bool SAVE, bool SP>
 __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next,
                                                int layer, int has_next, TrainSave sv) {
     __shared__ __attribute__((aligned(16))) float bufs[(MT <= 32 ? 2 : 1) * MT * LDA(H)];
-    node_tile_body<H, MT, SAVE, SP, 0>(bufs, lay, w, d, lw, lw_next, layer, has_next, sv, (int)blockIdx.x * MT, lay.N);
-}
-
-// ------------------------------------------------------------------------------------
-// k_node_mixed (round 3, sampler, H = 256, split engine, conditional model, small batches): k_node's launch at 64 pockets lasts as long as
-// its slowest tiles - the 60 phar tiles, which stream all seven weight units (W3 twice, W4, P_c, Q_c, P, Q of the next block) at ~4.3 us per
-// unit, while a CU's fill rate and not the matrix pipe sets that price.  Here a phar tile is TWO workgroups that both form h_new (three units)
-// and then split the projections (P_c | Q_c; P | Q of the next block): five units each; the CUs for the 60 extra workgroups come from the
-// pocket rows, which run as 32-row plane tiles (cmdgen_node_planes.h: 88 workgroups instead of 176, five or six units each).  Every
-// workgroup of the launch is resident at once (the launcher checks grid <= CUs).  The phar tiles' agg rows are zeroed by the coordinate
-// kernel that follows (both workgroups of a tile read them).  profiles/r03_u_node_mixed.txt.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void k_node_mixed(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next, int n_phar_wgs) {
-    constexpr int LDS_BYTES = (3 * 32 * NPLD + 64) * 2 > 2 * 16 * LDA(256) * 4 ? (3 * 32 * NPLD + 64) * 2 : 2 * 16 * LDA(256) * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-    const int bid = (int)blockIdx.x;
-    if (bid < n_phar_wgs) {
-        float* bufs = reinterpret_cast<float*>(smem);
-        if (!has_next) node_tile_body<256, 16, false, true, 1>(bufs, lay, w, d, lw, lw_next, layer, 0, TrainSave{}, bid * 16, lay.Nl);
-        else if (bid & 1) node_tile_body<256, 16, false, true, 2>(bufs, lay, w, d, lw, lw_next, layer, 1, TrainSave{}, (bid >> 1) * 16, lay.Nl);
-        else node_tile_body<256, 16, false, true, 1>(bufs, lay, w, d, lw, lw_next, layer, 1, TrainSave{}, (bid >> 1) * 16, lay.Nl);
-    } else {
-        node_planes_tile<32>(reinterpret_cast<unsigned short*>(smem), lay, w, d, lw, lw_next, layer, has_next, lay.Nl + (bid - n_phar_wgs) * 32, lay.N);
-    }
+    node_tile_body<H, MT, SAVE, SP>(bufs, lay, w, d, lw, lw_next, layer, has_next, sv, (int)blockIdx.x * MT, lay.N);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1154,12 +1085,7 @@ __global__ __launch_bounds__(256, 1) void k_node_mixed(Layout lay, Work w, Dims 
 // ------------------------------------------------------------------------------------
 template <int H, int MT, bool SAVE, bool SP, bool FK = false>
 __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
-                                                const int layer, const TrainSave& sv, const int vb, const int nb, const int zero_agg_rows = 0) {
-    // behind k_node_mixed: the phar tiles' agg rows are still as the node kernel read them (two workgroups per tile did): zero them for the next block
-    if (zero_agg_rows > 0) {
-        float4* a4 = reinterpret_cast<float4*>(w.agg);
-        for (int i = vb * (int)blockDim.x + (int)threadIdx.x; i < zero_agg_rows * (H / 4); i += nb * (int)blockDim.x) a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+                                                const int layer, const TrainSave& sv) {
     float* buf = L.buf; int* s_row = L.s_row; int* s_col = L.s_col;
     float* s_r = L.s_r; float* s_d0 = L.s_d0; float* s_w5 = L.s_vec; float* s_wrd = L.s_wrd;
     float (*s_cd)[3] = L.s_cd; float (*s_tr)[3] = L.s_tr;
@@ -1178,16 +1104,16 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
     const int ntiles = (E + MT - 1) / MT;
     int nx_row = -1, nx_col = -1; float nx_d0 = 0.f;           // the next tile's triple, one tile ahead (see edge_msg_body)
     {
-        const int t0 = xcd_tile(0, ntiles, vb, nb);
+        const int t0 = xcd_tile(0, ntiles);
         if (t0 >= 0 && tid < MT && t0 * MT + tid < E) { nx_row = w.crow[t0 * MT + tid]; nx_col = w.ccol[t0 * MT + tid]; nx_d0 = w.cd0[t0 * MT + tid]; }
     }
-    for (int k = 0, tile; (tile = xcd_tile(k, ntiles, vb, nb)) >= 0; ++k) {
+    for (int k = 0, tile; (tile = xcd_tile(k, ntiles)) >= 0; ++k) {
         const int e0 = tile * MT;
         const int ne = min(MT, E - e0);
         if (tid < MT) {
             const int row = nx_row, col = nx_col; const float d0 = nx_d0;               // phar receivers, self loops dropped
             nx_row = -1; nx_col = -1; nx_d0 = 0.f;
-            const int tn = xcd_tile(k + 1, ntiles, vb, nb);
+            const int tn = xcd_tile(k + 1, ntiles);
             if (tn >= 0 && tn * MT + tid < E) { nx_row = w.crow[tn * MT + tid]; nx_col = w.ccol[tn * MT + tid]; nx_d0 = w.cd0[tn * MT + tid]; }
             float r = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
             if (tid < ne) {
@@ -1267,148 +1193,10 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
     }
 }
 template <int H, int MT, bool SAVE, bool SP, bool FK = false>
-__global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer, TrainSave sv, int zero_agg_rows) {
+__global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer, TrainSave sv) {
     __shared__ __attribute__((aligned(16))) EdgeLds<H, MT, FK> L;
-    edge_coord_body<H, MT, SAVE, SP, FK>(L, lay, w, d, lw, layer, sv, (int)blockIdx.x, (int)gridDim.x, zero_agg_rows);
+    edge_coord_body<H, MT, SAVE, SP, FK>(L, lay, w, d, lw, layer, sv);
 }
-
-#if CMDGEN_EXPERIMENTS      // two merged-launch variants that were measured and lost (profiles/r03_c, r03_f); built only on request
-// ------------------------------------------------------------------------------------
-// k_coord_msg: the coordinate update of block l-1 and the edge messages of block l in ONE launch (sampler, H = 256).
-// Between them lies only a data dependency on the coordinate sums - not on every tile: workgroups [0, n_coord) first walk
-// the coordinate list and count themselves done (their float atomics drained); then EVERY workgroup walks the message list,
-// and only a tile that touches a moving node waits for that count (tiles of pocket-pocket edges start at once).  A chain
-// of an untrained model drifts to a handful of coordinate edges: their 8.5 us latency chain used to be a launch of its own.
-// The grid is at most two workgroups per CU (what __launch_bounds__(256, 2) guarantees co-resident), so every
-// coordinate-role workgroup is running or done when anyone waits; the wait is bounded all the same (wait_coord_done).
-// k_node of the block in between resets the count.
-// ------------------------------------------------------------------------------------
-template <int MTE, int MTC, bool SPE, bool SPC>
-__global__ __launch_bounds__(256, 2) void k_coord_msg(Layout lay, Work w, Dims d, LayerW lw_c, LayerW lw_m, int layer_m, int n_coord) {
-    union alignas(16) Both { EdgeLds<256, MTE> m; EdgeLds<256, MTC> c; };
-    __shared__ Both L;
-    const int bid = (int)blockIdx.x;
-    const int ntiles_c = (w.totals[1] + MTC - 1) / MTC;
-    if (bid < n_coord && xcd_tile(0, ntiles_c, bid, n_coord) >= 0) {
-        edge_coord_body<256, MTC, false, SPC>(L.c, lay, w, d, lw_c, layer_m - 1, TrainSave{}, bid, n_coord);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's atomics into ACC have been performed
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(w.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // (only workgroups that own a coordinate tile count themselves: a drifted chain has a handful, and hundreds of adds to
-    // one word would take microseconds; every workgroup derives the same target from the list's length)
-    edge_msg_body<256, MTE, false, SPE>(L.m, lay, w, d, lw_m, layer_m, 0, TrainSave{}, bid, (int)gridDim.x, w.sync, xcd_active_wgs(ntiles_c, n_coord));
-}
-
-// ------------------------------------------------------------------------------------
-// k_coord_proj: the coordinate update of block l and the edge-MLP projections P | Q of block l+1 in ONE launch (sampler,
-// H = 256, split engine).  The two do not depend on each other: both read the h that k_node(l) wrote, the coordinate
-// tiles P_c | Q_c, and nothing either writes is read by the other.  What it buys: k_node's 16-row tile streams every weight
-// of its GEMM chain per 16 rows (that stream, not the matrix pipe, is what a small batch's k_node waits for, profiles/r03_b);
-// the P | Q projection here runs as MT-row x 256-column tiles - one weight slice per workgroup, 4x / 2x the rows per byte
-// of weights - beside a coordinate kernel that is a latency chain of a few tiles at this size.
-// Workgroups [0, 4 * ceil(N / MTP)): projection tiles of MTP rows x 128 columns (P low / high half, Q low / high half); the
-// rest: the coordinate list.
-// ------------------------------------------------------------------------------------
-// acc[m] += A(lds fp32 image, rows 32 m .. 32 m + 31) x W^T for ONE 32-column tile of a packed split weight (bp: that tile's
-// k-block 0, this lane), K = 256.  Register split of A as in tile_gemm_rsplit; the weight fragments run THREE k-blocks ahead in
-// a ring of four register sets: a projection tile is one GEMM on a workgroup that is alone on its CU, so nothing but the
-// depth of its own prefetch hides the L2 latency of its weight stream (one k-block ahead: 21 us for a 64-row tile, r03_f).
-template <int NMT>
-__device__ __forceinline__ void proj_gemm(const float* ldsA, const int lda, const sbf16x8* bp, sf32x16 (&acc)[NMT]) {
-    constexpr int KB16 = 16;
-    const int lane = threadIdx.x & 63;
-    const float* ap = ldsA + (lane & 31) * lda + (lane >> 5) * 8;
-    sbf16x8 b[4][3];
-    float4 raw[2][NMT][2];
-    sbf16x8 a[2][NMT][3];
-#define PG_LOADB(SET, KB) _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) b[SET][s_] = bp[(unsigned)(KB) * 192u + s_ * 64];
-#define PG_LOADA(SET, KB) _Pragma("unroll") for (int m = 0; m < NMT; ++m) {                                  \
-        raw[SET][m][0] = *reinterpret_cast<const float4*>(ap + m * 32 * lda + (KB) * 16);                      \
-        raw[SET][m][1] = *reinterpret_cast<const float4*>(ap + m * 32 * lda + (KB) * 16 + 4); }
-#define PG_SPLIT(DST, SET) _Pragma("unroll") for (int m = 0; m < NMT; ++m) split8(raw[SET][m][0], raw[SET][m][1], a[DST][m][0], a[DST][m][1], a[DST][m][2]);
-#define PG_MFMAS(AS, BS) _Pragma("unroll") for (int m = 0; m < NMT; ++m) {                                                              \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][2], b[BS][0], acc[m], 0, 0, 0);                                        \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][1], b[BS][1], acc[m], 0, 0, 0);                                        \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], b[BS][2], acc[m], 0, 0, 0);                                        \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][1], b[BS][0], acc[m], 0, 0, 0);                                        \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], b[BS][1], acc[m], 0, 0, 0);                                        \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][m][0], b[BS][0], acc[m], 0, 0, 0); }
-#define PG_INTERLEAVE() _Pragma("unroll") for (int i = 0; i < NMT * 6; ++i) {                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
-#define PG_BLOCK(I) {                                                                                         \
-        if (kb + (I) + 3 < KB16) { PG_LOADB(((I) + 3) & 3, kb + (I) + 3) }                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        if (kb + (I) + 1 < KB16) { PG_SPLIT(((I) + 1) & 1, ((I) + 1) & 1) }                                   \
-        PG_MFMAS((I) & 1, (I) & 3)                                                                            \
-        PG_INTERLEAVE()                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        if (kb + (I) + 2 < KB16) { PG_LOADA((I) & 1, kb + (I) + 2) } }
-    PG_LOADB(0, 0) PG_LOADB(1, 1) PG_LOADB(2, 2)
-    PG_LOADA(0, 0) PG_LOADA(1, 1)
-    PG_SPLIT(0, 0)
-#pragma unroll 1
-    for (int kb = 0; kb < KB16; kb += 4) { PG_BLOCK(0) PG_BLOCK(1) PG_BLOCK(2) PG_BLOCK(3) }
-#undef PG_LOADB
-#undef PG_LOADA
-#undef PG_SPLIT
-#undef PG_MFMAS
-#undef PG_INTERLEAVE
-#undef PG_BLOCK
-}
-
-// one projection tile: MTP = 32 NMT rows x 128 columns of P (jobs 0, 1) or Q (jobs 2, 3) of the NEXT block, h read from global
-template <int NMT>
-__device__ __forceinline__ void proj_pq_body(float* buf, const Layout& lay, const Work& w, const LayerW& lw_next, const int vb) {
-    constexpr int H = 256, LPR = H / 4, MTP = 32 * NMT;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tile = vb >> 2, job = vb & 3;
-    const int row0 = tile * MTP, nvalid = min(MTP, lay.N - row0);
-    // Wpq_e is [2H out][H in] (rows 0..H-1 -> P, H.. -> Q) in 32-column tiles of 16 k-blocks x 3 pieces x 64 lanes
-    const int nt = job * 4 + wave;
-    const sbf16x8* bp = reinterpret_cast<const sbf16x8*>(lw_next.Wpq_e.ws) + (size_t)nt * (H / 16) * 192 + lane;
-    const int col = (job & 1) * 128 + wave * 32 + (lane & 31);
-    const float bias = job < 2 ? lw_next.b1[col] : 0.f;
-    const int c4 = tid % LPR, rsub = tid / LPR;
-    {
-        float4 hv[MTP / 4];
-#pragma unroll
-        for (int pass = 0; pass < MTP / 4; ++pass) {               // the whole tile in flight, then the LDS writes
-            const int r = pass * 4 + rsub;
-            hv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < nvalid) hv[pass] = reinterpret_cast<const float4*>(w.h + (size_t)(row0 + r) * H)[c4];
-        }
-#pragma unroll
-        for (int pass = 0; pass < MTP / 4; ++pass) *reinterpret_cast<float4*>(buf + (pass * 4 + rsub) * LDA(H) + 4 * c4) = hv[pass];
-    }
-    lds_barrier();
-    sf32x16 acc[NMT];
-#pragma unroll
-    for (int m = 0; m < NMT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
-    proj_gemm<NMT>(buf, LDA(H), bp, acc);
-    float* __restrict__ out = job < 2 ? w.P : w.Q;
-#pragma unroll
-    for (int m = 0; m < NMT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < nvalid) out[(size_t)(row0 + row) * H + col] = acc[m][r] + bias;
-        }
-}
-
-template <int MTC, bool SPC, int MTP>
-__global__ __launch_bounds__(256, 2) void k_coord_proj(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int n_proj) {
-    union alignas(16) Both { EdgeLds<256, MTC> c; float p[MTP * LDA(256)]; };
-    __shared__ Both L;
-    const int bid = (int)blockIdx.x;
-    if (bid < n_proj) proj_pq_body<MTP / 32>(L.p, lay, w, lw_next, bid);
-    else edge_coord_body<256, MTC, false, SPC>(L.c, lay, w, d, lw, layer, TrainSave{}, bid - n_proj, (int)gridDim.x - n_proj);
-}
-
-#endif  // CMDGEN_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------
 // k_readout: embedding_out (drop the time column), decoders, velocity, NaN flag
@@ -1567,7 +1355,7 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
         if (a.split16 && !a.save && a.layers[l].W3.ws16) { launch_node<H, 16, true>(a, l, s); return; }
     }
     const int nt = (a.lay.N + MT - 1) / MT;
-    const int has_next = l + 1 < a.d.L && !a.node_skip_next;       // (skip: the next block's P | Q come from k_coord_proj)
+    const int has_next = l + 1 < a.d.L;
     if (a.save) hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
                                    a.layers[has_next ? l + 1 : l], l, has_next, *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
@@ -1575,93 +1363,34 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
     else hipLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
                             a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1), TrainSave{});
 }
-// k_node_mixed where it applies (see the kernel): conditional sampler, H = 256, split engine with 16-row node tiles, the whole grid resident at once
-static bool launch_node_mixed(const EvalLaunch& a, int l, hipStream_t s) {
-    if (!a.node_mixed || a.save || !a.split || !a.split16 || a.d.H != 256 || a.d.joint || a.node_mt != 16 || a.lay.Np < 1 || a.lay.Nm != a.lay.Nl) return false;
-    if (!a.layers[l].W3.ws16 || !a.layers[l].W3.ws) return false;
-    const int has_next = l + 1 < a.d.L;
-    const int nph = (a.lay.Nl + 15) / 16, npk = (a.lay.Np + 31) / 32;
-    const int n_phar_wgs = has_next ? 2 * nph : nph;
-    if (n_phar_wgs + npk > a.n_cus) return false;
-    if (a.pe_start) hipExtLaunchKernelGGL(k_node_mixed, dim3(n_phar_wgs + npk), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l],
-                                          a.layers[has_next ? l + 1 : l], l, has_next, n_phar_wgs);
-    else hipLaunchKernelGGL(k_node_mixed, dim3(n_phar_wgs + npk), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next, n_phar_wgs);
-    return true;
-}
 template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
     // training forward: the split engine only where the step re-packs split weights (H = 256: edge_mlp.2 / coord_mlp.2)
-    if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save);
+    if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save, 0);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                               a.layers[l], l, a.ablate | (a.live_thr << 6), TrainSave{});
-    else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate | (a.live_thr << 6), TrainSave{});
+                                               a.layers[l], l, a.ablate, TrainSave{}, a.live_thr);
+    else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{}, a.live_thr);
 }
 // 32-row sampler tiles on the split engine: full-K planes (one build, one GEMM per tile; see cmdgen_split.h) unless CMDGEN_EDGE_FULLK=0
 static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.edge_mt != 32) return false;
     if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                          a.layers[l], l, a.ablate | (a.live_thr << 6), TrainSave{});
-    else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate | (a.live_thr << 6), TrainSave{});
+                                          a.layers[l], l, a.ablate, TrainSave{}, a.live_thr);
+    else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{}, a.live_thr);
     return true;
 }
 static bool launch_coord_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.coord_mt != 32) return false;
     if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                          a.layers[l], l, TrainSave{}, a.coord_zero_rows);
-    else hipLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{}, a.coord_zero_rows);
+                                          a.layers[l], l, TrainSave{});
+    else hipLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
     return true;
 }
 template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, SP && H == 256>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save, 0);
+    if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, SP && H == 256>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                               a.layers[l], l, TrainSave{}, a.coord_zero_rows);
-    else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{}, a.coord_zero_rows);
+                                               a.layers[l], l, TrainSave{});
+    else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
 }
-#if CMDGEN_EXPERIMENTS
-// the merged launch exists for the tile pairs cmdgen_set_layout picks on the split engine (everything else: two launches)
-template <int H> static bool launch_coord_msg(const EvalLaunch& a, int l /* block of the messages; < 0: only say whether the pair exists */, hipStream_t s) {
-    if constexpr (H != 256) return false;
-    else {
-        if (!a.split) return false;
-        if (l < 0) {
-            const int me = a.edge_mt, mc = a.coord_mt;
-            return (me == 64 && (mc == 64 || mc == 32)) || (me == 32 && (mc == 32 || mc == 16)) || (me == 16 && mc == 16);
-        }
-        const int grid = a.edge_grid < 2 * a.n_cus ? a.edge_grid : 2 * a.n_cus;            // co-resident by __launch_bounds__(256, 2)
-        int n_coord = (a.coord_grid < grid ? a.coord_grid : grid) & ~7;
-        if (n_coord < 8 || grid < 8) return false;
-#define CM(ME, MC, SE, SC) if (a.edge_mt == ME && a.coord_mt == MC) {                                                                         \
-            if (a.pe_start) hipExtLaunchKernelGGL((k_coord_msg<ME, MC, SE, SC>), dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, \
-                                                  a.layers[l - 1], a.layers[l], l, n_coord);                                                   \
-            else hipLaunchKernelGGL((k_coord_msg<ME, MC, SE, SC>), dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l - 1], a.layers[l], l, n_coord); \
-            return true; }
-        CM(64, 64, true, true) CM(64, 32, true, true) CM(32, 32, true, true) CM(32, 16, true, false) CM(16, 16, false, false)
-#undef CM
-        return false;
-    }
-}
-// coordinate tiles + next block's P | Q projection tiles in one launch; MTP from a.proj_mt (32 or 64)
-template <int H> static bool launch_coord_proj(const EvalLaunch& a, int l /* < 0: only say whether the variant exists */, hipStream_t s) {
-    if constexpr (H != 256) return false;
-    else {
-        if (!a.split || !a.layers[0].Wpq_e.ws) return false;
-        if (l < 0) return a.coord_mt == 64 || a.coord_mt == 32 || a.coord_mt == 16;
-        const int mtp = a.proj_mt == 64 ? 64 : 32;
-        const int n_proj = 4 * ((a.lay.N + mtp - 1) / mtp);
-        const int grid = n_proj + a.coord_grid;                 // (n_proj is a multiple of 4; xcd_tile's vb % 8 need not match blockIdx % 8: placement only)
-#define CP(MC, SC, MP) if (a.coord_mt == MC && mtp == MP) {                                                                                      \
-            if (a.pe_start) hipExtLaunchKernelGGL((k_coord_proj<MC, SC, MP>), dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, \
-                                                  a.layers[l], a.layers[l + 1], l, n_proj);                                                       \
-            else hipLaunchKernelGGL((k_coord_proj<MC, SC, MP>), dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[l + 1], l, n_proj); \
-            return true; }
-        CP(64, true, 64) CP(64, true, 32) CP(32, true, 64) CP(32, true, 32) CP(16, false, 64) CP(16, false, 32)
-#undef CP
-        return false;
-    }
-}
-#else
-template <int H> static bool launch_coord_msg(const EvalLaunch&, int, hipStream_t) { return false; }
-template <int H> static bool launch_coord_proj(const EvalLaunch&, int, hipStream_t) { return false; }
-#endif
 // tiles of >= 32 rows run on the split-bf16 engine when the launch asks for it (the training forward: only its two edge
 // kernels, and only when the step re-packed split weights for them - save_split); 16-row tiles are always fp32 MFMA
 // (there the L2 weight stream, not the matrix rate, binds)
@@ -1693,18 +1422,8 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     if (a.skip_count == 2) {          // training forward: the graph was built (and its size read back) before the activation store was sized
         REC(); REC();
         MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
-    } else if (a.side) {
-        // k_embed reads features only, k_edge_write positions and degrees only: they run side by side, and the first
-        // consumer of both (k_edge_msg of block 0) waits for the join
-        hipEventRecord(a.ev_fork, s);
-        hipStreamWaitEvent(a.side, a.ev_fork, 0);
-        hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(gthr), shm, a.side, a.lay, a.w, a.d);
-        hipEventRecord(a.ev_join, a.side);
-        REC(); REC();
-        MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
-        hipStreamWaitEvent(s, a.ev_join, 0);
     } else if (H == 256 && !ev && !a.save && gthr == 256 && shm <= 64 * 1024 && (size_t)emt * 1812 + 1024 + (shm > 12288 ? shm : 12288) <= 160 * 1024 &&
-               !getenv("CMDGEN_NO_WRITE_EMBED")) {      // (static LDS of the embedding body is 1812 B per tile row; one launch must hold both bodies' LDS)
+               a.write_embed) {      // (static LDS of the embedding body is 1812 B per tile row; one launch must hold both bodies' LDS)
         MT_DISPATCH(emt, launch_write_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);       // both in one launch
     } else {
         hipLaunchKernelGGL(k_edge_write, dim3(B), dim3(gthr), shm, s, a.lay, a.w, a.d);
@@ -1712,36 +1431,25 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         MT_DISPATCH(emt, launch_embed, a, xh_phar, xh_pocket, t_arr, coef, chain, s);
     }
     REC();
-    // k_edge_coord(l-1) and k_edge_msg(l) in one launch (k_coord_msg) wherever nothing has to look in between
-    const bool merge = a.merge_coord && !a.save && !ev && a.stop_block < 0 && launch_coord_msg<H>(a, -1, s);
-    // the next block's P | Q projections out of k_node into the coordinate kernel's launch (k_coord_proj)
-    const bool move_proj = !merge && a.proj_split && !a.save && !ev && a.stop_block < 0 && launch_coord_proj<H>(a, -1, s);
-    bool coord_pending = false;              // block l-1's coordinate update has not been launched yet
-    // dead work of the LAST block (conditional sampler, pocket output not asked for): see edge_msg_body / node_tile_body
-    const bool live_last = a.dead_skip && !eps_pocket && !a.save && !a.d.joint && a.stop_block < 0 && a.w.need_qc != nullptr && !merge && !move_proj;
+    // dead work (conditional sampler, pocket output not asked for): see edge_msg_body / cmdgen_node_planes.h
+    const bool live_last = a.dead_skip && !eps_pocket && !a.save && !a.d.joint && a.stop_block < 0 && a.w.need_qc != nullptr;
     for (int l = 0; l < a.d.L; ++l) {
-        a.live_thr = live_last ? (a.dead_skip >= 2 ? a.d.L - l : (l == a.d.L - 1 ? 1 : 0)) : 0;     // dead_skip 1: the last block only; 2: every block
+        a.live_thr = live_last ? (a.dead_skip >= 2 ? a.d.L - l : (l == a.d.L - 1 ? 1 : 0)) : 0;     // dead_skip 1: the last block only; 2: every block (a kernel argument of its own: any n_layers)
         const int stop = a.stop_block == l ? a.stop_stage : 0;        // parity aid: leave intermediates in the workspace
         REC();
         PROF_BEGIN(0);
-        if (coord_pending) launch_coord_msg<H>(a, l, s); else if (!cmdgen_launch_msg128(a, l, s) && !launch_msg_fullk(a, l, s)) MT_DISPATCH(a.edge_mt, launch_msg, a, l, s);
+        if (!cmdgen_launch_msg128(a, l, s) && !launch_msg_fullk(a, l, s)) MT_DISPATCH(a.edge_mt, launch_msg, a, l, s);
         PROF_END();
-        coord_pending = false;
         REC(); REC();
         if (stop == 1) return;
-        a.node_skip_next = move_proj ? 1 : 0;
         PROF_BEGIN(1);
-        a.coord_zero_rows = 0;
-        if (!merge && !move_proj && stop == 0 && launch_node_mixed(a, l, s)) a.coord_zero_rows = a.lay.Nl;      // (the coordinate launch below zeroes the phar rows of agg)
-        else if (!(a.node64 && !move_proj && cmdgen_launch_node64(a, l, s)) && !(a.node_pair && !move_proj && cmdgen_launch_node_pair(a, l, s)))
-            MT_DISPATCH(a.node_mt, launch_node, a, l, s);
+        if (!(a.node64 && cmdgen_launch_node64(a, l, s))) MT_DISPATCH(a.node_mt, launch_node, a, l, s);
         PROF_END();
-        a.node_skip_next = 0;
         REC(); REC();
         if (stop == 2) return;
-        if (merge && l + 1 < a.d.L) coord_pending = true;
-        else if (move_proj && l + 1 < a.d.L) { PROF_BEGIN(2); launch_coord_proj<H>(a, l, s); PROF_END(); }
-        else { PROF_BEGIN(2); if (!cmdgen_launch_coord128(a, l, s) && !launch_coord_fullk(a, l, s)) MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); PROF_END(); }
+        PROF_BEGIN(2);
+        if (!cmdgen_launch_coord128(a, l, s) && !launch_coord_fullk(a, l, s)) MT_DISPATCH(a.coord_mt, launch_coord, a, l, s);
+        PROF_END();
         REC();
         if (stop == 3) return;
     }

@@ -566,15 +566,16 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split128(WgradBatch g, int K, 
 //   156 316                 253              227 / 175                             155 / 103
 // These products are tall and skinny (256 x 256 outputs over 1e4-1e5 rows): operand reads and the split-K atomics bind them, not the
 // matrix pipe.  The 128-tile kernel reads each operand row half as often and wins once K >= ~32k (three pieces) / ~64k (bf16); below
-// that the fp32 instruction (three pieces) and the 64-tile kernel (bf16) stay.  CMDGEN_WGRAD_SPLIT=0: never three pieces; =1: always
-// where the shape allows; CMDGEN_WGRAD_TILE=64: never the 128-tile kernel.
+// that the fp32 instruction (three pieces) and the 64-tile kernel (bf16) stay.  Options (TrainTune, cmdgen_set_option): wgrad_split = 0: never
+// three pieces; = 1: always where the shape allows; wgrad_tile = 64: never the 128-tile kernel.
+thread_local TrainTune g_train_tune;      // set from the handle at every entry of the training step (cmdgen_train.hip)
 void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bool split3 = false, bool force3 = false) {
     if (g.n <= 0 || K <= 0) return;
     int tm = 1, tn = 1;
     for (int p = 0; p < g.n; ++p) { tm = max(tm, (g.M[p] + 63) / 64); tn = max(tn, (g.N[p] + 63) / 64); }
     {
-        static const int env3 = getenv("CMDGEN_WGRAD_SPLIT") ? atoi(getenv("CMDGEN_WGRAD_SPLIT")) : -1;
-        static const bool tile64 = getenv("CMDGEN_WGRAD_TILE") && atoi(getenv("CMDGEN_WGRAD_TILE")) == 64;
+        const int env3 = g_train_tune.wgrad_split;
+        const bool tile64 = g_train_tune.wgrad_tile == 64;
         bool ok64 = true, ok128 = !tile64;
         for (int p = 0; p < g.n; ++p) {
             ok64 = ok64 && g.M[p] % 64 == 0 && g.N[p] % 64 == 0 && g.lddy[p] % 4 == 0 && g.ldx[p] % 4 == 0 &&
@@ -588,7 +589,7 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bo
         if (sp128) {
             int tm = 1, tn = 1, tiles = 0;
             for (int p = 0; p < g.n; ++p) { tm = max(tm, g.M[p] / 128); tn = max(tn, g.N[p] / 128); tiles += (g.M[p] / 128) * (g.N[p] / 128); }
-            static const int wgs = getenv("CMDGEN_WGRAD_SPLIT_WGS") ? atoi(getenv("CMDGEN_WGRAD_SPLIT_WGS")) : 384;
+            const int wgs = g_train_tune.wgrad_split_wgs128;
             int zsplit = (wgs + tiles - 1) / tiles;
             const int max_split = (K + 127) / 128;
             if (zsplit > max_split) zsplit = max_split;
@@ -603,7 +604,7 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bo
         if (sp) {
             int tm = 1, tn = 1;
             for (int p = 0; p < g.n; ++p) { tm = max(tm, g.M[p] / 64); tn = max(tn, g.N[p] / 64); }
-            static const int wgs = getenv("CMDGEN_WGRAD_SPLIT_WGS") ? atoi(getenv("CMDGEN_WGRAD_SPLIT_WGS")) : 512;
+            const int wgs = g_train_tune.wgrad_split_wgs64;
             int zsplit = (wgs + tm * tn * g.n - 1) / (tm * tn * g.n);
             const int max_split = (K + 127) / 128;
             if (zsplit > max_split) zsplit = max_split;
@@ -616,7 +617,7 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bo
             return;
         }
     }
-    static const int target_wgs = getenv("CMDGEN_WGRAD_WGS") ? atoi(getenv("CMDGEN_WGRAD_WGS")) : 768;      // 3 workgroups (49 KB of LDS each) per CU; sweep: profiles/r02_t3_training_round2.txt
+    const int target_wgs = g_train_tune.wgrad_wgs;      // default 768: 3 workgroups (49 KB of LDS each) per CU; sweep: profiles/r02_t3_training_round2.txt
     int zsplit = (target_wgs + tm * tn * g.n - 1) / (tm * tn * g.n);
     const int max_split = (K + 127) / 128;
     if (zsplit > max_split) zsplit = max_split;
@@ -837,8 +838,8 @@ void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1,
                         const float* pre, hipStream_t s, int pieces = 3, const void* W0b = nullptr, float* Yb = nullptr,
                         bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0) {
     if (M <= 0) return;
-    static const char* mt = getenv("CMDGEN_DGRAD_MT");
-    const bool big = force_mt ? force_mt == 64 : (mt ? atoi(mt) == 64 : M >= 24576);     // force_mt: cmdgen_debug_dgrad
+    const int mt = g_train_tune.dgrad_mt;
+    const bool big = force_mt ? force_mt == 64 : (mt ? mt == 64 : M >= 24576);     // force_mt: cmdgen_debug_dgrad
     const int acc = accumulate ? 1 : 0, ny = W0b ? 2 : 1;
 #define DG(MT_, NP_) hipLaunchKernelGGL((k_dgrad_split<MT_, NP_>), dim3((M + MT_ - 1) / MT_, ny), dim3(256), 0, s, M, A0, W0, A1, W1, Y, acc, div, pre, \
                                         W0b, Yb, accumulate_b ? 1 : 0, div_b)

@@ -88,6 +88,8 @@ SYMBOLS = [
     ('cmdgen_profile_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.POINTER(KernelTimes), _vp]),
     ('cmdgen_query', C.c_int, [_vp, C.c_char_p, _i64p]),
     ('cmdgen_set_gemm_mode', C.c_int, [_vp, C.c_int32]),
+    ('cmdgen_set_option', C.c_int, [_vp, C.c_char_p, C.c_int64, C.c_int32]),
+    ('cmdgen_get_option', C.c_int, [_vp, C.c_char_p, _i64p, C.POINTER(C.c_int32)]),
     ('cmdgen_debug_stamps', C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int32]),
     ('cmdgen_time_evaluation', C.c_int, [_vp, _fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
     ('cmdgen_time_edge_kernel', C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp]),
@@ -121,6 +123,22 @@ def load_library():
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# Options every NEW Handle of this process starts with (cmdgen_set_option; the library itself reads no environment variable).
+# The parity tests pin tile sizes through it (monkeypatch.setitem), tools/ and bench.py fill it from their command line.
+DEFAULT_OPTIONS: Dict[str, int] = {}
+
+
+def parse_options(text: str) -> Dict[str, int]:
+    """'edge_mt=128,node64=0' -> {'edge_mt': 128, 'node64': 0}"""
+    out = {}
+    for item in (text or '').replace(';', ',').split(','):
+        item = item.strip()
+        if item:
+            k, v = item.split('=')
+            out[k.strip()] = int(v)
+    return out
 
 
 class Handle:
@@ -162,6 +180,8 @@ class Handle:
         self.cfg = dict(cfg)
         self._layout_key = None
         self.n_phar = self.n_pocket = self.batch = 0
+        for k, v in DEFAULT_OPTIONS.items():
+            self.set_option(k, v)
 
     # ---- helpers
     def _check(self, rc, what):
@@ -537,6 +557,15 @@ class Handle:
     def set_gemm_mode(self, split_bf16: bool) -> None:
         """Matrix engine of tiles of >= 32 rows (sampler and training step): True = split-bf16 (fp32-accurate, default), False = fp32 MFMA."""
         self._check(self.lib.cmdgen_set_gemm_mode(self.h, int(bool(split_bf16))), 'cmdgen_set_gemm_mode')
+
+    def set_option(self, key: str, value: Optional[int]) -> None:
+        """An explicit launch choice of this handle (include/cmdgen_hip.h, cmdgen_set_option); value None = back to the library's own choice."""
+        self._check(self.lib.cmdgen_set_option(self.h, key.encode(), int(value or 0), int(value is None)), 'cmdgen_set_option')
+
+    def get_option(self, key: str) -> Optional[int]:
+        v, isset = C.c_int64(0), C.c_int32(0)
+        self._check(self.lib.cmdgen_get_option(self.h, key.encode(), C.byref(v), C.byref(isset)), 'cmdgen_get_option')
+        return v.value if isset.value else None
 
     def debug_stamps(self, reset: bool = True):
         """Diagnostic builds (-DCMDGEN_STAMPS): the 64 summed in-kernel cycle counters (zero in production builds)."""

@@ -163,8 +163,11 @@ int cmdgen_radius_graph(cmdgen_handle* h, const float* x, const int64_t* counts_
 int cmdgen_debug_eval_prefix(cmdgen_handle* h, const float* xh_phar, const float* xh_pocket, const float* t,
                              int32_t block, int32_t stage, cmdgen_stream stream);
 
-/* Copy an internal activation of the last evaluation to host (parity aid):
- * what = "h" [N, hidden] after the last block, "x" [Nl, 4] final phar coordinates. */
+/* Copy an internal activation of the last evaluation to host (parity aid): what = "h" | "agg" | "P" | "Q" [N, hidden],
+ * "x0" [Nm, 4], "xl" / "acc" [n_layers, Nm, 4].  After a CONDITIONAL evaluation whose pocket output was not requested
+ * (eps_pocket == NULL, every chain) the POCKET rows of h / P / Q are undefined unless option "dead_skip" is 0: blocks skip
+ * tiles whose result nobody reads, so those rows hold a mix of earlier blocks.  Phar rows, agg (zero) and the positions are
+ * always complete; cmdgen_debug_eval_prefix never skips. */
 int cmdgen_debug_read(cmdgen_handle* h, const char* what, float* host, size_t n, cmdgen_stream stream);
 
 /* Fills out_dev[n_nodes * width] with the standard normals the sampler would draw for draw index
@@ -381,7 +384,7 @@ int cmdgen_debug_dgrad(cmdgen_handle* h, int32_t M, const float* A0, const float
 
 /* dW[M,N] += dY^T X (dY dev [K,M], X dev [K,N], both contiguous), db[M] += column sums of dY (db may be NULL), through the
  * training step's weight-gradient launch (test aid).  mode 0 = fp32 instruction, 1 = bf16 operands, 3 = three-piece split
- * (only with CMDGEN_WGRAD_SPLIT=1 in the environment; otherwise as 0). */
+ * where the shape allows, otherwise as 0). */
 int cmdgen_debug_wgrad(cmdgen_handle* h, int32_t K, int32_t M, int32_t N, const float* dY, const float* X, float* dW,
                        float* db, int32_t mode, cmdgen_stream stream);
 
@@ -392,17 +395,39 @@ int cmdgen_debug_wgrad(cmdgen_handle* h, int32_t K, int32_t M, int32_t N, const 
  *       <= 3 * 2^-24 |a||b|, below the fp32 accumulation rounding both engines share) at about twice the delivered
  *       rate of the fp32 matrix instruction; used by tiles of >= 32 rows;
  *   0 = v_mfma_f32_32x32x2_f32 / 16x16x4_f32 everywhere (bitwise an fmaf chain).
- * 16-row tiles (small batches) always use the fp32 instruction.  Environment CMDGEN_GEMM=fp32|split sets the
- * default of new handles.  Changing the mode drops captured step graphs (they are re-captured on the next chain). */
+ * 16-row node tiles use v_mfma_f32_16x16x32_bf16 the same way (option "node16_split"), 16-row edge / embedding tiles
+ * the fp32 instruction.  Changing the mode drops captured step graphs (they are re-captured on the next chain) and
+ * re-picks the tile sizes of the current layout. */
 int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16);
+
+/* Explicit launch choices of ONE handle (measurement, parity tests, A/B runs).  The library reads no environment variable:
+ * everything that used to be a CMDGEN_* switch is a key here.  unset != 0 removes the key (back to the library's own
+ * choice; `value` ignored).  Setting an option drops captured step graphs and re-picks the tiles of the current layout.
+ *   rows per tile        "node_mt" 16|32|64, "edge_mt" / "coord_mt" 16|32|64|128 (128: kernels_edge128.hip, split engine,
+ *                        hidden_nf 256), "embed_mt" 16|32|64
+ *   grids                "edge_wgs_per_cu", "coord_wgs_per_cu" (persistent-style edge grids of the <= 64-row kernels),
+ *                        "e128_wgs_per_cu" 1|2
+ *   kernel variants      "edge_fullk" 0|1 (full-K planes for 32-row edge tiles), "node64" 0|1|32 (64-row planes node kernel;
+ *                        32: its 32-row form), "node16_split" 0|1, "write_embed" 0|1 (graph pass 2 + k_embed in one launch)
+ *   dead work            "dead_skip" 0|1|2 (2, default: every block skips tiles beyond L - l hops of a moving node; 1: the
+ *                        last block only; 0: off)
+ *   chain                "fused_step" 0|1 (posterior step + graph pass 1 in one kernel), "pocket_cache" 0|1, "graph_steps"
+ *                        (denoising steps per captured graph, default 8)
+ *   training step        "wgrad_split" -1|0|1, "wgrad_tile" 0|64, "wgrad_split_wgs128", "wgrad_split_wgs64", "wgrad_wgs",
+ *                        "dgrad_mt" 0|32|64, "dgrad_tail" 0|1   (see TrainTune in csrc/cmdgen_dev.h)
+ * cmdgen_get_option: *value = the stored value, *is_set = 0 when the key is not set (either pointer may be NULL).
+ * Unknown keys: CMDGEN_EINVAL. */
+int cmdgen_set_option(cmdgen_handle* h, const char* key, int64_t value, int32_t unset);
+int cmdgen_get_option(cmdgen_handle* h, const char* key, int64_t* value, int32_t* is_set);
 
 /* Diagnostic builds only (kernels compiled with -DCMDGEN_STAMPS): 64 summed in-kernel cycle stamps of k_edge_msg
  * ([wave][phase], wave lifetimes, wave count); all zero in production builds.  Synchronises the device. */
 int cmdgen_debug_stamps(cmdgen_handle* h, uint64_t* out64, int32_t reset);
 
-/* Launch configuration chosen for the current layout (measurement aid): key = "node_mt" | "edge_mt" | "coord_mt"
+/* Launch configuration in force for the current layout (measurement aid): key = "node_mt" | "edge_mt" | "coord_mt"
  * (rows per tile of the three MFMA kernels), "edge_grid" | "coord_grid" (workgroups of the persistent-style edge
- * kernels), "gemm_split" (the mode above), "train_edges" | "train_coord_edges" (edges of the last cmdgen_train_forward). */
+ * kernels), "gemm_split" (the mode above), "node16_split", "node64", "edge_fullk", "dead_skip" (as resolved from the
+ * options and the layout), "train_edges" | "train_coord_edges" (edges of the last cmdgen_train_forward). */
 int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value);
 
 /* Steady-state timing of one network evaluation (bench.py's trained-geometry micro-benchmark): `graph_len`

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from helpers import load_golden, cases_of, dynamics_case, rms, bounded_case
+from cmdgen_amd import hip_backend
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
 from test_hip_parity_r2 import dev, new_handle, host_step_table, EVAL_TOL
 
@@ -20,11 +21,10 @@ G12 = load_golden('g12_fullsize.npz')
 G13 = load_golden('g13_bounded.npz')
 
 
-def force128(monkeypatch, node_mt=None):
-    monkeypatch.setenv('CMDGEN_EDGE_MT', '128')
-    monkeypatch.setenv('CMDGEN_COORD_MT', '128')
-    if node_mt:
-        monkeypatch.setenv('CMDGEN_NODE_MT', str(node_mt))
+def force128(monkeypatch):
+    """every Handle created from here on starts with these options (hip_backend.DEFAULT_OPTIONS -> cmdgen_set_option)"""
+    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'edge_mt', 128)
+    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'coord_mt', 128)
 
 
 @pytest.mark.parametrize('name', [n for n in cases_of(G2) if '_h256_' in n] + ['G12:dyn_fa366_b2'])
@@ -115,8 +115,8 @@ def test_large_batch_agrees_with_the_64_row_kernels(monkeypatch):
         t = dev(np.full((B,), 0.5, np.float32))
         out = {}
         for mt in ('64', '128'):
-            monkeypatch.setenv('CMDGEN_EDGE_MT', mt); monkeypatch.setenv('CMDGEN_COORD_MT', mt)
             h = new_handle(cfg, sd)
+            h.set_option('edge_mt', int(mt)); h.set_option('coord_mt', int(mt))
             h.set_layout(pb.num_nodes_phar, pb.size)
             assert h.query('edge_mt') == int(mt)
             eps, _ = h.dynamics_forward(xh, xq, t)
@@ -137,7 +137,7 @@ def test_dead_work_skip_with_128_row_tiles(monkeypatch):
     pb = make_pockets(64, 'CA')
     out = {}
     for flag in ('2', '0'):
-        monkeypatch.setenv('CMDGEN_DEAD_SKIP', flag)
+        monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'dead_skip', int(flag))
         h = new_handle(cfg, sd)
         h.set_layout(pb.num_nodes_phar, pb.size)
         h.reset_counters()

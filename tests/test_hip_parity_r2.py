@@ -55,8 +55,8 @@ def test_fullsize_dynamics_forward_every_tile_size(mt, monkeypatch):
     H=256, L=5, against the reference's output; tile sizes of all three MFMA kernels forced in turn."""
     name = 'dyn_fa366_b2'
     if mt is not None:
-        for k in ('CMDGEN_NODE_MT', 'CMDGEN_EDGE_MT', 'CMDGEN_COORD_MT'):
-            monkeypatch.setenv(k, str(mt))
+        for k in ('node_mt', 'edge_mt', 'coord_mt'):
+            monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, k, mt)
     cfg, sd, inp = dynamics_case(G12, name)
     h = new_handle(cfg, sd)                                   # fresh handle: tile sizes are chosen in cmdgen_set_layout
     h.set_layout(G12[name + '/num_nodes_phar'], G12[name + '/pocket_size'])

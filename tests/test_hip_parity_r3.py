@@ -252,7 +252,7 @@ def test_last_block_dead_work_skip_changes_nothing(monkeypatch):
     pb = make_pockets(24, 'CA')
     out = {}
     for flag in ('2', '1', '0'):
-        monkeypatch.setenv('CMDGEN_DEAD_SKIP', flag)
+        monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'dead_skip', int(flag))
         h = new_handle(cfg, sd)
         h.set_layout(pb.num_nodes_phar, pb.size)
         assert h.query('dead_skip') == int(flag)
@@ -282,7 +282,7 @@ def test_node64_skips_dead_tiles_at_256_pockets(monkeypatch):
     pb = make_pockets(256, 'CA')
     out = {}
     for flag in ('2', '0'):
-        monkeypatch.setenv('CMDGEN_DEAD_SKIP', flag)
+        monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'dead_skip', int(flag))
         h = new_handle(cfg, sd)
         h.set_layout(pb.num_nodes_phar, pb.size)
         h.reset_counters()

@@ -2,7 +2,7 @@
 
 Tiles of >= 32 rows multiply every fp32 product as six exact bf16 products accumulated in fp32; 16-row tiles keep
 v_mfma_f32_16x16x4_f32.  Small fixtures pick 16-row tiles by themselves, so these tests FORCE 32- and 64-row tiles
-(CMDGEN_*_MT) to put all three MFMA kernels and k_embed on the split engine, and run the same case on the fp32
+(handle options node_mt / edge_mt / coord_mt, cmdgen_set_option) to put all three MFMA kernels and k_embed on the split engine, and run the same case on the fp32
 engine next to it.  Same tolerances as everywhere else: one evaluation max|d eps| <= 2e-5 * max(1, max|eps|) against the
 reference's output, chains <= 1e-4 A ABSOLUTE coordinate RMS in the bounded regime, types exact.
 """
@@ -22,8 +22,9 @@ G13 = load_golden('g13_bounded.npz')
 
 
 def force_tiles(monkeypatch, mt):
-    for k in ('CMDGEN_NODE_MT', 'CMDGEN_EDGE_MT', 'CMDGEN_COORD_MT'):
-        monkeypatch.setenv(k, str(mt))
+    """every Handle created from here on starts with these options (hip_backend.DEFAULT_OPTIONS -> cmdgen_set_option)"""
+    for k in ('node_mt', 'edge_mt', 'coord_mt'):
+        monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, k, int(mt))
 
 
 @pytest.mark.parametrize('mt', [32, 64])
@@ -140,14 +141,14 @@ def test_joint_model_on_split_engine(mt, monkeypatch):
 # ----------------------------------------------------------------------------- 16-row tiles on the split engine (round 3)
 @pytest.mark.parametrize('name', [n for n in cases_of(G2) if '_h256_' in n or '_h128_' in n])
 def test_node_kernel_16_row_split_tiles_match_reference(name, monkeypatch):
-    """k_node<H, 16> on v_mfma_f32_16x16x32_bf16 (Eng<16, true>, CMDGEN_NODE16_SPLIT=1): every G2 evaluation fixture with
+    """k_node<H, 16> on v_mfma_f32_16x16x32_bf16 (Eng<16, true>, option node16_split = 1): every G2 evaluation fixture with
     H >= 128 against the reference's output, next to the fp32 16-row kernel."""
-    monkeypatch.setenv('CMDGEN_NODE_MT', '16')
+    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'node_mt', 16)
     cfg, sd, inp = dynamics_case(G2, name)
     want = G2[name + '/eps_phar']
     errs = {}
     for s16 in ('1', '0'):
-        monkeypatch.setenv('CMDGEN_NODE16_SPLIT', s16)
+        monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'node16_split', int(s16))
         h = new_handle(cfg, sd)
         h.set_layout(G2[name + '/num_nodes_phar'], G2[name + '/pocket_size'])
         assert h.query('node_mt') == 16
@@ -164,8 +165,8 @@ def test_node_kernel_16_row_split_tiles_match_reference(name, monkeypatch):
 @pytest.mark.parametrize('name', cases_of(G13))
 def test_bounded_chain_with_16_row_split_node_tiles(name, use_graph, monkeypatch):
     """The G13 reference chains (K = 50, K = T = 500) with the node kernel on 16-row split tiles: 1e-4 A absolute."""
-    monkeypatch.setenv('CMDGEN_NODE_MT', '16')
-    monkeypatch.setenv('CMDGEN_NODE16_SPLIT', '1')
+    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'node_mt', 16)
+    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'node16_split', 1)
     cfg, sd, pb, K = bounded_case(G13, name)
     h = new_handle(cfg, sd)
     h.set_layout(pb.num_nodes_phar, pb.size)
@@ -181,72 +182,17 @@ def test_bounded_chain_with_16_row_split_node_tiles(name, use_graph, monkeypatch
     h.close()
 
 
-# ----------------------------------------------------------------------------- k_node_pair (round 3): two workgroups share a 32-row tile
-@pytest.mark.parametrize('name', [n for n in cases_of(G2) if '_h256_' in n])
-def test_node_pair_kernel_matches_reference(name, monkeypatch):
-    """k_node_pair (kernels_node_pair.hip: GEMM1 / projections cut by output columns, GEMM2 by K, partial sums exchanged through
-    L2 between the two workgroups of a pair) against the reference's output on every H = 256 evaluation fixture, next to the
-    single-workgroup 16-row kernel."""
-    cfg, sd, inp = dynamics_case(G2, name)
-    want = G2[name + '/eps_phar']
-    errs = {}
-    for pair in ('1', '0'):
-        monkeypatch.setenv('CMDGEN_NODE_PAIR', pair)
-        h = new_handle(cfg, sd)
-        h.set_layout(G2[name + '/num_nodes_phar'], G2[name + '/pocket_size'])
-        assert h.query('node_pair') == int(pair)
-        for _ in range(3):      # the flags must return to zero between launches: several evaluations in a row
-            eps, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']))
-        torch.cuda.synchronize()
-        errs[pair] = float(np.abs(eps.cpu().numpy() - want).max())
-        h.close()
-    tol = EVAL_TOL * max(1.0, float(np.abs(want).max()))
-    print(f'{name}: max|d eps| pair kernel {errs["1"]:.2e}  16-row kernel {errs["0"]:.2e}  (tolerance {tol:.1e})')
-    assert errs['1'] <= tol and errs['0'] <= tol
-
-
-def test_node_pair_kernel_at_headline_size_equals_single_workgroup_kernel(monkeypatch):
-    """64 pockets (118 pairs = 236 workgroups, one per CU): one evaluation at the trained geometry, pair kernel vs 16-row kernel,
-    and 200 graph-replayed steps with the pair kernel leave no wait that gave up (cmdgen_chain_status would raise)."""
-    from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
-    cfg = ModelConfig(timesteps=1000, noise_precision=0.1, norm_values=(1.0, 0.25))
-    sd = make_state_dict(cfg, seed=0)
-    pb = make_pockets(64, 'CA', n_phar=15)
-    rng = np.random.Generator(np.random.PCG64(5))
-    nl = int(pb.num_nodes_phar.sum())
-    com = np.stack([pb.x[pb.mask == b].mean(0) for b in range(64)])
-    xh = np.concatenate([com[np.repeat(np.arange(64), 15)] + rng.normal(size=(nl, 3)) * 2.0, rng.normal(size=(nl, 8))], 1).astype(np.float32)
-    xq = np.concatenate([pb.x, pb.one_hot / 0.25], 1).astype(np.float32)
-    t = np.full((64, 1), 0.4, np.float32)
-    outs = {}
-    for pair in ('1', '0'):
-        monkeypatch.setenv('CMDGEN_NODE_PAIR', pair)
-        h = new_handle(cfg, sd)
-        h.set_layout(pb.num_nodes_phar, pb.size)
-        assert h.query('node_pair') == int(pair)
-        eps, _ = h.dynamics_forward(dev(xh), dev(xq), dev(t))
-        outs[pair] = eps.cpu().numpy()
-        if pair == '1':
-            h.sample_chain(dev(pb.x), dev(pb.one_hot), 200, noise=None, seed=3, pocket_ids=pb.pocket_index, use_graph=True)
-            st = h.chain_status()           # raises if any in-launch wait timed out
-            assert st['nan_resets'] == 0 and st['max_rel_com_error'] < 1e-2
-        h.close()
-    err = float(np.abs(outs['1'] - outs['0']).max())
-    print(f'pair kernel vs 16-row kernel at 64 pockets: max|d eps| {err:.2e} (max|eps| {np.abs(outs["0"]).max():.2f})')
-    assert err <= EVAL_TOL * max(1.0, float(np.abs(outs['0']).max()))
-
-
 # ----------------------------------------------------------------------------- k_node64 (round 3): 64-row node tiles, both images in LDS
 @pytest.mark.parametrize('name', [n for n in cases_of(G2) if '_h256_' in n] + ['dyn_fa366_b2'])
 def test_node64_kernel_matches_reference(name, monkeypatch):
-    """k_node64 (kernels_node64.hip) forced on (CMDGEN_NODE64=1) against the reference's output: every H = 256 evaluation fixture
+    """k_node64 (kernels_node64.hip) forced on (option node64 = 1) against the reference's output: every H = 256 evaluation fixture
     (ragged tiles, tiles that mix phar and pocket rows) and configs[4]'s shape (762 rows = 12 tiles), next to the 32-row kernel."""
     G = G12 if name.startswith('dyn_fa') else G2
     cfg, sd, inp = dynamics_case(G, name)
     want = G[name + '/eps_phar']
     errs = {}
     for n64 in ('1', '0'):
-        monkeypatch.setenv('CMDGEN_NODE64', n64)
+        monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'node64', int(n64))
         h = new_handle(cfg, sd)
         h.set_layout(G[name + '/num_nodes_phar'], G[name + '/pocket_size'])
         assert h.query('node64') == int(n64)
@@ -263,7 +209,7 @@ def test_node64_kernel_matches_reference(name, monkeypatch):
 @pytest.mark.parametrize('use_graph', [False, True])
 def test_bounded_chain_with_node64(use_graph, monkeypatch):
     """The K = T = 500 reference chain of G13 with the node kernel on 64-row tiles: 1e-4 A absolute, types exact."""
-    monkeypatch.setenv('CMDGEN_NODE64', '1')
+    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'node64', 1)
     name = 'ca_h256_KT_np05'
     cfg, sd, pb, K = bounded_case(G13, name)
     h = new_handle(cfg, sd)
@@ -281,19 +227,18 @@ def test_bounded_chain_with_node64(use_graph, monkeypatch):
 
 
 def test_node64_is_chosen_by_tile_count_and_agrees_with_the_32_row_kernel(monkeypatch):
-    """Without CMDGEN_NODE64 the launcher picks the 64-row kernel where its tiles fill the CUs in fewer rounds (256 C-alpha pockets:
+    """Without the option node64 the launcher picks the 64-row kernel where its tiles fill the CUs in fewer rounds (256 C-alpha pockets:
     236 tiles of 64 rows on 256 CUs), not at the headline size (64 pockets: 59 tiles); a 20-step chain of 256 pockets with it equals
     the 32-row kernel's to the engines' rounding (same pieces, same accumulation order per output tile)."""
     from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
-    monkeypatch.delenv('CMDGEN_NODE64', raising=False)
+    monkeypatch.delitem(hip_backend.DEFAULT_OPTIONS, 'node64', raising=False)
     cfg = ModelConfig(residue_nf=20, timesteps=1000, noise_precision=0.1, norm_values=(1.0, 0.25))
     sd = make_state_dict(cfg, seed=3)
     out = {}
-    for B, env, expect in ((64, None, 0), (256, None, 1), (256, '0', 0)):
-        if env is None: monkeypatch.delenv('CMDGEN_NODE64', raising=False)
-        else: monkeypatch.setenv('CMDGEN_NODE64', env)
+    for B, opt, expect in ((64, None, 0), (256, None, 1), (256, 0, 0)):
         pb = make_pockets(B, 'CA')
         h = hip_backend.Handle(cfg.as_dict(), 0); h.load_state_dict(sd)
+        h.set_option('node64', opt)                                  # None: the library's own choice
         h.set_layout(pb.num_nodes_phar, pb.size)
         if torch.cuda.get_device_properties(0).multi_processor_count == 256: assert h.query('node64') == expect
         if B == 256:
@@ -305,42 +250,3 @@ def test_node64_is_chosen_by_tile_count_and_agrees_with_the_32_row_kernel(monkey
         err = rms(out[1][:, :3], out[0][:, :3])
         print(f'256 pockets, 20 steps: coordinate RMS 64-row vs 32-row node kernel {err:.2e} A (max|x| {np.abs(out[0][:, :3]).max():.1f})')
         assert err <= 2e-5 and np.array_equal(out[1][:, 3:], out[0][:, 3:])
-
-
-# ----------------------------------------------------------------------------- k_node_mixed (round 3, opt-in): two workgroups per phar tile + 32-row plane tiles
-@pytest.mark.parametrize('name', [n for n in cases_of(G2) if '_h256_' in n][:4])
-def test_node_mixed_kernel_matches_reference(name, monkeypatch):
-    """k_node_mixed (CMDGEN_NODE_MIXED=1: the phar tiles' projections split over two workgroups, pocket rows as 32-row plane tiles, the phar
-    rows of agg zeroed by the coordinate kernel) against the reference's output, twice in a row (agg must have been left zero)."""
-    monkeypatch.setenv('CMDGEN_NODE_MIXED', '1')
-    cfg, sd, inp = dynamics_case(G2, name)
-    want = G2[name + '/eps_phar']
-    h = new_handle(cfg, sd)
-    h.set_layout(G2[name + '/num_nodes_phar'], G2[name + '/pocket_size'])
-    assert h.query('node_mixed') == 1
-    for _ in range(2):
-        eps, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']))
-    torch.cuda.synchronize()
-    err = float(np.abs(eps.cpu().numpy() - want).max())
-    print(f'{name}: max|d eps| k_node_mixed {err:.2e}')
-    assert err <= EVAL_TOL * max(1.0, float(np.abs(want).max()))
-    h.close()
-
-
-def test_bounded_chain_with_node_mixed(monkeypatch):
-    """The K = T = 500 reference chain of G13 through k_node_mixed, graph-replayed: 1e-4 A absolute, types exact."""
-    monkeypatch.setenv('CMDGEN_NODE_MIXED', '1')
-    name = 'ca_h256_KT_np05'
-    cfg, sd, pb, K = bounded_case(G13, name)
-    h = new_handle(cfg, sd)
-    h.set_layout(pb.num_nodes_phar, pb.size)
-    assert h.query('node_mixed') == 1
-    h.set_step_table(K, host_step_table(cfg, K))
-    xh_phar, _, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=dev(G13[name + '/noise']), use_graph=True)
-    st = h.chain_status()
-    want = G13[name + '/xh_phar']
-    err = rms(xh_phar[:, :3].cpu().numpy(), want[:, :3])
-    print(f'{name} k_node_mixed: coordinate RMS vs reference {err:.3e} A')
-    assert err <= 1e-4 and np.array_equal(xh_phar[:, 3:].cpu().numpy(), want[:, 3:])
-    assert st['max_rel_com_error'] < 1e-2 and st['nan_resets'] == 0
-    h.close()

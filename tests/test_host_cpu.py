@@ -47,6 +47,14 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(hip_backend.Config) == 19 * 4 and ctypes.sizeof(hip_backend.Counters) == 64
 
 
+def test_library_source_reads_no_environment_variable():
+    """Launch choices are per-handle options (cmdgen_set_option); the C ABI library has no process-global switches."""
+    csrc = os.path.join(ROOT, 'cmdgen_amd', 'csrc')
+    for f in os.listdir(csrc):
+        if f.endswith(('.hip', '.h')):
+            assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
+
+
 def test_product_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip('GPU present')

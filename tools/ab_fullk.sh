@@ -1,7 +1,7 @@
 #!/bin/bash
-# same-box A/B of the full-K plane build of the 32-row edge tiles (CMDGEN_EDGE_FULLK=1 default / 0)
+# same-box A/B of the full-K plane build of the 32-row edge tiles (option edge_fullk = 1 default / 0)
 for i in 1 2; do for F in 1 0; do
-  export CMDGEN_EDGE_FULLK=$F
+  export CMDGEN_OPTIONS=edge_fullk=$F
   timeout -k 10 200 python bench.py --batch 64 --steps 3 --warmup 1 --no-extra-shapes --no-cpu-baseline --north-star-batch 0 2>/dev/null | python -c "
 import sys,json
 d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); pk=d['roofline']['per_kernel']

@@ -1,7 +1,8 @@
 """A/B of the 64-row planes node kernel against the default node kernel over batch sizes: chain throughput (graph-replayed K steps)
-with CMDGEN_NODE64 = 0 / 1.  usage: python tools/ab_node64.py [CA|full] B [B ...]"""
+with option node64 = 0 / 1.  usage: python tools/ab_node64.py [CA|full] B [B ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _opts  # noqa: E401,F401  (CMDGEN_OPTIONS -> handle options)
 import torch
 from cmdgen_amd import hip_backend
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
@@ -14,8 +15,8 @@ for B in [int(a) for a in sys.argv[2:]]:
     x, oh = torch.from_numpy(pb.x).to(dev), torch.from_numpy(pb.one_hot).to(dev)
     row = []
     for v in ('0', '1'):
-        os.environ['CMDGEN_NODE64'] = v
         h = hip_backend.Handle(cfg.as_dict(), 0); h.load_state_dict(make_state_dict(cfg, seed=0))
+        h.set_option('node64', int(v))
         h.set_layout(pb.num_nodes_phar, pb.size)
         h.sample_chain(x, oh, K, seed=1)
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -1,6 +1,7 @@
 """Phase ablation of the edge-message kernel (timing-only; outputs are wrong while a phase is off)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _opts  # noqa: E401,F401  (CMDGEN_OPTIONS -> handle options)
 import torch, numpy as np
 import cmdgen_amd
 from cmdgen_amd import hip_backend

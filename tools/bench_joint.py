@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _opts  # noqa: E401,F401  (CMDGEN_OPTIONS -> handle options)
 import cmdgen_amd  # noqa: E402,F401
 from cmdgen_amd import hip_backend  # noqa: E402
 from cmdgen_amd.synthetic import ModelConfig, make_pockets, make_state_dict  # noqa: E402

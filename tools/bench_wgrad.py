@@ -4,6 +4,7 @@ Single products through cmdgen_debug_wgrad (the step groups the seven node-level
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _opts  # noqa: E401,F401  (CMDGEN_OPTIONS -> handle options)
 from cmdgen_amd import hip_backend  # noqa: E402
 from cmdgen_amd.synthetic import ModelConfig  # noqa: E402
 

@@ -3,6 +3,7 @@
 usage: python tools/concurrent_chains.py [B] [K] [only this number of streams]"""
 import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _opts  # noqa: E401,F401  (CMDGEN_OPTIONS -> handle options)
 import numpy as np, torch
 from cmdgen_amd import hip_backend
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets

@@ -2,6 +2,7 @@
 CMDGEN_LIB=build/libcmdgen_hip_stamps6.so) over repeated evaluations at the geometry a trained model holds.  usage: python tools/e128_stamps.py [B] [CA|full-atom]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _opts  # noqa: E401,F401  (CMDGEN_OPTIONS -> handle options)
 import numpy as np, torch
 from cmdgen_amd import hip_backend
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets

@@ -2,6 +2,7 @@
 CMDGEN_LIB=build/libcmdgen_hip_stamps1.so).  Every 4th workgroup that had a tile reports.  usage: python tools/edge_stamps.py [B] [CA|full-atom] [K]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _opts  # noqa: E401,F401  (CMDGEN_OPTIONS -> handle options)
 import torch, numpy as np
 from cmdgen_amd import hip_backend
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets

@@ -1,6 +1,7 @@
 """Per-phase cycle stamps of k_node64 (diagnostic build: FILE=kernels_node64.hip tools/build_variant.sh stamps5 -DCMDGEN_STAMPS=5 -fno-slp-vectorize)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _opts  # noqa: E401,F401  (CMDGEN_OPTIONS -> handle options)
 import torch, numpy as np
 from cmdgen_amd import hip_backend
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets

@@ -6,7 +6,7 @@ timeout -k 10 500 python -m pytest tests/test_hip_edge128.py -x -q -s > $o/r04_b
 if [ $rc -ne 0 ]; then echo "tests failed rc=$rc"; exit 1; fi
 for a in "256" "64 full-atom" "256 full-atom" "64"; do
   for mt in 64 128; do
-    if [ $mt = 128 ]; then export CMDGEN_EDGE_MT=128 CMDGEN_COORD_MT=128; else unset CMDGEN_EDGE_MT CMDGEN_COORD_MT; fi
+    if [ $mt = 128 ]; then export CMDGEN_OPTIONS=edge_mt=128,coord_mt=128; else unset CMDGEN_OPTIONS; fi
     timeout -k 10 200 python tools/steady_profile.py $a 2>/dev/null | tail -1
   done
 done > $o/r04_b_e128_profile.jsonl

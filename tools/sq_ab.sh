@@ -11,7 +11,7 @@ export CMDGEN_LIB=build/libcmdgen_hip_burst.so
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $o/sq_fa_burst -- python3 bench.py $FA > /dev/null 2>&1; echo rc=$?
 unset CMDGEN_LIB
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $o/sq_ca_n64 -- python3 bench.py $CA > /dev/null 2>&1; echo rc=$?
-export CMDGEN_NODE64=0
+export CMDGEN_OPTIONS=node64=0
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $o/sq_ca_n32 -- python3 bench.py $CA > /dev/null 2>&1; echo rc=$?
-unset CMDGEN_NODE64
+unset CMDGEN_OPTIONS
 for d in sq_fa_pin sq_fa_burst sq_ca_n64 sq_ca_n32; do echo "== $d"; python3 tools/sq_summary.py $o/$d | grep -E "k_edge_msg|k_node|k_edge_coord"; rm -rf $o/$d; done

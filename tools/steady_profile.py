@@ -2,6 +2,7 @@
 `steady_state_evaluation` workload of bench.py, through cmdgen_profile_evaluation (an event pair around every launch)."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _opts  # noqa: E401,F401  (CMDGEN_OPTIONS -> handle options)
 import numpy as np, torch
 import cmdgen_amd
 from cmdgen_amd import hip_backend

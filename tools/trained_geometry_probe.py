@@ -3,6 +3,7 @@
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _opts  # noqa: E401,F401  (CMDGEN_OPTIONS -> handle options)
 from cmdgen_amd import hip_backend
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
 B, T = 64, 1000
