@@ -94,6 +94,7 @@ class HipTrainer:
         self.gemm_dtype = gemm_dtype        # 'bf16': GEMM operands in bf16, fp32 accumulation (mixed precision); default exact fp32
         self.last_info: Dict[str, float] = {}
         self.overlap_allreduce = True       # all-reduce finished gradient chunks behind the rest of the backward pass
+        self.force_collectives = False      # run the data-parallel path (staged backward, chunked all-reduce) even in a ONE-rank process group (RCCL first contact on a one-GPU box)
         self.fused_loss = True              # noising and loss terms as three library launches (cmdgen_train_noise / _loss[_joint])
         self._gamma_host = self._logpn_host = None
         self._last_fused = None
@@ -253,6 +254,11 @@ class HipTrainer:
         import torch.distributed as dist
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def _dp_active(self) -> bool:
+        """Does the step go through the collectives?  (more than one rank - or a one-rank group on request)"""
+        import torch.distributed as dist
+        return self._world() > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized())
+
     def grad_chunks(self):
         """The flat gradient as the contiguous ranges that become final one after the other during the backward pass:
         [(last stage of the pass that completes the range, lo, hi)], back of the buffer first (DDP's reverse-order
@@ -275,7 +281,7 @@ class HipTrainer:
         are queued, so the collective runs behind the remaining differentiation (RCCL on its own stream) and only the
         small head chunk is exposed.  The sum is divided by the world size in ``_allreduce``."""
         self._pending = []
-        if self._world() == 1 or not self.overlap_allreduce:
+        if not self._dp_active() or not self.overlap_allreduce:
             self.h.train_backward(d_eps, self.grad, d_eps_q)
             return
         import torch.distributed as dist
@@ -287,7 +293,7 @@ class HipTrainer:
 
     def _allreduce(self):
         world = self._world()
-        if world > 1:
+        if self._dp_active():
             import torch.distributed as dist
             if self._pending:
                 for work in self._pending:
@@ -301,7 +307,7 @@ class HipTrainer:
         """Every replica starts from rank `src`'s parameters and optimizer state (what DDP does at construction,
         train.py:117-118): replicas built from differently seeded RNGs would otherwise drift apart silently, since
         only gradients are averaged."""
-        if self._world() > 1:
+        if self._dp_active():
             import torch.distributed as dist
             for t in (self.theta, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq):
                 dist.broadcast(t, src=src, group=self.group)

@@ -93,10 +93,11 @@ def exposed_allreduce_ms(tr, batch, dev, reps=5):
         out[label] = 1e3 * float(np.mean(ts[1:]))
     run('overlapped_chunks_ms', True, False)
     run('flat_after_backward_ms', False, False)
-    world = tr._world
+    world, forced = tr._world, tr.force_collectives
     tr._world = lambda: 1                      # the pass without any collective
+    tr.force_collectives = False
     run('no_allreduce_ms', False, True)
-    tr._world = world
+    tr._world, tr.force_collectives = world, forced
     tr.overlap_allreduce = True
     out['exposed_ms'] = out['overlapped_chunks_ms'] - out['no_allreduce_ms']
     out['hidden_ms'] = out['flat_after_backward_ms'] - out['overlapped_chunks_ms']
@@ -116,6 +117,7 @@ def main():
     ap.add_argument('--no-pipeline', action='store_true', help='wait for every step\'s gradient norm before queueing the next step (HipTrainer.pipelined = False)')
     ap.add_argument('--cpu-baseline', action='store_true', help='also time the oracle (torch CPU autograd) on the same batch shape')
     ap.add_argument('--gloo', action='store_true', help='rendezvous over gloo (rehearsal of the multi-rank path on a one-GPU box: all ranks on cuda:0)')
+    ap.add_argument('--force-dist', action='store_true', help='initialise the process group (RCCL) even with one rank and run the staged backward + chunked all-reduce through it (tests/test_hip_rccl.py)')
     ap.add_argument('--profile', action='store_true', help='print the per-kernel time table of 3 steps (torch.profiler)')
     a = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -124,17 +126,20 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo' if a.gloo else 'nccl', **({} if a.gloo else {'device_id': torch.device('cuda', local)}))
     dev = torch.device('cuda', local)
     cfg, model, tr = build_trainer(a.batch, a.representation, a.gemm, dev, pipelined=not a.no_pipeline, mode=a.mode)
     tr.fused_loss = not a.unfused_loss
+    tr.force_collectives = bool(a.force_dist)
+    if dist is not None:
+        tr.broadcast_state(0)
     batches = [synthetic_batch(a.batch, 50000 + 1000 * rank + 100 * i, dev, a.representation) for i in range(4)]
     torch.manual_seed(rank)
-    dt, losses = time_training(tr, batches, a.steps, a.warmup, dev, dist if world > 1 else None)
-    allreduce = exposed_allreduce_ms(tr, batches[0], dev) if world > 1 else None
+    dt, losses = time_training(tr, batches, a.steps, a.warmup, dev, dist)
+    allreduce = exposed_allreduce_ms(tr, batches[0], dev) if dist is not None else None
     if a.profile and rank == 0:
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
@@ -190,6 +195,7 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         print(json.dumps({'metric': 'training complexes/s', 'value': a.batch * world * a.steps / dt, 'n_gpus': world,
+                          'collectives': (dist.get_backend() if dist is not None else None),
                           'ms_per_step': dt / a.steps * 1e3, 'batch_per_gpu': a.batch, 'mode': a.mode, 'fused_loss': bool(tr.fused_loss and tr._fused_ok()), 'dtype': 'f32' if a.gemm == 'fp32' else 'bf16 GEMM operands, f32 accumulate/master',
                           'first_loss': losses[0], 'last_loss': losses[-1], 'cpu_baseline': cpu, 'pipelined': tr.pipelined,
                           'graph_of_last_step': {'nodes': tr.h.n_phar + tr.h.n_pocket, 'edges': tr.h.query('train_edges'),
