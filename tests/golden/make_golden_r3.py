@@ -49,10 +49,10 @@ def sample_index_lists(phar_mask, pocket_mask, B):
     return [np.nonzero(full == b)[0] for b in range(B)]
 
 
-def run_case(mods, name, rep, B, K, T, seed, nseed, window):
+def run_case(mods, name, rep, B, K, T, seed, nseed, window, noise_precision=0.05, norm_values=(1.0, 0.5), coord_gain=1.0):
     cfg = ModelConfig(hidden_nf=256, n_layers=5, residue_nf=20 if rep == 'CA' else 11, timesteps=T,
-                      noise_precision=0.05, norm_values=(1.0, 0.5))
-    ddpm, _ = build_reference_ddpm(mods, cfg, seed, 1.0, HIST)
+                      noise_precision=noise_precision, norm_values=tuple(norm_values))
+    ddpm, _ = build_reference_ddpm(mods, cfg, seed, coord_gain, HIST)
     first = 100 * seed
     pb = make_pockets(B, rep, n_phar=15, first_index=first)
     phar_mask = np.repeat(np.arange(B), pb.num_nodes_phar)
@@ -113,7 +113,8 @@ def run_case(mods, name, rep, B, K, T, seed, nseed, window):
     steps = sorted(ckpt)
     g = {
         'meta': np.asarray([256, 5, B, cfg.residue_nf, seed, K, T, first, nseed, window], dtype=np.int64),
-        'noise_precision': np.asarray(0.05), 'norm_values': np.asarray([1.0, 0.5]),
+        'noise_precision': np.asarray(float(noise_precision)), 'norm_values': np.asarray([float(v) for v in norm_values]),
+        'coord_gain': np.asarray(float(coord_gain)),
         'noise_probe': np.stack(probe).astype(np.float32),
         'xh_phar': xh_phar.numpy(), 'xh_pocket': xh_pocket.numpy(), 'phar_mask': pm.numpy(),
         'ckpt_steps': np.asarray(steps, dtype=np.int64),

@@ -297,3 +297,58 @@ def test_node64_skips_dead_tiles_at_256_pockets(monkeypatch):
     if out['2'][2]: assert on['node_rows_skipped'] > 0
     sc = max(1.0, float(np.abs(out['0'][0][:, :3]).max()))
     assert np.abs(out['2'][0][:, :3] - out['0'][0][:, :3]).max() <= 2e-5 * sc and np.array_equal(out['2'][0][:, 3:], out['0'][0][:, 3:])
+
+
+# ----------------------------------------------------------------------------- G15 (round 4): the SHIPPED schedule, step by step
+G15 = load_golden('g15_shipped_schedule_chain.npz')
+
+
+@pytest.mark.parametrize('engine', ['split', 'fp32'])
+def test_shipped_schedule_chain_per_step_g15(engine):
+    """The REAL reference's K = T = 500 chain under the shipped schedule (noise_precision 1e-5, norm_values [1, 4]; 8 C-alpha pockets, H = 256,
+    L = 5; make_golden_r4.py): with untrained weights the coordinates inflate by 1/alpha_T = 316, so the bound is stated in units of the fp32
+    spacing at the coordinates' magnitude - at EVERY 50-step checkpoint the per-step z (x columns AND the h columns carrying the [1, 4] scaling)
+    agrees with the reference to <= 4 ulp(max|z|) RMS and <= 32 ulp(max|z|) for the worst element, eager and graph; final x likewise, types exact.
+    Every sample kept a cutoff margin > 3e-4 A over the whole chain (fixture), so no edge decision is in question."""
+    name = 'ca_b8_KT500_shipped'
+    H, L, B, R, seed, K, T, first, nseed, window = [int(v) for v in G15[name + '/meta']]
+    cfg = ModelConfig(hidden_nf=H, n_layers=L, residue_nf=R, timesteps=T, noise_precision=float(G15[name + '/noise_precision']),
+                      norm_values=tuple(float(v) for v in G15[name + '/norm_values']))
+    assert cfg.noise_precision == 1e-5 and tuple(cfg.norm_values) == (1.0, 4.0)
+    sd = make_state_dict(cfg, seed=seed, coord_gain=float(G15[name + '/coord_gain']))
+    pb = make_pockets(B, 'CA', n_phar=15, first_index=first)
+    Nl = int(pb.num_nodes_phar.sum())
+    gen = torch.Generator().manual_seed(nseed)
+    noise = torch.stack([torch.randn((Nl, 11), generator=gen) for _ in range(K + 2)])
+    probe = G15[name + '/noise_probe']
+    assert np.array_equal(noise[0, :4].numpy(), probe[0]) and np.array_equal(noise[K + 1, :4].numpy(), probe[1])
+    assert float(G15[name + '/margins'].min()) > 1e-4
+    steps, ck_z = G15[name + '/ckpt_steps'], G15[name + '/ckpt_z']
+    want = G15[name + '/xh_phar']
+    ulp = lambda v: float(2.0 ** (np.floor(np.log2(max(float(v), 1e-30))) - 23))
+    h = new_handle(cfg, sd)
+    h.set_gemm_mode(engine == 'split')
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    h.set_step_table(K, host_step_table(cfg, K))
+    worst = []
+    for use_graph in (False, True):
+        got, got_p, z_steps = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=dev(noise.numpy()), want_steps=True, use_graph=use_graph)
+        st = h.chain_status()
+        assert st['max_rel_com_error'] < 1e-2 and st['nan_resets'] == 0
+        for i, s in enumerate(steps):
+            z = z_steps[int(s) - 1].cpu().numpy().astype(np.float64)
+            for lo, hi, what in ((0, 3, 'x'), (3, 11, 'h')):
+                ref = ck_z[i][:, lo:hi].astype(np.float64)
+                u = ulp(np.abs(ref).max())
+                d = z[:, lo:hi] - ref
+                r, m = float(np.sqrt((d ** 2).mean())) / u, float(np.abs(d).max()) / u
+                worst.append((r, m, int(s), what, use_graph, float(np.abs(ref).max())))
+                assert r <= 4.0 and m <= 32.0, (engine, use_graph, int(s), what, r, m)
+        g = got.cpu().numpy()
+        u = ulp(np.abs(want[:, :3]).max())
+        assert float(np.sqrt(((g[:, :3].astype(np.float64) - want[:, :3]) ** 2).mean())) <= 4.0 * u
+        assert np.array_equal(g[:, 3:], want[:, 3:])
+    r, m, s, what, ug, mag = max(worst)
+    print(f'G15 {engine}: worst checkpoint RMS {r:.2f} ulp (max element {max(w[1] for w in worst):.1f} ulp) at step {s} ({what} columns, max|z| {mag:.1f}); '
+          f'final max|x| {float(np.abs(want[:, :3]).max()):.1f} A')
+    h.close()
