@@ -365,7 +365,7 @@ static void pick_tiles(cmdgen_handle* h) {
     // A/B at 256 C-alpha pockets: messages -3 %, coordinate list -14 %; full-atom pockets: level; profiles/r04_d)
     if (h->gemm_split && d.H == 256) {
         if (e_est / 64.0 >= 4.0 * h->n_cus) h->edge_mt = 128;
-        if (ec_est / 32.0 >= 4.0 * h->n_cus) h->coord_mt = 128;
+        if (ec_est / 32.0 >= 3.0 * h->n_cus) h->coord_mt = 128;      // (from 128 C-alpha pockets: profiles/r04_h)
     }
     h->node_mt = (int)opt_of(h, "node_mt", h->node_mt);
     h->edge_mt = (int)opt_of(h, "edge_mt", h->edge_mt);
