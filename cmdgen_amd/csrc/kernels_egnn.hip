@@ -1176,18 +1176,20 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
             }
         }
         lds_barrier();
-        if (tid < 3) {   // segment sum of the three components in edge order
-            int cur = s_row[0];
-            float sum = 0.f;
-            for (int e = 0; e < ne; ++e) {
+        // Ordered segment sums of the three components: the list is sorted by receiver, so one thread per (row that begins a receiver's run,
+        // component) adds the run in list order.  A run inside the tile is complete: plain store (ACC is zero before the launch); a run that
+        // touches the tile's first or last row may continue in a neighbouring tile: one float atomic (two per receiver at most while a
+        // receiver's edges span two tiles: commutative, so the result does not depend on the order of the workgroups).
+        for (int i = tid; i < 3 * MT; i += H) {             // (H threads per workgroup)
+            const int e = i / 3, comp = i - 3 * e;
+            if (e < ne && (e == 0 || s_row[e] != s_row[e - 1])) {
                 const int rr = s_row[e];
-                if (rr != cur) {
-                    atomicAdd(reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nm + cur) + tid, sum);
-                    cur = rr; sum = 0.f;
-                }
-                sum += s_tr[e][tid];
+                float sum = 0.f;
+                int q = e;
+                for (; q < ne && s_row[q] == rr; ++q) sum += s_tr[q][comp];
+                float* dst = reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nm + rr) + comp;
+                if (e == 0 || q == ne) atomicAdd(dst, sum); else *dst = sum;
             }
-            atomicAdd(reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nm + cur) + tid, sum);
         }
         lds_barrier();
     }

@@ -1,10 +1,18 @@
 #!/bin/bash
-# Same-box A/B of two builds of the library: tools/ab_lib.sh <other .so> [batch sizes...]  (default build vs CMDGEN_LIB=<other>)
+# Same-box A/B of two builds of the library on the per-kernel times of one evaluation at the trained geometry:
+#   tools/ab_lib.sh <other .so> "<B> [rep]" ...      (default build vs CMDGEN_LIB=<other>, two rounds each)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 other=$1; shift
-for i in 1 2; do for L in default $other; do for B in ${@:-64 256}; do
-  if [ $L = default ]; then unset CMDGEN_LIB; else export CMDGEN_LIB=$L; fi
-  timeout -k 10 200 python bench.py --batch $B --steps 3 --warmup 1 --no-extra-shapes --no-cpu-baseline --north-star-batch 0 2>/dev/null | python -c "
+for shape in "$@"; do
+  echo "== $shape"
+  for rep in 1 2; do
+  for L in default $other; do
+    if [ $L = default ]; then unset CMDGEN_LIB; else export CMDGEN_LIB=$L; fi
+    echo -n "[$L] "
+    timeout -k 10 200 python tools/steady_profile.py $shape 2>/dev/null | tail -1 | python -c "
 import sys,json
-d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); pk=d['roofline']['per_kernel']
-print('$L', $B, round(d['value']), 'us per launch over the chain:', {k: round(v['avg_launch_ms'] * 1e3, 2) for k, v in pk.items()})"
-done; done; done
+d=json.loads(sys.stdin.read()); m=d['ms']; l=d['launch']
+print('mt', l['node_mt'], l['edge_mt'], l['coord_mt'], '| msg %.1f node %.1f coord %.1f us/launch | eval %.1f us' % (m['edge_msg_ms']*200, m['node_ms']*200, m['edge_coord_ms']*200, 1e3*(m['edge_build_ms']+m['embed_ms']+m['edge_msg_ms']+m['node_ms']+m['edge_coord_ms']+m['readout_ms'])))"
+  done
+  done
+done
