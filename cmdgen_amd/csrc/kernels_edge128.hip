@@ -26,7 +26,11 @@
 namespace {
 
 constexpr int H = 256;
-constexpr int MT = 128;                 // rows per tile (at most)
+#ifndef CMDGEN_E128_MT
+#define CMDGEN_E128_MT 128
+#endif
+constexpr int MT = CMDGEN_E128_MT;      // rows per tile (at most): 128, 96 or 64
+constexpr int MTL = 128;                // rows the per-tile index arrays hold (the index phase handles two rows per lane of wave 0)
 constexpr int KQ = 64;                  // k-values per build / GEMM pass
 constexpr int PLDA = KQ + 8;            // bf16 per plane row: 144 B, conflict-free ds_read_b128 over 16 consecutive rows
 constexpr int PE = MT * PLDA;           // bf16 per plane
@@ -36,14 +40,14 @@ struct alignas(16) EdgeRec { int row, col; float r, d0; };
 
 struct alignas(16) E128Lds {
     unsigned short planes[3 * PE + 64];         // three bf16 planes of the quarter in flight (+ the A prefetch's overshoot)
-    EdgeRec e[MT];                              // (receiver, sender, radial, d0) of the tile's rows; -1 / -1 / 0 / 0 beyond its end
-    float cd[MT][4];                            // coordinate kernel: coord_diff of the row, later coord_diff * tanh(phi) * range
-    float part[4][MT];                          // the four waves' partial row dots
-    float att[MT];                              // gate of each row
+    EdgeRec e[MTL];                              // (receiver, sender, radial, d0) of the tile's rows; -1 / -1 / 0 / 0 beyond its end
+    float cd[MTL][4];                            // coordinate kernel: coord_diff of the row, later coord_diff * tanh(phi) * range
+    float part[4][MTL];                          // the four waves' partial row dots
+    float att[MTL];                              // gate of each row
     float wrd[2 * H];                           // radial / d0 columns of the first layer
-    int segrow[MT];                             // receiver of each segment of the tile
-    int segstart[MT + 1];                       // first row of each segment (coordinate kernel)
-    unsigned char seg[MT];                      // segment index of each row (255 beyond the tile's end)
+    int segrow[MTL];                             // receiver of each segment of the tile
+    int segstart[MTL + 1];                       // first row of each segment (coordinate kernel)
+    unsigned char seg[MTL];                      // segment index of each row (255 beyond the tile's end)
     int meta[4];                                // [0] segments, [1] live, [2] rows of the tile
 };
 
@@ -439,8 +443,8 @@ __global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, 
             {
                 TileCtx tc; tc.P = P; tc.Q = Q; tc.wb = wb; tc.bias0 = bias0; tc.bias1 = bias1; tc.hv0 = hv0; tc.hv1 = hv1; tc.ba0 = ba0; tc.colw = colw; tc.layer = layer;
                 switch (nmt) {
-                    case 4: tile_compute<COORD, 4>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
-                    case 3: tile_compute<COORD, 3>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
+                    case 4: if constexpr (MT >= 128) tile_compute<COORD, 4>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
+                    case 3: if constexpr (MT >= 96) tile_compute<COORD, 3>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
                     case 2: tile_compute<COORD, 2>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
                     default: tile_compute<COORD, 1>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
                 }
