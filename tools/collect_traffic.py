@@ -23,9 +23,10 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KERNELS = {'edge_msg': 'k_edge_msg', 'node': 'k_node', 'edge_coord': 'k_edge_coord', 'embed': 'k_embed',
-           'readout': 'k_readout', 'ddpm_step': 'k_ddpm_step', 'edge_count': 'k_edge_count', 'edge_write': 'k_edge_write',
-           'step_glue': 'k_step_glue', 'write_embed': 'k_write_embed', 'step_count': 'k_step_count'}
+# kernel key -> substrings of the kernel name (the 128-row edge kernels of kernels_edge128.hip are k_edge128<false> = messages, <true> = coordinates)
+KERNELS = {'edge_msg': ('k_edge_msg', 'k_edge128<false>'), 'node': ('k_node',), 'edge_coord': ('k_edge_coord', 'k_edge128<true>'), 'embed': ('k_embed',),
+           'readout': ('k_readout',), 'ddpm_step': ('k_ddpm_step',), 'edge_count': ('k_edge_count',), 'edge_write': ('k_edge_write',),
+           'write_embed': ('k_write_embed',), 'step_count': ('k_step_count',)}
 
 
 def read_counters(directory):
@@ -38,7 +39,7 @@ def read_counters(directory):
         with open(f, newline='') as fh:
             for row in csv.DictReader(fh):
                 name = row.get('Kernel_Name') or row.get('Kernel-Name') or ''
-                key = next((k for k, pat in KERNELS.items() if pat in name), None)
+                key = next((k for k, pats in KERNELS.items() if any(pat in name for pat in pats)), None)
                 if key is None:
                     continue
                 c = row.get('Counter_Name') or row.get('Counter-Name')
