@@ -582,6 +582,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     // 16-row node tiles on the split engine too (v_mfma_f32_16x16x32_bf16; H >= 128): k_node<256,16> 35.0 -> 31.4 us at B=64 -
     // bound by the 6 B/weight stream of one workgroup per 16 rows, not by the matrix pipe (profiles/r03_b_*); option "node16_split" = 0 opts out
     a.split16 = (a.split && h->dims.H >= 128 && opt_of(h, "node16_split", 1) != 0) ? 1 : 0;
+    a.node16w = opt_of(h, "node16w", 1) != 0 ? 1 : 0;
     {   // k_embed: inside a conditional chain only the phar tiles take the full path (the pocket rows come from the per-chain
         // cache), and they are few: 16-row tiles spread them over twice the CUs and halve the two projection passes of each
         // (B=256: 120 tiles of 32 rows 38.6 us -> 240 tiles of 16 rows)
@@ -597,7 +598,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
 // options
 // ---------------------------------------------------------------------------------
 static const char* const kOptionKeys[] = {
-    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "edge_fullk", "node64", "node16_split",
+    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "edge_fullk", "node64", "node16_split", "node16w",
     "dead_skip", "write_embed", "fused_step", "pocket_cache", "graph_steps",
     "wgrad_split", "wgrad_tile", "wgrad_split_wgs128", "wgrad_split_wgs64", "wgrad_wgs", "dgrad_mt", "dgrad_tail"};
 
@@ -1246,6 +1247,7 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "gemm_split") *value = a.split;
     else if (k == "node16_split") *value = a.split16;
     else if (k == "node64") *value = a.node64;
+    else if (k == "node16w") *value = a.node16w;
     else if (k == "edge_fullk") *value = a.edge_fullk;
     else if (k == "dead_skip") *value = a.dead_skip;
     else if (k == "train_edges") *value = h->train_E;

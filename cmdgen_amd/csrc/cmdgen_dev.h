@@ -210,6 +210,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int split16 = 0;            // 1: 16-row node tiles too (Eng<16, true>; option "node16_split")
     int n_cus = 256;
     int edge_fullk = 0;         // 1: 32-row edge tiles of the sampler build all 256 columns at once (full-K planes; option "edge_fullk")
+    int node16w = 1;            // 1: 16-row node tiles of H = 256 on eight waves (kernels_node16w.hip)
     int node64 = 0;             // 1: large batches run k_node as 64-row tiles with both images in LDS (kernels_node64.hip)
     int dead_skip = 0;          // 2: every block of a conditional evaluation skips tiles whose new h nobody reads (by hop level); 1: the last block only; 0: off (option "dead_skip")
     mutable int live_thr = 0;   // set around a block's launches when that applies: nodes within this many hops of a moving node are still read

@@ -21,6 +21,7 @@
 #define LDA(H) ((H) + 4)
 
 bool cmdgen_launch_node64(const EvalLaunch& a, int l, hipStream_t s);         // kernels_node64.hip: k_node for large batches
+bool cmdgen_launch_node16w(const EvalLaunch& a, int l, hipStream_t s);        // kernels_node16w.hip: 16-row tiles on eight waves (small batches)
 bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s);         // kernels_edge128.hip: the edge kernels for long lists (128-row tiles)
 bool cmdgen_launch_coord128(const EvalLaunch& a, int l, hipStream_t s);
 
@@ -1445,7 +1446,7 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
         REC(); REC();
         if (stop == 1) return;
         PROF_BEGIN(1);
-        if (!(a.node64 && cmdgen_launch_node64(a, l, s))) MT_DISPATCH(a.node_mt, launch_node, a, l, s);
+        if (!(a.node64 && cmdgen_launch_node64(a, l, s)) && !cmdgen_launch_node16w(a, l, s)) MT_DISPATCH(a.node_mt, launch_node, a, l, s);
         PROF_END();
         REC(); REC();
         if (stop == 2) return;

@@ -34,3 +34,27 @@ def test_options_are_per_handle_and_reversible(monkeypatch):
     with pytest.raises(hip_backend.CmdgenError, match='unknown option'):
         a.set_option('edge_tiles', 1)
     a.close(); b.close()
+
+
+def test_eight_wave_node_tile_against_the_four_wave_one():
+    """kernels_node16w.hip (16-row node tiles of H = 256 on eight waves) against k_node<256, 16> on the same split engine: the same MFMAs in the
+    same order on every accumulator - the two agree as closely as two runs of either do (the segment sums upstream add a receiver's tile
+    partials with float atomics, so an evaluation is reproducible to the last bits, not bit for bit) - and both sit inside the evaluation
+    tolerance of the reference's result."""
+    for name in [n for n in cases_of(G2) if '_h256_' in n]:
+        cfg, sd, inp = dynamics_case(G2, name)
+        want = G2[name + '/eps_phar']
+        got = []
+        for on in (1, 0, 0):
+            h = new_handle(cfg, sd)
+            h.set_option('node_mt', 16); h.set_option('node64', 0); h.set_option('node16w', on)
+            h.set_layout(G2[name + '/num_nodes_phar'], G2[name + '/pocket_size'])
+            assert h.query('node_mt') == 16 and h.query('node16w') == on
+            eps, _ = h.dynamics_forward(dev(inp['xh_phar']), dev(inp['xh_pocket']), dev(inp['t']))
+            got.append(eps.cpu().numpy())
+            h.close()
+        scale = max(1.0, float(np.abs(want).max()))
+        run_to_run = float(np.abs(got[1] - got[2]).max())
+        assert float(np.abs(got[0] - got[1]).max()) <= max(4.0 * run_to_run, 2e-6 * scale), name
+        for g in got:
+            assert float(np.abs(g - want).max()) <= EVAL_TOL * scale

@@ -15,7 +15,9 @@ n64o=$C/kernels_node64.o
 [ "$f" = kernels_node64.hip ] && n64o=build/kernels_node64_$name.o
 traino=$C/kernels_train.o
 [ "$f" = kernels_train.hip ] && traino=build/kernels_train_$name.o
+n16o=$C/kernels_node16w.o
+[ "$f" = kernels_node16w.hip ] && n16o=build/kernels_node16w_$name.o
 e128o=$C/kernels_edge128.o
 [ "$f" = kernels_edge128.hip ] && e128o=build/kernels_edge128_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcmdgen_hip_$name.so $C/cmdgen_api.o $egnn $n64o $e128o $C/kernels_ddpm.o $C/kernels_joint.o $traino $C/cmdgen_train.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcmdgen_hip_$name.so $C/cmdgen_api.o $egnn $n64o $n16o $e128o $C/kernels_ddpm.o $C/kernels_joint.o $traino $C/cmdgen_train.o
 echo build/libcmdgen_hip_$name.so
