@@ -230,7 +230,7 @@ def kernel_table(h, prof, pc, H, L, nl_tot):
     flop_launch = {'edge_msg': 2.0 * (H * H + H) * units['edge_msg'],
                    'node': node_flop_per_launch(H, L, units['node'], nl_tot, False),
                    'edge_coord': coord_flop_per_launch(H, L, units['edge_coord'], pc['nodes'] / ev, False)}
-    launch_cfg = {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid', 'gemm_split', 'node16_split', 'node64')}
+    launch_cfg = {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid', 'gemm_split', 'node16_split', 'node16w', 'node64')}
     # node64: the 64-row planes node kernel took the launches (kernels_node64.hip; chosen per layout by tile count)
     mt_of = {'edge_msg': launch_cfg['edge_mt'], 'node': 64 if launch_cfg['node64'] else launch_cfg['node_mt'], 'edge_coord': launch_cfg['coord_mt']}
     on_split = {k: bool(launch_cfg['gemm_split']) and mt_of[k] >= 32 for k in mt_of}
