@@ -52,7 +52,7 @@ extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle
     const int H = cfg->hidden_nf;
     if (!(H == 64 || H == 128 || H == 256))
         return fail(nullptr, CMDGEN_EINVAL, "hidden_nf=%d unsupported: the gfx950 kernels tile 64 columns per wave (64, 128 or 256)", H);
-    if (cfg->inv_sublayers != 1) return fail(nullptr, CMDGEN_EINVAL, "inv_sublayers=%d unsupported (shipped configs use 1)", cfg->inv_sublayers);
+    if (cfg->inv_sublayers < 1 || cfg->inv_sublayers > 8) return fail(nullptr, CMDGEN_EINVAL, "inv_sublayers=%d out of range [1, 8]", cfg->inv_sublayers);
     if (cfg->n_layers < 1 || cfg->n_layers > CMDGEN_MAX_LAYERS) return fail(nullptr, CMDGEN_EINVAL, "n_layers out of range");
     if (cfg->phar_nf < 1 || 2 * cfg->phar_nf > CMDGEN_MAX_SMALL || cfg->residue_nf < 1 ||
         2 * cfg->residue_nf > CMDGEN_MAX_SMALL || cfg->joint_nf < 1 || cfg->joint_nf + 1 > CMDGEN_MAX_SMALL)
@@ -77,6 +77,7 @@ extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle
     d.joint = cfg->update_pocket_coords ? 1 : 0;
     d.cutoff2 = cfg->edge_cutoff < 0.f ? -1.f : cfg->edge_cutoff * cfg->edge_cutoff;
     d.norm_constant = cfg->norm_constant; d.norm_factor = cfg->normalization_factor; d.coords_range = cfg->coords_range;
+    d.S = cfg->inv_sublayers; d.agg_mean = cfg->aggregation_mean ? 1 : 0;
     d.norm_x = cfg->norm_x; d.norm_h = cfg->norm_h; d.bias_h = cfg->bias_h;
     h->n_cus = prop.multiProcessorCount;
     h->edge_grid = 2 * prop.multiProcessorCount;      // two 66 KB-LDS workgroups per CU at 64-row tiles
@@ -268,9 +269,12 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
         GET(dy + "egnn.embedding_out.bias", d.dyn); UP(s.embo_b);
     }
     const int ld1 = 2 * H + 2;
-    for (int b = 0; b < d.L; ++b) {
+    // one LayerW per GCL ("unit" b * S + sub, egnn_new.py:127-131); the block's EquivariantUpdate rides with its LAST GCL (the node kernel of
+    // that unit projects P_c | Q_c), earlier units of a block carry no coordinate weights
+    for (int b = 0; b < d.L; ++b)
+    for (int sub = 0; sub < d.S; ++sub) {
         LayerW lw{};
-        const std::string g = dy + "egnn.e_block_" + std::to_string(b) + ".gcl_0.";
+        const std::string g = dy + "egnn.e_block_" + std::to_string(b) + ".gcl_" + std::to_string(sub) + ".";
         const std::string c = dy + "egnn.e_block_" + std::to_string(b) + ".gcl_equiv.";
         auto split_first = [&](const std::string& wname, const std::string& bname, WPack* Wpq,
                                const float** bias, const float** wr, const float** wd) -> int {
@@ -305,10 +309,14 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
         GET(g + "node_mlp.0.bias", H); UP(lw.b3);
         rc = square(g + "node_mlp.2.weight", H, &lw.W4); if (rc) return rc;
         GET(g + "node_mlp.2.bias", H); UP(lw.b4);
-        rc = split_first(c + "coord_mlp.0.weight", c + "coord_mlp.0.bias", &lw.Wpq_c, &lw.b6, &lw.wr_c, &lw.wd_c); if (rc) return rc;
-        rc = square(c + "coord_mlp.2.weight", H, &lw.W7); if (rc) return rc;
-        GET(c + "coord_mlp.2.bias", H); UP(lw.b7);
-        GET(c + "coord_mlp.4.weight", H); UP(lw.w5);
+        if (sub == d.S - 1) {
+            rc = split_first(c + "coord_mlp.0.weight", c + "coord_mlp.0.bias", &lw.Wpq_c, &lw.b6, &lw.wr_c, &lw.wd_c); if (rc) return rc;
+            rc = square(c + "coord_mlp.2.weight", H, &lw.W7); if (rc) return rc;
+            GET(c + "coord_mlp.2.bias", H); UP(lw.b7);
+            GET(c + "coord_mlp.4.weight", H); UP(lw.w5);
+        } else {                       // never multiplied (the node kernel skips the projection); valid pointers for the bias prefetches
+            lw.Wpq_c = lw.Wpq_e; lw.b6 = lw.b1; lw.wr_c = lw.wr_e; lw.wd_c = lw.wd_e; lw.W7 = lw.W2; lw.b7 = lw.b2; lw.w5 = lw.b2;
+        }
         h->layers.push_back(lw);
     }
 #undef GET
@@ -472,7 +480,7 @@ static int set_layout_impl(cmdgen_handle* h, int64_t batch, const int64_t* nph, 
         ALLOC(w.XL, float4, (size_t)d.L * cNm, true); ALLOC(w.ACC, float4, (size_t)d.L * cNm, true);
         ALLOC(w.h, float, cN * H, true); ALLOC(w.P, float, cN * H, true); ALLOC(w.Q, float, cN * H, true);
         ALLOC(w.Pc, float, cN * H, true); ALLOC(w.Qc, float, cN * H, true); ALLOC(w.agg, float, cN * H, true);
-        ALLOC(w.degL, int, cN, true); ALLOC(w.need_qc, int, cN, true); ALLOC(w.pocketE, int, cB, true); ALLOC(w.pocketEph, int, cB, true);
+        ALLOC(w.adiv, float, cN, true); ALLOC(w.degL, int, cN, true); ALLOC(w.need_qc, int, cN, true); ALLOC(w.pocketE, int, cB, true); ALLOC(w.pocketEph, int, cB, true);
         ALLOC(w.pocketEns, int, cB, true); ALLOC(w.pocketEnsQ, int, cB, true);
         ALLOC(w.erow, int, ce, false); ALLOC(w.ecol, int, ce, false); ALLOC(w.ed0, float, ce, false); ALLOC(w.ehop, int, ce, false);
         ALLOC(w.crow, int, cec, false); ALLOC(w.ccol, int, cec, false); ALLOC(w.cd0, float, cec, false);
@@ -574,7 +582,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
             if (opt_set(h, "node64")) { const int64_t v = opt_of(h, "node64", 0); on = v == 32 ? 32 : v != 0; }
         }
         a.node64 = on;
-        a.dead_skip = h->dims.joint ? 0 : (int)opt_of(h, "dead_skip", 2);      // 2 (default): every block by hop level; 1: the last block only; 0: off
+        a.dead_skip = (h->dims.joint || h->dims.S != 1) ? 0 : (int)opt_of(h, "dead_skip", 2);   // (hop levels count blocks of ONE GCL)      // 2 (default): every block by hop level; 1: the last block only; 0: off
         if (!on && !a.dead_skip) a.w.need_qc = nullptr;
         a.w.hop_levels = a.dead_skip >= 2 ? h->dims.L : 1;
         if (!a.dead_skip) a.w.ehop = nullptr;           // the graph pass fills the flags only for the kernels that read them
@@ -1201,6 +1209,7 @@ extern "C" int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar,
     int rc = check_ready(h); if (rc) return rc;
     if (!out) return fail(h, CMDGEN_EINVAL, "null output");
     if (h->dims.joint) return fail(h, CMDGEN_ESTATE, "cmdgen_profile_evaluation supports the conditional model only");
+    if (h->dims.S != 1) return fail(h, CMDGEN_ESTATE, "cmdgen_profile_evaluation supports inv_sublayers = 1 only (cmdgen_set_kernel_profiling works for any)");
     hipStream_t s = (hipStream_t)stream;
     rc = begin_work(h, s); if (rc) return rc;
     const int L = h->dims.L;

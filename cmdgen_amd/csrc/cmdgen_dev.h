@@ -77,6 +77,8 @@ struct Dims {
     int joint;                  // update_pocket_coords (mode 'joint'): pocket nodes move, velocity COM removed
     float cutoff2;              // cutoff^2, < 0: no cutoff
     float norm_constant, norm_factor, coords_range;
+    int S;                      // inv_sublayers: GCLs per block (the weight units of an evaluation are L * S, LayerW of unit l * S + s)
+    int agg_mean;               // aggregation_method 'mean': segment sums are divided by Work::adiv[receiver] instead of norm_factor
     float norm_x, norm_h, bias_h;
 };
 
@@ -103,6 +105,7 @@ struct Work {                   // per-layout workspace; all pointers device
     float*  Pc;                 // [N][H]  coord-MLP receiver part (+b6), only phar rows read
     float*  Qc;                 // [N][H]
     float*  agg;                // [N][H]  zero between blocks
+    float*  adiv;               // [N] (flat node order) agg_mean only: max(degree, 1) as the divisor of the node's segment sums, written by pass 2 of the radius graph
     int*    degL;               // [N] degree in sample-local order
     int     hop_levels;         // how many hop levels the graph pass computes into need_qc (1, or n_layers when every block skips its dead tiles)
     int*    need_qc;            // [N] hop level from the moving nodes: 0 moves, 1 sends along a coordinate edge (its Q_c row is read), 2.. L, 255 none; may be null
@@ -120,6 +123,9 @@ struct Work {                   // per-layout workspace; all pointers device
     float*  eps_tmp;            // [Nl][3+P] evaluation output used by the chain
     unsigned long long* dbg;    // [64] diagnostic builds only (-DCMDGEN_STAMPS): summed in-kernel cycle stamps
 };
+
+// divisor of node n's segment sums (egnn_new.py:277-292): normalization_factor ('sum'), or the receiver's edge count ('mean')
+__device__ __forceinline__ float agg_div(const Work& w, const Dims& d, int n) { return d.agg_mean ? w.adiv[n] : d.norm_factor; }
 
 struct ChainState {             // device-resident denoising-loop state
     int step;                   // evaluations completed so far = index into coef[] of the NEXT evaluation; bumped by
@@ -213,11 +219,19 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int node16w = 1;            // 1: 16-row node tiles of H = 256 on eight waves (kernels_node16w.hip)
     int node64 = 0;             // 1: large batches run k_node as 64-row tiles with both images in LDS (kernels_node64.hip)
     int dead_skip = 0;          // 2: every block of a conditional evaluation skips tiles whose new h nobody reads (by hop level); 1: the last block only; 0: off (option "dead_skip")
+    mutable int unit = -1;      // weight unit (GCL) of the launches being issued: block l, sub-layer s -> l * S + s; -1: the block index itself (S = 1)
+    mutable int skip_pc = 0;    // 1: the unit is not the last GCL of its block - its node kernel projects no P_c | Q_c
     mutable int live_thr = 0;   // set around a block's launches when that applies: nodes within this many hops of a moving node are still read
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     int write_embed = 1;        // 1: pass 2 of the radius graph and k_embed share a launch (k_write_embed) where both fit (option "write_embed")
     int e128_wgs = 2;           // workgroups per CU of the 128-row edge kernels (kernels_edge128.hip)
 };
+// weight unit of block l's launches (EvalLaunch::unit), and the has_next argument of its node kernel: bit 0 = another unit follows
+// (its P | Q are projected), bits 1..29 = the dead-tile threshold of the plane tiles, bit 30 = no P_c | Q_c (EvalLaunch::skip_pc)
+inline int unit_of(const EvalLaunch& a, int l) { return a.unit >= 0 ? a.unit : l; }
+inline int unit_has_next(const EvalLaunch& a, int l) { return unit_of(a, l) + 1 < a.d.L * a.d.S ? 1 : 0; }
+inline int node_flags(const EvalLaunch& a, int l) { return unit_has_next(a, l) | (a.live_thr << 1) | (a.skip_pc << 30); }
+
 
 // ---------------------------------------------------------------------------------
 // SiLU / sigmoid on the fast hardware path: v_exp_f32 (base 2) + v_rcp_f32, 5 VALU instructions.

@@ -74,7 +74,8 @@ __device__ __forceinline__ const sbf16x8* n64_tile(const void* ws, int kb16_tota
 __device__ __forceinline__ float4 n64_node_pos(const Layout& lay, const Work& w, const Dims& d, int n, int layer) {
     const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nm + n];
     const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
-    return make_float4(p.x + a.x / d.norm_factor, p.y + a.y / d.norm_factor, p.z + a.z / d.norm_factor, 0.f);
+    const float dv = agg_div(w, d, n);
+    return make_float4(p.x + a.x / dv, p.y + a.y / dv, p.z + a.z / dv, 0.f);
 }
 
 #define N64_ZERO(ACC) _Pragma("unroll") for (int m = 0; m < NMT; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n) _Pragma("unroll") for (int r = 0; r < 16; ++r) ACC[m][n][r] = 0.0f;
@@ -87,7 +88,8 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
                                                  const LayerW& lw_next, const int layer, const int has_next_arg, const int row0, const int row_end) {
     constexpr int H = 256, LPR = H / 4, NMT = NROWS / 32, NPE = NROWS * NPLD;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int has_next = has_next_arg & 1, live_thr = has_next_arg >> 1;       // bits 1..: only tiles with a node within that many hops of a moving node (see below)
+    const int has_next = has_next_arg & 1, live_thr = (has_next_arg >> 1) & 0x1fffffff;       // bits 1..29: only tiles with a node within that many hops of a moving node (see below)
+    const bool skip_pc = ((has_next_arg >> 30) & 1) != 0;                     // not the last GCL of its block (inv_sublayers > 1): no P_c | Q_c
 #if CMDGEN_STAMPS == 5      // diagnostic build: per-phase cycle stamps into w.dbg ([wave][phase] sums, [32 + wave] lifetime, [40] waves)
     unsigned long long nst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nst_t = __builtin_amdgcn_s_memtime();
     const unsigned long long nst_begin = nst_t;
@@ -119,7 +121,7 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
     // projections: jobs 0..3 = P_c, Q_c, P', Q' (bit j of `jobs` set: the job runs); Wpq rows 0..H-1 -> P (tiles 0..7), H.. -> Q (8..15)
     // Q_c only where a row of the tile sends along a coordinate edge of this evaluation (flags of the graph pass, kernels_egnn.hip)
     const bool want_qc = want_pc || !w.need_qc || __ballot((lane & (NROWS - 1)) < nvalid && w.need_qc[row0 + (lane & (NROWS - 1))] <= 1) != 0ull;
-    const unsigned jobs = (want_pc ? 1u : 0u) | (want_qc ? 2u : 0u) | (has_next ? 12u : 0u);
+    const unsigned jobs = (want_pc && !skip_pc ? 1u : 0u) | (want_qc && !skip_pc ? 2u : 0u) | (has_next ? 12u : 0u);
     auto job_tile = [&](int j, int n) { return n64_tile(j < 2 ? lw.Wpq_c.ws : lw_next.Wpq_e.ws, 16, (j & 1) * 8 + 2 * wave + n, 0); };
     const int job0 = jobs ? __builtin_ctz(jobs) : 1;             // (no job at all: the W4 product's look-ahead reads Q_c's first blocks, unused)
     N64Ring ring;
@@ -167,7 +169,8 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
         const int r = pass * 4 + rsub;
         if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
         float4 v = av[pass];
-        v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
+        const float dv = r < nvalid ? agg_div(w, d, row0 + r) : 1.0f;
+        v.x /= dv; v.y /= dv; v.z /= dv; v.w /= dv;
         split_store4(planes, NPE, r * NPLD + 4 * c4, v);
     }
     n64_lds_barrier();

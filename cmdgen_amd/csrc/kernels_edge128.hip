@@ -59,7 +59,8 @@ __device__ __forceinline__ float4 pos_lazy(const Layout& lay, const Work& w, con
     if (layer == 0) return w.X0[n];
     const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nm + n];
     const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
-    return make_float4(p.x + a.x / d.norm_factor, p.y + a.y / d.norm_factor, p.z + a.z / d.norm_factor, 0.f);
+    const float dv = agg_div(w, d, n);
+    return make_float4(p.x + a.x / dv, p.y + a.y / dv, p.z + a.z / dv, 0.f);
 }
 __device__ __forceinline__ float4 pos_mat(const Layout& lay, const Work& w, int n, int layer) {
     if (n >= lay.Nm) return w.XP[n - lay.Nl];
@@ -472,16 +473,16 @@ __global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, 
 
 // launchers: true when the 128-row kernels took the launch (H = 256, split engine, sampler)
 bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.edge_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[l].W2.ws) return false;
+    if (a.edge_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[unit_of(a, l)].W2.ws) return false;
     const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 2 ? a.e128_wgs : 2) * a.n_cus;
-    if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l], l, a.live_thr);
-    else hipLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.live_thr);
+    if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.live_thr);
+    else hipLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.live_thr);
     return true;
 }
 bool cmdgen_launch_coord128(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.coord_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[l].W7.ws) return false;
+    if (a.coord_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[unit_of(a, l)].W7.ws) return false;
     const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 2 ? a.e128_wgs : 2) * a.n_cus;
-    if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l], l, 0);
-    else hipLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, 0);
+    if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, 0);
+    else hipLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, 0);
     return true;
 }

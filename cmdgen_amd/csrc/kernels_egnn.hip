@@ -121,6 +121,8 @@ __device__ __forceinline__ void edge_write_body(const Layout& lay, const Work& w
     for (int i = tid; i < n; i += blockDim.x) {
         spos[i] = i < nl ? w.X0[pb + i] : w.XP[qb + i - nl];
         sdg[i] = w.degL[pb + qb + i];
+        // aggregation_method 'mean' (egnn_new.py:288-292): every segment sum of a node is divided by its edge count, self loop included
+        if (d.agg_mean) w.adiv[flat_node(i, nl, pb, qb, lay.Nl)] = fmaxf((float)(sdg[i] & 0x3fffffff), 1.0f);
     }
     // The compact list is ordered like torch.where on the N x N adjacency of the flat node
     // numbering (dynamics.py:146): all phar receivers first (sample by sample), then all pocket
@@ -541,7 +543,8 @@ __device__ __forceinline__ float4 node_pos(const Layout& lay, const Work& w, con
     if (!lazy) return w.XL[(size_t)layer * lay.Nm + n];
     const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nm + n];
     const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
-    return make_float4(p.x + a.x / d.norm_factor, p.y + a.y / d.norm_factor, p.z + a.z / d.norm_factor, 0.f);
+    const float dv = agg_div(w, d, n);
+    return make_float4(p.x + a.x / dv, p.y + a.y / dv, p.z + a.z / dv, 0.f);
 }
 
 // A-tile generation shared by the two edge kernels:
@@ -915,7 +918,8 @@ __global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_msg(Layout lay, Work w, 
 template <int H, int MT, bool SAVE, bool SP>
 __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw, const LayerW& lw_next,
                                                const int layer, const int has_next_arg, const TrainSave& sv, const int row0, const int row_end) {
-    const int has_next = has_next_arg & 1;                                     // (bits 1.. carry the dead-tile threshold of the plane tiles: unused here)
+    const int has_next = has_next_arg & 1;                                     // (bits 1..29 carry the dead-tile threshold of the plane tiles: unused here)
+    const bool skip_pc = ((has_next_arg >> 30) & 1) != 0;                     // not the last GCL of its block (inv_sublayers > 1): no P_c | Q_c
     // Tiles of <= 32 rows keep two LDS images: buf0 = h (kept for the residual), buf1 = agg -> T -> h_new,
     // so h and agg are fetched together and the residual needs no second global read.  64-row tiles
     // (66 KB each) use one image so that two workgroups still fit a CU.
@@ -935,7 +939,7 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
     const Frag f3a = G::frag(lw.W3, 2 * H / 8, 0, wave), f3b = G::frag(lw.W3, 2 * H / 8, H / 8, wave);
     const Frag f4 = G::frag(lw.W4, H / 8, 0, wave);
     const Frag fn = G::frag(lw_next.Wpq_e, H / 8, 0, wave);
-    const Frag fc = G::frag(lw.Wpq_c, H / 8, 0, want_pc ? wave : H / 64 + wave);      // the GEMM behind W4
+    const Frag fc = skip_pc ? fn : G::frag(lw.Wpq_c, H / 8, 0, want_pc ? wave : H / 64 + wave);      // the GEMM behind W4
     typename G::Carry carry;
     G::prefetch(f3a, carry);
     // every epilogue's bias, fetched now: by the time an epilogue runs its values have long arrived (a load issued where
@@ -965,7 +969,8 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
                 float4* g = reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H) + c4;
                 v = *g;
                 *g = make_float4(0.f, 0.f, 0.f, 0.f);                      // agg is zero between blocks
-                v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
+                const float dv = agg_div(w, d, row0 + r);
+                v.x /= dv; v.y /= dv; v.z /= dv; v.w /= dv;
                 if (SAVE) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * H)[c4] = v;
             }
             *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
@@ -997,7 +1002,8 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
             const int r = pass * 4 + rsub;
             if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
             float4 v = av[pass];
-            v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
+            const float dv = r < nvalid ? agg_div(w, d, row0 + r) : 1.0f;
+            v.x /= dv; v.y /= dv; v.z /= dv; v.w /= dv;
             if (SAVE && r < nvalid) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * H)[c4] = v;
             *reinterpret_cast<float4*>(buf0 + r * LDA(H) + 4 * c4) = hv[pass];
             *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
@@ -1057,7 +1063,7 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
     }
     NSTAMP(4);
     // coord MLP projections: P_c only where the tile holds phar rows (receivers that move)
-    tile_project_pq<H, MT, SP>(buf1, lw.Wpq_c, b6v, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
+    if (!skip_pc) tile_project_pq<H, MT, SP>(buf1, lw.Wpq_c, b6v, w.Pc, w.Qc, row0, nvalid, want_pc, carry, fn);
     NSTAMP(5);
     if (has_next) tile_project_pq<H, MT, SP>(buf1, lw_next.Wpq_e, b1nv, w.P, w.Q, row0, nvalid, true, carry, fn);
     NSTAMP(6);
@@ -1276,9 +1282,10 @@ __global__ __launch_bounds__(256) void k_readout(Layout lay, Work w, Dims d, Sma
                 const float4 p = (d.L == 1) ? w.X0[n] : w.XL[(size_t)(d.L - 1) * lay.Nm + n];
                 const float4 a = w.ACC[(size_t)(d.L - 1) * lay.Nm + n];
                 const float4 x0 = w.X0[n];
-                vx = (p.x + a.x / d.norm_factor) - x0.x;
-                vy = (p.y + a.y / d.norm_factor) - x0.y;
-                vz = (p.z + a.z / d.norm_factor) - x0.z;
+                const float dv = agg_div(w, d, n);
+                vx = (p.x + a.x / dv) - x0.x;
+                vy = (p.y + a.y / dv) - x0.y;
+                vz = (p.z + a.z / dv) - x0.z;
                 if (isnan(vx) || isnan(vy) || isnan(vz)) atomicOr(w.nan_flag, 1);
             }
             out[0] = vx; out[1] = vy; out[2] = vz;
@@ -1355,44 +1362,43 @@ template <int H, int MT, bool SP> static void launch_write_embed(const EvalLaunc
 template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, int l, hipStream_t s) {
     if constexpr (MT == 16 && !SP && H >= 128) {
         // 16-row tiles on the split engine (v_mfma_f32_16x16x32_bf16): opt-in, see DESIGN section 4a for why it is not the default
-        if (a.split16 && !a.save && a.layers[l].W3.ws16) { launch_node<H, 16, true>(a, l, s); return; }
+        if (a.split16 && !a.save && a.layers[unit_of(a, l)].W3.ws16) { launch_node<H, 16, true>(a, l, s); return; }
     }
     const int nt = (a.lay.N + MT - 1) / MT;
-    const int has_next = l + 1 < a.d.L;
-    if (a.save) hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
-                                   a.layers[has_next ? l + 1 : l], l, has_next, *a.save);
+    if (a.save) hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)],
+                                   a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l), *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                               a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1), TrainSave{});
-    else hipLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l],
-                            a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1), TrainSave{});
+                                               a.layers[unit_of(a, l)], a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l), TrainSave{});
+    else hipLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)],
+                            a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l), TrainSave{});
 }
 template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
     // training forward: the split engine only where the step re-packs split weights (H = 256: edge_mlp.2 / coord_mlp.2)
-    if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, *a.save, 0);
+    if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, *a.save, 0);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                               a.layers[l], l, a.ablate, TrainSave{}, a.live_thr);
-    else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{}, a.live_thr);
+                                               a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
+    else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
 }
 // 32-row sampler tiles on the split engine: full-K planes (one build, one GEMM per tile; see cmdgen_split.h) unless CMDGEN_EDGE_FULLK=0
 static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.edge_mt != 32) return false;
     if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                          a.layers[l], l, a.ablate, TrainSave{}, a.live_thr);
-    else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, a.ablate, TrainSave{}, a.live_thr);
+                                          a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
+    else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
     return true;
 }
 static bool launch_coord_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.coord_mt != 32) return false;
     if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                          a.layers[l], l, TrainSave{});
-    else hipLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
+                                          a.layers[unit_of(a, l)], l, TrainSave{});
+    else hipLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, TrainSave{});
     return true;
 }
 template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, SP && H == 256>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, *a.save);
+    if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, SP && H == 256>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, *a.save);
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                               a.layers[l], l, TrainSave{});
-    else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[l], l, TrainSave{});
+                                               a.layers[unit_of(a, l)], l, TrainSave{});
+    else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, TrainSave{});
 }
 // tiles of >= 32 rows run on the split-bf16 engine when the launch asks for it (the training forward: only its two edge
 // kernels, and only when the step re-packed split weights for them - save_split); 16-row tiles are always fp32 MFMA
@@ -1439,21 +1445,28 @@ static void launch_eval_H(const EvalLaunch& a, const float* xh_phar, const float
     for (int l = 0; l < a.d.L; ++l) {
         a.live_thr = live_last ? (a.dead_skip >= 2 ? a.d.L - l : (l == a.d.L - 1 ? 1 : 0)) : 0;     // dead_skip 1: the last block only; 2: every block (a kernel argument of its own: any n_layers)
         const int stop = a.stop_block == l ? a.stop_stage : 0;        // parity aid: leave intermediates in the workspace
-        REC();
-        PROF_BEGIN(0);
-        if (!cmdgen_launch_msg128(a, l, s) && !launch_msg_fullk(a, l, s)) MT_DISPATCH(a.edge_mt, launch_msg, a, l, s);
-        PROF_END();
-        REC(); REC();
-        if (stop == 1) return;
-        PROF_BEGIN(1);
-        if (!(a.node64 && cmdgen_launch_node64(a, l, s)) && !cmdgen_launch_node16w(a, l, s)) MT_DISPATCH(a.node_mt, launch_node, a, l, s);
-        PROF_END();
-        REC(); REC();
-        if (stop == 2) return;
+        // the block's GCLs (inv_sublayers, egnn_new.py:152-154): message + node kernel per unit; only the last one projects P_c | Q_c.
+        // (The per-stage events and the prefix stops belong to the block's last unit; cmdgen_profile_evaluation asks for S = 1.)
+        for (int sub = 0; sub < a.d.S; ++sub) {
+            const bool last = sub == a.d.S - 1;
+            a.unit = l * a.d.S + sub; a.skip_pc = last ? 0 : 1;
+            if (last) REC();
+            PROF_BEGIN(0);
+            if (!cmdgen_launch_msg128(a, l, s) && !launch_msg_fullk(a, l, s)) MT_DISPATCH(a.edge_mt, launch_msg, a, l, s);
+            PROF_END();
+            if (last) { REC(); REC(); }
+            if (last && stop == 1) { a.unit = -1; a.skip_pc = 0; return; }
+            PROF_BEGIN(1);
+            if (!(a.node64 && cmdgen_launch_node64(a, l, s)) && !cmdgen_launch_node16w(a, l, s)) MT_DISPATCH(a.node_mt, launch_node, a, l, s);
+            PROF_END();
+            if (last) { REC(); REC(); }
+            if (last && stop == 2) { a.unit = -1; a.skip_pc = 0; return; }
+        }
         PROF_BEGIN(2);
         if (!cmdgen_launch_coord128(a, l, s) && !launch_coord_fullk(a, l, s)) MT_DISPATCH(a.coord_mt, launch_coord, a, l, s);
         PROF_END();
         REC();
+        a.unit = -1; a.skip_pc = 0;
         if (stop == 3) return;
     }
     REC();
@@ -1524,7 +1537,8 @@ __global__ void k_save_positions(Layout lay, Work w, Dims d, float4* __restrict_
         else {
             const float4 q = (d.L == 1) ? w.X0[n] : w.XL[(size_t)(d.L - 1) * lay.Nm + n];
             const float4 a = w.ACC[(size_t)(d.L - 1) * lay.Nm + n];
-            p = make_float4(q.x + a.x / d.norm_factor, q.y + a.y / d.norm_factor, q.z + a.z / d.norm_factor, 0.f);
+            const float dv = agg_div(w, d, n);
+            p = make_float4(q.x + a.x / dv, q.y + a.y / dv, q.z + a.z / dv, 0.f);
         }
         X[(size_t)l * lay.N + n] = p;
     }

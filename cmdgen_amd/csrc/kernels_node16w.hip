@@ -123,7 +123,8 @@ __device__ __forceinline__ void nw_store(const sf32x4 (&acc)[2], int wave, float
 __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next_arg) {
     __shared__ __attribute__((aligned(16))) float buf0[NW_MT * NW_LD];      // h (kept for the residual)
     __shared__ __attribute__((aligned(16))) float buf1[NW_MT * NW_LD];      // agg / nf -> T = SiLU(.) -> h_new
-    const int has_next = has_next_arg & 1;                                   // (bits 1.. : the dead-tile threshold of the plane tiles, unused here)
+    const int has_next = has_next_arg & 1;                                   // (bits 1..29: the dead-tile threshold of the plane tiles, unused here)
+    const bool skip_pc = ((has_next_arg >> 30) & 1) != 0;                   // not the last GCL of its block (inv_sublayers > 1): no P_c | Q_c
     const int tid = threadIdx.x, wave = tid >> 6;
     const int row0 = (int)blockIdx.x * NW_MT, nvalid = min(NW_MT, lay.N - row0);
     const bool want_pc = row0 < lay.Nm;                                      // the tile holds receivers that move
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
         if (tid < nvalid && n < lay.Nm) {
             const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nm + n];
             const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
-            w.XL[(size_t)layer * lay.Nm + n] = make_float4(p.x + a.x / d.norm_factor, p.y + a.y / d.norm_factor, p.z + a.z / d.norm_factor, 0.f);
+            const float dv = agg_div(w, d, n);
+            w.XL[(size_t)layer * lay.Nm + n] = make_float4(p.x + a.x / dv, p.y + a.y / dv, p.z + a.z / dv, 0.f);
         }
     }
     // h and agg of the tile: all global loads in flight together, then the LDS writes; agg is zero between blocks
@@ -162,7 +164,8 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
             const int idx = tid + 512 * j, r = idx >> 6, c4 = idx & 63;
             if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * NW_H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 v = av[j];
-            v.x /= d.norm_factor; v.y /= d.norm_factor; v.z /= d.norm_factor; v.w /= d.norm_factor;
+            const float dv = r < nvalid ? agg_div(w, d, row0 + r) : 1.0f;
+            v.x /= dv; v.y /= dv; v.z /= dv; v.w /= dv;
             *reinterpret_cast<float4*>(buf0 + r * NW_LD + 4 * c4) = hv[j];
             *reinterpret_cast<float4*>(buf1 + r * NW_LD + 4 * c4) = v;
         }
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
     nw_barrier();
     NSTAMP(2);
     nw_zero(acc);
-    const NwFrag fc = want_pc ? fcp : fcq;                                   // the GEMM behind W4
+    const NwFrag fc = skip_pc ? fnp : want_pc ? fcp : fcq;                   // the GEMM behind W4
     nw_gemm<KB>(buf1, f4, fc, acc, ring);
     NSTAMP(3);
     nw_barrier();
@@ -202,14 +205,16 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
     NSTAMP(4);
     // coordinate-MLP projections: P_c only where the tile holds phar rows (receivers that move); then P | Q of the next block's edge MLP
     // (results kept in registers and stored after the last GEMM: measured, no gain - profiles/r04_p_node16_eight_waves.txt)
-    if (want_pc) {
+    if (want_pc && !skip_pc) {
         nw_zero(acc);
         nw_gemm<KB>(buf1, fcp, fcq, acc, ring);
         nw_store(acc, wave, w.Pc, row0, nvalid, &b6v);
     }
-    nw_zero(acc);
-    nw_gemm<KB>(buf1, fcq, has_next ? fnp : fcq, acc, ring);
-    nw_store(acc, wave, w.Qc, row0, nvalid, nullptr);
+    if (!skip_pc) {
+        nw_zero(acc);
+        nw_gemm<KB>(buf1, fcq, has_next ? fnp : fcq, acc, ring);
+        nw_store(acc, wave, w.Qc, row0, nvalid, nullptr);
+    }
     NSTAMP(5);
     if (has_next) {
         nw_zero(acc);
@@ -232,11 +237,10 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
 
 // launcher: true when the eight-wave kernel took the launch (H = 256, 16-row tiles on the split engine, sampler)
 bool cmdgen_launch_node16w(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.d.H != 256 || a.node_mt != 16 || !a.split16 || !a.node16w || a.save || !a.layers[l].W3.ws16) return false;
+    if (a.d.H != 256 || a.node_mt != 16 || !a.split16 || !a.node16w || a.save || !a.layers[unit_of(a, l)].W3.ws16) return false;
     const int nt = (a.lay.N + NW_MT - 1) / NW_MT;
-    const int has_next = l + 1 < a.d.L;
-    if (a.pe_start) hipExtLaunchKernelGGL(k_node16w, dim3(nt), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l],
-                                          a.layers[has_next ? l + 1 : l], l, has_next);
-    else hipLaunchKernelGGL(k_node16w, dim3(nt), dim3(512), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next);
+    if (a.pe_start) hipExtLaunchKernelGGL(k_node16w, dim3(nt), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)],
+                                          a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l));
+    else hipLaunchKernelGGL(k_node16w, dim3(nt), dim3(512), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l));
     return true;
 }

@@ -29,18 +29,17 @@ __global__ __launch_bounds__(256, 1) void k_node32p(Layout lay, Work w, Dims d, 
 
 // launcher: true when the 64-row kernel took the launch (H = 256, split engine, sampler)
 bool cmdgen_launch_node64(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.d.H != 256 || !a.split || a.save || !a.node64 || !a.layers[l].W3.ws) return false;
-    const int has_next = l + 1 < a.d.L;
+    if (a.d.H != 256 || !a.split || a.save || !a.node64 || !a.layers[unit_of(a, l)].W3.ws) return false;
     if (a.node64 == 32) {
         const int nt32 = (a.lay.N + 31) / 32;
-        if (a.pe_start) hipExtLaunchKernelGGL(k_node32p, dim3(nt32), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l],
-                                              a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1));
-        else hipLaunchKernelGGL(k_node32p, dim3(nt32), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1));
+        if (a.pe_start) hipExtLaunchKernelGGL(k_node32p, dim3(nt32), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)],
+                                              a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l));
+        else hipLaunchKernelGGL(k_node32p, dim3(nt32), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l));
         return true;
     }
     const int nt = (a.lay.N + 63) / 64;
-    if (a.pe_start) hipExtLaunchKernelGGL(k_node64, dim3(nt), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[l],
-                                          a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1));
-    else hipLaunchKernelGGL(k_node64, dim3(nt), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[l], a.layers[has_next ? l + 1 : l], l, has_next | (a.live_thr << 1));
+    if (a.pe_start) hipExtLaunchKernelGGL(k_node64, dim3(nt), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)],
+                                          a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l));
+    else hipLaunchKernelGGL(k_node64, dim3(nt), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l));
     return true;
 }

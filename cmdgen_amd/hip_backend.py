@@ -24,7 +24,7 @@ class Config(C.Structure):
         'phar_nf', 'residue_nf', 'joint_nf', 'hidden_nf', 'n_layers', 'inv_sublayers',
         'attention', 'tanh', 'condition_time', 'timesteps', 'no_com_projection', 'update_pocket_coords')] + \
         [(n, C.c_float) for n in ('edge_cutoff', 'norm_constant', 'normalization_factor',
-                                  'coords_range', 'norm_x', 'norm_h', 'bias_h')]
+                                  'coords_range', 'norm_x', 'norm_h', 'bias_h')] + [('aggregation_mean', C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -167,8 +167,9 @@ class Handle:
         nv, nb = cfg['norm_values'], cfg['norm_biases']
         c.norm_x, c.norm_h = float(nv[0]), float(nv[1])
         c.bias_h = float(nb[1] if nb[1] is not None else 0.0)
-        if cfg.get('aggregation_method', 'sum') != 'sum':
-            raise CmdgenError("aggregation_method must be 'sum' (the only one the shipped configs use)")
+        if cfg.get('aggregation_method', 'sum') not in ('sum', 'mean'):
+            raise CmdgenError("aggregation_method must be 'sum' or 'mean' (egnn_new.py:277-292)")
+        c.aggregation_mean = int(cfg.get('aggregation_method', 'sum') == 'mean')
         if cfg.get('sin_embedding', False):
             raise CmdgenError('sin_embedding=True is not supported (shipped configs use False)')
         h = C.c_void_p()

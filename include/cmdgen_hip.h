@@ -53,7 +53,8 @@ typedef struct cmdgen_config {
     int32_t joint_nf;              /* 32 */
     int32_t hidden_nf;             /* 256; must be a multiple of 64, <= 256 */
     int32_t n_layers;              /* 5  */
-    int32_t inv_sublayers;         /* 1 (only value supported) */
+    int32_t inv_sublayers;         /* 1; GCLs per EquivariantBlock (egnn_new.py:127-131): >= 1 for sampling (dead-work skipping is off above 1),
+                                      the training step supports 1 only */
     int32_t attention;             /* 1  */
     int32_t tanh;                  /* 1  */
     int32_t condition_time;        /* 1  */
@@ -65,11 +66,13 @@ typedef struct cmdgen_config {
                                       required by cmdgen_joint_chain */
     float   edge_cutoff;           /* 6.0; < 0 means no cutoff (complete graph per sample) */
     float   norm_constant;         /* 1  */
-    float   normalization_factor;  /* 100 ('sum' aggregation only) */
+    float   normalization_factor;  /* 100 (aggregation_method 'sum': segment sums are divided by it, egnn_new.py:285-286) */
     float   coords_range;          /* 15 (egnn_new.py:161; quirk: never divided by n_layers) */
     float   norm_x;                /* norm_values[0] = 1 */
     float   norm_h;                /* norm_values[1] = 4 */
     float   bias_h;                /* norm_biases[1] = 0 */
+    int32_t aggregation_mean;      /* 0 = aggregation_method 'sum'; 1 = 'mean' (egnn_new.py:288-292: every segment sum is divided by its
+                                      receiver's edge count instead of normalization_factor); sampling only */
 } cmdgen_config;
 
 /* Work counters accumulated on the device since the last reset (for the
@@ -408,7 +411,8 @@ int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16);
  *   grids                "edge_wgs_per_cu", "coord_wgs_per_cu" (persistent-style edge grids of the <= 64-row kernels),
  *                        "e128_wgs_per_cu" 1|2
  *   kernel variants      "edge_fullk" 0|1 (full-K planes for 32-row edge tiles), "node64" 0|1|32 (64-row planes node kernel;
- *                        32: its 32-row form), "node16_split" 0|1, "write_embed" 0|1 (graph pass 2 + k_embed in one launch)
+ *                        32: its 32-row form), "node16_split" 0|1, "node16w" 0|1 (16-row node tiles of H = 256 on eight waves,
+ *                        kernels_node16w.hip; default 1), "write_embed" 0|1 (graph pass 2 + k_embed in one launch)
  *   dead work            "dead_skip" 0|1|2 (2, default: every block skips tiles beyond L - l hops of a moving node; 1: the
  *                        last block only; 0: off)
  *   chain                "fused_step" 0|1 (posterior step + graph pass 1 in one kernel), "pocket_cache" 0|1, "graph_steps"
@@ -426,7 +430,7 @@ int cmdgen_debug_stamps(cmdgen_handle* h, uint64_t* out64, int32_t reset);
 
 /* Launch configuration in force for the current layout (measurement aid): key = "node_mt" | "edge_mt" | "coord_mt"
  * (rows per tile of the three MFMA kernels), "edge_grid" | "coord_grid" (workgroups of the persistent-style edge
- * kernels), "gemm_split" (the mode above), "node16_split", "node64", "edge_fullk", "dead_skip" (as resolved from the
+ * kernels), "gemm_split" (the mode above), "node16_split", "node16w", "node64", "edge_fullk", "dead_skip" (as resolved from the
  * options and the layout), "train_edges" | "train_coord_edges" (edges of the last cmdgen_train_forward). */
 int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value);
 

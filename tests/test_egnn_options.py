@@ -1,0 +1,131 @@
+"""The two EGNN constructor options no shipped config uses but the reference implements - `inv_sublayers` > 1 (several GCLs per
+EquivariantBlock, egnn_new.py:127-131, :152-154) and `aggregation_method='mean'` (egnn_new.py:288-292) - against golden G16, captured from
+the real reference by tests/golden/make_golden_r4.py g16: the CPU oracle (not gpu) and the HIP path through every node / edge kernel
+family a layout can select (gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, masks_from_sizes, rms, NoiseTape
+from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
+
+G16 = load_golden('g16_egnn_options.npz')
+DYN = sorted({k.split('/')[0] for k in G16 if not k.startswith('chain_')})
+CHAINS = sorted({k.split('/')[0] for k in G16 if k.startswith('chain_')})
+
+
+def dyn_case(name):
+    H, L, S, mean, B, R, seed, first, ragged = [int(v) for v in G16[name + '/meta']]
+    cfg = ModelConfig(hidden_nf=H, n_layers=L, residue_nf=R, timesteps=500, inv_sublayers=S, aggregation_method='mean' if mean else 'sum')
+    return cfg, make_state_dict(cfg, seed=seed, coord_gain=1.0)
+
+
+def chain_case(name):
+    H, L, S, mean, B, R, seed, first, K = [int(v) for v in G16[name + '/meta']]
+    cfg = ModelConfig(hidden_nf=H, n_layers=L, residue_nf=R, timesteps=500, inv_sublayers=S, aggregation_method='mean' if mean else 'sum',
+                      noise_precision=0.05, norm_values=(1.0, 0.5))
+    return cfg, make_state_dict(cfg, seed=seed, coord_gain=1e-3), make_pockets(B, 'CA', ragged=True, n_phar=8, first_index=first), K
+
+
+# ----------------------------------------------------------------------------- the oracle (CPU)
+@pytest.mark.parametrize('name', DYN)
+def test_oracle_dynamics_forward_g16(name):
+    from oracle import ref_cpu
+    cfg, sd = dyn_case(name)
+    pm, qm = masks_from_sizes(G16[name + '/pocket_size'], G16[name + '/num_nodes_phar'])
+    with torch.no_grad():
+        ep, eq = ref_cpu.dynamics_forward(ref_cpu.to_torch_params(sd), cfg.as_dict(), torch.from_numpy(G16[name + '/xh_phar']),
+                                          torch.from_numpy(G16[name + '/xh_pocket']), torch.from_numpy(G16[name + '/t']),
+                                          torch.from_numpy(pm), torch.from_numpy(qm))
+    for got, key in ((ep, 'eps_phar'), (eq, 'eps_pocket')):
+        want = G16[name + '/' + key]
+        assert np.abs(got.numpy() - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize('name', CHAINS)
+def test_oracle_chain_g16(name):
+    from oracle import ref_cpu
+    cfg, sd, pb, K = chain_case(name)
+    pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot), 'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
+    tape = NoiseTape(G16[name + '/noise'])
+    with torch.no_grad():
+        out = ref_cpu.sample_given_pocket(ref_cpu.to_torch_params(sd), cfg.as_dict(), pocket, pb.num_nodes_phar, timesteps=K, noise=tape)
+    want = G16[name + '/xh_phar']
+    assert tape.i == K + 2
+    assert rms(out[0][:, :3].numpy(), want[:, :3]) < 1e-4 and np.array_equal(out[0][:, 3:].numpy(), want[:, 3:])
+
+
+# ----------------------------------------------------------------------------- the HIP path
+def _gpu():
+    from cmdgen_amd import hip_backend
+    return hip_backend, torch.device('cuda')
+
+
+OPTION_SETS = [{}, {'node_mt': 16, 'node16w': 0, 'edge_mt': 16, 'coord_mt': 16}, {'node_mt': 32, 'edge_mt': 64, 'coord_mt': 64},
+               {'node_mt': 64, 'node64': 0, 'edge_mt': 32, 'coord_mt': 32, 'edge_fullk': 0}, {'node64': 1, 'edge_mt': 128, 'coord_mt': 128},
+               {'node64': 32}]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('engine', ['split', 'fp32'])
+@pytest.mark.parametrize('opts', range(len(OPTION_SETS)))
+@pytest.mark.parametrize('name', DYN)
+def test_hip_dynamics_forward_g16(name, opts, engine):
+    hip_backend, dev = _gpu()
+    cfg, sd = dyn_case(name)
+    o = OPTION_SETS[opts]
+    if cfg.hidden_nf != 256 and any(k in o for k in ('node64', 'node16w')) and o.get('node64', 0):
+        pytest.skip('plane node tiles: hidden_nf 256 only')
+    if engine == 'fp32' and opts not in (0, 2):
+        pytest.skip('fp32 instruction: the default layout and one forced tile set')
+    h = hip_backend.Handle(cfg.as_dict(), 0)
+    h.load_state_dict(sd)
+    h.set_gemm_mode(engine == 'split')
+    for k, v in o.items():
+        if cfg.hidden_nf != 256 and (k in ('node64', 'node16w') or v == 128):
+            continue
+        h.set_option(k, v)
+    h.set_layout(G16[name + '/num_nodes_phar'], G16[name + '/pocket_size'])
+    ep, eq = h.dynamics_forward(torch.from_numpy(G16[name + '/xh_phar']).to(dev), torch.from_numpy(G16[name + '/xh_pocket']).to(dev),
+                                torch.from_numpy(G16[name + '/t']).to(dev), want_pocket=True)
+    want = G16[name + '/eps_phar']
+    assert float(np.abs(ep.cpu().numpy() - want).max()) <= 2e-5 * max(1.0, float(np.abs(want).max()))
+    wq = G16[name + '/eps_pocket']
+    assert float(np.abs(eq.cpu().numpy() - wq).max()) <= 2e-5 * max(1.0, float(np.abs(wq).max()))
+    h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('use_graph', [False, True])
+@pytest.mark.parametrize('name', CHAINS)
+def test_hip_chain_g16(name, use_graph):
+    hip_backend, dev = _gpu()
+    from test_hip_parity_r2 import host_step_table
+    cfg, sd, pb, K = chain_case(name)
+    h = hip_backend.Handle(cfg.as_dict(), 0)
+    h.load_state_dict(sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    h.set_step_table(K, host_step_table(cfg, K))
+    x, xp, _ = h.sample_chain(torch.from_numpy(pb.x).to(dev), torch.from_numpy(pb.one_hot).to(dev), K,
+                              noise=torch.from_numpy(G16[name + '/noise']).to(dev), use_graph=use_graph)
+    st = h.chain_status()
+    want = G16[name + '/xh_phar']
+    assert rms(x[:, :3].cpu().numpy(), want[:, :3]) <= 1e-4
+    assert np.array_equal(x[:, 3:].cpu().numpy(), want[:, 3:])
+    assert rms(xp.cpu().numpy(), G16[name + '/xh_pocket']) <= 1e-4
+    assert st['nan_resets'] == 0 and st['max_rel_com_error'] < 1e-2
+    h.close()
+
+
+@pytest.mark.gpu
+def test_training_refuses_the_options_it_does_not_cover():
+    hip_backend, dev = _gpu()
+    cfg, sd = dyn_case('ca_h64_s2_sum')
+    h = hip_backend.Handle(cfg.as_dict(), 0)
+    h.load_state_dict(sd)
+    h.set_layout(G16['ca_h64_s2_sum/num_nodes_phar'], G16['ca_h64_s2_sum/pocket_size'])
+    n = h.param_count() if hasattr(h, 'param_count') else 1
+    with pytest.raises(hip_backend.CmdgenError, match='inv_sublayers = 1'):
+        z = torch.zeros(8, device=dev)
+        h._check(h.lib.cmdgen_train_forward(h.h, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None, None), 'cmdgen_train_forward')
+    h.close()
