@@ -157,6 +157,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
         assert timesteps % return_frames == 0
         n_samples = len(pocket['size'])
         device = pocket['x'].device
+        self.refresh_learned_schedule()
         h = self.dynamics.hip_handle()
         sizes = pocket['size'].detach().to('cpu', torch.int64).numpy()
         nph = torch.as_tensor(num_nodes_phar).detach().to('cpu', torch.int64).numpy()
@@ -211,7 +212,7 @@ class SimpleConditionalDDPM(ConditionalDDPM):
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.dynamics.attach_diffusion(self.T, self.gamma.gamma.detach().cpu().numpy(), self.norm_values,
+        self.dynamics.attach_diffusion(self.T, self.gamma_table_host(), self.norm_values,
                                        self.norm_biases, no_com_projection=True)
 
     def subspace_dimensionality(self, input_size):

@@ -35,6 +35,49 @@ class PredefinedNoiseSchedule(nn.Module):
         return self.gamma[torch.round(t * self.timesteps).long()]
 
 
+class PositiveLinear(nn.Module):
+    """Linear layer whose weight enters through softplus (en_diffusion.py:1025-1056)."""
+    def __init__(self, in_features, out_features, weight_init_offset=-2):
+        super().__init__()
+        bound = 1.0 / math.sqrt(in_features)
+        self.weight = nn.Parameter(torch.empty(out_features, in_features).uniform_(-bound, bound) + weight_init_offset)
+        self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
+
+    def forward(self, x):
+        return F.linear(x, F.softplus(self.weight), self.bias)
+
+
+class GammaNetwork(nn.Module):
+    """noise_schedule='learned' (en_diffusion.py:1058-1096): a monotone network t -> gamma(t), normalised to
+    [gamma_0, gamma_1].  A scalar per-chain quantity like the predefined table: evaluated on the host with the reference's
+    torch ops; the sampler's per-step scalars (step_table) are built from it and handed to the HIP library."""
+    def __init__(self):
+        super().__init__()
+        self.l1, self.l2, self.l3 = PositiveLinear(1, 1), PositiveLinear(1, 1024), PositiveLinear(1024, 1)
+        self.gamma_0 = nn.Parameter(torch.tensor([-5.]))
+        self.gamma_1 = nn.Parameter(torch.tensor([10.]))
+
+    def gamma_tilde(self, t):
+        l1_t = self.l1(t)
+        return l1_t + self.l3(torch.sigmoid(self.l2(l1_t)))
+
+    def forward(self, t):
+        zeros, ones = torch.zeros_like(t), torch.ones_like(t)
+        g0, g1, gt = self.gamma_tilde(zeros), self.gamma_tilde(ones), self.gamma_tilde(t)
+        return self.gamma_0 + (self.gamma_1 - self.gamma_0) * ((gt - g0) / (g1 - g0))
+
+    def table(self, timesteps):
+        """gamma(i / T), i = 0..T, fp32 on the host: what the HIP handle stores where a predefined schedule has its lookup table."""
+        with torch.no_grad():
+            t = (torch.arange(timesteps + 1, dtype=torch.float32) / timesteps).view(-1, 1)
+            return self.cpu_copy()(t).view(-1).numpy().astype(np.float32)
+
+    def cpu_copy(self):
+        g = GammaNetwork()
+        g.load_state_dict({k: v.detach().cpu() for k, v in self.state_dict().items()})
+        return g
+
+
 class DistributionNodes:
     """Joint histogram over (n_phar, n_pocket) node counts with +1e-3 smoothing (en_diffusion.py:952-1022)."""
     def __init__(self, histogram):
@@ -108,10 +151,12 @@ class EnVariationalDiffusion(nn.Module):
         super().__init__()
         assert loss_type in {'vlb', 'l2'}
         assert parametrization == 'eps'
-        if noise_schedule == 'learned':
-            raise NotImplementedError("noise_schedule='learned' is not used by the shipped configs and not built")
+        self.learned_schedule = noise_schedule == 'learned'
+        if self.learned_schedule:       # (en_diffusion.py:41-46; sampling only here: the training step needs a predefined schedule)
+            assert loss_type == 'vlb', 'A noise schedule can only be learned with a vlb objective.'
         self.loss_type = loss_type
-        self.gamma = PredefinedNoiseSchedule(noise_schedule, timesteps=timesteps, precision=noise_precision)
+        self.gamma = GammaNetwork() if self.learned_schedule else \
+            PredefinedNoiseSchedule(noise_schedule, timesteps=timesteps, precision=noise_precision)
         self.dynamics = dynamics
         self.phar_nf, self.residue_nf, self.n_dims = phar_nf, residue_nf, n_dims
         self.num_classes = phar_nf
@@ -120,9 +165,10 @@ class EnVariationalDiffusion(nn.Module):
         self.norm_values, self.norm_biases = norm_values, norm_biases
         self.register_buffer('buffer', torch.zeros(1))
         self.size_distribution = DistributionNodes(size_histogram)
-        self.check_issues_norm_values()
+        if not self.learned_schedule:
+            self.check_issues_norm_values()
         if hasattr(dynamics, 'attach_diffusion'):
-            dynamics.attach_diffusion(timesteps, self.gamma.gamma.detach().cpu().numpy(), norm_values, norm_biases)
+            dynamics.attach_diffusion(timesteps, self.gamma_table_host(), norm_values, norm_biases)
 
     def check_issues_norm_values(self, num_stdevs=8):
         zeros = torch.zeros((1, 1))
@@ -155,11 +201,23 @@ class EnVariationalDiffusion(nn.Module):
         alpha_t_given_s = self.inflate_batch_array(torch.exp(0.5 * log_alpha2_t_given_s), target_tensor)
         return sigma2_t_given_s, torch.sqrt(sigma2_t_given_s), alpha_t_given_s
 
+    def gamma_table_host(self) -> np.ndarray:
+        """gamma at t = i / T: the predefined lookup table, or the learned network tabulated with its current weights."""
+        return self.gamma.table(self.T) if self.learned_schedule else self.gamma.gamma.detach().cpu().numpy()
+
+    def refresh_learned_schedule(self):
+        """A learned schedule's weights may have changed since the handle was built (load_state_dict): re-attach its table."""
+        if self.learned_schedule and hasattr(self.dynamics, 'attach_diffusion'):
+            tab = self.gamma_table_host()
+            if not np.array_equal(tab, getattr(self.dynamics, '_gamma', None)):
+                self.dynamics.attach_diffusion(self.T, tab, self.norm_values, self.norm_biases,
+                                               no_com_projection=bool(self.dynamics._cfg.get('no_com_projection', False)))
+
     def step_table(self, timesteps: int) -> np.ndarray:
         """[K+1, 4] per-step scalars of the ancestral sampler, evaluated with the reference's
         own op sequence on a single-sample batch (conditional_model.py:345-366, :429-433;
         final row: sigma_0, alpha_0, SNR(-gamma_0/2), t=0 from :108-131)."""
-        table = self.gamma.gamma.detach().cpu()
+        table = torch.from_numpy(self.gamma_table_host())          # (learned: the tabulation is the cache key, the network is evaluated at t itself)
         T, K = self.T, timesteps
         cache = self.__dict__.setdefault('_step_tables', {})        # K tiny torch ops x 15 per call otherwise
         hit = cache.get(K)
@@ -167,7 +225,11 @@ class EnVariationalDiffusion(nn.Module):
             return hit[1]
         z = torch.zeros(1, 1)
         rows = []
-        look = lambda t: table[torch.round(t * T).long()]
+        if self.learned_schedule:
+            net = self.gamma.cpu_copy()
+            look = lambda t: net(t).detach()
+        else:
+            look = lambda t: table[torch.round(t * T).long()]
         for s in reversed(range(K)):
             s_arr = torch.full((1, 1), fill_value=s) / K
             t_arr = (torch.full((1, 1), fill_value=s) + 1) / K
@@ -379,6 +441,7 @@ class EnVariationalDiffusion(nn.Module):
         if not getattr(self.dynamics, 'update_pocket_coords', False):
             raise ValueError("the joint sampler needs EGNNDynamics(update_pocket_coords=True) (mode 'joint', "
                              "lightning_modules.py:125)")
+        self.refresh_learned_schedule()      # (the joint chain's op table is built from the handle's gamma table)
         h = self.dynamics.hip_handle()
         h.set_layout(nph, npk)
         return h

@@ -135,8 +135,19 @@ def make_state_dict(cfg: ModelConfig, seed: int = 0, coord_gain: float = 1e-3,
     rng = np.random.Generator(np.random.PCG64(seed))
     sd = OrderedDict()
     sd[prefix + 'buffer'] = np.zeros(1, dtype=np.float32)
-    sd[prefix + 'gamma.gamma'] = gamma_table(cfg.noise_schedule, cfg.timesteps,
-                                             cfg.noise_precision)
+    if cfg.noise_schedule == 'learned':
+        # GammaNetwork (en_diffusion.py:1058-1074): PositiveLinear(1, 1), (1, 1024), (1024, 1) with the weights offset by -2 before
+        # the softplus, gamma_0 / gamma_1; its own stream, so the other tensors do not depend on the schedule
+        grng = np.random.Generator(np.random.PCG64(7_000_003 + seed))
+        for nm, (fo, fi) in (('l1', (1, 1)), ('l2', (1024, 1)), ('l3', (1, 1024))):
+            b = 1.0 / math.sqrt(fi)
+            sd[prefix + f'gamma.{nm}.weight'] = (grng.uniform(-b, b, size=(fo, fi)) - 2.0).astype(np.float32)
+            sd[prefix + f'gamma.{nm}.bias'] = grng.uniform(-b, b, size=(fo,)).astype(np.float32)
+        sd[prefix + 'gamma.gamma_0'] = np.asarray([-5.0], dtype=np.float32)
+        sd[prefix + 'gamma.gamma_1'] = np.asarray([10.0], dtype=np.float32)
+    else:
+        sd[prefix + 'gamma.gamma'] = gamma_table(cfg.noise_schedule, cfg.timesteps,
+                                                 cfg.noise_precision)
     for name, (fo, fi, has_bias) in linear_specs(cfg).items():
         if name.endswith('coord_mlp.4'):
             bound = coord_gain * math.sqrt(6.0 / (fi + fo))

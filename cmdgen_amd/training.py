@@ -61,6 +61,8 @@ class HipTrainer:
                  gemm_dtype: str = 'fp32'):
         self.joint = model.mode == 'joint'
         assert model.loss_type in ('l2', 'vlb')
+        if getattr(model.ddpm, 'learned_schedule', False):
+            raise NotImplementedError("noise_schedule='learned': the training step differentiates a predefined schedule only (sampling works)")
         self.model = model
         self.ddpm = model.ddpm
         self.dyn = model.ddpm.dynamics

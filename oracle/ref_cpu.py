@@ -96,8 +96,35 @@ def gamma_table(noise_schedule: str, timesteps: int, precision: float) -> torch.
     return torch.from_numpy(gamma).float()
 
 
-def gamma_lookup(table: torch.Tensor, t: torch.Tensor, T: int) -> torch.Tensor:
-    """PredefinedNoiseSchedule.forward :1186-1188."""
+class GammaNet:
+    """noise_schedule='learned': GammaNetwork.forward (en_diffusion.py:1058-1096) over PositiveLinear layers (:1025-1056) -
+    the monotone network l1(t) + l3(sigmoid(l2(l1(t)))) with softplus-ed weights, normalised to [gamma_0, gamma_1]."""
+    def __init__(self, p):
+        self.p = {k[len('gamma.'):]: v for k, v in p.items() if k.startswith('gamma.')}
+
+    def _pl(self, name, x):
+        return F.linear(x, F.softplus(self.p[name + '.weight']), self.p[name + '.bias'])
+
+    def tilde(self, t):
+        l1 = self._pl('l1', t)
+        return l1 + self._pl('l3', torch.sigmoid(self._pl('l2', l1)))
+
+    def __call__(self, t):
+        zeros, ones = torch.zeros_like(t), torch.ones_like(t)
+        g0, g1, gt = self.tilde(zeros), self.tilde(ones), self.tilde(t)
+        normalized = (gt - g0) / (g1 - g0)
+        return self.p['gamma_0'] + (self.p['gamma_1'] - self.p['gamma_0']) * normalized
+
+
+def gamma_source(p):
+    """The model's gamma: the lookup table of a predefined schedule, or the network of a learned one."""
+    return GammaNet(p) if 'gamma.l1.weight' in p else p['gamma.gamma']
+
+
+def gamma_lookup(table, t: torch.Tensor, T: int) -> torch.Tensor:
+    """PredefinedNoiseSchedule.forward :1186-1188; a learned schedule evaluates its network at t itself (:1082-1096)."""
+    if isinstance(table, GammaNet):
+        return table(t.to(FLOAT))
     return table[torch.round(t * T).long()]
 
 
@@ -301,7 +328,7 @@ def sample_given_pocket(p, cfg, pocket, num_nodes_phar, timesteps=None,
     T = cfg['timesteps']
     nd, pnf = cfg['n_dims'], cfg['phar_nf']
     nv, nb = cfg['norm_values'], cfg['norm_biases']
-    table = p['gamma.gamma']
+    table = gamma_source(p)
     timesteps = T if timesteps is None else timesteps
     draw = noise if noise is not None else (lambda shape: torch.randn(shape))
     n_samples = len(pocket['size'])
@@ -403,7 +430,7 @@ def _remove_mean_all(z_phar, z_pocket, phar_mask, pocket_mask, nd):
 def joint_sample_p_zs_given_zt(p, cfg, s, t, zt_phar, zt_pocket, phar_mask, pocket_mask, draw, checks=True):
     """EnVariationalDiffusion.sample_p_zs_given_zt, en_diffusion.py:499-553."""
     T, nd = cfg['timesteps'], cfg['n_dims']
-    table = p['gamma.gamma']
+    table = gamma_source(p)
     gamma_s, gamma_t = gamma_lookup(table, s, T), gamma_lookup(table, t, T)
     sigma2_ts, sigma_ts, alpha_ts = sigma_and_alpha_t_given_s(gamma_t, gamma_s)
     sigma_s, sigma_t = sigma_of(gamma_s), sigma_of(gamma_t)
@@ -438,7 +465,7 @@ def joint_sample_p_xh_given_z0(p, cfg, z0_phar, z0_pocket, phar_mask, pocket_mas
     T, nd = cfg['timesteps'], cfg['n_dims']
     nv, nb = cfg['norm_values'], cfg['norm_biases']
     t_zeros = torch.zeros((n_samples, 1))
-    gamma_0 = gamma_lookup(p['gamma.gamma'], t_zeros, T)
+    gamma_0 = gamma_lookup(gamma_source(p), t_zeros, T)
     sigma_x = torch.exp(-(-0.5 * gamma_0))
     net_phar, net_pocket = dynamics_forward(p, cfg, z0_phar, z0_pocket, t_zeros, phar_mask, pocket_mask)
     sigma_0, alpha_0 = sigma_of(gamma_0), alpha_of(gamma_0)
@@ -522,7 +549,7 @@ def joint_inpaint(p, cfg, phar, pocket, phar_fixed, pocket_fixed, resamplings=1,
     sample_given_pocket): the known part is built from raw x and raw one_hot."""
     T, nd = cfg['timesteps'], cfg['n_dims']
     assert cfg['update_pocket_coords']
-    table = p['gamma.gamma']
+    table = gamma_source(p)
     timesteps = T if timesteps is None else timesteps
     draw = noise if noise is not None else (lambda shape: torch.randn(shape))
     phar_fixed = torch.as_tensor(phar_fixed).to(FLOAT)
@@ -620,7 +647,7 @@ def _gaussian_KL(q_mu2, q_sigma, p_sigma, d):
 def ddpm_forward(p, cfg, phar, pocket, t_int, eps_draws, training, histogram):
     """-> the 12 loss terms + info of ConditionalDDPM.forward with t_int [B,1] and the Gaussian draws given."""
     T, nd, nv, nb = cfg['timesteps'], cfg['n_dims'], cfg['norm_values'], cfg['norm_biases']
-    table = p['gamma.gamma']
+    table = gamma_source(p)
     draws = iter(eps_draws)
     B = len(phar['size'])
     pm, qm = phar['mask'].to(INT), pocket['mask'].to(INT)
@@ -710,7 +737,7 @@ def joint_ddpm_forward(p, cfg, phar, pocket, t_int, draw, training, histogram):
     t_int [B,1] given and every Gaussian draw supplied by ``draw(shape)`` in the reference's call order."""
     T, nd, nv, nb = cfg['timesteps'], cfg['n_dims'], cfg['norm_values'], cfg['norm_biases']
     P, R = cfg['phar_nf'], cfg['residue_nf']
-    table = p['gamma.gamma']
+    table = gamma_source(p)
     B = len(phar['size'])
     pm, qm = phar['mask'].to(INT), pocket['mask'].to(INT)
     x_l, h_l = phar['x'].to(FLOAT) / nv[0], (phar['one_hot'].float() - nb[1]) / nv[1]        # normalize :874-889

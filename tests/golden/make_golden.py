@@ -110,7 +110,7 @@ def import_reference():
 
 
 # ------------------------------------------------------------------ builders
-def build_reference_ddpm(mods, cfg: ModelConfig, seed, coord_gain, histogram, simple=False):
+def build_reference_ddpm(mods, cfg: ModelConfig, seed, coord_gain, histogram, simple=False, loss_type='l2'):
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):      # reference prints the tables
         dyn = mods['dynamics'].EGNNDynamics(
@@ -125,7 +125,7 @@ def build_reference_ddpm(mods, cfg: ModelConfig, seed, coord_gain, histogram, si
         ddpm = cls(
             dynamics=dyn, phar_nf=cfg.phar_nf, residue_nf=cfg.residue_nf, n_dims=3,
             timesteps=cfg.timesteps, noise_schedule=cfg.noise_schedule,
-            noise_precision=cfg.noise_precision, loss_type='l2',
+            noise_precision=cfg.noise_precision, loss_type=loss_type,
             norm_values=list(cfg.norm_values), size_histogram=histogram)
     sd = make_state_dict(cfg, seed=seed, coord_gain=coord_gain, prefix='')
     missing = ddpm.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)

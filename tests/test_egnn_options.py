@@ -129,3 +129,61 @@ def test_training_refuses_the_options_it_does_not_cover():
         z = torch.zeros(8, device=dev)
         h._check(h.lib.cmdgen_train_forward(h.h, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None, None), 'cmdgen_train_forward')
     h.close()
+
+
+# ----------------------------------------------------------------------------- noise_schedule='learned' (GammaNetwork, en_diffusion.py:1058-1096): sampling
+G17 = load_golden('g17_learned_schedule.npz')
+LEARNED = sorted({k.split('/')[0] for k in G17})
+
+
+def learned_case(name):
+    H, L, B, seed, first, K = [int(v) for v in G17[name + '/meta']]
+    cfg = ModelConfig(hidden_nf=H, n_layers=L, residue_nf=20, timesteps=500, noise_schedule='learned')
+    return cfg, make_state_dict(cfg, seed=seed, coord_gain=1e-3), make_pockets(B, 'CA', ragged=True, n_phar=8, first_index=first), K
+
+
+@pytest.mark.parametrize('name', LEARNED)
+def test_oracle_learned_schedule_g17(name):
+    from oracle import ref_cpu
+    cfg, sd, pb, K = learned_case(name)
+    p = ref_cpu.to_torch_params(sd)
+    with torch.no_grad():
+        grid = ref_cpu.gamma_lookup(ref_cpu.gamma_source(p), torch.linspace(0, 1, 101).view(-1, 1), cfg.timesteps).view(-1).numpy()
+    assert np.abs(grid - G17[name + '/gamma_grid']).max() <= 2e-6 * 10.0                 # gamma in [-5, 10]
+    pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot), 'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
+    tape = NoiseTape(G17[name + '/noise'])
+    with torch.no_grad():
+        out = ref_cpu.sample_given_pocket(p, cfg.as_dict(), pocket, pb.num_nodes_phar, timesteps=K, noise=tape)
+    want = G17[name + '/xh_phar']
+    assert rms(out[0][:, :3].numpy(), want[:, :3]) <= 1e-6 * float(np.abs(want[:, :3]).max())      # |x| ~ 450 A (untrained weights, 1 / alpha_T = 150)
+    assert np.array_equal(out[0][:, 3:].numpy(), want[:, 3:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('use_graph', [False, True])
+@pytest.mark.parametrize('name', LEARNED)
+def test_hip_learned_schedule_chain_g17(name, use_graph):
+    """The Python mirror end to end: ConditionalDDPM(noise_schedule='learned') loads the reference's state_dict (gamma.l1 / l2 / l3 /
+    gamma_0 / gamma_1), builds the per-step scalars from the network with the reference's op sequence and runs the chain on the device."""
+    from cmdgen_amd.equivariant_diffusion.dynamics import EGNNDynamics
+    from cmdgen_amd.equivariant_diffusion.conditional_model import ConditionalDDPM
+    cfg, sd, pb, K = learned_case(name)
+    dyn = EGNNDynamics(phar_nf=8, residue_nf=20, n_dims=3, joint_nf=32, hidden_nf=cfg.hidden_nf, n_layers=cfg.n_layers, attention=True,
+                       tanh=True, norm_constant=1, inv_sublayers=1, normalization_factor=100, aggregation_method='sum',
+                       edge_cutoff=6.0, update_pocket_coords=False)
+    ddpm = ConditionalDDPM(dynamics=dyn, phar_nf=8, residue_nf=20, n_dims=3, timesteps=500, noise_schedule='learned',
+                           noise_precision=1e-5, loss_type='vlb', norm_values=[1, 4], size_histogram=np.ones((30, 70)))
+    ddpm.load_state_dict({k[len('ddpm.'):]: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    ddpm = ddpm.cuda()
+    ddpm.use_hip_graph = use_graph
+    with torch.no_grad():
+        grid = ddpm.gamma(torch.linspace(0, 1, 101, device='cuda').view(-1, 1)).view(-1).cpu().numpy()
+    assert np.abs(grid - G17[name + '/gamma_grid']).max() <= 2e-5
+    pocket = {'x': torch.from_numpy(pb.x).cuda(), 'one_hot': torch.from_numpy(pb.one_hot).cuda(), 'size': torch.from_numpy(pb.size).cuda(),
+              'mask': torch.from_numpy(pb.mask).cuda()}
+    out = ddpm.sample_given_pocket(pocket, torch.from_numpy(pb.num_nodes_phar), timesteps=K, noise=torch.from_numpy(G17[name + '/noise']))
+    want = G17[name + '/xh_phar']
+    got = out[0].cpu().numpy()
+    assert rms(got[:, :3], want[:, :3]) <= 2e-6 * float(np.abs(want[:, :3]).max())
+    assert np.array_equal(got[:, 3:], want[:, 3:])
+    assert rms(out[1].cpu().numpy(), G17[name + '/xh_pocket']) <= 2e-6 * float(np.abs(G17[name + '/xh_pocket']).max())
