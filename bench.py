@@ -551,7 +551,7 @@ def main(argv=None):
                             f'({"split-bf16 matrix engine on tiles of >= 32 rows: fp32-accurate" if launch_cfg["gemm_split"] else "fp32 MFMA"}); '
                             f'one bench step = one such chain',
                 'pockets_per_gpu': B, 'timesteps': T, 'representation': rep,
-                'model': f'EGNN denoiser hidden_nf={H} n_layers={L} joint_nf={cfg.joint_nf} cutoff={cfg.edge_cutoff}, '
+                'denoiser': f'EGNN hidden_nf={H} n_layers={L} joint_nf={cfg.joint_nf} cutoff={cfg.edge_cutoff}, '
                          f'random-init weights (seed 0), noise_precision={cfg.noise_precision}, norm_values={list(cfg.norm_values)}',
                 'hip_graph': use_graph, 'noise': 'on-device Philox4x32-10',
                 'us_per_denoising_step': 1e6 * elapsed / (args.steps * evals_per_chain),
