@@ -12,6 +12,12 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # A/B aid: CMDGEN_TEST_OPTIONS="node_w8=64,..." runs the whole suite with these launch options on every new Handle
+    # (the library itself reads no environment variable; tests that set options explicitly override them)
+    extra = os.environ.get('CMDGEN_TEST_OPTIONS', '')
+    if extra:
+        from cmdgen_amd import hip_backend
+        hip_backend.DEFAULT_OPTIONS.update(hip_backend.parse_options(extra))
 
 
 def pytest_collection_modifyitems(config, items):
