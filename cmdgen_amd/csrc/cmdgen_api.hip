@@ -18,6 +18,7 @@ void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* 
                         const float* t_arr, const float4* coef, ChainState* chain, float* eps_phar,
                         float* eps_pocket, hipStream_t s, hipEvent_t* ev);
 void cmdgen_launch_nan_fix(const EvalLaunch& a, float* eps_phar, hipStream_t s);
+void cmdgen_readout_allow_lds(size_t bytes);      // kernels_egnn.hip: k_readout's dynamic LDS above the 64 KiB default (hidden_nf 512)
 void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s);
 void cmdgen_build_pocket_cache(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, const float* t01,
                                float* c, float* P0, float* Q0, float* dh, float* dP, float* dQ, hipStream_t s);
@@ -50,8 +51,8 @@ extern "C" const char* cmdgen_last_error(const cmdgen_handle* h) { return h ? h-
 extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle** out) {
     if (!cfg || !out) return fail(nullptr, CMDGEN_EINVAL, "null argument");
     const int H = cfg->hidden_nf;
-    if (!(H == 64 || H == 128 || H == 256))
-        return fail(nullptr, CMDGEN_EINVAL, "hidden_nf=%d unsupported: the gfx950 kernels tile 64 columns per wave (64, 128 or 256)", H);
+    if (!(H == 64 || H == 128 || H == 256 || H == 512))
+        return fail(nullptr, CMDGEN_EINVAL, "hidden_nf=%d unsupported: the gfx950 kernels tile 64 columns per wave and are built for 64, 128, 256 and 512", H);
     if (cfg->inv_sublayers < 1 || cfg->inv_sublayers > 8) return fail(nullptr, CMDGEN_EINVAL, "inv_sublayers=%d out of range [1, 8]", cfg->inv_sublayers);
     if (cfg->n_layers < 1 || cfg->n_layers > CMDGEN_MAX_LAYERS) return fail(nullptr, CMDGEN_EINVAL, "n_layers out of range");
     if (cfg->phar_nf < 1 || 2 * cfg->phar_nf > CMDGEN_MAX_SMALL || cfg->residue_nf < 1 ||
@@ -80,6 +81,7 @@ extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle
     d.S = cfg->inv_sublayers; d.agg_mean = cfg->aggregation_mean ? 1 : 0;
     d.norm_x = cfg->norm_x; d.norm_h = cfg->norm_h; d.bias_h = cfg->bias_h;
     h->n_cus = prop.multiProcessorCount;
+    if ((size_t)(8 + d.dyn) * H * sizeof(float) > 64 * 1024) cmdgen_readout_allow_lds((size_t)(8 + d.dyn) * H * sizeof(float));
     h->edge_grid = 2 * prop.multiProcessorCount;      // two 66 KB-LDS workgroups per CU at 64-row tiles
     h->gemm_split = true;                             // matrix engine of the tiles of >= 32 rows (cmdgen_set_gemm_mode)
     *out = h;

@@ -149,6 +149,7 @@ void cmdgen_train_free(TrainState* t) {
 
 static int ensure_state(cmdgen_handle* h) {
     if (h->train) return 0;
+    if (h->dims.H > 256) return fail(h, CMDGEN_ESTATE, "the training step is built for hidden_nf <= 256");
     if (h->dims.S != 1 || h->dims.agg_mean)
         return fail(h, CMDGEN_ESTATE, "the training step supports inv_sublayers = 1 and aggregation_method 'sum' (the shipped configs); this handle samples only");
     TrainState* t = new TrainState();

@@ -1337,13 +1337,16 @@ __global__ __launch_bounds__(64) void k_vel_com(Layout lay, Work w, Dims d, floa
 // ------------------------------------------------------------------------------------
 template <int H, int MT, bool SP> static void launch_embed(const EvalLaunch& a, const float* xp, const float* xq, const float* t,
                                                   const float4* coef, ChainState* chain, hipStream_t s) {
-    const int nt = (a.lay.N + MT - 1) / MT;
-    const Dims& d = a.d;
-    const size_t shm = sizeof(float) * (size_t)(2 * d.P * d.P + 2 * d.P + d.J * 2 * d.P + d.J + 2 * d.R * d.R + 2 * d.R + d.J * 2 * d.R + d.J);
-    if (a.save) hipLaunchKernelGGL((k_embed<H, MT, false>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
-                                   (const ChainState*)chain, *a.save, PocketCache{});          // training packs: fp32 fragments only
-    else hipLaunchKernelGGL((k_embed<H, MT, SP>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
-                            (const ChainState*)chain, TrainSave{}, (chain && !t) ? a.pcache : PocketCache{});
+    if constexpr (H == 512 && MT == 64) launch_embed<H, 32, SP>(a, xp, xq, t, coef, chain, s);      // (its 64-row tile would need 181 KB of LDS)
+    else {
+        const int nt = (a.lay.N + MT - 1) / MT;
+        const Dims& d = a.d;
+        const size_t shm = sizeof(float) * (size_t)(2 * d.P * d.P + 2 * d.P + d.J * 2 * d.P + d.J + 2 * d.R * d.R + 2 * d.R + d.J * 2 * d.R + d.J);
+        if (a.save) hipLaunchKernelGGL((k_embed<H, MT, false>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
+                                       (const ChainState*)chain, *a.save, PocketCache{});          // training packs: fp32 fragments only
+        else hipLaunchKernelGGL((k_embed<H, MT, SP>), dim3(nt), dim3(H), shm, s, a.lay, a.w, a.d, a.sw, a.layers[0], xp, xq, t, coef,
+                                (const ChainState*)chain, TrainSave{}, (chain && !t) ? a.pcache : PocketCache{});
+    }
 }
 template <int H, int MT, bool SP> static void launch_write_embed(const EvalLaunch& a, const float* xp, const float* xq, const float* t,
                                                                  const float4* coef, ChainState* chain, hipStream_t s) {
@@ -1484,6 +1487,7 @@ void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* 
                         const float* t_arr, const float4* coef, ChainState* chain,
                         float* eps_phar, float* eps_pocket, hipStream_t s, hipEvent_t* ev) {
     switch (a.d.H) {
+        case 512: launch_eval_H<512>(a, xh_phar, xh_pocket, t_arr, coef, chain, eps_phar, eps_pocket, s, ev); break;
         case 256: launch_eval_H<256>(a, xh_phar, xh_pocket, t_arr, coef, chain, eps_phar, eps_pocket, s, ev); break;
         case 128: launch_eval_H<128>(a, xh_phar, xh_pocket, t_arr, coef, chain, eps_phar, eps_pocket, s, ev); break;
         case 64:  launch_eval_H<64>(a, xh_phar, xh_pocket, t_arr, coef, chain, eps_phar, eps_pocket, s, ev); break;
@@ -1515,6 +1519,7 @@ void cmdgen_build_pocket_cache(const EvalLaunch& a, const float* xh_phar, const 
     for (int stage = 0; stage < 2; ++stage) {
         const float* t = t01 + (size_t)stage * a.lay.B;
         switch (H) {
+            case 512: embed_only_H<512>(a, xh_phar, xh_pocket, t, s); break;
             case 256: embed_only_H<256>(a, xh_phar, xh_pocket, t, s); break;
             case 128: embed_only_H<128>(a, xh_phar, xh_pocket, t, s); break;
             case 64:  embed_only_H<64>(a, xh_phar, xh_pocket, t, s); break;
@@ -1561,6 +1566,11 @@ void cmdgen_edge_kernels_allow_lds(size_t bytes) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// k_readout stages 8 node rows + embedding_out^T in dynamic LDS: above the 64 KiB default (hidden_nf 512) the kernel needs the opt-in
+void cmdgen_readout_allow_lds(size_t bytes) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_readout), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 void cmdgen_launch_nan_fix(const EvalLaunch& a, float* eps_phar, hipStream_t s) {
     hipLaunchKernelGGL(k_nan_fix, dim3((a.lay.Nl + 255) / 256), dim3(256), 0, s, a.lay, a.w, a.d, eps_phar);
 }
@@ -1570,6 +1580,7 @@ template <int H> static void launch_msg_only_H(const EvalLaunch& a, int layer, h
 }
 void cmdgen_launch_edge_msg_only(const EvalLaunch& a, int layer, hipStream_t s) {
     switch (a.d.H) {
+        case 512: launch_msg_only_H<512>(a, layer, s); break;
         case 256: launch_msg_only_H<256>(a, layer, s); break;
         case 128: launch_msg_only_H<128>(a, layer, s); break;
         case 64:  launch_msg_only_H<64>(a, layer, s); break;

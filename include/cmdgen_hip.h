@@ -51,7 +51,7 @@ typedef struct cmdgen_config {
     int32_t phar_nf;               /* 8  */
     int32_t residue_nf;            /* 20 (CA) or 11 (full-atom) */
     int32_t joint_nf;              /* 32 */
-    int32_t hidden_nf;             /* 256; must be a multiple of 64, <= 256 */
+    int32_t hidden_nf;             /* 256; one of 64, 128, 256, 512 (512: sampling only, fp32-image tiles; the plane kernels are 256 only) */
     int32_t n_layers;              /* 5  */
     int32_t inv_sublayers;         /* 1; GCLs per EquivariantBlock (egnn_new.py:127-131): >= 1 for sampling (dead-work skipping is off above 1),
                                       the training step supports 1 only */

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (load_golden, cases_of, dynamics_case, chain_case, rms)
+from helpers import (load_golden, cases_of, dynamics_case, chain_case, rms, NoiseTape)
 from cmdgen_amd import hip_backend
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets, min_cutoff_margin
 
@@ -98,7 +98,7 @@ def test_dynamics_forward_matches_reference(name):
         assert float(np.abs(hfin[nl:nl + 16] - G2[name + f'/block{L - 1}_h_pocket_head']).max()) <= 5e-5 * max(1.0, float(np.abs(wh).max()))
 
 
-@pytest.mark.parametrize('H,L,rep', [(64, 2, 'CA'), (128, 3, 'CA'), (128, 2, 'full-atom')])
+@pytest.mark.parametrize('H,L,rep', [(64, 2, 'CA'), (128, 3, 'CA'), (128, 2, 'full-atom'), (512, 2, 'CA'), (512, 2, 'full-atom')])
 def test_dynamics_forward_matches_oracle_other_widths(H, L, rep):
     """Oracle-checked cases for the other supported hidden sizes (seeded inputs, ragged sizes)."""
     from oracle import ref_cpu
@@ -130,6 +130,34 @@ def test_dynamics_forward_matches_oracle_other_widths(H, L, rep):
     got, _ = h.dynamics_forward(dev(xh_phar), dev(xh_pocket), dev(t))
     err = float(np.abs(got.cpu().numpy() - want).max())
     assert err <= EVAL_TOL * max(1.0, float(np.abs(want).max())), err
+    if H == 512:                      # hidden_nf 512 (sampling only): every tile size of the three MFMA kernels, both engines, and a short chain
+        for mt in (16, 32, 64):
+            for split in (True, False):
+                h2 = hip_backend.Handle(cfg.as_dict(), 0)
+                h2.load_state_dict(sd); h2.set_gemm_mode(split)
+                for k in ('node_mt', 'edge_mt', 'coord_mt', 'embed_mt'):
+                    h2.set_option(k, mt)
+                h2.set_layout(pb.num_nodes_phar, pb.size)
+                g2, _ = h2.dynamics_forward(dev(xh_phar), dev(xh_pocket), dev(t))
+                e2 = float(np.abs(g2.cpu().numpy() - want).max())
+                assert e2 <= EVAL_TOL * max(1.0, float(np.abs(want).max())), (mt, split, e2)
+                h2.close()
+        K = 6
+        Nl = int(pb.num_nodes_phar.sum())
+        noise = np.random.Generator(np.random.PCG64(first)).normal(size=(K + 2, Nl, 3 + cfg.phar_nf)).astype(np.float32)
+        pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot), 'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
+        with torch.no_grad():
+            ref = ref_cpu.sample_given_pocket(p, cfg.as_dict(), pocket, pb.num_nodes_phar, timesteps=K, noise=NoiseTape(noise))
+        from test_hip_parity_r2 import host_step_table
+        for use_graph in (False, True):
+            h.set_step_table(K, host_step_table(cfg, K))
+            x, _, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), K, noise=dev(noise), use_graph=use_graph)
+            wx = ref[0].numpy()
+            assert rms(x[:, :3].cpu().numpy(), wx[:, :3]) <= 1e-4 * max(1.0, float(np.abs(wx[:, :3]).max()))
+            assert np.array_equal(x[:, 3:].cpu().numpy(), wx[:, 3:])
+        with pytest.raises(hip_backend.CmdgenError, match='hidden_nf <= 256'):
+            z = torch.zeros(8, device='cuda')
+            h._check(h.lib.cmdgen_train_forward(h.h, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None, None), 'cmdgen_train_forward')
 
 
 def run_chain(name, use_graph):
