@@ -79,11 +79,18 @@ extern "C" int cmdgen_create(const cmdgen_config* cfg, int device, cmdgen_handle
     d.cutoff2 = cfg->edge_cutoff < 0.f ? -1.f : cfg->edge_cutoff * cfg->edge_cutoff;
     d.norm_constant = cfg->norm_constant; d.norm_factor = cfg->normalization_factor; d.coords_range = cfg->coords_range;
     d.S = cfg->inv_sublayers; d.agg_mean = cfg->aggregation_mean ? 1 : 0;
+    d.sin = cfg->sin_embedding ? 1 : 0;
+    {   // SinusoidsEmbeddingNew.frequencies (egnn_new.py:252): 2 * pi * 4 ** arange(6) / 15 as torch evaluates it in fp32
+        const float two_pi = (float)6.283185307179586;
+        float p4 = 1.0f;
+        for (int k = 0; k < 6; ++k) { d.sin_freq[k] = (two_pi * p4) / 15.0f; p4 *= 4.0f; }
+    }
     d.norm_x = cfg->norm_x; d.norm_h = cfg->norm_h; d.bias_h = cfg->bias_h;
     h->n_cus = prop.multiProcessorCount;
     if ((size_t)(8 + d.dyn) * H * sizeof(float) > 64 * 1024) cmdgen_readout_allow_lds((size_t)(8 + d.dyn) * H * sizeof(float));
     h->edge_grid = 2 * prop.multiProcessorCount;      // two 66 KB-LDS workgroups per CU at 64-row tiles
-    h->gemm_split = true;                             // matrix engine of the tiles of >= 32 rows (cmdgen_set_gemm_mode)
+    h->gemm_split = !d.sin;                           // matrix engine of the tiles of >= 32 rows (cmdgen_set_gemm_mode); sin_embedding: the fp32
+                                                      // instruction (the split engine's plane builders carry the two scalar distance features only)
     *out = h;
     return CMDGEN_OK;
 }
@@ -270,7 +277,8 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
         rc = upload(h, t, &s.embo_wT); if (rc) return rc;
         GET(dy + "egnn.embedding_out.bias", d.dyn); UP(s.embo_b);
     }
-    const int ld1 = 2 * H + 2;
+    const int nfeat = d.sin ? 24 : 2;            // edge features behind [h_row | h_col]: radial + d0, or 12 + 12 sinusoids (egnn_new.py:174-176)
+    const int ld1 = 2 * H + nfeat;
     // one LayerW per GCL ("unit" b * S + sub, egnn_new.py:127-131); the block's EquivariantUpdate rides with its LAST GCL (the node kernel of
     // that unit projects P_c | Q_c), earlier units of a block carry no coordinate weights
     for (int b = 0; b < d.L; ++b)
@@ -279,7 +287,7 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
         const std::string g = dy + "egnn.e_block_" + std::to_string(b) + ".gcl_" + std::to_string(sub) + ".";
         const std::string c = dy + "egnn.e_block_" + std::to_string(b) + ".gcl_equiv.";
         auto split_first = [&](const std::string& wname, const std::string& bname, WPack* Wpq,
-                               const float** bias, const float** wr, const float** wd) -> int {
+                               const float** bias, const float** wr, const float** wd, const float** we) -> int {
             const std::vector<float>* w; int r = get_w(h, wname, (size_t)H * ld1, &w); if (r) return r;
             // stack [A ; B] as a [2H][H] matrix: rows 0..H-1 = columns 0..H-1 (h_row), rows H.. = columns H..2H-1 (h_col)
             std::vector<float> AB((size_t)2 * H * H);
@@ -293,6 +301,12 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
             }
             r = upload_pack(h, AB.data(), 2 * H, H, Wpq); if (r) return r;
             r = upload(h, vr, wr); if (r) return r; r = upload(h, vd, wd); if (r) return r;
+            *we = nullptr;
+            if (d.sin) {                   // the 24 feature columns, transposed [24][H]
+                std::vector<float> wt((size_t)24 * H);
+                for (int o = 0; o < H; ++o) for (int k = 0; k < 24; ++k) wt[(size_t)k * H + o] = (*w)[(size_t)o * ld1 + 2 * H + k];
+                r = upload(h, wt, we); if (r) return r;
+            }
             const std::vector<float>* bb; r = get_w(h, bname, H, &bb); if (r) return r;
             return upload(h, *bb, bias);
         };
@@ -300,7 +314,7 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
             const std::vector<float>* w; int r = get_w(h, wname, (size_t)H * in, &w); if (r) return r;
             return upload_pack(h, w->data(), H, in, Wp);
         };
-        rc = split_first(g + "edge_mlp.0.weight", g + "edge_mlp.0.bias", &lw.Wpq_e, &lw.b1, &lw.wr_e, &lw.wd_e); if (rc) return rc;
+        rc = split_first(g + "edge_mlp.0.weight", g + "edge_mlp.0.bias", &lw.Wpq_e, &lw.b1, &lw.wr_e, &lw.wd_e, &lw.we_e); if (rc) return rc;
         rc = square(g + "edge_mlp.2.weight", H, &lw.W2); if (rc) return rc;
         GET(g + "edge_mlp.2.bias", H); UP(lw.b2);
         if (d.attention) {
@@ -312,12 +326,12 @@ extern "C" int cmdgen_finalize_weights(cmdgen_handle* h) {
         rc = square(g + "node_mlp.2.weight", H, &lw.W4); if (rc) return rc;
         GET(g + "node_mlp.2.bias", H); UP(lw.b4);
         if (sub == d.S - 1) {
-            rc = split_first(c + "coord_mlp.0.weight", c + "coord_mlp.0.bias", &lw.Wpq_c, &lw.b6, &lw.wr_c, &lw.wd_c); if (rc) return rc;
+            rc = split_first(c + "coord_mlp.0.weight", c + "coord_mlp.0.bias", &lw.Wpq_c, &lw.b6, &lw.wr_c, &lw.wd_c, &lw.we_c); if (rc) return rc;
             rc = square(c + "coord_mlp.2.weight", H, &lw.W7); if (rc) return rc;
             GET(c + "coord_mlp.2.bias", H); UP(lw.b7);
             GET(c + "coord_mlp.4.weight", H); UP(lw.w5);
         } else {                       // never multiplied (the node kernel skips the projection); valid pointers for the bias prefetches
-            lw.Wpq_c = lw.Wpq_e; lw.b6 = lw.b1; lw.wr_c = lw.wr_e; lw.wd_c = lw.wd_e; lw.W7 = lw.W2; lw.b7 = lw.b2; lw.w5 = lw.b2;
+            lw.Wpq_c = lw.Wpq_e; lw.b6 = lw.b1; lw.wr_c = lw.wr_e; lw.wd_c = lw.wd_e; lw.we_c = lw.we_e; lw.W7 = lw.W2; lw.b7 = lw.b2; lw.w5 = lw.b2;
         }
         h->layers.push_back(lw);
     }
@@ -567,6 +581,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.n_cus = h->n_cus;
     const bool sp256 = h->dims.H == 256 && h->gemm_split;
     if (!sp256) { if (a.edge_mt == 128) a.edge_mt = 64; if (a.coord_mt == 128) a.coord_mt = 64; }      // the 128-row kernels are split-engine, H = 256
+    if (h->dims.sin && h->dims.H == 512) { if (a.edge_mt > 32) a.edge_mt = 32; if (a.coord_mt > 32) a.coord_mt = 32; }   // (64-row tiles + the 55 KB of feature columns exceed the LDS)
     a.edge_fullk = (sp256 && opt_of(h, "edge_fullk", 1) != 0) ? 1 : 0;
     a.e128_wgs = (int)opt_of(h, "e128_wgs_per_cu", 2);
     a.write_embed = opt_of(h, "write_embed", 1) != 0 ? 1 : 0;
@@ -1237,6 +1252,7 @@ extern "C" int cmdgen_profile_evaluation(cmdgen_handle* h, const float* xh_phar,
 
 extern "C" int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16) {
     if (!h) return CMDGEN_EINVAL;
+    if (split_bf16 && h->dims.sin) return fail(h, CMDGEN_ESTATE, "sin_embedding runs on the fp32 matrix instruction only (the split engine's tile builders carry two scalar edge features)");
     if (h->gemm_split != (split_bf16 != 0)) {
         drop_graphs(h);                 // captured graphs bake the kernel choice in; the pocket cache is rebuilt per chain anyway
         h->gemm_split = split_bf16 != 0;

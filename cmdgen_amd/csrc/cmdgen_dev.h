@@ -39,6 +39,7 @@ struct LayerW {                 // device pointers to one EquivariantBlock's pac
     const float*  b1;           // folded into P
     const float*  wr_e;         // column 2H   (radial)
     const float*  wd_e;         // column 2H+1 (d0)
+    const float*  we_e;         // sin_embedding: columns 2H .. 2H+23 transposed, [24][H] (wr_e / wd_e unused); else null
     WPack W2;                   // edge_mlp.2 [H][H]
     const float*  b2;
     const float*  wa;           // att_mlp.0 weight [H]
@@ -53,6 +54,7 @@ struct LayerW {                 // device pointers to one EquivariantBlock's pac
     const float*  b6;
     const float*  wr_c;
     const float*  wd_c;
+    const float*  we_c;         // (as we_e, for coord_mlp.0)
     WPack W7;                   // coord_mlp.2 [H][H]
     const float*  b7;
     const float*  w5;           // coord_mlp.4 weight [H], no bias
@@ -78,6 +80,8 @@ struct Dims {
     float cutoff2;              // cutoff^2, < 0: no cutoff
     float norm_constant, norm_factor, coords_range;
     int S;                      // inv_sublayers: GCLs per block (the weight units of an evaluation are L * S, LayerW of unit l * S + s)
+    int sin;                    // sin_embedding (egnn_new.py:249-260): the two distance features of an edge are 12 sines / cosines each
+    float sin_freq[6];          // 2 pi 4^k / 15 in the reference's fp32 arithmetic
     int agg_mean;               // aggregation_method 'mean': segment sums are divided by Work::adiv[receiver] instead of norm_factor
     float norm_x, norm_h, bias_h;
 };

@@ -150,8 +150,8 @@ void cmdgen_train_free(TrainState* t) {
 static int ensure_state(cmdgen_handle* h) {
     if (h->train) return 0;
     if (h->dims.H > 256) return fail(h, CMDGEN_ESTATE, "the training step is built for hidden_nf <= 256");
-    if (h->dims.S != 1 || h->dims.agg_mean)
-        return fail(h, CMDGEN_ESTATE, "the training step supports inv_sublayers = 1 and aggregation_method 'sum' (the shipped configs); this handle samples only");
+    if (h->dims.S != 1 || h->dims.agg_mean || h->dims.sin)
+        return fail(h, CMDGEN_ESTATE, "the training step supports inv_sublayers = 1, aggregation_method 'sum' and sin_embedding False (the shipped configs); this handle samples only");
     TrainState* t = new TrainState();
     build_table(h->dims, t->tab);
     t->bf16 = h->train_bf16;

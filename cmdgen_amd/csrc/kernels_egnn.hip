@@ -555,7 +555,9 @@ __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, co
                                                 const float* s_r, const float* s_d0, int ne,
                                                 const float* __restrict__ P, const float* __restrict__ Q,
                                                 const float4& wr4, const float4& wd4,      // this thread's four columns of w_r, w_d
-                                                float* __restrict__ pre_out = nullptr, float* __restrict__ act_out = nullptr) {
+                                                float* __restrict__ pre_out = nullptr, float* __restrict__ act_out = nullptr,
+                                                const float* s_emb = nullptr, const float* s_we = nullptr) {
+    // s_emb / s_we (sin_embedding, LDS): the tile's [MT][24] sinusoid features and the [24][H] feature columns of the first layer
     constexpr int LPR = H / 4;                  // lanes per row (float4 each) -> 4 rows per pass
     const int ltid = threadIdx.x % H;
     const int c4 = ltid % LPR, rsub = ltid / LPR;
@@ -567,7 +569,16 @@ __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, co
             const float4 p = reinterpret_cast<const float4*>(P + (size_t)s_row[e] * H)[c4];
             const float4 q = reinterpret_cast<const float4*>(Q + (size_t)s_col[e] * H)[c4];
             const float r = s_r[e], d0 = s_d0[e];
-            const float4 pre = make_float4(p.x + q.x + wr4.x * r + wd4.x * d0, p.y + q.y + wr4.y * r + wd4.y * d0,
+            float4 pre;
+            if (s_emb) {
+                pre = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+                for (int k = 0; k < 24; ++k) {
+                    const float f = s_emb[e * 24 + k];
+                    const float4 wk = *reinterpret_cast<const float4*>(s_we + k * H + 4 * c4);
+                    pre.x = fmaf(f, wk.x, pre.x); pre.y = fmaf(f, wk.y, pre.y); pre.z = fmaf(f, wk.z, pre.z); pre.w = fmaf(f, wk.w, pre.w);
+                }
+            } else
+            pre = make_float4(p.x + q.x + wr4.x * r + wd4.x * d0, p.y + q.y + wr4.y * r + wd4.y * d0,
                                            p.z + q.z + wr4.z * r + wd4.z * d0, p.w + q.w + wr4.w * r + wd4.w * d0);
             a.x = silu_f(pre.x); a.y = silu_f(pre.y); a.z = silu_f(pre.z); a.w = silu_f(pre.w);
             if (pre_out) {                                 // training: rows of the tile in the compact list's order
@@ -576,6 +587,22 @@ __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, co
             }
         }
         *reinterpret_cast<float4*>(buf + e * LDA(H) + 4 * c4) = a;
+    }
+}
+
+// squared distance rounded like the reference's coord2diff (torch.sum(coord_diff ** 2, 1): three products, two additions, no fma).  The sinusoid
+// features multiply sqrt(r) by up to 2 pi 1024 / 15: one ulp of r moves the argument by 1e-4 rad, so the features use THIS rounding, not dist2's
+__device__ __forceinline__ float sumsq_ref(const float4& a, const float4& b) {
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+// sin_embedding (egnn_new.py:249-260, :144-146, :196-197): per edge [sin(f_k sqrt(r + 1e-8)), k < 6 | cos(...) | the same of d0]
+template <int H, int MT>
+__device__ __forceinline__ void sin_features(float* s_emb, const float* s_r, const float* s_d0, int ne, const Dims& d) {
+    for (int idx = threadIdx.x; idx < ne * 24; idx += H) {
+        const int e = idx / 24, k = idx - e * 24, kk = k < 12 ? k : k - 12;
+        const float x = sqrtf((k < 12 ? s_r[e] : s_d0[e]) + 1e-8f) * d.sin_freq[kk < 6 ? kk : kk - 6];
+        s_emb[idx] = kk < 6 ? sinf(x) : cosf(x);
     }
 }
 
@@ -746,6 +773,8 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
     const ColVec<MT> b2v = col_load<MT>(lw.b2, wave);          // per-column bias and the gate's bias: once per workgroup
     const float ba0 = lw.ba[0];
     const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_e)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_e)[tid % (H / 4)];
+    extern __shared__ float s_dyn[];          // sin_embedding only (launched with (24 H + 24 MT) floats): the [24][H] feature columns of edge_mlp.0, then the tile's features
+    if (d.sin) for (int i = tid; i < 24 * H; i += H) s_dyn[i] = lw.we_e[i];          // (the first tile's barrier covers it)
     typedef Eng<MT, SP> G;
     const typename G::Frag fw = G::frag(lw.W2, H / 8, 0, wave);
     typename G::Carry carry;
@@ -796,7 +825,12 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
                 // bits) - no position round trip; later blocks form the lazily updated positions (node_pos)
                 r = ((ablate & 1) || layer == 0) ? d0 : dist2(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
             }
-            s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
+            float d0f = d0;
+            if (d.sin && tid < ne) {                        // the features' distances in the reference's rounding (sumsq_ref)
+                d0f = sumsq_ref(node_pos(lay, w, d, row, 0, true), node_pos(lay, w, d, col, 0, true));
+                r = layer == 0 ? d0f : sumsq_ref(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
+            }
+            s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0f;
         }
         lds_barrier();
         STAMP(0);
@@ -828,9 +862,11 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
             STAMP(1);
             if (!(ablate & 4)) tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw1, fw, acc.a, carry);
         } else {
+        if (d.sin) { sin_features<H, MT>(s_dyn + 24 * H, s_r, s_d0, ne, d); lds_barrier(); }
         if (!(ablate & 2)) build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4,
                                                   SAVE ? sv.pre1 + ((size_t)layer * sv.ecap + e0) * H : nullptr,
-                                                  SAVE ? sv.act1 + ((size_t)layer * sv.ecap + e0) * H : nullptr);
+                                                  SAVE ? sv.act1 + ((size_t)layer * sv.ecap + e0) * H : nullptr,
+                                                  d.sin ? s_dyn + 24 * H : nullptr, s_dyn);
         lds_barrier();
         STAMP(1);
         if (!(ablate & 4)) G::template gemm<H / 8>(buf, LDA(H), fw, fw, acc, carry);
@@ -1103,6 +1139,8 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
     if constexpr (PL && !FK) { s_wrd[tid] = lw.wr_c[tid]; s_wrd[H + tid] = lw.wd_c[tid]; }
     const ColVec<MT> b7v = col_load<MT>(lw.b7, wave);
     const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_c)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_c)[tid % (H / 4)];
+    extern __shared__ float s_dyn[];          // sin_embedding only: see edge_msg_body
+    if (d.sin) for (int i = tid; i < 24 * H; i += H) s_dyn[i] = lw.we_c[i];
     typedef Eng<MT, SP> G;
     const typename G::Frag fw = G::frag(lw.W7, H / 8, 0, wave);
     typename G::Carry carry;
@@ -1130,8 +1168,11 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
                 r = cx * cx + cy * cy + cz * cz;
                 const float den = sqrtf(r + 1e-8f) + d.norm_constant;      // coord2diff, egnn_new.py:265-271
                 cx /= den; cy /= den; cz /= den;
+                if (d.sin) r = sumsq_ref(pi, pj);                            // (the features' distance in the reference's rounding)
             }
-            s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0;
+            float d0f = d0;
+            if (d.sin && tid < ne) d0f = sumsq_ref(node_pos(lay, w, d, row, 0, false), node_pos(lay, w, d, col, 0, false));
+            s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0f;
             s_cd[tid][0] = cx; s_cd[tid][1] = cy; s_cd[tid][2] = cz;
         }
         lds_barrier();
@@ -1156,9 +1197,11 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
             lds_barrier();
             tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw1, fw, acc.a, carry);
         } else {
+        if (d.sin) { sin_features<H, MT>(s_dyn + 24 * H, s_r, s_d0, ne, d); lds_barrier(); }
         build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, wr4, wd4,
                                SAVE ? sv.pre6 + ((size_t)layer * sv.eccap + e0) * H : nullptr,
-                               SAVE ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr);
+                               SAVE ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr,
+                               d.sin ? s_dyn + 24 * H : nullptr, s_dyn);
         lds_barrier();
         G::template gemm<H / 8>(buf, LDA(H), fw, fw, acc, carry);
         }
@@ -1376,11 +1419,12 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
                             a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l), TrainSave{});
 }
 template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
+    const size_t shm = a.d.sin ? (size_t)(24 * H + 24 * MT) * sizeof(float) : 0;      // sin_embedding: feature columns + the tile's features (edge_msg_body)
     // training forward: the split engine only where the step re-packs split weights (H = 256: edge_mlp.2 / coord_mlp.2)
     if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, *a.save, 0);
-    else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
+    else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), shm, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
                                                a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
-    else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
+    else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), shm, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
 }
 // 32-row sampler tiles on the split engine: full-K planes (one build, one GEMM per tile; see cmdgen_split.h) unless CMDGEN_EDGE_FULLK=0
 static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
@@ -1398,10 +1442,11 @@ static bool launch_coord_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     return true;
 }
 template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
+    const size_t shm = a.d.sin ? (size_t)(24 * H + 24 * MT) * sizeof(float) : 0;
     if (a.save) hipLaunchKernelGGL((k_edge_coord<H, MT, true, SP && H == 256>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, *a.save);
-    else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
+    else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), shm, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
                                                a.layers[unit_of(a, l)], l, TrainSave{});
-    else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, TrainSave{});
+    else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), shm, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, TrainSave{});
 }
 // tiles of >= 32 rows run on the split-bf16 engine when the launch asks for it (the training forward: only its two edge
 // kernels, and only when the step re-packed split weights for them - save_split); 16-row tiles are always fp32 MFMA

@@ -72,8 +72,9 @@ class EGNN(nn.Module):
                  norm_constant=1, inv_sublayers=2, sin_embedding=False, normalization_factor=100,
                  aggregation_method='sum'):
         super().__init__()
-        if sin_embedding:
-            raise NotImplementedError('sin_embedding=True: not used by the shipped configs, not built')
+        # sin_embedding (egnn_new.py:174-176): SinusoidsEmbeddingNew has no parameters; it widens the edge features from 2 to 2 x 12
+        self.sin_embedding = object() if sin_embedding else None
+        edge_feat_nf = 24 if sin_embedding else 2
         out_node_nf = in_node_nf if out_node_nf is None else out_node_nf
         self.hidden_nf, self.n_layers = hidden_nf, n_layers
         self.coords_range = float(coords_range)
@@ -81,7 +82,7 @@ class EGNN(nn.Module):
         self.embedding_out = nn.Linear(hidden_nf, out_node_nf)
         for i in range(n_layers):
             self.add_module('e_block_%d' % i, EquivariantBlock(
-                hidden_nf, edge_feat_nf=2, act_fn=act_fn, n_layers=inv_sublayers, attention=attention,
+                hidden_nf, edge_feat_nf=edge_feat_nf, act_fn=act_fn, n_layers=inv_sublayers, attention=attention,
                 norm_diff=norm_diff, tanh=tanh, coords_range=coords_range, norm_constant=norm_constant,
                 normalization_factor=normalization_factor, aggregation_method=aggregation_method))
     forward = _no_forward

@@ -24,7 +24,7 @@ class Config(C.Structure):
         'phar_nf', 'residue_nf', 'joint_nf', 'hidden_nf', 'n_layers', 'inv_sublayers',
         'attention', 'tanh', 'condition_time', 'timesteps', 'no_com_projection', 'update_pocket_coords')] + \
         [(n, C.c_float) for n in ('edge_cutoff', 'norm_constant', 'normalization_factor',
-                                  'coords_range', 'norm_x', 'norm_h', 'bias_h')] + [('aggregation_mean', C.c_int32)]
+                                  'coords_range', 'norm_x', 'norm_h', 'bias_h')] + [('aggregation_mean', C.c_int32), ('sin_embedding', C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -170,8 +170,7 @@ class Handle:
         if cfg.get('aggregation_method', 'sum') not in ('sum', 'mean'):
             raise CmdgenError("aggregation_method must be 'sum' or 'mean' (egnn_new.py:277-292)")
         c.aggregation_mean = int(cfg.get('aggregation_method', 'sum') == 'mean')
-        if cfg.get('sin_embedding', False):
-            raise CmdgenError('sin_embedding=True is not supported (shipped configs use False)')
+        c.sin_embedding = int(bool(cfg.get('sin_embedding', False)))
         h = C.c_void_p()
         rc = self.lib.cmdgen_create(C.byref(c), int(device_index), C.byref(h))
         if rc != 0:

@@ -80,7 +80,7 @@ def linear_specs(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
     s['residue_decoder.2'] = (R, 2 * R, True)
     s['egnn.embedding'] = (H, dyn_nf, True)
     s['egnn.embedding_out'] = (dyn_nf, H, True)
-    edge_in = 2 * H + 2            # [h_row | h_col | radial | d0], egnn_new.py:35,146
+    edge_in = 2 * H + (24 if cfg.sin_embedding else 2)     # [h_row | h_col | radial | d0], egnn_new.py:35,146; sin_embedding: 12 + 12 features (:174-176)
     for b in range(cfg.n_layers):
         for g in range(cfg.inv_sublayers):
             p = f'egnn.e_block_{b}.gcl_{g}.'

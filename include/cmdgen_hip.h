@@ -73,6 +73,9 @@ typedef struct cmdgen_config {
     float   bias_h;                /* norm_biases[1] = 0 */
     int32_t aggregation_mean;      /* 0 = aggregation_method 'sum'; 1 = 'mean' (egnn_new.py:288-292: every segment sum is divided by its
                                       receiver's edge count instead of normalization_factor); sampling only */
+    int32_t sin_embedding;         /* 0; 1 = SinusoidsEmbeddingNew on both distance features of an edge (egnn_new.py:174-176, :249-260: the
+                                      first layer of the edge / coordinate MLPs has 2H + 24 inputs); sampling only, on the fp32 matrix
+                                      instruction (the plane kernels of the split engine carry the two scalar features only) */
 } cmdgen_config;
 
 /* Work counters accumulated on the device since the last reset (for the

@@ -158,6 +158,14 @@ def coord2diff(x, row, col, norm_constant=1.0):
     return radial, coord_diff
 
 
+def sin_embedding(x, max_res=15., min_res=15. / 2000., div_factor=4):
+    """SinusoidsEmbeddingNew, egnn_new.py:249-260: six frequencies 2 pi 4^k / 15 of sqrt(x + 1e-8) -> [sin x 6 | cos x 6]."""
+    n_freq = int(math.log(max_res / min_res, div_factor)) + 1
+    freqs = 2 * math.pi * div_factor ** torch.arange(n_freq) / max_res
+    emb = torch.sqrt(x + 1e-8) * freqs[None, :]
+    return torch.cat((emb.sin(), emb.cos()), dim=-1)
+
+
 def segment_sum(data, segment_ids, num_segments, normalization_factor, aggregation_method):
     """unsorted_segment_sum, egnn_new.py:276-292 (scatter_add_ in edge order)."""
     result = data.new_full((num_segments, data.size(1)), 0)
@@ -189,10 +197,15 @@ def egnn_forward(p, cfg, h, x, row, col, update_coords_mask, trace: Optional[dic
     pre = 'dynamics.egnn.'
     nf, agg_m = cfg['normalization_factor'], cfg['aggregation_method']
     d0, _ = coord2diff(x, row, col)                       # :195, default norm_constant (Q4)
+    sin = bool(cfg.get('sin_embedding', False))
+    if sin:
+        d0 = sin_embedding(d0)                            # :196-197
     h = _lin(p, pre + 'embedding', h)                     # :198
     for b in range(cfg['n_layers']):
         bp = f'{pre}e_block_{b}.'
         radial, coord_diff = coord2diff(x, row, col, cfg['norm_constant'])   # :143
+        if sin:
+            radial = sin_embedding(radial)                                   # :144-145
         edge_attr = torch.cat([radial, d0], dim=1)                           # :146
         for g in range(cfg['inv_sublayers']):
             gp = f'{bp}gcl_{g}.'

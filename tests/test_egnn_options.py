@@ -229,3 +229,89 @@ def test_hip_learned_schedule_through_the_python_mirror_g17(name):
             mode, loss_type = 'pocket_conditioning', 'vlb'
         m = _M(); m.ddpm = ddpm
         HipTrainer(m)
+
+
+# ----------------------------------------------------------------------------- sin_embedding=True (SinusoidsEmbeddingNew, egnn_new.py:174-176, :249-260)
+G18 = load_golden('g18_sin_embedding.npz')
+SIN_DYN = sorted({k.split('/')[0] for k in G18 if not k.startswith('chain_')})
+
+
+def sin_case(name):
+    H, L, S, mean, B, R, seed, first = [int(v) for v in G18[name + '/meta']]
+    cfg = ModelConfig(hidden_nf=H, n_layers=L, residue_nf=R, timesteps=500, inv_sublayers=S, aggregation_method='mean' if mean else 'sum', sin_embedding=True)
+    return cfg, make_state_dict(cfg, seed=seed, coord_gain=1.0)
+
+
+def sin_chain_case():
+    H, L, B, seed, first, K = [int(v) for v in G18['chain_h64_K20/meta']]
+    cfg = ModelConfig(hidden_nf=H, n_layers=L, residue_nf=20, timesteps=500, sin_embedding=True, noise_precision=0.05, norm_values=(1.0, 0.5))
+    return cfg, make_state_dict(cfg, seed=seed, coord_gain=1e-3), make_pockets(B, 'CA', ragged=True, n_phar=8, first_index=first), K
+
+
+@pytest.mark.parametrize('name', SIN_DYN)
+def test_oracle_sin_embedding_g18(name):
+    from oracle import ref_cpu
+    cfg, sd = sin_case(name)
+    pm, qm = masks_from_sizes(G18[name + '/pocket_size'], G18[name + '/num_nodes_phar'])
+    with torch.no_grad():
+        ep, eq = ref_cpu.dynamics_forward(ref_cpu.to_torch_params(sd), cfg.as_dict(), torch.from_numpy(G18[name + '/xh_phar']),
+                                          torch.from_numpy(G18[name + '/xh_pocket']), torch.from_numpy(G18[name + '/t']), torch.from_numpy(pm), torch.from_numpy(qm))
+    for got, key in ((ep, 'eps_phar'), (eq, 'eps_pocket')):
+        want = G18[name + '/' + key]
+        assert np.abs(got.numpy() - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+
+
+def test_oracle_sin_embedding_chain_g18():
+    from oracle import ref_cpu
+    cfg, sd, pb, K = sin_chain_case()
+    pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot), 'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
+    with torch.no_grad():
+        out = ref_cpu.sample_given_pocket(ref_cpu.to_torch_params(sd), cfg.as_dict(), pocket, pb.num_nodes_phar, timesteps=K, noise=NoiseTape(G18['chain_h64_K20/noise']))
+    want = G18['chain_h64_K20/xh_phar']
+    assert rms(out[0][:, :3].numpy(), want[:, :3]) < 1e-4 and np.array_equal(out[0][:, 3:].numpy(), want[:, 3:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mt', [None, 16, 32, 64])
+@pytest.mark.parametrize('name', SIN_DYN)
+def test_hip_sin_embedding_g18(name, mt):
+    hip_backend, dev = _gpu()
+    cfg, sd = sin_case(name)
+    h = hip_backend.Handle(cfg.as_dict(), 0)
+    h.load_state_dict(sd)
+    if mt is not None:
+        for k in ('node_mt', 'edge_mt', 'coord_mt'):
+            h.set_option(k, mt)
+    h.set_layout(G18[name + '/num_nodes_phar'], G18[name + '/pocket_size'])
+    assert h.query('gemm_split') == 0                      # the fp32 matrix instruction (the split engine's tile builders carry two scalar features)
+    with pytest.raises(hip_backend.CmdgenError, match='fp32 matrix instruction'):
+        h.set_gemm_mode(True)
+    ep, eq = h.dynamics_forward(torch.from_numpy(G18[name + '/xh_phar']).to(dev), torch.from_numpy(G18[name + '/xh_pocket']).to(dev),
+                                torch.from_numpy(G18[name + '/t']).to(dev), want_pocket=True)
+    # The highest sinusoid multiplies the distance by 2 pi 1024 / 15 = 429 rad / A: coordinate noise of 1e-6 A in a later block moves its argument by
+    # 4e-4 rad.  With 'sum' aggregation the coordinate updates are divided by 100 and the evaluation keeps its usual fp32 floor (the oracle in
+    # float64 against itself in float32: 1.7e-6 / 2.2e-6 on ca_h64 / ca_h256); with 'mean' (divided by ~10) the floor of ca_h128_s2_mean is 8.0e-5
+    # (same measurement) - the reference's own fp32 result is only defined that far.
+    tol = 2e-4 if name == 'ca_h128_s2_mean' else 2e-5
+    for got, key in ((ep, 'eps_phar'), (eq, 'eps_pocket')):
+        want = G18[name + '/' + key]
+        assert float(np.abs(got.cpu().numpy() - want).max()) <= tol * max(1.0, float(np.abs(want).max()))
+    h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_hip_sin_embedding_chain_g18(use_graph):
+    hip_backend, dev = _gpu()
+    from test_hip_parity_r2 import host_step_table
+    cfg, sd, pb, K = sin_chain_case()
+    h = hip_backend.Handle(cfg.as_dict(), 0)
+    h.load_state_dict(sd)
+    h.set_layout(pb.num_nodes_phar, pb.size)
+    h.set_step_table(K, host_step_table(cfg, K))
+    x, xp, _ = h.sample_chain(torch.from_numpy(pb.x).to(dev), torch.from_numpy(pb.one_hot).to(dev), K,
+                              noise=torch.from_numpy(G18['chain_h64_K20/noise']).to(dev), use_graph=use_graph)
+    want = G18['chain_h64_K20/xh_phar']
+    assert rms(x[:, :3].cpu().numpy(), want[:, :3]) <= 1e-4 and np.array_equal(x[:, 3:].cpu().numpy(), want[:, 3:])
+    assert rms(xp.cpu().numpy(), G18['chain_h64_K20/xh_pocket']) <= 1e-4
+    h.close()

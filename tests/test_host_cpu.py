@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol():
     bound = {n for n, _, _ in hip_backend.SYMBOLS}
     assert declared == bound, declared ^ bound
     assert b'gfx950' in lib.cmdgen_version()
-    assert ctypes.sizeof(hip_backend.Config) == 20 * 4 and ctypes.sizeof(hip_backend.Counters) == 64
+    assert ctypes.sizeof(hip_backend.Config) == 21 * 4 and ctypes.sizeof(hip_backend.Counters) == 64
 
 
 def test_library_source_reads_no_environment_variable():
