@@ -390,6 +390,10 @@ static void pick_tiles(cmdgen_handle* h) {
     if (h->gemm_split && d.H == 256) {
         if (e_est / 64.0 >= 4.0 * h->n_cus) h->edge_mt = 128;
         if (ec_est / 32.0 >= 3.0 * h->n_cus) h->coord_mt = 128;      // (from 128 C-alpha pockets: profiles/r04_h)
+        // dense samples (full-atom pockets: 36 neighbours per node, ~60 coordinate edges per phar point while the points sit at the pocket centre):
+        // a receiver's edges outnumber the rows of a 16- / 32-row tile, its sum would be three or more float-atomic partials whose order the
+        // hardware picks - the 128-row kernels (variable tiles, >= 128-row chunks) keep it at two, so full-atom chains are reproducible run to run
+        if (h->lay.max_n > 128) { h->edge_mt = 128; h->coord_mt = 128; }
     }
     h->node_mt = (int)opt_of(h, "node_mt", h->node_mt);
     h->edge_mt = (int)opt_of(h, "edge_mt", h->edge_mt);

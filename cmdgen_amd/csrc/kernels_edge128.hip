@@ -347,7 +347,8 @@ __global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, 
     const int E = w.totals[COORD ? 1 : 0];
     const int G = (int)gridDim.x;
     int CH = (((E + G - 1) / G) + 31) & ~31;
-    if (CH < 32) CH = 32;
+    if (CH < MTL) CH = MTL;            // at least one full tile per chunk: a receiver's rows (fewer than a tile's) then lie in at most two chunks, i.e. its sum has at
+                                       // most two float-atomic partials, which commute - short lists stay reproducible bit for bit (they use fewer workgroups)
     const int nch = (E + CH - 1) / CH;
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;       // diagnostic builds (-DCMDGEN_STAMPS=6): summed phase cycles
 #if CMDGEN_STAMPS == 6

@@ -151,3 +151,22 @@ def test_a_pockets_chain_does_not_depend_on_its_batch_at_256_pockets():
     assert float(np.sqrt(np.mean((whole[:, :3] - parts[:, :3]) ** 2))) <= 1e-5
     print(f'[256 pockets at once vs 4 x 64, K = {K}] coordinates: max {float(np.abs(whole[:, :3] - parts[:, :3]).max()):.1e} A, '
           f'RMS {float(np.sqrt(np.mean((whole[:, :3] - parts[:, :3]) ** 2))):.1e} A; types identical')
+
+
+@pytest.mark.parametrize('rep, B, K', [('CA', 64, 30), ('full-atom', 8, 30), ('full-atom', 64, 6)])
+def test_chains_are_reproducible_bit_for_bit(rep, B, K):
+    """Two fresh handles, the same Philox seed: identical bits, step by step.  Per receiver a segment sum is ordered inside a tile and has at
+    most two float-atomic partials across tiles (which commute) as long as the receiver's edges are fewer than a tile's rows: C-alpha layouts
+    have ~20 edges per receiver on 32-row tiles, dense (full-atom) layouts ~60 on the 128-row kernels with >= 128-row chunks (pick_tiles).
+    The chain starts with every phar point at the pocket centre - the densest graph it sees."""
+    cfg = bounded_config(20 if rep == 'CA' else 11, 1000)
+    sd = make_state_dict(cfg, seed=0)
+    pb = make_pockets(B, rep)
+    outs = []
+    for _ in range(2):
+        h = handle_for(cfg, sd, pb)
+        x, xp, zs = h.sample_chain(torch.from_numpy(pb.x).to(DEV), torch.from_numpy(pb.one_hot).to(DEV), K, seed=9, pocket_ids=pb.pocket_index, want_steps=True)
+        outs.append((x.cpu().numpy(), xp.cpu().numpy(), zs.cpu().numpy()))
+        h.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
