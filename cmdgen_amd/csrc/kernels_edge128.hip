@@ -347,8 +347,11 @@ __global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, 
     const int E = w.totals[COORD ? 1 : 0];
     const int G = (int)gridDim.x;
     int CH = (((E + G - 1) / G) + 31) & ~31;
-    if (CH < MTL) CH = MTL;            // at least one full tile per chunk: a receiver's rows (fewer than a tile's) then lie in at most two chunks, i.e. its sum has at
-                                       // most two float-atomic partials, which commute - short lists stay reproducible bit for bit (they use fewer workgroups)
+    // a chunk holds more rows than any receiver has edges: the receiver's rows then lie in at most two chunks, i.e. its sum has at most two
+    // float-atomic partials, which commute - results are reproducible bit for bit.  Dense samples (full-atom pockets: ~60 edges per phar point
+    // at the pocket centre) need a full tile for that; C-alpha samples (< 60 nodes each) half of one.  Short lists just use fewer workgroups.
+    const int minch = lay.max_n > 128 ? MTL : 64;
+    if (CH < minch) CH = minch;
     const int nch = (E + CH - 1) / CH;
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;       // diagnostic builds (-DCMDGEN_STAMPS=6): summed phase cycles
 #if CMDGEN_STAMPS == 6
