@@ -774,7 +774,8 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
     const float ba0 = lw.ba[0];
     const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_e)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_e)[tid % (H / 4)];
     extern __shared__ float s_dyn[];          // sin_embedding only (launched with (24 H + 24 MT) floats): the [24][H] feature columns of edge_mlp.0, then the tile's features
-    if (d.sin) for (int i = tid; i < 24 * H; i += H) s_dyn[i] = lw.we_e[i];          // (the first tile's barrier covers it)
+    if constexpr (!FK && !(SP && H == 256 && MT >= 32))      // (the plane variants never see sin_embedding: such a handle runs on the fp32 instruction)
+        if (d.sin) for (int i = tid; i < 24 * H; i += H) s_dyn[i] = lw.we_e[i];          // (the first tile's barrier covers it)
     typedef Eng<MT, SP> G;
     const typename G::Frag fw = G::frag(lw.W2, H / 8, 0, wave);
     typename G::Carry carry;
@@ -826,6 +827,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
                 r = ((ablate & 1) || layer == 0) ? d0 : dist2(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
             }
             float d0f = d0;
+            if constexpr (!FK && !(SP && H == 256 && MT >= 32))
             if (d.sin && tid < ne) {                        // the features' distances in the reference's rounding (sumsq_ref)
                 d0f = sumsq_ref(node_pos(lay, w, d, row, 0, true), node_pos(lay, w, d, col, 0, true));
                 r = layer == 0 ? d0f : sumsq_ref(node_pos(lay, w, d, row, layer, true), node_pos(lay, w, d, col, layer, true));
@@ -1140,7 +1142,8 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
     const ColVec<MT> b7v = col_load<MT>(lw.b7, wave);
     const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_c)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_c)[tid % (H / 4)];
     extern __shared__ float s_dyn[];          // sin_embedding only: see edge_msg_body
-    if (d.sin) for (int i = tid; i < 24 * H; i += H) s_dyn[i] = lw.we_c[i];
+    if constexpr (!FK && !(SP && H == 256 && MT >= 32))
+        if (d.sin) for (int i = tid; i < 24 * H; i += H) s_dyn[i] = lw.we_c[i];
     typedef Eng<MT, SP> G;
     const typename G::Frag fw = G::frag(lw.W7, H / 8, 0, wave);
     typename G::Carry carry;
@@ -1168,10 +1171,12 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
                 r = cx * cx + cy * cy + cz * cz;
                 const float den = sqrtf(r + 1e-8f) + d.norm_constant;      // coord2diff, egnn_new.py:265-271
                 cx /= den; cy /= den; cz /= den;
-                if (d.sin) r = sumsq_ref(pi, pj);                            // (the features' distance in the reference's rounding)
+                if constexpr (!FK && !(SP && H == 256 && MT >= 32))
+                    if (d.sin) r = sumsq_ref(pi, pj);                        // (the features' distance in the reference's rounding)
             }
             float d0f = d0;
-            if (d.sin && tid < ne) d0f = sumsq_ref(node_pos(lay, w, d, row, 0, false), node_pos(lay, w, d, col, 0, false));
+            if constexpr (!FK && !(SP && H == 256 && MT >= 32))
+                if (d.sin && tid < ne) d0f = sumsq_ref(node_pos(lay, w, d, row, 0, false), node_pos(lay, w, d, col, 0, false));
             s_row[tid] = row; s_col[tid] = col; s_r[tid] = r; s_d0[tid] = d0f;
             s_cd[tid][0] = cx; s_cd[tid][1] = cy; s_cd[tid][2] = cz;
         }
