@@ -395,6 +395,8 @@ static void pick_tiles(cmdgen_handle* h) {
         // hardware picks - the 128-row kernels (variable tiles, >= 128-row chunks) keep it at two, so full-atom chains are reproducible run to run
         if (h->lay.max_n > 128) { h->edge_mt = 128; h->coord_mt = 128; }
     }
+    // (the fp32 instruction / other widths have no 128-row kernels: their largest tile keeps most dense receivers at two partials)
+    if (!(h->gemm_split && d.H == 256) && h->lay.max_n > 128) { h->edge_mt = 64; h->coord_mt = 64; }
     h->node_mt = (int)opt_of(h, "node_mt", h->node_mt);
     h->edge_mt = (int)opt_of(h, "edge_mt", h->edge_mt);
     h->coord_mt = (int)opt_of(h, "coord_mt", h->coord_mt);
