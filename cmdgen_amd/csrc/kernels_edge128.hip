@@ -49,6 +49,7 @@ struct alignas(16) E128Lds {
     int segstart[MTL + 1];                       // first row of each segment (coordinate kernel)
     unsigned char seg[MTL];                      // segment index of each row (255 beyond the tile's end)
     int meta[4];                                // [0] segments, [1] live, [2] rows of the tile
+    int smask[4];                               // bit e: row e of the tile opens a segment (message kernel); bit ne: end of the listed rows
 };
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -264,64 +265,58 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
             if (sgi == 0 || sgi == nseg - 1) atomicAdd(dst, sum); else *dst = sum;      // a receiver may continue in the neighbouring tiles; ACC is zero before the launch
         }
     } else {
-        // gated messages, then the segment sum as a matrix product (see the head of this file).  The index phase cut the tile at 32 segments,
-        // so one 32 x 32 accumulator tile per column tile takes every segment and each row tile's accumulators die as they are consumed.
+        // gated messages and their ordered segment sum by receiver, in registers.  v_permlane32_swap_b32 on the register pair (column tile 0,
+        // column tile 1) of an accumulator row group turns the 32 x 32 layout (lane half = rows +0 / +4) into one where EVERY lane of a
+        // register holds the same row (lane = column 64 wave + lane): the tile's rows are then visited in list order by wave-uniform code, a
+        // receiver's sum is a chain of 64-lane FMAs (gate folded in) in ascending sender order like the reference's CPU scatter_add_
+        // (egnn_new.py:283), and a finished receiver leaves as one 256-byte row segment.  Segment starts are a 128-bit scalar mask.
         const int nseg = L.meta[0];
-        const unsigned myseg = (unsigned)(lane & 31);
-        sf32x16 sa[2];
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sa[n][r] = 0.0f;
-#pragma unroll
-        for (int m = 0; m < NMT; ++m) {
-            float4 g[4];
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) g[rq] = *reinterpret_cast<const float4*>(&L.att[E_ROW(m, 4 * rq)]);   // rows E_ROW(m, 4 rq) .. + 3 (one address per half wave: broadcast)
-            // S fragments of the two k-blocks of this row tile: k-slot j of lane half hf <-> row 32 m + 16 hb + 8 (j >> 2) + 4 hf + (j & 3),
-            // the row that accumulator register 8 hb + j of this lane half holds
-            sbf16x8 sf[2];
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                const unsigned g0 = *reinterpret_cast<const unsigned*>(&L.seg[E_ROW(m, 8 * hb)]);
-                const unsigned g1 = *reinterpret_cast<const unsigned*>(&L.seg[E_ROW(m, 8 * hb + 4)]);
-                typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                u4 sv;
-                sv[0] = ((g0 & 0xffu) == myseg ? 0x3F80u : 0u) | (((g0 >> 8) & 0xffu) == myseg ? 0x3F800000u : 0u);
-                sv[1] = (((g0 >> 16) & 0xffu) == myseg ? 0x3F80u : 0u) | ((g0 >> 24) == myseg ? 0x3F800000u : 0u);
-                sv[2] = ((g1 & 0xffu) == myseg ? 0x3F80u : 0u) | (((g1 >> 8) & 0xffu) == myseg ? 0x3F800000u : 0u);
-                sv[3] = (((g1 >> 16) & 0xffu) == myseg ? 0x3F80u : 0u) | ((g1 >> 24) == myseg ? 0x3F800000u : 0u);
-                sf[hb] = __builtin_bit_cast(sbf16x8, sv);
+        const unsigned sm[4] = {(unsigned)__builtin_amdgcn_readfirstlane(L.smask[0]), (unsigned)__builtin_amdgcn_readfirstlane(L.smask[1]),
+                                (unsigned)__builtin_amdgcn_readfirstlane(L.smask[2]), (unsigned)__builtin_amdgcn_readfirstlane(L.smask[3])};
+        const int segrow_v = L.segrow[lane & 31];                       // receiver of segment (lane & 31); read per finished segment with v_readlane
+        float* const aggc = w.agg + 64 * wave + lane;
+        float sum = 0.f;
+        int sg = 0;                                                      // wave-uniform: the segment being summed
+        auto flush = [&]() {
+            if (sg < nseg) {
+                float* dst = aggc + (size_t)__builtin_amdgcn_readlane(segrow_v, sg) * H;
+                if (sg == 0 || sg == nseg - 1) atomicAdd(dst, sum);     // the receiver may continue in the neighbouring tiles
+                else *dst = sum;                                         // agg is zero between blocks
             }
+            ++sg; sum = 0.f;
+        };
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+        for (int m = 0; m < NMT; ++m)
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {
-                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                    u4 p0, p1, p2;
+            for (int j = 0; j < 4; ++j) {
+                float x[4], y[4];
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int r = 8 * hb + 2 * jj;                                       // registers r, r + 1: rows of the same float4 of gates
-                        const float ga = (r & 2) ? g[r >> 2].z : g[r >> 2].x, gb = (r & 2) ? g[r >> 2].w : g[r >> 2].y;
-                        unsigned a0, a1, a2;
-                        split3_pair(acc[m][n][r] * ga, acc[m][n][r + 1] * gb, a0, a1, a2);
-                        p0[jj] = a0; p1[jj] = a1; p2[jj] = a2;
-                    }
-                    sa[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf[hb], __builtin_bit_cast(sbf16x8, p2), sa[n], 0, 0, 0);
-                    sa[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf[hb], __builtin_bit_cast(sbf16x8, p1), sa[n], 0, 0, 0);
-                    sa[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf[hb], __builtin_bit_cast(sbf16x8, p0), sa[n], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                    const u2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[m][0][4 * j + i]), __float_as_uint(acc[m][1][4 * j + i]), false, false);
+                    x[i] = __uint_as_float(sw[0]); y[i] = __uint_as_float(sw[1]);     // rows 32 m + 8 j + i and + 4 + i, all 64 columns of the wave
                 }
-        }
-        // segment (r & 3) + 8 (r >> 2) + 4 hf of column colw + 32 n
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int sgi = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (sgi < nseg) {
-                float* dst = w.agg + (size_t)L.segrow[sgi] * H + colw;
-                if (sgi == 0 || sgi == nseg - 1) { atomicAdd(dst, sa[0][r]); atomicAdd(dst + 32, sa[1][r]); }   // the receiver may continue in the neighbouring tiles
-                else { dst[0] = sa[0][r]; dst[32] = sa[1][r]; }                                               // agg is zero between blocks
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int base = 32 * m + 8 * j + 4 * hh;
+                    const float4 g4 = *reinterpret_cast<const float4*>(&L.att[base]);              // one address per wave: broadcast
+                    unsigned bits = (sm[base >> 5] >> (base & 31)) & 0xfu;
+                    if (base == 0) bits &= ~1u;                                                    // row 0 opens segment 0: nothing to flush
+                    const float* v = hh ? y : x;
+                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+                    if (bits == 0u) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum = __fmaf_rn(v[i], gg[i], sum);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (bits & (1u << i)) flush();
+                            sum = __fmaf_rn(v[i], gg[i], sum);
+                        }
+                    }
+                }
             }
-        }
+        flush();                                                         // the tile's last segment when it ends with the tile's last row
     }
 #undef STAMP
 }
@@ -433,7 +428,11 @@ __global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, 
                 L.seg[64 + lane] = (unsigned char)(64 + lane < ne ? sg1 : 255);
                 if (s0 && lane < ne) { L.segrow[sg0] = row[0]; L.segstart[sg0] = lane; }
                 if (s1 && 64 + lane < ne) { L.segrow[sg1] = row[1]; L.segstart[sg1] = 64 + lane; }
-                if (lane == 0) { L.meta[0] = ns; L.meta[1] = live ? 1 : 0; L.meta[2] = ne; L.segstart[ns] = ne; }
+                if (lane == 0) {
+                    L.meta[0] = ns; L.meta[1] = live ? 1 : 0; L.meta[2] = ne; L.segstart[ns] = ne;
+                    const unsigned long long k0 = m0 | (ne < 64 ? 1ull << ne : 0ull), k1 = m1 | (ne >= 64 && ne < 128 ? 1ull << (ne - 64) : 0ull);
+                    L.smask[0] = (int)(unsigned)k0; L.smask[1] = (int)(unsigned)(k0 >> 32); L.smask[2] = (int)(unsigned)k1; L.smask[3] = (int)(unsigned)(k1 >> 32);
+                }
             }
             lds_barrier();
             STAMP(0);
