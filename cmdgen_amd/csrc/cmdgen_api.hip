@@ -590,6 +590,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     if (h->dims.sin && h->dims.H == 512) { if (a.edge_mt > 32) a.edge_mt = 32; if (a.coord_mt > 32) a.coord_mt = 32; }   // (64-row tiles + the 55 KB of feature columns exceed the LDS)
     a.edge_fullk = (sp256 && opt_of(h, "edge_fullk", 1) != 0) ? 1 : 0;
     a.e128_wgs = (int)opt_of(h, "e128_wgs_per_cu", 2);
+    a.e128_pp = (int)opt_of(h, "e128_pp", 0);
     a.write_embed = opt_of(h, "write_embed", 1) != 0 ? 1 : 0;
     {   // k_node64 (kernels_node64.hip: 64-row node tiles, the A operand as producer-side bf16 planes, one workgroup per CU) against
         // k_node<H, 32> (register split, two workgroups per CU).  Per launch the 64-row kernel takes ~0.89 of a co-resident pair of
@@ -629,7 +630,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
 // options
 // ---------------------------------------------------------------------------------
 static const char* const kOptionKeys[] = {
-    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "edge_fullk", "node64", "node16_split", "node16w",
+    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "e128_pp", "edge_fullk", "node64", "node16_split", "node16w",
     "dead_skip", "write_embed", "fused_step", "pocket_cache", "graph_steps",
     "wgrad_split", "wgrad_tile", "wgrad_split_wgs128", "wgrad_split_wgs64", "wgrad_wgs", "dgrad_mt", "dgrad_tail"};
 

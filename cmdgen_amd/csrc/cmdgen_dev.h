@@ -229,6 +229,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     int write_embed = 1;        // 1: pass 2 of the radius graph and k_embed share a launch (k_write_embed) where both fit (option "write_embed")
     int e128_wgs = 2;           // workgroups per CU of the 128-row edge kernels (kernels_edge128.hip)
+    int e128_pp = 0;            // 1: the 128-row edge kernels run as ONE 512-thread workgroup per CU whose two halves are phase-locked one barrier apart (k_edge128pp)
 };
 // weight unit of block l's launches (EvalLaunch::unit), and the has_next argument of its node kernel: bit 0 = another unit follows
 // (its P | Q are projected), bits 1..29 = the dead-tile threshold of the plane tiles, bit 30 = no P_c | Q_c (EvalLaunch::skip_pc)

@@ -26,6 +26,16 @@
 namespace {
 
 constexpr int H = 256;
+#ifndef CMDGEN_STAMP_COORD
+#define CMDGEN_STAMP_COORD 0      // diagnostic builds: which of the two kernels records its phase stamps
+#endif
+// issue priority of a wave inside its GEMM quarters / everywhere else (s_setprio)
+#ifndef CMDGEN_E128_GPRIO
+#define CMDGEN_E128_GPRIO 1
+#endif
+#ifndef CMDGEN_E128_VPRIO
+#define CMDGEN_E128_VPRIO 0
+#endif
 #ifndef CMDGEN_E128_MT
 #define CMDGEN_E128_MT 128
 #endif
@@ -43,7 +53,7 @@ struct alignas(16) E128Lds {
     EdgeRec e[MTL];                              // (receiver, sender, radial, d0) of the tile's rows; -1 / -1 / 0 / 0 beyond its end
     float cd[MTL][4];                            // coordinate kernel: coord_diff of the row, later coord_diff * tanh(phi) * range
     float part[4][MTL];                          // the four waves' partial row dots
-    float att[MTL];                              // gate of each row
+    float gw[4][MTL];                            // gate (message kernel) / tanh(phi) * range (coordinate kernel) of each row, one copy per wave (each wave fills and reads its own: no barrier)
     float wrd[2 * H];                           // radial / d0 columns of the first layer
     int segrow[MTL];                             // receiver of each segment of the tile
     int segstart[MTL + 1];                       // first row of each segment (coordinate kernel)
@@ -66,16 +76,6 @@ __device__ __forceinline__ float4 pos_lazy(const Layout& lay, const Work& w, con
 __device__ __forceinline__ float4 pos_mat(const Layout& lay, const Work& w, int n, int layer) {
     if (n >= lay.Nm) return w.XP[n - lay.Nl];
     return layer == 0 ? w.X0[n] : w.XL[(size_t)layer * lay.Nm + n];
-}
-
-// the k-th chunk of this workgroup (XCD-aware: workgroups with equal blockIdx % 8 share an L2 and get one contiguous range of chunks)
-__device__ __forceinline__ int xcd_chunk(int k, int nch) {
-    const int vb = (int)blockIdx.x, nb = (int)gridDim.x;
-    const int g = vb & 7, wg_in_g = vb >> 3, wgs_in_g = (nb - g + 7) >> 3, per_g = (nch + 7) >> 3;
-    const int t = wg_in_g + k * wgs_in_g;
-    if (wgs_in_g == 0 || t >= per_g) return -1;
-    const int c = g * per_g + t;
-    return c < nch ? c : -1;
 }
 
 // ---- tile build: columns [64 q, 64 q + 64) of SiLU(P[row] + Q[col] + w_r r + w_d d0) as three bf16 planes, in two batches of 64 rows
@@ -180,7 +180,7 @@ struct TileCtx {
 template <bool COORD, int NMT>
 __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, const Work& w, const Dims& d, const TileCtx& c, const int ne,
                                              sbf16x8 (&bs)[2][2][3], unsigned long long (&st_)[8], unsigned long long& st_t) {
-    int tid = threadIdx.x;
+    int tid = threadIdx.x & 255;            // thread of the tile's four waves (the phase-locked driver runs two tiles per workgroup)
     asm volatile("" : "+v"(tid));           // opaque: per-lane addresses derived from it are recomputed per tile instead of being hoisted out of the tile loop and spilled
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* __restrict__ P = c.P; const float* __restrict__ Q = c.Q; const sbf16x8* __restrict__ wb = c.wb;
@@ -210,11 +210,13 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
         } else {
             store_half<NMT>(L, tid, q, 0, ne, g0);
         }
+        STAMP(6);
         lds_barrier();
         STAMP(1);
-        __builtin_amdgcn_s_setprio(1);                               // the matrix pipe is the scarce unit: its instructions win the issue arbitration against the partner workgroup's vector phases (+1..2 %, profiles/r04_d)
+        __builtin_amdgcn_s_setprio(CMDGEN_E128_GPRIO);
         gemm_quarter<NMT>(L.planes, lane, q, wb, acc, bs);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(CMDGEN_E128_VPRIO);
+        STAMP(7);
         lds_barrier();                                                                  // every wave is done reading the planes
         STAMP(2);
     }
@@ -242,16 +244,16 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
     }
     lds_barrier();
     STAMP(3);
-    if (tid < MT) {
-        const float s = (L.part[0][tid] + L.part[1][tid]) + (L.part[2][tid] + L.part[3][tid]);
-        if (COORD) {
-            const float g = d.use_tanh ? tanhf(s) * d.coords_range : s;
-            L.cd[tid][0] *= g; L.cd[tid][1] *= g; L.cd[tid][2] *= g;
-        } else {
-            L.att[tid] = d.attention ? sigmoid_f(s + ba0) : 1.0f;
+    // every wave forms the gates of all rows for itself (two rows per lane) and keeps them in its own LDS strip: no barrier before their use
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = 64 * u + lane;
+        if (e < 32 * NMT) {
+            const float s = (L.part[0][e] + L.part[1][e]) + (L.part[2][e] + L.part[3][e]);
+            L.gw[wave][e] = COORD ? (d.use_tanh ? tanhf(s) * d.coords_range : s) : (d.attention ? sigmoid_f(s + ba0) : 1.0f);
         }
     }
-    lds_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     STAMP(5);
     if constexpr (COORD) {
         // ordered segment sums of the three components: one thread per (segment, component), rows in list order
@@ -260,7 +262,7 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
             const int sgi = i / 3, comp = i - 3 * sgi;
             const int rb = L.segstart[sgi], re = L.segstart[sgi + 1];
             float sum = 0.f;
-            for (int e = rb; e < re; ++e) sum += L.cd[e][comp];
+            for (int e = rb; e < re; ++e) sum += L.cd[e][comp] * L.gw[wave][e];     // trans = coord_diff * tanh(phi) * range, summed in list order (egnn_new.py:94-96)
             float* dst = reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nm + L.segrow[sgi]) + comp;
             if (sgi == 0 || sgi == nseg - 1) atomicAdd(dst, sum); else *dst = sum;      // a receiver may continue in the neighbouring tiles; ACC is zero before the launch
         }
@@ -299,7 +301,7 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int base = 32 * m + 8 * j + 4 * hh;
-                    const float4 g4 = *reinterpret_cast<const float4*>(&L.att[base]);              // one address per wave: broadcast
+                    const float4 g4 = *reinterpret_cast<const float4*>(&L.gw[wave][base]);              // one address per wave: broadcast
                     unsigned bits = (sm[base >> 5] >> (base & 31)) & 0xfu;
                     if (base == 0) bits &= ~1u;                                                    // row 0 opens segment 0: nothing to flush
                     const float* v = hh ? y : x;
@@ -322,32 +324,164 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// What both drivers share: the per-kernel constants of a thread, the walk over a workgroup's (or half workgroup's) chunks and tiles, and the
+// index phase of a tile.
+template <bool COORD>
+struct EdgeSrc {
+    const float* P; const float* Q; const int* rowp; const int* colp; const float* d0p;
+    __device__ __forceinline__ EdgeSrc(const Work& w) : P(COORD ? w.Pc : w.P), Q(COORD ? w.Qc : w.Q), rowp(COORD ? w.crow : w.erow), colp(COORD ? w.ccol : w.ecol), d0p(COORD ? w.cd0 : w.ed0) {}
+};
+
+// the k-th chunk of virtual workgroup vb of nb (XCD-aware: workgroups with equal index % 8 share an L2 and get one contiguous range of chunks)
+__device__ __forceinline__ int xcd_chunk_v(int vb, int nb, int k, int nch) {
+    const int g = vb & 7, wg_in_g = vb >> 3, wgs_in_g = (nb - g + 7) >> 3, per_g = (nch + 7) >> 3;
+    const int t = wg_in_g + k * wgs_in_g;
+    if (wgs_in_g == 0 || t >= per_g) return -1;
+    const int c = g * per_g + t;
+    return c < nch ? c : -1;
+}
+
+// Tile walk: chunk size CH, nch chunks; a chunk is cut into equal tiles of 32 .. MT rows (trows).  All values wave-uniform.
+struct TileWalk {
+    int vb, nb, E, CH, nch;          // the list and its cut
+    int kc, cbeg, cend, trows, e0;   // the chunk in work and the next tile's first row; cbeg < 0: nothing left
+    __device__ __forceinline__ void load_chunk() {
+        const int c = xcd_chunk_v(vb, nb, kc, nch);
+        if (c < 0) { cbeg = -1; cend = -1; trows = 32; e0 = 0; return; }
+        cbeg = c * CH; cend = min(E, cbeg + CH);
+        const int ntile = (cend - cbeg + MT - 1) / MT;
+        trows = (((cend - cbeg + ntile - 1) / ntile) + 31) & ~31;        // equal tiles, a multiple of 32 rows, <= 128
+        e0 = cbeg;
+    }
+    __device__ __forceinline__ void init(int vb_, int nb_, int E_, int max_n) {
+        vb = vb_; nb = nb_; E = E_;
+        CH = (((E + nb - 1) / nb) + 31) & ~31;
+        // a chunk holds more rows than any receiver has edges: the receiver's rows then lie in at most two chunks, i.e. its sum has at most two
+        // float-atomic partials, which commute - results are reproducible bit for bit.  Dense samples (full-atom pockets: ~60 edges per phar point
+        // at the pocket centre) need a full tile for that; C-alpha samples (< 60 nodes each) half of one.  Short lists just use fewer workgroups.
+        const int minch = max_n > 128 ? MTL : 64;
+        if (CH < minch) CH = minch;
+        nch = (E + CH - 1) / CH;
+        kc = 0; load_chunk();
+    }
+    __device__ __forceinline__ bool valid() const { return cbeg >= 0; }
+    __device__ __forceinline__ int ne_full() const { return min(trows, cend - e0); }
+    // after a tile of ne rows: is there another tile for this walker?  (does not advance)
+    __device__ __forceinline__ bool more_after(int ne) const { return e0 + ne < cend || xcd_chunk_v(vb, nb, kc + 1, nch) >= 0; }
+    __device__ __forceinline__ void advance(int ne) { e0 += ne; if (e0 >= cend) { ++kc; load_chunk(); } }
+};
+
+// (row, col, d0, level) of a tile's rows, kept one tile ahead by wave 0: two rows per lane
+struct RowPref { int nrow[2], ncol[2], nhop[2]; float nd0[2]; int nx_e0; };
+template <bool COORD>
+__device__ __forceinline__ void pref_fetch(RowPref& pf, const EdgeSrc<COORD>& es, const Work& w, const int lane, const int live_thr, int e0, int ne) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        pf.nrow[u] = -1; pf.ncol[u] = -1; pf.nd0[u] = 0.f; pf.nhop[u] = 255;
+        if (64 * u + lane < ne) {
+            const int e = e0 + 64 * u + lane;
+            pf.nrow[u] = es.rowp[e]; pf.ncol[u] = es.colp[e]; pf.nd0[u] = es.d0p[e];
+            if (!COORD && live_thr) pf.nhop[u] = w.ehop[e];
+        }
+    }
+    pf.nx_e0 = e0;
+}
+
+// ---------------- index phase of the tile at e0 (wave 0 of the tile's four waves): positions, radial, segments.  Writes L.e / cd / seg /
+// segrow / segstart / smask / meta; requests the rows of the tile after it.
+template <bool COORD>
+__device__ __forceinline__ void index_phase(E128Lds& L, const Layout& lay, const Work& w, const Dims& d, const EdgeSrc<COORD>& es, RowPref& pf, const TileWalk& tw,
+                                            const int lane, const int layer, const int live_thr) {
+    const int e0 = tw.e0, ne_full = tw.ne_full(), cend = tw.cend, trows = tw.trows;
+    if (pf.nx_e0 != e0) pref_fetch<COORD>(pf, es, w, lane, live_thr, e0, ne_full);      // first tile of the chunk, or the previous tile was cut short (below)
+    int row[2], col[2], hop[2]; float d0[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { row[u] = pf.nrow[u]; col[u] = pf.ncol[u]; hop[u] = pf.nhop[u]; d0[u] = pf.nd0[u]; }
+    if (e0 + ne_full < cend) pref_fetch<COORD>(pf, es, w, lane, live_thr, e0 + ne_full, min(trows, cend - e0 - ne_full));
+    // segments: runs of equal receivers (the lists are sorted by receiver)
+    const int prev0 = __shfl_up(row[0], 1);
+    const bool s0 = lane < ne_full && (lane == 0 || row[0] != prev0);
+    const int last0 = __shfl(row[0], 63);
+    const int prev1 = __shfl_up(row[1], 1);
+    const bool s1 = 64 + lane < ne_full && row[1] != (lane == 0 ? last0 : prev1);
+    const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
+    const unsigned long long below = (2ull << lane) - 1ull;                        // lanes <= this one
+    const int n0 = __popcll(m0);
+    const int sg0 = __popcll(m0 & below) - 1, sg1 = n0 + __popcll(m1 & below) - 1;
+    int ne = ne_full, ns = n0 + __popcll(m1);
+    if (!COORD && ns > 32) {
+        // the message kernel's epilogue keeps 32 receivers per tile: cut the tile where the 33rd begins (the next tile starts there)
+        ne = __popcll(__ballot(lane < ne_full && sg0 < 32)) + __popcll(__ballot(64 + lane < ne_full && sg1 < 32));
+        ns = 32;
+    }
+    bool live = true;
+    if (!COORD && live_thr) live = (__ballot(lane < ne && hop[0] <= live_thr) | __ballot(64 + lane < ne && hop[1] <= live_thr)) != 0ull;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = 64 * u + lane;
+        float r = 0.f;
+        if (t < ne && live) {
+            if (COORD) {
+                const float4 pi = pos_mat(lay, w, row[u], layer), pj = pos_mat(lay, w, col[u], layer);
+                float cx = pi.x - pj.x, cy = pi.y - pj.y, cz = pi.z - pj.z;
+                r = cx * cx + cy * cy + cz * cz;
+                const float den = sqrtf(r + 1e-8f) + d.norm_constant;              // coord2diff, egnn_new.py:265-271
+                L.cd[t][0] = cx / den; L.cd[t][1] = cy / den; L.cd[t][2] = cz / den;
+            } else {
+                // block 0: the radial IS the d0 of the graph pass (same dist2, same operands); later blocks: lazily updated positions
+                r = layer == 0 ? d0[u] : dist2(pos_lazy(lay, w, d, row[u], layer), pos_lazy(lay, w, d, col[u], layer));
+            }
+        }
+        EdgeRec er; er.row = row[u]; er.col = col[u]; er.r = r; er.d0 = d0[u];
+        L.e[t] = er;
+    }
+    L.seg[lane] = (unsigned char)(lane < ne ? sg0 : 255);
+    L.seg[64 + lane] = (unsigned char)(64 + lane < ne ? sg1 : 255);
+    if (s0 && lane < ne) { L.segrow[sg0] = row[0]; L.segstart[sg0] = lane; }
+    if (s1 && 64 + lane < ne) { L.segrow[sg1] = row[1]; L.segstart[sg1] = 64 + lane; }
+    if (lane == 0) {
+        L.meta[0] = ns; L.meta[1] = live ? 1 : 0; L.meta[2] = ne; L.segstart[ns] = ne;
+        const unsigned long long k0 = m0 | (ne < 64 ? 1ull << ne : 0ull), k1 = m1 | (ne >= 64 && ne < 128 ? 1ull << (ne - 64) : 0ull);
+        L.smask[0] = (int)(unsigned)k0; L.smask[1] = (int)(unsigned)(k0 >> 32); L.smask[2] = (int)(unsigned)k1; L.smask[3] = (int)(unsigned)(k1 >> 32);
+    }
+}
+
+template <bool COORD>
+__device__ __forceinline__ void tile_dispatch(E128Lds& L, const Layout& lay, const Work& w, const Dims& d, const TileCtx& tc, const int ne, sbf16x8 (&bs)[2][2][3],
+                                              unsigned long long (&st_)[8], unsigned long long& st_t) {
+    switch ((ne + 31) >> 5) {
+        case 4: if constexpr (MT >= 128) tile_compute<COORD, 4>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
+        case 3: if constexpr (MT >= 96) tile_compute<COORD, 3>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
+        case 2: tile_compute<COORD, 2>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
+        default: tile_compute<COORD, 1>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
+    }
+}
+constexpr int TILE_BARRIERS = 9;        // barriers inside tile_compute (two per quarter, one after the row dots)
+
+template <bool COORD>
+__device__ __forceinline__ TileCtx make_ctx(const LayerW& lw, const EdgeSrc<COORD>& es, const int wave, const int lane, const int layer) {
+    const WPack& W = COORD ? lw.W7 : lw.W2;
+    const float* bvec = COORD ? lw.b7 : lw.b2;
+    const float* hvec = COORD ? lw.w5 : lw.wa;                                   // the row dot's weight vector
+    TileCtx tc;
+    tc.colw = 64 * wave + (lane & 31);
+    tc.P = es.P; tc.Q = es.Q; tc.layer = layer;
+    tc.bias0 = bvec[tc.colw]; tc.bias1 = bvec[tc.colw + 32]; tc.hv0 = hvec[tc.colw]; tc.hv1 = hvec[tc.colw + 32];
+    tc.ba0 = COORD ? 0.f : lw.ba[0];
+    tc.wb = reinterpret_cast<const sbf16x8*>(W.ws) + (size_t)(2 * wave) * 16 * 192 + lane;
+    return tc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Driver 1: two free-running 256-thread workgroups per CU, one chunk walk each.
 template <bool COORD>
 __global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, LayerW lw, int layer, int live_thr) {
     __shared__ E128Lds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const WPack& W = COORD ? lw.W7 : lw.W2;
-    const float* __restrict__ P = COORD ? w.Pc : w.P;
-    const float* __restrict__ Q = COORD ? w.Qc : w.Q;
-    const int* __restrict__ rowp = COORD ? w.crow : w.erow;
-    const int* __restrict__ colp = COORD ? w.ccol : w.ecol;
-    const float* __restrict__ d0p = COORD ? w.cd0 : w.ed0;
+    const EdgeSrc<COORD> es(w);
     L.wrd[tid] = (COORD ? lw.wr_c : lw.wr_e)[tid]; L.wrd[H + tid] = (COORD ? lw.wd_c : lw.wd_e)[tid];       // visible after the first tile's barrier
-    const int colw = 64 * wave + (lane & 31);
-    const float* bvec = COORD ? lw.b7 : lw.b2;
-    const float* hvec = COORD ? lw.w5 : lw.wa;                                   // the row dot's weight vector
-    const float bias0 = bvec[colw], bias1 = bvec[colw + 32], hv0 = hvec[colw], hv1 = hvec[colw + 32];
-    const float ba0 = COORD ? 0.f : lw.ba[0];
-    const sbf16x8* __restrict__ wb = reinterpret_cast<const sbf16x8*>(W.ws) + (size_t)(2 * wave) * 16 * 192 + lane;
-    const int E = w.totals[COORD ? 1 : 0];
-    const int G = (int)gridDim.x;
-    int CH = (((E + G - 1) / G) + 31) & ~31;
-    // a chunk holds more rows than any receiver has edges: the receiver's rows then lie in at most two chunks, i.e. its sum has at most two
-    // float-atomic partials, which commute - results are reproducible bit for bit.  Dense samples (full-atom pockets: ~60 edges per phar point
-    // at the pocket centre) need a full tile for that; C-alpha samples (< 60 nodes each) half of one.  Short lists just use fewer workgroups.
-    const int minch = lay.max_n > 128 ? MTL : 64;
-    if (CH < minch) CH = minch;
-    const int nch = (E + CH - 1) / CH;
+    const TileCtx tc = make_ctx<COORD>(lw, es, wave, lane, layer);
+    TileWalk tw; tw.init((int)blockIdx.x, (int)gridDim.x, w.totals[COORD ? 1 : 0], lay.max_n);
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;       // diagnostic builds (-DCMDGEN_STAMPS=6): summed phase cycles
 #if CMDGEN_STAMPS == 6
     st_t = __builtin_amdgcn_s_memtime();
@@ -356,114 +490,111 @@ __global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, 
 #else
 #define STAMP(i) do {} while (0)
 #endif
-    for (int kc = 0, c; (c = xcd_chunk(kc, nch)) >= 0; ++kc) {
-        const int cbeg = c * CH, cend = min(E, cbeg + CH);
-        const int ntile = (cend - cbeg + MT - 1) / MT;
-        const int trows = (((cend - cbeg + ntile - 1) / ntile) + 31) & ~31;         // equal tiles, a multiple of 32 rows, <= 128
-        // wave 0 keeps the next tile's (row, col, d0, level) one tile ahead: two rows per lane
-        int nrow[2] = {-1, -1}, ncol[2] = {-1, -1}, nhop[2] = {255, 255}; float nd0[2] = {0.f, 0.f};
-        int nx_e0 = -1;                                                             // the first row the prefetched records belong to
-        auto fetch = [&](int e0, int ne) {
+    RowPref pf; pf.nx_e0 = -1;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                nrow[u] = -1; ncol[u] = -1; nd0[u] = 0.f; nhop[u] = 255;
-                if (64 * u + lane < ne) {
-                    const int e = e0 + 64 * u + lane;
-                    nrow[u] = rowp[e]; ncol[u] = colp[e]; nd0[u] = d0p[e];
-                    if (!COORD && live_thr) nhop[u] = w.ehop[e];
-                }
-            }
-            nx_e0 = e0;
-        };
-        for (int e0 = cbeg; e0 < cend; ) {
-            const int ne_full = min(trows, cend - e0);
-            sbf16x8 bs[2][2][3];
+    for (int u = 0; u < 2; ++u) { pf.nrow[u] = -1; pf.ncol[u] = -1; pf.nhop[u] = 255; pf.nd0[u] = 0.f; }
+    while (tw.valid()) {
+        sbf16x8 bs[2][2][3];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) bs[0][i & 1][i >> 1] = wb[(unsigned)(i & 1) * NS + (unsigned)(i >> 1) * 64u];     // k-block 0, in flight during the index phase
-            // ---------------- index phase (wave 0): positions, radial, segments of the tile
+        for (int i = 0; i < 6; ++i) bs[0][i & 1][i >> 1] = tc.wb[(unsigned)(i & 1) * NS + (unsigned)(i >> 1) * 64u];     // k-block 0, in flight during the index phase
+        if (wave == 0) index_phase<COORD>(L, lay, w, d, es, pf, tw, lane, layer, live_thr);
+        lds_barrier();
+        STAMP(0);
+        const int ne = L.meta[2];
+        if (!L.meta[1]) {                                                                   // dead tile (see edge_msg_body, kernels_egnn.hip)
+            if (tid == 0) atomicAdd(&w.counters[6], (unsigned long long)ne);
+        } else {
+            tile_dispatch<COORD>(L, lay, w, d, tc, ne, bs, st_, st_t);
+        }
+        lds_barrier();                                                                      // the next index phase rewrites e / seg / meta
+        STAMP(4);
+        tw.advance(ne);
+#if CMDGEN_STAMPS == 6
+        ++st_tiles;
+#endif
+    }
+#if CMDGEN_STAMPS == 6
+    if (lane == 0 && (blockIdx.x & 3) == 0 && st_tiles > 0 && COORD == (CMDGEN_STAMP_COORD != 0)) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
+        atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
+        atomicAdd(&w.dbg[40], 1ull);
+        if (wave == 0) atomicAdd(&w.dbg[41], (unsigned long long)st_tiles);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Driver 2 (round 5): ONE 512-thread workgroup per CU whose two halves (waves 0-3, waves 4-7: a SIMD hosts wave i and wave i + 4) run the same
+// tile program on two chunk walks, PHASE-LOCKED one barrier apart.  s_barrier counts all eight waves, so with the second half started one
+// barrier late every barrier is a rendezvous of phase k of one half with phase k - 1 of the other: a half's GEMM quarter (the phases between
+// an odd and the following even barrier of its tile) always runs beside a build or epilogue phase of its partner, never beside the partner's
+// GEMM - the matrix pipe of a SIMD has one user at a time and that user's partner is issuing vector work.  Free-running workgroups (driver 1)
+// drift into lockstep instead: both in their GEMMs (sharing the pipe), then both in their builds (pipe idle); profiles/r04_l, r05_b.
+// Both halves execute the same number of tile slots (a half without a tile runs the slot's barriers only); whether another slot follows is
+// agreed through two LDS flags that each half writes in its index phase.  No wave ever waits on anything but s_barrier.
+template <bool COORD>
+__global__ __launch_bounds__(512, 2) void k_edge128pp(Layout lay, Work w, Dims d, LayerW lw, int layer, int live_thr) {
+    __shared__ E128Lds LL[2];
+    __shared__ int more_flag[2][2];                                                         // [slot parity][half]: the half has a tile in the NEXT slot
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), htid = tid & 255;
+    E128Lds& L = LL[half];
+    const EdgeSrc<COORD> es(w);
+    L.wrd[htid] = (COORD ? lw.wr_c : lw.wr_e)[htid]; L.wrd[H + htid] = (COORD ? lw.wd_c : lw.wd_e)[htid];   // visible after the first slot's first barrier
+    const TileCtx tc = make_ctx<COORD>(lw, es, wave, lane, layer);
+    const int E = w.totals[COORD ? 1 : 0];
+    TileWalk tw; tw.init((int)blockIdx.x + half * (int)gridDim.x, 2 * (int)gridDim.x, E, lay.max_n);        // (gridDim % 8 == 0: both halves' chunks lie in this XCD's range)
+    TileWalk other; other.init((int)blockIdx.x + (1 - half) * (int)gridDim.x, 2 * (int)gridDim.x, E, lay.max_n);
+    bool cont = tw.valid() || other.valid();                                                // wave-uniform and equal in all eight waves
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+#if CMDGEN_STAMPS == 6
+    st_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_t; int st_tiles = 0;
+#endif
+    RowPref pf; pf.nx_e0 = -1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { pf.nrow[u] = -1; pf.ncol[u] = -1; pf.nhop[u] = 255; pf.nd0[u] = 0.f; }
+    if (half == 1) lds_barrier();                                                           // the second half runs one phase behind
+    for (int slot = 0; cont; ++slot) {
+        const bool mine = tw.valid();
+        sbf16x8 bs[2][2][3];
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) bs[0][i & 1][i >> 1] = tc.wb[(unsigned)(i & 1) * NS + (unsigned)(i >> 1) * 64u];
             if (wave == 0) {
-                if (nx_e0 != e0) fetch(e0, ne_full);                                // first tile of the chunk, or the previous tile was cut short (below)
-                int row[2], col[2], hop[2]; float d0[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) { row[u] = nrow[u]; col[u] = ncol[u]; hop[u] = nhop[u]; d0[u] = nd0[u]; }
-                if (e0 + ne_full < cend) fetch(e0 + ne_full, min(trows, cend - e0 - ne_full));
-                // segments: runs of equal receivers (the lists are sorted by receiver)
-                const int prev0 = __shfl_up(row[0], 1);
-                const bool s0 = lane < ne_full && (lane == 0 || row[0] != prev0);
-                const int last0 = __shfl(row[0], 63);
-                const int prev1 = __shfl_up(row[1], 1);
-                const bool s1 = 64 + lane < ne_full && row[1] != (lane == 0 ? last0 : prev1);
-                const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
-                const unsigned long long below = (2ull << lane) - 1ull;                        // lanes <= this one
-                const int n0 = __popcll(m0);
-                const int sg0 = __popcll(m0 & below) - 1, sg1 = n0 + __popcll(m1 & below) - 1;
-                int ne = ne_full, ns = n0 + __popcll(m1);
-                if (!COORD && ns > 32) {
-                    // the message kernel's segment sum takes 32 segments per tile: cut the tile where the 33rd begins (the next tile starts there)
-                    ne = __popcll(__ballot(lane < ne_full && sg0 < 32)) + __popcll(__ballot(64 + lane < ne_full && sg1 < 32));
-                    ns = 32;
-                }
-                bool live = true;
-                if (!COORD && live_thr) live = (__ballot(lane < ne && hop[0] <= live_thr) | __ballot(64 + lane < ne && hop[1] <= live_thr)) != 0ull;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int t = 64 * u + lane;
-                    float r = 0.f;
-                    if (t < ne && live) {
-                        if (COORD) {
-                            const float4 pi = pos_mat(lay, w, row[u], layer), pj = pos_mat(lay, w, col[u], layer);
-                            float cx = pi.x - pj.x, cy = pi.y - pj.y, cz = pi.z - pj.z;
-                            r = cx * cx + cy * cy + cz * cz;
-                            const float den = sqrtf(r + 1e-8f) + d.norm_constant;              // coord2diff, egnn_new.py:265-271
-                            L.cd[t][0] = cx / den; L.cd[t][1] = cy / den; L.cd[t][2] = cz / den;
-                        } else {
-                            // block 0: the radial IS the d0 of the graph pass (same dist2, same operands); later blocks: lazily updated positions
-                            r = layer == 0 ? d0[u] : dist2(pos_lazy(lay, w, d, row[u], layer), pos_lazy(lay, w, d, col[u], layer));
-                        }
-                    }
-                    EdgeRec er; er.row = row[u]; er.col = col[u]; er.r = r; er.d0 = d0[u];
-                    L.e[t] = er;
-                }
-                L.seg[lane] = (unsigned char)(lane < ne ? sg0 : 255);
-                L.seg[64 + lane] = (unsigned char)(64 + lane < ne ? sg1 : 255);
-                if (s0 && lane < ne) { L.segrow[sg0] = row[0]; L.segstart[sg0] = lane; }
-                if (s1 && 64 + lane < ne) { L.segrow[sg1] = row[1]; L.segstart[sg1] = 64 + lane; }
-                if (lane == 0) {
-                    L.meta[0] = ns; L.meta[1] = live ? 1 : 0; L.meta[2] = ne; L.segstart[ns] = ne;
-                    const unsigned long long k0 = m0 | (ne < 64 ? 1ull << ne : 0ull), k1 = m1 | (ne >= 64 && ne < 128 ? 1ull << (ne - 64) : 0ull);
-                    L.smask[0] = (int)(unsigned)k0; L.smask[1] = (int)(unsigned)(k0 >> 32); L.smask[2] = (int)(unsigned)k1; L.smask[3] = (int)(unsigned)(k1 >> 32);
-                }
+                index_phase<COORD>(L, lay, w, d, es, pf, tw, lane, layer, live_thr);
+                if (lane == 0) more_flag[slot & 1][half] = tw.more_after(L.meta[2]) ? 1 : 0;   // (lane 0 wrote meta[2] itself)
             }
-            lds_barrier();
-            STAMP(0);
-            const int ne = L.meta[2];
-            const int nmt = (ne + 31) >> 5;
-            if (!L.meta[1]) {                                                                   // dead tile (see edge_msg_body, kernels_egnn.hip)
-                if (tid == 0) atomicAdd(&w.counters[6], (unsigned long long)ne);
-                lds_barrier();                                                                  // meta is rewritten by the next index phase
-                e0 += ne;
-                continue;
-            }
-            {
-                TileCtx tc; tc.P = P; tc.Q = Q; tc.wb = wb; tc.bias0 = bias0; tc.bias1 = bias1; tc.hv0 = hv0; tc.hv1 = hv1; tc.ba0 = ba0; tc.colw = colw; tc.layer = layer;
-                switch (nmt) {
-                    case 4: if constexpr (MT >= 128) tile_compute<COORD, 4>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
-                    case 3: if constexpr (MT >= 96) tile_compute<COORD, 3>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
-                    case 2: tile_compute<COORD, 2>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
-                    default: tile_compute<COORD, 1>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
-                }
-            }
-            lds_barrier();                                                                      // the next index phase rewrites e / seg / meta
-            STAMP(4);
-            e0 += ne;
+        } else if (htid == 0) {
+            more_flag[slot & 1][half] = 0;
+        }
+        lds_barrier();
+        STAMP(0);
+        int ne = 0;
+        bool live = false;
+        if (mine) { ne = L.meta[2]; live = L.meta[1] != 0; }
+        if (live) {
+            tile_dispatch<COORD>(L, lay, w, d, tc, ne, bs, st_, st_t);
+        } else {
+            if (mine && htid == 0) atomicAdd(&w.counters[6], (unsigned long long)ne);      // dead tile
+#pragma unroll 1
+            for (int i = 0; i < TILE_BARRIERS; ++i) lds_barrier();
+        }
+        lds_barrier();
+        STAMP(4);
+        if (mine) {
+            tw.advance(ne);
 #if CMDGEN_STAMPS == 6
             ++st_tiles;
 #endif
         }
+        // the partner wrote its flag of this slot at least one barrier ago (it is at most one phase away), and rewrites this parity two slots on
+        cont = (more_flag[slot & 1][0] | more_flag[slot & 1][1]) != 0;
     }
+    if (half == 0) lds_barrier();
 #if CMDGEN_STAMPS == 6
-    if (lane == 0 && (blockIdx.x & 3) == 0 && st_tiles > 0) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
+    if (lane == 0 && (blockIdx.x & 1) == 0 && half == 0 && st_tiles > 0 && COORD == (CMDGEN_STAMP_COORD != 0)) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
         atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
         atomicAdd(&w.dbg[40], 1ull);
         if (wave == 0) atomicAdd(&w.dbg[41], (unsigned long long)st_tiles);
@@ -477,6 +608,11 @@ __global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, 
 // launchers: true when the 128-row kernels took the launch (H = 256, split engine, sampler)
 bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s) {
     if (a.edge_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[unit_of(a, l)].W2.ws) return false;
+    if (a.e128_pp) {                     // the phase-locked driver: one 512-thread workgroup per CU
+        if (a.pe_start) hipExtLaunchKernelGGL(k_edge128pp<false>, dim3(a.n_cus), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.live_thr);
+        else hipLaunchKernelGGL(k_edge128pp<false>, dim3(a.n_cus), dim3(512), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.live_thr);
+        return true;
+    }
     const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 2 ? a.e128_wgs : 2) * a.n_cus;
     if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.live_thr);
     else hipLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.live_thr);
@@ -484,6 +620,11 @@ bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s) {
 }
 bool cmdgen_launch_coord128(const EvalLaunch& a, int l, hipStream_t s) {
     if (a.coord_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[unit_of(a, l)].W7.ws) return false;
+    if (a.e128_pp) {
+        if (a.pe_start) hipExtLaunchKernelGGL(k_edge128pp<true>, dim3(a.n_cus), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, 0);
+        else hipLaunchKernelGGL(k_edge128pp<true>, dim3(a.n_cus), dim3(512), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, 0);
+        return true;
+    }
     const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 2 ? a.e128_wgs : 2) * a.n_cus;
     if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, 0);
     else hipLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, 0);

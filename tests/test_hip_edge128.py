@@ -21,6 +21,14 @@ G12 = load_golden('g12_fullsize.npz')
 G13 = load_golden('g13_bounded.npz')
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=['two_wgs', 'phase_locked'])
+def e128_driver(request, monkeypatch):
+    """every test of this file runs on both drivers of the 128-row kernels: two free-running 256-thread workgroups per CU, and one
+    512-thread workgroup per CU whose halves are phase-locked one barrier apart (option e128_pp)"""
+    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'e128_pp', request.param)
+    return request.param
+
+
 def force128(monkeypatch):
     """every Handle created from here on starts with these options (hip_backend.DEFAULT_OPTIONS -> cmdgen_set_option)"""
     monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'edge_mt', 128)
