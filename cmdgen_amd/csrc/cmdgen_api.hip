@@ -210,6 +210,33 @@ static std::vector<unsigned short> pack_split16(const float* W, int out, int ld,
     return p;
 }
 
+// same matrix as TWO fp16 pieces of (scale * w) per weight in v_mfma_f32_32x32x16_f16 fragment order, the two pieces of a fragment
+// contiguous: Wh[((nt * KB16 + kb) * 2 + s) * 64 + lane] = 8 halves (cmdgen_split.h, "half" engine).  scale is a power of two chosen
+// so that the largest weight lands in [2^11, 2^12): both pieces of every weight that matters are normal fp16 numbers.
+static std::vector<unsigned short> pack_half(const float* W, int out, int ld, int c0, int in, float* scale) {
+    float mx = 0.f;
+    for (int o = 0; o < out; ++o) for (int k = 0; k < in; ++k) mx = std::max(mx, std::fabs(W[(size_t)o * ld + c0 + k]));
+    int e = 0;
+    if (mx > 0.f && std::isfinite(mx)) { int ex; std::frexp(mx, &ex); e = 12 - ex; }      // mx * 2^e in [2^11, 2^12)
+    e = std::max(-40, std::min(40, e));
+    const float sc = std::ldexp(1.0f, e);
+    *scale = sc;
+    const int NT = out / 32, KB = in / 16;
+    std::vector<unsigned short> p((size_t)NT * KB * 2 * 64 * 8);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const float w = W[(size_t)(32 * nt + (lane & 31)) * ld + c0 + 16 * kb + 8 * (lane >> 5) + j] * sc;
+                    const _Float16 h0 = (_Float16)w; const float r1 = w - (float)h0;
+                    const _Float16 h1 = (_Float16)r1;
+                    unsigned short u0, u1; memcpy(&u0, &h0, 2); memcpy(&u1, &h1, 2);
+                    const size_t base = (((size_t)nt * KB + kb) * 2) * 64 * 8;
+                    p[base + (0 * 64 + lane) * 8 + j] = u0; p[base + (1 * 64 + lane) * 8 + j] = u1;
+                }
+    return p;
+}
+
 static int upload_pack(cmdgen_handle* h, const float* W, int out, int in, WPack* wp) {
     const float* dp;
     std::vector<float> p = pack_frag(W, out, in, 0, in);
@@ -221,6 +248,13 @@ static int upload_pack(cmdgen_handle* h, const float* W, int out, int in, WPack*
     if (hipMemcpy(q, ps.data(), ps.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemcpy H2D failed");
     wp->ws = q;
     wp->ws16 = nullptr;
+    {
+        float sc = 1.0f;
+        const std::vector<unsigned short> ph = pack_half(W, out, in, 0, in, &sc);
+        r = dev_alloc(h, h->weight_allocs, &q, ph.size() * sizeof(unsigned short), false); if (r) return r;
+        if (hipMemcpy(q, ph.data(), ph.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemcpy H2D failed");
+        wp->wh = q; wp->wh_scale = sc; wp->wh_inv = 1.0f / sc;
+    }
     if (in % 128 == 0) {        // the 16-row split GEMM walks four k-blocks of 32 per iteration
         const std::vector<unsigned short> p16 = pack_split16(W, out, in, 0, in);
         r = dev_alloc(h, h->weight_allocs, &q, p16.size() * sizeof(unsigned short), false); if (r) return r;
@@ -591,6 +625,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.edge_fullk = (sp256 && opt_of(h, "edge_fullk", 1) != 0) ? 1 : 0;
     a.e128_wgs = (int)opt_of(h, "e128_wgs_per_cu", 2);
     a.e128_pp = (int)opt_of(h, "e128_pp", 0);
+    a.e128_f16 = (int)opt_of(h, "e128_f16", 1);
     a.write_embed = opt_of(h, "write_embed", 1) != 0 ? 1 : 0;
     {   // k_node64 (kernels_node64.hip: 64-row node tiles, the A operand as producer-side bf16 planes, one workgroup per CU) against
         // k_node<H, 32> (register split, two workgroups per CU).  Per launch the 64-row kernel takes ~0.89 of a co-resident pair of
@@ -630,7 +665,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
 // options
 // ---------------------------------------------------------------------------------
 static const char* const kOptionKeys[] = {
-    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "e128_pp", "edge_fullk", "node64", "node16_split", "node16w",
+    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "e128_pp", "e128_f16", "edge_fullk", "node64", "node16_split", "node16w",
     "dead_skip", "write_embed", "fused_step", "pocket_cache", "graph_steps",
     "wgrad_split", "wgrad_tile", "wgrad_split_wgs128", "wgrad_split_wgs64", "wgrad_wgs", "dgrad_mt", "dgrad_tail"};
 

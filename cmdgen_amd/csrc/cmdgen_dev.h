@@ -31,6 +31,9 @@ struct WPack {                  // one Linear weight in the MFMA fragment orders
     const float4* w16;          // v_mfma_f32_16x16x4_f32 order  (16-row tiles)
     const void*   ws;           // three bf16 pieces per weight in v_mfma_f32_32x32x16_bf16 order (cmdgen_split.h); null in training
     const void*   ws16;         // the same pieces in v_mfma_f32_16x16x32_bf16 order (16-row tiles on the split engine); null in training
+    const void*   wh;           // TWO fp16 pieces of (weight * wh_scale) per weight in v_mfma_f32_32x32x16_f16 order (cmdgen_split.h, "half" engine); null in training
+    float         wh_scale;     // the power of two the matrix was multiplied by before its split (keeps both pieces in fp16's normal range)
+    float         wh_inv;       // 1 / wh_scale
 };
 
 struct LayerW {                 // device pointers to one EquivariantBlock's packed weights
@@ -229,6 +232,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     int write_embed = 1;        // 1: pass 2 of the radius graph and k_embed share a launch (k_write_embed) where both fit (option "write_embed")
     int e128_wgs = 2;           // workgroups per CU of the 128-row edge kernels (kernels_edge128.hip)
+    int e128_f16 = 1;           // 1: the 128-row edge kernels multiply on the HALF engine (two fp16 pieces per operand, three MFMAs per product; cmdgen_split.h)
     int e128_pp = 0;            // 1: the 128-row edge kernels run as ONE 512-thread workgroup per CU whose two halves are phase-locked one barrier apart (k_edge128pp)
 };
 // weight unit of block l's launches (EvalLaunch::unit), and the has_next argument of its node kernel: bit 0 = another unit follows

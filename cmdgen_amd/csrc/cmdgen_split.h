@@ -50,6 +50,49 @@ __device__ __forceinline__ void split3_pair(float a, float b, uint32_t& p0, uint
     const float qa = ra - __uint_as_float(p1 << 16), qb = rb - __uint_as_float(p1 & 0xffff0000u);   // exact
     p2 = cvt_pk_bf16(qa, qb);
 }
+// ---------------------------------------------------------------------------------------------
+// "Half" engine (round 5): TWO fp16 pieces per operand, THREE v_mfma_f32_32x32x16_f16 per fp32 product.
+//   a = a0 + a1, a0 = fp16(a), a1 = fp16(a - a0):   |a - a0 - a1| <= 2^-22 |a|   (11 + 11 significant bits)
+//   a b ~= a1 b0 + a0 b1 + a0 b0                    (dropped: a1 b1 <= 2^-22 |a||b|; every kept product is exact in the fp32 accumulator)
+// Half the matrix instructions of the three-piece bf16 split and 2 instead of 5.5 vector operations per split element.  What it gives
+// up is two bits of operand precision - below the rounding of the fp32 accumulation both engines and the reference share: emulated on
+// [2048, 256] x [256, 256] products of SiLU activations (tools/half_split_error.py) the result is 7.8e-8 rms from the exact product
+// against 9.4e-8 for the six-product bf16 split (twice as many accumulator roundings) and 1.6e-7 for an fp32 fmaf chain / BLAS sgemm.
+// Range: fp16 ends at 65504.  Weights are pre-multiplied by a power of two (WPack::wh_scale: the largest weight in [2^11, 2^12)) so that
+// both pieces are normal numbers, and the epilogue folds 1 / wh_scale into constants it multiplies by anyway.  An ACTIVATION above 65504
+// becomes Inf and its second piece NaN: the evaluation's NaN guard then resets the step (dynamics.py:129-131), as for an infinite
+// activation on the bf16 split; no fixture or chain of this repository comes within three orders of magnitude of that.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sf16x2 __attribute__((ext_vector_type(2)));
+// two floats -> packed fp16 pair (round to nearest even; v_cvt_pk_f16_f32)
+__device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    const sf16x2 h = __builtin_convertvector(v, sf16x2);
+    return __builtin_bit_cast(uint32_t, h);
+}
+// a - (float)half, the half taken from the low / high 16 bits of p: one v_fma_mix_f32 each (exact: the difference is representable)
+__device__ __forceinline__ float sub_half_lo(float a, uint32_t p) {
+    float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(a)); return r;
+}
+__device__ __forceinline__ float sub_half_hi(float a, uint32_t p) {
+    float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(a)); return r;
+}
+// the two fp16 pieces of two floats, each piece packed {a, b}: 2 vector operations per element
+__device__ __forceinline__ void split2_pair(float a, float b, uint32_t& p0, uint32_t& p1) {
+    p0 = cvt_pk_f16(a, b);
+    p1 = cvt_pk_f16(sub_half_lo(a, p0), sub_half_hi(b, p0));
+}
+// four consecutive k-values of one row -> the two fp16 planes (8 bytes each)
+__device__ __forceinline__ void split_store4_half(unsigned short* planes, int plane_elems, int off, const float4& v) {
+    uint32_t a0, a1, b0, b1;
+    split2_pair(v.x, v.y, a0, a1);
+    split2_pair(v.z, v.w, b0, b1);
+    *reinterpret_cast<uint2*>(planes + off) = make_uint2(a0, b0);
+    *reinterpret_cast<uint2*>(planes + plane_elems + off) = make_uint2(a1, b1);
+}
+
 struct SFragPtr { const sbf16x8* p; unsigned ns; };     // a wave's first n-tile; ns = stride between n-tiles (16-byte units)
 
 // cg = the wave's 64-column group; kb16_total = K / 16 of the packed matrix; kb0 = first k-block of this GEMM

@@ -23,610 +23,42 @@
 #include "cmdgen_dev.h"
 #include <hip/hip_ext.h>
 
-namespace {
-
-constexpr int H = 256;
-#ifndef CMDGEN_STAMP_COORD
-#define CMDGEN_STAMP_COORD 0      // diagnostic builds: which of the two kernels records its phase stamps
-#endif
-// issue priority of a wave inside its GEMM quarters / everywhere else (s_setprio)
-#ifndef CMDGEN_E128_GPRIO
-#define CMDGEN_E128_GPRIO 1
-#endif
-#ifndef CMDGEN_E128_VPRIO
-#define CMDGEN_E128_VPRIO 0
-#endif
-#ifndef CMDGEN_E128_MT
-#define CMDGEN_E128_MT 128
-#endif
-constexpr int MT = CMDGEN_E128_MT;      // rows per tile (at most): 128, 96 or 64
-constexpr int MTL = 128;                // rows the per-tile index arrays hold (the index phase handles two rows per lane of wave 0)
-constexpr int KQ = 64;                  // k-values per build / GEMM pass
-constexpr int PLDA = KQ + 8;            // bf16 per plane row: 144 B, conflict-free ds_read_b128 over 16 consecutive rows
-constexpr int PE = MT * PLDA;           // bf16 per plane
-constexpr unsigned NS = 16u * 192u;     // 16-byte units between the two 32-column tiles of a wave in a packed [H][H] split weight
-
-struct alignas(16) EdgeRec { int row, col; float r, d0; };
-
-struct alignas(16) E128Lds {
-    unsigned short planes[3 * PE + 64];         // three bf16 planes of the quarter in flight (+ the A prefetch's overshoot)
-    EdgeRec e[MTL];                              // (receiver, sender, radial, d0) of the tile's rows; -1 / -1 / 0 / 0 beyond its end
-    float cd[MTL][4];                            // coordinate kernel: coord_diff of the row, later coord_diff * tanh(phi) * range
-    float part[4][MTL];                          // the four waves' partial row dots
-    float gw[4][MTL];                            // gate (message kernel) / tanh(phi) * range (coordinate kernel) of each row, one copy per wave (each wave fills and reads its own: no barrier)
-    float wrd[2 * H];                           // radial / d0 columns of the first layer
-    int segrow[MTL];                             // receiver of each segment of the tile
-    int segstart[MTL + 1];                       // first row of each segment (coordinate kernel)
-    unsigned char seg[MTL];                      // segment index of each row (255 beyond the tile's end)
-    int meta[4];                                // [0] segments, [1] live, [2] rows of the tile
-    int smask[4];                               // bit e: row e of the tile opens a segment (message kernel); bit ne: end of the listed rows
-};
-
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// lazily updated positions, as kernels_egnn.hip forms them (same expression, same bits)
-__device__ __forceinline__ float4 pos_lazy(const Layout& lay, const Work& w, const Dims& d, int n, int layer) {
-    if (n >= lay.Nm) return w.XP[n - lay.Nl];
-    if (layer == 0) return w.X0[n];
-    const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nm + n];
-    const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
-    const float dv = agg_div(w, d, n);
-    return make_float4(p.x + a.x / dv, p.y + a.y / dv, p.z + a.z / dv, 0.f);
+#define E128_NPL 2
+namespace e128_half {
+#include "cmdgen_edge128_body.h"
 }
-__device__ __forceinline__ float4 pos_mat(const Layout& lay, const Work& w, int n, int layer) {
-    if (n >= lay.Nm) return w.XP[n - lay.Nl];
-    return layer == 0 ? w.X0[n] : w.XL[(size_t)layer * lay.Nm + n];
+#undef E128_NPL
+#undef E128_MFMA
+#define E128_NPL 3
+namespace e128_bf3 {
+#include "cmdgen_edge128_body.h"
 }
+#undef E128_NPL
+#undef E128_MFMA
 
-// ---- tile build: columns [64 q, 64 q + 64) of SiLU(P[row] + Q[col] + w_r r + w_d d0) as three bf16 planes, in two batches of 64 rows
-// (8 gathered float4 per thread and batch: with the 128 accumulators and the weight fragments a whole tile's 16 would spill).  The
-// gather of a batch and its use are separate calls so that a batch can be in flight during the GEMM over the previous quarter.
-// Rows beyond the tile's end repeat its last row (finite values in rows nobody reads; no divergent code).  Thread -> 16 bytes of a quarter
-// row (16 lanes per row, 4 consecutive rows per wave instruction: edges of one receiver share their P row's cache lines).
-struct Gath { float4 p[4], q[4]; };
-template <int NMT>
-__device__ __forceinline__ void gather_half(const E128Lds& L, const int tid, const int q, const int half, const int ne, const float* __restrict__ P,
-                                            const float* __restrict__ Q, Gath& g) {
-    const int c4 = tid & 15, rsub = tid >> 4;
-    const unsigned cofs = (unsigned)(q * KQ + 4 * c4) * 4u;
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps)
-        if (half * 64 + ps * 16 < 32 * NMT) {
-            const int e = min(half * 64 + ps * 16 + rsub, ne - 1);
-            const int2 rc = *reinterpret_cast<const int2*>(&L.e[e]);
-            g.p[ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(P) + ((unsigned)rc.x * (unsigned)(H * 4) + cofs));
-            g.q[ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Q) + ((unsigned)rc.y * (unsigned)(H * 4) + cofs));
-        }
-}
-template <int NMT>
-__device__ __forceinline__ void store_half(E128Lds& L, const int tid, const int q, const int half, const int ne, const Gath& g) {
-    const int c4 = tid & 15, rsub = tid >> 4;
-    const int col = q * KQ + 4 * c4;
-    const float4 wr4 = *reinterpret_cast<const float4*>(L.wrd + col), wd4 = *reinterpret_cast<const float4*>(L.wrd + H + col);
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps)
-        if (half * 64 + ps * 16 < 32 * NMT) {
-            const int e = half * 64 + ps * 16 + rsub;
-            const float2 rd = *reinterpret_cast<const float2*>(&L.e[min(e, ne - 1)].r);
-            const float r = rd.x, d0 = rd.y;
-            const float4 a = make_float4(silu_f(g.p[ps].x + g.q[ps].x + wr4.x * r + wd4.x * d0), silu_f(g.p[ps].y + g.q[ps].y + wr4.y * r + wd4.y * d0),
-                                         silu_f(g.p[ps].z + g.q[ps].z + wr4.z * r + wd4.z * d0), silu_f(g.p[ps].w + g.q[ps].w + wr4.w * r + wd4.w * d0));
-            split_store4(L.planes, PE, e * PLDA + 4 * c4, a);
-        }
-}
-
-// ---- one quarter of the tile product: acc[m][n] += planes(rows 32 m .., k-blocks 4 q .. 4 q + 3) x W^T for m < NMT.
-// bs[0] holds the weight fragments of k-block 4 q on entry and of k-block 4 q + 4 on exit (q < 3).  One load pinned beside every pair of MFMAs; per accumulator the six products of a k-block keep the
-// order of cmdgen_split.h (small terms first).  wb: the wave's first 32-column tile, k-block 0, this lane.
-template <int NMT>
-__device__ __forceinline__ void gemm_quarter(const unsigned short* planes, const int lane, const int q, const sbf16x8* __restrict__ wb,
-                                             sf32x16 (&acc)[NMT][2], sbf16x8 (&bs)[2][2][3]) {
-    const unsigned short* ap = planes + (lane & 31) * PLDA + (lane >> 5) * 8;
-    sbf16x8 a[2][3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) a[0][s] = *reinterpret_cast<const sbf16x8*>(ap + s * PE);
-#pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {
-        const sbf16x8* qn = wb + (unsigned)((4 * q + kq + 1) & 15) * 192u;      // next k-block (wave-uniform)
-        constexpr int BPG = NMT == 1 ? 6 : 3;                                   // weight loads per row group: all of them early in the k-block
-#pragma unroll
-        for (int m = 0; m < NMT; ++m) {
-            const int it = kq * NMT + m, cs = it & 1, nx = cs ^ 1, bc = kq & 1, bn = bc ^ 1;
-            const bool more_a = (m + 1 < NMT) || (kq < 3);
-            const bool more_b = kq < 3 || q < 3;                                // wave-uniform: not past the tile's last k-block
-            const unsigned short* an = ap + ((m + 1 < NMT) ? (m + 1) * 32 * PLDA + kq * 16 : (kq + 1) * 16);
-            const int b0 = m * BPG;                                             // first weight load of this group (of 6: (n, s) = (i & 1, i >> 1))
-#define E_MF(N, AI, BI) acc[m][N] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][AI], bs[bc][N][BI], acc[m][N], 0, 0, 0);
-#define E_LA(S) if (more_a) a[nx][S] = *reinterpret_cast<const sbf16x8*>(an + (S) * PE);
-#define E_LB(I) if ((I) < 6 && (I) >= b0 && (I) < b0 + BPG && more_b) bs[bn][(I) & 1][(I) >> 1] = qn[(unsigned)((I) & 1) * NS + (unsigned)((I) >> 1) * 64u];
-            E_LA(2) E_MF(0, 2, 0) E_MF(1, 2, 0) __builtin_amdgcn_sched_barrier(0);
-            E_LA(1) E_MF(0, 1, 1) E_MF(1, 1, 1) __builtin_amdgcn_sched_barrier(0);
-            E_LA(0) E_MF(0, 0, 2) E_MF(1, 0, 2) __builtin_amdgcn_sched_barrier(0);
-            E_LB(b0) E_LB(b0 + 3) E_MF(0, 1, 0) E_MF(1, 1, 0) __builtin_amdgcn_sched_barrier(0);
-            E_LB(b0 + 1) E_LB(b0 + 4) E_MF(0, 0, 1) E_MF(1, 0, 1) __builtin_amdgcn_sched_barrier(0);
-            E_LB(b0 + 2) E_LB(b0 + 5) E_MF(0, 0, 0) E_MF(1, 0, 0) __builtin_amdgcn_sched_barrier(0);
-#undef E_MF
-#undef E_LA
-#undef E_LB
-        }
-    }
-}
-
-#define E_SWZ(V, D) __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(V), ((D) << 10) | 0x1f))     // value of lane ^ D (D < 32)
-
-// Sum over the 32 lanes of a half wave of 32 values per lane, by value halving: after the five exchanges lane l of a half holds the
-// complete sum of value l & 31 (31 exchanges instead of 160 for a butterfly on every value).
-__device__ __forceinline__ float reduce32_over32(float (&v)[32], const int lane) {
-#define E_STAGE(N, D) {                                                                                           \
-        const bool up = (lane & (D)) != 0;                                                                        \
-        _Pragma("unroll") for (int i = 0; i < (N) / 2; ++i) {                                                     \
-            const float keep = up ? v[i + (N) / 2] : v[i], send = up ? v[i] : v[i + (N) / 2];                     \
-            v[i] = keep + E_SWZ(send, D); } }
-    E_STAGE(32, 16) E_STAGE(16, 8) E_STAGE(8, 4) E_STAGE(4, 2) E_STAGE(2, 1)
-#undef E_STAGE
-    return v[0];
-}
-
-// accumulator register r of row tile m -> row of the tile
-#define E_ROW(M, R) ((M) * 32 + ((R) & 3) + 8 * ((R) >> 2) + 4 * (lane >> 5))
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// One tile of NMT x 32 rows (ne of them listed) after its index phase: K in four build -> GEMM passes, then the epilogue in registers.
-struct TileCtx {
-    const float* P; const float* Q; const sbf16x8* wb;
-    float bias0, bias1, hv0, hv1, ba0;
-    int colw, layer;
-};
-template <bool COORD, int NMT>
-__device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, const Work& w, const Dims& d, const TileCtx& c, const int ne,
-                                             sbf16x8 (&bs)[2][2][3], unsigned long long (&st_)[8], unsigned long long& st_t) {
-    int tid = threadIdx.x & 255;            // thread of the tile's four waves (the phase-locked driver runs two tiles per workgroup)
-    asm volatile("" : "+v"(tid));           // opaque: per-lane addresses derived from it are recomputed per tile instead of being hoisted out of the tile loop and spilled
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float* __restrict__ P = c.P; const float* __restrict__ Q = c.Q; const sbf16x8* __restrict__ wb = c.wb;
-    const float bias0 = c.bias0, bias1 = c.bias1, hv0 = c.hv0, hv1 = c.hv1, ba0 = c.ba0;
-    const int colw = c.colw, layer = c.layer;
-#if CMDGEN_STAMPS == 6
-#define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
-    sf32x16 acc[NMT][2];                                                                // start from the bias of the layer (b2 / b7)
-#pragma unroll
-    for (int m = 0; m < NMT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[m][0][r] = bias0; acc[m][1][r] = bias1; }
-    // ---------------- four build -> GEMM passes over a quarter of K each.  (Gathering the next quarter's first rows BEFORE the GEMM over
-    // this one was measured and lost: the 32 extra live registers spill around the GEMM and its waits cover the gather; profiles/r04_c.)
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        Gath g0;
-        gather_half<NMT>(L, tid, q, 0, ne, P, Q, g0);
-        if constexpr (NMT > 2) {
-            Gath g1;
-            gather_half<NMT>(L, tid, q, 1, ne, P, Q, g1);          // both batches in flight, the second lands while the first is consumed
-            store_half<NMT>(L, tid, q, 0, ne, g0);
-            store_half<NMT>(L, tid, q, 1, ne, g1);
-        } else {
-            store_half<NMT>(L, tid, q, 0, ne, g0);
-        }
-        STAMP(6);
-        lds_barrier();
-        STAMP(1);
-        __builtin_amdgcn_s_setprio(CMDGEN_E128_GPRIO);
-        gemm_quarter<NMT>(L.planes, lane, q, wb, acc, bs);
-        __builtin_amdgcn_s_setprio(CMDGEN_E128_VPRIO);
-        STAMP(7);
-        lds_barrier();                                                                  // every wave is done reading the planes
-        STAMP(2);
-    }
-    // ---------------- epilogue in registers: SiLU, the row dot (attention logit / coord_mlp.4)
-#pragma unroll
-    for (int mh = 0; mh < (NMT + 1) / 2; ++mh) {          // two row tiles (32 values per lane) at a time
-        float pl[32];
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = 2 * mh + mm;
-                float dotp = 0.f;
-                if (m < NMT) {
-                    const float v0 = silu_f(acc[m < NMT ? m : 0][0][r]), v1 = silu_f(acc[m < NMT ? m : 0][1][r]);
-                    acc[m < NMT ? m : 0][0][r] = v0; acc[m < NMT ? m : 0][1][r] = v1;
-                    dotp = v0 * hv0 + v1 * hv1;
-                }
-                pl[mm * 16 + r] = dotp;
-            }
-        const float o = reduce32_over32(pl, lane);
-        // value 16 mm + r = lane & 31
-        const int l5 = lane & 31;
-        L.part[wave][E_ROW(2 * mh + (l5 >> 4), l5 & 15)] = o;
-    }
-    lds_barrier();
-    STAMP(3);
-    // every wave forms the gates of all rows for itself (two rows per lane) and keeps them in its own LDS strip: no barrier before their use
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int e = 64 * u + lane;
-        if (e < 32 * NMT) {
-            const float s = (L.part[0][e] + L.part[1][e]) + (L.part[2][e] + L.part[3][e]);
-            L.gw[wave][e] = COORD ? (d.use_tanh ? tanhf(s) * d.coords_range : s) : (d.attention ? sigmoid_f(s + ba0) : 1.0f);
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    STAMP(5);
-    if constexpr (COORD) {
-        // ordered segment sums of the three components: one thread per (segment, component), rows in list order
-        const int nseg = L.meta[0];
-        for (int i = tid; i < 3 * nseg; i += 256) {
-            const int sgi = i / 3, comp = i - 3 * sgi;
-            const int rb = L.segstart[sgi], re = L.segstart[sgi + 1];
-            float sum = 0.f;
-            for (int e = rb; e < re; ++e) sum += L.cd[e][comp] * L.gw[wave][e];     // trans = coord_diff * tanh(phi) * range, summed in list order (egnn_new.py:94-96)
-            float* dst = reinterpret_cast<float*>(w.ACC + (size_t)layer * lay.Nm + L.segrow[sgi]) + comp;
-            if (sgi == 0 || sgi == nseg - 1) atomicAdd(dst, sum); else *dst = sum;      // a receiver may continue in the neighbouring tiles; ACC is zero before the launch
-        }
-    } else {
-        // gated messages and their ordered segment sum by receiver, in registers.  v_permlane32_swap_b32 on the register pair (column tile 0,
-        // column tile 1) of an accumulator row group turns the 32 x 32 layout (lane half = rows +0 / +4) into one where EVERY lane of a
-        // register holds the same row (lane = column 64 wave + lane): the tile's rows are then visited in list order by wave-uniform code, a
-        // receiver's sum is a chain of 64-lane FMAs (gate folded in) in ascending sender order like the reference's CPU scatter_add_
-        // (egnn_new.py:283), and a finished receiver leaves as one 256-byte row segment.  Segment starts are a 128-bit scalar mask.
-        const int nseg = L.meta[0];
-        const unsigned sm[4] = {(unsigned)__builtin_amdgcn_readfirstlane(L.smask[0]), (unsigned)__builtin_amdgcn_readfirstlane(L.smask[1]),
-                                (unsigned)__builtin_amdgcn_readfirstlane(L.smask[2]), (unsigned)__builtin_amdgcn_readfirstlane(L.smask[3])};
-        const int segrow_v = L.segrow[lane & 31];                       // receiver of segment (lane & 31); read per finished segment with v_readlane
-        float* const aggc = w.agg + 64 * wave + lane;
-        float sum = 0.f;
-        int sg = 0;                                                      // wave-uniform: the segment being summed
-        auto flush = [&]() {
-            if (sg < nseg) {
-                float* dst = aggc + (size_t)__builtin_amdgcn_readlane(segrow_v, sg) * H;
-                if (sg == 0 || sg == nseg - 1) atomicAdd(dst, sum);     // the receiver may continue in the neighbouring tiles
-                else *dst = sum;                                         // agg is zero between blocks
-            }
-            ++sg; sum = 0.f;
-        };
-#pragma unroll
-        for (int m = 0; m < NMT; ++m)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x[4], y[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-                    const u2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[m][0][4 * j + i]), __float_as_uint(acc[m][1][4 * j + i]), false, false);
-                    x[i] = __uint_as_float(sw[0]); y[i] = __uint_as_float(sw[1]);     // rows 32 m + 8 j + i and + 4 + i, all 64 columns of the wave
-                }
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int base = 32 * m + 8 * j + 4 * hh;
-                    const float4 g4 = *reinterpret_cast<const float4*>(&L.gw[wave][base]);              // one address per wave: broadcast
-                    unsigned bits = (sm[base >> 5] >> (base & 31)) & 0xfu;
-                    if (base == 0) bits &= ~1u;                                                    // row 0 opens segment 0: nothing to flush
-                    const float* v = hh ? y : x;
-                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
-                    if (bits == 0u) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) sum = __fmaf_rn(v[i], gg[i], sum);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (bits & (1u << i)) flush();
-                            sum = __fmaf_rn(v[i], gg[i], sum);
-                        }
-                    }
-                }
-            }
-        flush();                                                         // the tile's last segment when it ends with the tile's last row
-    }
-#undef STAMP
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// What both drivers share: the per-kernel constants of a thread, the walk over a workgroup's (or half workgroup's) chunks and tiles, and the
-// index phase of a tile.
-template <bool COORD>
-struct EdgeSrc {
-    const float* P; const float* Q; const int* rowp; const int* colp; const float* d0p;
-    __device__ __forceinline__ EdgeSrc(const Work& w) : P(COORD ? w.Pc : w.P), Q(COORD ? w.Qc : w.Q), rowp(COORD ? w.crow : w.erow), colp(COORD ? w.ccol : w.ecol), d0p(COORD ? w.cd0 : w.ed0) {}
-};
-
-// the k-th chunk of virtual workgroup vb of nb (XCD-aware: workgroups with equal index % 8 share an L2 and get one contiguous range of chunks)
-__device__ __forceinline__ int xcd_chunk_v(int vb, int nb, int k, int nch) {
-    const int g = vb & 7, wg_in_g = vb >> 3, wgs_in_g = (nb - g + 7) >> 3, per_g = (nch + 7) >> 3;
-    const int t = wg_in_g + k * wgs_in_g;
-    if (wgs_in_g == 0 || t >= per_g) return -1;
-    const int c = g * per_g + t;
-    return c < nch ? c : -1;
-}
-
-// Tile walk: chunk size CH, nch chunks; a chunk is cut into equal tiles of 32 .. MT rows (trows).  All values wave-uniform.
-struct TileWalk {
-    int vb, nb, E, CH, nch;          // the list and its cut
-    int kc, cbeg, cend, trows, e0;   // the chunk in work and the next tile's first row; cbeg < 0: nothing left
-    __device__ __forceinline__ void load_chunk() {
-        const int c = xcd_chunk_v(vb, nb, kc, nch);
-        if (c < 0) { cbeg = -1; cend = -1; trows = 32; e0 = 0; return; }
-        cbeg = c * CH; cend = min(E, cbeg + CH);
-        const int ntile = (cend - cbeg + MT - 1) / MT;
-        trows = (((cend - cbeg + ntile - 1) / ntile) + 31) & ~31;        // equal tiles, a multiple of 32 rows, <= 128
-        e0 = cbeg;
-    }
-    __device__ __forceinline__ void init(int vb_, int nb_, int E_, int max_n) {
-        vb = vb_; nb = nb_; E = E_;
-        CH = (((E + nb - 1) / nb) + 31) & ~31;
-        // a chunk holds more rows than any receiver has edges: the receiver's rows then lie in at most two chunks, i.e. its sum has at most two
-        // float-atomic partials, which commute - results are reproducible bit for bit.  Dense samples (full-atom pockets: ~60 edges per phar point
-        // at the pocket centre) need a full tile for that; C-alpha samples (< 60 nodes each) half of one.  Short lists just use fewer workgroups.
-        const int minch = max_n > 128 ? MTL : 64;
-        if (CH < minch) CH = minch;
-        nch = (E + CH - 1) / CH;
-        kc = 0; load_chunk();
-    }
-    __device__ __forceinline__ bool valid() const { return cbeg >= 0; }
-    __device__ __forceinline__ int ne_full() const { return min(trows, cend - e0); }
-    // after a tile of ne rows: is there another tile for this walker?  (does not advance)
-    __device__ __forceinline__ bool more_after(int ne) const { return e0 + ne < cend || xcd_chunk_v(vb, nb, kc + 1, nch) >= 0; }
-    __device__ __forceinline__ void advance(int ne) { e0 += ne; if (e0 >= cend) { ++kc; load_chunk(); } }
-};
-
-// (row, col, d0, level) of a tile's rows, kept one tile ahead by wave 0: two rows per lane
-struct RowPref { int nrow[2], ncol[2], nhop[2]; float nd0[2]; int nx_e0; };
-template <bool COORD>
-__device__ __forceinline__ void pref_fetch(RowPref& pf, const EdgeSrc<COORD>& es, const Work& w, const int lane, const int live_thr, int e0, int ne) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        pf.nrow[u] = -1; pf.ncol[u] = -1; pf.nd0[u] = 0.f; pf.nhop[u] = 255;
-        if (64 * u + lane < ne) {
-            const int e = e0 + 64 * u + lane;
-            pf.nrow[u] = es.rowp[e]; pf.ncol[u] = es.colp[e]; pf.nd0[u] = es.d0p[e];
-            if (!COORD && live_thr) pf.nhop[u] = w.ehop[e];
-        }
-    }
-    pf.nx_e0 = e0;
-}
-
-// ---------------- index phase of the tile at e0 (wave 0 of the tile's four waves): positions, radial, segments.  Writes L.e / cd / seg /
-// segrow / segstart / smask / meta; requests the rows of the tile after it.
-template <bool COORD>
-__device__ __forceinline__ void index_phase(E128Lds& L, const Layout& lay, const Work& w, const Dims& d, const EdgeSrc<COORD>& es, RowPref& pf, const TileWalk& tw,
-                                            const int lane, const int layer, const int live_thr) {
-    const int e0 = tw.e0, ne_full = tw.ne_full(), cend = tw.cend, trows = tw.trows;
-    if (pf.nx_e0 != e0) pref_fetch<COORD>(pf, es, w, lane, live_thr, e0, ne_full);      // first tile of the chunk, or the previous tile was cut short (below)
-    int row[2], col[2], hop[2]; float d0[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) { row[u] = pf.nrow[u]; col[u] = pf.ncol[u]; hop[u] = pf.nhop[u]; d0[u] = pf.nd0[u]; }
-    if (e0 + ne_full < cend) pref_fetch<COORD>(pf, es, w, lane, live_thr, e0 + ne_full, min(trows, cend - e0 - ne_full));
-    // segments: runs of equal receivers (the lists are sorted by receiver)
-    const int prev0 = __shfl_up(row[0], 1);
-    const bool s0 = lane < ne_full && (lane == 0 || row[0] != prev0);
-    const int last0 = __shfl(row[0], 63);
-    const int prev1 = __shfl_up(row[1], 1);
-    const bool s1 = 64 + lane < ne_full && row[1] != (lane == 0 ? last0 : prev1);
-    const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
-    const unsigned long long below = (2ull << lane) - 1ull;                        // lanes <= this one
-    const int n0 = __popcll(m0);
-    const int sg0 = __popcll(m0 & below) - 1, sg1 = n0 + __popcll(m1 & below) - 1;
-    int ne = ne_full, ns = n0 + __popcll(m1);
-    if (!COORD && ns > 32) {
-        // the message kernel's epilogue keeps 32 receivers per tile: cut the tile where the 33rd begins (the next tile starts there)
-        ne = __popcll(__ballot(lane < ne_full && sg0 < 32)) + __popcll(__ballot(64 + lane < ne_full && sg1 < 32));
-        ns = 32;
-    }
-    bool live = true;
-    if (!COORD && live_thr) live = (__ballot(lane < ne && hop[0] <= live_thr) | __ballot(64 + lane < ne && hop[1] <= live_thr)) != 0ull;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int t = 64 * u + lane;
-        float r = 0.f;
-        if (t < ne && live) {
-            if (COORD) {
-                const float4 pi = pos_mat(lay, w, row[u], layer), pj = pos_mat(lay, w, col[u], layer);
-                float cx = pi.x - pj.x, cy = pi.y - pj.y, cz = pi.z - pj.z;
-                r = cx * cx + cy * cy + cz * cz;
-                const float den = sqrtf(r + 1e-8f) + d.norm_constant;              // coord2diff, egnn_new.py:265-271
-                L.cd[t][0] = cx / den; L.cd[t][1] = cy / den; L.cd[t][2] = cz / den;
-            } else {
-                // block 0: the radial IS the d0 of the graph pass (same dist2, same operands); later blocks: lazily updated positions
-                r = layer == 0 ? d0[u] : dist2(pos_lazy(lay, w, d, row[u], layer), pos_lazy(lay, w, d, col[u], layer));
-            }
-        }
-        EdgeRec er; er.row = row[u]; er.col = col[u]; er.r = r; er.d0 = d0[u];
-        L.e[t] = er;
-    }
-    L.seg[lane] = (unsigned char)(lane < ne ? sg0 : 255);
-    L.seg[64 + lane] = (unsigned char)(64 + lane < ne ? sg1 : 255);
-    if (s0 && lane < ne) { L.segrow[sg0] = row[0]; L.segstart[sg0] = lane; }
-    if (s1 && 64 + lane < ne) { L.segrow[sg1] = row[1]; L.segstart[sg1] = 64 + lane; }
-    if (lane == 0) {
-        L.meta[0] = ns; L.meta[1] = live ? 1 : 0; L.meta[2] = ne; L.segstart[ns] = ne;
-        const unsigned long long k0 = m0 | (ne < 64 ? 1ull << ne : 0ull), k1 = m1 | (ne >= 64 && ne < 128 ? 1ull << (ne - 64) : 0ull);
-        L.smask[0] = (int)(unsigned)k0; L.smask[1] = (int)(unsigned)(k0 >> 32); L.smask[2] = (int)(unsigned)k1; L.smask[3] = (int)(unsigned)(k1 >> 32);
-    }
-}
-
-template <bool COORD>
-__device__ __forceinline__ void tile_dispatch(E128Lds& L, const Layout& lay, const Work& w, const Dims& d, const TileCtx& tc, const int ne, sbf16x8 (&bs)[2][2][3],
-                                              unsigned long long (&st_)[8], unsigned long long& st_t) {
-    switch ((ne + 31) >> 5) {
-        case 4: if constexpr (MT >= 128) tile_compute<COORD, 4>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
-        case 3: if constexpr (MT >= 96) tile_compute<COORD, 3>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
-        case 2: tile_compute<COORD, 2>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
-        default: tile_compute<COORD, 1>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
-    }
-}
-constexpr int TILE_BARRIERS = 9;        // barriers inside tile_compute (two per quarter, one after the row dots)
-
-template <bool COORD>
-__device__ __forceinline__ TileCtx make_ctx(const LayerW& lw, const EdgeSrc<COORD>& es, const int wave, const int lane, const int layer) {
-    const WPack& W = COORD ? lw.W7 : lw.W2;
-    const float* bvec = COORD ? lw.b7 : lw.b2;
-    const float* hvec = COORD ? lw.w5 : lw.wa;                                   // the row dot's weight vector
-    TileCtx tc;
-    tc.colw = 64 * wave + (lane & 31);
-    tc.P = es.P; tc.Q = es.Q; tc.layer = layer;
-    tc.bias0 = bvec[tc.colw]; tc.bias1 = bvec[tc.colw + 32]; tc.hv0 = hvec[tc.colw]; tc.hv1 = hvec[tc.colw + 32];
-    tc.ba0 = COORD ? 0.f : lw.ba[0];
-    tc.wb = reinterpret_cast<const sbf16x8*>(W.ws) + (size_t)(2 * wave) * 16 * 192 + lane;
-    return tc;
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// Driver 1: two free-running 256-thread workgroups per CU, one chunk walk each.
-template <bool COORD>
-__global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, LayerW lw, int layer, int live_thr) {
-    __shared__ E128Lds L;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const EdgeSrc<COORD> es(w);
-    L.wrd[tid] = (COORD ? lw.wr_c : lw.wr_e)[tid]; L.wrd[H + tid] = (COORD ? lw.wd_c : lw.wd_e)[tid];       // visible after the first tile's barrier
-    const TileCtx tc = make_ctx<COORD>(lw, es, wave, lane, layer);
-    TileWalk tw; tw.init((int)blockIdx.x, (int)gridDim.x, w.totals[COORD ? 1 : 0], lay.max_n);
-    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;       // diagnostic builds (-DCMDGEN_STAMPS=6): summed phase cycles
-#if CMDGEN_STAMPS == 6
-    st_t = __builtin_amdgcn_s_memtime();
-    const unsigned long long st_begin = st_t; int st_tiles = 0;
-#define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
-    RowPref pf; pf.nx_e0 = -1;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) { pf.nrow[u] = -1; pf.ncol[u] = -1; pf.nhop[u] = 255; pf.nd0[u] = 0.f; }
-    while (tw.valid()) {
-        sbf16x8 bs[2][2][3];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) bs[0][i & 1][i >> 1] = tc.wb[(unsigned)(i & 1) * NS + (unsigned)(i >> 1) * 64u];     // k-block 0, in flight during the index phase
-        if (wave == 0) index_phase<COORD>(L, lay, w, d, es, pf, tw, lane, layer, live_thr);
-        lds_barrier();
-        STAMP(0);
-        const int ne = L.meta[2];
-        if (!L.meta[1]) {                                                                   // dead tile (see edge_msg_body, kernels_egnn.hip)
-            if (tid == 0) atomicAdd(&w.counters[6], (unsigned long long)ne);
-        } else {
-            tile_dispatch<COORD>(L, lay, w, d, tc, ne, bs, st_, st_t);
-        }
-        lds_barrier();                                                                      // the next index phase rewrites e / seg / meta
-        STAMP(4);
-        tw.advance(ne);
-#if CMDGEN_STAMPS == 6
-        ++st_tiles;
-#endif
-    }
-#if CMDGEN_STAMPS == 6
-    if (lane == 0 && (blockIdx.x & 3) == 0 && st_tiles > 0 && COORD == (CMDGEN_STAMP_COORD != 0)) {
-        for (int i = 0; i < 8; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
-        atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
-        atomicAdd(&w.dbg[40], 1ull);
-        if (wave == 0) atomicAdd(&w.dbg[41], (unsigned long long)st_tiles);
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// Driver 2 (round 5): ONE 512-thread workgroup per CU whose two halves (waves 0-3, waves 4-7: a SIMD hosts wave i and wave i + 4) run the same
-// tile program on two chunk walks, PHASE-LOCKED one barrier apart.  s_barrier counts all eight waves, so with the second half started one
-// barrier late every barrier is a rendezvous of phase k of one half with phase k - 1 of the other: a half's GEMM quarter (the phases between
-// an odd and the following even barrier of its tile) always runs beside a build or epilogue phase of its partner, never beside the partner's
-// GEMM - the matrix pipe of a SIMD has one user at a time and that user's partner is issuing vector work.  Free-running workgroups (driver 1)
-// drift into lockstep instead: both in their GEMMs (sharing the pipe), then both in their builds (pipe idle); profiles/r04_l, r05_b.
-// Both halves execute the same number of tile slots (a half without a tile runs the slot's barriers only); whether another slot follows is
-// agreed through two LDS flags that each half writes in its index phase.  No wave ever waits on anything but s_barrier.
-template <bool COORD>
-__global__ __launch_bounds__(512, 2) void k_edge128pp(Layout lay, Work w, Dims d, LayerW lw, int layer, int live_thr) {
-    __shared__ E128Lds LL[2];
-    __shared__ int more_flag[2][2];                                                         // [slot parity][half]: the half has a tile in the NEXT slot
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int half = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), htid = tid & 255;
-    E128Lds& L = LL[half];
-    const EdgeSrc<COORD> es(w);
-    L.wrd[htid] = (COORD ? lw.wr_c : lw.wr_e)[htid]; L.wrd[H + htid] = (COORD ? lw.wd_c : lw.wd_e)[htid];   // visible after the first slot's first barrier
-    const TileCtx tc = make_ctx<COORD>(lw, es, wave, lane, layer);
-    const int E = w.totals[COORD ? 1 : 0];
-    TileWalk tw; tw.init((int)blockIdx.x + half * (int)gridDim.x, 2 * (int)gridDim.x, E, lay.max_n);        // (gridDim % 8 == 0: both halves' chunks lie in this XCD's range)
-    TileWalk other; other.init((int)blockIdx.x + (1 - half) * (int)gridDim.x, 2 * (int)gridDim.x, E, lay.max_n);
-    bool cont = tw.valid() || other.valid();                                                // wave-uniform and equal in all eight waves
-    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
-#if CMDGEN_STAMPS == 6
-    st_t = __builtin_amdgcn_s_memtime();
-    const unsigned long long st_begin = st_t; int st_tiles = 0;
-#endif
-    RowPref pf; pf.nx_e0 = -1;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) { pf.nrow[u] = -1; pf.ncol[u] = -1; pf.nhop[u] = 255; pf.nd0[u] = 0.f; }
-    if (half == 1) lds_barrier();                                                           // the second half runs one phase behind
-    for (int slot = 0; cont; ++slot) {
-        const bool mine = tw.valid();
-        sbf16x8 bs[2][2][3];
-        if (mine) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) bs[0][i & 1][i >> 1] = tc.wb[(unsigned)(i & 1) * NS + (unsigned)(i >> 1) * 64u];
-            if (wave == 0) {
-                index_phase<COORD>(L, lay, w, d, es, pf, tw, lane, layer, live_thr);
-                if (lane == 0) more_flag[slot & 1][half] = tw.more_after(L.meta[2]) ? 1 : 0;   // (lane 0 wrote meta[2] itself)
-            }
-        } else if (htid == 0) {
-            more_flag[slot & 1][half] = 0;
-        }
-        lds_barrier();
-        STAMP(0);
-        int ne = 0;
-        bool live = false;
-        if (mine) { ne = L.meta[2]; live = L.meta[1] != 0; }
-        if (live) {
-            tile_dispatch<COORD>(L, lay, w, d, tc, ne, bs, st_, st_t);
-        } else {
-            if (mine && htid == 0) atomicAdd(&w.counters[6], (unsigned long long)ne);      // dead tile
-#pragma unroll 1
-            for (int i = 0; i < TILE_BARRIERS; ++i) lds_barrier();
-        }
-        lds_barrier();
-        STAMP(4);
-        if (mine) {
-            tw.advance(ne);
-#if CMDGEN_STAMPS == 6
-            ++st_tiles;
-#endif
-        }
-        // the partner wrote its flag of this slot at least one barrier ago (it is at most one phase away), and rewrites this parity two slots on
-        cont = (more_flag[slot & 1][0] | more_flag[slot & 1][1]) != 0;
-    }
-    if (half == 0) lds_barrier();
-#if CMDGEN_STAMPS == 6
-    if (lane == 0 && (blockIdx.x & 1) == 0 && half == 0 && st_tiles > 0 && COORD == (CMDGEN_STAMP_COORD != 0)) {
-        for (int i = 0; i < 8; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
-        atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
-        atomicAdd(&w.dbg[40], 1ull);
-        if (wave == 0) atomicAdd(&w.dbg[41], (unsigned long long)st_tiles);
-    }
-#endif
-#undef STAMP
-}
-
-}  // namespace
 
 // launchers: true when the 128-row kernels took the launch (H = 256, split engine, sampler)
+#define E128_LAUNCH(NSP, COORD_, LIVE)                                                                                                              \
+    do {                                                                                                                                            \
+        if (a.e128_pp) {                     /* the phase-locked driver: one 512-thread workgroup per CU */                                         \
+            if (a.pe_start) hipExtLaunchKernelGGL(NSP::k_edge128pp<COORD_>, dim3(a.n_cus), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE); \
+            else hipLaunchKernelGGL(NSP::k_edge128pp<COORD_>, dim3(a.n_cus), dim3(512), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE);    \
+        } else {                                                                                                                                    \
+            const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 2 ? a.e128_wgs : 2) * a.n_cus;                                                       \
+            if (a.pe_start) hipExtLaunchKernelGGL(NSP::k_edge128<COORD_>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE); \
+            else hipLaunchKernelGGL(NSP::k_edge128<COORD_>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE);         \
+        }                                                                                                                                           \
+    } while (0)
 bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.edge_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[unit_of(a, l)].W2.ws) return false;
-    if (a.e128_pp) {                     // the phase-locked driver: one 512-thread workgroup per CU
-        if (a.pe_start) hipExtLaunchKernelGGL(k_edge128pp<false>, dim3(a.n_cus), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.live_thr);
-        else hipLaunchKernelGGL(k_edge128pp<false>, dim3(a.n_cus), dim3(512), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.live_thr);
-        return true;
-    }
-    const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 2 ? a.e128_wgs : 2) * a.n_cus;
-    if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.live_thr);
-    else hipLaunchKernelGGL(k_edge128<false>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.live_thr);
+    const WPack& W = a.layers[unit_of(a, l)].W2;
+    if (a.edge_mt != 128 || a.d.H != 256 || !a.split || a.save || !W.ws) return false;
+    if (a.e128_f16 && W.wh) E128_LAUNCH(e128_half, false, a.live_thr); else E128_LAUNCH(e128_bf3, false, a.live_thr);
     return true;
 }
 bool cmdgen_launch_coord128(const EvalLaunch& a, int l, hipStream_t s) {
-    if (a.coord_mt != 128 || a.d.H != 256 || !a.split || a.save || !a.layers[unit_of(a, l)].W7.ws) return false;
-    if (a.e128_pp) {
-        if (a.pe_start) hipExtLaunchKernelGGL(k_edge128pp<true>, dim3(a.n_cus), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, 0);
-        else hipLaunchKernelGGL(k_edge128pp<true>, dim3(a.n_cus), dim3(512), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, 0);
-        return true;
-    }
-    const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 2 ? a.e128_wgs : 2) * a.n_cus;
-    if (a.pe_start) hipExtLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, 0);
-    else hipLaunchKernelGGL(k_edge128<true>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, 0);
+    const WPack& W = a.layers[unit_of(a, l)].W7;
+    if (a.coord_mt != 128 || a.d.H != 256 || !a.split || a.save || !W.ws) return false;
+    if (a.e128_f16 && W.wh) E128_LAUNCH(e128_half, true, 0); else E128_LAUNCH(e128_bf3, true, 0);
     return true;
 }
+#undef E128_LAUNCH
