@@ -625,7 +625,11 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     a.edge_fullk = (sp256 && opt_of(h, "edge_fullk", 1) != 0) ? 1 : 0;
     a.e128_wgs = (int)opt_of(h, "e128_wgs_per_cu", 2);
     a.e128_pp = (int)opt_of(h, "e128_pp", 0);
-    a.e128_f16 = (int)opt_of(h, "e128_f16", 1);
+    {   // the half engine's operands end at 65504: by default only where the radial features are bounded by a cutoff (every shipped config);
+        // 2 forces it, 0 keeps the three-piece bf16 split everywhere
+        const int he = (int)opt_of(h, "half_engine", 1);
+        a.half_engine = he == 2 || (he == 1 && h->dims.cutoff2 >= 0.f) ? 1 : 0;
+    }
     a.write_embed = opt_of(h, "write_embed", 1) != 0 ? 1 : 0;
     {   // k_node64 (kernels_node64.hip: 64-row node tiles, the A operand as producer-side bf16 planes, one workgroup per CU) against
         // k_node<H, 32> (register split, two workgroups per CU).  Per launch the 64-row kernel takes ~0.89 of a co-resident pair of
@@ -665,7 +669,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
 // options
 // ---------------------------------------------------------------------------------
 static const char* const kOptionKeys[] = {
-    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "e128_pp", "e128_f16", "edge_fullk", "node64", "node16_split", "node16w",
+    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "e128_pp", "half_engine", "edge_fullk", "node64", "node16_split", "node16w",
     "dead_skip", "write_embed", "fused_step", "pocket_cache", "graph_steps",
     "wgrad_split", "wgrad_tile", "wgrad_split_wgs128", "wgrad_split_wgs64", "wgrad_wgs", "dgrad_mt", "dgrad_tail"};
 
@@ -1314,6 +1318,7 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "edge_grid") *value = a.edge_grid;
     else if (k == "coord_grid") *value = a.coord_grid;
     else if (k == "gemm_split") *value = a.split;
+    else if (k == "half_engine") *value = a.split ? a.half_engine : 0;
     else if (k == "node16_split") *value = a.split16;
     else if (k == "node64") *value = a.node64;
     else if (k == "node16w") *value = a.node16w;

@@ -232,7 +232,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     int write_embed = 1;        // 1: pass 2 of the radius graph and k_embed share a launch (k_write_embed) where both fit (option "write_embed")
     int e128_wgs = 2;           // workgroups per CU of the 128-row edge kernels (kernels_edge128.hip)
-    int e128_f16 = 1;           // 1: the 128-row edge kernels multiply on the HALF engine (two fp16 pieces per operand, three MFMAs per product; cmdgen_split.h)
+    int half_engine = 1;        // 1: split-engine kernels that have a HALF form (two fp16 pieces per operand, three MFMAs per product; cmdgen_split.h) use it
     int e128_pp = 0;            // 1: the 128-row edge kernels run as ONE 512-thread workgroup per CU whose two halves are phase-locked one barrier apart (k_edge128pp)
 };
 // weight unit of block l's launches (EvalLaunch::unit), and the has_next argument of its node kernel: bit 0 = another unit follows

@@ -1,50 +1,67 @@
 // cmdgen_node_planes.h - one node tile of 64 or 32 rows with the A operand as producer-side bf16 planes (node_planes_tile): the body of
 // k_node64 / k_node32p (kernels_node64.hip) and of the pocket tiles of k_node_mixed (kernels_egnn.hip).  See kernels_node64.hip for the why.
-#pragma once
-#include "cmdgen_dev.h"
+// Included once per matrix engine by kernels_node64.hip (N64_NPL = 3: three bf16 pieces per operand, six MFMAs per product; 2: two fp16
+// pieces, three MFMAs - the "half" engine of cmdgen_split.h) inside a namespace of its own.  No include guard on purpose.
 
-#define NPLD 264            // bf16 per plane row: 256 + 8 (row stride 528 B: conflict-free ds_read_b128)
+#define NPLD 264            // 16-bit elements per plane row: 256 + 8 (row stride 528 B: conflict-free ds_read_b128)
 #define NRING 4
+constexpr int NPL = N64_NPL;
+constexpr unsigned KBS = 64u * NPL;          // 16-byte units per k-block of a 32-column tile in the packed split weight
+#if N64_NPL == 3
+typedef sbf16x8 nfrag;
+#define N64_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#else
+typedef sf16x8 nfrag;
+#define N64_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+#endif
 
 __device__ __forceinline__ void n64_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct N64Ring { sbf16x8 b[NRING][2][3]; };     // k-blocks x two 32-column tiles x three pieces
+struct N64Ring { nfrag b[NRING][2][NPL]; };   // k-blocks x two 32-column tiles x NPL pieces
 
 // acc[m][n] += A(planes) x W_n^T over K = 256 (16 k-blocks) for the wave's two 32-column tiles.  planes: the three bf16 planes of
 // the 64-row tile; cur[n] / nxt[n]: WAVE-UNIFORM pointers to k-block 0 of tile n of this GEMM / the next one (the lane's 16 bytes at
 // [lane + 64 piece]).  On entry the ring holds k-blocks 0, 1, 2 of this GEMM in sets 0, 1, 2; on exit those of the next.
 template <int NMT>
-__device__ __forceinline__ void n64_gemm(const unsigned short* planes, const sbf16x8* const (&cur)[2], const sbf16x8* const (&nxt)[2],
+__device__ __forceinline__ void n64_gemm(const unsigned short* planes, const nfrag* const (&cur)[2], const nfrag* const (&nxt)[2],
                                          sf32x16 (&acc)[NMT][2], N64Ring& ring) {
     constexpr int KB16 = 16, NPE = NMT * 32 * NPLD;
     const int lane = threadIdx.x & 63;
     const unsigned short* ap = planes + (lane & 31) * NPLD + (lane >> 5) * 8;
-    sbf16x8 a[2][NMT][3];                            // [set][m][piece]
+    nfrag a[2][NMT][NPL];                          // [set][m][piece]
     // one 16-byte load each: the weight fragment (tile n, piece s) of k-block KB into ring set SET / the A fragment (rows 32 m.., piece s)
 #define NG_LB(SET, KB, N, S) ring.b[SET][N][S] = (N == 0 ? q0_ : q1_)[lane + (S) * 64];
     // (past the k-range the A reads fetch the row's pad / the next row: in bounds, unused)
-#define NG_LA(SET, KB, M, S) a[SET][M][S] = *reinterpret_cast<const sbf16x8*>(ap + (S) * NPE + (M) * 32 * NPLD + (KB) * 16);
-#define NG_LOADA(SET, KB) _Pragma("unroll") for (int m_ = 0; m_ < NMT; ++m_) _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) \
-        a[SET][m_][s_] = *reinterpret_cast<const sbf16x8*>(ap + s_ * NPE + m_ * 32 * NPLD + (KB) * 16);
-#define NG_MF(M, N, AS, AI, BS, BI) acc[M][N] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AS][M][AI], ring.b[BS][N][BI], acc[M][N], 0, 0, 0);
+#define NG_LA(SET, KB, M, S) a[SET][M][S] = *reinterpret_cast<const nfrag*>(ap + (S) * NPE + (M) * 32 * NPLD + (KB) * 16);
+#define NG_LOADA(SET, KB) _Pragma("unroll") for (int m_ = 0; m_ < NMT; ++m_) _Pragma("unroll") for (int s_ = 0; s_ < NPL; ++s_) \
+        a[SET][m_][s_] = *reinterpret_cast<const nfrag*>(ap + s_ * NPE + m_ * 32 * NPLD + (KB) * 16);
+#define NG_MF(M, N, AS, AI, BS, BI) acc[M][N] = N64_MFMA(a[AS][M][AI], ring.b[BS][N][BI], acc[M][N]);
     // one group = one load and the two MFMAs of one row half (pieces AI x BI), pinned: the loads issue in the shadow of the MFMAs
     // instead of in a burst between k-blocks (which left the matrix pipe idle ~100 cycles per block).  Small terms first.
 #define NG_GRP(LOAD, M, AS, BS, AI, BI) LOAD NG_MF(M, 0, AS, AI, BS, BI) NG_MF(M, 1, AS, AI, BS, BI) __builtin_amdgcn_sched_barrier(0);
 #define NG_BLOCK(I) { constexpr int AS_ = (I) & 1, AN_ = ((I) + 1) & 1, BS_ = (I) & (NRING - 1), BN_ = ((I) + NRING - 1) & (NRING - 1);  \
         const int ka_ = kb + (I) + 1, kq_ = kb + (I) + NRING - 1;                                             \
-        const bool in_ = kq_ < KB16; const unsigned ko_ = (unsigned)(in_ ? kq_ : kq_ - KB16) * 192u;           \
-        const sbf16x8* q0_ = (in_ ? cur[0] : nxt[0]) + ko_; const sbf16x8* q1_ = (in_ ? cur[1] : nxt[1]) + ko_; \
-        if constexpr (NMT == 2) {                                                                             \
+        const bool in_ = kq_ < KB16; const unsigned ko_ = (unsigned)(in_ ? kq_ : kq_ - KB16) * KBS;           \
+        const nfrag* q0_ = (in_ ? cur[0] : nxt[0]) + ko_; const nfrag* q1_ = (in_ ? cur[1] : nxt[1]) + ko_; \
+        if constexpr (NPL == 3 && NMT == 2) {                                                                 \
         NG_GRP(NG_LA(AN_, ka_, 0, 2), 0, AS_, BS_, 2, 0) NG_GRP(NG_LA(AN_, ka_, 1, 2), 1, AS_, BS_, 2, 0)       \
         NG_GRP(NG_LA(AN_, ka_, 0, 1), 0, AS_, BS_, 1, 1) NG_GRP(NG_LA(AN_, ka_, 1, 1), 1, AS_, BS_, 1, 1)       \
         NG_GRP(NG_LA(AN_, ka_, 0, 0), 0, AS_, BS_, 0, 2) NG_GRP(NG_LA(AN_, ka_, 1, 0), 1, AS_, BS_, 0, 2)       \
         NG_GRP(NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 1, 0) NG_GRP(NG_LB(BN_, kq_, 0, 1), 1, AS_, BS_, 1, 0)       \
         NG_GRP(NG_LB(BN_, kq_, 0, 2), 0, AS_, BS_, 0, 1) NG_GRP(NG_LB(BN_, kq_, 1, 0), 1, AS_, BS_, 0, 1)       \
         NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 0) NG_GRP(NG_LB(BN_, kq_, 1, 2), 1, AS_, BS_, 0, 0)       \
-        } else {    /* 32-row tile: twelve MFMAs, nine loads */                                               \
+        } else if constexpr (NPL == 3) {    /* 32-row tile: twelve MFMAs, nine loads */                       \
         NG_GRP(NG_LA(AN_, ka_, 0, 2) NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 2, 0) NG_GRP(NG_LA(AN_, ka_, 0, 1) NG_LB(BN_, kq_, 0, 1), 0, AS_, BS_, 1, 1) \
         NG_GRP(NG_LA(AN_, ka_, 0, 0) NG_LB(BN_, kq_, 0, 2), 0, AS_, BS_, 0, 2) NG_GRP(NG_LB(BN_, kq_, 1, 0), 0, AS_, BS_, 1, 0) \
-        NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 1) NG_GRP(NG_LB(BN_, kq_, 1, 2), 0, AS_, BS_, 0, 0) } }
+        NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 1) NG_GRP(NG_LB(BN_, kq_, 1, 2), 0, AS_, BS_, 0, 0)       \
+        } else if constexpr (NMT == 2) {    /* half engine, 64 rows: twelve MFMAs (a1 b0, a0 b1, a0 b0), eight loads */ \
+        NG_GRP(NG_LA(AN_, ka_, 0, 1), 0, AS_, BS_, 1, 0) NG_GRP(NG_LA(AN_, ka_, 1, 1), 1, AS_, BS_, 1, 0)       \
+        NG_GRP(NG_LA(AN_, ka_, 0, 0) NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 0, 1) NG_GRP(NG_LA(AN_, ka_, 1, 0) NG_LB(BN_, kq_, 0, 1), 1, AS_, BS_, 0, 1) \
+        NG_GRP(NG_LB(BN_, kq_, 1, 0), 0, AS_, BS_, 0, 0) NG_GRP(NG_LB(BN_, kq_, 1, 1), 1, AS_, BS_, 0, 0)       \
+        } else {                            /* half engine, 32 rows: six MFMAs, six loads */                  \
+        NG_GRP(NG_LA(AN_, ka_, 0, 1) NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 1, 0)                                  \
+        NG_GRP(NG_LA(AN_, ka_, 0, 0) NG_LB(BN_, kq_, 0, 1) NG_LB(BN_, kq_, 1, 0), 0, AS_, BS_, 0, 1)            \
+        NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 0) } }
     NG_LOADA(0, 0)
 #pragma unroll 1
     for (int kb = 0; kb < KB16; kb += NRING) { NG_BLOCK(0) NG_BLOCK(1) NG_BLOCK(2) NG_BLOCK(3) }
@@ -59,16 +76,35 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const sbf
 // two values of the SAME column and two rows (an accumulator register pair) -> the three planes: one packed conversion per piece,
 // low half to row ra, high half to row rb
 __device__ __forceinline__ void n64_split_store2(unsigned short* planes, int NPE, int off_a, int off_b, float va, float vb) {
-    uint32_t p0, p1, p2;
-    split3_pair(va, vb, p0, p1, p2);
-    planes[off_a] = (unsigned short)p0;            planes[off_b] = (unsigned short)(p0 >> 16);
-    planes[NPE + off_a] = (unsigned short)p1;      planes[NPE + off_b] = (unsigned short)(p1 >> 16);
-    planes[2 * NPE + off_a] = (unsigned short)p2;  planes[2 * NPE + off_b] = (unsigned short)(p2 >> 16);
+    if constexpr (NPL == 3) {
+        uint32_t p0, p1, p2;
+        split3_pair(va, vb, p0, p1, p2);
+        planes[off_a] = (unsigned short)p0;            planes[off_b] = (unsigned short)(p0 >> 16);
+        planes[NPE + off_a] = (unsigned short)p1;      planes[NPE + off_b] = (unsigned short)(p1 >> 16);
+        planes[2 * NPE + off_a] = (unsigned short)p2;  planes[2 * NPE + off_b] = (unsigned short)(p2 >> 16);
+    } else {
+        uint32_t p0, p1;
+        split2_pair(va, vb, p0, p1);
+        planes[off_a] = (unsigned short)p0;            planes[off_b] = (unsigned short)(p0 >> 16);
+        planes[NPE + off_a] = (unsigned short)p1;      planes[NPE + off_b] = (unsigned short)(p1 >> 16);
+    }
 }
 
-// a 32-column tile of a packed split weight ([nt][K/16][3 pieces][64 lanes] x 16 bytes) at k-block kb0: wave-uniform pointer
-__device__ __forceinline__ const sbf16x8* n64_tile(const void* ws, int kb16_total, int nt, int kb0) {
-    return reinterpret_cast<const sbf16x8*>(ws) + ((size_t)nt * kb16_total + kb0) * 192;
+// a 32-column tile of a packed split weight ([nt][K/16][NPL pieces][64 lanes] x 16 bytes) at k-block kb0: wave-uniform pointer
+__device__ __forceinline__ const nfrag* n64_tile(const WPack& W, int kb16_total, int nt, int kb0) {
+    return reinterpret_cast<const nfrag*>(NPL == 3 ? W.ws : W.wh) + ((size_t)nt * kb16_total + kb0) * KBS;
+}
+// four consecutive k of one row -> the planes
+__device__ __forceinline__ void n64_store4(unsigned short* planes, int NPE, int off, const float4& v) {
+    if constexpr (NPL == 3) split_store4(planes, NPE, off, v); else split_store4_half(planes, NPE, off, v);
+}
+// the power of two a weight pack's accumulators carry (1 on the bf16 split) and its inverse
+__device__ __forceinline__ float n64_scale(const WPack& W) { return NPL == 3 ? 1.0f : W.wh_scale; }
+__device__ __forceinline__ float n64_inv(const WPack& W) { return NPL == 3 ? 1.0f : W.wh_inv; }
+// SiLU(a / sc) for an accumulator carrying the scale sc (c1 = -log2(e) / sc): five operations, the bits of silu_f(a / sc)
+__device__ __forceinline__ float n64_silu_scaled(float a, float c1, float sc) {
+    const float u = __builtin_amdgcn_exp2f(a * c1);
+    return a * __builtin_amdgcn_rcpf(__fmaf_rn(u, sc, sc));
 }
 
 __device__ __forceinline__ float4 n64_node_pos(const Layout& lay, const Work& w, const Dims& d, int n, int layer) {
@@ -115,18 +151,19 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
         }
     }
     // the chain's weight tiles: this wave's columns 64 wave .. 64 wave + 63 = tiles 2 wave, 2 wave + 1 of every [H out] matrix
-    const sbf16x8* const t3a[2] = {n64_tile(lw.W3.ws, 32, 2 * wave, 0), n64_tile(lw.W3.ws, 32, 2 * wave + 1, 0)};
-    const sbf16x8* const t3b[2] = {n64_tile(lw.W3.ws, 32, 2 * wave, 16), n64_tile(lw.W3.ws, 32, 2 * wave + 1, 16)};
-    const sbf16x8* const t4[2] = {n64_tile(lw.W4.ws, 16, 2 * wave, 0), n64_tile(lw.W4.ws, 16, 2 * wave + 1, 0)};
+    const nfrag* const t3a[2] = {n64_tile(lw.W3, 32, 2 * wave, 0), n64_tile(lw.W3, 32, 2 * wave + 1, 0)};
+    const nfrag* const t3b[2] = {n64_tile(lw.W3, 32, 2 * wave, 16), n64_tile(lw.W3, 32, 2 * wave + 1, 16)};
+    const nfrag* const t4[2] = {n64_tile(lw.W4, 16, 2 * wave, 0), n64_tile(lw.W4, 16, 2 * wave + 1, 0)};
     // projections: jobs 0..3 = P_c, Q_c, P', Q' (bit j of `jobs` set: the job runs); Wpq rows 0..H-1 -> P (tiles 0..7), H.. -> Q (8..15)
     // Q_c only where a row of the tile sends along a coordinate edge of this evaluation (flags of the graph pass, kernels_egnn.hip)
     const bool want_qc = want_pc || !w.need_qc || __ballot((lane & (NROWS - 1)) < nvalid && w.need_qc[row0 + (lane & (NROWS - 1))] <= 1) != 0ull;
     const unsigned jobs = (want_pc && !skip_pc ? 1u : 0u) | (want_qc && !skip_pc ? 2u : 0u) | (has_next ? 12u : 0u);
-    auto job_tile = [&](int j, int n) { return n64_tile(j < 2 ? lw.Wpq_c.ws : lw_next.Wpq_e.ws, 16, (j & 1) * 8 + 2 * wave + n, 0); };
+    auto job_tile = [&](int j, int n) { return n64_tile(j < 2 ? lw.Wpq_c : lw_next.Wpq_e, 16, (j & 1) * 8 + 2 * wave + n, 0); };
     const int job0 = jobs ? __builtin_ctz(jobs) : 1;             // (no job at all: the W4 product's look-ahead reads Q_c's first blocks, unused)
     N64Ring ring;
     const int colw = 64 * wave + (lane & 31);
-    const float b3c0 = lw.b3[colw], b3c1 = lw.b3[colw + 32], b4c0 = lw.b4[colw], b4c1 = lw.b4[colw + 32];
+    const float sc3 = n64_scale(lw.W3), c13 = -1.4426950408889634f * n64_inv(lw.W3), inv4 = n64_inv(lw.W4);       // the accumulators carry their weight pack's scale
+    const float b3c0 = lw.b3[colw] * sc3, b3c1 = lw.b3[colw + 32] * sc3, b4c0 = lw.b4[colw], b4c1 = lw.b4[colw + 32];
     if (layer >= 1 && tid < NROWS) {                                           // materialise the coordinates entering this block
         const int n = row0 + tid;
         if (tid < nvalid && n < lay.Nm) w.XL[(size_t)layer * lay.Nm + n] = n64_node_pos(lay, w, d, n, layer);
@@ -146,9 +183,9 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int s_ = 0; s_ < 3; ++s_) ring.b[kb][n][s_] = t3a[n][(unsigned)kb * 192u + lane + s_ * 64];
+                for (int s_ = 0; s_ < NPL; ++s_) ring.b[kb][n][s_] = t3a[n][(unsigned)kb * KBS + lane + s_ * 64];
 #pragma unroll
-        for (int pass = 0; pass < NROWS / 4; ++pass) split_store4(planes, NPE, (pass * 4 + rsub) * NPLD + 4 * c4, hv[pass]);
+        for (int pass = 0; pass < NROWS / 4; ++pass) n64_store4(planes, NPE, (pass * 4 + rsub) * NPLD + 4 * c4, hv[pass]);
     }
     // agg: requested now, consumed after the h-part of the first product
     float4 av[NROWS / 4];
@@ -171,7 +208,7 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
         float4 v = av[pass];
         const float dv = r < nvalid ? agg_div(w, d, row0 + r) : 1.0f;
         v.x /= dv; v.y /= dv; v.z /= dv; v.w /= dv;
-        split_store4(planes, NPE, r * NPLD + 4 * c4, v);
+        n64_store4(planes, NPE, r * NPLD + 4 * c4, v);
     }
     n64_lds_barrier();
     n64_gemm<NMT>(planes, t3b, t4, acc, ring);                                      // agg part
@@ -186,7 +223,7 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
             for (int r = 0; r < 16; r += 2) {
                 const float bb = n == 0 ? b3c0 : b3c1;
                 const int col = colw + 32 * n;
-                n64_split_store2(planes, NPE, N64_ROW(m, r) * NPLD + col, N64_ROW(m, r + 1) * NPLD + col, silu_f(acc[m][n][r] + bb), silu_f(acc[m][n][r + 1] + bb));
+                n64_split_store2(planes, NPE, N64_ROW(m, r) * NPLD + col, N64_ROW(m, r + 1) * NPLD + col, n64_silu_scaled(acc[m][n][r] + bb, c13, sc3), n64_silu_scaled(acc[m][n][r + 1] + bb, c13, sc3));
             }
     // the residual's h, in the accumulator layout, requested now (L2) and consumed after the W4 product
     float hold[NMT][2][16];
@@ -203,7 +240,7 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
     NSTAMP(2);
     N64_ZERO(acc)
     {
-        const sbf16x8* const nxt[2] = {job_tile(job0, 0), job_tile(job0, 1)};
+        const nfrag* const nxt[2] = {job_tile(job0, 0), job_tile(job0, 1)};
         n64_gemm<NMT>(planes, t4, nxt, acc, ring);
     }
     NSTAMP(3);
@@ -217,7 +254,7 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
             for (int r = 0; r < 16; r += 2) {
                 const float bb = n == 0 ? b4c0 : b4c1;
                 const int col = colw + 32 * n, ra = N64_ROW(m, r), rb = N64_ROW(m, r + 1);
-                const float ha = hold[m][n][r] + (acc[m][n][r] + bb), hb = hold[m][n][r + 1] + (acc[m][n][r + 1] + bb);       // residual (egnn_new.py:57)
+                const float ha = hold[m][n][r] + __fmaf_rn(acc[m][n][r], inv4, bb), hb = hold[m][n][r + 1] + __fmaf_rn(acc[m][n][r + 1], inv4, bb);       // residual (egnn_new.py:57); inv4: a power of two, exact
                 if (ra < nvalid) w.h[(size_t)(row0 + ra) * H + col] = ha;
                 if (rb < nvalid) w.h[(size_t)(row0 + rb) * H + col] = hb;
                 n64_split_store2(planes, NPE, ra * NPLD + col, rb * NPLD + col, ra < nvalid ? ha : 0.f, rb < nvalid ? hb : 0.f);
@@ -230,11 +267,12 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
         const int j = __builtin_ctz(rest);
         const unsigned after = rest & (rest - 1u);
         const int jn = after ? __builtin_ctz(after) : j;                       // (last job: re-reads its own first blocks)
-        const sbf16x8* const tc[2] = {job_tile(j, 0), job_tile(j, 1)};
-        const sbf16x8* const tn[2] = {job_tile(jn, 0), job_tile(jn, 1)};
+        const nfrag* const tc[2] = {job_tile(j, 0), job_tile(j, 1)};
+        const nfrag* const tn[2] = {job_tile(jn, 0), job_tile(jn, 1)};
         float* __restrict__ out = j == 0 ? w.Pc : j == 1 ? w.Qc : j == 2 ? w.P : w.Q;
         const float* bv = j == 0 ? lw.b6 : lw_next.b1;
         const float bias0 = (j == 0 || j == 2) ? bv[colw] : 0.f, bias1 = (j == 0 || j == 2) ? bv[colw + 32] : 0.f;       // (in flight during the GEMM)
+        const float invj = n64_inv(j < 2 ? lw.Wpq_c : lw_next.Wpq_e);
         N64_ZERO(acc)
         n64_gemm<NMT>(planes, tc, tn, acc, ring);
 #pragma unroll
@@ -244,7 +282,7 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = N64_ROW(m, r);
-                    if (row < nvalid) out[(size_t)(row0 + row) * H + colw + 32 * n] = acc[m][n][r] + (n == 0 ? bias0 : bias1);
+                    if (row < nvalid) out[(size_t)(row0 + row) * H + colw + 32 * n] = __fmaf_rn(acc[m][n][r], invj, n == 0 ? bias0 : bias1);
                 }
     }
     NSTAMP(5);

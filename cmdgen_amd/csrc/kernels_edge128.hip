@@ -52,13 +52,13 @@ namespace e128_bf3 {
 bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s) {
     const WPack& W = a.layers[unit_of(a, l)].W2;
     if (a.edge_mt != 128 || a.d.H != 256 || !a.split || a.save || !W.ws) return false;
-    if (a.e128_f16 && W.wh) E128_LAUNCH(e128_half, false, a.live_thr); else E128_LAUNCH(e128_bf3, false, a.live_thr);
+    if (a.half_engine && W.wh) E128_LAUNCH(e128_half, false, a.live_thr); else E128_LAUNCH(e128_bf3, false, a.live_thr);
     return true;
 }
 bool cmdgen_launch_coord128(const EvalLaunch& a, int l, hipStream_t s) {
     const WPack& W = a.layers[unit_of(a, l)].W7;
     if (a.coord_mt != 128 || a.d.H != 256 || !a.split || a.save || !W.ws) return false;
-    if (a.e128_f16 && W.wh) E128_LAUNCH(e128_half, true, 0); else E128_LAUNCH(e128_bf3, true, 0);
+    if (a.half_engine && W.wh) E128_LAUNCH(e128_half, true, 0); else E128_LAUNCH(e128_bf3, true, 0);
     return true;
 }
 #undef E128_LAUNCH

@@ -15,7 +15,7 @@
 // with a 4-float row pad (conflict-free ds_read_b128); the B operand (weights) streams from
 // L2 in MFMA fragment order (cmdgen_dev.h).
 #include "cmdgen_dev.h"
-#include "cmdgen_node_planes.h"
+#include "cmdgen_dev.h"
 #include <hip/hip_ext.h>
 
 #define LDA(H) ((H) + 4)

@@ -14,32 +14,58 @@
 // agg is requested into registers while the h-part of the first product runs.
 // Tile: 64 rows x 256 columns, 4 waves x 64 columns (2 x 2 accumulator tiles of 32 x 32), v_mfma_f32_32x32x16_bf16; weight
 // fragments three k-blocks ahead in a ring of four register sets carried from one GEMM of the chain into the next.
-#include "cmdgen_node_planes.h"
+#include "cmdgen_dev.h"
 #include <hip/hip_ext.h>
 
+#define N64_NPL 2
+namespace n64_half {
+#include "cmdgen_node_planes.h"
 __global__ __launch_bounds__(256, 1) void k_node64(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next) {
-    __shared__ __attribute__((aligned(16))) unsigned short planes[3 * 64 * NPLD + 64];      // + the A prefetch's overshoot past the last row
+    __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 64 * NPLD + 64];      // + the A prefetch's overshoot past the last row
     node_planes_tile<64>(planes, lay, w, d, lw, lw_next, layer, has_next, (int)blockIdx.x * 64, lay.N);
 }
-// the same tile at 32 rows (measurement aid: CMDGEN_NODE64=32 runs every node tile of a layout through it; profiles/r03_m_node64.txt)
+// the same tile at 32 rows (measurement aid: option node64 = 32 runs every node tile of a layout through it; profiles/r03_m_node64.txt)
 __global__ __launch_bounds__(256, 1) void k_node32p(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next) {
-    __shared__ __attribute__((aligned(16))) unsigned short planes[3 * 32 * NPLD + 64];
+    __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 32 * NPLD + 64];
     node_planes_tile<32>(planes, lay, w, d, lw, lw_next, layer, has_next, (int)blockIdx.x * 32, lay.N);
+}
+}
+#undef N64_NPL
+#undef N64_MFMA
+#undef NPLD
+#undef NRING
+#undef N64_ZERO
+#undef N64_ROW
+#define N64_NPL 3
+namespace n64_bf3 {
+#include "cmdgen_node_planes.h"
+__global__ __launch_bounds__(256, 1) void k_node64(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next) {
+    __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 64 * NPLD + 64];
+    node_planes_tile<64>(planes, lay, w, d, lw, lw_next, layer, has_next, (int)blockIdx.x * 64, lay.N);
+}
+__global__ __launch_bounds__(256, 1) void k_node32p(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next) {
+    __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 32 * NPLD + 64];
+    node_planes_tile<32>(planes, lay, w, d, lw, lw_next, layer, has_next, (int)blockIdx.x * 32, lay.N);
+}
 }
 
 // launcher: true when the 64-row kernel took the launch (H = 256, split engine, sampler)
+#define N64_LAUNCH(NSP)                                                                                                                              \
+    do {                                                                                                                                             \
+        const LayerW& lw_ = a.layers[unit_of(a, l)]; const LayerW& ln_ = a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)];          \
+        if (a.node64 == 32) {                                                                                                                        \
+            const int nt32 = (a.lay.N + 31) / 32;                                                                                                    \
+            if (a.pe_start) hipExtLaunchKernelGGL(NSP::k_node32p, dim3(nt32), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l)); \
+            else hipLaunchKernelGGL(NSP::k_node32p, dim3(nt32), dim3(256), 0, s, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l));                     \
+        } else {                                                                                                                                     \
+            const int nt = (a.lay.N + 63) / 64;                                                                                                      \
+            if (a.pe_start) hipExtLaunchKernelGGL(NSP::k_node64, dim3(nt), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l)); \
+            else hipLaunchKernelGGL(NSP::k_node64, dim3(nt), dim3(256), 0, s, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l));                        \
+        }                                                                                                                                            \
+    } while (0)
 bool cmdgen_launch_node64(const EvalLaunch& a, int l, hipStream_t s) {
     if (a.d.H != 256 || !a.split || a.save || !a.node64 || !a.layers[unit_of(a, l)].W3.ws) return false;
-    if (a.node64 == 32) {
-        const int nt32 = (a.lay.N + 31) / 32;
-        if (a.pe_start) hipExtLaunchKernelGGL(k_node32p, dim3(nt32), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)],
-                                              a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l));
-        else hipLaunchKernelGGL(k_node32p, dim3(nt32), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l));
-        return true;
-    }
-    const int nt = (a.lay.N + 63) / 64;
-    if (a.pe_start) hipExtLaunchKernelGGL(k_node64, dim3(nt), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)],
-                                          a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l));
-    else hipLaunchKernelGGL(k_node64, dim3(nt), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l));
+    if (a.half_engine && a.layers[unit_of(a, l)].W3.wh) N64_LAUNCH(n64_half); else N64_LAUNCH(n64_bf3);
     return true;
 }
+#undef N64_LAUNCH

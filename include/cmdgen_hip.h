@@ -413,8 +413,10 @@ int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16);
  *                        hidden_nf 256), "embed_mt" 16|32|64
  *   grids                "edge_wgs_per_cu", "coord_wgs_per_cu" (persistent-style edge grids of the <= 64-row kernels),
  *                        "e128_wgs_per_cu" 1|2, "e128_pp" 0|1 (1: the 128-row edge kernels as one 512-thread workgroup per CU whose two
- *                        halves run phase-locked one barrier apart), "e128_f16" 0|1 (1, default: the 128-row edge kernels multiply with two fp16
- *                        pieces per operand, three MFMAs per fp32 product; 0: three bf16 pieces, six MFMAs)
+ *                        halves run phase-locked one barrier apart)
+ *   matrix engine        "half_engine" 0|1|2: the split-engine kernels that have a HALF form (two fp16 pieces per operand, three MFMAs per
+ *                        fp32 product instead of three bf16 pieces and six; csrc/cmdgen_split.h) use it: 1 (default) when the model has an
+ *                        edge cutoff (the radial features are bounded; fp16 ends at 65504), 2 always, 0 never
  *   kernel variants      "edge_fullk" 0|1 (full-K planes for 32-row edge tiles), "node64" 0|1|32 (64-row planes node kernel;
  *                        32: its 32-row form), "node16_split" 0|1, "node16w" 0|1 (16-row node tiles of H = 256 on eight waves,
  *                        kernels_node16w.hip; default 1), "write_embed" 0|1 (graph pass 2 + k_embed in one launch)
