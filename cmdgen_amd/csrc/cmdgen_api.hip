@@ -237,6 +237,26 @@ static std::vector<unsigned short> pack_half(const float* W, int out, int ld, in
     return p;
 }
 
+// the same two fp16 pieces of (scale * w) in v_mfma_f32_16x16x32_f16 fragment order (16-row tiles; k order inside a block of 32 as pack_split16)
+static std::vector<unsigned short> pack_half16(const float* W, int out, int ld, int c0, int in, float sc) {
+    const int NT = out / 16, KB = in / 32;
+    std::vector<unsigned short> p((size_t)NT * KB * 2 * 64 * 8);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int g = lane >> 4;
+                    const int k = 32 * kb + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+                    const float w = W[(size_t)(16 * nt + (lane & 15)) * ld + c0 + k] * sc;
+                    const _Float16 h0 = (_Float16)w; const float r1 = w - (float)h0;
+                    const _Float16 h1 = (_Float16)r1;
+                    unsigned short u0, u1; memcpy(&u0, &h0, 2); memcpy(&u1, &h1, 2);
+                    const size_t base = (((size_t)nt * KB + kb) * 2) * 64 * 8;
+                    p[base + (0 * 64 + lane) * 8 + j] = u0; p[base + (1 * 64 + lane) * 8 + j] = u1;
+                }
+    return p;
+}
+
 static int upload_pack(cmdgen_handle* h, const float* W, int out, int in, WPack* wp) {
     const float* dp;
     std::vector<float> p = pack_frag(W, out, in, 0, in);
@@ -254,6 +274,13 @@ static int upload_pack(cmdgen_handle* h, const float* W, int out, int in, WPack*
         r = dev_alloc(h, h->weight_allocs, &q, ph.size() * sizeof(unsigned short), false); if (r) return r;
         if (hipMemcpy(q, ph.data(), ph.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemcpy H2D failed");
         wp->wh = q; wp->wh_scale = sc; wp->wh_inv = 1.0f / sc;
+        wp->wh16 = nullptr;
+        if (in % 128 == 0) {
+            const std::vector<unsigned short> ph16 = pack_half16(W, out, in, 0, in, sc);
+            r = dev_alloc(h, h->weight_allocs, &q, ph16.size() * sizeof(unsigned short), false); if (r) return r;
+            if (hipMemcpy(q, ph16.data(), ph16.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return fail(h, CMDGEN_EHIP, "hipMemcpy H2D failed");
+            wp->wh16 = q;
+        }
     }
     if (in % 128 == 0) {        // the 16-row split GEMM walks four k-blocks of 32 per iteration
         const std::vector<unsigned short> p16 = pack_split16(W, out, in, 0, in);

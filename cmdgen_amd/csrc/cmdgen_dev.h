@@ -32,6 +32,7 @@ struct WPack {                  // one Linear weight in the MFMA fragment orders
     const void*   ws;           // three bf16 pieces per weight in v_mfma_f32_32x32x16_bf16 order (cmdgen_split.h); null in training
     const void*   ws16;         // the same pieces in v_mfma_f32_16x16x32_bf16 order (16-row tiles on the split engine); null in training
     const void*   wh;           // TWO fp16 pieces of (weight * wh_scale) per weight in v_mfma_f32_32x32x16_f16 order (cmdgen_split.h, "half" engine); null in training
+    const void*   wh16;         // the same two pieces in v_mfma_f32_16x16x32_f16 order (16-row tiles); null in training / where in % 128 != 0
     float         wh_scale;     // the power of two the matrix was multiplied by before its split (keeps both pieces in fp16's normal range)
     float         wh_inv;       // 1 / wh_scale
 };
