@@ -451,3 +451,64 @@ __device__ __forceinline__ void tile_gemm_planes_swz32(const unsigned short* pla
 #undef SW_GRP
 #undef SW_HALF
 }
+
+// ---------------------------------------------------------------------------------------------
+// Half engine (two fp16 pieces per operand, three MFMAs per product; see the top of this file) for the full-K 32-row plane image:
+// two swizzled planes of [32][256] fp16 (32 KB), weight fragments from WPack::wh ([nt][K/16][2 pieces][64 lanes] x 16 bytes).
+// Carry contract as tile_gemm_planes_swz32.  The accumulators carry WPack::wh_scale.
+// ---------------------------------------------------------------------------------------------
+struct HFragPtr { const sf16x8* p; unsigned ns; };      // a wave's first n-tile; ns = stride between n-tiles (16-byte units)
+__device__ __forceinline__ HFragPtr hfrag_ptr(const void* Wh, int kb16_total, int kb0, int cg) {
+    const int lane = threadIdx.x & 63;
+    HFragPtr f;
+    f.p = reinterpret_cast<const sf16x8*>(Wh) + ((size_t)(2 * cg) * kb16_total + kb0) * 128 + lane;
+    f.ns = (unsigned)kb16_total * 128u;
+    return f;
+}
+struct HCarry { sf16x8 b[2][2][2]; };                   // two register sets of [2 n-tiles][2 pieces]
+__device__ __forceinline__ void half_prefetch(const HFragPtr& f, HCarry& c) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { c.b[0][0][s] = f.p[s * 64]; c.b[0][1][s] = (f.p + f.ns)[s * 64]; }
+}
+// four consecutive k-values (4 c4 .. 4 c4 + 3) of row e -> the two swizzled fp16 planes
+__device__ __forceinline__ void split_store4_swz_half(unsigned short* planes, int e, int c4, const float4& v) {
+    split_store4_half(planes, SPLIT_SWZ_PE, split_swz_off(e, c4 >> 1) + ((c4 & 1) << 2), v);
+}
+__device__ __forceinline__ void tile_gemm_planes_swz32_half(const unsigned short* planes, const HFragPtr cur, const HFragPtr next,
+                                                            sf32x16 (&acc)[1][2], HCarry& carry) {
+    constexpr int KB16 = 16, PE = SPLIT_SWZ_PE;
+    const int lane = threadIdx.x & 63, row = lane & 31, hi = lane >> 5;
+    const unsigned short* rp = planes + row * 256;
+    const sf16x8* q0 = cur.p + 128;
+    const sf16x8* q1 = q0 + cur.ns;
+    sf16x8 a[2][2];
+#define HW_PTR(KB) (rp + (((2 * (KB) + hi) ^ row) << 3))
+#define HW_LA(SET, PTR, S) a[SET][S] = *reinterpret_cast<const sf16x8*>((PTR) + (S) * PE);
+#define HW_LB(SET, N, S) carry.b[SET][N][S] = ((N) == 0 ? q0 : q1)[(S) * 64];
+#define HW_MF(N, AS, AI, BS, BI) acc[0][N] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[AS][AI], carry.b[BS][N][BI], acc[0][N], 0, 0, 0);
+#define HW_GRP(LOADS, AS, BS, AI, BI) LOADS HW_MF(0, AS, AI, BS, BI) HW_MF(1, AS, AI, BS, BI) __builtin_amdgcn_sched_barrier(0);
+    // a1 b0, a0 b1, a0 b0 (small terms first); two loads in the shadow of every two MFMAs
+#define HW_HALF(AS, BS, AN, BN, PTR)                                                                                              \
+        HW_GRP(HW_LA(AN, PTR, 1) HW_LB(BN, 0, 0), AS, BS, 1, 0) HW_GRP(HW_LA(AN, PTR, 0) HW_LB(BN, 0, 1), AS, BS, 0, 1)             \
+        HW_GRP(HW_LB(BN, 1, 0) HW_LB(BN, 1, 1), AS, BS, 0, 0)
+    { const unsigned short* p0 = HW_PTR(0); HW_LA(0, p0, 0) HW_LA(0, p0, 1) }
+#pragma unroll 1
+    for (int kb = 0; kb < KB16; kb += 2) {
+        const bool more = kb + 2 < KB16;
+        const unsigned short* p1 = HW_PTR(kb + 1);
+        const unsigned short* p2 = HW_PTR(more ? kb + 2 : kb);       // (last block: re-reads its own fragments, unused)
+        __builtin_amdgcn_sched_barrier(0);
+        HW_HALF(0, 0, 1, 1, p1)
+        q0 = more ? q0 + 128 : next.p;
+        q1 = more ? q1 + 128 : next.p + next.ns;
+        __builtin_amdgcn_sched_barrier(0);
+        HW_HALF(1, 1, 0, 0, p2)
+        q0 += 128; q1 += 128;
+    }
+#undef HW_PTR
+#undef HW_LA
+#undef HW_LB
+#undef HW_MF
+#undef HW_GRP
+#undef HW_HALF
+}

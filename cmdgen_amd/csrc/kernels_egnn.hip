@@ -652,6 +652,7 @@ __device__ __forceinline__ void build_edge_half(unsigned short* planes, int half
 // Full-K tile build for 32-row tiles (cmdgen_split.h, tile_gemm_planes_swz32): all 256 columns of the tile at once - 16 gathered rows
 // per thread in flight together, ONE round trip per tile - into the swizzled, unpadded plane image.  Thread -> columns 4 c4 .. 4 c4 + 3
 // (c4 = tid % 64) of rows pass * 4 + tid / 64; wr4 / wd4: the thread's four radial / d0 weights (fixed columns: registers, no LDS).
+template <int NPC>
 __device__ __forceinline__ void build_edge_full32(unsigned short* planes, const int* s_row, const int* s_col, const float* s_r, const float* s_d0,
                                                   int ne, const float* __restrict__ P, const float* __restrict__ Q, const float4& wr4, const float4& wd4) {
     constexpr int H = 256, MT = 32;
@@ -675,7 +676,7 @@ __device__ __forceinline__ void build_edge_full32(unsigned short* planes, const 
             a = make_float4(silu_f(p[pass].x + q[pass].x + wr4.x * r + wd4.x * d0), silu_f(p[pass].y + q[pass].y + wr4.y * r + wd4.y * d0),
                             silu_f(p[pass].z + q[pass].z + wr4.z * r + wd4.z * d0), silu_f(p[pass].w + q[pass].w + wr4.w * r + wd4.w * d0));
         }
-        split_store4_swz(planes, e, c4, a);
+        if constexpr (NPC == 3) split_store4_swz(planes, e, c4, a); else split_store4_swz_half(planes, e, c4, a);
     }
 }
 
@@ -739,13 +740,34 @@ __device__ __forceinline__ int xcd_tile(int k, int ntiles) {
     return tile < ntiles ? tile : -1;
 }
 
+// the matrix engine of the full-K 32-row plane tiles (FK = pieces per operand): fragments, carry, GEMM, and the inverse of the power of
+// two the accumulators carry (half engine: WPack::wh_scale)
+template <int FK> struct EngFK;
+template <> struct EngFK<3> {
+    typedef SFragPtr Frag; typedef SCarry Carry;
+    static __device__ __forceinline__ Frag frag(const WPack& W, int, int, int cg) { return sfrag_ptr(W.ws, 16, 0, cg); }
+    static __device__ __forceinline__ void prefetch(const Frag& f, Carry& c) { split_prefetch(f, c); }
+    static __device__ __forceinline__ void gemm(const unsigned short* planes, const Frag f, sf32x16 (&acc)[1][2], Carry& c) { tile_gemm_planes_swz32(planes, f, f, acc, c); }
+    static __device__ __forceinline__ float inv(const WPack&) { return 1.0f; }
+};
+template <> struct EngFK<2> {
+    typedef HFragPtr Frag; typedef HCarry Carry;
+    static __device__ __forceinline__ Frag frag(const WPack& W, int, int, int cg) { return hfrag_ptr(W.wh, 16, 0, cg); }
+    static __device__ __forceinline__ void prefetch(const Frag& f, Carry& c) { half_prefetch(f, c); }
+    static __device__ __forceinline__ void gemm(const unsigned short* planes, const Frag f, sf32x16 (&acc)[1][2], Carry& c) { tile_gemm_planes_swz32_half(planes, f, f, acc, c); }
+    static __device__ __forceinline__ float inv(const WPack& W) { return W.wh_inv; }
+};
+template <int MT, bool SP, int FK> struct EdgeEng { typedef Eng<MT, SP> G; };
+template <int MT, bool SP> struct EdgeEng<MT, SP, 3> { typedef EngFK<3> G; };
+template <int MT, bool SP> struct EdgeEng<MT, SP, 2> { typedef EngFK<2> G; };
+
 // ------------------------------------------------------------------------------------
 // LDS of an edge-tile workgroup, shared by the two edge bodies.
 // ------------------------------------------------------------------------------------
 // FK (full-K planes, 32-row tiles of the sampler on the split engine): the A tile is three unpadded [32][256] bf16 planes (48 KB) and the
 // radial / d0 weights live in registers - 51.6 KB in all, three workgroups per CU.
-template <int H, int MT, bool FK = false> struct EdgeLds {
-    float buf[FK ? 3 * MT * H / 2 : MT * LDA(H)];   // A tile (fp32 image or bf16 planes), then the epilogue's m tile
+template <int H, int MT, int FK = 0> struct EdgeLds {       // FK: 0, or the number of full-K planes (3: bf16 split, 2: half engine)
+    float buf[FK ? (FK * MT * H / 2 > MT * LDA(H) ? FK * MT * H / 2 : MT * LDA(H)) : MT * LDA(H)];   // A tile (fp32 image or bf16 planes), then the epilogue's m tile
     int s_row[MT], s_col[MT];
     float s_r[MT], s_d0[MT], s_att[MT];
     float s_cd[MT][3], s_tr[MT][3];         // coordinate body only
@@ -760,7 +782,7 @@ template <int H, int MT, bool FK = false> struct EdgeLds {
 // device-side edge count is exhausted, so the launch geometry is static (graph-capturable).
 // live_thr: 0 = every tile; else only tiles with a receiver within that many hops of a moving node (dead work).
 // ------------------------------------------------------------------------------------
-template <int H, int MT, bool SAVE, bool SP, bool FK = false>
+template <int H, int MT, bool SAVE, bool SP, int FK = 0>
 __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
                                               const int layer, const int ablate, const TrainSave& sv, const int live_thr) {
     float* buf = L.buf; int* s_row = L.s_row; int* s_col = L.s_col;
@@ -776,7 +798,9 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
     extern __shared__ float s_dyn[];          // sin_embedding only (launched with (24 H + 24 MT) floats): the [24][H] feature columns of edge_mlp.0, then the tile's features
     if constexpr (!FK && !(SP && H == 256 && MT >= 32))      // (the plane variants never see sin_embedding: such a handle runs on the fp32 instruction)
         if (d.sin) for (int i = tid; i < 24 * H; i += H) s_dyn[i] = lw.we_e[i];          // (the first tile's barrier covers it)
-    typedef Eng<MT, SP> G;
+    typedef typename EdgeEng<MT, SP, FK>::G G;
+    float inv2 = 1.0f;                                         // the half engine's accumulators carry the weight pack's power-of-two scale
+    if constexpr (FK != 0) inv2 = G::inv(lw.W2);
     const typename G::Frag fw = G::frag(lw.W2, H / 8, 0, wave);
     typename G::Carry carry;
     G::prefetch(fw, carry);     // before the edge count is known: the first fragments fly beside that load and the index / position
@@ -844,10 +868,10 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
         acc_zero<MT>(acc);
         if constexpr (FK) {
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
-            if (!(ablate & 2)) build_edge_full32(planes, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4);
+            if (!(ablate & 2)) build_edge_full32<FK>(planes, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4);
             lds_barrier();
             STAMP(1);
-            if (!(ablate & 4)) tile_gemm_planes_swz32(planes, fw, fw, acc.a, carry);
+            if (!(ablate & 4)) G::gemm(planes, fw, acc.a, carry);
         } else if constexpr (PL) {
             // two half-K passes: build columns [0,128) as bf16 planes -> GEMM over k 0..127 -> build [128,256) -> GEMM over the rest
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
@@ -877,7 +901,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
         lds_barrier();                         // every wave is done reading the A tile
         STAMP(3);
         acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {                 // m_ij
-            const float pre = v + b2v.v[n];
+            const float pre = __fmaf_rn(v, inv2, b2v.v[n]);
             buf[row * LDA(H) + col] = SAVE ? pre : silu_f(pre);
         });
         lds_barrier();
@@ -940,7 +964,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
 #endif
 #undef STAMP
 }
-template <int H, int MT, bool SAVE, bool SP, bool FK = false>
+template <int H, int MT, bool SAVE, bool SP, int FK = 0>
 __global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_msg(Layout lay, Work w, Dims d, LayerW lw, int layer, int ablate, TrainSave sv, int live_thr) {
     __shared__ __attribute__((aligned(16))) EdgeLds<H, MT, FK> L;
     edge_msg_body<H, MT, SAVE, SP, FK>(L, lay, w, d, lw, layer, ablate, sv, live_thr);
@@ -1128,7 +1152,7 @@ __global__ __launch_bounds__(H, (MT == 16 && SP) ? 1 : 2) void k_node(Layout lay
 //   phi = w5 . SiLU(W7 SiLU(W6 [h_i, h_j, r, d0] + b6) + b7)
 //   ACC[l][i] += (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant) * tanh(phi) * coords_range
 // ------------------------------------------------------------------------------------
-template <int H, int MT, bool SAVE, bool SP, bool FK = false>
+template <int H, int MT, bool SAVE, bool SP, int FK = 0>
 __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
                                                 const int layer, const TrainSave& sv) {
     float* buf = L.buf; int* s_row = L.s_row; int* s_col = L.s_col;
@@ -1144,7 +1168,9 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
     extern __shared__ float s_dyn[];          // sin_embedding only: see edge_msg_body
     if constexpr (!FK && !(SP && H == 256 && MT >= 32))
         if (d.sin) for (int i = tid; i < 24 * H; i += H) s_dyn[i] = lw.we_c[i];
-    typedef Eng<MT, SP> G;
+    typedef typename EdgeEng<MT, SP, FK>::G G;
+    float inv7 = 1.0f;                                         // (see edge_msg_body)
+    if constexpr (FK != 0) inv7 = G::inv(lw.W7);
     const typename G::Frag fw = G::frag(lw.W7, H / 8, 0, wave);
     typename G::Carry carry;
     G::prefetch(fw, carry);                                    // unconditional, see edge_msg_body
@@ -1185,9 +1211,9 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
         acc_zero<MT>(acc);
         if constexpr (FK) {
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
-            build_edge_full32(planes, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, wr4, wd4);
+            build_edge_full32<FK>(planes, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, wr4, wd4);
             lds_barrier();
-            tile_gemm_planes_swz32(planes, fw, fw, acc.a, carry);
+            G::gemm(planes, fw, acc.a, carry);
         } else if constexpr (PL) {
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
             constexpr int PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
@@ -1212,7 +1238,7 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
         }
         lds_barrier();
         acc_foreach_n<MT>(acc, wave, [&](int row, int col, int n, float v) {
-            const float pre = v + b7v.v[n];
+            const float pre = __fmaf_rn(v, inv7, b7v.v[n]);
             buf[row * LDA(H) + col] = SAVE ? pre : silu_f(pre);
         });
         lds_barrier();
@@ -1249,7 +1275,7 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
         lds_barrier();
     }
 }
-template <int H, int MT, bool SAVE, bool SP, bool FK = false>
+template <int H, int MT, bool SAVE, bool SP, int FK = 0>
 __global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_coord(Layout lay, Work w, Dims d, LayerW lw, int layer, TrainSave sv) {
     __shared__ __attribute__((aligned(16))) EdgeLds<H, MT, FK> L;
     edge_coord_body<H, MT, SAVE, SP, FK>(L, lay, w, d, lw, layer, sv);
@@ -1434,16 +1460,26 @@ template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, in
 // 32-row sampler tiles on the split engine: full-K planes (one build, one GEMM per tile; see cmdgen_split.h) unless CMDGEN_EDGE_FULLK=0
 static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.edge_mt != 32) return false;
-    if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                          a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
-    else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, true>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
+    const LayerW& lw = a.layers[unit_of(a, l)];
+    if (a.half_engine && lw.W2.wh) {
+        if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<256, 32, false, true, 2>), dim3(a.edge_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw, l, a.ablate, TrainSave{}, a.live_thr);
+        else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, 2>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, lw, l, a.ablate, TrainSave{}, a.live_thr);
+    } else {
+        if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<256, 32, false, true, 3>), dim3(a.edge_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw, l, a.ablate, TrainSave{}, a.live_thr);
+        else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, 3>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, lw, l, a.ablate, TrainSave{}, a.live_thr);
+    }
     return true;
 }
 static bool launch_coord_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.coord_mt != 32) return false;
-    if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
-                                          a.layers[unit_of(a, l)], l, TrainSave{});
-    else hipLaunchKernelGGL((k_edge_coord<256, 32, false, true, true>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, TrainSave{});
+    const LayerW& lw = a.layers[unit_of(a, l)];
+    if (a.half_engine && lw.W7.wh) {
+        if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<256, 32, false, true, 2>), dim3(a.coord_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw, l, TrainSave{});
+        else hipLaunchKernelGGL((k_edge_coord<256, 32, false, true, 2>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, lw, l, TrainSave{});
+    } else {
+        if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<256, 32, false, true, 3>), dim3(a.coord_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw, l, TrainSave{});
+        else hipLaunchKernelGGL((k_edge_coord<256, 32, false, true, 3>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, lw, l, TrainSave{});
+    }
     return true;
 }
 template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
