@@ -46,11 +46,23 @@ from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets  # n
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 # dense bf16 MFMA peak of the same guide ("~2.5 PF"): 256 CUs x 4 SIMDs x 1024 FLOP/clk (v_mfma_f32_32x32x16_bf16:
 # 32768 FLOP per 32 cycles) x 2.4 GHz.  The split engine EXECUTES six bf16 MFMA FLOPs per algorithmic fp32 FLOP.
-PEAK_BF16_MFMA_TFLOPS = 2516.6
+PEAK_BF16_MFMA_TFLOPS = 2516.6      # (the fp16 forms take the same cycles: same dense peak)
 SPLIT_MFMAS_PER_PRODUCT = 6
-# the ceiling of a kernel that runs on the split engine, in ALGORITHMIC fp32 FLOP/s: the bf16 pipe's dense peak / 6
+# the ceiling of a kernel that runs on the three-piece bf16 split, in ALGORITHMIC fp32 FLOP/s: the pipe's dense peak / 6 (rounds 2-4's ceiling)
 PEAK_SPLIT_FP32_EQUIV_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_MFMAS_PER_PRODUCT
+# ... and of a kernel on the HALF engine (round 5: two fp16 pieces per operand, THREE MFMAs per fp32 product): the same pipe / 3
+PEAK_HALF_FP32_EQUIV_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3
 PEAK_HBM_TBS = 8.0
+
+
+def peak_of(mfmas_per_product):
+    """ceiling in algorithmic fp32 FLOP/s of a kernel that executes `mfmas_per_product` 16-bit MFMAs per fp32 product (1: the fp32 instruction)"""
+    return PEAK_FP32_MFMA_TFLOPS if mfmas_per_product <= 1 else PEAK_BF16_MFMA_TFLOPS / mfmas_per_product
+
+
+def alg_bytes_per_evaluation(H, L, nodes, edges, n_params):
+    """B_alg of SURVEY section 8d: node state read + written once per block, 12 B of index + d0 per edge and block, every parameter once"""
+    return L * (nodes * (2 * H + 6) * 4.0 + 12.0 * edges) + 4.0 * n_params
 
 
 def bounded_config(residue_nf, T):
@@ -230,23 +242,28 @@ def kernel_table(h, prof, pc, H, L, nl_tot):
     flop_launch = {'edge_msg': 2.0 * (H * H + H) * units['edge_msg'],
                    'node': node_flop_per_launch(H, L, units['node'], nl_tot, False),
                    'edge_coord': coord_flop_per_launch(H, L, units['edge_coord'], pc['nodes'] / ev, False)}
-    launch_cfg = {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid', 'gemm_split', 'node16_split', 'node16w', 'node64')}
+    launch_cfg = {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid', 'gemm_split', 'half_engine', 'node16_split', 'node16w', 'node64',
+                                           'msg_mfmas_per_product', 'node_mfmas_per_product', 'coord_mfmas_per_product')}
     # node64: the 64-row planes node kernel took the launches (kernels_node64.hip; chosen per layout by tile count)
     mt_of = {'edge_msg': launch_cfg['edge_mt'], 'node': 64 if launch_cfg['node64'] else launch_cfg['node_mt'], 'edge_coord': launch_cfg['coord_mt']}
-    on_split = {k: bool(launch_cfg['gemm_split']) and mt_of[k] >= 32 for k in mt_of}
-    on_split['node'] = on_split['node'] or bool(launch_cfg['node16_split'] and mt_of['node'] == 16)
+    # the matrix engine each kernel ran on, as the library's launchers resolve it: MFMAs per fp32 product (1 / 6 / 3)
+    mpp = {'edge_msg': launch_cfg['msg_mfmas_per_product'], 'node': launch_cfg['node_mfmas_per_product'], 'edge_coord': launch_cfg['coord_mfmas_per_product']}
     per_kernel = {}
     for k, (ms_k, n_k) in prof.items():
         avg = ms_k / max(n_k, 1)
         tf = (flop_launch[k] / (avg * 1e-3) / 1e12) if avg > 0 else 0.0
-        peak = PEAK_SPLIT_FP32_EQUIV_TFLOPS if on_split[k] else PEAK_FP32_MFMA_TFLOPS
+        peak = peak_of(mpp[k])
+        ins = 'v_mfma_f32_16x16x32_' if mt_of[k] == 16 else 'v_mfma_f32_32x32x16_'
         per_kernel[k] = {'total_ms': ms_k, 'launches': n_k, 'avg_launch_ms': avg, 'flop_per_launch': flop_launch[k],
-                         'tflops': tf, 'rows_per_tile': mt_of[k],
-                         'mfma': ('v_mfma_f32_16x16x32_bf16' if mt_of[k] == 16 else 'v_mfma_f32_32x32x16_bf16') + ' x6 per fp32 product (split engine)' if on_split[k]
-                                 else ('v_mfma_f32_16x16x4_f32' if mt_of[k] == 16 else 'v_mfma_f32_32x32x2_f32'),
-                         # the ceiling of the pipe the kernel executes on, in algorithmic fp32 FLOP/s: the bf16 pipe's dense peak / 6
-                         # for split-engine kernels (six bf16 MFMAs per fp32 product), the fp32 instruction's otherwise
-                         'peak': peak, 'frac': tf / peak, 'frac_of_fp32_instruction_peak': tf / PEAK_FP32_MFMA_TFLOPS}
+                         'tflops': tf, 'rows_per_tile': mt_of[k], 'mfmas_per_fp32_product': mpp[k],
+                         'mfma': (ins + 'f16 x3 per fp32 product (half engine: two fp16 pieces per operand)' if mpp[k] == 3 else
+                                  ins + 'bf16 x6 per fp32 product (three bf16 pieces per operand)' if mpp[k] == 6 else
+                                  ('v_mfma_f32_16x16x4_f32' if mt_of[k] == 16 else 'v_mfma_f32_32x32x2_f32')),
+                         # the ceiling of the pipe the kernel executes on, in algorithmic fp32 FLOP/s: the 16-bit pipe's dense peak / (MFMAs per
+                         # fp32 product) for the split engines, the fp32 instruction's otherwise - so no `frac` can exceed 1.  A kernel that moves from
+                         # six to three MFMAs per product doubles its ceiling: `frac_of_six_mfma_ceiling` keeps rounds 2-4's yardstick (419.4 TF)
+                         'peak': peak, 'frac': tf / peak, 'frac_of_six_mfma_ceiling': tf / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
+                         'frac_of_fp32_instruction_peak': tf / PEAK_FP32_MFMA_TFLOPS}
     dom = max(per_kernel, key=lambda k: per_kernel[k]['total_ms'])
     return per_kernel, dom, launch_cfg, units
 
@@ -254,10 +271,10 @@ def kernel_table(h, prof, pc, H, L, nl_tot):
 KERNEL_NAMES = {'edge_msg': 'k_edge_msg (GCL.edge_model + attention + segment sum)',
                 'node': 'k_node (GCL.node_model + P_c|Q_c projections + P|Q of the next block)',
                 'edge_coord': 'k_edge_coord (EquivariantUpdate.coord_model)'}
-PER_KERNEL_KEYS = ('total_ms', 'avg_launch_ms', 'tflops', 'flop_per_launch', 'rows_per_tile', 'mfma', 'peak', 'frac', 'frac_of_fp32_instruction_peak')
+PER_KERNEL_KEYS = ('total_ms', 'avg_launch_ms', 'tflops', 'flop_per_launch', 'rows_per_tile', 'mfmas_per_fp32_product', 'mfma', 'peak', 'frac', 'frac_of_six_mfma_ceiling', 'frac_of_fp32_instruction_peak')
 
 
-def chain_record(cfg, sd, pb, K, dev, stream, use_graph, prof_steps=0, gemm=None):
+def chain_record(cfg, sd, pb, K, dev, stream, use_graph, prof_steps=0, gemm=None, warm_K=None):
     """One warm chain (captures the step graph), one timed chain of K posterior steps on a fresh handle; optionally a short
     eager chain with per-launch events for the dominant kernel's roofline.  -> dict"""
     H, L, dyn = cfg.hidden_nf, cfg.n_layers, cfg.joint_nf + 1
@@ -269,7 +286,7 @@ def chain_record(cfg, sd, pb, K, dev, stream, use_graph, prof_steps=0, gemm=None
     h.set_layout(pb.num_nodes_phar, pb.size)
     px, poh = torch.from_numpy(pb.x).to(dev), torch.from_numpy(pb.one_hot).to(dev)
     with torch.cuda.stream(stream):
-        h.sample_chain(px, poh, K, noise=None, seed=11, pocket_ids=pb.pocket_index, use_graph=use_graph)
+        h.sample_chain(px, poh, warm_K or K, noise=None, seed=11, pocket_ids=pb.pocket_index, use_graph=use_graph)     # (captures the step graph: K-independent)
         torch.cuda.synchronize(dev)
         h.reset_counters()
         t0 = time.perf_counter()
@@ -284,8 +301,12 @@ def chain_record(cfg, sd, pb, K, dev, stream, use_graph, prof_steps=0, gemm=None
         rec = {'pockets': B, 'posterior_steps': K, 'value': B * (K + 1) / dt, 'unit': 'pocket-steps/s',
                'us_per_denoising_step': 1e6 * dt / (K + 1), 'edges_per_pocket_eval': c['edges'] / ev / B,
                'coord_edges_per_pocket_eval': c['edges_phar'] / ev / B, 'edges_per_s': c['edges'] / dt,
-               'whole_step_alg_tflops': f_alg / dt / 1e12, 'whole_job_frac': f_alg / dt / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
+               'whole_step_alg_tflops': f_alg / dt / 1e12,
+               # whole job against the ceiling of the engine its tile kernels run on (below, once the engines are known) and against rounds 2-4's
+               'whole_job_frac_of_six_mfma_ceiling': f_alg / dt / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
                'whole_job_frac_of_fp32_instruction_peak': f_alg / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+               # SURVEY 8d's byte view: algorithmic bytes (node state once per block, 12 B per edge, the parameters once) / wall / 8 TB/s - not the binding roofline
+               'hbm_fraction': alg_bytes_per_evaluation(H, L, c['nodes'] / ev, c['edges'] / ev, sum(int(np.prod(v.shape)) for v in sd.values())) * ev / dt / (PEAK_HBM_TBS * 1e12),
                'reference_work_tflops': f_ref / dt / 1e12,       # the reference's FLOPs of these evaluations per second (not a pipe fraction: dead work is skipped)
                'chain_status': st,
                # share of the reference's per-block edge / node-row work this chain did NOT execute because nobody reads its result
@@ -301,10 +322,15 @@ def chain_record(cfg, sd, pb, K, dev, stream, use_graph, prof_steps=0, gemm=None
             rec['launch'] = launch_cfg
             rec['roofline'] = {'bound': 'mfma', 'kernel': KERNEL_NAMES[dom], 'achieved': per_kernel[dom]['tflops'], 'peak': per_kernel[dom]['peak'],
                                'unit': 'TFLOP/s', 'frac': per_kernel[dom]['frac'], 'mfma': per_kernel[dom]['mfma'],
+                               'frac_of_six_mfma_ceiling': per_kernel[dom]['frac_of_six_mfma_ceiling'],
                                'frac_of_fp32_instruction_peak': per_kernel[dom]['frac_of_fp32_instruction_peak'],
                                'avg_launch_ms': per_kernel[dom]['avg_launch_ms'], 'flop_per_launch': per_kernel[dom]['flop_per_launch'],
                                'units_per_launch': units[dom], 'timing': f'per-launch HIP events of an eager chain of {prof_steps} steps in the geometry the chain starts from',
                                'per_kernel': {k: {kk: v[kk] for kk in PER_KERNEL_KEYS} for k, v in per_kernel.items()}}
+            mpp_dom = per_kernel[dom]['mfmas_per_fp32_product']
+        else:
+            mpp_dom = h.query('msg_mfmas_per_product')
+        rec['whole_job_frac'] = f_alg / dt / 1e12 / peak_of(mpp_dom)       # against the ceiling of the engine the dominant kernel runs on
     h.close()
     return rec
 
@@ -389,7 +415,9 @@ def main(argv=None):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.dry_run_launch:
         return dry_run(args, world, rank)
-    hip_backend.DEFAULT_OPTIONS.update(hip_backend.parse_options(','.join(args.option)))     # every Handle below starts with them
+    # every Handle below starts with these: CMDGEN_OPTIONS=k=v,... of the environment (what the A/B scripts under tools/ export), then --option k=v
+    hip_backend.DEFAULT_OPTIONS.update(hip_backend.parse_options(os.environ.get('CMDGEN_OPTIONS', '')))
+    hip_backend.DEFAULT_OPTIONS.update(hip_backend.parse_options(','.join(args.option)))
     dist = None
     one_gpu = args.rehearse_on_one_gpu
     if world > 1 or args.force_dist:
@@ -548,7 +576,7 @@ def main(argv=None):
                             f'(sample_given_pocket: {evals_per_chain} network evaluations per pocket), '
                             + ('SHIPPED schedule (drifting chain, mostly dead work), ' if args.shipped_schedule else
                                'phar points inside the pocket for the whole chain (bounded schedule: noise_precision 0.1, norm_values [1, 0.25]), ') + f'fp32 '
-                            f'({"split-bf16 matrix engine on tiles of >= 32 rows: fp32-accurate" if launch_cfg["gemm_split"] else "fp32 MFMA"}); '
+                            f'({("half matrix engine (two fp16 pieces per operand, three MFMAs per fp32 product): fp32-accurate" if launch_cfg["half_engine"] else "split-bf16 matrix engine on tiles of >= 32 rows: fp32-accurate") if launch_cfg["gemm_split"] else "fp32 MFMA"}); '
                             f'one bench step = one such chain',
                 'pockets_per_gpu': B, 'timesteps': T, 'representation': rep,
                 'denoiser': f'EGNN hidden_nf={H} n_layers={L} joint_nf={cfg.joint_nf} cutoff={cfg.edge_cutoff}, '
@@ -584,12 +612,23 @@ def main(argv=None):
                 # product = six exact bf16 products on the bf16 pipe, cmdgen_split.h) - so no `frac` can exceed 1.  The
                 # fraction of the fp32 INSTRUCTION's peak (what round 2 reported) stays as `frac_of_fp32_instruction_peak`.
                 'mfma': per_kernel[dom]['mfma'], 'frac_of_fp32_instruction_peak': per_kernel[dom]['frac_of_fp32_instruction_peak'],
+                # round 5: the dominant kernels run on the HALF engine (three fp16 MFMAs per fp32 product): their ceiling is 2516.6 / 3 = 838.9 TF.
+                # The same achieved rate against rounds 2-4's ceiling (six MFMAs per product, 419.4 TF):
+                'frac_of_six_mfma_ceiling': per_kernel[dom]['frac_of_six_mfma_ceiling'], 'mfmas_per_fp32_product': per_kernel[dom]['mfmas_per_fp32_product'],
                 # `flop_per_launch` / `achieved` / `frac` count the work the kernel EXECUTED: since round 3 the last block of a conditional
                 # evaluation skips tiles whose output nobody reads.  Priced on the work the REFERENCE does in those launches
                 # (every row of every block - what rounds 1-2 reported, and what a recomputation from N, Nl and the launch time gives):
                 'frac_on_reference_work': (reference_flop_per_launch / (avg_ms * 1e-3) / 1e12 / per_kernel[dom]['peak']) if avg_ms > 0 else None,
                 'reference_flop_per_launch': reference_flop_per_launch,
-                'whole_job_frac': f_alg / elapsed / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,          # executed work (dead tiles are skipped since round 3)
+                'whole_job_frac': f_alg / elapsed / 1e12 / per_kernel[dom]['peak'],               # executed work against the dominant kernel's ceiling
+                'whole_job_frac_of_six_mfma_ceiling': f_alg / elapsed / 1e12 / PEAK_SPLIT_FP32_EQUIV_TFLOPS,
+                # SURVEY 8d's byte view: algorithmic bytes per evaluation (node state once per block, 12 B per edge, the parameters once) / wall / 8 TB/s
+                'hbm_fraction': alg_bytes_per_evaluation(H, L, cnt['nodes'] / max(cnt['evaluations'], 1), cnt['edges'] / max(cnt['evaluations'], 1),
+                                                         sum(int(np.prod(v.shape)) for v in sd.values())) * cnt['evaluations'] / elapsed / (PEAK_HBM_TBS * 1e12),
+                # algorithmic bytes of ONE launch of the dominant kernel (rows it reads / writes once + index triples + one pass over its weights): `traffic` / this = wasted re-reads
+                'traffic_alg_bytes': {'edge_msg': units['edge_msg'] * 12.0 + (pc['nodes'] / p_ev) * 3 * H * 4.0 + 2.0 * H * H * 4,
+                                      'node': (pc['nodes'] / p_ev) * 7 * H * 4.0 + 7.0 * H * H * 4,
+                                      'edge_coord': units['edge_coord'] * 12.0 + (pc['nodes'] / p_ev) * 2 * H * 4.0 + 2.0 * H * H * 4}[dom],
                 'whole_job_reference_work_tflops': f_ref / elapsed / 1e12,                         # the reference's FLOPs of the same evaluations per second
                 'whole_job_frac_of_fp32_instruction_peak': f_alg / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 # the north-star also asks for the HBM view: PMC bytes per launch / launch time / 8 TB/s (not the binding roofline)
@@ -607,9 +646,9 @@ def main(argv=None):
                 result['config']['north_star_trained'] = ns
             # BASELINE configs[4]: 256 full-atom pockets (Np=366), 100 strided steps of the T-step model, bounded schedule
             cfg_f = bounded_config(11, T)
-            fa = chain_record(cfg_f, make_state_dict(cfg_f, seed=0), make_pockets(256, 'full-atom', n_phar=args.n_phar), 100, dev, stream,
-                              use_graph, prof_steps=6, gemm=args.gemm)
-            fa['workload'] = 'BASELINE.json configs[4]: 256 full-atom pockets (Np=366, Nl=15), 100 strided steps of the 1000-step model (bounded schedule)'
+            fa = chain_record(cfg_f, make_state_dict(cfg_f, seed=0), make_pockets(256, 'full-atom', n_phar=args.n_phar), T, dev, stream,
+                              use_graph, prof_steps=6, gemm=args.gemm, warm_K=16)
+            fa['workload'] = f'BASELINE.json configs[4] at its literal size: 256 full-atom pockets (Np=366, Nl=15), all {T} steps of the {T}-step model (bounded schedule), one chain'
             result['config']['fullatom_trained'] = fa
             # the same 64-pocket chain under the SHIPPED schedule: untrained weights drift out of the pocket, most edge work is dead and skipped -
             # an artefact of random weights, reported for completeness only (never the headline, never a vs_baseline)
@@ -624,6 +663,22 @@ def main(argv=None):
                 result['config']['fp32_instruction_engine'] = {k: f32[k] for k in ('value', 'unit', 'us_per_denoising_step', 'whole_job_frac_of_fp32_instruction_peak', 'edges_per_pocket_eval')}
             # BASELINE configs[3]'s per-GPU work: the training step
             result['config']['training_step'] = training_step_record(dev)
+            # the same numbers once more as FLAT scalars (a record that keeps only short values still shows them)
+            flat = result['config']
+            for tag, r in (('north_star', ns), ('fullatom', fa)):
+                if r is None:
+                    continue
+                flat[tag + '_value'] = round(r['value'], 1)
+                flat[tag + '_us_per_step'] = round(r['us_per_denoising_step'], 1)
+                flat[tag + '_whole_job_frac'] = round(r['whole_job_frac'], 4)
+                flat[tag + '_whole_frac_6mfma'] = round(r['whole_job_frac_of_six_mfma_ceiling'], 4)
+                flat[tag + '_dominant_frac'] = round(r['roofline']['frac'], 4)
+                flat[tag + '_dom_frac_6mfma'] = round(r['roofline']['frac_of_six_mfma_ceiling'], 4)
+                flat[tag + '_dead_edge_frac'] = round(r['dead_work_skipped']['edge_visits'], 4)
+                flat[tag + '_hbm_fraction'] = round(r['hbm_fraction'], 5)
+            ts = flat['training_step']
+            flat['train_ms_fp32'] = round(ts['fp32_results']['ms_per_step'], 3)
+            flat['train_ms_bf16_operands'] = round(ts['bf16_gemm_operands']['ms_per_step'], 3)
         if not args.no_cpu_baseline and n_gpus == 1:      # timed on rank 0 at N=1 only
             result['cpu_baseline'] = cpu_baseline(cfg, sd, B, rep, args.n_phar, args.cpu_seconds)
             cpu_v = result['cpu_baseline']['value']

@@ -1334,6 +1334,25 @@ extern "C" int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16) {
     return CMDGEN_OK;
 }
 
+// MFMAs per fp32 product of the three tile kernels of an evaluation, as the launchers pick them: 1 = the fp32 matrix instruction, 6 = three bf16
+// pieces per operand, 3 = the half engine (two fp16 pieces).  which: 0 messages, 1 node, 2 coordinates.
+static int mfmas_per_product(const EvalLaunch& a, int which) {
+    const LayerW& lw = a.layers[0];
+    const bool sampler = !a.save, h256 = a.d.H == 256;
+    if (which == 1) {
+        if (h256 && a.split && sampler && a.node64 && lw.W3.ws) return a.half_engine && lw.W3.wh ? 3 : 6;
+        if (h256 && a.node_mt == 16 && a.split16 && a.node16w && sampler && lw.W3.ws16) return a.half_engine && lw.W3.wh16 ? 3 : 6;
+        if ((a.split && a.node_mt >= 32) || (a.split16 && a.node_mt == 16)) return 6;
+        return 1;
+    }
+    const int mt = which == 0 ? a.edge_mt : a.coord_mt;
+    const WPack& W = which == 0 ? lw.W2 : lw.W7;
+    if (mt == 128 && h256 && a.split && sampler && W.ws) return a.half_engine && W.wh ? 3 : 6;
+    if (a.edge_fullk && sampler && a.split && h256 && mt == 32) return a.half_engine && W.wh ? 3 : 6;
+    if (a.split && mt >= 32) return 6;
+    return 1;
+}
+
 extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     if (!h || !key || !value) return CMDGEN_EINVAL;
     if (!h->have_layout) return fail(h, CMDGEN_ESTATE, "no batch layout (cmdgen_set_layout)");
@@ -1346,6 +1365,9 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     else if (k == "coord_grid") *value = a.coord_grid;
     else if (k == "gemm_split") *value = a.split;
     else if (k == "half_engine") *value = a.split ? a.half_engine : 0;
+    else if (k == "msg_mfmas_per_product") *value = mfmas_per_product(a, 0);
+    else if (k == "node_mfmas_per_product") *value = mfmas_per_product(a, 1);
+    else if (k == "coord_mfmas_per_product") *value = mfmas_per_product(a, 2);
     else if (k == "node16_split") *value = a.split16;
     else if (k == "node64") *value = a.node64;
     else if (k == "node16w") *value = a.node16w;

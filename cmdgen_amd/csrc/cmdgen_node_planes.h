@@ -39,22 +39,26 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const nfr
     // one group = one load and the two MFMAs of one row half (pieces AI x BI), pinned: the loads issue in the shadow of the MFMAs
     // instead of in a burst between k-blocks (which left the matrix pipe idle ~100 cycles per block).  Small terms first.
 #define NG_GRP(LOAD, M, AS, BS, AI, BI) LOAD NG_MF(M, 0, AS, AI, BS, BI) NG_MF(M, 1, AS, AI, BS, BI) __builtin_amdgcn_sched_barrier(0);
-#define NG_BLOCK(I) { constexpr int AS_ = (I) & 1, AN_ = ((I) + 1) & 1, BS_ = (I) & (NRING - 1), BN_ = ((I) + NRING - 1) & (NRING - 1);  \
+#define NG_HEAD(I) constexpr int AS_ = (I) & 1, AN_ = ((I) + 1) & 1, BS_ = (I) & (NRING - 1), BN_ = ((I) + NRING - 1) & (NRING - 1);  \
         const int ka_ = kb + (I) + 1, kq_ = kb + (I) + NRING - 1;                                             \
         const bool in_ = kq_ < KB16; const unsigned ko_ = (unsigned)(in_ ? kq_ : kq_ - KB16) * KBS;           \
-        const nfrag* q0_ = (in_ ? cur[0] : nxt[0]) + ko_; const nfrag* q1_ = (in_ ? cur[1] : nxt[1]) + ko_; \
-        if constexpr (NPL == 3 && NMT == 2) {                                                                 \
+        const nfrag* q0_ = (in_ ? cur[0] : nxt[0]) + ko_; const nfrag* q1_ = (in_ ? cur[1] : nxt[1]) + ko_;
+#if N64_NPL == 3
+#define NG_BLOCK(I) { NG_HEAD(I)                                                                              \
+        if constexpr (NMT == 2) {                                                                             \
         NG_GRP(NG_LA(AN_, ka_, 0, 2), 0, AS_, BS_, 2, 0) NG_GRP(NG_LA(AN_, ka_, 1, 2), 1, AS_, BS_, 2, 0)       \
         NG_GRP(NG_LA(AN_, ka_, 0, 1), 0, AS_, BS_, 1, 1) NG_GRP(NG_LA(AN_, ka_, 1, 1), 1, AS_, BS_, 1, 1)       \
         NG_GRP(NG_LA(AN_, ka_, 0, 0), 0, AS_, BS_, 0, 2) NG_GRP(NG_LA(AN_, ka_, 1, 0), 1, AS_, BS_, 0, 2)       \
         NG_GRP(NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 1, 0) NG_GRP(NG_LB(BN_, kq_, 0, 1), 1, AS_, BS_, 1, 0)       \
         NG_GRP(NG_LB(BN_, kq_, 0, 2), 0, AS_, BS_, 0, 1) NG_GRP(NG_LB(BN_, kq_, 1, 0), 1, AS_, BS_, 0, 1)       \
         NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 0) NG_GRP(NG_LB(BN_, kq_, 1, 2), 1, AS_, BS_, 0, 0)       \
-        } else if constexpr (NPL == 3) {    /* 32-row tile: twelve MFMAs, nine loads */                       \
+        } else {    /* 32-row tile: twelve MFMAs, nine loads */                                               \
         NG_GRP(NG_LA(AN_, ka_, 0, 2) NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 2, 0) NG_GRP(NG_LA(AN_, ka_, 0, 1) NG_LB(BN_, kq_, 0, 1), 0, AS_, BS_, 1, 1) \
         NG_GRP(NG_LA(AN_, ka_, 0, 0) NG_LB(BN_, kq_, 0, 2), 0, AS_, BS_, 0, 2) NG_GRP(NG_LB(BN_, kq_, 1, 0), 0, AS_, BS_, 1, 0) \
-        NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 1) NG_GRP(NG_LB(BN_, kq_, 1, 2), 0, AS_, BS_, 0, 0)       \
-        } else if constexpr (NMT == 2) {    /* half engine, 64 rows: twelve MFMAs (a1 b0, a0 b1, a0 b0), eight loads */ \
+        NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 1) NG_GRP(NG_LB(BN_, kq_, 1, 2), 0, AS_, BS_, 0, 0) } }
+#else
+#define NG_BLOCK(I) { NG_HEAD(I)                                                                              \
+        if constexpr (NMT == 2) {           /* half engine, 64 rows: twelve MFMAs (a1 b0, a0 b1, a0 b0), eight loads */ \
         NG_GRP(NG_LA(AN_, ka_, 0, 1), 0, AS_, BS_, 1, 0) NG_GRP(NG_LA(AN_, ka_, 1, 1), 1, AS_, BS_, 1, 0)       \
         NG_GRP(NG_LA(AN_, ka_, 0, 0) NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 0, 1) NG_GRP(NG_LA(AN_, ka_, 1, 0) NG_LB(BN_, kq_, 0, 1), 1, AS_, BS_, 0, 1) \
         NG_GRP(NG_LB(BN_, kq_, 1, 0), 0, AS_, BS_, 0, 0) NG_GRP(NG_LB(BN_, kq_, 1, 1), 1, AS_, BS_, 0, 0)       \
@@ -62,6 +66,7 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const nfr
         NG_GRP(NG_LA(AN_, ka_, 0, 1) NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 1, 0)                                  \
         NG_GRP(NG_LA(AN_, ka_, 0, 0) NG_LB(BN_, kq_, 0, 1) NG_LB(BN_, kq_, 1, 0), 0, AS_, BS_, 0, 1)            \
         NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 0) } }
+#endif
     NG_LOADA(0, 0)
 #pragma unroll 1
     for (int kb = 0; kb < KB16; kb += NRING) { NG_BLOCK(0) NG_BLOCK(1) NG_BLOCK(2) NG_BLOCK(3) }
@@ -71,23 +76,28 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const nfr
 #undef NG_MF
 #undef NG_GRP
 #undef NG_BLOCK
+#undef NG_HEAD
 }
 
 // two values of the SAME column and two rows (an accumulator register pair) -> the three planes: one packed conversion per piece,
 // low half to row ra, high half to row rb
 __device__ __forceinline__ void n64_split_store2(unsigned short* planes, int NPE, int off_a, int off_b, float va, float vb) {
-    if constexpr (NPL == 3) {
+#if N64_NPL == 3
+    {
         uint32_t p0, p1, p2;
         split3_pair(va, vb, p0, p1, p2);
         planes[off_a] = (unsigned short)p0;            planes[off_b] = (unsigned short)(p0 >> 16);
         planes[NPE + off_a] = (unsigned short)p1;      planes[NPE + off_b] = (unsigned short)(p1 >> 16);
         planes[2 * NPE + off_a] = (unsigned short)p2;  planes[2 * NPE + off_b] = (unsigned short)(p2 >> 16);
-    } else {
+    }
+#else
+    {
         uint32_t p0, p1;
         split2_pair(va, vb, p0, p1);
         planes[off_a] = (unsigned short)p0;            planes[off_b] = (unsigned short)(p0 >> 16);
         planes[NPE + off_a] = (unsigned short)p1;      planes[NPE + off_b] = (unsigned short)(p1 >> 16);
     }
+#endif
 }
 
 // a 32-column tile of a packed split weight ([nt][K/16][NPL pieces][64 lanes] x 16 bytes) at k-block kb0: wave-uniform pointer

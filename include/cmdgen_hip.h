@@ -438,7 +438,9 @@ int cmdgen_debug_stamps(cmdgen_handle* h, uint64_t* out64, int32_t reset);
 /* Launch configuration in force for the current layout (measurement aid): key = "node_mt" | "edge_mt" | "coord_mt"
  * (rows per tile of the three MFMA kernels), "edge_grid" | "coord_grid" (workgroups of the persistent-style edge
  * kernels), "gemm_split" (the mode above), "node16_split", "node16w", "node64", "edge_fullk", "dead_skip" (as resolved from the
- * options and the layout), "train_edges" | "train_coord_edges" (edges of the last cmdgen_train_forward). */
+ * options and the layout), "half_engine" (the engine option as resolved: 1 = kernels with a half form use it), "msg_mfmas_per_product" |
+ * "node_mfmas_per_product" | "coord_mfmas_per_product" (1: the fp32 matrix instruction, 6: three bf16 pieces per operand, 3: two fp16 pieces - the
+ * engine the three tile kernels of the current layout run on), "train_edges" | "train_coord_edges" (edges of the last cmdgen_train_forward). */
 int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value);
 
 /* Steady-state timing of one network evaluation (bench.py's trained-geometry micro-benchmark): `graph_len`
