@@ -12,6 +12,9 @@ constexpr int H = 256;
 #ifndef CMDGEN_E128_VPRIO
 #define CMDGEN_E128_VPRIO 0
 #endif
+#ifndef CMDGEN_E128_AHEAD
+#define CMDGEN_E128_AHEAD 1     // the first 64 rows of the next quarter are gathered before the GEMM over this one (half engine)
+#endif
 #ifndef CMDGEN_E128_MT
 #define CMDGEN_E128_MT 128
 #endif
@@ -40,6 +43,7 @@ struct alignas(16) E128Lds {
     float part[4][MTL];                          // the four waves' partial row dots
     float gw[4][MTL];                            // gate (message kernel) / tanh(phi) * range (coordinate kernel) of each row, one copy per wave (each wave fills and reads its own: no barrier)
     float wrd[2 * H];                           // radial / d0 columns of the first layer
+    float colv[2 * H];                          // per-column constants of the epilogue: bias of the second layer (times the engine's scale), the row dot's weight vector
     int segrow[MTL];                             // receiver of each segment of the tile
     int segstart[MTL + 1];                       // first row of each segment (coordinate kernel)
     unsigned char seg[MTL];                      // segment index of each row (255 beyond the tile's end)
@@ -49,13 +53,17 @@ struct alignas(16) E128Lds {
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// lazily updated positions, as kernels_egnn.hip forms them (same expression, same bits)
+// lazily updated positions, as kernels_egnn.hip forms them (same expression, same bits).  Branch-free: the loads of a pocket node and of a
+// moving node are the same instructions with other addresses (a pocket node adds a zero), so the four position loads of an edge leave together
+// instead of one divergent path after the other (each with its own round trip).
 __device__ __forceinline__ float4 pos_lazy(const Layout& lay, const Work& w, const Dims& d, int n, int layer) {
-    if (n >= lay.Nm) return w.XP[n - lay.Nl];
-    if (layer == 0) return w.X0[n];
-    const float4 p = (layer == 1) ? w.X0[n] : w.XL[(size_t)(layer - 1) * lay.Nm + n];
-    const float4 a = w.ACC[(size_t)(layer - 1) * lay.Nm + n];
-    const float dv = agg_div(w, d, n);
+    const bool mov = n < lay.Nm;
+    if (layer == 0) return *(mov ? w.X0 + n : w.XP + (n - lay.Nl));
+    const float4* pp = mov ? (layer == 1 ? w.X0 + n : w.XL + ((size_t)(layer - 1) * lay.Nm + n)) : w.XP + (n - lay.Nl);
+    const float4 p = *pp;
+    float4 a = w.ACC[(size_t)(layer - 1) * lay.Nm + (mov ? n : 0)];
+    const float dv = d.agg_mean ? w.adiv[mov ? n : 0] : d.norm_factor;
+    if (!mov) return p;
     return make_float4(p.x + a.x / dv, p.y + a.y / dv, p.z + a.z / dv, 0.f);
 }
 __device__ __forceinline__ float4 pos_mat(const Layout& lay, const Work& w, int n, int layer) {
@@ -68,10 +76,20 @@ __device__ __forceinline__ float4 pos_mat(const Layout& lay, const Work& w, int 
 // gather of a batch and its use are separate calls so that a batch can be in flight during the GEMM over the previous quarter.
 // Rows beyond the tile's end repeat its last row (finite values in rows nobody reads; no divergent code).  Thread -> 16 bytes of a quarter
 // row (16 lanes per row, 4 consecutive rows per wave instruction: edges of one receiver share their P row's cache lines).
-struct Gath { float4 p[4], q[4]; };
+// The rows are addressed through buffer descriptors (base in scalar registers, one 32-bit byte offset per lane: ONE vector instruction per
+// address, row << 10 | column bytes, instead of the three 64-bit adds of a flat pointer - 30 loads per thread and quarter).
+typedef unsigned gq4 __attribute__((ext_vector_type(4)));
+struct Gath { gq4 p[4], q[4]; };
+struct RowBufs { __amdgpu_buffer_rsrc_t P, Q; };
+__device__ __forceinline__ RowBufs row_bufs(const float* P, const float* Q, int n_rows) {
+    RowBufs b;
+    const int bytes = n_rows * (H * 4);                                  // (< 2 GiB: 2M nodes of 1 KiB rows)
+    b.P = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, bytes, 0x00020000);
+    b.Q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Q), 0, bytes, 0x00020000);
+    return b;
+}
 template <int NMT>
-__device__ __forceinline__ void gather_half(const E128Lds& L, const int tid, const int q, const int half, const int ne, const float* __restrict__ P,
-                                            const float* __restrict__ Q, Gath& g) {
+__device__ __forceinline__ void gather_half(const E128Lds& L, const int tid, const int q, const int half, const int ne, const RowBufs& rb, Gath& g) {
     const int c4 = tid & 15, rsub = tid >> 4;
     const unsigned cofs = (unsigned)(q * KQ + 4 * c4) * 4u;
 #pragma unroll
@@ -79,8 +97,8 @@ __device__ __forceinline__ void gather_half(const E128Lds& L, const int tid, con
         if (half * 64 + ps * 16 < 32 * NMT) {
             const int e = min(half * 64 + ps * 16 + rsub, ne - 1);
             const int2 rc = *reinterpret_cast<const int2*>(&L.e[e]);
-            g.p[ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(P) + ((unsigned)rc.x * (unsigned)(H * 4) + cofs));
-            g.q[ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Q) + ((unsigned)rc.y * (unsigned)(H * 4) + cofs));
+            g.p[ps] = __builtin_amdgcn_raw_buffer_load_b128(rb.P, (int)(((unsigned)rc.x << 10) + cofs), 0, 0);
+            g.q[ps] = __builtin_amdgcn_raw_buffer_load_b128(rb.Q, (int)(((unsigned)rc.y << 10) + cofs), 0, 0);
         }
 }
 template <int NMT>
@@ -94,17 +112,25 @@ __device__ __forceinline__ void store_half(E128Lds& L, const int tid, const int 
             const int e = half * 64 + ps * 16 + rsub;
             const float2 rd = *reinterpret_cast<const float2*>(&L.e[min(e, ne - 1)].r);
             const float r = rd.x, d0 = rd.y;
-            const float4 a = make_float4(silu_f(g.p[ps].x + g.q[ps].x + wr4.x * r + wd4.x * d0), silu_f(g.p[ps].y + g.q[ps].y + wr4.y * r + wd4.y * d0),
-                                         silu_f(g.p[ps].z + g.q[ps].z + wr4.z * r + wd4.z * d0), silu_f(g.p[ps].w + g.q[ps].w + wr4.w * r + wd4.w * d0));
+#define G_F(V, I) __uint_as_float(V[ps][I])
+            const float4 a = make_float4(silu_f(G_F(g.p, 0) + G_F(g.q, 0) + wr4.x * r + wd4.x * d0), silu_f(G_F(g.p, 1) + G_F(g.q, 1) + wr4.y * r + wd4.y * d0),
+                                         silu_f(G_F(g.p, 2) + G_F(g.q, 2) + wr4.z * r + wd4.z * d0), silu_f(G_F(g.p, 3) + G_F(g.q, 3) + wr4.w * r + wd4.w * d0));
+#undef G_F
             if constexpr (NPL == 3) split_store4(L.planes, PE, e * PLDA + 4 * c4, a); else split_store4_half(L.planes, PE, e * PLDA + 4 * c4, a);
         }
+}
+
+// one 16-byte weight fragment: descriptor base (the wave's first 32-column tile) + lane * 16 + a scalar byte offset: no address arithmetic
+// in vector registers, one register (lane * 16) for every weight address of the kernel
+__device__ __forceinline__ efrag w_frag(const __amdgpu_buffer_rsrc_t rw, const int lane, const int soff) {
+    return __builtin_bit_cast(efrag, __builtin_amdgcn_raw_buffer_load_b128(rw, lane << 4, soff, 0));
 }
 
 // ---- one quarter of the tile product: acc[m][n] += planes(rows 32 m .., k-blocks 4 q .. 4 q + 3) x W^T for m < NMT.
 // bs[0] holds the weight fragments of k-block 4 q on entry and of k-block 4 q + 4 on exit (q < 3).  One load pinned beside every pair of MFMAs; per accumulator the six products of a k-block keep the
 // order of cmdgen_split.h (small terms first).  wb: the wave's first 32-column tile, k-block 0, this lane.
 template <int NMT>
-__device__ __forceinline__ void gemm_quarter(const unsigned short* planes, const int lane, const int q, const efrag* __restrict__ wb,
+__device__ __forceinline__ void gemm_quarter(const unsigned short* planes, const int lane, const int q, const __amdgpu_buffer_rsrc_t rw,
                                              sf32x16 (&acc)[NMT][2], efrag (&bs)[2][2][NPL]) {
     const unsigned short* ap = planes + (lane & 31) * PLDA + (lane >> 5) * 8;
     efrag a[2][NPL];
@@ -112,7 +138,7 @@ __device__ __forceinline__ void gemm_quarter(const unsigned short* planes, const
     for (int s = 0; s < NPL; ++s) a[0][s] = *reinterpret_cast<const efrag*>(ap + s * PE);
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
-        const efrag* qn = wb + (unsigned)((4 * q + kq + 1) & 15) * KBS;         // next k-block (wave-uniform)
+        const int qn = (int)(((unsigned)((4 * q + kq + 1) & 15) * KBS) << 4);    // byte offset of the next k-block in the wave's weight tiles (scalar)
         constexpr int NBL = 2 * NPL;                                            // weight loads per k-block: (n, s) = (i & 1, i >> 1)
         constexpr int BPG = (NBL + NMT - 1) / NMT;                              // ... per row group: all of them early in the k-block
 #pragma unroll
@@ -124,7 +150,7 @@ __device__ __forceinline__ void gemm_quarter(const unsigned short* planes, const
             const int b0 = m * BPG;                                             // first weight load of this group
 #define E_MF(N, AI, BI) acc[m][N] = E128_MFMA(a[cs][AI], bs[bc][N][BI], acc[m][N]);
 #define E_LA(S) if (more_a) a[nx][S] = *reinterpret_cast<const efrag*>(an + (S) * PE);
-#define E_LB(I) if ((I) < NBL && (I) >= b0 && (I) < b0 + BPG && more_b) bs[bn][(I) & 1][(I) >> 1] = qn[(unsigned)((I) & 1) * NS + (unsigned)((I) >> 1) * 64u];
+#define E_LB(I) if ((I) < NBL && (I) >= b0 && (I) < b0 + BPG && more_b) bs[bn][(I) & 1][(I) >> 1] = w_frag(rw, lane, qn + (int)((((unsigned)((I) & 1) * NS + (unsigned)((I) >> 1) * 64u)) << 4));
             if constexpr (NPL == 3) {
                 E_LA(2) E_MF(0, 2, 0) E_MF(1, 2, 0) __builtin_amdgcn_sched_barrier(0);
                 E_LA(1) E_MF(0, 1, 1) E_MF(1, 1, 1) __builtin_amdgcn_sched_barrier(0);
@@ -173,8 +199,8 @@ __device__ __forceinline__ float silu_scaled(float a, float c1, float sc) {
 // ------------------------------------------------------------------------------------------------------------------------------
 // One tile of NMT x 32 rows (ne of them listed) after its index phase: K in four build -> GEMM passes, then the epilogue in registers.
 struct TileCtx {
-    const float* P; const float* Q; const efrag* wb;
-    float bias0, bias1, hv0, hv1, ba0;
+    RowBufs rb; __amdgpu_buffer_rsrc_t rw;     // P / Q rows; the wave's two 32-column tiles of the split weight
+    float ba0;
     float c1, sc;                   // SiLU of a scaled accumulator: x = acc / sc;  c1 = -log2(e) / sc
     int colw, layer;
 };
@@ -184,28 +210,38 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
     int tid = threadIdx.x & 255;            // thread of the tile's four waves (the phase-locked driver runs two tiles per workgroup)
     asm volatile("" : "+v"(tid));           // opaque: per-lane addresses derived from it are recomputed per tile instead of being hoisted out of the tile loop and spilled
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float* __restrict__ P = c.P; const float* __restrict__ Q = c.Q; const efrag* __restrict__ wb = c.wb;
-    const float bias0 = c.bias0, bias1 = c.bias1, hv0 = c.hv0, hv1 = c.hv1, ba0 = c.ba0, c1 = c.c1, sc = c.sc;
+    const RowBufs rb = c.rb; const __amdgpu_buffer_rsrc_t rw = c.rw;
+    const float ba0 = c.ba0, c1 = c.c1, sc = c.sc;
+    const int colw = 64 * wave + (lane & 31);
     const int layer = c.layer;
 #if CMDGEN_STAMPS == 6
 #define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+#define STAMPB(i) do {} while (0)
+#elif CMDGEN_STAMPS == 9      // second diagnostic mode: work and wait of the index phase and of the epilogue's pieces (tools/e128_stamps.py --mode 9)
+#define STAMPB(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+#define STAMP(i) do {} while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define STAMPB(i) do {} while (0)
 #endif
-    sf32x16 acc[NMT][2];                                                                // start from the bias of the layer (b2 / b7)
+    sf32x16 acc[NMT][2];                                                                // start from the bias of the layer (b2 / b7; staged in LDS: not a register held across the tile loop)
+    const float bias0 = L.colv[colw], bias1 = L.colv[colw + 32];
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[m][0][r] = bias0; acc[m][1][r] = bias1; }
-    // ---------------- four build -> GEMM passes over a quarter of K each.  (Gathering the next quarter's first rows BEFORE the GEMM over
-    // this one was measured and lost: the 32 extra live registers spill around the GEMM and its waits cover the gather; profiles/r04_c.)
+    // ---------------- four build -> GEMM passes over a quarter of K each.  The first 64 rows of the NEXT quarter are gathered before the GEMM
+    // over this one and land during it (32 registers; the half engine's GEMM leaves them - on the three-piece bf16 split they spilled, profiles/r04_c);
+    // the other 64 rows are requested at the start of the build and land while the first batch is turned into planes.
+    constexpr bool AHEAD = NPL == 2 && CMDGEN_E128_AHEAD != 0;
+    Gath g0;
+    if constexpr (AHEAD) gather_half<NMT>(L, tid, 0, 0, ne, rb, g0);
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
-        Gath g0;
-        gather_half<NMT>(L, tid, q, 0, ne, P, Q, g0);
+        if constexpr (!AHEAD) gather_half<NMT>(L, tid, q, 0, ne, rb, g0);
         if constexpr (NMT > 2) {
             Gath g1;
-            gather_half<NMT>(L, tid, q, 1, ne, P, Q, g1);          // both batches in flight, the second lands while the first is consumed
+            gather_half<NMT>(L, tid, q, 1, ne, rb, g1);
             store_half<NMT>(L, tid, q, 0, ne, g0);
             store_half<NMT>(L, tid, q, 1, ne, g1);
         } else {
@@ -214,14 +250,17 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
         STAMP(6);
         lds_barrier();
         STAMP(1);
+        if constexpr (AHEAD) if (q < 3) gather_half<NMT>(L, tid, q + 1, 0, ne, rb, g0);
         __builtin_amdgcn_s_setprio(CMDGEN_E128_GPRIO);
-        gemm_quarter<NMT>(L.planes, lane, q, wb, acc, bs);
+        gemm_quarter<NMT>(L.planes, lane, q, rw, acc, bs);
         __builtin_amdgcn_s_setprio(CMDGEN_E128_VPRIO);
         STAMP(7);
         lds_barrier();                                                                  // every wave is done reading the planes
         STAMP(2);
     }
+    STAMPB(2);
     // ---------------- epilogue in registers: SiLU, the row dot (attention logit / coord_mlp.4)
+    const float hv0 = L.colv[H + colw], hv1 = L.colv[H + colw + 32];
 #pragma unroll
     for (int mh = 0; mh < (NMT + 1) / 2; ++mh) {          // two row tiles (32 values per lane) at a time
         float pl[32];
@@ -243,8 +282,10 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
         const int l5 = lane & 31;
         L.part[wave][E_ROW(2 * mh + (l5 >> 4), l5 & 15)] = o;
     }
+    STAMPB(3);
     lds_barrier();
     STAMP(3);
+    STAMPB(4);
     // every wave forms the gates of all rows for itself (two rows per lane) and keeps them in its own LDS strip: no barrier before their use
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -256,6 +297,7 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     STAMP(5);
+    STAMPB(5);
     if constexpr (COORD) {
         // ordered segment sums of the three components: one thread per (segment, component), rows in list order
         const int nseg = L.meta[0];
@@ -271,7 +313,7 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
         // gated messages and their ordered segment sum by receiver, in registers.  v_permlane32_swap_b32 on the register pair (column tile 0,
         // column tile 1) of an accumulator row group turns the 32 x 32 layout (lane half = rows +0 / +4) into one where EVERY lane of a
         // register holds the same row (lane = column 64 wave + lane): the tile's rows are then visited in list order by wave-uniform code, a
-        // receiver's sum is a chain of 64-lane FMAs (gate folded in) in ascending sender order like the reference's CPU scatter_add_
+        // receiver's sum is a chain of 64-lane adds of the gated messages in ascending sender order like the reference's CPU scatter_add_
         // (egnn_new.py:283), and a finished receiver leaves as one 256-byte row segment.  Segment starts are a 128-bit scalar mask.
         const int nseg = L.meta[0];
         const unsigned sm[4] = {(unsigned)__builtin_amdgcn_readfirstlane(L.smask[0]), (unsigned)__builtin_amdgcn_readfirstlane(L.smask[1]),
@@ -288,6 +330,21 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
             }
             ++sg; sum = 0.f;
         };
+        // gate every message in the accumulator layout first (one broadcast read per four rows, all of them in flight together: the scan below
+        // is full of scalar branches, a read issued there would be waited for on the spot)
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+            float4 g[4];
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) g[rq] = *reinterpret_cast<const float4*>(&L.gw[wave][E_ROW(m, 4 * rq)]);    // rows E_ROW(m, 4 rq) .. + 3 of this lane half
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float gg = (r & 3) == 0 ? g[r >> 2].x : (r & 3) == 1 ? g[r >> 2].y : (r & 3) == 2 ? g[r >> 2].z : g[r >> 2].w;
+                    acc[m][n][r] *= gg;
+                }
+        }
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -302,19 +359,17 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int base = 32 * m + 8 * j + 4 * hh;
-                    const float4 g4 = *reinterpret_cast<const float4*>(&L.gw[wave][base]);              // one address per wave: broadcast
                     unsigned bits = (sm[base >> 5] >> (base & 31)) & 0xfu;
                     if (base == 0) bits &= ~1u;                                                    // row 0 opens segment 0: nothing to flush
                     const float* v = hh ? y : x;
-                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
                     if (bits == 0u) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) sum = __fmaf_rn(v[i], gg[i], sum);
+                        for (int i = 0; i < 4; ++i) sum += v[i];
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             if (bits & (1u << i)) flush();
-                            sum = __fmaf_rn(v[i], gg[i], sum);
+                            sum += v[i];
                         }
                     }
                 }
@@ -322,6 +377,7 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
         flush();                                                         // the tile's last segment when it ends with the tile's last row
     }
 #undef STAMP
+#undef STAMPB
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -392,7 +448,13 @@ __device__ __forceinline__ void pref_fetch(RowPref& pf, const EdgeSrc<COORD>& es
 // segrow / segstart / smask / meta; requests the rows of the tile after it.
 template <bool COORD>
 __device__ __forceinline__ void index_phase(E128Lds& L, const Layout& lay, const Work& w, const Dims& d, const EdgeSrc<COORD>& es, RowPref& pf, const TileWalk& tw,
-                                            const int lane, const int layer, const int live_thr) {
+                                            const int lane_in, const int layer_in, const int live_thr) {
+    // opaque copies: whatever this phase derives from the lane or the layer (lane masks, per-lane addresses, 64-bit row offsets) is formed HERE, per tile,
+    // instead of once per kernel - hoisted, such values stay live across the tile's GEMMs and end up in scratch memory, whose reloads wait
+    // (s_waitcnt vmcnt) for every store of the previous tile
+    int lane = lane_in, layer = layer_in;
+    asm volatile("" : "+v"(lane));
+    asm volatile("" : "+s"(layer));
     const int e0 = tw.e0, ne_full = tw.ne_full(), cend = tw.cend, trows = tw.trows;
     if (pf.nx_e0 != e0) pref_fetch<COORD>(pf, es, w, lane, live_thr, e0, ne_full);      // first tile of the chunk, or the previous tile was cut short (below)
     int row[2], col[2], hop[2]; float d0[2];
@@ -400,10 +462,11 @@ __device__ __forceinline__ void index_phase(E128Lds& L, const Layout& lay, const
     for (int u = 0; u < 2; ++u) { row[u] = pf.nrow[u]; col[u] = pf.ncol[u]; hop[u] = pf.nhop[u]; d0[u] = pf.nd0[u]; }
     if (e0 + ne_full < cend) pref_fetch<COORD>(pf, es, w, lane, live_thr, e0 + ne_full, min(trows, cend - e0 - ne_full));
     // segments: runs of equal receivers (the lists are sorted by receiver)
-    const int prev0 = __shfl_up(row[0], 1);
+    // (lane - 1's value by DPP wave_shr:1, lane 63's by v_readlane: no lane-id arithmetic kept in registers across the tile)
+    const int prev0 = __builtin_amdgcn_update_dpp(row[0], row[0], 0x138, 0xf, 0xf, false);
     const bool s0 = lane < ne_full && (lane == 0 || row[0] != prev0);
-    const int last0 = __shfl(row[0], 63);
-    const int prev1 = __shfl_up(row[1], 1);
+    const int last0 = __builtin_amdgcn_readlane(row[0], 63);
+    const int prev1 = __builtin_amdgcn_update_dpp(row[1], row[1], 0x138, 0xf, 0xf, false);
     const bool s1 = 64 + lane < ne_full && row[1] != (lane == 0 ? last0 : prev1);
     const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
     const unsigned long long below = (2ull << lane) - 1ull;                        // lanes <= this one
@@ -460,18 +523,18 @@ __device__ __forceinline__ void tile_dispatch(E128Lds& L, const Layout& lay, con
 constexpr int TILE_BARRIERS = 9;        // barriers inside tile_compute (two per quarter, one after the row dots)
 
 template <bool COORD>
-__device__ __forceinline__ TileCtx make_ctx(const LayerW& lw, const EdgeSrc<COORD>& es, const int wave, const int lane, const int layer) {
+__device__ __forceinline__ TileCtx make_ctx(const LayerW& lw, const EdgeSrc<COORD>& es, const int wave, const int lane, const int layer, const int n_rows) {
     const WPack& W = COORD ? lw.W7 : lw.W2;
     const float* bvec = COORD ? lw.b7 : lw.b2;
     const float* hvec = COORD ? lw.w5 : lw.wa;                                   // the row dot's weight vector
     TileCtx tc;
     tc.colw = 64 * wave + (lane & 31);
-    tc.P = es.P; tc.Q = es.Q; tc.layer = layer;
+    tc.rb = row_bufs(es.P, es.Q, n_rows); tc.layer = layer;
     const float sc = NPL == 3 ? 1.0f : W.wh_scale;                               // the accumulators carry the weight pack's scale
     tc.sc = sc; tc.c1 = -1.4426950408889634f * (NPL == 3 ? 1.0f : W.wh_inv);
-    tc.bias0 = bvec[tc.colw] * sc; tc.bias1 = bvec[tc.colw + 32] * sc; tc.hv0 = hvec[tc.colw]; tc.hv1 = hvec[tc.colw + 32];
+    (void)bvec; (void)hvec;
     tc.ba0 = COORD ? 0.f : lw.ba[0];
-    tc.wb = reinterpret_cast<const efrag*>(NPL == 3 ? W.ws : W.wh) + (size_t)(2 * wave) * NS + lane;
+    tc.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<efrag*>(reinterpret_cast<const efrag*>(NPL == 3 ? W.ws : W.wh) + (size_t)(2 * wave) * NS), 0, (int)(2u * NS * 16u), 0x00020000);
     return tc;
 }
 
@@ -483,15 +546,23 @@ __global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const EdgeSrc<COORD> es(w);
     L.wrd[tid] = (COORD ? lw.wr_c : lw.wr_e)[tid]; L.wrd[H + tid] = (COORD ? lw.wd_c : lw.wd_e)[tid];       // visible after the first tile's barrier
-    const TileCtx tc = make_ctx<COORD>(lw, es, wave, lane, layer);
+    L.colv[tid] = (COORD ? lw.b7 : lw.b2)[tid] * (NPL == 3 ? 1.0f : (COORD ? lw.W7 : lw.W2).wh_scale); L.colv[H + tid] = (COORD ? lw.w5 : lw.wa)[tid];
+    const TileCtx tc = make_ctx<COORD>(lw, es, wave, lane, layer, lay.N);
     TileWalk tw; tw.init((int)blockIdx.x, (int)gridDim.x, w.totals[COORD ? 1 : 0], lay.max_n);
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;       // diagnostic builds (-DCMDGEN_STAMPS=6): summed phase cycles
-#if CMDGEN_STAMPS == 6
+#if CMDGEN_STAMPS == 6 || CMDGEN_STAMPS == 9
     st_t = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_t; int st_tiles = 0;
+#endif
+#if CMDGEN_STAMPS == 6
 #define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+#define STAMPB(i) do {} while (0)
+#elif CMDGEN_STAMPS == 9
+#define STAMPB(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+#define STAMP(i) do {} while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define STAMPB(i) do {} while (0)
 #endif
     RowPref pf; pf.nx_e0 = -1;
 #pragma unroll
@@ -499,24 +570,28 @@ __global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, 
     while (tw.valid()) {
         efrag bs[2][2][NPL];
 #pragma unroll
-        for (int i = 0; i < 2 * NPL; ++i) bs[0][i & 1][i >> 1] = tc.wb[(unsigned)(i & 1) * NS + (unsigned)(i >> 1) * 64u];     // k-block 0, in flight during the index phase
+        for (int i = 0; i < 2 * NPL; ++i) bs[0][i & 1][i >> 1] = w_frag(tc.rw, lane, (int)(((unsigned)(i & 1) * NS + (unsigned)(i >> 1) * 64u) << 4));     // k-block 0, in flight during the index phase
         if (wave == 0) index_phase<COORD>(L, lay, w, d, es, pf, tw, lane, layer, live_thr);
+        STAMPB(0);
         lds_barrier();
         STAMP(0);
+        STAMPB(1);
         const int ne = L.meta[2];
         if (!L.meta[1]) {                                                                   // dead tile (see edge_msg_body, kernels_egnn.hip)
             if (tid == 0) atomicAdd(&w.counters[6], (unsigned long long)ne);
         } else {
             tile_dispatch<COORD>(L, lay, w, d, tc, ne, bs, st_, st_t);
         }
+        STAMPB(6);
         lds_barrier();                                                                      // the next index phase rewrites e / seg / meta
         STAMP(4);
+        STAMPB(7);
         tw.advance(ne);
-#if CMDGEN_STAMPS == 6
+#if CMDGEN_STAMPS == 6 || CMDGEN_STAMPS == 9
         ++st_tiles;
 #endif
     }
-#if CMDGEN_STAMPS == 6
+#if CMDGEN_STAMPS == 6 || CMDGEN_STAMPS == 9
     if (lane == 0 && (blockIdx.x & 3) == 0 && st_tiles > 0 && COORD == (CMDGEN_STAMP_COORD != 0)) {
         for (int i = 0; i < 8; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
         atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
@@ -544,13 +619,14 @@ __global__ __launch_bounds__(512, 2) void k_edge128pp(Layout lay, Work w, Dims d
     E128Lds& L = LL[half];
     const EdgeSrc<COORD> es(w);
     L.wrd[htid] = (COORD ? lw.wr_c : lw.wr_e)[htid]; L.wrd[H + htid] = (COORD ? lw.wd_c : lw.wd_e)[htid];   // visible after the first slot's first barrier
-    const TileCtx tc = make_ctx<COORD>(lw, es, wave, lane, layer);
+    L.colv[htid] = (COORD ? lw.b7 : lw.b2)[htid] * (NPL == 3 ? 1.0f : (COORD ? lw.W7 : lw.W2).wh_scale); L.colv[H + htid] = (COORD ? lw.w5 : lw.wa)[htid];
+    const TileCtx tc = make_ctx<COORD>(lw, es, wave, lane, layer, lay.N);
     const int E = w.totals[COORD ? 1 : 0];
     TileWalk tw; tw.init((int)blockIdx.x + half * (int)gridDim.x, 2 * (int)gridDim.x, E, lay.max_n);        // (gridDim % 8 == 0: both halves' chunks lie in this XCD's range)
     TileWalk other; other.init((int)blockIdx.x + (1 - half) * (int)gridDim.x, 2 * (int)gridDim.x, E, lay.max_n);
     bool cont = tw.valid() || other.valid();                                                // wave-uniform and equal in all eight waves
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
-#if CMDGEN_STAMPS == 6
+#if CMDGEN_STAMPS == 6 || CMDGEN_STAMPS == 9
     st_t = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_t; int st_tiles = 0;
 #endif
@@ -563,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void k_edge128pp(Layout lay, Work w, Dims d
         efrag bs[2][2][NPL];
         if (mine) {
 #pragma unroll
-            for (int i = 0; i < 2 * NPL; ++i) bs[0][i & 1][i >> 1] = tc.wb[(unsigned)(i & 1) * NS + (unsigned)(i >> 1) * 64u];
+            for (int i = 0; i < 2 * NPL; ++i) bs[0][i & 1][i >> 1] = w_frag(tc.rw, lane, (int)(((unsigned)(i & 1) * NS + (unsigned)(i >> 1) * 64u) << 4));
             if (wave == 0) {
                 index_phase<COORD>(L, lay, w, d, es, pf, tw, lane, layer, live_thr);
                 if (lane == 0) more_flag[slot & 1][half] = tw.more_after(L.meta[2]) ? 1 : 0;   // (lane 0 wrote meta[2] itself)
@@ -587,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void k_edge128pp(Layout lay, Work w, Dims d
         STAMP(4);
         if (mine) {
             tw.advance(ne);
-#if CMDGEN_STAMPS == 6
+#if CMDGEN_STAMPS == 6 || CMDGEN_STAMPS == 9
             ++st_tiles;
 #endif
         }
@@ -595,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void k_edge128pp(Layout lay, Work w, Dims d
         cont = (more_flag[slot & 1][0] | more_flag[slot & 1][1]) != 0;
     }
     if (half == 0) lds_barrier();
-#if CMDGEN_STAMPS == 6
+#if CMDGEN_STAMPS == 6 || CMDGEN_STAMPS == 9
     if (lane == 0 && (blockIdx.x & 1) == 0 && half == 0 && st_tiles > 0 && COORD == (CMDGEN_STAMP_COORD != 0)) {
         for (int i = 0; i < 8; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
         atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
@@ -604,5 +680,6 @@ __global__ __launch_bounds__(512, 2) void k_edge128pp(Layout lay, Work w, Dims d
     }
 #endif
 #undef STAMP
+#undef STAMPB
 }
 

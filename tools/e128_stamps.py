@@ -31,7 +31,8 @@ for _ in range(N):
 torch.cuda.synchronize()
 s = h.debug_stamps(True)
 wgs, tiles = max(s[40] / 4, 1), max(s[41], 1)
-names = ['index phase', 'builds: wait at their barrier', 'GEMMs: wait at their barrier', 'SiLU + row dot + exchange (+ barrier)', 'segment sum / stores + end-of-tile barrier', 'gates (every wave for itself)', 'builds: work', 'GEMMs: work']
+MODE9 = os.environ.get('E128_STAMP_MODE') == '9'
+names = ['index phase: work (wave 0; the others idle)', 'index phase: wait at its barrier', 'builds + GEMMs (all four quarters, barriers included)', 'SiLU + row dot + partials to LDS: work', 'partials: wait at the barrier', 'gates (every wave for itself)', 'gate multiply + lane swap + ordered scan + stores: work', 'end-of-tile barrier: wait'] if MODE9 else ['index phase', 'builds: wait at their barrier', 'GEMMs: wait at their barrier', 'SiLU + row dot + exchange (+ barrier)', 'segment sum / stores + end-of-tile barrier', 'gates (every wave for itself)', 'builds: work', 'GEMMs: work']
 print(f'B {B} {rep}: edge_mt {h.query("edge_mt")} coord_mt {h.query("coord_mt")}; sampled {wgs:.0f} workgroup launches (message kernel; -DCMDGEN_STAMP_COORD=1 builds record the coordinate kernel), {tiles / wgs:.2f} tiles each')
 print('cycles per TILE (waves 0..3):')
 tot = 0
