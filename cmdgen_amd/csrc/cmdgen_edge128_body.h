@@ -406,9 +406,16 @@ struct TileWalk {
         const int c = xcd_chunk_v(vb, nb, kc, nch);
         if (c < 0) { cbeg = -1; cend = -1; trows = 32; e0 = 0; return; }
         cbeg = c * CH; cend = min(E, cbeg + CH);
-        const int ntile = (cend - cbeg + MT - 1) / MT;
-        trows = (((cend - cbeg + ntile - 1) / ntile) + 31) & ~31;        // equal tiles, a multiple of 32 rows, <= 128
         e0 = cbeg;
+        split_rest();
+    }
+    // rows of the next tile: what is left of the chunk cut into equal tiles of at most MT rows (a multiple of 32).  Re-split before EVERY tile,
+    // so a chunk never ends in a short tile behind full ones (416 rows -> 128, 96, 96, 96; after a tile was cut at its 33rd receiver the
+    // rest is divided again): a receiver with fewer edges than the shortest tile (>= 64 rows while the chunk has them) lies in at most two tiles.
+    __device__ __forceinline__ void split_rest() {
+        const int rest = cend - e0;
+        const int ntile = (rest + MT - 1) / MT;
+        trows = ntile > 0 ? ((((rest + ntile - 1) / ntile) + 31) & ~31) : 32;
     }
     __device__ __forceinline__ void init(int vb_, int nb_, int E_, int max_n) {
         vb = vb_; nb = nb_; E = E_;
@@ -425,7 +432,7 @@ struct TileWalk {
     __device__ __forceinline__ int ne_full() const { return min(trows, cend - e0); }
     // after a tile of ne rows: is there another tile for this walker?  (does not advance)
     __device__ __forceinline__ bool more_after(int ne) const { return e0 + ne < cend || xcd_chunk_v(vb, nb, kc + 1, nch) >= 0; }
-    __device__ __forceinline__ void advance(int ne) { e0 += ne; if (e0 >= cend) { ++kc; load_chunk(); } }
+    __device__ __forceinline__ void advance(int ne) { e0 += ne; if (e0 >= cend) { ++kc; load_chunk(); } else split_rest(); }
 };
 
 // (row, col, d0, level) of a tile's rows, kept one tile ahead by wave 0: two rows per lane
@@ -460,7 +467,10 @@ __device__ __forceinline__ void index_phase(E128Lds& L, const Layout& lay, const
     int row[2], col[2], hop[2]; float d0[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) { row[u] = pf.nrow[u]; col[u] = pf.ncol[u]; hop[u] = pf.nhop[u]; d0[u] = pf.nd0[u]; }
-    if (e0 + ne_full < cend) pref_fetch<COORD>(pf, es, w, lane, live_thr, e0 + ne_full, min(trows, cend - e0 - ne_full));
+    if (e0 + ne_full < cend) {                   // the rows of the tile after this one (sized as TileWalk::split_rest will size it; a cut tile is fetched again)
+        const int rest = cend - e0 - ne_full, ntile = (rest + MT - 1) / MT;
+        pref_fetch<COORD>(pf, es, w, lane, live_thr, e0 + ne_full, min(rest, (((rest + ntile - 1) / ntile) + 31) & ~31));
+    }
     // segments: runs of equal receivers (the lists are sorted by receiver)
     // (lane - 1's value by DPP wave_shr:1, lane 63's by v_readlane: no lane-id arithmetic kept in registers across the tile)
     const int prev0 = __builtin_amdgcn_update_dpp(row[0], row[0], 0x138, 0xf, 0xf, false);

@@ -1661,8 +1661,12 @@ void cmdgen_launch_nan_fix(const EvalLaunch& a, float* eps_phar, hipStream_t s) 
     hipLaunchKernelGGL(k_nan_fix, dim3((a.lay.Nl + 255) / 256), dim3(256), 0, s, a.lay, a.w, a.d, eps_phar);
 }
 
+// (the kernel the evaluation itself would run for this block: the 128-row kernel, then the full-K 32-row tiles, then the generic dispatch;
+// weight unit of the block's first GCL when a block has several)
 template <int H> static void launch_msg_only_H(const EvalLaunch& a, int layer, hipStream_t s) {
-    MT_DISPATCH(a.edge_mt, launch_msg, a, layer, s);
+    a.unit = layer * a.d.S;
+    if (!cmdgen_launch_msg128(a, layer, s) && !launch_msg_fullk(a, layer, s)) MT_DISPATCH(a.edge_mt, launch_msg, a, layer, s);
+    a.unit = -1;
 }
 void cmdgen_launch_edge_msg_only(const EvalLaunch& a, int layer, hipStream_t s) {
     switch (a.d.H) {

@@ -73,7 +73,11 @@ class GammaNetwork(nn.Module):
             return self.cpu_copy()(t).view(-1).numpy().astype(np.float32)
 
     def cpu_copy(self):
-        g = GammaNetwork()
+        """a host copy for scalar evaluations.  Built under fork_rng: PositiveLinear.__init__ draws ~2k uniform values from the GLOBAL torch
+        generator, and the reference's sampler leaves that stream alone - host-side randn after a sampling call must not depend on how often
+        this helper ran"""
+        with torch.random.fork_rng(devices=[]):
+            g = GammaNetwork()
         g.load_state_dict({k: v.detach().cpu() for k, v in self.state_dict().items()})
         return g
 
@@ -437,7 +441,12 @@ class EnVariationalDiffusion(nn.Module):
             t += stride
         return runs[::-1]
 
-    def _joint_handle(self, nph, npk):
+    def _joint_handle(self, nph, npk, timesteps=None):
+        if self.learned_schedule and timesteps is not None and self.T % timesteps != 0:
+            # the joint chain's op table takes gamma from the network's TABULATION on the T-grid (gamma[round(step / K * T)]); the reference
+            # evaluates the network at step / K itself (en_diffusion.py:599-606).  The two agree exactly when K divides T; otherwise the chain
+            # would use gamma at a rounded time, so it is refused (the conditional sampler evaluates the network at step / K: step_table)
+            raise NotImplementedError(f"noise_schedule='learned' with the joint sampler needs timesteps that divide T = {self.T} (got {timesteps})")
         if not getattr(self.dynamics, 'update_pocket_coords', False):
             raise ValueError("the joint sampler needs EGNNDynamics(update_pocket_coords=True) (mode 'joint', "
                              "lightning_modules.py:125)")
@@ -480,7 +489,7 @@ class EnVariationalDiffusion(nn.Module):
         nph = torch.as_tensor(num_nodes_phar).detach().to('cpu', torch.int64).numpy()
         npk = torch.as_tensor(num_nodes_pocket).detach().to('cpu', torch.int64).numpy()
         assert len(nph) == n_samples and len(npk) == n_samples
-        h = self._joint_handle(nph, npk)
+        h = self._joint_handle(nph, npk, timesteps)
         dev = next(self.dynamics.parameters()).device
         if noise is not None:
             noise = noise.detach().to(dev, torch.float32).contiguous()
@@ -509,7 +518,7 @@ class EnVariationalDiffusion(nn.Module):
         for m in (phar['mask'], pocket['mask']):
             if m.numel() > 1 and bool((m[1:] < m[:-1]).any()):
                 raise ValueError('batch masks must be ascending and contiguous')
-        h = self._joint_handle(nph, npk)
+        h = self._joint_handle(nph, npk, timesteps)
         f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()
         if noise is not None:
             noise = f32(noise)

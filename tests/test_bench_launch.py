@@ -74,3 +74,18 @@ def test_traffic_file_is_tied_to_the_kernel_sources():
     assert len(sha) == 16 and sha == bench.kernel_source_sha()
     tj = json.load(open(os.path.join(ROOT, 'profiles', 'kernel_traffic.json')))
     assert 'kernel_source_sha' in tj and set(tj['hbm_bytes_per_launch']) >= {'edge_msg', 'node', 'edge_coord'}
+
+
+def test_scale_day_one_script_dry_run(tmp_path):
+    """tools/scale_day_one.sh --dry-run-launch: the whole 8-GPU protocol (weak and strong scaling at N = 1, 2, 4, 8) through the real launch
+    path on CPU over gloo - every line reports the rank count it COUNTED, the strong runs split one batch of 512 pockets."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['SCALE_OUT'] = str(tmp_path)
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'scale_day_one.sh'), '--dry-run-launch'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    for n in (1, 2, 4, 8):
+        weak = json.loads(open(tmp_path / f'weak_n{n}.json').read().strip().splitlines()[-1])
+        strong = json.loads(open(tmp_path / f'strong_n{n}.json').read().strip().splitlines()[-1])
+        assert weak['n_gpus'] == n and weak['scaling'] == 'weak' and len(weak['pocket_blocks']) == n
+        assert strong['n_gpus'] == n and strong['scaling'] == 'strong'
+        assert strong['pocket_blocks'][0][0] == 0 and strong['pocket_blocks'][-1][1] == 512

@@ -159,3 +159,38 @@ def test_dead_work_skip_with_128_row_tiles(monkeypatch):
     assert off['edges_skipped'] == 0 and on['edges_skipped'] > 0
     sc = max(1.0, float(np.abs(out['0'][0][:, :3]).max()))
     assert np.abs(out['2'][0][:, :3] - out['0'][0][:, :3]).max() <= 2e-5 * sc and np.array_equal(out['2'][0][:, 3:], out['0'][0][:, 3:])
+
+
+def test_nonfinite_message_stays_with_its_receiver_and_resets_the_batch(monkeypatch):
+    """A pocket node of ONE sample carries an infinite feature: its messages are non-finite, the velocity has a NaN and the evaluation resets
+    EVERY velocity of the batch to zero like the reference (dynamics.py:129-131, batch-global).  What must not happen on the 128-row tiles -
+    where receivers of several samples share a tile - is the poison reaching another sample's receivers through the segment sum: the decoded
+    features of every other sample still equal the oracle's (the ordered in-register scan keeps a NaN in its own receiver's sum; the
+    segment-sum-as-MFMA of round 4 spread it over the tile through 0 * NaN)."""
+    from oracle import ref_cpu
+    force128(monkeypatch)
+    name = 'ca_h256_b8'
+    cfg, sd, inp = dynamics_case(G2, name)
+    nl, npk = G2[name + '/num_nodes_phar'], G2[name + '/pocket_size']
+    bad_sample = 3
+    xq = inp['xh_pocket'].copy()
+    xq[int(np.cumsum(npk)[bad_sample - 1]) + 2, 3 + 1] = np.inf             # one feature of the third pocket node of sample 3
+    p = ref_cpu.to_torch_params(sd)
+    with torch.no_grad():
+        want, _ = ref_cpu.dynamics_forward(p, cfg.as_dict(), torch.from_numpy(inp['xh_phar']), torch.from_numpy(xq), torch.from_numpy(inp['t']),
+                                           torch.from_numpy(inp['mask_phar']), torch.from_numpy(inp['mask_pocket']))
+    want = want.numpy()
+    h = new_handle(cfg, sd)
+    h.set_layout(nl, npk)
+    assert h.query('edge_mt') == 128
+    eps, _p = h.dynamics_forward(dev(inp['xh_phar']), dev(xq), dev(inp['t']))
+    torch.cuda.synchronize()
+    got = eps.cpu().numpy()
+    assert np.all(want[:, :3] == 0.0) and np.all(got[:, :3] == 0.0)        # the batch-global reset, in the oracle and here
+    others = inp['mask_phar'] != bad_sample
+    assert np.isfinite(want[others, 3:]).all()
+    assert np.isfinite(got[others, 3:]).all(), 'a non-finite message leaked into another sample'
+    assert np.abs(got[others, 3:] - want[others, 3:]).max() <= EVAL_TOL * max(1.0, float(np.abs(want[others, 3:]).max()))
+    assert not np.isfinite(got[~others, 3:]).all()                          # the poisoned sample itself is non-finite in both
+    assert not np.isfinite(want[~others, 3:]).all()
+    h.close()

@@ -292,3 +292,27 @@ def test_per_sample_table_matches_the_tensor_op_scalars():
     for i, w in enumerate(want):
         w = torch.as_tensor(w, dtype=torch.float32).reshape(-1)
         assert torch.allclose(tab[i], w, rtol=2e-6, atol=1e-7), (i, tab[i], w)
+
+
+def test_gamma_network_host_copy_leaves_the_global_rng_alone():
+    """GammaNetwork.cpu_copy() constructs a fresh network (PositiveLinear.__init__ draws from the global generator): it must not advance the
+    caller's stream - the reference's sampler does not touch it, so host-side randn after a sampling call stays reproducible against it."""
+    from cmdgen_amd.equivariant_diffusion.en_diffusion import GammaNetwork
+    g = GammaNetwork()
+    torch.manual_seed(123)
+    want = torch.rand(4)
+    torch.manual_seed(123)
+    g.cpu_copy(); g.table(50)
+    assert torch.equal(torch.rand(4), want)
+
+
+def test_joint_sampler_refuses_a_learned_schedule_off_the_T_grid():
+    """mode 'joint' + noise_schedule='learned': the joint chain's op table reads gamma from the network's tabulation on the T-grid, which
+    equals the reference's gamma(step / K) only when K divides T - any other K is refused before the handle is touched (no GPU needed)."""
+    from cmdgen_amd.equivariant_diffusion.en_diffusion import EnVariationalDiffusion
+    dyn = EGNNDynamics(phar_nf=8, residue_nf=20, n_dims=3, joint_nf=16, hidden_nf=64, n_layers=1, attention=True, tanh=True, norm_constant=1,
+                       inv_sublayers=1, normalization_factor=100, aggregation_method='sum', edge_cutoff=6.0, update_pocket_coords=True)
+    ddpm = EnVariationalDiffusion(dynamics=dyn, phar_nf=8, residue_nf=20, n_dims=3, timesteps=500, noise_schedule='learned', noise_precision=1e-5,
+                                  loss_type='vlb', norm_values=[1, 4], size_histogram=np.ones((30, 70)))
+    with pytest.raises(NotImplementedError, match='divide T'):
+        ddpm._joint_handle(np.array([8]), np.array([40]), timesteps=7)
