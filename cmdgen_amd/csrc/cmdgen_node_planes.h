@@ -3,8 +3,15 @@
 // Included once per matrix engine by kernels_node64.hip (N64_NPL = 3: three bf16 pieces per operand, six MFMAs per product; 2: two fp16
 // pieces, three MFMAs - the "half" engine of cmdgen_split.h) inside a namespace of its own.  No include guard on purpose.
 
+#ifndef CMDGEN_N64_EXP
+#define CMDGEN_N64_EXP 0      // timing experiments only (1: agg * rcp(nf) instead of agg / nf; 2: no zero stores to agg - wrong results)
+#endif
 #define NPLD 264            // 16-bit elements per plane row: 256 + 8 (row stride 528 B: conflict-free ds_read_b128)
-#define NRING 4
+// Depth of the weight ring (k-blocks of fragments in registers).  4: three blocks ahead.  16 (half engine, 64-row tiles): a GEMM's WHOLE weight
+// stream (16 k-blocks x 2 tiles x 2 pieces = 256 registers per lane; one wave per SIMD has 512) is requested while the previous GEMM runs, i.e.
+// BEFORE that GEMM's results are stored: the stores (64 KB per tile and output, bound by the chip's HBM write rate - every workgroup reaches the
+// same phase together) drain under the next GEMM instead of in front of its weight loads (in-order memory queue).  profiles/r05_s
+template <int NROWS> struct N64Depth { static constexpr int v = (N64_NPL == 2 && NROWS == 64) ? 16 : 4; };
 constexpr int NPL = N64_NPL;
 constexpr unsigned KBS = 64u * NPL;          // 16-byte units per k-block of a 32-column tile in the packed split weight
 #if N64_NPL == 3
@@ -17,14 +24,14 @@ typedef sf16x8 nfrag;
 
 __device__ __forceinline__ void n64_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct N64Ring { nfrag b[NRING][2][NPL]; };   // k-blocks x two 32-column tiles x NPL pieces
+template <int NRING> struct N64Ring { nfrag b[NRING][2][NPL]; };   // k-blocks x two 32-column tiles x NPL pieces
 
 // acc[m][n] += A(planes) x W_n^T over K = 256 (16 k-blocks) for the wave's two 32-column tiles.  planes: the three bf16 planes of
 // the 64-row tile; cur[n] / nxt[n]: WAVE-UNIFORM pointers to k-block 0 of tile n of this GEMM / the next one (the lane's 16 bytes at
 // [lane + 64 piece]).  On entry the ring holds k-blocks 0, 1, 2 of this GEMM in sets 0, 1, 2; on exit those of the next.
-template <int NMT>
+template <int NMT, int NRING>
 __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const nfrag* const (&cur)[2], const nfrag* const (&nxt)[2],
-                                         sf32x16 (&acc)[NMT][2], N64Ring& ring) {
+                                         sf32x16 (&acc)[NMT][2], N64Ring<NRING>& ring) {
     constexpr int KB16 = 16, NPE = NMT * 32 * NPLD;
     const int lane = threadIdx.x & 63;
     const unsigned short* ap = planes + (lane & 31) * NPLD + (lane >> 5) * 8;
@@ -68,8 +75,14 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const nfr
         NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 0) } }
 #endif
     NG_LOADA(0, 0)
+    if constexpr (NRING == 16) {
+      constexpr int kb = 0;
+      NG_BLOCK(0) NG_BLOCK(1) NG_BLOCK(2) NG_BLOCK(3) NG_BLOCK(4) NG_BLOCK(5) NG_BLOCK(6) NG_BLOCK(7)
+      NG_BLOCK(8) NG_BLOCK(9) NG_BLOCK(10) NG_BLOCK(11) NG_BLOCK(12) NG_BLOCK(13) NG_BLOCK(14) NG_BLOCK(15)
+    } else {
 #pragma unroll 1
-    for (int kb = 0; kb < KB16; kb += NRING) { NG_BLOCK(0) NG_BLOCK(1) NG_BLOCK(2) NG_BLOCK(3) }
+      for (int kb = 0; kb < KB16; kb += NRING) { NG_BLOCK(0) NG_BLOCK(1) NG_BLOCK(2) NG_BLOCK(3) }
+    }
 #undef NG_LB
 #undef NG_LA
 #undef NG_LOADA
@@ -111,6 +124,12 @@ __device__ __forceinline__ void n64_store4(unsigned short* planes, int NPE, int 
 // the power of two a weight pack's accumulators carry (1 on the bf16 split) and its inverse
 __device__ __forceinline__ float n64_scale(const WPack& W) { return NPL == 3 ? 1.0f : W.wh_scale; }
 __device__ __forceinline__ float n64_inv(const WPack& W) { return NPL == 3 ? 1.0f : W.wh_inv; }
+// x / d with the reciprocal r = 1 / d and one correction step (three operations instead of the ten of the IEEE sequence; the quotient is the
+// correctly rounded one except in rare half-ulp ties)
+__device__ __forceinline__ float n64_div(float x, float d, float r) {
+    const float q = x * r;
+    return __fmaf_rn(__fmaf_rn(-q, d, x), r, q);
+}
 // SiLU(a / sc) for an accumulator carrying the scale sc (c1 = -log2(e) / sc): five operations, the bits of silu_f(a / sc)
 __device__ __forceinline__ float n64_silu_scaled(float a, float c1, float sc) {
     const float u = __builtin_amdgcn_exp2f(a * c1);
@@ -129,8 +148,11 @@ __device__ __forceinline__ float4 n64_node_pos(const Layout& lay, const Work& w,
 #define N64_ROW(M, R) ((M) * 32 + ((R) & 3) + 8 * ((R) >> 2) + 4 * (lane >> 5))
 
 // One NROWS-row tile (64, or 32: one accumulator row per wave) of rows row0 .. min(row0 + NROWS, row_end) - 1.
-template <int NROWS>
-__device__ __forceinline__ void node_planes_tile(unsigned short* planes, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
+// FULL: the tile has all its rows - every `row < nvalid` test folds away, so the row loads of a phase are plain back-to-back loads in flight
+// together and the row stores carry no exec-mask branches (with the tests, hipcc wraps each load in its own branch and even waits inside the
+// sequence: the tile-in and agg hand-over phases took 12k cycles each; profiles/r05_q).  Only a layout's last tile takes the general path.
+template <int NROWS, bool FULL>
+__device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
                                                  const LayerW& lw_next, const int layer, const int has_next_arg, const int row0, const int row_end) {
     constexpr int H = 256, LPR = H / 4, NMT = NROWS / 32, NPE = NROWS * NPLD;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -143,7 +165,10 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
 #else
 #define NSTAMP(i) do {} while (0)
 #endif
-    const int nvalid = min(NROWS, row_end - row0);
+    const int nvalid = FULL ? NROWS : min(NROWS, row_end - row0);
+    // half engine: the fp32 h tile stays in LDS behind the planes (64 KB; the residual reads it there instead of fetching h again)
+    constexpr bool HLDS = NPL == 2;
+    float* const hf = reinterpret_cast<float*>(planes + NPL * NPE + 64);
     const bool want_pc = row0 < lay.Nm;
     const int c4 = tid % LPR, rsub = tid / LPR;
     if (live_thr && !want_pc && w.need_qc) {
@@ -170,7 +195,8 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
     const unsigned jobs = (want_pc && !skip_pc ? 1u : 0u) | (want_qc && !skip_pc ? 2u : 0u) | (has_next ? 12u : 0u);
     auto job_tile = [&](int j, int n) { return n64_tile(j < 2 ? lw.Wpq_c : lw_next.Wpq_e, 16, (j & 1) * 8 + 2 * wave + n, 0); };
     const int job0 = jobs ? __builtin_ctz(jobs) : 1;             // (no job at all: the W4 product's look-ahead reads Q_c's first blocks, unused)
-    N64Ring ring;
+    constexpr int NRING = N64Depth<NROWS>::v;
+    N64Ring<NRING> ring;
     const int colw = 64 * wave + (lane & 31);
     const float sc3 = n64_scale(lw.W3), c13 = -1.4426950408889634f * n64_inv(lw.W3), inv4 = n64_inv(lw.W4);       // the accumulators carry their weight pack's scale
     const float b3c0 = lw.b3[colw] * sc3, b3c1 = lw.b3[colw + 32] * sc3, b4c0 = lw.b4[colw], b4c1 = lw.b4[colw + 32];
@@ -195,7 +221,10 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
 #pragma unroll
                 for (int s_ = 0; s_ < NPL; ++s_) ring.b[kb][n][s_] = t3a[n][(unsigned)kb * KBS + lane + s_ * 64];
 #pragma unroll
-        for (int pass = 0; pass < NROWS / 4; ++pass) n64_store4(planes, NPE, (pass * 4 + rsub) * NPLD + 4 * c4, hv[pass]);
+        for (int pass = 0; pass < NROWS / 4; ++pass) {
+            n64_store4(planes, NPE, (pass * 4 + rsub) * NPLD + 4 * c4, hv[pass]);
+            if constexpr (HLDS) *reinterpret_cast<float4*>(hf + (pass * 4 + rsub) * H + 4 * c4) = hv[pass];
+        }
     }
     // agg: requested now, consumed after the h-part of the first product
     float4 av[NROWS / 4];
@@ -209,19 +238,23 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
     NSTAMP(0);
     sf32x16 acc[NMT][2];
     N64_ZERO(acc)
-    n64_gemm<NMT>(planes, t3a, t3b, acc, ring);                                     // h part of [h | agg]
+    n64_gemm<NMT, NRING>(planes, t3a, t3b, acc, ring);                                     // h part of [h | agg]
+    NSTAMP(6);
     n64_lds_barrier();                                                         // every wave is done reading h
 #pragma unroll
     for (int pass = 0; pass < NROWS / 4; ++pass) {
         const int r = pass * 4 + rsub;
+#if CMDGEN_N64_EXP != 2
         if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
+#endif
         float4 v = av[pass];
         const float dv = r < nvalid ? agg_div(w, d, row0 + r) : 1.0f;
-        v.x /= dv; v.y /= dv; v.z /= dv; v.w /= dv;
+        { const float rv = __builtin_amdgcn_rcpf(dv); v.x = n64_div(v.x, dv, rv); v.y = n64_div(v.y, dv, rv); v.z = n64_div(v.z, dv, rv); v.w = n64_div(v.w, dv, rv); }
         n64_store4(planes, NPE, r * NPLD + 4 * c4, v);
     }
     n64_lds_barrier();
-    n64_gemm<NMT>(planes, t3b, t4, acc, ring);                                      // agg part
+    NSTAMP(7);
+    n64_gemm<NMT, NRING>(planes, t3b, t4, acc, ring);                                      // agg part
     NSTAMP(1);
     n64_lds_barrier();                                                         // every wave is done reading agg
     // ---- T = SiLU(pre3): from the accumulators straight into the planes (register pairs r, r + 1 = two rows of one column)
@@ -244,14 +277,14 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = N64_ROW(m, r);
-                hold[m][n][r] = row < nvalid ? w.h[(size_t)(row0 + row) * H + colw + 32 * n] : 0.f;
+                if constexpr (!HLDS) hold[m][n][r] = row < nvalid ? w.h[(size_t)(row0 + row) * H + colw + 32 * n] : 0.f;
             }
     n64_lds_barrier();
     NSTAMP(2);
     N64_ZERO(acc)
     {
         const nfrag* const nxt[2] = {job_tile(job0, 0), job_tile(job0, 1)};
-        n64_gemm<NMT>(planes, t4, nxt, acc, ring);
+        n64_gemm<NMT, NRING>(planes, t4, nxt, acc, ring);
     }
     NSTAMP(3);
     n64_lds_barrier();                                                         // every wave is done reading T
@@ -264,7 +297,7 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
             for (int r = 0; r < 16; r += 2) {
                 const float bb = n == 0 ? b4c0 : b4c1;
                 const int col = colw + 32 * n, ra = N64_ROW(m, r), rb = N64_ROW(m, r + 1);
-                const float ha = hold[m][n][r] + __fmaf_rn(acc[m][n][r], inv4, bb), hb = hold[m][n][r + 1] + __fmaf_rn(acc[m][n][r + 1], inv4, bb);       // residual (egnn_new.py:57); inv4: a power of two, exact
+                const float ha = (HLDS ? hf[ra * H + col] : hold[m][n][r]) + __fmaf_rn(acc[m][n][r], inv4, bb), hb = (HLDS ? hf[rb * H + col] : hold[m][n][r + 1]) + __fmaf_rn(acc[m][n][r + 1], inv4, bb);       // residual (egnn_new.py:57); inv4: a power of two, exact
                 if (ra < nvalid) w.h[(size_t)(row0 + ra) * H + col] = ha;
                 if (rb < nvalid) w.h[(size_t)(row0 + rb) * H + col] = hb;
                 n64_split_store2(planes, NPE, ra * NPLD + col, rb * NPLD + col, ra < nvalid ? ha : 0.f, rb < nvalid ? hb : 0.f);
@@ -284,7 +317,7 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
         const float bias0 = (j == 0 || j == 2) ? bv[colw] : 0.f, bias1 = (j == 0 || j == 2) ? bv[colw + 32] : 0.f;       // (in flight during the GEMM)
         const float invj = n64_inv(j < 2 ? lw.Wpq_c : lw_next.Wpq_e);
         N64_ZERO(acc)
-        n64_gemm<NMT>(planes, tc, tn, acc, ring);
+        n64_gemm<NMT, NRING>(planes, tc, tn, acc, ring);
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -298,11 +331,19 @@ __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const L
     NSTAMP(5);
 #if CMDGEN_STAMPS == 5
     if (lane == 0) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&w.dbg[wave * 8 + i], nst_[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(&w.dbg[wave * 8 + i], nst_[i]);
         atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - nst_begin);
         atomicAdd(&w.dbg[40], 1ull);
     }
 #endif
 #undef NSTAMP
 }
+
+template <int NROWS>
+__device__ __forceinline__ void node_planes_tile(unsigned short* planes, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
+                                                 const LayerW& lw_next, const int layer, const int has_next_arg, const int row0, const int row_end) {
+    if (row_end - row0 >= NROWS) node_planes_tile_body<NROWS, true>(planes, lay, w, d, lw, lw_next, layer, has_next_arg, row0, row_end);
+    else node_planes_tile_body<NROWS, false>(planes, lay, w, d, lw, lw_next, layer, has_next_arg, row0, row_end);
+}
+
 

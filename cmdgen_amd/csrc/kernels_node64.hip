@@ -21,19 +21,18 @@
 namespace n64_half {
 #include "cmdgen_node_planes.h"
 __global__ __launch_bounds__(256, 1) void k_node64(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next) {
-    __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 64 * NPLD + 64];      // + the A prefetch's overshoot past the last row
+    __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 64 * NPLD + 64 + 64 * 256 * 2];      // + the A prefetch's overshoot past the last row + the fp32 h tile (residual)
     node_planes_tile<64>(planes, lay, w, d, lw, lw_next, layer, has_next, (int)blockIdx.x * 64, lay.N);
 }
 // the same tile at 32 rows (measurement aid: option node64 = 32 runs every node tile of a layout through it; profiles/r03_m_node64.txt)
 __global__ __launch_bounds__(256, 1) void k_node32p(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next) {
-    __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 32 * NPLD + 64];
+    __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 32 * NPLD + 64 + 32 * 256 * 2];
     node_planes_tile<32>(planes, lay, w, d, lw, lw_next, layer, has_next, (int)blockIdx.x * 32, lay.N);
 }
 }
 #undef N64_NPL
 #undef N64_MFMA
 #undef NPLD
-#undef NRING
 #undef N64_ZERO
 #undef N64_ROW
 #define N64_NPL 3

@@ -16,7 +16,7 @@ h.debug_stamps(True)
 h.sample_chain(torch.from_numpy(pb.x).to(dev), torch.from_numpy(pb.one_hot).to(dev), 20, seed=2, use_graph=False)
 s = h.debug_stamps(True)
 nw = max(s[40], 1) / 4
-names = ['launch -> tile in LDS', 'GEMM W3 (h | agg)', 'SiLU epilogue', 'GEMM W4', 'residual + h rows out', 'projections + stores']
+names = ['launch -> tile in LDS', 'GEMM W3, agg part', 'SiLU epilogue', 'GEMM W4', 'residual + h rows out', 'projections + stores', 'GEMM W3, h part', 'agg: barrier, zero stores, / nf, split into the planes, barrier']
 print('B', B, rep, 'node64', h.query('node64'), 'mean cycles per wave per WORKGROUP (waves 0..3):')
 for i, nm in enumerate(names):
     print(f'  {nm:28s}', [round(s[w * 8 + i] / nw) for w in range(4)])
