@@ -448,8 +448,20 @@ static void pick_tiles(cmdgen_handle* h) {
     }
     // long lists on the split engine: the 128-row kernels of kernels_edge128.hip (every workgroup owns one chunk of the list; same-box
     // A/B at 256 C-alpha pockets: messages -3 %, coordinate list -14 %; full-atom pockets: level; profiles/r04_d)
+    // (the half engine as make_launch resolves it)
+    const int he_opt = (int)opt_of(h, "half_engine", 1);
+    const bool half = h->gemm_split && d.H == 256 && (he_opt == 2 || (he_opt == 1 && d.cutoff2 >= 0.f));
     if (h->gemm_split && d.H == 256) {
         if (e_est / 64.0 >= 4.0 * h->n_cus) h->edge_mt = 128;
+        // on the half engine the chunked 128-row message kernel wins from ~48 C-alpha pockets (64: 29.6 vs 32.4 us per launch for the 32-row full-K
+        // tiles, 96: 37.7 vs 58.7 for the 64-row plane tiles; profiles/r05_t); the coordinate list stays on 32-row tiles until it is long
+        if (half && e_est >= 96.0 * h->n_cus) h->edge_mt = 128;
+        // ... and more 16-row node tiles than CUs means two rounds of k_node16w where 64-row plane tiles need one
+        if (half && (N + 15) / 16 > h->n_cus) h->node_mt = 32;
+        // the 32-row full-K coordinate tiles run on the half engine, 16-row tiles on the fp32 instruction: 32 rows from a quarter of a tile per CU
+        // (48 pockets: 32.9 us per launch on 16-row tiles, 64 pockets: 18.3 on 32-row ones)
+        if (half && h->coord_mt == 16 && ec_est / 32.0 >= 0.25 * h->n_cus) h->coord_mt = 32;
+        if (half && h->edge_mt == 16 && e_est / 32.0 >= 0.25 * h->n_cus) h->edge_mt = 32;        // (16 pockets: 29.0 us on 16-row tiles; 32 pockets: 21.2 on 32-row ones)
         if (ec_est / 32.0 >= 3.0 * h->n_cus) h->coord_mt = 128;      // (from 128 C-alpha pockets: profiles/r04_h)
         // dense samples (full-atom pockets: 36 neighbours per node, ~60 coordinate edges per phar point while the points sit at the pocket centre):
         // a receiver's edges outnumber the rows of a 16- / 32-row tile, its sum would be three or more float-atomic partials whose order the
@@ -667,8 +679,11 @@ EvalLaunch make_launch(cmdgen_handle* h) {
             const int ncu = h->n_cus, t64 = (h->lay.N + 63) / 64, t32 = (h->lay.N + 31) / 32;
             const float cost64 = (float)((t64 + ncu - 1) / ncu);
             const int full = t32 / (2 * ncu), rem = t32 - full * 2 * ncu;
-            const float cost32 = 1.12f * full + (rem == 0 ? 0.f : rem <= ncu ? 0.62f : 1.12f);
-            on = cost64 < cost32;
+            float cost32 = 1.12f * full + (rem == 0 ? 0.f : rem <= ncu ? 0.62f : 1.12f);
+            // half engine: k_node64 has a half form, the register-split 32-row tile has not - measured per launch (profiles/r05_t) 54.0 vs 44.6 us at
+            // 96 pockets (177 32-row tiles, one per CU), 87.5 vs 46.1 at 160 (two per CU)
+            if (a.half_engine) cost32 = 1.9f * full + (rem == 0 ? 0.f : rem <= ncu ? 1.22f : 1.9f);
+            on = cost64 < cost32 && !(a.half_engine && h->node_mt == 16);
             if (opt_set(h, "node64")) { const int64_t v = opt_of(h, "node64", 0); on = v == 32 ? 32 : v != 0; }
         }
         a.node64 = on;
