@@ -15,6 +15,9 @@ constexpr int H = 256;
 #ifndef CMDGEN_E128_AHEAD
 #define CMDGEN_E128_AHEAD 1     // the first 64 rows of the next quarter are gathered before the GEMM over this one (half engine)
 #endif
+#ifndef CMDGEN_E128_WPS
+#define CMDGEN_E128_WPS 2       // workgroups per CU the register allocation aims at (3 with 64-row tiles: diagnostic builds)
+#endif
 #ifndef CMDGEN_E128_MT
 #define CMDGEN_E128_MT 128
 #endif
@@ -551,7 +554,7 @@ __device__ __forceinline__ TileCtx make_ctx(const LayerW& lw, const EdgeSrc<COOR
 // ------------------------------------------------------------------------------------------------------------------------------
 // Driver 1: two free-running 256-thread workgroups per CU, one chunk walk each.
 template <bool COORD>
-__global__ __launch_bounds__(256, 2) void k_edge128(Layout lay, Work w, Dims d, LayerW lw, int layer, int live_thr) {
+__global__ __launch_bounds__(256, CMDGEN_E128_WPS) void k_edge128(Layout lay, Work w, Dims d, LayerW lw, int layer, int live_thr) {
     __shared__ E128Lds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const EdgeSrc<COORD> es(w);

@@ -44,7 +44,7 @@ namespace e128_bf3 {
             if (a.pe_start) hipExtLaunchKernelGGL(NSP::k_edge128pp<COORD_>, dim3(a.n_cus), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE); \
             else hipLaunchKernelGGL(NSP::k_edge128pp<COORD_>, dim3(a.n_cus), dim3(512), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE);    \
         } else {                                                                                                                                    \
-            const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 2 ? a.e128_wgs : 2) * a.n_cus;                                                       \
+            const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 4 ? a.e128_wgs : 2) * a.n_cus;                                                       \
             if (a.pe_start) hipExtLaunchKernelGGL(NSP::k_edge128<COORD_>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE); \
             else hipLaunchKernelGGL(NSP::k_edge128<COORD_>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE);         \
         }                                                                                                                                           \
