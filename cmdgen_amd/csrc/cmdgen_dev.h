@@ -35,6 +35,7 @@ struct WPack {                  // one Linear weight in the MFMA fragment orders
     const void*   wh16;         // the same two pieces in v_mfma_f32_16x16x32_f16 order (16-row tiles); null in training / where in % 128 != 0
     float         wh_scale;     // the power of two the matrix was multiplied by before its split (keeps both pieces in fp16's normal range)
     float         wh_inv;       // 1 / wh_scale
+    const float*  wh_dev;       // training forward: {wh_scale, 1 / wh_scale} of a pack re-made on the device every step (k_repack_half); null in the sampler
 };
 
 struct LayerW {                 // device pointers to one EquivariantBlock's packed weights
@@ -205,6 +206,7 @@ struct TrainTune {              // launch choices of the training step's gradien
     int wgrad_wgs = 768;        // ... of the fp32-instruction kernel (3 workgroups of 49 KB LDS per CU; profiles/r02_t3_training_round2.txt)
     int dgrad_mt = 0;           // rows per tile of the data-gradient kernel: 0 = by row count (64 from 24576 rows), 32, 64
     int dgrad_tail = 1;         // 1: dpre of an edge list is consumed inside the second-layer data gradient (k_dgrad_tail)
+    int wgrad_stream = 1;       // 1: weight / bias gradients on the handle's second stream, beside the chain of data gradients (cmdgen_train.hip)
 };
 
 struct EvalLaunch {             // everything one evaluation's launches need (host side)
@@ -230,6 +232,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     mutable int unit = -1;      // weight unit (GCL) of the launches being issued: block l, sub-layer s -> l * S + s; -1: the block index itself (S = 1)
     mutable int skip_pc = 0;    // 1: the unit is not the last GCL of its block - its node kernel projects no P_c | Q_c
     mutable int live_thr = 0;   // set around a block's launches when that applies: nodes within this many hops of a moving node are still read
+    int save_half = 0;          // with `save`: W2 / W7 (.wh, .wh_dev) carry half packs re-made this step: the two edge kernels run their 32-row full-K half form
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     int write_embed = 1;        // 1: pass 2 of the radius graph and k_embed share a launch (k_write_embed) where both fit (option "write_embed")
     int e128_wgs = 2;           // workgroups per CU of the 128-row edge kernels (kernels_edge128.hip)

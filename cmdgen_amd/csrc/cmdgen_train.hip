@@ -24,9 +24,11 @@ struct WgradBatch {               // kernels_train.hip: up to 8 weight gradients
 void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bool split3 = false, bool force3 = false);
 struct RepackSplitT { int src_off, ld; void* dst; int transpose; };                                       // kernels_train.hip
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s);
+struct RepackHalf { int src_off, ld; void* dst; float* sc; };                                                // kernels_train.hip
+void tr_repack_half(const float* theta, const void* tab, int n, hipStream_t s);
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
                         const float* pre, hipStream_t s, int pieces = 3, const void* W0b = nullptr, float* Yb = nullptr,
-                        bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0);
+                        bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0, const float* Yin = nullptr);
 void tr_reduce_pair(int E, int H, const float* scratch_a, float* out_w, float* out_b, const float* scratch_t, float* dWcol, int ldw, hipStream_t s);
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
 void tr_scale(float* x, float a, size_t n, hipStream_t s);
@@ -128,22 +130,33 @@ struct TrainState {
     float *dh, *dX, *dagg, *dP, *dQ, *dn, *dhfin, *ddec, *ddeca, *dhdyn, *denca_l, *denca_p;
     float *vel, *qdec1, *qdeca, *qdec_out, *dqdec, *dqdeca;     // velocity [N][4]; residue decoder (joint model's pocket output)
     float* d_scalar;                    // [4] device scalars (sum of squares, ...)
+    // Weight gradients on a second stream (option wgrad_stream, default on): they are off the chain of data gradients, and most of
+    // them are launches that cannot fill the chip (256 x 256 outputs over 4k-36k rows, split-K) - beside the data-gradient kernels they
+    // cost a fraction of what they cost alone.  What they read must outlive the main stream's next writer of the same buffer, so the
+    // buffers one block's weight gradients read while the next kernels of the chain write alternate: dpre2 / dpre7 by block parity,
+    // dP | dQ separately for the coordinate and the message list, dn by block parity, dh between the two sides of the node model.
+    hipStream_t ws = nullptr;
+    std::vector<hipEvent_t> evs;
+    float *actA2 = nullptr, *actB2 = nullptr, *dPc = nullptr, *dQc = nullptr, *dn2 = nullptr, *dh2 = nullptr;
     // the fused forward (the sampler's evaluation kernels with save hooks): per-step packed copies of the parameters
     std::vector<void*> pack_allocs;
     std::vector<LayerW> layers;         // device pointers: packed fragments + vectors inside theta (rebuilt per call: theta is the caller's)
     struct PackBlk { float *pq_e32, *pq_e16, *w2_32, *w2_16, *w3_32, *w3_16, *w4_32, *w4_16, *pq_c32, *pq_c16, *w7_32, *w7_16, *rd_e, *rd_c;
                      // split-bf16 fragment packs of the TRANSPOSED 256 x 256 blocks (data gradients, cmdgen_dgrad_split); H = 256 only
                      void *t_e0a, *t_e0b, *t_e2, *t_n0a, *t_n0b, *t_n2, *t_c0a, *t_c0b, *t_c2;
-                     void *s_e2, *s_c2; };       // split packs of edge_mlp.2 / coord_mlp.2 themselves: the forward's two edge kernels
+                     void *s_e2, *s_c2;          // split packs of edge_mlp.2 / coord_mlp.2 themselves: the forward's two edge kernels
+                     void *h_e2, *h_c2; float *hs_e2, *hs_c2; };   // ... and their half-engine packs with the device-side {scale, 1 / scale} (k_repack_half)
     std::vector<PackBlk> pack;          // rd_e / rd_c: [2][H] radial column then d0 column of edge_mlp.0 / coord_mlp.0
     float *emb_wT = nullptr, *embo_wT = nullptr;
-    void *frag_tab = nullptr, *misc_tab = nullptr, *split_tab = nullptr;
-    int n_frag = 0, n_misc = 0, max_frag4 = 0, max_misc = 0, n_split = 0;
+    void *frag_tab = nullptr, *misc_tab = nullptr, *split_tab = nullptr, *half_tab = nullptr;
+    int n_frag = 0, n_misc = 0, max_frag4 = 0, max_misc = 0, n_split = 0, n_half = 0;
 };
 
 void cmdgen_train_free(TrainState* t) {
     if (!t) return;
     free_pool(t->node_allocs); free_pool(t->edge_allocs); free_pool(t->pack_allocs);
+    for (hipEvent_t e : t->evs) hipEventDestroy(e);
+    if (t->ws) hipStreamDestroy(t->ws);
     delete t;
 }
 
@@ -171,6 +184,7 @@ static int ensure_state(cmdgen_handle* h) {
     NA(t->dh, float, N * H); NA(t->dX, float, N * 4); NA(t->dagg, float, N * H);
     NA(t->dP, float, 2 * N * H); t->dQ = t->dP + N * H;      // adjacent: zeroed by one memset
     NA(t->dn, float, N * H); NA(t->dhfin, float, N * d.dyn);
+    NA(t->dPc, float, 2 * N * H); t->dQc = t->dPc + N * H; NA(t->dn2, float, N * H); NA(t->dh2, float, N * H);
     NA(t->ddec, float, Nl * d.P); NA(t->ddeca, float, Nl * 2 * d.P); NA(t->dhdyn, float, N * d.dyn);
     NA(t->denca_l, float, Nl * 2 * d.P); NA(t->denca_p, float, Np * 2 * d.R);
     NA(t->vel, float, N * 4); NA(t->qdec1, float, Np * 2 * d.R); NA(t->qdeca, float, Np * 2 * d.R);
@@ -225,6 +239,21 @@ static int ensure_state(cmdgen_handle* h) {
             }
             if (!rc) rc = dev_alloc(h, t->pack_allocs, &p, st.size() * sizeof(RepackSplitT), false);
             if (!rc) { t->split_tab = p; hipMemcpy(p, st.data(), st.size() * sizeof(RepackSplitT), hipMemcpyHostToDevice); t->n_split = (int)st.size(); }
+            std::vector<RepackHalf> ht;
+            for (size_t l = 0; l < L && !rc; ++l) {
+                TrainState::PackBlk& k = t->pack[l];
+                const ParamTable::Blk& b = tb.blk[l];
+                auto hp = [&](const PRef& r, void** dst, float** sc) {
+                    if (rc) return;
+                    float* q = nullptr;
+                    rc = alloc((size_t)H * H + 4, &q); if (rc) return;              // two fp16 pieces per weight, then {scale, 1 / scale}
+                    *dst = q; *sc = q + (size_t)H * H;
+                    ht.push_back(RepackHalf{(int)r.w, r.in, q, *sc});
+                };
+                hp(b.e2, &k.h_e2, &k.hs_e2); hp(b.c2, &k.h_c2, &k.hs_c2);
+            }
+            if (!rc) rc = dev_alloc(h, t->pack_allocs, &p, ht.size() * sizeof(RepackHalf), false);
+            if (!rc) { t->half_tab = p; hipMemcpy(p, ht.data(), ht.size() * sizeof(RepackHalf), hipMemcpyHostToDevice); t->n_half = (int)ht.size(); }
         }
         if (!rc) rc = alloc((size_t)H * d.dyn, &t->emb_wT);
         if (!rc) rc = alloc((size_t)H * d.dyn, &t->embo_wT);
@@ -243,9 +272,44 @@ static int ensure_state(cmdgen_handle* h) {
         for (const RepackFrag& f : ft) t->max_frag4 = std::max(t->max_frag4, f.out * f.in / 4);
         for (const RepackMisc& m : mt) t->max_misc = std::max(t->max_misc, m.rows * m.cols);
     }
+    if (hipStreamCreateWithFlags(&t->ws, hipStreamNonBlocking) != hipSuccess) { t->ws = nullptr; (void)hipGetLastError(); }
     h->train = t;
     return 0;
 }
+
+// The second stream of the backward pass (TrainState::ws).  fork(): the side stream waits for everything queued on the main stream so
+// far and is returned (the main stream itself when the option is off: then every call below is a no-op and the pass is the serial one).
+// reads(bufs): what has just been queued on the side stream reads these buffers; writes(buf): the main stream is about to overwrite one -
+// it waits for the side stream's last reader first.  join(): the main stream waits for all side work (end of every backward call: the
+// caller's next kernel - optimizer, all-reduce - sees complete gradients).
+struct SideStream {
+    hipStream_t main, ws; bool on; std::vector<hipEvent_t>* pool; size_t next = 0;
+    std::map<const void*, hipEvent_t> rd;
+    bool forked = false;
+    hipEvent_t ev() {
+        if (next == pool->size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); pool->push_back(e); }
+        return (*pool)[next++];
+    }
+    hipStream_t fork() {
+        if (!on) return main;
+        hipEvent_t e = ev(); hipEventRecord(e, main); hipStreamWaitEvent(ws, e, 0); forked = true;
+        return ws;
+    }
+    void reads(std::initializer_list<const void*> bufs) {
+        if (!on) return;
+        hipEvent_t e = ev(); hipEventRecord(e, ws);
+        for (const void* b : bufs) rd[b] = e;
+    }
+    void writes(const void* b) {
+        if (!on) return;
+        auto it = rd.find(b);
+        if (it != rd.end()) { hipStreamWaitEvent(main, it->second, 0); rd.erase(it); }
+    }
+    void join() {
+        if (!on || !forked) return;
+        hipEvent_t e = ev(); hipEventRecord(e, ws); hipStreamWaitEvent(main, e, 0); rd.clear(); forked = false;
+    }
+};
 
 static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
     if ((size_t)E <= t->ecap && (size_t)Ec <= t->eccap) return 0;
@@ -260,6 +324,7 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
     EA(t->act1, float, L * ec * H); EA(t->act6, float, L * ecc * H);      // SiLU(pre2) / SiLU(pre7) are recomputed by their one consumer
     EA(t->pre6, float, L * ecc * H); EA(t->pre7, float, L * ecc * H); EA(t->phi, float, L * ecc);
     EA(t->actA, float, em * H); EA(t->actB, float, em * H);
+    EA(t->actA2, float, ec * H); EA(t->actB2, float, ecc * H);
     EA(t->dphi, float, ecc);
     EA(t->dcd, float4, ecc);
     EA(t->tail_scratch, float, std::max(tr_edge_tail_scratch_floats(em, H), tr_partial_scratch_floats(em, H)));
@@ -348,6 +413,9 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     tr_repack(theta, t->frag_tab, t->n_frag, t->max_frag4, t->misc_tab, t->n_misc, t->max_misc, s);
     if (h->gemm_split || t->bf16) tr_repack_split_t(theta, t->split_tab, t->n_split, s);        // data gradients (and the forward's two
     t->split_packs_valid = (h->gemm_split || t->bf16) && t->n_split > 0;                         // edge kernels) on the bf16 matrix pipe
+    // the forward's two edge kernels on the half engine (two fp16 pieces, three MFMAs per product: cmdgen_split.h) wherever the sampler would use it
+    const bool fwd_half = h->gemm_split && H == 256 && a.half_engine && a.edge_fullk && t->n_half > 0 && opt_of(h, "train_half", 1) != 0;
+    if (fwd_half) tr_repack_half(theta, t->half_tab, t->n_half, s);
     t->layers.assign(L, LayerW{});
     for (int l = 0; l < L; ++l) {
         const ParamTable::Blk& b = tb.blk[l];
@@ -355,11 +423,13 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
         LayerW& lw = t->layers[l];
         lw.Wpq_e = WPack{(const float4*)k.pq_e32, (const float4*)k.pq_e16}; lw.b1 = theta + b.e0.b; lw.wr_e = k.rd_e; lw.wd_e = k.rd_e + H;
         lw.W2 = WPack{(const float4*)k.w2_32, (const float4*)k.w2_16, H == 256 ? k.s_e2 : nullptr}; lw.b2 = theta + b.e2.b;
+        if (fwd_half) { lw.W2.wh = k.h_e2; lw.W2.wh_dev = k.hs_e2; }
         lw.wa = d.attention ? theta + b.att.w : theta + b.e2.b; lw.ba = d.attention ? theta + b.att.b : theta + b.e2.b;
         lw.W3 = WPack{(const float4*)k.w3_32, (const float4*)k.w3_16}; lw.b3 = theta + b.n0.b;
         lw.W4 = WPack{(const float4*)k.w4_32, (const float4*)k.w4_16}; lw.b4 = theta + b.n2.b;
         lw.Wpq_c = WPack{(const float4*)k.pq_c32, (const float4*)k.pq_c16}; lw.b6 = theta + b.c0.b; lw.wr_c = k.rd_c; lw.wd_c = k.rd_c + H;
         lw.W7 = WPack{(const float4*)k.w7_32, (const float4*)k.w7_16, H == 256 ? k.s_c2 : nullptr}; lw.b7 = theta + b.c2.b; lw.w5 = theta + b.c4.w;
+        if (fwd_half) { lw.W7.wh = k.h_c2; lw.W7.wh_dev = k.hs_c2; }
     }
     SmallW sw{};
     sw.pe0_w = theta + tb.pe0.w; sw.pe0_b = theta + tb.pe0.b; sw.pe2_w = theta + tb.pe2.w; sw.pe2_b = theta + tb.pe2.b;
@@ -376,6 +446,17 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     sv.qdec1 = t->qdec1; sv.qdeca = t->qdeca; sv.qdec_out = t->qdec_out;
     sv.ecap = t->ecap; sv.eccap = t->eccap;
     a.layers = t->layers.data(); a.sw = sw; a.save = &sv; a.skip_count = 2;
+    {   // tile rows of the two edge kernels: the training forward knows its lists' lengths (the sampler's pick_tiles estimates them, and its
+        // 128-row kernels have no activation-saving form): 32-row tiles until 64-row ones fill every CU four times over
+        auto rows = [&](int n) { return n / 64 >= 4 * h->n_cus ? 64 : (n / 32 >= h->n_cus / 4 ? 32 : 16); };
+        auto grid = [&](int n, int mt) { const int cap = (mt >= 64 ? 2 : 4) * h->n_cus, g = (int)((n / mt + 1) * 1.25) + 8; return g < h->n_cus / 4 ? h->n_cus / 4 : (g > cap ? cap : g); };
+        if (!opt_set(h, "edge_mt") || a.edge_mt == 128) { a.edge_mt = rows(E); a.edge_grid = grid(E, a.edge_mt); }
+        if (!opt_set(h, "coord_mt") || a.coord_mt == 128) { a.coord_mt = rows(Ec); a.coord_grid = grid(Ec, a.coord_mt); }
+        if (fwd_half) {     // the half form exists for 32-row full-K tiles (three workgroups per CU)
+            a.save_half = 1;
+            a.edge_mt = 32; a.edge_grid = grid(E, 32); a.coord_mt = 32; a.coord_grid = grid(Ec, 32);
+        }
+    }
     a.save_split = (h->gemm_split && t->split_packs_valid && H == 256) ? 1 : 0;
     if (h->agg_dirty) { HIPCHK(h, hipMemsetAsync(h->work.agg, 0, NH * sizeof(float), s)); h->agg_dirty = false; }
     cmdgen_launch_eval(a, xh_phar, xh_pocket, t_arr, nullptr, nullptr, eps_phar, eps_pocket, s, nullptr);
@@ -425,7 +506,15 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     const Work& w = h->work;
     const ParamTable& tb = t->tab;
     const size_t NH = (size_t)N * H;
-    auto bias_grad = [&](const PRef& r, int M, const float* dy, int ld) { tr_colsum(M, r.out, dy, ld, nullptr, grad + r.b, 1, s); };
+    const bool w3 = h->gemm_split;                                    // (three-piece weight gradients: opt-in, see cmdgen_wgrad_group)
+    const bool sp = t->split_packs_valid && H == 256;                 // [.,256] x [256,256] data gradients on the bf16 matrix pipe:
+    const int pcs = g_bf16 ? 1 : 3;                                   // three pieces per operand (fp32-accurate) or the leading one (bf16 operands)
+    const bool tail_fused = sp && g_train_tune.dgrad_tail != 0;
+    // weight / bias gradients leave the chain of data gradients for the second stream (TrainState::ws) where the buffers they read
+    // alternate (the fused-tail path); ss.on = false: everything on the caller's stream, in the order written
+    SideStream ss{s, t->ws, tail_fused && t->ws != nullptr && g_train_tune.wgrad_stream != 0, &t->evs};
+    hipStream_t sw = s;                                               // stream of the weight-gradient launches being queued
+    auto bias_grad = [&](const PRef& r, int M, const float* dy, int ld) { tr_colsum(M, r.out, dy, ld, nullptr, grad + r.b, 1, sw); };
     // node-level weight (and bias) gradients of a block are collected and launched together (cmdgen_wgrad_group)
     WgradBatch wb; wb.n = 0;
     auto defer_wgrad = [&](const PRef& r, int col0, int in, const float* dy, const float* x, bool with_bias) {
@@ -433,37 +522,39 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         wb.dy[q] = dy; wb.x[q] = x; wb.dw[q] = grad + r.w + col0; wb.db[q] = (with_bias && r.has_bias) ? grad + r.b : nullptr;
         wb.M[q] = r.out; wb.N[q] = in; wb.lddy[q] = r.out; wb.ldx[q] = in; wb.ldw[q] = r.in;
     };
-    auto flush_wgrads = [&]() { cmdgen_wgrad_group(wb, N, g_bf16, s, h->gemm_split); wb.n = 0; };
-    const bool w3 = h->gemm_split;                                    // (three-piece weight gradients: opt-in, see cmdgen_wgrad_group)
-    const bool sp = t->split_packs_valid && H == 256;                 // [.,256] x [256,256] data gradients on the bf16 matrix pipe:
-    const int pcs = g_bf16 ? 1 : 3;                                   // three pieces per operand (fp32-accurate) or the leading one (bf16 operands)
+    auto flush_wgrads = [&]() { cmdgen_wgrad_group(wb, N, g_bf16, sw, h->gemm_split); wb.n = 0; };
+    // small weight + bias gradient of one Linear of the readout / embedding stages
+    auto small_wgrad = [&](const PRef& r, int in, int M, const float* dy, int lddy, const float* x, int ldx) {
+        sw = ss.fork();
+        linear_wgrad(grad, r, 0, in, M, dy, lddy, x, ldx, sw);
+        bias_grad(r, M, dy, lddy);
+        sw = s;
+    };
+    // dh alternates between two buffers: block k of the pass (k = 0 for block L-1) reads dhb[k & 1] and leaves dL/dh_l in dhb[(k + 1) & 1]
+    float* dhb[2] = {t->dh, ss.on ? t->dh2 : t->dh};
     if (first_stage == 0) {
     // readout
+    float* dh0 = dhb[0];
     HIPCHK(h, hipMemsetAsync(t->dX, 0, (size_t)N * 4 * sizeof(float), s));
     tr_eps_bwd(Nl, P, 0, d_eps_phar, t->dX, t->ddec, s);
     HIPCHK(h, hipMemsetAsync(t->dhfin, 0, (size_t)N * d.dyn * sizeof(float), s));
     if (d_eps_pocket) {     // the pocket output exists in the loss (joint model): velocity rows Nl.. and the residue decoder
         tr_eps_bwd(Np, R, Nl, d_eps_pocket, t->dX, t->dqdec, s);
-        linear_wgrad(grad, tb.rd2, 0, 2 * R, Np, t->dqdec, R, t->qdeca, 2 * R, s);
-        bias_grad(tb.rd2, Np, t->dqdec, R);
+        small_wgrad(tb.rd2, 2 * R, Np, t->dqdec, R, t->qdeca, 2 * R);
         linear_dgrad(theta, tb.rd2, 0, 2 * R, Np, t->dqdec, R, t->dqdeca, 2 * R, false, s);
         tr_silu_bwd(t->dqdeca, t->qdec1, (size_t)Np * 2 * R, s);
-        linear_wgrad(grad, tb.rd0, 0, J, Np, t->dqdeca, 2 * R, t->hfin + (size_t)Nl * d.dyn, d.dyn, s);
-        bias_grad(tb.rd0, Np, t->dqdeca, 2 * R);
+        small_wgrad(tb.rd0, J, Np, t->dqdeca, 2 * R, t->hfin + (size_t)Nl * d.dyn, d.dyn);
         linear_dgrad(theta, tb.rd0, 0, J, Np, t->dqdeca, 2 * R, t->dhfin + (size_t)Nl * d.dyn, d.dyn, false, s);
     }
     if (d.joint) tr_center_per_sample(h->lay, t->dX, s);      // adjoint of the velocity's mean removal (a symmetric projection)
     if (!d.joint && Np) HIPCHK(h, hipMemsetAsync(t->dX + (size_t)Nl * 4, 0, (size_t)Np * 4 * sizeof(float), s));   // pocket rows do not move
-    linear_wgrad(grad, tb.pd2, 0, 2 * P, Nl, t->ddec, P, t->deca, 2 * P, s);
-    bias_grad(tb.pd2, Nl, t->ddec, P);
+    small_wgrad(tb.pd2, 2 * P, Nl, t->ddec, P, t->deca, 2 * P);
     linear_dgrad(theta, tb.pd2, 0, 2 * P, Nl, t->ddec, P, t->ddeca, 2 * P, false, s);
     tr_silu_bwd(t->ddeca, t->dec1, (size_t)Nl * 2 * P, s);
-    linear_wgrad(grad, tb.pd0, 0, J, Nl, t->ddeca, 2 * P, t->hfin, d.dyn, s);
-    bias_grad(tb.pd0, Nl, t->ddeca, 2 * P);
+    small_wgrad(tb.pd0, J, Nl, t->ddeca, 2 * P, t->hfin, d.dyn);
     linear_dgrad(theta, tb.pd0, 0, J, Nl, t->ddeca, 2 * P, t->dhfin, d.dyn, false, s);
-    linear_wgrad(grad, tb.embo, 0, H, N, t->dhfin, d.dyn, t->h + (size_t)L * NH, H, s);
-    bias_grad(tb.embo, N, t->dhfin, d.dyn);
-    linear_dgrad(theta, tb.embo, 0, H, N, t->dhfin, d.dyn, t->dh, H, false, s);
+    small_wgrad(tb.embo, H, N, t->dhfin, d.dyn, t->h + (size_t)L * NH, H);
+    linear_dgrad(theta, tb.embo, 0, H, N, t->dhfin, d.dyn, dh0, H, false, s);
     }
     for (int l = L - 1; l >= 0; --l) {
         const int stage = L - l;
@@ -479,105 +570,118 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         const float* act1 = t->act1 + (size_t)l * t->ecap * H;
         const float* act6 = t->act6 + (size_t)l * t->eccap * H;
         const float* nact = t->nact + (size_t)l * NH;
+        // this block's buffers (side stream on: what a weight gradient reads is not what the chain's next kernels write)
+        const int par = (L - 1 - l) & 1;
+        float* dh_in = dhb[par]; float* dh_out = dhb[par ^ 1];            // dL/dh_{l+1} (complete after the coordinate model's part) -> dL/dh_l
+        float* actA = ss.on && par ? t->actA2 : t->actA;                  // dpre2 [E]
+        float* actB = ss.on && par ? t->actB2 : t->actB;                  // dpre7 [Ec]
+        float* dn = ss.on && par ? t->dn2 : t->dn;
+        float* dPc = ss.on ? t->dPc : t->dP; float* dQc = ss.on ? t->dQc : t->dQ;       // coordinate list's dP | dQ
+        float* dPe = t->dP; float* dQe = t->dQ;                                          // message list's
         // ---- EquivariantUpdate: x_{l+1} = x_l + acc / nf ; dX holds dL/dx_{l+1} and becomes dL/dx_l
         // (dL/d acc = dX / normalization_factor is formed where it is read; every later kernel of the block only adds to dX)
         tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, Nm, t->dphi, t->dcd, s);
-        const size_t pq_floats = (size_t)(t->dQ - t->dP) + NH;                            // dP and dQ, adjacent
+        const size_t pq_floats = (size_t)(t->dQ - t->dP) + NH;            // dP and dQ, adjacent (dPc | dQc alike)
         const TrainState::PackBlk& pk = t->pack[l];
-        const bool tail_fused = sp && g_train_tune.dgrad_tail != 0;
         const bool pair = tail_fused;                         // the list's two reductions (head / gate partials, tail partials) as one launch
         // actB <- dpre7, d coord_mlp.4; also clears dP | dQ (hidden_nf is 64, 128 or 256: cmdgen_create)
-        tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, t->actB, pair ? t->part_scratch : t->tail_scratch, grad + b.c4.w, t->dP, pq_floats, s, pair);
+        ss.writes(actB); ss.writes(dPc);
+        tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, actB, pair ? t->part_scratch : t->tail_scratch, grad + b.c4.w, dPc, pq_floats, s, pair);
         {   // weight and bias gradient of coord_mlp.2 in one launch (c1 = act6)
             WgradBatch one; one.n = 1;
-            one.dy[0] = t->actB; one.x[0] = act6; one.dw[0] = grad + b.c2.w; one.db[0] = grad + b.c2.b;
+            one.dy[0] = actB; one.x[0] = act6; one.dw[0] = grad + b.c2.w; one.db[0] = grad + b.c2.b;
             one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.c2.in;
-            cmdgen_wgrad_group(one, Ec, g_bf16, s, w3);
+            sw = ss.fork();
+            cmdgen_wgrad_group(one, Ec, g_bf16, sw, w3);
+            ss.reads({actB}); sw = s;
         }
         if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
-            cmdgen_dgrad_tail(Ec, t->actB, pk.t_c2, pre6, w.crow, w.ccol, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
-                              t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
+            cmdgen_dgrad_tail(Ec, actB, pk.t_c2, pre6, w.crow, w.ccol, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
+                              dPc, dQc, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
         if (pair) tr_reduce_pair(Ec, H, t->part_scratch, grad + b.c4.w, nullptr, t->tail_scratch, grad + b.c0.w + 2 * H, ld1, s);
         else {
-            if (sp) cmdgen_dgrad_split(Ec, t->actB, pk.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s, pcs);
-            else linear_dgrad(theta, b.c2, 0, H, Ec, t->actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
+            if (sp) cmdgen_dgrad_split(Ec, actB, pk.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s, pcs);
+            else linear_dgrad(theta, b.c2, 0, H, Ec, actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
             // adjoints of the gathers, the radial / d0 column gradients, d radial and the geometry adjoint: one pass over dpre6
             tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
-                             t->dP, t->dQ, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, s);
+                             dPc, dQc, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, s);
         }
-        if (sp) cmdgen_dgrad_split(N, t->dP, pk.t_c0a, t->dQ, pk.t_c0b, t->dh, true, 1.0f, nullptr, s, pcs);
+        if (sp) cmdgen_dgrad_split(N, dPc, pk.t_c0a, dQc, pk.t_c0b, dh_in, true, 1.0f, nullptr, s, pcs);
         else {
-            linear_dgrad(theta, b.c0, 0, H, N, t->dP, H, t->dh, H, true, s);
-            linear_dgrad(theta, b.c0, H, H, N, t->dQ, H, t->dh, H, true, s);
+            linear_dgrad(theta, b.c0, 0, H, N, dPc, H, dh_in, H, true, s);
+            linear_dgrad(theta, b.c0, H, H, N, dQc, H, dh_in, H, true, s);
         }
-        // ---- node model: h_{l+1} = h_l + W4 SiLU(W3 [h_l | aggn] + b3) + b4 ; dh holds dL/dh_{l+1}
+        // ---- node model: h_{l+1} = h_l + W4 SiLU(W3 [h_l | aggn] + b3) + b4 ; dh_in holds dL/dh_{l+1}
         // weight / bias gradients of coord_mlp.0 (both halves) and node_mlp.2: one grouped launch, while dP, dQ and dh
-        // still hold what they are the gradients of (dP / dQ are reused by the edge model below, dh moves on to dL/dh_l)
-        defer_wgrad(b.c0, 0, H, t->dP, hn, true);
-        defer_wgrad(b.c0, H, H, t->dQ, hn, false);
-        defer_wgrad(b.n2, 0, H, t->dh, nact, true);
-        flush_wgrads();
+        // still hold what they are the gradients of
+        defer_wgrad(b.c0, 0, H, dPc, hn, true);
+        defer_wgrad(b.c0, H, H, dQc, hn, false);
+        defer_wgrad(b.n2, 0, H, dh_in, nact, true);
+        sw = ss.fork(); flush_wgrads(); ss.reads({dPc, dh_in}); sw = s;
+        ss.writes(dn);
         if (sp) {
-            cmdgen_dgrad_split(N, t->dh, pk.t_n2, nullptr, nullptr, t->dn, false, 1.0f, pre3, s, pcs);
-            cmdgen_dgrad_split(N, t->dn, pk.t_n0a, nullptr, nullptr, t->dh, true, 1.0f, nullptr, s, pcs,       // dh += dpre3 W3[:, :H] and
-                               pk.t_n0b, t->dagg, false, d.norm_factor);                                        // dagg = dpre3 W3[:, H:] / nf: one launch
+            cmdgen_dgrad_split(N, dh_in, pk.t_n2, nullptr, nullptr, dn, false, 1.0f, pre3, s, pcs);
+            ss.writes(dh_out);
+            cmdgen_dgrad_split(N, dn, pk.t_n0a, nullptr, nullptr, dh_out, true, 1.0f, nullptr, s, pcs,         // dh_out = dh_in + dpre3 W3[:, :H] and
+                               pk.t_n0b, t->dagg, false, d.norm_factor, 0, dh_in);                              // dagg = dpre3 W3[:, H:] / nf: one launch
         } else {
-            linear_dgrad(theta, b.n2, 0, H, N, t->dh, H, t->dn, H, false, s, pre3);       // dn <- dn1 * SiLU'(pre3) = dpre3
-            linear_dgrad(theta, b.n0, 0, H, N, t->dn, H, t->dh, H, true, s);              // dh is now dL/dh_l (residual kept)
-            linear_dgrad(theta, b.n0, H, H, N, t->dn, H, t->dagg, H, false, s);
+            linear_dgrad(theta, b.n2, 0, H, N, dh_in, H, dn, H, false, s, pre3);       // dn <- dn1 * SiLU'(pre3) = dpre3
+            linear_dgrad(theta, b.n0, 0, H, N, dn, H, dh_in, H, true, s);              // dh is now dL/dh_l (residual kept)
+            linear_dgrad(theta, b.n0, H, H, N, dn, H, t->dagg, H, false, s);
             tr_scale(t->dagg, d.norm_factor, NH, s);
         }
         // ---- edge model
         // actA <- dpre2, d att_mlp; also clears dP | dQ
-        tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, t->actA, pair ? t->part_scratch : t->tail_scratch,
-                    d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, t->dP, pq_floats, s, pair);
+        ss.writes(actA); ss.writes(dPe);
+        tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, actA, pair ? t->part_scratch : t->tail_scratch,
+                    d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, dPe, pq_floats, s, pair);
         {   // weight and bias gradient of edge_mlp.2 in one launch (m1 = act1)
             WgradBatch one; one.n = 1;
-            one.dy[0] = t->actA; one.x[0] = act1; one.dw[0] = grad + b.e2.w; one.db[0] = grad + b.e2.b;
+            one.dy[0] = actA; one.x[0] = act1; one.dw[0] = grad + b.e2.w; one.db[0] = grad + b.e2.b;
             one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.e2.in;
-            cmdgen_wgrad_group(one, E, g_bf16, s, w3);
+            sw = ss.fork();
+            cmdgen_wgrad_group(one, E, g_bf16, sw, w3);
+            ss.reads({actA}); sw = s;
         }
         if (tail_fused)
-            cmdgen_dgrad_tail(E, t->actA, pk.t_e2, pre1, w.erow, w.ecol, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
-                              t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
+            cmdgen_dgrad_tail(E, actA, pk.t_e2, pre1, w.erow, w.ecol, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
+                              dPe, dQe, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
         if (pair) tr_reduce_pair(E, H, t->part_scratch, d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr,
                                  t->tail_scratch, grad + b.e0.w + 2 * H, ld1, s);
         else {
-            if (sp) cmdgen_dgrad_split(E, t->actA, pk.t_e2, nullptr, nullptr, t->actB, false, 1.0f, pre1, s, pcs);
-            else linear_dgrad(theta, b.e2, 0, H, E, t->actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
+            if (sp) cmdgen_dgrad_split(E, actA, pk.t_e2, nullptr, nullptr, t->actB, false, 1.0f, pre1, s, pcs);
+            else linear_dgrad(theta, b.e2, 0, H, E, actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
             tr_edge_tail_bwd(E, H, w.erow, w.ecol, t->actB, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
-                             t->dP, t->dQ, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, s);
+                             dPe, dQe, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, s);
         }
         // node_mlp.0 (both halves) and edge_mlp.0 (both halves): the second grouped launch of the block
-        defer_wgrad(b.n0, 0, H, t->dn, hl, true);
-        defer_wgrad(b.n0, H, H, t->dn, aggn, false);
-        defer_wgrad(b.e0, 0, H, t->dP, hl, true);
-        defer_wgrad(b.e0, H, H, t->dQ, hl, false);
-        flush_wgrads();
-        if (sp) cmdgen_dgrad_split(N, t->dP, pk.t_e0a, t->dQ, pk.t_e0b, t->dh, true, 1.0f, nullptr, s, pcs);
+        defer_wgrad(b.n0, 0, H, dn, hl, true);
+        defer_wgrad(b.n0, H, H, dn, aggn, false);
+        defer_wgrad(b.e0, 0, H, dPe, hl, true);
+        defer_wgrad(b.e0, H, H, dQe, hl, false);
+        sw = ss.fork(); flush_wgrads(); ss.reads({dn, dPe}); sw = s;
+        float* dh_l = dh_out;                       // (= dh_in when the side stream is off: in place)
+        if (sp) cmdgen_dgrad_split(N, dPe, pk.t_e0a, dQe, pk.t_e0b, dh_l, true, 1.0f, nullptr, s, pcs);
         else {
-            linear_dgrad(theta, b.e0, 0, H, N, t->dP, H, t->dh, H, true, s);
-            linear_dgrad(theta, b.e0, H, H, N, t->dQ, H, t->dh, H, true, s);
+            linear_dgrad(theta, b.e0, 0, H, N, dPe, H, dh_l, H, true, s);
+            linear_dgrad(theta, b.e0, H, H, N, dQe, H, dh_l, H, true, s);
         }
     }
-    if (last_stage < L + 1) { HIPCHK(h, hipGetLastError()); return CMDGEN_OK; }
+    if (last_stage < L + 1) { ss.join(); HIPCHK(h, hipGetLastError()); return CMDGEN_OK; }
     // embedding and encoders
-    linear_wgrad(grad, tb.emb, 0, d.dyn, N, t->dh, H, t->hdyn, d.dyn, s);
-    bias_grad(tb.emb, N, t->dh, H);
-    linear_dgrad(theta, tb.emb, 0, d.dyn, N, t->dh, H, t->dhdyn, d.dyn, false, s);
-    linear_wgrad(grad, tb.pe2, 0, 2 * P, Nl, t->dhdyn, d.dyn, t->enca_l, 2 * P, s);
-    bias_grad(tb.pe2, Nl, t->dhdyn, d.dyn);
+    float* dhE = dhb[L & 1];
+    small_wgrad(tb.emb, d.dyn, N, dhE, H, t->hdyn, d.dyn);
+    linear_dgrad(theta, tb.emb, 0, d.dyn, N, dhE, H, t->dhdyn, d.dyn, false, s);
+    small_wgrad(tb.pe2, 2 * P, Nl, t->dhdyn, d.dyn, t->enca_l, 2 * P);
     linear_dgrad(theta, tb.pe2, 0, 2 * P, Nl, t->dhdyn, d.dyn, t->denca_l, 2 * P, false, s);
     tr_silu_bwd(t->denca_l, t->enc1_l, (size_t)Nl * 2 * P, s);
-    linear_wgrad(grad, tb.pe0, 0, P, Nl, t->denca_l, 2 * P, t->xh_phar + 3, ldp, s);
-    bias_grad(tb.pe0, Nl, t->denca_l, 2 * P);
+    small_wgrad(tb.pe0, P, Nl, t->denca_l, 2 * P, t->xh_phar + 3, ldp);
     const float* dq = t->dhdyn + (size_t)Nl * d.dyn;
-    linear_wgrad(grad, tb.re2, 0, 2 * R, Np, dq, d.dyn, t->enca_p, 2 * R, s);
-    bias_grad(tb.re2, Np, dq, d.dyn);
+    small_wgrad(tb.re2, 2 * R, Np, dq, d.dyn, t->enca_p, 2 * R);
     linear_dgrad(theta, tb.re2, 0, 2 * R, Np, dq, d.dyn, t->denca_p, 2 * R, false, s);
     tr_silu_bwd(t->denca_p, t->enc1_p, (size_t)Np * 2 * R, s);
-    linear_wgrad(grad, tb.re0, 0, R, Np, t->denca_p, 2 * R, t->xh_pocket + 3, ldq, s);
-    bias_grad(tb.re0, Np, t->denca_p, 2 * R);
+    small_wgrad(tb.re0, R, Np, t->denca_p, 2 * R, t->xh_pocket + 3, ldq);
+    ss.join();
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;
 }

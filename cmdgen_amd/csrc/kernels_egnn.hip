@@ -654,7 +654,9 @@ __device__ __forceinline__ void build_edge_half(unsigned short* planes, int half
 // (c4 = tid % 64) of rows pass * 4 + tid / 64; wr4 / wd4: the thread's four radial / d0 weights (fixed columns: registers, no LDS).
 template <int NPC>
 __device__ __forceinline__ void build_edge_full32(unsigned short* planes, const int* s_row, const int* s_col, const float* s_r, const float* s_d0,
-                                                  int ne, const float* __restrict__ P, const float* __restrict__ Q, const float4& wr4, const float4& wd4) {
+                                                  int ne, const float* __restrict__ P, const float* __restrict__ Q, const float4& wr4, const float4& wd4,
+                                                  float* __restrict__ pre_out = nullptr, float* __restrict__ act_out = nullptr) {
+    // pre_out / act_out (training forward): the tile's first row of the stored pre-activations / activations (whole 1 KB rows per wave)
     constexpr int H = 256, MT = 32;
     const int c4 = threadIdx.x & 63, rsub = threadIdx.x >> 6;
     float4 p[MT / 4], q[MT / 4];
@@ -673,8 +675,13 @@ __device__ __forceinline__ void build_edge_full32(unsigned short* planes, const 
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < ne) {
             const float r = s_r[e], d0 = s_d0[e];
-            a = make_float4(silu_f(p[pass].x + q[pass].x + wr4.x * r + wd4.x * d0), silu_f(p[pass].y + q[pass].y + wr4.y * r + wd4.y * d0),
-                            silu_f(p[pass].z + q[pass].z + wr4.z * r + wd4.z * d0), silu_f(p[pass].w + q[pass].w + wr4.w * r + wd4.w * d0));
+            const float4 pre = make_float4(p[pass].x + q[pass].x + wr4.x * r + wd4.x * d0, p[pass].y + q[pass].y + wr4.y * r + wd4.y * d0,
+                                           p[pass].z + q[pass].z + wr4.z * r + wd4.z * d0, p[pass].w + q[pass].w + wr4.w * r + wd4.w * d0);
+            a = make_float4(silu_f(pre.x), silu_f(pre.y), silu_f(pre.z), silu_f(pre.w));
+            if (pre_out) {
+                reinterpret_cast<float4*>(pre_out + (size_t)e * H)[c4] = pre;
+                reinterpret_cast<float4*>(act_out + (size_t)e * H)[c4] = a;
+            }
         }
         if constexpr (NPC == 3) split_store4_swz(planes, e, c4, a); else split_store4_swz_half(planes, e, c4, a);
     }
@@ -790,7 +797,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
     const int tid = threadIdx.x, wave = tid >> 6;
     s_wa[tid] = lw.wa[tid];                                    // visible after the first tile's barriers
     constexpr bool PL = SP && H == 256 && MT >= 32;            // plane variant: the producer splits (build_edge_half)
-    static_assert(!FK || (PL && MT == 32 && !SAVE), "full-K planes: 32-row sampler tiles on the split engine");
+    static_assert(!FK || (PL && MT == 32 && (!SAVE || FK == 2)), "full-K planes: 32-row tiles on the split engine (training forward: the half engine only)");
     if constexpr (PL && !FK) { s_wrd[tid] = lw.wr_e[tid]; s_wrd[H + tid] = lw.wd_e[tid]; }
     const ColVec<MT> b2v = col_load<MT>(lw.b2, wave);          // per-column bias and the gate's bias: once per workgroup
     const float ba0 = lw.ba[0];
@@ -800,7 +807,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
         if (d.sin) for (int i = tid; i < 24 * H; i += H) s_dyn[i] = lw.we_e[i];          // (the first tile's barrier covers it)
     typedef typename EdgeEng<MT, SP, FK>::G G;
     float inv2 = 1.0f;                                         // the half engine's accumulators carry the weight pack's power-of-two scale
-    if constexpr (FK != 0) inv2 = G::inv(lw.W2);
+    if constexpr (FK != 0) inv2 = SAVE ? lw.W2.wh_dev[1] : G::inv(lw.W2);      // (training: the pack and its scale are re-made on the device every step)
     const typename G::Frag fw = G::frag(lw.W2, H / 8, 0, wave);
     typename G::Carry carry;
     G::prefetch(fw, carry);     // before the edge count is known: the first fragments fly beside that load and the index / position
@@ -868,7 +875,9 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
         acc_zero<MT>(acc);
         if constexpr (FK) {
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
-            if (!(ablate & 2)) build_edge_full32<FK>(planes, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4);
+            if (!(ablate & 2)) build_edge_full32<FK>(planes, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4,
+                                                     SAVE ? sv.pre1 + ((size_t)layer * sv.ecap + e0) * H : nullptr,
+                                                     SAVE ? sv.act1 + ((size_t)layer * sv.ecap + e0) * H : nullptr);
             lds_barrier();
             STAMP(1);
             if (!(ablate & 4)) G::gemm(planes, fw, acc.a, carry);
@@ -1161,7 +1170,7 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
     const int tid = threadIdx.x, wave = tid >> 6;
     s_w5[tid] = lw.w5[tid];                                    // coord_mlp.4 weight, staged once per workgroup (see edge_msg_body)
     constexpr bool PL = SP && H == 256 && MT >= 32;            // plane variant, see edge_msg_body
-    static_assert(!FK || (PL && MT == 32 && !SAVE), "full-K planes: 32-row sampler tiles on the split engine");
+    static_assert(!FK || (PL && MT == 32 && (!SAVE || FK == 2)), "full-K planes: 32-row tiles on the split engine (training forward: the half engine only)");
     if constexpr (PL && !FK) { s_wrd[tid] = lw.wr_c[tid]; s_wrd[H + tid] = lw.wd_c[tid]; }
     const ColVec<MT> b7v = col_load<MT>(lw.b7, wave);
     const float4 wr4 = reinterpret_cast<const float4*>(lw.wr_c)[tid % (H / 4)], wd4 = reinterpret_cast<const float4*>(lw.wd_c)[tid % (H / 4)];
@@ -1170,7 +1179,7 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
         if (d.sin) for (int i = tid; i < 24 * H; i += H) s_dyn[i] = lw.we_c[i];
     typedef typename EdgeEng<MT, SP, FK>::G G;
     float inv7 = 1.0f;                                         // (see edge_msg_body)
-    if constexpr (FK != 0) inv7 = G::inv(lw.W7);
+    if constexpr (FK != 0) inv7 = SAVE ? lw.W7.wh_dev[1] : G::inv(lw.W7);
     const typename G::Frag fw = G::frag(lw.W7, H / 8, 0, wave);
     typename G::Carry carry;
     G::prefetch(fw, carry);                                    // unconditional, see edge_msg_body
@@ -1211,7 +1220,9 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
         acc_zero<MT>(acc);
         if constexpr (FK) {
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
-            build_edge_full32<FK>(planes, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, wr4, wd4);
+            build_edge_full32<FK>(planes, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, wr4, wd4,
+                                  SAVE ? sv.pre6 + ((size_t)layer * sv.eccap + e0) * H : nullptr,
+                                  SAVE ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr);
             lds_barrier();
             G::gemm(planes, fw, acc.a, carry);
         } else if constexpr (PL) {
@@ -1459,8 +1470,12 @@ template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, in
 }
 // 32-row sampler tiles on the split engine: full-K planes (one build, one GEMM per tile; see cmdgen_split.h) unless CMDGEN_EDGE_FULLK=0
 static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
-    if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.edge_mt != 32) return false;
+    if (!a.edge_fullk || (a.save && !a.save_half) || !a.split || a.d.H != 256 || a.edge_mt != 32) return false;
     const LayerW& lw = a.layers[unit_of(a, l)];
+    if (a.save) {       // training forward on the half engine (packs and scale re-made on the device every step: WPack::wh_dev)
+        hipLaunchKernelGGL((k_edge_msg<256, 32, true, true, 2>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, lw, l, a.ablate, *a.save, 0);
+        return true;
+    }
     if (a.half_engine && lw.W2.wh) {
         if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<256, 32, false, true, 2>), dim3(a.edge_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw, l, a.ablate, TrainSave{}, a.live_thr);
         else hipLaunchKernelGGL((k_edge_msg<256, 32, false, true, 2>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, lw, l, a.ablate, TrainSave{}, a.live_thr);
@@ -1471,8 +1486,12 @@ static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     return true;
 }
 static bool launch_coord_fullk(const EvalLaunch& a, int l, hipStream_t s) {
-    if (!a.edge_fullk || a.save || !a.split || a.d.H != 256 || a.coord_mt != 32) return false;
+    if (!a.edge_fullk || (a.save && !a.save_half) || !a.split || a.d.H != 256 || a.coord_mt != 32) return false;
     const LayerW& lw = a.layers[unit_of(a, l)];
+    if (a.save) {
+        hipLaunchKernelGGL((k_edge_coord<256, 32, true, true, 2>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, lw, l, *a.save);
+        return true;
+    }
     if (a.half_engine && lw.W7.wh) {
         if (a.pe_start) hipExtLaunchKernelGGL((k_edge_coord<256, 32, false, true, 2>), dim3(a.coord_grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw, l, TrainSave{});
         else hipLaunchKernelGGL((k_edge_coord<256, 32, false, true, 2>), dim3(a.coord_grid), dim3(256), 0, s, a.lay, a.w, a.d, lw, l, TrainSave{});

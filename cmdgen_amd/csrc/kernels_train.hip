@@ -764,11 +764,12 @@ __device__ __forceinline__ void dgrad_tile_gemm(unsigned short* planes, int M, i
 template <int MT, int NPC>
 __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __restrict__ A0, const void* __restrict__ W0,
                                                         const float* __restrict__ A1, const void* __restrict__ W1,
-                                                        float* __restrict__ Y, int accumulate, float div,
+                                                        float* Y, int accumulate, float div,
                                                         const float* __restrict__ pre, const void* __restrict__ W0b,
-                                                        float* __restrict__ Yb, int accumulate_b, float div_b) {
+                                                        float* __restrict__ Yb, int accumulate_b, float div_b, const float* Yin) {
     // gridDim.y = 2: a second product of the same A0 (W0b -> Yb; the two halves of node_mlp.0 share dpre3) in the same launch
-    if (blockIdx.y) { W0 = W0b; Y = Yb; accumulate = accumulate_b; div = div_b; }
+    // Yin: the running value an accumulating product adds to (Y itself, or another buffer: Y = Yin + product, out of place)
+    if (blockIdx.y) { W0 = W0b; Y = Yb; Yin = Yb; accumulate = accumulate_b; div = div_b; }
     constexpr int HH = 256, PLDA = SPLIT_PLANE_LDA(HH / 2), PE = MT * PLDA;
     constexpr int LDO = HH + 4, SMEM = 3 * PE * 2 > 32 * LDO * 4 ? 3 * PE * 2 : 32 * LDO * 4;   // planes / 32-row fp32 output image
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __re
             const int row = row0 + m * 32 + p * 4 + rs;
             if (row < M) {
                 if (pre) pv[p] = reinterpret_cast<const float4*>(pre + (size_t)row * HH)[q4];
-                if (accumulate) yv[p] = reinterpret_cast<const float4*>(Y + (size_t)row * HH)[q4];
+                if (accumulate) yv[p] = reinterpret_cast<const float4*>(Yin + (size_t)row * HH)[q4];
             }
         }
 #pragma unroll
@@ -832,17 +833,67 @@ __global__ void k_repack_split_t(const float* __restrict__ theta, const RepackSp
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_repack_split_t, dim3(8 * 16 * 64 / 256, n), dim3(256), 0, s, theta, (const RepackSplitT*)tab);
 }
+// Half-engine packs of the training forward's two edge kernels (cmdgen_split.h, "half" engine), re-made every step like the split packs:
+// two fp16 pieces of (w * 2^e) per weight in v_mfma_f32_32x32x16_f16 fragment order (the layout of pack_half, cmdgen_api.hip), e chosen ON
+// THE DEVICE so that the largest |w| of the matrix lands in [2^11, 2^12) - the parameters move every step, no host value can be trusted -
+// and sc = {2^e, 2^-e} left beside the pack for the kernel's epilogue (WPack::wh_dev).  One workgroup of 1024 threads per 256 x 256 matrix:
+// the 64 weights a thread packs stay in its registers between the maximum and the split.
+struct RepackHalf { int src_off, ld; void* dst; float* sc; };
+__global__ __launch_bounds__(1024) void k_repack_half(const float* __restrict__ theta, const RepackHalf* __restrict__ tab) {
+    const RepackHalf f = tab[blockIdx.x];
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    float4 va[8], vb[8];
+    float mx = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int idx = q * 1024 + tid;                                // (nt * 16 + kb) * 64 + lane, nt < 8, kb < 16
+        const int lane = idx & 63, kb = (idx >> 6) & 15, nt = idx >> 10;
+        const int o = 32 * nt + (lane & 31), k = 16 * kb + 8 * (lane >> 5);
+        const float4* src = reinterpret_cast<const float4*>(theta + f.src_off + (size_t)o * f.ld + k);
+        va[q] = src[0]; vb[q] = src[1];
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(va[q].x), fabsf(va[q].y)), fmaxf(fabsf(va[q].z), fabsf(va[q].w))));
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(vb[q].x), fabsf(vb[q].y)), fmaxf(fabsf(vb[q].z), fabsf(vb[q].w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
+    int e = 0;
+    if (mx > 0.f && mx < 3.0e38f) e = 12 - ((int)((__float_as_uint(mx) >> 23) & 0xffu) - 126);     // mx = m 2^ex, m in [0.5, 1): mx 2^e in [2^11, 2^12)
+    e = max(-40, min(40, e));
+    const float sc = __uint_as_float((unsigned)(127 + e) << 23);
+    if (tid == 0) { f.sc[0] = sc; f.sc[1] = __uint_as_float((unsigned)(127 - e) << 23); }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int idx = q * 1024 + tid;
+        const int lane = idx & 63;
+        const float w[8] = {va[q].x * sc, va[q].y * sc, va[q].z * sc, va[q].w * sc, vb[q].x * sc, vb[q].y * sc, vb[q].z * sc, vb[q].w * sc};
+        union { _Float16 h[8]; uint4 u; } p0, p1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { p0.h[j] = (_Float16)w[j]; p1.h[j] = (_Float16)(w[j] - (float)p0.h[j]); }
+        uint4* d = reinterpret_cast<uint4*>(f.dst) + (size_t)((idx >> 6) * 2) * 64 + lane;
+        d[0] = p0.u; d[64] = p1.u;
+    }
+}
+void tr_repack_half(const float* theta, const void* tab, int n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_repack_half, dim3(n), dim3(1024), 0, s, theta, (const RepackHalf*)tab);
+}
 // pieces = 3: fp32-accurate (split engine); 1: the operands' leading bf16 piece only (= operands rounded to nearest-even
 // bf16, fp32 accumulation: cmdgen_train_set_precision(1))
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
                         const float* pre, hipStream_t s, int pieces = 3, const void* W0b = nullptr, float* Yb = nullptr,
-                        bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0) {
+                        bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0, const float* Yin = nullptr) {
     if (M <= 0) return;
+    if (!Yin) Yin = Y;
     const int mt = g_train_tune.dgrad_mt;
     const bool big = force_mt ? force_mt == 64 : (mt ? mt == 64 : M >= 24576);     // force_mt: cmdgen_debug_dgrad
     const int acc = accumulate ? 1 : 0, ny = W0b ? 2 : 1;
 #define DG(MT_, NP_) hipLaunchKernelGGL((k_dgrad_split<MT_, NP_>), dim3((M + MT_ - 1) / MT_, ny), dim3(256), 0, s, M, A0, W0, A1, W1, Y, acc, div, pre, \
-                                        W0b, Yb, accumulate_b ? 1 : 0, div_b)
+                                        W0b, Yb, accumulate_b ? 1 : 0, div_b, Yin)
     if (pieces == 3) { if (big) DG(64, 3); else DG(32, 3); }
     else { if (big) DG(64, 1); else DG(32, 1); }
 #undef DG

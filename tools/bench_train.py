@@ -17,6 +17,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cmdgen_amd  # noqa: E402,F401
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _opts  # noqa: E402,F401   (CMDGEN_OPTIONS="wgrad_stream=0,..." -> every new handle)
 from cmdgen_amd.lightning_modules import PharPocketDDPM  # noqa: E402
 from cmdgen_amd.synthetic import ModelConfig, make_pockets, make_state_dict  # noqa: E402
 from cmdgen_amd.training import HipTrainer  # noqa: E402
