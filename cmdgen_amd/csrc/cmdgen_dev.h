@@ -233,6 +233,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     mutable int skip_pc = 0;    // 1: the unit is not the last GCL of its block - its node kernel projects no P_c | Q_c
     mutable int live_thr = 0;   // set around a block's launches when that applies: nodes within this many hops of a moving node are still read
     int save_half = 0;          // with `save`: W2 / W7 (.wh, .wh_dev) carry half packs re-made this step: the two edge kernels run their 32-row full-K half form
+    int save_half16 = 0;        // with `save`: W3 / W4 / Wpq_c / Wpq_e (.wh16, .wh_dev) carry 16-row half packs re-made this step: k_node16w<true>
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     int write_embed = 1;        // 1: pass 2 of the radius graph and k_embed share a launch (k_write_embed) where both fit (option "write_embed")
     int e128_wgs = 2;           // workgroups per CU of the 128-row edge kernels (kernels_edge128.hip)

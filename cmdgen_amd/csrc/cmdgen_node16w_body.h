@@ -142,7 +142,10 @@ __device__ __forceinline__ float nw_silu_scaled(float a, float c1, float sc) {
     const float u = __builtin_amdgcn_exp2f(a * c1);
     return a * __builtin_amdgcn_rcpf(__fmaf_rn(u, sc, sc));
 }
-__global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next_arg) {
+// SAVE (training forward, half engine only): the tile also leaves agg / nf, the node MLP's pre-activation and activation and the new h in the
+// activation store (TrainSave), and the packs' power-of-two scales come from the device (WPack::wh_dev: the packs are re-made every step)
+template <bool SAVE>
+__global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next_arg, TrainSave sv) {
     __shared__ __attribute__((aligned(16))) float buf0[NW_MT * NW_LD];      // h (kept for the residual)
     __shared__ __attribute__((aligned(16))) float buf1[NW_MT * NW_LD];      // agg / nf -> T = SiLU(.) -> h_new
     const int has_next = has_next_arg & 1;                                   // (bits 1..29: the dead-tile threshold of the plane tiles, unused here)
@@ -160,7 +163,9 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
     nw_prefetch(f3a, ring);
     NwCol b3v = nw_col(lw.b3, wave);
     const NwCol b4v = nw_col(lw.b4, wave), b6v = nw_col(lw.b6, wave), b1nv = nw_col(lw_next.b1, wave);
-    const float sc3 = nw_scale(lw.W3), c13 = -1.4426950408889634f * nw_inv(lw.W3), inv4 = nw_inv(lw.W4), invc = nw_inv(lw.Wpq_c), invn = nw_inv(lw_next.Wpq_e);
+    float sc3 = nw_scale(lw.W3), inv3 = nw_inv(lw.W3), inv4 = nw_inv(lw.W4), invc = nw_inv(lw.Wpq_c), invn = nw_inv(lw_next.Wpq_e);
+    if constexpr (SAVE) { sc3 = lw.W3.wh_dev[0]; inv3 = lw.W3.wh_dev[1]; inv4 = lw.W4.wh_dev[1]; invc = lw.Wpq_c.wh_dev[1]; invn = lw_next.Wpq_e.wh_dev[1]; }
+    const float c13 = -1.4426950408889634f * inv3;
     b3v.v[0] *= sc3; b3v.v[1] *= sc3;                                      // the accumulators carry their weight pack's scale
     // materialise the phar coordinates entering this block (node_pos, kernels_egnn.hip: X[l] = X[l-1] + ACC[l-1] / normalization_factor)
     if (layer >= 1 && tid < NW_MT) {
@@ -191,6 +196,7 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
             float4 v = av[j];
             const float dv = r < nvalid ? agg_div(w, d, row0 + r) : 1.0f;
             v.x /= dv; v.y /= dv; v.z /= dv; v.w /= dv;
+            if (SAVE && r < nvalid) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * NW_H)[c4] = v;
             *reinterpret_cast<float4*>(buf0 + r * NW_LD + 4 * c4) = hv[j];
             *reinterpret_cast<float4*>(buf1 + r * NW_LD + 4 * c4) = v;
         }
@@ -210,7 +216,14 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
     nw_gemm<KB>(buf1, f3b, f4, acc, ring);                                   // agg part
     NSTAMP(1);
     nw_barrier();
-    nw_foreach(acc, wave, [&](int row, int col, int n, float v) { buf1[row * NW_LD + col] = nw_silu_scaled(v + b3v.v[n], c13, sc3); });
+    nw_foreach(acc, wave, [&](int row, int col, int n, float v) {
+        const float t = nw_silu_scaled(v + b3v.v[n], c13, sc3);
+        buf1[row * NW_LD + col] = t;
+        if (SAVE && row < nvalid) {
+            const size_t o = ((size_t)layer * lay.N + row0 + row) * NW_H + col;
+            sv.pre3[o] = (v + b3v.v[n]) * inv3; sv.nact[o] = t;
+        }
+    });
     nw_barrier();
     NSTAMP(2);
     nw_zero(acc);
@@ -223,6 +236,7 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
         if (row < nvalid) {
             hn = buf0[row * NW_LD + col] + __fmaf_rn(v, inv4, b4v.v[n]);        // residual (egnn_new.py:57)
             w.h[(size_t)(row0 + row) * NW_H + col] = hn;
+            if (SAVE) sv.h[((size_t)(layer + 1) * lay.N + row0 + row) * NW_H + col] = hn;      // h entering block layer + 1
         }
         buf1[row * NW_LD + col] = hn;
     });

@@ -3,6 +3,7 @@
 // buffers owned by the caller (one contiguous bucket: a single RCCL all-reduce per step for data parallelism).
 // Conditional and joint (update_pocket_coords = 1) models.  Kernels: kernels_train.hip.
 #include "cmdgen_host.h"
+#include <functional>
 
 void cmdgen_launch_edges(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, hipStream_t s);
 void cmdgen_launch_eval(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, const float* t_arr, const float4* coef,
@@ -26,6 +27,8 @@ struct RepackSplitT { int src_off, ld; void* dst; int transpose; };             
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s);
 struct RepackHalf { int src_off, ld; void* dst; float* sc; };                                                // kernels_train.hip
 void tr_repack_half(const float* theta, const void* tab, int n, hipStream_t s);
+struct RepackHalf16 { int src_off, ld, out, in, row_split, col_shift; void* dst; float* sc; };            // kernels_train.hip
+void tr_repack_half16(const float* theta, const void* tab, int n, int max8, hipStream_t s);
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
                         const float* pre, hipStream_t s, int pieces = 3, const void* W0b = nullptr, float* Yb = nullptr,
                         bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0, const float* Yin = nullptr);
@@ -135,9 +138,9 @@ struct TrainState {
     // cost a fraction of what they cost alone.  What they read must outlive the main stream's next writer of the same buffer, so the
     // buffers one block's weight gradients read while the next kernels of the chain write alternate: dpre2 / dpre7 by block parity,
     // dP | dQ separately for the coordinate and the message list, dn by block parity, dh between the two sides of the node model.
-    hipStream_t ws = nullptr;
+    hipStream_t ws = nullptr, ws_low = nullptr;      // (ws_low: the same at the device's lowest stream priority, wgrad_stream = 2)
     std::vector<hipEvent_t> evs;
-    float *actA2 = nullptr, *actB2 = nullptr, *dPc = nullptr, *dQc = nullptr, *dn2 = nullptr, *dh2 = nullptr;
+    float *actA2 = nullptr, *actB2 = nullptr, *dPx[3] = {nullptr, nullptr, nullptr}, *dn2 = nullptr, *dh2 = nullptr, *dh3 = nullptr;
     // the fused forward (the sampler's evaluation kernels with save hooks): per-step packed copies of the parameters
     std::vector<void*> pack_allocs;
     std::vector<LayerW> layers;         // device pointers: packed fragments + vectors inside theta (rebuilt per call: theta is the caller's)
@@ -145,11 +148,12 @@ struct TrainState {
                      // split-bf16 fragment packs of the TRANSPOSED 256 x 256 blocks (data gradients, cmdgen_dgrad_split); H = 256 only
                      void *t_e0a, *t_e0b, *t_e2, *t_n0a, *t_n0b, *t_n2, *t_c0a, *t_c0b, *t_c2;
                      void *s_e2, *s_c2;          // split packs of edge_mlp.2 / coord_mlp.2 themselves: the forward's two edge kernels
-                     void *h_e2, *h_c2; float *hs_e2, *hs_c2; };   // ... and their half-engine packs with the device-side {scale, 1 / scale} (k_repack_half)
+                     void *h_e2, *h_c2; float *hs_e2, *hs_c2;
+                     void *h16_w3, *h16_w4, *h16_pqc, *h16_pqe; float *hs_w3, *hs_w4, *hs_pqc, *hs_pqe; };   // 16-row half packs of the node kernel (k_repack_half16)   // ... and their half-engine packs with the device-side {scale, 1 / scale} (k_repack_half)
     std::vector<PackBlk> pack;          // rd_e / rd_c: [2][H] radial column then d0 column of edge_mlp.0 / coord_mlp.0
     float *emb_wT = nullptr, *embo_wT = nullptr;
-    void *frag_tab = nullptr, *misc_tab = nullptr, *split_tab = nullptr, *half_tab = nullptr;
-    int n_frag = 0, n_misc = 0, max_frag4 = 0, max_misc = 0, n_split = 0, n_half = 0;
+    void *frag_tab = nullptr, *misc_tab = nullptr, *split_tab = nullptr, *half_tab = nullptr, *half16_tab = nullptr;
+    int n_frag = 0, n_misc = 0, max_frag4 = 0, max_misc = 0, n_split = 0, n_half = 0, n_half16 = 0, max_half16 = 0;
 };
 
 void cmdgen_train_free(TrainState* t) {
@@ -157,6 +161,7 @@ void cmdgen_train_free(TrainState* t) {
     free_pool(t->node_allocs); free_pool(t->edge_allocs); free_pool(t->pack_allocs);
     for (hipEvent_t e : t->evs) hipEventDestroy(e);
     if (t->ws) hipStreamDestroy(t->ws);
+    if (t->ws_low) hipStreamDestroy(t->ws_low);
     delete t;
 }
 
@@ -184,7 +189,8 @@ static int ensure_state(cmdgen_handle* h) {
     NA(t->dh, float, N * H); NA(t->dX, float, N * 4); NA(t->dagg, float, N * H);
     NA(t->dP, float, 2 * N * H); t->dQ = t->dP + N * H;      // adjacent: zeroed by one memset
     NA(t->dn, float, N * H); NA(t->dhfin, float, N * d.dyn);
-    NA(t->dPc, float, 2 * N * H); t->dQc = t->dPc + N * H; NA(t->dn2, float, N * H); NA(t->dh2, float, N * H);
+    for (int i = 0; i < 3; ++i) NA(t->dPx[i], float, 2 * N * H);       // (dP | dQ pairs: coordinate / message list by block parity, with t->dP)
+    NA(t->dn2, float, N * H); NA(t->dh2, float, N * H); NA(t->dh3, float, N * H);
     NA(t->ddec, float, Nl * d.P); NA(t->ddeca, float, Nl * 2 * d.P); NA(t->dhdyn, float, N * d.dyn);
     NA(t->denca_l, float, Nl * 2 * d.P); NA(t->denca_p, float, Np * 2 * d.R);
     NA(t->vel, float, N * 4); NA(t->qdec1, float, Np * 2 * d.R); NA(t->qdeca, float, Np * 2 * d.R);
@@ -254,6 +260,25 @@ static int ensure_state(cmdgen_handle* h) {
             }
             if (!rc) rc = dev_alloc(h, t->pack_allocs, &p, ht.size() * sizeof(RepackHalf), false);
             if (!rc) { t->half_tab = p; hipMemcpy(p, ht.data(), ht.size() * sizeof(RepackHalf), hipMemcpyHostToDevice); t->n_half = (int)ht.size(); }
+            std::vector<RepackHalf16> h16;
+            for (size_t l = 0; l < L && !rc; ++l) {
+                TrainState::PackBlk& k = t->pack[l];
+                const ParamTable::Blk& b = tb.blk[l];
+                auto hp = [&](const PRef& r, int out, int in, int row_split, int col_shift, void** dst, float** sc) {
+                    if (rc) return;
+                    float* q = nullptr;
+                    rc = alloc((size_t)out * in + 4, &q); if (rc) return;           // two fp16 pieces per weight, then {scale, 1 / scale}
+                    *dst = q; *sc = q + (size_t)out * in;
+                    h16.push_back(RepackHalf16{(int)r.w, r.in, out, in, row_split, col_shift, q, *sc});
+                    t->max_half16 = std::max(t->max_half16, out * in / 8);
+                };
+                hp(b.n0, (int)H, 2 * (int)H, 0, 0, &k.h16_w3, &k.hs_w3);
+                hp(b.n2, (int)H, (int)H, 0, 0, &k.h16_w4, &k.hs_w4);
+                hp(b.c0, 2 * (int)H, (int)H, (int)H, (int)H, &k.h16_pqc, &k.hs_pqc);
+                hp(b.e0, 2 * (int)H, (int)H, (int)H, (int)H, &k.h16_pqe, &k.hs_pqe);
+            }
+            if (!rc) rc = dev_alloc(h, t->pack_allocs, &p, h16.size() * sizeof(RepackHalf16), false);
+            if (!rc) { t->half16_tab = p; hipMemcpy(p, h16.data(), h16.size() * sizeof(RepackHalf16), hipMemcpyHostToDevice); t->n_half16 = (int)h16.size(); }
         }
         if (!rc) rc = alloc((size_t)H * d.dyn, &t->emb_wT);
         if (!rc) rc = alloc((size_t)H * d.dyn, &t->embo_wT);
@@ -273,18 +298,23 @@ static int ensure_state(cmdgen_handle* h) {
         for (const RepackMisc& m : mt) t->max_misc = std::max(t->max_misc, m.rows * m.cols);
     }
     if (hipStreamCreateWithFlags(&t->ws, hipStreamNonBlocking) != hipSuccess) { t->ws = nullptr; (void)hipGetLastError(); }
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&t->ws_low, hipStreamNonBlocking, least) != hipSuccess) { t->ws_low = nullptr; (void)hipGetLastError(); }
+    }
     h->train = t;
     return 0;
 }
 
-// The second stream of the backward pass (TrainState::ws).  fork(): the side stream waits for everything queued on the main stream so
-// far and is returned (the main stream itself when the option is off: then every call below is a no-op and the pass is the serial one).
-// reads(bufs): what has just been queued on the side stream reads these buffers; writes(buf): the main stream is about to overwrite one -
-// it waits for the side stream's last reader first.  join(): the main stream waits for all side work (end of every backward call: the
-// caller's next kernel - optimizer, all-reduce - sees complete gradients).
+// The second stream of the backward pass (TrainState::ws).  Every event operation on the main stream costs its queue a ~6 us bubble
+// (profiles/r05_ad_train_chain.txt), so the protocol is coarse: the weight gradients of a block are queued TOGETHER at the block's end -
+// fork(): the side stream waits for everything queued on the main stream so far (one event) - and everything they read sits in buffers
+// that the main stream writes again only two blocks later (TrainState: rotating dpre / dP | dQ / dn / dh), so one wait per block for the
+// side work of two blocks ago (mark() / wait()) covers every hazard.  join(): the main stream waits for all side work (end of every
+// backward call: the caller's next kernel - optimizer, all-reduce - sees complete gradients).  on = false: everything on the caller's stream.
 struct SideStream {
     hipStream_t main, ws; bool on; std::vector<hipEvent_t>* pool; size_t next = 0;
-    std::map<const void*, hipEvent_t> rd;
     bool forked = false;
     hipEvent_t ev() {
         if (next == pool->size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); pool->push_back(e); }
@@ -295,19 +325,11 @@ struct SideStream {
         hipEvent_t e = ev(); hipEventRecord(e, main); hipStreamWaitEvent(ws, e, 0); forked = true;
         return ws;
     }
-    void reads(std::initializer_list<const void*> bufs) {
-        if (!on) return;
-        hipEvent_t e = ev(); hipEventRecord(e, ws);
-        for (const void* b : bufs) rd[b] = e;
-    }
-    void writes(const void* b) {
-        if (!on) return;
-        auto it = rd.find(b);
-        if (it != rd.end()) { hipStreamWaitEvent(main, it->second, 0); rd.erase(it); }
-    }
+    hipEvent_t mark() { if (!on) return nullptr; hipEvent_t e = ev(); hipEventRecord(e, ws); return e; }
+    void wait(hipEvent_t e) { if (on && e) hipStreamWaitEvent(main, e, 0); }
     void join() {
         if (!on || !forked) return;
-        hipEvent_t e = ev(); hipEventRecord(e, ws); hipStreamWaitEvent(main, e, 0); rd.clear(); forked = false;
+        hipEvent_t e = ev(); hipEventRecord(e, ws); hipStreamWaitEvent(main, e, 0); forked = false;
     }
 };
 
@@ -416,6 +438,9 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     // the forward's two edge kernels on the half engine (two fp16 pieces, three MFMAs per product: cmdgen_split.h) wherever the sampler would use it
     const bool fwd_half = h->gemm_split && H == 256 && a.half_engine && a.edge_fullk && t->n_half > 0 && opt_of(h, "train_half", 1) != 0;
     if (fwd_half) tr_repack_half(theta, t->half_tab, t->n_half, s);
+    // ... and the node kernel as the sampler's eight-wave 16-row tile (k_node16w) where 16-row tiles are what the layout gets
+    const bool node_half = fwd_half && a.node_mt == 16 && t->n_half16 > 0 && opt_of(h, "train_half", 1) != 2;
+    if (node_half) tr_repack_half16(theta, t->half16_tab, t->n_half16, t->max_half16, s);
     t->layers.assign(L, LayerW{});
     for (int l = 0; l < L; ++l) {
         const ParamTable::Blk& b = tb.blk[l];
@@ -430,6 +455,10 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
         lw.Wpq_c = WPack{(const float4*)k.pq_c32, (const float4*)k.pq_c16}; lw.b6 = theta + b.c0.b; lw.wr_c = k.rd_c; lw.wd_c = k.rd_c + H;
         lw.W7 = WPack{(const float4*)k.w7_32, (const float4*)k.w7_16, H == 256 ? k.s_c2 : nullptr}; lw.b7 = theta + b.c2.b; lw.w5 = theta + b.c4.w;
         if (fwd_half) { lw.W7.wh = k.h_c2; lw.W7.wh_dev = k.hs_c2; }
+        if (node_half) {
+            lw.W3.wh16 = k.h16_w3; lw.W3.wh_dev = k.hs_w3; lw.W4.wh16 = k.h16_w4; lw.W4.wh_dev = k.hs_w4;
+            lw.Wpq_c.wh16 = k.h16_pqc; lw.Wpq_c.wh_dev = k.hs_pqc; lw.Wpq_e.wh16 = k.h16_pqe; lw.Wpq_e.wh_dev = k.hs_pqe;
+        }
     }
     SmallW sw{};
     sw.pe0_w = theta + tb.pe0.w; sw.pe0_b = theta + tb.pe0.b; sw.pe2_w = theta + tb.pe2.w; sw.pe2_b = theta + tb.pe2.b;
@@ -453,7 +482,7 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
         if (!opt_set(h, "edge_mt") || a.edge_mt == 128) { a.edge_mt = rows(E); a.edge_grid = grid(E, a.edge_mt); }
         if (!opt_set(h, "coord_mt") || a.coord_mt == 128) { a.coord_mt = rows(Ec); a.coord_grid = grid(Ec, a.coord_mt); }
         if (fwd_half) {     // the half form exists for 32-row full-K tiles (three workgroups per CU)
-            a.save_half = 1;
+            a.save_half = 1; a.save_half16 = node_half ? 1 : 0;
             a.edge_mt = 32; a.edge_grid = grid(E, 32); a.coord_mt = 32; a.coord_grid = grid(Ec, 32);
         }
     }
@@ -510,11 +539,21 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     const bool sp = t->split_packs_valid && H == 256;                 // [.,256] x [256,256] data gradients on the bf16 matrix pipe:
     const int pcs = g_bf16 ? 1 : 3;                                   // three pieces per operand (fp32-accurate) or the leading one (bf16 operands)
     const bool tail_fused = sp && g_train_tune.dgrad_tail != 0;
-    // weight / bias gradients leave the chain of data gradients for the second stream (TrainState::ws) where the buffers they read
-    // alternate (the fused-tail path); ss.on = false: everything on the caller's stream, in the order written
-    SideStream ss{s, t->ws, tail_fused && t->ws != nullptr && g_train_tune.wgrad_stream != 0, &t->evs};
-    hipStream_t sw = s;                                               // stream of the weight-gradient launches being queued
-    auto bias_grad = [&](const PRef& r, int M, const float* dy, int ld) { tr_colsum(M, r.out, dy, ld, nullptr, grad + r.b, 1, sw); };
+    // weight / bias gradients leave the chain of data gradients for the second stream (SideStream above) where the buffers they read
+    // rotate (the fused-tail path); ss.on = false: everything on the caller's stream, in the order written
+    hipStream_t side = g_train_tune.wgrad_stream == 2 && t->ws_low ? t->ws_low : t->ws;
+    SideStream ss{s, side, tail_fused && side != nullptr && g_train_tune.wgrad_stream != 0, &t->evs};
+    // deferred side work: queued where the serial pass launches it, run on the side stream by flush_side() (serial pass: run at once)
+    std::vector<std::function<void(hipStream_t)>> pending;
+    auto defer = [&](std::function<void(hipStream_t)> f) { if (ss.on) pending.push_back(std::move(f)); else f(s); };
+    auto flush_side = [&]() -> hipEvent_t {
+        if (pending.empty()) return nullptr;
+        hipStream_t q = ss.fork();
+        for (auto& f : pending) f(q);
+        pending.clear();
+        return ss.mark();
+    };
+    auto bias_grad = [&](const PRef& r, int M, const float* dy, int ld, hipStream_t q) { tr_colsum(M, r.out, dy, ld, nullptr, grad + r.b, 1, q); };
     // node-level weight (and bias) gradients of a block are collected and launched together (cmdgen_wgrad_group)
     WgradBatch wb; wb.n = 0;
     auto defer_wgrad = [&](const PRef& r, int col0, int in, const float* dy, const float* x, bool with_bias) {
@@ -522,16 +561,26 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         wb.dy[q] = dy; wb.x[q] = x; wb.dw[q] = grad + r.w + col0; wb.db[q] = (with_bias && r.has_bias) ? grad + r.b : nullptr;
         wb.M[q] = r.out; wb.N[q] = in; wb.lddy[q] = r.out; wb.ldx[q] = in; wb.ldw[q] = r.in;
     };
-    auto flush_wgrads = [&]() { cmdgen_wgrad_group(wb, N, g_bf16, sw, h->gemm_split); wb.n = 0; };
+    const bool bf = g_bf16, gs = h->gemm_split;
+    auto flush_wgrads = [&]() { const WgradBatch g = wb; defer([=](hipStream_t q) { cmdgen_wgrad_group(g, N, bf, q, gs); }); wb.n = 0; };
+    // weight + bias gradient of one edge-level Linear (K = list length) in one launch
+    auto edge_wgrad = [&](const PRef& r, const float* dy, const float* x, int K) {
+        WgradBatch one; one.n = 1;
+        one.dy[0] = dy; one.x[0] = x; one.dw[0] = grad + r.w; one.db[0] = grad + r.b;
+        one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = r.in;
+        defer([=](hipStream_t q) { cmdgen_wgrad_group(one, K, bf, q, w3); });
+    };
     // small weight + bias gradient of one Linear of the readout / embedding stages
     auto small_wgrad = [&](const PRef& r, int in, int M, const float* dy, int lddy, const float* x, int ldx) {
-        sw = ss.fork();
-        linear_wgrad(grad, r, 0, in, M, dy, lddy, x, ldx, sw);
-        bias_grad(r, M, dy, lddy);
-        sw = s;
+        const PRef* rp = &r;
+        defer([=](hipStream_t q) { g_bf16 = bf; linear_wgrad(grad, *rp, 0, in, M, dy, lddy, x, ldx, q); tr_colsum(M, rp->out, dy, lddy, nullptr, grad + rp->b, 1, q); });
     };
-    // dh alternates between two buffers: block k of the pass (k = 0 for block L-1) reads dhb[k & 1] and leaves dL/dh_l in dhb[(k + 1) & 1]
-    float* dhb[2] = {t->dh, ss.on ? t->dh2 : t->dh};
+    (void)bias_grad;
+    // rotating buffers (side stream on): block k of the pass (k = 0 for block L-1) reads dL/dh_{l+1} in dhb[k % 3] and leaves dL/dh_l in
+    // dhb[(k + 1) % 3]; dpre2 / dpre7 / dn / the two dP | dQ pairs by the parity of k.  Off: one buffer each, updated in place.
+    float* dhb[3] = {t->dh, ss.on ? t->dh2 : t->dh, ss.on ? t->dh3 : t->dh};
+    const size_t pq_off = (size_t)(t->dQ - t->dP);                    // dQ = dP + pq_off in every pair
+    std::vector<hipEvent_t> blk_done((size_t)L + 1, nullptr);         // side work of block k of THIS call
     if (first_stage == 0) {
     // readout
     float* dh0 = dhb[0];
@@ -555,6 +604,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     linear_dgrad(theta, tb.pd0, 0, J, Nl, t->ddeca, 2 * P, t->dhfin, d.dyn, false, s);
     small_wgrad(tb.embo, H, N, t->dhfin, d.dyn, t->h + (size_t)L * NH, H);
     linear_dgrad(theta, tb.embo, 0, H, N, t->dhfin, d.dyn, dh0, H, false, s);
+    flush_side();           // (none of what these read is written again in this pass)
     }
     for (int l = L - 1; l >= 0; --l) {
         const int stage = L - l;
@@ -570,31 +620,25 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         const float* act1 = t->act1 + (size_t)l * t->ecap * H;
         const float* act6 = t->act6 + (size_t)l * t->eccap * H;
         const float* nact = t->nact + (size_t)l * NH;
-        // this block's buffers (side stream on: what a weight gradient reads is not what the chain's next kernels write)
-        const int par = (L - 1 - l) & 1;
-        float* dh_in = dhb[par]; float* dh_out = dhb[par ^ 1];            // dL/dh_{l+1} (complete after the coordinate model's part) -> dL/dh_l
+        // this block's buffers
+        const int k = L - 1 - l, par = k & 1;
+        float* dh_in = dhb[k % 3]; float* dh_out = dhb[(k + 1) % 3];      // dL/dh_{l+1} (complete after the coordinate model's part) -> dL/dh_l
         float* actA = ss.on && par ? t->actA2 : t->actA;                  // dpre2 [E]
         float* actB = ss.on && par ? t->actB2 : t->actB;                  // dpre7 [Ec]
         float* dn = ss.on && par ? t->dn2 : t->dn;
-        float* dPc = ss.on ? t->dPc : t->dP; float* dQc = ss.on ? t->dQc : t->dQ;       // coordinate list's dP | dQ
-        float* dPe = t->dP; float* dQe = t->dQ;                                          // message list's
+        float* dPc = ss.on ? t->dPx[par] : t->dP; float* dQc = dPc + pq_off;                    // coordinate list's dP | dQ
+        float* dPe = ss.on && par ? t->dPx[2] : t->dP; float* dQe = dPe + pq_off;               // message list's
+        // everything this block writes was last read by the side work of block k - 2
+        if (k >= 2) ss.wait(blk_done[k - 2]);
         // ---- EquivariantUpdate: x_{l+1} = x_l + acc / nf ; dX holds dL/dx_{l+1} and becomes dL/dx_l
         // (dL/d acc = dX / normalization_factor is formed where it is read; every later kernel of the block only adds to dX)
         tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, Nm, t->dphi, t->dcd, s);
-        const size_t pq_floats = (size_t)(t->dQ - t->dP) + NH;            // dP and dQ, adjacent (dPc | dQc alike)
+        const size_t pq_floats = pq_off + NH;                             // dP and dQ, adjacent
         const TrainState::PackBlk& pk = t->pack[l];
         const bool pair = tail_fused;                         // the list's two reductions (head / gate partials, tail partials) as one launch
         // actB <- dpre7, d coord_mlp.4; also clears dP | dQ (hidden_nf is 64, 128 or 256: cmdgen_create)
-        ss.writes(actB); ss.writes(dPc);
         tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, actB, pair ? t->part_scratch : t->tail_scratch, grad + b.c4.w, dPc, pq_floats, s, pair);
-        {   // weight and bias gradient of coord_mlp.2 in one launch (c1 = act6)
-            WgradBatch one; one.n = 1;
-            one.dy[0] = actB; one.x[0] = act6; one.dw[0] = grad + b.c2.w; one.db[0] = grad + b.c2.b;
-            one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.c2.in;
-            sw = ss.fork();
-            cmdgen_wgrad_group(one, Ec, g_bf16, sw, w3);
-            ss.reads({actB}); sw = s;
-        }
+        edge_wgrad(b.c2, actB, act6, Ec);                     // weight and bias gradient of coord_mlp.2 (c1 = act6)
         if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
             cmdgen_dgrad_tail(Ec, actB, pk.t_c2, pre6, w.crow, w.ccol, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
                               dPc, dQc, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
@@ -617,11 +661,10 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         defer_wgrad(b.c0, 0, H, dPc, hn, true);
         defer_wgrad(b.c0, H, H, dQc, hn, false);
         defer_wgrad(b.n2, 0, H, dh_in, nact, true);
-        sw = ss.fork(); flush_wgrads(); ss.reads({dPc, dh_in}); sw = s;
-        ss.writes(dn);
+        flush_wgrads();
+        if (l == 0) flush_side();       // the last block of the pass: its side work starts as early as it can (nothing comes after to hide it)
         if (sp) {
             cmdgen_dgrad_split(N, dh_in, pk.t_n2, nullptr, nullptr, dn, false, 1.0f, pre3, s, pcs);
-            ss.writes(dh_out);
             cmdgen_dgrad_split(N, dn, pk.t_n0a, nullptr, nullptr, dh_out, true, 1.0f, nullptr, s, pcs,         // dh_out = dh_in + dpre3 W3[:, :H] and
                                pk.t_n0b, t->dagg, false, d.norm_factor, 0, dh_in);                              // dagg = dpre3 W3[:, H:] / nf: one launch
         } else {
@@ -632,17 +675,9 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         }
         // ---- edge model
         // actA <- dpre2, d att_mlp; also clears dP | dQ
-        ss.writes(actA); ss.writes(dPe);
         tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, actA, pair ? t->part_scratch : t->tail_scratch,
                     d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, dPe, pq_floats, s, pair);
-        {   // weight and bias gradient of edge_mlp.2 in one launch (m1 = act1)
-            WgradBatch one; one.n = 1;
-            one.dy[0] = actA; one.x[0] = act1; one.dw[0] = grad + b.e2.w; one.db[0] = grad + b.e2.b;
-            one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = b.e2.in;
-            sw = ss.fork();
-            cmdgen_wgrad_group(one, E, g_bf16, sw, w3);
-            ss.reads({actA}); sw = s;
-        }
+        edge_wgrad(b.e2, actA, act1, E);                      // weight and bias gradient of edge_mlp.2 (m1 = act1)
         if (tail_fused)
             cmdgen_dgrad_tail(E, actA, pk.t_e2, pre1, w.erow, w.ecol, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
                               dPe, dQe, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
@@ -659,17 +694,17 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         defer_wgrad(b.n0, H, H, dn, aggn, false);
         defer_wgrad(b.e0, 0, H, dPe, hl, true);
         defer_wgrad(b.e0, H, H, dQe, hl, false);
-        sw = ss.fork(); flush_wgrads(); ss.reads({dn, dPe}); sw = s;
-        float* dh_l = dh_out;                       // (= dh_in when the side stream is off: in place)
-        if (sp) cmdgen_dgrad_split(N, dPe, pk.t_e0a, dQe, pk.t_e0b, dh_l, true, 1.0f, nullptr, s, pcs);
+        flush_wgrads();
+        blk_done[k] = flush_side();                 // the block's weight gradients: one fork
+        if (sp) cmdgen_dgrad_split(N, dPe, pk.t_e0a, dQe, pk.t_e0b, dh_out, true, 1.0f, nullptr, s, pcs);       // (dh_out = dh_in when the side stream is off)
         else {
-            linear_dgrad(theta, b.e0, 0, H, N, dPe, H, dh_l, H, true, s);
-            linear_dgrad(theta, b.e0, H, H, N, dQe, H, dh_l, H, true, s);
+            linear_dgrad(theta, b.e0, 0, H, N, dPe, H, dh_out, H, true, s);
+            linear_dgrad(theta, b.e0, H, H, N, dQe, H, dh_out, H, true, s);
         }
     }
     if (last_stage < L + 1) { ss.join(); HIPCHK(h, hipGetLastError()); return CMDGEN_OK; }
     // embedding and encoders
-    float* dhE = dhb[L & 1];
+    float* dhE = dhb[L % 3];
     small_wgrad(tb.emb, d.dyn, N, dhE, H, t->hdyn, d.dyn);
     linear_dgrad(theta, tb.emb, 0, d.dyn, N, dhE, H, t->dhdyn, d.dyn, false, s);
     small_wgrad(tb.pe2, 2 * P, Nl, t->dhdyn, d.dyn, t->enca_l, 2 * P);
@@ -681,6 +716,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     linear_dgrad(theta, tb.re2, 0, 2 * R, Np, dq, d.dyn, t->denca_p, 2 * R, false, s);
     tr_silu_bwd(t->denca_p, t->enc1_p, (size_t)Np * 2 * R, s);
     small_wgrad(tb.re0, R, Np, t->denca_p, 2 * R, t->xh_pocket + 3, ldq);
+    flush_side();
     ss.join();
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;

@@ -31,14 +31,19 @@ namespace nw_bf3 {
 bool cmdgen_launch_node16w(const EvalLaunch& a, int l, hipStream_t s) {
     const LayerW& lw = a.layers[unit_of(a, l)];
     const LayerW& ln = a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)];
-    if (a.d.H != 256 || a.node_mt != 16 || !a.split16 || !a.node16w || a.save || !lw.W3.ws16) return false;
     const int nt = (a.lay.N + 15) / 16;
+    if (a.save) {       // training forward: the half form with save hooks, where the step re-made the 16-row half packs (EvalLaunch::save_half16)
+        if (a.d.H != 256 || a.node_mt != 16 || !a.save_half16 || !lw.W3.wh16 || !lw.W3.wh_dev) return false;
+        hipLaunchKernelGGL(nw_half::k_node16w<true>, dim3(nt), dim3(512), 0, s, a.lay, a.w, a.d, lw, ln, l, node_flags(a, l), *a.save);
+        return true;
+    }
+    if (a.d.H != 256 || a.node_mt != 16 || !a.split16 || !a.node16w || !lw.W3.ws16) return false;
     if (a.half_engine && lw.W3.wh16) {
-        if (a.pe_start) hipExtLaunchKernelGGL(nw_half::k_node16w, dim3(nt), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw, ln, l, node_flags(a, l));
-        else hipLaunchKernelGGL(nw_half::k_node16w, dim3(nt), dim3(512), 0, s, a.lay, a.w, a.d, lw, ln, l, node_flags(a, l));
+        if (a.pe_start) hipExtLaunchKernelGGL(nw_half::k_node16w<false>, dim3(nt), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw, ln, l, node_flags(a, l), TrainSave{});
+        else hipLaunchKernelGGL(nw_half::k_node16w<false>, dim3(nt), dim3(512), 0, s, a.lay, a.w, a.d, lw, ln, l, node_flags(a, l), TrainSave{});
     } else {
-        if (a.pe_start) hipExtLaunchKernelGGL(nw_bf3::k_node16w, dim3(nt), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw, ln, l, node_flags(a, l));
-        else hipLaunchKernelGGL(nw_bf3::k_node16w, dim3(nt), dim3(512), 0, s, a.lay, a.w, a.d, lw, ln, l, node_flags(a, l));
+        if (a.pe_start) hipExtLaunchKernelGGL(nw_bf3::k_node16w<false>, dim3(nt), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw, ln, l, node_flags(a, l), TrainSave{});
+        else hipLaunchKernelGGL(nw_bf3::k_node16w<false>, dim3(nt), dim3(512), 0, s, a.lay, a.w, a.d, lw, ln, l, node_flags(a, l), TrainSave{});
     }
     return true;
 }

@@ -882,6 +882,57 @@ __global__ __launch_bounds__(1024) void k_repack_half(const float* __restrict__ 
 void tr_repack_half(const float* theta, const void* tab, int n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_repack_half, dim3(n), dim3(1024), 0, s, theta, (const RepackHalf*)tab);
 }
+// The same for the node kernel of the training forward (k_node16w<true>): the 16-row half packs (v_mfma_f32_16x16x32_f16 fragment order,
+// the layout of pack_half16, cmdgen_api.hip) of node_mlp.0 [H][2H], node_mlp.2 [H][H] and the stacked projections [2H][H] of coord_mlp.0 /
+// edge_mlp.0 (RepackFrag's row_split / col_shift).  A pack has ONE scale (its products share accumulators), so the maximum is a launch of
+// its own: k_wmax16 (one workgroup per pack) leaves {2^e, 2^-e}, k_repack_half16 splits.
+struct RepackHalf16 { int src_off, ld, out, in, row_split, col_shift; void* dst; float* sc; };
+__device__ __forceinline__ const float* rh16_src(const float* theta, const RepackHalf16& f, int row, int k) {
+    int r = row, c = k;
+    if (f.row_split && row >= f.row_split) { r = row - f.row_split; c = k + f.col_shift; }
+    return theta + f.src_off + (size_t)r * f.ld + c;
+}
+__global__ __launch_bounds__(1024) void k_wmax16(const float* __restrict__ theta, const RepackHalf16* __restrict__ tab) {
+    const RepackHalf16 f = tab[blockIdx.x];
+    __shared__ float red[16];
+    const int tid = threadIdx.x, n4 = f.out * f.in / 4, k4 = f.in / 4;
+    float mx = 0.f;
+    for (int i = tid; i < n4; i += 1024) {
+        const float* src = rh16_src(theta, f, i / k4, 4 * (i % k4));
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(src[0]), fabsf(src[1])), fmaxf(fabsf(src[2]), fabsf(src[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        mx = red[0];
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) e = 12 - ((int)((__float_as_uint(mx) >> 23) & 0xffu) - 126);
+        e = max(-40, min(40, e));
+        f.sc[0] = __uint_as_float((unsigned)(127 + e) << 23); f.sc[1] = __uint_as_float((unsigned)(127 - e) << 23);
+    }
+}
+__global__ void k_repack_half16(const float* __restrict__ theta, const RepackHalf16* __restrict__ tab) {
+    const RepackHalf16 f = tab[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;         // (nt * KB + kb) * 64 + lane, nt < out / 16, kb < in / 32
+    if (idx >= f.out * f.in / 8) return;
+    const int KB = f.in / 32, lane = idx & 63, kb = (idx >> 6) % KB, nt = (idx >> 6) / KB, g = lane >> 4;
+    const float sc = f.sc[0];
+    const float* lo = rh16_src(theta, f, 16 * nt + (lane & 15), 32 * kb + 4 * g);           // k = 4g .. 4g + 3, then 16 + 4g .. 16 + 4g + 3
+    const float w[8] = {lo[0] * sc, lo[1] * sc, lo[2] * sc, lo[3] * sc, lo[16] * sc, lo[17] * sc, lo[18] * sc, lo[19] * sc};
+    union { _Float16 h[8]; uint4 u; } p0, p1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p0.h[j] = (_Float16)w[j]; p1.h[j] = (_Float16)(w[j] - (float)p0.h[j]); }
+    uint4* d = reinterpret_cast<uint4*>(f.dst) + (size_t)((idx >> 6) * 2) * 64 + lane;
+    d[0] = p0.u; d[64] = p1.u;
+}
+void tr_repack_half16(const float* theta, const void* tab, int n, int max8, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_wmax16, dim3(n), dim3(1024), 0, s, theta, (const RepackHalf16*)tab);
+    hipLaunchKernelGGL(k_repack_half16, dim3((max8 + 255) / 256, n), dim3(256), 0, s, theta, (const RepackHalf16*)tab);
+}
 // pieces = 3: fp32-accurate (split engine); 1: the operands' leading bf16 piece only (= operands rounded to nearest-even
 // bf16, fp32 accumulation: cmdgen_train_set_precision(1))
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,

@@ -29,3 +29,14 @@ for i, (s, e, n, q) in enumerate(step):
     tot[(n, q)][0] += 1; tot[(n, q)][1] += e - s; tot[(n, q)][2] += min(ov, e - s)
 for (n, q), (c, d, ov) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:28]:
     print(f'{1e-3 * d:8.1f} us {c:4d} x  overlapped {1e-3 * ov:7.1f} us  q{q}  {n}')
+
+# the main queue's chain in launch order (option --chain): start offset, duration, gap before it, kernel; side-queue launches marked '|'
+if '--chain' in sys.argv:
+    mainq = max(set(q for *_, q in step), key=lambda q: sum(1 for r in step if r[3] == q))
+    prev = t0
+    for s_, e_, n_, q_ in step:
+        if q_ == mainq:
+            print(f'{1e-3 * (s_ - t0):9.1f} +{1e-3 * (e_ - s_):7.1f}  gap {1e-3 * max(0, s_ - prev):6.1f}  {n_}')
+            prev = e_
+        else:
+            print(f'{1e-3 * (s_ - t0):9.1f} +{1e-3 * (e_ - s_):7.1f}              | {n_}')
