@@ -206,6 +206,7 @@ struct TrainTune {              // launch choices of the training step's gradien
     int wgrad_wgs = 768;        // ... of the fp32-instruction kernel (3 workgroups of 49 KB LDS per CU; profiles/r02_t3_training_round2.txt)
     int dgrad_mt = 0;           // rows per tile of the data-gradient kernel: 0 = by row count (64 from 24576 rows), 32, 64
     int dgrad_tail = 1;         // 1: dpre of an edge list is consumed inside the second-layer data gradient (k_dgrad_tail)
+    unsigned long long* dbg = nullptr;   // Work::dbg for the stamped diagnostic build of k_dgrad_tail (tools/tail_stamps.py)
     int wgrad_stream = 1;       // 1: weight / bias gradients on the handle's second stream, beside the chain of data gradients (cmdgen_train.hip)
 };
 

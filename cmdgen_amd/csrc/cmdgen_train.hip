@@ -25,7 +25,13 @@ struct WgradBatch {               // kernels_train.hip: up to 8 weight gradients
 void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bool split3 = false, bool force3 = false);
 struct RepackSplitT { int src_off, ld; void* dst; int transpose; };                                       // kernels_train.hip
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s);
-struct RepackHalf { int src_off, ld; void* dst; float* sc; };                                                // kernels_train.hip
+struct RepackHalf { int src_off, ld; void* dst; float* sc; int transpose; };                                 // kernels_train.hip
+struct HalfW { const void* w; const float* sc; };        // half pack of a transposed 256 x 256 block + {scale, 1 / scale} on the device
+void cmdgen_dgrad_split_h(int M, const float* A0, HalfW W0, const float* A1, HalfW W1, float* Y, bool accumulate, float div, const float* pre,
+                          hipStream_t s, HalfW W0b, float* Yb, bool accumulate_b, float div_b, const float* Yin);
+void cmdgen_dgrad_tail_h(int E, const float* dY, HalfW Wt, const float* pre1, const int* row, const int* col, const float* d0,
+                         const float* Wcol, int ldw, const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ,
+                         float* dX, float* scratch, hipStream_t s);
 void tr_repack_half(const float* theta, const void* tab, int n, hipStream_t s);
 struct RepackHalf16 { int src_off, ld, out, in, row_split, col_shift; void* dst; float* sc; };            // kernels_train.hip
 void tr_repack_half16(const float* theta, const void* tab, int n, int max8, hipStream_t s);
@@ -116,6 +122,7 @@ struct TrainState {
     size_t ecap = 0, eccap = 0;
     bool have_forward = false;
     bool split_packs_valid = false;     // the last forward re-packed the transposed split fragments (backward may use them)
+    bool half_packs_valid = false;      // ... and the half packs (forward edge kernels + the transposed blocks of the data gradients)
     bool bf16 = false;                  // GEMM operands in bf16 (fp32 accumulation); default exact fp32
     const float* theta = nullptr;       // parameters used by the last forward (backward reads the same)
     const float* xh_phar = nullptr; const float* xh_pocket = nullptr;
@@ -149,11 +156,12 @@ struct TrainState {
                      void *t_e0a, *t_e0b, *t_e2, *t_n0a, *t_n0b, *t_n2, *t_c0a, *t_c0b, *t_c2;
                      void *s_e2, *s_c2;          // split packs of edge_mlp.2 / coord_mlp.2 themselves: the forward's two edge kernels
                      void *h_e2, *h_c2; float *hs_e2, *hs_c2;
+                     HalfW th_e0a, th_e0b, th_e2, th_n0a, th_n0b, th_n2, th_c0a, th_c0b, th_c2;      // half packs of the transposed blocks (data gradients on the half engine)
                      void *h16_w3, *h16_w4, *h16_pqc, *h16_pqe; float *hs_w3, *hs_w4, *hs_pqc, *hs_pqe; };   // 16-row half packs of the node kernel (k_repack_half16)   // ... and their half-engine packs with the device-side {scale, 1 / scale} (k_repack_half)
     std::vector<PackBlk> pack;          // rd_e / rd_c: [2][H] radial column then d0 column of edge_mlp.0 / coord_mlp.0
     float *emb_wT = nullptr, *embo_wT = nullptr;
     void *frag_tab = nullptr, *misc_tab = nullptr, *split_tab = nullptr, *half_tab = nullptr, *half16_tab = nullptr;
-    int n_frag = 0, n_misc = 0, max_frag4 = 0, max_misc = 0, n_split = 0, n_half = 0, n_half16 = 0, max_half16 = 0;
+    int n_frag = 0, n_misc = 0, max_frag4 = 0, max_misc = 0, n_split = 0, n_half = 0, n_half_fwd = 0, n_half16 = 0, max_half16 = 0;
 };
 
 void cmdgen_train_free(TrainState* t) {
@@ -254,9 +262,24 @@ static int ensure_state(cmdgen_handle* h) {
                     float* q = nullptr;
                     rc = alloc((size_t)H * H + 4, &q); if (rc) return;              // two fp16 pieces per weight, then {scale, 1 / scale}
                     *dst = q; *sc = q + (size_t)H * H;
-                    ht.push_back(RepackHalf{(int)r.w, r.in, q, *sc});
+                    ht.push_back(RepackHalf{(int)r.w, r.in, q, *sc, 0});
                 };
                 hp(b.e2, &k.h_e2, &k.hs_e2); hp(b.c2, &k.h_c2, &k.hs_c2);
+            }
+            t->n_half_fwd = (int)ht.size();         // the forward's entries come first: the transposed blocks are re-made only when the data gradients use them
+            for (size_t l = 0; l < L && !rc; ++l) {
+                TrainState::PackBlk& k = t->pack[l];
+                const ParamTable::Blk& b = tb.blk[l];
+                auto tp = [&](const PRef& r, int col0, HalfW* dst) {
+                    if (rc) return;
+                    float* q = nullptr;
+                    rc = alloc((size_t)H * H + 4, &q); if (rc) return;
+                    dst->w = q; dst->sc = q + (size_t)H * H;
+                    ht.push_back(RepackHalf{(int)r.w + col0, r.in, q, q + (size_t)H * H, 1});
+                };
+                tp(b.e0, 0, &k.th_e0a); tp(b.e0, (int)H, &k.th_e0b); tp(b.e2, 0, &k.th_e2);
+                tp(b.n0, 0, &k.th_n0a); tp(b.n0, (int)H, &k.th_n0b); tp(b.n2, 0, &k.th_n2);
+                tp(b.c0, 0, &k.th_c0a); tp(b.c0, (int)H, &k.th_c0b); tp(b.c2, 0, &k.th_c2);
             }
             if (!rc) rc = dev_alloc(h, t->pack_allocs, &p, ht.size() * sizeof(RepackHalf), false);
             if (!rc) { t->half_tab = p; hipMemcpy(p, ht.data(), ht.size() * sizeof(RepackHalf), hipMemcpyHostToDevice); t->n_half = (int)ht.size(); }
@@ -437,7 +460,9 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     t->split_packs_valid = (h->gemm_split || t->bf16) && t->n_split > 0;                         // edge kernels) on the bf16 matrix pipe
     // the forward's two edge kernels on the half engine (two fp16 pieces, three MFMAs per product: cmdgen_split.h) wherever the sampler would use it
     const bool fwd_half = h->gemm_split && H == 256 && a.half_engine && a.edge_fullk && t->n_half > 0 && opt_of(h, "train_half", 1) != 0;
-    if (fwd_half) tr_repack_half(theta, t->half_tab, t->n_half, s);
+    const bool dgrad_half = fwd_half && !t->bf16 && opt_of(h, "dgrad_half", 0) != 0;      // (built, parity-green, not faster: profiles/r05_ag)
+    if (fwd_half) tr_repack_half(theta, t->half_tab, dgrad_half ? t->n_half : t->n_half_fwd, s);
+    t->half_packs_valid = dgrad_half;
     // ... and the node kernel as the sampler's eight-wave 16-row tile (k_node16w) where 16-row tiles are what the layout gets
     const bool node_half = fwd_half && a.node_mt == 16 && t->n_half16 > 0 && opt_of(h, "train_half", 1) != 2;
     if (node_half) tr_repack_half16(theta, t->half16_tab, t->n_half16, t->max_half16, s);
@@ -524,7 +549,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     if (!d_eps_phar || !grad) return fail(h, CMDGEN_EINVAL, "null device pointer");
     hipSetDevice(h->device);
     TrainState* t = h->train;
-    g_bf16 = t->bf16; g_train_tune = h->tune;
+    g_bf16 = t->bf16; g_train_tune = h->tune; g_train_tune.dbg = h->work.dbg;
     hipStream_t s = (hipStream_t)stream;
     h->last_stream = s;
     const Dims& d = h->dims;
@@ -539,6 +564,9 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     const bool sp = t->split_packs_valid && H == 256;                 // [.,256] x [256,256] data gradients on the bf16 matrix pipe:
     const int pcs = g_bf16 ? 1 : 3;                                   // three pieces per operand (fp32-accurate) or the leading one (bf16 operands)
     const bool tail_fused = sp && g_train_tune.dgrad_tail != 0;
+    // fp32-accurate data gradients on the half engine (row-scaled gradient rows, kernels_train.hip) where the forward made the half packs
+    const bool dgh = tail_fused && !g_bf16 && t->half_packs_valid;
+    const HalfW no_w{nullptr, nullptr};
     // weight / bias gradients leave the chain of data gradients for the second stream (SideStream above) where the buffers they read
     // rotate (the fused-tail path); ss.on = false: everything on the caller's stream, in the order written
     hipStream_t side = g_train_tune.wgrad_stream == 2 && t->ws_low ? t->ws_low : t->ws;
@@ -639,8 +667,10 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         // actB <- dpre7, d coord_mlp.4; also clears dP | dQ (hidden_nf is 64, 128 or 256: cmdgen_create)
         tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, actB, pair ? t->part_scratch : t->tail_scratch, grad + b.c4.w, dPc, pq_floats, s, pair);
         edge_wgrad(b.c2, actB, act6, Ec);                     // weight and bias gradient of coord_mlp.2 (c1 = act6)
-        if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
-            cmdgen_dgrad_tail(Ec, actB, pk.t_c2, pre6, w.crow, w.ccol, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
+        if (dgh) cmdgen_dgrad_tail_h(Ec, actB, pk.th_c2, pre6, w.crow, w.ccol, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
+                                     dPc, dQc, t->dX, t->tail_scratch, s);
+        else if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
+            cmdgen_dgrad_tail(Ec, actB, pk.t_c2, pre6, w.crow, w.ccol, w.cd0, pair ? pk.rd_c : theta + b.c0.w + 2 * H /* radial column: the forward's contiguous copy */, pair ? 1 : ld1, Xl, d.norm_constant, t->dcd, Nm,
                               dPc, dQc, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
         if (pair) tr_reduce_pair(Ec, H, t->part_scratch, grad + b.c4.w, nullptr, t->tail_scratch, grad + b.c0.w + 2 * H, ld1, s);
         else {
@@ -650,7 +680,8 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
                              dPc, dQc, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, s);
         }
-        if (sp) cmdgen_dgrad_split(N, dPc, pk.t_c0a, dQc, pk.t_c0b, dh_in, true, 1.0f, nullptr, s, pcs);
+        if (dgh) cmdgen_dgrad_split_h(N, dPc, pk.th_c0a, dQc, pk.th_c0b, dh_in, true, 1.0f, nullptr, s, no_w, nullptr, false, 1.0f, nullptr);
+        else if (sp) cmdgen_dgrad_split(N, dPc, pk.t_c0a, dQc, pk.t_c0b, dh_in, true, 1.0f, nullptr, s, pcs);
         else {
             linear_dgrad(theta, b.c0, 0, H, N, dPc, H, dh_in, H, true, s);
             linear_dgrad(theta, b.c0, H, H, N, dQc, H, dh_in, H, true, s);
@@ -663,7 +694,10 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         defer_wgrad(b.n2, 0, H, dh_in, nact, true);
         flush_wgrads();
         if (l == 0) flush_side();       // the last block of the pass: its side work starts as early as it can (nothing comes after to hide it)
-        if (sp) {
+        if (dgh) {
+            cmdgen_dgrad_split_h(N, dh_in, pk.th_n2, nullptr, no_w, dn, false, 1.0f, pre3, s, no_w, nullptr, false, 1.0f, nullptr);
+            cmdgen_dgrad_split_h(N, dn, pk.th_n0a, nullptr, no_w, dh_out, true, 1.0f, nullptr, s, pk.th_n0b, t->dagg, false, d.norm_factor, dh_in);
+        } else if (sp) {
             cmdgen_dgrad_split(N, dh_in, pk.t_n2, nullptr, nullptr, dn, false, 1.0f, pre3, s, pcs);
             cmdgen_dgrad_split(N, dn, pk.t_n0a, nullptr, nullptr, dh_out, true, 1.0f, nullptr, s, pcs,         // dh_out = dh_in + dpre3 W3[:, :H] and
                                pk.t_n0b, t->dagg, false, d.norm_factor, 0, dh_in);                              // dagg = dpre3 W3[:, H:] / nf: one launch
@@ -678,8 +712,10 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, actA, pair ? t->part_scratch : t->tail_scratch,
                     d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, dPe, pq_floats, s, pair);
         edge_wgrad(b.e2, actA, act1, E);                      // weight and bias gradient of edge_mlp.2 (m1 = act1)
-        if (tail_fused)
-            cmdgen_dgrad_tail(E, actA, pk.t_e2, pre1, w.erow, w.ecol, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
+        if (dgh) cmdgen_dgrad_tail_h(E, actA, pk.th_e2, pre1, w.erow, w.ecol, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
+                                     dPe, dQe, t->dX, t->tail_scratch, s);
+        else if (tail_fused)
+            cmdgen_dgrad_tail(E, actA, pk.t_e2, pre1, w.erow, w.ecol, w.ed0, pair ? pk.rd_e : theta + b.e0.w + 2 * H, pair ? 1 : ld1, Xl, d.norm_constant, nullptr, Nm,
                               dPe, dQe, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
         if (pair) tr_reduce_pair(E, H, t->part_scratch, d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr,
                                  t->tail_scratch, grad + b.e0.w + 2 * H, ld1, s);
@@ -696,7 +732,8 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         defer_wgrad(b.e0, H, H, dQe, hl, false);
         flush_wgrads();
         blk_done[k] = flush_side();                 // the block's weight gradients: one fork
-        if (sp) cmdgen_dgrad_split(N, dPe, pk.t_e0a, dQe, pk.t_e0b, dh_out, true, 1.0f, nullptr, s, pcs);       // (dh_out = dh_in when the side stream is off)
+        if (dgh) cmdgen_dgrad_split_h(N, dPe, pk.th_e0a, dQe, pk.th_e0b, dh_out, true, 1.0f, nullptr, s, no_w, nullptr, false, 1.0f, nullptr);
+        else if (sp) cmdgen_dgrad_split(N, dPe, pk.t_e0a, dQe, pk.t_e0b, dh_out, true, 1.0f, nullptr, s, pcs);       // (dh_out = dh_in when the side stream is off)
         else {
             linear_dgrad(theta, b.e0, 0, H, N, dPe, H, dh_out, H, true, s);
             linear_dgrad(theta, b.e0, H, H, N, dQe, H, dh_out, H, true, s);
