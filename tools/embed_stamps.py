@@ -1,4 +1,4 @@
-"""Per-phase cycle stamps of k_embed's full-path tiles (diagnostic build: kernels_egnn.hip compiled with -DCMDGEN_STAMPS=3)."""
+"""Per-phase cycle stamps of k_embed's full-path tiles (diagnostic build: kernels_egnn_graph.hip compiled with -DCMDGEN_STAMPS=3)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _opts  # noqa: E401,F401  (CMDGEN_OPTIONS -> handle options)
