@@ -197,6 +197,7 @@ struct TrainSave {              // activation store of the TRAINING forward (cmd
     float *hfin, *dec1, *deca, *dec_out;        // readout: [N][dyn], phar decoder [Nl][2P] x2, [Nl][P]
     float *qdec1, *qdeca, *qdec_out;            // residue decoder (joint model) [Np][2R] x2, [Np][R]
     size_t ecap, eccap;                         // row capacities of the per-block edge arrays
+    int slot;                                   // index of this launch's GCL in the per-GCL arrays (h, pre1 .. z, aggn .. nact): block * inv_sublayers + sub (set by the launcher; the coordinate arrays are per block)
 };
 
 struct TrainTune {              // launch choices of the training step's gradient kernels (cmdgen_set_option; defaults from sweeps on MI355X)

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
             float4 v = av[j];
             const float dv = r < nvalid ? agg_div(w, d, row0 + r) : 1.0f;
             v.x /= dv; v.y /= dv; v.z /= dv; v.w /= dv;
-            if (SAVE && r < nvalid) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * NW_H)[c4] = v;
+            if (SAVE && r < nvalid) reinterpret_cast<float4*>(sv.aggn + ((size_t)sv.slot * lay.N + row0 + r) * NW_H)[c4] = v;
             *reinterpret_cast<float4*>(buf0 + r * NW_LD + 4 * c4) = hv[j];
             *reinterpret_cast<float4*>(buf1 + r * NW_LD + 4 * c4) = v;
         }
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
         const float t = nw_silu_scaled(v + b3v.v[n], c13, sc3);
         buf1[row * NW_LD + col] = t;
         if (SAVE && row < nvalid) {
-            const size_t o = ((size_t)layer * lay.N + row0 + row) * NW_H + col;
+            const size_t o = ((size_t)sv.slot * lay.N + row0 + row) * NW_H + col;
             sv.pre3[o] = (v + b3v.v[n]) * inv3; sv.nact[o] = t;
         }
     });
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512) void k_node16w(Layout lay, Work w, Dims d, Lay
         if (row < nvalid) {
             hn = buf0[row * NW_LD + col] + __fmaf_rn(v, inv4, b4v.v[n]);        // residual (egnn_new.py:57)
             w.h[(size_t)(row0 + row) * NW_H + col] = hn;
-            if (SAVE) sv.h[((size_t)(layer + 1) * lay.N + row0 + row) * NW_H + col] = hn;      // h entering block layer + 1
+            if (SAVE) sv.h[((size_t)(sv.slot + 1) * lay.N + row0 + row) * NW_H + col] = hn;      // h entering block layer + 1
         }
         buf1[row * NW_LD + col] = hn;
     });

@@ -28,7 +28,7 @@ void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s
 struct RepackHalf { int src_off, ld; void* dst; float* sc; int transpose; };                                 // kernels_train.hip
 struct HalfW { const void* w; const float* sc; };        // half pack of a transposed 256 x 256 block + {scale, 1 / scale} on the device
 void cmdgen_dgrad_split_h(int M, const float* A0, HalfW W0, const float* A1, HalfW W1, float* Y, bool accumulate, float div, const float* pre,
-                          hipStream_t s, HalfW W0b, float* Yb, bool accumulate_b, float div_b, const float* Yin);
+                          hipStream_t s, HalfW W0b, float* Yb, bool accumulate_b, float div_b, const float* Yin, const float* rowdiv_b);
 void cmdgen_dgrad_tail_h(int E, const float* dY, HalfW Wt, const float* pre1, const int* row, const int* col, const float* d0,
                          const float* Wcol, int ldw, const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ,
                          float* dX, float* scratch, hipStream_t s);
@@ -37,12 +37,13 @@ struct RepackHalf16 { int src_off, ld, out, in, row_split, col_shift; void* dst;
 void tr_repack_half16(const float* theta, const void* tab, int n, int max8, hipStream_t s);
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
                         const float* pre, hipStream_t s, int pieces = 3, const void* W0b = nullptr, float* Yb = nullptr,
-                        bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0, const float* Yin = nullptr);
+                        bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0, const float* Yin = nullptr, const float* rowdiv_b = nullptr);
 void tr_reduce_pair(int E, int H, const float* scratch_a, float* out_w, float* out_b, const float* scratch_t, float* dWcol, int ldw, hipStream_t s);
 void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s);
 void tr_scale(float* x, float a, size_t n, hipStream_t s);
+void tr_scale_rows(float* x, const float* div, int H, size_t n, hipStream_t s);
 void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, const float* phi, int use_tanh, float range,
-                      float nc, const float* dacc, float dacc_div, int n_moving, float* dphi, float4* dcd, hipStream_t s);
+                      float nc, const float* dacc, float dacc_div, int n_moving, float* dphi, float4* dcd, hipStream_t s, const float* adiv = nullptr);
 void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float* g, const float* d0, const float* Wcol, int ldw,
                       const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ, float* dWcol, float* dX,
                       float* scratch, hipStream_t s);
@@ -87,7 +88,7 @@ struct ParamTable {
 };
 
 static void build_table(const Dims& d, ParamTable& t) {
-    t.blk.resize(d.L);
+    t.blk.resize((size_t)d.L * d.S);
     t.order.clear();
     size_t off = 0;
     auto add = [&](PRef& r, const std::string& name, int out, int in, bool bias) {
@@ -103,12 +104,18 @@ static void build_table(const Dims& d, ParamTable& t) {
     add(t.re0, "residue_encoder.0", 2 * R, R, true);   add(t.re2, "residue_encoder.2", J, 2 * R, true);
     add(t.rd0, "residue_decoder.0", 2 * R, J, true);   add(t.rd2, "residue_decoder.2", R, 2 * R, true);
     add(t.emb, "egnn.embedding", H, d.dyn, true);      add(t.embo, "egnn.embedding_out", d.dyn, H, true);
+    // one Blk per GCL ("unit" l * S + sub, egnn_new.py:127-131) in registration order: gcl_0 .. gcl_{S-1}, then the block's gcl_equiv, whose
+    // tensors ride with the block's LAST unit (c0 / c2 / c4 of the other units stay empty)
     for (int l = 0; l < d.L; ++l) {
-        const std::string g = "egnn.e_block_" + std::to_string(l) + ".gcl_0.", c = "egnn.e_block_" + std::to_string(l) + ".gcl_equiv.";
-        ParamTable::Blk& b = t.blk[l];
-        add(b.e0, g + "edge_mlp.0", H, 2 * H + 2, true);   add(b.e2, g + "edge_mlp.2", H, H, true);
-        add(b.n0, g + "node_mlp.0", H, 2 * H, true);       add(b.n2, g + "node_mlp.2", H, H, true);
-        if (d.attention) add(b.att, g + "att_mlp.0", 1, H, true);
+        for (int sub = 0; sub < d.S; ++sub) {
+            const std::string g = "egnn.e_block_" + std::to_string(l) + ".gcl_" + std::to_string(sub) + ".";
+            ParamTable::Blk& b = t.blk[(size_t)l * d.S + sub];
+            add(b.e0, g + "edge_mlp.0", H, 2 * H + 2, true);   add(b.e2, g + "edge_mlp.2", H, H, true);
+            add(b.n0, g + "node_mlp.0", H, 2 * H, true);       add(b.n2, g + "node_mlp.2", H, H, true);
+            if (d.attention) add(b.att, g + "att_mlp.0", 1, H, true);
+        }
+        const std::string c = "egnn.e_block_" + std::to_string(l) + ".gcl_equiv.";
+        ParamTable::Blk& b = t.blk[(size_t)l * d.S + d.S - 1];
         add(b.c0, c + "coord_mlp.0", H, 2 * H + 2, true);  add(b.c2, c + "coord_mlp.2", H, H, true);
         add(b.c4, c + "coord_mlp.4", 1, H, false);
     }
@@ -176,23 +183,23 @@ void cmdgen_train_free(TrainState* t) {
 static int ensure_state(cmdgen_handle* h) {
     if (h->train) return 0;
     if (h->dims.H > 256) return fail(h, CMDGEN_ESTATE, "the training step is built for hidden_nf <= 256");
-    if (h->dims.S != 1 || h->dims.agg_mean || h->dims.sin)
-        return fail(h, CMDGEN_ESTATE, "the training step supports inv_sublayers = 1, aggregation_method 'sum' and sin_embedding False (the shipped configs); this handle samples only");
+    if (h->dims.sin)
+        return fail(h, CMDGEN_ESTATE, "the training step supports sin_embedding False only (every shipped config); this handle samples only");
     TrainState* t = new TrainState();
     build_table(h->dims, t->tab);
     t->bf16 = h->train_bf16;
     const Dims& d = h->dims;
     // sized by the layout CAPACITIES (cmdgen_set_layout): the state survives every new batch that fits them
-    const size_t N = h->cap_N, Nl = h->cap_Nl, Np = h->cap_Np, H = d.H, L = d.L;
+    const size_t N = h->cap_N, Nl = h->cap_Nl, Np = h->cap_Np, H = d.H, L = d.L, U = (size_t)d.L * d.S;      // U: GCLs ("units")
     int rc; void* p;
 #define NA(dst, type, count) do { rc = dev_alloc(h, t->node_allocs, &p, (size_t)(count) * sizeof(type), true); \
         if (rc) { cmdgen_train_free(t); return rc; } dst = (type*)p; } while (0)
     NA(t->enc1_l, float, Nl * 2 * d.P); NA(t->enca_l, float, Nl * 2 * d.P);
     NA(t->enc1_p, float, Np * 2 * d.R); NA(t->enca_p, float, Np * 2 * d.R);
     NA(t->enc_out, float, N * d.J); NA(t->hdyn, float, N * d.dyn);
-    NA(t->h, float, (L + 1) * N * H); NA(t->X, float4, (L + 1) * N);
-    NA(t->P, float, N * H); NA(t->Q, float, N * H); NA(t->aggn, float, L * N * H); NA(t->pre3, float, L * N * H);
-    NA(t->nact, float, L * N * H); NA(t->accx, float, N * 4); NA(t->hfin, float, N * d.dyn);
+    NA(t->h, float, (U + 1) * N * H); NA(t->X, float4, (L + 1) * N);
+    NA(t->P, float, N * H); NA(t->Q, float, N * H); NA(t->aggn, float, U * N * H); NA(t->pre3, float, U * N * H);
+    NA(t->nact, float, U * N * H); NA(t->accx, float, N * 4); NA(t->hfin, float, N * d.dyn);
     NA(t->dec1, float, Nl * 2 * d.P); NA(t->deca, float, Nl * 2 * d.P); NA(t->dec_out, float, Nl * d.P);
     NA(t->dh, float, N * H); NA(t->dX, float, N * 4); NA(t->dagg, float, N * H);
     NA(t->dP, float, 2 * N * H); t->dQ = t->dP + N * H;      // adjacent: zeroed by one memset
@@ -211,8 +218,8 @@ static int ensure_state(cmdgen_handle* h) {
         auto alloc = [&](size_t floats, float** out) -> int {
             int r = dev_alloc(h, t->pack_allocs, &p, floats * sizeof(float), true); if (!r) *out = (float*)p; return r; };
         const int ld1 = 2 * (int)H + 2;
-        t->pack.resize(L);
-        for (size_t l = 0; l < L && !rc; ++l) {
+        t->pack.resize(U);
+        for (size_t l = 0; l < U && !rc; ++l) {                 // (l runs over the units; coordinate tensors exist on a block's last unit only)
             TrainState::PackBlk& k = t->pack[l];
             const ParamTable::Blk& b = tb.blk[l];
             auto frag = [&](const PRef& r, int out, int in, int row_split, int col_shift, float** d32, float** d16) {
@@ -225,22 +232,24 @@ static int ensure_state(cmdgen_handle* h) {
             frag(b.e2, (int)H, (int)H, 0, 0, &k.w2_32, &k.w2_16);
             frag(b.n0, (int)H, 2 * (int)H, 0, 0, &k.w3_32, &k.w3_16);
             frag(b.n2, (int)H, (int)H, 0, 0, &k.w4_32, &k.w4_16);
+            if (b.c0.out) {
             frag(b.c0, 2 * (int)H, (int)H, (int)H, (int)H, &k.pq_c32, &k.pq_c16);
             frag(b.c2, (int)H, (int)H, 0, 0, &k.w7_32, &k.w7_16);
+            }
             if (!rc) rc = alloc(2 * H, &k.rd_e);
             if (!rc) rc = alloc(2 * H, &k.rd_c);
             if (!rc) {
                 mt.push_back(RepackMisc{(int)b.e0.w + 2 * (int)H, ld1, (int)H, 2, k.rd_e});
-                mt.push_back(RepackMisc{(int)b.c0.w + 2 * (int)H, ld1, (int)H, 2, k.rd_c});
+                if (b.c0.out) mt.push_back(RepackMisc{(int)b.c0.w + 2 * (int)H, ld1, (int)H, 2, k.rd_c});
             }
         }
         std::vector<RepackSplitT> st;
         if (H == 256) {
-            for (size_t l = 0; l < L && !rc; ++l) {
+            for (size_t l = 0; l < U && !rc; ++l) {
                 TrainState::PackBlk& k = t->pack[l];
                 const ParamTable::Blk& b = tb.blk[l];
                 auto tp = [&](const PRef& r, int col0, void** dst, int transpose = 1) {
-                    if (rc) return;
+                    if (rc || !r.out) return;
                     float* q = nullptr;
                     rc = alloc((size_t)H * H * 6 / 4, &q); if (rc) return;          // three bf16 pieces per weight
                     *dst = q;
@@ -254,11 +263,11 @@ static int ensure_state(cmdgen_handle* h) {
             if (!rc) rc = dev_alloc(h, t->pack_allocs, &p, st.size() * sizeof(RepackSplitT), false);
             if (!rc) { t->split_tab = p; hipMemcpy(p, st.data(), st.size() * sizeof(RepackSplitT), hipMemcpyHostToDevice); t->n_split = (int)st.size(); }
             std::vector<RepackHalf> ht;
-            for (size_t l = 0; l < L && !rc; ++l) {
+            for (size_t l = 0; l < U && !rc; ++l) {
                 TrainState::PackBlk& k = t->pack[l];
                 const ParamTable::Blk& b = tb.blk[l];
                 auto hp = [&](const PRef& r, void** dst, float** sc) {
-                    if (rc) return;
+                    if (rc || !r.out) return;
                     float* q = nullptr;
                     rc = alloc((size_t)H * H + 4, &q); if (rc) return;              // two fp16 pieces per weight, then {scale, 1 / scale}
                     *dst = q; *sc = q + (size_t)H * H;
@@ -267,11 +276,11 @@ static int ensure_state(cmdgen_handle* h) {
                 hp(b.e2, &k.h_e2, &k.hs_e2); hp(b.c2, &k.h_c2, &k.hs_c2);
             }
             t->n_half_fwd = (int)ht.size();         // the forward's entries come first: the transposed blocks are re-made only when the data gradients use them
-            for (size_t l = 0; l < L && !rc; ++l) {
+            for (size_t l = 0; l < U && !rc; ++l) {
                 TrainState::PackBlk& k = t->pack[l];
                 const ParamTable::Blk& b = tb.blk[l];
                 auto tp = [&](const PRef& r, int col0, HalfW* dst) {
-                    if (rc) return;
+                    if (rc || !r.out) return;
                     float* q = nullptr;
                     rc = alloc((size_t)H * H + 4, &q); if (rc) return;
                     dst->w = q; dst->sc = q + (size_t)H * H;
@@ -284,11 +293,11 @@ static int ensure_state(cmdgen_handle* h) {
             if (!rc) rc = dev_alloc(h, t->pack_allocs, &p, ht.size() * sizeof(RepackHalf), false);
             if (!rc) { t->half_tab = p; hipMemcpy(p, ht.data(), ht.size() * sizeof(RepackHalf), hipMemcpyHostToDevice); t->n_half = (int)ht.size(); }
             std::vector<RepackHalf16> h16;
-            for (size_t l = 0; l < L && !rc; ++l) {
+            for (size_t l = 0; l < U && !rc; ++l) {
                 TrainState::PackBlk& k = t->pack[l];
                 const ParamTable::Blk& b = tb.blk[l];
                 auto hp = [&](const PRef& r, int out, int in, int row_split, int col_shift, void** dst, float** sc) {
-                    if (rc) return;
+                    if (rc || !r.out) return;
                     float* q = nullptr;
                     rc = alloc((size_t)out * in + 4, &q); if (rc) return;           // two fp16 pieces per weight, then {scale, 1 / scale}
                     *dst = q; *sc = q + (size_t)out * in;
@@ -360,13 +369,13 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
     if ((size_t)E <= t->ecap && (size_t)Ec <= t->eccap) return 0;
     hipDeviceSynchronize();
     free_pool(t->edge_allocs);
-    const size_t ec = (size_t)(E * 1.25) + 64, ecc = (size_t)(Ec * 1.25) + 64, H = h->dims.H, L = h->dims.L;
+    const size_t ec = (size_t)(E * 1.25) + 64, ecc = (size_t)(Ec * 1.25) + 64, H = h->dims.H, L = h->dims.L, U = L * h->dims.S;
     const size_t em = ec > ecc ? ec : ecc;
     int rc; void* p;
 #define EA(dst, type, count) do { rc = dev_alloc(h, t->edge_allocs, &p, (size_t)(count) * sizeof(type), false); \
         if (rc) return rc; dst = (type*)p; } while (0)
-    EA(t->pre1, float, L * ec * H); EA(t->pre2, float, L * ec * H); EA(t->z, float, L * ec);
-    EA(t->act1, float, L * ec * H); EA(t->act6, float, L * ecc * H);      // SiLU(pre2) / SiLU(pre7) are recomputed by their one consumer
+    EA(t->pre1, float, U * ec * H); EA(t->pre2, float, U * ec * H); EA(t->z, float, U * ec);
+    EA(t->act1, float, U * ec * H); EA(t->act6, float, L * ecc * H);      // SiLU(pre2) / SiLU(pre7) are recomputed by their one consumer
     EA(t->pre6, float, L * ecc * H); EA(t->pre7, float, L * ecc * H); EA(t->phi, float, L * ecc);
     EA(t->actA, float, em * H); EA(t->actB, float, em * H);
     EA(t->actA2, float, ec * H); EA(t->actB2, float, ecc * H);
@@ -466,8 +475,9 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     // ... and the node kernel as the sampler's eight-wave 16-row tile (k_node16w) where 16-row tiles are what the layout gets
     const bool node_half = fwd_half && a.node_mt == 16 && t->n_half16 > 0 && opt_of(h, "train_half", 1) != 2;
     if (node_half) tr_repack_half16(theta, t->half16_tab, t->n_half16, t->max_half16, s);
-    t->layers.assign(L, LayerW{});
-    for (int l = 0; l < L; ++l) {
+    const int U = L * d.S;
+    t->layers.assign(U, LayerW{});
+    for (int l = 0; l < U; ++l) {                       // units
         const ParamTable::Blk& b = tb.blk[l];
         const TrainState::PackBlk& k = t->pack[l];
         LayerW& lw = t->layers[l];
@@ -477,12 +487,18 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
         lw.wa = d.attention ? theta + b.att.w : theta + b.e2.b; lw.ba = d.attention ? theta + b.att.b : theta + b.e2.b;
         lw.W3 = WPack{(const float4*)k.w3_32, (const float4*)k.w3_16}; lw.b3 = theta + b.n0.b;
         lw.W4 = WPack{(const float4*)k.w4_32, (const float4*)k.w4_16}; lw.b4 = theta + b.n2.b;
+        if (!b.c0.out) {        // not the block's last GCL: never multiplied (the node kernel skips the projection); valid pointers for the bias prefetches
+            lw.Wpq_c = lw.Wpq_e; lw.b6 = lw.b1; lw.wr_c = lw.wr_e; lw.wd_c = lw.wd_e; lw.W7 = lw.W2; lw.b7 = lw.b2; lw.w5 = lw.b2;
+        } else {
         lw.Wpq_c = WPack{(const float4*)k.pq_c32, (const float4*)k.pq_c16}; lw.b6 = theta + b.c0.b; lw.wr_c = k.rd_c; lw.wd_c = k.rd_c + H;
         lw.W7 = WPack{(const float4*)k.w7_32, (const float4*)k.w7_16, H == 256 ? k.s_c2 : nullptr}; lw.b7 = theta + b.c2.b; lw.w5 = theta + b.c4.w;
         if (fwd_half) { lw.W7.wh = k.h_c2; lw.W7.wh_dev = k.hs_c2; }
+        }
         if (node_half) {
             lw.W3.wh16 = k.h16_w3; lw.W3.wh_dev = k.hs_w3; lw.W4.wh16 = k.h16_w4; lw.W4.wh_dev = k.hs_w4;
-            lw.Wpq_c.wh16 = k.h16_pqc; lw.Wpq_c.wh_dev = k.hs_pqc; lw.Wpq_e.wh16 = k.h16_pqe; lw.Wpq_e.wh_dev = k.hs_pqe;
+            if (b.c0.out) { lw.Wpq_c.wh16 = k.h16_pqc; lw.Wpq_c.wh_dev = k.hs_pqc; }
+            else { lw.Wpq_c.wh16 = k.h16_pqe; lw.Wpq_c.wh_dev = k.hs_pqe; }
+            lw.Wpq_e.wh16 = k.h16_pqe; lw.Wpq_e.wh_dev = k.hs_pqe;
         }
     }
     SmallW sw{};
@@ -608,7 +624,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     // dhb[(k + 1) % 3]; dpre2 / dpre7 / dn / the two dP | dQ pairs by the parity of k.  Off: one buffer each, updated in place.
     float* dhb[3] = {t->dh, ss.on ? t->dh2 : t->dh, ss.on ? t->dh3 : t->dh};
     const size_t pq_off = (size_t)(t->dQ - t->dP);                    // dQ = dP + pq_off in every pair
-    std::vector<hipEvent_t> blk_done((size_t)L + 1, nullptr);         // side work of block k of THIS call
+    std::vector<hipEvent_t> blk_done((size_t)L * d.S + 1, nullptr);   // side work of GCL k of THIS call
     if (first_stage == 0) {
     // readout
     float* dh0 = dhb[0];
@@ -630,82 +646,92 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     tr_silu_bwd(t->ddeca, t->dec1, (size_t)Nl * 2 * P, s);
     small_wgrad(tb.pd0, J, Nl, t->ddeca, 2 * P, t->hfin, d.dyn);
     linear_dgrad(theta, tb.pd0, 0, J, Nl, t->ddeca, 2 * P, t->dhfin, d.dyn, false, s);
-    small_wgrad(tb.embo, H, N, t->dhfin, d.dyn, t->h + (size_t)L * NH, H);
+    small_wgrad(tb.embo, H, N, t->dhfin, d.dyn, t->h + (size_t)L * d.S * NH, H);
     linear_dgrad(theta, tb.embo, 0, H, N, t->dhfin, d.dyn, dh0, H, false, s);
     flush_side();           // (none of what these read is written again in this pass)
     }
+    const int S = d.S, U = L * S;
+    const float* rowdiv = d.agg_mean ? w.adiv : nullptr;              // aggregation 'mean': sums were divided by the receiver's edge count (egnn_new.py:288-292)
     for (int l = L - 1; l >= 0; --l) {
         const int stage = L - l;
         if (stage < first_stage || stage > last_stage) continue;
-        const ParamTable::Blk& b = tb.blk[l];
-        const float* hl = t->h + (size_t)l * NH;
-        const float* hn = t->h + (size_t)(l + 1) * NH;
+        const int ulast = l * S + S - 1;                                  // the block's last GCL carries its EquivariantUpdate
+        const ParamTable::Blk& bc = tb.blk[ulast];
+        const TrainState::PackBlk& pkc = t->pack[ulast];
         const float4* Xl = t->X + (size_t)l * N;
-        const float* pre1 = t->pre1 + (size_t)l * t->ecap * H; const float* pre2 = t->pre2 + (size_t)l * t->ecap * H;
         const float* pre6 = t->pre6 + (size_t)l * t->eccap * H; const float* pre7 = t->pre7 + (size_t)l * t->eccap * H;
-        const float* aggn = t->aggn + (size_t)l * NH; const float* pre3 = t->pre3 + (size_t)l * NH;
-        const float* phi = t->phi + (size_t)l * t->eccap; const float* z = t->z + (size_t)l * t->ecap;
-        const float* act1 = t->act1 + (size_t)l * t->ecap * H;
+        const float* phi = t->phi + (size_t)l * t->eccap;
         const float* act6 = t->act6 + (size_t)l * t->eccap * H;
-        const float* nact = t->nact + (size_t)l * NH;
-        // this block's buffers
-        const int k = L - 1 - l, par = k & 1;
-        float* dh_in = dhb[k % 3]; float* dh_out = dhb[(k + 1) % 3];      // dL/dh_{l+1} (complete after the coordinate model's part) -> dL/dh_l
+        const size_t pq_floats = pq_off + NH;                             // dP and dQ, adjacent
+        const bool pair = tail_fused;                         // the list's two reductions (head / gate partials, tail partials) as one launch
+        for (int sub = S - 1; sub >= 0; --sub) {
+        const int u = l * S + sub;
+        const ParamTable::Blk& b = tb.blk[u];
+        const TrainState::PackBlk& pk = t->pack[u];
+        const float* hl = t->h + (size_t)u * NH;
+        const float* hn = t->h + (size_t)(u + 1) * NH;
+        const float* pre1 = t->pre1 + (size_t)u * t->ecap * H; const float* pre2 = t->pre2 + (size_t)u * t->ecap * H;
+        const float* aggn = t->aggn + (size_t)u * NH; const float* pre3 = t->pre3 + (size_t)u * NH;
+        const float* z = t->z + (size_t)u * t->ecap;
+        const float* act1 = t->act1 + (size_t)u * t->ecap * H;
+        const float* nact = t->nact + (size_t)u * NH;
+        // this GCL's buffers: k counts the GCLs of the pass (k = 0 for the last GCL of block L-1)
+        const int k = U - 1 - u, par = k & 1;
+        float* dh_in = dhb[k % 3]; float* dh_out = dhb[(k + 1) % 3];      // dL/dh_{u+1} (complete after the coordinate model's part) -> dL/dh_u
         float* actA = ss.on && par ? t->actA2 : t->actA;                  // dpre2 [E]
         float* actB = ss.on && par ? t->actB2 : t->actB;                  // dpre7 [Ec]
         float* dn = ss.on && par ? t->dn2 : t->dn;
         float* dPc = ss.on ? t->dPx[par] : t->dP; float* dQc = dPc + pq_off;                    // coordinate list's dP | dQ
         float* dPe = ss.on && par ? t->dPx[2] : t->dP; float* dQe = dPe + pq_off;               // message list's
-        // everything this block writes was last read by the side work of block k - 2
+        // everything this GCL writes was last read by the side work of GCL k - 2
         if (k >= 2) ss.wait(blk_done[k - 2]);
+        if (sub == S - 1) {
         // ---- EquivariantUpdate: x_{l+1} = x_l + acc / nf ; dX holds dL/dx_{l+1} and becomes dL/dx_l
         // (dL/d acc = dX / normalization_factor is formed where it is read; every later kernel of the block only adds to dX)
-        tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, Nm, t->dphi, t->dcd, s);
-        const size_t pq_floats = pq_off + NH;                             // dP and dQ, adjacent
-        const TrainState::PackBlk& pk = t->pack[l];
-        const bool pair = tail_fused;                         // the list's two reductions (head / gate partials, tail partials) as one launch
+        tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, Nm, t->dphi, t->dcd, s, rowdiv);
         // actB <- dpre7, d coord_mlp.4; also clears dP | dQ (hidden_nf is 64, 128 or 256: cmdgen_create)
-        tr_head_bwd(Ec, H, t->dphi, theta + b.c4.w, pre7, actB, pair ? t->part_scratch : t->tail_scratch, grad + b.c4.w, dPc, pq_floats, s, pair);
-        edge_wgrad(b.c2, actB, act6, Ec);                     // weight and bias gradient of coord_mlp.2 (c1 = act6)
-        if (dgh) cmdgen_dgrad_tail_h(Ec, actB, pk.th_c2, pre6, w.crow, w.ccol, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
+        tr_head_bwd(Ec, H, t->dphi, theta + bc.c4.w, pre7, actB, pair ? t->part_scratch : t->tail_scratch, grad + bc.c4.w, dPc, pq_floats, s, pair);
+        edge_wgrad(bc.c2, actB, act6, Ec);                    // weight and bias gradient of coord_mlp.2 (c1 = act6)
+        if (dgh) cmdgen_dgrad_tail_h(Ec, actB, pkc.th_c2, pre6, w.crow, w.ccol, w.cd0, theta + bc.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
                                      dPc, dQc, t->dX, t->tail_scratch, s);
         else if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
-            cmdgen_dgrad_tail(Ec, actB, pk.t_c2, pre6, w.crow, w.ccol, w.cd0, pair ? pk.rd_c : theta + b.c0.w + 2 * H /* radial column: the forward's contiguous copy */, pair ? 1 : ld1, Xl, d.norm_constant, t->dcd, Nm,
-                              dPc, dQc, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
-        if (pair) tr_reduce_pair(Ec, H, t->part_scratch, grad + b.c4.w, nullptr, t->tail_scratch, grad + b.c0.w + 2 * H, ld1, s);
+            cmdgen_dgrad_tail(Ec, actB, pkc.t_c2, pre6, w.crow, w.ccol, w.cd0, pair ? pkc.rd_c : theta + bc.c0.w + 2 * H /* radial column: the forward's contiguous copy */, pair ? 1 : ld1, Xl,
+                              d.norm_constant, t->dcd, Nm, dPc, dQc, grad + bc.c0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
+        if (pair) tr_reduce_pair(Ec, H, t->part_scratch, grad + bc.c4.w, nullptr, t->tail_scratch, grad + bc.c0.w + 2 * H, ld1, s);
         else {
-            if (sp) cmdgen_dgrad_split(Ec, actB, pk.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s, pcs);
-            else linear_dgrad(theta, b.c2, 0, H, Ec, actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
+            if (sp) cmdgen_dgrad_split(Ec, actB, pkc.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s, pcs);
+            else linear_dgrad(theta, bc.c2, 0, H, Ec, actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
             // adjoints of the gathers, the radial / d0 column gradients, d radial and the geometry adjoint: one pass over dpre6
-            tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + b.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
-                             dPc, dQc, grad + b.c0.w + 2 * H, t->dX, t->tail_scratch, s);
+            tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + bc.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
+                             dPc, dQc, grad + bc.c0.w + 2 * H, t->dX, t->tail_scratch, s);
         }
-        if (dgh) cmdgen_dgrad_split_h(N, dPc, pk.th_c0a, dQc, pk.th_c0b, dh_in, true, 1.0f, nullptr, s, no_w, nullptr, false, 1.0f, nullptr);
-        else if (sp) cmdgen_dgrad_split(N, dPc, pk.t_c0a, dQc, pk.t_c0b, dh_in, true, 1.0f, nullptr, s, pcs);
+        if (dgh) cmdgen_dgrad_split_h(N, dPc, pkc.th_c0a, dQc, pkc.th_c0b, dh_in, true, 1.0f, nullptr, s, no_w, nullptr, false, 1.0f, nullptr, nullptr);
+        else if (sp) cmdgen_dgrad_split(N, dPc, pkc.t_c0a, dQc, pkc.t_c0b, dh_in, true, 1.0f, nullptr, s, pcs);
         else {
-            linear_dgrad(theta, b.c0, 0, H, N, dPc, H, dh_in, H, true, s);
-            linear_dgrad(theta, b.c0, H, H, N, dQc, H, dh_in, H, true, s);
+            linear_dgrad(theta, bc.c0, 0, H, N, dPc, H, dh_in, H, true, s);
+            linear_dgrad(theta, bc.c0, H, H, N, dQc, H, dh_in, H, true, s);
         }
-        // ---- node model: h_{l+1} = h_l + W4 SiLU(W3 [h_l | aggn] + b3) + b4 ; dh_in holds dL/dh_{l+1}
-        // weight / bias gradients of coord_mlp.0 (both halves) and node_mlp.2: one grouped launch, while dP, dQ and dh
+        // weight / bias gradients of coord_mlp.0 (both halves): with node_mlp.2 below in one grouped launch, while dP, dQ and dh
         // still hold what they are the gradients of
-        defer_wgrad(b.c0, 0, H, dPc, hn, true);
-        defer_wgrad(b.c0, H, H, dQc, hn, false);
+        defer_wgrad(bc.c0, 0, H, dPc, hn, true);
+        defer_wgrad(bc.c0, H, H, dQc, hn, false);
+        }
+        // ---- node model: h_{u+1} = h_u + W4 SiLU(W3 [h_u | aggn] + b3) + b4 ; dh_in holds dL/dh_{u+1}
         defer_wgrad(b.n2, 0, H, dh_in, nact, true);
         flush_wgrads();
-        if (l == 0) flush_side();       // the last block of the pass: its side work starts as early as it can (nothing comes after to hide it)
+        if (u == 0) flush_side();       // the last GCL of the pass: its side work starts as early as it can (nothing comes after to hide it)
         if (dgh) {
-            cmdgen_dgrad_split_h(N, dh_in, pk.th_n2, nullptr, no_w, dn, false, 1.0f, pre3, s, no_w, nullptr, false, 1.0f, nullptr);
-            cmdgen_dgrad_split_h(N, dn, pk.th_n0a, nullptr, no_w, dh_out, true, 1.0f, nullptr, s, pk.th_n0b, t->dagg, false, d.norm_factor, dh_in);
+            cmdgen_dgrad_split_h(N, dh_in, pk.th_n2, nullptr, no_w, dn, false, 1.0f, pre3, s, no_w, nullptr, false, 1.0f, nullptr, nullptr);
+            cmdgen_dgrad_split_h(N, dn, pk.th_n0a, nullptr, no_w, dh_out, true, 1.0f, nullptr, s, pk.th_n0b, t->dagg, false, d.norm_factor, dh_in, rowdiv);
         } else if (sp) {
             cmdgen_dgrad_split(N, dh_in, pk.t_n2, nullptr, nullptr, dn, false, 1.0f, pre3, s, pcs);
             cmdgen_dgrad_split(N, dn, pk.t_n0a, nullptr, nullptr, dh_out, true, 1.0f, nullptr, s, pcs,         // dh_out = dh_in + dpre3 W3[:, :H] and
-                               pk.t_n0b, t->dagg, false, d.norm_factor, 0, dh_in);                              // dagg = dpre3 W3[:, H:] / nf: one launch
+                               pk.t_n0b, t->dagg, false, d.norm_factor, 0, dh_in, rowdiv);                      // dagg = dpre3 W3[:, H:] / nf: one launch
         } else {
             linear_dgrad(theta, b.n2, 0, H, N, dh_in, H, dn, H, false, s, pre3);       // dn <- dn1 * SiLU'(pre3) = dpre3
-            linear_dgrad(theta, b.n0, 0, H, N, dn, H, dh_in, H, true, s);              // dh is now dL/dh_l (residual kept)
+            linear_dgrad(theta, b.n0, 0, H, N, dn, H, dh_in, H, true, s);              // dh is now dL/dh_u (residual kept)
             linear_dgrad(theta, b.n0, H, H, N, dn, H, t->dagg, H, false, s);
-            tr_scale(t->dagg, d.norm_factor, NH, s);
+            if (rowdiv) tr_scale_rows(t->dagg, rowdiv, H, NH, s); else tr_scale(t->dagg, d.norm_factor, NH, s);
         }
         // ---- edge model
         // actA <- dpre2, d att_mlp; also clears dP | dQ
@@ -725,23 +751,24 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             tr_edge_tail_bwd(E, H, w.erow, w.ecol, t->actB, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
                              dPe, dQe, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, s);
         }
-        // node_mlp.0 (both halves) and edge_mlp.0 (both halves): the second grouped launch of the block
+        // node_mlp.0 (both halves) and edge_mlp.0 (both halves): the second grouped launch of the GCL
         defer_wgrad(b.n0, 0, H, dn, hl, true);
         defer_wgrad(b.n0, H, H, dn, aggn, false);
         defer_wgrad(b.e0, 0, H, dPe, hl, true);
         defer_wgrad(b.e0, H, H, dQe, hl, false);
         flush_wgrads();
-        blk_done[k] = flush_side();                 // the block's weight gradients: one fork
-        if (dgh) cmdgen_dgrad_split_h(N, dPe, pk.th_e0a, dQe, pk.th_e0b, dh_out, true, 1.0f, nullptr, s, no_w, nullptr, false, 1.0f, nullptr);
+        blk_done[k] = flush_side();                 // the GCL's weight gradients: one fork
+        if (dgh) cmdgen_dgrad_split_h(N, dPe, pk.th_e0a, dQe, pk.th_e0b, dh_out, true, 1.0f, nullptr, s, no_w, nullptr, false, 1.0f, nullptr, nullptr);
         else if (sp) cmdgen_dgrad_split(N, dPe, pk.t_e0a, dQe, pk.t_e0b, dh_out, true, 1.0f, nullptr, s, pcs);       // (dh_out = dh_in when the side stream is off)
         else {
             linear_dgrad(theta, b.e0, 0, H, N, dPe, H, dh_out, H, true, s);
             linear_dgrad(theta, b.e0, H, H, N, dQe, H, dh_out, H, true, s);
         }
+        }
     }
     if (last_stage < L + 1) { ss.join(); HIPCHK(h, hipGetLastError()); return CMDGEN_OK; }
     // embedding and encoders
-    float* dhE = dhb[L % 3];
+    float* dhE = dhb[(L * d.S) % 3];
     small_wgrad(tb.emb, d.dyn, N, dhE, H, t->hdyn, d.dyn);
     linear_dgrad(theta, tb.emb, 0, d.dyn, N, dhE, H, t->dhdyn, d.dyn, false, s);
     small_wgrad(tb.pe2, 2 * P, Nl, t->dhdyn, d.dyn, t->enca_l, 2 * P);

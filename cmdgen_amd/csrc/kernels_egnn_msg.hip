@@ -95,8 +95,8 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
         if constexpr (FK) {
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
             if (!(ablate & 2)) build_edge_full32<FK>(planes, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4,
-                                                     SAVE ? sv.pre1 + ((size_t)layer * sv.ecap + e0) * H : nullptr,
-                                                     SAVE ? sv.act1 + ((size_t)layer * sv.ecap + e0) * H : nullptr);
+                                                     SAVE ? sv.pre1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr,
+                                                     SAVE ? sv.act1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr);
             lds_barrier();
             STAMP(1);
             if (!(ablate & 4)) G::gemm(planes, fw, acc.a, carry);
@@ -105,8 +105,8 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
             constexpr int PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
             const typename G::Frag fw1 = G::frag(lw.W2, H / 8, H / 16, wave);
-            float* pre1_o = SAVE ? sv.pre1 + ((size_t)layer * sv.ecap + e0) * H : nullptr;
-            float* act1_o = SAVE ? sv.act1 + ((size_t)layer * sv.ecap + e0) * H : nullptr;
+            float* pre1_o = SAVE ? sv.pre1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr;
+            float* act1_o = SAVE ? sv.act1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr;
             if (!(ablate & 2)) build_edge_half<MT>(planes, 0, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, s_wrd, s_wrd + H, pre1_o, act1_o);
             lds_barrier();
             if (!(ablate & 4)) tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw, fw1, acc.a, carry);
@@ -118,8 +118,8 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
         } else {
         if (d.sin) { sin_features<H, MT>(s_dyn + 24 * H, s_r, s_d0, ne, d); lds_barrier(); }
         if (!(ablate & 2)) build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4,
-                                                  SAVE ? sv.pre1 + ((size_t)layer * sv.ecap + e0) * H : nullptr,
-                                                  SAVE ? sv.act1 + ((size_t)layer * sv.ecap + e0) * H : nullptr,
+                                                  SAVE ? sv.pre1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr,
+                                                  SAVE ? sv.act1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr,
                                                   d.sin ? s_dyn + 24 * H : nullptr, s_dyn);
         lds_barrier();
         STAMP(1);
@@ -134,7 +134,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
         });
         lds_barrier();
         if constexpr (SAVE) {
-            const size_t o = ((size_t)layer * sv.ecap + e0) * H;
+            const size_t o = ((size_t)sv.slot * sv.ecap + e0) * H;
             save_rows_silu<H, MT>(buf, ne, sv.pre2 + o, sv.act2 ? sv.act2 + o : nullptr);
             lds_barrier();
         }
@@ -145,7 +145,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
             if (lead) {
                 const float zl = s + ba0;
                 s_att[r] = d.attention ? sigmoid_f(zl) : 1.0f;
-                if (SAVE && d.attention && r < ne) sv.z[(size_t)layer * sv.ecap + e0 + r] = zl;
+                if (SAVE && d.attention && r < ne) sv.z[(size_t)sv.slot * sv.ecap + e0 + r] = zl;
             }
         }
         lds_barrier();
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_msg(Layout lay, Work w, 
 template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
     const size_t shm = a.d.sin ? (size_t)(24 * H + 24 * MT) * sizeof(float) : 0;      // sin_embedding: feature columns + the tile's features (edge_msg_body)
     // training forward: the split engine only where the step re-packs split weights (H = 256: edge_mlp.2 / coord_mlp.2)
-    if (a.save) hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, *a.save, 0);
+    if (a.save) { TrainSave sv = *a.save; sv.slot = unit_of(a, l); hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, sv, 0); }
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), shm, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
                                                a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
     else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), shm, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
@@ -214,7 +214,8 @@ static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || (a.save && !a.save_half) || !a.split || a.d.H != 256 || a.edge_mt != 32) return false;
     const LayerW& lw = a.layers[unit_of(a, l)];
     if (a.save) {       // training forward on the half engine (packs and scale re-made on the device every step: WPack::wh_dev)
-        hipLaunchKernelGGL((k_edge_msg<256, 32, true, true, 2>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, lw, l, a.ablate, *a.save, 0);
+        TrainSave sv = *a.save; sv.slot = unit_of(a, l);
+        hipLaunchKernelGGL((k_edge_msg<256, 32, true, true, 2>), dim3(a.edge_grid), dim3(256), 0, s, a.lay, a.w, a.d, lw, l, a.ablate, sv, 0);
         return true;
     }
     if (a.half_engine && lw.W2.wh) {

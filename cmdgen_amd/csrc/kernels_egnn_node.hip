@@ -66,7 +66,7 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
                 *g = make_float4(0.f, 0.f, 0.f, 0.f);                      // agg is zero between blocks
                 const float dv = agg_div(w, d, row0 + r);
                 v.x /= dv; v.y /= dv; v.z /= dv; v.w /= dv;
-                if (SAVE) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * H)[c4] = v;
+                if (SAVE) reinterpret_cast<float4*>(sv.aggn + ((size_t)sv.slot * lay.N + row0 + r) * H)[c4] = v;
             }
             *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
         }
@@ -99,7 +99,7 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
             float4 v = av[pass];
             const float dv = r < nvalid ? agg_div(w, d, row0 + r) : 1.0f;
             v.x /= dv; v.y /= dv; v.z /= dv; v.w /= dv;
-            if (SAVE && r < nvalid) reinterpret_cast<float4*>(sv.aggn + ((size_t)layer * lay.N + row0 + r) * H)[c4] = v;
+            if (SAVE && r < nvalid) reinterpret_cast<float4*>(sv.aggn + ((size_t)sv.slot * lay.N + row0 + r) * H)[c4] = v;
             *reinterpret_cast<float4*>(buf0 + r * LDA(H) + 4 * c4) = hv[pass];
             *reinterpret_cast<float4*>(buf1 + r * LDA(H) + 4 * c4) = v;
         }
@@ -124,7 +124,7 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
     });
     lds_barrier();
     if constexpr (SAVE) {
-        const size_t o = ((size_t)layer * lay.N + row0) * H;
+        const size_t o = ((size_t)sv.slot * lay.N + row0) * H;
         save_rows_silu<H, MT>(buf1, nvalid, sv.pre3 + o, sv.nact + o);
         lds_barrier();
     }
@@ -152,7 +152,7 @@ __device__ __forceinline__ void node_tile_body(float* bufs, const Layout& lay, c
             if (r < nvalid) {
                 const float4 hv = *reinterpret_cast<const float4*>(buf1 + r * LDA(H) + 4 * c4);
                 reinterpret_cast<float4*>(w.h + (size_t)(row0 + r) * H)[c4] = hv;
-                if (SAVE) reinterpret_cast<float4*>(sv.h + ((size_t)(layer + 1) * lay.N + row0 + r) * H)[c4] = hv;   // h entering block layer+1
+                if (SAVE) reinterpret_cast<float4*>(sv.h + ((size_t)(sv.slot + 1) * lay.N + row0 + r) * H)[c4] = hv;   // h entering block layer+1
             }
         }
     }
@@ -188,8 +188,11 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
         if (a.split16 && !a.save && a.layers[unit_of(a, l)].W3.ws16) { launch_node<H, 16, true>(a, l, s); return; }
     }
     const int nt = (a.lay.N + MT - 1) / MT;
-    if (a.save) hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)],
-                                   a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l), *a.save);
+    if (a.save) {
+        TrainSave sv = *a.save; sv.slot = unit_of(a, l);
+        hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)],
+                           a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l), sv);
+    }
     else if (a.pe_start) hipExtLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
                                                a.layers[unit_of(a, l)], a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l), TrainSave{});
     else hipLaunchKernelGGL((k_node<H, MT, false, SP>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)],

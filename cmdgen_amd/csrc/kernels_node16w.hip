@@ -34,7 +34,8 @@ bool cmdgen_launch_node16w(const EvalLaunch& a, int l, hipStream_t s) {
     const int nt = (a.lay.N + 15) / 16;
     if (a.save) {       // training forward: the half form with save hooks, where the step re-made the 16-row half packs (EvalLaunch::save_half16)
         if (a.d.H != 256 || a.node_mt != 16 || !a.save_half16 || !lw.W3.wh16 || !lw.W3.wh_dev) return false;
-        hipLaunchKernelGGL(nw_half::k_node16w<true>, dim3(nt), dim3(512), 0, s, a.lay, a.w, a.d, lw, ln, l, node_flags(a, l), *a.save);
+        TrainSave sv = *a.save; sv.slot = unit_of(a, l);
+        hipLaunchKernelGGL(nw_half::k_node16w<true>, dim3(nt), dim3(512), 0, s, a.lay, a.w, a.d, lw, ln, l, node_flags(a, l), sv);
         return true;
     }
     if (a.d.H != 256 || a.node_mt != 16 || !a.split16 || !a.node16w || !lw.W3.ws16) return false;

@@ -766,10 +766,13 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __re
                                                         const float* __restrict__ A1, const void* __restrict__ W1,
                                                         float* Y, int accumulate, float div,
                                                         const float* __restrict__ pre, const void* __restrict__ W0b,
-                                                        float* __restrict__ Yb, int accumulate_b, float div_b, const float* Yin) {
+                                                        float* __restrict__ Yb, int accumulate_b, float div_b, const float* Yin,
+                                                        const float* __restrict__ rowdiv_b) {
     // gridDim.y = 2: a second product of the same A0 (W0b -> Yb; the two halves of node_mlp.0 share dpre3) in the same launch
     // Yin: the running value an accumulating product adds to (Y itself, or another buffer: Y = Yin + product, out of place)
-    if (blockIdx.y) { W0 = W0b; Y = Yb; Yin = Yb; accumulate = accumulate_b; div = div_b; }
+    // rowdiv_b: per-row divisor of the second product instead of div_b (aggregation 'mean': the receiver's edge count)
+    const float* rowdiv = nullptr;
+    if (blockIdx.y) { W0 = W0b; Y = Yb; Yin = Yb; accumulate = accumulate_b; div = div_b; rowdiv = rowdiv_b; }
     constexpr int HH = 256, PLDA = SPLIT_PLANE_LDA(HH / 2), PE = MT * PLDA;
     constexpr int LDO = HH + 4, SMEM = 3 * PE * 2 > 32 * LDO * 4 ? 3 * PE * 2 : 32 * LDO * 4;   // planes / 32-row fp32 output image
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
@@ -805,7 +808,8 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __re
             const int rl = p * 4 + rs, row = row0 + m * 32 + rl;
             if (row < M) {
                 float4 x = *reinterpret_cast<const float4*>(obuf + rl * LDO + 4 * q4);
-                if (div != 1.0f) { x.x = x.x / div; x.y = x.y / div; x.z = x.z / div; x.w = x.w / div; }
+                if (rowdiv) { const float dvr = rowdiv[row]; x.x = x.x / dvr; x.y = x.y / dvr; x.z = x.z / dvr; x.w = x.w / dvr; }
+                else if (div != 1.0f) { x.x = x.x / div; x.y = x.y / div; x.z = x.z / div; x.w = x.w / div; }
                 if (pre) { x.x *= dsilu(pv[p].x); x.y *= dsilu(pv[p].y); x.z *= dsilu(pv[p].z); x.w *= dsilu(pv[p].w); }
                 if (accumulate) { x.x += yv[p].x; x.y += yv[p].y; x.z += yv[p].z; x.w += yv[p].w; }
                 reinterpret_cast<float4*>(Y + (size_t)row * HH)[q4] = x;
@@ -903,9 +907,11 @@ __device__ __forceinline__ void dgrad_tile_gemm_h(unsigned short* planes, float*
 
 __global__ __launch_bounds__(256, 3) void k_dgrad_split_h(int M, const float* __restrict__ A0, HalfW W0, const float* __restrict__ A1, HalfW W1,
                                                           float* Y, int accumulate, float div, const float* __restrict__ pre, HalfW W0b,
-                                                          float* __restrict__ Yb, int accumulate_b, float div_b, const float* Yin) {
+                                                          float* __restrict__ Yb, int accumulate_b, float div_b, const float* Yin,
+                                                          const float* __restrict__ rowdiv_b) {
     // arguments as k_dgrad_split (gridDim.y = 2: the second product W0b -> Yb of the same A0)
-    if (blockIdx.y) { W0 = W0b; Y = Yb; Yin = Yb; accumulate = accumulate_b; div = div_b; }
+    const float* rowdiv = nullptr;
+    if (blockIdx.y) { W0 = W0b; Y = Yb; Yin = Yb; accumulate = accumulate_b; div = div_b; rowdiv = rowdiv_b; }
     constexpr int MT = 32, HH = 256, LDO = HH + 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[32 * LDO * 4];          // two fp16 planes (32 KB) / the fp32 output image (33 KB)
     __shared__ float rinv[MT];
@@ -937,7 +943,8 @@ __global__ __launch_bounds__(256, 3) void k_dgrad_split_h(int M, const float* __
         const int rl = p * 4 + rs, row = row0 + rl;
         if (row < M) {
             float4 x = *reinterpret_cast<const float4*>(obuf + rl * LDO + 4 * q4);
-            if (div != 1.0f) { x.x = x.x / div; x.y = x.y / div; x.z = x.z / div; x.w = x.w / div; }
+            if (rowdiv) { const float dvr = rowdiv[row]; x.x = x.x / dvr; x.y = x.y / dvr; x.z = x.z / dvr; x.w = x.w / dvr; }
+                else if (div != 1.0f) { x.x = x.x / div; x.y = x.y / div; x.z = x.z / div; x.w = x.w / div; }
             if (pre) { x.x *= dsilu(pv[p].x); x.y *= dsilu(pv[p].y); x.z *= dsilu(pv[p].z); x.w *= dsilu(pv[p].w); }
             if (accumulate) { x.x += yv[p].x; x.y += yv[p].y; x.z += yv[p].z; x.w += yv[p].w; }
             reinterpret_cast<float4*>(Y + (size_t)row * HH)[q4] = x;
@@ -945,11 +952,11 @@ __global__ __launch_bounds__(256, 3) void k_dgrad_split_h(int M, const float* __
     }
 }
 void cmdgen_dgrad_split_h(int M, const float* A0, HalfW W0, const float* A1, HalfW W1, float* Y, bool accumulate, float div, const float* pre,
-                          hipStream_t s, HalfW W0b, float* Yb, bool accumulate_b, float div_b, const float* Yin) {
+                          hipStream_t s, HalfW W0b, float* Yb, bool accumulate_b, float div_b, const float* Yin, const float* rowdiv_b) {
     if (M <= 0) return;
     if (!Yin) Yin = Y;
     hipLaunchKernelGGL(k_dgrad_split_h, dim3((M + 31) / 32, W0b.w ? 2 : 1), dim3(256), 0, s, M, A0, W0, A1, W1, Y, accumulate ? 1 : 0, div, pre,
-                       W0b, Yb, accumulate_b ? 1 : 0, div_b, Yin);
+                       W0b, Yb, accumulate_b ? 1 : 0, div_b, Yin, rowdiv_b);
 }
 
 // split fragment packs of transposed weight sub-blocks: dst = pack of Wt, Wt[o'][k] = theta[src_off + k * ld + o'] (o', k < 256)
@@ -1081,14 +1088,14 @@ void tr_repack_half16(const float* theta, const void* tab, int n, int max8, hipS
 // bf16, fp32 accumulation: cmdgen_train_set_precision(1))
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
                         const float* pre, hipStream_t s, int pieces = 3, const void* W0b = nullptr, float* Yb = nullptr,
-                        bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0, const float* Yin = nullptr) {
+                        bool accumulate_b = false, float div_b = 1.0f, int force_mt = 0, const float* Yin = nullptr, const float* rowdiv_b = nullptr) {
     if (M <= 0) return;
     if (!Yin) Yin = Y;
     const int mt = g_train_tune.dgrad_mt;
     const bool big = force_mt ? force_mt == 64 : (mt ? mt == 64 : M >= 24576);     // force_mt: cmdgen_debug_dgrad
     const int acc = accumulate ? 1 : 0, ny = W0b ? 2 : 1;
 #define DG(MT_, NP_) hipLaunchKernelGGL((k_dgrad_split<MT_, NP_>), dim3((M + MT_ - 1) / MT_, ny), dim3(256), 0, s, M, A0, W0, A1, W1, Y, acc, div, pre, \
-                                        W0b, Yb, accumulate_b ? 1 : 0, div_b, Yin)
+                                        W0b, Yb, accumulate_b ? 1 : 0, div_b, Yin, rowdiv_b)
     if (pieces == 3) { if (big) DG(64, 3); else DG(32, 3); }
     else { if (big) DG(64, 1); else DG(32, 1); }
 #undef DG
@@ -1105,6 +1112,11 @@ __global__ void k_silu_bwd4(float4* __restrict__ g, const float4* __restrict__ p
     const float4 p = pre[i]; float4 v = g[i];
     v.x *= dsilu(p.x); v.y *= dsilu(p.y); v.z *= dsilu(p.z); v.w *= dsilu(p.w);
     g[i] = v;
+}
+// x[row][:] /= div[row]  (aggregation 'mean': the receiver's edge count)
+__global__ void k_scale_rows(float* __restrict__ x, const float* __restrict__ div, int H, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = x[i] / div[i / H];
 }
 __global__ void k_scale(float* __restrict__ x, float d, size_t n) {      // x /= d (a true division, as the reference)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1252,7 +1264,7 @@ __global__ __launch_bounds__(256) void k_partial_reduce(int nwg, int H, const fl
 __global__ void k_coord_out_bwd(int E, const int* __restrict__ row, const int* __restrict__ col,
                                 const float4* __restrict__ X, const float* __restrict__ phi, int use_tanh, float range,
                                 float norm_constant, const float* __restrict__ dacc, float dacc_div, int n_moving,
-                                float* __restrict__ dphi_out, float4* __restrict__ dcd_out) {
+                                float* __restrict__ dphi_out, float4* __restrict__ dcd_out, const float* __restrict__ adiv) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const int i = row[e], j = col[e];
@@ -1262,7 +1274,8 @@ __global__ void k_coord_out_bwd(int E, const int* __restrict__ row, const int* _
     const float den = sqrtf(r + 1e-8f) + norm_constant;
     const float cx = dx / den, cy = dy / den, cz = dz / den;
     const float4 dv = *reinterpret_cast<const float4*>(dacc + (size_t)i * 4);
-    const float da[3] = {dv.x / dacc_div, dv.y / dacc_div, dv.z / dacc_div};      // dL/d acc = dL/dx_{l+1} / normalization_factor
+    const float dd = adiv ? adiv[i] : dacc_div;                  // aggregation 'mean': the receiver's edge count (egnn_new.py:288-292), else normalization_factor
+    const float da[3] = {dv.x / dd, dv.y / dd, dv.z / dd};      // dL/d acc = dL/dx_{l+1} / divisor
     const float p = phi[e];
     const float th = use_tanh ? tanhf(p) : 0.f;
     const float g = use_tanh ? th * range : p;
@@ -2097,6 +2110,7 @@ void tr_silu_bwd(float* g, const float* pre, size_t n, hipStream_t s) {
     else hipLaunchKernelGGL(k_silu_bwd, EW_GRID(n), 0, s, g, pre, n);
 }
 void tr_scale(float* x, float d, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_scale, EW_GRID(n), 0, s, x, d, n); }
+void tr_scale_rows(float* x, const float* div, int H, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_scale_rows, EW_GRID(n), 0, s, x, div, H, n); }
 // The two reductions of an edge list in one launch: blockIdx.y = 0 is k_partial_reduce's job (gate / head partial sums,
 // scratch rows of H + 4 floats), blockIdx.y = 1, 2 are k_tail_colsum_reduce's (radial / d0 column partials, rows of 2 H).
 __global__ __launch_bounds__(256) void k_reduce_pair(int nwg_a, int H, const float* __restrict__ scratch_a, float* __restrict__ out_w,
@@ -2154,8 +2168,8 @@ void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* 
     if (!defer_reduce) hipLaunchKernelGGL(k_partial_reduce, dim3((H + 63) / 64, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, d_w5, (float*)nullptr);
 }
 void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, const float* phi, int use_tanh, float range,
-                      float nc, const float* dacc, float dacc_div, int n_moving, float* dphi, float4* dcd, hipStream_t s) {
-    if (E) hipLaunchKernelGGL(k_coord_out_bwd, EW_GRID(E), 0, s, E, row, col, X, phi, use_tanh, range, nc, dacc, dacc_div, n_moving, dphi, dcd);
+                      float nc, const float* dacc, float dacc_div, int n_moving, float* dphi, float4* dcd, hipStream_t s, const float* adiv = nullptr) {
+    if (E) hipLaunchKernelGGL(k_coord_out_bwd, EW_GRID(E), 0, s, E, row, col, X, phi, use_tanh, range, nc, dacc, dacc_div, n_moving, dphi, dcd, adiv);
 }
 void tr_edge_tail_bwd(int E, int H, const int* row, const int* col, const float* g, const float* d0, const float* Wcol, int ldw,
                       const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ, float* dWcol, float* dX,

@@ -119,13 +119,16 @@ def test_hip_chain_g16(name, use_graph):
 
 @pytest.mark.gpu
 def test_training_refuses_the_options_it_does_not_cover():
+    """inv_sublayers > 1 and aggregation 'mean' train since round 5 (tests/test_hip_train.py, G19); sin_embedding (and a learned schedule,
+    hidden_nf 512) still sample only - and say so."""
+    import dataclasses
     hip_backend, dev = _gpu()
-    cfg, sd = dyn_case('ca_h64_s2_sum')
+    cfg, _ = dyn_case('ca_h64_s2_sum')
+    cfg = dataclasses.replace(cfg, sin_embedding=True)
     h = hip_backend.Handle(cfg.as_dict(), 0)
-    h.load_state_dict(sd)
+    h.load_state_dict(make_state_dict(cfg, seed=3, coord_gain=1.0))
     h.set_layout(G16['ca_h64_s2_sum/num_nodes_phar'], G16['ca_h64_s2_sum/pocket_size'])
-    n = h.param_count() if hasattr(h, 'param_count') else 1
-    with pytest.raises(hip_backend.CmdgenError, match='inv_sublayers = 1'):
+    with pytest.raises(hip_backend.CmdgenError, match='sin_embedding False'):
         z = torch.zeros(8, device=dev)
         h._check(h.lib.cmdgen_train_forward(h.h, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None, None), 'cmdgen_train_forward')
     h.close()

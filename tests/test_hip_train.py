@@ -171,16 +171,20 @@ def test_weight_gradient_launch(mode):
 
 
 # ------------------------------------------------------------------ the reference's training step (G11)
-def build_trainer(lr=1e-3):
+def build_trainer(lr=1e-3, inv_sublayers=1, aggregation_method='sum'):
     from argparse import Namespace
     from cmdgen_amd.lightning_modules import PharPocketDDPM
     from cmdgen_amd.training import HipTrainer
     g6 = load_golden('g6_loss.npz')
     cfg, sd, phar, pocket, hist = loss_case(g6)
+    if inv_sublayers != 1 or aggregation_method != 'sum':
+        import dataclasses
+        cfg = dataclasses.replace(cfg, inv_sublayers=inv_sublayers, aggregation_method=aggregation_method)
+        sd = make_state_dict(cfg, seed=int(g6['meta'][4]), coord_gain=1.0)
     hp = dict(outdir='out', dataset='crossdock', datadir='data', batch_size=4, lr=lr,
               egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=cfg.hidden_nf,
-                                    n_layers=cfg.n_layers, attention=True, tanh=True, norm_constant=1, inv_sublayers=1,
-                                    sin_embedding=False, aggregation_method='sum', normalization_factor=100),
+                                    n_layers=cfg.n_layers, attention=True, tanh=True, norm_constant=1, inv_sublayers=inv_sublayers,
+                                    sin_embedding=False, aggregation_method=aggregation_method, normalization_factor=100),
               diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
                                          diffusion_noise_precision=1e-5, diffusion_loss_type='l2',
                                          normalize_factors=[1, 4]),
@@ -759,3 +763,78 @@ def test_vlb_objective_gradients_vs_oracle_autograd():
         off, cnt = tr.h.param_offset(name[len('dynamics.'):])
         g_want = np.zeros(cnt, np.float32) if leaf.grad is None else leaf.grad.numpy().reshape(-1)
         assert np.abs(grad[off:off + cnt] - g_want).max() <= GRAD_TOL * max(float(np.abs(g_want).max()), 1e-6), name
+
+
+# ------------------------------------------------------------------ EGNN options in the training step (G19, round 5)
+@pytest.mark.parametrize('case', ['s2_sum', 's1_mean', 's3_mean'])
+def test_training_gradients_with_egnn_options_match_reference(case):
+    """inv_sublayers > 1 (several GCLs per block, egnn_new.py:127-131, :152-154) and aggregation_method 'mean' (egnn_new.py:285-292)
+    in the training step: loss, per-sample nll and the gradient of every tensor against the REAL reference's autograd
+    (tests/golden/make_golden_r5.py; the G6 inputs); staged backward == single pass with several GCLs per stage."""
+    g = load_golden('g19_train_options.npz')
+    S, mean = [int(v) for v in g[f'{case}/options']]
+    model, tr, data, g6 = build_trainer(inv_sublayers=S, aggregation_method='mean' if mean else 'sum')
+    t_int, eps = dev(g6['t_int']), [dev(g6['eps0'])]
+    loss, nll, info = tr.loss_and_grad(data, t_int=t_int, eps=eps)
+    assert abs(float(loss) - float(g[f'{case}/loss'])) < 2e-6 * max(1.0, abs(float(g[f'{case}/loss'])))
+    assert np.abs(nll.cpu().numpy() - g[f'{case}/nll']).max() < 1e-5
+    grad = tr.grad.cpu().numpy()
+    n = 0
+    pre = f'{case}/grad/'
+    for key, want in g.items():
+        if key.startswith(pre) and key != pre + 'gamma.gamma':
+            off, cnt = tr.h.param_offset(key[len(pre + 'dynamics.'):])
+            got = grad[off:off + cnt].reshape(want.shape)
+            assert np.abs(got - want).max() <= GRAD_TOL * max(float(np.abs(want).max()), 1e-6), key
+            n += 1
+    L = int(g6['meta'][1])
+    assert n == 20 + 10 * S * L + 5 * L
+    # one optimizer step runs and the sampler takes the updated weights
+    tr.optimizer_step(None)
+    pocket = {'x': data['pocket_c_alpha'].cuda(), 'one_hot': data['pocket_one_hot'].cuda(),
+              'size': data['num_pocket_nodes'].cuda(), 'mask': data['pocket_mask'].cuda()}
+    out = model.ddpm.sample_given_pocket(pocket, data['num_phar_atoms'], timesteps=5, seed=1)
+    assert torch.isfinite(out[0]).all()
+
+
+@pytest.mark.parametrize('S,agg', [(2, 'mean'), (2, 'sum'), (1, 'mean')])
+def test_training_options_at_width_256_agree_across_engines(S, agg):
+    """The same options on the width the fast kernels exist for (H = 256: half-engine forward with save hooks, fused tails, weight
+    gradients beside the data gradients): the step's gradient against the same step on the fp32 instruction with the stand-alone
+    passes (the path G19 pins against the reference), every tensor to GRAD_TOL of its own scale - and against the oracle's autograd loss."""
+    import importlib.util, os
+    from argparse import Namespace
+    from cmdgen_amd.lightning_modules import PharPocketDDPM
+    from cmdgen_amd.training import HipTrainer
+    spec = importlib.util.spec_from_file_location('bench_train', os.path.join(os.path.dirname(__file__), '..', 'tools', 'bench_train.py'))
+    bt = importlib.util.module_from_spec(spec); spec.loader.exec_module(bt)
+    cfg = ModelConfig(n_layers=2, inv_sublayers=S, aggregation_method=agg)
+    hp = dict(outdir='out', dataset='crossdock', datadir='data', batch_size=16, lr=1e-3,
+              egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=256, n_layers=2, attention=True, tanh=True,
+                                    norm_constant=1, inv_sublayers=S, sin_embedding=False, aggregation_method=agg, normalization_factor=100),
+              diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2', diffusion_noise_precision=1e-5,
+                                         diffusion_loss_type='l2', normalize_factors=[1, 4]),
+              num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
+              eval_params=Namespace(n_eval_samples=100, eval_batch_size=100), mode='pocket_conditioning',
+              node_histogram=np.ones((30, 500)), pocket_representation='CA')
+    model = PharPocketDDPM(**hp)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed=0).items()}, strict=True)
+    tr = HipTrainer(model.cuda())
+    batch = bt.synthetic_batch(16, 7000, torch.device('cuda', 0))
+    gen = torch.Generator().manual_seed(12)
+    t_int = torch.randint(0, 501, (16, 1), generator=gen).float()
+    eps = [torch.randn((int(batch['num_phar_atoms'].sum()), 11), generator=gen).cuda()]
+    loss_s, _, _ = tr.loss_and_grad(batch, t_int=t_int, eps=eps)
+    grad_s = tr.grad.clone()
+    tr.h.set_gemm_mode(False)
+    loss_f, _, _ = tr.loss_and_grad(batch, t_int=t_int, eps=eps)
+    grad_f = tr.grad.clone()
+    tr.h.set_gemm_mode(True)
+    assert abs(float(loss_s) - float(loss_f)) <= 2e-6 * max(1.0, abs(float(loss_f)))
+    n = 0
+    for name, p in tr.dyn.named_parameters():
+        off, cnt = tr.h.param_offset(name)
+        a, b = grad_s[off:off + cnt], grad_f[off:off + cnt]
+        assert float((a - b).abs().max()) <= GRAD_TOL * max(float(b.abs().max()), 1e-6), name
+        n += 1
+    assert n == 20 + 10 * S * 2 + 5 * 2

@@ -253,3 +253,40 @@ def test_g11_oracle_autograd_matches_reference_gradients():
             assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-3), name
             n += 1
     assert n == 50
+
+
+@pytest.mark.parametrize('case', ['s2_sum', 's1_mean', 's3_mean'])
+def test_g19_oracle_autograd_matches_reference_gradients_with_egnn_options(case):
+    """inv_sublayers > 1 (egnn_new.py:127-131) and aggregation 'mean' (egnn_new.py:285-292) in the TRAINING loss: the oracle's autograd
+    gradients against the real reference's (tests/golden/make_golden_r5.py) - the checker of the HIP backward pass with these options."""
+    import dataclasses
+    from helpers import loss_case
+    g = load_golden('g19_train_options.npz')
+    g6 = load_golden('g6_loss.npz')
+    S, mean = [int(v) for v in g[f'{case}/options']]
+    cfg, _, phar, pocket, hist = loss_case(g6)
+    cfg = dataclasses.replace(cfg, inv_sublayers=S, aggregation_method='mean' if mean else 'sum')
+    H, L, B, R, seed, first = [int(v) for v in g6['meta']]
+    sd = make_state_dict(cfg, seed=seed, coord_gain=1.0)
+    p = ref_cpu.to_torch_params(sd)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith('dynamics.')}
+    p2 = dict(p); p2.update(leaves)
+    terms = ref_cpu.ddpm_forward(p2, cfg.as_dict(), phar, pocket, torch.from_numpy(g6['t_int']), [torch.from_numpy(g6['eps0'])],
+                                 training=True, histogram=hist)
+    nll = ref_cpu.nll_from_terms(terms, cfg.as_dict(), phar['size'], pocket['size'], training=True)
+    loss = nll.mean(0)
+    loss.backward()
+    assert abs(float(loss) - float(g[f'{case}/loss'])) < 2e-6
+    assert np.abs(nll.detach().numpy() - g[f'{case}/nll']).max() < 1e-5
+    n = 0
+    for key, want in g.items():
+        if key.startswith(f'{case}/grad/'):
+            name = key[len(f'{case}/grad/'):]
+            if name == 'gamma.gamma':
+                assert not want.any()
+                continue
+            got = leaves[name].grad
+            got = np.zeros_like(want) if got is None else got.numpy()
+            assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-3), name
+            n += 1
+    assert n == 20 + S * 10 * L + 5 * L          # 20 encoder / decoder / embedding tensors, 10 per GCL (with attention), 5 per EquivariantUpdate
