@@ -152,8 +152,10 @@ struct TrainState {
     // cost a fraction of what they cost alone.  What they read must outlive the main stream's next writer of the same buffer, so the
     // buffers one block's weight gradients read while the next kernels of the chain write alternate: dpre2 / dpre7 by block parity,
     // dP | dQ separately for the coordinate and the message list, dn by block parity, dh between the two sides of the node model.
+    int* h_tot = nullptr; hipEvent_t tot_ev = nullptr;          // pinned landing place of the list lengths and the event behind their copy (cmdgen_train_forward)
     hipStream_t ws = nullptr, ws_low = nullptr;      // (ws_low: the same at the device's lowest stream priority, wgrad_stream = 2)
     std::vector<hipEvent_t> evs;
+    float *part_x[4] = {nullptr, nullptr, nullptr, nullptr}, *tail_x[4] = {nullptr, nullptr, nullptr, nullptr};
     float *actA2 = nullptr, *actB2 = nullptr, *dPx[3] = {nullptr, nullptr, nullptr}, *dn2 = nullptr, *dh2 = nullptr, *dh3 = nullptr;
     // the fused forward (the sampler's evaluation kernels with save hooks): per-step packed copies of the parameters
     std::vector<void*> pack_allocs;
@@ -175,6 +177,8 @@ void cmdgen_train_free(TrainState* t) {
     if (!t) return;
     free_pool(t->node_allocs); free_pool(t->edge_allocs); free_pool(t->pack_allocs);
     for (hipEvent_t e : t->evs) hipEventDestroy(e);
+    if (t->h_tot) hipHostFree(t->h_tot);
+    if (t->tot_ev) hipEventDestroy(t->tot_ev);
     if (t->ws) hipStreamDestroy(t->ws);
     if (t->ws_low) hipStreamDestroy(t->ws_low);
     delete t;
@@ -379,6 +383,10 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
     EA(t->pre6, float, L * ecc * H); EA(t->pre7, float, L * ecc * H); EA(t->phi, float, L * ecc);
     EA(t->actA, float, em * H); EA(t->actB, float, em * H);
     EA(t->actA2, float, ec * H); EA(t->actB2, float, ecc * H);
+    for (int i = 0; i < 4; ++i) {       // [list: coordinate / message][GCL parity]: the partial sums the side stream reduces (tr_reduce_pair)
+        EA(t->part_x[i], float, tr_partial_scratch_floats(i < 2 ? ecc : ec, H));
+        EA(t->tail_x[i], float, std::max(tr_edge_tail_scratch_floats(i < 2 ? ecc : ec, H), tr_partial_scratch_floats(i < 2 ? ecc : ec, H)));
+    }
     EA(t->dphi, float, ecc);
     EA(t->dcd, float4, ecc);
     EA(t->tail_scratch, float, std::max(tr_edge_tail_scratch_floats(em, H), tr_partial_scratch_floats(em, H)));
@@ -450,17 +458,14 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     EvalLaunch a = make_launch(h);
     a.dead_skip = 0; a.w.need_qc = nullptr; a.w.ehop = nullptr; a.w.hop_levels = 1;       // the training forward skips nothing: no hop levels in its graph pass
     cmdgen_launch_edges(a, xh_phar, xh_pocket, s);
-    int tot[2];
-    HIPCHK(h, hipMemcpyAsync(tot, h->work.totals, sizeof tot, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
-    const int E = tot[0], Ec = tot[1];
-    rc = ensure_edges(h, t, E, Ec); if (rc) return rc;
-    g_bf16 = t->bf16; g_train_tune = h->tune;
-    h->train_E = E; h->train_Ec = Ec;
-    t->E = E; t->Ec = Ec; t->theta = theta; t->xh_phar = xh_phar; t->xh_pocket = xh_pocket;
-    const Work& w = h->work;
-    const ParamTable& tb = t->tab;
-    const size_t NH = (size_t)N * H;
+    // the list lengths come to the host through pinned memory and an event of their own: the re-packs below depend on the parameters only
+    // and are queued BEHIND the copy, so the device works on them while the host wakes up (a stream synchronize would wait for them too)
+    if (!t->h_tot) {
+        HIPCHK(h, hipHostMalloc((void**)&t->h_tot, 4 * sizeof(int), hipHostMallocDefault));
+        HIPCHK(h, hipEventCreateWithFlags(&t->tot_ev, hipEventDisableTiming));
+    }
+    HIPCHK(h, hipMemcpyAsync(t->h_tot, h->work.totals, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipEventRecord(t->tot_ev, s));
     // The forward pass IS the sampler's fused evaluation (k_embed, then per block k_edge_msg / k_node / k_edge_coord, then
     // k_readout) with save hooks that keep what the backward pass reads (TrainSave): ~20 launches instead of ~190, GEMMs on
     // the fragment-streaming tile kernels.  The parameters the optimizer has just updated are re-packed on the device.
@@ -475,6 +480,15 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     // ... and the node kernel as the sampler's eight-wave 16-row tile (k_node16w) where 16-row tiles are what the layout gets
     const bool node_half = fwd_half && a.node_mt == 16 && t->n_half16 > 0 && opt_of(h, "train_half", 1) != 2;
     if (node_half) tr_repack_half16(theta, t->half16_tab, t->n_half16, t->max_half16, s);
+    HIPCHK(h, hipEventSynchronize(t->tot_ev));
+    const int E = t->h_tot[0], Ec = t->h_tot[1];
+    rc = ensure_edges(h, t, E, Ec); if (rc) return rc;
+    g_bf16 = t->bf16; g_train_tune = h->tune;
+    h->train_E = E; h->train_Ec = Ec;
+    t->E = E; t->Ec = Ec; t->theta = theta; t->xh_phar = xh_phar; t->xh_pocket = xh_pocket;
+    const Work& w = h->work;
+    const ParamTable& tb = t->tab;
+    const size_t NH = (size_t)N * H;
     const int U = L * d.S;
     t->layers.assign(U, LayerW{});
     for (int l = 0; l < U; ++l) {                       // units
@@ -683,6 +697,8 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         float* dn = ss.on && par ? t->dn2 : t->dn;
         float* dPc = ss.on ? t->dPx[par] : t->dP; float* dQc = dPc + pq_off;                    // coordinate list's dP | dQ
         float* dPe = ss.on && par ? t->dPx[2] : t->dP; float* dQe = dPe + pq_off;               // message list's
+        float* part_c = ss.on ? t->part_x[par] : t->part_scratch; float* tail_c = ss.on ? t->tail_x[par] : t->tail_scratch;          // partial sums: coordinate list
+        float* part_e = ss.on ? t->part_x[2 + par] : t->part_scratch; float* tail_e = ss.on ? t->tail_x[2 + par] : t->tail_scratch;  // ... message list
         // everything this GCL writes was last read by the side work of GCL k - 2
         if (k >= 2) ss.wait(blk_done[k - 2]);
         if (sub == S - 1) {
@@ -690,14 +706,14 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         // (dL/d acc = dX / normalization_factor is formed where it is read; every later kernel of the block only adds to dX)
         tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, Nm, t->dphi, t->dcd, s, rowdiv);
         // actB <- dpre7, d coord_mlp.4; also clears dP | dQ (hidden_nf is 64, 128 or 256: cmdgen_create)
-        tr_head_bwd(Ec, H, t->dphi, theta + bc.c4.w, pre7, actB, pair ? t->part_scratch : t->tail_scratch, grad + bc.c4.w, dPc, pq_floats, s, pair);
+        tr_head_bwd(Ec, H, t->dphi, theta + bc.c4.w, pre7, actB, pair ? part_c : t->tail_scratch, grad + bc.c4.w, dPc, pq_floats, s, pair);
         edge_wgrad(bc.c2, actB, act6, Ec);                    // weight and bias gradient of coord_mlp.2 (c1 = act6)
         if (dgh) cmdgen_dgrad_tail_h(Ec, actB, pkc.th_c2, pre6, w.crow, w.ccol, w.cd0, theta + bc.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
-                                     dPc, dQc, t->dX, t->tail_scratch, s);
+                                     dPc, dQc, t->dX, tail_c, s);
         else if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
             cmdgen_dgrad_tail(Ec, actB, pkc.t_c2, pre6, w.crow, w.ccol, w.cd0, pair ? pkc.rd_c : theta + bc.c0.w + 2 * H /* radial column: the forward's contiguous copy */, pair ? 1 : ld1, Xl,
-                              d.norm_constant, t->dcd, Nm, dPc, dQc, grad + bc.c0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
-        if (pair) tr_reduce_pair(Ec, H, t->part_scratch, grad + bc.c4.w, nullptr, t->tail_scratch, grad + bc.c0.w + 2 * H, ld1, s);
+                              d.norm_constant, t->dcd, Nm, dPc, dQc, grad + bc.c0.w + 2 * H, t->dX, tail_c, pcs, s, pair);
+        if (pair) { float* gw = grad + bc.c4.w; float* gc = grad + bc.c0.w + 2 * H; defer([=](hipStream_t q) { tr_reduce_pair(Ec, H, part_c, gw, nullptr, tail_c, gc, ld1, q); }); }
         else {
             if (sp) cmdgen_dgrad_split(Ec, actB, pkc.t_c2, nullptr, nullptr, t->actA, false, 1.0f, pre6, s, pcs);
             else linear_dgrad(theta, bc.c2, 0, H, Ec, actB, H, t->actA, H, false, s, pre6);  // actA <- dc1 * SiLU'(pre6) = dpre6
@@ -735,16 +751,18 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         }
         // ---- edge model
         // actA <- dpre2, d att_mlp; also clears dP | dQ
-        tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, actA, pair ? t->part_scratch : t->tail_scratch,
+        tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, actA, pair ? part_e : t->tail_scratch,
                     d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, dPe, pq_floats, s, pair);
         edge_wgrad(b.e2, actA, act1, E);                      // weight and bias gradient of edge_mlp.2 (m1 = act1)
         if (dgh) cmdgen_dgrad_tail_h(E, actA, pk.th_e2, pre1, w.erow, w.ecol, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
-                                     dPe, dQe, t->dX, t->tail_scratch, s);
+                                     dPe, dQe, t->dX, tail_e, s);
         else if (tail_fused)
             cmdgen_dgrad_tail(E, actA, pk.t_e2, pre1, w.erow, w.ecol, w.ed0, pair ? pk.rd_e : theta + b.e0.w + 2 * H, pair ? 1 : ld1, Xl, d.norm_constant, nullptr, Nm,
-                              dPe, dQe, grad + b.e0.w + 2 * H, t->dX, t->tail_scratch, pcs, s, pair);
-        if (pair) tr_reduce_pair(E, H, t->part_scratch, d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr,
-                                 t->tail_scratch, grad + b.e0.w + 2 * H, ld1, s);
+                              dPe, dQe, grad + b.e0.w + 2 * H, t->dX, tail_e, pcs, s, pair);
+        if (pair) {
+            float* gaw = d.attention ? grad + b.att.w : nullptr; float* gab = d.attention ? grad + b.att.b : nullptr; float* ge = grad + b.e0.w + 2 * H;
+            defer([=](hipStream_t q) { tr_reduce_pair(E, H, part_e, gaw, gab, tail_e, ge, ld1, q); });
+        }
         else {
             if (sp) cmdgen_dgrad_split(E, actA, pk.t_e2, nullptr, nullptr, t->actB, false, 1.0f, pre1, s, pcs);
             else linear_dgrad(theta, b.e2, 0, H, E, actA, H, t->actB, H, false, s, pre1);   // actB <- dm1 * SiLU'(pre1) = dpre1
