@@ -55,8 +55,10 @@ size_t tr_partial_scratch_floats(size_t E, size_t H);
 void tr_gate_bwd(int E, int H, const int* row, const float* pre2, const float* wa, const float* z, int attention, const float* dagg,
                  float* dpre2, float* scratch, float* d_wa, float* d_ba, float* zero, size_t zero_floats, hipStream_t s,
                  bool defer_reduce = false);
+struct CoordOutArgs { const int* row; const int* col; const float4* X; const float* phi; int use_tanh; float range, norm_constant;
+                      const float* dacc; float dacc_div; const float* adiv; float4* dcd_out; };       // kernels_train.hip
 void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
-                 float* zero, size_t zero_floats, hipStream_t s, bool defer_reduce = false);
+                 float* zero, size_t zero_floats, hipStream_t s, bool defer_reduce = false, const CoordOutArgs* co = nullptr);
 void tr_colsum(int E, int H, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s);
 void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s);
 void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, float* ddec, hipStream_t s);
@@ -704,9 +706,10 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         if (sub == S - 1) {
         // ---- EquivariantUpdate: x_{l+1} = x_l + acc / nf ; dX holds dL/dx_{l+1} and becomes dL/dx_l
         // (dL/d acc = dX / normalization_factor is formed where it is read; every later kernel of the block only adds to dX)
-        tr_coord_out_bwd(Ec, w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, Nm, t->dphi, t->dcd, s, rowdiv);
+        // (its per-edge arithmetic runs inside tr_head_bwd: one launch)
+        const CoordOutArgs co{w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, rowdiv, t->dcd};
         // actB <- dpre7, d coord_mlp.4; also clears dP | dQ (hidden_nf is 64, 128 or 256: cmdgen_create)
-        tr_head_bwd(Ec, H, t->dphi, theta + bc.c4.w, pre7, actB, pair ? part_c : t->tail_scratch, grad + bc.c4.w, dPc, pq_floats, s, pair);
+        tr_head_bwd(Ec, H, t->dphi, theta + bc.c4.w, pre7, actB, pair ? part_c : t->tail_scratch, grad + bc.c4.w, dPc, pq_floats, s, pair, &co);
         edge_wgrad(bc.c2, actB, act6, Ec);                    // weight and bias gradient of coord_mlp.2 (c1 = act6)
         if (dgh) cmdgen_dgrad_tail_h(Ec, actB, pkc.th_c2, pre6, w.crow, w.ccol, w.cd0, theta + bc.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
                                      dPc, dQc, t->dX, tail_c, s);

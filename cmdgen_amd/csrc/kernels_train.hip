@@ -1198,17 +1198,40 @@ __global__ __launch_bounds__(256) void k_gate_bwd(int E, int H, const int* __res
     if (threadIdx.x == 0) out[H] = (red[0][256] + red[1][256]) + (red[2][256] + red[3][256]);
 }
 
+// the inputs of k_coord_out_bwd, for the form of k_head_bwd that computes dphi (and writes dcd) itself: one launch less per block
+struct CoordOutArgs { const int* row; const int* col; const float4* X; const float* phi; int use_tanh; float range, norm_constant;
+                      const float* dacc; float dacc_div; const float* adiv; float4* dcd_out; };
 // dpre7[e][c] = dphi_e w5[c] SiLU'(pre7[e][c]) and, in the same pass, the partial sums of d coord_mlp.4.weight[c] =
 // sum_e dphi_e SiLU(pre7[e][c]) (c2 is recomputed, not read); same workgroup shape and scratch layout as k_gate_bwd.
 __global__ __launch_bounds__(256) void k_head_bwd(int E, int H, const float* __restrict__ dphi, const float* __restrict__ w5,
                                                   const float* __restrict__ pre7, float* __restrict__ dpre7,
                                                   float* __restrict__ scratch /* [workgroups][H + 4] */,
-                                                  float4* __restrict__ zero, size_t zero_n4) {
+                                                  float4* __restrict__ zero, size_t zero_n4, CoordOutArgs co) {
     __shared__ float red[4][260];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero_n4; i += (size_t)gridDim.x * 256) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool on = 4 * lane < H;
     const int e0 = blockIdx.x * (4 * GATE_EPW) + wave * GATE_EPW, e1 = min(E, e0 + GATE_EPW);
+    // co.row: dphi is not read but formed here, by lane k for the wave's k-th edge (the arithmetic of k_coord_out_bwd), and dcd written
+    float my_dphi = 0.f;
+    if (co.row && lane < GATE_EPW && e0 + lane < e1) {
+        const int e = e0 + lane;
+        const int i = co.row[e], j = co.col[e];
+        const float4 a = co.X[i], b = co.X[j];
+        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+        const float r = dx * dx + dy * dy + dz * dz;
+        const float den = sqrtf(r + 1e-8f) + co.norm_constant;
+        const float cx = dx / den, cy = dy / den, cz = dz / den;
+        const float4 dv = *reinterpret_cast<const float4*>(co.dacc + (size_t)i * 4);
+        const float dd = co.adiv ? co.adiv[i] : co.dacc_div;
+        const float da[3] = {dv.x / dd, dv.y / dd, dv.z / dd};
+        const float p = co.phi[e];
+        const float th = co.use_tanh ? tanhf(p) : 0.f;
+        const float g = co.use_tanh ? th * co.range : p;
+        const float dg = cx * da[0] + cy * da[1] + cz * da[2];
+        my_dphi = co.use_tanh ? dg * co.range * (1.0f - th * th) : dg;
+        co.dcd_out[e] = make_float4(g * da[0], g * da[1], g * da[2], 0.f);
+    }
     float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), cs = w4;
     if (on) w4 = reinterpret_cast<const float4*>(w5)[lane];
     float4 pv[GATE_EPW]; float sv[GATE_EPW];
@@ -1216,7 +1239,12 @@ __global__ __launch_bounds__(256) void k_head_bwd(int E, int H, const float* __r
     for (int k = 0; k < GATE_EPW; ++k) {
         const int e = e0 + k;
         pv[k] = make_float4(0.f, 0.f, 0.f, 0.f); sv[k] = 0.f;
-        if (e < e1) { sv[k] = dphi[e]; if (on) pv[k] = reinterpret_cast<const float4*>(pre7 + (size_t)e * H)[lane]; }
+        if (e < e1 && on) pv[k] = reinterpret_cast<const float4*>(pre7 + (size_t)e * H)[lane];
+        if (!co.row && e < e1) sv[k] = dphi[e];
+    }
+    if (co.row) {
+#pragma unroll
+        for (int k = 0; k < GATE_EPW; ++k) sv[k] = __shfl(my_dphi, k);
     }
 #pragma unroll
     for (int k = 0; k < GATE_EPW; ++k) {
@@ -2161,10 +2189,10 @@ void tr_gate_bwd(int E, int H, const int* row, const float* pre2, const float* w
 }
 // dpre7 from dphi, and d coord_mlp.4.weight
 void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
-                 float* zero, size_t zero_floats, hipStream_t s, bool defer_reduce = false) {
+                 float* zero, size_t zero_floats, hipStream_t s, bool defer_reduce = false, const CoordOutArgs* co = nullptr) {
     if (!E) { if (zero_floats) hipMemsetAsync(zero, 0, zero_floats * sizeof(float), s); return; }
     const int nwg = (E + 4 * GATE_EPW - 1) / (4 * GATE_EPW);
-    hipLaunchKernelGGL(k_head_bwd, dim3(nwg), dim3(256), 0, s, E, H, dphi, w5, pre7, dpre7, scratch, (float4*)zero, zero_floats / 4);
+    hipLaunchKernelGGL(k_head_bwd, dim3(nwg), dim3(256), 0, s, E, H, dphi, w5, pre7, dpre7, scratch, (float4*)zero, zero_floats / 4, co ? *co : CoordOutArgs{});
     if (!defer_reduce) hipLaunchKernelGGL(k_partial_reduce, dim3((H + 63) / 64, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, H, scratch, d_w5, (float*)nullptr);
 }
 void tr_coord_out_bwd(int E, const int* row, const int* col, const float4* X, const float* phi, int use_tanh, float range,
