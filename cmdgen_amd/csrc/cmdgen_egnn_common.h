@@ -121,7 +121,7 @@ __device__ __forceinline__ void build_edge_tile(float* buf, const int* s_row, co
             a.x = silu_f(pre.x); a.y = silu_f(pre.y); a.z = silu_f(pre.z); a.w = silu_f(pre.w);
             if (pre_out) {                                 // training: rows of the tile in the compact list's order
                 reinterpret_cast<float4*>(pre_out + (size_t)e * H)[c4] = pre;
-                reinterpret_cast<float4*>(act_out + (size_t)e * H)[c4] = a;
+                if (act_out) reinterpret_cast<float4*>(act_out + (size_t)e * H)[c4] = a;
             }
         }
         *reinterpret_cast<float4*>(buf + e * LDA(H) + 4 * c4) = a;
@@ -180,7 +180,7 @@ __device__ __forceinline__ void build_edge_half(unsigned short* planes, int half
             a = make_float4(silu_f(pre.x), silu_f(pre.y), silu_f(pre.z), silu_f(pre.w));
             if (pre_out) {
                 *reinterpret_cast<float4*>(pre_out + (size_t)e * H + col) = pre;
-                *reinterpret_cast<float4*>(act_out + (size_t)e * H + col) = a;
+                if (act_out) *reinterpret_cast<float4*>(act_out + (size_t)e * H + col) = a;
             }
         }
         split_store4(planes, PE, e * PLDA + 4 * c4, a);
@@ -218,7 +218,7 @@ __device__ __forceinline__ void build_edge_full32(unsigned short* planes, const 
             a = make_float4(silu_f(pre.x), silu_f(pre.y), silu_f(pre.z), silu_f(pre.w));
             if (pre_out) {
                 reinterpret_cast<float4*>(pre_out + (size_t)e * H)[c4] = pre;
-                reinterpret_cast<float4*>(act_out + (size_t)e * H)[c4] = a;
+                if (act_out) reinterpret_cast<float4*>(act_out + (size_t)e * H)[c4] = a;
             }
         }
         if constexpr (NPC == 3) split_store4_swz(planes, e, c4, a); else split_store4_swz_half(planes, e, c4, a);

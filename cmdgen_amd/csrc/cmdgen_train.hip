@@ -21,6 +21,7 @@ struct WgradBatch {               // kernels_train.hip: up to 8 weight gradients
     const float* dy[8]; const float* x[8]; float* dw[8]; float* db[8];
     int M[8], N[8], lddy[8], ldx[8], ldw[8];
     int n;
+    int xs[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // 1: X_p holds pre-activations, SiLU applied while staging
 };
 void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bool split3 = false, bool force3 = false);
 struct RepackSplitT { int src_off, ld; void* dst; int transpose; };                                       // kernels_train.hip
@@ -131,6 +132,7 @@ struct TrainState {
     size_t ecap = 0, eccap = 0;
     bool have_forward = false;
     bool split_packs_valid = false;     // the last forward re-packed the transposed split fragments (backward may use them)
+    int wsilu = 0;                      // which activations the last forward did NOT store (option wgrad_silu)
     bool half_packs_valid = false;      // ... and the half packs (forward edge kernels + the transposed blocks of the data gradients)
     bool bf16 = false;                  // GEMM operands in bf16 (fp32 accumulation); default exact fp32
     const float* theta = nullptr;       // parameters used by the last forward (backward reads the same)
@@ -381,7 +383,7 @@ static int ensure_edges(cmdgen_handle* h, TrainState* t, int E, int Ec) {
 #define EA(dst, type, count) do { rc = dev_alloc(h, t->edge_allocs, &p, (size_t)(count) * sizeof(type), false); \
         if (rc) return rc; dst = (type*)p; } while (0)
     EA(t->pre1, float, U * ec * H); EA(t->pre2, float, U * ec * H); EA(t->z, float, U * ec);
-    EA(t->act1, float, U * ec * H); EA(t->act6, float, L * ecc * H);      // SiLU(pre2) / SiLU(pre7) are recomputed by their one consumer
+    EA(t->act1, float, U * ec * H); EA(t->act6, float, L * ecc * H);      // (unused where the weight gradient forms SiLU(pre) itself: option wgrad_silu)
     EA(t->pre6, float, L * ecc * H); EA(t->pre7, float, L * ecc * H); EA(t->phi, float, L * ecc);
     EA(t->actA, float, em * H); EA(t->actB, float, em * H);
     EA(t->actA2, float, ec * H); EA(t->actB2, float, ecc * H);
@@ -525,9 +527,13 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     sw.emb_wT = t->emb_wT; sw.emb_b = theta + tb.emb.b; sw.embo_wT = t->embo_wT; sw.embo_b = theta + tb.embo.b;
     TrainSave sv{};
     sv.enc1_l = t->enc1_l; sv.enca_l = t->enca_l; sv.enc1_p = t->enc1_p; sv.enca_p = t->enca_p; sv.hdyn = t->hdyn; sv.h = t->h;
-    sv.pre1 = t->pre1; sv.act1 = t->act1; sv.pre2 = t->pre2; sv.act2 = nullptr; sv.z = t->z;
+    // option wgrad_silu (bit 0: message list, bit 1: coordinate list): SiLU(pre1) / SiLU(pre6) are not stored - the one consumer, the second
+    // layer's weight gradient, forms them while it stages its operand
+    const int wsilu = (int)opt_of(h, "wgrad_silu", t->bf16 ? 3 : 0);
+    t->wsilu = wsilu;
+    sv.pre1 = t->pre1; sv.act1 = (wsilu & 1) ? nullptr : t->act1; sv.pre2 = t->pre2; sv.act2 = nullptr; sv.z = t->z;
     sv.aggn = t->aggn; sv.pre3 = t->pre3; sv.nact = t->nact;
-    sv.pre6 = t->pre6; sv.act6 = t->act6; sv.pre7 = t->pre7; sv.act7 = nullptr; sv.phi = t->phi;
+    sv.pre6 = t->pre6; sv.act6 = (wsilu & 2) ? nullptr : t->act6; sv.pre7 = t->pre7; sv.act7 = nullptr; sv.phi = t->phi;
     sv.hfin = t->hfin; sv.dec1 = t->dec1; sv.deca = t->deca; sv.dec_out = t->dec_out;
     sv.qdec1 = t->qdec1; sv.qdeca = t->qdeca; sv.qdec_out = t->qdec_out;
     sv.ecap = t->ecap; sv.eccap = t->eccap;
@@ -624,8 +630,8 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     const bool bf = g_bf16, gs = h->gemm_split;
     auto flush_wgrads = [&]() { const WgradBatch g = wb; defer([=](hipStream_t q) { cmdgen_wgrad_group(g, N, bf, q, gs); }); wb.n = 0; };
     // weight + bias gradient of one edge-level Linear (K = list length) in one launch
-    auto edge_wgrad = [&](const PRef& r, const float* dy, const float* x, int K) {
-        WgradBatch one; one.n = 1;
+    auto edge_wgrad = [&](const PRef& r, const float* dy, const float* x, int K, int x_is_pre) {       // x_is_pre: x is the layer's PRE-activation (its SiLU is formed while the operand is staged)
+        WgradBatch one; one.n = 1; one.xs[0] = x_is_pre;
         one.dy[0] = dy; one.x[0] = x; one.dw[0] = grad + r.w; one.db[0] = grad + r.b;
         one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = r.in;
         defer([=](hipStream_t q) { cmdgen_wgrad_group(one, K, bf, q, w3); });
@@ -677,7 +683,6 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         const float4* Xl = t->X + (size_t)l * N;
         const float* pre6 = t->pre6 + (size_t)l * t->eccap * H; const float* pre7 = t->pre7 + (size_t)l * t->eccap * H;
         const float* phi = t->phi + (size_t)l * t->eccap;
-        const float* act6 = t->act6 + (size_t)l * t->eccap * H;
         const size_t pq_floats = pq_off + NH;                             // dP and dQ, adjacent
         const bool pair = tail_fused;                         // the list's two reductions (head / gate partials, tail partials) as one launch
         for (int sub = S - 1; sub >= 0; --sub) {
@@ -689,7 +694,6 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         const float* pre1 = t->pre1 + (size_t)u * t->ecap * H; const float* pre2 = t->pre2 + (size_t)u * t->ecap * H;
         const float* aggn = t->aggn + (size_t)u * NH; const float* pre3 = t->pre3 + (size_t)u * NH;
         const float* z = t->z + (size_t)u * t->ecap;
-        const float* act1 = t->act1 + (size_t)u * t->ecap * H;
         const float* nact = t->nact + (size_t)u * NH;
         // this GCL's buffers: k counts the GCLs of the pass (k = 0 for the last GCL of block L-1)
         const int k = U - 1 - u, par = k & 1;
@@ -710,7 +714,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         const CoordOutArgs co{w.crow, w.ccol, Xl, phi, d.use_tanh, d.coords_range, d.norm_constant, t->dX, d.norm_factor, rowdiv, t->dcd};
         // actB <- dpre7, d coord_mlp.4; also clears dP | dQ (hidden_nf is 64, 128 or 256: cmdgen_create)
         tr_head_bwd(Ec, H, t->dphi, theta + bc.c4.w, pre7, actB, pair ? part_c : t->tail_scratch, grad + bc.c4.w, dPc, pq_floats, s, pair, &co);
-        edge_wgrad(bc.c2, actB, act6, Ec);                    // weight and bias gradient of coord_mlp.2 (c1 = act6)
+        edge_wgrad(bc.c2, actB, (t->wsilu & 2) ? pre6 : t->act6 + (size_t)l * t->eccap * H, Ec, (t->wsilu & 2) ? 1 : 0);      // weight and bias gradient of coord_mlp.2 (c1 = SiLU(pre6))
         if (dgh) cmdgen_dgrad_tail_h(Ec, actB, pkc.th_c2, pre6, w.crow, w.ccol, w.cd0, theta + bc.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
                                      dPc, dQc, t->dX, tail_c, s);
         else if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
@@ -756,7 +760,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         // actA <- dpre2, d att_mlp; also clears dP | dQ
         tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, actA, pair ? part_e : t->tail_scratch,
                     d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, dPe, pq_floats, s, pair);
-        edge_wgrad(b.e2, actA, act1, E);                      // weight and bias gradient of edge_mlp.2 (m1 = act1)
+        edge_wgrad(b.e2, actA, (t->wsilu & 1) ? pre1 : t->act1 + (size_t)u * t->ecap * H, E, (t->wsilu & 1) ? 1 : 0);            // weight and bias gradient of edge_mlp.2 (m1 = SiLU(pre1))
         if (dgh) cmdgen_dgrad_tail_h(E, actA, pk.th_e2, pre1, w.erow, w.ecol, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
                                      dPe, dQe, t->dX, tail_e, s);
         else if (tail_fused)

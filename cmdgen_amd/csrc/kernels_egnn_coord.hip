@@ -70,7 +70,7 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
             build_edge_full32<FK>(planes, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, wr4, wd4,
                                   SAVE ? sv.pre6 + ((size_t)layer * sv.eccap + e0) * H : nullptr,
-                                  SAVE ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr);
+                                  (SAVE && sv.act6) ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr);
             lds_barrier();
             G::gemm(planes, fw, acc.a, carry);
         } else if constexpr (PL) {
@@ -78,7 +78,7 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
             constexpr int PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
             const typename G::Frag fw1 = G::frag(lw.W7, H / 8, H / 16, wave);
             float* pre6_o = SAVE ? sv.pre6 + ((size_t)layer * sv.eccap + e0) * H : nullptr;
-            float* act6_o = SAVE ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr;
+            float* act6_o = (SAVE && sv.act6) ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr;
             build_edge_half<MT>(planes, 0, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, s_wrd, s_wrd + H, pre6_o, act6_o);
             lds_barrier();
             tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw, fw1, acc.a, carry);
@@ -90,7 +90,7 @@ __device__ __forceinline__ void edge_coord_body(EdgeLds<H, MT, FK>& L, const Lay
         if (d.sin) { sin_features<H, MT>(s_dyn + 24 * H, s_r, s_d0, ne, d); lds_barrier(); }
         build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.Pc, w.Qc, wr4, wd4,
                                SAVE ? sv.pre6 + ((size_t)layer * sv.eccap + e0) * H : nullptr,
-                               SAVE ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr,
+                               (SAVE && sv.act6) ? sv.act6 + ((size_t)layer * sv.eccap + e0) * H : nullptr,
                                d.sin ? s_dyn + 24 * H : nullptr, s_dyn);
         lds_barrier();
         G::template gemm<H / 8>(buf, LDA(H), fw, fw, acc, carry);

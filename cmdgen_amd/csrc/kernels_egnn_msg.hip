@@ -96,7 +96,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
             unsigned short* planes = reinterpret_cast<unsigned short*>(buf);
             if (!(ablate & 2)) build_edge_full32<FK>(planes, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4,
                                                      SAVE ? sv.pre1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr,
-                                                     SAVE ? sv.act1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr);
+                                                     (SAVE && sv.act1) ? sv.act1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr);
             lds_barrier();
             STAMP(1);
             if (!(ablate & 4)) G::gemm(planes, fw, acc.a, carry);
@@ -106,7 +106,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
             constexpr int PLDA = SPLIT_PLANE_LDA(H / 2), PE = MT * PLDA;
             const typename G::Frag fw1 = G::frag(lw.W2, H / 8, H / 16, wave);
             float* pre1_o = SAVE ? sv.pre1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr;
-            float* act1_o = SAVE ? sv.act1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr;
+            float* act1_o = (SAVE && sv.act1) ? sv.act1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr;
             if (!(ablate & 2)) build_edge_half<MT>(planes, 0, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, s_wrd, s_wrd + H, pre1_o, act1_o);
             lds_barrier();
             if (!(ablate & 4)) tile_gemm_planes<MT, H / 32>(planes, PE, PLDA, fw, fw1, acc.a, carry);
@@ -119,7 +119,7 @@ __device__ __forceinline__ void edge_msg_body(EdgeLds<H, MT, FK>& L, const Layou
         if (d.sin) { sin_features<H, MT>(s_dyn + 24 * H, s_r, s_d0, ne, d); lds_barrier(); }
         if (!(ablate & 2)) build_edge_tile<H, MT>(buf, s_row, s_col, s_r, s_d0, ne, w.P, w.Q, wr4, wd4,
                                                   SAVE ? sv.pre1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr,
-                                                  SAVE ? sv.act1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr,
+                                                  (SAVE && sv.act1) ? sv.act1 + ((size_t)sv.slot * sv.ecap + e0) * H : nullptr,
                                                   d.sin ? s_dyn + 24 * H : nullptr, s_dyn);
         lds_barrier();
         STAMP(1);

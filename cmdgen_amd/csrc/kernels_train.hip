@@ -235,9 +235,11 @@ struct WgradBatch {
     const float* dy[8]; const float* x[8]; float* dw[8]; float* db[8];
     int M[8], N[8], lddy[8], ldx[8], ldw[8];
     int n;
+    int xs[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // 1: X_p holds PRE-activations - SiLU is applied while the operand is staged (the forward then stores pre1 / pre6 only)
 };
+__device__ __forceinline__ float4 silu4(const float4& v) { return make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w)); }
 
-template <bool BF>
+template <bool BF, bool XS = false>      // XS: some X_p holds pre-activations (WgradBatch::xs) - a separate instantiation: the default one carries no trace of it
 __global__ __launch_bounds__(256) void k_wgrad_group(WgradBatch g, int K, int kchunk, int zsplit) {
     constexpr int KT = 64;
     // fp32 path: both operands lie in memory k-major ([k][channel]) and stay that way in LDS ([k][WG_LDK]): v_mfma_f32_32x32x2
@@ -271,6 +273,10 @@ __global__ __launch_bounds__(256) void k_wgrad_group(WgradBatch g, int K, int kc
         if (want_bias) {
 #pragma unroll
             for (int q = 0; q < TG_P(KT); ++q) { colsum.x += ra[q].x; colsum.y += ra[q].y; colsum.z += ra[q].z; colsum.w += ra[q].w; }
+        }
+        if constexpr (XS) if (g.xs[p]) {
+#pragma unroll
+            for (int q = 0; q < TG_P(KT); ++q) rb[q] = silu4(rb[q]);
         }
         if (BF) { tg_put_bf16<KT, true>(Ah, ra); tg_put_bf16<KT, true>(Bh, rb); }
         else {
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(256) void k_wgrad_group(WgradBatch g, int K, int kc
 // Threads 0-127 stage dY, 128-255 stage X; the next k tile's rows are in flight during the MFMAs.  NPC = 1: leading pieces
 // only (bf16 operands).
 // ------------------------------------------------------------------------------------
-template <int NPC>
+template <int NPC, bool XS = false>
 __global__ __launch_bounds__(256, 2) void k_wgrad_split(WgradBatch g, int K, int kchunk, int zsplit) {
     constexpr int KT = 64, PLD = KT + 8, PE = 64 * PLD;               // bf16 elements per plane row / per plane
     __shared__ __attribute__((aligned(16))) unsigned short planes[2 * NPC * PE];
@@ -374,6 +380,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(WgradBatch g, int K, int
             for (int i = 0; i < 8; ++i) { colsum.x += v[i].x; colsum.y += v[i].y; colsum.z += v[i].z; colsum.w += v[i].w; }
         }
         {   // transpose in registers: channel c gets the eight k values v[0..7].c, split into the pieces, one 16-byte store per plane
+            if constexpr (XS) if (isB && g.xs[p]) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = silu4(v[i]);
+            }
             const float c0[8] = {v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x};
             const float c1[8] = {v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y};
             const float c2[8] = {v[0].z, v[1].z, v[2].z, v[3].z, v[4].z, v[5].z, v[6].z, v[7].z};
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(WgradBatch g, int K, int
 // position XOR-swizzled by the channel group, so the sixteen lanes of a store cycle fall on sixteen different bank groups
 // (channel rows four apart put them on four).  Every M_p, N_p a multiple of 128.
 // ------------------------------------------------------------------------------------
-template <int NPC>
+template <int NPC, bool XS = false>
 __global__ __launch_bounds__(256, 2) void k_wgrad_split128(WgradBatch g, int K, int kchunk, int zsplit) {
     constexpr int KT = 32, PLD = KT + 8, TM = 128, PE = TM * PLD;     // bf16 elements per plane row / per plane
     __shared__ __attribute__((aligned(16))) unsigned short planes[2 * NPC * PE];
@@ -493,6 +503,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split128(WgradBatch g, int K, 
             for (int i = 0; i < 8; ++i) { colsum.x += v[i].x; colsum.y += v[i].y; colsum.z += v[i].z; colsum.w += v[i].w; }
         }
         {
+            if constexpr (XS) if (isB && g.xs[p]) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = silu4(v[i]);
+            }
             const float c0[8] = {v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x};
             const float c1[8] = {v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y};
             const float c2[8] = {v[0].z, v[1].z, v[2].z, v[3].z, v[4].z, v[5].z, v[6].z, v[7].z};
@@ -571,6 +585,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split128(WgradBatch g, int K, 
 thread_local TrainTune g_train_tune;      // set from the handle at every entry of the training step (cmdgen_train.hip)
 void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bool split3 = false, bool force3 = false) {
     if (g.n <= 0 || K <= 0) return;
+    bool xs = false;
+    for (int p = 0; p < g.n; ++p) xs = xs || g.xs[p] != 0;
     int tm = 1, tn = 1;
     for (int p = 0; p < g.n; ++p) { tm = max(tm, (g.M[p] + 63) / 64); tn = max(tn, (g.N[p] + 63) / 64); }
     {
@@ -597,7 +613,9 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bo
             const int kchunk = ((K + zsplit - 1) / zsplit + 31) / 32 * 32;
             zsplit = (K + kchunk - 1) / kchunk;
             const dim3 grid(tn, tm, g.n * zsplit);
-            if (bf16) hipLaunchKernelGGL(k_wgrad_split128<1>, grid, dim3(256), 0, s, g, K, kchunk, zsplit);
+            if (xs) { if (bf16) hipLaunchKernelGGL((k_wgrad_split128<1, true>), grid, dim3(256), 0, s, g, K, kchunk, zsplit);
+                      else hipLaunchKernelGGL((k_wgrad_split128<3, true>), grid, dim3(256), 0, s, g, K, kchunk, zsplit); }
+            else if (bf16) hipLaunchKernelGGL(k_wgrad_split128<1>, grid, dim3(256), 0, s, g, K, kchunk, zsplit);
             else hipLaunchKernelGGL(k_wgrad_split128<3>, grid, dim3(256), 0, s, g, K, kchunk, zsplit);
             return;
         }
@@ -612,7 +630,9 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bo
             const int kchunk = ((K + zsplit - 1) / zsplit + 63) / 64 * 64;
             zsplit = (K + kchunk - 1) / kchunk;
             const dim3 grid(tn, tm, g.n * zsplit);
-            if (bf16) hipLaunchKernelGGL(k_wgrad_split<1>, grid, dim3(256), 0, s, g, K, kchunk, zsplit);
+            if (xs) { if (bf16) hipLaunchKernelGGL((k_wgrad_split<1, true>), grid, dim3(256), 0, s, g, K, kchunk, zsplit);
+                      else hipLaunchKernelGGL((k_wgrad_split<3, true>), grid, dim3(256), 0, s, g, K, kchunk, zsplit); }
+            else if (bf16) hipLaunchKernelGGL(k_wgrad_split<1>, grid, dim3(256), 0, s, g, K, kchunk, zsplit);
             else hipLaunchKernelGGL(k_wgrad_split<3>, grid, dim3(256), 0, s, g, K, kchunk, zsplit);
             return;
         }
@@ -625,7 +645,9 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bo
     const int kchunk = ((K + zsplit - 1) / zsplit + 63) / 64 * 64;
     zsplit = (K + kchunk - 1) / kchunk;
     const dim3 grid(tn, tm, g.n * zsplit), block(256);
-    if (bf16) hipLaunchKernelGGL(k_wgrad_group<true>, grid, block, 0, s, g, K, kchunk, zsplit);
+    if (xs) { if (bf16) hipLaunchKernelGGL((k_wgrad_group<true, true>), grid, block, 0, s, g, K, kchunk, zsplit);
+              else hipLaunchKernelGGL((k_wgrad_group<false, true>), grid, block, 0, s, g, K, kchunk, zsplit); }
+    else if (bf16) hipLaunchKernelGGL(k_wgrad_group<true>, grid, block, 0, s, g, K, kchunk, zsplit);
     else hipLaunchKernelGGL(k_wgrad_group<false>, grid, block, 0, s, g, K, kchunk, zsplit);
 }
 
