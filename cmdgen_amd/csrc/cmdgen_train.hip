@@ -482,6 +482,9 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     if (fwd_half) tr_repack_half(theta, t->half_tab, dgrad_half ? t->n_half : t->n_half_fwd, s);
     t->half_packs_valid = dgrad_half;
     // ... and the node kernel as the sampler's eight-wave 16-row tile (k_node16w) where 16-row tiles are what the layout gets
+    // (option train_node16: 16-row tiles for the node kernel at EVERY size - the save-hook form of the node kernel exists on the half engine
+    // for these tiles only; larger layouts otherwise fall back to the fp32-instruction k_node<H, 32 / 64, SAVE>)
+    if (fwd_half && opt_of(h, "train_node16", 1) != 0) a.node_mt = 16;
     const bool node_half = fwd_half && a.node_mt == 16 && t->n_half16 > 0 && opt_of(h, "train_half", 1) != 2;
     if (node_half) tr_repack_half16(theta, t->half16_tab, t->n_half16, t->max_half16, s);
     HIPCHK(h, hipEventSynchronize(t->tot_ev));

@@ -448,10 +448,12 @@ def test_training_gradient_at_bench_size_both_engines():
         assert float((a - b).abs().max()) <= GRAD_TOL * max(float(b.abs().max()), 1e-6), name
 
 
-def test_staged_backward_equals_single_pass():
+@pytest.mark.parametrize('S,agg', [(1, 'sum'), (2, 'mean')])
+def test_staged_backward_equals_single_pass(S, agg):
     """cmdgen_train_backward_stages (what the overlapped all-reduce drives) over any split of the stages 0..L+1 leaves
-    the same flat gradient as the single call, and the chunks HipTrainer reduces are final when their stage is done."""
-    model, tr, data, g6 = build_trainer()
+    the same flat gradient as the single call, and the chunks HipTrainer reduces are final when their stage is done
+    (a stage is a BLOCK: with inv_sublayers > 1 it holds several GCLs)."""
+    model, tr, data, g6 = build_trainer(inv_sublayers=S, aggregation_method=agg)
     t_int, eps = torch.from_numpy(g6['t_int']).cuda(), [torch.from_numpy(g6['eps0']).cuda()]
     tr.loss_and_grad(data, t_int=t_int, eps=eps)
     whole = tr.grad.clone()
@@ -838,3 +840,54 @@ def test_training_options_at_width_256_agree_across_engines(S, agg):
         assert float((a - b).abs().max()) <= GRAD_TOL * max(float(b.abs().max()), 1e-6), name
         n += 1
     assert n == 20 + 10 * S * 2 + 5 * 2
+
+
+def test_staged_backward_with_the_second_stream_at_width_256():
+    """H = 256: the weight gradients run on the handle's second stream and every staged call joins it - any split of the stages leaves the
+    single call's gradient (the rotating buffers carry over between calls: GCL k of the pass uses the same ones whichever call runs it)."""
+    import importlib.util, os
+    from argparse import Namespace
+    from cmdgen_amd.lightning_modules import PharPocketDDPM
+    from cmdgen_amd.training import HipTrainer
+    spec = importlib.util.spec_from_file_location('bench_train', os.path.join(os.path.dirname(__file__), '..', 'tools', 'bench_train.py'))
+    bt = importlib.util.module_from_spec(spec); spec.loader.exec_module(bt)
+    L = 3
+    cfg = ModelConfig(n_layers=L)
+    hp = dict(outdir='out', dataset='crossdock', datadir='data', batch_size=16, lr=1e-3,
+              egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=256, n_layers=L, attention=True, tanh=True,
+                                    norm_constant=1, inv_sublayers=1, sin_embedding=False, aggregation_method='sum', normalization_factor=100),
+              diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2', diffusion_noise_precision=1e-5,
+                                         diffusion_loss_type='l2', normalize_factors=[1, 4]),
+              num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
+              eval_params=Namespace(n_eval_samples=100, eval_batch_size=100), mode='pocket_conditioning',
+              node_histogram=np.ones((30, 500)), pocket_representation='CA')
+    model = PharPocketDDPM(**hp)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed=0).items()}, strict=True)
+    tr = HipTrainer(model.cuda())
+    batch = bt.synthetic_batch(16, 7100, torch.device('cuda', 0))
+    gen = torch.Generator().manual_seed(13)
+    t_int = torch.randint(0, 501, (16, 1), generator=gen).float()
+    eps = [torch.randn((int(batch['num_phar_atoms'].sum()), 11), generator=gen).cuda()]
+    seen = {}
+    orig = tr.h.train_backward
+
+    def rec(d_eps, grad, d_eps_q=None):
+        seen['d_eps'] = d_eps.clone()
+        return orig(d_eps, grad, d_eps_q)
+    tr.h.train_backward = rec
+    tr.loss_and_grad(batch, t_int=t_int, eps=eps)
+    tr.h.train_backward = orig
+    whole = tr.grad.clone()
+    assert tr.h.get_option('wgrad_stream') is None          # not set: the default, second stream on
+    for split in ([(0, 0), (1, L), (L + 1, L + 1)], [(s, s) for s in range(L + 2)], [(0, 1), (2, L + 1)]):
+        tr.grad.zero_()
+        for first, last in split:
+            tr.h.train_backward_stages(seen['d_eps'], tr.grad, first, last)
+        torch.cuda.synchronize()
+        assert torch.allclose(tr.grad, whole, rtol=0, atol=2e-6 * float(whole.abs().max())), split
+    # and the serial pass (option wgrad_stream = 0) agrees with the two-stream one
+    tr.h.set_option('wgrad_stream', 0)
+    tr.grad.zero_()
+    tr.h.train_backward(seen['d_eps'], tr.grad)
+    torch.cuda.synchronize()
+    assert torch.allclose(tr.grad, whole, rtol=0, atol=2e-6 * float(whole.abs().max()))
