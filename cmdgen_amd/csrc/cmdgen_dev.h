@@ -201,8 +201,9 @@ struct TrainSave {              // activation store of the TRAINING forward (cmd
 };
 
 struct TrainTune {              // launch choices of the training step's gradient kernels (cmdgen_set_option; defaults from sweeps on MI355X)
-    int wgrad_split = -1;       // weight gradients as three-piece split products: -1 = by shape (K >= 32k rows on 128 x 128 tiles), 0 = never, 1 = wherever the shape allows
+    int wgrad_split = -1;       // weight gradients as three-piece split products: -1 = wherever the handle runs the split engine (tile by wgrad_k128), 0 = never (fp32 instruction), 1 = always on 128 x 128 tiles where the shape allows
     int wgrad_tile = 0;         // 64: never the 128 x 128-tile kernel
+    int wgrad_k128 = 131072;    // rows x 128-tiles of a launch from which a three-piece weight gradient uses 128 x 128 tiles (below: 64 x 64)
     int wgrad_split_wgs128 = 384, wgrad_split_wgs64 = 512;   // workgroups the split-K factor of the two split kernels aims at
     int wgrad_wgs = 768;        // ... of the fp32-instruction kernel (3 workgroups of 49 KB LDS per CU; profiles/r02_t3_training_round2.txt)
     int dgrad_mt = 0;           // rows per tile of the data-gradient kernel: 0 = by row count (64 from 24576 rows), 32, 64

@@ -599,9 +599,16 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bo
             ok128 = ok128 && g.M[p] % 128 == 0 && g.N[p] % 128 == 0;
         }
         ok128 = ok128 && ok64;
-        const bool three = !bf16 && (force3 || (split3 && (env3 == 1 || (env3 != 0 && ok128 && K >= 32768))));
+        // Round 5: the weight gradients run BESIDE the chain of data gradients (cmdgen_train.hip), where the fp32 instruction's long hold on the
+        // matrix pipe costs the other stream more than its own launch gains: three pieces whenever the handle is on the split engine, 64 x 64
+        // tiles for short products and 128 x 128 from TrainTune::wgrad_k128 rows (same-box sweeps with both streams running: profiles/r05_an, r05_ao)
+        // (the 128-tile kernel splits K over wgrad_split_wgs128 / tiles workgroups: it pays once a workgroup's share is ~500 rows, i.e. from
+        // K x tiles >= TrainTune::wgrad_k128 - a 4-product node-level group at 15k rows, a single product from 49k)
+        long tiles128 = 0;
+        for (int p = 0; p < g.n; ++p) tiles128 += (long)(g.M[p] / 128) * (g.N[p] / 128);
+        const bool three = !bf16 && (force3 || (split3 && env3 != 0 && ok64));
         const bool sp = ok64 && (bf16 || three);
-        const bool sp128 = sp && ok128 && (force3 || env3 == 1 || K >= (bf16 ? 65536 : 32768));
+        const bool sp128 = sp && ok128 && (force3 || env3 == 1 || (bf16 ? K >= 65536 : (long)K * tiles128 >= (long)g_train_tune.wgrad_k128));
         if (sp128) {
             int tm = 1, tn = 1, tiles = 0;
             for (int p = 0; p < g.n; ++p) { tm = max(tm, g.M[p] / 128); tn = max(tn, g.N[p] / 128); tiles += (g.M[p] / 128) * (g.N[p] / 128); }
