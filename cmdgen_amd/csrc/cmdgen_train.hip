@@ -33,7 +33,7 @@ void cmdgen_dgrad_split_h(int M, const float* A0, HalfW W0, const float* A1, Hal
 void cmdgen_dgrad_tail_h(int E, const float* dY, HalfW Wt, const float* pre1, const int* row, const int* col, const float* d0,
                          const float* Wcol, int ldw, const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ,
                          float* dX, float* scratch, hipStream_t s);
-void tr_repack_half(const float* theta, const void* tab, int n, hipStream_t s);
+void tr_repack_half(const float* theta, const void* tab, int n_plain, int n, hipStream_t s);
 struct RepackHalf16 { int src_off, ld, out, in, row_split, col_shift; void* dst; float* sc; };            // kernels_train.hip
 void tr_repack_half16(const float* theta, const void* tab, int n, int max8, hipStream_t s);
 void cmdgen_dgrad_split(int M, const float* A0, const void* W0, const float* A1, const void* W1, float* Y, bool accumulate, float div,
@@ -473,19 +473,20 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     // The forward pass IS the sampler's fused evaluation (k_embed, then per block k_edge_msg / k_node / k_edge_coord, then
     // k_readout) with save hooks that keep what the backward pass reads (TrainSave): ~20 launches instead of ~190, GEMMs on
     // the fragment-streaming tile kernels.  The parameters the optimizer has just updated are re-packed on the device.
-    tr_repack(theta, t->frag_tab, t->n_frag, t->max_frag4, t->misc_tab, t->n_misc, t->max_misc, s);
-    if (h->gemm_split || t->bf16) tr_repack_split_t(theta, t->split_tab, t->n_split, s);        // data gradients (and the forward's two
-    t->split_packs_valid = (h->gemm_split || t->bf16) && t->n_split > 0;                         // edge kernels) on the bf16 matrix pipe
     // the forward's two edge kernels on the half engine (two fp16 pieces, three MFMAs per product: cmdgen_split.h) wherever the sampler would use it
     const bool fwd_half = h->gemm_split && H == 256 && a.half_engine && a.edge_fullk && t->n_half > 0 && opt_of(h, "train_half", 1) != 0;
     const bool dgrad_half = fwd_half && !t->bf16 && opt_of(h, "dgrad_half", 0) != 0;      // (built, parity-green, not faster: profiles/r05_ag)
-    if (fwd_half) tr_repack_half(theta, t->half_tab, dgrad_half ? t->n_half : t->n_half_fwd, s);
-    t->half_packs_valid = dgrad_half;
-    // ... and the node kernel as the sampler's eight-wave 16-row tile (k_node16w) where 16-row tiles are what the layout gets
+    // ... and the node kernel as the sampler's eight-wave 16-row tile (k_node16w)
     // (option train_node16: 16-row tiles for the node kernel at EVERY size - the save-hook form of the node kernel exists on the half engine
     // for these tiles only; larger layouts otherwise fall back to the fp32-instruction k_node<H, 32 / 64, SAVE>)
     if (fwd_half && opt_of(h, "train_node16", 1) != 0) a.node_mt = 16;
     const bool node_half = fwd_half && a.node_mt == 16 && t->n_half16 > 0 && opt_of(h, "train_half", 1) != 2;
+    // fp32 fragment packs: with every tile kernel on the half engine only k_embed reads one (block 0's P | Q projection: the table's first entry)
+    tr_repack(theta, t->frag_tab, (fwd_half && node_half) ? 1 : t->n_frag, t->max_frag4, t->misc_tab, t->n_misc, t->max_misc, s);
+    if (h->gemm_split || t->bf16) tr_repack_split_t(theta, t->split_tab, t->n_split, s);        // data gradients (and the forward's two
+    t->split_packs_valid = (h->gemm_split || t->bf16) && t->n_split > 0;                         // edge kernels) on the bf16 matrix pipe
+    if (fwd_half) tr_repack_half(theta, t->half_tab, t->n_half_fwd, dgrad_half ? t->n_half : t->n_half_fwd, s);
+    t->half_packs_valid = dgrad_half;
     if (node_half) tr_repack_half16(theta, t->half16_tab, t->n_half16, t->max_half16, s);
     HIPCHK(h, hipEventSynchronize(t->tot_ev));
     const int E = t->h_tot[0], Ec = t->h_tot[1];

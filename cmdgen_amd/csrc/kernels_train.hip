@@ -1013,6 +1013,7 @@ void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s
 // and sc = {2^e, 2^-e} left beside the pack for the kernel's epilogue (WPack::wh_dev).  One workgroup of 1024 threads per 256 x 256 matrix:
 // the 64 weights a thread packs stay in its registers between the maximum and the split.
 struct RepackHalf { int src_off, ld; void* dst; float* sc; int transpose; };     // transpose: the pack of W^T (data gradients: dX = dY W)
+template <bool TR>      // TR: the entries are transposed blocks (a strided gather; its own instantiation: sharing one cost the plain packs 20 us per step)
 __global__ __launch_bounds__(1024) void k_repack_half(const float* __restrict__ theta, const RepackHalf* __restrict__ tab) {
     const RepackHalf f = tab[blockIdx.x];
     __shared__ float red[16];
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(1024) void k_repack_half(const float* __restrict__ 
         const int idx = q * 1024 + tid;                                // (nt * 16 + kb) * 64 + lane, nt < 8, kb < 16
         const int lane = idx & 63, kb = (idx >> 6) & 15, nt = idx >> 10;
         const int o = 32 * nt + (lane & 31), k = 16 * kb + 8 * (lane >> 5);
-        if (f.transpose) {                                             // Wt[o][k] = W[k][o]
+        if constexpr (TR) {                                            // Wt[o][k] = W[k][o]
             const float* src = theta + f.src_off + (size_t)k * f.ld + o;
             va[q] = make_float4(src[0], src[(size_t)f.ld], src[2 * (size_t)f.ld], src[3 * (size_t)f.ld]);
             vb[q] = make_float4(src[4 * (size_t)f.ld], src[5 * (size_t)f.ld], src[6 * (size_t)f.ld], src[7 * (size_t)f.ld]);
@@ -1059,8 +1060,10 @@ __global__ __launch_bounds__(1024) void k_repack_half(const float* __restrict__ 
         d[0] = p0.u; d[64] = p1.u;
     }
 }
-void tr_repack_half(const float* theta, const void* tab, int n, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_repack_half, dim3(n), dim3(1024), 0, s, theta, (const RepackHalf*)tab);
+// entries [0, n_plain) are packs of W itself, [n_plain, n) of transposed blocks (the table's order, cmdgen_train.hip)
+void tr_repack_half(const float* theta, const void* tab, int n_plain, int n, hipStream_t s) {
+    if (n_plain) hipLaunchKernelGGL(k_repack_half<false>, dim3(n_plain), dim3(1024), 0, s, theta, (const RepackHalf*)tab);
+    if (n > n_plain) hipLaunchKernelGGL(k_repack_half<true>, dim3(n - n_plain), dim3(1024), 0, s, theta, (const RepackHalf*)tab + n_plain);
 }
 // The same for the node kernel of the training forward (k_node16w<true>): the 16-row half packs (v_mfma_f32_16x16x32_f16 fragment order,
 // the layout of pack_half16, cmdgen_api.hip) of node_mlp.0 [H][2H], node_mlp.2 [H][H] and the stacked projections [2H][H] of coord_mlp.0 /
@@ -1077,9 +1080,12 @@ __global__ __launch_bounds__(1024) void k_wmax16(const float* __restrict__ theta
     __shared__ float red[16];
     const int tid = threadIdx.x, n4 = f.out * f.in / 4, k4 = f.in / 4;
     float mx = 0.f;
+    const int sh = 31 - __clz(k4);                                      // in is 256 or 512: k4 a power of two (no integer division per element)
+#pragma unroll 4
     for (int i = tid; i < n4; i += 1024) {
-        const float* src = rh16_src(theta, f, i / k4, 4 * (i % k4));
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(src[0]), fabsf(src[1])), fmaxf(fabsf(src[2]), fabsf(src[3]))));
+        const float2* src = reinterpret_cast<const float2*>(rh16_src(theta, f, i >> sh, 4 * (i & (k4 - 1))));      // (every tensor starts 16-byte aligned, rows are an even number of floats)
+        const float2 a = src[0], b = src[1];
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(b.x), fabsf(b.y))));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
