@@ -61,6 +61,9 @@ struct CoordOutArgs { const int* row; const int* col; const float4* X; const flo
 void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
                  float* zero, size_t zero_floats, hipStream_t s, bool defer_reduce = false, const CoordOutArgs* co = nullptr);
 void tr_colsum(int E, int H, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s);
+struct SmallWgrad { const float* dy; const float* x; float* dw; float* db; int M, N, K, lddy, ldx, ldw; };      // kernels_train.hip: k_small_wgrads
+bool cmdgen_small_wgrads_fit(int M, int N);
+void cmdgen_small_wgrads(const SmallWgrad* probs, int n, hipStream_t s);
 void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s);
 void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, float* ddec, hipStream_t s);
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
@@ -158,7 +161,7 @@ struct TrainState {
     // dP | dQ separately for the coordinate and the message list, dn by block parity, dh between the two sides of the node model.
     int* h_tot = nullptr; hipEvent_t tot_ev = nullptr;          // pinned landing place of the list lengths and the event behind their copy (cmdgen_train_forward)
     hipStream_t ws = nullptr, ws_low = nullptr;      // (ws_low: the same at the device's lowest stream priority, wgrad_stream = 2)
-    std::vector<hipEvent_t> evs;
+    std::vector<hipEvent_t> evs, evs2;
     float *part_x[4] = {nullptr, nullptr, nullptr, nullptr}, *tail_x[4] = {nullptr, nullptr, nullptr, nullptr};
     float *actA2 = nullptr, *actB2 = nullptr, *dPx[3] = {nullptr, nullptr, nullptr}, *dn2 = nullptr, *dh2 = nullptr, *dh3 = nullptr;
     // the fused forward (the sampler's evaluation kernels with save hooks): per-step packed copies of the parameters
@@ -181,6 +184,7 @@ void cmdgen_train_free(TrainState* t) {
     if (!t) return;
     free_pool(t->node_allocs); free_pool(t->edge_allocs); free_pool(t->pack_allocs);
     for (hipEvent_t e : t->evs) hipEventDestroy(e);
+    for (hipEvent_t e : t->evs2) hipEventDestroy(e);
     if (t->h_tot) hipHostFree(t->h_tot);
     if (t->tot_ev) hipEventDestroy(t->tot_ev);
     if (t->ws) hipStreamDestroy(t->ws);
@@ -640,10 +644,30 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = r.in;
         defer([=](hipStream_t q) { cmdgen_wgrad_group(one, K, bf, q, w3); });
     };
-    // small weight + bias gradient of one Linear of the readout / embedding stages
+    // small weight + bias gradients of the readout / embedding stages (encoders, decoders, the two embeddings): collected and launched as ONE
+    // kernel per stage (k_small_wgrads; as a k_sgemm + k_colsum pair per Linear they were the serial tail of the pass)
+    std::vector<SmallWgrad> small;
+    SideStream ss3{s, t->ws_low, ss.on && t->ws_low != nullptr && side != t->ws_low, &t->evs2};      // a third stream for the embedding stage's small gradients
+    bool tail_stage = false;
     auto small_wgrad = [&](const PRef& r, int in, int M, const float* dy, int lddy, const float* x, int ldx) {
+        if (M <= 0) return;
+        if (cmdgen_small_wgrads_fit(r.out, in) && opt_of(h, "small_wgrads", 0) != 0 && small.size() < 8) {       // (one kernel for all of them: built, and slower - the same-address atomics of hundreds of workgroups; profiles/r05_ar)
+            small.push_back(SmallWgrad{dy, x, grad + r.w, r.has_bias ? grad + r.b : nullptr, r.out, in, M, lddy, ldx, r.in});
+            return;
+        }
         const PRef* rp = &r;
+        if (tail_stage && ss3.on) {     // the pass's last stage: nothing follows to hide a serial tail - every pair starts as soon as its input exists, on a stream of its own
+            hipStream_t q = ss3.fork();
+            linear_wgrad(grad, *rp, 0, in, M, dy, lddy, x, ldx, q); tr_colsum(M, rp->out, dy, lddy, nullptr, grad + rp->b, 1, q);
+            return;
+        }
         defer([=](hipStream_t q) { g_bf16 = bf; linear_wgrad(grad, *rp, 0, in, M, dy, lddy, x, ldx, q); tr_colsum(M, rp->out, dy, lddy, nullptr, grad + rp->b, 1, q); });
+    };
+    auto flush_small = [&]() {
+        if (small.empty()) return;
+        const std::vector<SmallWgrad> batch = small;
+        small.clear();
+        defer([=](hipStream_t q) { cmdgen_small_wgrads(batch.data(), (int)batch.size(), q); });
     };
     (void)bias_grad;
     // rotating buffers (side stream on): block k of the pass (k = 0 for block L-1) reads dL/dh_{l+1} in dhb[k % 3] and leaves dL/dh_l in
@@ -674,6 +698,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     linear_dgrad(theta, tb.pd0, 0, J, Nl, t->ddeca, 2 * P, t->dhfin, d.dyn, false, s);
     small_wgrad(tb.embo, H, N, t->dhfin, d.dyn, t->h + (size_t)L * d.S * NH, H);
     linear_dgrad(theta, tb.embo, 0, H, N, t->dhfin, d.dyn, dh0, H, false, s);
+    flush_small();
     flush_side();           // (none of what these read is written again in this pass)
     }
     const int S = d.S, U = L * S;
@@ -797,6 +822,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     }
     if (last_stage < L + 1) { ss.join(); HIPCHK(h, hipGetLastError()); return CMDGEN_OK; }
     // embedding and encoders
+    tail_stage = true;
     float* dhE = dhb[(L * d.S) % 3];
     small_wgrad(tb.emb, d.dyn, N, dhE, H, t->hdyn, d.dyn);
     linear_dgrad(theta, tb.emb, 0, d.dyn, N, dhE, H, t->dhdyn, d.dyn, false, s);
@@ -809,7 +835,9 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     linear_dgrad(theta, tb.re2, 0, 2 * R, Np, dq, d.dyn, t->denca_p, 2 * R, false, s);
     tr_silu_bwd(t->denca_p, t->enc1_p, (size_t)Np * 2 * R, s);
     small_wgrad(tb.re0, R, Np, t->denca_p, 2 * R, t->xh_pocket + 3, ldq);
+    flush_small();
     flush_side();
+    ss3.join();
     ss.join();
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;

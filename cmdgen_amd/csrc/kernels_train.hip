@@ -1707,6 +1707,83 @@ __global__ __launch_bounds__(256) void k_tail_colsum_reduce(int nwg, int H, cons
     if (part == 0 && c < H) atomicAdd(dWcol + which + (size_t)c * ldw, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
+// ------------------------------------------------------------------------------------
+// k_small_wgrads: the weight AND bias gradients of up to eight SMALL Linears (encoders, decoders, the two embeddings: at most 256 x 40
+// weights, different row counts) in ONE launch: dW_p[M][N] += dY_p^T X_p, db_p[M] += column sums of dY_p.  As ten k_sgemm / k_colsum launches
+// of 5-15 us each they were the tail of the backward pass (profiles/r05_aq_train_chain.txt: 110 us on the side stream after the main
+// stream's last kernel).  A workgroup takes 128 rows of one problem in sub-chunks of 32 staged in LDS; thread m owns row m of dW in
+// registers and adds it once with atomics; any leading dimensions / alignment (scalar loads).
+// ------------------------------------------------------------------------------------
+struct SmallWgrad { const float* dy; const float* x; float* dw; float* db; int M, N, K, lddy, ldx, ldw; };
+struct SmallWgradBatch { SmallWgrad p[8]; int n; int first_wg[9]; };      // first_wg: prefix sums of ceil(K_p / SW_ROWS)
+constexpr int SW_ROWS = 32, SW_SUB = 32, SW_MAXM = 256, SW_MAXN = 40;       // (one sub-chunk per workgroup: every load of a workgroup is in flight at once)
+__global__ __launch_bounds__(256) void k_small_wgrads(SmallWgradBatch b) {
+    // thread m owns row m of dW (N <= 40 accumulators in registers): per k one conflict-free read of dY[k][m] and N / 4 broadcast reads of X[k][:]
+    __shared__ float sdy[SW_SUB][SW_MAXM];
+    __shared__ __attribute__((aligned(16))) float sx[SW_SUB][SW_MAXN];
+    // (the problem is picked with selects: indexing the by-value argument with a run-time index would put the whole table in scratch)
+    SmallWgrad P = b.p[0];
+    int wg0 = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < b.n && (int)blockIdx.x >= b.first_wg[i]) { P = b.p[i]; wg0 = b.first_wg[i]; }
+    const int M = P.M, N = P.N, tid = threadIdx.x;
+    const int k_begin = ((int)blockIdx.x - wg0) * SW_ROWS, k_end = min(P.K, k_begin + SW_ROWS);
+    float acc[SW_MAXN], bacc = 0.f;
+#pragma unroll
+    for (int n = 0; n < SW_MAXN; ++n) acc[n] = 0.f;
+    const int n4 = (N + 3) / 4;
+    for (int k0 = k_begin; k0 < k_end; k0 += SW_SUB) {
+        const int kn = min(SW_SUB, k_end - k0);
+        {   // all loads of the sub-chunk first (registers), then the LDS stores: one round trip, not one per unrolled group
+            float rdy[SW_SUB], rx[SW_SUB];
+#pragma unroll
+            for (int k = 0; k < SW_SUB; ++k) {
+                rdy[k] = (tid < M && k < kn) ? P.dy[(size_t)(k0 + k) * P.lddy + tid] : 0.f;
+                rx[k] = (tid < N && k < kn) ? P.x[(size_t)(k0 + k) * P.ldx + tid] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < SW_SUB; ++k) {
+                if (tid < M) sdy[k][tid] = rdy[k];
+                if (tid < SW_MAXN) sx[k][tid] = rx[k];
+            }
+        }
+        __syncthreads();
+        if (tid < M) {
+#pragma unroll 4
+            for (int k = 0; k < SW_SUB; ++k) {
+                const float a = sdy[k][tid];
+                bacc += a;
+#pragma unroll
+                for (int j = 0; j < SW_MAXN / 4; ++j) {
+                    if (j < n4) {                                    // wave-uniform
+                        const float4 xv = *reinterpret_cast<const float4*>(&sx[k][4 * j]);
+                        acc[4 * j] = __fmaf_rn(a, xv.x, acc[4 * j]); acc[4 * j + 1] = __fmaf_rn(a, xv.y, acc[4 * j + 1]);
+                        acc[4 * j + 2] = __fmaf_rn(a, xv.z, acc[4 * j + 2]); acc[4 * j + 3] = __fmaf_rn(a, xv.w, acc[4 * j + 3]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < M) {
+#pragma unroll
+        for (int n = 0; n < SW_MAXN; ++n) if (n < N) atomicAdd(P.dw + (size_t)tid * P.ldw + n, acc[n]);
+        if (P.db) atomicAdd(P.db + tid, bacc);
+    }
+}
+bool cmdgen_small_wgrads_fit(int M, int N) { return M <= SW_MAXM && N <= SW_MAXN; }
+void cmdgen_small_wgrads(const SmallWgrad* probs, int n, hipStream_t s) {
+    SmallWgradBatch b; b.n = 0; b.first_wg[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (probs[i].K <= 0) continue;
+        b.p[b.n] = probs[i];
+        b.first_wg[b.n + 1] = b.first_wg[b.n] + (probs[i].K + SW_ROWS - 1) / SW_ROWS;
+        ++b.n;
+    }
+    if (b.n) hipLaunchKernelGGL(k_small_wgrads, dim3(b.first_wg[b.n]), dim3(256), 0, s, b);
+}
+
 // out[c * ldo] += sum_e s[e] * X[e][c]   (s may be null = 1): bias gradients, radial / d0 column gradients, att and
 // coordinate-head weight gradients.  One workgroup per 256-row chunk, one column per thread (coalesced rows).
 __global__ void k_colsum(int E, int ncols, const float* __restrict__ X, int ldx, const float* __restrict__ s,
