@@ -23,3 +23,6 @@ print(f'B {B}: {wgs} sampled workgroups over {steps} steps')
 for i, nm in enumerate(names):
     print(f'  {nm:44s}', [round(s[w * 8 + i] / wgs) for w in range(4)])
 print('  lifetime', [round(s[32 + w] / wgs) for w in range(4)])
+# (slots 44..47 are filled only with profiles/r05_ay_tail_gemm_stamps.patch applied: stamps inside dgrad_tile_gemm)
+if any(s[44:48]):
+    print('  inside the GEMM phase (wave 0): rows wait + split + barrier / GEMM, stage 0:', round(s[44] / wgs), '/', round(s[45] / wgs), ' stage 1:', round(s[46] / wgs), '/', round(s[47] / wgs))
