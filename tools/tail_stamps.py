@@ -10,6 +10,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 dev = torch.device('cuda:0')
 cfg, model, tr = bt.build_trainer(B, 'CA', 'fp32', dev)
 batches = [bt.synthetic_batch(B, B * i, dev) for i in range(2)]
+if os.environ.get('TAIL_LR0'):      # diagnostic libraries with deliberately wrong arithmetic: keep the parameters (and with them the lists) where they are
+    tr.lr = 0.0
 for i in range(3): tr.training_step(batches[i % 2])
 torch.cuda.synchronize()
 tr.h.debug_stamps(True)
