@@ -891,3 +891,45 @@ def test_staged_backward_with_the_second_stream_at_width_256():
     tr.h.train_backward(seen['d_eps'], tr.grad)
     torch.cuda.synchronize()
     assert torch.allclose(tr.grad, whole, rtol=0, atol=2e-6 * float(whole.abs().max()))
+
+
+@pytest.mark.parametrize('opts', [{'wgrad_silu': 3}, {'wgrad_stream': 0, 'train_half': 0}, {'wgrad_split': 0}, {'dgrad_half': 1}, {'small_wgrads': 1}, {'train_node16': 0}, {'wgrad_k128': 1}])
+def test_training_step_options_leave_the_gradient_where_it_is(opts):
+    """Every launch choice of the round-5 training step (cmdgen_set_option) against the default on the width the fast kernels exist for:
+    SiLU recomputed by the second-layer weight gradients, the serial pass without the half-engine forward, weight gradients on the fp32
+    instruction, half-engine data gradients, one kernel for the small gradients, the generic node tiles, 128 x 128 weight-gradient tiles
+    everywhere - the same loss and, tensor by tensor, the same gradient to GRAD_TOL of its scale."""
+    import importlib.util, os
+    from argparse import Namespace
+    from cmdgen_amd.lightning_modules import PharPocketDDPM
+    from cmdgen_amd.training import HipTrainer
+    spec = importlib.util.spec_from_file_location('bench_train', os.path.join(os.path.dirname(__file__), '..', 'tools', 'bench_train.py'))
+    bt = importlib.util.module_from_spec(spec); spec.loader.exec_module(bt)
+    L = 2
+    cfg = ModelConfig(n_layers=L)
+    hp = dict(outdir='out', dataset='crossdock', datadir='data', batch_size=24, lr=1e-3,
+              egnn_params=Namespace(device='cuda', edge_cutoff=6.0, joint_nf=32, hidden_nf=256, n_layers=L, attention=True, tanh=True,
+                                    norm_constant=1, inv_sublayers=1, sin_embedding=False, aggregation_method='sum', normalization_factor=100),
+              diffusion_params=Namespace(diffusion_steps=500, diffusion_noise_schedule='polynomial_2', diffusion_noise_precision=1e-5,
+                                         diffusion_loss_type='l2', normalize_factors=[1, 4]),
+              num_workers=0, augment_noise=0, augment_rotation=False, clip_grad=True, eval_epochs=50,
+              eval_params=Namespace(n_eval_samples=100, eval_batch_size=100), mode='pocket_conditioning',
+              node_histogram=np.ones((30, 500)), pocket_representation='CA')
+    model = PharPocketDDPM(**hp)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed=0).items()}, strict=True)
+    tr = HipTrainer(model.cuda())
+    batch = bt.synthetic_batch(24, 7300, torch.device('cuda', 0))
+    gen = torch.Generator().manual_seed(14)
+    t_int = torch.randint(0, 501, (24, 1), generator=gen).float()
+    eps = [torch.randn((int(batch['num_phar_atoms'].sum()), 11), generator=gen).cuda()]
+    loss_a, _, _ = tr.loss_and_grad(batch, t_int=t_int, eps=eps)
+    grad_a = tr.grad.clone()
+    for k, v in opts.items():
+        tr.h.set_option(k, v)
+    loss_b, _, _ = tr.loss_and_grad(batch, t_int=t_int, eps=eps)
+    grad_b = tr.grad.clone()
+    assert abs(float(loss_a) - float(loss_b)) <= 2e-6 * max(1.0, abs(float(loss_a)))
+    for name, p in tr.dyn.named_parameters():
+        off, cnt = tr.h.param_offset(name)
+        a, b = grad_a[off:off + cnt], grad_b[off:off + cnt]
+        assert float((a - b).abs().max()) <= GRAD_TOL * max(float(a.abs().max()), 1e-6), (name, opts)
