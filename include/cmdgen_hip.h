@@ -253,15 +253,20 @@ int cmdgen_param_offset(cmdgen_handle* h, const char* name, int64_t* offset, int
 /* EGNNDynamics.forward (dynamics.py:75-139) on the parameters `theta`, keeping every activation the backward
  * pass needs (after cmdgen_set_layout; no cmdgen_finalize_weights needed).  t dev [batch].  Writes
  * eps_phar dev [Nl, 3+phar_nf] and, when non-NULL, eps_pocket dev [Np, 3+residue_nf] (required for the joint model,
- * config.update_pocket_coords = 1; the conditional loss never uses it).  Synchronises the stream once (the edge count
- * sizes the activation store). */
+ * config.update_pocket_coords = 1; the conditional loss never uses it).  Waits once for the host copy of the two list lengths (they
+ * size the activation store and the grids; the parameter re-packs are queued behind that copy, so the device keeps working while the
+ * host wakes up). */
 int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const float* xh_phar, const float* xh_pocket,
                          const float* t, float* eps_phar, float* eps_pocket, cmdgen_stream stream);
 
 /* Backward of the last cmdgen_train_forward: given dL/d eps_phar (dev [Nl, 3+phar_nf]) and optionally
  * dL/d eps_pocket (dev [Np, 3+residue_nf], NULL = zero) ADDS dL/d theta into
  * `grad` (dev, same layout as theta; zero it first for a fresh gradient).  What autograd does for
- * loss.backward() in the reference's training_step (lightning_modules.py:245-260). */
+ * loss.backward() in the reference's training_step (lightning_modules.py:245-260).
+ * Streams: the pass queues its weight / bias gradients on streams of the handle beside the chain of data gradients it queues on `stream`
+ * (option "wgrad_stream"); before the call returns, `stream` has been made to wait for all of them - work queued on `stream` after the
+ * call (the optimizer, an all-reduce ordered behind `stream`) sees the complete gradient, exactly as if everything had run on `stream`.
+ * Gradients are accumulated with float atomics: equal run to run up to the order of those sums. */
 int cmdgen_train_backward(cmdgen_handle* h, const float* d_eps_phar, const float* d_eps_pocket, float* grad,
                           cmdgen_stream stream);
 
