@@ -66,6 +66,7 @@ bool cmdgen_small_wgrads_fit(int M, int N);
 void cmdgen_small_wgrads(const SmallWgrad* probs, int n, hipStream_t s);
 void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s);
 void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, float* ddec, hipStream_t s);
+void tr_bwd_init(int Nl, int N, int P, int dyn, const float* deps, float* dX, float* ddec, float* dhfin, hipStream_t s);
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
               float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s, const float* sqnorm = nullptr,
               float max_norm = 0.f);
@@ -606,7 +607,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     const Work& w = h->work;
     const ParamTable& tb = t->tab;
     const size_t NH = (size_t)N * H;
-    const bool w3 = h->gemm_split;                                    // (three-piece weight gradients: opt-in, see cmdgen_wgrad_group)
+    const bool w3 = h->gemm_split;                                    // (three-piece weight gradients wherever the handle runs the split engine: cmdgen_wgrad_group)
     const bool sp = t->split_packs_valid && H == 256;                 // [.,256] x [256,256] data gradients on the bf16 matrix pipe:
     const int pcs = g_bf16 ? 1 : 3;                                   // three pieces per operand (fp32-accurate) or the leading one (bf16 operands)
     const bool tail_fused = sp && g_train_tune.dgrad_tail != 0;
@@ -627,7 +628,6 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         pending.clear();
         return ss.mark();
     };
-    auto bias_grad = [&](const PRef& r, int M, const float* dy, int ld, hipStream_t q) { tr_colsum(M, r.out, dy, ld, nullptr, grad + r.b, 1, q); };
     // node-level weight (and bias) gradients of a block are collected and launched together (cmdgen_wgrad_group)
     WgradBatch wb; wb.n = 0;
     auto defer_wgrad = [&](const PRef& r, int col0, int in, const float* dy, const float* x, bool with_bias) {
@@ -644,8 +644,9 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         one.M[0] = H; one.N[0] = H; one.lddy[0] = H; one.ldx[0] = H; one.ldw[0] = r.in;
         defer([=](hipStream_t q) { cmdgen_wgrad_group(one, K, bf, q, w3); });
     };
-    // small weight + bias gradients of the readout / embedding stages (encoders, decoders, the two embeddings): collected and launched as ONE
-    // kernel per stage (k_small_wgrads; as a k_sgemm + k_colsum pair per Linear they were the serial tail of the pass)
+    // small weight + bias gradients of the readout / embedding stages (encoders, decoders, the two embeddings): a k_sgemm + k_colsum pair per
+    // Linear.  Readout stage: with the side stream's first batch.  Embedding stage (the pass's tail): each pair on a third stream as soon as its
+    // input exists.  (Option small_wgrads: all of a stage's pairs as ONE kernel, k_small_wgrads - built, parity-green, slower.)
     std::vector<SmallWgrad> small;
     SideStream ss3{s, t->ws_low, ss.on && t->ws_low != nullptr && side != t->ws_low, &t->evs2};      // a third stream for the embedding stage's small gradients
     bool tail_stage = false;
@@ -669,7 +670,6 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         small.clear();
         defer([=](hipStream_t q) { cmdgen_small_wgrads(batch.data(), (int)batch.size(), q); });
     };
-    (void)bias_grad;
     // rotating buffers (side stream on): block k of the pass (k = 0 for block L-1) reads dL/dh_{l+1} in dhb[k % 3] and leaves dL/dh_l in
     // dhb[(k + 1) % 3]; dpre2 / dpre7 / dn / the two dP | dQ pairs by the parity of k.  Off: one buffer each, updated in place.
     float* dhb[3] = {t->dh, ss.on ? t->dh2 : t->dh, ss.on ? t->dh3 : t->dh};
@@ -678,9 +678,13 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     if (first_stage == 0) {
     // readout
     float* dh0 = dhb[0];
+    const bool one_init = !d_eps_pocket && !d.joint;          // the conditional model: one launch (k_bwd_init) for the three fills and k_eps_bwd
+    if (one_init) tr_bwd_init(Nl, N, P, d.dyn, d_eps_phar, t->dX, t->ddec, t->dhfin, s);
+    else {
     HIPCHK(h, hipMemsetAsync(t->dX, 0, (size_t)N * 4 * sizeof(float), s));
     tr_eps_bwd(Nl, P, 0, d_eps_phar, t->dX, t->ddec, s);
     HIPCHK(h, hipMemsetAsync(t->dhfin, 0, (size_t)N * d.dyn * sizeof(float), s));
+    }
     if (d_eps_pocket) {     // the pocket output exists in the loss (joint model): velocity rows Nl.. and the residue decoder
         tr_eps_bwd(Np, R, Nl, d_eps_pocket, t->dX, t->dqdec, s);
         small_wgrad(tb.rd2, 2 * R, Np, t->dqdec, R, t->qdeca, 2 * R);
@@ -690,7 +694,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         linear_dgrad(theta, tb.rd0, 0, J, Np, t->dqdeca, 2 * R, t->dhfin + (size_t)Nl * d.dyn, d.dyn, false, s);
     }
     if (d.joint) tr_center_per_sample(h->lay, t->dX, s);      // adjoint of the velocity's mean removal (a symmetric projection)
-    if (!d.joint && Np) HIPCHK(h, hipMemsetAsync(t->dX + (size_t)Nl * 4, 0, (size_t)Np * 4 * sizeof(float), s));   // pocket rows do not move
+    if (!d.joint && Np && !one_init) HIPCHK(h, hipMemsetAsync(t->dX + (size_t)Nl * 4, 0, (size_t)Np * 4 * sizeof(float), s));   // pocket rows do not move
     small_wgrad(tb.pd2, 2 * P, Nl, t->ddec, P, t->deca, 2 * P);
     linear_dgrad(theta, tb.pd2, 0, 2 * P, Nl, t->ddec, P, t->ddeca, 2 * P, false, s);
     tr_silu_bwd(t->ddeca, t->dec1, (size_t)Nl * 2 * P, s);

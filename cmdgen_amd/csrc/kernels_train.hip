@@ -2353,6 +2353,19 @@ void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s) {
 void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, float* ddec, hipStream_t s) {
     if (n_rows) hipLaunchKernelGGL(k_eps_bwd, EW_GRID((size_t)n_rows * (3 + F)), 0, s, n_rows, F, row0, deps, dvel, ddec);
 }
+// start of the conditional model's backward pass in one launch instead of three fills and k_eps_bwd: dX <- the velocity part of d_eps on the phar
+// rows and zero elsewhere (pocket rows do not move), ddec <- its feature part, dhfin <- 0
+__global__ void k_bwd_init(int Nl, int N, int P, int dyn, const float* __restrict__ deps, float* __restrict__ dX, float* __restrict__ ddec,
+                           float* __restrict__ dhfin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * 4) { const int n = i >> 2, k = i & 3; dX[i] = (n < Nl && k < 3) ? deps[(size_t)n * (3 + P) + k] : 0.f; }
+    if (i < Nl * P) { const int n = i / P, k = i - n * P; ddec[i] = deps[(size_t)n * (3 + P) + 3 + k]; }
+    if (i < N * dyn) dhfin[i] = 0.f;
+}
+void tr_bwd_init(int Nl, int N, int P, int dyn, const float* deps, float* dX, float* ddec, float* dhfin, hipStream_t s) {
+    const size_t n = (size_t)N * (dyn > 4 ? dyn : 4) > (size_t)Nl * P ? (size_t)N * (dyn > 4 ? dyn : 4) : (size_t)Nl * P;
+    if (n) hipLaunchKernelGGL(k_bwd_init, EW_GRID(n), 0, s, Nl, N, P, dyn, deps, dX, ddec, dhfin);
+}
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
               float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s, const float* sqnorm = nullptr,
               float max_norm = 0.f) {
