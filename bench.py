@@ -605,6 +605,10 @@ def main(argv=None):
                 'bound': 'mfma', 'kernel': kname[dom],
                 'achieved': achieved, 'peak': per_kernel[dom]['peak'], 'unit': 'TFLOP/s',
                 'frac': per_kernel[dom]['frac'], 'traffic': traffic, 'traffic_note': traffic_note,
+                # which ceiling `peak` / `frac` / `whole_job_frac` are priced on (it follows the dominant kernel's engine; rounds 2-4 used 419.4 TF for every kernel:
+                # `frac_of_six_mfma_ceiling` / `whole_job_frac_of_six_mfma_ceiling` keep that yardstick, `frac_of_fp32_instruction_peak` round 2's)
+                'yardstick': ('2516.6 TF dense 16-bit MFMA / %d MFMAs per fp32 product' % per_kernel[dom]['mfmas_per_fp32_product']) if per_kernel[dom]['mfmas_per_fp32_product'] > 1
+                             else '157.3 TF fp32 MFMA instruction',
                 'flop_per_launch': flop_per_launch, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
                 'units_per_launch': units[dom],
                 # `achieved` is ALGORITHMIC fp32 FLOP/s; `peak` is the ceiling of the pipe the dominant kernel executes on:
@@ -679,6 +683,21 @@ def main(argv=None):
             ts = flat['training_step']
             flat['train_ms_fp32'] = round(ts['fp32_results']['ms_per_step'], 3)
             flat['train_ms_bf16_operands'] = round(ts['bf16_gemm_operands']['ms_per_step'], 3)
+            # the reference DRIVER's own operating points (generate_phars.py:17-24: n_samples 20, num_nodes_phar 3, --timesteps; configs[0]: one pocket,
+            # 8 phar points, 50 steps): small batches, where a step is a chain of 3 + 3 L dependent launches and nothing fills the chip
+            cfg_d = bounded_config(20, 500)
+            sd_d = make_state_dict(cfg_d, seed=0)
+            shapes = {}
+            for tag, (b_d, nl_d, k_d) in (('driver_shape', (20, 3, 500)), ('driver_shape_t50', (20, 3, 50)), ('single_pocket', (1, 8, 50))):
+                r = chain_record(cfg_d, sd_d, make_pockets(b_d, 'CA', n_phar=nl_d), k_d, dev, stream, use_graph, prof_steps=0, gemm=args.gemm, warm_K=16)
+                r['workload'] = (f'{b_d} C-alpha pocket copies x {nl_d} phar points, {k_d} of the T = 500 model\'s steps (generate_phars.py defaults / --timesteps 50; '
+                                 f'BASELINE configs[0] on the GPU)')
+                r['launches_per_step'] = 3 + 3 * cfg_d.n_layers
+                shapes[tag] = r
+                flat[tag + '_us_per_step'] = round(r['us_per_denoising_step'], 1)
+                flat[tag + '_value'] = round(r['value'], 1)
+            flat['launches_per_step'] = 3 + 3 * cfg_d.n_layers
+            flat['driver_shapes'] = shapes
         if not args.no_cpu_baseline and n_gpus == 1:      # timed on rank 0 at N=1 only
             result['cpu_baseline'] = cpu_baseline(cfg, sd, B, rep, args.n_phar, args.cpu_seconds)
             cpu_v = result['cpu_baseline']['value']
@@ -691,6 +710,11 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # the flat scalar records FIRST (right after `workload`): a reader that keeps only the leading short values of `config` still shows them
+        c0 = result['config']
+        lead = [k for k in c0 if k.startswith(('north_star_', 'fullatom_', 'train_ms_', 'gpu_over_cpu', 'driver_shape_', 'single_pocket_', 'launches_per_step'))
+                and not isinstance(c0[k], (dict, list, str))]
+        result['config'] = {'workload': c0['workload'], **{k: c0[k] for k in lead}, **{k: v for k, v in c0.items() if k != 'workload' and k not in lead}}
         print(json.dumps(result))
 
 

@@ -234,6 +234,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int dead_skip = 0;          // 2: every block of a conditional evaluation skips tiles whose new h nobody reads (by hop level); 1: the last block only; 0: off (option "dead_skip")
     mutable int unit = -1;      // weight unit (GCL) of the launches being issued: block l, sub-layer s -> l * S + s; -1: the block index itself (S = 1)
     mutable int skip_pc = 0;    // 1: the unit is not the last GCL of its block - its node kernel projects no P_c | Q_c
+    mutable int frag_launches = 0;   // tile launches of this evaluation that read the fp32 FRAGMENT packs (the generic k_edge_msg / k_node / k_edge_coord forms): the training step re-packs those only when one will run
     mutable int live_thr = 0;   // set around a block's launches when that applies: nodes within this many hops of a moving node are still read
     int save_half = 0;          // with `save`: W2 / W7 (.wh, .wh_dev) carry half packs re-made this step: the two edge kernels run their 32-row full-K half form
     int save_half16 = 0;        // with `save`: W3 / W4 / Wpq_c / Wpq_e (.wh16, .wh_dev) carry 16-row half packs re-made this step: k_node16w<true>

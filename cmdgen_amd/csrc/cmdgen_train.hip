@@ -69,8 +69,9 @@ void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, flo
 void tr_bwd_init(int Nl, int N, int P, int dyn, const float* deps, float* dX, float* ddec, float* dhfin, hipStream_t s);
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
               float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s, const float* sqnorm = nullptr,
-              float max_norm = 0.f);
+              float max_norm = 0.f, int skip_nonfinite = 0);
 void tr_sqsum(size_t n, const float* x, float* out, hipStream_t s);
+void tr_norm_guard(float* sq, const int* nan_flag, hipStream_t s);
 void tr_noise(const Layout& lay, const Dims& d, const float* px, const float* poh, const float* qx, const float* qoh, const float* tab,
               const float* eps, float* z_t, float* xh_pocket, float* klsum, hipStream_t s);
 void tr_noise_joint(const Layout& lay, const Dims& d, const float* px, const float* poh, const float* qx, const float* qoh, const float* tab,
@@ -137,6 +138,7 @@ struct TrainState {
     bool have_forward = false;
     bool split_packs_valid = false;     // the last forward re-packed the transposed split fragments (backward may use them)
     int wsilu = 0;                      // which activations the last forward did NOT store (option wgrad_silu)
+    bool fwd_on_half = false;           // the last forward's tile kernels ran on the half engine (fp16 range: a non-finite gradient after it skips the update)
     bool half_packs_valid = false;      // ... and the half packs (forward edge kernels + the transposed blocks of the data gradients)
     bool bf16 = false;                  // GEMM operands in bf16 (fp32 accumulation); default exact fp32
     const float* theta = nullptr;       // parameters used by the last forward (backward reads the same)
@@ -487,7 +489,8 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     if (fwd_half && opt_of(h, "train_node16", 1) != 0) a.node_mt = 16;
     const bool node_half = fwd_half && a.node_mt == 16 && t->n_half16 > 0 && opt_of(h, "train_half", 1) != 2;
     // fp32 fragment packs: with every tile kernel on the half engine only k_embed reads one (block 0's P | Q projection: the table's first entry)
-    tr_repack(theta, t->frag_tab, (fwd_half && node_half) ? 1 : t->n_frag, t->max_frag4, t->misc_tab, t->n_misc, t->max_misc, s);
+    const bool frag_partial = fwd_half && node_half;
+    tr_repack(theta, t->frag_tab, frag_partial ? 1 : t->n_frag, t->max_frag4, t->misc_tab, t->n_misc, t->max_misc, s);
     if (h->gemm_split || t->bf16) tr_repack_split_t(theta, t->split_tab, t->n_split, s);        // data gradients (and the forward's two
     t->split_packs_valid = (h->gemm_split || t->bf16) && t->n_split > 0;                         // edge kernels) on the bf16 matrix pipe
     if (fwd_half) tr_repack_half(theta, t->half_tab, t->n_half_fwd, dgrad_half ? t->n_half : t->n_half_fwd, s);
@@ -560,9 +563,18 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     }
     a.save_split = (h->gemm_split && t->split_packs_valid && H == 256) ? 1 : 0;
     if (h->agg_dirty) { HIPCHK(h, hipMemsetAsync(h->work.agg, 0, NH * sizeof(float), s)); h->agg_dirty = false; }
+    a.frag_launches = 0;
     cmdgen_launch_eval(a, xh_phar, xh_pocket, t_arr, nullptr, nullptr, eps_phar, eps_pocket, s, nullptr);
     if (!d.joint) cmdgen_launch_nan_fix(a, eps_phar, s);                    // dynamics.py:129-131 (joint: inside k_vel_com)
     cmdgen_launch_save_positions(a, t->X, s);
+    // Only the first fp32 fragment pack was refreshed above when every tile kernel was expected on its half form.  The launchers report what they
+    // actually ran: a generic (fragment-reading) tile launch here would have multiplied with the weights of an earlier step - refuse the step
+    // instead of training on them (the conditions above and in launch_msg_fullk / launch_coord_fullk / cmdgen_launch_node16w must agree).
+    t->fwd_on_half = fwd_half;
+    if (frag_partial && a.frag_launches > 0) {
+        t->have_forward = false;
+        return fail(h, CMDGEN_ESTATE, "internal: %d tile launches of the training forward read fp32 weight fragments this step did not re-pack (set option train_half=0)", a.frag_launches);
+    }
     (void)Np; (void)ldp; (void)ldq; (void)ld1; (void)P; (void)R; (void)J; (void)w;
     HIPCHK(h, hipGetLastError());
     t->have_forward = true;
@@ -965,8 +977,11 @@ extern "C" int cmdgen_adamw_step_clipped(cmdgen_handle* h, float* theta, const f
     tr_sqsum((size_t)n, grad, sq, s);
     const float bias1 = 1.0f - powf(beta1, (float)step), bias2 = 1.0f - powf(beta2, (float)step);
     // the update is queued behind the norm without a host round trip: the clipping coefficient is formed on the device
+    // (after a half-engine forward a non-finite norm skips the update on the device: see k_adamw)
+    const bool guard = h->train && h->train->fwd_on_half;
+    if (guard) tr_norm_guard(sq, (const int*)h->work.nan_flag, s);
     tr_adamw((size_t)n, theta, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bias1, sqrtf(bias2), 1.0f, s,
-             max_grad_norm > 0.f ? sq : nullptr, max_grad_norm);
+             (max_grad_norm > 0.f || guard) ? sq : nullptr, max_grad_norm, guard ? 1 : 0);
     // (the readback state lives in the handle: a later cmdgen_set_layout that outgrows the workspaces frees the training state)
     if (!h->h_norm) { HIPCHK(h, hipHostMalloc((void**)&h->h_norm, sizeof(float), hipHostMallocDefault)); HIPCHK(h, hipEventCreateWithFlags(&h->norm_ev, hipEventDisableTiming)); }
     HIPCHK(h, hipMemcpyAsync(h->h_norm, sq, sizeof(float), hipMemcpyDeviceToHost, s));

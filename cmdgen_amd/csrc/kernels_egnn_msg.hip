@@ -204,6 +204,7 @@ __global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_msg(Layout lay, Work w, 
 template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, int l, hipStream_t s) {
     const size_t shm = a.d.sin ? (size_t)(24 * H + 24 * MT) * sizeof(float) : 0;      // sin_embedding: feature columns + the tile's features (edge_msg_body)
     // training forward: the split engine only where the step re-packs split weights (H = 256: edge_mlp.2 / coord_mlp.2)
+    ++a.frag_launches;
     if (a.save) { TrainSave sv = *a.save; sv.slot = unit_of(a, l); hipLaunchKernelGGL((k_edge_msg<H, MT, true, SP && H == 256>), dim3(a.edge_grid), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, sv, 0); }
     else if (a.pe_start) hipExtLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), shm, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d,
                                                a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);

@@ -188,6 +188,7 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
         if (a.split16 && !a.save && a.layers[unit_of(a, l)].W3.ws16) { launch_node<H, 16, true>(a, l, s); return; }
     }
     const int nt = (a.lay.N + MT - 1) / MT;
+    ++a.frag_launches;
     if (a.save) {
         TrainSave sv = *a.save; sv.slot = unit_of(a, l);
         hipLaunchKernelGGL((k_node<H, MT, true, false>), dim3(nt), dim3(H), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)],

@@ -1858,10 +1858,16 @@ __global__ void k_eps_bwd(int n_rows, int F, int row0, const float* __restrict__
 __global__ void k_adamw(size_t n, float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
                         float* __restrict__ v, float* __restrict__ vmax, float lr, float beta1, float beta2, float eps,
                         float weight_decay, float bias1, float bias2_sqrt, float clip, const float* __restrict__ sqnorm,
-                        float max_norm) {
+                        float max_norm, int skip_nonfinite) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (sqnorm) clip = fminf(1.0f, max_norm / (sqrtf(sqnorm[0]) + 1e-6f));      // clip_grad_norm_'s coefficient from the device-side norm
+    if (sqnorm) {
+        const float sq = sqnorm[0];
+        // a step whose forward ran on the half engine and whose gradient is not finite (an activation beyond fp16's range) leaves parameters and
+        // moments untouched: the host sees the norm, switches the forward to the bf16 engine and repeats the batch (training.HipTrainer)
+        if (skip_nonfinite && !(sq <= 3.0e38f)) return;
+        if (max_norm > 0.f) clip = fminf(1.0f, max_norm / (sqrtf(sq) + 1e-6f));  // clip_grad_norm_'s coefficient from the device-side norm
+    }
     const float g = grad[i] * clip;
     float p = theta[i];
     p *= 1.0f - lr * weight_decay;
@@ -1872,6 +1878,12 @@ __global__ void k_adamw(size_t n, float* __restrict__ theta, const float* __rest
     const float denom = sqrtf(vm) / bias2_sqrt + eps;
     theta[i] = p - (lr / bias1) * (mi / denom);
 }
+// after a forward on the half engine: a NaN reset of that forward (the evaluation's guard zeroed the velocities - the fp32 reference would not have
+// seen a NaN there) makes the step's norm non-finite, so that k_adamw skips the update and the host repeats the batch on the bf16 engine
+__global__ void k_norm_guard(float* __restrict__ sq, const int* __restrict__ nan_flag) {
+    if (*nan_flag) *sq = __int_as_float(0x7fc00000);
+}
+void tr_norm_guard(float* sq, const int* nan_flag, hipStream_t s) { hipLaunchKernelGGL(k_norm_guard, dim3(1), dim3(1), 0, s, sq, nan_flag); }
 __global__ __launch_bounds__(256) void k_sqsum(size_t n, const float* __restrict__ x, float* __restrict__ out) {
     // one atomic per workgroup: thousands of waves adding into the same address serialise (44 us for 3M elements before)
     __shared__ float red[4];
@@ -2368,8 +2380,8 @@ void tr_bwd_init(int Nl, int N, int P, int dyn, const float* deps, float* dX, fl
 }
 void tr_adamw(size_t n, float* theta, const float* grad, float* m, float* v, float* vmax, float lr, float b1, float b2,
               float eps, float wd, float bias1, float bias2_sqrt, float clip, hipStream_t s, const float* sqnorm = nullptr,
-              float max_norm = 0.f) {
-    if (n) hipLaunchKernelGGL(k_adamw, EW_GRID(n), 0, s, n, theta, grad, m, v, vmax, lr, b1, b2, eps, wd, bias1, bias2_sqrt, clip, sqnorm, max_norm);
+              float max_norm = 0.f, int skip_nonfinite = 0) {
+    if (n) hipLaunchKernelGGL(k_adamw, EW_GRID(n), 0, s, n, theta, grad, m, v, vmax, lr, b1, b2, eps, wd, bias1, bias2_sqrt, clip, sqnorm, max_norm, skip_nonfinite);
 }
 void tr_sqsum(size_t n, const float* x, float* out, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_sqsum, dim3((unsigned)(n / 8192 + 1 > 512 ? 512 : n / 8192 + 1)), dim3(256), 0, s, n, x, out);

@@ -95,7 +95,18 @@ class EGNNDynamics(nn.Module):
         h.set_layout(nph, npk)
         xp = xh_phars.detach().to(torch.float32).contiguous()
         xr = xh_residues.detach().to(torch.float32).contiguous()
-        return h.dynamics_forward(xp, xr, t.detach(), want_pocket=True)
+        # one evaluation: the NaN guard's counter tells whether a reset happened (the reference syncs here too: `torch.any(torch.isnan(vel))`,
+        # dynamics.py:129); on the half matrix engine such a reset is re-run on the bf16 split engine before it is believed
+        if not h.half_engine_active():
+            return h.dynamics_forward(xp, xr, t.detach(), want_pocket=True)
+        seen = [h.nan_resets_total()]
+
+        def status():
+            now = h.nan_resets_total()
+            d, seen[0] = now - seen[0], now
+            return {'nan_resets': max(d, 0)}
+        out, _ = h.run_range_guarded(lambda: h.dynamics_forward(xp, xr, t.detach(), want_pocket=True), status)
+        return out
 
     def get_edges(self, batch_mask=None, x=None):
         """Radius graph as [2, E] int64: pairs (i, j), self loops included, with batch_mask[i] == batch_mask[j] and

@@ -455,8 +455,8 @@ class EnVariationalDiffusion(nn.Module):
         h.set_layout(nph, npk)
         return h
 
-    def _finish_joint(self, h, xh_phar, xh_pocket, z_steps, frame_of_step, return_frames):
-        st = h.chain_status()
+    def _finish_joint(self, h, run, frame_of_step, return_frames):
+        (xh_phar, xh_pocket, z_steps), st = h.run_range_guarded(run, h.chain_status)       # (half engine: a NaN reset is re-run on the bf16 split engine first)
         self.last_chain_status = st
         assert st['max_rel_com_error'] < 1e-2, f"Mean is not zero, relative_error {st['max_rel_com_error']}"
         if st['nan_resets']:
@@ -493,12 +493,12 @@ class EnVariationalDiffusion(nn.Module):
         dev = next(self.dynamics.parameters()).device
         if noise is not None:
             noise = noise.detach().to(dev, torch.float32).contiguous()
-        xh_phar, xh_pocket, z_steps = h.joint_chain(
-            timesteps, noise=noise, seed=fresh_seed() if seed is None else seed, pocket_ids=pocket_ids,
-            want_steps=return_frames > 1, use_graph=self.use_hip_graph, device=dev)
+        seed = fresh_seed() if seed is None else seed
+        run = lambda: h.joint_chain(timesteps, noise=noise, seed=seed, pocket_ids=pocket_ids,
+                                    want_steps=return_frames > 1, use_graph=self.use_hip_graph, device=dev)
         frames = [(timesteps - 1 - s, (s * return_frames) // timesteps) for s in range(timesteps)
                   if (s * return_frames) % timesteps == 0]
-        out = self._finish_joint(h, xh_phar, xh_pocket, z_steps, frames, return_frames)
+        out = self._finish_joint(h, run, frames, return_frames)
         phar_mask = utils.num_nodes_to_batch_mask(n_samples, torch.as_tensor(nph), dev)
         pocket_mask = utils.num_nodes_to_batch_mask(n_samples, torch.as_tensor(npk), dev)
         return out[0], out[1], phar_mask, pocket_mask
@@ -522,12 +522,11 @@ class EnVariationalDiffusion(nn.Module):
         f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()
         if noise is not None:
             noise = f32(noise)
-        xh_phar, xh_pocket, z_steps = h.joint_chain(
-            timesteps, phar=(f32(phar['x']), f32(phar['one_hot'])), pocket=(f32(pocket['x']), f32(pocket['one_hot'])),
-            phar_fixed=f32(phar_fixed).reshape(-1), pocket_fixed=f32(pocket_fixed).reshape(-1),
-            resamplings=resamplings, jump_length=jump_length, noise=noise,
-            seed=fresh_seed() if seed is None else seed, pocket_ids=pocket_ids,
-            want_steps=return_frames > 1, use_graph=self.use_hip_graph)
+        seed = fresh_seed() if seed is None else seed
+        args = dict(phar=(f32(phar['x']), f32(phar['one_hot'])), pocket=(f32(pocket['x']), f32(pocket['one_hot'])),
+                    phar_fixed=f32(phar_fixed).reshape(-1), pocket_fixed=f32(pocket_fixed).reshape(-1))
+        run = lambda: h.joint_chain(timesteps, resamplings=resamplings, jump_length=jump_length, noise=noise, seed=seed, pocket_ids=pocket_ids,
+                                    want_steps=return_frames > 1, use_graph=self.use_hip_graph, **args)
         frames = []
         if return_frames > 1:       # walk the schedule as :723-813 do, noting which steps write a frame
             schedule = self.get_repaint_schedule(resamplings, jump_length, timesteps)
@@ -540,5 +539,5 @@ class EnVariationalDiffusion(nn.Module):
                         s = s + jump_length
                     s -= 1
                     step += 1
-        out = self._finish_joint(h, xh_phar, xh_pocket, z_steps, frames, return_frames)
+        out = self._finish_joint(h, run, frames, return_frames)
         return out[0], out[1], phar['mask'], pocket['mask']

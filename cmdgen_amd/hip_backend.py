@@ -531,10 +531,44 @@ class Handle:
         return out
 
     def chain_status(self):
+        """Deferred checks of the last chain.  `nan_resets` counts the NaN reset steps since the previous call (the library's counter is
+        cumulative: `nan_resets_total`)."""
         a, b, n = C.c_float(0), C.c_float(0), C.c_int64(0)
         self._check(self.lib.cmdgen_chain_status(self.h, C.byref(a), C.byref(b), C.byref(n), self._stream()),
                     'cmdgen_chain_status')
-        return {'max_rel_com_error': a.value, 'max_cog': b.value, 'nan_resets': n.value}
+        seen = getattr(self, '_nan_seen', 0)
+        self._nan_seen = n.value
+        return {'max_rel_com_error': a.value, 'max_cog': b.value, 'nan_resets': max(n.value - seen, 0), 'nan_resets_total': n.value}
+
+    # ---- the half engine's range (two fp16 pieces per operand: an activation beyond 65504 becomes Inf -> NaN -> a reset step the fp32 reference
+    # does not take).  A NaN reset on a half-engine handle is therefore never accepted as it stands: the call is repeated on the three-piece bf16
+    # split engine (fp32's exponent range) with the same inputs and draws.  If that run is clean, its result is returned (and a warning names the
+    # cause); if it resets too, the NaN is the model's own - the reference resets there as well (dynamics.py:129-131) - and that run is returned.
+    def half_engine_active(self) -> bool:
+        return bool(self.query('half_engine'))
+
+    def run_range_guarded(self, run, status):
+        """run() queues the work and returns its outputs; status() -> dict with 'nan_resets' of that run.  -> (outputs, status dict)."""
+        out = run()
+        st = status()
+        if not st['nan_resets'] or not self.half_engine_active():
+            return out, st
+        import warnings
+        prev = self.get_option('half_engine')
+        self.set_option('half_engine', 0)
+        try:
+            out2 = run()
+            st2 = status()
+        finally:
+            self.set_option('half_engine', prev)
+        st2['half_engine_fallback'] = True
+        if not st2['nan_resets']:
+            warnings.warn('an activation left the half matrix engine\'s range (|a| > 65504): this call was repeated on the three-piece bf16 engine '
+                          '(set option half_engine=0 on this handle to run there from the start)', RuntimeWarning, stacklevel=3)
+        return out2, st2
+
+    def nan_resets_total(self) -> int:
+        return self.counters()['nan_resets']
 
     # ---- measurement
     def counters(self) -> Dict[str, int]:
@@ -544,6 +578,7 @@ class Handle:
 
     def reset_counters(self):
         self._check(self.lib.cmdgen_reset_counters(self.h, self._stream()), 'cmdgen_reset_counters')
+        self._nan_seen = 0
 
     def profile_evaluation(self, xh_phar, xh_pocket, t):
         import torch

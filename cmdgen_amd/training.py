@@ -322,10 +322,27 @@ class HipTrainer:
             self._norm_pending = None
             grad_norm = self.h.last_grad_norm()
             self.last_grad_norm = grad_norm
+            if self._left_half_range(grad_norm):
+                import warnings
+                warnings.warn('the previous training step produced a non-finite gradient on the half matrix engine (an activation beyond fp16\'s 65504): '
+                              'its update was skipped on the device; the forward runs on the bf16 split engine from here on', RuntimeWarning, stacklevel=3)
+                return
             if self.clip_grad:
                 self.gradnorm_queue.add(float(mx) if grad_norm > mx else grad_norm)
                 if grad_norm > mx:
                     print(f'Clipped gradient with value {grad_norm:.1f} while allowed {mx:.1f}')
+
+    def _left_half_range(self, grad_norm) -> bool:
+        """A non-finite gradient norm after a forward on the half matrix engine (two fp16 pieces per operand: range 65504): the device has skipped
+        the update (k_adamw); switch this handle's training forward to the three-piece bf16 engine (fp32's range).  True when that happened."""
+        import math
+        if grad_norm is None or math.isfinite(grad_norm):
+            return False
+        if self.h.get_option('train_half') == 0 or not self.h.half_engine_active():
+            return False                    # not the half engine's doing: the reference would carry the NaN on as well
+        self.h.set_option('train_half', 0)
+        self.half_range_fallbacks = getattr(self, 'half_range_fallbacks', 0) + 1
+        return True
 
     def optimizer_step(self, max_grad_norm: Optional[float] = None):
         """Adaptive clipping + AdamW(amsgrad) on the flat buffers; returns (grad_norm, max_grad_norm).  With
@@ -345,6 +362,9 @@ class HipTrainer:
             self._norm_pending = float(max_grad_norm) if self.clip_grad else float('inf')
             return None, max_grad_norm
         self.last_grad_norm = grad_norm
+        if self._left_half_range(grad_norm):
+            self.step_count -= 1            # the device skipped this update; training_step repeats the batch on the bf16 engine
+            return grad_norm, max_grad_norm
         if self.clip_grad:
             self.gradnorm_queue.add(float(max_grad_norm) if grad_norm > max_grad_norm else grad_norm)
             if grad_norm > max_grad_norm:
@@ -354,7 +374,15 @@ class HipTrainer:
     def training_step(self, data, t_int=None, eps=None, max_grad_norm: Optional[float] = None):
         loss, nll, info = self.loss_and_grad(data, t_int=t_int, eps=eps)
         self._allreduce()
+        before = getattr(self, 'half_range_fallbacks', 0)
         grad_norm, mx = self.optimizer_step(max_grad_norm)
+        if getattr(self, 'half_range_fallbacks', 0) != before and not self.pipelined:
+            import warnings
+            warnings.warn('non-finite gradient on the half matrix engine (an activation beyond fp16\'s 65504): the step is repeated on the bf16 split engine',
+                          RuntimeWarning, stacklevel=2)
+            loss, nll, info = self.loss_and_grad(data, t_int=t_int, eps=eps)
+            self._allreduce()
+            grad_norm, mx = self.optimizer_step(max_grad_norm)
         info = dict(info)
         info['loss'] = loss
         info['grad_norm'] = grad_norm

@@ -933,3 +933,129 @@ def test_training_step_options_leave_the_gradient_where_it_is(opts):
         off, cnt = tr.h.param_offset(name)
         a, b = grad_a[off:off + cnt], grad_b[off:off + cnt]
         assert float((a - b).abs().max()) <= GRAD_TOL * max(float(a.abs().max()), 1e-6), (name, opts)
+
+
+# ------------------------------------------------------------------ round 6: the big-list kernels against the ORACLE, the half engine's range, re-pack hygiene
+def _bench_trainer(B, pipelined=False, sd_edit=None, lr=1e-3):
+    """PharPocketDDPM (shipped hyper-parameters, seeded weights) + HipTrainer + one synthetic batch of B ragged C-alpha complexes (tools/bench_train.py)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location('bench_train', os.path.join(os.path.dirname(__file__), '..', 'tools', 'bench_train.py'))
+    bt = importlib.util.module_from_spec(spec); spec.loader.exec_module(bt)
+    cfg, model, tr = bt.build_trainer(B, 'CA', 'fp32', torch.device('cuda', 0), pipelined=pipelined)
+    sd = make_state_dict(cfg, seed=0)
+    if sd_edit is not None:
+        sd = sd_edit(dict(sd))
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        tr = bt.HipTrainer(model, gemm_dtype='fp32')
+        tr.pipelined = pipelined
+    tr.lr = lr
+    return cfg, sd, model, tr, bt
+
+
+def test_default_step_at_bench_size_matches_oracle_autograd():
+    """The DEFAULT training step at the benchmark's size - 64 ragged complexes, H = 256, L = 5, ~36k message / ~16k coordinate edges: half-engine
+    forward with save hooks, two / three streams, k_wgrad_split128, the fused k_dgrad_tail - against AUTOGRAD THROUGH THE ORACLE on the same batch,
+    draws and time steps: per-sample nll and the gradient of every tensor at GRAD_TOL of its own scale.  (The other big-list tests compare
+    engines with each other; this one pins the big-list kernels to the reference's arithmetic.)"""
+    cfg, sd, model, tr, bt = _bench_trainer(64)
+    batch = bt.synthetic_batch(64, 7000, torch.device('cuda', 0))
+    nl_tot = int(batch['num_phar_atoms'].sum())
+    hist = np.ones((30, 500))
+    for seed in range(11, 40):            # draws whose noised geometry keeps every pair clear of the cutoff (the radius graph is a hard threshold)
+        gen = torch.Generator().manual_seed(seed)
+        t_int = torch.randint(1, 501, (64, 1), generator=gen).float()
+        eps0 = torch.randn((nl_tot, 11), generator=gen)
+        loss, nll, info = tr.loss_and_grad(batch, t_int=t_int.cuda(), eps=[eps0.cuda()])
+        z = tr._last_fused['z_t'][:, :3].cpu().numpy()
+        q = tr._last_fused['xh_pocket'][:, :3].cpu().numpy()
+        margin = min_cutoff_margin(np.concatenate([z, q]), np.concatenate([batch['phar_mask'].cpu().numpy(), batch['pocket_mask'].cpu().numpy()]), 6.0)
+        if margin > 5e-5:
+            break
+    assert margin > 5e-5
+    E, Ec = tr.h.query('train_edges'), tr.h.query('train_coord_edges')
+    assert E > 24576 and tr.h.half_engine_active() and tr.h.get_option('train_half') is None and tr.h.get_option('wgrad_stream') is None
+    grad = tr.grad.cpu().numpy()
+    cpu = lambda k: batch[k].detach().cpu()
+    phar = {'x': cpu('phar_coords'), 'one_hot': cpu('phar_one_hot'), 'size': cpu('num_phar_atoms'), 'mask': cpu('phar_mask')}
+    pocket = {'x': cpu('pocket_c_alpha'), 'one_hot': cpu('pocket_one_hot'), 'size': cpu('num_pocket_nodes'), 'mask': cpu('pocket_mask')}
+    p = ref_cpu.to_torch_params(sd)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith('dynamics.')}
+    p2 = dict(p); p2.update(leaves)
+    terms = ref_cpu.ddpm_forward(p2, cfg.as_dict(), phar, pocket, t_int, [eps0], training=True, histogram=hist)
+    want = ref_cpu.nll_from_terms(terms, cfg.as_dict(), phar['size'], pocket['size'], training=True)
+    want.mean(0).backward()
+    w = want.detach().numpy()
+    err_nll = float(np.abs(nll.cpu().numpy() - w).max())
+    print(f'64 complexes, {E} / {Ec} edges, cutoff margin {margin:.1e}: per-sample nll max diff {err_nll:.2e} (|nll| max {np.abs(w).max():.3f})')
+    assert err_nll <= 2e-5 * max(1.0, float(np.abs(w).max()))
+    assert abs(float(loss) - float(w.mean())) <= 2e-6 * max(1.0, abs(float(w.mean())))
+    worst = (0.0, None)
+    for name, leaf in leaves.items():
+        off, cnt = tr.h.param_offset(name[len('dynamics.'):])
+        g_want = np.zeros(cnt, np.float32) if leaf.grad is None else leaf.grad.numpy().reshape(-1)
+        rel = float(np.abs(grad[off:off + cnt] - g_want).max()) / max(float(np.abs(g_want).max()), 1e-6)
+        if rel > worst[0]:
+            worst = (rel, name)
+        assert rel <= GRAD_TOL, (name, rel)
+    print(f'worst tensor {worst[1]}: {worst[0]:.2e} of its own scale (tolerance {GRAD_TOL:.0e})')
+
+
+def test_half_forward_sees_the_parameters_of_this_step():
+    """With the half-engine forward only ONE fp32 fragment pack is refreshed per step (cmdgen_train.hip): after an optimizer update the forward must
+    still multiply with the NEW weights in every kernel.  Two steps with a large learning rate on the default path against two steps with
+    train_half = 0 (every pack refreshed): the second step's loss and gradient agree, and differ clearly from the first step's."""
+    out = {}
+    for th in (None, 0):
+        cfg, sd, model, tr, bt = _bench_trainer(8, lr=2e-2)
+        if th is not None:
+            tr.h.set_option('train_half', th)
+        tr.clip_grad = False
+        batch = bt.synthetic_batch(8, 9100, torch.device('cuda', 0))
+        gen = torch.Generator().manual_seed(3)
+        t_int = torch.randint(1, 501, (8, 1), generator=gen).float().cuda()
+        eps = [torch.randn((int(batch['num_phar_atoms'].sum()), 11), generator=gen).cuda()]
+        l1, _, _ = tr.loss_and_grad(batch, t_int=t_int, eps=eps)
+        g1 = tr.grad.clone()
+        tr.optimizer_step()
+        l2, _, _ = tr.loss_and_grad(batch, t_int=t_int, eps=eps)
+        out[th] = (float(l1), g1.cpu().numpy(), float(l2), tr.grad.cpu().numpy().copy(), tr)
+    (l1a, g1a, l2a, g2a, tra), (l1b, g1b, l2b, g2b, trb) = out[None], out[0]
+    assert tra.h.half_engine_active()
+    assert abs(l2a - l1a) > 1e-3 * abs(l1a), 'the update must move the loss for this test to mean anything'
+    assert abs(l2a - l2b) <= 1e-4 * max(1.0, abs(l2b)), (l2a, l2b)
+    for name, _p in tra.dyn.named_parameters():
+        off, cnt = tra.h.param_offset(name)
+        a, b = g2a[off:off + cnt], g2b[off:off + cnt]
+        assert float(np.abs(a - b).max()) <= 5 * GRAD_TOL * max(float(np.abs(b).max()), 1e-6), name       # (two steps: the first step's rounding differences pass through an update with lr 2e-2)
+
+
+def test_training_step_leaves_the_half_range_and_repeats_on_the_bf16_engine():
+    """A model whose message MLP's hidden activation exceeds fp16's 65504 (fp32 keeps it finite): the half-engine forward yields a non-finite
+    gradient, the device skips that update, the trainer switches the forward to the three-piece bf16 engine, repeats the batch and warns -
+    parameters after the step equal those of a trainer that ran with train_half = 0 from the start."""
+    def edit(sd):
+        for s in ('.weight', '.bias'):
+            k = 'ddpm.dynamics.egnn.e_block_1.gcl_0.edge_mlp.0' + s
+            sd[k] = (sd[k] * 3.0e6).astype(np.float32)
+        return sd
+    res = {}
+    for th in (None, 0):
+        cfg, sd, model, tr, bt = _bench_trainer(8, sd_edit=edit)
+        if th is not None:
+            tr.h.set_option('train_half', th)
+        batch = bt.synthetic_batch(8, 9100, torch.device('cuda', 0))
+        gen = torch.Generator().manual_seed(3)
+        t_int = torch.randint(1, 501, (8, 1), generator=gen).float().cuda()
+        eps = [torch.randn((int(batch['num_phar_atoms'].sum()), 11), generator=gen).cuda()]
+        theta0 = tr.theta.clone()
+        if th is None:
+            with pytest.warns(RuntimeWarning, match='half matrix engine'):
+                info = tr.training_step(batch, t_int=t_int, eps=eps)
+            assert tr.h.get_option('train_half') == 0 and tr.half_range_fallbacks == 1
+        else:
+            info = tr.training_step(batch, t_int=t_int, eps=eps)
+        assert np.isfinite(float(info['loss'])) and np.isfinite(tr.last_grad_norm)
+        assert tr.step_count == 1 and not torch.equal(tr.theta, theta0) and bool(torch.isfinite(tr.theta).all())
+        res[th] = (float(info['loss']), tr.theta.cpu().numpy().copy())
+    assert abs(res[None][0] - res[0][0]) <= 1e-6 * max(1.0, abs(res[0][0]))
+    assert np.array_equal(res[None][1], res[0][1]) or np.abs(res[None][1] - res[0][1]).max() <= 1e-6
