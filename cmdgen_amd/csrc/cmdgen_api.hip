@@ -663,7 +663,6 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     if (h->dims.sin && h->dims.H == 512) { if (a.edge_mt > 32) a.edge_mt = 32; if (a.coord_mt > 32) a.coord_mt = 32; }   // (64-row tiles + the 55 KB of feature columns exceed the LDS)
     a.edge_fullk = (sp256 && opt_of(h, "edge_fullk", 1) != 0) ? 1 : 0;
     a.e128_wgs = (int)opt_of(h, "e128_wgs_per_cu", 2);
-    a.e128_pp = (int)opt_of(h, "e128_pp", 0);
     {   // the half engine's operands end at 65504: by default only where the radial features are bounded by a cutoff (every shipped config);
         // 2 forces it, 0 keeps the three-piece bf16 split everywhere
         const int he = (int)opt_of(h, "half_engine", 1);
@@ -711,7 +710,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
 // options
 // ---------------------------------------------------------------------------------
 static const char* const kOptionKeys[] = {
-    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "e128_pp", "half_engine", "edge_fullk", "node64", "node16_split", "node16w",
+    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "half_engine", "edge_fullk", "node64", "node16_split", "node16w",
     "dead_skip", "write_embed", "fused_step", "pocket_cache", "graph_steps",
     "wgrad_split", "wgrad_tile", "wgrad_split_wgs128", "wgrad_split_wgs64", "wgrad_wgs", "dgrad_mt", "dgrad_tail", "wgrad_stream", "train_half", "dgrad_half", "wgrad_silu", "train_node16", "wgrad_k128", "small_wgrads"};
 

@@ -242,7 +242,6 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int write_embed = 1;        // 1: pass 2 of the radius graph and k_embed share a launch (k_write_embed) where both fit (option "write_embed")
     int e128_wgs = 2;           // workgroups per CU of the 128-row edge kernels (kernels_edge128.hip)
     int half_engine = 1;        // 1: split-engine kernels that have a HALF form (two fp16 pieces per operand, three MFMAs per product; cmdgen_split.h) use it
-    int e128_pp = 0;            // 1: the 128-row edge kernels run as ONE 512-thread workgroup per CU whose two halves are phase-locked one barrier apart (k_edge128pp)
 };
 // weight unit of block l's launches (EvalLaunch::unit), and the has_next argument of its node kernel: bit 0 = another unit follows
 // (its P | Q are projected), bits 1..29 = the dead-tile threshold of the plane tiles, bit 30 = no P_c | Q_c (EvalLaunch::skip_pc)

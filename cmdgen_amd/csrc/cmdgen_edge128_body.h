@@ -21,6 +21,9 @@ constexpr int H = 256;
 #ifndef CMDGEN_E128_MT
 #define CMDGEN_E128_MT 128
 #endif
+#ifndef CMDGEN_E128_FUSED
+#define CMDGEN_E128_FUSED 1     // half engine: the build of quarter q + 1 is issued INSIDE the GEMM over quarter q (double-buffered planes; see x_main)
+#endif
 constexpr int MT = CMDGEN_E128_MT;      // rows per tile (at most): 128, 96 or 64
 constexpr int MTL = 128;                // rows the per-tile index arrays hold (the index phase handles two rows per lane of wave 0)
 constexpr int KQ = 64;                  // k-values per build / GEMM pass
@@ -29,6 +32,8 @@ constexpr int PE = MT * PLDA;           // bf16 per plane
 constexpr int NPL = E128_NPL;           // pieces per operand = planes of the A image: 3 (bf16 split, six MFMAs per product) or 2 (fp16 "half" engine, three)
 constexpr unsigned KBS = 64u * NPL;     // 16-byte units per k-block of a 32-column tile in the packed split weight
 constexpr unsigned NS = 16u * KBS;      // ... between the two 32-column tiles of a wave ([H][H] weight: 16 k-blocks)
+constexpr bool FUSED = E128_NPL == 2 && CMDGEN_E128_FUSED != 0 && CMDGEN_E128_MT == 128;
+constexpr int PLF = 128 * KQ;           // fused form: fp16 per plane - rows of 128 B, unpadded, 16-byte chunks XOR-swizzled by (row & 7); planes[buffer 2][piece 2][PLF]
 #if E128_NPL == 3
 typedef sbf16x8 efrag;
 #define E128_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
@@ -40,7 +45,7 @@ typedef sf16x8 efrag;
 struct alignas(16) EdgeRec { int row, col; float r, d0; };
 
 struct alignas(16) E128Lds {
-    unsigned short planes[NPL * PE + 64];       // the NPL planes (bf16 / fp16 pieces) of the quarter in flight (+ the A prefetch's overshoot)
+    unsigned short planes[FUSED ? 4 * PLF : NPL * PE + 64];   // the NPL planes (bf16 / fp16 pieces) of the quarter in flight (+ the A prefetch's overshoot); fused form: two quarters (64 KB)
     EdgeRec e[MTL];                              // (receiver, sender, radial, d0) of the tile's rows; -1 / -1 / 0 / 0 beyond its end
     float cd[MTL][4];                            // coordinate kernel: coord_diff of the row, later coord_diff * tanh(phi) * range
     float part[4][MTL];                          // the four waves' partial row dots
@@ -174,18 +179,169 @@ __device__ __forceinline__ void gemm_quarter(const unsigned short* planes, const
     }
 }
 
-#define E_SWZ(V, D) __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(V), ((D) << 10) | 0x1f))     // value of lane ^ D (D < 32)
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 6 - the fused main loop of a tile (half engine): the BUILD of quarter q + 1 is issued inside the GEMM over quarter q.
+// The kernel was not issue-bound (12 % fewer vector instructions bought 1 %, profiles/r06_b): a workgroup's tile is a chain of phases - index,
+// 4 x (build, GEMM), epilogue - that a wave walks one after the other, and with two waves per SIMD the partner hides only part of it.  Here a
+// wave's vector work for the next quarter rides in the shadow of its own MFMAs: the planes are double-buffered (unpadded 128-byte rows whose
+// 16-byte chunks are XOR-swizzled by row & 7: 2 x 32 KB, conflict-free b64 writes and b128 reads), a thread's share of a quarter - 2 NMT "slots" of
+// 4 columns x 16 rows apart - is cut into six pieces per slot, one piece behind each pair of MFMAs (two (m, k-block) groups = six pairs per slot:
+// <= 8 vector instructions per pair, at most four of them v_exp / v_rcp), gathers are requested three slots ahead (24 registers instead of the 64 a
+// whole quarter needs), and a quarter costs ONE barrier (the next quarter's planes complete + this quarter's planes free) instead of two.
+// Only quarter 0 of a tile is built without MFMAs beside it.
+#ifndef CMDGEN_E128_RING
+#define CMDGEN_E128_RING 2      // slots of gathered rows in flight (2: no spill inside the loop; 3 and 4 spill and measure 2-3 % slower, profiles/r06_c)
+#endif
+template <int NMT> struct XPipe {
+    static constexpr int SL = 2 * NMT;          // slots per quarter
+    static constexpr int R = NMT == 1 ? 2 : CMDGEN_E128_RING;                       // ring of slots in flight = how many slots ahead a gather is requested (indexed by the tile-wide slot number)
+    gq4 p[R], q[R]; float r[R], d0[R];          // gathered P / Q chunks and the row's (radial, d0)
+    int4 rec;                                   // (row, col, r, d0) of the slot after them
+    float4 wr, wd;                              // the first layer's radial / d0 weights of this thread's four columns, for the quarter being built
+    float v[4], e[4];
+};
+// (qb, sl): quarter being built and slot inside it - compile-time constants after unrolling (the ring index is the tile-wide slot number mod R)
+template <int NMT>
+__device__ __forceinline__ void x_rec(XPipe<NMT>& X, const E128Lds& L, const int tid, const int sl, const int ne) {
+    const int e = min(16 * (sl % XPipe<NMT>::SL) + (tid >> 4), ne - 1);
+    X.rec = *reinterpret_cast<const int4*>(&L.e[e]);
+}
+template <int NMT>
+__device__ __forceinline__ void x_issue(XPipe<NMT>& X, const RowBufs& rb, const int tid, const int qb, const int sl) {
+    constexpr int R = XPipe<NMT>::R;
+    const unsigned cofs = (unsigned)(qb * KQ + 4 * (tid & 15)) * 4u;
+    const int k = (qb * XPipe<NMT>::SL + sl) % R;
+    X.p[k] = __builtin_amdgcn_raw_buffer_load_b128(rb.P, (int)(((unsigned)X.rec.x << 10) + cofs), 0, 0);
+    X.q[k] = __builtin_amdgcn_raw_buffer_load_b128(rb.Q, (int)(((unsigned)X.rec.y << 10) + cofs), 0, 0);
+    X.r[k] = __int_as_float(X.rec.z); X.d0[k] = __int_as_float(X.rec.w);
+}
+template <int NMT>
+__device__ __forceinline__ void x_cols(XPipe<NMT>& X, const E128Lds& L, const int tid, const int q) {
+    const int col = q * KQ + 4 * (tid & 15);
+    X.wr = *reinterpret_cast<const float4*>(L.wrd + col); X.wd = *reinterpret_cast<const float4*>(L.wrd + H + col);
+}
+// piece 0..5 of slot sl of quarter qb; wofs: this thread's (swizzled) byte offset inside a 16-row group of a plane
+template <int NMT>
+__device__ __forceinline__ void x_piece(XPipe<NMT>& X, E128Lds& L, const RowBufs& rb, const int tid, const int qb, const int sl, const int piece, const int ne, const int wofs) {
+    constexpr int SL = XPipe<NMT>::SL, R = XPipe<NMT>::R;
+    const int k = (qb * SL + sl) % R;
+    const float wr[4] = {X.wr.x, X.wr.y, X.wr.z, X.wr.w}, wd[4] = {X.wd.x, X.wd.y, X.wd.z, X.wd.w};
+    if (piece == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) X.v[i] = __fmaf_rn(wr[i], X.r[k], __uint_as_float(X.p[k][i]) + __uint_as_float(X.q[k][i]));
+    } else if (piece == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { X.v[i] = __fmaf_rn(wd[i], X.d0[k], X.v[i]); X.e[i] = X.v[i] * -1.4426950408889634f; }
+    } else if (piece == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) X.e[i] = __builtin_amdgcn_exp2f(X.e[i]);
+    } else if (piece == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) X.e[i] = 1.0f + X.e[i];
+        X.e[0] = __builtin_amdgcn_rcpf(X.e[0]); X.e[1] = __builtin_amdgcn_rcpf(X.e[1]);
+    } else if (piece == 4) {
+        X.e[2] = __builtin_amdgcn_rcpf(X.e[2]); X.e[3] = __builtin_amdgcn_rcpf(X.e[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) X.v[i] *= X.e[i];                     // silu_f's operations, in its order
+    } else {
+        uint32_t a0, a1, b0, b1;
+        split2_pair(X.v[0], X.v[1], a0, a1); split2_pair(X.v[2], X.v[3], b0, b1);
+        unsigned char* dst = reinterpret_cast<unsigned char*>(L.planes) + (qb & 1) * (4 * PLF) + sl * (16 * KQ * 2) + wofs;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(dst + 2 * PLF) = make_uint2(a1, b1);
+        // the ring entry of this slot was consumed in pieces 0 / 1: request the slot R ahead into it, read the record of the one after
+        if (sl + R < SL) x_issue<NMT>(X, rb, tid, qb, sl + R); else if (qb < 3) x_issue<NMT>(X, rb, tid, qb + 1, sl + R - SL);
+        if (sl + R + 1 < SL || qb < 3) x_rec<NMT>(X, L, tid, (sl + R + 1) % SL, ne);
+        if (sl == SL - 1 && qb < 3) x_cols<NMT>(X, L, tid, qb + 1);
+    }
+}
 
-// Sum over the 32 lanes of a half wave of 32 values per lane, by value halving: after the five exchanges lane l of a half holds the
-// complete sum of value l & 31 (31 exchanges instead of 160 for a butterfly on every value).
+// the A fragment (16-byte chunk 2 kq + lane / 32 of row 32 m + lane % 32) of piece s in plane buffer b: a0 = this lane's byte offset for kq = 0
+__device__ __forceinline__ efrag x_afrag(const E128Lds& L, const int a0, const int b, const int s, const int m, const int kq) {
+    return *reinterpret_cast<const efrag*>(reinterpret_cast<const unsigned char*>(L.planes) + b * (4 * PLF) + s * (2 * PLF) + m * (32 * KQ * 2) + (a0 ^ (kq << 5)));
+}
+
+template <int NMT>
+__device__ __forceinline__ void x_main(E128Lds& L, const int tid, const int lane, const int ne, const RowBufs& rb, const __amdgpu_buffer_rsrc_t rw,
+                                       sf32x16 (&acc)[NMT][2], efrag (&bs)[2][2][NPL]) {
+    constexpr int SL = XPipe<NMT>::SL;
+    XPipe<NMT> X;
+    const int rsub = tid >> 4, c4 = tid & 15;
+    const int wofs = (rsub * KQ + ((((c4 >> 1) ^ (rsub & 7)) << 3) | ((c4 & 1) << 2))) * 2;
+    const int a0 = ((lane & 31) * KQ + ((((lane >> 5) ^ (lane & 7)) & 7) << 3)) * 2;
+    // prologue: the first R slots requested, the next one's record read; then quarter 0 is built with nothing beside it
+    constexpr int R = XPipe<NMT>::R;
+    x_cols<NMT>(X, L, tid, 0);
+#pragma unroll
+    for (int sl = 0; sl < R; ++sl) { x_rec<NMT>(X, L, tid, sl, ne); x_issue<NMT>(X, rb, tid, 0, sl); }
+    x_rec<NMT>(X, L, tid, R % SL, ne);
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) x_piece<NMT>(X, L, rb, tid, 0, sl, pc, ne, wofs);
+    lds_barrier();
+    // (the four quarters are unrolled: the waits for gathers and weight fragments stay counted across quarter boundaries - behind a loop's back edge
+    // the compiler waits for everything in flight - and no piece needs a branch on "is there a next quarter")
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int b = q & 1;
+        __builtin_amdgcn_s_setprio(CMDGEN_E128_GPRIO);
+        efrag a[2][NPL];
+#pragma unroll
+        for (int s = 0; s < NPL; ++s) a[0][s] = x_afrag(L, a0, b, s, 0, 0);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const int qn = (int)(((unsigned)((4 * q + kq + 1) & 15) * KBS) << 4);        // byte offset of the next k-block in the wave's weight tiles (scalar)
+            constexpr int NBL = 2 * NPL, BPG = (NBL + NMT - 1) / NMT;
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                const int g = kq * NMT + m, cs = g & 1, nx = cs ^ 1, bc = kq & 1, bn = bc ^ 1;
+                const bool more_a = (m + 1 < NMT) || (kq < 3);
+                const bool more_b = kq < 3 || q < 3;
+                const int nm = (m + 1 < NMT) ? m + 1 : 0, nkq = (m + 1 < NMT) ? kq : kq + 1;
+                const int b0 = m * BPG;
+                // the slot of quarter q + 1 whose pieces ride behind this group's MFMA pairs (q is a run-time value: the slot index is quarter-relative)
+                const int sl = g >> 1, pc0 = 3 * (g & 1);
+#define X_PC(I) if (q < 3) x_piece<NMT>(X, L, rb, tid, q + 1, sl, pc0 + (I), ne, wofs);
+#define E_MF(N, AI, BI) acc[m][N] = E128_MFMA(a[cs][AI], bs[bc][N][BI], acc[m][N]);
+#define E_LA(S) if (more_a) a[nx][S] = x_afrag(L, a0, b, S, nm, nkq);
+#define E_LB(I) if ((I) < NBL && (I) >= b0 && (I) < b0 + BPG && more_b) bs[bn][(I) & 1][(I) >> 1] = w_frag(rw, lane, qn + (int)((((unsigned)((I) & 1) * NS + (unsigned)((I) >> 1) * 64u)) << 4));
+                E_LA(1) E_LB(b0 + 2) X_PC(0) E_MF(0, 1, 0) E_MF(1, 1, 0) __builtin_amdgcn_sched_barrier(0);
+                E_LA(0) E_LB(b0) E_LB(b0 + 3) X_PC(1) E_MF(0, 0, 1) E_MF(1, 0, 1) __builtin_amdgcn_sched_barrier(0);
+                E_LB(b0 + 1) X_PC(2) E_MF(0, 0, 0) E_MF(1, 0, 0) __builtin_amdgcn_sched_barrier(0);
+#undef X_PC
+#undef E_MF
+#undef E_LA
+#undef E_LB
+            }
+        }
+        __builtin_amdgcn_s_setprio(CMDGEN_E128_VPRIO);
+        lds_barrier();                        // quarter q + 1's planes are complete, quarter q's are free
+    }
+}
+
+// Sum over the 32 lanes of a half wave of 32 values per lane, by value halving: after five exchanges lane l of a half holds the complete
+// sum of value l & 31 (31 exchanges instead of 160 for a butterfly on every value).  Round 6: no LDS round trips and no selects around the
+// exchange - the first stage is v_permlane16_swap_b32 (rows of 16 lanes: the odd rows of one register against the even rows of the other,
+// i.e. exactly "keep your half of the values, hand over the other half") + one add per pair; the other four stages add a DPP-permuted copy
+// (row_mirror, row_half_mirror, two quad permutations: the partner differs in the stage's lane bit, and over the five stages the partners
+// cover all 32 lanes) and keep one of the two sums by that lane bit.  65 vector instructions per 32 values (93 + 31 ds_swizzle before).
 __device__ __forceinline__ float reduce32_over32(float (&v)[32], const int lane) {
-#define E_STAGE(N, D) {                                                                                           \
-        const bool up = (lane & (D)) != 0;                                                                        \
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const u2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+        v[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);        // lanes with bit 4 clear: value i of lanes l, l + 16; bit 4 set: value i + 16
+    }
+#define E_DPP(V, CTRL) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(V), CTRL, 0xf, 0xf, true))
+#define E_STAGE(N, BIT, CTRL) {                                                                                   \
+        const bool up = (lane & (BIT)) != 0;                                                                      \
         _Pragma("unroll") for (int i = 0; i < (N) / 2; ++i) {                                                     \
-            const float keep = up ? v[i + (N) / 2] : v[i], send = up ? v[i] : v[i + (N) / 2];                     \
-            v[i] = keep + E_SWZ(send, D); } }
-    E_STAGE(32, 16) E_STAGE(16, 8) E_STAGE(8, 4) E_STAGE(4, 2) E_STAGE(2, 1)
+            const float lo = v[i] + E_DPP(v[i], CTRL), hi = v[i + (N) / 2] + E_DPP(v[i + (N) / 2], CTRL);         \
+            v[i] = up ? hi : lo; } }
+    E_STAGE(16, 8, 0x140) E_STAGE(8, 4, 0x141) E_STAGE(4, 2, 0x4e) E_STAGE(2, 1, 0xb1)
 #undef E_STAGE
+#undef E_DPP
     return v[0];
 }
 
@@ -228,15 +384,37 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
 #define STAMPB(i) do {} while (0)
 #endif
     sf32x16 acc[NMT][2];                                                                // start from the bias of the layer (b2 / b7; staged in LDS: not a register held across the tile loop)
-    const float bias0 = L.colv[colw], bias1 = L.colv[colw + 32];
+    if constexpr (NPL == 2) {
+        // half engine (round 6): every accumulator tile starts as ONE MORE MFMA - the rank-1 product (column of 256s) x (row of bias pieces) with
+        // C = 0: the B fragment holds, in its k = 0 / k = 1 slots, the two fp16 pieces of bias * scale / 256 of the lane's column (lanes 0-31; zero
+        // elsewhere), the A fragment 256 in the same two slots.  8 MFMAs per tile instead of 128 v_mov_b32 per lane.
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 onesu = {lane < 32 ? 0x5c005c00u : 0u, 0u, 0u, 0u};                   // fp16 256.0 at k = 0 and k = 1 of every row
+        const efrag ones = __builtin_bit_cast(efrag, onesu);
+        const sf32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int m = 0; m < NMT; ++m)
+        for (int n = 0; n < 2; ++n) {
+            uint32_t p0, p1;
+            split2_pair(L.colv[colw + 32 * n] * 0.00390625f, 0.f, p0, p1);             // two fp16 pieces of bias * scale / 256 (low halves; the high halves are zero)
+            const u4 v = {lane < 32 ? ((p0 & 0xffffu) | (p1 << 16)) : 0u, 0u, 0u, 0u};
+            const efrag cb = __builtin_bit_cast(efrag, v);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[m][0][r] = bias0; acc[m][1][r] = bias1; }
+            for (int m = 0; m < NMT; ++m) acc[m][n] = E128_MFMA(ones, cb, zero);
+        }
+    } else {
+        const float bias0 = L.colv[colw], bias1 = L.colv[colw + 32];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[m][0][r] = bias0; acc[m][1][r] = bias1; }
+    }
     // ---------------- four build -> GEMM passes over a quarter of K each.  The first 64 rows of the NEXT quarter are gathered before the GEMM
     // over this one and land during it (32 registers; the half engine's GEMM leaves them - on the three-piece bf16 split they spilled, profiles/r04_c);
     // the other 64 rows are requested at the start of the build and land while the first batch is turned into planes.
     constexpr bool AHEAD = NPL == 2 && CMDGEN_E128_AHEAD != 0;
+    if constexpr (FUSED) {
+        x_main<NMT>(L, tid, lane, ne, rb, rw, acc, bs);
+    } else {
     Gath g0;
     if constexpr (AHEAD) gather_half<NMT>(L, tid, 0, 0, ne, rb, g0);
 #pragma unroll 1
@@ -260,6 +438,7 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
         STAMP(7);
         lds_barrier();                                                                  // every wave is done reading the planes
         STAMP(2);
+    }
     }
     STAMPB(2);
     // ---------------- epilogue in registers: SiLU, the row dot (attention logit / coord_mlp.4)
@@ -333,25 +512,22 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
             }
             ++sg; sum = 0.f;
         };
-        // gate every message in the accumulator layout first (one broadcast read per four rows, all of them in flight together: the scan below
-        // is full of scalar branches, a read issued there would be waited for on the spot)
-#pragma unroll
-        for (int m = 0; m < NMT; ++m) {
-            float4 g[4];
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) g[rq] = *reinterpret_cast<const float4*>(&L.gw[wave][E_ROW(m, 4 * rq)]);    // rows E_ROW(m, 4 rq) .. + 3 of this lane half
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float gg = (r & 3) == 0 ? g[r >> 2].x : (r & 3) == 1 ? g[r >> 2].y : (r & 3) == 2 ? g[r >> 2].z : g[r >> 2].w;
-                    acc[m][n][r] *= gg;
-                }
-        }
+        // Round 6: the gate multiply rides in the scan's add (one v_fma per element instead of v_mul + v_add): after the swap a register holds ONE
+        // row, whose gate is the same in every lane - a broadcast read of four consecutive rows' gates (one ds_read_b128 per four rows, as the
+        // separate gating pass needed), requested one row group ahead so that the scan's scalar branches never wait for it.
+        auto gates_of = [&](int mj, float4& gx, float4& gy) {
+            const int base = 32 * (mj >> 2) + 8 * (mj & 3);
+            gx = *reinterpret_cast<const float4*>(&L.gw[wave][base]);
+            gy = *reinterpret_cast<const float4*>(&L.gw[wave][base + 4]);
+        };
+        float4 gxn, gyn;
+        gates_of(0, gxn, gyn);
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                const float4 gx = gxn, gy = gyn;
+                if (4 * m + j + 1 < 4 * NMT) gates_of(4 * m + j + 1, gxn, gyn);
                 float x[4], y[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -365,14 +541,16 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
                     unsigned bits = (sm[base >> 5] >> (base & 31)) & 0xfu;
                     if (base == 0) bits &= ~1u;                                                    // row 0 opens segment 0: nothing to flush
                     const float* v = hh ? y : x;
+                    const float4 gq = hh ? gy : gx;
+                    const float g[4] = {gq.x, gq.y, gq.z, gq.w};
                     if (bits == 0u) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) sum += v[i];
+                        for (int i = 0; i < 4; ++i) sum = __fmaf_rn(v[i], g[i], sum);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             if (bits & (1u << i)) flush();
-                            sum += v[i];
+                            sum = __fmaf_rn(v[i], g[i], sum);
                         }
                     }
                 }
@@ -533,7 +711,6 @@ __device__ __forceinline__ void tile_dispatch(E128Lds& L, const Layout& lay, con
         default: tile_compute<COORD, 1>(L, lay, w, d, tc, ne, bs, st_, st_t); break;
     }
 }
-constexpr int TILE_BARRIERS = 9;        // barriers inside tile_compute (two per quarter, one after the row dots)
 
 template <bool COORD>
 __device__ __forceinline__ TileCtx make_ctx(const LayerW& lw, const EdgeSrc<COORD>& es, const int wave, const int lane, const int layer, const int n_rows) {
@@ -552,10 +729,12 @@ __device__ __forceinline__ TileCtx make_ctx(const LayerW& lw, const EdgeSrc<COOR
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Driver 1: two free-running 256-thread workgroups per CU, one chunk walk each.
+// The driver: two free-running 256-thread workgroups per CU, one chunk walk each.  (Round 5's phase-locked 512-thread driver, k_edge128pp, lost its
+// A/B by 4-6 % and left the build in round 6: profiles/r06_removed_experiments.patch.)
 template <bool COORD>
 __global__ __launch_bounds__(256, CMDGEN_E128_WPS) void k_edge128(Layout lay, Work w, Dims d, LayerW lw, int layer, int live_thr) {
-    __shared__ E128Lds L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char e128_lds[];        // (dynamic: the fused form's two plane buffers bring E128Lds to 77 KB)
+    E128Lds& L = *reinterpret_cast<E128Lds*>(e128_lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const EdgeSrc<COORD> es(w);
     L.wrd[tid] = (COORD ? lw.wr_c : lw.wr_e)[tid]; L.wrd[H + tid] = (COORD ? lw.wd_c : lw.wd_e)[tid];       // visible after the first tile's barrier
@@ -613,86 +792,5 @@ __global__ __launch_bounds__(256, CMDGEN_E128_WPS) void k_edge128(Layout lay, Wo
     }
 #endif
 }
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// Driver 2 (round 5): ONE 512-thread workgroup per CU whose two halves (waves 0-3, waves 4-7: a SIMD hosts wave i and wave i + 4) run the same
-// tile program on two chunk walks, PHASE-LOCKED one barrier apart.  s_barrier counts all eight waves, so with the second half started one
-// barrier late every barrier is a rendezvous of phase k of one half with phase k - 1 of the other: a half's GEMM quarter (the phases between
-// an odd and the following even barrier of its tile) always runs beside a build or epilogue phase of its partner, never beside the partner's
-// GEMM - the matrix pipe of a SIMD has one user at a time and that user's partner is issuing vector work.  Free-running workgroups (driver 1)
-// drift into lockstep instead: both in their GEMMs (sharing the pipe), then both in their builds (pipe idle); profiles/r04_l, r05_b.
-// Both halves execute the same number of tile slots (a half without a tile runs the slot's barriers only); whether another slot follows is
-// agreed through two LDS flags that each half writes in its index phase.  No wave ever waits on anything but s_barrier.
-template <bool COORD>
-__global__ __launch_bounds__(512, 2) void k_edge128pp(Layout lay, Work w, Dims d, LayerW lw, int layer, int live_thr) {
-    __shared__ E128Lds LL[2];
-    __shared__ int more_flag[2][2];                                                         // [slot parity][half]: the half has a tile in the NEXT slot
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int half = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), htid = tid & 255;
-    E128Lds& L = LL[half];
-    const EdgeSrc<COORD> es(w);
-    L.wrd[htid] = (COORD ? lw.wr_c : lw.wr_e)[htid]; L.wrd[H + htid] = (COORD ? lw.wd_c : lw.wd_e)[htid];   // visible after the first slot's first barrier
-    L.colv[htid] = (COORD ? lw.b7 : lw.b2)[htid] * (NPL == 3 ? 1.0f : (COORD ? lw.W7 : lw.W2).wh_scale); L.colv[H + htid] = (COORD ? lw.w5 : lw.wa)[htid];
-    const TileCtx tc = make_ctx<COORD>(lw, es, wave, lane, layer, lay.N);
-    const int E = w.totals[COORD ? 1 : 0];
-    TileWalk tw; tw.init((int)blockIdx.x + half * (int)gridDim.x, 2 * (int)gridDim.x, E, lay.max_n);        // (gridDim % 8 == 0: both halves' chunks lie in this XCD's range)
-    TileWalk other; other.init((int)blockIdx.x + (1 - half) * (int)gridDim.x, 2 * (int)gridDim.x, E, lay.max_n);
-    bool cont = tw.valid() || other.valid();                                                // wave-uniform and equal in all eight waves
-    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
-#if CMDGEN_STAMPS == 6 || CMDGEN_STAMPS == 9
-    st_t = __builtin_amdgcn_s_memtime();
-    const unsigned long long st_begin = st_t; int st_tiles = 0;
-#endif
-    RowPref pf; pf.nx_e0 = -1;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) { pf.nrow[u] = -1; pf.ncol[u] = -1; pf.nhop[u] = 255; pf.nd0[u] = 0.f; }
-    if (half == 1) lds_barrier();                                                           // the second half runs one phase behind
-    for (int slot = 0; cont; ++slot) {
-        const bool mine = tw.valid();
-        efrag bs[2][2][NPL];
-        if (mine) {
-#pragma unroll
-            for (int i = 0; i < 2 * NPL; ++i) bs[0][i & 1][i >> 1] = w_frag(tc.rw, lane, (int)(((unsigned)(i & 1) * NS + (unsigned)(i >> 1) * 64u) << 4));
-            if (wave == 0) {
-                index_phase<COORD>(L, lay, w, d, es, pf, tw, lane, layer, live_thr);
-                if (lane == 0) more_flag[slot & 1][half] = tw.more_after(L.meta[2]) ? 1 : 0;   // (lane 0 wrote meta[2] itself)
-            }
-        } else if (htid == 0) {
-            more_flag[slot & 1][half] = 0;
-        }
-        lds_barrier();
-        STAMP(0);
-        int ne = 0;
-        bool live = false;
-        if (mine) { ne = L.meta[2]; live = L.meta[1] != 0; }
-        if (live) {
-            tile_dispatch<COORD>(L, lay, w, d, tc, ne, bs, st_, st_t);
-        } else {
-            if (mine && htid == 0) atomicAdd(&w.counters[6], (unsigned long long)ne);      // dead tile
-#pragma unroll 1
-            for (int i = 0; i < TILE_BARRIERS; ++i) lds_barrier();
-        }
-        lds_barrier();
-        STAMP(4);
-        if (mine) {
-            tw.advance(ne);
-#if CMDGEN_STAMPS == 6 || CMDGEN_STAMPS == 9
-            ++st_tiles;
-#endif
-        }
-        // the partner wrote its flag of this slot at least one barrier ago (it is at most one phase away), and rewrites this parity two slots on
-        cont = (more_flag[slot & 1][0] | more_flag[slot & 1][1]) != 0;
-    }
-    if (half == 0) lds_barrier();
-#if CMDGEN_STAMPS == 6 || CMDGEN_STAMPS == 9
-    if (lane == 0 && (blockIdx.x & 1) == 0 && half == 0 && st_tiles > 0 && COORD == (CMDGEN_STAMP_COORD != 0)) {
-        for (int i = 0; i < 8; ++i) atomicAdd(&w.dbg[wave * 8 + i], st_[i]);
-        atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - st_begin);
-        atomicAdd(&w.dbg[40], 1ull);
-        if (wave == 0) atomicAdd(&w.dbg[41], (unsigned long long)st_tiles);
-    }
-#endif
 #undef STAMP
 #undef STAMPB
-}
-

@@ -79,10 +79,15 @@ __device__ __forceinline__ float sub_half_lo(float a, uint32_t p) {
 __device__ __forceinline__ float sub_half_hi(float a, uint32_t p) {
     float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(a)); return r;
 }
-// the two fp16 pieces of two floats, each piece packed {a, b}: 2 vector operations per element
+// the two fp16 pieces of two floats, each piece packed {a, b}: 1.5 vector operations per element (round 6: the residual a - (float)a0 is
+// formed AND rounded to fp16 by one v_fma_mixlo_f16 / v_fma_mixhi_f16 - the difference is exact in fp32, so the single rounding gives the
+// bits of the former v_fma_mix_f32 + v_cvt_pk_f16_f32 pair)
 __device__ __forceinline__ void split2_pair(float a, float b, uint32_t& p0, uint32_t& p1) {
     p0 = cvt_pk_f16(a, b);
-    p1 = cvt_pk_f16(sub_half_lo(a, p0), sub_half_hi(b, p0));
+    uint32_t r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p0), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(p0), "v"(b));
+    p1 = r;
 }
 // four consecutive k-values of one row -> the two fp16 planes (8 bytes each)
 __device__ __forceinline__ void split_store4_half(unsigned short* planes, int plane_elems, int off, const float4& v) {

@@ -40,13 +40,12 @@ namespace e128_bf3 {
 // launchers: true when the 128-row kernels took the launch (H = 256, split engine, sampler)
 #define E128_LAUNCH(NSP, COORD_, LIVE)                                                                                                              \
     do {                                                                                                                                            \
-        if (a.e128_pp) {                     /* the phase-locked driver: one 512-thread workgroup per CU */                                         \
-            if (a.pe_start) hipExtLaunchKernelGGL(NSP::k_edge128pp<COORD_>, dim3(a.n_cus), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE); \
-            else hipLaunchKernelGGL(NSP::k_edge128pp<COORD_>, dim3(a.n_cus), dim3(512), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE);    \
-        } else {                                                                                                                                    \
+        {                                                                                                                                           \
             const int grid = (a.e128_wgs >= 1 && a.e128_wgs <= 4 ? a.e128_wgs : 2) * a.n_cus;                                                       \
-            if (a.pe_start) hipExtLaunchKernelGGL(NSP::k_edge128<COORD_>, dim3(grid), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE); \
-            else hipLaunchKernelGGL(NSP::k_edge128<COORD_>, dim3(grid), dim3(256), 0, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE);         \
+            static bool lds_set = false;     /* (one flag per expansion = per kernel instantiation) */                                              \
+            if (!lds_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(NSP::k_edge128<COORD_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NSP::E128Lds)); lds_set = true; } \
+            if (a.pe_start) hipExtLaunchKernelGGL(NSP::k_edge128<COORD_>, dim3(grid), dim3(256), sizeof(NSP::E128Lds), s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE); \
+            else hipLaunchKernelGGL(NSP::k_edge128<COORD_>, dim3(grid), dim3(256), sizeof(NSP::E128Lds), s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, LIVE);         \
         }                                                                                                                                           \
     } while (0)
 bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s) {

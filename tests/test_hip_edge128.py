@@ -21,13 +21,11 @@ G12 = load_golden('g12_fullsize.npz')
 G13 = load_golden('g13_bounded.npz')
 
 
-@pytest.fixture(autouse=True, params=[(0, 2), (1, 2), (0, 0)], ids=['half_two_wgs', 'half_phase_locked', 'bf16x3_two_wgs'])
-def e128_driver(request, monkeypatch):
-    """every test of this file runs on both matrix engines of the 128-row kernels (two fp16 pieces per operand and three MFMAs per product,
-    the default where the model has an edge cutoff, forced here with half_engine = 2; three bf16 pieces and six: half_engine = 0) and on both drivers (two free-running 256-thread workgroups per CU; one
-    512-thread workgroup per CU whose halves are phase-locked one barrier apart: option e128_pp)"""
-    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'e128_pp', request.param[0])
-    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'half_engine', request.param[1])
+@pytest.fixture(autouse=True, params=[2, 0], ids=['half', 'bf16x3'])
+def e128_engine(request, monkeypatch):
+    """every test of this file runs on both matrix engines of the 128-row kernels: two fp16 pieces per operand and three MFMAs per product
+    (the default where the model has an edge cutoff, forced here with half_engine = 2), and three bf16 pieces and six (half_engine = 0)"""
+    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'half_engine', request.param)
     return request.param
 
 

@@ -149,7 +149,8 @@ def test_chain_on_an_overflowing_model_equals_the_bf16_engine_chain():
     assert st['nan_resets'] == ref_resets and st.get('half_engine_fallback')
     if ref_resets == 0:
         assert any('half matrix engine' in str(x.message) for x in w)
-    assert np.array_equal(got, want)
+    # (the two handles may pick other tiles - the choice depends on the engine - so sums differ in their last bits: the evaluation tolerance, types exact)
+    assert np.abs(got[:, :3] - want[:, :3]).max() <= EVAL_TOL * max(1.0, float(np.abs(want[:, :3]).max())) and np.array_equal(got[:, 3:], want[:, 3:])
     h.close()
     # inside the range: no second run, no warning
     cfg2, sd2, _ = dynamics_case(G2, NAME)
