@@ -712,7 +712,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
 static const char* const kOptionKeys[] = {
     "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "half_engine", "edge_fullk", "node64", "node16_split", "node16w",
     "dead_skip", "write_embed", "fused_step", "pocket_cache", "graph_steps",
-    "wgrad_split", "wgrad_tile", "wgrad_split_wgs128", "wgrad_split_wgs64", "wgrad_wgs", "dgrad_mt", "dgrad_tail", "wgrad_stream", "train_half", "dgrad_half", "wgrad_silu", "train_node16", "wgrad_k128", "small_wgrads"};
+    "wgrad_split", "wgrad_tile", "wgrad_split_wgs128", "wgrad_split_wgs64", "wgrad_wgs", "dgrad_mt", "dgrad_tail", "wgrad_stream", "train_half", "wgrad_silu", "train_node16", "wgrad_k128"};
 
 static void drop_graphs(cmdgen_handle* h) {
     // captured graphs bake the kernel choice in; a replay of the graph destroyed here may still be running

@@ -27,12 +27,6 @@ void cmdgen_wgrad_group(const WgradBatch& g, int K, bool bf16, hipStream_t s, bo
 struct RepackSplitT { int src_off, ld; void* dst; int transpose; };                                       // kernels_train.hip
 void tr_repack_split_t(const float* theta, const void* tab, int n, hipStream_t s);
 struct RepackHalf { int src_off, ld; void* dst; float* sc; int transpose; };                                 // kernels_train.hip
-struct HalfW { const void* w; const float* sc; };        // half pack of a transposed 256 x 256 block + {scale, 1 / scale} on the device
-void cmdgen_dgrad_split_h(int M, const float* A0, HalfW W0, const float* A1, HalfW W1, float* Y, bool accumulate, float div, const float* pre,
-                          hipStream_t s, HalfW W0b, float* Yb, bool accumulate_b, float div_b, const float* Yin, const float* rowdiv_b);
-void cmdgen_dgrad_tail_h(int E, const float* dY, HalfW Wt, const float* pre1, const int* row, const int* col, const float* d0,
-                         const float* Wcol, int ldw, const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ,
-                         float* dX, float* scratch, hipStream_t s);
 void tr_repack_half(const float* theta, const void* tab, int n_plain, int n, hipStream_t s);
 struct RepackHalf16 { int src_off, ld, out, in, row_split, col_shift; void* dst; float* sc; };            // kernels_train.hip
 void tr_repack_half16(const float* theta, const void* tab, int n, int max8, hipStream_t s);
@@ -61,9 +55,6 @@ struct CoordOutArgs { const int* row; const int* col; const float4* X; const flo
 void tr_head_bwd(int E, int H, const float* dphi, const float* w5, const float* pre7, float* dpre7, float* scratch, float* d_w5,
                  float* zero, size_t zero_floats, hipStream_t s, bool defer_reduce = false, const CoordOutArgs* co = nullptr);
 void tr_colsum(int E, int H, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s);
-struct SmallWgrad { const float* dy; const float* x; float* dw; float* db; int M, N, K, lddy, ldx, ldw; };      // kernels_train.hip: k_small_wgrads
-bool cmdgen_small_wgrads_fit(int M, int N);
-void cmdgen_small_wgrads(const SmallWgrad* probs, int n, hipStream_t s);
 void tr_center_per_sample(const Layout& lay, float* v, hipStream_t s);
 void tr_eps_bwd(int n_rows, int F, int row0, const float* deps, float* dvel, float* ddec, hipStream_t s);
 void tr_bwd_init(int Nl, int N, int P, int dyn, const float* deps, float* dX, float* ddec, float* dhfin, hipStream_t s);
@@ -139,7 +130,6 @@ struct TrainState {
     bool split_packs_valid = false;     // the last forward re-packed the transposed split fragments (backward may use them)
     int wsilu = 0;                      // which activations the last forward did NOT store (option wgrad_silu)
     bool fwd_on_half = false;           // the last forward's tile kernels ran on the half engine (fp16 range: a non-finite gradient after it skips the update)
-    bool half_packs_valid = false;      // ... and the half packs (forward edge kernels + the transposed blocks of the data gradients)
     bool bf16 = false;                  // GEMM operands in bf16 (fp32 accumulation); default exact fp32
     const float* theta = nullptr;       // parameters used by the last forward (backward reads the same)
     const float* xh_phar = nullptr; const float* xh_pocket = nullptr;
@@ -175,7 +165,6 @@ struct TrainState {
                      void *t_e0a, *t_e0b, *t_e2, *t_n0a, *t_n0b, *t_n2, *t_c0a, *t_c0b, *t_c2;
                      void *s_e2, *s_c2;          // split packs of edge_mlp.2 / coord_mlp.2 themselves: the forward's two edge kernels
                      void *h_e2, *h_c2; float *hs_e2, *hs_c2;
-                     HalfW th_e0a, th_e0b, th_e2, th_n0a, th_n0b, th_n2, th_c0a, th_c0b, th_c2;      // half packs of the transposed blocks (data gradients on the half engine)
                      void *h16_w3, *h16_w4, *h16_pqc, *h16_pqe; float *hs_w3, *hs_w4, *hs_pqc, *hs_pqe; };   // 16-row half packs of the node kernel (k_repack_half16)   // ... and their half-engine packs with the device-side {scale, 1 / scale} (k_repack_half)
     std::vector<PackBlk> pack;          // rd_e / rd_c: [2][H] radial column then d0 column of edge_mlp.0 / coord_mlp.0
     float *emb_wT = nullptr, *embo_wT = nullptr;
@@ -290,21 +279,7 @@ static int ensure_state(cmdgen_handle* h) {
                 };
                 hp(b.e2, &k.h_e2, &k.hs_e2); hp(b.c2, &k.h_c2, &k.hs_c2);
             }
-            t->n_half_fwd = (int)ht.size();         // the forward's entries come first: the transposed blocks are re-made only when the data gradients use them
-            for (size_t l = 0; l < U && !rc; ++l) {
-                TrainState::PackBlk& k = t->pack[l];
-                const ParamTable::Blk& b = tb.blk[l];
-                auto tp = [&](const PRef& r, int col0, HalfW* dst) {
-                    if (rc || !r.out) return;
-                    float* q = nullptr;
-                    rc = alloc((size_t)H * H + 4, &q); if (rc) return;
-                    dst->w = q; dst->sc = q + (size_t)H * H;
-                    ht.push_back(RepackHalf{(int)r.w + col0, r.in, q, q + (size_t)H * H, 1});
-                };
-                tp(b.e0, 0, &k.th_e0a); tp(b.e0, (int)H, &k.th_e0b); tp(b.e2, 0, &k.th_e2);
-                tp(b.n0, 0, &k.th_n0a); tp(b.n0, (int)H, &k.th_n0b); tp(b.n2, 0, &k.th_n2);
-                tp(b.c0, 0, &k.th_c0a); tp(b.c0, (int)H, &k.th_c0b); tp(b.c2, 0, &k.th_c2);
-            }
+            t->n_half_fwd = (int)ht.size();
             if (!rc) rc = dev_alloc(h, t->pack_allocs, &p, ht.size() * sizeof(RepackHalf), false);
             if (!rc) { t->half_tab = p; hipMemcpy(p, ht.data(), ht.size() * sizeof(RepackHalf), hipMemcpyHostToDevice); t->n_half = (int)ht.size(); }
             std::vector<RepackHalf16> h16;
@@ -482,7 +457,6 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     // the fragment-streaming tile kernels.  The parameters the optimizer has just updated are re-packed on the device.
     // the forward's two edge kernels on the half engine (two fp16 pieces, three MFMAs per product: cmdgen_split.h) wherever the sampler would use it
     const bool fwd_half = h->gemm_split && H == 256 && a.half_engine && a.edge_fullk && t->n_half > 0 && opt_of(h, "train_half", 1) != 0;
-    const bool dgrad_half = fwd_half && !t->bf16 && opt_of(h, "dgrad_half", 0) != 0;      // (built, parity-green, not faster: profiles/r05_ag)
     // ... and the node kernel as the sampler's eight-wave 16-row tile (k_node16w)
     // (option train_node16: 16-row tiles for the node kernel at EVERY size - the save-hook form of the node kernel exists on the half engine
     // for these tiles only; larger layouts otherwise fall back to the fp32-instruction k_node<H, 32 / 64, SAVE>)
@@ -493,8 +467,7 @@ extern "C" int cmdgen_train_forward(cmdgen_handle* h, const float* theta, const 
     tr_repack(theta, t->frag_tab, frag_partial ? 1 : t->n_frag, t->max_frag4, t->misc_tab, t->n_misc, t->max_misc, s);
     if (h->gemm_split || t->bf16) tr_repack_split_t(theta, t->split_tab, t->n_split, s);        // data gradients (and the forward's two
     t->split_packs_valid = (h->gemm_split || t->bf16) && t->n_split > 0;                         // edge kernels) on the bf16 matrix pipe
-    if (fwd_half) tr_repack_half(theta, t->half_tab, t->n_half_fwd, dgrad_half ? t->n_half : t->n_half_fwd, s);
-    t->half_packs_valid = dgrad_half;
+    if (fwd_half) tr_repack_half(theta, t->half_tab, t->n_half_fwd, t->n_half_fwd, s);
     if (node_half) tr_repack_half16(theta, t->half16_tab, t->n_half16, t->max_half16, s);
     HIPCHK(h, hipEventSynchronize(t->tot_ev));
     const int E = t->h_tot[0], Ec = t->h_tot[1];
@@ -623,9 +596,6 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     const bool sp = t->split_packs_valid && H == 256;                 // [.,256] x [256,256] data gradients on the bf16 matrix pipe:
     const int pcs = g_bf16 ? 1 : 3;                                   // three pieces per operand (fp32-accurate) or the leading one (bf16 operands)
     const bool tail_fused = sp && g_train_tune.dgrad_tail != 0;
-    // fp32-accurate data gradients on the half engine (row-scaled gradient rows, kernels_train.hip) where the forward made the half packs
-    const bool dgh = tail_fused && !g_bf16 && t->half_packs_valid;
-    const HalfW no_w{nullptr, nullptr};
     // weight / bias gradients leave the chain of data gradients for the second stream (SideStream above) where the buffers they read
     // rotate (the fused-tail path); ss.on = false: everything on the caller's stream, in the order written
     hipStream_t side = g_train_tune.wgrad_stream == 2 && t->ws_low ? t->ws_low : t->ws;
@@ -658,16 +628,11 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     };
     // small weight + bias gradients of the readout / embedding stages (encoders, decoders, the two embeddings): a k_sgemm + k_colsum pair per
     // Linear.  Readout stage: with the side stream's first batch.  Embedding stage (the pass's tail): each pair on a third stream as soon as its
-    // input exists.  (Option small_wgrads: all of a stage's pairs as ONE kernel, k_small_wgrads - built, parity-green, slower.)
-    std::vector<SmallWgrad> small;
+    // input exists.  (All of a stage's pairs as ONE kernel was built and is slower: profiles/r05_ar, removed in round 6.)
     SideStream ss3{s, t->ws_low, ss.on && t->ws_low != nullptr && side != t->ws_low, &t->evs2};      // a third stream for the embedding stage's small gradients
     bool tail_stage = false;
     auto small_wgrad = [&](const PRef& r, int in, int M, const float* dy, int lddy, const float* x, int ldx) {
         if (M <= 0) return;
-        if (cmdgen_small_wgrads_fit(r.out, in) && opt_of(h, "small_wgrads", 0) != 0 && small.size() < 8) {       // (one kernel for all of them: built, and slower - the same-address atomics of hundreds of workgroups; profiles/r05_ar)
-            small.push_back(SmallWgrad{dy, x, grad + r.w, r.has_bias ? grad + r.b : nullptr, r.out, in, M, lddy, ldx, r.in});
-            return;
-        }
         const PRef* rp = &r;
         if (tail_stage && ss3.on) {     // the pass's last stage: nothing follows to hide a serial tail - every pair starts as soon as its input exists, on a stream of its own
             hipStream_t q = ss3.fork();
@@ -675,12 +640,6 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             return;
         }
         defer([=](hipStream_t q) { g_bf16 = bf; linear_wgrad(grad, *rp, 0, in, M, dy, lddy, x, ldx, q); tr_colsum(M, rp->out, dy, lddy, nullptr, grad + rp->b, 1, q); });
-    };
-    auto flush_small = [&]() {
-        if (small.empty()) return;
-        const std::vector<SmallWgrad> batch = small;
-        small.clear();
-        defer([=](hipStream_t q) { cmdgen_small_wgrads(batch.data(), (int)batch.size(), q); });
     };
     // rotating buffers (side stream on): block k of the pass (k = 0 for block L-1) reads dL/dh_{l+1} in dhb[k % 3] and leaves dL/dh_l in
     // dhb[(k + 1) % 3]; dpre2 / dpre7 / dn / the two dP | dQ pairs by the parity of k.  Off: one buffer each, updated in place.
@@ -714,7 +673,6 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     linear_dgrad(theta, tb.pd0, 0, J, Nl, t->ddeca, 2 * P, t->dhfin, d.dyn, false, s);
     small_wgrad(tb.embo, H, N, t->dhfin, d.dyn, t->h + (size_t)L * d.S * NH, H);
     linear_dgrad(theta, tb.embo, 0, H, N, t->dhfin, d.dyn, dh0, H, false, s);
-    flush_small();
     flush_side();           // (none of what these read is written again in this pass)
     }
     const int S = d.S, U = L * S;
@@ -760,9 +718,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         // actB <- dpre7, d coord_mlp.4; also clears dP | dQ (hidden_nf is 64, 128 or 256: cmdgen_create)
         tr_head_bwd(Ec, H, t->dphi, theta + bc.c4.w, pre7, actB, pair ? part_c : t->tail_scratch, grad + bc.c4.w, dPc, pq_floats, s, pair, &co);
         edge_wgrad(bc.c2, actB, (t->wsilu & 2) ? pre6 : t->act6 + (size_t)l * t->eccap * H, Ec, (t->wsilu & 2) ? 1 : 0);      // weight and bias gradient of coord_mlp.2 (c1 = SiLU(pre6))
-        if (dgh) cmdgen_dgrad_tail_h(Ec, actB, pkc.th_c2, pre6, w.crow, w.ccol, w.cd0, theta + bc.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
-                                     dPc, dQc, t->dX, tail_c, s);
-        else if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
+        if (tail_fused)     // dpre6 = (dpre7 W7) SiLU'(pre6) and everything done with it, in one kernel: it never reaches HBM
             cmdgen_dgrad_tail(Ec, actB, pkc.t_c2, pre6, w.crow, w.ccol, w.cd0, pair ? pkc.rd_c : theta + bc.c0.w + 2 * H /* radial column: the forward's contiguous copy */, pair ? 1 : ld1, Xl,
                               d.norm_constant, t->dcd, Nm, dPc, dQc, grad + bc.c0.w + 2 * H, t->dX, tail_c, pcs, s, pair);
         if (pair) { float* gw = grad + bc.c4.w; float* gc = grad + bc.c0.w + 2 * H; defer([=](hipStream_t q) { tr_reduce_pair(Ec, H, part_c, gw, nullptr, tail_c, gc, ld1, q); }); }
@@ -773,8 +729,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
             tr_edge_tail_bwd(Ec, H, w.crow, w.ccol, t->actA, w.cd0, theta + bc.c0.w + 2 * H, ld1, Xl, d.norm_constant, t->dcd, Nm,
                              dPc, dQc, grad + bc.c0.w + 2 * H, t->dX, t->tail_scratch, s);
         }
-        if (dgh) cmdgen_dgrad_split_h(N, dPc, pkc.th_c0a, dQc, pkc.th_c0b, dh_in, true, 1.0f, nullptr, s, no_w, nullptr, false, 1.0f, nullptr, nullptr);
-        else if (sp) cmdgen_dgrad_split(N, dPc, pkc.t_c0a, dQc, pkc.t_c0b, dh_in, true, 1.0f, nullptr, s, pcs);
+        if (sp) cmdgen_dgrad_split(N, dPc, pkc.t_c0a, dQc, pkc.t_c0b, dh_in, true, 1.0f, nullptr, s, pcs);
         else {
             linear_dgrad(theta, bc.c0, 0, H, N, dPc, H, dh_in, H, true, s);
             linear_dgrad(theta, bc.c0, H, H, N, dQc, H, dh_in, H, true, s);
@@ -788,10 +743,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         defer_wgrad(b.n2, 0, H, dh_in, nact, true);
         flush_wgrads();
         if (u == 0) flush_side();       // the last GCL of the pass: its side work starts as early as it can (nothing comes after to hide it)
-        if (dgh) {
-            cmdgen_dgrad_split_h(N, dh_in, pk.th_n2, nullptr, no_w, dn, false, 1.0f, pre3, s, no_w, nullptr, false, 1.0f, nullptr, nullptr);
-            cmdgen_dgrad_split_h(N, dn, pk.th_n0a, nullptr, no_w, dh_out, true, 1.0f, nullptr, s, pk.th_n0b, t->dagg, false, d.norm_factor, dh_in, rowdiv);
-        } else if (sp) {
+        if (sp) {
             cmdgen_dgrad_split(N, dh_in, pk.t_n2, nullptr, nullptr, dn, false, 1.0f, pre3, s, pcs);
             cmdgen_dgrad_split(N, dn, pk.t_n0a, nullptr, nullptr, dh_out, true, 1.0f, nullptr, s, pcs,         // dh_out = dh_in + dpre3 W3[:, :H] and
                                pk.t_n0b, t->dagg, false, d.norm_factor, 0, dh_in, rowdiv);                      // dagg = dpre3 W3[:, H:] / nf: one launch
@@ -806,9 +758,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         tr_gate_bwd(E, H, w.erow, pre2, d.attention ? theta + b.att.w : nullptr, z, d.attention, t->dagg, actA, pair ? part_e : t->tail_scratch,
                     d.attention ? grad + b.att.w : nullptr, d.attention ? grad + b.att.b : nullptr, dPe, pq_floats, s, pair);
         edge_wgrad(b.e2, actA, (t->wsilu & 1) ? pre1 : t->act1 + (size_t)u * t->ecap * H, E, (t->wsilu & 1) ? 1 : 0);            // weight and bias gradient of edge_mlp.2 (m1 = SiLU(pre1))
-        if (dgh) cmdgen_dgrad_tail_h(E, actA, pk.th_e2, pre1, w.erow, w.ecol, w.ed0, theta + b.e0.w + 2 * H, ld1, Xl, d.norm_constant, nullptr, Nm,
-                                     dPe, dQe, t->dX, tail_e, s);
-        else if (tail_fused)
+        if (tail_fused)
             cmdgen_dgrad_tail(E, actA, pk.t_e2, pre1, w.erow, w.ecol, w.ed0, pair ? pk.rd_e : theta + b.e0.w + 2 * H, pair ? 1 : ld1, Xl, d.norm_constant, nullptr, Nm,
                               dPe, dQe, grad + b.e0.w + 2 * H, t->dX, tail_e, pcs, s, pair);
         if (pair) {
@@ -828,8 +778,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         defer_wgrad(b.e0, H, H, dQe, hl, false);
         flush_wgrads();
         blk_done[k] = flush_side();                 // the GCL's weight gradients: one fork
-        if (dgh) cmdgen_dgrad_split_h(N, dPe, pk.th_e0a, dQe, pk.th_e0b, dh_out, true, 1.0f, nullptr, s, no_w, nullptr, false, 1.0f, nullptr, nullptr);
-        else if (sp) cmdgen_dgrad_split(N, dPe, pk.t_e0a, dQe, pk.t_e0b, dh_out, true, 1.0f, nullptr, s, pcs);       // (dh_out = dh_in when the side stream is off)
+        if (sp) cmdgen_dgrad_split(N, dPe, pk.t_e0a, dQe, pk.t_e0b, dh_out, true, 1.0f, nullptr, s, pcs);       // (dh_out = dh_in when the side stream is off)
         else {
             linear_dgrad(theta, b.e0, 0, H, N, dPe, H, dh_out, H, true, s);
             linear_dgrad(theta, b.e0, H, H, N, dQe, H, dh_out, H, true, s);
@@ -851,7 +800,6 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     linear_dgrad(theta, tb.re2, 0, 2 * R, Np, dq, d.dyn, t->denca_p, 2 * R, false, s);
     tr_silu_bwd(t->denca_p, t->enc1_p, (size_t)Np * 2 * R, s);
     small_wgrad(tb.re0, R, Np, t->denca_p, 2 * R, t->xh_pocket + 3, ldq);
-    flush_small();
     flush_side();
     ss3.join();
     ss.join();

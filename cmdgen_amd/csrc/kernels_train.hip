@@ -847,147 +847,6 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_split(int M, const float* __re
     }
 }
 
-// ------------------------------------------------------------------------------------
-// The same data gradients on the HALF engine (cmdgen_split.h: two fp16 pieces per operand, three MFMAs per product) with full-K planes
-// (one load phase and one GEMM per source instead of two half-K passes): k_dgrad_split_h / k_dgrad_tail_h.  The weights come as half packs
-// of the transposed blocks with their device-side power-of-two scale (k_repack_half, transpose = 1).  The A operand is a GRADIENT, whose
-// magnitude nobody bounds - so every ROW of the tile is multiplied by its own power of two before the split: the row's largest element
-// lands in [2^13, 2^14) (fp16 ends at 65504), elements down to 2^-24 of it keep a piece, and what is dropped is <= 2^-22 of the row's
-// maximum per product - the size of the fp32 accumulation's own rounding.  The accumulator row r carries scale_w * scale_r; the epilogue
-// multiplies by the exact inverse.  Two sources (A0 W0 + A1 W1, one accumulator): one row scale for both, A1 additionally multiplied by
-// scale_w0 / scale_w1 (a power of two; the halves of one Linear differ by a factor of one or two).
-// ------------------------------------------------------------------------------------
-struct HalfW { const void* w; const float* sc; };        // half pack of a transposed 256 x 256 block + {scale, 1 / scale} on the device
-// planes: 2 x [32][256] fp16 (swizzled, cmdgen_split.h); rinv[32]: 1 / (scale_w0 * scale_r) per tile row.  Ends with a barrier.
-__device__ __forceinline__ void dgrad_tile_gemm_h(unsigned short* planes, float* rinv, int M, int row0, const float* __restrict__ A0, const HalfW W0,
-                                                  const float* __restrict__ A1, const HalfW W1, sf32x16 (&acc)[1][2]) {
-    constexpr int HH = 256;
-    const int tid = threadIdx.x, wave = tid >> 6, c4 = tid & 63;          // a wave loads whole rows: rows pass * 4 + wave, 16 bytes per lane
-    const HFragPtr f0 = hfrag_ptr(W0.w, HH / 16, 0, wave);
-    HCarry carry;
-    half_prefetch(f0, carry);
-    const float sw0 = W0.sc[0], iw0 = W0.sc[1];
-    const float ratio = A1 ? sw0 * W1.sc[1] : 1.0f;                        // scale_w0 / scale_w1
-    float4 v[8];
-    float rs[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int r = row0 + p * 4 + wave;
-        v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < M) v[p] = reinterpret_cast<const float4*>(A0 + (size_t)r * HH)[c4];
-    }
-#pragma unroll
-    for (int p = 0; p < 8; ++p) rs[p] = fmaxf(fmaxf(fabsf(v[p].x), fabsf(v[p].y)), fmaxf(fabsf(v[p].z), fabsf(v[p].w)));
-    if (A1) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int r = row0 + p * 4 + wave;
-            if (r < M) {
-                const float4 u = reinterpret_cast<const float4*>(A1 + (size_t)r * HH)[c4];
-                rs[p] = fmaxf(rs[p], ratio * fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))));
-            }
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        float m = rs[p];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        int e = 0;
-        if (m > 0.f && m < 3.0e38f) e = 14 - ((int)((__float_as_uint(m) >> 23) & 0xffu) - 126);       // m 2^e in [2^13, 2^14)
-        e = max(-100, min(100, e));
-        rs[p] = __uint_as_float((unsigned)(127 + e) << 23);
-        if (c4 == 0) rinv[p * 4 + wave] = iw0 * __uint_as_float((unsigned)(127 - e) << 23);
-    }
-#pragma unroll
-    for (int m = 0; m < 1; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const float sc = rs[p];
-        split_store4_swz_half(planes, p * 4 + wave, c4, make_float4(v[p].x * sc, v[p].y * sc, v[p].z * sc, v[p].w * sc));
-    }
-    __syncthreads();
-    if (A1) {       // the second source's rows are requested under the first product (they were read once for the row maxima: L2 hits)
-        const HFragPtr f1 = hfrag_ptr(W1.w, HH / 16, 0, wave);
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int r = row0 + p * 4 + wave;
-            v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < M) v[p] = reinterpret_cast<const float4*>(A1 + (size_t)r * HH)[c4];
-        }
-        tile_gemm_planes_swz32_half(planes, f0, f1, acc, carry);
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const float sc = rs[p] * ratio;
-            split_store4_swz_half(planes, p * 4 + wave, c4, make_float4(v[p].x * sc, v[p].y * sc, v[p].z * sc, v[p].w * sc));
-        }
-        __syncthreads();
-        tile_gemm_planes_swz32_half(planes, f1, f1, acc, carry);
-    } else {
-        tile_gemm_planes_swz32_half(planes, f0, f0, acc, carry);
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256, 3) void k_dgrad_split_h(int M, const float* __restrict__ A0, HalfW W0, const float* __restrict__ A1, HalfW W1,
-                                                          float* Y, int accumulate, float div, const float* __restrict__ pre, HalfW W0b,
-                                                          float* __restrict__ Yb, int accumulate_b, float div_b, const float* Yin,
-                                                          const float* __restrict__ rowdiv_b) {
-    // arguments as k_dgrad_split (gridDim.y = 2: the second product W0b -> Yb of the same A0)
-    const float* rowdiv = nullptr;
-    if (blockIdx.y) { W0 = W0b; Y = Yb; Yin = Yb; accumulate = accumulate_b; div = div_b; rowdiv = rowdiv_b; }
-    constexpr int MT = 32, HH = 256, LDO = HH + 4;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[32 * LDO * 4];          // two fp16 planes (32 KB) / the fp32 output image (33 KB)
-    __shared__ float rinv[MT];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int row0 = blockIdx.x * MT;
-    sf32x16 acc[1][2];
-    dgrad_tile_gemm_h(reinterpret_cast<unsigned short*>(smem), rinv, M, row0, A0, W0, A1, W1, acc);
-    float* obuf = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            obuf[row * LDO + wave * 64 + n * 32 + (lane & 31)] = acc[0][n][r] * rinv[row];
-        }
-    __syncthreads();
-    const int q4 = tid & 63, rs = tid >> 6;          // a wave writes one row per pass
-    float4 pv[8], yv[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int row = row0 + p * 4 + rs;
-        if (row < M) {
-            if (pre) pv[p] = reinterpret_cast<const float4*>(pre + (size_t)row * HH)[q4];
-            if (accumulate) yv[p] = reinterpret_cast<const float4*>(Yin + (size_t)row * HH)[q4];
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int rl = p * 4 + rs, row = row0 + rl;
-        if (row < M) {
-            float4 x = *reinterpret_cast<const float4*>(obuf + rl * LDO + 4 * q4);
-            if (rowdiv) { const float dvr = rowdiv[row]; x.x = x.x / dvr; x.y = x.y / dvr; x.z = x.z / dvr; x.w = x.w / dvr; }
-                else if (div != 1.0f) { x.x = x.x / div; x.y = x.y / div; x.z = x.z / div; x.w = x.w / div; }
-            if (pre) { x.x *= dsilu(pv[p].x); x.y *= dsilu(pv[p].y); x.z *= dsilu(pv[p].z); x.w *= dsilu(pv[p].w); }
-            if (accumulate) { x.x += yv[p].x; x.y += yv[p].y; x.z += yv[p].z; x.w += yv[p].w; }
-            reinterpret_cast<float4*>(Y + (size_t)row * HH)[q4] = x;
-        }
-    }
-}
-void cmdgen_dgrad_split_h(int M, const float* A0, HalfW W0, const float* A1, HalfW W1, float* Y, bool accumulate, float div, const float* pre,
-                          hipStream_t s, HalfW W0b, float* Yb, bool accumulate_b, float div_b, const float* Yin, const float* rowdiv_b) {
-    if (M <= 0) return;
-    if (!Yin) Yin = Y;
-    hipLaunchKernelGGL(k_dgrad_split_h, dim3((M + 31) / 32, W0b.w ? 2 : 1), dim3(256), 0, s, M, A0, W0, A1, W1, Y, accumulate ? 1 : 0, div, pre,
-                       W0b, Yb, accumulate_b ? 1 : 0, div_b, Yin, rowdiv_b);
-}
-
 // split fragment packs of transposed weight sub-blocks: dst = pack of Wt, Wt[o'][k] = theta[src_off + k * ld + o'] (o', k < 256)
 struct RepackSplitT { int src_off, ld; void* dst; int transpose; };      // transpose = 0: the pack of W itself (forward: Y = X W^T)
 __global__ void k_repack_split_t(const float* __restrict__ theta, const RepackSplitT* __restrict__ tab) {
@@ -1585,109 +1444,6 @@ __global__ __launch_bounds__(256, 3) void k_dgrad_tail(int M, const float* __res
 #undef TSTAMP
 }
 
-// the half-engine form (dgrad_tile_gemm_h: full-K planes, row-scaled gradient rows); everything behind the GEMM as k_dgrad_tail
-__global__ __launch_bounds__(256, 3) void k_dgrad_tail_h(int M, const float* __restrict__ A0, HalfW W0,
-                                                         const float* __restrict__ pre, TailArgs ta) {
-    constexpr int MT = 32, HH = 256;
-    constexpr int LDO = HH + 4, SMEM = 32 * LDO * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
-    __shared__ float rinv[MT];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int row0 = blockIdx.x * MT;
-    // the tail's per-edge scalars: requested before the GEMM, used after it
-    const int e0 = row0 + wave * 8, ne = max(0, min(8, M - e0));
-    int my_i = -1, my_j = -1; float my_r = 0.f, my_d0 = 0.f, dxl = 0.f, dyl = 0.f, dzl = 0.f;
-    if (lane < ne) {
-        my_i = ta.row[e0 + lane]; my_j = ta.col[e0 + lane]; my_d0 = ta.d0[e0 + lane];
-        const float4 a = ta.X[my_i], b = ta.X[my_j];
-        dxl = a.x - b.x; dyl = a.y - b.y; dzl = a.z - b.z;
-        my_r = dxl * dxl + dyl * dyl + dzl * dzl;
-    }
-    float wr[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wr[q] = ta.Wcol[(size_t)(lane + 64 * q) * ta.ldw];
-    sf32x16 acc[1][2];
-    dgrad_tile_gemm_h(reinterpret_cast<unsigned short*>(smem), rinv, M, row0, A0, W0, nullptr, HalfW{nullptr, nullptr}, acc);
-    float* obuf = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int orow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            obuf[orow * LDO + wave * 64 + n * 32 + (lane & 31)] = acc[0][n][r] * rinv[orow];
-        }
-    __syncthreads();
-    // SiLU'(pre1) on this wave's rows 8 wave .. 8 wave + 7 (the same rows its tail walks: no barrier in between)
-    {
-        float4 pv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if (k < ne) pv[k] = reinterpret_cast<const float4*>(pre + (size_t)(e0 + k) * HH)[lane];
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k < ne) {
-                float4* cell = reinterpret_cast<float4*>(obuf + (wave * 8 + k) * LDO + 4 * lane);
-                float4 x = *cell;
-                x.x *= dsilu(pv[k].x); x.y *= dsilu(pv[k].y); x.z *= dsilu(pv[k].z); x.w *= dsilu(pv[k].w);
-                *cell = x;
-            }
-    }
-    float accR[4] = {0.f, 0.f, 0.f, 0.f}, accD[4] = {0.f, 0.f, 0.f, 0.f}, run[4] = {0.f, 0.f, 0.f, 0.f};
-    float my_gr = 0.f;
-    int cur = __shfl(my_i, 0);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (k < ne) {                                        // wave-uniform
-            const int i = __shfl(my_i, k), j = __shfl(my_j, k);
-            const float r = __shfl(my_r, k), dd = __shfl(my_d0, k);
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = obuf[(wave * 8 + k) * LDO + lane + 64 * q];
-            if (i != cur) {                                  // the receiver's run ended: one add per run
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { atomicAdd(ta.dP + (size_t)cur * HH + lane + 64 * q, run[q]); run[q] = 0.f; }
-                cur = i;
-            }
-            float dot = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                accR[q] += r * v[q]; accD[q] += dd * v[q]; run[q] += v[q]; dot += v[q] * wr[q];
-#if CMDGEN_TAIL_EXP != 1
-                atomicAdd(ta.dQ + (size_t)j * HH + lane + 64 * q, v[q]);
-#endif
-            }
-            const float gr = wave_sum(dot);                  // dL/d radial of this edge
-            if (lane == k) my_gr = gr;
-        }
-    }
-    if (ne > 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) atomicAdd(ta.dP + (size_t)cur * HH + lane + 64 * q, run[q]);
-    }
-    if (lane < ne && my_i != my_j) {                         // geometry adjoint, one lane per edge (as k_geom_bwd)
-        const float sq = sqrtf(my_r + 1e-8f), den = sq + ta.norm_constant;
-        float gx = 0.f, gy = 0.f, gz = 0.f, gr = my_gr;
-        if (ta.dcd) {
-            const float4 d = ta.dcd[e0 + lane];
-            gx = d.x / den; gy = d.y / den; gz = d.z / den;
-            const float dden = -(d.x * dxl + d.y * dyl + d.z * dzl) / (den * den);
-            gr += dden * 0.5f / sq;
-        }
-        gx += 2.0f * dxl * gr; gy += 2.0f * dyl * gr; gz += 2.0f * dzl * gr;
-        if (my_i < ta.n_moving) { float* p = ta.dX + (size_t)my_i * 4; atomicAdd(p, gx); atomicAdd(p + 1, gy); atomicAdd(p + 2, gz); }
-        if (my_j < ta.n_moving) { float* p = ta.dX + (size_t)my_j * 4; atomicAdd(p, -gx); atomicAdd(p + 1, -gy); atomicAdd(p + 2, -gz); }
-    }
-    // column sums: per-workgroup partials to the scratch row (k_tail_colsum_reduce adds them up)
-    __syncthreads();                                         // every wave is done with the output image
-    float* red = obuf;                                       // [2][4][256]
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { red[(0 * 4 + wave) * 256 + lane + 64 * q] = accR[q]; red[(1 * 4 + wave) * 256 + lane + 64 * q] = accD[q]; }
-    __syncthreads();
-    for (int idx = tid; idx < 2 * HH; idx += 256) {
-        const int which = idx / HH, c = idx - which * HH;
-        ta.scratch[((size_t)blockIdx.x * 2 + which) * HH + c] =
-            (red[(which * 4 + 0) * 256 + c] + red[(which * 4 + 1) * 256 + c]) + (red[(which * 4 + 2) * 256 + c] + red[(which * 4 + 3) * 256 + c]);
-    }
-}
 
 // dWcol[which + c * ldw] += sum over workgroups of scratch[wg][which][c].  grid (H / 64, 2, slices): every workgroup sums
 // one slice of the partial rows for 64 columns (4 rows in flight per column) and adds its result with one atomic.
@@ -1707,82 +1463,6 @@ __global__ __launch_bounds__(256) void k_tail_colsum_reduce(int nwg, int H, cons
     if (part == 0 && c < H) atomicAdd(dWcol + which + (size_t)c * ldw, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
-// ------------------------------------------------------------------------------------
-// k_small_wgrads: the weight AND bias gradients of up to eight SMALL Linears (encoders, decoders, the two embeddings: at most 256 x 40
-// weights, different row counts) in ONE launch: dW_p[M][N] += dY_p^T X_p, db_p[M] += column sums of dY_p.  As ten k_sgemm / k_colsum launches
-// of 5-15 us each they were the tail of the backward pass (profiles/r05_aq_train_chain.txt: 110 us on the side stream after the main
-// stream's last kernel).  A workgroup takes 128 rows of one problem in sub-chunks of 32 staged in LDS; thread m owns row m of dW in
-// registers and adds it once with atomics; any leading dimensions / alignment (scalar loads).
-// ------------------------------------------------------------------------------------
-struct SmallWgrad { const float* dy; const float* x; float* dw; float* db; int M, N, K, lddy, ldx, ldw; };
-struct SmallWgradBatch { SmallWgrad p[8]; int n; int first_wg[9]; };      // first_wg: prefix sums of ceil(K_p / SW_ROWS)
-constexpr int SW_ROWS = 32, SW_SUB = 32, SW_MAXM = 256, SW_MAXN = 40;       // (one sub-chunk per workgroup: every load of a workgroup is in flight at once)
-__global__ __launch_bounds__(256) void k_small_wgrads(SmallWgradBatch b) {
-    // thread m owns row m of dW (N <= 40 accumulators in registers): per k one conflict-free read of dY[k][m] and N / 4 broadcast reads of X[k][:]
-    __shared__ float sdy[SW_SUB][SW_MAXM];
-    __shared__ __attribute__((aligned(16))) float sx[SW_SUB][SW_MAXN];
-    // (the problem is picked with selects: indexing the by-value argument with a run-time index would put the whole table in scratch)
-    SmallWgrad P = b.p[0];
-    int wg0 = 0;
-#pragma unroll
-    for (int i = 1; i < 8; ++i)
-        if (i < b.n && (int)blockIdx.x >= b.first_wg[i]) { P = b.p[i]; wg0 = b.first_wg[i]; }
-    const int M = P.M, N = P.N, tid = threadIdx.x;
-    const int k_begin = ((int)blockIdx.x - wg0) * SW_ROWS, k_end = min(P.K, k_begin + SW_ROWS);
-    float acc[SW_MAXN], bacc = 0.f;
-#pragma unroll
-    for (int n = 0; n < SW_MAXN; ++n) acc[n] = 0.f;
-    const int n4 = (N + 3) / 4;
-    for (int k0 = k_begin; k0 < k_end; k0 += SW_SUB) {
-        const int kn = min(SW_SUB, k_end - k0);
-        {   // all loads of the sub-chunk first (registers), then the LDS stores: one round trip, not one per unrolled group
-            float rdy[SW_SUB], rx[SW_SUB];
-#pragma unroll
-            for (int k = 0; k < SW_SUB; ++k) {
-                rdy[k] = (tid < M && k < kn) ? P.dy[(size_t)(k0 + k) * P.lddy + tid] : 0.f;
-                rx[k] = (tid < N && k < kn) ? P.x[(size_t)(k0 + k) * P.ldx + tid] : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < SW_SUB; ++k) {
-                if (tid < M) sdy[k][tid] = rdy[k];
-                if (tid < SW_MAXN) sx[k][tid] = rx[k];
-            }
-        }
-        __syncthreads();
-        if (tid < M) {
-#pragma unroll 4
-            for (int k = 0; k < SW_SUB; ++k) {
-                const float a = sdy[k][tid];
-                bacc += a;
-#pragma unroll
-                for (int j = 0; j < SW_MAXN / 4; ++j) {
-                    if (j < n4) {                                    // wave-uniform
-                        const float4 xv = *reinterpret_cast<const float4*>(&sx[k][4 * j]);
-                        acc[4 * j] = __fmaf_rn(a, xv.x, acc[4 * j]); acc[4 * j + 1] = __fmaf_rn(a, xv.y, acc[4 * j + 1]);
-                        acc[4 * j + 2] = __fmaf_rn(a, xv.z, acc[4 * j + 2]); acc[4 * j + 3] = __fmaf_rn(a, xv.w, acc[4 * j + 3]);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (tid < M) {
-#pragma unroll
-        for (int n = 0; n < SW_MAXN; ++n) if (n < N) atomicAdd(P.dw + (size_t)tid * P.ldw + n, acc[n]);
-        if (P.db) atomicAdd(P.db + tid, bacc);
-    }
-}
-bool cmdgen_small_wgrads_fit(int M, int N) { return M <= SW_MAXM && N <= SW_MAXN; }
-void cmdgen_small_wgrads(const SmallWgrad* probs, int n, hipStream_t s) {
-    SmallWgradBatch b; b.n = 0; b.first_wg[0] = 0;
-    for (int i = 0; i < n; ++i) {
-        if (probs[i].K <= 0) continue;
-        b.p[b.n] = probs[i];
-        b.first_wg[b.n + 1] = b.first_wg[b.n] + (probs[i].K + SW_ROWS - 1) / SW_ROWS;
-        ++b.n;
-    }
-    if (b.n) hipLaunchKernelGGL(k_small_wgrads, dim3(b.first_wg[b.n]), dim3(256), 0, s, b);
-}
 
 // out[c * ldo] += sum_e s[e] * X[e][c]   (s may be null = 1): bias gradients, radial / d0 column gradients, att and
 // coordinate-head weight gradients.  One workgroup per 256-row chunk, one column per thread (coalesced rows).
@@ -2344,14 +2024,6 @@ void cmdgen_dgrad_tail(int E, const float* dY, const void* Wt, const float* pre1
     if (!defer_reduce) hipLaunchKernelGGL(k_tail_colsum_reduce, dim3(4, 2, min(32, (nwg + 15) / 16)), dim3(256), 0, s, nwg, 256, scratch, dWcol, ldw);
 }
 size_t tr_edge_tail_scratch_floats(size_t E, size_t H) { return ((E + 4 * TAIL_EPW - 1) / (4 * TAIL_EPW)) * 2 * H; }
-void cmdgen_dgrad_tail_h(int E, const float* dY, HalfW Wt, const float* pre1, const int* row, const int* col, const float* d0,
-                         const float* Wcol, int ldw, const float4* X, float nc, const float4* dcd, int n_moving, float* dP, float* dQ,
-                         float* dX, float* scratch, hipStream_t s) {
-    // (the partial sums are reduced by the caller's tr_reduce_pair, as cmdgen_dgrad_tail with defer_reduce)
-    if (E <= 0) return;
-    TailArgs ta{row, col, d0, Wcol, ldw, X, nc, dcd, n_moving, dP, dQ, scratch, dX, nullptr};
-    hipLaunchKernelGGL(k_dgrad_tail_h, dim3((E + 31) / 32), dim3(256), 0, s, E, dY, Wt, pre1, ta);
-}
 void tr_colsum(int E, int ncols, const float* X, int ldx, const float* sv, float* out, int ldo, hipStream_t s) {
     if (!E) return;
     if (ncols % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ncols <= 256)

@@ -433,12 +433,12 @@ int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16);
  *                        "wgrad_stream" 0|1|2 (weight / bias gradients and partial-sum reductions on the handle's second stream beside the chain
  *                        of data gradients; 2: at the lowest stream priority; default 1), "train_half" 0|1|2 (the training forward's tile kernels on
  *                        the half engine, packs and scales re-made on the device every step; 2: the two edge kernels only; default 1 where
- *                        "half_engine" resolves on), "dgrad_half" 0|1 (data gradients on the half engine with row-scaled gradient rows; default 0),
+ *                        "half_engine" resolves on),
  *                        "wgrad_silu" 0..3 (bit 0 / 1: SiLU(pre1) / SiLU(pre6) are not stored by the forward but formed by the second layer's
  *                        weight gradient; default 3 with bf16 operands, 0 for fp32 results), "wgrad_k128" (rows x 128-tiles of a launch from which a
  *                        three-piece weight gradient uses 128 x 128 tiles; default 131072), "train_node16" 0|1 (16-row node tiles in the training
- *                        forward at every batch size; default 1), "small_wgrads" 0|1 (all small weight / bias gradients of a stage in one kernel;
- *                        built, slower: default 0)
+ *                        forward at every batch size; default 1)
+ *   (round 6: the options whose A/B lost - "e128_pp", "dgrad_half", "small_wgrads" - left the build: profiles/r06_removed_experiments.patch)
  * cmdgen_get_option: *value = the stored value, *is_set = 0 when the key is not set (either pointer may be NULL).
  * Unknown keys: CMDGEN_EINVAL. */
 int cmdgen_set_option(cmdgen_handle* h, const char* key, int64_t value, int32_t unset);
