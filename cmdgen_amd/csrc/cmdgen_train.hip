@@ -584,6 +584,22 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     g_bf16 = t->bf16; g_train_tune = h->tune; g_train_tune.dbg = h->work.dbg;
     hipStream_t s = (hipStream_t)stream;
     h->last_stream = s;
+    // The pass forks work onto the handle's side streams and joins them with events.  With the LEGACY DEFAULT stream as the caller's stream that
+    // protocol is not reliable (round 6: with a second handle alive in the process, gradients of the side streams' tensors came out 1e-4 ... 1e-3
+    // off now and then; any other stream as the caller's: never - tools/train_grad_diag4.py, profiles/r06_d).  As the sampler does for its chains,
+    // such a call runs on a stream of the handle's own, ordered behind the caller's pending work and in front of its later work by events.
+    const hipStream_t caller = s;
+    const bool bridged = caller == nullptr && g_train_tune.wgrad_stream != 0 && g_train_tune.dgrad_tail != 0;
+    if (bridged) {
+        if (!h->own_stream) {
+            HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+        }
+        HIPCHK(h, hipEventRecord(h->ev_in, caller));
+        HIPCHK(h, hipStreamWaitEvent(h->own_stream, h->ev_in, 0));
+        s = h->own_stream;
+    }
     const Dims& d = h->dims;
     const float* theta = t->theta;
     const int N = h->lay.N, Nl = h->lay.Nl, Np = h->lay.Np, H = d.H, L = d.L, P = d.P, R = d.R, J = d.J;
@@ -785,7 +801,12 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
         }
         }
     }
-    if (last_stage < L + 1) { ss.join(); HIPCHK(h, hipGetLastError()); return CMDGEN_OK; }
+    if (last_stage < L + 1) {
+        ss.join();
+        if (bridged) { HIPCHK(h, hipEventRecord(h->ev_out, s)); HIPCHK(h, hipStreamWaitEvent(caller, h->ev_out, 0)); }
+        HIPCHK(h, hipGetLastError());
+        return CMDGEN_OK;
+    }
     // embedding and encoders
     tail_stage = true;
     float* dhE = dhb[(L * d.S) % 3];
@@ -803,6 +824,10 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     flush_side();
     ss3.join();
     ss.join();
+    if (bridged) {
+        HIPCHK(h, hipEventRecord(h->ev_out, s));
+        HIPCHK(h, hipStreamWaitEvent(caller, h->ev_out, 0));
+    }
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;
 }

@@ -1061,6 +1061,9 @@ def test_training_step_leaves_the_half_range_and_repeats_on_the_bf16_engine():
             info = tr.training_step(batch, t_int=t_int, eps=eps)
         assert np.isfinite(float(info['loss'])) and np.isfinite(tr.last_grad_norm)
         assert tr.step_count == 1 and not torch.equal(tr.theta, theta0) and bool(torch.isfinite(tr.theta).all())
-        res[th] = (float(info['loss']), tr.theta.cpu().numpy().copy())
+        res[th] = (float(info['loss']), tr.theta.cpu().numpy().copy(), float(tr.last_grad_norm))
     assert abs(res[None][0] - res[0][0]) <= 1e-6 * max(1.0, abs(res[0][0]))
-    assert np.array_equal(res[None][1], res[0][1]) or np.abs(res[None][1] - res[0][1]).max() <= 1e-6
+    assert abs(res[None][2] - res[0][2]) <= 1e-4 * res[0][2]
+    # (the first AdamW step moves every parameter by ~lr * g / |g|: where g is at the rounding level the two runs' updates may differ by up to 2 lr)
+    d = np.abs(res[None][1] - res[0][1])
+    assert d.max() <= 2.1e-3 and np.mean(d > 1e-6) < 1e-3, (float(d.max()), float(np.mean(d > 1e-6)))
