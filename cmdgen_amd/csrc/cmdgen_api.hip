@@ -483,6 +483,10 @@ static void pick_tiles(cmdgen_handle* h) {
     };
     h->edge_grid = grid_for(e_est, h->edge_mt);
     h->coord_grid = grid_for(ec_est, h->coord_mt);
+    // the 128-row kernels' fused main loop pays once a workgroup (two per CU) walks more than one tile: same-box chains, profiles/r06_f
+    // (64 C-alpha pockets, one 96-row tile per workgroup: -1.6 %; 96 pockets, one 128-row tile: +1.2 %; 128 pockets: +2 %; 256: +3 %; full-atom: +8 %)
+    h->e128_fused = (e_est > 160.0 * h->n_cus ? 1 : 0) | (ec_est > 160.0 * h->n_cus ? 2 : 0);
+    if (opt_set(h, "e128_fused")) h->e128_fused = (int)opt_of(h, "e128_fused", 3) & 3;
     if (opt_set(h, "edge_wgs_per_cu")) h->edge_grid = (int)opt_of(h, "edge_wgs_per_cu", 2) * h->n_cus;
     if (opt_set(h, "coord_wgs_per_cu")) h->coord_grid = (int)opt_of(h, "coord_wgs_per_cu", 2) * h->n_cus;
     if (h->node_mt != 64 && h->node_mt != 32 && h->node_mt != 16) h->node_mt = 64;
@@ -663,6 +667,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
     if (h->dims.sin && h->dims.H == 512) { if (a.edge_mt > 32) a.edge_mt = 32; if (a.coord_mt > 32) a.coord_mt = 32; }   // (64-row tiles + the 55 KB of feature columns exceed the LDS)
     a.edge_fullk = (sp256 && opt_of(h, "edge_fullk", 1) != 0) ? 1 : 0;
     a.e128_wgs = (int)opt_of(h, "e128_wgs_per_cu", 2);
+    a.e128_fused = h->e128_fused;
     {   // the half engine's operands end at 65504: by default only where the radial features are bounded by a cutoff (every shipped config);
         // 2 forces it, 0 keeps the three-piece bf16 split everywhere
         const int he = (int)opt_of(h, "half_engine", 1);
@@ -710,7 +715,7 @@ EvalLaunch make_launch(cmdgen_handle* h) {
 // options
 // ---------------------------------------------------------------------------------
 static const char* const kOptionKeys[] = {
-    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "half_engine", "edge_fullk", "node64", "node16_split", "node16w",
+    "node_mt", "edge_mt", "coord_mt", "embed_mt", "edge_wgs_per_cu", "coord_wgs_per_cu", "e128_wgs_per_cu", "e128_fused", "half_engine", "edge_fullk", "node64", "node16_split", "node16w",
     "dead_skip", "write_embed", "fused_step", "pocket_cache", "graph_steps",
     "wgrad_split", "wgrad_tile", "wgrad_split_wgs128", "wgrad_split_wgs64", "wgrad_wgs", "dgrad_mt", "dgrad_tail", "wgrad_stream", "train_half", "wgrad_silu", "train_node16", "wgrad_k128"};
 
@@ -1375,6 +1380,7 @@ extern "C" int cmdgen_query(cmdgen_handle* h, const char* key, int64_t* value) {
     const EvalLaunch a = make_launch(h);
     if (k == "node_mt") *value = a.node_mt;
     else if (k == "edge_mt") *value = a.edge_mt;
+    else if (k == "e128_fused") *value = a.e128_fused;
     else if (k == "coord_mt") *value = a.coord_mt;
     else if (k == "edge_grid") *value = a.edge_grid;
     else if (k == "coord_grid") *value = a.coord_grid;

@@ -241,6 +241,7 @@ struct EvalLaunch {             // everything one evaluation's launches need (ho
     int save_split = 0;         // with `save`: W2 / W7 carry split packs, the two edge kernels may use them (H = 256)
     int write_embed = 1;        // 1: pass 2 of the radius graph and k_embed share a launch (k_write_embed) where both fit (option "write_embed")
     int e128_wgs = 2;           // workgroups per CU of the 128-row edge kernels (kernels_edge128.hip)
+    int e128_fused = 3;         // bit 0 / 1: the 128-row message / coordinate kernel runs its fused main loop (half engine; lists long enough for more than one tile per workgroup)
     int half_engine = 1;        // 1: split-engine kernels that have a HALF form (two fp16 pieces per operand, three MFMAs per product; cmdgen_split.h) use it
 };
 // weight unit of block l's launches (EvalLaunch::unit), and the has_next argument of its node kernel: bit 0 = another unit follows

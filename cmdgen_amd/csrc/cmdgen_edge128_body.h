@@ -22,7 +22,7 @@ constexpr int H = 256;
 #define CMDGEN_E128_MT 128
 #endif
 #ifndef CMDGEN_E128_FUSED
-#define CMDGEN_E128_FUSED 1     // half engine: the build of quarter q + 1 is issued INSIDE the GEMM over quarter q (double-buffered planes; see x_main)
+#define CMDGEN_E128_FUSED 0     // 1 (half engine; set by kernels_edge128.hip): the build of quarter q + 1 is issued INSIDE the GEMM over quarter q (double-buffered planes; see x_main)
 #endif
 constexpr int MT = CMDGEN_E128_MT;      // rows per tile (at most): 128, 96 or 64
 constexpr int MTL = 128;                // rows the per-tile index arrays hold (the index phase handles two rows per lane of wave 0)

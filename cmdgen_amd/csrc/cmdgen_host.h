@@ -42,6 +42,7 @@ struct cmdgen_handle {
     int64_t ecap = 0, eccap = 0;
     int64_t cap_B = 0, cap_Nl = 0, cap_Np = 0, cap_N = 0, cap_e = 0, cap_ec = 0;   // allocated capacities of the workspaces
     int edge_grid = 512, coord_grid = 256;
+    int e128_fused = 3;                    // bit 0 / 1: fused main loop of the 128-row message / coordinate kernel (pick_tiles)
     int n_cus = 256;
     int node_mt = 64, edge_mt = 64, coord_mt = 64;   // rows per tile, chosen in cmdgen_set_layout
     bool gemm_split = true;                // tiles of >= 32 rows multiply on the bf16 matrix pipe (cmdgen_set_gemm_mode)

@@ -23,10 +23,20 @@
 #include "cmdgen_dev.h"
 #include <hip/hip_ext.h>
 
+// half engine, twice: the FUSED main loop (the next quarter's build inside the GEMM; long lists) and the plain one (build -> barrier -> GEMM -> barrier;
+// lists that give a workgroup a single tile - 64 C-alpha pockets - where the unrolled fused loop's larger code and prologue cost 1-2 %: profiles/r06_f)
 #define E128_NPL 2
+#define CMDGEN_E128_FUSED 1
 namespace e128_half {
 #include "cmdgen_edge128_body.h"
 }
+#undef CMDGEN_E128_FUSED
+#undef E128_MFMA
+#define CMDGEN_E128_FUSED 0
+namespace e128_half_u {
+#include "cmdgen_edge128_body.h"
+}
+#undef CMDGEN_E128_FUSED
 #undef E128_NPL
 #undef E128_MFMA
 #define E128_NPL 3
@@ -51,13 +61,15 @@ namespace e128_bf3 {
 bool cmdgen_launch_msg128(const EvalLaunch& a, int l, hipStream_t s) {
     const WPack& W = a.layers[unit_of(a, l)].W2;
     if (a.edge_mt != 128 || a.d.H != 256 || !a.split || a.save || !W.ws) return false;
-    if (a.half_engine && W.wh) E128_LAUNCH(e128_half, false, a.live_thr); else E128_LAUNCH(e128_bf3, false, a.live_thr);
+    if (a.half_engine && W.wh) { if (a.e128_fused & 1) E128_LAUNCH(e128_half, false, a.live_thr); else E128_LAUNCH(e128_half_u, false, a.live_thr); }
+    else E128_LAUNCH(e128_bf3, false, a.live_thr);
     return true;
 }
 bool cmdgen_launch_coord128(const EvalLaunch& a, int l, hipStream_t s) {
     const WPack& W = a.layers[unit_of(a, l)].W7;
     if (a.coord_mt != 128 || a.d.H != 256 || !a.split || a.save || !W.ws) return false;
-    if (a.half_engine && W.wh) E128_LAUNCH(e128_half, true, 0); else E128_LAUNCH(e128_bf3, true, 0);
+    if (a.half_engine && W.wh) { if (a.e128_fused & 2) E128_LAUNCH(e128_half, true, 0); else E128_LAUNCH(e128_half_u, true, 0); }
+    else E128_LAUNCH(e128_bf3, true, 0);
     return true;
 }
 #undef E128_LAUNCH

@@ -417,7 +417,8 @@ int cmdgen_set_gemm_mode(cmdgen_handle* h, int32_t split_bf16);
  *   rows per tile        "node_mt" 16|32|64, "edge_mt" / "coord_mt" 16|32|64|128 (128: kernels_edge128.hip, split engine,
  *                        hidden_nf 256), "embed_mt" 16|32|64
  *   grids                "edge_wgs_per_cu", "coord_wgs_per_cu" (persistent-style edge grids of the <= 64-row kernels),
- *                        "e128_wgs_per_cu" 1|2
+ *                        "e128_wgs_per_cu" 1|2, "e128_fused" 0..3 (bit 0 / 1: the 128-row message / coordinate kernel issues the next quarter's
+ *                        tile build inside its GEMM; default: by the estimated list length - more than one tile per workgroup)
  *   matrix engine        "half_engine" 0|1|2: the split-engine kernels that have a HALF form (two fp16 pieces per operand, three MFMAs per
  *                        fp32 product instead of three bf16 pieces and six; csrc/cmdgen_split.h) use it: 1 (default) when the model has an
  *                        edge cutoff (the radial features are bounded; fp16 ends at 65504), 2 always, 0 never

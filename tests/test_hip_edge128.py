@@ -21,11 +21,14 @@ G12 = load_golden('g12_fullsize.npz')
 G13 = load_golden('g13_bounded.npz')
 
 
-@pytest.fixture(autouse=True, params=[2, 0], ids=['half', 'bf16x3'])
+@pytest.fixture(autouse=True, params=[(2, 3), (2, 0), (0, 0)], ids=['half_fused', 'half_plain', 'bf16x3'])
 def e128_engine(request, monkeypatch):
-    """every test of this file runs on both matrix engines of the 128-row kernels: two fp16 pieces per operand and three MFMAs per product
-    (the default where the model has an edge cutoff, forced here with half_engine = 2), and three bf16 pieces and six (half_engine = 0)"""
-    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'half_engine', request.param)
+    """every test of this file runs on both matrix engines of the 128-row kernels - two fp16 pieces per operand and three MFMAs per product (the
+    default where the model has an edge cutoff, forced here with half_engine = 2), three bf16 pieces and six (half_engine = 0) - and, on the half
+    engine, on both main loops: the fused one (round 6: the next quarter's tile build inside the GEMM; what long lists run) and the plain one
+    (what a list of one tile per workgroup runs); option e128_fused"""
+    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'half_engine', request.param[0])
+    monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'e128_fused', request.param[1])
     return request.param
 
 

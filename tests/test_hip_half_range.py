@@ -35,7 +35,8 @@ TARGETS = {
 }
 # launch choices that put the three tile kernels on each half-engine family
 OPTION_SETS = {
-    'rows128_node64': dict(edge_mt=128, coord_mt=128, node64=1),
+    'rows128_node64': dict(edge_mt=128, coord_mt=128, node64=1, e128_fused=0),
+    'rows128_fused': dict(edge_mt=128, coord_mt=128, node64=1, e128_fused=3),
     'fullk32_node16w': dict(edge_mt=32, coord_mt=32, node_mt=16),
 }
 
