@@ -11,15 +11,18 @@
 //     the A operand is built a QUARTER of K at a time (three bf16 planes of [128][64 + 8], 55 KB) so that two workgroups still share a CU and
 //     one's builds and epilogue run beside the other's MFMAs;
 //   * the epilogue stays in registers: SiLU on the accumulators, the gate's (or coord_mlp.4's) row dot as in-lane FMAs + a value-halving
-//     butterfly over the 32 lanes that hold a row (ds_swizzle), one 2 KB exchange of the four waves' partial sums, and the ordered segment
-//     sum by receiver as ONE MORE MATRIX PRODUCT: agg_tile[segment][col] = S[segment][row] x (att[row] m[row][col]), S the 0/1 membership
-//     matrix (exact in bf16), the gated messages split into three bf16 pieces straight from the accumulator registers - the 32 x 32
-//     accumulator layout (lane = column, registers = rows) IS the B-operand layout of v_mfma_f32_32x32x16_bf16 up to a fixed permutation of k,
-//     which the S fragments are built to match.  No m tile in LDS, no per-row scan, 48 MFMAs (+6 %) per tile;
+//     reduction over the 32 lanes that hold a row (round 6: v_permlane16_swap + DPP adds, no LDS round trip), one 2 KB exchange of the four
+//     waves' partial sums, and the ordered segment sum by receiver as an IN-REGISTER SCAN (round 5; it replaced round 4's segment-sum-as-MFMA,
+//     which spread a non-finite message over the whole tile through 0 x NaN): v_permlane32_swap turns the 32 x 32 accumulator layout into one
+//     where a register holds ONE row, the rows are visited in list order by wave-uniform code driven by a 128-bit mask of segment starts, a
+//     receiver's sum is a chain of fma(message, gate, sum) in ascending sender order like the reference's CPU scatter_add_, and a finished
+//     receiver leaves as one 256-byte row segment (plain store inside the tile, one float atomic where a tile or chunk boundary cuts it);
+//   * round 6, half engine: the bias enters as one rank-1 MFMA per accumulator tile, and on lists that give a workgroup more than one tile the
+//     BUILD of quarter q + 1 is issued inside the GEMM over quarter q (double-buffered, XOR-swizzled planes; x_main in cmdgen_edge128_body.h);
 //   * every workgroup owns ONE contiguous chunk of the list, sized so that all workgroups of the launch finish together (a chunk is cut into
 //     equal tiles of 32 .. 128 rows; accumulator tiles beyond a tile's rows are not multiplied): no tail round of whole tiles.
-// Results: the same sums as kernels_egnn.hip up to fp32 re-association (row dots and segment sums add in another order); deterministic run
-// to run as long as a receiver's edges span at most two tiles (one float atomic each: commutative).
+// Results: the same sums as kernels_egnn.hip up to fp32 re-association (row dots add in another order; receiver sums in list order);
+// deterministic run to run as long as a receiver's edges span at most two tiles (one float atomic each: commutative).
 #include "cmdgen_dev.h"
 #include <hip/hip_ext.h>
 

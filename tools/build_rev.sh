@@ -10,7 +10,7 @@ mkdir -p build/rev_$name/cmdgen_amd/csrc build/rev_$name/include
 git show $rev:$C/$f > build/rev_$name/cmdgen_amd/csrc/$f
 for h in $(git ls-tree --name-only $rev $C/ | grep '\.h$'); do git show $rev:$h > build/rev_$name/$h; done
 git show $rev:include/cmdgen_hip.h > build/rev_$name/include/cmdgen_hip.h
-extra="-fno-slp-vectorize"
+extra=$(python3 tools/file_flags.py $f)      # the flags __graft_entry__ gives this file (one table)
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function -Wno-unused-value $extra "$@" -c build/rev_$name/cmdgen_amd/csrc/$f -o build/${f%.hip}_$name.o
 objs=""
 for o in cmdgen_api kernels_egnn kernels_egnn_graph kernels_egnn_msg kernels_egnn_node kernels_egnn_coord kernels_node64 kernels_node16w kernels_edge128 kernels_ddpm kernels_joint kernels_train cmdgen_train; do

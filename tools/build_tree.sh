@@ -12,8 +12,7 @@ C=$d/cmdgen_amd/csrc
 objs=""
 pids=""
 for f in $C/*.hip; do
-  b=$(basename $f .hip); extra=""
-  case $b in kernels_node64|kernels_edge128|kernels_node16w) extra="-fno-slp-vectorize";; kernels_ddpm|kernels_joint) extra="-ffp-contract=off";; esac
+  b=$(basename $f .hip); extra=$(python3 tools/file_flags.py $b.hip)      # the flags __graft_entry__ gives this file (one table)
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function -Wno-unused-value $extra -c $f -o $C/$b.o 2>/dev/null &
   pids="$pids $!"; objs="$objs $C/$b.o"
 done
