@@ -1,7 +1,7 @@
 #!/bin/bash
 # One pass over everything profiles/ cites (run on the GPU box: gpurun -- 'bash tools/gpu_evidence.sh <tag>').
 # Writes under gpurun_out/<tag>_*; kernel_traffic.json is stamped with the hash of the kernel sources it was measured on.
-tag=${1:-r05_z}
+tag=${1:-r06_z}
 part=${2:-all}      # all | a (tests, smoke, the default line, headline kernel stats + PMC) | b (256-pocket stats + PMC, training, joint, per-kernel profiles): two gpurun calls of < 20 min
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out
