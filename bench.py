@@ -666,7 +666,8 @@ def main(argv=None):
                 f32 = chain_record(cfg, sd, pb, T, dev, stream, use_graph, prof_steps=0, gemm='fp32')
                 result['config']['fp32_instruction_engine'] = {k: f32[k] for k in ('value', 'unit', 'us_per_denoising_step', 'whole_job_frac_of_fp32_instruction_peak', 'edges_per_pocket_eval')}
             # BASELINE configs[3]'s per-GPU work: the training step
-            result['config']['training_step'] = training_step_record(dev)
+            with torch.cuda.stream(stream):          # (a torch stream like the sampler's records: the legacy default stream is the slower, bracketed path)
+                result['config']['training_step'] = training_step_record(dev)
             # the same numbers once more as FLAT scalars (a record that keeps only short values still shows them)
             flat = result['config']
             for tag, r in (('north_star', ns), ('fullatom', fa)):

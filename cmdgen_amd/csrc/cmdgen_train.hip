@@ -154,6 +154,7 @@ struct TrainState {
     // dP | dQ separately for the coordinate and the message list, dn by block parity, dh between the two sides of the node model.
     int* h_tot = nullptr; hipEvent_t tot_ev = nullptr;          // pinned landing place of the list lengths and the event behind their copy (cmdgen_train_forward)
     hipStream_t ws = nullptr, ws_low = nullptr;      // (ws_low: the same at the device's lowest stream priority, wgrad_stream = 2)
+    hipEvent_t br_in = nullptr, br_out = nullptr;    // a caller on the legacy default stream: the pass runs on ws, bracketed by these (train_backward_stages)
     std::vector<hipEvent_t> evs, evs2;
     float *part_x[4] = {nullptr, nullptr, nullptr, nullptr}, *tail_x[4] = {nullptr, nullptr, nullptr, nullptr};
     float *actA2 = nullptr, *actB2 = nullptr, *dPx[3] = {nullptr, nullptr, nullptr}, *dn2 = nullptr, *dh2 = nullptr, *dh3 = nullptr;
@@ -179,6 +180,8 @@ void cmdgen_train_free(TrainState* t) {
     for (hipEvent_t e : t->evs2) hipEventDestroy(e);
     if (t->h_tot) hipHostFree(t->h_tot);
     if (t->tot_ev) hipEventDestroy(t->tot_ev);
+    if (t->br_in) hipEventDestroy(t->br_in);
+    if (t->br_out) hipEventDestroy(t->br_out);
     if (t->ws) hipStreamDestroy(t->ws);
     if (t->ws_low) hipStreamDestroy(t->ws_low);
     delete t;
@@ -586,19 +589,21 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     h->last_stream = s;
     // The pass forks work onto the handle's side streams and joins them with events.  With the LEGACY DEFAULT stream as the caller's stream that
     // protocol is not reliable (round 6: with a second handle alive in the process, gradients of the side streams' tensors came out 1e-4 ... 1e-3
-    // off now and then; any other stream as the caller's: never - tools/train_grad_diag4.py, profiles/r06_d).  As the sampler does for its chains,
-    // such a call runs on a stream of the handle's own, ordered behind the caller's pending work and in front of its later work by events.
+    // off now and then; any other stream as the caller's: never - tools/train_grad_diag4.py, profiles/r06_d).  Such a call runs on streams of the
+    // handle's own, ordered behind the caller's pending work and in front of its later work by two events (what the sampler does for its chains).
+    // (No stream is added for this - the process's streams share a handful of hardware queues, and a fifth active stream made two of the pass's
+    // streams share one: 2.7 -> 4.5 ms per step inside bench.py - the pass's main chain takes the handle's first side stream, the weight
+    // gradients its second, and the embedding stage's third stream is folded into the second.)
     const hipStream_t caller = s;
-    const bool bridged = caller == nullptr && g_train_tune.wgrad_stream != 0 && g_train_tune.dgrad_tail != 0;
+    const bool bridged = caller == nullptr && g_train_tune.wgrad_stream != 0 && g_train_tune.dgrad_tail != 0 && t->ws && t->ws_low;
     if (bridged) {
-        if (!h->own_stream) {
-            HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
-            HIPCHK(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
-            HIPCHK(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+        if (!t->br_in) {
+            HIPCHK(h, hipEventCreateWithFlags(&t->br_in, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&t->br_out, hipEventDisableTiming));
         }
-        HIPCHK(h, hipEventRecord(h->ev_in, caller));
-        HIPCHK(h, hipStreamWaitEvent(h->own_stream, h->ev_in, 0));
-        s = h->own_stream;
+        HIPCHK(h, hipEventRecord(t->br_in, caller));
+        HIPCHK(h, hipStreamWaitEvent(t->ws, t->br_in, 0));
+        s = t->ws;
     }
     const Dims& d = h->dims;
     const float* theta = t->theta;
@@ -614,7 +619,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     const bool tail_fused = sp && g_train_tune.dgrad_tail != 0;
     // weight / bias gradients leave the chain of data gradients for the second stream (SideStream above) where the buffers they read
     // rotate (the fused-tail path); ss.on = false: everything on the caller's stream, in the order written
-    hipStream_t side = g_train_tune.wgrad_stream == 2 && t->ws_low ? t->ws_low : t->ws;
+    hipStream_t side = (bridged || (g_train_tune.wgrad_stream == 2 && t->ws_low)) ? t->ws_low : t->ws;
     SideStream ss{s, side, tail_fused && side != nullptr && g_train_tune.wgrad_stream != 0, &t->evs};
     // deferred side work: queued where the serial pass launches it, run on the side stream by flush_side() (serial pass: run at once)
     std::vector<std::function<void(hipStream_t)>> pending;
@@ -803,7 +808,7 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     }
     if (last_stage < L + 1) {
         ss.join();
-        if (bridged) { HIPCHK(h, hipEventRecord(h->ev_out, s)); HIPCHK(h, hipStreamWaitEvent(caller, h->ev_out, 0)); }
+        if (bridged) { HIPCHK(h, hipEventRecord(t->br_out, s)); HIPCHK(h, hipStreamWaitEvent(caller, t->br_out, 0)); }
         HIPCHK(h, hipGetLastError());
         return CMDGEN_OK;
     }
@@ -825,8 +830,8 @@ static int train_backward_stages(cmdgen_handle* h, const float* d_eps_phar, cons
     ss3.join();
     ss.join();
     if (bridged) {
-        HIPCHK(h, hipEventRecord(h->ev_out, s));
-        HIPCHK(h, hipStreamWaitEvent(caller, h->ev_out, 0));
+        HIPCHK(h, hipEventRecord(t->br_out, s));
+        HIPCHK(h, hipStreamWaitEvent(caller, t->br_out, 0));
     }
     HIPCHK(h, hipGetLastError());
     return CMDGEN_OK;

@@ -120,6 +120,7 @@ def main():
     ap.add_argument('--cpu-baseline', action='store_true', help='also time the oracle (torch CPU autograd) on the same batch shape')
     ap.add_argument('--gloo', action='store_true', help='rendezvous over gloo (rehearsal of the multi-rank path on a one-GPU box: all ranks on cuda:0)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group (RCCL) even with one rank and run the staged backward + chunked all-reduce through it (tests/test_hip_rccl.py)')
+    ap.add_argument('--torch-stream', action='store_true', help='run on a torch side stream instead of the legacy default stream')
     ap.add_argument('--profile', action='store_true', help='print the per-kernel time table of 3 steps (torch.profiler)')
     a = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -133,6 +134,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo' if a.gloo else 'nccl', **({} if a.gloo else {'device_id': torch.device('cuda', local)}))
     dev = torch.device('cuda', local)
+    if a.torch_stream:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     cfg, model, tr = build_trainer(a.batch, a.representation, a.gemm, dev, pipelined=not a.no_pipeline, mode=a.mode)
     tr.fused_loss = not a.unfused_loss
     tr.force_collectives = bool(a.force_dist)
