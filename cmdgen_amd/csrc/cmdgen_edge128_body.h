@@ -535,23 +535,27 @@ __device__ __forceinline__ void tile_compute(E128Lds& L, const Layout& lay, cons
                     const u2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[m][0][4 * j + i]), __float_as_uint(acc[m][1][4 * j + i]), false, false);
                     x[i] = __uint_as_float(sw[0]); y[i] = __uint_as_float(sw[1]);     // rows 32 m + 8 j + i and + 4 + i, all 64 columns of the wave
                 }
+                // the eight rows of this group in list order: one test for "no segment starts here" (the common case: a receiver has ~20 C-alpha /
+                // ~60 full-atom edges), else row by row
+                const int base8 = 32 * m + 8 * j;
+                unsigned bits8 = (sm[base8 >> 5] >> (base8 & 31)) & 0xffu;
+                if (base8 == 0) bits8 &= ~1u;                                                      // row 0 opens segment 0: nothing to flush
+                const float gxa[4] = {gx.x, gx.y, gx.z, gx.w}, gya[4] = {gy.x, gy.y, gy.z, gy.w};
+                if (bits8 == 0u) {
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int base = 32 * m + 8 * j + 4 * hh;
-                    unsigned bits = (sm[base >> 5] >> (base & 31)) & 0xfu;
-                    if (base == 0) bits &= ~1u;                                                    // row 0 opens segment 0: nothing to flush
-                    const float* v = hh ? y : x;
-                    const float4 gq = hh ? gy : gx;
-                    const float g[4] = {gq.x, gq.y, gq.z, gq.w};
-                    if (bits == 0u) {
+                    for (int i = 0; i < 4; ++i) sum = __fmaf_rn(x[i], gxa[i], sum);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) sum = __fmaf_rn(v[i], g[i], sum);
-                    } else {
+                    for (int i = 0; i < 4; ++i) sum = __fmaf_rn(y[i], gya[i], sum);
+                } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (bits & (1u << i)) flush();
-                            sum = __fmaf_rn(v[i], g[i], sum);
-                        }
+                    for (int i = 0; i < 4; ++i) {
+                        if (bits8 & (1u << i)) flush();
+                        sum = __fmaf_rn(x[i], gxa[i], sum);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (bits8 & (16u << i)) flush();
+                        sum = __fmaf_rn(y[i], gya[i], sum);
                     }
                 }
             }
