@@ -245,7 +245,7 @@ def kernel_table(h, prof, pc, H, L, nl_tot):
     launch_cfg = {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt', 'edge_grid', 'coord_grid', 'gemm_split', 'half_engine', 'node16_split', 'node16w', 'node64',
                                            'msg_mfmas_per_product', 'node_mfmas_per_product', 'coord_mfmas_per_product')}
     # node64: the 64-row planes node kernel took the launches (kernels_node64.hip; chosen per layout by tile count)
-    mt_of = {'edge_msg': launch_cfg['edge_mt'], 'node': 64 if launch_cfg['node64'] else launch_cfg['node_mt'], 'edge_coord': launch_cfg['coord_mt']}
+    mt_of = {'edge_msg': launch_cfg['edge_mt'], 'node': 32 if launch_cfg['node64'] == 32 else 64 if launch_cfg['node64'] else launch_cfg['node_mt'], 'edge_coord': launch_cfg['coord_mt']}
     # the matrix engine each kernel ran on, as the library's launchers resolve it: MFMAs per fp32 product (1 / 6 / 3)
     mpp = {'edge_msg': launch_cfg['msg_mfmas_per_product'], 'node': launch_cfg['node_mfmas_per_product'], 'edge_coord': launch_cfg['coord_mfmas_per_product']}
     per_kernel = {}

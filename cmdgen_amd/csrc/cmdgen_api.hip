@@ -688,6 +688,11 @@ EvalLaunch make_launch(cmdgen_handle* h) {
             // 96 pockets (177 32-row tiles, one per CU), 87.5 vs 46.1 at 160 (two per CU)
             if (a.half_engine) cost32 = 1.9f * full + (rem == 0 ? 0.f : rem <= ncu ? 1.22f : 1.9f);
             on = cost64 < cost32 && !(a.half_engine && h->node_mt == 16);
+            // Round 6: on the half engine the 32-ROW plane tile (k_node32p: 193 registers, 67 KB of LDS - TWO workgroups per CU, so one's HBM phases run
+            // beside the other's GEMMs) beats both the 64-row tile and the register-split 32-row tile wherever the eight-wave 16-row tile does not apply:
+            // per evaluation -13 % at 80 C-alpha pockets, -10 % at 128, -1.4 % at 256, -2 % / -1.4 % at 64 / 256 full-atom pockets
+            // (profiles/r06_h_node_tile_sweep.txt; the 64-row tile stays behind option node64 = 1)
+            if (a.half_engine && h->node_mt != 16) on = 32;
             if (opt_set(h, "node64")) { const int64_t v = opt_of(h, "node64", 0); on = v == 32 ? 32 : v != 0; }
         }
         a.node64 = on;
