@@ -227,15 +227,15 @@ def test_bounded_chain_with_node64(use_graph, monkeypatch):
 
 
 def test_node64_is_chosen_by_tile_count_and_agrees_with_the_32_row_kernel(monkeypatch):
-    """Without the option node64 the launcher picks the 64-row kernel where its tiles fill the CUs in fewer rounds (256 C-alpha pockets:
-    236 tiles of 64 rows on 256 CUs), not at the headline size (64 pockets: 59 tiles); a 20-step chain of 256 pockets with it equals
-    the 32-row kernel's to the engines' rounding (same pieces, same accumulation order per output tile)."""
+    """Without the option node64 the launcher picks the plane node tiles where the eight-wave 16-row tile does not apply (round 6: the 32-ROW plane
+    tile, two workgroups per CU - 256 C-alpha pockets; not at the headline size: 64 pockets run k_node16w); 20-step chains of 256 pockets on the
+    32-row plane tile, the 64-row plane tile (option node64 = 1) and the register-split 32-row kernel (node64 = 0) agree to the engines' rounding."""
     from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
     monkeypatch.delitem(hip_backend.DEFAULT_OPTIONS, 'node64', raising=False)
     cfg = ModelConfig(residue_nf=20, timesteps=1000, noise_precision=0.1, norm_values=(1.0, 0.25))
     sd = make_state_dict(cfg, seed=3)
     out = {}
-    for B, opt, expect in ((64, None, 0), (256, None, 1), (256, 0, 0)):
+    for B, opt, expect in ((64, None, 0), (256, None, 32), (256, 1, 1), (256, 0, 0)):
         pb = make_pockets(B, 'CA')
         h = hip_backend.Handle(cfg.as_dict(), 0); h.load_state_dict(sd)
         h.set_option('node64', opt)                                  # None: the library's own choice
@@ -246,7 +246,8 @@ def test_node64_is_chosen_by_tile_count_and_agrees_with_the_32_row_kernel(monkey
             out[h.query('node64')] = xh.cpu().numpy()
             assert h.chain_status()['nan_resets'] == 0
         h.close()
-    if len(out) == 2:
-        err = rms(out[1][:, :3], out[0][:, :3])
-        print(f'256 pockets, 20 steps: coordinate RMS 64-row vs 32-row node kernel {err:.2e} A (max|x| {np.abs(out[0][:, :3]).max():.1f})')
-        assert err <= 2e-5 and np.array_equal(out[1][:, 3:], out[0][:, 3:])
+    for k in (1, 32):
+        if k in out and 0 in out:
+            err = rms(out[k][:, :3], out[0][:, :3])
+            print(f'256 pockets, 20 steps: coordinate RMS {"64" if k == 1 else "32"}-row plane tile vs register-split 32-row node kernel {err:.2e} A (max|x| {np.abs(out[0][:, :3]).max():.1f})')
+            assert err <= 2e-5 and np.array_equal(out[k][:, 3:], out[0][:, 3:])
