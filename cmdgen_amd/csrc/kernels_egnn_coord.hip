@@ -1,5 +1,10 @@
 // kernels_egnn_coord.hip - k_edge_coord: EquivariantUpdate.coord_model (egnn_new.py:87-104) on 16- / 32- / 64-row tiles of the coordinate
 // list (the 128-row form lives in kernels_edge128.hip).  Shared helpers: cmdgen_egnn_common.h.
+// Build time: this file is compiled TWICE - as itself (CMDGEN_H_PART 0: hidden_nf = 256 and everything that does not depend on the width) and through
+// the two-line wrapper kernels_egnn_coord_hx.hip (CMDGEN_H_PART 1: the widths 64 / 128 / 512, reached from the dispatchers below through *_hx).
+#ifndef CMDGEN_H_PART
+#define CMDGEN_H_PART 0
+#endif
 #include "cmdgen_egnn_common.h"
 
 // ------------------------------------------------------------------------------------
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(H, FK ? 3 : 2) void k_edge_coord(Layout lay, Work w
 // ------------------------------------------------------------------------------------
 // host-callable launchers (C++ linkage)
 // ------------------------------------------------------------------------------------
+#if CMDGEN_H_PART == 0
 static bool launch_coord_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || (a.save && !a.save_half) || !a.split || a.d.H != 256 || a.coord_mt != 32) return false;
     const LayerW& lw = a.layers[unit_of(a, l)];
@@ -159,6 +165,7 @@ static bool launch_coord_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     }
     return true;
 }
+#endif
 template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, int l, hipStream_t s) {
     const size_t shm = a.d.sin ? (size_t)(24 * H + 24 * MT) * sizeof(float) : 0;
     ++a.frag_launches;
@@ -168,13 +175,19 @@ template <int H, int MT, bool SP> static void launch_coord(const EvalLaunch& a, 
     else hipLaunchKernelGGL((k_edge_coord<H, MT, false, SP>), dim3(a.coord_grid), dim3(H), shm, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, TrainSave{});
 }
 template <int H> static void coord_tiles_H(const EvalLaunch& a, int l, hipStream_t s) { MT_DISPATCH(a.coord_mt, launch_coord, a, l, s); }
+#if CMDGEN_H_PART == 0
+void cmdgen_launch_coord_tiles_hx(const EvalLaunch& a, int l, hipStream_t s);     // kernels_egnn_coord_hx.hip
 void cmdgen_launch_coord_tiles(const EvalLaunch& a, int l, hipStream_t s) {
     if (launch_coord_fullk(a, l, s)) return;
+    if (a.d.H == 256) coord_tiles_H<256>(a, l, s); else cmdgen_launch_coord_tiles_hx(a, l, s);
+}
+#else
+void cmdgen_launch_coord_tiles_hx(const EvalLaunch& a, int l, hipStream_t s) {
     switch (a.d.H) {
         case 512: coord_tiles_H<512>(a, l, s); break;
-        case 256: coord_tiles_H<256>(a, l, s); break;
         case 128: coord_tiles_H<128>(a, l, s); break;
         case 64:  coord_tiles_H<64>(a, l, s); break;
         default: break;   // rejected in cmdgen_create
     }
 }
+#endif

@@ -1,5 +1,10 @@
 // kernels_egnn_graph.hip - the radius graph (k_edge_count / k_edge_write, dynamics.py:141-147) and k_embed / k_write_embed (encoders, time
 // column, embedding, P | Q of block 0) with the chain-start pocket cache.  Shared helpers: cmdgen_egnn_common.h.
+// Build time: this file is compiled TWICE - as itself (CMDGEN_H_PART 0: hidden_nf = 256 and everything that does not depend on the width) and through
+// the two-line wrapper kernels_egnn_graph_hx.hip (CMDGEN_H_PART 1: the widths 64 / 128 / 512, reached from the dispatchers below through *_hx).
+#ifndef CMDGEN_H_PART
+#define CMDGEN_H_PART 0
+#endif
 #include "cmdgen_egnn_common.h"
 
 // ------------------------------------------------------------------------------------
@@ -11,6 +16,7 @@ __device__ __forceinline__ int flat_node(int i, int nl, int pb, int qb, int Nl) 
     return i < nl ? pb + i : Nl + qb + (i - nl);
 }
 
+#if CMDGEN_H_PART == 0
 __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict__ xh_phar,
                              const float* __restrict__ xh_pocket) {
     extern __shared__ float4 spos[];            // [max_n] positions, then int sdeg[max_n]
@@ -74,6 +80,7 @@ __global__ void k_edge_count(Layout lay, Work w, Dims d, const float* __restrict
         atomicAdd(&w.counters[3], (unsigned long long)lay.N);  // nodes
     }
 }
+#endif
 
 // (a device function: it is also the first B workgroups of k_write_embed)
 __device__ __forceinline__ void edge_write_body(const Layout& lay, const Work& w, const Dims& d, const int b) {
@@ -245,7 +252,9 @@ __device__ __forceinline__ void edge_write_body(const Layout& lay, const Work& w
         atomicAdd(&w.counters[2], (unsigned long long)Ec);
     }
 }
+#if CMDGEN_H_PART == 0
 __global__ void k_edge_write(Layout lay, Work w, Dims d) { edge_write_body(lay, w, d, blockIdx.x); }
+#endif
 
 // ------------------------------------------------------------------------------------
 // k_embed: h0 = embedding([encoder(features) | t]) for an MT-node tile, then P/Q of block 0.
@@ -491,18 +500,28 @@ template <int H, int MT, bool SP> static void launch_write_embed(const EvalLaunc
                            a.layers[0], xp, xq, t, coef, (const ChainState*)chain, pc, npair);
     }
 }
+template <int H> static void embed_only_H(const EvalLaunch& a, const float* xp, const float* xq, const float* t, hipStream_t s) {
+    MT_DISPATCH(a.node_mt, launch_embed, a, xp, xq, t, nullptr, nullptr, s);
+}
 template <int H> static void embed_tiles_H(const EvalLaunch& a, int mt, const float* xp, const float* xq, const float* t, const float4* coef, ChainState* chain, hipStream_t s) {
     MT_DISPATCH(mt, launch_embed, a, xp, xq, t, coef, chain, s);
 }
+#if CMDGEN_H_PART == 0
+void cmdgen_launch_embed_tiles_hx(const EvalLaunch& a, int mt, const float* xp, const float* xq, const float* t, const float4* coef, ChainState* chain, hipStream_t s);   // kernels_egnn_graph_hx.hip
 void cmdgen_launch_embed_tiles(const EvalLaunch& a, int mt, const float* xp, const float* xq, const float* t, const float4* coef, ChainState* chain, hipStream_t s) {
+    if (a.d.H == 256) embed_tiles_H<256>(a, mt, xp, xq, t, coef, chain, s); else cmdgen_launch_embed_tiles_hx(a, mt, xp, xq, t, coef, chain, s);
+}
+#else
+void cmdgen_launch_embed_tiles_hx(const EvalLaunch& a, int mt, const float* xp, const float* xq, const float* t, const float4* coef, ChainState* chain, hipStream_t s) {
     switch (a.d.H) {
         case 512: embed_tiles_H<512>(a, mt, xp, xq, t, coef, chain, s); break;
-        case 256: embed_tiles_H<256>(a, mt, xp, xq, t, coef, chain, s); break;
         case 128: embed_tiles_H<128>(a, mt, xp, xq, t, coef, chain, s); break;
         case 64:  embed_tiles_H<64>(a, mt, xp, xq, t, coef, chain, s); break;
         default: break;   // rejected in cmdgen_create
     }
 }
+#endif
+#if CMDGEN_H_PART == 0
 void cmdgen_launch_write_embed_tiles(const EvalLaunch& a, int mt, const float* xp, const float* xq, const float* t, const float4* coef, ChainState* chain, hipStream_t s) {
     constexpr int H = 256;
     MT_DISPATCH(mt, launch_write_embed, a, xp, xq, t, coef, chain, s);
@@ -529,9 +548,7 @@ __global__ void k_pocket_cache(Layout lay, Work w, int H, float* __restrict__ c,
         dh[i] = w.h[base + i] - c[i]; dP[i] = w.P[base + i] - P0[i]; dQ[i] = w.Q[base + i] - Q0[i];
     }
 }
-template <int H> static void embed_only_H(const EvalLaunch& a, const float* xp, const float* xq, const float* t, hipStream_t s) {
-    MT_DISPATCH(a.node_mt, launch_embed, a, xp, xq, t, nullptr, nullptr, s);
-}
+void cmdgen_embed_only_hx(const EvalLaunch& a, const float* xp, const float* xq, const float* t, hipStream_t s);     // kernels_egnn_graph_hx.hip
 // builds the cache from two embed-only passes with the time feature pinned to 0 and to 1 (t01: device [2][B])
 void cmdgen_build_pocket_cache(const EvalLaunch& a, const float* xh_phar, const float* xh_pocket, const float* t01,
                                float* c, float* P0, float* Q0, float* dh, float* dP, float* dQ, hipStream_t s) {
@@ -539,13 +556,7 @@ void cmdgen_build_pocket_cache(const EvalLaunch& a, const float* xh_phar, const 
     const int H = a.d.H;
     for (int stage = 0; stage < 2; ++stage) {
         const float* t = t01 + (size_t)stage * a.lay.B;
-        switch (H) {
-            case 512: embed_only_H<512>(a, xh_phar, xh_pocket, t, s); break;
-            case 256: embed_only_H<256>(a, xh_phar, xh_pocket, t, s); break;
-            case 128: embed_only_H<128>(a, xh_phar, xh_pocket, t, s); break;
-            case 64:  embed_only_H<64>(a, xh_phar, xh_pocket, t, s); break;
-            default: break;
-        }
+        if (H == 256) embed_only_H<256>(a, xh_phar, xh_pocket, t, s); else cmdgen_embed_only_hx(a, xh_phar, xh_pocket, t, s);
         const size_t n = stage == 0 ? (size_t)a.lay.Np * H : (size_t)H;
         hipLaunchKernelGGL(k_pocket_cache, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.lay, a.w, H, c, P0, Q0, dh, dP, dQ, stage);
     }
@@ -564,4 +575,14 @@ void cmdgen_edge_kernels_allow_lds(size_t bytes) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
-
+#endif      // CMDGEN_H_PART == 0
+#if CMDGEN_H_PART == 1
+void cmdgen_embed_only_hx(const EvalLaunch& a, const float* xp, const float* xq, const float* t, hipStream_t s) {
+    switch (a.d.H) {
+        case 512: embed_only_H<512>(a, xp, xq, t, s); break;
+        case 128: embed_only_H<128>(a, xp, xq, t, s); break;
+        case 64:  embed_only_H<64>(a, xp, xq, t, s); break;
+        default: break;
+    }
+}
+#endif

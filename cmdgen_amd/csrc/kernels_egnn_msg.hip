@@ -1,5 +1,10 @@
 // kernels_egnn_msg.hip - k_edge_msg: GCL.edge_model + attention gate + segment sum by receiver (egnn_new.py:31-52) on 16- / 32- / 64-row
 // tiles of the compact edge list (the 128-row form lives in kernels_edge128.hip).  Shared helpers: cmdgen_egnn_common.h.
+// Build time: this file is compiled TWICE - as itself (CMDGEN_H_PART 0: hidden_nf = 256 and everything that does not depend on the width) and through
+// the two-line wrapper kernels_egnn_msg_hx.hip (CMDGEN_H_PART 1: the widths 64 / 128 / 512, reached from the dispatchers below through *_hx).
+#ifndef CMDGEN_H_PART
+#define CMDGEN_H_PART 0
+#endif
 #include "cmdgen_egnn_common.h"
 
 // ------------------------------------------------------------------------------------
@@ -210,6 +215,7 @@ template <int H, int MT, bool SP> static void launch_msg(const EvalLaunch& a, in
                                                a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
     else hipLaunchKernelGGL((k_edge_msg<H, MT, false, SP>), dim3(a.edge_grid), dim3(H), shm, s, a.lay, a.w, a.d, a.layers[unit_of(a, l)], l, a.ablate, TrainSave{}, a.live_thr);
 }
+#if CMDGEN_H_PART == 0
 // 32-row sampler tiles on the split engine: full-K planes (one build, one GEMM per tile; see cmdgen_split.h) unless CMDGEN_EDGE_FULLK=0
 static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     if (!a.edge_fullk || (a.save && !a.save_half) || !a.split || a.d.H != 256 || a.edge_mt != 32) return false;
@@ -228,33 +234,50 @@ static bool launch_msg_fullk(const EvalLaunch& a, int l, hipStream_t s) {
     }
     return true;
 }
+#endif
 template <int H> static void msg_tiles_H(const EvalLaunch& a, int l, hipStream_t s) { MT_DISPATCH(a.edge_mt, launch_msg, a, l, s); }
 // the launch of one block's message kernel on <= 64-row tiles: the full-K 32-row form where it applies, else the generic dispatch
+#if CMDGEN_H_PART == 0
+void cmdgen_launch_msg_tiles_hx(const EvalLaunch& a, int l, hipStream_t s);       // kernels_egnn_msg_hx.hip
 void cmdgen_launch_msg_tiles(const EvalLaunch& a, int l, hipStream_t s) {
     if (launch_msg_fullk(a, l, s)) return;
+    if (a.d.H == 256) msg_tiles_H<256>(a, l, s); else cmdgen_launch_msg_tiles_hx(a, l, s);
+}
+#else
+void cmdgen_launch_msg_tiles_hx(const EvalLaunch& a, int l, hipStream_t s) {
     switch (a.d.H) {
         case 512: msg_tiles_H<512>(a, l, s); break;
-        case 256: msg_tiles_H<256>(a, l, s); break;
         case 128: msg_tiles_H<128>(a, l, s); break;
         case 64:  msg_tiles_H<64>(a, l, s); break;
         default: break;   // rejected in cmdgen_create
     }
 }
+#endif
 
 // (the kernel the evaluation itself would run for this block: the 128-row kernel, then the full-K 32-row tiles, then the generic dispatch;
 // weight unit of the block's first GCL when a block has several)
+#if CMDGEN_H_PART == 0
 template <int H> static void launch_msg_only_H(const EvalLaunch& a, int layer, hipStream_t s) {
     a.unit = layer * a.d.S;
     if (!cmdgen_launch_msg128(a, layer, s) && !launch_msg_fullk(a, layer, s)) MT_DISPATCH(a.edge_mt, launch_msg, a, layer, s);
     a.unit = -1;
 }
+void cmdgen_launch_edge_msg_only_hx(const EvalLaunch& a, int layer, hipStream_t s);       // kernels_egnn_msg_hx.hip
 void cmdgen_launch_edge_msg_only(const EvalLaunch& a, int layer, hipStream_t s) {
+    if (a.d.H == 256) launch_msg_only_H<256>(a, layer, s); else cmdgen_launch_edge_msg_only_hx(a, layer, s);
+}
+#else
+template <int H> static void launch_msg_only_H(const EvalLaunch& a, int layer, hipStream_t s) {
+    a.unit = layer * a.d.S;
+    MT_DISPATCH(a.edge_mt, launch_msg, a, layer, s);          // (the 128-row and full-K forms are hidden_nf = 256 only)
+    a.unit = -1;
+}
+void cmdgen_launch_edge_msg_only_hx(const EvalLaunch& a, int layer, hipStream_t s) {
     switch (a.d.H) {
         case 512: launch_msg_only_H<512>(a, layer, s); break;
-        case 256: launch_msg_only_H<256>(a, layer, s); break;
         case 128: launch_msg_only_H<128>(a, layer, s); break;
         case 64:  launch_msg_only_H<64>(a, layer, s); break;
         default: break;
     }
 }
-
+#endif

@@ -1,6 +1,11 @@
 // kernels_egnn_node.hip - k_node: GCL.node_model for an MT-node tile (egnn_new.py:48-58) and the projections P_c | Q_c / P | Q the later
 // kernels gather, on the register-split tiles (16 / 32 / 64 rows; the plane tiles live in kernels_node64.hip, the eight-wave 16-row tile
 // in kernels_node16w.hip).  Shared helpers: cmdgen_egnn_common.h.
+// Build time: this file is compiled TWICE - as itself (CMDGEN_H_PART 0: hidden_nf = 256 and everything that does not depend on the width) and through
+// the two-line wrapper kernels_egnn_node_hx.hip (CMDGEN_H_PART 1: the widths 64 / 128 / 512, reached from the dispatchers below through *_hx).
+#ifndef CMDGEN_H_PART
+#define CMDGEN_H_PART 0
+#endif
 #include "cmdgen_egnn_common.h"
 
 // ------------------------------------------------------------------------------------
@@ -200,12 +205,18 @@ template <int H, int MT, bool SP> static void launch_node(const EvalLaunch& a, i
                             a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)], l, node_flags(a, l), TrainSave{});
 }
 template <int H> static void node_tiles_H(const EvalLaunch& a, int l, hipStream_t s) { MT_DISPATCH(a.node_mt, launch_node, a, l, s); }
+#if CMDGEN_H_PART == 0
+void cmdgen_launch_node_tiles_hx(const EvalLaunch& a, int l, hipStream_t s);      // kernels_egnn_node_hx.hip
 void cmdgen_launch_node_tiles(const EvalLaunch& a, int l, hipStream_t s) {
+    if (a.d.H == 256) node_tiles_H<256>(a, l, s); else cmdgen_launch_node_tiles_hx(a, l, s);
+}
+#else
+void cmdgen_launch_node_tiles_hx(const EvalLaunch& a, int l, hipStream_t s) {
     switch (a.d.H) {
         case 512: node_tiles_H<512>(a, l, s); break;
-        case 256: node_tiles_H<256>(a, l, s); break;
         case 128: node_tiles_H<128>(a, l, s); break;
         case 64:  node_tiles_H<64>(a, l, s); break;
         default: break;   // rejected in cmdgen_create
     }
 }
+#endif

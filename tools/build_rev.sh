@@ -13,7 +13,7 @@ git show $rev:include/cmdgen_hip.h > build/rev_$name/include/cmdgen_hip.h
 extra=$(python3 tools/file_flags.py $f)      # the flags __graft_entry__ gives this file (one table)
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function -Wno-unused-value $extra "$@" -c build/rev_$name/cmdgen_amd/csrc/$f -o build/${f%.hip}_$name.o
 objs=""
-for o in cmdgen_api kernels_egnn kernels_egnn_graph kernels_egnn_msg kernels_egnn_node kernels_egnn_coord kernels_node64 kernels_node16w kernels_edge128 kernels_ddpm kernels_joint kernels_train cmdgen_train; do
+for o in cmdgen_api kernels_egnn kernels_egnn_graph kernels_egnn_msg kernels_egnn_node kernels_egnn_coord kernels_egnn_graph_hx kernels_egnn_msg_hx kernels_egnn_node_hx kernels_egnn_coord_hx kernels_node64 kernels_node16w kernels_edge128 kernels_ddpm kernels_joint kernels_train cmdgen_train; do
   if [ "$o.hip" = "$f" ]; then objs="$objs build/${o}_$name.o"; else objs="$objs $C/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcmdgen_hip_$name.so $objs
