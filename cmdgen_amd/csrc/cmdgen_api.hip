@@ -467,6 +467,10 @@ static void pick_tiles(cmdgen_handle* h) {
         // a receiver's edges outnumber the rows of a 16- / 32-row tile, its sum would be three or more float-atomic partials whose order the
         // hardware picks - the 128-row kernels (variable tiles, >= 128-row chunks) keep it at two, so full-atom chains are reproducible run to run
         if (h->lay.max_n > 128) { h->edge_mt = 128; h->coord_mt = 128; }
+        // joint chains noise the pocket nodes too: over the first steps a C-alpha sample is nearly fully connected (~48 k edges per evaluation
+        // on average at 64 pockets where the layout estimate says 34 k), and over those lists the 32-row full-K message tiles win - same-box
+        // chains at 64 / 128 / 256 pockets: +8.6 / +5.0 / +4.7 % (profiles/r06_m); the coordinate list (the same edges) stays on 128 rows
+        else if (half && d.joint && h->edge_mt == 128) h->edge_mt = 32;
     }
     // (the fp32 instruction / other widths have no 128-row kernels: their largest tile keeps most dense receivers at two partials)
     if (!(h->gemm_split && d.H == 256) && h->lay.max_n > 128) { h->edge_mt = 64; h->coord_mt = 64; }

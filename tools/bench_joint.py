@@ -47,12 +47,14 @@ def main():
         return h.joint_chain(K, phar=phar, pocket=pocket, phar_fixed=fp, pocket_fixed=fq, resamplings=a.resamplings,
                              jump_length=a.jump, seed=1, pocket_ids=pb.pocket_index, use_graph=graph)
     chain(); torch.cuda.synchronize()
+    h.reset_counters()
     t0 = time.perf_counter()
     for _ in range(a.reps):
         chain()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.reps
     st = h.chain_status()
+    cn = h.counters()
     # per-kernel event timing on a short eager chain
     Kp = min(100, a.timesteps)
     chain(False, Kp); torch.cuda.synchronize()
@@ -65,6 +67,8 @@ def main():
                     f'resamplings={a.resamplings}, jump_length={a.jump}',
         'denoising_steps': n_steps, 'combined_draws': n_draws, 'chain_s': dt,
         'pocket_steps_per_s': a.batch * n_steps / dt, 'us_per_step': dt / (n_steps + 1) * 1e6,
+        'edges_per_evaluation': cn['edges'] / max(1, cn['evaluations']), 'coordinate_edges_per_evaluation': cn['edges_phar'] / max(1, cn['evaluations']),
+        'tiles': {k: h.query(k) for k in ('node_mt', 'edge_mt', 'coord_mt')},
         'status': st, 'kernel_profile': prof}))
 
 
