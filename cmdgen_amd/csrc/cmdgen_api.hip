@@ -697,7 +697,12 @@ EvalLaunch make_launch(cmdgen_handle* h) {
             // per evaluation -13 % at 80 C-alpha pockets, -10 % at 128, -1.4 % at 256, -2 % / -1.4 % at 64 / 256 full-atom pockets
             // (profiles/r06_h_node_tile_sweep.txt; the 64-row tile stays behind option node64 = 1)
             if (a.half_engine && h->node_mt != 16) on = 32;
-            if (opt_set(h, "node64")) { const int64_t v = opt_of(h, "node64", 0); on = v == 32 ? 32 : v != 0; }
+            // ... except where the 32-row tiles need both slots of a CU and the 64-row tiles still fit one per CU (8 k < N <= 16 k rows on 256 CUs: 144 - 272
+            // C-alpha pockets, the north star's 256): there the 64-row tile on EIGHT waves (k_node64e) streams the weights once per CU instead of twice and its
+            // GEMM phases run at the matrix pipe's rate (k_node32p's are bound by the 64 B/clk of L1 fill: 85 B/clk asked) - per evaluation -1.4 .. -1.9 %
+            // (profiles/r06_n_node64e.txt)
+            if (on == 32 && t32 > ncu && t64 <= ncu) on = 8;
+            if (opt_set(h, "node64")) { const int64_t v = opt_of(h, "node64", 0); on = v == 32 ? 32 : v == 8 ? 8 : v != 0; }
         }
         a.node64 = on;
         a.dead_skip = (h->dims.joint || h->dims.S != 1) ? 0 : (int)opt_of(h, "dead_skip", 2);   // (hop levels count blocks of ONE GCL)      // 2 (default): every block by hop level; 1: the last block only; 0: off

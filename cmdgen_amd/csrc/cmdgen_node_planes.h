@@ -6,12 +6,15 @@
 #ifndef CMDGEN_N64_EXP
 #define CMDGEN_N64_EXP 0      // timing experiments only (1: agg * rcp(nf) instead of agg / nf; 2: no zero stores to agg - wrong results)
 #endif
+#ifndef N64E_RING
+#define N64E_RING 8      // ring depth of the eight-wave tile (two waves per SIMD: 256 registers each; 16 spills)
+#endif
 #define NPLD 264            // 16-bit elements per plane row: 256 + 8 (row stride 528 B: conflict-free ds_read_b128)
 // Depth of the weight ring (k-blocks of fragments in registers).  4: three blocks ahead.  16 (half engine, 64-row tiles): a GEMM's WHOLE weight
 // stream (16 k-blocks x 2 tiles x 2 pieces = 256 registers per lane; one wave per SIMD has 512) is requested while the previous GEMM runs, i.e.
 // BEFORE that GEMM's results are stored: the stores (64 KB per tile and output, bound by the chip's HBM write rate - every workgroup reaches the
 // same phase together) drain under the next GEMM instead of in front of its weight loads (in-order memory queue).  profiles/r05_s
-template <int NROWS> struct N64Depth { static constexpr int v = (N64_NPL == 2 && NROWS == 64) ? 16 : 4; };
+template <int NROWS, int NCT> struct N64Depth { static constexpr int v = (N64_NPL == 2 && NROWS == 64) ? (NCT == 1 ? N64E_RING : 16) : 4; };
 constexpr int NPL = N64_NPL;
 constexpr unsigned KBS = 64u * NPL;          // 16-byte units per k-block of a 32-column tile in the packed split weight
 #if N64_NPL == 3
@@ -24,14 +27,15 @@ typedef sf16x8 nfrag;
 
 __device__ __forceinline__ void n64_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NRING> struct N64Ring { nfrag b[NRING][2][NPL]; };   // k-blocks x two 32-column tiles x NPL pieces
+template <int NRING, int NCT> struct N64Ring { nfrag b[NRING][NCT][NPL]; };   // k-blocks x the wave's NCT 32-column tiles x NPL pieces
+template <int NCT> struct N64Tiles { const nfrag* p[NCT]; };                   // WAVE-UNIFORM pointers to k-block 0 of the wave's tiles of one GEMM
 
-// acc[m][n] += A(planes) x W_n^T over K = 256 (16 k-blocks) for the wave's two 32-column tiles.  planes: the three bf16 planes of
-// the 64-row tile; cur[n] / nxt[n]: WAVE-UNIFORM pointers to k-block 0 of tile n of this GEMM / the next one (the lane's 16 bytes at
-// [lane + 64 piece]).  On entry the ring holds k-blocks 0, 1, 2 of this GEMM in sets 0, 1, 2; on exit those of the next.
-template <int NMT, int NRING>
-__device__ __forceinline__ void n64_gemm(const unsigned short* planes, const nfrag* const (&cur)[2], const nfrag* const (&nxt)[2],
-                                         sf32x16 (&acc)[NMT][2], N64Ring<NRING>& ring) {
+// acc[m][n] += A(planes) x W_n^T over K = 256 (16 k-blocks) for the wave's NCT 32-column tiles (2: four waves per tile; 1: eight waves, half
+// engine, 64 rows).  planes: the planes of the tile; cur.p[n] / nxt.p[n]: tile n of this GEMM / the next one (the lane's 16 bytes at
+// [lane + 64 piece]).  On entry the ring holds k-blocks 0 .. NRING - 2 of this GEMM; on exit those of the next.
+template <int NMT, int NRING, int NCT>
+__device__ __forceinline__ void n64_gemm(const unsigned short* planes, const N64Tiles<NCT>& cur, const N64Tiles<NCT>& nxt,
+                                         sf32x16 (&acc)[NMT][NCT], N64Ring<NRING, NCT>& ring) {
     constexpr int KB16 = 16, NPE = NMT * 32 * NPLD;
     const int lane = threadIdx.x & 63;
     const unsigned short* ap = planes + (lane & 31) * NPLD + (lane >> 5) * 8;
@@ -46,10 +50,11 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const nfr
     // one group = one load and the two MFMAs of one row half (pieces AI x BI), pinned: the loads issue in the shadow of the MFMAs
     // instead of in a burst between k-blocks (which left the matrix pipe idle ~100 cycles per block).  Small terms first.
 #define NG_GRP(LOAD, M, AS, BS, AI, BI) LOAD NG_MF(M, 0, AS, AI, BS, BI) NG_MF(M, 1, AS, AI, BS, BI) __builtin_amdgcn_sched_barrier(0);
+#define NG_GRP1(LOAD, M, AS, BS, AI, BI) LOAD NG_MF(M, 0, AS, AI, BS, BI) __builtin_amdgcn_sched_barrier(0);
 #define NG_HEAD(I) constexpr int AS_ = (I) & 1, AN_ = ((I) + 1) & 1, BS_ = (I) & (NRING - 1), BN_ = ((I) + NRING - 1) & (NRING - 1);  \
         const int ka_ = kb + (I) + 1, kq_ = kb + (I) + NRING - 1;                                             \
         const bool in_ = kq_ < KB16; const unsigned ko_ = (unsigned)(in_ ? kq_ : kq_ - KB16) * KBS;           \
-        const nfrag* q0_ = (in_ ? cur[0] : nxt[0]) + ko_; const nfrag* q1_ = (in_ ? cur[1] : nxt[1]) + ko_;
+        const nfrag* q0_ = (in_ ? cur.p[0] : nxt.p[0]) + ko_; const nfrag* q1_ = (in_ ? cur.p[NCT - 1] : nxt.p[NCT - 1]) + ko_;
 #if N64_NPL == 3
 #define NG_BLOCK(I) { NG_HEAD(I)                                                                              \
         if constexpr (NMT == 2) {                                                                             \
@@ -65,7 +70,12 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const nfr
         NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 1) NG_GRP(NG_LB(BN_, kq_, 1, 2), 0, AS_, BS_, 0, 0) } }
 #else
 #define NG_BLOCK(I) { NG_HEAD(I)                                                                              \
-        if constexpr (NMT == 2) {           /* half engine, 64 rows: twelve MFMAs (a1 b0, a0 b1, a0 b0), eight loads */ \
+        if constexpr (NCT == 1) {           /* half engine, 64 rows, eight waves: six MFMAs, six loads */         \
+        static_assert(NCT == 2 || NMT == 2, "one column tile per wave: 64-row tiles");                        \
+        NG_GRP1(NG_LA(AN_, ka_, 0, 1), 0, AS_, BS_, 1, 0) NG_GRP1(NG_LA(AN_, ka_, 1, 1), 1, AS_, BS_, 1, 0)     \
+        NG_GRP1(NG_LA(AN_, ka_, 0, 0) NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 0, 1) NG_GRP1(NG_LA(AN_, ka_, 1, 0) NG_LB(BN_, kq_, 0, 1), 1, AS_, BS_, 0, 1) \
+        NG_GRP1(, 0, AS_, BS_, 0, 0) NG_GRP1(, 1, AS_, BS_, 0, 0)                                              \
+        } else if constexpr (NMT == 2) {    /* half engine, 64 rows: twelve MFMAs (a1 b0, a0 b1, a0 b0), eight loads */ \
         NG_GRP(NG_LA(AN_, ka_, 0, 1), 0, AS_, BS_, 1, 0) NG_GRP(NG_LA(AN_, ka_, 1, 1), 1, AS_, BS_, 1, 0)       \
         NG_GRP(NG_LA(AN_, ka_, 0, 0) NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 0, 1) NG_GRP(NG_LA(AN_, ka_, 1, 0) NG_LB(BN_, kq_, 0, 1), 1, AS_, BS_, 0, 1) \
         NG_GRP(NG_LB(BN_, kq_, 1, 0), 0, AS_, BS_, 0, 0) NG_GRP(NG_LB(BN_, kq_, 1, 1), 1, AS_, BS_, 0, 0)       \
@@ -79,7 +89,11 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const nfr
       constexpr int kb = 0;
       NG_BLOCK(0) NG_BLOCK(1) NG_BLOCK(2) NG_BLOCK(3) NG_BLOCK(4) NG_BLOCK(5) NG_BLOCK(6) NG_BLOCK(7)
       NG_BLOCK(8) NG_BLOCK(9) NG_BLOCK(10) NG_BLOCK(11) NG_BLOCK(12) NG_BLOCK(13) NG_BLOCK(14) NG_BLOCK(15)
+    } else if constexpr (NRING == 8) {
+#pragma unroll 1
+      for (int kb = 0; kb < KB16; kb += NRING) { NG_BLOCK(0) NG_BLOCK(1) NG_BLOCK(2) NG_BLOCK(3) NG_BLOCK(4) NG_BLOCK(5) NG_BLOCK(6) NG_BLOCK(7) }
     } else {
+      static_assert(NRING == 4, "ring depths: 4, 8, 16");
 #pragma unroll 1
       for (int kb = 0; kb < KB16; kb += NRING) { NG_BLOCK(0) NG_BLOCK(1) NG_BLOCK(2) NG_BLOCK(3) }
     }
@@ -88,6 +102,7 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const nfr
 #undef NG_LOADA
 #undef NG_MF
 #undef NG_GRP
+#undef NG_GRP1
 #undef NG_BLOCK
 #undef NG_HEAD
 }
@@ -143,18 +158,20 @@ __device__ __forceinline__ float4 n64_node_pos(const Layout& lay, const Work& w,
     return make_float4(p.x + a.x / dv, p.y + a.y / dv, p.z + a.z / dv, 0.f);
 }
 
-#define N64_ZERO(ACC) _Pragma("unroll") for (int m = 0; m < NMT; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n) _Pragma("unroll") for (int r = 0; r < 16; ++r) ACC[m][n][r] = 0.0f;
-// accumulator layout: register r of tile (m, n) -> row = 32 m + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = 64 wave + 32 n + (lane & 31)
+#define N64_ZERO(ACC) _Pragma("unroll") for (int m = 0; m < NMT; ++m) _Pragma("unroll") for (int n = 0; n < NCT; ++n) _Pragma("unroll") for (int r = 0; r < 16; ++r) ACC[m][n][r] = 0.0f;
+// accumulator layout: register r of tile (m, n) -> row = 32 m + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = 32 NCT wave + 32 n + (lane & 31)
 #define N64_ROW(M, R) ((M) * 32 + ((R) & 3) + 8 * ((R) >> 2) + 4 * (lane >> 5))
 
 // One NROWS-row tile (64, or 32: one accumulator row per wave) of rows row0 .. min(row0 + NROWS, row_end) - 1.
 // FULL: the tile has all its rows - every `row < nvalid` test folds away, so the row loads of a phase are plain back-to-back loads in flight
 // together and the row stores carry no exec-mask branches (with the tests, hipcc wraps each load in its own branch and even waits inside the
 // sequence: the tile-in and agg hand-over phases took 12k cycles each; profiles/r05_q).  Only a layout's last tile takes the general path.
-template <int NROWS, bool FULL>
+// NCT: 32-column tiles per wave - 2: four waves (256 threads); 1: eight waves (512 threads), each with half the columns and half the epilogue work.
+template <int NROWS, bool FULL, int NCT>
 __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
                                                  const LayerW& lw_next, const int layer, const int has_next_arg, const int row0, const int row_end) {
     constexpr int H = 256, LPR = H / 4, NMT = NROWS / 32, NPE = NROWS * NPLD;
+    constexpr int NW = 8 / NCT, NPASS = NROWS / NW;        // waves = rows per pass of the row-wise phases (64 threads per row)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int has_next = has_next_arg & 1, live_thr = (has_next_arg >> 1) & 0x1fffffff;       // bits 1..29: only tiles with a node within that many hops of a moving node (see below)
     const bool skip_pc = ((has_next_arg >> 30) & 1) != 0;                     // not the last GCL of its block (inv_sublayers > 1): no P_c | Q_c
@@ -177,39 +194,43 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
         const int r = lane & (NROWS - 1);
         if (__ballot(r < nvalid && w.need_qc[row0 + r] <= live_thr) == 0ull) {
 #pragma unroll
-            for (int pass = 0; pass < NROWS / 4; ++pass) {
-                const int rr = pass * 4 + rsub;
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int rr = pass * NW + rsub;
                 if (rr < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + rr) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (tid == 0) atomicAdd(&w.counters[7], (unsigned long long)nvalid);
             return;
         }
     }
-    // the chain's weight tiles: this wave's columns 64 wave .. 64 wave + 63 = tiles 2 wave, 2 wave + 1 of every [H out] matrix
-    const nfrag* const t3a[2] = {n64_tile(lw.W3, 32, 2 * wave, 0), n64_tile(lw.W3, 32, 2 * wave + 1, 0)};
-    const nfrag* const t3b[2] = {n64_tile(lw.W3, 32, 2 * wave, 16), n64_tile(lw.W3, 32, 2 * wave + 1, 16)};
-    const nfrag* const t4[2] = {n64_tile(lw.W4, 16, 2 * wave, 0), n64_tile(lw.W4, 16, 2 * wave + 1, 0)};
+    // the chain's weight tiles: this wave's columns 32 NCT wave .. = tiles NCT wave (, NCT wave + 1) of every [H out] matrix
+    N64Tiles<NCT> t3a, t3b, t4;
+#pragma unroll
+    for (int n = 0; n < NCT; ++n) { t3a.p[n] = n64_tile(lw.W3, 32, NCT * wave + n, 0); t3b.p[n] = n64_tile(lw.W3, 32, NCT * wave + n, 16); t4.p[n] = n64_tile(lw.W4, 16, NCT * wave + n, 0); }
     // projections: jobs 0..3 = P_c, Q_c, P', Q' (bit j of `jobs` set: the job runs); Wpq rows 0..H-1 -> P (tiles 0..7), H.. -> Q (8..15)
     // Q_c only where a row of the tile sends along a coordinate edge of this evaluation (flags of the graph pass, kernels_egnn.hip)
     const bool want_qc = want_pc || !w.need_qc || __ballot((lane & (NROWS - 1)) < nvalid && w.need_qc[row0 + (lane & (NROWS - 1))] <= 1) != 0ull;
     const unsigned jobs = (want_pc && !skip_pc ? 1u : 0u) | (want_qc && !skip_pc ? 2u : 0u) | (has_next ? 12u : 0u);
-    auto job_tile = [&](int j, int n) { return n64_tile(j < 2 ? lw.Wpq_c : lw_next.Wpq_e, 16, (j & 1) * 8 + 2 * wave + n, 0); };
+    auto job_tiles = [&](int j) { N64Tiles<NCT> t;
+        _Pragma("unroll") for (int n = 0; n < NCT; ++n) t.p[n] = n64_tile(j < 2 ? lw.Wpq_c : lw_next.Wpq_e, 16, (j & 1) * 8 + NCT * wave + n, 0);
+        return t; };
     const int job0 = jobs ? __builtin_ctz(jobs) : 1;             // (no job at all: the W4 product's look-ahead reads Q_c's first blocks, unused)
-    constexpr int NRING = N64Depth<NROWS>::v;
-    N64Ring<NRING> ring;
-    const int colw = 64 * wave + (lane & 31);
+    constexpr int NRING = N64Depth<NROWS, NCT>::v;
+    N64Ring<NRING, NCT> ring;
+    const int colw = 32 * NCT * wave + (lane & 31);
     const float sc3 = n64_scale(lw.W3), c13 = -1.4426950408889634f * n64_inv(lw.W3), inv4 = n64_inv(lw.W4);       // the accumulators carry their weight pack's scale
-    const float b3c0 = lw.b3[colw] * sc3, b3c1 = lw.b3[colw + 32] * sc3, b4c0 = lw.b4[colw], b4c1 = lw.b4[colw + 32];
+    float b3c[NCT], b4c[NCT];
+#pragma unroll
+    for (int n = 0; n < NCT; ++n) { b3c[n] = lw.b3[colw + 32 * n] * sc3; b4c[n] = lw.b4[colw + 32 * n]; }
     if (layer >= 1 && tid < NROWS) {                                           // materialise the coordinates entering this block
         const int n = row0 + tid;
         if (tid < nvalid && n < lay.Nm) w.XL[(size_t)layer * lay.Nm + n] = n64_node_pos(lay, w, d, n, layer);
     }
     // ---- h: rows in flight, then split once per element into the planes (four consecutive k per thread and row)
     {
-        float4 hv[NROWS / 4];
+        float4 hv[NPASS];
 #pragma unroll
-        for (int pass = 0; pass < NROWS / 4; ++pass) {
-            const int r = pass * 4 + rsub;
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int r = pass * NW + rsub;
             hv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < nvalid) hv[pass] = reinterpret_cast<const float4*>(w.h + (size_t)(row0 + r) * H)[c4];
         }
@@ -217,33 +238,33 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
 #pragma unroll
         for (int kb = 0; kb < NRING - 1; ++kb)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < NCT; ++n)
 #pragma unroll
-                for (int s_ = 0; s_ < NPL; ++s_) ring.b[kb][n][s_] = t3a[n][(unsigned)kb * KBS + lane + s_ * 64];
+                for (int s_ = 0; s_ < NPL; ++s_) ring.b[kb][n][s_] = t3a.p[n][(unsigned)kb * KBS + lane + s_ * 64];
 #pragma unroll
-        for (int pass = 0; pass < NROWS / 4; ++pass) {
-            n64_store4(planes, NPE, (pass * 4 + rsub) * NPLD + 4 * c4, hv[pass]);
-            if constexpr (HLDS) *reinterpret_cast<float4*>(hf + (pass * 4 + rsub) * H + 4 * c4) = hv[pass];
+        for (int pass = 0; pass < NPASS; ++pass) {
+            n64_store4(planes, NPE, (pass * NW + rsub) * NPLD + 4 * c4, hv[pass]);
+            if constexpr (HLDS) *reinterpret_cast<float4*>(hf + (pass * NW + rsub) * H + 4 * c4) = hv[pass];
         }
     }
     // agg: requested now, consumed after the h-part of the first product
-    float4 av[NROWS / 4];
+    float4 av[NPASS];
 #pragma unroll
-    for (int pass = 0; pass < NROWS / 4; ++pass) {
-        const int r = pass * 4 + rsub;
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int r = pass * NW + rsub;
         av[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < nvalid) av[pass] = reinterpret_cast<const float4*>(w.agg + (size_t)(row0 + r) * H)[c4];
     }
     n64_lds_barrier();
     NSTAMP(0);
-    sf32x16 acc[NMT][2];
+    sf32x16 acc[NMT][NCT];
     N64_ZERO(acc)
-    n64_gemm<NMT, NRING>(planes, t3a, t3b, acc, ring);                                     // h part of [h | agg]
+    n64_gemm<NMT, NRING, NCT>(planes, t3a, t3b, acc, ring);                                     // h part of [h | agg]
     NSTAMP(6);
     n64_lds_barrier();                                                         // every wave is done reading h
 #pragma unroll
-    for (int pass = 0; pass < NROWS / 4; ++pass) {
-        const int r = pass * 4 + rsub;
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int r = pass * NW + rsub;
 #if CMDGEN_N64_EXP != 2
         if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
 #endif
@@ -254,26 +275,26 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
     }
     n64_lds_barrier();
     NSTAMP(7);
-    n64_gemm<NMT, NRING>(planes, t3b, t4, acc, ring);                                      // agg part
+    n64_gemm<NMT, NRING, NCT>(planes, t3b, t4, acc, ring);                                      // agg part
     NSTAMP(1);
     n64_lds_barrier();                                                         // every wave is done reading agg
     // ---- T = SiLU(pre3): from the accumulators straight into the planes (register pairs r, r + 1 = two rows of one column)
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NCT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float bb = n == 0 ? b3c0 : b3c1;
+                const float bb = b3c[n];
                 const int col = colw + 32 * n;
                 n64_split_store2(planes, NPE, N64_ROW(m, r) * NPLD + col, N64_ROW(m, r + 1) * NPLD + col, n64_silu_scaled(acc[m][n][r] + bb, c13, sc3), n64_silu_scaled(acc[m][n][r + 1] + bb, c13, sc3));
             }
     // the residual's h, in the accumulator layout, requested now (L2) and consumed after the W4 product
-    float hold[NMT][2][16];
+    float hold[NMT][NCT][16];
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NCT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = N64_ROW(m, r);
@@ -283,8 +304,8 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
     NSTAMP(2);
     N64_ZERO(acc)
     {
-        const nfrag* const nxt[2] = {job_tile(job0, 0), job_tile(job0, 1)};
-        n64_gemm<NMT, NRING>(planes, t4, nxt, acc, ring);
+        const N64Tiles<NCT> nxt = job_tiles(job0);
+        n64_gemm<NMT, NRING, NCT>(planes, t4, nxt, acc, ring);
     }
     NSTAMP(3);
     n64_lds_barrier();                                                         // every wave is done reading T
@@ -292,10 +313,10 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NCT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float bb = n == 0 ? b4c0 : b4c1;
+                const float bb = b4c[n];
                 const int col = colw + 32 * n, ra = N64_ROW(m, r), rb = N64_ROW(m, r + 1);
                 const float ha = (HLDS ? hf[ra * H + col] : hold[m][n][r]) + __fmaf_rn(acc[m][n][r], inv4, bb), hb = (HLDS ? hf[rb * H + col] : hold[m][n][r + 1]) + __fmaf_rn(acc[m][n][r + 1], inv4, bb);       // residual (egnn_new.py:57); inv4: a power of two, exact
                 if (ra < nvalid) w.h[(size_t)(row0 + ra) * H + col] = ha;
@@ -310,27 +331,28 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
         const int j = __builtin_ctz(rest);
         const unsigned after = rest & (rest - 1u);
         const int jn = after ? __builtin_ctz(after) : j;                       // (last job: re-reads its own first blocks)
-        const nfrag* const tc[2] = {job_tile(j, 0), job_tile(j, 1)};
-        const nfrag* const tn[2] = {job_tile(jn, 0), job_tile(jn, 1)};
+        const N64Tiles<NCT> tc = job_tiles(j), tn = job_tiles(jn);
         float* __restrict__ out = j == 0 ? w.Pc : j == 1 ? w.Qc : j == 2 ? w.P : w.Q;
         const float* bv = j == 0 ? lw.b6 : lw_next.b1;
-        const float bias0 = (j == 0 || j == 2) ? bv[colw] : 0.f, bias1 = (j == 0 || j == 2) ? bv[colw + 32] : 0.f;       // (in flight during the GEMM)
+        float biasv[NCT];                                                       // (in flight during the GEMM)
+#pragma unroll
+        for (int n = 0; n < NCT; ++n) biasv[n] = (j == 0 || j == 2) ? bv[colw + 32 * n] : 0.f;
         const float invj = n64_inv(j < 2 ? lw.Wpq_c : lw_next.Wpq_e);
         N64_ZERO(acc)
-        n64_gemm<NMT, NRING>(planes, tc, tn, acc, ring);
+        n64_gemm<NMT, NRING, NCT>(planes, tc, tn, acc, ring);
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < NCT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = N64_ROW(m, r);
-                    if (row < nvalid) out[(size_t)(row0 + row) * H + colw + 32 * n] = __fmaf_rn(acc[m][n][r], invj, n == 0 ? bias0 : bias1);
+                    if (row < nvalid) out[(size_t)(row0 + row) * H + colw + 32 * n] = __fmaf_rn(acc[m][n][r], invj, biasv[n]);
                 }
     }
     NSTAMP(5);
 #if CMDGEN_STAMPS == 5
-    if (lane == 0) {
+    if (lane == 0 && wave < 4) {                   // (the eight-wave tile reports its first four waves)
         for (int i = 0; i < 8; ++i) atomicAdd(&w.dbg[wave * 8 + i], nst_[i]);
         atomicAdd(&w.dbg[32 + wave], __builtin_amdgcn_s_memtime() - nst_begin);
         atomicAdd(&w.dbg[40], 1ull);
@@ -339,11 +361,11 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
 #undef NSTAMP
 }
 
-template <int NROWS>
+template <int NROWS, int NCT = 2>
 __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
                                                  const LayerW& lw_next, const int layer, const int has_next_arg, const int row0, const int row_end) {
-    if (row_end - row0 >= NROWS) node_planes_tile_body<NROWS, true>(planes, lay, w, d, lw, lw_next, layer, has_next_arg, row0, row_end);
-    else node_planes_tile_body<NROWS, false>(planes, lay, w, d, lw, lw_next, layer, has_next_arg, row0, row_end);
+    if (row_end - row0 >= NROWS) node_planes_tile_body<NROWS, true, NCT>(planes, lay, w, d, lw, lw_next, layer, has_next_arg, row0, row_end);
+    else node_planes_tile_body<NROWS, false, NCT>(planes, lay, w, d, lw, lw_next, layer, has_next_arg, row0, row_end);
 }
 
 

@@ -29,6 +29,13 @@ __global__ __launch_bounds__(256, 1) void k_node32p(Layout lay, Work w, Dims d, 
     __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 32 * NPLD + 64 + 32 * 256 * 2];
     node_planes_tile<32>(planes, lay, w, d, lw, lw_next, layer, has_next, (int)blockIdx.x * 32, lay.N);
 }
+// the 64-row tile on EIGHT waves (512 threads, one 32-column tile per wave): the weights of the chain are streamed once per 64 rows as in k_node64
+// (k_node32p's two co-resident workgroups stream them twice per CU - 779 MB per launch at 256 pockets, ~17 TB/s out of the L2s, TCP_TCC_READ_REQ),
+// with two waves per SIMD to overlap the epilogues and memory phases that k_node64's single wave per SIMD runs back to back.  Option node64 = 8.
+__global__ __launch_bounds__(512, 1) void k_node64e(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next) {
+    __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 64 * NPLD + 64 + 64 * 256 * 2];
+    node_planes_tile<64, 1>(planes, lay, w, d, lw, lw_next, layer, has_next, (int)blockIdx.x * 64, lay.N);
+}
 }
 #undef N64_NPL
 #undef N64_MFMA
@@ -49,10 +56,14 @@ __global__ __launch_bounds__(256, 1) void k_node32p(Layout lay, Work w, Dims d, 
 }
 
 // launcher: true when the 64-row kernel took the launch (H = 256, split engine, sampler)
-#define N64_LAUNCH(NSP)                                                                                                                              \
+#define N64_LAUNCH(NSP, EIGHT)                                                                                                                              \
     do {                                                                                                                                             \
         const LayerW& lw_ = a.layers[unit_of(a, l)]; const LayerW& ln_ = a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)];          \
-        if (a.node64 == 32) {                                                                                                                        \
+        if (a.node64 == 8 && EIGHT) {                                                                                                                \
+            const int nt = (a.lay.N + 63) / 64;                                                                                                      \
+            if (a.pe_start) hipExtLaunchKernelGGL(n64_half::k_node64e, dim3(nt), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l)); \
+            else hipLaunchKernelGGL(n64_half::k_node64e, dim3(nt), dim3(512), 0, s, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l));                  \
+        } else if (a.node64 == 32) {                                                                                                                 \
             const int nt32 = (a.lay.N + 31) / 32;                                                                                                    \
             if (a.pe_start) hipExtLaunchKernelGGL(NSP::k_node32p, dim3(nt32), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l)); \
             else hipLaunchKernelGGL(NSP::k_node32p, dim3(nt32), dim3(256), 0, s, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l));                     \
@@ -64,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void k_node32p(Layout lay, Work w, Dims d, 
     } while (0)
 bool cmdgen_launch_node64(const EvalLaunch& a, int l, hipStream_t s) {
     if (a.d.H != 256 || !a.split || a.save || !a.node64 || !a.layers[unit_of(a, l)].W3.ws) return false;
-    if (a.half_engine && a.layers[unit_of(a, l)].W3.wh) N64_LAUNCH(n64_half); else N64_LAUNCH(n64_bf3);
+    if (a.half_engine && a.layers[unit_of(a, l)].W3.wh) N64_LAUNCH(n64_half, true); else N64_LAUNCH(n64_bf3, false);
     return true;
 }
 #undef N64_LAUNCH
