@@ -33,9 +33,13 @@ template <int NCT> struct N64Tiles { const nfrag* p[NCT]; };                   /
 // acc[m][n] += A(planes) x W_n^T over K = 256 (16 k-blocks) for the wave's NCT 32-column tiles (2: four waves per tile; 1: eight waves, half
 // engine, 64 rows).  planes: the planes of the tile; cur.p[n] / nxt.p[n]: tile n of this GEMM / the next one (the lane's 16 bytes at
 // [lane + 64 piece]).  On entry the ring holds k-blocks 0 .. NRING - 2 of this GEMM; on exit those of the next.
-template <int NMT, int NRING, int NCT>
+// side: work of the caller issued in the shadow of the MFMAs, one call per k-block with the block's index as a type (eight-wave tile: the
+// stores of the PREVIOUS projection's results - its epilogue then costs no phase of its own); the GEMM is fully unrolled for it.
+template <int I> struct N64Idx { static constexpr int v = I; };
+struct N64NoSide { template <int I> __device__ __forceinline__ void operator()(N64Idx<I>) const {} };
+template <int NMT, int NRING, int NCT, class SIDE = N64NoSide>
 __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const N64Tiles<NCT>& cur, const N64Tiles<NCT>& nxt,
-                                         sf32x16 (&acc)[NMT][NCT], N64Ring<NRING, NCT>& ring) {
+                                         sf32x16 (&acc)[NMT][NCT], N64Ring<NRING, NCT>& ring, const SIDE& side = SIDE()) {
     constexpr int KB16 = 16, NPE = NMT * 32 * NPLD;
     const int lane = threadIdx.x & 63;
     const unsigned short* ap = planes + (lane & 31) * NPLD + (lane >> 5) * 8;
@@ -74,7 +78,7 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const N64
         static_assert(NCT == 2 || NMT == 2, "one column tile per wave: 64-row tiles");                        \
         NG_GRP1(NG_LA(AN_, ka_, 0, 1), 0, AS_, BS_, 1, 0) NG_GRP1(NG_LA(AN_, ka_, 1, 1), 1, AS_, BS_, 1, 0)     \
         NG_GRP1(NG_LA(AN_, ka_, 0, 0) NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 0, 1) NG_GRP1(NG_LA(AN_, ka_, 1, 0) NG_LB(BN_, kq_, 0, 1), 1, AS_, BS_, 0, 1) \
-        NG_GRP1(, 0, AS_, BS_, 0, 0) NG_GRP1(, 1, AS_, BS_, 0, 0)                                              \
+        NG_GRP1(NG_SIDE(I), 0, AS_, BS_, 0, 0) NG_GRP1(, 1, AS_, BS_, 0, 0)                                    \
         } else if constexpr (NMT == 2) {    /* half engine, 64 rows: twelve MFMAs (a1 b0, a0 b1, a0 b0), eight loads */ \
         NG_GRP(NG_LA(AN_, ka_, 0, 1), 0, AS_, BS_, 1, 0) NG_GRP(NG_LA(AN_, ka_, 1, 1), 1, AS_, BS_, 1, 0)       \
         NG_GRP(NG_LA(AN_, ka_, 0, 0) NG_LB(BN_, kq_, 0, 0), 0, AS_, BS_, 0, 1) NG_GRP(NG_LA(AN_, ka_, 1, 0) NG_LB(BN_, kq_, 0, 1), 1, AS_, BS_, 0, 1) \
@@ -85,11 +89,14 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const N64
         NG_GRP(NG_LB(BN_, kq_, 1, 1), 0, AS_, BS_, 0, 0) } }
 #endif
     NG_LOADA(0, 0)
-    if constexpr (NRING == 16) {
+#define NG_SIDE(I) side(N64Idx<(I)>{});
+    if constexpr (NRING == 16 || !std::is_same<SIDE, N64NoSide>::value) {
       constexpr int kb = 0;
       NG_BLOCK(0) NG_BLOCK(1) NG_BLOCK(2) NG_BLOCK(3) NG_BLOCK(4) NG_BLOCK(5) NG_BLOCK(6) NG_BLOCK(7)
       NG_BLOCK(8) NG_BLOCK(9) NG_BLOCK(10) NG_BLOCK(11) NG_BLOCK(12) NG_BLOCK(13) NG_BLOCK(14) NG_BLOCK(15)
     } else if constexpr (NRING == 8) {
+#undef NG_SIDE
+#define NG_SIDE(I)
 #pragma unroll 1
       for (int kb = 0; kb < KB16; kb += NRING) { NG_BLOCK(0) NG_BLOCK(1) NG_BLOCK(2) NG_BLOCK(3) NG_BLOCK(4) NG_BLOCK(5) NG_BLOCK(6) NG_BLOCK(7) }
     } else {
@@ -103,6 +110,7 @@ __device__ __forceinline__ void n64_gemm(const unsigned short* planes, const N64
 #undef NG_MF
 #undef NG_GRP
 #undef NG_GRP1
+#undef NG_SIDE
 #undef NG_BLOCK
 #undef NG_HEAD
 }
@@ -184,8 +192,12 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
 #endif
     const int nvalid = FULL ? NROWS : min(NROWS, row_end - row0);
     // half engine: the fp32 h tile stays in LDS behind the planes (64 KB; the residual reads it there instead of fetching h again)
-    constexpr bool HLDS = NPL == 2;
+    // eight-wave tile: a SECOND plane image instead (agg / nf is split into it while the tile comes in, so the two halves of the first product
+    // run back to back with no hand-over phase between them; later it takes h_new while other waves still read T from the first image)
+    constexpr bool TWO = NCT == 1;
+    constexpr bool HLDS = NPL == 2 && !TWO;
     float* const hf = reinterpret_cast<float*>(planes + NPL * NPE + 64);
+    unsigned short* const planesB = TWO ? planes + NPL * NPE + 64 : planes;
     const bool want_pc = row0 < lay.Nm;
     const int c4 = tid % LPR, rsub = tid / LPR;
     if (live_thr && !want_pc && w.need_qc) {
@@ -226,6 +238,15 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
         if (tid < nvalid && n < lay.Nm) w.XL[(size_t)layer * lay.Nm + n] = n64_node_pos(lay, w, d, n, layer);
     }
     // ---- h: rows in flight, then split once per element into the planes (four consecutive k per thread and row)
+    float4 av[NPASS];
+    auto agg_load = [&]() {
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int r = pass * NW + rsub;
+            av[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nvalid) av[pass] = reinterpret_cast<const float4*>(w.agg + (size_t)(row0 + r) * H)[c4];
+        }
+    };
     {
         float4 hv[NPASS];
 #pragma unroll
@@ -234,6 +255,7 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
             hv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < nvalid) hv[pass] = reinterpret_cast<const float4*>(w.h + (size_t)(row0 + r) * H)[c4];
         }
+        if constexpr (TWO) agg_load();             // two images: agg is split before the first product - in flight together with h
         // the first GEMM's weight fragments: requested behind the tile's own loads (vmcnt retires in order)
 #pragma unroll
         for (int kb = 0; kb < NRING - 1; ++kb)
@@ -248,34 +270,51 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
         }
     }
     // agg: requested now, consumed after the h-part of the first product
-    float4 av[NPASS];
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int r = pass * NW + rsub;
-        av[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nvalid) av[pass] = reinterpret_cast<const float4*>(w.agg + (size_t)(row0 + r) * H)[c4];
-    }
-    n64_lds_barrier();
-    NSTAMP(0);
-    sf32x16 acc[NMT][NCT];
-    N64_ZERO(acc)
-    n64_gemm<NMT, NRING, NCT>(planes, t3a, t3b, acc, ring);                                     // h part of [h | agg]
-    NSTAMP(6);
-    n64_lds_barrier();                                                         // every wave is done reading h
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
+    if constexpr (!TWO) agg_load();
+    auto agg_pass = [&](auto pidx) {          // one pass of: agg / nf -> planes (second image), agg <- 0 ("agg is zero between blocks")
+        constexpr int pass = decltype(pidx)::v;
         const int r = pass * NW + rsub;
 #if CMDGEN_N64_EXP != 2
-        if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);   // agg is zero between blocks
+        if (r < nvalid) reinterpret_cast<float4*>(w.agg + (size_t)(row0 + r) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
         float4 v = av[pass];
         const float dv = r < nvalid ? agg_div(w, d, row0 + r) : 1.0f;
         { const float rv = __builtin_amdgcn_rcpf(dv); v.x = n64_div(v.x, dv, rv); v.y = n64_div(v.y, dv, rv); v.z = n64_div(v.z, dv, rv); v.w = n64_div(v.w, dv, rv); }
-        n64_store4(planes, NPE, r * NPLD + 4 * c4, v);
-    }
+        n64_store4(planesB, NPE, r * NPLD + 4 * c4, v);
+    };
     n64_lds_barrier();
-    NSTAMP(7);
-    n64_gemm<NMT, NRING, NCT>(planes, t3b, t4, acc, ring);                                      // agg part
+    NSTAMP(0);
+    sf32x16 acc[NMT][NCT];
+    N64_ZERO(acc)
+    // the residual's h in the accumulator layout (two images: no fp32 tile in LDS; fetched under the agg part's MFMAs, two values per k-block, by
+    // buffer loads - the row's offset a scalar operand, rows past the tile's valid ones read as 0)
+    float hold[NMT][NCT][16];
+    if constexpr (TWO) {
+        // agg is split under the h part's MFMAs (one pass per two k-blocks), one barrier before the agg part reads it
+        static_assert(!TWO || NPASS == 8, "eight passes over sixteen k-blocks");
+        n64_gemm<NMT, NRING, NCT>(planes, t3a, t3b, acc, ring, [&](auto idx) { if constexpr (decltype(idx)::v % 2 == 0) agg_pass(N64Idx<decltype(idx)::v / 2>{}); });
+        NSTAMP(6);
+        n64_lds_barrier();
+        NSTAMP(7);
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w.h) + (size_t)row0 * H, 0, nvalid * H * 4, 0x00020000);
+        const int hoff = ((4 * (lane >> 5)) * H + colw) * 4;
+        n64_gemm<NMT, NRING, NCT>(planesB, t3b, t4, acc, ring, [&](auto idx) {
+            constexpr int r = decltype(idx)::v;
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+                hold[m][0][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, hoff, (m * 32 + (r & 3) + 8 * (r >> 2)) * H * 4, 0));
+        });
+    } else {
+        n64_gemm<NMT, NRING, NCT>(planes, t3a, t3b, acc, ring);                                 // h part of [h | agg]
+        NSTAMP(6);
+        n64_lds_barrier();                                                     // every wave is done reading h
+        agg_pass(N64Idx<0>{}); agg_pass(N64Idx<1>{}); agg_pass(N64Idx<2>{}); agg_pass(N64Idx<3>{}); agg_pass(N64Idx<4>{}); agg_pass(N64Idx<5>{}); agg_pass(N64Idx<6>{}); agg_pass(N64Idx<7>{});
+        if constexpr (NPASS == 16) { agg_pass(N64Idx<8>{}); agg_pass(N64Idx<9>{}); agg_pass(N64Idx<10>{}); agg_pass(N64Idx<11>{}); agg_pass(N64Idx<12>{}); agg_pass(N64Idx<13>{}); agg_pass(N64Idx<14>{}); agg_pass(N64Idx<15>{}); }
+        static_assert(NPASS == 8 || NPASS == 16, "row passes of the tile");
+        n64_lds_barrier();
+        NSTAMP(7);
+        n64_gemm<NMT, NRING, NCT>(planesB, t3b, t4, acc, ring);                                 // agg part
+    }
     NSTAMP(1);
     n64_lds_barrier();                                                         // every wave is done reading agg
     // ---- T = SiLU(pre3): from the accumulators straight into the planes (register pairs r, r + 1 = two rows of one column)
@@ -289,8 +328,7 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
                 const int col = colw + 32 * n;
                 n64_split_store2(planes, NPE, N64_ROW(m, r) * NPLD + col, N64_ROW(m, r + 1) * NPLD + col, n64_silu_scaled(acc[m][n][r] + bb, c13, sc3), n64_silu_scaled(acc[m][n][r + 1] + bb, c13, sc3));
             }
-    // the residual's h, in the accumulator layout, requested now (L2) and consumed after the W4 product
-    float hold[NMT][NCT][16];
+    // the residual's h, in the accumulator layout, requested now (L2) and consumed after the W4 product (two images: fetched above)
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -298,7 +336,7 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = N64_ROW(m, r);
-                if constexpr (!HLDS) hold[m][n][r] = row < nvalid ? w.h[(size_t)(row0 + row) * H + colw + 32 * n] : 0.f;
+                if constexpr (!HLDS && !TWO) hold[m][n][r] = row < nvalid ? w.h[(size_t)(row0 + row) * H + colw + 32 * n] : 0.f;
             }
     n64_lds_barrier();
     NSTAMP(2);
@@ -308,8 +346,12 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
         n64_gemm<NMT, NRING, NCT>(planes, t4, nxt, acc, ring);
     }
     NSTAMP(3);
-    n64_lds_barrier();                                                         // every wave is done reading T
+    if constexpr (!TWO) n64_lds_barrier();                                     // every wave is done reading T (two images: h_new goes to the other one)
     // ---- h_new = h + (acc + b4): to global from the accumulators, and split into the planes for the projections
+    // (eight waves: the rows go out under the first projection's MFMAs - see the projections - or after them when the tile has no projection)
+    sf32x16 accp[NMT][1];
+    bool have_prev = false; float biasp = 0.f, invp = 1.f;
+    __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(w.h + (size_t)row0 * H, 0, nvalid * H * 4, 0x00020000);
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -319,13 +361,57 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
                 const float bb = b4c[n];
                 const int col = colw + 32 * n, ra = N64_ROW(m, r), rb = N64_ROW(m, r + 1);
                 const float ha = (HLDS ? hf[ra * H + col] : hold[m][n][r]) + __fmaf_rn(acc[m][n][r], inv4, bb), hb = (HLDS ? hf[rb * H + col] : hold[m][n][r + 1]) + __fmaf_rn(acc[m][n][r + 1], inv4, bb);       // residual (egnn_new.py:57); inv4: a power of two, exact
-                if (ra < nvalid) w.h[(size_t)(row0 + ra) * H + col] = ha;
-                if (rb < nvalid) w.h[(size_t)(row0 + rb) * H + col] = hb;
-                n64_split_store2(planes, NPE, ra * NPLD + col, rb * NPLD + col, ra < nvalid ? ha : 0.f, rb < nvalid ? hb : 0.f);
+                if constexpr (NCT == 1) { accp[m][0][r] = ha; accp[m][0][r + 1] = hb; }
+                else {
+                    if (ra < nvalid) w.h[(size_t)(row0 + ra) * H + col] = ha;
+                    if (rb < nvalid) w.h[(size_t)(row0 + rb) * H + col] = hb;
+                }
+                n64_split_store2(planesB, NPE, ra * NPLD + col, rb * NPLD + col, ra < nvalid ? ha : 0.f, rb < nvalid ? hb : 0.f);
             }
     n64_lds_barrier();
     NSTAMP(4);
     // ---- projections, K = 256, A = h_new: one rolled loop over the jobs
+    if constexpr (NCT == 1) {
+        // eight waves: a projection's results leave under the NEXT projection's MFMAs (two stores per k-block: n64_gemm's side work) instead of in a
+        // phase of their own between two GEMMs; only the last job's are stored after the loop
+        // (buffer stores: the row's offset is a compile-time scalar operand, the lane's part one register for the whole loop - no per-row
+        // address registers - and rows past the tile's valid ones fall outside the descriptor's range, dropped by the hardware)
+        have_prev = true; biasp = -0.0f; invp = 1.0f;            // h_new itself is the first "previous result": x * 1 + (-0) = x, bit for bit
+        const int voff = ((4 * (lane >> 5)) * H + colw) * 4;
+        auto store_prev = [&](auto idx) {
+            constexpr int r = decltype(idx)::v;
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __fmaf_rn(accp[m][0][r], invp, biasp)), rp, voff, (m * 32 + (r & 3) + 8 * (r >> 2)) * H * 4, 0);
+        };
+#pragma unroll 1
+        for (unsigned rest = jobs; rest != 0u; rest &= rest - 1u) {
+            const int j = __builtin_ctz(rest);
+            const unsigned after = rest & (rest - 1u);
+            const int jn = after ? __builtin_ctz(after) : j;
+            const N64Tiles<NCT> tc = job_tiles(j), tn = job_tiles(jn);
+            float* out = j == 0 ? w.Pc : j == 1 ? w.Qc : j == 2 ? w.P : w.Q;
+            const float* bv = j == 0 ? lw.b6 : lw_next.b1;
+            const float bias0 = (j == 0 || j == 2) ? bv[colw] : 0.f;
+            const float invj = n64_inv(j < 2 ? lw.Wpq_c : lw_next.Wpq_e);
+            N64_ZERO(acc)
+            if (have_prev) n64_gemm<NMT, NRING, NCT>(planesB, tc, tn, acc, ring, store_prev);
+            else n64_gemm<NMT, NRING, NCT>(planesB, tc, tn, acc, ring);
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accp[m][0][r] = acc[m][0][r];
+            rp = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)row0 * H, 0, nvalid * H * 4, 0x00020000);
+            have_prev = true; biasp = bias0; invp = invj;
+        }
+        if (have_prev) {
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __fmaf_rn(accp[m][0][r], invp, biasp)), rp, voff, (m * 32 + (r & 3) + 8 * (r >> 2)) * H * 4, 0);
+        }
+    } else {
 #pragma unroll 1
     for (unsigned rest = jobs; rest != 0u; rest &= rest - 1u) {
         const int j = __builtin_ctz(rest);
@@ -349,6 +435,7 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
                     const int row = N64_ROW(m, r);
                     if (row < nvalid) out[(size_t)(row0 + row) * H + colw + 32 * n] = __fmaf_rn(acc[m][n][r], invj, biasv[n]);
                 }
+    }
     }
     NSTAMP(5);
 #if CMDGEN_STAMPS == 5

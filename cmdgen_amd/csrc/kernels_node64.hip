@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256, 1) void k_node32p(Layout lay, Work w, Dims d, 
 // (k_node32p's two co-resident workgroups stream them twice per CU - 779 MB per launch at 256 pockets, ~17 TB/s out of the L2s, TCP_TCC_READ_REQ),
 // with two waves per SIMD to overlap the epilogues and memory phases that k_node64's single wave per SIMD runs back to back.  Option node64 = 8.
 __global__ __launch_bounds__(512, 1) void k_node64e(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next) {
-    __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 64 * NPLD + 64 + 64 * 256 * 2];
+    __shared__ __attribute__((aligned(16))) unsigned short planes[2 * (NPL * 64 * NPLD + 64)];          // two plane images (h / T, agg / h_new), each + the A prefetch's overshoot
     node_planes_tile<64, 1>(planes, lay, w, d, lw, lw_next, layer, has_next, (int)blockIdx.x * 64, lay.N);
 }
 }
