@@ -702,7 +702,10 @@ EvalLaunch make_launch(cmdgen_handle* h) {
             // GEMM phases run at the matrix pipe's rate (k_node32p's are bound by the 64 B/clk of L1 fill: 85 B/clk asked) - per evaluation -1.4 .. -1.9 %
             // (profiles/r06_n_node64e.txt)
             if (on == 32 && t32 > ncu && t64 <= ncu) on = 8;
-            if (opt_set(h, "node64")) { const int64_t v = opt_of(h, "node64", 0); on = v == 32 ? 32 : v == 8 ? 8 : v != 0; }
+            // ... and with more 64-row tiles than CUs the lean 64-row tile, two workgroups per CU (k_node64d: 43 B/clk of weight fragments asked, and a
+            // partner workgroup beside every phase): per launch -5 % at 288 C-alpha pockets, -8 % at 384, -15 % at 512, -7 % / -11 % at 64 / 128 full-atom pockets
+            else if (on == 32 && t64 > ncu) on = 2;
+            if (opt_set(h, "node64")) { const int64_t v = opt_of(h, "node64", 0); on = v == 32 ? 32 : v == 8 ? 8 : v == 2 ? 2 : v != 0; }
         }
         a.node64 = on;
         a.dead_skip = (h->dims.joint || h->dims.S != 1) ? 0 : (int)opt_of(h, "dead_skip", 2);   // (hop levels count blocks of ONE GCL)      // 2 (default): every block by hop level; 1: the last block only; 0: off

@@ -175,7 +175,8 @@ __device__ __forceinline__ float4 n64_node_pos(const Layout& lay, const Work& w,
 // together and the row stores carry no exec-mask branches (with the tests, hipcc wraps each load in its own branch and even waits inside the
 // sequence: the tile-in and agg hand-over phases took 12k cycles each; profiles/r05_q).  Only a layout's last tile takes the general path.
 // NCT: 32-column tiles per wave - 2: four waves (256 threads); 1: eight waves (512 threads), each with half the columns and half the epilogue work.
-template <int NROWS, bool FULL, int NCT>
+// LEAN: the 64-row four-wave tile sized for TWO workgroups per CU - ring of four k-blocks, no fp32 h tile in LDS (68 KB, <= 256 registers).
+template <int NROWS, bool FULL, int NCT, bool LEAN>
 __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
                                                  const LayerW& lw_next, const int layer, const int has_next_arg, const int row0, const int row_end) {
     constexpr int H = 256, LPR = H / 4, NMT = NROWS / 32, NPE = NROWS * NPLD;
@@ -195,7 +196,7 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
     // eight-wave tile: a SECOND plane image instead (agg / nf is split into it while the tile comes in, so the two halves of the first product
     // run back to back with no hand-over phase between them; later it takes h_new while other waves still read T from the first image)
     constexpr bool TWO = NCT == 1;
-    constexpr bool HLDS = NPL == 2 && !TWO;
+    constexpr bool HLDS = NPL == 2 && !TWO && !LEAN;
     float* const hf = reinterpret_cast<float*>(planes + NPL * NPE + 64);
     unsigned short* const planesB = TWO ? planes + NPL * NPE + 64 : planes;
     const bool want_pc = row0 < lay.Nm;
@@ -226,7 +227,7 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
         _Pragma("unroll") for (int n = 0; n < NCT; ++n) t.p[n] = n64_tile(j < 2 ? lw.Wpq_c : lw_next.Wpq_e, 16, (j & 1) * 8 + NCT * wave + n, 0);
         return t; };
     const int job0 = jobs ? __builtin_ctz(jobs) : 1;             // (no job at all: the W4 product's look-ahead reads Q_c's first blocks, unused)
-    constexpr int NRING = N64Depth<NROWS, NCT>::v;
+    constexpr int NRING = LEAN ? 4 : N64Depth<NROWS, NCT>::v;
     N64Ring<NRING, NCT> ring;
     const int colw = 32 * NCT * wave + (lane & 31);
     const float sc3 = n64_scale(lw.W3), c13 = -1.4426950408889634f * n64_inv(lw.W3), inv4 = n64_inv(lw.W4);       // the accumulators carry their weight pack's scale
@@ -270,7 +271,7 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
         }
     }
     // agg: requested now, consumed after the h-part of the first product
-    if constexpr (!TWO) agg_load();
+    if constexpr (!TWO && !LEAN) agg_load();       // (LEAN: 64 registers it cannot hold across the GEMM - loaded in the hand-over phase, beside the partner workgroup's work)
     auto agg_pass = [&](auto pidx) {          // one pass of: agg / nf -> planes (second image), agg <- 0 ("agg is zero between blocks")
         constexpr int pass = decltype(pidx)::v;
         const int r = pass * NW + rsub;
@@ -308,6 +309,7 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
         n64_gemm<NMT, NRING, NCT>(planes, t3a, t3b, acc, ring);                                 // h part of [h | agg]
         NSTAMP(6);
         n64_lds_barrier();                                                     // every wave is done reading h
+        if constexpr (LEAN) agg_load();
         agg_pass(N64Idx<0>{}); agg_pass(N64Idx<1>{}); agg_pass(N64Idx<2>{}); agg_pass(N64Idx<3>{}); agg_pass(N64Idx<4>{}); agg_pass(N64Idx<5>{}); agg_pass(N64Idx<6>{}); agg_pass(N64Idx<7>{});
         if constexpr (NPASS == 16) { agg_pass(N64Idx<8>{}); agg_pass(N64Idx<9>{}); agg_pass(N64Idx<10>{}); agg_pass(N64Idx<11>{}); agg_pass(N64Idx<12>{}); agg_pass(N64Idx<13>{}); agg_pass(N64Idx<14>{}); agg_pass(N64Idx<15>{}); }
         static_assert(NPASS == 8 || NPASS == 16, "row passes of the tile");
@@ -336,7 +338,7 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = N64_ROW(m, r);
-                if constexpr (!HLDS && !TWO) hold[m][n][r] = row < nvalid ? w.h[(size_t)(row0 + row) * H + colw + 32 * n] : 0.f;
+                if constexpr (!HLDS && !TWO && !LEAN) hold[m][n][r] = row < nvalid ? w.h[(size_t)(row0 + row) * H + colw + 32 * n] : 0.f;
             }
     n64_lds_barrier();
     NSTAMP(2);
@@ -346,12 +348,24 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
         n64_gemm<NMT, NRING, NCT>(planes, t4, nxt, acc, ring);
     }
     NSTAMP(3);
+    // the tile's rows of h as a buffer: the row's offset is a compile-time scalar operand of every access, the lane's part one register - no
+    // per-row address registers (the eight-wave and the lean tile have 256 registers) - and rows past the valid ones fall outside its range
+    __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(w.h + (size_t)row0 * H, 0, nvalid * H * 4, 0x00020000);
+    const int lean_off = ((4 * (lane >> 5)) * H + colw) * 4;
+    if constexpr (LEAN) {           // the residual's h: fetched here (not held across the W4 product: registers), in flight during the barrier
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int n = 0; n < NCT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    hold[m][n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, lean_off + 32 * n * 4, (m * 32 + (r & 3) + 8 * (r >> 2)) * H * 4, 0));
+    }
     if constexpr (!TWO) n64_lds_barrier();                                     // every wave is done reading T (two images: h_new goes to the other one)
     // ---- h_new = h + (acc + b4): to global from the accumulators, and split into the planes for the projections
     // (eight waves: the rows go out under the first projection's MFMAs - see the projections - or after them when the tile has no projection)
     sf32x16 accp[NMT][1];
     bool have_prev = false; float biasp = 0.f, invp = 1.f;
-    __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(w.h + (size_t)row0 * H, 0, nvalid * H * 4, 0x00020000);
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -362,7 +376,10 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
                 const int col = colw + 32 * n, ra = N64_ROW(m, r), rb = N64_ROW(m, r + 1);
                 const float ha = (HLDS ? hf[ra * H + col] : hold[m][n][r]) + __fmaf_rn(acc[m][n][r], inv4, bb), hb = (HLDS ? hf[rb * H + col] : hold[m][n][r + 1]) + __fmaf_rn(acc[m][n][r + 1], inv4, bb);       // residual (egnn_new.py:57); inv4: a power of two, exact
                 if constexpr (NCT == 1) { accp[m][0][r] = ha; accp[m][0][r + 1] = hb; }
-                else {
+                else if constexpr (LEAN) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ha), rp, lean_off + 32 * n * 4, (m * 32 + (r & 3) + 8 * (r >> 2)) * H * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hb), rp, lean_off + 32 * n * 4, (m * 32 + ((r + 1) & 3) + 8 * ((r + 1) >> 2)) * H * 4, 0);
+                } else {
                     if (ra < nvalid) w.h[(size_t)(row0 + ra) * H + col] = ha;
                     if (rb < nvalid) w.h[(size_t)(row0 + rb) * H + col] = hb;
                 }
@@ -377,7 +394,7 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
         // (buffer stores: the row's offset is a compile-time scalar operand, the lane's part one register for the whole loop - no per-row
         // address registers - and rows past the tile's valid ones fall outside the descriptor's range, dropped by the hardware)
         have_prev = true; biasp = -0.0f; invp = 1.0f;            // h_new itself is the first "previous result": x * 1 + (-0) = x, bit for bit
-        const int voff = ((4 * (lane >> 5)) * H + colw) * 4;
+        const int voff = lean_off;
         auto store_prev = [&](auto idx) {
             constexpr int r = decltype(idx)::v;
 #pragma unroll
@@ -424,6 +441,7 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
 #pragma unroll
         for (int n = 0; n < NCT; ++n) biasv[n] = (j == 0 || j == 2) ? bv[colw + 32 * n] : 0.f;
         const float invj = n64_inv(j < 2 ? lw.Wpq_c : lw_next.Wpq_e);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)row0 * H, 0, nvalid * H * 4, 0x00020000);
         N64_ZERO(acc)
         n64_gemm<NMT, NRING, NCT>(planes, tc, tn, acc, ring);
 #pragma unroll
@@ -433,7 +451,8 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = N64_ROW(m, r);
-                    if (row < nvalid) out[(size_t)(row0 + row) * H + colw + 32 * n] = __fmaf_rn(acc[m][n][r], invj, biasv[n]);
+                    if constexpr (LEAN) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __fmaf_rn(acc[m][n][r], invj, biasv[n])), ro, lean_off + 32 * n * 4, (m * 32 + (r & 3) + 8 * (r >> 2)) * H * 4, 0);
+                    else if (row < nvalid) out[(size_t)(row0 + row) * H + colw + 32 * n] = __fmaf_rn(acc[m][n][r], invj, biasv[n]);
                 }
     }
     }
@@ -448,11 +467,11 @@ __device__ __forceinline__ void node_planes_tile_body(unsigned short* planes, co
 #undef NSTAMP
 }
 
-template <int NROWS, int NCT = 2>
+template <int NROWS, int NCT = 2, bool LEAN = false>
 __device__ __forceinline__ void node_planes_tile(unsigned short* planes, const Layout& lay, const Work& w, const Dims& d, const LayerW& lw,
                                                  const LayerW& lw_next, const int layer, const int has_next_arg, const int row0, const int row_end) {
-    if (row_end - row0 >= NROWS) node_planes_tile_body<NROWS, true, NCT>(planes, lay, w, d, lw, lw_next, layer, has_next_arg, row0, row_end);
-    else node_planes_tile_body<NROWS, false, NCT>(planes, lay, w, d, lw, lw_next, layer, has_next_arg, row0, row_end);
+    if (row_end - row0 >= NROWS) node_planes_tile_body<NROWS, true, NCT, LEAN>(planes, lay, w, d, lw, lw_next, layer, has_next_arg, row0, row_end);
+    else node_planes_tile_body<NROWS, false, NCT, LEAN>(planes, lay, w, d, lw, lw_next, layer, has_next_arg, row0, row_end);
 }
 
 

@@ -29,6 +29,13 @@ __global__ __launch_bounds__(256, 1) void k_node32p(Layout lay, Work w, Dims d, 
     __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 32 * NPLD + 64 + 32 * 256 * 2];
     node_planes_tile<32>(planes, lay, w, d, lw, lw_next, layer, has_next, (int)blockIdx.x * 32, lay.N);
 }
+// the 64-row four-wave tile with TWO workgroups per CU (ring of four k-blocks, no fp32 h tile: 68 KB of LDS, <= 256 registers): for layouts with more
+// 64-row tiles than CUs.  Eight waves per CU ask the L1 for 43 B/clk of weight fragments (k_node32p's two workgroups: 85, the L1 fills 64), and the two
+// workgroups run their memory phases beside each other's GEMMs.  Option node64 = 2.
+__global__ __launch_bounds__(256, 2) void k_node64d(Layout lay, Work w, Dims d, LayerW lw, LayerW lw_next, int layer, int has_next) {
+    __shared__ __attribute__((aligned(16))) unsigned short planes[NPL * 64 * NPLD + 64];
+    node_planes_tile<64, 2, true>(planes, lay, w, d, lw, lw_next, layer, has_next, (int)blockIdx.x * 64, lay.N);
+}
 // the 64-row tile on EIGHT waves (512 threads, one 32-column tile per wave): the weights of the chain are streamed once per 64 rows as in k_node64
 // (k_node32p's two co-resident workgroups stream them twice per CU - 779 MB per launch at 256 pockets, ~17 TB/s out of the L2s, TCP_TCC_READ_REQ),
 // with two waves per SIMD to overlap the epilogues and memory phases that k_node64's single wave per SIMD runs back to back.  Option node64 = 8.
@@ -59,7 +66,11 @@ __global__ __launch_bounds__(256, 1) void k_node32p(Layout lay, Work w, Dims d, 
 #define N64_LAUNCH(NSP, EIGHT)                                                                                                                              \
     do {                                                                                                                                             \
         const LayerW& lw_ = a.layers[unit_of(a, l)]; const LayerW& ln_ = a.layers[unit_has_next(a, l) ? unit_of(a, l) + 1 : unit_of(a, l)];          \
-        if (a.node64 == 8 && EIGHT) {                                                                                                                \
+        if (a.node64 == 2 && EIGHT) {                                                                                                                \
+            const int nt = (a.lay.N + 63) / 64;                                                                                                      \
+            if (a.pe_start) hipExtLaunchKernelGGL(n64_half::k_node64d, dim3(nt), dim3(256), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l)); \
+            else hipLaunchKernelGGL(n64_half::k_node64d, dim3(nt), dim3(256), 0, s, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l));                  \
+        } else if (a.node64 == 8 && EIGHT) {                                                                                                         \
             const int nt = (a.lay.N + 63) / 64;                                                                                                      \
             if (a.pe_start) hipExtLaunchKernelGGL(n64_half::k_node64e, dim3(nt), dim3(512), 0, s, a.pe_start, a.pe_stop, 0, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l)); \
             else hipLaunchKernelGGL(n64_half::k_node64e, dim3(nt), dim3(512), 0, s, a.lay, a.w, a.d, lw_, ln_, l, node_flags(a, l));                  \

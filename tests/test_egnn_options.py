@@ -63,7 +63,7 @@ def _gpu():
 
 OPTION_SETS = [{}, {'node_mt': 16, 'node16w': 0, 'edge_mt': 16, 'coord_mt': 16}, {'node_mt': 32, 'edge_mt': 64, 'coord_mt': 64},
                {'node_mt': 64, 'node64': 0, 'edge_mt': 32, 'coord_mt': 32, 'edge_fullk': 0}, {'node64': 1, 'edge_mt': 128, 'coord_mt': 128},
-               {'node64': 32}, {'node64': 8}]
+               {'node64': 32}, {'node64': 8}, {'node64': 2}]
 
 
 @pytest.mark.gpu

@@ -191,7 +191,7 @@ def test_node64_kernel_matches_reference(name, monkeypatch):
     cfg, sd, inp = dynamics_case(G, name)
     want = G[name + '/eps_phar']
     errs = {}
-    for n64 in ('1', '8', '0'):           # 8: the 64-row tile on eight waves (k_node64e)
+    for n64 in ('1', '8', '2', '0'):      # 8: the 64-row tile on eight waves (k_node64e); 2: the lean 64-row tile, two workgroups per CU (k_node64d)
         monkeypatch.setitem(hip_backend.DEFAULT_OPTIONS, 'node64', int(n64))
         h = new_handle(cfg, sd)
         h.set_layout(G[name + '/num_nodes_phar'], G[name + '/pocket_size'])
@@ -202,8 +202,8 @@ def test_node64_kernel_matches_reference(name, monkeypatch):
         errs[n64] = float(np.abs(eps.cpu().numpy() - want).max())
         h.close()
     tol = EVAL_TOL * max(1.0, float(np.abs(want).max()))
-    print(f'{name}: max|d eps| 64-row kernel {errs["1"]:.2e}  eight-wave 64-row kernel {errs["8"]:.2e}  default {errs["0"]:.2e}  (tolerance {tol:.1e})')
-    assert errs['1'] <= tol and errs['8'] <= tol and errs['0'] <= tol
+    print(f'{name}: max|d eps| 64-row kernel {errs["1"]:.2e}  eight-wave 64-row kernel {errs["8"]:.2e}  lean 64-row kernel {errs["2"]:.2e}  default {errs["0"]:.2e}  (tolerance {tol:.1e})')
+    assert errs['1'] <= tol and errs['8'] <= tol and errs['2'] <= tol and errs['0'] <= tol
 
 
 @pytest.mark.parametrize('use_graph', [False, True])
@@ -228,16 +228,16 @@ def test_bounded_chain_with_node64(use_graph, monkeypatch):
 
 def test_node64_is_chosen_by_tile_count_and_agrees_with_the_32_row_kernel(monkeypatch):
     """Without the option node64 the launcher picks the plane node tiles where the eight-wave 16-row tile does not apply (round 6: the 32-ROW plane
-    tile, two workgroups per CU - 128 and 384 C-alpha pockets; the 64-row tile on eight waves, k_node64e, where 64-row tiles fit one per CU and
-    32-row tiles do not - 256 pockets; not at the headline size: 64 pockets run k_node16w); 20-step chains of 256 pockets on the eight-wave 64-row
-    tile, the 32-row plane tile, the 64-row plane tile (option node64 = 1) and the register-split 32-row kernel (node64 = 0) agree to the engines'
-    rounding."""
+    tile, two workgroups per CU - 128 C-alpha pockets; the 64-row tile on eight waves, k_node64e, where 64-row tiles fit one per CU and 32-row
+    tiles do not - 256 pockets; the lean 64-row tile, two workgroups per CU, k_node64d, with more 64-row tiles than CUs - 384 pockets; not at the
+    headline size: 64 pockets run k_node16w); 20-step chains of 256 pockets on the eight-wave 64-row tile, the 32-row plane tile, the lean and the
+    full 64-row plane tile (options node64 = 2 / 1) and the register-split 32-row kernel (node64 = 0) agree to the engines' rounding."""
     from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets
     monkeypatch.delitem(hip_backend.DEFAULT_OPTIONS, 'node64', raising=False)
     cfg = ModelConfig(residue_nf=20, timesteps=1000, noise_precision=0.1, norm_values=(1.0, 0.25))
     sd = make_state_dict(cfg, seed=3)
     out = {}
-    for B, opt, expect in ((64, None, 0), (128, None, 32), (384, None, 32), (256, None, 8), (256, 32, 32), (256, 1, 1), (256, 0, 0)):
+    for B, opt, expect in ((64, None, 0), (128, None, 32), (384, None, 2), (256, None, 8), (256, 32, 32), (256, 2, 2), (256, 1, 1), (256, 0, 0)):
         pb = make_pockets(B, 'CA')
         h = hip_backend.Handle(cfg.as_dict(), 0); h.load_state_dict(sd)
         h.set_option('node64', opt)                                  # None: the library's own choice
@@ -248,8 +248,8 @@ def test_node64_is_chosen_by_tile_count_and_agrees_with_the_32_row_kernel(monkey
             out[h.query('node64')] = xh.cpu().numpy()
             assert h.chain_status()['nan_resets'] == 0
         h.close()
-    tile_name = {1: '64-row', 32: '32-row', 8: 'eight-wave 64-row'}
-    for k in (1, 32, 8):
+    tile_name = {1: '64-row', 32: '32-row', 8: 'eight-wave 64-row', 2: 'lean 64-row'}
+    for k in (1, 32, 8, 2):
         if k in out and 0 in out:
             err = rms(out[k][:, :3], out[0][:, :3])
             print(f'256 pockets, 20 steps: coordinate RMS {tile_name[k]} plane tile vs register-split 32-row node kernel {err:.2e} A (max|x| {np.abs(out[0][:, :3]).max():.1f})')
