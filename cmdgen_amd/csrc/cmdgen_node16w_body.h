@@ -1,6 +1,13 @@
 // cmdgen_node16w_body.h - the body of kernels_node16w.hip, included once per matrix engine (NW_NPL = 3: three bf16 pieces per operand, six
 // MFMAs per product; 2: two fp16 pieces, three MFMAs - the "half" engine of cmdgen_split.h) inside a namespace of its own.  No include guard.
-constexpr int NW_H = 256, NW_MT = 16, NW_LD = NW_H + 4 /* LDA(H), kernels_egnn.hip */, NW_RD = 4;
+#ifndef NW_RD_HALF
+#define NW_RD_HALF 8
+#endif
+// NW_RD: depth of the weight ring (k-blocks of fragments in registers, NW_RD - 1 ahead of the MFMAs).  The tile is bound by its weight stream
+// (1.8 MB per 16 rows through the CU's L1), and what a CU has in flight sets the rate it gets: eight waves x 3 blocks x 4 KB = 96 KB against
+// ~0.8 us of L2 latency gave ~113 GB/s in the GEMM phases where the L1 fills at 154 (64 B/clk); the half engine's registers allow 7 blocks ahead
+// (one whole GEMM: 218 registers), the three-piece engine stays at 3.
+constexpr int NW_H = 256, NW_MT = 16, NW_LD = NW_H + 4 /* LDA(H), kernels_egnn.hip */, NW_RD = NW_NPL == 2 ? NW_RD_HALF : 4;
 constexpr int NPL = NW_NPL;                  // pieces per operand: 3 (bf16 split, six MFMAs per product) or 2 (fp16 "half" engine, three)
 constexpr unsigned KBS = 64u * NPL;          // 16-byte units per k-block of a 16-column tile in the packed split weight
 #if NW_NPL == 3
@@ -24,16 +31,17 @@ __device__ __forceinline__ NwFrag nw_frag(const void* Ws16, int kb32_total, int 
     f.ns = (unsigned)kb32_total * KBS;
     return f;
 }
-struct NwRing { wfrag b[NW_RD][2][NPL]; };              // ring of four k-blocks x [2 n-tiles][3 pieces]
+struct NwRing { wfrag b[NW_RD][2][NPL]; };              // ring of NW_RD k-blocks x [2 n-tiles][NPL pieces]
 __device__ __forceinline__ void nw_load_set(const wfrag* q, unsigned ns, wfrag (&dst)[2][NPL]) {
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int s = 0; s < NPL; ++s) dst[n][s] = q[n * ns + s * 64];
 }
-// a GEMM enters with its k-blocks 0, 1, 2 in sets 0, 1, 2 and leaves with those of `next` there
+// a GEMM enters with its k-blocks 0 .. NW_RD - 2 in sets 0 .. NW_RD - 2 and leaves with those of `next` there
 __device__ __forceinline__ void nw_prefetch(const NwFrag& f, NwRing& c) {
-    nw_load_set(f.p, f.ns, c.b[0]); nw_load_set(f.p + KBS, f.ns, c.b[1]); nw_load_set(f.p + 2 * KBS, f.ns, c.b[2]);
+#pragma unroll
+    for (int i = 0; i < NW_RD - 1; ++i) nw_load_set(f.p + i * KBS, f.ns, c.b[i]);
 }
 
 // eight k-values of one row (two float4) -> the NPL fragments of the 16 x 16 x 32 MFMA
@@ -55,7 +63,7 @@ __device__ __forceinline__ void nw_split8(const float4& lo, const float4& hi, wf
 // acc[n] += A(lds fp32 image, 16 rows) x W_n^T over KB32 * 32 k-values for the wave's two 16-column tiles (tile_gemm_rsplit16 at half the width)
 template <int KB32>
 __device__ __forceinline__ void nw_gemm(const float* ldsA, const NwFrag cur, const NwFrag next, sf32x4 (&acc)[2], NwRing& ring) {
-    static_assert(KB32 % 4 == 0, "K must be a multiple of 128");
+    static_assert(KB32 % NW_RD == 0 && (NW_RD == 4 || NW_RD == 8), "K must be a multiple of the ring's k-range");
     const int lane = threadIdx.x & 63;
     const float* ap = ldsA + (lane & 15) * NW_LD + (lane >> 4) * 4;
     float4 raw[2][2];
@@ -79,16 +87,16 @@ __device__ __forceinline__ void nw_gemm(const float* ldsA, const NwFrag cur, con
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                  \
         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
 #endif
-    // block i: MFMAs on set i % 4; set (i + 3) % 4 <- weight block i + 3 (or block i + 3 - KB32 of `next`);
+    // block i: MFMAs on set i % NW_RD; set (i + NW_RD - 1) % NW_RD <- weight block i + NW_RD - 1 (or that block - KB32 of `next`);
     // raw[i % 2] <- A block i + 2; a[(i + 1) % 2] <- split of raw[(i + 1) % 2]
 #define NW_BLOCK(I)                                                                                                         \
     {                                                                                                                       \
-        const bool tail = kb + (I) + 3 >= KB32;                      /* wave-uniform */                                     \
-        const wfrag* q = tail ? next.p + (unsigned)(kb + (I) + 3 - KB32) * KBS : cur.p + (unsigned)(kb + (I) + 3) * KBS; \
-        nw_load_set(q, tail ? next.ns : cur.ns, ring.b[((I) + 3) & 3]);                                                     \
+        const bool tail = kb + (I) + NW_RD - 1 >= KB32;              /* wave-uniform */                                     \
+        const wfrag* q = tail ? next.p + (unsigned)(kb + (I) + NW_RD - 1 - KB32) * KBS : cur.p + (unsigned)(kb + (I) + NW_RD - 1) * KBS; \
+        nw_load_set(q, tail ? next.ns : cur.ns, ring.b[((I) + NW_RD - 1) % NW_RD]);                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         if (kb + (I) + 1 < KB32) { NW_SPLIT(((I) + 1) & 1, ((I) + 1) & 1) }                                                 \
-        NW_MFMAS((I) & 1, (I) & 3)                                                                                          \
+        NW_MFMAS((I) & 1, (I) % NW_RD)                                                                                      \
         NW_INTERLEAVE()                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         if (kb + (I) + 2 < KB32) { NW_LOADA((I) & 1, ap + (kb + (I) + 2) * 32) }                                            \
@@ -97,8 +105,9 @@ __device__ __forceinline__ void nw_gemm(const float* ldsA, const NwFrag cur, con
     NW_LOADA(1, ap + 32)
     NW_SPLIT(0, 0)
 #pragma unroll 1
-    for (int kb = 0; kb < KB32; kb += 4) {
+    for (int kb = 0; kb < KB32; kb += NW_RD) {
         NW_BLOCK(0) NW_BLOCK(1) NW_BLOCK(2) NW_BLOCK(3)
+        if constexpr (NW_RD == 8) { NW_BLOCK(4) NW_BLOCK(5) NW_BLOCK(6) NW_BLOCK(7) }
     }
 #undef NW_LOADA
 #undef NW_SPLIT
