@@ -1,7 +1,13 @@
-// cmdgen_node_planes.h - one node tile of 64 or 32 rows with the A operand as producer-side bf16 planes (node_planes_tile): the body of
-// k_node64 / k_node32p (kernels_node64.hip) and of the pocket tiles of k_node_mixed (kernels_egnn.hip).  See kernels_node64.hip for the why.
+// cmdgen_node_planes.h - one node tile of 64 or 32 rows with the A operand as producer-side planes (node_planes_tile): the body of the four
+// plane node kernels of kernels_node64.hip -
+//   k_node64   64 rows, four waves (two 32-column tiles each), one workgroup per CU: ring of 16 k-blocks, fp32 h tile in LDS
+//   k_node32p  32 rows, four waves, two workgroups per CU
+//   k_node64e  64 rows, EIGHT waves (NCT = 1: one 32-column tile each), one workgroup per CU: two plane images, stores under the next GEMM's MFMAs
+//   k_node64d  64 rows, four waves, LEAN: ring of four, no fp32 h tile, buffer addressing - two workgroups per CU
+// (which one runs: make_launch, cmdgen_api.hip; why: kernels_node64.hip and profiles/r06_n_node64e.txt).
 // Included once per matrix engine by kernels_node64.hip (N64_NPL = 3: three bf16 pieces per operand, six MFMAs per product; 2: two fp16
-// pieces, three MFMAs - the "half" engine of cmdgen_split.h) inside a namespace of its own.  No include guard on purpose.
+// pieces, three MFMAs - the "half" engine of cmdgen_split.h; the eight-wave and the lean tile exist on the half engine only) inside a namespace
+// of its own.  No include guard on purpose.
 
 #ifndef CMDGEN_N64_EXP
 #define CMDGEN_N64_EXP 0      // timing experiments only (1: agg * rcp(nf) instead of agg / nf; 2: no zero stores to agg - wrong results)

@@ -14,6 +14,12 @@
 // agg is requested into registers while the h-part of the first product runs.
 // Tile: 64 rows x 256 columns, 4 waves x 64 columns (2 x 2 accumulator tiles of 32 x 32), v_mfma_f32_32x32x16_bf16; weight
 // fragments three k-blocks ahead in a ring of four register sets carried from one GEMM of the chain into the next.
+//
+// Round 6: what bounds a node tile is the chain's 1.8 MB of weight fragments through its CU's L1 (64 B/clk; every tile streams all of it,
+// co-resident workgroups share nothing: TCP_TCC_READ_REQ, profiles/r06_n_node64e.txt).  Four tiles of one body, picked by how the layout's
+// tiles fill the CUs (make_launch): k_node32p (two workgroups per CU: a partner beside every phase, but 85 B/clk asked in the GEMM phases),
+// k_node64e (64 rows on eight waves: 43 B/clk, GEMM phases at the matrix pipe's rate, no partner - so its stores leave under the next GEMM's
+// MFMAs), k_node64d (lean 64-row tile, two workgroups per CU: both), and k_node64 (the round-3 tile, option node64 = 1).
 #include "cmdgen_dev.h"
 #include <hip/hip_ext.h>
 
