@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 import cmdgen_amd  # noqa: E402,F401
 from cmdgen_amd import hip_backend  # noqa: E402
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets  # noqa: E402
+from cmdgen_amd.training import wait_collective  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 # dense bf16 MFMA peak of the same guide ("~2.5 PF"): 256 CUs x 4 SIMDs x 1024 FLOP/clk (v_mfma_f32_32x32x16_bf16:
@@ -435,7 +436,7 @@ def main(argv=None):
     n_gpus = world
     if dist is not None:                          # the ranks that actually run (RCCL all-reduce of ones)
         ones = torch.ones(1, device=cdev)
-        dist.all_reduce(ones)
+        wait_collective(dist.all_reduce(ones, async_op=True))
         n_gpus = int(ones.item())
         assert n_gpus == world, (n_gpus, world)
     if args.gpus != n_gpus and rank == 0:
@@ -469,7 +470,7 @@ def main(argv=None):
     def fence():
         torch.cuda.synchronize(dev)
         if dist is not None:
-            dist.barrier()
+            wait_collective(dist.barrier(async_op=True))          # never a blocking collective on the stream the chain is captured on (training.wait_collective)
         torch.cuda.synchronize(dev)
 
     with torch.cuda.stream(stream):
@@ -486,7 +487,7 @@ def main(argv=None):
         st = h.chain_status()
     if dist is not None:
         tmax = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wait_collective(dist.all_reduce(tmax, op=dist.ReduceOp.MAX, async_op=True))
         elapsed = float(tmax.item())
     evals_per_chain = T + 1
     total_pockets = args.global_batch if args.strong else n_gpus * B
@@ -708,7 +709,7 @@ def main(argv=None):
         else:
             result['cpu_baseline'] = None
     if dist is not None:
-        dist.barrier()
+        wait_collective(dist.barrier(async_op=True))
         dist.destroy_process_group()
     if rank == 0:
         # the flat scalar records FIRST (right after `workload`): a reader that keeps only the leading short values of `config` still shows them

@@ -72,11 +72,12 @@ def _gather_rows(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
     all_gather of the counts, one of the row-padded payload - device tensors stay on the device (RCCL over xGMI
     with the nccl backend, gloo on CPU), nothing is pickled through the host."""
     import torch.distributed as dist
+    from .collectives import wait_collective
     # (rows, columns) of every rank: a rank whose block is empty (fewer pockets than ranks) does not know the row width -
     # it takes it from the ranks that have rows
     n = torch.tensor([t.shape[0], t.shape[1] if t.dim() > 1 else 0], dtype=torch.int64, device=t.device)
     shapes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(shapes, n, group=group)
+    wait_collective(dist.all_gather(shapes, n, group=group, async_op=True))
     counts = [int(c[0].item()) for c in shapes]
     if t.shape[0] == 0 and t.dim() > 1:
         t = torch.zeros((0, max(int(c[1].item()) for c in shapes)), dtype=t.dtype, device=t.device)
@@ -84,7 +85,7 @@ def _gather_rows(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
     pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[:t.shape[0]] = t
     parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
+    wait_collective(dist.all_gather(parts, pad, group=group, async_op=True))
     return torch.cat([p[:c] for p, c in zip(parts, counts)])
 
 
@@ -109,9 +110,12 @@ def sample_sharded(sample_fn: Callable, pocket: Dict[str, torch.Tensor], num_nod
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             from .equivariant_diffusion.en_diffusion import fresh_seed
-            box = [fresh_seed() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            kw['seed'] = int(box[0])
+            from .collectives import wait_collective
+            # (a tensor broadcast issued asynchronously, not broadcast_object_list: a blocking collective must not leave its completion event on
+            # the stream the chain below is captured on - collectives.wait_collective)
+            box = torch.tensor([fresh_seed() if rank == 0 else 0], dtype=torch.int64, device=pocket['size'].device)
+            wait_collective(dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group, async_op=True))
+            kw['seed'] = int(box.item())
     sub, nph = slice_pocket(pocket, num_nodes_phar, lo, hi)
     ids = list(range(lo, hi))
     if hi > lo:

@@ -76,7 +76,8 @@ def validate(model, dataset, batch_size, rank, world):
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([tot, cnt], dtype=torch.float64, device=model.device)
-        dist.all_reduce(t)
+        from .collectives import wait_collective
+        wait_collective(dist.all_reduce(t, async_op=True))
         tot, cnt = float(t[0]), float(t[1])
     model.train()
     return tot / cnt if cnt > 0 else float('nan')      # an empty validation set must not look like a perfect model
@@ -184,7 +185,8 @@ def main(argv=None):
         if done:
             break
     if world > 1:
-        dist.barrier()
+        from .collectives import wait_collective
+        wait_collective(dist.barrier(async_op=True))
         dist.destroy_process_group()
     return {'epochs': epoch + 1 - start_epoch, 'steps': trainer.step_count, 'best_val': best, 'out_dir': str(out_dir),
             'resumed_from': resume_path}

@@ -55,6 +55,8 @@ def per_sample_table(gamma, log_pn, T, n_dims, norm_values, t_int, n_phar, n_poc
     return torch.from_numpy(np.ascontiguousarray(tab))
 
 
+from .collectives import wait_collective  # noqa: E402,F401  (re-exported: bench.py, tools/bench_train.py)
+
 class HipTrainer:
     def __init__(self, model, lr: Optional[float] = None, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-12, clip_grad: Optional[bool] = None, process_group=None,
@@ -302,7 +304,7 @@ class HipTrainer:
                     work.wait()
                 self._pending = []
             else:
-                dist.all_reduce(self.grad, group=self.group)          # one flat bucket over RCCL
+                wait_collective(dist.all_reduce(self.grad, group=self.group, async_op=True))          # one flat bucket over RCCL
             self.grad.div_(world)
 
     def broadcast_state(self, src: int = 0):
@@ -312,7 +314,7 @@ class HipTrainer:
         if self._dp_active():
             import torch.distributed as dist
             for t in (self.theta, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq):
-                dist.broadcast(t, src=src, group=self.group)
+                wait_collective(dist.broadcast(t, src=src, group=self.group, async_op=True))
             self.dyn._weights_sig = None
 
     def _collect_norm(self):

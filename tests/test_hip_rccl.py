@@ -45,3 +45,14 @@ def test_training_step_chunked_allreduce_runs_through_rccl():
     assert ar is not None and ar['overlapped_chunks_ms'] > 0 and ar['flat_after_backward_ms'] > 0
     import math
     assert math.isfinite(d['first_loss']) and math.isfinite(d['last_loss'])
+
+
+def test_collectives_never_leave_an_event_on_a_stream_the_library_captures():
+    """cmdgen_amd/collectives.py: a blocking RCCL collective on the chain's stream followed by a capture on that stream aborts the process when
+    the backend's watchdog polls during the capture (profiles/r06_o_rccl_watchdog_capture.txt).  The fixed form - async_op=True, then wait -
+    through 30 x [barrier -> sleep sweeping the watchdog's poll period -> capture of 100 evaluations]."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run([sys.executable, 'tools/rccl_capture_probe.py', 'async', '30', '100'], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and 'no abort' in r.stdout, r.stderr[-3000:]

@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _opts  # noqa: E402,F401   (CMDGEN_OPTIONS="wgrad_stream=0,..." -> every new handle)
 from cmdgen_amd.lightning_modules import PharPocketDDPM  # noqa: E402
 from cmdgen_amd.synthetic import ModelConfig, make_pockets, make_state_dict  # noqa: E402
-from cmdgen_amd.training import HipTrainer  # noqa: E402
+from cmdgen_amd.training import HipTrainer, wait_collective  # noqa: E402
 
 
 def synthetic_batch(B, first, dev, rep='CA'):
@@ -57,7 +57,8 @@ def time_training(tr, batches, steps, warmup, dev, dist=None):
         tr.training_step(batches[i % len(batches)])
     torch.cuda.synchronize(dev)
     if dist is not None:
-        dist.barrier()
+        wait_collective(dist.barrier(async_op=True))
+        torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     losses = []
     for i in range(steps):
@@ -66,7 +67,7 @@ def time_training(tr, batches, steps, warmup, dev, dist=None):
     dt = time.perf_counter() - t0
     if dist is not None:
         td = torch.tensor([dt], device=dev)
-        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        wait_collective(dist.all_reduce(td, op=dist.ReduceOp.MAX, async_op=True))
         dt = float(td)
     return dt, [float(x) for x in losses]
 
