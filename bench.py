@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 import cmdgen_amd  # noqa: E402,F401
 from cmdgen_amd import hip_backend  # noqa: E402
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets  # noqa: E402
-from cmdgen_amd.training import wait_collective  # noqa: E402
+from cmdgen_amd.collectives import host_barrier, wait_collective  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 # dense bf16 MFMA peak of the same guide ("~2.5 PF"): 256 CUs x 4 SIMDs x 1024 FLOP/clk (v_mfma_f32_32x32x16_bf16:
@@ -470,7 +470,7 @@ def main(argv=None):
     def fence():
         torch.cuda.synchronize(dev)
         if dist is not None:
-            wait_collective(dist.barrier(async_op=True))          # never a blocking collective on the stream the chain is captured on (training.wait_collective)
+            host_barrier(device=dev)          # never a blocking collective on the stream the chain is captured on (collectives.wait_collective)
         torch.cuda.synchronize(dev)
 
     with torch.cuda.stream(stream):
@@ -709,7 +709,7 @@ def main(argv=None):
         else:
             result['cpu_baseline'] = None
     if dist is not None:
-        wait_collective(dist.barrier(async_op=True))
+        host_barrier(device=dev)
         dist.destroy_process_group()
     if rank == 0:
         # the flat scalar records FIRST (right after `workload`): a reader that keeps only the leading short values of `config` still shows them

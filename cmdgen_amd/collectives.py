@@ -13,3 +13,12 @@ def wait_collective(work):
     if work is not None:
         work.wait()
     return work
+
+
+def host_barrier(group=None, device=None):
+    """A barrier the HOST waits for (all ranks have arrived when it returns), issued the way ``wait_collective`` asks for."""
+    import torch
+    import torch.distributed as dist
+    wait_collective(dist.barrier(group=group, async_op=True))
+    if dist.get_backend(group) == 'nccl':                 # a device-side barrier: its wait() orders the stream; the host waits for the device
+        torch.cuda.synchronize(device)

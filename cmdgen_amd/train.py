@@ -185,8 +185,8 @@ def main(argv=None):
         if done:
             break
     if world > 1:
-        from .collectives import wait_collective
-        wait_collective(dist.barrier(async_op=True))
+        from .collectives import host_barrier
+        host_barrier()
         dist.destroy_process_group()
     return {'epochs': epoch + 1 - start_epoch, 'steps': trainer.step_count, 'best_val': best, 'out_dir': str(out_dir),
             'resumed_from': resume_path}

@@ -21,7 +21,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _opts  # noqa: E402,F401   (CMDGEN_OPTIONS="wgrad_stream=0,..." -> every new handle)
 from cmdgen_amd.lightning_modules import PharPocketDDPM  # noqa: E402
 from cmdgen_amd.synthetic import ModelConfig, make_pockets, make_state_dict  # noqa: E402
-from cmdgen_amd.training import HipTrainer, wait_collective  # noqa: E402
+from cmdgen_amd.collectives import host_barrier, wait_collective  # noqa: E402
+from cmdgen_amd.training import HipTrainer  # noqa: E402
 
 
 def synthetic_batch(B, first, dev, rep='CA'):
@@ -57,8 +58,7 @@ def time_training(tr, batches, steps, warmup, dev, dist=None):
         tr.training_step(batches[i % len(batches)])
     torch.cuda.synchronize(dev)
     if dist is not None:
-        wait_collective(dist.barrier(async_op=True))
-        torch.cuda.synchronize(dev)
+        host_barrier(device=dev)
     t0 = time.perf_counter()
     losses = []
     for i in range(steps):
