@@ -50,7 +50,10 @@ __device__ __forceinline__ void jdraw4(const JointBuf& c, const Layout& lay, con
 // Workgroup scratch: sm = broadcast slots; xs / fx = the sample's x columns ([3][n], phar rows then pocket rows) and fixed flags staged for the
 // ordered sums below (null when the sample is too large for the buffer the launcher sized: the sums then read global memory)
 struct JScratch { float* sm; float* xs; float* fx; };
-constexpr int J_STAGE_MAX_N = 3800;      // (8 + 4 n) floats <= 60 KB of dynamic LDS
+#ifndef CMDGEN_J_STAGE_MAX_N
+#define CMDGEN_J_STAGE_MAX_N 3800      // (8 + 4 n) floats <= 60 KB of dynamic LDS; larger samples (the layout allows 5705 nodes) sum from global memory.
+#endif                                  // (-DCMDGEN_J_STAGE_MAX_N=4 puts every sample on that path: how tests/test_hip_joint.py was run over it once, profiles/r06_m)
+constexpr int J_STAGE_MAX_N = CMDGEN_J_STAGE_MAX_N;
 
 __device__ __forceinline__ JScratch scratch_of(float* jsm, const Layout& lay) {
     const bool st = lay.max_n <= J_STAGE_MAX_N;
