@@ -20,11 +20,13 @@ from cmdgen_amd import sharding  # noqa: E402
 from cmdgen_amd.synthetic import ModelConfig, make_state_dict, make_pockets  # noqa: E402
 
 
-def oracle_sampler(cfg, sd, K):
+def oracle_sampler(cfg, sd, K, seen=None):
     from oracle import ref_cpu
     p = ref_cpu.to_torch_params(sd)
 
     def fn(pocket, num_nodes_phar, pocket_ids=None, **kw):
+        if seen is not None:
+            seen.append(kw.get('seed'))           # the Philox seed sample_sharded agreed on (rank 0's, by a tensor broadcast)
         nph = torch.as_tensor(num_nodes_phar)
         # per-pocket noise streams keyed by global id -> independent of the sharding
         draws = []
@@ -48,9 +50,13 @@ def _worker(rank, world, port, q, n_pockets=5):
     pb = make_pockets(n_pockets, 'CA', ragged=True)
     pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot),
               'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
-    out = sharding.sample_sharded(oracle_sampler(cfg, sd, 3), pocket, pb.num_nodes_phar, rank, world)
+    seen = []
+    torch.manual_seed(100 + rank)                 # the ranks' global generators differ: each would draw another seed
+    out = sharding.sample_sharded(oracle_sampler(cfg, sd, 3, seen), pocket, pb.num_nodes_phar, rank, world)
+    seeds = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(seeds, torch.tensor([seen[0] if seen else -1], dtype=torch.int64))
     if rank == 0:
-        q.put([o.numpy() for o in out])
+        q.put([o.numpy() for o in out] + [np.array([int(t) for t in seeds])])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,6 +78,8 @@ def test_two_rank_sharded_sampling_equals_single_process():
     pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot),
               'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
     want = sharding.sample_sharded(oracle_sampler(cfg, sd, 3), pocket, pb.num_nodes_phar, 0, 1)
+    seeds = got.pop()
+    assert seeds[0] == seeds[1] and seeds[0] >= 0    # both ranks sampled with rank 0's seed
     for a, b in zip(got, want):
         assert np.array_equal(a, b.numpy())          # bit-identical: shards are independent
 
@@ -96,6 +104,8 @@ def test_rank_with_an_empty_block_still_joins_the_gather():
     pocket = {'x': torch.from_numpy(pb.x), 'one_hot': torch.from_numpy(pb.one_hot),
               'size': torch.from_numpy(pb.size), 'mask': torch.from_numpy(pb.mask)}
     want = sharding.sample_sharded(oracle_sampler(cfg, sd, 3), pocket, pb.num_nodes_phar, 0, 1)
+    seeds = got.pop()
+    assert seeds[0] >= 0 and seeds[1] == -1          # (the rank with the empty block ran no chain)
     for a, b in zip(got, want):
         assert np.array_equal(a, b.numpy())
 
