@@ -237,7 +237,8 @@ def test_node64_is_chosen_by_tile_count_and_agrees_with_the_32_row_kernel(monkey
     cfg = ModelConfig(residue_nf=20, timesteps=1000, noise_precision=0.1, norm_values=(1.0, 0.25))
     sd = make_state_dict(cfg, seed=3)
     out = {}
-    for B, opt, expect in ((64, None, 0), (128, None, 32), (384, None, 2), (256, None, 8), (256, 32, 32), (256, 2, 2), (256, 1, 1), (256, 0, 0)):
+    out384 = {}
+    for B, opt, expect in ((64, None, 0), (128, None, 32), (384, None, 2), (384, 32, 32), (256, None, 8), (256, 32, 32), (256, 2, 2), (256, 1, 1), (256, 0, 0)):
         pb = make_pockets(B, 'CA')
         h = hip_backend.Handle(cfg.as_dict(), 0); h.load_state_dict(sd)
         h.set_option('node64', opt)                                  # None: the library's own choice
@@ -247,7 +248,15 @@ def test_node64_is_chosen_by_tile_count_and_agrees_with_the_32_row_kernel(monkey
             xh, _, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), 20, seed=5)
             out[h.query('node64')] = xh.cpu().numpy()
             assert h.chain_status()['nan_resets'] == 0
+        if B == 384:         # the lean tile where it is the rule: two workgroups per CU
+            xh, _, _ = h.sample_chain(dev(pb.x), dev(pb.one_hot), 20, seed=5)
+            out384[h.query('node64')] = xh.cpu().numpy()
+            assert h.chain_status()['nan_resets'] == 0
         h.close()
+    if 2 in out384 and 32 in out384:
+        err = rms(out384[2][:, :3], out384[32][:, :3])
+        print(f'384 pockets, 20 steps: coordinate RMS lean 64-row plane tile (two per CU) vs 32-row plane tile {err:.2e} A')
+        assert err <= 2e-5 and np.array_equal(out384[2][:, 3:], out384[32][:, 3:])
     tile_name = {1: '64-row', 32: '32-row', 8: 'eight-wave 64-row', 2: 'lean 64-row'}
     for k in (1, 32, 8, 2):
         if k in out and 0 in out:
